@@ -1,0 +1,838 @@
+/*
+ * bbduk_oracle.c -- CPU ORACLE (test infrastructure only; see bbduk_oracle.h).  PARITY UNPINNED.
+ *
+ * Loop-for-loop restatement, in plain C, of the reference's BBDuk k-mer matching path
+ * (BBTools v40.02).  Every function cites the reference file:line it follows, relative to
+ * /root/reference/current/ .  Nothing here is optimised: the sequential rolling loops, the
+ * recursive mutate(), the 7-way key%7 HashArray1D with `extra`=60 no-wrap probing and a
+ * victim overflow are kept as the reference has them so that the restatement can be read
+ * side by side with the Java.
+ */
+#include "bbduk_oracle.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <pthread.h>
+
+/* ------------------------------------------------------------------------------------------ */
+/* dna/AminoAcid.java:1284-1311 -- baseToNumber (-1 undefined), baseToNumber0, baseToComplementNumber0 */
+static int8_t T_num[128], T_num0[128], T_cnum0[128];
+static int tables_ready = 0;
+static void init_tables(void) {
+    if (tables_ready) return;
+    memset(T_num, -1, sizeof T_num);
+    memset(T_num0, 0, sizeof T_num0);
+    memset(T_cnum0, 0, sizeof T_cnum0);
+    const char* acgt = "ACGT";
+    for (int i = 0; i < 4; i++) {                       /* :1288-1295 */
+        int x = acgt[i], x2 = x + 32;
+        T_num[x] = T_num[x2] = (int8_t)i;
+        T_num0[x] = T_num0[x2] = (int8_t)i;
+    }
+    T_num['U'] = T_num['u'] = 3;                         /* :1296-1297 */
+    T_num0['U'] = T_num0['u'] = 3;
+    T_cnum0['A'] = T_cnum0['a'] = 3;                     /* :1306-1311 */
+    T_cnum0['C'] = T_cnum0['c'] = 2;
+    T_cnum0['G'] = T_cnum0['g'] = 1;
+    T_cnum0['T'] = T_cnum0['t'] = 0;
+    T_cnum0['U'] = T_cnum0['u'] = 0;
+    tables_ready = 1;
+}
+/* Java indexes these tables with a signed byte; a byte >=128 would throw.  Reads reach this path
+ * after Read.validate, so it cannot happen there; here such bytes are treated as undefined (0). */
+int bbo_base_to_number(int b)             { init_tables(); return (b < 0 || b > 127) ? -1 : T_num[b]; }
+int bbo_base_to_number0(int b)            { init_tables(); return (b < 0 || b > 127) ? 0 : T_num0[b]; }
+int bbo_base_to_complement_number0(int b) { init_tables(); return (b < 0 || b > 127) ? 0 : T_cnum0[b]; }
+
+/* bbduk/BBDukProcessorS.java:2858-2860 / BBDukLoader.java:538-540: symbol>=0 && symbolToNumber[symbol]>=0 */
+static inline int is_fully_defined(uint8_t b) { return b < 128 && T_num[b] >= 0; }
+static inline int64_t num0(uint8_t b)  { return b < 128 ? T_num0[b] : 0; }
+static inline int64_t cnum0(uint8_t b) { return b < 128 ? T_cnum0[b] : 0; }
+
+/* dna/AminoAcid.java:585-601 reverseComplementBinaryFast(long,int).  Java >>> is a logical shift. */
+int64_t bbo_rcomp(int64_t kmer, int k) {
+    uint64_t x = ~(uint64_t)kmer;
+    x = ((x & 0x3333333333333333ULL) << 2)  | ((x & 0xCCCCCCCCCCCCCCCCULL) >> 2);
+    x = ((x & 0x0F0F0F0F0F0F0F0FULL) << 4)  | ((x & 0xF0F0F0F0F0F0F0F0ULL) >> 4);
+    x = ((x & 0x00FF00FF00FF00FFULL) << 8)  | ((x & 0xFF00FF00FF00FF00ULL) >> 8);
+    x = ((x & 0x0000FFFF0000FFFFULL) << 16) | ((x & 0xFFFF0000FFFF0000ULL) >> 16);
+    x = (x << 32) | (x >> 32);
+    x = x >> (2 * (32 - k));      /* k in 1..31 here; Java shift distance is mod 64, same for these k */
+    return (int64_t)x;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* kmer/HashArray.java + kmer/HashArray1D.java restated.  One instance per way.
+ * NOT_PRESENT=-1, HASH_COLLISION=-2 (kmer/AbstractKmerTable.java:807).                         */
+#define NOT_PRESENT   (-1)
+#define HASH_COLLISION (-2)
+#define HA_EXTRA 60                         /* kmer/HashArray.java:687 */
+#define HA_MAX_LOAD 0.88f                   /* :695 */
+#define HA_MIN_LOAD 0.58f                   /* :693 */
+#define HA_RESIZE_MULT 2.0f                 /* :691 */
+#define HA_INITIAL_SIZE 128000              /* kmer/ScheduleMaker.java:104,233 initialSizeDefault */
+
+typedef struct {
+    int      prime;
+    int64_t  size, sizeLimit;
+    int64_t* array;                         /* long[prime+extra], NOT_PRESENT = empty */
+    int32_t* values;                        /* int [prime+extra]                       */
+    /* victims: the reference uses a HashForest (bucket array of BSTs, kmer/HashForest.java).  It is a
+     * key->value map reached only after `extra` consecutive occupied cells; a flat list with linear
+     * search is decision-equivalent and is what victims().toList() hands across the boundary. */
+    int64_t  vsize, vcap;
+    int64_t* vkeys;
+    int32_t* vvals;
+} hash_array;
+
+static int is_prime(int64_t x) {
+    if (x < 2) return 0;
+    if (x % 2 == 0) return x == 2;
+    for (int64_t d = 3; d * d <= x; d += 2) if (x % d == 0) return 0;
+    return 1;
+}
+static int64_t prime_at_least(int64_t x) { while (!is_prime(x)) x++; return x; }  /* shared/Primes.java:100 */
+
+static void ha_alloc(hash_array* h, int prime) {
+    h->prime = prime;
+    h->sizeLimit = (int64_t)(HA_MAX_LOAD * prime);                  /* HashArray.java:62 */
+    h->array  = (int64_t*)malloc(sizeof(int64_t) * ((size_t)prime + HA_EXTRA));
+    h->values = (int32_t*)calloc((size_t)prime + HA_EXTRA, sizeof(int32_t));
+    for (int64_t i = 0; i < (int64_t)prime + HA_EXTRA; i++) h->array[i] = NOT_PRESENT;   /* :65 */
+    h->size = 0;
+}
+static void ha_init(hash_array* h) {
+    memset(h, 0, sizeof *h);
+    ha_alloc(h, (int)prime_at_least(HA_INITIAL_SIZE));
+}
+static void ha_free(hash_array* h) { free(h->array); free(h->values); free(h->vkeys); free(h->vvals); }
+
+/* kmer/HashArray.java:153-156 kmerToCell; coreMask=-1 for BBDuk.  Java % on a non-negative long. */
+static inline int ha_kmer_to_cell(const hash_array* h, int64_t kmer) { return (int)(kmer % h->prime); }
+
+/* kmer/HashArray.java:434-447 findKmer */
+static int ha_find_kmer(const hash_array* h, int64_t kmer) {
+    int cell = ha_kmer_to_cell(h, kmer);
+    for (const int max = cell + HA_EXTRA; cell < max; cell++) {
+        const int64_t n = h->array[cell];
+        if (n == kmer) return cell;
+        else if (n == NOT_PRESENT) return NOT_PRESENT;
+    }
+    return HASH_COLLISION;
+}
+static int victims_get(const hash_array* h, int64_t kmer) {           /* kmer/HashForest.java:229-233 */
+    for (int64_t i = 0; i < h->vsize; i++) if (h->vkeys[i] == kmer) return h->vvals[i];
+    return NOT_PRESENT;
+}
+static int victims_set_if_not_present(hash_array* h, int64_t kmer, int value) {
+    for (int64_t i = 0; i < h->vsize; i++) if (h->vkeys[i] == kmer) return 0;
+    if (h->vsize == h->vcap) {
+        h->vcap = h->vcap ? h->vcap * 2 : 16;
+        h->vkeys = (int64_t*)realloc(h->vkeys, sizeof(int64_t) * (size_t)h->vcap);
+        h->vvals = (int32_t*)realloc(h->vvals, sizeof(int32_t) * (size_t)h->vcap);
+    }
+    h->vkeys[h->vsize] = kmer; h->vvals[h->vsize] = value; h->vsize++;
+    return 1;
+}
+/* kmer/HashArray.java:242-247 getValue + kmer/HashArray1D.java:117-119 readCellValue */
+static int ha_get_value(const hash_array* h, int64_t kmer) {
+    int cell = ha_find_kmer(h, kmer);
+    if (cell == NOT_PRESENT) return NOT_PRESENT;
+    if (cell == HASH_COLLISION) return victims_get(h, kmer);
+    return h->values[cell];
+}
+static int ha_set_if_not_present(hash_array* h, int64_t kmer, int value);
+
+/* kmer/HashArray1D.java:260-339 resize(), schedule==null branch ("old method"); re-inserts every
+ * (key,value).  The reference's default BBDuk schedule depends on the JVM heap size
+ * (kmer/ScheduleMaker.java:60-163) and is not reproducible here; table geometry never affects a
+ * lookup result (it is a map), so only the map semantics are pinned. */
+static void ha_resize(hash_array* h) {
+    const int64_t totalSize = h->size + h->vsize;
+    const int64_t maxAllowed = (int64_t)(totalSize * (1 / HA_MIN_LOAD));
+    const int64_t minAllowed = (int64_t)(totalSize * (1 / HA_MAX_LOAD));
+    if (maxAllowed < h->prime) { h->sizeLimit = (int64_t)(HA_MAX_LOAD * h->prime); return; }
+    int64_t x = 10 + (int64_t)(h->prime * HA_RESIZE_MULT);
+    if (x < minAllowed) x = minAllowed;
+    if (x > maxAllowed) x = maxAllowed;
+    int prime2 = (int)prime_at_least(x);
+    if (prime2 <= h->prime) { h->sizeLimit = (int64_t)(HA_MAX_LOAD * h->prime); return; }
+    hash_array old = *h;
+    h->vkeys = NULL; h->vvals = NULL; h->vsize = h->vcap = 0;
+    ha_alloc(h, prime2);
+    for (int64_t i = 0; i < (int64_t)old.prime + HA_EXTRA; i++)
+        if (old.array[i] > NOT_PRESENT) ha_set_if_not_present(h, old.array[i], old.values[i]);
+    for (int64_t i = 0; i < old.vsize; i++) ha_set_if_not_present(h, old.vkeys[i], old.vvals[i]);
+    free(old.array); free(old.values); free(old.vkeys); free(old.vvals);
+}
+/* kmer/HashArray.java:221-239 setIfNotPresent: first writer wins */
+static int ha_set_if_not_present(hash_array* h, int64_t kmer, int value) {
+    int cell = ha_kmer_to_cell(h, kmer);
+    for (const int max = cell + HA_EXTRA; cell < max; cell++) {
+        int64_t n = h->array[cell];
+        if (n == kmer) return 0;
+        else if (n == NOT_PRESENT) {
+            h->array[cell] = kmer;
+            h->values[cell] = value;                                   /* HashArray1D.insertValue */
+            h->size++;
+            if (h->size + h->vsize > h->sizeLimit) ha_resize(h);
+            return 1;
+        }
+    }
+    int x = victims_set_if_not_present(h, kmer, value);
+    if (h->size + h->vsize > h->sizeLimit) ha_resize(h);
+    return x;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+#define WAYS 7                               /* jgi/BBDuk.java:5425; BBDukIndexMod key%WAYS */
+#define SYMBOLS 4
+#define SYMBOL_ARRAY_LEN 32                  /* (64+2-1)/2, BBDukParser.java:251 */
+
+struct bbo_ctx {
+    bbo_args a;
+    /* derived -- BBDukParser.java:130-312 */
+    int k, mink, hammingDistance, hammingDistance2, editDistance, editDistance2, qHammingDistance, qHammingDistance2;
+    int forbidNs, rcomp, maskMiddle, midMaskLen, useShortKmers, kfilter;
+    int minlen, minminlen, minlen2, shift, shift2, minSkip, maxSkip;
+    int64_t mask, kmask, middleMask, symbolMask;
+    int64_t clearMasks[SYMBOL_ARRAY_LEN], leftMasks[SYMBOL_ARRAY_LEN], rightMasks[SYMBOL_ARRAY_LEN], lengthMasks[SYMBOL_ARRAY_LEN];
+    int64_t setMasks[SYMBOLS][SYMBOL_ARRAY_LEN];
+    int removePairsIfEitherBad, trimFailuresTo1bp;
+    /* index */
+    hash_array keySets[WAYS];
+    int numScaffolds;                        /* scaffoldNames.size(); [0] reserved (BBDukIndex.java:105-107) */
+    int64_t storedKmers;
+    /* counters (thread 0 / merged) */
+    int64_t counters[BBO_NCOUNTERS];
+    int64_t* scafReads; int64_t* scafBases; int scafCap;
+};
+
+void bbo_default_args(bbo_args* a) {
+    memset(a, 0, sizeof *a);
+    a->k = 27;                /* BBDukParser.java:163 */
+    a->mink = -1;             /* :1230 */
+    a->hdist = 0; a->hdist2 = -1; a->edist = 0; a->edist2 = -1; a->qhdist = 0; a->qhdist2 = -1;
+    a->maskMiddle = 1;        /* :1091 */
+    a->midMaskLen = 0;
+    a->rcomp = 1;             /* :1208 */
+    a->forbidN = 0;
+    a->maxBadKmers0 = 0;      /* :1232 */
+    a->minReadLength = 10;    /* :437 */
+    a->minLenFraction = 0.f;  /* :439 */
+    a->minSkip = 1; a->maxSkip = 1;
+}
+
+static int imax(int a, int b) { return a > b ? a : b; }
+static int imin(int a, int b) { return a < b ? a : b; }
+static int imid(int lo, int x, int hi) { return x < lo ? lo : (x > hi ? hi : x); }   /* Tools.mid */
+
+bbo_ctx* bbo_create(const bbo_args* a) {
+    init_tables();
+    if (a->k < 1 || a->k > 31) return NULL;                 /* maxSupportedK=31, kbig out of scope (:162-165) */
+    if (a->edist > 0 || a->edist2 > 0) { /* allowed: mutate() below restates Del/Ins too */ }
+    bbo_ctx* c = (bbo_ctx*)calloc(1, sizeof *c);
+    c->a = *a;
+    /* BBDukParser.java:130-132 */
+    int hd = a->hdist, hd2 = a->hdist2, ed = a->edist, ed2 = a->edist2, qhd = a->qhdist, qhd2 = a->qhdist2;
+    if (hd2 == -1) hd2 = hd;
+    if (qhd2 == -1) qhd2 = qhd;
+    if (ed2 == -1) ed2 = ed;
+    /* :146-150 */
+    hd = imax(ed, hd);
+    hd2 = imax(ed2, hd2);
+    c->minSkip = imax(1, imin(a->minSkip, a->maxSkip));
+    c->maxSkip = imax(c->minSkip, a->maxSkip);
+    c->forbidNs = (a->forbidN || hd < 1);
+    c->hammingDistance = hd; c->hammingDistance2 = hd2; c->editDistance = ed; c->editDistance2 = ed2;
+    c->qHammingDistance = qhd; c->qHammingDistance2 = qhd2;
+    c->rcomp = a->rcomp;                                    /* :158-159 (amino=false) */
+    c->k = a->k;
+    /* :230-245 */
+    c->maskMiddle = a->maskMiddle;
+    if (c->maskMiddle) c->midMaskLen = (a->midMaskLen > 0 ? a->midMaskLen : 2 - (c->k & 1));
+    else c->midMaskLen = 0;
+    c->mink = imin(a->mink, c->k);
+    /* :247-281 */
+    c->symbolMask = 3;
+    for (int i = 0; i < SYMBOL_ARRAY_LEN; i++) {
+        c->clearMasks[i]  = (int64_t)~((uint64_t)c->symbolMask << (2 * i));
+        c->leftMasks[i]   = (int64_t)(~0ULL << (2 * i));
+        c->rightMasks[i]  = (int64_t)~(~0ULL << (2 * i));
+        c->lengthMasks[i] = (int64_t)(1ULL << (2 * i));
+        for (int64_t j = 0; j < SYMBOLS; j++) c->setMasks[j][i] = (int64_t)((uint64_t)j << (2 * i));
+    }
+    c->minlen = c->k - 1;
+    c->minminlen = c->mink - 1;
+    c->minlen2 = (c->maskMiddle ? (c->k - c->midMaskLen) / 2 : c->k);   /* computed BEFORE mink disables maskMiddle */
+    c->shift = 2 * c->k;
+    c->shift2 = c->shift - 2;
+    c->mask = (c->shift > 63 ? -1LL : (int64_t)~(~0ULL << c->shift));
+    c->kmask = c->lengthMasks[c->k];
+    /* :289-296 */
+    if (c->mink > 0 && c->mink < c->k) c->useShortKmers = 1;
+    if (c->useShortKmers && c->maskMiddle) { c->maskMiddle = 0; c->midMaskLen = 0; }
+    /* :298 */
+    c->kfilter = !(a->ktrimRight || a->ktrimLeft);
+    if (c->useShortKmers && !(a->ktrimRight || a->ktrimLeft)) { free(c); return NULL; }   /* :301 assert */
+    /* :303-312 */
+    if (c->maskMiddle) {
+        if (!(c->k > c->midMaskLen + 1)) { free(c); return NULL; }
+        int bits = c->midMaskLen * 2;
+        int shift = ((c->k - c->midMaskLen) / 2) * 2;
+        c->middleMask = (int64_t)~((~(~0ULL << bits)) << shift);
+    } else c->middleMask = -1LL;
+    /* :105-109 */
+    c->trimFailuresTo1bp = 0;
+    c->removePairsIfEitherBad = (!a->requireBothBad) && (!c->trimFailuresTo1bp);
+    for (int w = 0; w < WAYS; w++) ha_init(&c->keySets[w]);
+    c->numScaffolds = 1;                                    /* scaffoldNames.add("") : first id is 1 */
+    c->scafCap = 64;
+    c->scafReads = (int64_t*)calloc((size_t)c->scafCap, sizeof(int64_t));
+    c->scafBases = (int64_t*)calloc((size_t)c->scafCap, sizeof(int64_t));
+    return c;
+}
+void bbo_destroy(bbo_ctx* c) {
+    if (!c) return;
+    for (int w = 0; w < WAYS; w++) ha_free(&c->keySets[w]);
+    free(c->scafReads); free(c->scafBases); free(c);
+}
+int64_t bbo_constant(const bbo_ctx* c, const char* n) {
+#define K(s, v) if (!strcmp(n, s)) return (int64_t)(v)
+    K("k", c->k); K("mink", c->mink); K("hdist", c->hammingDistance); K("hdist2", c->hammingDistance2);
+    K("forbidNs", c->forbidNs); K("minlen", c->minlen); K("minlen2", c->minlen2); K("shift2", c->shift2);
+    K("mask", c->mask); K("kmask", c->kmask); K("middleMask", c->middleMask); K("useShortKmers", c->useShortKmers);
+    K("maskMiddle", c->maskMiddle); K("midMaskLen", c->midMaskLen); K("kfilter", c->kfilter);
+    K("qhdist", c->qHammingDistance); K("qhdist2", c->qHammingDistance2);
+#undef K
+    return INT64_MIN;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* bbduk/BBDukIndexMod.java:532-544 toValue */
+static inline int64_t to_value(const bbo_ctx* c, int64_t kmer, int64_t rkmer, int64_t lengthMask) {
+    const int64_t value = (c->rcomp ? (kmer > rkmer ? kmer : rkmer) : kmer);     /* Tools.max, signed */
+    return (value & c->middleMask) | lengthMask;
+}
+
+/* bbduk/BBDukIndexMod.java:383-445 mutate */
+static int64_t mutate(bbo_ctx* c, const int64_t kmer, const int64_t rkmer, const int len, const int id,
+                      const int dist, const int64_t extraBase, const int tnum) {
+    hash_array* map = &c->keySets[tnum];
+    int64_t added = 0;
+    const int64_t key = to_value(c, kmer, rkmer, c->lengthMasks[len]);
+    if (key % WAYS == tnum) added += ha_set_if_not_present(map, key, id);
+    if (dist > 0) {
+        const int dist2 = dist - 1;
+        /* Sub */
+        for (int j = 0; j < SYMBOLS; j++) {
+            for (int i = 0; i < len; i++) {
+                const int64_t temp = (kmer & c->clearMasks[i]) | c->setMasks[j][i];
+                if (temp != kmer) {
+                    int64_t rtemp = bbo_rcomp(temp, len);
+                    added += mutate(c, temp, rtemp, len, id, dist2, extraBase, tnum);
+                }
+            }
+        }
+        if (c->editDistance > 0) {
+            /* Del (:415-425) */
+            if (extraBase >= 0 && extraBase <= 3) {
+                for (int i = 1; i < len; i++) {
+                    const int64_t temp = (kmer & c->leftMasks[i]) | ((int64_t)((uint64_t)kmer << 2) & c->rightMasks[i]) | extraBase;
+                    if (temp != kmer) {
+                        int64_t rtemp = bbo_rcomp(temp, len);
+                        added += mutate(c, temp, rtemp, len, id, dist2, -1, tnum);
+                    }
+                }
+            }
+            /* Ins (:427-439); Java's >> on a non-negative long == logical */
+            const int64_t eb2 = kmer & c->symbolMask;
+            for (int i = 1; i < len; i++) {
+                const int64_t temp0 = (kmer & c->leftMasks[i]) | ((kmer & c->rightMasks[i]) >> 2);
+                for (int j = 0; j < SYMBOLS; j++) {
+                    const int64_t temp = temp0 | c->setMasks[j][i - 1];
+                    if (temp != kmer) {
+                        int64_t rtemp = bbo_rcomp(temp, len);
+                        added += mutate(c, temp, rtemp, len, id, dist2, eb2, tnum);
+                    }
+                }
+            }
+        }
+    }
+    return added;
+}
+
+/* bbduk/BBDukIndexMod.java:351-373 addToMap */
+static int64_t idx_add_to_map(bbo_ctx* c, const int64_t kmer, const int64_t rkmer, const int len, const int64_t extraBase,
+                              const int id, const int64_t kmask0, const int hdist, const int edist, const int tnum) {
+    /* asserts :354-355 */
+    if (kmask0 != c->lengthMasks[len] || (kmer & kmask0) != 0) { fprintf(stderr, "oracle: addToMap assertion\n"); abort(); }
+    if (hdist == 0) {
+        const int64_t key = to_value(c, kmer, rkmer, kmask0);
+        if (key % WAYS != tnum) return 0;
+        return ha_set_if_not_present(&c->keySets[tnum], key, id);
+    } else if (edist > 0) {
+        return mutate(c, kmer, rkmer, len, id, edist, extraBase, tnum);
+    } else {
+        return mutate(c, kmer, rkmer, len, id, hdist, -1, tnum);
+    }
+}
+/* bbduk/BBDukIndexMod.java:289-310 addToMapLeftShift */
+static int64_t idx_add_left_shift(bbo_ctx* c, int64_t kmer, int64_t rkmer, const int64_t extraBase, const int id, const int tnum) {
+    int64_t added = 0;
+    for (int i = c->k - 1; i >= c->mink; i--) {
+        kmer = kmer & c->rightMasks[i];
+        rkmer = (int64_t)((uint64_t)rkmer >> 2);
+        added += idx_add_to_map(c, kmer, rkmer, i, extraBase, id, c->lengthMasks[i], c->hammingDistance2, c->editDistance2, tnum);
+    }
+    return added;
+}
+/* bbduk/BBDukIndexMod.java:320-341 addToMapRightShift */
+static int64_t idx_add_right_shift(bbo_ctx* c, int64_t kmer, int64_t rkmer, const int id, const int tnum) {
+    int64_t added = 0;
+    for (int i = c->k - 1; i >= c->mink; i--) {
+        int64_t extraBase = kmer & c->symbolMask;
+        kmer = (int64_t)((uint64_t)kmer >> 2);
+        rkmer = rkmer & c->rightMasks[i];
+        added += idx_add_to_map(c, kmer, rkmer, i, extraBase, id, c->lengthMasks[i], c->hammingDistance2, c->editDistance2, tnum);
+    }
+    return added;
+}
+
+/* bbduk/BBDukLoader.java:416-494 LoadThread.addToMap(Read,skip) for one way (tnum) */
+static int64_t loader_add_to_map(bbo_ctx* c, const uint8_t* bases, int64_t blen, int id, int skip, int tnum) {
+    skip = imax(c->minSkip, imin(c->maxSkip, skip));
+    const int k = c->k, k2 = k - 1;
+    int64_t kmer = 0, rkmer = 0, added = 0;
+    int64_t len = 0;
+    if (bases == NULL || blen < k) return 0;
+    if (skip > 1) {
+        for (int64_t i = 0; i < blen; i++) {
+            uint8_t b = bases[i];
+            int64_t x = num0(b), x2 = cnum0(b);
+            kmer = (int64_t)((((uint64_t)kmer << 2) | (uint64_t)x) & (uint64_t)c->mask);
+            rkmer = (int64_t)((((uint64_t)rkmer >> 2) | ((uint64_t)x2 << c->shift2)) & (uint64_t)c->mask);
+            if (is_fully_defined(b)) len++; else { len = 0; rkmer = 0; }
+            if (len >= k) {
+                if (len % skip == 0) {
+                    const int64_t extraBase = (i >= blen - 1 ? -1 : bbo_base_to_number(bases[i + 1]));
+                    added += idx_add_to_map(c, kmer, rkmer, k, extraBase, id, c->kmask, c->hammingDistance, c->editDistance, tnum);
+                    if (c->useShortKmers) {
+                        if (i == k2) added += idx_add_right_shift(c, kmer, rkmer, id, tnum);
+                        if (i == blen - 1) added += idx_add_left_shift(c, kmer, rkmer, extraBase, id, tnum);
+                    }
+                }
+            }
+        }
+    } else {
+        for (int64_t i = 0; i < blen; i++) {
+            const uint8_t b = bases[i];
+            const int64_t x = num0(b), x2 = cnum0(b);
+            kmer = (int64_t)((((uint64_t)kmer << 2) | (uint64_t)x) & (uint64_t)c->mask);
+            rkmer = (int64_t)((((uint64_t)rkmer >> 2) | ((uint64_t)x2 << c->shift2)) & (uint64_t)c->mask);
+            if (is_fully_defined(b)) len++; else { len = 0; rkmer = 0; }
+            if (len >= k) {
+                const int64_t extraBase = (i >= blen - 1 ? -1 : bbo_base_to_number(bases[i + 1]));
+                added += idx_add_to_map(c, kmer, rkmer, k, extraBase, id, c->kmask, c->hammingDistance, c->editDistance, tnum);
+                if (c->useShortKmers) {
+                    if (i == k2) added += idx_add_right_shift(c, kmer, rkmer, id, tnum);
+                    if (i == blen - 1) added += idx_add_left_shift(c, kmer, rkmer, extraBase, id, tnum);
+                }
+            }
+        }
+    }
+    return added;
+}
+
+/* bbduk/BBDukLoader.java:219-251, 388-404: every scaffold gets the next id; every LoadThread (one per way)
+ * sees every scaffold in file order and inserts only keys it owns, so within a way insertion order is
+ * file order and setIfNotPresent keeps the id of the first scaffold that produced the key. */
+int64_t bbo_add_ref_sequence(bbo_ctx* c, const uint8_t* bases, int64_t len) {
+    const int id = c->numScaffolds++;
+    if (c->numScaffolds > c->scafCap) {
+        int nc = c->scafCap * 2;
+        c->scafReads = (int64_t*)realloc(c->scafReads, sizeof(int64_t) * (size_t)nc);
+        c->scafBases = (int64_t*)realloc(c->scafBases, sizeof(int64_t) * (size_t)nc);
+        memset(c->scafReads + c->scafCap, 0, sizeof(int64_t) * (size_t)(nc - c->scafCap));
+        memset(c->scafBases + c->scafCap, 0, sizeof(int64_t) * (size_t)(nc - c->scafCap));
+        c->scafCap = nc;
+    }
+    const int skip = len > 20000000 ? c->k : len > 5000000 ? 11 : len > 500000 ? 2 : 0;     /* :397 */
+    int64_t added = 0;
+    for (int tnum = 0; tnum < WAYS; tnum++) added += loader_add_to_map(c, bases, len, id, skip, tnum);
+    c->storedKmers += added;
+    return added;
+}
+
+int bbo_load_fasta(bbo_ctx* c, const char* path) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return -1;
+    size_t cap = 1 << 16, n = 0; uint8_t* seq = (uint8_t*)malloc(cap);
+    int have = 0, nrec = 0, ch, bol = 1, inhdr = 0;
+    while ((ch = fgetc(f)) != EOF) {
+        if (inhdr) { if (ch == '\n') { inhdr = 0; bol = 1; } continue; }
+        if (bol && ch == '>') {
+            if (have && n > 0) { bbo_add_ref_sequence(c, seq, (int64_t)n); nrec++; }   /* stream/FastaReadInputStream minLen=1 */
+            have = 1; n = 0; inhdr = 1; continue;
+        }
+        if (ch == '\n' || ch == '\r') { bol = 1; continue; }
+        bol = 0;
+        if (ch > '\r') {                                   /* FastaReadInputStream.java:362 buffer[x]>slashr */
+            if (n == cap) { cap *= 2; seq = (uint8_t*)realloc(seq, cap); }
+            seq[n++] = (uint8_t)ch;
+        }
+    }
+    if (have && n > 0) { bbo_add_ref_sequence(c, seq, (int64_t)n); nrec++; }
+    free(seq); fclose(f);
+    return nrec;
+}
+int bbo_num_scaffolds(const bbo_ctx* c) { return c->numScaffolds; }
+int64_t bbo_stored_kmers(const bbo_ctx* c) { return c->storedKmers; }
+
+int bbo_table_get(const bbo_ctx* c, int64_t key) {
+    if (key < 0) return NOT_PRESENT;
+    return ha_get_value(&c->keySets[(int)(key % WAYS)], key);
+}
+int bbo_num_ways(const bbo_ctx* c) { (void)c; return WAYS; }
+int bbo_way_image(const bbo_ctx* c, int way, int* prime, int64_t* ncells, const int64_t** keys, const int32_t** values,
+                  int64_t* nvictims, const int64_t** vkeys, const int32_t** vvals) {
+    if (way < 0 || way >= WAYS) return -1;
+    const hash_array* h = &c->keySets[way];
+    *prime = h->prime; *ncells = (int64_t)h->prime + HA_EXTRA; *keys = h->array; *values = h->values;
+    *nvictims = h->vsize; *vkeys = h->vkeys; *vvals = h->vvals;
+    return 0;
+}
+int64_t bbo_dump_pairs(const bbo_ctx* c, int64_t* keys, int32_t* values, int64_t cap) {
+    int64_t n = 0;
+    for (int w = 0; w < WAYS; w++) {
+        const hash_array* h = &c->keySets[w];
+        for (int64_t i = 0; i < (int64_t)h->prime + HA_EXTRA; i++) if (h->array[i] > NOT_PRESENT) {
+            if (keys && n < cap) { keys[n] = h->array[i]; values[n] = h->values[i]; }
+            n++;
+        }
+        for (int64_t i = 0; i < h->vsize; i++) {
+            if (keys && n < cap) { keys[n] = h->vkeys[i]; values[n] = h->vvals[i]; }
+            n++;
+        }
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* bbduk/BBDukIndexMod.java:492-520 getValueInner (qSkip=1, speed=0) */
+static int get_value_inner(const bbo_ctx* c, const int64_t kmer, const int64_t rkmer, const int64_t lengthMask) {
+    const int64_t max = (c->rcomp ? (kmer > rkmer ? kmer : rkmer) : kmer);
+    const int64_t key = (max & c->middleMask) | lengthMask;
+    return ha_get_value(&c->keySets[(int)(key % WAYS)], key);
+}
+/* bbduk/BBDukIndexMod.java:462-481 getValue */
+int bbo_get_value(const bbo_ctx* c, const int64_t kmer, const int64_t rkmer, const int64_t lengthMask, const int qPos, const int len, const int qHDist) {
+    int id = get_value_inner(c, kmer, rkmer, lengthMask);
+    if (id < 1 && qHDist > 0) {
+        const int qHDist2 = qHDist - 1;
+        for (int j = 0; j < SYMBOLS && id < 1; j++) {
+            for (int i = 0; i < len && id < 1; i++) {
+                const int64_t temp = (kmer & c->clearMasks[i]) | c->setMasks[j][i];
+                if (temp != kmer) {
+                    int64_t rtemp = bbo_rcomp(temp, len);
+                    id = bbo_get_value(c, temp, rtemp, lengthMask, qPos, len, qHDist2);
+                }
+            }
+        }
+    }
+    return id;
+}
+
+/* per-thread counter block */
+typedef struct { int64_t counters[BBO_NCOUNTERS]; int64_t* scafReads; int64_t* scafBases; } tcounters;
+
+/* shared/TrimRead.java:304-345 trimByAmount, on lengths only (bases/quals are copied by the caller in Java).
+ * Returns total trimmed; *newLen gets the resulting length. */
+static int trim_by_amount(int len, int leftTrimAmount, int rightTrimAmount, int minResultingLength, int* newLen) {
+    leftTrimAmount = imax(leftTrimAmount, 0);
+    rightTrimAmount = imax(rightTrimAmount, 0);
+    if (len < 1) { *newLen = len; return 0; }
+    minResultingLength = imin(len, imax(minResultingLength, 0));
+    if (leftTrimAmount + rightTrimAmount + minResultingLength > len) {
+        rightTrimAmount = imax(1, len - minResultingLength);
+        leftTrimAmount = 0;
+    }
+    const int total = leftTrimAmount + rightTrimAmount;
+    *newLen = len - total;
+    return total;
+}
+/* shared/TrimRead.java:273-276 trimToPosition */
+static int trim_to_position(int len, int leftLoc, int rightLoc, int minResultingLength, int* newLen) {
+    return trim_by_amount(len, leftLoc, len - rightLoc - 1, minResultingLength, newLen);
+}
+
+/* bbduk/BBDukProcessorS.java:1993-2140 ktrim(Read,start,stop).  *newLen = r.length() afterwards. */
+static int ktrim_span(const bbo_ctx* c, tcounters* tc, const uint8_t* bases, const int blen, const int pairnum,
+                      const int start, const int stop, int* id0out, int* newLen) {
+    const int k = c->k;
+    *newLen = blen; *id0out = -1;
+    if (blen < imax(1, (c->useShortKmers ? imin(k, c->mink) : k)) || c->storedKmers < 1) return 0;
+    if ((c->a.skipR1 && pairnum == 0) || (c->a.skipR2 && pairnum == 1)) return 0;
+    const int ktrimLeft = c->a.ktrimLeft, ktrimRight = c->a.ktrimRight;
+    int64_t kmer = 0, rkmer = 0;
+    int found = 0, len = 0, id0 = -1;
+    int minLoc = 999999999, minLocExclusive = 999999999;
+    int maxLoc = -1, maxLocExclusive = -1;
+
+    for (int i = start; i < stop; i++) {                                            /* :2009-2029 */
+        uint8_t b = bases[i];
+        int64_t x = num0(b), x2 = cnum0(b);
+        kmer = (int64_t)((((uint64_t)kmer << 2) | (uint64_t)x) & (uint64_t)c->mask);
+        rkmer = (int64_t)((((uint64_t)rkmer >> 2) | ((uint64_t)x2 << c->shift2)) & (uint64_t)c->mask);
+        if (c->forbidNs && !is_fully_defined(b)) { len = 0; rkmer = 0; } else { len++; }
+        if (len >= c->minlen2 && i >= c->minlen) {
+            const int id = bbo_get_value(c, kmer, rkmer, c->kmask, i, k, c->qHammingDistance);
+            if (id > 0) {
+                if (id0 < 0) id0 = id;
+                minLoc = imin(minLoc, i - k + 1);
+                maxLoc = i;
+                found++;
+            }
+        }
+    }
+    if (minLoc != minLocExclusive) minLocExclusive = minLoc + k;                    /* :2031-2032 */
+    if (maxLoc != maxLocExclusive) maxLocExclusive = maxLoc - k;
+
+    if (c->useShortKmers && found == 0) {                                           /* :2034-2103 */
+        if (ktrimLeft) {
+            kmer = 0; rkmer = 0; len = 0;
+            const int lim = imin(k, stop);
+            for (int i = start; i < lim; i++) {
+                uint8_t b = bases[i];
+                int64_t x = num0(b), x2 = cnum0(b);
+                kmer = (int64_t)((((uint64_t)kmer << 2) | (uint64_t)x) & (uint64_t)c->mask);
+                rkmer = rkmer | (int64_t)((uint64_t)x2 << (2 * len));
+                len++;
+                if (len >= c->mink) {
+                    const int id = bbo_get_value(c, kmer, rkmer, c->lengthMasks[len], i, len, c->qHammingDistance2);
+                    if (id > 0) {
+                        if (id0 < 0) id0 = id;
+                        minLoc = 0;
+                        minLocExclusive = imin(minLocExclusive, i + 1);
+                        maxLoc = imax(maxLoc, i);
+                        maxLocExclusive = imax(maxLocExclusive, 0);
+                        found++;
+                    }
+                }
+            }
+        }
+        if (ktrimRight) {
+            kmer = 0; rkmer = 0; len = 0;
+            const int lim = imax(-1, stop - k);
+            for (int i = stop - 1; i > lim; i--) {
+                uint8_t b = bases[i];
+                int64_t x = num0(b), x2 = cnum0(b);
+                kmer = kmer | (int64_t)((uint64_t)x << (2 * len));
+                rkmer = (int64_t)((((uint64_t)rkmer << 2) | (uint64_t)x2) & (uint64_t)c->mask);
+                len++;
+                if (len >= c->mink) {
+                    const int id = bbo_get_value(c, kmer, rkmer, c->lengthMasks[len], i, len, c->qHammingDistance2);
+                    if (id > 0) {
+                        if (id0 < 0) id0 = id;
+                        minLoc = i;
+                        minLocExclusive = imin(minLocExclusive, blen);
+                        maxLoc = blen - 1;
+                        maxLocExclusive = imax(maxLocExclusive, i - 1);
+                        found++;
+                    }
+                }
+            }
+        }
+    }
+    if (found == 0) return 0;                                                        /* :2108 */
+    tc->scafReads[id0]++;                                                            /* :2111-2119 */
+    tc->scafBases[id0] += blen;
+    *id0out = id0;
+    if (c->a.trimPad != 0) {                                                         /* :2121-2126 */
+        const int tp = c->a.trimPad;
+        maxLoc = imid(0, maxLoc + tp, blen);
+        minLoc = imid(0, minLoc - tp, blen);
+        maxLocExclusive = imid(0, maxLocExclusive + tp, blen);
+        minLocExclusive = imid(0, minLocExclusive - tp, blen);
+    }
+    if (ktrimLeft) {                                                                 /* :2128-2132 */
+        return trim_to_position(blen, c->a.ktrimExclusive ? maxLocExclusive + 1 : maxLoc + 1, blen - 1, 1, newLen);
+    } else {                                                                         /* :2133-2139 */
+        return trim_to_position(blen, 0, c->a.ktrimExclusive ? minLocExclusive - 1 : minLoc - 1, 1, newLen);
+    }
+}
+/* bbduk/BBDukProcessorS.java:1806-1811 ktrim(Read) */
+static int ktrim_read(const bbo_ctx* c, tcounters* tc, const uint8_t* bases, int len, int pairnum, int* id0, int* newLen) {
+    const int start = (c->a.restrictRight < 1 ? 0 : imax(0, len - c->a.restrictRight));
+    const int stop  = (c->a.restrictLeft  < 1 ? len : imin(len, c->a.restrictLeft));
+    return ktrim_span(c, tc, bases, len, pairnum, start, stop, id0, newLen);
+}
+
+/* bbduk/BBDukProcessorS.java:1534-1593 countSetKmers */
+static int count_set_kmers(const bbo_ctx* c, tcounters* tc, const uint8_t* bases, const int blen, const int pairnum,
+                           const int maxBadKmers, int* idout) {
+    const int k = c->k;
+    *idout = -1;
+    if (blen < k || c->storedKmers < 1) return 0;
+    if ((c->a.skipR1 && pairnum == 0) || (c->a.skipR2 && pairnum == 1)) return 0;
+    int64_t kmer = 0, rkmer = 0;
+    int found = 0, len = 0;
+    const int start = (c->a.restrictRight < 1 ? 0 : imax(0, blen - c->a.restrictRight));
+    const int stop  = (c->a.restrictLeft  < 1 ? blen : imin(blen, c->a.restrictLeft));
+    for (int i = start; i < stop; i++) {
+        uint8_t b = bases[i];
+        int64_t x = num0(b), x2 = cnum0(b);
+        kmer = (int64_t)((((uint64_t)kmer << 2) | (uint64_t)x) & (uint64_t)c->mask);
+        rkmer = (int64_t)((((uint64_t)rkmer >> 2) | ((uint64_t)x2 << c->shift2)) & (uint64_t)c->mask);
+        if (c->forbidNs && !is_fully_defined(b)) { len = 0; rkmer = 0; } else { len++; }
+        if (len >= c->minlen2 && i >= c->minlen) {
+            const int id = bbo_get_value(c, kmer, rkmer, c->kmask, i, k, c->qHammingDistance);
+            if (id > 0) {
+                if (found == maxBadKmers) {
+                    tc->scafReads[id]++;
+                    tc->scafBases[id] += blen;
+                    *idout = id;
+                    return (found = found + 1);
+                }
+                found++;
+            }
+        }
+    }
+    return found;
+}
+
+static tcounters main_tc(bbo_ctx* c) { tcounters t; memset(&t, 0, sizeof t); t.scafReads = c->scafReads; t.scafBases = c->scafBases; return t; }
+
+int bbo_ktrim_read(bbo_ctx* c, const uint8_t* bases, int len, int pairnum, int* id0) {
+    tcounters t = main_tc(c); int nl;
+    return ktrim_read(c, &t, bases, len, pairnum, id0, &nl);
+}
+int bbo_count_set_kmers(bbo_ctx* c, const uint8_t* bases, int len, int pairnum, int maxBadKmers, int* id) {
+    tcounters t = main_tc(c);
+    return count_set_kmers(c, &t, bases, len, pairnum, maxBadKmers, id);
+}
+
+/* bbduk/BBDukProcessorS.java:778-1093,1431-1443 -- one pair (r2len<0 => unpaired), k-mer stage only.
+ * Everything before the k-mer stage (junk/chastity/GC/force-trim...) and after it (tbo/qtrim/...) is off
+ * in every BASELINE config and stays in the Java host. */
+static void process_pair(const bbo_ctx* c, tcounters* tc, const uint8_t* b1, int l1, const uint8_t* b2, int l2, int has2,
+                         int32_t* a, int32_t* ids, uint8_t* fl) {
+    const int initialLength1 = l1, initialLength2 = has2 ? l2 : 0;
+    const int pairCount = has2 ? 2 : 1;
+    const int minlen1 = (int)((float)initialLength1 * c->a.minLenFraction > (float)c->a.minReadLength ?
+                              (float)initialLength1 * c->a.minLenFraction : (float)c->a.minReadLength);   /* :812 */
+    const int minlen2 = (int)((float)initialLength2 * c->a.minLenFraction > (float)c->a.minReadLength ?
+                              (float)initialLength2 * c->a.minLenFraction : (float)c->a.minReadLength);   /* :813 */
+    tc->counters[BBO_READS_IN] += pairCount;                                          /* :817-818 */
+    tc->counters[BBO_BASES_IN] += initialLength1 + initialLength2;
+    int d1 = 0, d2 = 0, remove = 0;
+    int newLen1 = l1, newLen2 = initialLength2;
+    const int doKmerTrimming = c->storedKmers > 0 && (c->a.ktrimLeft || c->a.ktrimRight);   /* :772 */
+    const int doKmerFiltering = c->storedKmers > 0 && !doKmerTrimming;                      /* :773 */
+    a[0] = 0; ids[0] = -1; if (has2) { a[1] = 0; ids[1] = -1; }
+    if (doKmerTrimming) {                                                             /* :948-1033 */
+        int rlen1 = 0, rlen2 = 0, xsum = 0, rktsum = 0;
+        {
+            int id0; int x = ktrim_read(c, tc, b1, l1, 0, &id0, &newLen1);
+            xsum += x; rktsum += (x > 0 ? 1 : 0); rlen1 = newLen1;
+            if (rlen1 < minlen1) d1 = 1;
+            a[0] = x; ids[0] = id0;
+        }
+        if (has2) {
+            int id0; int x = ktrim_read(c, tc, b2, l2, 1, &id0, &newLen2);
+            xsum += x; rktsum += (x > 0 ? 1 : 0); rlen2 = newLen2;
+            if (rlen2 < minlen2) d2 = 1;
+            a[1] = x; ids[1] = id0;
+        }
+        /* shouldRemove (:1489-1492) */
+        if ((c->removePairsIfEitherBad && (d1 || d2)) || (d1 && (!has2 || d2))) {
+            xsum += (rlen1 + rlen2);                                                  /* :1011-1014 (!ktrimN) */
+            rktsum = pairCount;
+            remove = 1;
+        }
+        tc->counters[BBO_BASES_KTRIMMED] += xsum;                                     /* :1028-1029 */
+        tc->counters[BBO_READS_KTRIMMED] += rktsum;
+    } else if (doKmerFiltering) {                                                     /* :1035-1093 */
+        const int maxBadKmersR1 = c->a.maxBadKmers0, maxBadKmersR2 = c->a.maxBadKmers0;   /* minKmerFraction==0 (:1056-1057) */
+        int id; const int av = count_set_kmers(c, tc, b1, l1, 0, maxBadKmersR1, &id);
+        a[0] = av; ids[0] = id;
+        if (av > maxBadKmersR1) d1 = 1;
+        if (has2) {
+            const int bv = count_set_kmers(c, tc, b2, l2, 1, maxBadKmersR2, &id);
+            a[1] = bv; ids[1] = id;
+            if (bv > maxBadKmersR2) d2 = 1;
+        }
+        if ((c->removePairsIfEitherBad && (d1 || d2)) || (d1 && (!has2 || d2))) {
+            remove = 1;
+            tc->counters[BBO_READS_KFILTERED]++; tc->counters[BBO_BASES_KFILTERED] += initialLength1;
+            if (has2) { tc->counters[BBO_READS_KFILTERED]++; tc->counters[BBO_BASES_KFILTERED] += initialLength2; }
+        }
+    }
+    if (remove) {                                                                     /* :1431-1443 */
+        tc->counters[BBO_READS_OUTM] += pairCount;
+        tc->counters[BBO_BASES_OUTM] += newLen1 + newLen2;
+    } else {
+        tc->counters[BBO_READS_OUTU] += pairCount;
+        tc->counters[BBO_BASES_OUTU] += newLen1 + newLen2;
+    }
+    fl[0] = (uint8_t)((d1 ? BBO_FLAG_DISCARDED : 0) | (remove ? BBO_FLAG_REMOVED : 0));
+    if (has2) fl[1] = (uint8_t)((d2 ? BBO_FLAG_DISCARDED : 0) | (remove ? BBO_FLAG_REMOVED : 0));
+}
+
+typedef struct {
+    const bbo_ctx* c; const uint8_t* bases; const int64_t* offsets; int64_t n; int paired;
+    int32_t* out_a; int32_t* out_id; uint8_t* out_flags; int64_t u0, u1; tcounters tc;
+} job;
+
+static void* job_run(void* p) {
+    job* j = (job*)p;
+    const int step = j->paired ? 2 : 1;
+    for (int64_t u = j->u0; u < j->u1; u++) {
+        int64_t r = u * step;
+        const uint8_t* b1 = j->bases + j->offsets[r]; int l1 = (int)(j->offsets[r + 1] - j->offsets[r]);
+        const uint8_t* b2 = NULL; int l2 = 0;
+        if (j->paired) { b2 = j->bases + j->offsets[r + 1]; l2 = (int)(j->offsets[r + 2] - j->offsets[r + 1]); }
+        process_pair(j->c, &j->tc, b1, l1, b2, l2, j->paired, j->out_a + r, j->out_id + r, j->out_flags + r);
+    }
+    return NULL;
+}
+
+int bbo_process_batch(bbo_ctx* c, const uint8_t* bases, const int64_t* offsets, int64_t n, int paired,
+                      int32_t* out_a, int32_t* out_id, uint8_t* out_flags, int nthreads) {
+    if (paired && (n & 1)) return -1;
+    if (nthreads < 1) nthreads = 1;
+    const int64_t units = paired ? n / 2 : n;
+    if (units < nthreads) nthreads = units > 0 ? (int)units : 1;
+    job* jobs = (job*)calloc((size_t)nthreads, sizeof(job));
+    pthread_t* th = (pthread_t*)calloc((size_t)nthreads, sizeof(pthread_t));
+    const int ns = c->numScaffolds;
+    for (int t = 0; t < nthreads; t++) {
+        job* j = &jobs[t];
+        j->c = c; j->bases = bases; j->offsets = offsets; j->n = n; j->paired = paired;
+        j->out_a = out_a; j->out_id = out_id; j->out_flags = out_flags;
+        j->u0 = units * t / nthreads; j->u1 = units * (t + 1) / nthreads;
+        j->tc.scafReads = (int64_t*)calloc((size_t)ns, sizeof(int64_t));             /* thread-local copies (:272-277) */
+        j->tc.scafBases = (int64_t*)calloc((size_t)ns, sizeof(int64_t));
+        if (nthreads > 1) pthread_create(&th[t], NULL, job_run, j); else job_run(j);
+    }
+    for (int t = 0; t < nthreads; t++) {
+        if (nthreads > 1) pthread_join(th[t], NULL);
+        for (int i = 0; i < BBO_NCOUNTERS; i++) c->counters[i] += jobs[t].tc.counters[i];   /* BBDukProcessorS.add :300-342 */
+        for (int i = 0; i < ns; i++) { c->scafReads[i] += jobs[t].tc.scafReads[i]; c->scafBases[i] += jobs[t].tc.scafBases[i]; }
+        free(jobs[t].tc.scafReads); free(jobs[t].tc.scafBases);
+    }
+    free(jobs); free(th);
+    return 0;
+}
+
+int bbo_counters_len(const bbo_ctx* c) { return BBO_NCOUNTERS + 2 * c->numScaffolds; }
+void bbo_get_counters(const bbo_ctx* c, int64_t* out) {
+    memcpy(out, c->counters, sizeof c->counters);
+    memcpy(out + BBO_NCOUNTERS, c->scafReads, sizeof(int64_t) * (size_t)c->numScaffolds);
+    memcpy(out + BBO_NCOUNTERS + c->numScaffolds, c->scafBases, sizeof(int64_t) * (size_t)c->numScaffolds);
+}
+void bbo_reset_counters(bbo_ctx* c) {
+    memset(c->counters, 0, sizeof c->counters);
+    memset(c->scafReads, 0, sizeof(int64_t) * (size_t)c->scafCap);
+    memset(c->scafBases, 0, sizeof(int64_t) * (size_t)c->scafCap);
+}

@@ -1,0 +1,121 @@
+/*
+ * bbduk_oracle.h -- CPU ORACLE for the BBDuk k-mer matching path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is a plain-C restatement of the reference's algorithm (BBTools v40.02, Java) for the one
+ * hot path this repo accelerates.  It exists so that the HIP path can be checked bit-for-bit.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the product
+ * (bbtools_amd/) never links, imports or calls anything in oracle/.
+ *
+ * PARITY UNPINNED: the reference is Java, there is no JVM in the build image, and the reference
+ * ships no tests / golden vectors for bbduk/ or kmer/ (SURVEY.md §4, §8c).  The oracle is therefore
+ * pinned only (a) against hand-derived known-answer values, (b) against the assertion identities
+ * the reference itself checks under -ea, and (c) by differential testing against a second,
+ * structurally different restatement (oracle/spec.py: string-based closed form).
+ *
+ * All citations are relative to /root/reference/current/ .
+ */
+#ifndef BBDUK_ORACLE_H
+#define BBDUK_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* User-level arguments, i.e. the bbduk.sh key=value flags that reach this path
+ * (bbduk/BBDukParser.java:448-874).  Fill with bbo_default_args() first. */
+typedef struct bbo_args {
+    int k;              /* k=            (default 27 when absent: BBDukParser.java:163) */
+    int mink;           /* mink=         (-1 = off; :1230) */
+    int hdist, hdist2;  /* hdist= hdist2= (hdist2=-1 -> hdist; :130) */
+    int edist, edist2;  /* edist= edist2= */
+    int qhdist, qhdist2;/* qhdist= qhdist2= */
+    int maskMiddle;     /* mm=           (default t; :1091) */
+    int midMaskLen;     /* mml=          (0 -> 2-(k&1); :232-236) */
+    int rcomp;          /* rcomp=        (default t; :1208) */
+    int forbidN;        /* forbidn=      (default f) */
+    int ktrimRight;     /* ktrim=r */
+    int ktrimLeft;      /* ktrim=l */
+    int maxBadKmers0;   /* mbk= / mkh=-1 (default 0; :1232) */
+    int minReadLength;  /* minlen=       (default 10; :437) */
+    float minLenFraction;/* mlf=         (default 0;  :439) */
+    int requireBothBad; /* rieb=f  ->  removePairsIfEitherBad=false (:109) */
+    int trimPad;        /* tp= */
+    int ktrimExclusive; /* ktrimexclusive= */
+    int restrictLeft, restrictRight; /* restrictleft= restrictright= */
+    int skipR1, skipR2; /* skipr1= skipr2= */
+    int minSkip, maxSkip;/* rskip/minskip/maxskip (default 1,1) */
+} bbo_args;
+
+#define BBO_NCOUNTERS 16
+enum { BBO_READS_IN=0, BBO_BASES_IN, BBO_READS_KTRIMMED, BBO_BASES_KTRIMMED,
+       BBO_READS_KFILTERED, BBO_BASES_KFILTERED, BBO_READS_OUTU, BBO_BASES_OUTU,
+       BBO_READS_OUTM, BBO_BASES_OUTM };
+
+#define BBO_FLAG_DISCARDED 1   /* this read was setDiscarded()                 */
+#define BBO_FLAG_REMOVED   2   /* its pair was removed (shouldRemove -> remove) */
+
+typedef struct bbo_ctx bbo_ctx;
+
+void     bbo_default_args(bbo_args* a);
+/* Create a context: derives all constants exactly as BBDukParser does. Returns NULL on bad args. */
+bbo_ctx* bbo_create(const bbo_args* a);
+void     bbo_destroy(bbo_ctx* c);
+
+/* Derived constants, for known-answer tests.  name in {"k","mink","hdist","hdist2","forbidNs","minlen",
+ * "minlen2","shift2","mask","kmask","middleMask","useShortKmers","maskMiddle","midMaskLen","kfilter"} */
+int64_t  bbo_constant(const bbo_ctx* c, const char* name);
+
+/* Primitive restatements, exported for known-answer tests. */
+int64_t  bbo_rcomp(int64_t kmer, int k);                 /* dna/AminoAcid.java:585-601 */
+int      bbo_base_to_number(int b);                      /* dna/AminoAcid.java:1284-1298 (-1 undefined) */
+int      bbo_base_to_number0(int b);
+int      bbo_base_to_complement_number0(int b);
+
+/* Reference loading (BBDukLoader.spawnLoadThreads + LoadThread.addToMap).  Sequences are given in file
+ * order; scaffold ids are assigned 1,2,3...  Returns number of keys added (sum of setIfNotPresent). */
+int64_t  bbo_add_ref_sequence(bbo_ctx* c, const uint8_t* bases, int64_t len);
+/* Convenience: parse a FASTA file (plain text) and add every record of length>=1. Returns #records or <0. */
+int      bbo_load_fasta(bbo_ctx* c, const char* path);
+int      bbo_num_scaffolds(const bbo_ctx* c);            /* scaffoldNames.size()  (ids are 1..n-1) */
+int64_t  bbo_stored_kmers(const bbo_ctx* c);
+
+/* Table access. */
+int      bbo_table_get(const bbo_ctx* c, int64_t key);   /* AbstractKmerTable.getValue: -1 if absent */
+/* Image of one HashArray1D way, the arrays a JVM caller would hand to bbduk_upload_table_way():
+ * array() (kmer/HashArray.java:672), values() (kmer/HashArray1D.java:407), victims().toList(). */
+int      bbo_num_ways(const bbo_ctx* c);
+int      bbo_way_image(const bbo_ctx* c, int way, int* prime, int64_t* ncells,
+                       const int64_t** keys, const int32_t** values,
+                       int64_t* nvictims, const int64_t** vkeys, const int32_t** vvals);
+/* Flat (key,value) dump of everything stored; returns count (call with NULLs to size). */
+int64_t  bbo_dump_pairs(const bbo_ctx* c, int64_t* keys, int32_t* values, int64_t cap);
+
+/* Index.getValue (BBDukIndexMod.java:462-520) incl. query-side Hamming expansion. */
+int      bbo_get_value(const bbo_ctx* c, int64_t kmer, int64_t rkmer, int64_t lengthMask, int qPos, int len, int qHDist);
+
+/* Per-read scans, exactly as the reference's private methods; they do NOT mutate anything but counters.
+ * ktrim: returns bases trimmed x (BBDukProcessorS.java:1806-1811,1993-2140); *id0 = first hit id or -1.
+ * pairnum = 0/1.  scaffold counters inside ctx (thread 0) are bumped.  */
+int      bbo_ktrim_read(bbo_ctx* c, const uint8_t* bases, int len, int pairnum, int* id0);
+/* countSetKmers (:1534-1593); *id = id at the exit hit or -1. */
+int      bbo_count_set_kmers(bbo_ctx* c, const uint8_t* bases, int len, int pairnum, int maxBadKmers, int* id);
+
+/* Batch = what processList does around the k-mer stage for every read/pair of a ListNum
+ * (BBDukProcessorS.java:807-813, 948-1093, 1431-1443, 1464-1493).
+ * bases: concatenated ASCII; offsets[n+1]; if paired, reads 2i and 2i+1 are mates (n even).
+ * out_a[i]  = ktrim: bases trimmed x        | kfilter: found (countSetKmers return)
+ * out_id[i] = ktrim: id0 (or -1)            | kfilter: id at exit hit (or -1)
+ * out_flags[i] = BBO_FLAG_* bits.   Counters accumulate in ctx.   nthreads>=1 (pairs are sharded). */
+int      bbo_process_batch(bbo_ctx* c, const uint8_t* bases, const int64_t* offsets, int64_t n, int paired,
+                           int32_t* out_a, int32_t* out_id, uint8_t* out_flags, int nthreads);
+
+/* counters: out[0..15] as BBO_* then scaffoldReadCounts[0..nscaf) then scaffoldBaseCounts[0..nscaf). */
+int      bbo_counters_len(const bbo_ctx* c);
+void     bbo_get_counters(const bbo_ctx* c, int64_t* out);
+void     bbo_reset_counters(bbo_ctx* c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,387 @@
+"""
+spec.py -- SECOND, structurally different restatement of the BBDuk k-mer matching path.
+TEST INFRASTRUCTURE ONLY (used by tests/ and by tests/golden/make_golden.py).  PARITY UNPINNED
+(no JVM in the image; the reference ships no golden vectors for this path -- SURVEY.md §8c).
+
+Where oracle/bbduk_oracle.c follows the reference's sequential rolling loops line by line, this file
+works on *strings* and uses the position-parallel closed form: every k-mer
+is re-derived from a slice of the read, the reference table is a plain dict.  The two restatements share
+no code and no data structure, so agreement between them (tests/test_oracle.py differential fuzz) is
+evidence that both read the reference the same way.
+
+Citations are relative to /root/reference/current/ .
+"""
+from dataclasses import dataclass, field
+
+# dna/AminoAcid.java:1284-1311
+_FWD = {c: i for i, c in enumerate("ACGT")}
+_FWD.update({c.lower(): i for c, i in list(_FWD.items())})
+_FWD.update({"U": 3, "u": 3})
+_COMP = {c: 3 - v for c, v in _FWD.items()}
+
+
+def defined(ch: int) -> bool:
+    return ch < 128 and chr(ch) in _FWD
+
+
+def fwd_code(ch: int) -> int:           # baseToNumber0: undefined -> 0
+    return _FWD.get(chr(ch), 0) if ch < 128 else 0
+
+
+def comp_code(ch: int) -> int:          # baseToComplementNumber0: undefined -> 0
+    return _COMP.get(chr(ch), 0) if ch < 128 else 0
+
+
+def rcomp_int(kmer: int, k: int) -> int:
+    """dna/AminoAcid.java:585-601, done the slow obvious way (digit reversal)."""
+    out = 0
+    for _ in range(k):
+        out = (out << 2) | (3 - (kmer & 3))
+        kmer >>= 2
+    return out
+
+
+@dataclass
+class Args:
+    k: int = 27
+    mink: int = -1
+    hdist: int = 0
+    hdist2: int = -1
+    qhdist: int = 0
+    qhdist2: int = -1
+    maskMiddle: bool = True
+    midMaskLen: int = 0
+    rcomp: bool = True
+    forbidN: bool = False
+    ktrimRight: bool = False
+    ktrimLeft: bool = False
+    maxBadKmers0: int = 0
+    minReadLength: int = 10
+    minLenFraction: float = 0.0
+    requireBothBad: bool = False
+    trimPad: int = 0
+    ktrimExclusive: bool = False
+    restrictLeft: int = 0
+    restrictRight: int = 0
+    skipR1: bool = False
+    skipR2: bool = False
+
+
+COUNTER_NAMES = ["readsIn", "basesIn", "readsKTrimmed", "basesKTrimmed", "readsKFiltered", "basesKFiltered",
+                 "readsOutu", "basesOutu", "readsOutm", "basesOutm"]
+NCOUNTERS = 16
+FLAG_DISCARDED, FLAG_REMOVED = 1, 2
+
+
+class Spec:
+    def __init__(self, a: Args):
+        self.a = a
+        k = a.k
+        assert 1 <= k <= 31
+        # bbduk/BBDukParser.java:130-150
+        self.hdist = a.hdist
+        self.hdist2 = a.hdist if a.hdist2 == -1 else a.hdist2
+        self.qhdist = a.qhdist
+        self.qhdist2 = a.qhdist if a.qhdist2 == -1 else a.qhdist2
+        self.forbidNs = a.forbidN or self.hdist < 1
+        self.k = k
+        mm = a.maskMiddle
+        mml = (a.midMaskLen if a.midMaskLen > 0 else 2 - (k & 1)) if mm else 0     # :230-236
+        self.mink = min(a.mink, k)                                                 # :245
+        self.minlen = k - 1                                                        # :274
+        self.minlen2 = (k - mml) // 2 if mm else k                                 # :276 (before mink switches mm off)
+        self.kmask = 1 << (2 * k)
+        self.useShortKmers = 0 < self.mink < k                                     # :289
+        if self.useShortKmers:
+            mm, mml = False, 0                                                     # :290-296
+            assert a.ktrimLeft or a.ktrimRight                                     # :301
+        if mm:                                                                     # :303-312
+            self.middleMask = ~(((1 << (2 * mml)) - 1) << (((k - mml) // 2) * 2))
+        else:
+            self.middleMask = -1
+        self.kfilter = not (a.ktrimLeft or a.ktrimRight)
+        self.rieb = not a.requireBothBad                                           # :109
+        self.table = {}            # key -> id  (first writer wins == smallest id; ids ascend in file order)
+        self.nscaf = 1             # scaffoldNames[0] reserved (bbduk/BBDukIndex.java:105-107)
+        self.counters = [0] * NCOUNTERS
+        self.scafReads = [0]
+        self.scafBases = [0]
+
+    # ---------------------------------------------------------------- keys
+    def key_of(self, kmer: int, rkmer: int, length: int) -> int:
+        """bbduk/BBDukIndexMod.java:532-544 toValue.  kmer, rkmer < 2^62 so signed max == int max."""
+        v = max(kmer, rkmer) if self.a.rcomp else kmer
+        return (v & self.middleMask) | (1 << (2 * length))
+
+    def _neighbours(self, kmer: int, length: int, dist: int, out: list):
+        """bbduk/BBDukIndexMod.java:383-413 mutate (substitutions only), as a plain enumeration."""
+        out.append(kmer)
+        if dist > 0:
+            for j in range(4):
+                for i in range(length):
+                    t = (kmer & ~(3 << (2 * i))) | (j << (2 * i))
+                    if t != kmer:
+                        self._neighbours(t, length, dist - 1, out)
+
+    def _store(self, kmer: int, length: int, dist: int, sid: int) -> None:
+        vs = []
+        self._neighbours(kmer, length, dist, vs)
+        for v in vs:
+            key = self.key_of(v, rcomp_int(v, length), length)
+            self.table.setdefault(key, sid)
+
+    # ---------------------------------------------------------------- reference
+    def add_ref(self, seq: bytes) -> None:
+        """bbduk/BBDukLoader.java:416-494 for skip==1, by slicing instead of rolling."""
+        sid = self.nscaf
+        self.nscaf += 1
+        self.scafReads.append(0)
+        self.scafBases.append(0)
+        k, n = self.k, len(seq)
+        if n < k:
+            return
+        ok = [defined(c) for c in seq]
+        for i in range(k - 1, n):
+            win = seq[i - k + 1:i + 1]
+            if not all(ok[i - k + 1:i + 1]):          # len>=k <=> the last k bases are all defined
+                continue
+            kmer = 0
+            for c in win:
+                kmer = (kmer << 2) | fwd_code(c)
+            self._store(kmer, k, self.hdist, sid)
+            if self.useShortKmers:
+                if i == k - 1:                         # addToMapRightShift: prefixes of the first k-mer
+                    for L in range(k - 1, self.mink - 1, -1):
+                        self._store(kmer >> (2 * (k - L)), L, self.hdist2, sid)
+                if i == n - 1:                         # addToMapLeftShift: suffixes of the last k-mer
+                    for L in range(k - 1, self.mink - 1, -1):
+                        self._store(kmer & ((1 << (2 * L)) - 1), L, self.hdist2, sid)
+
+    def load_fasta(self, path: str) -> int:
+        import gzip
+        op = gzip.open if path.endswith(".gz") else open
+        seq, have, nrec = bytearray(), False, 0
+        with op(path, "rb") as f:
+            for line in f:
+                line = line.rstrip(b"\r\n")
+                if line.startswith(b">"):
+                    if have and len(seq) > 0:
+                        self.add_ref(bytes(seq)); nrec += 1
+                    have, seq = True, bytearray()
+                else:
+                    seq += bytes(c for c in line if c > 13)
+        if have and len(seq) > 0:
+            self.add_ref(bytes(seq)); nrec += 1
+        return nrec
+
+    # ---------------------------------------------------------------- lookup
+    def lookup(self, kmer: int, rkmer: int, length: int, qhdist: int) -> int:
+        """bbduk/BBDukIndexMod.java:462-520 getValue / getValueInner."""
+        vid = self.table.get(self.key_of(kmer, rkmer, length), -1)
+        if vid < 1 and qhdist > 0:
+            for j in range(4):
+                for i in range(length):
+                    t = (kmer & ~(3 << (2 * i))) | (j << (2 * i))
+                    if t != kmer:
+                        vid = self.lookup(t, rcomp_int(t, length), length, qhdist - 1)
+                        if vid >= 1:
+                            return vid
+        return vid
+
+    # ---------------------------------------------------------------- scans (closed form)
+    def _span(self, n: int):
+        a = self.a
+        start = 0 if a.restrictRight < 1 else max(0, n - a.restrictRight)
+        stop = n if a.restrictLeft < 1 else min(n, a.restrictLeft)
+        return start, stop
+
+    def _main_hits(self, read: bytes, start: int, stop: int):
+        """Yield (i, id) for every position of the main scan whose lookup returns id>0, in increasing i.
+        bbduk/BBDukProcessorS.java:2009-2029 == :1547-1591."""
+        k = self.k
+        for i in range(max(start, k - 1), stop):
+            lo = max(start, i - k + 1)
+            lastN = start - 1
+            if self.forbidNs:
+                for j in range(i, start - 1, -1):
+                    if not defined(read[j]):
+                        lastN = j
+                        break
+            length = i - lastN
+            if length < self.minlen2:
+                continue
+            kmer = 0
+            for j in range(lo, i + 1):
+                kmer |= fwd_code(read[j]) << (2 * (i - j))
+            rk = 0
+            for j in range(max(lo, lastN + 1), i + 1):
+                rk |= comp_code(read[j]) << (2 * (k - 1 - (i - j)))
+            vid = self.lookup(kmer, rk, k, self.qhdist)
+            if vid > 0:
+                yield i, vid
+
+    @staticmethod
+    def _trim_by_amount(n, left, right, minres):
+        """shared/TrimRead.java:304-345 on lengths."""
+        left, right = max(left, 0), max(right, 0)
+        if n < 1:
+            return 0, n
+        minres = min(n, max(minres, 0))
+        if left + right + minres > n:
+            right, left = max(1, n - minres), 0
+        return left + right, n - (left + right)
+
+    def ktrim(self, read: bytes, pairnum: int):
+        """Returns (x, id0, newLen).  bbduk/BBDukProcessorS.java:1806-1811, 1993-2140."""
+        a, k, n = self.a, self.k, len(read)
+        if n < max(1, min(k, self.mink) if self.useShortKmers else k) or not self.table:
+            return 0, -1, n
+        if (a.skipR1 and pairnum == 0) or (a.skipR2 and pairnum == 1):
+            return 0, -1, n
+        start, stop = self._span(n)
+        hits = list(self._main_hits(read, start, stop))
+        BIG = 999999999
+        found, id0 = len(hits), (hits[0][1] if hits else -1)
+        minLoc = min((i - k + 1 for i, _ in hits), default=BIG)
+        maxLoc = max((i for i, _ in hits), default=-1)
+        minLocEx = minLoc + k if hits else BIG
+        maxLocEx = maxLoc - k if hits else -1
+        if self.useShortKmers and found == 0:
+            if a.ktrimLeft:                                   # :2037-2069
+                for i in range(start, min(k, stop)):
+                    s = read[start:i + 1]
+                    L = len(s)
+                    if L < self.mink:
+                        continue
+                    km = 0
+                    for c in s:
+                        km = ((km << 2) | fwd_code(c)) & ((1 << (2 * k)) - 1)
+                    rk = 0
+                    for t, c in enumerate(s):
+                        rk |= comp_code(c) << (2 * t)
+                    vid = self.lookup(km, rk, L, self.qhdist2)
+                    if vid > 0:
+                        if id0 < 0: id0 = vid
+                        minLoc = 0
+                        minLocEx = min(minLocEx, i + 1)
+                        maxLoc = max(maxLoc, i)
+                        maxLocEx = max(maxLocEx, 0)
+                        found += 1
+            if a.ktrimRight:                                  # :2072-2102
+                for L in range(1, (k - 1 if stop >= k else stop) + 1):
+                    i = stop - L
+                    if L < self.mink:
+                        continue
+                    s = read[i:stop]
+                    km = 0
+                    for c in s:
+                        km = (km << 2) | fwd_code(c)
+                    rk = 0
+                    for t, c in enumerate(s):
+                        rk |= comp_code(c) << (2 * t)
+                    rk &= (1 << (2 * k)) - 1
+                    vid = self.lookup(km, rk, L, self.qhdist2)
+                    if vid > 0:
+                        if id0 < 0: id0 = vid
+                        minLoc = i
+                        minLocEx = min(minLocEx, n)
+                        maxLoc = n - 1
+                        maxLocEx = max(maxLocEx, i - 1)
+                        found += 1
+        if found == 0:
+            return 0, -1, n
+        self.scafReads[id0] += 1
+        self.scafBases[id0] += n
+        if a.trimPad != 0:
+            mid = lambda lo, x, hi: lo if x < lo else (hi if x > hi else x)
+            maxLoc = mid(0, maxLoc + a.trimPad, n)
+            minLoc = mid(0, minLoc - a.trimPad, n)
+            maxLocEx = mid(0, maxLocEx + a.trimPad, n)
+            minLocEx = mid(0, minLocEx - a.trimPad, n)
+        if a.ktrimLeft:
+            leftLoc, rightLoc = (maxLocEx + 1 if a.ktrimExclusive else maxLoc + 1), n - 1
+        else:
+            leftLoc, rightLoc = 0, (minLocEx - 1 if a.ktrimExclusive else minLoc - 1)
+        x, newLen = self._trim_by_amount(n, leftLoc, n - rightLoc - 1, 1)   # TrimRead.java:273-276
+        return x, id0, newLen
+
+    def count_set_kmers(self, read: bytes, pairnum: int, maxBad: int):
+        """Returns (found, id).  bbduk/BBDukProcessorS.java:1534-1593."""
+        a, k, n = self.a, self.k, len(read)
+        if n < k or not self.table:
+            return 0, -1
+        if (a.skipR1 and pairnum == 0) or (a.skipR2 and pairnum == 1):
+            return 0, -1
+        start, stop = self._span(n)
+        found = 0
+        for _, vid in self._main_hits(read, start, stop):
+            if found == maxBad:
+                self.scafReads[vid] += 1
+                self.scafBases[vid] += n
+                return found + 1, vid
+            found += 1
+        return found, -1
+
+    # ---------------------------------------------------------------- pair stage
+    def process_pair(self, r1: bytes, r2):
+        """bbduk/BBDukProcessorS.java:807-818, 948-1093, 1431-1443.  Returns [(a, id, flags), ...] per mate."""
+        a, C = self.a, self.counters
+        has2 = r2 is not None
+        l1, l2 = len(r1), (len(r2) if has2 else 0)
+        pc = 2 if has2 else 1
+        import numpy as np
+        f32 = np.float32
+        minlen1 = int(max(f32(l1) * f32(a.minLenFraction), f32(a.minReadLength)))
+        minlen2 = int(max(f32(l2) * f32(a.minLenFraction), f32(a.minReadLength)))
+        C[0] += pc; C[1] += l1 + l2
+        d1 = d2 = remove = False
+        n1, n2 = l1, l2
+        res = []
+        if self.table and (a.ktrimLeft or a.ktrimRight):
+            x1, i1, n1 = self.ktrim(r1, 0)
+            xsum, rkt = x1, int(x1 > 0)
+            d1 = n1 < minlen1
+            x2 = 0; i2 = -1
+            if has2:
+                x2, i2, n2 = self.ktrim(r2, 1)
+                xsum += x2; rkt += int(x2 > 0)
+                d2 = n2 < minlen2
+            if (self.rieb and (d1 or d2)) or (d1 and (not has2 or d2)):
+                xsum += n1 + n2; rkt = pc; remove = True
+            C[3] += xsum; C[2] += rkt
+            res = [(x1, i1)] + ([(x2, i2)] if has2 else [])
+        elif self.table:
+            f1, i1 = self.count_set_kmers(r1, 0, a.maxBadKmers0)
+            d1 = f1 > a.maxBadKmers0
+            res = [(f1, i1)]
+            if has2:
+                f2, i2 = self.count_set_kmers(r2, 1, a.maxBadKmers0)
+                d2 = f2 > a.maxBadKmers0
+                res.append((f2, i2))
+            if (self.rieb and (d1 or d2)) or (d1 and (not has2 or d2)):
+                remove = True
+                C[4] += pc; C[5] += l1 + l2
+        else:
+            res = [(0, -1)] * pc
+        if remove:
+            C[8] += pc; C[9] += n1 + n2
+        else:
+            C[6] += pc; C[7] += n1 + n2
+        fl = [(FLAG_DISCARDED if d1 else 0) | (FLAG_REMOVED if remove else 0)]
+        if has2:
+            fl.append((FLAG_DISCARDED if d2 else 0) | (FLAG_REMOVED if remove else 0))
+        return [(r[0], r[1], f) for r, f in zip(res, fl)]
+
+    def process_batch(self, reads, paired: bool):
+        out = []
+        if paired:
+            assert len(reads) % 2 == 0
+            for i in range(0, len(reads), 2):
+                out += self.process_pair(reads[i], reads[i + 1])
+        else:
+            for r in reads:
+                out += self.process_pair(r, None)
+        return out
+
+    def all_counters(self):
+        return list(self.counters) + list(self.scafReads) + list(self.scafBases)
