@@ -1,0 +1,362 @@
+"""
+Python binding over the C ABI (include/bbduk_gpu.h, include/bbduk_host.h).
+
+Names follow the reference: `BBDuk(args)` takes the bbduk.sh key=value string (bbduk/BBDukParser.java),
+`load_refs` / `build_index` play BBDukLoader.loadIndex (bbduk/BBDukLoader.java:82-103), and
+`ktrim` / `kfilter` are the batch forms of BBDukProcessorS.ktrim / countSetKmers plus the k-mer stage of
+processList (bbduk/BBDukProcessorS.java:948-1093).  There is no CPU fallback: if libbbduk_hip.so is
+missing or no GPU is visible, construction raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._build import lib_path
+
+OK = 0
+MODE_KFILTER, MODE_KTRIM_R, MODE_KTRIM_L = 0, 1, 2
+FLAG_DISCARDED, FLAG_REMOVED = 1, 2
+NCOUNTERS = 16
+COUNTER_NAMES = ["readsIn", "basesIn", "readsKTrimmed", "basesKTrimmed", "readsKFiltered", "basesKFiltered",
+                 "readsOutu", "basesOutu", "readsOutm", "basesOutm"]
+DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "data")
+
+
+class BBDukError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):          # struct bbduk_params
+    _fields_ = [("abi_version", C.c_int32), ("mode", C.c_int32), ("k", C.c_int32), ("mink", C.c_int32),
+                ("rcomp", C.c_int32), ("forbidNs", C.c_int32), ("minlen", C.c_int32), ("minlen2", C.c_int32),
+                ("middleMask", C.c_int64), ("qhdist", C.c_int32), ("qhdist2", C.c_int32),
+                ("maxBadKmers", C.c_int32), ("minReadLength", C.c_int32), ("minLenFraction", C.c_float),
+                ("removePairsIfEitherBad", C.c_int32), ("trimPad", C.c_int32), ("ktrimExclusive", C.c_int32),
+                ("restrictLeft", C.c_int32), ("restrictRight", C.c_int32), ("skipR1", C.c_int32),
+                ("skipR2", C.c_int32), ("numScaffolds", C.c_int32), ("device", C.c_int32),
+                ("reserved", C.c_int32 * 8)]
+
+
+class SynthParams(C.Structure):     # struct bbduk_synth_params
+    _fields_ = [("seed", C.c_uint64), ("read_len", C.c_int32), ("ins_min", C.c_int32), ("ins_max", C.c_int32),
+                ("adapter1_len", C.c_int32), ("adapter2_len", C.c_int32), ("adapter1", C.c_char_p),
+                ("adapter2", C.c_char_p), ("sub_rate_q32", C.c_uint32), ("n_rate_q32", C.c_uint32),
+                ("contam_frac_q32", C.c_uint32), ("contam_len", C.c_int64), ("contam", C.c_char_p)]
+
+
+# every symbol include/bbduk_gpu.h and include/bbduk_host.h declare
+GPU_SYMBOLS = ["bbduk_abi_version", "bbduk_create", "bbduk_destroy", "bbduk_last_error", "bbduk_upload_table_way",
+               "bbduk_upload_pairs", "bbduk_finalize_table", "bbduk_table_size", "bbduk_table_bytes",
+               "bbduk_table_lookup", "bbduk_ktrim_batch", "bbduk_kfilter_batch", "bbduk_ktrim_batch_device",
+               "bbduk_kfilter_batch_device", "bbduk_counters_len", "bbduk_get_counters", "bbduk_reset_counters",
+               "bbduk_synth_generate_device", "bbduk_synth_generate_host"]
+HOST_SYMBOLS = ["bbduk_host_parse", "bbduk_host_destroy", "bbduk_host_add_ref", "bbduk_host_load_fasta",
+                "bbduk_host_load_refs", "bbduk_host_build_index", "bbduk_host_index_pairs",
+                "bbduk_host_num_scaffolds", "bbduk_host_params", "bbduk_host_upload_index"]
+
+_lib = None
+
+
+def lib():
+    """Loads libbbduk_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise BBDukError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(there is no CPU fallback for this path)" % path)
+    # torch bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Import it first so that this library
+    # binds to the HIP runtime torch already loaded: one runtime per process, device pointers interchangeable.
+    import torch  # noqa: F401
+    L = C.CDLL(path)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    L.bbduk_abi_version.restype = C.c_int
+    L.bbduk_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
+    L.bbduk_destroy.argtypes = [vp]
+    L.bbduk_last_error.restype = C.c_char_p
+    L.bbduk_last_error.argtypes = [vp]
+    L.bbduk_upload_table_way.argtypes = [vp, i32, i32, vp, vp, i64, vp, vp, i64]
+    L.bbduk_upload_pairs.argtypes = [vp, vp, vp, i64]
+    L.bbduk_finalize_table.argtypes = [vp]
+    L.bbduk_table_size.restype = i64
+    L.bbduk_table_size.argtypes = [vp]
+    L.bbduk_table_bytes.restype = i64
+    L.bbduk_table_bytes.argtypes = [vp]
+    L.bbduk_table_lookup.argtypes = [vp, vp, i64, vp]
+    for f in (L.bbduk_ktrim_batch, L.bbduk_kfilter_batch):
+        f.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp]
+    for f in (L.bbduk_ktrim_batch_device, L.bbduk_kfilter_batch_device):
+        f.argtypes = [vp, vp, vp, i64, i64, i32, vp, vp, vp, vp, vp]
+    L.bbduk_counters_len.argtypes = [vp]
+    L.bbduk_get_counters.argtypes = [vp, vp, i32]
+    L.bbduk_reset_counters.argtypes = [vp]
+    L.bbduk_synth_generate_device.argtypes = [C.POINTER(SynthParams), i64, i64, vp, vp, i32, vp]
+    L.bbduk_synth_generate_host.argtypes = [C.POINTER(SynthParams), i64, i64, vp, vp]
+    L.bbduk_host_parse.argtypes = [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_int]
+    L.bbduk_host_destroy.argtypes = [vp]
+    L.bbduk_host_destroy.restype = None
+    L.bbduk_host_add_ref.argtypes = [vp, C.c_char_p, i64]
+    L.bbduk_host_load_fasta.argtypes = [vp, C.c_char_p]
+    L.bbduk_host_load_refs.argtypes = [vp, C.c_char_p]
+    L.bbduk_host_build_index.restype = i64
+    L.bbduk_host_build_index.argtypes = [vp]
+    L.bbduk_host_index_pairs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64)]
+    L.bbduk_host_num_scaffolds.argtypes = [vp]
+    L.bbduk_host_params.argtypes = [vp, i32, C.POINTER(Params)]
+    L.bbduk_host_upload_index.argtypes = [vp, vp]
+    _lib = L
+    return L
+
+
+class HostIndex:
+    """BBDukParser + BBDukLoader/BBDukIndexMod roles (C++ host mirror).  No GPU needed."""
+
+    def __init__(self, args: str):
+        self.h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = lib().bbduk_host_parse(args.encode(), C.byref(self.h), err, len(err))
+        if rc != OK:
+            raise BBDukError("bbduk_host_parse: %s" % err.value.decode())
+        self.args = args
+        self.built = False
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().bbduk_host_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_ref(self, seq: bytes):
+        if lib().bbduk_host_add_ref(self.h, seq, len(seq)) != OK:
+            raise BBDukError("bbduk_host_add_ref failed")
+
+    def load_fasta(self, path: str) -> int:
+        n = lib().bbduk_host_load_fasta(self.h, path.encode())
+        if n < 0:
+            raise BBDukError("cannot load %s" % path)
+        return n
+
+    def load_refs(self, resource_dir: str = DATA_DIR) -> int:
+        n = lib().bbduk_host_load_refs(self.h, resource_dir.encode())
+        if n < 0:
+            raise BBDukError("cannot load references named by ref=/literal=")
+        return n
+
+    def build_index(self) -> int:
+        n = lib().bbduk_host_build_index(self.h)
+        if n < 0:
+            raise BBDukError("bbduk_host_build_index failed")
+        self.built = True
+        return n
+
+    def pairs(self):
+        pk, pv, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        if lib().bbduk_host_index_pairs(self.h, C.byref(pk), C.byref(pv), C.byref(n)) != OK:
+            raise BBDukError("index not built")
+        if n.value == 0:
+            return np.empty(0, np.int64), np.empty(0, np.int32)
+        keys = np.ctypeslib.as_array(C.cast(pk, C.POINTER(C.c_int64)), (n.value,)).copy()
+        vals = np.ctypeslib.as_array(C.cast(pv, C.POINTER(C.c_int32)), (n.value,)).copy()
+        return keys, vals
+
+    @property
+    def num_scaffolds(self) -> int:
+        return lib().bbduk_host_num_scaffolds(self.h)
+
+    def params(self, device: int = 0) -> Params:
+        p = Params()
+        if lib().bbduk_host_params(self.h, device, C.byref(p)) != OK:
+            raise BBDukError("bbduk_host_params failed")
+        return p
+
+
+def pack_reads(reads):
+    """list[bytes] -> (bases uint8[], offsets int64[n+1]): the batch layout of the boundary."""
+    offsets = np.zeros(len(reads) + 1, np.int64)
+    if reads:
+        offsets[1:] = np.cumsum([len(r) for r in reads])
+    bases = np.frombuffer(b"".join(reads), dtype=np.uint8).copy() if reads else np.zeros(0, np.uint8)
+    return bases, offsets
+
+
+class BBDukGpu:
+    """Device handle: the k-mer map resident in HBM + the batch operators."""
+
+    def __init__(self, params: Params):
+        self.h = C.c_void_p()
+        self.params = params
+        rc = lib().bbduk_create(C.byref(params), C.byref(self.h))
+        if rc != OK:
+            raise BBDukError("bbduk_create failed rc=%d (no GPU visible, or unsupported parameters)" % rc)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().bbduk_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != OK:
+            raise BBDukError("%s rc=%d: %s" % (what, rc, lib().bbduk_last_error(self.h).decode()))
+
+    # ---- table
+    def upload_pairs(self, keys: np.ndarray, values: np.ndarray):
+        keys = np.ascontiguousarray(keys, np.int64); values = np.ascontiguousarray(values, np.int32)
+        self._check(lib().bbduk_upload_pairs(self.h, keys.ctypes.data, values.ctypes.data, len(keys)), "upload_pairs")
+
+    def upload_table_way(self, way, prime, keys, values, vkeys, vvals):
+        keys = np.ascontiguousarray(keys, np.int64); values = np.ascontiguousarray(values, np.int32)
+        vkeys = np.ascontiguousarray(vkeys, np.int64); vvals = np.ascontiguousarray(vvals, np.int32)
+        self._check(lib().bbduk_upload_table_way(self.h, way, prime, keys.ctypes.data, values.ctypes.data, len(keys),
+                                                 vkeys.ctypes.data if len(vkeys) else None,
+                                                 vvals.ctypes.data if len(vvals) else None, len(vkeys)),
+                    "upload_table_way")
+
+    def finalize_table(self):
+        self._check(lib().bbduk_finalize_table(self.h), "finalize_table")
+
+    @property
+    def table_size(self) -> int:
+        return lib().bbduk_table_size(self.h)
+
+    @property
+    def table_bytes(self) -> int:
+        return lib().bbduk_table_bytes(self.h)
+
+    def table_lookup(self, keys: np.ndarray) -> np.ndarray:
+        keys = np.ascontiguousarray(keys, np.int64)
+        out = np.empty(len(keys), np.int32)
+        self._check(lib().bbduk_table_lookup(self.h, keys.ctypes.data, len(keys), out.ctypes.data), "table_lookup")
+        return out
+
+    # ---- host-buffer operators
+    def _host_op(self, fn, what, bases, offsets, paired):
+        bases = np.ascontiguousarray(bases, np.uint8); offsets = np.ascontiguousarray(offsets, np.int64)
+        n = len(offsets) - 1
+        a = np.empty(n, np.int32); ids = np.empty(n, np.int32); fl = np.empty(n, np.uint8)
+        self._check(fn(self.h, bases.ctypes.data if len(bases) else None, offsets.ctypes.data, n, int(paired),
+                       a.ctypes.data, ids.ctypes.data, fl.ctypes.data), what)
+        return a, ids, fl
+
+    def ktrim_batch(self, bases, offsets, paired):
+        return self._host_op(lib().bbduk_ktrim_batch, "ktrim_batch", bases, offsets, paired)
+
+    def kfilter_batch(self, bases, offsets, paired):
+        return self._host_op(lib().bbduk_kfilter_batch, "kfilter_batch", bases, offsets, paired)
+
+    def process_batch(self, bases, offsets, paired):
+        if self.params.mode == MODE_KFILTER:
+            return self.kfilter_batch(bases, offsets, paired)
+        return self.ktrim_batch(bases, offsets, paired)
+
+    # ---- device-buffer operators (torch tensors are only carriers of HBM pointers)
+    def process_batch_device(self, d_bases, d_offsets, paired, d_a, d_id, d_fl, d_counters, stream_ptr=0):
+        n = d_offsets.numel() - 1
+        fn = lib().bbduk_kfilter_batch_device if self.params.mode == MODE_KFILTER else lib().bbduk_ktrim_batch_device
+        self._check(fn(self.h, d_bases.data_ptr(), d_offsets.data_ptr(), n, d_bases.numel(), int(paired),
+                       d_a.data_ptr(), d_id.data_ptr(), d_fl.data_ptr(), d_counters.data_ptr(), stream_ptr),
+                    "batch_device")
+
+    # ---- counters
+    @property
+    def counters_len(self) -> int:
+        return lib().bbduk_counters_len(self.h)
+
+    def counters(self) -> np.ndarray:
+        out = np.zeros(self.counters_len, np.int64)
+        self._check(lib().bbduk_get_counters(self.h, out.ctypes.data, len(out)), "get_counters")
+        return out
+
+    def reset_counters(self):
+        self._check(lib().bbduk_reset_counters(self.h), "reset_counters")
+
+
+class BBDuk:
+    """`bbduk.sh <args>` minus the file streaming: parse, load refs, build the index, hold it on the GPU."""
+
+    def __init__(self, args: str, device: int = 0, resource_dir: str = DATA_DIR, refs=None):
+        self.host = HostIndex(args)
+        if refs is not None:
+            for r in refs:
+                self.host.add_ref(r)
+        else:
+            self.host.load_refs(resource_dir)
+        self.stored_kmers = self.host.build_index()
+        self.gpu = BBDukGpu(self.host.params(device))
+        rc = lib().bbduk_host_upload_index(self.host.h, self.gpu.h)
+        self.gpu._check(rc, "upload_index")
+
+    def process_reads(self, reads, paired: bool):
+        bases, offsets = pack_reads(reads)
+        return self.gpu.process_batch(bases, offsets, paired)
+
+    def counters(self):
+        return self.gpu.counters()
+
+    def close(self):
+        self.gpu.close(); self.host.close()
+
+
+# ---- synthetic workload
+TRUSEQ_R1 = b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACATCACGATCTCGTATGCCGTCTTCTGCTTG"      # data/adapters.fa >Reverse_adapter
+TRUSEQ_R2 = b"AGATCGGAAGAGCGTCGTGTAGGGAAAGAGTGTAGATCTCGGTGGTCGCCGTATCATT"            # revcomp of >TruSeq_Universal_Adapter
+
+
+def synth_params(seed: int, read_len=150, ins_min=50, ins_max=350, adapter1=TRUSEQ_R1, adapter2=TRUSEQ_R2,
+                 sub_rate=0.005, n_rate=0.001, contam: bytes = b"", contam_frac=0.0) -> SynthParams:
+    sp = SynthParams()
+    sp.seed = seed; sp.read_len = read_len; sp.ins_min = ins_min; sp.ins_max = ins_max
+    sp.adapter1 = adapter1; sp.adapter1_len = len(adapter1)
+    sp.adapter2 = adapter2; sp.adapter2_len = len(adapter2)
+    q = lambda x: min(0xFFFFFFFF, int(round(x * 4294967296.0)))
+    sp.sub_rate_q32 = q(sub_rate); sp.n_rate_q32 = q(n_rate); sp.contam_frac_q32 = q(contam_frac)
+    sp.contam = contam if contam else None; sp.contam_len = len(contam)
+    sp._keep = (adapter1, adapter2, contam)
+    return sp
+
+
+def synth_generate_host(sp: SynthParams, first_pair: int, n_pairs: int):
+    bases = np.empty(n_pairs * 2 * sp.read_len, np.uint8)
+    offsets = np.empty(2 * n_pairs + 1, np.int64)
+    rc = lib().bbduk_synth_generate_host(C.byref(sp), first_pair, n_pairs, bases.ctypes.data, offsets.ctypes.data)
+    if rc != OK:
+        raise BBDukError("synth_generate_host rc=%d" % rc)
+    return bases, offsets
+
+
+def synth_generate_device(sp: SynthParams, first_pair: int, n_pairs: int, d_bases, d_offsets, device: int, stream_ptr=0):
+    rc = lib().bbduk_synth_generate_device(C.byref(sp), first_pair, n_pairs, d_bases.data_ptr(), d_offsets.data_ptr(),
+                                           device, stream_ptr)
+    if rc != OK:
+        raise BBDukError("synth_generate_device rc=%d" % rc)
+
+
+def read_fasta(path: str):
+    """[(name, seq bytes)] -- small helper for contaminant sequences (phiX) used by the generator."""
+    import gzip
+    op = gzip.open if path.endswith(".gz") else open
+    out, name, seq = [], None, bytearray()
+    with op(path, "rb") as f:
+        for line in f:
+            line = line.rstrip(b"\r\n")
+            if line.startswith(b">"):
+                if name is not None:
+                    out.append((name, bytes(seq)))
+                name, seq = line[1:].decode(), bytearray()
+            else:
+                seq += line
+    if name is not None:
+        out.append((name, bytes(seq)))
+    return out

@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""
+bench.py -- BBDuk k-mer matching path on MI355X.
+
+Metric (BASELINE.json): Gbases/s, BBDuk ktrim=r k=23 mink=11 hdist=1 ref=adapters on synthetic 2x150bp
+reads (configs[1]: 100 M reads = 15 Gbases per GPU, resident in HBM before the timed region).
+A "step" = one pass of the hot path (one kernel launch) over the rank's whole read set + the counter
+all-reduce.  N>1: one process per GPU (torch.distributed, backend nccl = RCCL), reads sharded (weak scaling:
+every rank owns the next 100 M reads of the counter-based synthetic stream), k-mer map replicated, no
+data-path collective.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--no-cpu-baseline]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ARGS_C2 = "ktrim=r k=23 mink=11 hdist=1 ref=adapters"
+ORACLE_C2 = dict(k=23, mink=11, hdist=1, ktrimRight=1)
+READ_LEN = 150
+ALGO_BYTES_PER_READ = READ_LEN + 8 + 8          # bases + int64 offset + (trimmed, id0)   
+HBM_PEAK_GBS = 8000.0                           # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU (pairs = reads/2)")
+    ap.add_argument("--seed", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from bbtools_amd import bbduk as B
+    from bbtools_amd import dist as D
+
+    rank, world, local = D.env_rank_world()
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = local if distributed else 0
+    torch.cuda.set_device(dev)
+    assert a.gpus == world, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run for N>1)"
+
+    n_pairs = a.reads // 2
+    n = 2 * n_pairs
+    duk = B.BBDuk(ARGS_C2, device=dev)
+    sp = B.synth_params(a.seed)
+    lo, hi = D.weak_shard(n_pairs, rank)
+
+    d_bases = torch.empty(n * READ_LEN, dtype=torch.uint8, device="cuda")
+    d_off = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    B.synth_generate_device(sp, lo, n_pairs, d_bases, d_off, dev)
+    d_a = torch.empty(n, dtype=torch.int32, device="cuda")
+    d_id = torch.empty(n, dtype=torch.int32, device="cuda")
+    d_fl = torch.empty(n, dtype=torch.uint8, device="cuda")
+    d_ctr = torch.zeros(duk.gpu.counters_len, dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(ev0=None, ev1=None):
+        d_ctr.zero_()
+        if ev0 is not None:
+            ev0.record()
+        duk.gpu.process_batch_device(d_bases, d_off, True, d_a, d_id, d_fl, d_ctr, stream)
+        if ev1 is not None:
+            ev1.record()
+        total = d_ctr.clone()
+        D.all_reduce_counters(total)             # the path's only collective: global hit/trim counters
+        return total
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        totals = step(*evs[i])
+    barrier()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(1, a.steps)
+
+    ctr = totals.cpu().numpy()
+    status = int(d_ctr[B.NCOUNTERS - 1].item())
+    total_bases = float(n) * READ_LEN * world
+    gbases = total_bases * a.steps / dt / 1e9
+    out = {
+        "metric": "Gbases/s BBDuk k=23 ktrim on 2x150bp synthetic FASTQ",
+        "value": round(gbases, 3), "unit": "Gbases/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+        "config": {"workload": "BBDuk ktrim=r k=23 mink=11 hdist=1 ref=adapters, %d synthetic 2x150bp reads per GPU "
+                               "(configs[1]), device-resident batch" % n,
+                   "args": ARGS_C2, "reads_per_gpu": n, "read_len": READ_LEN, "seed": a.seed,
+                   "table_keys": int(duk.stored_kmers), "table_bytes": int(duk.gpu.table_bytes),
+                   "parallelism": "reads sharded x%d, table replicated, 1 counter all-reduce/step" % world},
+        "counters": {k: int(v) for k, v in zip(B.COUNTER_NAMES, ctr[:10])},
+        "device_status": status,
+    }
+    algo_bytes = ALGO_BYTES_PER_READ * n
+    ach = algo_bytes / (kern_ms * 1e-3) / 1e9
+    out["roofline"] = {"bound": "hbm", "kernel": "bbduk_batch_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                       "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                       "kernel_ms": round(kern_ms, 3), "algorithmic_bytes_per_launch": algo_bytes}
+
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        # CPU baseline: the oracle (a C restatement of the reference's loops, NOT the Java reference: no JVM
+        # here) on a bounded sample of the same workload, all host cores, plus a parity check of that sample.
+        from oracle.oracle_ffi import Oracle
+        cores = os.cpu_count() or 1
+        o = Oracle(**ORACLE_C2)
+        o.load_fasta(os.path.join(ROOT, "data", "adapters.fa"))
+        hb, hoff = B.synth_generate_host(sp, lo, 100_000)
+        t = time.perf_counter(); o.process_batch(hb, hoff, True, nthreads=cores); probe = time.perf_counter() - t
+        sample_pairs = int(min(n_pairs, max(100_000, 100_000 * a.cpu_seconds / max(probe, 1e-3))))
+        hb, hoff = B.synth_generate_host(sp, lo, sample_pairs)
+        o.reset_counters()
+        t = time.perf_counter(); oa, oi, of = o.process_batch(hb, hoff, True, nthreads=cores); cpu_dt = time.perf_counter() - t
+        m = 2 * sample_pairs
+        ok = bool(np.array_equal(d_a[:m].cpu().numpy(), oa) and np.array_equal(d_id[:m].cpu().numpy(), oi)
+                  and np.array_equal(d_fl[:m].cpu().numpy(), of))
+        out["cpu_baseline"] = {"value": round(m * READ_LEN / cpu_dt / 1e9, 4), "unit": "Gbases/s", "cores": cores,
+                               "kind": "port", "sample": "first %d reads of the same synthetic workload, %.1f s, "
+                               "oracle/bbduk_oracle.c with %d pthreads (match only, no I/O)" % (m, cpu_dt, cores)}
+        out["parity_sample_ok"] = ok
+    if rank == 0:
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

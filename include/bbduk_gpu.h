@@ -1,0 +1,158 @@
+/*
+ * bbduk_gpu.h -- C ABI of the MI355X-native BBDuk k-mer matching path (libbbduk_hip.so).
+ *
+ * This is the drop-in boundary SURVEY.md §8(b) describes: the reference (BBTools v40.02, Java) has no
+ * plugin API for this path, so the boundary is introduced at *batch* granularity and follows the
+ * reference's own JNI convention (jni/BBMergeOverlapper.c:505-519, jni/jgi_BBMergeOverlapper.h:22-39):
+ * plain pointers and sizes, caller-owned buffers, an int status (0 = OK, negative = error; never throws,
+ * never aborts), no callbacks, no pointer retained past return.  The JNI shim a maintainer would add
+ * (Java_bbduk_BBDukGpu_*) is shown in INTEGRATION.md.
+ *
+ * What each entry point replaces in the reference (paths relative to /root/reference/current/):
+ *
+ *   bbduk_create            the derived constants of bbduk/BBDukParser.java:146-165,230-312 (handed over
+ *                           already derived, exactly as the Java fields hold them) and the per-thread
+ *                           processor state of bbduk/BBDukProcessorS.java:272-277.
+ *   bbduk_upload_table_way  a verbatim image of one kmer.HashArray1D way: array() (kmer/HashArray.java:672),
+ *                           values() (kmer/HashArray1D.java:407), victims().toList() (kmer/HashForest.java).
+ *   bbduk_upload_pairs      the same key->id map as a flat list (the map.LongIntMapX default of BBDukS:
+ *                           keys()/values(), map/LongIntMapX.java:589-596).
+ *   bbduk_finalize_table    BBDukIndex.setKmersLoaded: the map becomes read-only and HBM-resident.
+ *   bbduk_ktrim_batch       the ktrim(r1)/ktrim(r2) calls + the trimming branch of processList
+ *                           (bbduk/BBDukProcessorS.java:948-1033, 1806-1811, 1993-2140) for a whole batch.
+ *   bbduk_kfilter_batch     the countSetKmers calls + the filtering branch (:1035-1093, 1534-1593).
+ *   bbduk_get_counters      BBDukProcessorS.add (:300-342): readsIn ... basesOutm + scaffold counters.
+ *   *_device variants       the same operators on buffers that already live in HBM (no PCIe in the call);
+ *                           this is what a device-side ingest stage and bench.py call.
+ *
+ * Batch layout: `bases` = the reads' ASCII bases concatenated (what Read.bases holds after
+ * Read.validate), `offsets[n+1]` = int64 start of each read (offsets[n] = total bytes).  If `paired`,
+ * reads 2i and 2i+1 are mates r1,r2 (n must be even); pairnum = index&1.
+ */
+#ifndef BBDUK_GPU_H
+#define BBDUK_GPU_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BBDUK_ABI_VERSION 1
+
+/* status codes */
+#define BBDUK_OK                 0
+#define BBDUK_ERR_ARG           -1   /* bad argument / unsupported parameter combination */
+#define BBDUK_ERR_STATE         -2   /* call out of order (e.g. batch before finalize)    */
+#define BBDUK_ERR_NOMEM         -3
+#define BBDUK_ERR_DEVICE        -4   /* a HIP call failed; see bbduk_last_error           */
+#define BBDUK_ERR_READ_TOO_LONG -5   /* a read exceeds BBDUK_MAX_READ_LEN                  */
+
+#define BBDUK_MAX_READ_LEN   16384   /* per-read limit of the LDS-staged kernel (bases)     */
+
+/* operator selected at create time */
+#define BBDUK_MODE_KFILTER   0       /* countSetKmers + filtering branch */
+#define BBDUK_MODE_KTRIM_R   1       /* ktrim=r */
+#define BBDUK_MODE_KTRIM_L   2       /* ktrim=l */
+
+/* per-read output flags */
+#define BBDUK_FLAG_DISCARDED 1       /* setDiscarded(r)  (BBDukProcessorS.java:1464-1470)    */
+#define BBDUK_FLAG_REMOVED   2       /* shouldRemove(r1,r2) -> remove (:1489-1492)           */
+
+/* counter vector: [0..15] fixed slots, then scaffoldReadCounts[0..numScaffolds), then
+ * scaffoldBaseCounts[0..numScaffolds)  (BBDukProcessorS.java:300-342). */
+#define BBDUK_NCOUNTERS 16
+enum { BBDUK_READS_IN = 0, BBDUK_BASES_IN, BBDUK_READS_KTRIMMED, BBDUK_BASES_KTRIMMED,
+       BBDUK_READS_KFILTERED, BBDUK_BASES_KFILTERED, BBDUK_READS_OUTU, BBDUK_BASES_OUTU,
+       BBDUK_READS_OUTM, BBDUK_BASES_OUTM, BBDUK_CTR_STATUS = 15 /* nonzero = device-side error code */ };
+
+/* The a1 scalars of SURVEY §8a, as BBDukParser holds them AFTER its own derivations. */
+typedef struct bbduk_params {
+    int32_t abi_version;            /* BBDUK_ABI_VERSION */
+    int32_t mode;                   /* BBDUK_MODE_* */
+    int32_t k;                      /* 1..31 (BBDukParser.java:162-165) */
+    int32_t mink;                   /* useShortKmers iff 0<mink<k (:289) */
+    int32_t rcomp;                  /* :159 */
+    int32_t forbidNs;               /* forbidNs || hdist<1 (:150) */
+    int32_t minlen;                 /* k-1 (:274) */
+    int32_t minlen2;                /* (maskMiddle?(k-midMaskLen)/2:k) (:276) */
+    int64_t middleMask;             /* :303-312 (-1 when off) */
+    int32_t qhdist, qhdist2;        /* qHammingDistance, qHammingDistance2 (query-side expansion) */
+    int32_t maxBadKmers;            /* maxBadKmers0 (:1232) */
+    int32_t minReadLength;          /* :437 */
+    float   minLenFraction;         /* :439 */
+    int32_t removePairsIfEitherBad; /* :109 */
+    int32_t trimPad;                /* tp= */
+    int32_t ktrimExclusive;
+    int32_t restrictLeft, restrictRight;
+    int32_t skipR1, skipR2;
+    int32_t numScaffolds;           /* scaffoldNames.size(): ids are 1..numScaffolds-1 */
+    int32_t device;                 /* HIP device ordinal */
+    int32_t reserved[8];            /* must be zero */
+} bbduk_params;
+
+typedef struct bbduk_handle bbduk_handle;
+
+int  bbduk_abi_version(void);
+int  bbduk_create(const bbduk_params* p, bbduk_handle** out);
+int  bbduk_destroy(bbduk_handle* h);
+const char* bbduk_last_error(const bbduk_handle* h);      /* valid until the next call on h */
+
+/* ---- table: key -> scaffold id (>0).  May be called repeatedly before finalize; first writer wins. */
+int  bbduk_upload_table_way(bbduk_handle* h, int32_t way, int32_t prime,
+                            const int64_t* keys, const int32_t* values, int64_t ncells,   /* keys[i]==-1: empty */
+                            const int64_t* vkeys, const int32_t* vvals, int64_t nvictims);
+int  bbduk_upload_pairs(bbduk_handle* h, const int64_t* keys, const int32_t* values, int64_t n);
+int  bbduk_finalize_table(bbduk_handle* h);
+int64_t bbduk_table_size(const bbduk_handle* h);          /* distinct keys resident, or <0 */
+int64_t bbduk_table_bytes(const bbduk_handle* h);         /* HBM bytes held by the table image */
+/* point lookups through the device table (test hook): out_ids[i] = id or -1 */
+int  bbduk_table_lookup(bbduk_handle* h, const int64_t* keys, int64_t n, int32_t* out_ids);
+
+/* ---- host-buffer operators (PCIe inside the call; staging is the library's) */
+int  bbduk_ktrim_batch(bbduk_handle* h, const uint8_t* bases, const int64_t* offsets, int64_t n, int32_t paired,
+                       int32_t* out_trimmed /* x: bases removed by ktrim */, int32_t* out_id0 /* or -1 */,
+                       uint8_t* out_flags);
+int  bbduk_kfilter_batch(bbduk_handle* h, const uint8_t* bases, const int64_t* offsets, int64_t n, int32_t paired,
+                         int32_t* out_found /* countSetKmers return */, int32_t* out_id /* or -1 */,
+                         uint8_t* out_flags);
+
+/* ---- device-buffer operators: every pointer is HBM; d_bases must be 16-byte aligned; `stream` is a
+ * hipStream_t (NULL = default stream).  Asynchronous: returns after enqueue.  d_counters is an int64
+ * vector of bbduk_counters_len(h) that the kernel accumulates into (caller zeroes it).                 */
+int  bbduk_ktrim_batch_device(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d_offsets, int64_t n,
+                              int64_t total_bases, int32_t paired, int32_t* d_out_trimmed, int32_t* d_out_id0,
+                              uint8_t* d_out_flags, int64_t* d_counters, void* stream);
+int  bbduk_kfilter_batch_device(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d_offsets, int64_t n,
+                                int64_t total_bases, int32_t paired, int32_t* d_out_found, int32_t* d_out_id,
+                                uint8_t* d_out_flags, int64_t* d_counters, void* stream);
+
+/* ---- counters accumulated by the host-buffer operators */
+int  bbduk_counters_len(const bbduk_handle* h);           /* 16 + 2*numScaffolds */
+int  bbduk_get_counters(bbduk_handle* h, int64_t* out, int32_t n);
+int  bbduk_reset_counters(bbduk_handle* h);
+
+/* ---- deterministic synthetic read generator, device side; the bit-identical host side is
+ * bbduk_synth_generate_host.  Reads are fixed length; pair p = reads 2p, 2p+1.                        */
+typedef struct bbduk_synth_params {
+    uint64_t seed;
+    int32_t  read_len;             /* 150 */
+    int32_t  ins_min, ins_max;     /* insert size ~ U[ins_min, ins_max] */
+    int32_t  adapter1_len, adapter2_len;
+    const uint8_t* adapter1;       /* read-through sequence seen by r1 after the insert (host pointer) */
+    const uint8_t* adapter2;       /* ... by r2 */
+    uint32_t sub_rate_q32;         /* substitution probability inside adapters/contaminant, * 2^32 */
+    uint32_t n_rate_q32;           /* probability of an N at any base, * 2^32 */
+    uint32_t contam_frac_q32;      /* fraction of pairs drawn from the contaminant sequence, * 2^32 */
+    int64_t  contam_len;           /* length of contaminant sequence (0 = none) */
+    const uint8_t* contam;         /* contaminant sequence (host pointer) */
+} bbduk_synth_params;
+
+int  bbduk_synth_generate_device(const bbduk_synth_params* sp, int64_t first_pair, int64_t n_pairs,
+                                 uint8_t* d_bases, int64_t* d_offsets /* 2*n_pairs+1 */, int32_t device, void* stream);
+int  bbduk_synth_generate_host(const bbduk_synth_params* sp, int64_t first_pair, int64_t n_pairs,
+                               uint8_t* bases, int64_t* offsets);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,54 @@
+/*
+ * bbduk_host.h -- C API of the host-side mirror (bbtools_amd/csrc/bbduk_host.cpp).
+ *
+ * In the reference the host side of this path is Java and stays Java (north_star): BBDukParser derives
+ * the constants, BBDukLoader/BBDukIndexMod build the k-mer map, BBDukProcessorS.processList drives the
+ * per-read calls.  There is no JVM in this image, so the same three roles are written in C++ above the
+ * C ABI of bbduk_gpu.h, with the reference's names, argument meaning and error behaviour, so that the
+ * tests can drive the device exactly the way the Java host would:
+ *
+ *   bbduk_host_parse        bbduk/BBDukParser.java:448-874 (key=value flags) + :130-312 (derived constants)
+ *   bbduk_host_add_ref /    bbduk/BBDukLoader.java:192-356,416-494 + bbduk/BBDukIndexMod.java:289-445
+ *   bbduk_host_build_index  (reference scan, short k-mers, ref-side Hamming expansion, first id wins)
+ *   bbduk_host_params       the bbduk_params a JNI caller would fill from the BBDukParser fields
+ *
+ * This code is product code: it never touches oracle/.
+ */
+#ifndef BBDUK_HOST_H
+#define BBDUK_HOST_H
+#include <stdint.h>
+#include "bbduk_gpu.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bbduk_host bbduk_host;
+
+/* args: whitespace-separated key=value tokens as given to bbduk.sh (e.g. "ktrim=r k=23 mink=11 hdist=1").
+ * `ref=` / `literal=` are recorded but not loaded (use bbduk_host_load_refs).  Unknown keys are an error,
+ * as in the reference (BBDukParser.java:870-872).  Returns BBDUK_OK or BBDUK_ERR_ARG (message in errbuf). */
+int  bbduk_host_parse(const char* args, bbduk_host** out, char* errbuf, int errlen);
+void bbduk_host_destroy(bbduk_host* h);
+
+/* Reference sequences in file order; each gets the next scaffold id (first = 1). */
+int  bbduk_host_add_ref(bbduk_host* h, const uint8_t* seq, int64_t len);
+/* FASTA (plain, or .gz through `gzip -dc`); returns number of records added or <0. */
+int  bbduk_host_load_fasta(bbduk_host* h, const char* path);
+/* Loads everything named by ref= (keywords adapters/phix resolved inside `resource_dir`) and literal=. */
+int  bbduk_host_load_refs(bbduk_host* h, const char* resource_dir);
+
+/* Builds the key -> id map; returns the number of distinct keys (storedKmers) or <0. */
+int64_t bbduk_host_build_index(bbduk_host* h);
+int  bbduk_host_index_pairs(const bbduk_host* h, const int64_t** keys, const int32_t** values, int64_t* n);
+int  bbduk_host_num_scaffolds(const bbduk_host* h);
+
+/* Fills the boundary struct from the parsed + derived fields (device ordinal as given). */
+int  bbduk_host_params(const bbduk_host* h, int32_t device, bbduk_params* out);
+
+/* Convenience for callers that hold a device handle: upload_pairs + finalize. */
+int  bbduk_host_upload_index(const bbduk_host* h, bbduk_handle* dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,85 @@
+"""
+Generates the golden fixtures in this directory from oracle/spec.py (the string-based restatement).
+Run from the repo root:  python tests/golden/make_golden.py
+Inputs: data/adapters.fa, data/phix2.fa.gz (benchmark inputs named by BASELINE.json: ref=adapters, ref=phix)
+and reads drawn from the repo's own deterministic generator plus hand-written edge cases.  Each fixture
+stores the reads themselves, so nothing but this JSON is needed to replay it.
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path.insert(0, ROOT)
+from oracle.spec import Spec, Args  # noqa: E402
+from bbtools_amd.bbduk import synth_params, synth_generate_host, read_fasta  # noqa: E402
+
+ADAPTERS = os.path.join(ROOT, "data", "adapters.fa")
+PHIX = os.path.join(ROOT, "data", "phix2.fa.gz")
+
+
+def synth_reads(seed, n_pairs, **kw):
+    sp = synth_params(seed, **kw)
+    b, off = synth_generate_host(sp, 0, n_pairs)
+    return [bytes(b[off[i]:off[i + 1]]).decode() for i in range(2 * n_pairs)]
+
+
+def run_case(name, cli, spec_args, ref, reads, paired):
+    s = Spec(Args(**spec_args))
+    if isinstance(ref, str):
+        s.load_fasta(ref)
+        ref_desc = {"fasta": os.path.relpath(ref, ROOT)}
+    else:
+        for r in ref:
+            s.add_ref(r.encode())
+        ref_desc = {"literal": ref}
+    out = s.process_batch([r.encode() for r in reads], paired)
+    fx = {"name": name, "cli": cli, "spec_args": spec_args, "ref": ref_desc, "paired": paired, "reads": reads,
+          "expected": [list(t) for t in out], "counters": s.all_counters(), "stored_kmers": len(s.table),
+          "num_scaffolds": s.nscaf}
+    with open(os.path.join(os.path.dirname(__file__), name + ".json"), "w") as f:
+        json.dump(fx, f, indent=0)
+    hit = sum(1 for t in out if t[0])
+    print(name, "reads", len(reads), "with_hits", hit, "keys", len(s.table))
+
+
+def main():
+    phix = read_fasta(PHIX)[0][1]
+    # C1: ktrim=r k=23 hdist=0 ref=adapters
+    reads = synth_reads(1, 60, ins_min=30, ins_max=260)
+    run_case("c1_ktrimr_k23_hdist0_adapters", "ktrim=r k=23 hdist=0 ref=adapters",
+             dict(k=23, ktrimRight=True), ADAPTERS, reads, True)
+    # C2: ktrim=r k=23 mink=11 hdist=1 ref=adapters
+    reads = synth_reads(2, 60, ins_min=30, ins_max=260, sub_rate=0.02, n_rate=0.004)
+    run_case("c2_ktrimr_k23_mink11_hdist1_adapters", "ktrim=r k=23 mink=11 hdist=1 ref=adapters",
+             dict(k=23, mink=11, hdist=1, ktrimRight=True), ADAPTERS, reads, True)
+    # C3: kfilter k=31 hdist=1 ref=phix
+    reads = synth_reads(3, 60, contam=phix, contam_frac=0.3, sub_rate=0.02, n_rate=0.004)
+    run_case("c3_kfilter_k31_hdist1_phix", "k=31 hdist=1 ref=phix", dict(k=31, hdist=1), PHIX, reads, True)
+    # C4-shaped: kfilter k=31 hdist=0 (forbidNs true) against phiX, unpaired
+    reads = synth_reads(4, 40, contam=phix, contam_frac=0.3, sub_rate=0.01, n_rate=0.01)
+    run_case("c4_kfilter_k31_hdist0_phix_unpaired", "k=31 hdist=0 ref=phix", dict(k=31), PHIX, reads, False)
+    # hand-written known-answer cases
+    ad = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCACATCACGATCTCGTATGCCGTCTTCTGCTTG"
+    g = "ACGGTCAGTCCATGGACTTAGCATCAGGATACCATTGACCAGTAGGACCATAGCAGTTACGATCAGGACTTAACGGATTACAGGCATTAG"
+    kat = [
+        ad + "ACGT" * 5,                       # whole-read adapter: trimmed to 1 base -> discarded at minlength=10
+        g[:60] + ad[:40],                      # adapter read-through at 60
+        g[:80] + ad[:14],                      # only a short k-mer (14 >= mink) matches at the 3' end
+        g[:84] + ad[:10],                      # 10 < mink: no match
+        g[:50] + ad[:12] + "N" + ad[13:40],    # N inside the adapter: under hdist=1 N reads as A forward, 0 reverse
+        g,                                     # clean
+        "",                                    # empty read
+        "ACGTACGTAC",                          # shorter than mink
+        ad[:23],                               # exactly one k-mer
+        g[:5] + ad[:30],                       # adapter at position 5 -> trimmed length 5 < minlength
+    ]
+    run_case("kat_ktrimr_k23_mink11_hdist1", "ktrim=r k=23 mink=11 hdist=1 ref=adapters",
+             dict(k=23, mink=11, hdist=1, ktrimRight=True), ADAPTERS, kat, False)
+    run_case("kat_ktriml_k23_mink11", "ktrim=l k=23 mink=11 ref=adapters",
+             dict(k=23, mink=11, ktrimLeft=True), ADAPTERS,
+             [ad[-30:] + g[:60], ad[-12:] + g[:60], g, ad, g[:40] + ad[:30] + g[40:70]], False)
+
+
+if __name__ == "__main__":
+    main()

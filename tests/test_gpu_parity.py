@@ -1,0 +1,207 @@
+"""GPU parity tests (run on the MI355X box with -m gpu).  Every check goes through the C ABI
+(libbbduk_hip.so) and compares bit-for-bit with the CPU oracle on the same seeded inputs, with the
+committed golden fixtures, and -- at full workload sizes -- through size-independent properties."""
+import random
+
+import numpy as np
+import pytest
+
+from bbtools_amd import bbduk as B
+from oracle.oracle_ffi import Oracle, pack_reads
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def make_pair(args, okw, refs=None, ref_fasta=None):
+    if refs is not None:
+        d = B.BBDuk(args, refs=refs)
+        o = Oracle(**okw)
+        for r in refs:
+            o.add_ref(r)
+    else:
+        d = B.BBDuk(args)
+        o = Oracle(**okw)
+        o.load_fasta(ref_fasta)
+    assert d.stored_kmers == o.stored_kmers == d.gpu.table_size
+    return d, o
+
+
+def check_batch(d, o, reads, paired, nthreads=4):
+    b, off = pack_reads(reads)
+    d.gpu.reset_counters(); o.reset_counters()
+    ga, gi, gf = d.gpu.process_batch(b, off, paired)
+    oa, oi, of = o.process_batch(b, off, paired, nthreads=nthreads)
+    bad = np.nonzero((ga != oa) | (gi != oi) | (gf != of))[0]
+    assert len(bad) == 0, [(int(i), reads[i], (int(ga[i]), int(gi[i]), int(gf[i])), (int(oa[i]), int(oi[i]), int(of[i]))) for i in bad[:3]]
+    assert np.array_equal(d.gpu.counters(), o.counters())
+
+
+# ---- golden fixtures
+@pytest.mark.parametrize("name", util.golden_names())
+def test_golden(name):
+    fx = util.load_golden(name)
+    if "fasta" in fx["ref"]:
+        d = B.BBDuk(fx["cli"])
+    else:
+        d = B.BBDuk(fx["cli"], refs=[r.encode() for r in fx["ref"]["literal"]])
+    assert d.stored_kmers == fx["stored_kmers"]
+    b, off = pack_reads([r.encode() for r in fx["reads"]])
+    a, ids, fl = d.gpu.process_batch(b, off, fx["paired"])
+    got = [list(t) for t in zip(a.tolist(), ids.tolist(), fl.tolist())]
+    assert got == fx["expected"]
+    assert d.gpu.counters().tolist() == fx["counters"]
+
+
+# ---- table
+def test_table_lookup_and_way_images():
+    args, okw, ref = util.CONFIGS["c2"]
+    o = Oracle(**okw); o.load_fasta(ref)
+    h = B.HostIndex(args); h.load_refs(); h.build_index()
+    # the device map built from the HashArray1D images a JVM would hand over == built from the flat pairs
+    g1 = B.BBDukGpu(h.params(0))
+    for w, (prime, keys, vals, vk, vv) in enumerate(o.way_images()):
+        g1.upload_table_way(w, prime, keys, vals, vk, vv)
+    g1.finalize_table()
+    ks, vs = o.dump_pairs()
+    assert g1.table_size == len(ks)
+    rng = np.random.default_rng(3)
+    probe = np.concatenate([ks, rng.integers(0, 1 << 47, 50000, dtype=np.int64), np.array([-1, 0, 1 << 62], np.int64)])
+    got = g1.table_lookup(probe)
+    exp = np.array([o.table_get(int(x)) for x in probe], np.int32)
+    assert np.array_equal(got, exp)
+    with pytest.raises(B.BBDukError):
+        g1.finalize_table()                      # read-only after finalize
+
+
+# ---- seeded synthetic inputs, the BASELINE configs at oracle-sized n
+@pytest.mark.parametrize("cfg", list(util.CONFIGS))
+def test_synthetic_config_parity(cfg):
+    args, okw, ref = util.CONFIGS[cfg]
+    d, o = make_pair(args, okw, ref_fasta=ref)
+    kw = {}
+    if "phix" in args:
+        kw = dict(contam=B.read_fasta(util.PHIX)[0][1], contam_frac=0.05)
+    sp = B.synth_params(11, **kw)
+    b, off = B.synth_generate_host(sp, 1000, 20000)          # 40k reads
+    d.gpu.reset_counters(); o.reset_counters()
+    ga, gi, gf = d.gpu.process_batch(b, off, True)
+    oa, oi, of = o.process_batch(b, off, True, nthreads=8)
+    assert np.array_equal(ga, oa) and np.array_equal(gi, oi) and np.array_equal(gf, of)
+    assert np.array_equal(d.gpu.counters(), o.counters())
+    assert int((ga > 0).sum()) > 100                          # the workload really exercises hits
+
+
+# ---- fuzz over parameter space, ragged / empty / junk reads
+FUZZ = [("ktrim=r k=23", dict(k=23, ktrimRight=1)),
+        ("ktrim=r k=23 mink=11 hdist=1", dict(k=23, ktrimRight=1, mink=11, hdist=1)),
+        ("k=31 hdist=1", dict(k=31, hdist=1)), ("k=31", dict(k=31)),
+        ("ktrim=l k=13 mink=6 hdist=1 hdist2=0", dict(k=13, ktrimLeft=1, mink=6, hdist=1, hdist2=0)),
+        ("k=12 mm=f qhdist=1", dict(k=12, maskMiddle=0, qhdist=1)),
+        ("ktrim=r k=11 mink=5 qhdist=1 qhdist2=1 rcomp=f", dict(k=11, ktrimRight=1, mink=5, qhdist=1, qhdist2=1, rcomp=0)),
+        ("ktrim=r k=15 restrictright=40 forbidn=t hdist=1", dict(k=15, ktrimRight=1, restrictRight=40, forbidN=1, hdist=1)),
+        ("ktrim=l k=15 restrictleft=30 tp=2", dict(k=15, ktrimLeft=1, restrictLeft=30, trimPad=2)),
+        ("k=20 mbk=2 rieb=f mlf=0.5", dict(k=20, maxBadKmers0=2, requireBothBad=1, minLenFraction=0.5)),
+        ("ktrim=r k=14 ktrimexclusive=t mink=8 mlf=0.9", dict(k=14, ktrimRight=1, ktrimExclusive=1, mink=8, minLenFraction=0.9)),
+        ("k=9 hdist=2 mm=f", dict(k=9, hdist=2, maskMiddle=0)), ("ktrim=r k=16 skipr2=t", dict(k=16, ktrimRight=1, skipR2=1)),
+        ("k=10 qhdist=2 mm=f", dict(k=10, qhdist=2, maskMiddle=0)), ("k=1 mm=f", dict(k=1, maskMiddle=0)),
+        ("ktrim=l k=31 mink=1", dict(k=31, ktrimLeft=1, mink=1)), ("k=24", dict(k=24)), ("ktrim=r k=31 mink=30 tp=-3", dict(k=31, ktrimRight=1, mink=30, trimPad=-3))]
+
+
+@pytest.mark.parametrize("ci", range(len(FUZZ)))
+def test_fuzz_parity(ci):
+    args, okw = FUZZ[ci]
+    for seed in range(3):
+        rng = random.Random(100 * ci + seed)
+        refs = [util.rand_seq(rng, rng.randint(5, 90), 0.01) for _ in range(8)]
+        d, o = make_pair(args, okw, refs=refs)
+        reads = util.fuzz_reads(rng, refs, 600, [0, 1, 2, 5, 10, 11, 22, 23, 30, 31, 32, 40, 63, 64, 65, 75, 150, 151, 300], junk=True)
+        check_batch(d, o, reads, True)
+        check_batch(d, o, reads[:301], False)
+        d.close()
+
+
+def test_edge_shapes():
+    args, okw, ref = util.CONFIGS["c2"]
+    d, o = make_pair(args, okw, ref_fasta=ref)
+    ad = B.TRUSEQ_R1
+    rng = random.Random(4)
+    # empty batch, single read, all-empty reads, reads of 1..70 bases, a tile boundary (129 reads), long reads
+    check_batch(d, o, [], False)
+    check_batch(d, o, [ad], False)
+    check_batch(d, o, [b""] * 10, True)
+    check_batch(d, o, [util.rand_seq(rng, n) + ad[:n % 40] for n in range(1, 71)], True)
+    check_batch(d, o, [util.rand_seq(rng, 150)] * 129, False)
+    longs = [util.rand_seq(rng, n, 0.001) + ad for n in (1000, 5000, 9000, 16000 - len(ad))]
+    check_batch(d, o, longs, True)
+    check_batch(d, o, longs + [util.rand_seq(rng, 40) + ad[:30]] * 301, False)
+    # too long -> explicit error, not a silent wrong answer
+    b, off = pack_reads([util.rand_seq(rng, 30000)])
+    with pytest.raises(B.BBDukError):
+        d.gpu.process_batch(b, off, False)
+    # wrong operator for the mode, odd paired batch
+    b, off = pack_reads([ad, ad, ad])
+    with pytest.raises(B.BBDukError):
+        d.gpu.kfilter_batch(b, off, False)
+    with pytest.raises(B.BBDukError):
+        d.gpu.ktrim_batch(b, off, True)
+
+
+def test_generator_device_matches_host():
+    import torch
+    sp = B.synth_params(5, contam=B.read_fasta(util.PHIX)[0][1], contam_frac=0.1)
+    n_pairs = 3000
+    hb, hoff = B.synth_generate_host(sp, 123456, n_pairs)
+    db = torch.empty(n_pairs * 300, dtype=torch.uint8, device="cuda")
+    doff = torch.empty(2 * n_pairs + 1, dtype=torch.int64, device="cuda")
+    B.synth_generate_device(sp, 123456, n_pairs, db, doff, 0)
+    assert np.array_equal(db.cpu().numpy(), hb) and np.array_equal(doff.cpu().numpy(), hoff)
+
+
+def test_device_operator_and_full_size_properties():
+    """Device-resident operator at a workload the oracle cannot replay whole: (i) an oracle-checked sample,
+    (ii) size-independent properties: counters are additive over shards and equal the per-read outputs'
+    own sums; trimming is idempotent w.r.t. untouched reads; results do not depend on batch split."""
+    import torch
+    args, okw, ref = util.CONFIGS["c2"]
+    d, o = make_pair(args, okw, ref_fasta=ref)
+    sp = B.synth_params(2)
+    n_pairs = 2_000_000                                       # 4M reads, 600 Mbases
+    n = 2 * n_pairs
+    db = torch.empty(n * 150, dtype=torch.uint8, device="cuda")
+    doff = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    B.synth_generate_device(sp, 0, n_pairs, db, doff, 0)
+    da = torch.empty(n, dtype=torch.int32, device="cuda"); di = torch.empty_like(da)
+    df = torch.empty(n, dtype=torch.uint8, device="cuda")
+    dc = torch.zeros(d.gpu.counters_len, dtype=torch.int64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    d.gpu.process_batch_device(db, doff, True, da, di, df, dc, st)
+    torch.cuda.synchronize()
+    a, ids, fl, c = da.cpu().numpy(), di.cpu().numpy(), df.cpu().numpy(), dc.cpu().numpy()
+    assert c[B.NCOUNTERS - 1] == 0
+    # (i) oracle on a slice in the middle
+    s0, s1 = 1_000_000, 1_040_000
+    hb, hoff = B.synth_generate_host(sp, s0 // 2, (s1 - s0) // 2)
+    oa, oi, of = o.process_batch(hb, hoff, True, nthreads=8)
+    assert np.array_equal(a[s0:s1], oa) and np.array_equal(ids[s0:s1], oi) and np.array_equal(fl[s0:s1], of)
+    # (ii) properties
+    assert c[0] == n and c[1] == n * 150
+    removed = (fl & 2) != 0
+    assert c[6] + c[8] == n and c[8] == int(removed.sum())
+    assert np.array_equal(removed[0::2], removed[1::2])                          # mates leave together
+    newlen = 150 - a.astype(np.int64)
+    assert c[7] == int(newlen[~removed].sum()) and c[9] == int(newlen[removed].sum())
+    assert c[2] == int(((a > 0) | removed).sum())                               # readsKTrimmed
+    assert c[3] == int(a.sum() + newlen[removed].sum())                         # basesKTrimmed
+    assert np.all((ids > 0) == (a > 0))
+    nsc = d.gpu.params.numScaffolds
+    assert c[16:16 + nsc].sum() == int((a > 0).sum()) and c[16 + nsc:].sum() == 150 * int((a > 0).sum())
+    assert np.array_equal(np.bincount(ids[a > 0], minlength=nsc), c[16:16 + nsc])
+    # split invariance: two half batches give the same per-read answers and counters that add up
+    dc2 = torch.zeros_like(dc)
+    half = n // 2
+    d.gpu.process_batch_device(db[:half * 150], doff[:half + 1], True, da[:half], di[:half], df[:half], dc2, st)
+    off2 = (doff[half:] - doff[half]).contiguous()
+    d.gpu.process_batch_device(db[half * 150:], off2, True, da[half:], di[half:], df[half:], dc2, st)
+    torch.cuda.synchronize()
+    assert np.array_equal(da.cpu().numpy(), a) and np.array_equal(df.cpu().numpy(), fl) and np.array_equal(dc2.cpu().numpy(), c)

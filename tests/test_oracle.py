@@ -1,0 +1,163 @@
+"""CPU tests of the checker itself: known answers, the reference's own assertion identities, golden
+fixtures (produced by oracle/spec.py) replayed through the C oracle, and a differential fuzz between the
+two restatements.  No GPU."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle.oracle_ffi import Oracle, lib, pack_reads
+from oracle.spec import Spec, Args, rcomp_int
+from tests import util
+
+
+def enc(s):
+    v = 0
+    for ch in s:
+        v = (v << 2) | "ACGT".index(ch)
+    return v
+
+
+# ---- hand-derived known answers
+def test_kat_encode_and_rcomp():
+    assert enc("ACGT") == 27
+    assert lib().bbo_rcomp(27, 4) == 27                       # ACGT is its own reverse complement
+    assert lib().bbo_rcomp(enc("AAAC"), 4) == enc("GTTT")
+    for b, (x, x2, d) in {"A": (0, 3, 0), "C": (1, 2, 1), "G": (2, 1, 2), "T": (3, 0, 3), "U": (3, 0, 3),
+                          "a": (0, 3, 0), "t": (3, 0, 3), "u": (3, 0, 3), "N": (0, 0, -1), ".": (0, 0, -1)}.items():
+        assert lib().bbo_base_to_number0(ord(b)) == x
+        assert lib().bbo_base_to_complement_number0(ord(b)) == x2
+        assert lib().bbo_base_to_number(ord(b)) == d
+
+
+def test_kat_derived_constants():
+    o = Oracle(k=23, ktrimRight=1)                            # C1
+    assert o.constant("kmask") == 1 << 46
+    assert o.constant("middleMask") == ~(3 << 22)
+    assert (o.constant("minlen"), o.constant("minlen2"), o.constant("forbidNs")) == (22, 11, 1)
+    o = Oracle(k=23, mink=11, hdist=1, ktrimRight=1)          # C2: mink switches maskMiddle off AFTER minlen2
+    assert o.constant("middleMask") == -1
+    assert (o.constant("minlen2"), o.constant("forbidNs"), o.constant("useShortKmers")) == (11, 0, 1)
+    assert o.constant("hdist2") == 1
+    o = Oracle(k=31, hdist=1)                                 # C3
+    assert o.constant("middleMask") == ~(3 << 30)
+    assert (o.constant("minlen"), o.constant("minlen2"), o.constant("forbidNs")) == (30, 15, 0)
+    o = Oracle(k=31)                                          # C4
+    assert o.constant("forbidNs") == 1
+    o = Oracle(k=24, maskMiddle=1)                            # even k masks two bases
+    assert o.constant("midMaskLen") == 2 and o.constant("middleMask") == ~(15 << 22)
+    o = Oracle(k=23, maskMiddle=0)
+    assert o.constant("minlen2") == 23 and o.constant("middleMask") == -1
+    o = Oracle()                                              # k defaults to 27 (BBDukParser.java:163)
+    assert o.constant("k") == 27
+
+
+def test_rcomp_identities():
+    """The identities the reference asserts under -ea (BBDukProcessorS.java:1561-1568)."""
+    rng = random.Random(5)
+    for _ in range(2000):
+        k = rng.randint(1, 31)
+        v = rng.getrandbits(2 * k)
+        r = lib().bbo_rcomp(v, k)
+        assert r == rcomp_int(v, k)
+        assert lib().bbo_rcomp(r, k) == v
+
+
+def test_key_count_upper_bound():
+    """docs/guides/BBDukGuide.txt:34: at most 1+(3k)^hdist keys per reference k-mer."""
+    ref = util.rand_seq(random.Random(9), 200)
+    o0 = Oracle(k=21); o0.add_ref(ref)
+    o1 = Oracle(k=21, hdist=1); o1.add_ref(ref)
+    n0, n1 = o0.stored_kmers, o1.stored_kmers
+    assert n0 == 200 - 21 + 1
+    assert n0 < n1 <= n0 * (1 + 3 * 21)
+
+
+def test_whole_read_adapter_leaves_one_base():
+    o = Oracle(k=23, ktrimRight=1); o.load_fasta(util.ADAPTERS)
+    ad = b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACATCACGATCTCGTATGCCGTCTTCTGCTTG"
+    x, id0 = o.ktrim(ad)
+    assert (x, id0) == (len(ad) - 1, 1)                        # TrimRead clamps to one surviving base
+    b, off = pack_reads([ad])
+    a, ids, fl = o.process_batch(b, off, False)
+    assert fl[0] == 3                                          # 1 < minlength=10 -> discarded, removed
+
+
+def test_n_matches_a_under_hdist1():
+    """with hdist>=1 forbidNs is false; N encodes as A forward and 0 in the reverse k-mer."""
+    ref = b"GATTACAGATTACACCAGTAGCATCGA"          # 27 bases, k=27 -> one k-mer
+    k = len(ref)
+    read = bytearray(ref); read[5] = ord("N")      # ref[5] == 'C' -> reads as A: one substitution away
+    for kw, expect_hit in ((dict(k=k, hdist=1, maskMiddle=0, rcomp=0), True), (dict(k=k, hdist=0, maskMiddle=0, rcomp=0), False)):
+        o = Oracle(**kw); o.add_ref(ref)
+        f, _ = o.count_set_kmers(bytes(read))
+        assert (f > 0) == expect_hit
+
+
+# ---- golden fixtures through the C oracle
+@pytest.mark.parametrize("name", util.golden_names())
+def test_golden_c_oracle(name):
+    fx = util.load_golden(name)
+    o = Oracle(**util.oracle_kwargs_from_spec(fx["spec_args"]))
+    if "fasta" in fx["ref"]:
+        o.load_fasta(util.ROOT + "/" + fx["ref"]["fasta"])
+    else:
+        for r in fx["ref"]["literal"]:
+            o.add_ref(r.encode())
+    assert o.stored_kmers == fx["stored_kmers"]
+    assert o.num_scaffolds == fx["num_scaffolds"]
+    b, off = pack_reads([r.encode() for r in fx["reads"]])
+    a, ids, fl = o.process_batch(b, off, fx["paired"], nthreads=2)
+    got = [list(t) for t in zip(a.tolist(), ids.tolist(), fl.tolist())]
+    assert got == fx["expected"]
+    assert o.counters().tolist() == fx["counters"]
+
+
+# ---- differential fuzz: rolling C restatement vs string-based closed form
+FUZZ = [dict(k=23, ktrimRight=1), dict(k=23, ktrimRight=1, mink=11, hdist=1), dict(k=31, hdist=1), dict(k=31),
+        dict(k=13, ktrimLeft=1, mink=6, hdist=1, hdist2=0), dict(k=12, maskMiddle=0, qhdist=1),
+        dict(k=11, ktrimRight=1, mink=5, qhdist=1, qhdist2=1, rcomp=0),
+        dict(k=15, ktrimRight=1, restrictRight=40, forbidN=1, hdist=1), dict(k=15, ktrimLeft=1, restrictLeft=30, trimPad=2),
+        dict(k=20, maxBadKmers0=2, requireBothBad=1, minLenFraction=0.5),
+        dict(k=14, ktrimRight=1, ktrimExclusive=1, mink=8, minLenFraction=0.9), dict(k=9, hdist=2, maskMiddle=0),
+        dict(k=16, ktrimRight=1, skipR2=1), dict(k=10, qhdist=2, maskMiddle=0)]
+BOOLS = ("maskMiddle", "rcomp", "forbidN", "ktrimRight", "ktrimLeft", "requireBothBad", "ktrimExclusive", "skipR1", "skipR2")
+
+
+@pytest.mark.parametrize("ci", range(len(FUZZ)))
+def test_differential_fuzz(ci):
+    kw = FUZZ[ci]
+    for seed in range(6):
+        rng = random.Random(1000 * ci + seed)
+        refs = [util.rand_seq(rng, rng.randint(5, 80), 0.01) for _ in range(6)]
+        o = Oracle(**kw)
+        s = Spec(Args(**{k: (bool(v) if k in BOOLS else v) for k, v in kw.items()}))
+        for r in refs:
+            o.add_ref(r); s.add_ref(r)
+        ks, vs = o.dump_pairs()
+        assert dict(zip(ks.tolist(), vs.tolist())) == s.table
+        reads = util.fuzz_reads(rng, refs, 40, [0, 1, 5, 10, 11, 22, 23, 30, 31, 40, 75, 150], junk=True)
+        for paired in (True, False):
+            o.reset_counters()
+            s.counters = [0] * 16; s.scafReads = [0] * s.nscaf; s.scafBases = [0] * s.nscaf
+            b, off = pack_reads(reads)
+            a, ids, fl = o.process_batch(b, off, paired, nthreads=3)
+            assert list(zip(a.tolist(), ids.tolist(), fl.tolist())) == s.process_batch(reads, paired)
+            assert o.counters().tolist() == s.all_counters()
+
+
+def test_way_images_cover_the_map():
+    """The HashArray1D images handed across the boundary hold exactly the map (kmer/HashArray.java:672)."""
+    o = Oracle(k=23, mink=11, hdist=1, ktrimRight=1); o.load_fasta(util.ADAPTERS)
+    ks, vs = o.dump_pairs()
+    seen = {}
+    for w, (prime, keys, vals, vk, vv) in enumerate(o.way_images()):
+        assert len(keys) == prime + 60
+        m = keys >= 0
+        assert np.all(keys[m] % 7 == w)                      # key%WAYS sharding (BBDukIndexMod.java:506)
+        seen.update(zip(keys[m].tolist(), vals[m].tolist()))
+        seen.update(zip(vk.tolist(), vv.tolist()))
+    assert seen == dict(zip(ks.tolist(), vs.tolist()))
+    for key in ks[:200].tolist():
+        assert o.table_get(key) == seen[key]
+    assert o.table_get(12345) == -1
