@@ -30,13 +30,18 @@
 static_assert(sizeof(bbduk_params) == 128, "bbduk_params layout is part of the ABI");
 static_assert(sizeof(bbduk_synth_params) == 80, "bbduk_synth_params layout is part of the ABI");
 
-#define BLOCK_THREADS   256
+#define BLOCK_THREADS   1024
 #define NWAVES          (BLOCK_THREADS / 64)
-#define TILE_READS      128                    // reads per tile (even: whole pairs)
-#define CAP_BASES       33792                  // LDS plane capacity in bases (>= 2*BBDUK_MAX_READ_LEN + 32: a pair fits)
+#define TILE_READS      256                    // reads per tile (even: whole pairs)
+#define CAP_BASES       40960                  // LDS plane capacity in bases (>= 2*BBDUK_MAX_READ_LEN + 32: a pair fits)
 #define CAP_CHUNKS      (CAP_BASES / 16)
 #define EMPTY_KEY       0xFFFFFFFFFFFFFFFFULL  // keys are < 2^63
 #define HASH_MULT       0x9E3779B97F4A7C15ULL
+#define FH_C1           0x9E3779B1u            // filter hash constants (host and device must agree)
+#define FH_C2           0x85EBCA77u
+#define FH_C3           0xC2B2AE3Du
+#define FH_C4           0x27D4EB2Fu
+#define MAX_LDS_BITS    20                     // 128 KiB presence filter per workgroup
 #define BIGLOC          999999999
 
 struct KParams {
@@ -44,11 +49,20 @@ struct KParams {
     float   minLenFraction;
     int32_t rieb, trimPad, ktrimExclusive, restrictLeft, restrictRight, skipR1, skipR2, numScaffolds, useShort;
     uint64_t mask, kmask, middleMask;
-    const uint64_t* tkeys;      // open-addressed, power-of-two capacity, EMPTY_KEY = free
-    const int32_t*  tvals;
-    uint64_t capMask;
-    int32_t  hashShift;
+    // The map, device layout: 4-way buckets.  tags[b] packs four 16-bit fingerprints (0 = free way); the full
+    // key and its id live at bkeys/bvals[4*b+way] and are touched only when a fingerprint matches.  A key sits in
+    // the first bucket >= its home bucket that had a free way (bucket-granular linear probing), so a query stops
+    // at the first bucket that has a free way.  One 8-byte gather answers almost every absent k-mer.
+    const uint64_t* tags;
+    const uint64_t* bkeys;
+    const int32_t*  bvals;
+    uint32_t bucketMask;
+    int32_t  bucketBits;
     int64_t  storedKmers;
+    // presence filter in front of the map: one bit per hash slot, copied into LDS by every workgroup
+    const uint32_t* ldsImage;   // HBM copy of the LDS bitmap (2^ldsBits bits); 0 bits = absent
+    int32_t  ldsBits;
+    int32_t  dbg;               // timing experiments only (BBDUK_DBG); 0 in production
 };
 
 // --------------------------------------------------------------------------------------------------
@@ -61,26 +75,59 @@ __device__ __forceinline__ uint64_t dev_rcomp(uint64_t kmer, int len) {
     return x >> (64 - 2 * len);
 }
 
-__device__ __forceinline__ int table_get(const KParams& P, uint64_t key) {
-    uint64_t s = (key * HASH_MULT) >> P.hashShift;
-    for (;;) {
-        const uint64_t kk = P.tkeys[s];
-        if (kk == key) return P.tvals[s];
-        if (kk == EMPTY_KEY) return -1;
-        s = (s + 1) & P.capMask;
-    }
+__host__ __device__ __forceinline__ uint32_t filter_mix(uint64_t key) {
+    return ((uint32_t)key * FH_C1) ^ ((uint32_t)(key >> 32) * FH_C2);
 }
 
-// getValueInner (bbduk/BBDukIndexMod.java:492-520): canonicalise, mask middle, add length bit, probe
-__device__ __forceinline__ int get_value_inner(const KParams& P, uint64_t kmer, uint64_t rkmer, uint64_t lengthMask) {
+__host__ __device__ __forceinline__ uint32_t bucket_of(uint32_t m, int bucketBits) { return bucketBits ? (m * FH_C3) >> (32 - bucketBits) : 0u; }
+__host__ __device__ __forceinline__ uint32_t tag_of(uint32_t m) { const uint32_t t = (m * FH_C4) >> 16; return t ? t : 1u; }
+
+// 0x8000 in every 16-bit lane of v that is zero (may also flag lanes above a true zero lane: callers verify)
+__device__ __forceinline__ uint64_t zero16(uint64_t v) { return (v - 0x0001000100010001ULL) & ~v & 0x8000800080008000ULL; }
+
+// map lookup with the filter mix already computed: id (>0) or -1
+__device__ __forceinline__ int table_get_m(const KParams& P, uint64_t key, uint32_t m) {
+    uint32_t b = bucket_of(m, P.bucketBits);
+    const uint64_t pat = (uint64_t)tag_of(m) * 0x0001000100010001ULL;
+    for (;;) {
+        const uint64_t t = P.tags[b];
+        uint64_t cand = zero16(t ^ pat);
+        while (cand) {
+            const int way = (__ffsll((unsigned long long)cand) - 1) >> 4;
+            if (P.bkeys[4ULL * b + way] == key) return P.bvals[4ULL * b + way];
+            cand &= cand - 1;
+        }
+        if (zero16(t)) return -1;                 // a free way: the key cannot be further along
+        b = (b + 1) & P.bucketMask;
+    }
+}
+__device__ __forceinline__ int table_get(const KParams& P, uint64_t key) { return table_get_m(P, key, filter_mix(key)); }
+
+// key -> id through the cascade: LDS presence bit -> bucket fingerprints -> key/id.  `ok` = lane has a real query.
+__device__ __forceinline__ int probe_key(const KParams& P, const uint32_t* s_filt, uint64_t key, bool ok) {
+    const uint32_t m = filter_mix(key);
+    bool p = ok;
+    if (P.dbg == 1) return (m == 0x12345u) ? 1 : -1;
+    if (P.ldsBits) {
+        const uint32_t h1 = m >> (32 - P.ldsBits);
+        p = p && ((s_filt[h1 >> 5] >> (h1 & 31)) & 1u);
+    }
+    if (P.dbg == 2) return (p && m == 0x12345u) ? 1 : -1;
+    int id = -1;
+    if (p) id = table_get_m(P, key, m);
+    return id;
+}
+
+// getValueInner (bbduk/BBDukIndexMod.java:492-520): canonicalise, mask middle, add length bit
+__device__ __forceinline__ uint64_t make_key(const KParams& P, uint64_t kmer, uint64_t rkmer, uint64_t lengthMask) {
     const uint64_t mx = P.rcomp ? (kmer > rkmer ? kmer : rkmer) : kmer;   // values < 2^62: unsigned max == Java signed max
-    return table_get(P, (mx & P.middleMask) | lengthMask);
+    return (mx & P.middleMask) | lengthMask;
 }
 
 // getValue (bbduk/BBDukIndexMod.java:462-481): query-side Hamming expansion, same (j,i) order, first id>=1 wins
 template <int D>
 __device__ int get_value(const KParams& P, uint64_t kmer, uint64_t rkmer, uint64_t lengthMask, int len, int qh) {
-    int id = get_value_inner(P, kmer, rkmer, lengthMask);
+    int id = table_get(P, make_key(P, kmer, rkmer, lengthMask));
     if constexpr (D > 0) {
         if (id < 1 && qh > 0) {
             for (int j = 0; j < 4 && id < 1; j++) {
@@ -93,19 +140,23 @@ __device__ int get_value(const KParams& P, uint64_t kmer, uint64_t rkmer, uint64
     }
     return id;
 }
-__device__ __forceinline__ int lookup(const KParams& P, uint64_t kmer, uint64_t rkmer, uint64_t lengthMask, int len, int qh) {
-    if (qh <= 0) return get_value_inner(P, kmer, rkmer, lengthMask);
-    return get_value<2>(P, kmer, rkmer, lengthMask, len, qh);
+// index.getValue(kmer, rkmer, lengthMask, qPos, len, qHDist): filtered fast path when there is no query expansion
+__device__ __forceinline__ int lookup(const KParams& P, const uint32_t* s_filt, uint64_t kmer, uint64_t rkmer,
+                                      uint64_t lengthMask, int len, int qh, bool ok) {
+    if (qh <= 0) return probe_key(P, s_filt, make_key(P, kmer, rkmer, lengthMask), ok);
+    return ok ? get_value<2>(P, kmer, rkmer, lengthMask, len, qh) : -1;
 }
 
-// nb (1..31) 2-bit symbols starting at symbol index `idx` of a little-endian 2-bit stream
-__device__ __forceinline__ uint64_t extract2(const uint32_t* plane, int idx, int nb) {
+// symbols [idx, idx+nb) of a little-endian 2-bit stream, as a 64-bit value (caller masks)
+__device__ __forceinline__ uint64_t extract2raw(const uint32_t* plane, int idx) {
     const int bit = idx * 2, w = bit >> 5, sh = bit & 31;
     const uint32_t w0 = plane[w], w1 = plane[w + 1], w2 = plane[w + 2];
     const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);
     const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);
-    const uint64_t v = ((uint64_t)hi << 32) | lo;
-    return v & ((1ULL << (2 * nb)) - 1ULL);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t extract2(const uint32_t* plane, int idx, int nb) {   // nb in 1..31
+    return extract2raw(plane, idx) & ((1ULL << (2 * nb)) - 1ULL);
 }
 // nb (1..31) bits starting at bit index `idx` of a little-endian 1-bit stream
 __device__ __forceinline__ uint32_t extract1(const uint32_t* plane, int idx, int nb) {
@@ -136,8 +187,6 @@ __device__ __forceinline__ void encode4(uint32_t w, uint32_t& code8, uint32_t& c
     valid4 = (y | (y >> 7) | (y >> 14) | (y >> 21)) & 0xFu;
 }
 
-struct ReadResult { int a; int id; int newLen; };
-
 // shared/TrimRead.java:304-345 trimByAmount on lengths
 __device__ __forceinline__ int trim_by_amount(int len, int left, int right, int minRes, int& newLen) {
     left = max(left, 0); right = max(right, 0);
@@ -149,28 +198,47 @@ __device__ __forceinline__ int trim_by_amount(int len, int left, int right, int 
 }
 __device__ __forceinline__ int imid(int lo, int x, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
-// One read, one wave.  base0 = index of the read's first base in the tile's planes; T = 16*nchunks.
-// ktrim: bbduk/BBDukProcessorS.java:1806-1811,1993-2140.  kfilter: :1534-1593.  All outputs wave-uniform.
-__device__ ReadResult scan_read(const KParams& P, const uint32_t* s_fwd, const uint32_t* s_cmp, const uint32_t* s_nm,
-                                const int base0, const int L, const int pairnum, const int T, const int lane,
-                                int64_t* __restrict__ counters) {
-    ReadResult R; R.a = 0; R.id = -1; R.newLen = L;
-    const int k = P.k;
-    const bool kfilter = (P.mode == BBDUK_MODE_KFILTER);
-    if (P.storedKmers < 1) return R;
-    if (kfilter) { if (L < k) return R; }
-    else { if (L < max(1, P.useShort ? min(k, P.mink) : k)) return R; }
-    if ((P.skipR1 && pairnum == 0) || (P.skipR2 && pairnum == 1)) return R;
-    const int start = (P.restrictRight < 1 ? 0 : max(0, L - P.restrictRight));
-    const int stop  = (P.restrictLeft  < 1 ? L : min(L, P.restrictLeft));
+struct Planes { const uint32_t* fwd; const uint32_t* cmp; const uint32_t* nm; const uint32_t* filt; int T; };
 
-    // does [start,stop) hold an undefined base?  (only matters when forbidNs)
-    bool hasN = false;
+// Wave-uniform state of one read's scan.
+struct ReadScan {
+    int base0, L, start, stop;          // base0 = index of the read's first base in the tile planes
+    bool scan;                          // false: the reference returns 0 before scanning (too short, skipR1/2, no k-mers)
+    int found, iFirst, iLast, id0;      // main-scan result
+    int minLoc, minLocEx, maxLoc, maxLocEx;
+    int a, id, newLen;                  // operator outputs: ktrim x / countSetKmers found, id0 / exit id, r.length() after
+};
+
+__device__ __forceinline__ void read_init(const KParams& P, ReadScan& R, int base0, int L, int pairnum, bool present) {
+    R.base0 = base0; R.L = L;
+    R.found = 0; R.iFirst = BIGLOC; R.iLast = -1; R.id0 = -1;
+    R.a = 0; R.id = -1; R.newLen = L;
+    const int k = P.k;
+    bool s = present && P.storedKmers > 0;
+    if (P.mode == BBDUK_MODE_KFILTER) s = s && (L >= k);                                   // BBDukProcessorS.java:1535
+    else s = s && (L >= max(1, P.useShort ? min(k, P.mink) : k));                          // :1995
+    if ((P.skipR1 && pairnum == 0) || (P.skipR2 && pairnum == 1)) s = false;               // :1536, :1996
+    R.scan = s;
+    R.start = (P.restrictRight < 1 ? 0 : max(0, L - P.restrictRight));                     // :1808-1809, :1542-1543
+    R.stop  = (P.restrictLeft  < 1 ? L : min(L, P.restrictLeft));
+}
+
+// Main scan of one read by one wave: one lane per k-mer end position (closed form).
+// bbduk/BBDukProcessorS.java:2009-2029 (ktrim) == :1547-1591 (countSetKmers).
+__device__ __forceinline__ void main_scan(const KParams& P, const Planes& Q, ReadScan& R, const int lane) {
+    if (!R.scan) return;
+    const int k = P.k, start = R.start, stop = R.stop, base0 = R.base0;
+    const bool kfilter = (P.mode == BBDUK_MODE_KFILTER);
+    const bool exitOnFirst = (P.mode == BBDUK_MODE_KTRIM_R);     // only minLoc/id0 of the first hit are used
+    const int first = max(start, k - 1);                         // i>=minlen (minlen=k-1)
+    if (first >= stop) return;
+
+    bool hasN = false;                                           // undefined base inside [start,stop)? (forbidNs only)
     if (P.forbidNs) {
-        const int b0 = base0 + start, b1 = base0 + stop;            // bit range in the N plane
+        const int b0 = base0 + start, b1 = base0 + stop;
         uint32_t acc = 0;
-        for (int w = (b0 >> 5) + lane; w <= ((b1 - 1) >> 5) && b1 > b0; w += 64) {
-            uint32_t v = s_nm[w];
+        for (int w = (b0 >> 5) + lane; w <= ((b1 - 1) >> 5); w += 64) {
+            uint32_t v = Q.nm[w];
             const int lo = w << 5;
             if (lo < b0) v &= ~0u << (b0 - lo);
             if (lo + 32 > b1) v &= ~0u >> (lo + 32 - b1);
@@ -178,138 +246,187 @@ __device__ ReadResult scan_read(const KParams& P, const uint32_t* s_fwd, const u
         }
         hasN = __ballot(acc != 0) != 0;
     }
+    const bool plain = (start == 0) && !hasN;                    // every window is k defined-or-not bases, no reset
 
-    int found = 0, iFirst = BIGLOC, iLast = -1, id0 = -1;
-    bool kfDone = false;
-    const int first = max(start, k - 1);                            // i>=minlen (minlen=k-1)
+    int found = 0;
     for (int ib = first; ib < stop; ib += 64) {
         const int i = ib + lane;
         const bool act = i < stop;
-        const int ic = act ? i : stop - 1;                          // clamp so inactive lanes read in-bounds
-        const int lo = max(start, ic - k + 1);
-        const int nb = ic - lo + 1;                                 // bases in the window (== k unless cut by start)
-        uint64_t kmer = extract2(s_fwd, T - 1 - (base0 + ic), nb);  // base ic in bits 0-1, base lo on top
-        uint64_t rk   = extract2(s_cmp, base0 + lo, nb);            // base lo in bits 0-1
-        int len = ic - start + 1;                                   // no reset seen
-        if (hasN) {
-            const uint32_t nwin = extract1(s_nm, base0 + lo, nb);   // bit t <=> base lo+t undefined
-            if (nwin) {
-                const int msb = 31 - __clz(nwin);
-                len = nb - 1 - msb;                                 // bases after the last undefined one
-                rk &= ~0ULL << (2 * (msb + 1));                     // rkmer was reset there; kmer keeps its history
+        const int ic = act ? i : stop - 1;                       // inactive lanes read in-bounds
+        uint64_t kmer, rk;
+        bool ok = act;
+        if (plain) {
+            kmer = extract2raw(Q.fwd, Q.T - 1 - (base0 + ic)) & P.mask;     // base ic in bits 0-1, base ic-k+1 on top
+            rk   = extract2raw(Q.cmp, base0 + ic - k + 1) & P.mask;         // base ic-k+1 in bits 0-1
+        } else {
+            const int lo = max(start, ic - k + 1);
+            const int nb = ic - lo + 1;                          // bases in the window (== k unless cut by start)
+            kmer = extract2(Q.fwd, Q.T - 1 - (base0 + ic), nb);
+            rk   = extract2(Q.cmp, base0 + lo, nb);
+            int len = ic - start + 1;
+            if (hasN) {
+                const uint32_t nwin = extract1(Q.nm, base0 + lo, nb);       // bit t <=> base lo+t undefined
+                if (nwin) {
+                    const int msb = 31 - __clz(nwin);
+                    len = nb - 1 - msb;                          // bases after the last undefined one
+                    rk &= ~0ULL << (2 * (msb + 1));              // rkmer was reset there; kmer keeps its history
+                }
             }
+            rk <<= 2 * (k - nb);                                 // base j sits at 2*(k-1-(i-j))
+            ok = act && len >= P.minlen2;
         }
-        rk <<= 2 * (k - nb);                                        // base j sits at 2*(k-1-(i-j))
-        const bool ok = act && len >= P.minlen2;
-        int id = -1;
-        if (ok) id = lookup(P, kmer, rk, P.kmask, k, P.qhdist);
+        const int id = lookup(P, Q.filt, kmer, rk, P.kmask, k, P.qhdist, ok);
         const uint64_t m = __ballot(id > 0);
         if (m) {
             if (!kfilter) {
                 const int fl = __ffsll((unsigned long long)m) - 1, ll = 63 - __clzll((long long)m);
-                if (found == 0) { iFirst = ib + fl; id0 = __builtin_amdgcn_readlane(id, fl); }
-                iLast = ib + ll;
+                if (found == 0) { R.iFirst = ib + fl; R.id0 = __builtin_amdgcn_readlane(id, fl); }
+                R.iLast = ib + ll;
                 found += __popcll(m);
+                if (exitOnFirst) break;
             } else {
                 const int c = __popcll(m);
-                if (found + c > P.maxBadKmers) {                    // the (maxBadKmers+1)-th hit is in this pass
+                if (found + c > P.maxBadKmers) {                 // the (maxBadKmers+1)-th hit is in this pass
                     uint64_t mm = m;
                     for (int q = found; q < P.maxBadKmers; q++) mm &= mm - 1;
                     const int fl = __ffsll((unsigned long long)mm) - 1;
-                    id0 = __builtin_amdgcn_readlane(id, fl);
+                    R.id0 = __builtin_amdgcn_readlane(id, fl);
                     found = P.maxBadKmers + 1;
-                    kfDone = true;
-                } else found += c;
+                    R.iFirst = 0;                                // marks the early exit
+                    break;
+                }
+                found += c;
             }
         }
-        if (kfDone) break;
     }
+    R.found = found;
+}
 
-    if (kfilter) {
-        R.a = found;
-        if (kfDone) {
-            R.id = id0;
-            if (lane == 0) {
-                atomicAdd((unsigned long long*)&counters[BBDUK_NCOUNTERS + id0], 1ULL);
-                atomicAdd((unsigned long long*)&counters[BBDUK_NCOUNTERS + P.numScaffolds + id0], (unsigned long long)L);
-            }
+// Short k-mer scans of two reads in one pass: lanes 0-31 serve read A, lanes 32-63 read B, one lane per
+// length mink..  (bbduk/BBDukProcessorS.java:2034-2103).  Only reads whose main scan found nothing take part.
+__device__ __forceinline__ void short_scan_pair(const KParams& P, const Planes& Q, ReadScan& A, ReadScan& B, const int lane) {
+    const bool needA = A.scan && A.found == 0, needB = B.scan && B.found == 0;
+    if (!needA && !needB) return;
+    const int k = P.k;
+    const bool left = (P.mode == BBDUK_MODE_KTRIM_L);
+    const bool hiHalf = lane >= 32;
+    const bool need = hiHalf ? needB : needA;
+    const int base0 = hiHalf ? B.base0 : A.base0;
+    const int start = hiHalf ? B.start : A.start;
+    const int stop  = hiHalf ? B.stop : A.stop;
+    const int Ls = P.mink + (lane & 31);
+    int id = -1;
+    if (left) {
+        const int Lmax = min(k, stop) - start;                   // lengths 1..Lmax, i = start+Ls-1
+        const bool act = need && Ls <= Lmax;
+        const int Lc = act ? Ls : 1;
+        const int i = start + Lc - 1;
+        uint64_t kmer = 0, rk = 0;
+        if (act) {
+            kmer = extract2(Q.fwd, Q.T - 1 - (base0 + i), Lc) & P.mask;
+            rk   = extract2(Q.cmp, base0 + start, Lc);
         }
-        return R;
+        id = lookup(P, Q.filt, kmer, rk, 1ULL << (2 * Lc), Lc, P.qhdist2, act);
+    } else {
+        const int Lmax = (stop >= k ? k - 1 : stop);             // lengths 1..Lmax, i = stop-Ls
+        const bool act = need && Ls <= Lmax;
+        const int Lc = act ? Ls : 1;
+        uint64_t kmer = 0, rk = 0;
+        if (act) {
+            kmer = extract2(Q.fwd, Q.T - 1 - (base0 + stop - 1), Lc);            // base stop-1 in bits 0-1
+            rk   = extract2(Q.cmp, base0 + stop - Lc, Lc) & P.mask;              // base i in bits 0-1
+        }
+        id = lookup(P, Q.filt, kmer, rk, 1ULL << (2 * Lc), Lc, P.qhdist2, act);
     }
-
-    const bool ktrimLeft = (P.mode == BBDUK_MODE_KTRIM_L);
-    int minLoc = BIGLOC, minLocEx = BIGLOC, maxLoc = -1, maxLocEx = -1;
-    if (found > 0) { minLoc = iFirst - k + 1; maxLoc = iLast; minLocEx = minLoc + k; maxLocEx = maxLoc - k; }
-
-    if (P.useShort && found == 0) {                                 // :2034-2103, one lane per short length
-        if (ktrimLeft) {
-            const int Lmax = min(k, stop) - start;                  // lengths 1..Lmax, i = start+Ls-1
-            const int Ls = P.mink + lane;
-            const bool act = Ls <= Lmax;
-            const int Lc = act ? Ls : max(1, min(Lmax, 1));
-            int id = -1;
-            if (act && Lmax >= 1) {
-                const int i = start + Lc - 1;
-                const uint64_t kmer = extract2(s_fwd, T - 1 - (base0 + i), Lc);
-                const uint64_t rk   = extract2(s_cmp, base0 + start, Lc);
-                id = lookup(P, kmer, rk, 1ULL << (2 * Lc), Lc, P.qhdist2);
-            }
-            const uint64_t m = __ballot(id > 0);
-            if (m) {
-                const int fl = __ffsll((unsigned long long)m) - 1, ll = 63 - __clzll((long long)m);
-                id0 = __builtin_amdgcn_readlane(id, fl);             // first hit in scan order = shortest
-                found = __popcll(m);
-                minLoc = 0;
-                minLocEx = start + (P.mink + fl) - 1 + 1;            // min over hits of i+1
-                maxLoc = start + (P.mink + ll) - 1;                  // max over hits of i
-                maxLocEx = 0;                                        // max(-1, 0)
-            }
+    const uint64_t m = __ballot(id > 0);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint32_t mh = (uint32_t)(m >> (32 * h));
+        if (!mh) continue;
+        ReadScan& R = h ? B : A;
+        const int fl = __ffs(mh) - 1, ll = 31 - __clz(mh);
+        R.id0 = __builtin_amdgcn_readlane(id, 32 * h + fl);      // first hit in scan order = shortest length
+        R.found = __popc(mh);
+        if (left) {
+            R.minLoc = 0;
+            R.minLocEx = R.start + (P.mink + fl);                // min over hits of i+1
+            R.maxLoc = R.start + (P.mink + ll) - 1;              // max over hits of i
+            R.maxLocEx = 0;                                      // max(-1, 0)
         } else {
-            const int Lmax = (stop >= k ? k - 1 : stop);             // lengths 1..Lmax, i = stop-Ls
-            const int Ls = P.mink + lane;
-            const bool act = Ls <= Lmax;
-            int id = -1;
-            if (act) {
-                const uint64_t kmer = extract2(s_fwd, T - 1 - (base0 + stop - 1), Ls);   // base stop-1 in bits 0-1
-                const uint64_t rk   = extract2(s_cmp, base0 + stop - Ls, Ls) & P.mask;   // base i in bits 0-1
-                id = lookup(P, kmer, rk, 1ULL << (2 * Ls), Ls, P.qhdist2);
-            }
-            const uint64_t m = __ballot(id > 0);
-            if (m) {
-                const int fl = __ffsll((unsigned long long)m) - 1, ll = 63 - __clzll((long long)m);
-                id0 = __builtin_amdgcn_readlane(id, fl);             // first hit in scan order = shortest
-                found = __popcll(m);
-                minLoc = stop - (P.mink + ll);                       // last hit overwrites: longest match
-                minLocEx = L;                                        // min(BIG, bases.length)
-                maxLoc = L - 1;
-                maxLocEx = stop - (P.mink + fl) - 1;                 // max over hits of i-1
-            }
+            R.minLoc = R.stop - (P.mink + ll);                   // the last hit overwrites: longest match
+            R.minLocEx = R.L;                                    // min(BIG, bases.length)
+            R.maxLoc = R.L - 1;
+            R.maxLocEx = R.stop - (P.mink + fl) - 1;             // max over hits of i-1
         }
     }
-    if (found == 0) return R;
-    if (lane == 0) {                                                // :2111-2119
-        atomicAdd((unsigned long long*)&counters[BBDUK_NCOUNTERS + id0], 1ULL);
-        atomicAdd((unsigned long long*)&counters[BBDUK_NCOUNTERS + P.numScaffolds + id0], (unsigned long long)L);
+}
+
+// Per-wave accumulator for scaffoldReadCounts / scaffoldBaseCounts (BBDukProcessorS.java:2111-2119, 1577-1583).
+// Hits cluster on very few scaffold ids (a library has one adapter per mate), so bumping the global counters
+// once per read serialises the whole grid on two or three addresses (measured: 55 of 68 ms).  A wave keeps a
+// 4-entry cache of (id, reads, bases) in wave-uniform registers and only an evicted entry costs two atomics.
+#define SCAF_WAYS 4
+struct ScafAcc { int id[SCAF_WAYS]; int reads[SCAF_WAYS]; long long bases[SCAF_WAYS]; int next; };
+__device__ __forceinline__ void scaf_init(ScafAcc& S) {
+#pragma unroll
+    for (int w = 0; w < SCAF_WAYS; w++) { S.id[w] = -1; S.reads[w] = 0; S.bases[w] = 0; }
+    S.next = 0;
+}
+__device__ __forceinline__ void scaf_flush_way(const KParams& P, ScafAcc& S, const int w, const int lane, int64_t* __restrict__ counters) {
+    if (S.id[w] > 0 && lane == 0) {
+        atomicAdd((unsigned long long*)&counters[BBDUK_NCOUNTERS + S.id[w]], (unsigned long long)S.reads[w]);
+        atomicAdd((unsigned long long*)&counters[BBDUK_NCOUNTERS + P.numScaffolds + S.id[w]], (unsigned long long)S.bases[w]);
     }
-    if (P.trimPad != 0) {                                           // :2121-2126
+    S.id[w] = -1; S.reads[w] = 0; S.bases[w] = 0;
+}
+__device__ __forceinline__ void scaf_flush(const KParams& P, ScafAcc& S, const int lane, int64_t* __restrict__ counters) {
+#pragma unroll
+    for (int w = 0; w < SCAF_WAYS; w++) scaf_flush_way(P, S, w, lane, counters);
+}
+__device__ __forceinline__ void scaf_add(const KParams& P, ScafAcc& S, int id, int L, const int lane, int64_t* __restrict__ counters) {
+    bool done = false;
+#pragma unroll
+    for (int w = 0; w < SCAF_WAYS; w++) if (!done && S.id[w] == id) { S.reads[w]++; S.bases[w] += L; done = true; }
+    if (done) return;
+    const int v = S.next;
+    S.next = (S.next + 1) & (SCAF_WAYS - 1);
+#pragma unroll
+    for (int w = 0; w < SCAF_WAYS; w++) if (w == v) { scaf_flush_way(P, S, w, lane, counters); S.id[w] = id; S.reads[w] = 1; S.bases[w] = L; }
+}
+
+// After the scans: scaffold counters, trimPad, trimToPosition / countSetKmers return value.
+__device__ __forceinline__ void read_finish(const KParams& P, ReadScan& R, const int lane, ScafAcc& S, int64_t* __restrict__ counters) {
+    if (!R.scan) return;
+    const int L = R.L;
+    if (P.mode == BBDUK_MODE_KFILTER) {
+        R.a = R.found;
+        if (R.iFirst == 0) {                                     // early exit taken (BBDukProcessorS.java:1575-1586)
+            R.id = R.id0;
+            scaf_add(P, S, R.id0, L, lane, counters);
+        }
+        return;
+    }
+    if (R.found == 0) return;                                    // :2108
+    scaf_add(P, S, R.id0, L, lane, counters);                    // :2111-2119
+    int minLoc = R.minLoc, minLocEx = R.minLocEx, maxLoc = R.maxLoc, maxLocEx = R.maxLocEx;
+    if (P.trimPad != 0) {                                        // :2121-2126
         maxLoc = imid(0, maxLoc + P.trimPad, L);
         minLoc = imid(0, minLoc - P.trimPad, L);
         maxLocEx = imid(0, maxLocEx + P.trimPad, L);
         minLocEx = imid(0, minLocEx - P.trimPad, L);
     }
-    R.id = id0;
-    if (ktrimLeft) {   // trimToPosition(r, leftLoc, len-1, 1)  (shared/TrimRead.java:273-276)
+    R.id = R.id0;
+    if (P.mode == BBDUK_MODE_KTRIM_L) {   // trimToPosition(r, leftLoc, len-1, 1)  (shared/TrimRead.java:273-276)
         const int leftLoc = P.ktrimExclusive ? maxLocEx + 1 : maxLoc + 1;
-        R.a = trim_by_amount(L, leftLoc, L - (L - 1) - 1, 1, R.newLen);
-    } else {           // trimToPosition(r, 0, rightLoc, 1)
+        R.a = trim_by_amount(L, leftLoc, 0, 1, R.newLen);
+    } else {                              // trimToPosition(r, 0, rightLoc, 1)
         const int rightLoc = P.ktrimExclusive ? minLocEx - 1 : minLoc - 1;
         R.a = trim_by_amount(L, 0, L - rightLoc - 1, 1, R.newLen);
     }
-    return R;
 }
 
 // --------------------------------------------------------------------------------------------------
-// The batch kernel: persistent blocks walk tiles of TILE_READS reads.
+// The batch kernel: persistent workgroups (one per CU when the LDS filter is large) walk tiles of reads.
 __global__ __launch_bounds__(BLOCK_THREADS)
 void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
                         const int64_t n, const int64_t totalBases, const int paired,
@@ -323,18 +440,24 @@ void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
     __shared__ int32_t  s_id[TILE_READS];
     __shared__ uint8_t  s_fl[TILE_READS];
     __shared__ long long s_ctr[NWAVES][10];
+    extern __shared__ uint32_t s_filt[];                          // 2^ldsBits bits, copied once per workgroup
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
-    const int step = paired ? 2 : 1;
     long long c_[10];
 #pragma unroll
     for (int q = 0; q < 10; q++) c_[q] = 0;
+    ScafAcc scaf; scaf_init(scaf);
+
+    if (P.ldsBits) {
+        const int words = 1 << (P.ldsBits - 5);
+        for (int w = tid; w < words; w += BLOCK_THREADS) s_filt[w] = P.ldsImage[w];
+    }
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t r0 = tile * TILE_READS;
         const int cnt = (int)min((int64_t)TILE_READS, n - r0);
-        __syncthreads();                                            // previous tile's LDS fully consumed
+        __syncthreads();                                            // previous tile's LDS fully consumed (and filter landed)
         if (tid <= cnt) s_off[tid] = offsets[r0 + tid];
         __syncthreads();
 
@@ -348,10 +471,8 @@ void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
             if (paired) fit &= ~1;
             if (fit == 0) {                                         // read (or pair) too long for the LDS tile
                 if (tid == 0) atomicMax((unsigned long long*)&counters[BBDUK_CTR_STATUS], (unsigned long long)(-BBDUK_ERR_READ_TOO_LONG));
-                const int skip = min(step, cnt - s);
-                if (tid < skip) {
-                    s_a[s + tid] = 0; s_id[s + tid] = -1; s_fl[s + tid] = 0;
-                }
+                const int skip = min(paired ? 2 : 1, cnt - s);
+                if (tid < skip) { s_a[s + tid] = 0; s_id[s + tid] = -1; s_fl[s + tid] = 0; }
                 s += skip;
                 continue;
             }
@@ -359,7 +480,6 @@ void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
             const int64_t B0 = off_s, B1 = s_off[e];
             const int64_t A0 = B0 & ~15LL;
             const int nchunks = (int)((B1 - A0 + 15) >> 4);
-            const int T = nchunks * 16;
             // ---- stage: 16 bases per thread-iteration -> three bit-planes
             for (int c = tid; c < nchunks; c += BLOCK_THREADS) {
                 const int64_t a = A0 + 16LL * c;
@@ -395,49 +515,75 @@ void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
             if (tid == 0 && (nchunks & 1)) reinterpret_cast<uint16_t*>(s_nm)[nchunks] = 0;
             __syncthreads();
 
-            // ---- scan: one wave per read / pair
-            const int nunits = (e - s) / step;
+            // ---- scan: one wave per unit of two consecutive reads (a pair when paired)
+            Planes Q; Q.fwd = s_fwd; Q.cmp = s_cmp; Q.nm = s_nm; Q.filt = s_filt; Q.T = nchunks * 16;
+            const int nunits = (e - s + 1) >> 1;
             for (int u = wave; u < nunits; u += NWAVES) {
-                const int ra = s + u * step;
+                const int ra = s + 2 * u;
+                const bool hasB = (ra + 1) < e;
                 const int L1 = (int)(s_off[ra + 1] - s_off[ra]);
-                const ReadResult A = scan_read(P, s_fwd, s_cmp, s_nm, (int)(s_off[ra] - A0), L1, 0, T, lane, counters);
-                ReadResult Bz; Bz.a = 0; Bz.id = -1; Bz.newLen = 0;
-                int L2 = 0;
-                if (paired) {
-                    L2 = (int)(s_off[ra + 2] - s_off[ra + 1]);
-                    Bz = scan_read(P, s_fwd, s_cmp, s_nm, (int)(s_off[ra + 1] - A0), L2, 1, T, lane, counters);
+                const int L2 = hasB ? (int)(s_off[ra + 2] - s_off[ra + 1]) : 0;
+                ReadScan A, Bz;
+                read_init(P, A, (int)(s_off[ra] - A0), L1, paired ? 0 : 0, true);
+                read_init(P, Bz, hasB ? (int)(s_off[ra + 1] - A0) : 0, L2, paired ? 1 : 0, hasB);
+                if (P.dbg != 4) {
+                main_scan(P, Q, A, lane);
+                main_scan(P, Q, Bz, lane);
                 }
+                if (P.mode != BBDUK_MODE_KFILTER) {
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        ReadScan& R = h ? Bz : A;
+                        R.minLoc = BIGLOC; R.minLocEx = BIGLOC; R.maxLoc = -1; R.maxLocEx = -1;
+                        if (R.found > 0) { R.minLoc = R.iFirst - P.k + 1; R.maxLoc = R.iLast; R.minLocEx = R.minLoc + P.k; R.maxLocEx = R.maxLoc - P.k; }
+                    }
+                    if (P.useShort && P.dbg != 4 && P.dbg != 5) short_scan_pair(P, Q, A, Bz, lane);
+                }
+                read_finish(P, A, lane, scaf, counters);
+                read_finish(P, Bz, lane, scaf, counters);
+
                 // ---- pair stage (bbduk/BBDukProcessorS.java:807-818, 948-1093, 1431-1443), wave-uniform
-                const int pairCount = paired ? 2 : 1;
-                const float f1 = (float)L1 * P.minLenFraction, f2 = (float)L2 * P.minLenFraction;
-                const int minlen1 = (int)(f1 > (float)P.minReadLength ? f1 : (float)P.minReadLength);
-                const int minlen2 = (int)(f2 > (float)P.minReadLength ? f2 : (float)P.minReadLength);
-                bool d1 = false, d2 = false, remove = false;
-                c_[BBDUK_READS_IN] += pairCount; c_[BBDUK_BASES_IN] += L1 + L2;
-                if (P.storedKmers > 0) {
-                    if (P.mode != BBDUK_MODE_KFILTER) {
-                        int xsum = A.a + Bz.a, rkt = (A.a > 0) + (Bz.a > 0);
-                        d1 = A.newLen < minlen1;
-                        d2 = paired && (Bz.newLen < minlen2);
-                        if ((P.rieb && (d1 || d2)) || (d1 && (!paired || d2))) { xsum += A.newLen + Bz.newLen; rkt = pairCount; remove = true; }
-                        c_[BBDUK_BASES_KTRIMMED] += xsum; c_[BBDUK_READS_KTRIMMED] += rkt;
-                    } else {
-                        d1 = A.a > P.maxBadKmers;
-                        d2 = paired && (Bz.a > P.maxBadKmers);
-                        if ((P.rieb && (d1 || d2)) || (d1 && (!paired || d2))) {
-                            remove = true;
-                            c_[BBDUK_READS_KFILTERED] += pairCount; c_[BBDUK_BASES_KFILTERED] += L1 + L2;
+                const int nlog = paired ? 1 : (hasB ? 2 : 1);       // logical records in this unit
+#pragma unroll
+                for (int g = 0; g < 2; g++) {
+                    if (g >= nlog) break;
+                    const ReadScan& X = (g == 0) ? A : Bz;          // first mate of the record
+                    const bool two = paired;                        // record has a second mate (then X == A, mate == Bz)
+                    const int l1 = X.L, l2 = two ? Bz.L : 0;
+                    const int n1 = X.newLen, n2 = two ? Bz.newLen : 0;
+                    const int pairCount = two ? 2 : 1;
+                    const float f1 = (float)l1 * P.minLenFraction, f2 = (float)l2 * P.minLenFraction;
+                    const int minlen1 = (int)(f1 > (float)P.minReadLength ? f1 : (float)P.minReadLength);
+                    const int minlen2 = (int)(f2 > (float)P.minReadLength ? f2 : (float)P.minReadLength);
+                    bool d1 = false, d2 = false, remove = false;
+                    c_[BBDUK_READS_IN] += pairCount; c_[BBDUK_BASES_IN] += l1 + l2;
+                    if (P.storedKmers > 0) {
+                        if (P.mode != BBDUK_MODE_KFILTER) {
+                            const int x2 = two ? Bz.a : 0;
+                            int xsum = X.a + x2, rkt = (X.a > 0) + (x2 > 0);
+                            d1 = n1 < minlen1;
+                            d2 = two && (n2 < minlen2);
+                            if ((P.rieb && (d1 || d2)) || (d1 && (!two || d2))) { xsum += n1 + n2; rkt = pairCount; remove = true; }
+                            c_[BBDUK_BASES_KTRIMMED] += xsum; c_[BBDUK_READS_KTRIMMED] += rkt;
+                        } else {
+                            d1 = X.a > P.maxBadKmers;
+                            d2 = two && (Bz.a > P.maxBadKmers);
+                            if ((P.rieb && (d1 || d2)) || (d1 && (!two || d2))) {
+                                remove = true;
+                                c_[BBDUK_READS_KFILTERED] += pairCount; c_[BBDUK_BASES_KFILTERED] += l1 + l2;
+                            }
                         }
                     }
-                }
-                if (remove) { c_[BBDUK_READS_OUTM] += pairCount; c_[BBDUK_BASES_OUTM] += A.newLen + Bz.newLen; }
-                else        { c_[BBDUK_READS_OUTU] += pairCount; c_[BBDUK_BASES_OUTU] += A.newLen + Bz.newLen; }
-                if (lane == 0) {
-                    s_a[ra] = A.a; s_id[ra] = A.id;
-                    s_fl[ra] = (uint8_t)((d1 ? BBDUK_FLAG_DISCARDED : 0) | (remove ? BBDUK_FLAG_REMOVED : 0));
-                    if (paired) {
-                        s_a[ra + 1] = Bz.a; s_id[ra + 1] = Bz.id;
-                        s_fl[ra + 1] = (uint8_t)((d2 ? BBDUK_FLAG_DISCARDED : 0) | (remove ? BBDUK_FLAG_REMOVED : 0));
+                    if (remove) { c_[BBDUK_READS_OUTM] += pairCount; c_[BBDUK_BASES_OUTM] += n1 + n2; }
+                    else        { c_[BBDUK_READS_OUTU] += pairCount; c_[BBDUK_BASES_OUTU] += n1 + n2; }
+                    if (lane == 0) {
+                        const int rr = ra + g;
+                        s_a[rr] = X.a; s_id[rr] = X.id;
+                        s_fl[rr] = (uint8_t)((d1 ? BBDUK_FLAG_DISCARDED : 0) | (remove ? BBDUK_FLAG_REMOVED : 0));
+                        if (two) {
+                            s_a[rr + 1] = Bz.a; s_id[rr + 1] = Bz.id;
+                            s_fl[rr + 1] = (uint8_t)((d2 ? BBDUK_FLAG_DISCARDED : 0) | (remove ? BBDUK_FLAG_REMOVED : 0));
+                        }
                     }
                 }
             }
@@ -451,7 +597,8 @@ void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
             outFlags[r0 + tid] = s_fl[tid];
         }
     }
-    // ---- counters: per-wave registers -> LDS -> one atomic per slot per block
+    scaf_flush(P, scaf, lane, counters);
+    // ---- counters: per-wave registers -> LDS -> one atomic per slot per workgroup
     if (lane == 0) {
 #pragma unroll
         for (int q = 0; q < 10; q++) s_ctr[wave][q] = c_[q];
@@ -495,7 +642,8 @@ struct bbduk_handle {
     std::vector<int64_t> hkeys;          // staged (key,value) pairs before finalize
     std::vector<int32_t> hvals;
     int64_t nkeys = 0;
-    uint64_t* d_tkeys = nullptr; int32_t* d_tvals = nullptr; uint64_t cap = 0; int hashShift = 0;
+    uint64_t* d_tags = nullptr; uint64_t* d_bkeys = nullptr; int32_t* d_bvals = nullptr; uint64_t nbuckets = 0; int bucketBits = 0;
+    uint32_t* d_ldsImage = nullptr; int ldsBits = 0;
     // host-operator staging
     uint8_t* d_bases = nullptr; size_t cap_bases = 0;
     int64_t* d_off = nullptr;   size_t cap_reads = 0;
@@ -503,6 +651,7 @@ struct bbduk_handle {
     int64_t* d_counters = nullptr;
     hipStream_t stream = nullptr;
     int numCU = 256;
+    bool ldsAttrSet = false;
 };
 
 #define HIP_TRY(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
@@ -545,7 +694,8 @@ extern "C" int bbduk_create(const bbduk_params* p, bbduk_handle** out) {
 extern "C" int bbduk_destroy(bbduk_handle* h) {
     if (!h) return BBDUK_ERR_ARG;
     hipSetDevice(h->p.device);
-    hipFree(h->d_tkeys); hipFree(h->d_tvals); hipFree(h->d_bases); hipFree(h->d_off);
+    hipFree(h->d_tags); hipFree(h->d_bkeys); hipFree(h->d_bvals); hipFree(h->d_bases); hipFree(h->d_off);
+    hipFree(h->d_ldsImage);
     hipFree(h->d_a); hipFree(h->d_id); hipFree(h->d_fl); hipFree(h->d_counters);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -583,34 +733,70 @@ extern "C" int bbduk_finalize_table(bbduk_handle* h) {
     if (h->finalized) return fail(h, BBDUK_ERR_STATE, "table already finalized");
     HIP_TRY(h, hipSetDevice(h->p.device));
     const size_t n = h->hkeys.size();
-    uint64_t cap = 1024;
-    while (cap < 2 * (uint64_t)n + 2) cap <<= 1;                  // load factor <= 0.5
-    int bits = 0; while ((1ULL << bits) < cap) bits++;
-    std::vector<uint64_t> tk(cap, EMPTY_KEY);
-    std::vector<int32_t> tv(cap, 0);
-    const int shift = 64 - bits;
+    // 4-way fingerprint buckets, about one key per bucket on average (see KParams).
+    int bbits = 10;
+    while (bbits < 32 && (1ULL << bbits) < (uint64_t)n) bbits++;
+    if (const char* e = getenv("BBDUK_BUCKET_BITS")) { const int v = atoi(e); if (v >= 4 && v <= 32) bbits = v; }
+    const uint64_t nb = 1ULL << bbits;
+    if (4 * nb < (uint64_t)n + nb / 8) return fail(h, BBDUK_ERR_ARG, "too many keys for the bucket index");
+    std::vector<uint64_t> tg(nb, 0ULL), bk(4 * nb, EMPTY_KEY);
+    std::vector<int32_t> bv(4 * nb, 0);
+    const uint32_t bmask = (uint32_t)(nb - 1);
     int64_t distinct = 0;
     for (size_t i = 0; i < n; i++) {                              // first writer wins (HashArray.setIfNotPresent)
         const uint64_t key = (uint64_t)h->hkeys[i];
-        uint64_t s = (key * HASH_MULT) >> shift;
+        const uint32_t m = filter_mix(key);
+        const uint64_t tag = tag_of(m);
+        uint32_t b = bucket_of(m, bbits);
         for (;;) {
-            if (tk[s] == key) break;
-            if (tk[s] == EMPTY_KEY) { tk[s] = key; tv[s] = h->hvals[i]; distinct++; break; }
-            s = (s + 1) & (cap - 1);
+            bool done = false;
+            for (int w = 0; w < 4 && !done; w++) {
+                const uint64_t tw = (tg[b] >> (16 * w)) & 0xFFFFULL;
+                if (tw == 0) { tg[b] |= tag << (16 * w); bk[4ULL * b + w] = key; bv[4ULL * b + w] = h->hvals[i]; distinct++; done = true; }
+                else if (tw == tag && bk[4ULL * b + w] == key) done = true;
+            }
+            if (done) break;
+            b = (b + 1) & bmask;
         }
     }
-    HIP_TRY(h, hipMalloc(&h->d_tkeys, cap * sizeof(uint64_t)));
-    HIP_TRY(h, hipMalloc(&h->d_tvals, cap * sizeof(int32_t)));
-    HIP_TRY(h, hipMemcpy(h->d_tkeys, tk.data(), cap * sizeof(uint64_t), hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->d_tvals, tv.data(), cap * sizeof(int32_t), hipMemcpyHostToDevice));
-    h->cap = cap; h->hashShift = shift; h->nkeys = distinct;
+    HIP_TRY(h, hipMalloc(&h->d_tags, nb * sizeof(uint64_t)));
+    HIP_TRY(h, hipMalloc(&h->d_bkeys, 4 * nb * sizeof(uint64_t)));
+    HIP_TRY(h, hipMalloc(&h->d_bvals, 4 * nb * sizeof(int32_t)));
+    HIP_TRY(h, hipMemcpy(h->d_tags, tg.data(), nb * sizeof(uint64_t), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_bkeys, bk.data(), 4 * nb * sizeof(uint64_t), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_bvals, bv.data(), 4 * nb * sizeof(int32_t), hipMemcpyHostToDevice));
+    h->nbuckets = nb; h->bucketBits = bbits; h->nkeys = distinct;
+    // Presence filter in front of the map.  Most query k-mers are absent, so one bit per hash slot held in LDS
+    // (<=128 KiB per workgroup) answers most of them without leaving the CU.  Size follows the key count;
+    // BBDUK_LDS_BITS (log2 bits, 0 = off) overrides for experiments.  Huge maps (HBM-resident, SURVEY config 4)
+    // skip it: a filter that small would be all ones.
+    {
+        auto ceil_log2 = [](uint64_t x) { int b = 0; while ((1ULL << b) < x) b++; return b; };
+        int lb = 0;
+        if (distinct > 0 && distinct <= (1LL << 22)) lb = std::min(MAX_LDS_BITS, std::max(10, ceil_log2(32ULL * (uint64_t)distinct)));
+        if (const char* e = getenv("BBDUK_LDS_BITS")) { const int v = atoi(e); if (v >= 0) lb = v == 0 ? 0 : std::min(MAX_LDS_BITS, std::max(10, v)); }
+        if (lb) {
+            std::vector<uint32_t> f1((size_t)1 << (lb - 5), 0u);
+            for (uint64_t s = 0; s < 4 * nb; s++) {
+                if (bk[s] == EMPTY_KEY) continue;
+                const uint32_t h1 = filter_mix(bk[s]) >> (32 - lb);
+                f1[h1 >> 5] |= 1u << (h1 & 31);
+            }
+            HIP_TRY(h, hipMalloc(&h->d_ldsImage, f1.size() * 4));
+            HIP_TRY(h, hipMemcpy(h->d_ldsImage, f1.data(), f1.size() * 4, hipMemcpyHostToDevice));
+        }
+        h->ldsBits = lb;
+    }
     h->hkeys.clear(); h->hkeys.shrink_to_fit(); h->hvals.clear(); h->hvals.shrink_to_fit();
     h->finalized = true;
     return BBDUK_OK;
 }
 
 extern "C" int64_t bbduk_table_size(const bbduk_handle* h) { return (h && h->finalized) ? h->nkeys : -1; }
-extern "C" int64_t bbduk_table_bytes(const bbduk_handle* h) { return (h && h->finalized) ? (int64_t)(h->cap * 12) : -1; }
+extern "C" int64_t bbduk_table_bytes(const bbduk_handle* h) {
+    if (!h || !h->finalized) return -1;
+    return (int64_t)(h->nbuckets * (8 + 4 * 12)) + (h->ldsBits ? (1LL << (h->ldsBits - 3)) : 0);
+}
 
 static KParams make_kparams(const bbduk_handle* h) {
     const bbduk_params& p = h->p;
@@ -626,8 +812,10 @@ static KParams make_kparams(const bbduk_handle* h) {
     K.mask = (2 * p.k > 63) ? ~0ULL : ~(~0ULL << (2 * p.k));
     K.kmask = 1ULL << (2 * p.k);
     K.middleMask = (uint64_t)p.middleMask;
-    K.tkeys = h->d_tkeys; K.tvals = h->d_tvals; K.capMask = h->cap - 1; K.hashShift = h->hashShift;
+    K.tags = h->d_tags; K.bkeys = h->d_bkeys; K.bvals = h->d_bvals; K.bucketMask = (uint32_t)(h->nbuckets - 1); K.bucketBits = h->bucketBits;
     K.storedKmers = h->nkeys;
+    if (const char* e = getenv("BBDUK_DBG")) K.dbg = atoi(e);
+    K.ldsImage = h->d_ldsImage; K.ldsBits = h->ldsBits;
     return K;
 }
 
@@ -644,8 +832,14 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     if (((uintptr_t)d_bases & 15) != 0) return fail(h, BBDUK_ERR_ARG, "d_bases must be 16-byte aligned");
     const KParams K = make_kparams(h);
     const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
-    const int grid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU * 8);
-    hipLaunchKernelGGL(bbduk_batch_kernel, dim3(grid), dim3(BLOCK_THREADS), 0, st, K, d_bases, d_offsets, n, total_bases,
+    const size_t dynLds = h->ldsBits ? ((size_t)1 << (h->ldsBits - 3)) : 0;
+    if (!h->ldsAttrSet) {
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bbduk_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
+        h->ldsAttrSet = true;
+    }
+    const int perCU = (dynLds + 32768 <= 80 * 1024) ? 2 : 1;      // 1024-thread workgroups: at most 2 per CU
+    const int grid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU * perCU);
+    hipLaunchKernelGGL(bbduk_batch_kernel, dim3(grid), dim3(BLOCK_THREADS), dynLds, st, K, d_bases, d_offsets, n, total_bases,
                        (int)paired, d_a, d_id, d_fl, d_counters);
     HIP_TRY(h, hipGetLastError());
     return BBDUK_OK;

@@ -136,7 +136,7 @@ def test_edge_shapes():
     check_batch(d, o, longs, True)
     check_batch(d, o, longs + [util.rand_seq(rng, 40) + ad[:30]] * 301, False)
     # too long -> explicit error, not a silent wrong answer
-    b, off = pack_reads([util.rand_seq(rng, 30000)])
+    b, off = pack_reads([util.rand_seq(rng, 50000)])
     with pytest.raises(B.BBDukError):
         d.gpu.process_batch(b, off, False)
     # wrong operator for the mode, odd paired batch
