@@ -618,17 +618,20 @@ __global__ void bbduk_lookup_kernel(const KParams P, const int64_t* keys, int64_
 
 __global__ void bbduk_synth_kernel(const bb_synth_dev sp, const int64_t firstPair, const int64_t nPairs,
                                    uint8_t* __restrict__ bases, int64_t* __restrict__ offsets) {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per base
     const int64_t per = 2LL * sp.read_len;
     const int64_t total = nPairs * per;
-    if (g <= 2 * nPairs) offsets[g] = g * sp.read_len;
-    if (g >= total) return;
-    const int64_t p = g / per;
-    const int32_t rem = (int32_t)(g - p * per);
-    const int32_t mate = rem >= sp.read_len ? 1 : 0;
-    const int32_t j = rem - mate * sp.read_len;
-    const bb_pair_hdr h = bb_synth_pair_header(sp, (uint64_t)(firstPair + p));
-    bases[g] = bb_synth_read_base(sp, (uint64_t)(firstPair + p), h, mate, j);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    // grid-stride: one base per thread-iteration (a launch of > 2^31 threads is not portable)
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total || g <= 2 * nPairs; g += stride) {
+        if (g <= 2 * nPairs) offsets[g] = g * sp.read_len;
+        if (g >= total) continue;
+        const int64_t p = g / per;
+        const int32_t rem = (int32_t)(g - p * per);
+        const int32_t mate = rem >= sp.read_len ? 1 : 0;
+        const int32_t j = rem - mate * sp.read_len;
+        const bb_pair_hdr h = bb_synth_pair_header(sp, (uint64_t)(firstPair + p));
+        bases[g] = bb_synth_read_base(sp, (uint64_t)(firstPair + p), h, mate, j);
+    }
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -986,7 +989,7 @@ extern "C" int bbduk_synth_generate_device(const bbduk_synth_params* sp, int64_t
     if (ok) {
         d.adapter1 = da1; d.adapter2 = da2; d.contam = dc;
         const int64_t total = std::max<int64_t>(n_pairs * 2LL * d.read_len, 2 * n_pairs + 1);
-        const int64_t blocks = (total + 255) / 256;
+        const int64_t blocks = std::min<int64_t>((total + 255) / 256, 1 << 20);
         hipLaunchKernelGGL(bbduk_synth_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d, first_pair, n_pairs, d_bases, d_offsets);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = BBDUK_ERR_DEVICE;
     } else rc = BBDUK_ERR_DEVICE;

@@ -156,6 +156,14 @@ def test_generator_device_matches_host():
     doff = torch.empty(2 * n_pairs + 1, dtype=torch.int64, device="cuda")
     B.synth_generate_device(sp, 123456, n_pairs, db, doff, 0)
     assert np.array_equal(db.cpu().numpy(), hb) and np.array_equal(doff.cpu().numpy(), hoff)
+    # beyond 2^31 bytes (the 100 M-read workload is 15e9 bytes): check the tail of a 2.7e9-byte buffer
+    n_big = 9_000_000
+    db = torch.empty(n_big * 300, dtype=torch.uint8, device="cuda")
+    doff = torch.empty(2 * n_big + 1, dtype=torch.int64, device="cuda")
+    B.synth_generate_device(sp, 77, n_big, db, doff, 0)
+    hb, hoff = B.synth_generate_host(sp, 77 + n_big - 500, 500)
+    assert np.array_equal(db[-500 * 300:].cpu().numpy(), hb)
+    assert int(doff[-1].item()) == n_big * 300
 
 
 def test_device_operator_and_full_size_properties():
