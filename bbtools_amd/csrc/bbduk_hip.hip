@@ -36,8 +36,7 @@ static_assert(sizeof(bbduk_synth_params) == 80, "bbduk_synth_params layout is pa
 #define CAP_BASES       40960                  // LDS plane capacity in bases (>= 2*BBDUK_MAX_READ_LEN + 32: a pair fits)
 #define CAP_CHUNKS      (CAP_BASES / 16)
 #define EMPTY_KEY       0xFFFFFFFFFFFFFFFFULL  // keys are < 2^63
-#define HASH_MULT       0x9E3779B97F4A7C15ULL
-#define FH_C1           0x9E3779B1u            // filter hash constants (host and device must agree)
+#define FH_C1           0x9E3779B1u            // hash constants (host and device must agree)
 #define FH_C2           0x85EBCA77u
 #define FH_C3           0xC2B2AE3Du
 #define FH_C4           0x27D4EB2Fu
@@ -49,11 +48,11 @@ struct KParams {
     float   minLenFraction;
     int32_t rieb, trimPad, ktrimExclusive, restrictLeft, restrictRight, skipR1, skipR2, numScaffolds, useShort;
     uint64_t mask, kmask, middleMask;
-    // The map, device layout: 4-way buckets.  tags[b] packs four 16-bit fingerprints (0 = free way); the full
-    // key and its id live at bkeys/bvals[4*b+way] and are touched only when a fingerprint matches.  A key sits in
-    // the first bucket >= its home bucket that had a free way (bucket-granular linear probing), so a query stops
-    // at the first bucket that has a free way.  One 8-byte gather answers almost every absent k-mer.
-    const uint64_t* tags;
+    // The map, device layout: 4-way buckets.  tags[b] packs four 8-bit fingerprints (0 = free way); the full key
+    // and its id live at bkeys/bvals[4*b+way] and are touched only when a fingerprint matches.  A key sits in the
+    // first bucket >= its home bucket that had a free way (bucket-granular linear probing), so a query stops at
+    // the first bucket that has a free way.  One 4-byte gather answers almost every absent k-mer.
+    const uint32_t* tags;
     const uint64_t* bkeys;
     const int32_t*  bvals;
     uint32_t bucketMask;
@@ -62,7 +61,6 @@ struct KParams {
     // presence filter in front of the map: one bit per hash slot, copied into LDS by every workgroup
     const uint32_t* ldsImage;   // HBM copy of the LDS bitmap (2^ldsBits bits); 0 bits = absent
     int32_t  ldsBits;
-    int32_t  dbg;               // timing experiments only (BBDUK_DBG); 0 in production
 };
 
 // --------------------------------------------------------------------------------------------------
@@ -78,26 +76,25 @@ __device__ __forceinline__ uint64_t dev_rcomp(uint64_t kmer, int len) {
 __host__ __device__ __forceinline__ uint32_t filter_mix(uint64_t key) {
     return ((uint32_t)key * FH_C1) ^ ((uint32_t)(key >> 32) * FH_C2);
 }
+__host__ __device__ __forceinline__ uint32_t bucket_of(uint32_t m, int bucketBits) { return (m * FH_C3) >> (32 - bucketBits); }
+__host__ __device__ __forceinline__ uint32_t tag_of(uint32_t m) { const uint32_t t = (m * FH_C4) >> 24; return t ? t : 1u; }
 
-__host__ __device__ __forceinline__ uint32_t bucket_of(uint32_t m, int bucketBits) { return bucketBits ? (m * FH_C3) >> (32 - bucketBits) : 0u; }
-__host__ __device__ __forceinline__ uint32_t tag_of(uint32_t m) { const uint32_t t = (m * FH_C4) >> 16; return t ? t : 1u; }
+// 0x80 in every byte of v that is zero (may also flag bytes above a true zero byte: callers verify)
+__device__ __forceinline__ uint32_t zero8(uint32_t v) { return (v - 0x01010101u) & ~v & 0x80808080u; }
 
-// 0x8000 in every 16-bit lane of v that is zero (may also flag lanes above a true zero lane: callers verify)
-__device__ __forceinline__ uint64_t zero16(uint64_t v) { return (v - 0x0001000100010001ULL) & ~v & 0x8000800080008000ULL; }
-
-// map lookup with the filter mix already computed: id (>0) or -1
+// map lookup with the mix already computed: id (>0) or -1
 __device__ __forceinline__ int table_get_m(const KParams& P, uint64_t key, uint32_t m) {
     uint32_t b = bucket_of(m, P.bucketBits);
-    const uint64_t pat = (uint64_t)tag_of(m) * 0x0001000100010001ULL;
+    const uint32_t pat = tag_of(m) * 0x01010101u;
     for (;;) {
-        const uint64_t t = P.tags[b];
-        uint64_t cand = zero16(t ^ pat);
+        const uint32_t t = P.tags[b];
+        uint32_t cand = zero8(t ^ pat);
         while (cand) {
-            const int way = (__ffsll((unsigned long long)cand) - 1) >> 4;
+            const int way = (__ffs(cand) - 1) >> 3;
             if (P.bkeys[4ULL * b + way] == key) return P.bvals[4ULL * b + way];
             cand &= cand - 1;
         }
-        if (zero16(t)) return -1;                 // a free way: the key cannot be further along
+        if (zero8(t)) return -1;                  // a free way: the key cannot be further along
         b = (b + 1) & P.bucketMask;
     }
 }
@@ -107,27 +104,27 @@ __device__ __forceinline__ int table_get(const KParams& P, uint64_t key) { retur
 __device__ __forceinline__ int probe_key(const KParams& P, const uint32_t* s_filt, uint64_t key, bool ok) {
     const uint32_t m = filter_mix(key);
     bool p = ok;
-    if (P.dbg == 1) return (m == 0x12345u) ? 1 : -1;
     if (P.ldsBits) {
         const uint32_t h1 = m >> (32 - P.ldsBits);
         p = p && ((s_filt[h1 >> 5] >> (h1 & 31)) & 1u);
     }
-    if (P.dbg == 2) return (p && m == 0x12345u) ? 1 : -1;
     int id = -1;
     if (p) id = table_get_m(P, key, m);
     return id;
 }
 
 // getValueInner (bbduk/BBDukIndexMod.java:492-520): canonicalise, mask middle, add length bit
+template <bool GENERAL>
 __device__ __forceinline__ uint64_t make_key(const KParams& P, uint64_t kmer, uint64_t rkmer, uint64_t lengthMask) {
-    const uint64_t mx = P.rcomp ? (kmer > rkmer ? kmer : rkmer) : kmer;   // values < 2^62: unsigned max == Java signed max
+    // values < 2^62: unsigned max == Java's signed Tools.max
+    const uint64_t mx = (!GENERAL || P.rcomp) ? (kmer > rkmer ? kmer : rkmer) : kmer;
     return (mx & P.middleMask) | lengthMask;
 }
 
 // getValue (bbduk/BBDukIndexMod.java:462-481): query-side Hamming expansion, same (j,i) order, first id>=1 wins
 template <int D>
 __device__ int get_value(const KParams& P, uint64_t kmer, uint64_t rkmer, uint64_t lengthMask, int len, int qh) {
-    int id = table_get(P, make_key(P, kmer, rkmer, lengthMask));
+    int id = table_get(P, make_key<true>(P, kmer, rkmer, lengthMask));
     if constexpr (D > 0) {
         if (id < 1 && qh > 0) {
             for (int j = 0; j < 4 && id < 1; j++) {
@@ -140,19 +137,25 @@ __device__ int get_value(const KParams& P, uint64_t kmer, uint64_t rkmer, uint64
     }
     return id;
 }
+__device__ __noinline__ int get_value_expand(const KParams& P, uint64_t kmer, uint64_t rkmer, uint64_t lengthMask, int len, int qh) {
+    return get_value<2>(P, kmer, rkmer, lengthMask, len, qh);
+}
 // index.getValue(kmer, rkmer, lengthMask, qPos, len, qHDist): filtered fast path when there is no query expansion
+template <bool GENERAL>
 __device__ __forceinline__ int lookup(const KParams& P, const uint32_t* s_filt, uint64_t kmer, uint64_t rkmer,
                                       uint64_t lengthMask, int len, int qh, bool ok) {
-    if (qh <= 0) return probe_key(P, s_filt, make_key(P, kmer, rkmer, lengthMask), ok);
-    return ok ? get_value<2>(P, kmer, rkmer, lengthMask, len, qh) : -1;
+    if constexpr (GENERAL) {
+        if (qh > 0) return ok ? get_value_expand(P, kmer, rkmer, lengthMask, len, qh) : -1;
+    }
+    return probe_key(P, s_filt, make_key<GENERAL>(P, kmer, rkmer, lengthMask), ok);
 }
 
-// symbols [idx, idx+nb) of a little-endian 2-bit stream, as a 64-bit value (caller masks)
+// symbols [idx, idx+32) of a little-endian 2-bit stream, as a 64-bit value (caller masks)
 __device__ __forceinline__ uint64_t extract2raw(const uint32_t* plane, int idx) {
-    const int bit = idx * 2, w = bit >> 5, sh = bit & 31;
+    const int bit = idx * 2, w = bit >> 5;
     const uint32_t w0 = plane[w], w1 = plane[w + 1], w2 = plane[w + 2];
-    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);
-    const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, bit);      // the shift uses bit[4:0] only
+    const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, bit);
     return ((uint64_t)hi << 32) | lo;
 }
 __device__ __forceinline__ uint64_t extract2(const uint32_t* plane, int idx, int nb) {   // nb in 1..31
@@ -160,8 +163,8 @@ __device__ __forceinline__ uint64_t extract2(const uint32_t* plane, int idx, int
 }
 // nb (1..31) bits starting at bit index `idx` of a little-endian 1-bit stream
 __device__ __forceinline__ uint32_t extract1(const uint32_t* plane, int idx, int nb) {
-    const int w = idx >> 5, sh = idx & 31;
-    const uint32_t v = __builtin_amdgcn_alignbit(plane[w + 1], plane[w], sh);
+    const int w = idx >> 5;
+    const uint32_t v = __builtin_amdgcn_alignbit(plane[w + 1], plane[w], idx);
     return v & ((1u << nb) - 1u);
 }
 
@@ -197,10 +200,11 @@ __device__ __forceinline__ int trim_by_amount(int len, int left, int right, int 
     return left + right;
 }
 __device__ __forceinline__ int imid(int lo, int x, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }   // value known wave-uniform -> SGPR
 
 struct Planes { const uint32_t* fwd; const uint32_t* cmp; const uint32_t* nm; const uint32_t* filt; int T; };
 
-// Wave-uniform state of one read's scan.
+// Wave-uniform state of one read's scan (all fields live in SGPRs).
 struct ReadScan {
     int base0, L, start, stop;          // base0 = index of the read's first base in the tile planes
     bool scan;                          // false: the reference returns 0 before scanning (too short, skipR1/2, no k-mers)
@@ -209,32 +213,36 @@ struct ReadScan {
     int a, id, newLen;                  // operator outputs: ktrim x / countSetKmers found, id0 / exit id, r.length() after
 };
 
+template <int MODE, bool SHORT, bool GENERAL>
 __device__ __forceinline__ void read_init(const KParams& P, ReadScan& R, int base0, int L, int pairnum, bool present) {
     R.base0 = base0; R.L = L;
     R.found = 0; R.iFirst = BIGLOC; R.iLast = -1; R.id0 = -1;
+    R.minLoc = BIGLOC; R.minLocEx = BIGLOC; R.maxLoc = -1; R.maxLocEx = -1;
     R.a = 0; R.id = -1; R.newLen = L;
     const int k = P.k;
     bool s = present && P.storedKmers > 0;
-    if (P.mode == BBDUK_MODE_KFILTER) s = s && (L >= k);                                   // BBDukProcessorS.java:1535
-    else s = s && (L >= max(1, P.useShort ? min(k, P.mink) : k));                          // :1995
-    if ((P.skipR1 && pairnum == 0) || (P.skipR2 && pairnum == 1)) s = false;               // :1536, :1996
+    if (MODE == BBDUK_MODE_KFILTER) s = s && (L >= k);                                     // BBDukProcessorS.java:1535
+    else s = s && (L >= max(1, (SHORT && P.useShort) ? min(k, P.mink) : k));               // :1995
+    R.start = 0; R.stop = L;
+    if constexpr (GENERAL) {
+        if ((P.skipR1 && pairnum == 0) || (P.skipR2 && pairnum == 1)) s = false;           // :1536, :1996
+        R.start = (P.restrictRight < 1 ? 0 : max(0, L - P.restrictRight));                 // :1808-1809, :1542-1543
+        R.stop  = (P.restrictLeft  < 1 ? L : min(L, P.restrictLeft));
+    }
     R.scan = s;
-    R.start = (P.restrictRight < 1 ? 0 : max(0, L - P.restrictRight));                     // :1808-1809, :1542-1543
-    R.stop  = (P.restrictLeft  < 1 ? L : min(L, P.restrictLeft));
 }
 
 // Main scan of one read by one wave: one lane per k-mer end position (closed form).
 // bbduk/BBDukProcessorS.java:2009-2029 (ktrim) == :1547-1591 (countSetKmers).
+template <int MODE, bool FORBIDN, bool GENERAL>
 __device__ __forceinline__ void main_scan(const KParams& P, const Planes& Q, ReadScan& R, const int lane) {
     if (!R.scan) return;
     const int k = P.k, start = R.start, stop = R.stop, base0 = R.base0;
-    const bool kfilter = (P.mode == BBDUK_MODE_KFILTER);
-    const bool exitOnFirst = (P.mode == BBDUK_MODE_KTRIM_R);     // only minLoc/id0 of the first hit are used
     const int first = max(start, k - 1);                         // i>=minlen (minlen=k-1)
     if (first >= stop) return;
 
     bool hasN = false;                                           // undefined base inside [start,stop)? (forbidNs only)
-    if (P.forbidNs) {
+    if (FORBIDN && P.forbidNs) {
         const int b0 = base0 + start, b1 = base0 + stop;
         uint32_t acc = 0;
         for (int w = (b0 >> 5) + lane; w <= ((b1 - 1) >> 5); w += 64) {
@@ -246,9 +254,11 @@ __device__ __forceinline__ void main_scan(const KParams& P, const Planes& Q, Rea
         }
         hasN = __ballot(acc != 0) != 0;
     }
-    const bool plain = (start == 0) && !hasN;                    // every window is k defined-or-not bases, no reset
+    const bool plain = (!GENERAL || start == 0) && !hasN;        // every window holds k bases and no reset
 
     int found = 0;
+    const int fbase = Q.T - 1 - base0;                           // forward (reversed) plane: symbol index of base i is fbase - i
+    const int cbase = base0 - k + 1;                             // complement plane: window of base i starts at cbase + i
     for (int ib = first; ib < stop; ib += 64) {
         const int i = ib + lane;
         const bool act = i < stop;
@@ -256,12 +266,12 @@ __device__ __forceinline__ void main_scan(const KParams& P, const Planes& Q, Rea
         uint64_t kmer, rk;
         bool ok = act;
         if (plain) {
-            kmer = extract2raw(Q.fwd, Q.T - 1 - (base0 + ic)) & P.mask;     // base ic in bits 0-1, base ic-k+1 on top
-            rk   = extract2raw(Q.cmp, base0 + ic - k + 1) & P.mask;         // base ic-k+1 in bits 0-1
+            kmer = extract2raw(Q.fwd, fbase - ic) & P.mask;      // base ic in bits 0-1, base ic-k+1 on top
+            rk   = extract2raw(Q.cmp, cbase + ic) & P.mask;      // base ic-k+1 in bits 0-1
         } else {
             const int lo = max(start, ic - k + 1);
             const int nb = ic - lo + 1;                          // bases in the window (== k unless cut by start)
-            kmer = extract2(Q.fwd, Q.T - 1 - (base0 + ic), nb);
+            kmer = extract2(Q.fwd, fbase - ic, nb);
             rk   = extract2(Q.cmp, base0 + lo, nb);
             int len = ic - start + 1;
             if (hasN) {
@@ -275,15 +285,15 @@ __device__ __forceinline__ void main_scan(const KParams& P, const Planes& Q, Rea
             rk <<= 2 * (k - nb);                                 // base j sits at 2*(k-1-(i-j))
             ok = act && len >= P.minlen2;
         }
-        const int id = lookup(P, Q.filt, kmer, rk, P.kmask, k, P.qhdist, ok);
+        const int id = lookup<GENERAL>(P, Q.filt, kmer, rk, P.kmask, k, P.qhdist, ok);
         const uint64_t m = __ballot(id > 0);
         if (m) {
-            if (!kfilter) {
+            if (MODE != BBDUK_MODE_KFILTER) {
                 const int fl = __ffsll((unsigned long long)m) - 1, ll = 63 - __clzll((long long)m);
                 if (found == 0) { R.iFirst = ib + fl; R.id0 = __builtin_amdgcn_readlane(id, fl); }
                 R.iLast = ib + ll;
                 found += __popcll(m);
-                if (exitOnFirst) break;
+                if (MODE == BBDUK_MODE_KTRIM_R) break;           // only minLoc/id0 of the first hit are used
             } else {
                 const int c = __popcll(m);
                 if (found + c > P.maxBadKmers) {                 // the (maxBadKmers+1)-th hit is in this pass
@@ -300,15 +310,18 @@ __device__ __forceinline__ void main_scan(const KParams& P, const Planes& Q, Rea
         }
     }
     R.found = found;
+    if (MODE != BBDUK_MODE_KFILTER && found > 0) {
+        R.minLoc = R.iFirst - k + 1; R.maxLoc = R.iLast; R.minLocEx = R.minLoc + k; R.maxLocEx = R.maxLoc - k;
+    }
 }
 
 // Short k-mer scans of two reads in one pass: lanes 0-31 serve read A, lanes 32-63 read B, one lane per
 // length mink..  (bbduk/BBDukProcessorS.java:2034-2103).  Only reads whose main scan found nothing take part.
+template <int MODE, bool GENERAL>
 __device__ __forceinline__ void short_scan_pair(const KParams& P, const Planes& Q, ReadScan& A, ReadScan& B, const int lane) {
     const bool needA = A.scan && A.found == 0, needB = B.scan && B.found == 0;
     if (!needA && !needB) return;
     const int k = P.k;
-    const bool left = (P.mode == BBDUK_MODE_KTRIM_L);
     const bool hiHalf = lane >= 32;
     const bool need = hiHalf ? needB : needA;
     const int base0 = hiHalf ? B.base0 : A.base0;
@@ -316,17 +329,16 @@ __device__ __forceinline__ void short_scan_pair(const KParams& P, const Planes& 
     const int stop  = hiHalf ? B.stop : A.stop;
     const int Ls = P.mink + (lane & 31);
     int id = -1;
-    if (left) {
+    if (MODE == BBDUK_MODE_KTRIM_L) {
         const int Lmax = min(k, stop) - start;                   // lengths 1..Lmax, i = start+Ls-1
         const bool act = need && Ls <= Lmax;
         const int Lc = act ? Ls : 1;
-        const int i = start + Lc - 1;
         uint64_t kmer = 0, rk = 0;
         if (act) {
-            kmer = extract2(Q.fwd, Q.T - 1 - (base0 + i), Lc) & P.mask;
+            kmer = extract2(Q.fwd, Q.T - 1 - (base0 + start + Lc - 1), Lc) & P.mask;
             rk   = extract2(Q.cmp, base0 + start, Lc);
         }
-        id = lookup(P, Q.filt, kmer, rk, 1ULL << (2 * Lc), Lc, P.qhdist2, act);
+        id = lookup<GENERAL>(P, Q.filt, kmer, rk, 1ULL << (2 * Lc), Lc, P.qhdist2, act);
     } else {
         const int Lmax = (stop >= k ? k - 1 : stop);             // lengths 1..Lmax, i = stop-Ls
         const bool act = need && Ls <= Lmax;
@@ -336,7 +348,7 @@ __device__ __forceinline__ void short_scan_pair(const KParams& P, const Planes& 
             kmer = extract2(Q.fwd, Q.T - 1 - (base0 + stop - 1), Lc);            // base stop-1 in bits 0-1
             rk   = extract2(Q.cmp, base0 + stop - Lc, Lc) & P.mask;              // base i in bits 0-1
         }
-        id = lookup(P, Q.filt, kmer, rk, 1ULL << (2 * Lc), Lc, P.qhdist2, act);
+        id = lookup<GENERAL>(P, Q.filt, kmer, rk, 1ULL << (2 * Lc), Lc, P.qhdist2, act);
     }
     const uint64_t m = __ballot(id > 0);
 #pragma unroll
@@ -347,7 +359,7 @@ __device__ __forceinline__ void short_scan_pair(const KParams& P, const Planes& 
         const int fl = __ffs(mh) - 1, ll = 31 - __clz(mh);
         R.id0 = __builtin_amdgcn_readlane(id, 32 * h + fl);      // first hit in scan order = shortest length
         R.found = __popc(mh);
-        if (left) {
+        if (MODE == BBDUK_MODE_KTRIM_L) {
             R.minLoc = 0;
             R.minLocEx = R.start + (P.mink + fl);                // min over hits of i+1
             R.maxLoc = R.start + (P.mink + ll) - 1;              // max over hits of i
@@ -395,10 +407,11 @@ __device__ __forceinline__ void scaf_add(const KParams& P, ScafAcc& S, int id, i
 }
 
 // After the scans: scaffold counters, trimPad, trimToPosition / countSetKmers return value.
+template <int MODE>
 __device__ __forceinline__ void read_finish(const KParams& P, ReadScan& R, const int lane, ScafAcc& S, int64_t* __restrict__ counters) {
     if (!R.scan) return;
     const int L = R.L;
-    if (P.mode == BBDUK_MODE_KFILTER) {
+    if (MODE == BBDUK_MODE_KFILTER) {
         R.a = R.found;
         if (R.iFirst == 0) {                                     // early exit taken (BBDukProcessorS.java:1575-1586)
             R.id = R.id0;
@@ -416,7 +429,7 @@ __device__ __forceinline__ void read_finish(const KParams& P, ReadScan& R, const
         minLocEx = imid(0, minLocEx - P.trimPad, L);
     }
     R.id = R.id0;
-    if (P.mode == BBDUK_MODE_KTRIM_L) {   // trimToPosition(r, leftLoc, len-1, 1)  (shared/TrimRead.java:273-276)
+    if (MODE == BBDUK_MODE_KTRIM_L) {     // trimToPosition(r, leftLoc, len-1, 1)  (shared/TrimRead.java:273-276)
         const int leftLoc = P.ktrimExclusive ? maxLocEx + 1 : maxLoc + 1;
         R.a = trim_by_amount(L, leftLoc, 0, 1, R.newLen);
     } else {                              // trimToPosition(r, 0, rightLoc, 1)
@@ -425,8 +438,43 @@ __device__ __forceinline__ void read_finish(const KParams& P, ReadScan& R, const
     }
 }
 
+// One logical record (a pair, or a single read): discard / remove decision and the additive counters.
+// bbduk/BBDukProcessorS.java:807-818, 948-1093, 1431-1443, 1464-1493.  acc[0]=readsKTrimmed acc[1]=basesKTrimmed
+// acc[2]=readsOutm acc[3]=basesOutm; the other counters follow from these and readsIn/basesIn (see kernel end).
+template <int MODE>
+__device__ __forceinline__ void record_stage(const KParams& P, const ReadScan& X, const ReadScan* Y, int* acc, uint8_t& f1, uint8_t& f2) {
+    const bool two = (Y != nullptr);
+    const int l1 = X.L, l2 = two ? Y->L : 0;
+    const int n1 = X.newLen, n2 = two ? Y->newLen : 0;
+    const int pairCount = two ? 2 : 1;
+    const float g1 = (float)l1 * P.minLenFraction, g2 = (float)l2 * P.minLenFraction;
+    const int minlen1 = (int)(g1 > (float)P.minReadLength ? g1 : (float)P.minReadLength);
+    const int minlen2 = (int)(g2 > (float)P.minReadLength ? g2 : (float)P.minReadLength);
+    bool d1 = false, d2 = false, remove = false;
+    if (P.storedKmers > 0) {
+        if (MODE != BBDUK_MODE_KFILTER) {
+            const int x2 = two ? Y->a : 0;
+            int xsum = X.a + x2, rkt = (X.a > 0) + (x2 > 0);
+            d1 = n1 < minlen1;
+            d2 = two && (n2 < minlen2);
+            if ((P.rieb && (d1 || d2)) || (d1 && (!two || d2))) { xsum += n1 + n2; rkt = pairCount; remove = true; }
+            acc[0] += rkt; acc[1] += xsum;
+        } else {
+            d1 = X.a > P.maxBadKmers;
+            d2 = two && (Y->a > P.maxBadKmers);
+            if ((P.rieb && (d1 || d2)) || (d1 && (!two || d2))) remove = true;
+        }
+    }
+    if (remove) { acc[2] += pairCount; acc[3] += n1 + n2; }
+    f1 = (uint8_t)((d1 ? BBDUK_FLAG_DISCARDED : 0) | (remove ? BBDUK_FLAG_REMOVED : 0));
+    f2 = (uint8_t)((d2 ? BBDUK_FLAG_DISCARDED : 0) | (remove ? BBDUK_FLAG_REMOVED : 0));
+}
+
 // --------------------------------------------------------------------------------------------------
 // The batch kernel: persistent workgroups (one per CU when the LDS filter is large) walk tiles of reads.
+// Template flags strip what a configuration cannot need: SHORT (mink), FORBIDN (undefined-base resets),
+// GENERAL (qhdist, restrictleft/right, skipr1/2, rcomp=f).
+template <int MODE, bool SHORT, bool FORBIDN, bool GENERAL>
 __global__ __launch_bounds__(BLOCK_THREADS)
 void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
                         const int64_t n, const int64_t totalBases, const int paired,
@@ -439,16 +487,14 @@ void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
     __shared__ int32_t  s_a[TILE_READS];
     __shared__ int32_t  s_id[TILE_READS];
     __shared__ uint8_t  s_fl[TILE_READS];
-    __shared__ long long s_ctr[NWAVES][10];
+    __shared__ unsigned long long s_acc[6];                       // rkt, basesKTrimmed, readsOutm, basesOutm, readsIn, basesIn
     extern __shared__ uint32_t s_filt[];                          // 2^ldsBits bits, copied once per workgroup
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
-    long long c_[10];
-#pragma unroll
-    for (int q = 0; q < 10; q++) c_[q] = 0;
     ScafAcc scaf; scaf_init(scaf);
 
+    if (tid < 6) s_acc[tid] = 0;
     if (P.ldsBits) {
         const int words = 1 << (P.ldsBits - 5);
         for (int w = tid; w < words; w += BLOCK_THREADS) s_filt[w] = P.ldsImage[w];
@@ -460,6 +506,8 @@ void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
         __syncthreads();                                            // previous tile's LDS fully consumed (and filter landed)
         if (tid <= cnt) s_off[tid] = offsets[r0 + tid];
         __syncthreads();
+        if (tid == 0) { s_acc[4] += (unsigned long long)cnt; s_acc[5] += (unsigned long long)(s_off[cnt] - s_off[0]); }
+        int acc[4] = {0, 0, 0, 0};
 
         int s = 0;
         while (s < cnt) {
@@ -467,7 +515,7 @@ void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
             const int64_t off_s = s_off[s];
             const int cand = s + 1 + tid;
             const int okc = (cand <= cnt) && (s_off[min(cand, cnt)] - off_s <= (int64_t)(CAP_BASES - 32));
-            int fit = __syncthreads_count(okc);
+            int fit = uni(__syncthreads_count(okc));
             if (paired) fit &= ~1;
             if (fit == 0) {                                         // read (or pair) too long for the LDS tile
                 if (tid == 0) atomicMax((unsigned long long*)&counters[BBDUK_CTR_STATUS], (unsigned long long)(-BBDUK_ERR_READ_TOO_LONG));
@@ -485,7 +533,8 @@ void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
                 const int64_t a = A0 + 16LL * c;
                 uint32_t w[4];
                 if (a + 16 <= totalBases) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(bases + a);
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(bases + a));   // streamed once: keep it out of L2's way
                     w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
                 } else {
 #pragma unroll
@@ -518,97 +567,84 @@ void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
             // ---- scan: one wave per unit of two consecutive reads (a pair when paired)
             Planes Q; Q.fwd = s_fwd; Q.cmp = s_cmp; Q.nm = s_nm; Q.filt = s_filt; Q.T = nchunks * 16;
             const int nunits = (e - s + 1) >> 1;
+            const int a0lo = (int)(A0 - s_off[0]);                  // tile-relative origin of the planes (fits int)
             for (int u = wave; u < nunits; u += NWAVES) {
                 const int ra = s + 2 * u;
                 const bool hasB = (ra + 1) < e;
-                const int L1 = (int)(s_off[ra + 1] - s_off[ra]);
-                const int L2 = hasB ? (int)(s_off[ra + 2] - s_off[ra + 1]) : 0;
+                const int o0 = uni((int)(s_off[ra] - s_off[0]));
+                const int o1 = uni((int)(s_off[ra + 1] - s_off[0]));
+                const int o2 = hasB ? uni((int)(s_off[ra + 2] - s_off[0])) : o1;
                 ReadScan A, Bz;
-                read_init(P, A, (int)(s_off[ra] - A0), L1, paired ? 0 : 0, true);
-                read_init(P, Bz, hasB ? (int)(s_off[ra + 1] - A0) : 0, L2, paired ? 1 : 0, hasB);
-                if (P.dbg != 4) {
-                main_scan(P, Q, A, lane);
-                main_scan(P, Q, Bz, lane);
+                read_init<MODE, SHORT, GENERAL>(P, A, o0 - a0lo, o1 - o0, 0, true);
+                read_init<MODE, SHORT, GENERAL>(P, Bz, o1 - a0lo, o2 - o1, paired ? 1 : 0, hasB);
+                main_scan<MODE, FORBIDN, GENERAL>(P, Q, A, lane);
+                main_scan<MODE, FORBIDN, GENERAL>(P, Q, Bz, lane);
+                if constexpr (MODE != BBDUK_MODE_KFILTER && SHORT) {
+                    if (P.useShort) short_scan_pair<MODE, GENERAL>(P, Q, A, Bz, lane);
                 }
-                if (P.mode != BBDUK_MODE_KFILTER) {
-#pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        ReadScan& R = h ? Bz : A;
-                        R.minLoc = BIGLOC; R.minLocEx = BIGLOC; R.maxLoc = -1; R.maxLocEx = -1;
-                        if (R.found > 0) { R.minLoc = R.iFirst - P.k + 1; R.maxLoc = R.iLast; R.minLocEx = R.minLoc + P.k; R.maxLocEx = R.maxLoc - P.k; }
-                    }
-                    if (P.useShort && P.dbg != 4 && P.dbg != 5) short_scan_pair(P, Q, A, Bz, lane);
+                read_finish<MODE>(P, A, lane, scaf, counters);
+                read_finish<MODE>(P, Bz, lane, scaf, counters);
+                uint8_t f1 = 0, f2 = 0, f3 = 0, f4 = 0;
+                if (paired) record_stage<MODE>(P, A, &Bz, acc, f1, f2);
+                else {
+                    record_stage<MODE>(P, A, nullptr, acc, f1, f3);
+                    if (hasB) record_stage<MODE>(P, Bz, nullptr, acc, f2, f4);
                 }
-                read_finish(P, A, lane, scaf, counters);
-                read_finish(P, Bz, lane, scaf, counters);
-
-                // ---- pair stage (bbduk/BBDukProcessorS.java:807-818, 948-1093, 1431-1443), wave-uniform
-                const int nlog = paired ? 1 : (hasB ? 2 : 1);       // logical records in this unit
-#pragma unroll
-                for (int g = 0; g < 2; g++) {
-                    if (g >= nlog) break;
-                    const ReadScan& X = (g == 0) ? A : Bz;          // first mate of the record
-                    const bool two = paired;                        // record has a second mate (then X == A, mate == Bz)
-                    const int l1 = X.L, l2 = two ? Bz.L : 0;
-                    const int n1 = X.newLen, n2 = two ? Bz.newLen : 0;
-                    const int pairCount = two ? 2 : 1;
-                    const float f1 = (float)l1 * P.minLenFraction, f2 = (float)l2 * P.minLenFraction;
-                    const int minlen1 = (int)(f1 > (float)P.minReadLength ? f1 : (float)P.minReadLength);
-                    const int minlen2 = (int)(f2 > (float)P.minReadLength ? f2 : (float)P.minReadLength);
-                    bool d1 = false, d2 = false, remove = false;
-                    c_[BBDUK_READS_IN] += pairCount; c_[BBDUK_BASES_IN] += l1 + l2;
-                    if (P.storedKmers > 0) {
-                        if (P.mode != BBDUK_MODE_KFILTER) {
-                            const int x2 = two ? Bz.a : 0;
-                            int xsum = X.a + x2, rkt = (X.a > 0) + (x2 > 0);
-                            d1 = n1 < minlen1;
-                            d2 = two && (n2 < minlen2);
-                            if ((P.rieb && (d1 || d2)) || (d1 && (!two || d2))) { xsum += n1 + n2; rkt = pairCount; remove = true; }
-                            c_[BBDUK_BASES_KTRIMMED] += xsum; c_[BBDUK_READS_KTRIMMED] += rkt;
-                        } else {
-                            d1 = X.a > P.maxBadKmers;
-                            d2 = two && (Bz.a > P.maxBadKmers);
-                            if ((P.rieb && (d1 || d2)) || (d1 && (!two || d2))) {
-                                remove = true;
-                                c_[BBDUK_READS_KFILTERED] += pairCount; c_[BBDUK_BASES_KFILTERED] += l1 + l2;
-                            }
-                        }
-                    }
-                    if (remove) { c_[BBDUK_READS_OUTM] += pairCount; c_[BBDUK_BASES_OUTM] += n1 + n2; }
-                    else        { c_[BBDUK_READS_OUTU] += pairCount; c_[BBDUK_BASES_OUTU] += n1 + n2; }
-                    if (lane == 0) {
-                        const int rr = ra + g;
-                        s_a[rr] = X.a; s_id[rr] = X.id;
-                        s_fl[rr] = (uint8_t)((d1 ? BBDUK_FLAG_DISCARDED : 0) | (remove ? BBDUK_FLAG_REMOVED : 0));
-                        if (two) {
-                            s_a[rr + 1] = Bz.a; s_id[rr + 1] = Bz.id;
-                            s_fl[rr + 1] = (uint8_t)((d2 ? BBDUK_FLAG_DISCARDED : 0) | (remove ? BBDUK_FLAG_REMOVED : 0));
-                        }
-                    }
+                if (lane == 0) {
+                    s_a[ra] = A.a; s_id[ra] = A.id; s_fl[ra] = f1;
+                    if (hasB) { s_a[ra + 1] = Bz.a; s_id[ra + 1] = Bz.id; s_fl[ra + 1] = f2; }
                 }
             }
             __syncthreads();
             s = e;
         }
-        // ---- coalesced write-back of the tile's results
+        // ---- coalesced write-back of the tile's results; per-wave partial sums -> LDS
         if (tid < cnt) {
             outA[r0 + tid] = s_a[tid];
             outId[r0 + tid] = s_id[tid];
             outFlags[r0 + tid] = s_fl[tid];
         }
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (acc[q]) atomicAdd(&s_acc[q], (unsigned long long)acc[q]);
+        }
     }
     scaf_flush(P, scaf, lane, counters);
-    // ---- counters: per-wave registers -> LDS -> one atomic per slot per workgroup
-    if (lane == 0) {
-#pragma unroll
-        for (int q = 0; q < 10; q++) s_ctr[wave][q] = c_[q];
-    }
     __syncthreads();
-    if (tid < 10) {
-        long long v = 0;
-        for (int w = 0; w < NWAVES; w++) v += s_ctr[w][tid];
-        if (v) atomicAdd((unsigned long long*)&counters[tid], (unsigned long long)v);
+    // ---- counters (BBDukProcessorS.add, :300-342).  With rkt/xsum/outm and in-totals known, the rest follows:
+    // readsOutu = readsIn - readsOutm; ktrim: basesOutu = basesIn - basesKTrimmed (every base either survives in a
+    // kept pair or is counted as k-trimmed); kfilter: basesOutu = basesIn - basesOutm, filtered == removed.
+    if (tid == 0) {
+        const unsigned long long rkt = s_acc[0], xs = s_acc[1], rm = s_acc[2], bm = s_acc[3], rin = s_acc[4], bin = s_acc[5];
+        auto add = [&](int slot, unsigned long long v) { if (v) atomicAdd((unsigned long long*)&counters[slot], v); };
+        add(BBDUK_READS_IN, rin); add(BBDUK_BASES_IN, bin);
+        add(BBDUK_READS_OUTM, rm); add(BBDUK_BASES_OUTM, bm);
+        add(BBDUK_READS_OUTU, rin - rm);
+        if (MODE != BBDUK_MODE_KFILTER) {
+            add(BBDUK_READS_KTRIMMED, rkt); add(BBDUK_BASES_KTRIMMED, xs);
+            add(BBDUK_BASES_OUTU, bin - xs);
+        } else {
+            add(BBDUK_READS_KFILTERED, rm); add(BBDUK_BASES_KFILTERED, bm);
+            add(BBDUK_BASES_OUTU, bin - bm);
+        }
     }
+}
+
+// runtime -> template dispatch
+typedef void (*batch_kernel_t)(const KParams, const uint8_t*, const int64_t*, const int64_t, const int64_t, const int,
+                               int32_t*, int32_t*, uint8_t*, int64_t*);
+template <int MODE>
+static batch_kernel_t pick_kernel_mode(bool general, bool useShort, bool forbidN) {
+    if (general) return bbduk_batch_kernel<MODE, true, true, true>;
+    if (MODE == BBDUK_MODE_KFILTER) return forbidN ? bbduk_batch_kernel<MODE, false, true, false> : bbduk_batch_kernel<MODE, false, false, false>;
+    if (useShort) return forbidN ? bbduk_batch_kernel<MODE, true, true, false> : bbduk_batch_kernel<MODE, true, false, false>;
+    return forbidN ? bbduk_batch_kernel<MODE, false, true, false> : bbduk_batch_kernel<MODE, false, false, false>;
+}
+static batch_kernel_t pick_kernel(const KParams& K) {
+    const bool general = K.qhdist > 0 || K.qhdist2 > 0 || K.restrictLeft > 0 || K.restrictRight > 0 || K.skipR1 || K.skipR2 || !K.rcomp;
+    if (K.mode == BBDUK_MODE_KFILTER) return pick_kernel_mode<BBDUK_MODE_KFILTER>(general, false, K.forbidNs != 0);
+    if (K.mode == BBDUK_MODE_KTRIM_L) return pick_kernel_mode<BBDUK_MODE_KTRIM_L>(general, K.useShort != 0, K.forbidNs != 0);
+    return pick_kernel_mode<BBDUK_MODE_KTRIM_R>(general, K.useShort != 0, K.forbidNs != 0);
 }
 
 __global__ void bbduk_lookup_kernel(const KParams P, const int64_t* keys, int64_t n, int32_t* out) {
@@ -645,7 +681,7 @@ struct bbduk_handle {
     std::vector<int64_t> hkeys;          // staged (key,value) pairs before finalize
     std::vector<int32_t> hvals;
     int64_t nkeys = 0;
-    uint64_t* d_tags = nullptr; uint64_t* d_bkeys = nullptr; int32_t* d_bvals = nullptr; uint64_t nbuckets = 0; int bucketBits = 0;
+    uint32_t* d_tags = nullptr; uint64_t* d_bkeys = nullptr; int32_t* d_bvals = nullptr; uint64_t nbuckets = 0; int bucketBits = 0;
     uint32_t* d_ldsImage = nullptr; int ldsBits = 0;
     // host-operator staging
     uint8_t* d_bases = nullptr; size_t cap_bases = 0;
@@ -654,7 +690,6 @@ struct bbduk_handle {
     int64_t* d_counters = nullptr;
     hipStream_t stream = nullptr;
     int numCU = 256;
-    bool ldsAttrSet = false;
 };
 
 #define HIP_TRY(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
@@ -736,36 +771,37 @@ extern "C" int bbduk_finalize_table(bbduk_handle* h) {
     if (h->finalized) return fail(h, BBDUK_ERR_STATE, "table already finalized");
     HIP_TRY(h, hipSetDevice(h->p.device));
     const size_t n = h->hkeys.size();
-    // 4-way fingerprint buckets, about one key per bucket on average (see KParams).
+    // 4-way buckets of 8-bit fingerprints, about one key per bucket on average (see KParams).
     int bbits = 10;
     while (bbits < 32 && (1ULL << bbits) < (uint64_t)n) bbits++;
     if (const char* e = getenv("BBDUK_BUCKET_BITS")) { const int v = atoi(e); if (v >= 4 && v <= 32) bbits = v; }
     const uint64_t nb = 1ULL << bbits;
     if (4 * nb < (uint64_t)n + nb / 8) return fail(h, BBDUK_ERR_ARG, "too many keys for the bucket index");
-    std::vector<uint64_t> tg(nb, 0ULL), bk(4 * nb, EMPTY_KEY);
+    std::vector<uint32_t> tg(nb, 0u);
+    std::vector<uint64_t> bk(4 * nb, EMPTY_KEY);
     std::vector<int32_t> bv(4 * nb, 0);
     const uint32_t bmask = (uint32_t)(nb - 1);
     int64_t distinct = 0;
     for (size_t i = 0; i < n; i++) {                              // first writer wins (HashArray.setIfNotPresent)
         const uint64_t key = (uint64_t)h->hkeys[i];
         const uint32_t m = filter_mix(key);
-        const uint64_t tag = tag_of(m);
+        const uint32_t tag = tag_of(m);
         uint32_t b = bucket_of(m, bbits);
         for (;;) {
             bool done = false;
             for (int w = 0; w < 4 && !done; w++) {
-                const uint64_t tw = (tg[b] >> (16 * w)) & 0xFFFFULL;
-                if (tw == 0) { tg[b] |= tag << (16 * w); bk[4ULL * b + w] = key; bv[4ULL * b + w] = h->hvals[i]; distinct++; done = true; }
+                const uint32_t tw = (tg[b] >> (8 * w)) & 0xFFu;
+                if (tw == 0) { tg[b] |= tag << (8 * w); bk[4ULL * b + w] = key; bv[4ULL * b + w] = h->hvals[i]; distinct++; done = true; }
                 else if (tw == tag && bk[4ULL * b + w] == key) done = true;
             }
             if (done) break;
             b = (b + 1) & bmask;
         }
     }
-    HIP_TRY(h, hipMalloc(&h->d_tags, nb * sizeof(uint64_t)));
+    HIP_TRY(h, hipMalloc(&h->d_tags, nb * sizeof(uint32_t)));
     HIP_TRY(h, hipMalloc(&h->d_bkeys, 4 * nb * sizeof(uint64_t)));
     HIP_TRY(h, hipMalloc(&h->d_bvals, 4 * nb * sizeof(int32_t)));
-    HIP_TRY(h, hipMemcpy(h->d_tags, tg.data(), nb * sizeof(uint64_t), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_tags, tg.data(), nb * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_bkeys, bk.data(), 4 * nb * sizeof(uint64_t), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_bvals, bv.data(), 4 * nb * sizeof(int32_t), hipMemcpyHostToDevice));
     h->nbuckets = nb; h->bucketBits = bbits; h->nkeys = distinct;
@@ -798,7 +834,7 @@ extern "C" int bbduk_finalize_table(bbduk_handle* h) {
 extern "C" int64_t bbduk_table_size(const bbduk_handle* h) { return (h && h->finalized) ? h->nkeys : -1; }
 extern "C" int64_t bbduk_table_bytes(const bbduk_handle* h) {
     if (!h || !h->finalized) return -1;
-    return (int64_t)(h->nbuckets * (8 + 4 * 12)) + (h->ldsBits ? (1LL << (h->ldsBits - 3)) : 0);
+    return (int64_t)(h->nbuckets * (4 + 4 * 12)) + (h->ldsBits ? (1LL << (h->ldsBits - 3)) : 0);
 }
 
 static KParams make_kparams(const bbduk_handle* h) {
@@ -817,7 +853,6 @@ static KParams make_kparams(const bbduk_handle* h) {
     K.middleMask = (uint64_t)p.middleMask;
     K.tags = h->d_tags; K.bkeys = h->d_bkeys; K.bvals = h->d_bvals; K.bucketMask = (uint32_t)(h->nbuckets - 1); K.bucketBits = h->bucketBits;
     K.storedKmers = h->nkeys;
-    if (const char* e = getenv("BBDUK_DBG")) K.dbg = atoi(e);
     K.ldsImage = h->d_ldsImage; K.ldsBits = h->ldsBits;
     return K;
 }
@@ -836,14 +871,11 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     const KParams K = make_kparams(h);
     const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
     const size_t dynLds = h->ldsBits ? ((size_t)1 << (h->ldsBits - 3)) : 0;
-    if (!h->ldsAttrSet) {
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bbduk_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
-        h->ldsAttrSet = true;
-    }
+    const batch_kernel_t kern = pick_kernel(K);
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
     const int perCU = (dynLds + 32768 <= 80 * 1024) ? 2 : 1;      // 1024-thread workgroups: at most 2 per CU
     const int grid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU * perCU);
-    hipLaunchKernelGGL(bbduk_batch_kernel, dim3(grid), dim3(BLOCK_THREADS), dynLds, st, K, d_bases, d_offsets, n, total_bases,
-                       (int)paired, d_a, d_id, d_fl, d_counters);
+    kern<<<dim3(grid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters);
     HIP_TRY(h, hipGetLastError());
     return BBDUK_OK;
 }
