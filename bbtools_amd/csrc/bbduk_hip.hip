@@ -35,11 +35,8 @@ static_assert(sizeof(bbduk_synth_params) == 80, "bbduk_synth_params layout is pa
 #define TILE_READS      256                    // reads per tile (even: whole pairs)
 #define CAP_BASES       40960                  // LDS plane capacity in bases (>= 2*BBDUK_MAX_READ_LEN + 32: a pair fits)
 #define CAP_CHUNKS      (CAP_BASES / 16)
+#define PLANE_PAD       12                     // words of slack on both sides of the 2-bit planes
 #define EMPTY_KEY       0xFFFFFFFFFFFFFFFFULL  // keys are < 2^63
-#define FH_C1           0x9E3779B1u            // hash constants (host and device must agree)
-#define FH_C2           0x85EBCA77u
-#define FH_C3           0xC2B2AE3Du
-#define FH_C4           0x27D4EB2Fu
 #define MAX_LDS_BITS    20                     // 128 KiB presence filter per workgroup
 #define BIGLOC          999999999
 
@@ -73,19 +70,43 @@ __device__ __forceinline__ uint64_t dev_rcomp(uint64_t kmer, int len) {
     return x >> (64 - 2 * len);
 }
 
-__host__ __device__ __forceinline__ uint32_t filter_mix(uint64_t key) {
-    return ((uint32_t)key * FH_C1) ^ ((uint32_t)(key >> 32) * FH_C2);
+// Two independent 32-bit mixes of a key, built from 24x24-bit multiplies only (v_mul_u32_u24 / v_mad_u32_u24 are
+// full-rate on CDNA; v_mul_lo_u32 is not).  A key (< 2^63) is cut into three 24-bit pieces; the top bits of each
+// sum are well mixed (measured on the adapter / phiX key sets: filter fill and bucket loads equal the ideal
+// Poisson figures).  mix_a feeds the LDS presence bit and the 8-bit fingerprint, mix_b the bucket index.
+#define MA0 0x9E3779u
+#define MA1 0x85EBCBu
+#define MA2 0xC2B2AFu
+#define MB0 0x27D4EBu
+#define MB1 0x165667u
+#define MB2 0xD3A265u
+__host__ __device__ __forceinline__ uint32_t mul24(uint32_t x, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(x, c);
+#else
+    return (x & 0xFFFFFFu) * c;
+#endif
 }
-__host__ __device__ __forceinline__ uint32_t bucket_of(uint32_t m, int bucketBits) { return (m * FH_C3) >> (32 - bucketBits); }
-__host__ __device__ __forceinline__ uint32_t tag_of(uint32_t m) { const uint32_t t = (m * FH_C4) >> 24; return t ? t : 1u; }
+__host__ __device__ __forceinline__ uint32_t mix_a(uint64_t key) {
+    const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+    const uint32_t p1 = (lo >> 24) | (hi << 8), p2 = hi >> 16;
+    return mul24(lo, MA0) + mul24(p1, MA1) + mul24(p2, MA2);
+}
+__host__ __device__ __forceinline__ uint32_t mix_b(uint64_t key) {
+    const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+    const uint32_t p1 = (lo >> 24) | (hi << 8), p2 = hi >> 16;
+    return mul24(lo, MB0) + mul24(p1, MB1) + mul24(p2, MB2);
+}
+__host__ __device__ __forceinline__ uint32_t bucket_of(uint32_t mb, int bucketBits) { return mb >> (32 - bucketBits); }
+__host__ __device__ __forceinline__ uint32_t tag_of(uint32_t ma) { const uint32_t t = (ma >> 3) & 0xFFu; return t ? t : 1u; }
 
 // 0x80 in every byte of v that is zero (may also flag bytes above a true zero byte: callers verify)
 __device__ __forceinline__ uint32_t zero8(uint32_t v) { return (v - 0x01010101u) & ~v & 0x80808080u; }
 
-// map lookup with the mix already computed: id (>0) or -1
-__device__ __forceinline__ int table_get_m(const KParams& P, uint64_t key, uint32_t m) {
-    uint32_t b = bucket_of(m, P.bucketBits);
-    const uint32_t pat = tag_of(m) * 0x01010101u;
+// map lookup with the mixes already computed: id (>0) or -1
+__device__ __forceinline__ int table_get_m(const KParams& P, uint64_t key, uint32_t ma, uint32_t mb) {
+    uint32_t b = bucket_of(mb, P.bucketBits);
+    const uint32_t pat = tag_of(ma) * 0x01010101u;
     for (;;) {
         const uint32_t t = P.tags[b];
         uint32_t cand = zero8(t ^ pat);
@@ -98,18 +119,18 @@ __device__ __forceinline__ int table_get_m(const KParams& P, uint64_t key, uint3
         b = (b + 1) & P.bucketMask;
     }
 }
-__device__ __forceinline__ int table_get(const KParams& P, uint64_t key) { return table_get_m(P, key, filter_mix(key)); }
+__device__ __forceinline__ int table_get(const KParams& P, uint64_t key) { return table_get_m(P, key, mix_a(key), mix_b(key)); }
 
 // key -> id through the cascade: LDS presence bit -> bucket fingerprints -> key/id.  `ok` = lane has a real query.
 __device__ __forceinline__ int probe_key(const KParams& P, const uint32_t* s_filt, uint64_t key, bool ok) {
-    const uint32_t m = filter_mix(key);
+    const uint32_t ma = mix_a(key);
     bool p = ok;
     if (P.ldsBits) {
-        const uint32_t h1 = m >> (32 - P.ldsBits);
-        p = p && ((s_filt[h1 >> 5] >> (h1 & 31)) & 1u);
+        const uint32_t h1 = ma >> (32 - P.ldsBits);
+        p = p & (bool)((s_filt[h1 >> 5] >> (h1 & 31)) & 1u);
     }
     int id = -1;
-    if (p) id = table_get_m(P, key, m);
+    if (p) id = table_get_m(P, key, ma, mix_b(key));
     return id;
 }
 
@@ -232,18 +253,23 @@ __device__ __forceinline__ void read_init(const KParams& P, ReadScan& R, int bas
     R.scan = s;
 }
 
-// Main scan of one read by one wave: one lane per k-mer end position (closed form).
+// ---- main scan -------------------------------------------------------------------------------------
+// One wave scans the two reads of a unit together.  Each loop iteration covers 128 k-mer end positions of
+// each read: four "slots" (read A/B x positions +0/+64), one lane per position in each slot (closed form,
+// SURVEY A.12).  The four slots are computed in straight-line code so that their LDS reads and their bucket
+// gathers are in flight together (the scan is latency-bound otherwise: LDS -> filter -> L2 gather per pass).
 // bbduk/BBDukProcessorS.java:2009-2029 (ktrim) == :1547-1591 (countSetKmers).
-template <int MODE, bool FORBIDN, bool GENERAL>
-__device__ __forceinline__ void main_scan(const KParams& P, const Planes& Q, ReadScan& R, const int lane) {
-    if (!R.scan) return;
-    const int k = P.k, start = R.start, stop = R.stop, base0 = R.base0;
-    const int first = max(start, k - 1);                         // i>=minlen (minlen=k-1)
-    if (first >= stop) return;
 
-    bool hasN = false;                                           // undefined base inside [start,stop)? (forbidNs only)
-    if (FORBIDN && P.forbidNs) {
-        const int b0 = base0 + start, b1 = base0 + stop;
+struct ReadWin { int first, stop, start, base0; bool on, plain, hasN; };   // wave-uniform per read
+
+template <bool FORBIDN, bool GENERAL>
+__device__ __forceinline__ void win_init(const KParams& P, const Planes& Q, const ReadScan& R, ReadWin& W, const int lane) {
+    W.start = R.start; W.stop = R.stop; W.base0 = R.base0;
+    W.first = max(R.start, P.k - 1);                             // i>=minlen (minlen=k-1)
+    W.on = R.scan && W.first < W.stop;
+    W.hasN = false;                                              // undefined base inside [start,stop)? (forbidNs only)
+    if (FORBIDN && P.forbidNs && W.on) {
+        const int b0 = W.base0 + W.start, b1 = W.base0 + W.stop;
         uint32_t acc = 0;
         for (int w = (b0 >> 5) + lane; w <= ((b1 - 1) >> 5); w += 64) {
             uint32_t v = Q.nm[w];
@@ -252,66 +278,151 @@ __device__ __forceinline__ void main_scan(const KParams& P, const Planes& Q, Rea
             if (lo + 32 > b1) v &= ~0u >> (lo + 32 - b1);
             acc |= v;
         }
-        hasN = __ballot(acc != 0) != 0;
+        W.hasN = __ballot(acc != 0) != 0;
     }
-    const bool plain = (!GENERAL || start == 0) && !hasN;        // every window holds k bases and no reset
+    W.plain = (!GENERAL || W.start == 0) && !W.hasN;             // every window holds k bases and no reset
+}
 
-    int found = 0;
-    const int fbase = Q.T - 1 - base0;                           // forward (reversed) plane: symbol index of base i is fbase - i
-    const int cbase = base0 - k + 1;                             // complement plane: window of base i starts at cbase + i
-    for (int ib = first; ib < stop; ib += 64) {
-        const int i = ib + lane;
-        const bool act = i < stop;
-        const int ic = act ? i : stop - 1;                       // inactive lanes read in-bounds
-        uint64_t kmer, rk;
-        bool ok = act;
-        if (plain) {
-            kmer = extract2raw(Q.fwd, fbase - ic) & P.mask;      // base ic in bits 0-1, base ic-k+1 on top
-            rk   = extract2raw(Q.cmp, cbase + ic) & P.mask;      // base ic-k+1 in bits 0-1
-        } else {
-            const int lo = max(start, ic - k + 1);
-            const int nb = ic - lo + 1;                          // bases in the window (== k unless cut by start)
-            kmer = extract2(Q.fwd, fbase - ic, nb);
-            rk   = extract2(Q.cmp, base0 + lo, nb);
-            int len = ic - start + 1;
-            if (hasN) {
-                const uint32_t nwin = extract1(Q.nm, base0 + lo, nb);       // bit t <=> base lo+t undefined
-                if (nwin) {
-                    const int msb = 31 - __clz(nwin);
-                    len = nb - 1 - msb;                          // bases after the last undefined one
-                    rk &= ~0ULL << (2 * (msb + 1));              // rkmer was reset there; kmer keeps its history
-                }
+// kmer / rkmer of the windows ending at positions i and i+64 of read W (lane-varying i); ok=false: no lookup due.
+// Plain reads (no reset, no cut) need no clamping: the planes are padded, out-of-read lanes are simply not ok,
+// and the second slot reuses the first slot's shift and word address (+-64 symbols = +-4 words).
+template <bool FORBIDN, bool GENERAL>
+__device__ __forceinline__ void windows2(const KParams& P, const Planes& Q, const ReadWin& W, const int i, const bool on,
+                                         uint64_t* kmer, uint64_t* rk, bool* ok) {
+    const int k = P.k;
+    if (W.plain) {
+        const int fbit = 2 * (Q.T - 1 - W.base0 - i) - 128;      // slot 1 (i+64) sits 64 symbols lower in the reversed plane
+        const uint32_t* pf = Q.fwd + (fbit >> 5);
+        const uint32_t f0 = pf[0], f1 = pf[1], f2 = pf[2], f4 = pf[4], f5 = pf[5], f6 = pf[6];
+        const int cbit = 2 * (W.base0 - k + 1 + i);
+        const uint32_t* pc = Q.cmp + (cbit >> 5);
+        const uint32_t c0 = pc[0], c1 = pc[1], c2 = pc[2], c4 = pc[4], c5 = pc[5], c6 = pc[6];
+        kmer[0] = (((uint64_t)__builtin_amdgcn_alignbit(f6, f5, fbit) << 32) | __builtin_amdgcn_alignbit(f5, f4, fbit)) & P.mask;
+        kmer[1] = (((uint64_t)__builtin_amdgcn_alignbit(f2, f1, fbit) << 32) | __builtin_amdgcn_alignbit(f1, f0, fbit)) & P.mask;
+        rk[0]   = (((uint64_t)__builtin_amdgcn_alignbit(c2, c1, cbit) << 32) | __builtin_amdgcn_alignbit(c1, c0, cbit)) & P.mask;
+        rk[1]   = (((uint64_t)__builtin_amdgcn_alignbit(c6, c5, cbit) << 32) | __builtin_amdgcn_alignbit(c5, c4, cbit)) & P.mask;
+        ok[0] = on & (i < W.stop);
+        ok[1] = on & (i + 64 < W.stop);
+        return;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int ih = i + 64 * h;
+        const bool act = on && ih < W.stop;
+        const int ic = min(max(ih, W.first), W.stop - 1);        // inactive lanes read in-bounds
+        const int lo = max(W.start, ic - k + 1);
+        const int nb = ic - lo + 1;                              // bases in the window (== k unless cut by start)
+        uint64_t km = extract2(Q.fwd, Q.T - 1 - W.base0 - ic, nb);
+        uint64_t rr = extract2(Q.cmp, W.base0 + lo, nb);
+        int len = ic - W.start + 1;
+        if (FORBIDN && W.hasN) {
+            const uint32_t nwin = extract1(Q.nm, W.base0 + lo, nb);          // bit t <=> base lo+t undefined
+            if (nwin) {
+                const int msb = 31 - __clz(nwin);
+                len = nb - 1 - msb;                              // bases after the last undefined one
+                rr &= ~0ULL << (2 * (msb + 1));                  // rkmer was reset there; kmer keeps its history
             }
-            rk <<= 2 * (k - nb);                                 // base j sits at 2*(k-1-(i-j))
-            ok = act && len >= P.minlen2;
         }
-        const int id = lookup<GENERAL>(P, Q.filt, kmer, rk, P.kmask, k, P.qhdist, ok);
-        const uint64_t m = __ballot(id > 0);
-        if (m) {
-            if (MODE != BBDUK_MODE_KFILTER) {
-                const int fl = __ffsll((unsigned long long)m) - 1, ll = 63 - __clzll((long long)m);
-                if (found == 0) { R.iFirst = ib + fl; R.id0 = __builtin_amdgcn_readlane(id, fl); }
-                R.iLast = ib + ll;
-                found += __popcll(m);
-                if (MODE == BBDUK_MODE_KTRIM_R) break;           // only minLoc/id0 of the first hit are used
-            } else {
-                const int c = __popcll(m);
-                if (found + c > P.maxBadKmers) {                 // the (maxBadKmers+1)-th hit is in this pass
-                    uint64_t mm = m;
-                    for (int q = found; q < P.maxBadKmers; q++) mm &= mm - 1;
-                    const int fl = __ffsll((unsigned long long)mm) - 1;
-                    R.id0 = __builtin_amdgcn_readlane(id, fl);
-                    found = P.maxBadKmers + 1;
-                    R.iFirst = 0;                                // marks the early exit
-                    break;
-                }
-                found += c;
-            }
+        rr <<= 2 * (k - nb);                                     // base j sits at 2*(k-1-(i-j))
+        kmer[h] = km; rk[h] = rr;
+        ok[h] = act && len >= P.minlen2;
+    }
+}
+
+// four independent key -> id lookups with their memory operations overlapped
+template <bool GENERAL>
+__device__ __forceinline__ void lookup4(const KParams& P, const uint32_t* s_filt, const uint64_t* kmer, const uint64_t* rk,
+                                        const bool* ok, int* id) {
+    if constexpr (GENERAL) {
+        if (P.qhdist > 0) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) id[s] = ok[s] ? get_value_expand(P, kmer[s], rk[s], P.kmask, P.k, P.qhdist) : -1;
+            return;
         }
     }
-    R.found = found;
-    if (MODE != BBDUK_MODE_KFILTER && found > 0) {
-        R.minLoc = R.iFirst - k + 1; R.maxLoc = R.iLast; R.minLocEx = R.minLoc + k; R.maxLocEx = R.maxLoc - k;
+    uint64_t key[4]; uint32_t ma[4], mb[4], t[4]; bool p[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        key[s] = make_key<GENERAL>(P, kmer[s], rk[s], P.kmask);
+        ma[s] = mix_a(key[s]);
+        mb[s] = mix_b(key[s]);
+        p[s] = ok[s];
+    }
+    if (P.ldsBits) {                                              // four presence bits, read together
+        uint32_t w[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) w[s] = s_filt[(ma[s] >> (32 - P.ldsBits)) >> 5];
+#pragma unroll
+        for (int s = 0; s < 4; s++) p[s] = p[s] & (bool)((w[s] >> ((ma[s] >> (32 - P.ldsBits)) & 31)) & 1u);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; s++) t[s] = p[s] ? P.tags[bucket_of(mb[s], P.bucketBits)] : 0u;   // four gathers in flight
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        // rare: a fingerprint matched, or the home bucket is full -> walk the bucket chain
+        const uint32_t cand = zero8(t[s] ^ (tag_of(ma[s]) * 0x01010101u));
+        id[s] = -1;
+        if (p[s] && (cand != 0u || zero8(t[s]) == 0u)) id[s] = table_get_m(P, key[s], ma[s], mb[s]);
+    }
+}
+
+// fold one slot's hit mask into the read's scan state; returns true when the scan of this read is over
+template <int MODE>
+__device__ __forceinline__ bool fold_hits(const KParams& P, ReadScan& R, int& found, const uint64_t m, const int id, const int ibase) {
+    if (!m) return false;
+    if (MODE != BBDUK_MODE_KFILTER) {
+        const int fl = __ffsll((unsigned long long)m) - 1, ll = 63 - __clzll((long long)m);
+        if (found == 0) { R.iFirst = ibase + fl; R.id0 = __builtin_amdgcn_readlane(id, fl); }
+        R.iLast = ibase + ll;
+        found += __popcll(m);
+        return MODE == BBDUK_MODE_KTRIM_R;                       // only minLoc/id0 of the first hit are used
+    } else {
+        const int c = __popcll(m);
+        if (found + c > P.maxBadKmers) {                         // the (maxBadKmers+1)-th hit is in this slot
+            uint64_t mm = m;
+            for (int q = found; q < P.maxBadKmers; q++) mm &= mm - 1;
+            const int fl = __ffsll((unsigned long long)mm) - 1;
+            R.id0 = __builtin_amdgcn_readlane(id, fl);
+            found = P.maxBadKmers + 1;
+            R.iFirst = 0;                                        // marks the early exit
+            return true;
+        }
+        found += c;
+        return false;
+    }
+}
+
+template <int MODE, bool FORBIDN, bool GENERAL>
+__device__ __forceinline__ void main_scan_pair(const KParams& P, const Planes& Q, ReadScan& A, ReadScan& B, const int lane) {
+    ReadWin WA, WB;
+    win_init<FORBIDN, GENERAL>(P, Q, A, WA, lane);
+    win_init<FORBIDN, GENERAL>(P, Q, B, WB, lane);
+    int ibA = WA.first, ibB = WB.first, foundA = 0, foundB = 0;
+    bool onA = WA.on, onB = WB.on;
+    while (onA || onB) {
+        uint64_t kmer[4], rk[4]; bool ok[4]; int id[4];
+        windows2<FORBIDN, GENERAL>(P, Q, WA, ibA + lane, onA, kmer, rk, ok);
+        windows2<FORBIDN, GENERAL>(P, Q, WB, ibB + lane, onB, kmer + 2, rk + 2, ok + 2);
+        lookup4<GENERAL>(P, Q.filt, kmer, rk, ok, id);
+        const uint64_t m0 = __ballot(id[0] > 0), m1 = __ballot(id[1] > 0), m2 = __ballot(id[2] > 0), m3 = __ballot(id[3] > 0);
+        if (onA) {
+            bool ex = fold_hits<MODE>(P, A, foundA, m0, id[0], ibA);
+            if (!ex) ex = fold_hits<MODE>(P, A, foundA, m1, id[1], ibA + 64);
+            ibA += 128;
+            onA = !ex && ibA < WA.stop;
+        }
+        if (onB) {
+            bool ex = fold_hits<MODE>(P, B, foundB, m2, id[2], ibB);
+            if (!ex) ex = fold_hits<MODE>(P, B, foundB, m3, id[3], ibB + 64);
+            ibB += 128;
+            onB = !ex && ibB < WB.stop;
+        }
+    }
+    A.found = foundA; B.found = foundB;
+    if (MODE != BBDUK_MODE_KFILTER) {
+        const int k = P.k;
+        if (foundA > 0) { A.minLoc = A.iFirst - k + 1; A.maxLoc = A.iLast; A.minLocEx = A.minLoc + k; A.maxLocEx = A.maxLoc - k; }
+        if (foundB > 0) { B.minLoc = B.iFirst - k + 1; B.maxLoc = B.iLast; B.minLocEx = B.minLoc + k; B.maxLocEx = B.maxLoc - k; }
     }
 }
 
@@ -377,33 +488,33 @@ __device__ __forceinline__ void short_scan_pair(const KParams& P, const Planes& 
 // Hits cluster on very few scaffold ids (a library has one adapter per mate), so bumping the global counters
 // once per read serialises the whole grid on two or three addresses (measured: 55 of 68 ms).  A wave keeps a
 // 4-entry cache of (id, reads, bases) in wave-uniform registers and only an evicted entry costs two atomics.
-#define SCAF_WAYS 4
-struct ScafAcc { int id[SCAF_WAYS]; int reads[SCAF_WAYS]; long long bases[SCAF_WAYS]; int next; };
+struct ScafAcc { int i0, i1, i2, i3; int r0, r1, r2, r3; long long b0, b1, b2, b3; };
 __device__ __forceinline__ void scaf_init(ScafAcc& S) {
-#pragma unroll
-    for (int w = 0; w < SCAF_WAYS; w++) { S.id[w] = -1; S.reads[w] = 0; S.bases[w] = 0; }
-    S.next = 0;
+    S.i0 = S.i1 = S.i2 = S.i3 = -1; S.r0 = S.r1 = S.r2 = S.r3 = 0; S.b0 = S.b1 = S.b2 = S.b3 = 0;
 }
-__device__ __forceinline__ void scaf_flush_way(const KParams& P, ScafAcc& S, const int w, const int lane, int64_t* __restrict__ counters) {
-    if (S.id[w] > 0 && lane == 0) {
-        atomicAdd((unsigned long long*)&counters[BBDUK_NCOUNTERS + S.id[w]], (unsigned long long)S.reads[w]);
-        atomicAdd((unsigned long long*)&counters[BBDUK_NCOUNTERS + P.numScaffolds + S.id[w]], (unsigned long long)S.bases[w]);
+__device__ __forceinline__ void scaf_emit(const KParams& P, int id, int reads, long long bases, const int lane, int64_t* __restrict__ counters) {
+    if (id > 0 && lane == 0) {
+        atomicAdd((unsigned long long*)&counters[BBDUK_NCOUNTERS + id], (unsigned long long)reads);
+        atomicAdd((unsigned long long*)&counters[BBDUK_NCOUNTERS + P.numScaffolds + id], (unsigned long long)bases);
     }
-    S.id[w] = -1; S.reads[w] = 0; S.bases[w] = 0;
 }
 __device__ __forceinline__ void scaf_flush(const KParams& P, ScafAcc& S, const int lane, int64_t* __restrict__ counters) {
-#pragma unroll
-    for (int w = 0; w < SCAF_WAYS; w++) scaf_flush_way(P, S, w, lane, counters);
+    scaf_emit(P, S.i0, S.r0, S.b0, lane, counters); scaf_emit(P, S.i1, S.r1, S.b1, lane, counters);
+    scaf_emit(P, S.i2, S.r2, S.b2, lane, counters); scaf_emit(P, S.i3, S.r3, S.b3, lane, counters);
+    scaf_init(S);
 }
 __device__ __forceinline__ void scaf_add(const KParams& P, ScafAcc& S, int id, int L, const int lane, int64_t* __restrict__ counters) {
-    bool done = false;
-#pragma unroll
-    for (int w = 0; w < SCAF_WAYS; w++) if (!done && S.id[w] == id) { S.reads[w]++; S.bases[w] += L; done = true; }
-    if (done) return;
-    const int v = S.next;
-    S.next = (S.next + 1) & (SCAF_WAYS - 1);
-#pragma unroll
-    for (int w = 0; w < SCAF_WAYS; w++) if (w == v) { scaf_flush_way(P, S, w, lane, counters); S.id[w] = id; S.reads[w] = 1; S.bases[w] = L; }
+    if (id == S.i0) { S.r0++; S.b0 += L; }
+    else if (id == S.i1) { S.r1++; S.b1 += L; }
+    else if (id == S.i2) { S.r2++; S.b2 += L; }
+    else if (id == S.i3) { S.r3++; S.b3 += L; }
+    else {                                                       // evict the oldest entry, insert in front
+        scaf_emit(P, S.i3, S.r3, S.b3, lane, counters);
+        S.i3 = S.i2; S.r3 = S.r2; S.b3 = S.b2;
+        S.i2 = S.i1; S.r2 = S.r1; S.b2 = S.b1;
+        S.i1 = S.i0; S.r1 = S.r0; S.b1 = S.b0;
+        S.i0 = id; S.r0 = 1; S.b0 = L;
+    }
 }
 
 // After the scans: scaffold counters, trimPad, trimToPosition / countSetKmers return value.
@@ -480,8 +591,8 @@ void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
                         const int64_t n, const int64_t totalBases, const int paired,
                         int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
                         int64_t* __restrict__ counters) {
-    __shared__ uint32_t s_fwd[CAP_CHUNKS + 4];
-    __shared__ uint32_t s_cmp[CAP_CHUNKS + 4];
+    __shared__ uint32_t s_fwd[PLANE_PAD + CAP_CHUNKS + PLANE_PAD];   // padded both ends: the plain path reads past a read's end unclamped
+    __shared__ uint32_t s_cmp[PLANE_PAD + CAP_CHUNKS + PLANE_PAD];
     __shared__ uint32_t s_nm[CAP_CHUNKS / 2 + 4];
     __shared__ int64_t  s_off[TILE_READS + 1];
     __shared__ int32_t  s_a[TILE_READS];
@@ -557,15 +668,15 @@ void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
                 }
                 uint32_t r = __brev(code);                          // reverse the order of the 16 symbols
                 r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
-                s_fwd[nchunks - 1 - c] = r;
-                s_cmp[c] = comp;
+                s_fwd[PLANE_PAD + nchunks - 1 - c] = r;
+                s_cmp[PLANE_PAD + c] = comp;
                 reinterpret_cast<uint16_t*>(s_nm)[c] = (uint16_t)(~valid & 0xFFFFu);
             }
             if (tid == 0 && (nchunks & 1)) reinterpret_cast<uint16_t*>(s_nm)[nchunks] = 0;
             __syncthreads();
 
             // ---- scan: one wave per unit of two consecutive reads (a pair when paired)
-            Planes Q; Q.fwd = s_fwd; Q.cmp = s_cmp; Q.nm = s_nm; Q.filt = s_filt; Q.T = nchunks * 16;
+            Planes Q; Q.fwd = s_fwd + PLANE_PAD; Q.cmp = s_cmp + PLANE_PAD; Q.nm = s_nm; Q.filt = s_filt; Q.T = nchunks * 16;
             const int nunits = (e - s + 1) >> 1;
             const int a0lo = (int)(A0 - s_off[0]);                  // tile-relative origin of the planes (fits int)
             for (int u = wave; u < nunits; u += NWAVES) {
@@ -577,8 +688,7 @@ void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
                 ReadScan A, Bz;
                 read_init<MODE, SHORT, GENERAL>(P, A, o0 - a0lo, o1 - o0, 0, true);
                 read_init<MODE, SHORT, GENERAL>(P, Bz, o1 - a0lo, o2 - o1, paired ? 1 : 0, hasB);
-                main_scan<MODE, FORBIDN, GENERAL>(P, Q, A, lane);
-                main_scan<MODE, FORBIDN, GENERAL>(P, Q, Bz, lane);
+                main_scan_pair<MODE, FORBIDN, GENERAL>(P, Q, A, Bz, lane);
                 if constexpr (MODE != BBDUK_MODE_KFILTER && SHORT) {
                     if (P.useShort) short_scan_pair<MODE, GENERAL>(P, Q, A, Bz, lane);
                 }
@@ -784,9 +894,8 @@ extern "C" int bbduk_finalize_table(bbduk_handle* h) {
     int64_t distinct = 0;
     for (size_t i = 0; i < n; i++) {                              // first writer wins (HashArray.setIfNotPresent)
         const uint64_t key = (uint64_t)h->hkeys[i];
-        const uint32_t m = filter_mix(key);
-        const uint32_t tag = tag_of(m);
-        uint32_t b = bucket_of(m, bbits);
+        const uint32_t tag = tag_of(mix_a(key));
+        uint32_t b = bucket_of(mix_b(key), bbits);
         for (;;) {
             bool done = false;
             for (int w = 0; w < 4 && !done; w++) {
@@ -818,7 +927,7 @@ extern "C" int bbduk_finalize_table(bbduk_handle* h) {
             std::vector<uint32_t> f1((size_t)1 << (lb - 5), 0u);
             for (uint64_t s = 0; s < 4 * nb; s++) {
                 if (bk[s] == EMPTY_KEY) continue;
-                const uint32_t h1 = filter_mix(bk[s]) >> (32 - lb);
+                const uint32_t h1 = mix_a(bk[s]) >> (32 - lb);
                 f1[h1 >> 5] |= 1u << (h1 & 31);
             }
             HIP_TRY(h, hipMalloc(&h->d_ldsImage, f1.size() * 4));
@@ -875,6 +984,11 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
     const int perCU = (dynLds + 32768 <= 80 * 1024) ? 2 : 1;      // 1024-thread workgroups: at most 2 per CU
     const int grid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU * perCU);
+    if (getenv("BBDUK_VERBOSE")) {
+        int occ = -1;
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), BLOCK_THREADS, dynLds);
+        fprintf(stderr, "[bbduk] grid=%d block=%d dynLds=%zu perCU=%d occupancyAPI=%d numCU=%d\n", grid, BLOCK_THREADS, dynLds, perCU, occ, h->numCU);
+    }
     kern<<<dim3(grid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters);
     HIP_TRY(h, hipGetLastError());
     return BBDUK_OK;
