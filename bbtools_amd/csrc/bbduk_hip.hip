@@ -58,6 +58,8 @@ struct KParams {
     // presence filter in front of the map: one bit per hash slot, copied into LDS by every workgroup
     const uint32_t* ldsImage;   // HBM copy of the LDS bitmap (2^ldsBits bits); 0 bits = absent
     int32_t  ldsBits;
+    int32_t  prof;              // BBDUK_PROF=1: per-phase s_memtime sums into counters[] tail (timing experiments only)
+    unsigned long long* profOut;
 };
 
 // --------------------------------------------------------------------------------------------------
@@ -103,35 +105,45 @@ __host__ __device__ __forceinline__ uint32_t tag_of(uint32_t ma) { const uint32_
 // 0x80 in every byte of v that is zero (may also flag bytes above a true zero byte: callers verify)
 __device__ __forceinline__ uint32_t zero8(uint32_t v) { return (v - 0x01010101u) & ~v & 0x80808080u; }
 
-// map lookup with the mixes already computed: id (>0) or -1
-__device__ __forceinline__ int table_get_m(const KParams& P, uint64_t key, uint32_t ma, uint32_t mb) {
+// map lookup with the mixes already computed: slot (4*bucket+way) of the key, or -1.  t0 = tags of the home bucket.
+__device__ __forceinline__ int table_find_t(const KParams& P, uint64_t key, uint32_t ma, uint32_t mb, uint32_t t0) {
     uint32_t b = bucket_of(mb, P.bucketBits);
     const uint32_t pat = tag_of(ma) * 0x01010101u;
+    uint32_t t = t0;
     for (;;) {
-        const uint32_t t = P.tags[b];
         uint32_t cand = zero8(t ^ pat);
         while (cand) {
             const int way = (__ffs(cand) - 1) >> 3;
-            if (P.bkeys[4ULL * b + way] == key) return P.bvals[4ULL * b + way];
+            if (P.bkeys[4ULL * b + way] == key) return (int)(4u * b + way);
             cand &= cand - 1;
         }
         if (zero8(t)) return -1;                  // a free way: the key cannot be further along
         b = (b + 1) & P.bucketMask;
+        t = P.tags[b];
     }
 }
-__device__ __forceinline__ int table_get(const KParams& P, uint64_t key) { return table_get_m(P, key, mix_a(key), mix_b(key)); }
+__device__ __forceinline__ int table_find_m(const KParams& P, uint64_t key, uint32_t ma, uint32_t mb) {
+    return table_find_t(P, key, ma, mb, P.tags[bucket_of(mb, P.bucketBits)]);
+}
+__device__ __forceinline__ int table_get(const KParams& P, uint64_t key) {
+    const int slot = table_find_m(P, key, mix_a(key), mix_b(key));
+    return slot < 0 ? -1 : P.bvals[slot];
+}
+// A lookup result is carried as a "ref": -1 = absent, >= 0 = slot whose id (bvals[slot]) is fetched only by the
+// one lane whose hit is used, <= -3 = an id already known (-2 - id; query-expansion path).
+__device__ __forceinline__ int ref_to_id(const KParams& P, int ref) { return ref >= 0 ? P.bvals[ref] : (ref == -1 ? -1 : -2 - ref); }
 
-// key -> id through the cascade: LDS presence bit -> bucket fingerprints -> key/id.  `ok` = lane has a real query.
-__device__ __forceinline__ int probe_key(const KParams& P, const uint32_t* s_filt, uint64_t key, bool ok) {
+// key -> ref through the cascade: LDS presence bit -> bucket fingerprints -> key.  `ok` = lane has a real query.
+__device__ __forceinline__ int probe_ref(const KParams& P, const uint32_t* s_filt, uint64_t key, bool ok) {
     const uint32_t ma = mix_a(key);
     bool p = ok;
     if (P.ldsBits) {
         const uint32_t h1 = ma >> (32 - P.ldsBits);
         p = p & (bool)((s_filt[h1 >> 5] >> (h1 & 31)) & 1u);
     }
-    int id = -1;
-    if (p) id = table_get_m(P, key, ma, mix_b(key));
-    return id;
+    int ref = -1;
+    if (p) ref = table_find_m(P, key, ma, mix_b(key));
+    return ref;
 }
 
 // getValueInner (bbduk/BBDukIndexMod.java:492-520): canonicalise, mask middle, add length bit
@@ -161,14 +173,17 @@ __device__ int get_value(const KParams& P, uint64_t kmer, uint64_t rkmer, uint64
 __device__ __noinline__ int get_value_expand(const KParams& P, uint64_t kmer, uint64_t rkmer, uint64_t lengthMask, int len, int qh) {
     return get_value<2>(P, kmer, rkmer, lengthMask, len, qh);
 }
-// index.getValue(kmer, rkmer, lengthMask, qPos, len, qHDist): filtered fast path when there is no query expansion
+// index.getValue(kmer, rkmer, lengthMask, qPos, len, qHDist) as a ref: filtered fast path when there is no query expansion
 template <bool GENERAL>
 __device__ __forceinline__ int lookup(const KParams& P, const uint32_t* s_filt, uint64_t kmer, uint64_t rkmer,
                                       uint64_t lengthMask, int len, int qh, bool ok) {
     if constexpr (GENERAL) {
-        if (qh > 0) return ok ? get_value_expand(P, kmer, rkmer, lengthMask, len, qh) : -1;
+        if (qh > 0) {
+            const int id = ok ? get_value_expand(P, kmer, rkmer, lengthMask, len, qh) : -1;
+            return id > 0 ? -2 - id : -1;
+        }
     }
-    return probe_key(P, s_filt, make_key<GENERAL>(P, kmer, rkmer, lengthMask), ok);
+    return probe_ref(P, s_filt, make_key<GENERAL>(P, kmer, rkmer, lengthMask), ok);
 }
 
 // symbols [idx, idx+32) of a little-endian 2-bit stream, as a 64-bit value (caller masks)
@@ -209,6 +224,37 @@ __device__ __forceinline__ void encode4(uint32_t w, uint32_t& code8, uint32_t& c
     code8 = pack(x);
     comp8 = pack(c);
     valid4 = (y | (y >> 7) | (y >> 14) | (y >> 21)) & 0xFu;
+}
+
+// 16 consecutive bases starting at byte a -> 32-bit reversed forward codes, 32-bit complement codes, 16 valid bits
+__device__ __forceinline__ void encode_chunk(const uint8_t* __restrict__ bases, const int64_t a, const int64_t totalBases,
+                                             uint32_t& fwdRev, uint32_t& comp, uint32_t& valid) {
+    uint32_t w[4];
+    if (a + 16 <= totalBases) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(bases + a));   // streamed once: keep it out of L2's way
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int64_t p = a + 4 * q + b;
+                if (p < totalBases) x |= (uint32_t)bases[p] << (8 * b);
+            }
+            w[q] = x;
+        }
+    }
+    uint32_t code = 0; comp = 0; valid = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint32_t c8, m8, v4;
+        encode4(w[q], c8, m8, v4);
+        code |= c8 << (8 * q); comp |= m8 << (8 * q); valid |= v4 << (4 * q);
+    }
+    uint32_t r = __brev(code);                                    // reverse the order of the 16 symbols
+    fwdRev = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
 }
 
 // shared/TrimRead.java:304-345 trimByAmount on lengths
@@ -329,14 +375,17 @@ __device__ __forceinline__ void windows2(const KParams& P, const Planes& Q, cons
     }
 }
 
-// four independent key -> id lookups with their memory operations overlapped
+// four independent key -> ref lookups with their memory operations overlapped
 template <bool GENERAL>
 __device__ __forceinline__ void lookup4(const KParams& P, const uint32_t* s_filt, const uint64_t* kmer, const uint64_t* rk,
-                                        const bool* ok, int* id) {
+                                        const bool* ok, int* ref) {
     if constexpr (GENERAL) {
         if (P.qhdist > 0) {
 #pragma unroll
-            for (int s = 0; s < 4; s++) id[s] = ok[s] ? get_value_expand(P, kmer[s], rk[s], P.kmask, P.k, P.qhdist) : -1;
+            for (int s = 0; s < 4; s++) {
+                const int id = ok[s] ? get_value_expand(P, kmer[s], rk[s], P.kmask, P.k, P.qhdist) : -1;
+                ref[s] = id > 0 ? -2 - id : -1;
+            }
             return;
         }
     }
@@ -359,20 +408,20 @@ __device__ __forceinline__ void lookup4(const KParams& P, const uint32_t* s_filt
     for (int s = 0; s < 4; s++) t[s] = p[s] ? P.tags[bucket_of(mb[s], P.bucketBits)] : 0u;   // four gathers in flight
 #pragma unroll
     for (int s = 0; s < 4; s++) {
-        // rare: a fingerprint matched, or the home bucket is full -> walk the bucket chain
+        // rare: a fingerprint matched, or the home bucket is full -> check the key / walk the bucket chain
         const uint32_t cand = zero8(t[s] ^ (tag_of(ma[s]) * 0x01010101u));
-        id[s] = -1;
-        if (p[s] && (cand != 0u || zero8(t[s]) == 0u)) id[s] = table_get_m(P, key[s], ma[s], mb[s]);
+        ref[s] = -1;
+        if (p[s] && (cand != 0u || zero8(t[s]) == 0u)) ref[s] = table_find_t(P, key[s], ma[s], mb[s], t[s]);
     }
 }
 
 // fold one slot's hit mask into the read's scan state; returns true when the scan of this read is over
 template <int MODE>
-__device__ __forceinline__ bool fold_hits(const KParams& P, ReadScan& R, int& found, const uint64_t m, const int id, const int ibase) {
+__device__ __forceinline__ bool fold_hits(const KParams& P, ReadScan& R, int& found, const uint64_t m, const int ref, const int ibase) {
     if (!m) return false;
     if (MODE != BBDUK_MODE_KFILTER) {
         const int fl = __ffsll((unsigned long long)m) - 1, ll = 63 - __clzll((long long)m);
-        if (found == 0) { R.iFirst = ibase + fl; R.id0 = __builtin_amdgcn_readlane(id, fl); }
+        if (found == 0) { R.iFirst = ibase + fl; R.id0 = ref_to_id(P, __builtin_amdgcn_readlane(ref, fl)); }
         R.iLast = ibase + ll;
         found += __popcll(m);
         return MODE == BBDUK_MODE_KTRIM_R;                       // only minLoc/id0 of the first hit are used
@@ -382,7 +431,7 @@ __device__ __forceinline__ bool fold_hits(const KParams& P, ReadScan& R, int& fo
             uint64_t mm = m;
             for (int q = found; q < P.maxBadKmers; q++) mm &= mm - 1;
             const int fl = __ffsll((unsigned long long)mm) - 1;
-            R.id0 = __builtin_amdgcn_readlane(id, fl);
+            R.id0 = ref_to_id(P, __builtin_amdgcn_readlane(ref, fl));
             found = P.maxBadKmers + 1;
             R.iFirst = 0;                                        // marks the early exit
             return true;
@@ -404,7 +453,7 @@ __device__ __forceinline__ void main_scan_pair(const KParams& P, const Planes& Q
         windows2<FORBIDN, GENERAL>(P, Q, WA, ibA + lane, onA, kmer, rk, ok);
         windows2<FORBIDN, GENERAL>(P, Q, WB, ibB + lane, onB, kmer + 2, rk + 2, ok + 2);
         lookup4<GENERAL>(P, Q.filt, kmer, rk, ok, id);
-        const uint64_t m0 = __ballot(id[0] > 0), m1 = __ballot(id[1] > 0), m2 = __ballot(id[2] > 0), m3 = __ballot(id[3] > 0);
+        const uint64_t m0 = __ballot(id[0] != -1), m1 = __ballot(id[1] != -1), m2 = __ballot(id[2] != -1), m3 = __ballot(id[3] != -1);
         if (onA) {
             bool ex = fold_hits<MODE>(P, A, foundA, m0, id[0], ibA);
             if (!ex) ex = fold_hits<MODE>(P, A, foundA, m1, id[1], ibA + 64);
@@ -461,14 +510,14 @@ __device__ __forceinline__ void short_scan_pair(const KParams& P, const Planes& 
         }
         id = lookup<GENERAL>(P, Q.filt, kmer, rk, 1ULL << (2 * Lc), Lc, P.qhdist2, act);
     }
-    const uint64_t m = __ballot(id > 0);
+    const uint64_t m = __ballot(id != -1);
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const uint32_t mh = (uint32_t)(m >> (32 * h));
         if (!mh) continue;
         ReadScan& R = h ? B : A;
         const int fl = __ffs(mh) - 1, ll = 31 - __clz(mh);
-        R.id0 = __builtin_amdgcn_readlane(id, 32 * h + fl);      // first hit in scan order = shortest length
+        R.id0 = ref_to_id(P, __builtin_amdgcn_readlane(id, 32 * h + fl));   // first hit in scan order = shortest length
         R.found = __popc(mh);
         if (MODE == BBDUK_MODE_KTRIM_L) {
             R.minLoc = 0;
@@ -581,6 +630,25 @@ __device__ __forceinline__ void record_stage(const KParams& P, const ReadScan& X
     f2 = (uint8_t)((d2 ? BBDUK_FLAG_DISCARDED : 0) | (remove ? BBDUK_FLAG_REMOVED : 0));
 }
 
+// counters (BBDukProcessorS.add, :300-342).  With rkt/xsum/outm and in-totals known, the rest follows:
+// readsOutu = readsIn - readsOutm; ktrim: basesOutu = basesIn - basesKTrimmed (every base either survives in a
+// kept pair or is counted as k-trimmed); kfilter: basesOutu = basesIn - basesOutm, filtered == removed.
+template <int MODE>
+__device__ __forceinline__ void publish_counters(const unsigned long long* s_acc, int64_t* __restrict__ counters) {
+    const unsigned long long rkt = s_acc[0], xs = s_acc[1], rm = s_acc[2], bm = s_acc[3], rin = s_acc[4], bin = s_acc[5];
+    auto add = [&](int slot, unsigned long long v) { if (v) atomicAdd((unsigned long long*)&counters[slot], v); };
+    add(BBDUK_READS_IN, rin); add(BBDUK_BASES_IN, bin);
+    add(BBDUK_READS_OUTM, rm); add(BBDUK_BASES_OUTM, bm);
+    add(BBDUK_READS_OUTU, rin - rm);
+    if (MODE != BBDUK_MODE_KFILTER) {
+        add(BBDUK_READS_KTRIMMED, rkt); add(BBDUK_BASES_KTRIMMED, xs);
+        add(BBDUK_BASES_OUTU, bin - xs);
+    } else {
+        add(BBDUK_READS_KFILTERED, rm); add(BBDUK_BASES_KFILTERED, bm);
+        add(BBDUK_BASES_OUTU, bin - bm);
+    }
+}
+
 // --------------------------------------------------------------------------------------------------
 // The batch kernel: persistent workgroups (one per CU when the LDS filter is large) walk tiles of reads.
 // Template flags strip what a configuration cannot need: SHORT (mink), FORBIDN (undefined-base resets),
@@ -590,7 +658,8 @@ __global__ __launch_bounds__(BLOCK_THREADS)
 void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
                         const int64_t n, const int64_t totalBases, const int paired,
                         int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
-                        int64_t* __restrict__ counters) {
+                        int64_t* __restrict__ counters, const int* __restrict__ slowFlag) {
+    if (*slowFlag == 0) return;                                   // every unit fits a wave's planes: the wave kernel ran
     __shared__ uint32_t s_fwd[PLANE_PAD + CAP_CHUNKS + PLANE_PAD];   // padded both ends: the plain path reads past a read's end unclamped
     __shared__ uint32_t s_cmp[PLANE_PAD + CAP_CHUNKS + PLANE_PAD];
     __shared__ uint32_t s_nm[CAP_CHUNKS / 2 + 4];
@@ -641,33 +710,8 @@ void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
             const int nchunks = (int)((B1 - A0 + 15) >> 4);
             // ---- stage: 16 bases per thread-iteration -> three bit-planes
             for (int c = tid; c < nchunks; c += BLOCK_THREADS) {
-                const int64_t a = A0 + 16LL * c;
-                uint32_t w[4];
-                if (a + 16 <= totalBases) {
-                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(bases + a));   // streamed once: keep it out of L2's way
-                    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        uint32_t x = 0;
-#pragma unroll
-                        for (int b = 0; b < 4; b++) {
-                            const int64_t p = a + 4 * q + b;
-                            if (p < totalBases) x |= (uint32_t)bases[p] << (8 * b);
-                        }
-                        w[q] = x;
-                    }
-                }
-                uint32_t code = 0, comp = 0, valid = 0;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    uint32_t c8, m8, v4;
-                    encode4(w[q], c8, m8, v4);
-                    code |= c8 << (8 * q); comp |= m8 << (8 * q); valid |= v4 << (4 * q);
-                }
-                uint32_t r = __brev(code);                          // reverse the order of the 16 symbols
-                r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+                uint32_t r, comp, valid;
+                encode_chunk(bases, A0 + 16LL * c, totalBases, r, comp, valid);
                 s_fwd[PLANE_PAD + nchunks - 1 - c] = r;
                 s_cmp[PLANE_PAD + c] = comp;
                 reinterpret_cast<uint16_t*>(s_nm)[c] = (uint16_t)(~valid & 0xFFFFu);
@@ -721,36 +765,185 @@ void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
     }
     scaf_flush(P, scaf, lane, counters);
     __syncthreads();
-    // ---- counters (BBDukProcessorS.add, :300-342).  With rkt/xsum/outm and in-totals known, the rest follows:
-    // readsOutu = readsIn - readsOutm; ktrim: basesOutu = basesIn - basesKTrimmed (every base either survives in a
-    // kept pair or is counted as k-trimmed); kfilter: basesOutu = basesIn - basesOutm, filtered == removed.
-    if (tid == 0) {
-        const unsigned long long rkt = s_acc[0], xs = s_acc[1], rm = s_acc[2], bm = s_acc[3], rin = s_acc[4], bin = s_acc[5];
-        auto add = [&](int slot, unsigned long long v) { if (v) atomicAdd((unsigned long long*)&counters[slot], v); };
-        add(BBDUK_READS_IN, rin); add(BBDUK_BASES_IN, bin);
-        add(BBDUK_READS_OUTM, rm); add(BBDUK_BASES_OUTM, bm);
-        add(BBDUK_READS_OUTU, rin - rm);
-        if (MODE != BBDUK_MODE_KFILTER) {
-            add(BBDUK_READS_KTRIMMED, rkt); add(BBDUK_BASES_KTRIMMED, xs);
-            add(BBDUK_BASES_OUTU, bin - xs);
-        } else {
-            add(BBDUK_READS_KFILTERED, rm); add(BBDUK_BASES_KFILTERED, bm);
-            add(BBDUK_BASES_OUTU, bin - bm);
-        }
+    if (tid == 0) publish_counters<MODE>(s_acc, counters);
+}
+
+// --------------------------------------------------------------------------------------------------
+// Wave-autonomous batch kernel (the fast path): every wave owns a mini-tile of MT_READS consecutive reads,
+// stages it into its private slice of LDS and scans it, with no workgroup barrier after the one that lands
+// the presence filter.  Waves of a CU therefore sit in different phases (HBM load, LDS extraction, L2 gather),
+// which is what hides the latencies; with the tile-synchronous kernel above 52 % of all wave cycles were
+// waits, much of it at barriers behind the slowest wave.  Requires every unit (pair) to fit WCAP_BASES;
+// a pre-pass (bbduk_span_kernel) raises *slowFlag otherwise and the tile kernel takes the batch instead.
+#define MT_READS     12                            // reads per wave mini-tile (even: whole pairs)
+#define WCAP_BASES   2560                          // per-wave plane capacity in bases
+#define WCAP_CHUNKS  (WCAP_BASES / 16)
+#define WPLANE_WORDS (PLANE_PAD + WCAP_CHUNKS + PLANE_PAD)
+#define WUNIT_MAX    (WCAP_BASES - 48)             // longest unit (pair) the wave kernel accepts
+
+template <int MODE, bool SHORT, bool FORBIDN, bool GENERAL>
+__global__ __launch_bounds__(BLOCK_THREADS)
+void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
+                       const int64_t n, const int64_t totalBases, const int paired,
+                       int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
+                       int64_t* __restrict__ counters, const int* __restrict__ slowFlag) {
+    __shared__ uint32_t s_wf[NWAVES][WPLANE_WORDS];
+    __shared__ uint32_t s_wc[NWAVES][WPLANE_WORDS];
+    __shared__ uint32_t s_wn[NWAVES][WCAP_CHUNKS / 2 + 4];
+    __shared__ int32_t  s_ra[NWAVES][MT_READS];
+    __shared__ int32_t  s_ri[NWAVES][MT_READS];
+    __shared__ uint32_t s_rf[NWAVES][MT_READS];
+    __shared__ unsigned long long s_acc[6];                       // rkt, basesKTrimmed, readsOutm, basesOutm, readsIn, basesIn
+    extern __shared__ uint32_t s_filt[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+    if (tid < 6) s_acc[tid] = 0;
+    if (P.ldsBits) {
+        const int words = 1 << (P.ldsBits - 5);
+        for (int w = tid; w < words; w += BLOCK_THREADS) s_filt[w] = P.ldsImage[w];
     }
+    __syncthreads();
+    if (*slowFlag != 0) return;                                   // a unit does not fit a wave's planes: tile kernel's job
+
+    uint32_t* const wf = s_wf[wave]; uint32_t* const wc = s_wc[wave]; uint32_t* const wn = s_wn[wave];
+    ScafAcc scaf; scaf_init(scaf);
+    unsigned long long tot[6] = {0, 0, 0, 0, 0, 0};
+    const int64_t nmt = (n + MT_READS - 1) / MT_READS;
+    const int64_t gw = (int64_t)blockIdx.x * NWAVES + wave, nw = (int64_t)gridDim.x * NWAVES;
+
+    unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = P.prof ? clock64() : 0;
+#define PH(i) do { if (P.prof) { const unsigned long long tn_ = clock64(); ph[i] += tn_ - tprev; tprev = tn_; } } while (0)
+    for (int64_t mt = gw; mt < nmt; mt += nw) {
+        const int64_t r0 = mt * MT_READS;
+        const int cnt = (int)min((int64_t)MT_READS, n - r0);
+        const int64_t myoff = offsets[r0 + min(lane, cnt)];
+        const int64_t O0 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(myoff >> 32)) << 32) |
+                           (uint32_t)__builtin_amdgcn_readfirstlane((int)myoff);
+        const int rel = (int)(myoff - O0);                         // lane j (<= cnt): start of read j relative to the mini-tile
+        const int relEnd = __builtin_amdgcn_readlane(rel, cnt);
+        tot[4] += (unsigned long long)cnt; tot[5] += (unsigned long long)relEnd;
+        int acc[4] = {0, 0, 0, 0};
+        PH(0);
+
+        int s = 0;
+        while (s < cnt) {
+            const int rel_s = __builtin_amdgcn_readlane(rel, s);
+            const uint64_t okm = __ballot(lane > s && lane <= cnt && (rel - rel_s) <= (WCAP_BASES - 32));
+            int fit = __popcll(okm);
+            if (paired) fit &= ~1;
+            if (fit == 0) {                                         // cannot happen when the span pre-pass ran
+                if (lane == 0) {
+                    atomicMax((unsigned long long*)&counters[BBDUK_CTR_STATUS], (unsigned long long)(-BBDUK_ERR_READ_TOO_LONG));
+                    s_ra[wave][s] = 0; s_ri[wave][s] = -1; s_rf[wave][s] = 0;
+                    if (paired && s + 1 < cnt) { s_ra[wave][s + 1] = 0; s_ri[wave][s + 1] = -1; s_rf[wave][s + 1] = 0; }
+                }
+                s += min(paired ? 2 : 1, cnt - s);
+                continue;
+            }
+            const int e = s + fit;
+            const int rel_e = __builtin_amdgcn_readlane(rel, e);
+            const int64_t B0 = O0 + rel_s;
+            const int64_t A0 = B0 & ~15LL;
+            const int lead = (int)(B0 - A0);                        // bases in front of read s inside the first chunk
+            const int nchunks = (lead + (rel_e - rel_s) + 15) >> 4;
+            // ---- stage this wave's reads: 16 bases per lane-iteration -> the wave's private bit-planes
+            for (int c = lane; c < nchunks; c += 64) {
+                uint32_t r, comp, valid;
+                encode_chunk(bases, A0 + 16LL * c, totalBases, r, comp, valid);
+                wf[PLANE_PAD + nchunks - 1 - c] = r;
+                wc[PLANE_PAD + c] = comp;
+                reinterpret_cast<uint16_t*>(wn)[c] = (uint16_t)(~valid & 0xFFFFu);
+            }
+            if (lane == 0 && (nchunks & 1)) reinterpret_cast<uint16_t*>(wn)[nchunks] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // LDS is in-order per wave; keep the compiler honest
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            PH(1);
+
+            Planes Q; Q.fwd = wf + PLANE_PAD; Q.cmp = wc + PLANE_PAD; Q.nm = wn; Q.filt = s_filt; Q.T = nchunks * 16;
+            for (int ra = s; ra < e; ra += 2) {
+                const bool hasB = (ra + 1) < e;
+                const int o0 = __builtin_amdgcn_readlane(rel, ra);
+                const int o1 = __builtin_amdgcn_readlane(rel, ra + 1);
+                const int o2 = hasB ? __builtin_amdgcn_readlane(rel, ra + 2) : o1;
+                ReadScan A, Bz;
+                read_init<MODE, SHORT, GENERAL>(P, A, o0 - rel_s + lead, o1 - o0, 0, true);
+                read_init<MODE, SHORT, GENERAL>(P, Bz, o1 - rel_s + lead, o2 - o1, paired ? 1 : 0, hasB);
+                PH(2);
+                main_scan_pair<MODE, FORBIDN, GENERAL>(P, Q, A, Bz, lane);
+                PH(3);
+                if constexpr (MODE != BBDUK_MODE_KFILTER && SHORT) {
+                    if (P.useShort) short_scan_pair<MODE, GENERAL>(P, Q, A, Bz, lane);
+                }
+                PH(4);
+                read_finish<MODE>(P, A, lane, scaf, counters);
+                read_finish<MODE>(P, Bz, lane, scaf, counters);
+                uint8_t f1 = 0, f2 = 0, f3 = 0, f4 = 0;
+                if (paired) record_stage<MODE>(P, A, &Bz, acc, f1, f2);
+                else {
+                    record_stage<MODE>(P, A, nullptr, acc, f1, f3);
+                    if (hasB) record_stage<MODE>(P, Bz, nullptr, acc, f2, f4);
+                }
+                PH(5);
+                if (lane == 0) {
+                    s_ra[wave][ra] = A.a; s_ri[wave][ra] = A.id; s_rf[wave][ra] = f1;
+                    if (hasB) { s_ra[wave][ra + 1] = Bz.a; s_ri[wave][ra + 1] = Bz.id; s_rf[wave][ra + 1] = f2; }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // scans done before the planes are overwritten
+            __builtin_amdgcn_wave_barrier();
+            s = e;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < cnt) {
+            outA[r0 + lane] = s_ra[wave][lane];
+            outId[r0 + lane] = s_ri[wave][lane];
+            outFlags[r0 + lane] = (uint8_t)s_rf[wave][lane];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) tot[q] += (unsigned long long)acc[q];
+        PH(6);
+    }
+#undef PH
+    if (P.prof && lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) atomicAdd(&P.profOut[q], ph[q]);
+    }
+    scaf_flush(P, scaf, lane, counters);
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) if (tot[q]) atomicAdd(&s_acc[q], tot[q]);
+    }
+    __syncthreads();
+    if (tid == 0) publish_counters<MODE>(s_acc, counters);
+}
+
+// Pre-pass: does every unit (mate pair, or single read) fit a wave's planes?  One thread per unit.
+__global__ void bbduk_span_kernel(const int64_t* __restrict__ offsets, const int64_t n, const int paired, int* __restrict__ slowFlag) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int step = paired ? 2 : 1;
+    const int64_t units = n / step;
+    bool bad = false;
+    for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += stride)
+        bad |= (offsets[u * step + step] - offsets[u * step]) > (int64_t)WUNIT_MAX;
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(slowFlag, 1);
 }
 
 // runtime -> template dispatch
 typedef void (*batch_kernel_t)(const KParams, const uint8_t*, const int64_t*, const int64_t, const int64_t, const int,
-                               int32_t*, int32_t*, uint8_t*, int64_t*);
+                               int32_t*, int32_t*, uint8_t*, int64_t*, const int*);
+struct KernelPair { batch_kernel_t wave, tile; };
+template <int MODE, bool SHORT, bool FORBIDN, bool GENERAL>
+static KernelPair kpair() { return KernelPair{bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL>, bbduk_batch_kernel<MODE, SHORT, FORBIDN, GENERAL>}; }
 template <int MODE>
-static batch_kernel_t pick_kernel_mode(bool general, bool useShort, bool forbidN) {
-    if (general) return bbduk_batch_kernel<MODE, true, true, true>;
-    if (MODE == BBDUK_MODE_KFILTER) return forbidN ? bbduk_batch_kernel<MODE, false, true, false> : bbduk_batch_kernel<MODE, false, false, false>;
-    if (useShort) return forbidN ? bbduk_batch_kernel<MODE, true, true, false> : bbduk_batch_kernel<MODE, true, false, false>;
-    return forbidN ? bbduk_batch_kernel<MODE, false, true, false> : bbduk_batch_kernel<MODE, false, false, false>;
+static KernelPair pick_kernel_mode(bool general, bool useShort, bool forbidN) {
+    if (general) return kpair<MODE, true, true, true>();
+    if (MODE == BBDUK_MODE_KFILTER) return forbidN ? kpair<MODE, false, true, false>() : kpair<MODE, false, false, false>();
+    if (useShort) return forbidN ? kpair<MODE, true, true, false>() : kpair<MODE, true, false, false>();
+    return forbidN ? kpair<MODE, false, true, false>() : kpair<MODE, false, false, false>();
 }
-static batch_kernel_t pick_kernel(const KParams& K) {
+static KernelPair pick_kernel(const KParams& K) {
     const bool general = K.qhdist > 0 || K.qhdist2 > 0 || K.restrictLeft > 0 || K.restrictRight > 0 || K.skipR1 || K.skipR2 || !K.rcomp;
     if (K.mode == BBDUK_MODE_KFILTER) return pick_kernel_mode<BBDUK_MODE_KFILTER>(general, false, K.forbidNs != 0);
     if (K.mode == BBDUK_MODE_KTRIM_L) return pick_kernel_mode<BBDUK_MODE_KTRIM_L>(general, K.useShort != 0, K.forbidNs != 0);
@@ -793,6 +986,8 @@ struct bbduk_handle {
     int64_t nkeys = 0;
     uint32_t* d_tags = nullptr; uint64_t* d_bkeys = nullptr; int32_t* d_bvals = nullptr; uint64_t nbuckets = 0; int bucketBits = 0;
     uint32_t* d_ldsImage = nullptr; int ldsBits = 0;
+    int* d_slowFlag = nullptr;
+    unsigned long long* d_prof = nullptr;
     // host-operator staging
     uint8_t* d_bases = nullptr; size_t cap_bases = 0;
     int64_t* d_off = nullptr;   size_t cap_reads = 0;
@@ -834,7 +1029,8 @@ extern "C" int bbduk_create(const bbduk_params* p, bbduk_handle** out) {
     if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return BBDUK_ERR_DEVICE; }
     const size_t nc = (size_t)(BBDUK_NCOUNTERS + 2 * p->numScaffolds);
     if (hipMalloc(&h->d_counters, nc * sizeof(int64_t)) != hipSuccess ||
-        hipMemset(h->d_counters, 0, nc * sizeof(int64_t)) != hipSuccess) { hipStreamDestroy(h->stream); delete h; return BBDUK_ERR_DEVICE; }
+        hipMemset(h->d_counters, 0, nc * sizeof(int64_t)) != hipSuccess || hipMalloc(&h->d_slowFlag, sizeof(int)) != hipSuccess ||
+        hipMalloc(&h->d_prof, 16 * sizeof(unsigned long long)) != hipSuccess || hipMemset(h->d_prof, 0, 128) != hipSuccess) { hipStreamDestroy(h->stream); delete h; return BBDUK_ERR_DEVICE; }
     *out = h;
     return BBDUK_OK;
 }
@@ -843,7 +1039,15 @@ extern "C" int bbduk_destroy(bbduk_handle* h) {
     if (!h) return BBDUK_ERR_ARG;
     hipSetDevice(h->p.device);
     hipFree(h->d_tags); hipFree(h->d_bkeys); hipFree(h->d_bvals); hipFree(h->d_bases); hipFree(h->d_off);
-    hipFree(h->d_ldsImage);
+    if (getenv("BBDUK_PROF") && h->d_prof) {
+        unsigned long long ph[8];
+        if (hipMemcpy(ph, h->d_prof, sizeof ph, hipMemcpyDeviceToHost) == hipSuccess) {
+            unsigned long long t = 0; for (int q = 0; q < 8; q++) t += ph[q];
+            fprintf(stderr, "[bbduk prof] wave-cycle share: offsets %.1f%% stage %.1f%% init %.1f%% main %.1f%% short %.1f%% finish %.1f%% writeback %.1f%% (total %.3g wave-cycles)\n",
+                    100.0 * ph[0] / t, 100.0 * ph[1] / t, 100.0 * ph[2] / t, 100.0 * ph[3] / t, 100.0 * ph[4] / t, 100.0 * ph[5] / t, 100.0 * ph[6] / t, (double)t);
+        }
+    }
+    hipFree(h->d_ldsImage); hipFree(h->d_slowFlag); hipFree(h->d_prof);
     hipFree(h->d_a); hipFree(h->d_id); hipFree(h->d_fl); hipFree(h->d_counters);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -886,7 +1090,7 @@ extern "C" int bbduk_finalize_table(bbduk_handle* h) {
     while (bbits < 32 && (1ULL << bbits) < (uint64_t)n) bbits++;
     if (const char* e = getenv("BBDUK_BUCKET_BITS")) { const int v = atoi(e); if (v >= 4 && v <= 32) bbits = v; }
     const uint64_t nb = 1ULL << bbits;
-    if (4 * nb < (uint64_t)n + nb / 8) return fail(h, BBDUK_ERR_ARG, "too many keys for the bucket index");
+    if (4 * nb < (uint64_t)n + nb / 8 || 4 * nb > (1ULL << 31)) return fail(h, BBDUK_ERR_ARG, "too many keys for the bucket index");
     std::vector<uint32_t> tg(nb, 0u);
     std::vector<uint64_t> bk(4 * nb, EMPTY_KEY);
     std::vector<int32_t> bv(4 * nb, 0);
@@ -963,6 +1167,7 @@ static KParams make_kparams(const bbduk_handle* h) {
     K.tags = h->d_tags; K.bkeys = h->d_bkeys; K.bvals = h->d_bvals; K.bucketMask = (uint32_t)(h->nbuckets - 1); K.bucketBits = h->bucketBits;
     K.storedKmers = h->nkeys;
     K.ldsImage = h->d_ldsImage; K.ldsBits = h->ldsBits;
+    K.prof = getenv("BBDUK_PROF") ? 1 : 0; K.profOut = h->d_prof;
     return K;
 }
 
@@ -980,16 +1185,28 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     const KParams K = make_kparams(h);
     const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
     const size_t dynLds = h->ldsBits ? ((size_t)1 << (h->ldsBits - 3)) : 0;
-    const batch_kernel_t kern = pick_kernel(K);
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
-    const int perCU = (dynLds + 32768 <= 80 * 1024) ? 2 : 1;      // 1024-thread workgroups: at most 2 per CU
-    const int grid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU * perCU);
+    const KernelPair kp = pick_kernel(K);
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.tile), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
+    // pre-pass: if some pair is longer than a wave's planes the tile kernel takes the whole batch, else the wave kernel
+    HIP_TRY(h, hipMemsetAsync(h->d_slowFlag, 0, sizeof(int), st));
+    if (getenv("BBDUK_FORCE_TILE")) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(h->d_slowFlag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }
+    else {
+        const int64_t units = paired ? n / 2 : n;
+        const int sgrid = (int)std::min<int64_t>((units + 255) / 256, (int64_t)h->numCU * 8);
+        bbduk_span_kernel<<<dim3(std::max(sgrid, 1)), dim3(256), 0, st>>>(d_offsets, n, (int)paired, h->d_slowFlag);
+    }
+    const int perCU = 1;                                            // 1024-thread workgroups; VGPR budget admits one per CU
+    const int64_t nmt = (n + MT_READS - 1) / MT_READS;
+    const int wgrid = (int)std::min<int64_t>((nmt + NWAVES - 1) / NWAVES, (int64_t)h->numCU * perCU);
+    const int tgrid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU * perCU);
     if (getenv("BBDUK_VERBOSE")) {
         int occ = -1;
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), BLOCK_THREADS, dynLds);
-        fprintf(stderr, "[bbduk] grid=%d block=%d dynLds=%zu perCU=%d occupancyAPI=%d numCU=%d\n", grid, BLOCK_THREADS, dynLds, perCU, occ, h->numCU);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kp.wave), BLOCK_THREADS, dynLds);
+        fprintf(stderr, "[bbduk] wave grid=%d tile grid=%d block=%d dynLds=%zu occupancyAPI=%d numCU=%d\n", wgrid, tgrid, BLOCK_THREADS, dynLds, occ, h->numCU);
     }
-    kern<<<dim3(grid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters);
+    kp.wave<<<dim3(wgrid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, h->d_slowFlag);
+    kp.tile<<<dim3(tgrid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, h->d_slowFlag);
     HIP_TRY(h, hipGetLastError());
     return BBDUK_OK;
 }

@@ -143,6 +143,7 @@ def main():
                                "kind": "port", "sample": "first %d reads of the same synthetic workload, %.1f s, "
                                "oracle/bbduk_oracle.c with %d pthreads (match only, no I/O)" % (m, cpu_dt, cores)}
         out["parity_sample_ok"] = ok
+    duk.close()
     if rank == 0:
         print(json.dumps(out))
     if distributed:

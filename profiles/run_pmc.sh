@@ -17,7 +17,7 @@ import csv,glob,collections
 agg=collections.defaultdict(list)
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "bbduk_batch" in r["Kernel_Name"]:
+        if "bbduk_wave" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(agg): print("%-28s n=%d mean=%.6g" % (k, len(agg[k]), sum(agg[k])/len(agg[k])))
 PY
