@@ -271,32 +271,82 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 
 struct Planes { const uint32_t* fwd; const uint32_t* cmp; const uint32_t* nm; const uint32_t* filt; int T; };
 
-// Wave-uniform state of one read's scan (all fields live in SGPRs).
+// Wave-uniform state of one read's scan (all fields live in SGPRs).  Only raw scan facts are kept here; the
+// trim / id arithmetic happens afterwards in finish_read(), which the wave kernel runs data-parallel over the
+// reads of a mini-tile (one lane per read) and the tile kernel runs per read.
 struct ReadScan {
-    int base0, L, start, stop;          // base0 = index of the read's first base in the tile planes
+    int base0, L, start, stop;          // base0 = index of the read's first base in the planes
     bool scan;                          // false: the reference returns 0 before scanning (too short, skipR1/2, no k-mers)
-    int found, iFirst, iLast, id0;      // main-scan result
-    int minLoc, minLocEx, maxLoc, maxLocEx;
-    int a, id, newLen;                  // operator outputs: ktrim x / countSetKmers found, id0 / exit id, r.length() after
+    int found, iFirst, iLast;           // main scan: hits seen, first / last hit position (iFirst==0 marks the kfilter exit)
+    int ref;                            // ref (see ref_to_id) of the hit whose id the reference reports
+    int shortFl, shortLl;               // short k-mer scan: first / last hit lane (length index); shortFl<0: none
 };
 
 template <int MODE, bool SHORT, bool GENERAL>
-__device__ __forceinline__ void read_init(const KParams& P, ReadScan& R, int base0, int L, int pairnum, bool present) {
-    R.base0 = base0; R.L = L;
-    R.found = 0; R.iFirst = BIGLOC; R.iLast = -1; R.id0 = -1;
-    R.minLoc = BIGLOC; R.minLocEx = BIGLOC; R.maxLoc = -1; R.maxLocEx = -1;
-    R.a = 0; R.id = -1; R.newLen = L;
+__device__ __forceinline__ bool scan_due(const KParams& P, int L, int pairnum, bool present) {
     const int k = P.k;
     bool s = present && P.storedKmers > 0;
     if (MODE == BBDUK_MODE_KFILTER) s = s && (L >= k);                                     // BBDukProcessorS.java:1535
     else s = s && (L >= max(1, (SHORT && P.useShort) ? min(k, P.mink) : k));               // :1995
-    R.start = 0; R.stop = L;
     if constexpr (GENERAL) {
         if ((P.skipR1 && pairnum == 0) || (P.skipR2 && pairnum == 1)) s = false;           // :1536, :1996
-        R.start = (P.restrictRight < 1 ? 0 : max(0, L - P.restrictRight));                 // :1808-1809, :1542-1543
-        R.stop  = (P.restrictLeft  < 1 ? L : min(L, P.restrictLeft));
     }
-    R.scan = s;
+    return s;
+}
+template <bool GENERAL> __device__ __forceinline__ int span_start(const KParams& P, int L) {      // :1808-1809, :1542-1543
+    if constexpr (GENERAL) return (P.restrictRight < 1 ? 0 : max(0, L - P.restrictRight));
+    return 0;
+}
+template <bool GENERAL> __device__ __forceinline__ int span_stop(const KParams& P, int L) {
+    if constexpr (GENERAL) return (P.restrictLeft < 1 ? L : min(L, P.restrictLeft));
+    return L;
+}
+template <int MODE, bool SHORT, bool GENERAL>
+__device__ __forceinline__ void read_init(const KParams& P, ReadScan& R, int base0, int L, int pairnum, bool present) {
+    R.base0 = base0; R.L = L;
+    R.found = 0; R.iFirst = BIGLOC; R.iLast = -1; R.ref = -1; R.shortFl = -1; R.shortLl = -1;
+    R.start = span_start<GENERAL>(P, L); R.stop = span_stop<GENERAL>(P, L);
+    R.scan = scan_due<MODE, SHORT, GENERAL>(P, L, pairnum, present);
+}
+
+// From the raw scan facts of one read to the operator's outputs (works on wave-uniform or per-lane values alike).
+// ktrim: bbduk/BBDukProcessorS.java:2031-2032, 2108-2139 + shared/TrimRead.java:273-345; kfilter: :1575-1591.
+// a = ktrim x | countSetKmers return; ref = ref of the credited scaffold or -1; hit = a scaffold counter is due.
+template <int MODE>
+__device__ __forceinline__ void finish_read(const KParams& P, const int L, const int start, const int stop, const int found,
+                                            const int iFirst, const int iLast, const int shortFl, const int shortLl, const int refIn,
+                                            int& a, int& newLen, int& ref, bool& hit) {
+    a = 0; newLen = L; ref = -1; hit = false;
+    if (MODE == BBDUK_MODE_KFILTER) {
+        a = found;
+        if (iFirst == 0) { ref = refIn; hit = true; }                   // early exit taken
+        return;
+    }
+    const int k = P.k;
+    int minLoc = BIGLOC, minLocEx = BIGLOC, maxLoc = -1, maxLocEx = -1;
+    if (found > 0 && shortFl < 0) { minLoc = iFirst - k + 1; maxLoc = iLast; minLocEx = minLoc + k; maxLocEx = maxLoc - k; }
+    if (shortFl >= 0) {                                                  // short k-mer hits (only when the main scan found none)
+        if (MODE == BBDUK_MODE_KTRIM_L) {
+            minLoc = 0; minLocEx = start + (P.mink + shortFl); maxLoc = start + (P.mink + shortLl) - 1; maxLocEx = 0;
+        } else {
+            minLoc = stop - (P.mink + shortLl); minLocEx = L; maxLoc = L - 1; maxLocEx = stop - (P.mink + shortFl) - 1;
+        }
+    }
+    if (found == 0) return;                                              // :2108
+    hit = true; ref = refIn;
+    if (P.trimPad != 0) {                                                // :2121-2126
+        maxLoc = imid(0, maxLoc + P.trimPad, L);
+        minLoc = imid(0, minLoc - P.trimPad, L);
+        maxLocEx = imid(0, maxLocEx + P.trimPad, L);
+        minLocEx = imid(0, minLocEx - P.trimPad, L);
+    }
+    if (MODE == BBDUK_MODE_KTRIM_L) {     // trimToPosition(r, leftLoc, len-1, 1)
+        const int leftLoc = P.ktrimExclusive ? maxLocEx + 1 : maxLoc + 1;
+        a = trim_by_amount(L, leftLoc, 0, 1, newLen);
+    } else {                              // trimToPosition(r, 0, rightLoc, 1)
+        const int rightLoc = P.ktrimExclusive ? minLocEx - 1 : minLoc - 1;
+        a = trim_by_amount(L, 0, L - rightLoc - 1, 1, newLen);
+    }
 }
 
 // ---- main scan -------------------------------------------------------------------------------------
@@ -421,7 +471,7 @@ __device__ __forceinline__ bool fold_hits(const KParams& P, ReadScan& R, int& fo
     if (!m) return false;
     if (MODE != BBDUK_MODE_KFILTER) {
         const int fl = __ffsll((unsigned long long)m) - 1, ll = 63 - __clzll((long long)m);
-        if (found == 0) { R.iFirst = ibase + fl; R.id0 = ref_to_id(P, __builtin_amdgcn_readlane(ref, fl)); }
+        if (found == 0) { R.iFirst = ibase + fl; R.ref = __builtin_amdgcn_readlane(ref, fl); }
         R.iLast = ibase + ll;
         found += __popcll(m);
         return MODE == BBDUK_MODE_KTRIM_R;                       // only minLoc/id0 of the first hit are used
@@ -431,7 +481,7 @@ __device__ __forceinline__ bool fold_hits(const KParams& P, ReadScan& R, int& fo
             uint64_t mm = m;
             for (int q = found; q < P.maxBadKmers; q++) mm &= mm - 1;
             const int fl = __ffsll((unsigned long long)mm) - 1;
-            R.id0 = ref_to_id(P, __builtin_amdgcn_readlane(ref, fl));
+            R.ref = __builtin_amdgcn_readlane(ref, fl);
             found = P.maxBadKmers + 1;
             R.iFirst = 0;                                        // marks the early exit
             return true;
@@ -468,11 +518,6 @@ __device__ __forceinline__ void main_scan_pair(const KParams& P, const Planes& Q
         }
     }
     A.found = foundA; B.found = foundB;
-    if (MODE != BBDUK_MODE_KFILTER) {
-        const int k = P.k;
-        if (foundA > 0) { A.minLoc = A.iFirst - k + 1; A.maxLoc = A.iLast; A.minLocEx = A.minLoc + k; A.maxLocEx = A.maxLoc - k; }
-        if (foundB > 0) { B.minLoc = B.iFirst - k + 1; B.maxLoc = B.iLast; B.minLocEx = B.minLoc + k; B.maxLocEx = B.maxLoc - k; }
-    }
 }
 
 // Short k-mer scans of two reads in one pass: lanes 0-31 serve read A, lanes 32-63 read B, one lane per
@@ -517,19 +562,9 @@ __device__ __forceinline__ void short_scan_pair(const KParams& P, const Planes& 
         if (!mh) continue;
         ReadScan& R = h ? B : A;
         const int fl = __ffs(mh) - 1, ll = 31 - __clz(mh);
-        R.id0 = ref_to_id(P, __builtin_amdgcn_readlane(id, 32 * h + fl));   // first hit in scan order = shortest length
+        R.ref = __builtin_amdgcn_readlane(id, 32 * h + fl);       // first hit in scan order = shortest length
         R.found = __popc(mh);
-        if (MODE == BBDUK_MODE_KTRIM_L) {
-            R.minLoc = 0;
-            R.minLocEx = R.start + (P.mink + fl);                // min over hits of i+1
-            R.maxLoc = R.start + (P.mink + ll) - 1;              // max over hits of i
-            R.maxLocEx = 0;                                      // max(-1, 0)
-        } else {
-            R.minLoc = R.stop - (P.mink + ll);                   // the last hit overwrites: longest match
-            R.minLocEx = R.L;                                    // min(BIG, bases.length)
-            R.maxLoc = R.L - 1;
-            R.maxLocEx = R.stop - (P.mink + fl) - 1;             // max over hits of i-1
-        }
+        R.shortFl = fl; R.shortLl = ll;
     }
 }
 
@@ -552,57 +587,39 @@ __device__ __forceinline__ void scaf_flush(const KParams& P, ScafAcc& S, const i
     scaf_emit(P, S.i2, S.r2, S.b2, lane, counters); scaf_emit(P, S.i3, S.r3, S.b3, lane, counters);
     scaf_init(S);
 }
-__device__ __forceinline__ void scaf_add(const KParams& P, ScafAcc& S, int id, int L, const int lane, int64_t* __restrict__ counters) {
-    if (id == S.i0) { S.r0++; S.b0 += L; }
-    else if (id == S.i1) { S.r1++; S.b1 += L; }
-    else if (id == S.i2) { S.r2++; S.b2 += L; }
-    else if (id == S.i3) { S.r3++; S.b3 += L; }
+__device__ __forceinline__ void scaf_add_n(const KParams& P, ScafAcc& S, int id, int nreads, int L, const int lane, int64_t* __restrict__ counters) {
+    if (id == S.i0) { S.r0 += nreads; S.b0 += L; }
+    else if (id == S.i1) { S.r1 += nreads; S.b1 += L; }
+    else if (id == S.i2) { S.r2 += nreads; S.b2 += L; }
+    else if (id == S.i3) { S.r3 += nreads; S.b3 += L; }
     else {                                                       // evict the oldest entry, insert in front
         scaf_emit(P, S.i3, S.r3, S.b3, lane, counters);
         S.i3 = S.i2; S.r3 = S.r2; S.b3 = S.b2;
         S.i2 = S.i1; S.r2 = S.r1; S.b2 = S.b1;
         S.i1 = S.i0; S.r1 = S.r0; S.b1 = S.b0;
-        S.i0 = id; S.r0 = 1; S.b0 = L;
+        S.i0 = id; S.r0 = nreads; S.b0 = L;
     }
 }
+__device__ __forceinline__ void scaf_add(const KParams& P, ScafAcc& S, int id, int L, const int lane, int64_t* __restrict__ counters) {
+    scaf_add_n(P, S, id, 1, L, lane, counters);
+}
 
-// After the scans: scaffold counters, trimPad, trimToPosition / countSetKmers return value.
+// Scalar (per-read) finish used by the tile kernel: outputs + scaffold counters.
+struct ReadOut { int L, a, id, newLen; };
 template <int MODE>
-__device__ __forceinline__ void read_finish(const KParams& P, ReadScan& R, const int lane, ScafAcc& S, int64_t* __restrict__ counters) {
+__device__ __forceinline__ void read_finish(const KParams& P, const ReadScan& R, ReadOut& O, const int lane, ScafAcc& S, int64_t* __restrict__ counters) {
+    O.L = R.L; O.a = 0; O.id = -1; O.newLen = R.L;
     if (!R.scan) return;
-    const int L = R.L;
-    if (MODE == BBDUK_MODE_KFILTER) {
-        R.a = R.found;
-        if (R.iFirst == 0) {                                     // early exit taken (BBDukProcessorS.java:1575-1586)
-            R.id = R.id0;
-            scaf_add(P, S, R.id0, L, lane, counters);
-        }
-        return;
-    }
-    if (R.found == 0) return;                                    // :2108
-    scaf_add(P, S, R.id0, L, lane, counters);                    // :2111-2119
-    int minLoc = R.minLoc, minLocEx = R.minLocEx, maxLoc = R.maxLoc, maxLocEx = R.maxLocEx;
-    if (P.trimPad != 0) {                                        // :2121-2126
-        maxLoc = imid(0, maxLoc + P.trimPad, L);
-        minLoc = imid(0, minLoc - P.trimPad, L);
-        maxLocEx = imid(0, maxLocEx + P.trimPad, L);
-        minLocEx = imid(0, minLocEx - P.trimPad, L);
-    }
-    R.id = R.id0;
-    if (MODE == BBDUK_MODE_KTRIM_L) {     // trimToPosition(r, leftLoc, len-1, 1)  (shared/TrimRead.java:273-276)
-        const int leftLoc = P.ktrimExclusive ? maxLocEx + 1 : maxLoc + 1;
-        R.a = trim_by_amount(L, leftLoc, 0, 1, R.newLen);
-    } else {                              // trimToPosition(r, 0, rightLoc, 1)
-        const int rightLoc = P.ktrimExclusive ? minLocEx - 1 : minLoc - 1;
-        R.a = trim_by_amount(L, 0, L - rightLoc - 1, 1, R.newLen);
-    }
+    int ref; bool hit;
+    finish_read<MODE>(P, R.L, R.start, R.stop, R.found, R.iFirst, R.iLast, R.shortFl, R.shortLl, R.ref, O.a, O.newLen, ref, hit);
+    if (hit) { O.id = ref_to_id(P, ref); scaf_add(P, S, O.id, R.L, lane, counters); }
 }
 
 // One logical record (a pair, or a single read): discard / remove decision and the additive counters.
 // bbduk/BBDukProcessorS.java:807-818, 948-1093, 1431-1443, 1464-1493.  acc[0]=readsKTrimmed acc[1]=basesKTrimmed
 // acc[2]=readsOutm acc[3]=basesOutm; the other counters follow from these and readsIn/basesIn (see kernel end).
 template <int MODE>
-__device__ __forceinline__ void record_stage(const KParams& P, const ReadScan& X, const ReadScan* Y, int* acc, uint8_t& f1, uint8_t& f2) {
+__device__ __forceinline__ void record_stage(const KParams& P, const ReadOut& X, const ReadOut* Y, int* acc, uint8_t& f1, uint8_t& f2) {
     const bool two = (Y != nullptr);
     const int l1 = X.L, l2 = two ? Y->L : 0;
     const int n1 = X.newLen, n2 = two ? Y->newLen : 0;
@@ -736,17 +753,18 @@ void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
                 if constexpr (MODE != BBDUK_MODE_KFILTER && SHORT) {
                     if (P.useShort) short_scan_pair<MODE, GENERAL>(P, Q, A, Bz, lane);
                 }
-                read_finish<MODE>(P, A, lane, scaf, counters);
-                read_finish<MODE>(P, Bz, lane, scaf, counters);
+                ReadOut OA, OB;
+                read_finish<MODE>(P, A, OA, lane, scaf, counters);
+                read_finish<MODE>(P, Bz, OB, lane, scaf, counters);
                 uint8_t f1 = 0, f2 = 0, f3 = 0, f4 = 0;
-                if (paired) record_stage<MODE>(P, A, &Bz, acc, f1, f2);
+                if (paired) record_stage<MODE>(P, OA, &OB, acc, f1, f2);
                 else {
-                    record_stage<MODE>(P, A, nullptr, acc, f1, f3);
-                    if (hasB) record_stage<MODE>(P, Bz, nullptr, acc, f2, f4);
+                    record_stage<MODE>(P, OA, nullptr, acc, f1, f3);
+                    if (hasB) record_stage<MODE>(P, OB, nullptr, acc, f2, f4);
                 }
                 if (lane == 0) {
-                    s_a[ra] = A.a; s_id[ra] = A.id; s_fl[ra] = f1;
-                    if (hasB) { s_a[ra + 1] = Bz.a; s_id[ra + 1] = Bz.id; s_fl[ra + 1] = f2; }
+                    s_a[ra] = OA.a; s_id[ra] = OA.id; s_fl[ra] = f1;
+                    if (hasB) { s_a[ra + 1] = OB.a; s_id[ra + 1] = OB.id; s_fl[ra + 1] = f2; }
                 }
             }
             __syncthreads();
@@ -781,6 +799,13 @@ void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
 #define WPLANE_WORDS (PLANE_PAD + WCAP_CHUNKS + PLANE_PAD)
 #define WUNIT_MAX    (WCAP_BASES - 48)             // longest unit (pair) the wave kernel accepts
 
+// sum of v over the lanes of a wave, returned wave-uniform
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
 template <int MODE, bool SHORT, bool FORBIDN, bool GENERAL>
 __global__ __launch_bounds__(BLOCK_THREADS)
 void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
@@ -790,9 +815,6 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
     __shared__ uint32_t s_wf[NWAVES][WPLANE_WORDS];
     __shared__ uint32_t s_wc[NWAVES][WPLANE_WORDS];
     __shared__ uint32_t s_wn[NWAVES][WCAP_CHUNKS / 2 + 4];
-    __shared__ int32_t  s_ra[NWAVES][MT_READS];
-    __shared__ int32_t  s_ri[NWAVES][MT_READS];
-    __shared__ uint32_t s_rf[NWAVES][MT_READS];
     __shared__ unsigned long long s_acc[6];                       // rkt, basesKTrimmed, readsOutm, basesOutm, readsIn, basesIn
     extern __shared__ uint32_t s_filt[];
 
@@ -807,13 +829,12 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
 
     uint32_t* const wf = s_wf[wave]; uint32_t* const wc = s_wc[wave]; uint32_t* const wn = s_wn[wave];
     ScafAcc scaf; scaf_init(scaf);
-    unsigned long long tot[6] = {0, 0, 0, 0, 0, 0};
+    // per-lane partial sums (lane j accumulates what read j of every mini-tile contributes), reduced once at the end
+    unsigned long long vRkt = 0, vXs = 0, vRm = 0, vBm = 0;
+    unsigned long long sIn = 0, sBin = 0;                         // wave-uniform: reads / bases seen
     const int64_t nmt = (n + MT_READS - 1) / MT_READS;
     const int64_t gw = (int64_t)blockIdx.x * NWAVES + wave, nw = (int64_t)gridDim.x * NWAVES;
 
-    unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tprev = P.prof ? clock64() : 0;
-#define PH(i) do { if (P.prof) { const unsigned long long tn_ = clock64(); ph[i] += tn_ - tprev; tprev = tn_; } } while (0)
     for (int64_t mt = gw; mt < nmt; mt += nw) {
         const int64_t r0 = mt * MT_READS;
         const int cnt = (int)min((int64_t)MT_READS, n - r0);
@@ -822,9 +843,16 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                            (uint32_t)__builtin_amdgcn_readfirstlane((int)myoff);
         const int rel = (int)(myoff - O0);                         // lane j (<= cnt): start of read j relative to the mini-tile
         const int relEnd = __builtin_amdgcn_readlane(rel, cnt);
-        tot[4] += (unsigned long long)cnt; tot[5] += (unsigned long long)relEnd;
-        int acc[4] = {0, 0, 0, 0};
-        PH(0);
+        sIn += (unsigned long long)cnt; sBin += (unsigned long long)relEnd;
+        // per-lane view of "my read" (lane j < cnt)
+        const int vL = __shfl_down(rel, 1) - rel;                  // length of read j
+        const bool mine = lane < cnt;
+        const int vPairnum = paired ? (lane & 1) : 0;
+        const bool vScan = scan_due<MODE, SHORT, GENERAL>(P, vL, vPairnum, mine);
+        const uint64_t scanMask = __ballot(vScan);
+        const int vStart = span_start<GENERAL>(P, vL), vStop = span_stop<GENERAL>(P, vL);
+        // raw scan facts of my read, filled in by v_writelane as the pairs are scanned
+        int vFound = 0, vFirst = BIGLOC, vLast = -1, vRef = -1, vSFl = -1, vSLl = -1;
 
         int s = 0;
         while (s < cnt) {
@@ -833,11 +861,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
             int fit = __popcll(okm);
             if (paired) fit &= ~1;
             if (fit == 0) {                                         // cannot happen when the span pre-pass ran
-                if (lane == 0) {
-                    atomicMax((unsigned long long*)&counters[BBDUK_CTR_STATUS], (unsigned long long)(-BBDUK_ERR_READ_TOO_LONG));
-                    s_ra[wave][s] = 0; s_ri[wave][s] = -1; s_rf[wave][s] = 0;
-                    if (paired && s + 1 < cnt) { s_ra[wave][s + 1] = 0; s_ri[wave][s + 1] = -1; s_rf[wave][s + 1] = 0; }
-                }
+                if (lane == 0) atomicMax((unsigned long long*)&counters[BBDUK_CTR_STATUS], (unsigned long long)(-BBDUK_ERR_READ_TOO_LONG));
                 s += min(paired ? 2 : 1, cnt - s);
                 continue;
             }
@@ -859,61 +883,93 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // LDS is in-order per wave; keep the compiler honest
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            PH(1);
 
             Planes Q; Q.fwd = wf + PLANE_PAD; Q.cmp = wc + PLANE_PAD; Q.nm = wn; Q.filt = s_filt; Q.T = nchunks * 16;
+            const int origin = lead - rel_s;                        // plane index of a base = origin + (its offset in the mini-tile)
             for (int ra = s; ra < e; ra += 2) {
                 const bool hasB = (ra + 1) < e;
-                const int o0 = __builtin_amdgcn_readlane(rel, ra);
-                const int o1 = __builtin_amdgcn_readlane(rel, ra + 1);
-                const int o2 = hasB ? __builtin_amdgcn_readlane(rel, ra + 2) : o1;
                 ReadScan A, Bz;
-                read_init<MODE, SHORT, GENERAL>(P, A, o0 - rel_s + lead, o1 - o0, 0, true);
-                read_init<MODE, SHORT, GENERAL>(P, Bz, o1 - rel_s + lead, o2 - o1, paired ? 1 : 0, hasB);
-                PH(2);
+                A.base0 = origin + __builtin_amdgcn_readlane(rel, ra);
+                A.L = __builtin_amdgcn_readlane(vL, ra);
+                A.scan = (scanMask >> ra) & 1;
+                Bz.base0 = origin + __builtin_amdgcn_readlane(rel, ra + 1);
+                Bz.L = hasB ? __builtin_amdgcn_readlane(vL, ra + 1) : 0;
+                Bz.scan = hasB && ((scanMask >> (ra + 1)) & 1);
+                A.start = span_start<GENERAL>(P, A.L); A.stop = span_stop<GENERAL>(P, A.L);
+                Bz.start = span_start<GENERAL>(P, Bz.L); Bz.stop = span_stop<GENERAL>(P, Bz.L);
+                A.found = 0; A.iFirst = BIGLOC; A.iLast = -1; A.ref = -1; A.shortFl = -1; A.shortLl = -1;
+                Bz.found = 0; Bz.iFirst = BIGLOC; Bz.iLast = -1; Bz.ref = -1; Bz.shortFl = -1; Bz.shortLl = -1;
                 main_scan_pair<MODE, FORBIDN, GENERAL>(P, Q, A, Bz, lane);
-                PH(3);
                 if constexpr (MODE != BBDUK_MODE_KFILTER && SHORT) {
                     if (P.useShort) short_scan_pair<MODE, GENERAL>(P, Q, A, Bz, lane);
                 }
-                PH(4);
-                read_finish<MODE>(P, A, lane, scaf, counters);
-                read_finish<MODE>(P, Bz, lane, scaf, counters);
-                uint8_t f1 = 0, f2 = 0, f3 = 0, f4 = 0;
-                if (paired) record_stage<MODE>(P, A, &Bz, acc, f1, f2);
-                else {
-                    record_stage<MODE>(P, A, nullptr, acc, f1, f3);
-                    if (hasB) record_stage<MODE>(P, Bz, nullptr, acc, f2, f4);
+                if (A.found) {                                      // hand the facts to lane ra (most reads have none)
+                    vFound = (lane == ra) ? A.found : vFound; vFirst = (lane == ra) ? A.iFirst : vFirst;
+                    vLast = (lane == ra) ? A.iLast : vLast;   vRef = (lane == ra) ? A.ref : vRef;
+                    vSFl = (lane == ra) ? A.shortFl : vSFl;   vSLl = (lane == ra) ? A.shortLl : vSLl;
                 }
-                PH(5);
-                if (lane == 0) {
-                    s_ra[wave][ra] = A.a; s_ri[wave][ra] = A.id; s_rf[wave][ra] = f1;
-                    if (hasB) { s_ra[wave][ra + 1] = Bz.a; s_ri[wave][ra + 1] = Bz.id; s_rf[wave][ra + 1] = f2; }
+                if (Bz.found) {
+                    vFound = (lane == ra + 1) ? Bz.found : vFound; vFirst = (lane == ra + 1) ? Bz.iFirst : vFirst;
+                    vLast = (lane == ra + 1) ? Bz.iLast : vLast;   vRef = (lane == ra + 1) ? Bz.ref : vRef;
+                    vSFl = (lane == ra + 1) ? Bz.shortFl : vSFl;   vSLl = (lane == ra + 1) ? Bz.shortLl : vSLl;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // scans done before the planes are overwritten
             __builtin_amdgcn_wave_barrier();
             s = e;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < cnt) {
-            outA[r0 + lane] = s_ra[wave][lane];
-            outId[r0 + lane] = s_ri[wave][lane];
-            outFlags[r0 + lane] = (uint8_t)s_rf[wave][lane];
+
+        // ---- finish, data-parallel: lane j turns read j's scan facts into outputs, pair logic via the neighbour lane
+        int a, newLen, ref; bool hit;
+        finish_read<MODE>(P, vL, vStart, vStop, vFound, vFirst, vLast, vSFl, vSLl, vRef, a, newLen, ref, hit);
+        hit = hit && mine && vScan;
+        if (!(mine && vScan)) { a = 0; newLen = vL; }
+        int id = -1;
+        if (hit) id = ref_to_id(P, ref);
+        const float g = (float)vL * P.minLenFraction;              // BBDukProcessorS.java:812-813
+        const int minlenR = (int)(g > (float)P.minReadLength ? g : (float)P.minReadLength);
+        bool d = false, remove = false;
+        if (P.storedKmers > 0) {
+            d = (MODE != BBDUK_MODE_KFILTER) ? (newLen < minlenR) : (a > P.maxBadKmers);
+            if (paired) {
+                const bool dm = __shfl_xor((int)d, 1) != 0;         // my mate's verdict
+                remove = (P.rieb && (d || dm)) || (d && dm);        // shouldRemove (:1489-1492)
+            } else remove = d;
         }
-#pragma unroll
-        for (int q = 0; q < 4; q++) tot[q] += (unsigned long long)acc[q];
-        PH(6);
-    }
-#undef PH
-    if (P.prof && lane == 0) {
-#pragma unroll
-        for (int q = 0; q < 16; q++) atomicAdd(&P.profOut[q], ph[q]);
+        if (mine) {
+            outA[r0 + lane] = a; outId[r0 + lane] = id;
+            outFlags[r0 + lane] = (uint8_t)((d ? BBDUK_FLAG_DISCARDED : 0) | (remove ? BBDUK_FLAG_REMOVED : 0));
+            if (MODE != BBDUK_MODE_KFILTER) {                       // :1011-1029, per read: the pair's sums are the mates' sums
+                vRkt += remove ? 1u : (a > 0 ? 1u : 0u);
+                vXs += (unsigned)a + (remove ? (unsigned)newLen : 0u);
+            }
+            if (remove) { vRm += 1; vBm += (unsigned)newLen; }
+        }
+        // scaffold counters (:2111-2119, :1577-1583): group the hit lanes by id, one cache update per distinct id
+        uint64_t hm = __ballot(hit);
+        while (hm) {
+            const int l0 = __ffsll((unsigned long long)hm) - 1;
+            const int sid = __builtin_amdgcn_readlane(id, l0);
+            const bool same = hit && id == sid;
+            const uint64_t sm = __ballot(same);
+            scaf_add_n(P, scaf, sid, __popcll(sm), wave_sum(same ? vL : 0), lane, counters);
+            hm &= ~sm;
+        }
     }
     scaf_flush(P, scaf, lane, counters);
-    if (lane == 0) {
+    {   // wave reduction of the per-lane sums (64-bit, via two 32-bit halves is unnecessary: use shuffles on long long)
+        unsigned long long t4[4] = {vRkt, vXs, vRm, vBm};
 #pragma unroll
-        for (int q = 0; q < 6; q++) if (tot[q]) atomicAdd(&s_acc[q], tot[q]);
+        for (int q = 0; q < 4; q++) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) t4[q] += __shfl_xor(t4[q], o);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (t4[q]) atomicAdd(&s_acc[q], t4[q]);
+            if (sIn) atomicAdd(&s_acc[4], sIn);
+            if (sBin) atomicAdd(&s_acc[5], sBin);
+        }
     }
     __syncthreads();
     if (tid == 0) publish_counters<MODE>(s_acc, counters);
