@@ -816,6 +816,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
     __shared__ uint32_t s_wc[NWAVES][WPLANE_WORDS];
     __shared__ uint32_t s_wn[NWAVES][WCAP_CHUNKS / 2 + 4];
     __shared__ unsigned long long s_acc[6];                       // rkt, basesKTrimmed, readsOutm, basesOutm, readsIn, basesIn
+    __shared__ int s_sel[NWAVES][MT_READS];                       // short-scan: compacted list of participating reads
     extern __shared__ uint32_t s_filt[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
@@ -826,6 +827,10 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
     }
     __syncthreads();
     if (*slowFlag != 0) return;                                   // a unit does not fit a wave's planes: tile kernel's job
+    // short-scan geometry: `lens` candidate lengths per read, rpp reads per 64-lane pass
+    const int lens = max(1, (MODE == BBDUK_MODE_KTRIM_L) ? (P.k - P.mink + 1) : (P.k - P.mink));
+    const int rpp = max(1, 64 / lens);
+    const int sslot = lane / lens, st = lane - sslot * lens;
 
     uint32_t* const wf = s_wf[wave]; uint32_t* const wc = s_wc[wave]; uint32_t* const wn = s_wn[wave];
     ScafAcc scaf; scaf_init(scaf);
@@ -835,10 +840,15 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
     const int64_t nmt = (n + MT_READS - 1) / MT_READS;
     const int64_t gw = (int64_t)blockIdx.x * NWAVES + wave, nw = (int64_t)gridDim.x * NWAVES;
 
+    int64_t myoffNext = (gw < nmt) ? offsets[gw * MT_READS + min((int64_t)lane, min((int64_t)MT_READS, n - gw * MT_READS))] : 0;
     for (int64_t mt = gw; mt < nmt; mt += nw) {
         const int64_t r0 = mt * MT_READS;
         const int cnt = (int)min((int64_t)MT_READS, n - r0);
-        const int64_t myoff = offsets[r0 + min(lane, cnt)];
+        const int64_t myoff = myoffNext;
+        {   // prefetch the next mini-tile's offsets: their HBM latency hides behind this mini-tile's work
+            const int64_t mtn = mt + nw;
+            if (mtn < nmt) myoffNext = offsets[mtn * MT_READS + min((int64_t)lane, min((int64_t)MT_READS, n - mtn * MT_READS))];
+        }
         const int64_t O0 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(myoff >> 32)) << 32) |
                            (uint32_t)__builtin_amdgcn_readfirstlane((int)myoff);
         const int rel = (int)(myoff - O0);                         // lane j (<= cnt): start of read j relative to the mini-tile
@@ -900,9 +910,6 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                 A.found = 0; A.iFirst = BIGLOC; A.iLast = -1; A.ref = -1; A.shortFl = -1; A.shortLl = -1;
                 Bz.found = 0; Bz.iFirst = BIGLOC; Bz.iLast = -1; Bz.ref = -1; Bz.shortFl = -1; Bz.shortLl = -1;
                 main_scan_pair<MODE, FORBIDN, GENERAL>(P, Q, A, Bz, lane);
-                if constexpr (MODE != BBDUK_MODE_KFILTER && SHORT) {
-                    if (P.useShort) short_scan_pair<MODE, GENERAL>(P, Q, A, Bz, lane);
-                }
                 if (A.found) {                                      // hand the facts to lane ra (most reads have none)
                     vFound = (lane == ra) ? A.found : vFound; vFirst = (lane == ra) ? A.iFirst : vFirst;
                     vLast = (lane == ra) ? A.iLast : vLast;   vRef = (lane == ra) ? A.ref : vRef;
@@ -912,6 +919,59 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                     vFound = (lane == ra + 1) ? Bz.found : vFound; vFirst = (lane == ra + 1) ? Bz.iFirst : vFirst;
                     vLast = (lane == ra + 1) ? Bz.iLast : vLast;   vRef = (lane == ra + 1) ? Bz.ref : vRef;
                     vSFl = (lane == ra + 1) ? Bz.shortFl : vSFl;   vSLl = (lane == ra + 1) ? Bz.shortLl : vSLl;
+                }
+            }
+            // ---- short k-mers (:2034-2103) for the reads of [s,e) whose main scan found nothing, several reads per
+            // pass: worker lane w looks up length mink+st of the read in slot sslot (lens lengths per read).
+            if constexpr (MODE != BBDUK_MODE_KFILTER && SHORT) {
+                if (P.useShort) {
+                    const bool need = mine && vScan && vFound == 0 && lane >= s && lane < e;
+                    uint64_t needM = __ballot(need);
+                    if (needM) {
+                        const int rank = __popcll(needM & ((1ULL << lane) - 1ULL));
+                        if (need) s_sel[wave][rank] = lane;            // compact list of the reads that take part
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        const int nneed = __popcll(needM);
+                        const int vBase0 = origin + rel;
+                        for (int pb = 0; pb < nneed; pb += rpp) {
+                            const int q = pb + sslot;
+                            const bool have = sslot < rpp && q < nneed;
+                            const int j = have ? s_sel[wave][q] : 0;   // the read this worker lane serves
+                            const int jb = __shfl(vBase0, j), jstart = __shfl(vStart, j), jstop = __shfl(vStop, j);
+                            const int Ls = P.mink + st;
+                            uint64_t kmer = 0, rk = 0; bool act; int Lc;
+                            if (MODE == BBDUK_MODE_KTRIM_L) {
+                                const int Lmax = min(P.k, jstop) - jstart;         // lengths 1..Lmax, i = start+Ls-1
+                                act = have && Ls <= Lmax; Lc = act ? Ls : 1;
+                                if (act) {
+                                    kmer = extract2(Q.fwd, Q.T - 1 - (jb + jstart + Lc - 1), Lc) & P.mask;
+                                    rk   = extract2(Q.cmp, jb + jstart, Lc);
+                                }
+                            } else {
+                                const int Lmax = (jstop >= P.k ? P.k - 1 : jstop);  // lengths 1..Lmax, i = stop-Ls
+                                act = have && Ls <= Lmax; Lc = act ? Ls : 1;
+                                if (act) {
+                                    kmer = extract2(Q.fwd, Q.T - 1 - (jb + jstop - 1), Lc);          // base stop-1 in bits 0-1
+                                    rk   = extract2(Q.cmp, jb + jstop - Lc, Lc) & P.mask;            // base i in bits 0-1
+                                }
+                            }
+                            const int sref = lookup<GENERAL>(P, Q.filt, kmer, rk, 1ULL << (2 * Lc), Lc, P.qhdist2, act);
+                            uint64_t hm = __ballot(sref != -1);
+                            while (hm) {                                // rare: some read has a short hit
+                                const int l0 = __ffsll((unsigned long long)hm) - 1;
+                                const int slot = l0 / lens;
+                                const uint64_t seg = (hm >> (slot * lens)) & ((1ULL << lens) - 1ULL);
+                                const int fl = __ffsll((unsigned long long)seg) - 1, ll = 63 - __clzll((long long)seg);
+                                const int jr = s_sel[wave][pb + slot];
+                                const int r1 = __builtin_amdgcn_readlane(sref, slot * lens + fl);   // first hit in scan order = shortest
+                                const int jru = __builtin_amdgcn_readfirstlane(jr);
+                                if (lane == jru) { vRef = r1; vFound = __popcll(seg); vSFl = fl; vSLl = ll; }
+                                hm &= ~(((1ULL << lens) - 1ULL) << (slot * lens));
+                            }
+                        }
+                    }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // scans done before the planes are overwritten
