@@ -45,13 +45,13 @@ struct KParams {
     float   minLenFraction;
     int32_t rieb, trimPad, ktrimExclusive, restrictLeft, restrictRight, skipR1, skipR2, numScaffolds, useShort;
     uint64_t mask, kmask, middleMask;
-    // The map, device layout: 4-way buckets.  tags[b] packs four 8-bit fingerprints (0 = free way); the full key
-    // and its id live at bkeys/bvals[4*b+way] and are touched only when a fingerprint matches.  A key sits in the
+    // The map, device layout: 4-way buckets.  tags[b] packs four 16-bit fingerprints (0 = free way); the full key
+    // and its id live together in bkv[4*b+way] (16 bytes: one fetch verifies the key and yields the id) and are
+    // touched only when a fingerprint matches.  A key sits in the
     // first bucket >= its home bucket that had a free way (bucket-granular linear probing), so a query stops at
-    // the first bucket that has a free way.  One 4-byte gather answers almost every absent k-mer.
-    const uint32_t* tags;
-    const uint64_t* bkeys;
-    const int32_t*  bvals;
+    // the first bucket that has a free way.  One 8-byte gather answers almost every absent k-mer.
+    const uint64_t* tags;
+    const uint4*    bkv;        // {key lo, key hi, id, 0}
     uint32_t bucketMask;
     int32_t  bucketBits;
     int64_t  storedKmers;
@@ -100,24 +100,25 @@ __host__ __device__ __forceinline__ uint32_t mix_b(uint64_t key) {
     return mul24(lo, MB0) + mul24(p1, MB1) + mul24(p2, MB2);
 }
 __host__ __device__ __forceinline__ uint32_t bucket_of(uint32_t mb, int bucketBits) { return mb >> (32 - bucketBits); }
-__host__ __device__ __forceinline__ uint32_t tag_of(uint32_t ma) { const uint32_t t = (ma >> 3) & 0xFFu; return t ? t : 1u; }
+__host__ __device__ __forceinline__ uint32_t tag_of(uint32_t ma) { const uint32_t t = (ma >> 3) & 0xFFFFu; return t ? t : 1u; }
 
-// 0x80 in every byte of v that is zero (may also flag bytes above a true zero byte: callers verify)
-__device__ __forceinline__ uint32_t zero8(uint32_t v) { return (v - 0x01010101u) & ~v & 0x80808080u; }
+// 0x8000 in every 16-bit lane of v that is zero (may also flag lanes above a true zero lane: callers verify)
+__device__ __forceinline__ uint64_t zero16(uint64_t v) { return (v - 0x0001000100010001ULL) & ~v & 0x8000800080008000ULL; }
 
-// map lookup with the mixes already computed: slot (4*bucket+way) of the key, or -1.  t0 = tags of the home bucket.
-__device__ __forceinline__ int table_find_t(const KParams& P, uint64_t key, uint32_t ma, uint32_t mb, uint32_t t0) {
+// map lookup with the mixes already computed: id (>0) of the key, or -1.  t0 = tags of the home bucket.
+__device__ __forceinline__ int table_find_t(const KParams& P, uint64_t key, uint32_t ma, uint32_t mb, uint64_t t0) {
     uint32_t b = bucket_of(mb, P.bucketBits);
-    const uint32_t pat = tag_of(ma) * 0x01010101u;
-    uint32_t t = t0;
+    const uint64_t pat = (uint64_t)tag_of(ma) * 0x0001000100010001ULL;
+    uint64_t t = t0;
     for (;;) {
-        uint32_t cand = zero8(t ^ pat);
+        uint64_t cand = zero16(t ^ pat);
         while (cand) {
-            const int way = (__ffs(cand) - 1) >> 3;
-            if (P.bkeys[4ULL * b + way] == key) return (int)(4u * b + way);
+            const int way = (__ffsll((unsigned long long)cand) - 1) >> 4;
+            const uint4 kv = P.bkv[4ULL * b + way];
+            if ((((uint64_t)kv.y << 32) | kv.x) == key) return (int)kv.z;
             cand &= cand - 1;
         }
-        if (zero8(t)) return -1;                  // a free way: the key cannot be further along
+        if (zero16(t)) return -1;                 // a free way: the key cannot be further along
         b = (b + 1) & P.bucketMask;
         t = P.tags[b];
     }
@@ -125,13 +126,9 @@ __device__ __forceinline__ int table_find_t(const KParams& P, uint64_t key, uint
 __device__ __forceinline__ int table_find_m(const KParams& P, uint64_t key, uint32_t ma, uint32_t mb) {
     return table_find_t(P, key, ma, mb, P.tags[bucket_of(mb, P.bucketBits)]);
 }
-__device__ __forceinline__ int table_get(const KParams& P, uint64_t key) {
-    const int slot = table_find_m(P, key, mix_a(key), mix_b(key));
-    return slot < 0 ? -1 : P.bvals[slot];
-}
-// A lookup result is carried as a "ref": -1 = absent, >= 0 = slot whose id (bvals[slot]) is fetched only by the
-// one lane whose hit is used, <= -3 = an id already known (-2 - id; query-expansion path).
-__device__ __forceinline__ int ref_to_id(const KParams& P, int ref) { return ref >= 0 ? P.bvals[ref] : (ref == -1 ? -1 : -2 - ref); }
+__device__ __forceinline__ int table_get(const KParams& P, uint64_t key) { return table_find_m(P, key, mix_a(key), mix_b(key)); }
+// A lookup result ("ref") is -1 = absent or the id (>0) itself.
+__device__ __forceinline__ int ref_to_id(const KParams& P, int ref) { return ref; }
 
 // key -> ref through the cascade: LDS presence bit -> bucket fingerprints -> key.  `ok` = lane has a real query.
 __device__ __forceinline__ int probe_ref(const KParams& P, const uint32_t* s_filt, uint64_t key, bool ok) {
@@ -180,7 +177,7 @@ __device__ __forceinline__ int lookup(const KParams& P, const uint32_t* s_filt, 
     if constexpr (GENERAL) {
         if (qh > 0) {
             const int id = ok ? get_value_expand(P, kmer, rkmer, lengthMask, len, qh) : -1;
-            return id > 0 ? -2 - id : -1;
+            return id > 0 ? id : -1;
         }
     }
     return probe_ref(P, s_filt, make_key<GENERAL>(P, kmer, rkmer, lengthMask), ok);
@@ -280,6 +277,7 @@ struct ReadScan {
     int found, iFirst, iLast;           // main scan: hits seen, first / last hit position (iFirst==0 marks the kfilter exit)
     int ref;                            // ref (see ref_to_id) of the hit whose id the reference reports
     int shortFl, shortLl;               // short k-mer scan: first / last hit lane (length index); shortFl<0: none
+    int candSlot; uint32_t candKeyLo, candKeyHi;   // candidate mode: first unverified fingerprint match (slot, key)
 };
 
 template <int MODE, bool SHORT, bool GENERAL>
@@ -426,20 +424,22 @@ __device__ __forceinline__ void windows2(const KParams& P, const Planes& Q, cons
 }
 
 // four independent key -> ref lookups with their memory operations overlapped
+// candOnly: do not check keys; ref = slot (4*bucket+way) of the first matching fingerprint, -2 if the home bucket is
+// full without a match (chain walk needed), -1 if certainly absent; keyOut receives the lanes' keys.
 template <bool GENERAL>
 __device__ __forceinline__ void lookup4(const KParams& P, const uint32_t* s_filt, const uint64_t* kmer, const uint64_t* rk,
-                                        const bool* ok, int* ref) {
+                                        const bool* ok, int* ref, const bool candOnly = false, uint64_t* keyOut = nullptr) {
     if constexpr (GENERAL) {
         if (P.qhdist > 0) {
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 const int id = ok[s] ? get_value_expand(P, kmer[s], rk[s], P.kmask, P.k, P.qhdist) : -1;
-                ref[s] = id > 0 ? -2 - id : -1;
+                ref[s] = id > 0 ? id : -1;
             }
             return;
         }
     }
-    uint64_t key[4]; uint32_t ma[4], mb[4], t[4]; bool p[4];
+    uint64_t key[4], t[4]; uint32_t ma[4], mb[4]; bool p[4];
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         key[s] = make_key<GENERAL>(P, kmer[s], rk[s], P.kmask);
@@ -455,13 +455,17 @@ __device__ __forceinline__ void lookup4(const KParams& P, const uint32_t* s_filt
         for (int s = 0; s < 4; s++) p[s] = p[s] & (bool)((w[s] >> ((ma[s] >> (32 - P.ldsBits)) & 31)) & 1u);
     }
 #pragma unroll
-    for (int s = 0; s < 4; s++) t[s] = p[s] ? P.tags[bucket_of(mb[s], P.bucketBits)] : 0u;   // four gathers in flight
+    for (int s = 0; s < 4; s++) t[s] = p[s] ? P.tags[bucket_of(mb[s], P.bucketBits)] : 0ULL;  // four gathers in flight
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         // rare: a fingerprint matched, or the home bucket is full -> check the key / walk the bucket chain
-        const uint32_t cand = zero8(t[s] ^ (tag_of(ma[s]) * 0x01010101u));
+        const uint64_t cand = zero16(t[s] ^ ((uint64_t)tag_of(ma[s]) * 0x0001000100010001ULL));
         ref[s] = -1;
-        if (p[s] && (cand != 0u || zero8(t[s]) == 0u)) ref[s] = table_find_t(P, key[s], ma[s], mb[s], t[s]);
+        if (candOnly) {
+            if (p[s] && cand != 0ULL) ref[s] = (int)(4u * bucket_of(mb[s], P.bucketBits)) + ((__ffsll((unsigned long long)cand) - 1) >> 4);
+            else if (p[s] && zero16(t[s]) == 0ULL) ref[s] = -2;
+            keyOut[s] = key[s];
+        } else if (p[s] && (cand != 0ULL || zero16(t[s]) == 0ULL)) ref[s] = table_find_t(P, key[s], ma[s], mb[s], t[s]);
     }
 }
 
@@ -518,6 +522,48 @@ __device__ __forceinline__ void main_scan_pair(const KParams& P, const Planes& Q
         }
     }
     A.found = foundA; B.found = foundB;
+}
+
+// Candidate form of the pair scan (ktrim=r, kfilter with maxbadkmers=0: only the first hit of a read matters): stop
+// at the first fingerprint match of each read WITHOUT fetching its key; the caller verifies the candidates of a whole
+// sub-tile in one overlapped batch (one lane per read) and falls back to main_scan_pair for the rare impostor.
+template <bool FORBIDN, bool GENERAL>
+__device__ __forceinline__ void main_scan_pair_cand(const KParams& P, const Planes& Q, ReadScan& A, ReadScan& B, const int lane) {
+    ReadWin WA, WB;
+    win_init<FORBIDN, GENERAL>(P, Q, A, WA, lane);
+    win_init<FORBIDN, GENERAL>(P, Q, B, WB, lane);
+    int ibA = WA.first, ibB = WB.first;
+    bool onA = WA.on, onB = WB.on;
+    A.candSlot = -1; B.candSlot = -1;
+    while (onA || onB) {
+        uint64_t kmer[4], rk[4], key[4]; bool ok[4]; int ref[4];
+        windows2<FORBIDN, GENERAL>(P, Q, WA, ibA + lane, onA, kmer, rk, ok);
+        windows2<FORBIDN, GENERAL>(P, Q, WB, ibB + lane, onB, kmer + 2, rk + 2, ok + 2);
+        lookup4<GENERAL>(P, Q.filt, kmer, rk, ok, ref, true, key);
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            ReadScan& R = r ? B : A;
+            bool& on = r ? onB : onA;
+            int& ib = r ? ibB : ibA;
+            if (!on) continue;
+            const uint64_t m0 = __ballot(ref[2 * r] != -1), m1 = __ballot(ref[2 * r + 1] != -1);
+            if (m0 | m1) {
+                const int h = m0 ? 0 : 1;
+                const uint64_t m = m0 ? m0 : m1;
+                const int l = __ffsll((unsigned long long)m) - 1;
+                const int rs = h ? ref[2 * r + 1] : ref[2 * r];
+                const uint64_t ks = h ? key[2 * r + 1] : key[2 * r];
+                R.candSlot = __builtin_amdgcn_readlane(rs, l);
+                R.candKeyLo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ks, l);
+                R.candKeyHi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ks >> 32), l);
+                R.iFirst = ib + 64 * h + l;
+                on = false;
+            } else {
+                ib += 128;
+                on = ib < (r ? WB.stop : WA.stop);
+            }
+        }
+    }
 }
 
 // Short k-mer scans of two reads in one pass: lanes 0-31 serve read A, lanes 32-63 read B, one lane per
@@ -588,17 +634,19 @@ __device__ __forceinline__ void scaf_flush(const KParams& P, ScafAcc& S, const i
     scaf_init(S);
 }
 __device__ __forceinline__ void scaf_add_n(const KParams& P, ScafAcc& S, int id, int nreads, int L, const int lane, int64_t* __restrict__ counters) {
-    if (id == S.i0) { S.r0 += nreads; S.b0 += L; }
-    else if (id == S.i1) { S.r1 += nreads; S.b1 += L; }
-    else if (id == S.i2) { S.r2 += nreads; S.b2 += L; }
-    else if (id == S.i3) { S.r3 += nreads; S.b3 += L; }
-    else {                                                       // evict the oldest entry, insert in front
+    // move-to-front (true LRU): the one or two hot ids stay in the cache, a rare id only ever evicts another rare id
+    if (id == S.i0) { S.r0 += nreads; S.b0 += L; return; }
+    int ri, rr; long long rb;                                     // the entry that goes to the front
+    if (id == S.i1) { ri = S.i1; rr = S.r1 + nreads; rb = S.b1 + L; }
+    else if (id == S.i2) { ri = S.i2; rr = S.r2 + nreads; rb = S.b2 + L; S.i2 = S.i1; S.r2 = S.r1; S.b2 = S.b1; }
+    else if (id == S.i3) { ri = S.i3; rr = S.r3 + nreads; rb = S.b3 + L; S.i3 = S.i2; S.r3 = S.r2; S.b3 = S.b2; S.i2 = S.i1; S.r2 = S.r1; S.b2 = S.b1; }
+    else {                                                       // miss: evict the least recently used entry
         scaf_emit(P, S.i3, S.r3, S.b3, lane, counters);
-        S.i3 = S.i2; S.r3 = S.r2; S.b3 = S.b2;
-        S.i2 = S.i1; S.r2 = S.r1; S.b2 = S.b1;
-        S.i1 = S.i0; S.r1 = S.r0; S.b1 = S.b0;
-        S.i0 = id; S.r0 = nreads; S.b0 = L;
+        ri = id; rr = nreads; rb = L;
+        S.i3 = S.i2; S.r3 = S.r2; S.b3 = S.b2; S.i2 = S.i1; S.r2 = S.r1; S.b2 = S.b1;
     }
+    S.i1 = S.i0; S.r1 = S.r0; S.b1 = S.b0;
+    S.i0 = ri; S.r0 = rr; S.b0 = rb;
 }
 __device__ __forceinline__ void scaf_add(const KParams& P, ScafAcc& S, int id, int L, const int lane, int64_t* __restrict__ counters) {
     scaf_add_n(P, S, id, 1, L, lane, counters);
@@ -828,12 +876,18 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
     __syncthreads();
     if (*slowFlag != 0) return;                                   // a unit does not fit a wave's planes: tile kernel's job
     // short-scan geometry: `lens` candidate lengths per read, rpp reads per 64-lane pass
+    // first-hit-only operators verify candidates in batches (see main_scan_pair_cand)
+    const bool candMode = (!GENERAL || P.qhdist == 0) && (MODE == BBDUK_MODE_KTRIM_R || (MODE == BBDUK_MODE_KFILTER && P.maxBadKmers == 0));
     const int lens = max(1, (MODE == BBDUK_MODE_KTRIM_L) ? (P.k - P.mink + 1) : (P.k - P.mink));
     const int rpp = max(1, 64 / lens);
     const int sslot = lane / lens, st = lane - sslot * lens;
 
     uint32_t* const wf = s_wf[wave]; uint32_t* const wc = s_wc[wave]; uint32_t* const wn = s_wn[wave];
-    ScafAcc scaf; scaf_init(scaf);
+    // scaffold-counter cache: lane w (< SCAF_LANES) owns one (id, reads, bases) entry in registers; a hit is one ballot
+    // plus a predicated add, a miss evicts round-robin with two atomics.  The adapter library has ~6 frequent ids:
+    // with the 4-entry scalar cache 4-15 % of the hit reads still caused evictions onto a dozen hot addresses.
+    constexpr int SCAF_LANES = 16;
+    int scId = -1, scReads = 0, scNext = 0; long long scBases = 0;
     // per-lane partial sums (lane j accumulates what read j of every mini-tile contributes), reduced once at the end
     unsigned long long vRkt = 0, vXs = 0, vRm = 0, vBm = 0;
     unsigned long long sIn = 0, sBin = 0;                         // wave-uniform: reads / bases seen
@@ -863,6 +917,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
         const int vStart = span_start<GENERAL>(P, vL), vStop = span_stop<GENERAL>(P, vL);
         // raw scan facts of my read, filled in by v_writelane as the pairs are scanned
         int vFound = 0, vFirst = BIGLOC, vLast = -1, vRef = -1, vSFl = -1, vSLl = -1;
+        int vCSlot = -1; uint32_t vCKeyLo = 0, vCKeyHi = 0;       // candidate mode: my read's first unverified match
 
         int s = 0;
         while (s < cnt) {
@@ -909,6 +964,18 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                 Bz.start = span_start<GENERAL>(P, Bz.L); Bz.stop = span_stop<GENERAL>(P, Bz.L);
                 A.found = 0; A.iFirst = BIGLOC; A.iLast = -1; A.ref = -1; A.shortFl = -1; A.shortLl = -1;
                 Bz.found = 0; Bz.iFirst = BIGLOC; Bz.iLast = -1; Bz.ref = -1; Bz.shortFl = -1; Bz.shortLl = -1;
+                if (candMode) {
+                    main_scan_pair_cand<FORBIDN, GENERAL>(P, Q, A, Bz, lane);
+                    if (A.candSlot != -1) {
+                        vCSlot = (lane == ra) ? A.candSlot : vCSlot; vFirst = (lane == ra) ? A.iFirst : vFirst;
+                        vCKeyLo = (lane == ra) ? A.candKeyLo : vCKeyLo; vCKeyHi = (lane == ra) ? A.candKeyHi : vCKeyHi;
+                    }
+                    if (Bz.candSlot != -1) {
+                        vCSlot = (lane == ra + 1) ? Bz.candSlot : vCSlot; vFirst = (lane == ra + 1) ? Bz.iFirst : vFirst;
+                        vCKeyLo = (lane == ra + 1) ? Bz.candKeyLo : vCKeyLo; vCKeyHi = (lane == ra + 1) ? Bz.candKeyHi : vCKeyHi;
+                    }
+                    continue;
+                }
                 main_scan_pair<MODE, FORBIDN, GENERAL>(P, Q, A, Bz, lane);
                 if (A.found) {                                      // hand the facts to lane ra (most reads have none)
                     vFound = (lane == ra) ? A.found : vFound; vFirst = (lane == ra) ? A.iFirst : vFirst;
@@ -919,6 +986,36 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                     vFound = (lane == ra + 1) ? Bz.found : vFound; vFirst = (lane == ra + 1) ? Bz.iFirst : vFirst;
                     vLast = (lane == ra + 1) ? Bz.iLast : vLast;   vRef = (lane == ra + 1) ? Bz.ref : vRef;
                     vSFl = (lane == ra + 1) ? Bz.shortFl : vSFl;   vSLl = (lane == ra + 1) ? Bz.shortLl : vSLl;
+                }
+            }
+            if (candMode) {
+                // ---- verify the sub-tile's candidates together: lane j fetches key+id of read j's candidate
+                const bool inSub = lane >= s && lane < e;
+                bool fb = inSub && vCSlot == -2;                    // full home bucket: needs the chain walk
+                if (inSub && vCSlot >= 0) {
+                    const uint4 kv = P.bkv[vCSlot];
+                    if (kv.x == vCKeyLo && kv.y == vCKeyHi) {
+                        vRef = (int)kv.z; vFound = (MODE == BBDUK_MODE_KFILTER) ? P.maxBadKmers + 1 : 1;
+                        if (MODE == BBDUK_MODE_KFILTER) vFirst = 0;    // marks the early exit
+                    } else fb = true;
+                }
+                uint64_t fbm = __ballot(fb);
+                while (fbm) {                                       // rare: an impostor fingerprint; rescan that pair exactly
+                    const int j = __ffsll((unsigned long long)fbm) - 1;
+                    const int ra = s + ((j - s) & ~1);
+                    const bool hasB = (ra + 1) < e;
+                    ReadScan A, Bz;
+                    A.base0 = origin + __builtin_amdgcn_readlane(rel, ra); A.L = __builtin_amdgcn_readlane(vL, ra); A.scan = (scanMask >> ra) & 1;
+                    Bz.base0 = origin + __builtin_amdgcn_readlane(rel, ra + 1); Bz.L = hasB ? __builtin_amdgcn_readlane(vL, ra + 1) : 0;
+                    Bz.scan = hasB && ((scanMask >> (ra + 1)) & 1);
+                    A.start = span_start<GENERAL>(P, A.L); A.stop = span_stop<GENERAL>(P, A.L);
+                    Bz.start = span_start<GENERAL>(P, Bz.L); Bz.stop = span_stop<GENERAL>(P, Bz.L);
+                    A.found = 0; A.iFirst = BIGLOC; A.iLast = -1; A.ref = -1; A.shortFl = -1; A.shortLl = -1;
+                    Bz.found = 0; Bz.iFirst = BIGLOC; Bz.iLast = -1; Bz.ref = -1; Bz.shortFl = -1; Bz.shortLl = -1;
+                    main_scan_pair<MODE, FORBIDN, GENERAL>(P, Q, A, Bz, lane);
+                    vFound = (lane == ra) ? A.found : vFound; vFirst = (lane == ra) ? A.iFirst : vFirst; vRef = (lane == ra) ? A.ref : vRef;
+                    if (hasB) { vFound = (lane == ra + 1) ? Bz.found : vFound; vFirst = (lane == ra + 1) ? Bz.iFirst : vFirst; vRef = (lane == ra + 1) ? Bz.ref : vRef; }
+                    fbm &= ~(3ULL << ra);
                 }
             }
             // ---- short k-mers (:2034-2103) for the reads of [s,e) whose main scan found nothing, several reads per
@@ -1012,11 +1109,26 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
             const int sid = __builtin_amdgcn_readlane(id, l0);
             const bool same = hit && id == sid;
             const uint64_t sm = __ballot(same);
-            scaf_add_n(P, scaf, sid, __popcll(sm), wave_sum(same ? vL : 0), lane, counters);
+            const int nrd = __popcll(sm), nbs = wave_sum(same ? vL : 0);
+            const uint64_t mt_ = __ballot(lane < SCAF_LANES && scId == sid);
+            if (mt_) { if (lane < SCAF_LANES && scId == sid) { scReads += nrd; scBases += nbs; } }
+            else {
+                if (lane == scNext) {
+                    if (scId > 0) {
+                        atomicAdd((unsigned long long*)&counters[BBDUK_NCOUNTERS + scId], (unsigned long long)scReads);
+                        atomicAdd((unsigned long long*)&counters[BBDUK_NCOUNTERS + P.numScaffolds + scId], (unsigned long long)scBases);
+                    }
+                    scId = sid; scReads = nrd; scBases = nbs;
+                }
+                scNext = (scNext + 1) & (SCAF_LANES - 1);
+            }
             hm &= ~sm;
         }
     }
-    scaf_flush(P, scaf, lane, counters);
+    if (lane < SCAF_LANES && scId > 0) {
+        atomicAdd((unsigned long long*)&counters[BBDUK_NCOUNTERS + scId], (unsigned long long)scReads);
+        atomicAdd((unsigned long long*)&counters[BBDUK_NCOUNTERS + P.numScaffolds + scId], (unsigned long long)scBases);
+    }
     {   // wave reduction of the per-lane sums (64-bit, via two 32-bit halves is unnecessary: use shuffles on long long)
         unsigned long long t4[4] = {vRkt, vXs, vRm, vBm};
 #pragma unroll
@@ -1100,7 +1212,7 @@ struct bbduk_handle {
     std::vector<int64_t> hkeys;          // staged (key,value) pairs before finalize
     std::vector<int32_t> hvals;
     int64_t nkeys = 0;
-    uint32_t* d_tags = nullptr; uint64_t* d_bkeys = nullptr; int32_t* d_bvals = nullptr; uint64_t nbuckets = 0; int bucketBits = 0;
+    uint64_t* d_tags = nullptr; uint4* d_bkv = nullptr; uint64_t nbuckets = 0; int bucketBits = 0;
     uint32_t* d_ldsImage = nullptr; int ldsBits = 0;
     int* d_slowFlag = nullptr;
     unsigned long long* d_prof = nullptr;
@@ -1154,7 +1266,7 @@ extern "C" int bbduk_create(const bbduk_params* p, bbduk_handle** out) {
 extern "C" int bbduk_destroy(bbduk_handle* h) {
     if (!h) return BBDUK_ERR_ARG;
     hipSetDevice(h->p.device);
-    hipFree(h->d_tags); hipFree(h->d_bkeys); hipFree(h->d_bvals); hipFree(h->d_bases); hipFree(h->d_off);
+    hipFree(h->d_tags); hipFree(h->d_bkv); hipFree(h->d_bases); hipFree(h->d_off);
     if (getenv("BBDUK_PROF") && h->d_prof) {
         unsigned long long ph[8];
         if (hipMemcpy(ph, h->d_prof, sizeof ph, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -1201,38 +1313,40 @@ extern "C" int bbduk_finalize_table(bbduk_handle* h) {
     if (h->finalized) return fail(h, BBDUK_ERR_STATE, "table already finalized");
     HIP_TRY(h, hipSetDevice(h->p.device));
     const size_t n = h->hkeys.size();
-    // 4-way buckets of 8-bit fingerprints, about one key per bucket on average (see KParams).
+    // 4-way buckets of 16-bit fingerprints, about one key per bucket on average (see KParams).
     int bbits = 10;
     while (bbits < 32 && (1ULL << bbits) < (uint64_t)n) bbits++;
     if (const char* e = getenv("BBDUK_BUCKET_BITS")) { const int v = atoi(e); if (v >= 4 && v <= 32) bbits = v; }
     const uint64_t nb = 1ULL << bbits;
     if (4 * nb < (uint64_t)n + nb / 8 || 4 * nb > (1ULL << 31)) return fail(h, BBDUK_ERR_ARG, "too many keys for the bucket index");
-    std::vector<uint32_t> tg(nb, 0u);
+    std::vector<uint64_t> tg(nb, 0ULL);
     std::vector<uint64_t> bk(4 * nb, EMPTY_KEY);
     std::vector<int32_t> bv(4 * nb, 0);
     const uint32_t bmask = (uint32_t)(nb - 1);
     int64_t distinct = 0;
     for (size_t i = 0; i < n; i++) {                              // first writer wins (HashArray.setIfNotPresent)
         const uint64_t key = (uint64_t)h->hkeys[i];
-        const uint32_t tag = tag_of(mix_a(key));
+        const uint64_t tag = tag_of(mix_a(key));
         uint32_t b = bucket_of(mix_b(key), bbits);
         for (;;) {
             bool done = false;
             for (int w = 0; w < 4 && !done; w++) {
-                const uint32_t tw = (tg[b] >> (8 * w)) & 0xFFu;
-                if (tw == 0) { tg[b] |= tag << (8 * w); bk[4ULL * b + w] = key; bv[4ULL * b + w] = h->hvals[i]; distinct++; done = true; }
+                const uint64_t tw = (tg[b] >> (16 * w)) & 0xFFFFULL;
+                if (tw == 0) { tg[b] |= tag << (16 * w); bk[4ULL * b + w] = key; bv[4ULL * b + w] = h->hvals[i]; distinct++; done = true; }
                 else if (tw == tag && bk[4ULL * b + w] == key) done = true;
             }
             if (done) break;
             b = (b + 1) & bmask;
         }
     }
-    HIP_TRY(h, hipMalloc(&h->d_tags, nb * sizeof(uint32_t)));
-    HIP_TRY(h, hipMalloc(&h->d_bkeys, 4 * nb * sizeof(uint64_t)));
-    HIP_TRY(h, hipMalloc(&h->d_bvals, 4 * nb * sizeof(int32_t)));
-    HIP_TRY(h, hipMemcpy(h->d_tags, tg.data(), nb * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->d_bkeys, bk.data(), 4 * nb * sizeof(uint64_t), hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->d_bvals, bv.data(), 4 * nb * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMalloc(&h->d_tags, nb * sizeof(uint64_t)));
+    {
+        std::vector<uint4> kvh(4 * nb);
+        for (uint64_t q = 0; q < 4 * nb; q++) kvh[q] = make_uint4((uint32_t)bk[q], (uint32_t)(bk[q] >> 32), (uint32_t)bv[q], 0u);
+        HIP_TRY(h, hipMalloc(&h->d_bkv, 4 * nb * sizeof(uint4)));
+        HIP_TRY(h, hipMemcpy(h->d_bkv, kvh.data(), 4 * nb * sizeof(uint4), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(h, hipMemcpy(h->d_tags, tg.data(), nb * sizeof(uint64_t), hipMemcpyHostToDevice));
     h->nbuckets = nb; h->bucketBits = bbits; h->nkeys = distinct;
     // Presence filter in front of the map.  Most query k-mers are absent, so one bit per hash slot held in LDS
     // (<=128 KiB per workgroup) answers most of them without leaving the CU.  Size follows the key count;
@@ -1263,7 +1377,7 @@ extern "C" int bbduk_finalize_table(bbduk_handle* h) {
 extern "C" int64_t bbduk_table_size(const bbduk_handle* h) { return (h && h->finalized) ? h->nkeys : -1; }
 extern "C" int64_t bbduk_table_bytes(const bbduk_handle* h) {
     if (!h || !h->finalized) return -1;
-    return (int64_t)(h->nbuckets * (4 + 4 * 12)) + (h->ldsBits ? (1LL << (h->ldsBits - 3)) : 0);
+    return (int64_t)(h->nbuckets * (8 + 4 * 16)) + (h->ldsBits ? (1LL << (h->ldsBits - 3)) : 0);
 }
 
 static KParams make_kparams(const bbduk_handle* h) {
@@ -1280,7 +1394,7 @@ static KParams make_kparams(const bbduk_handle* h) {
     K.mask = (2 * p.k > 63) ? ~0ULL : ~(~0ULL << (2 * p.k));
     K.kmask = 1ULL << (2 * p.k);
     K.middleMask = (uint64_t)p.middleMask;
-    K.tags = h->d_tags; K.bkeys = h->d_bkeys; K.bvals = h->d_bvals; K.bucketMask = (uint32_t)(h->nbuckets - 1); K.bucketBits = h->bucketBits;
+    K.tags = h->d_tags; K.bkv = h->d_bkv; K.bucketMask = (uint32_t)(h->nbuckets - 1); K.bucketBits = h->bucketBits;
     K.storedKmers = h->nkeys;
     K.ldsImage = h->d_ldsImage; K.ldsBits = h->ldsBits;
     K.prof = getenv("BBDUK_PROF") ? 1 : 0; K.profOut = h->d_prof;

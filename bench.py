@@ -57,7 +57,11 @@ def main():
     n_pairs = a.reads // 2
     n = 2 * n_pairs
     duk = B.BBDuk(ARGS_C2, device=dev)
-    sp = B.synth_params(a.seed)
+    sp_kw = {}
+    if os.environ.get("BBDUK_BENCH_INS"):            # experiments only: "min,max" insert range (default 50,350)
+        lo_, hi_ = os.environ["BBDUK_BENCH_INS"].split(",")
+        sp_kw = dict(ins_min=int(lo_), ins_max=int(hi_))
+    sp = B.synth_params(a.seed, **sp_kw)
     lo, hi = D.weak_shard(n_pairs, rank)
 
     d_bases = torch.empty(n * READ_LEN, dtype=torch.uint8, device="cuda")
