@@ -49,7 +49,7 @@ class SynthParams(C.Structure):     # struct bbduk_synth_params
 GPU_SYMBOLS = ["bbduk_abi_version", "bbduk_create", "bbduk_destroy", "bbduk_last_error", "bbduk_upload_table_way",
                "bbduk_upload_pairs", "bbduk_finalize_table", "bbduk_table_size", "bbduk_table_bytes",
                "bbduk_table_lookup", "bbduk_ktrim_batch", "bbduk_kfilter_batch", "bbduk_ktrim_batch_device",
-               "bbduk_kfilter_batch_device", "bbduk_counters_len", "bbduk_get_counters", "bbduk_reset_counters",
+               "bbduk_kfilter_batch_device", "bbduk_kernel_time_ms", "bbduk_counters_len", "bbduk_get_counters", "bbduk_reset_counters",
                "bbduk_synth_generate_device", "bbduk_synth_generate_host"]
 HOST_SYMBOLS = ["bbduk_host_parse", "bbduk_host_destroy", "bbduk_host_add_ref", "bbduk_host_load_fasta",
                 "bbduk_host_load_refs", "bbduk_host_build_index", "bbduk_host_index_pairs",
@@ -89,6 +89,7 @@ def lib():
         f.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp]
     for f in (L.bbduk_ktrim_batch_device, L.bbduk_kfilter_batch_device):
         f.argtypes = [vp, vp, vp, i64, i64, i32, vp, vp, vp, vp, vp]
+    L.bbduk_kernel_time_ms.argtypes = [vp, i32, C.POINTER(C.c_float)]
     L.bbduk_counters_len.argtypes = [vp]
     L.bbduk_get_counters.argtypes = [vp, vp, i32]
     L.bbduk_reset_counters.argtypes = [vp]
@@ -268,6 +269,11 @@ class BBDukGpu:
         self._check(fn(self.h, d_bases.data_ptr(), d_offsets.data_ptr(), n, d_bases.numel(), int(paired),
                        d_a.data_ptr(), d_id.data_ptr(), d_fl.data_ptr(), d_counters.data_ptr(), stream_ptr),
                     "batch_device")
+
+    def kernel_time_ms(self, last_k: int) -> float:
+        ms = C.c_float()
+        self._check(lib().bbduk_kernel_time_ms(self.h, last_k, C.byref(ms)), "kernel_time_ms")
+        return ms.value
 
     # ---- counters
     @property

@@ -1215,6 +1215,8 @@ struct bbduk_handle {
     uint64_t* d_tags = nullptr; uint4* d_bkv = nullptr; uint64_t nbuckets = 0; int bucketBits = 0;
     uint32_t* d_ldsImage = nullptr; int ldsBits = 0;
     int* d_slowFlag = nullptr;
+    static const int EV_RING = 64;                                // HIP events around the dominant kernel of the last launches
+    hipEvent_t ev0[EV_RING] = {}, ev1[EV_RING] = {}; int64_t evCount = 0;
     unsigned long long* d_prof = nullptr;
     // host-operator staging
     uint8_t* d_bases = nullptr; size_t cap_bases = 0;
@@ -1276,6 +1278,7 @@ extern "C" int bbduk_destroy(bbduk_handle* h) {
         }
     }
     hipFree(h->d_ldsImage); hipFree(h->d_slowFlag); hipFree(h->d_prof);
+    for (int q = 0; q < bbduk_handle::EV_RING; q++) { if (h->ev0[q]) hipEventDestroy(h->ev0[q]); if (h->ev1[q]) hipEventDestroy(h->ev1[q]); }
     hipFree(h->d_a); hipFree(h->d_id); hipFree(h->d_fl); hipFree(h->d_counters);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -1435,7 +1438,12 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kp.wave), BLOCK_THREADS, dynLds);
         fprintf(stderr, "[bbduk] wave grid=%d tile grid=%d block=%d dynLds=%zu occupancyAPI=%d numCU=%d\n", wgrid, tgrid, BLOCK_THREADS, dynLds, occ, h->numCU);
     }
+    const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
+    if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
+    HIP_TRY(h, hipEventRecord(h->ev0[evi], st));
     kp.wave<<<dim3(wgrid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, h->d_slowFlag);
+    HIP_TRY(h, hipEventRecord(h->ev1[evi], st));
+    h->evCount++;
     kp.tile<<<dim3(tgrid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, h->d_slowFlag);
     HIP_TRY(h, hipGetLastError());
     return BBDUK_OK;
@@ -1518,6 +1526,22 @@ extern "C" int bbduk_table_lookup(bbduk_handle* h, const int64_t* keys, int64_t 
     if (e == hipSuccess) e = hipMemcpy(out_ids, dv, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost);
     hipFree(dk); hipFree(dv);
     if (e != hipSuccess) { h->err = hipGetErrorString(e); return BBDUK_ERR_DEVICE; }
+    return BBDUK_OK;
+}
+
+extern "C" int bbduk_kernel_time_ms(bbduk_handle* h, int32_t last_k, float* avg_ms) {
+    if (!h || !avg_ms || last_k < 1) return BBDUK_ERR_ARG;
+    const int64_t have = std::min<int64_t>(h->evCount, bbduk_handle::EV_RING);
+    const int64_t k = std::min<int64_t>(last_k, have);
+    if (k < 1) return fail(h, BBDUK_ERR_STATE, "no launch recorded");
+    double sum = 0;
+    for (int64_t q = 0; q < k; q++) {
+        const int evi = (int)((h->evCount - 1 - q) % bbduk_handle::EV_RING);
+        HIP_TRY(h, hipEventSynchronize(h->ev1[evi]));
+        float ms = 0; HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0[evi], h->ev1[evi]));
+        sum += ms;
+    }
+    *avg_ms = (float)(sum / (double)k);
     return BBDUK_OK;
 }
 

@@ -126,6 +126,10 @@ int  bbduk_kfilter_batch_device(bbduk_handle* h, const uint8_t* d_bases, const i
                                 int64_t total_bases, int32_t paired, int32_t* d_out_found, int32_t* d_out_id,
                                 uint8_t* d_out_flags, int64_t* d_counters, void* stream);
 
+/* Average duration (HIP events on the launch stream) of the dominant kernel over the last `last_k` batch launches
+ * of this handle (at most 64 are remembered).  Synchronises on those launches.  For roofline reporting. */
+int  bbduk_kernel_time_ms(bbduk_handle* h, int32_t last_k, float* avg_ms);
+
 /* ---- counters accumulated by the host-buffer operators */
 int  bbduk_counters_len(const bbduk_handle* h);           /* 16 + 2*numScaffolds */
 int  bbduk_get_counters(bbduk_handle* h, int64_t* out, int32_t n);

@@ -147,6 +147,28 @@ def test_edge_shapes():
         d.gpu.ktrim_batch(b, off, True)
 
 
+def test_tile_kernel_fallback_matches_wave_kernel(monkeypatch):
+    """The tile-synchronous kernel only runs when a pair exceeds a wave's LDS slice; force it on ordinary reads so
+    that both kernels stay interchangeable (same results, same counters as the oracle)."""
+    for cfg in ("c2", "c3", "c1"):
+        args, okw, ref = util.CONFIGS[cfg]
+        d, o = make_pair(args, okw, ref_fasta=ref)
+        kw = dict(contam=B.read_fasta(util.PHIX)[0][1], contam_frac=0.05) if "phix" in args else {}
+        b, off = B.synth_generate_host(B.synth_params(21, **kw), 0, 6000)
+        o.reset_counters(); oa, oi, of = o.process_batch(b, off, True, nthreads=8)
+        for force in (False, True):
+            if force:
+                monkeypatch.setenv("BBDUK_FORCE_TILE", "1")
+            else:
+                monkeypatch.delenv("BBDUK_FORCE_TILE", raising=False)
+            d.gpu.reset_counters()
+            ga, gi, gf = d.gpu.process_batch(b, off, True)
+            assert np.array_equal(ga, oa) and np.array_equal(gi, oi) and np.array_equal(gf, of), (cfg, force)
+            assert np.array_equal(d.gpu.counters(), o.counters()), (cfg, force)
+        monkeypatch.delenv("BBDUK_FORCE_TILE", raising=False)
+        d.close()
+
+
 def test_generator_device_matches_host():
     import torch
     sp = B.synth_params(5, contam=B.read_fasta(util.PHIX)[0][1], contam_frac=0.1)
