@@ -1323,8 +1323,8 @@ extern "C" int bbduk_finalize_table(bbduk_handle* h) {
     const uint64_t nb = 1ULL << bbits;
     if (4 * nb < (uint64_t)n + nb / 8 || 4 * nb > (1ULL << 31)) return fail(h, BBDUK_ERR_ARG, "too many keys for the bucket index");
     std::vector<uint64_t> tg(nb, 0ULL);
-    std::vector<uint64_t> bk(4 * nb, EMPTY_KEY);
-    std::vector<int32_t> bv(4 * nb, 0);
+    std::vector<uint4> kvh(4 * nb, make_uint4(~0u, ~0u, 0u, 0u));  // {key lo, key hi, id, 0}; all-ones key = free
+    auto key_at = [&](uint64_t q) { return ((uint64_t)kvh[q].y << 32) | kvh[q].x; };
     const uint32_t bmask = (uint32_t)(nb - 1);
     int64_t distinct = 0;
     for (size_t i = 0; i < n; i++) {                              // first writer wins (HashArray.setIfNotPresent)
@@ -1335,20 +1335,17 @@ extern "C" int bbduk_finalize_table(bbduk_handle* h) {
             bool done = false;
             for (int w = 0; w < 4 && !done; w++) {
                 const uint64_t tw = (tg[b] >> (16 * w)) & 0xFFFFULL;
-                if (tw == 0) { tg[b] |= tag << (16 * w); bk[4ULL * b + w] = key; bv[4ULL * b + w] = h->hvals[i]; distinct++; done = true; }
-                else if (tw == tag && bk[4ULL * b + w] == key) done = true;
+                if (tw == 0) { tg[b] |= tag << (16 * w); kvh[4ULL * b + w] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)h->hvals[i], 0u); distinct++; done = true; }
+                else if (tw == tag && key_at(4ULL * b + w) == key) done = true;
             }
             if (done) break;
             b = (b + 1) & bmask;
         }
     }
     HIP_TRY(h, hipMalloc(&h->d_tags, nb * sizeof(uint64_t)));
-    {
-        std::vector<uint4> kvh(4 * nb);
-        for (uint64_t q = 0; q < 4 * nb; q++) kvh[q] = make_uint4((uint32_t)bk[q], (uint32_t)(bk[q] >> 32), (uint32_t)bv[q], 0u);
-        HIP_TRY(h, hipMalloc(&h->d_bkv, 4 * nb * sizeof(uint4)));
-        HIP_TRY(h, hipMemcpy(h->d_bkv, kvh.data(), 4 * nb * sizeof(uint4), hipMemcpyHostToDevice));
-    }
+    h->hkeys.clear(); h->hkeys.shrink_to_fit(); h->hvals.clear(); h->hvals.shrink_to_fit();
+    HIP_TRY(h, hipMalloc(&h->d_bkv, 4 * nb * sizeof(uint4)));
+    HIP_TRY(h, hipMemcpy(h->d_bkv, kvh.data(), 4 * nb * sizeof(uint4), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_tags, tg.data(), nb * sizeof(uint64_t), hipMemcpyHostToDevice));
     h->nbuckets = nb; h->bucketBits = bbits; h->nkeys = distinct;
     // Presence filter in front of the map.  Most query k-mers are absent, so one bit per hash slot held in LDS
@@ -1363,8 +1360,8 @@ extern "C" int bbduk_finalize_table(bbduk_handle* h) {
         if (lb) {
             std::vector<uint32_t> f1((size_t)1 << (lb - 5), 0u);
             for (uint64_t s = 0; s < 4 * nb; s++) {
-                if (bk[s] == EMPTY_KEY) continue;
-                const uint32_t h1 = mix_a(bk[s]) >> (32 - lb);
+                if (key_at(s) == EMPTY_KEY) continue;
+                const uint32_t h1 = mix_a(key_at(s)) >> (32 - lb);
                 f1[h1 >> 5] |= 1u << (h1 & 31);
             }
             HIP_TRY(h, hipMalloc(&h->d_ldsImage, f1.size() * 4));
