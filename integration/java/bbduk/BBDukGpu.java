@@ -1,0 +1,67 @@
+package bbduk;
+
+import shared.Shared;
+
+/**
+ * Batch k-mer stage of BBDuk on an MI355X, through libbbduk_jni.so -> libbbduk_hip.so (C ABI: include/bbduk_gpu.h).
+ * Follows the JNI pattern of jgi.BBMergeOverlapper (static natives, Shared.loadJNI, int status, int[]/byte[] outputs).
+ * NOT compiled in this repository (no JDK in the build image); see INTEGRATION.md.
+ *
+ * Usage from BBDukProcessorS.processList (split into pass A / device call / pass B, SURVEY.md section 8b):
+ *   long h = BBDukGpu.create(parser, index.scaffoldNames.size(), deviceOrdinal);
+ *   for each way w: BBDukGpu.uploadWay(h, w, table.prime(), table.array(), table.values(), victimKeys, victimVals);
+ *   BBDukGpu.finalizeTable(h);
+ *   ... per >=1e5 reads: concatenate r.bases into one byte[] + long[] offsets, mates adjacent ...
+ *   BBDukGpu.ktrimBatch(h, bases, offsets, n, paired, outTrimmed, outId0, outFlags);
+ *   ... TrimRead.trimByAmount(r, 0, outTrimmed[i], 1) for ktrim=r; discard/remove from outFlags[i] ...
+ */
+public final class BBDukGpu {
+
+	static{
+		if(Shared.USE_JNI){Shared.loadJNI("bbduk_jni");}
+	}
+
+	/** ip = {mode,k,mink,rcomp,forbidNs,minlen,minlen2,qhdist,qhdist2,maxBadKmers,minReadLength,
+	 *  removePairsIfEitherBad,trimPad,ktrimExclusive,restrictLeft,restrictRight,skipR1,skipR2,numScaffolds,device} */
+	private static native long createJNI(int[] ip, long middleMask, float minLenFraction);
+	private static native int uploadWayJNI(long h, int way, int prime, long[] keys, int[] values, long[] vkeys, int[] vvals);
+	private static native int uploadPairsJNI(long h, long[] keys, int[] values);
+	private static native int finalizeJNI(long h);
+	private static native int ktrimBatchJNI(long h, byte[] bases, long[] offsets, int n, boolean paired,
+			int[] outTrimmed, int[] outId0, byte[] outFlags);
+	private static native int kfilterBatchJNI(long h, byte[] bases, long[] offsets, int n, boolean paired,
+			int[] outFound, int[] outId, byte[] outFlags);
+	private static native int countersJNI(long h, long[] out);
+	private static native void destroyJNI(long h);
+
+	public static final int MODE_KFILTER=0, MODE_KTRIM_R=1, MODE_KTRIM_L=2;
+	public static final int FLAG_DISCARDED=1, FLAG_REMOVED=2;
+
+	public static long create(BBDukParser p, int numScaffolds, int device){
+		final int mode=(p.ktrimRight ? MODE_KTRIM_R : p.ktrimLeft ? MODE_KTRIM_L : MODE_KFILTER);
+		final int[] ip={mode, p.k, p.mink, p.rcomp ? 1 : 0, p.forbidNs ? 1 : 0, p.minlen, p.minlen2,
+				p.qHammingDistance, p.qHammingDistance2, p.maxBadKmers0, p.minReadLength,
+				p.removePairsIfEitherBad ? 1 : 0, p.trimPad, p.ktrimExclusive ? 1 : 0,
+				p.restrictLeft, p.restrictRight, p.skipR1 ? 1 : 0, p.skipR2 ? 1 : 0, numScaffolds, device};
+		final long h=createJNI(ip, p.middleMask, p.minLenFraction);
+		if(h<=0){throw new RuntimeException("bbduk_create failed: "+h);}
+		return h;
+	}
+	public static void uploadWay(long h, int way, int prime, long[] keys, int[] values, long[] vkeys, int[] vvals){
+		check(uploadWayJNI(h, way, prime, keys, values, vkeys, vvals), "bbduk_upload_table_way");
+	}
+	public static void uploadPairs(long h, long[] keys, int[] values){check(uploadPairsJNI(h, keys, values), "bbduk_upload_pairs");}
+	public static void finalizeTable(long h){check(finalizeJNI(h), "bbduk_finalize_table");}
+	public static void ktrimBatch(long h, byte[] bases, long[] offsets, int n, boolean paired, int[] outTrimmed, int[] outId0, byte[] outFlags){
+		check(ktrimBatchJNI(h, bases, offsets, n, paired, outTrimmed, outId0, outFlags), "bbduk_ktrim_batch");
+	}
+	public static void kfilterBatch(long h, byte[] bases, long[] offsets, int n, boolean paired, int[] outFound, int[] outId, byte[] outFlags){
+		check(kfilterBatchJNI(h, bases, offsets, n, paired, outFound, outId, outFlags), "bbduk_kfilter_batch");
+	}
+	public static void counters(long h, long[] out){check(countersJNI(h, out), "bbduk_get_counters");}
+	public static void destroy(long h){destroyJNI(h);}
+
+	private static void check(int rc, String what){
+		if(rc!=0){throw new RuntimeException(what+" returned "+rc);}   // caller ORs this into errorState (BBDukS.java:199-202)
+	}
+}
