@@ -40,6 +40,9 @@ def main():
 
     import numpy as np
     import torch
+    import bbtools_amd
+    if not os.path.exists(bbtools_amd.lib_path()):   # the prebuilt .so normally travels with the tree; build it (hipcc, gfx950) if not
+        bbtools_amd.build()
     from bbtools_amd import bbduk as B
     from bbtools_amd import dist as D
 
