@@ -58,6 +58,7 @@ struct KParams {
     // presence filter in front of the map: one bit per hash slot, copied into LDS by every workgroup
     const uint32_t* ldsImage;   // HBM copy of the LDS bitmap (2^ldsBits bits); 0 bits = absent
     int32_t  ldsBits;
+    int32_t  dbg;               // BBDUK_DBG: timing experiments only (results become wrong); 0 in production
     int32_t  prof;              // BBDUK_PROF=1: per-phase s_memtime sums into counters[] tail (timing experiments only)
     unsigned long long* profOut;
 };
@@ -377,31 +378,25 @@ __device__ __forceinline__ void win_init(const KParams& P, const Planes& Q, cons
     W.plain = (!GENERAL || W.start == 0) && !W.hasN;             // every window holds k bases and no reset
 }
 
-// kmer / rkmer of the windows ending at positions i and i+64 of read W (lane-varying i); ok=false: no lookup due.
-// Plain reads (no reset, no cut) need no clamping: the planes are padded, out-of-read lanes are simply not ok,
-// and the second slot reuses the first slot's shift and word address (+-64 symbols = +-4 words).
+// kmer / rkmer of the windows ending at the ADJACENT positions i and i+1 of read W (lane-varying i); ok=false: no
+// lookup due.  Plain reads (no reset, no cut): one (k+1)-symbol cut per plane serves both positions (k+1 <= 32 symbols
+// fit the 64-bit cut); the planes are padded, so no clamping -- out-of-read lanes are simply not ok.
 template <bool FORBIDN, bool GENERAL>
 __device__ __forceinline__ void windows2(const KParams& P, const Planes& Q, const ReadWin& W, const int i, const bool on,
                                          uint64_t* kmer, uint64_t* rk, bool* ok) {
     const int k = P.k;
     if (W.plain) {
-        const int fbit = 2 * (Q.T - 1 - W.base0 - i) - 128;      // slot 1 (i+64) sits 64 symbols lower in the reversed plane
-        const uint32_t* pf = Q.fwd + (fbit >> 5);
-        const uint32_t f0 = pf[0], f1 = pf[1], f2 = pf[2], f4 = pf[4], f5 = pf[5], f6 = pf[6];
-        const int cbit = 2 * (W.base0 - k + 1 + i);
-        const uint32_t* pc = Q.cmp + (cbit >> 5);
-        const uint32_t c0 = pc[0], c1 = pc[1], c2 = pc[2], c4 = pc[4], c5 = pc[5], c6 = pc[6];
-        kmer[0] = (((uint64_t)__builtin_amdgcn_alignbit(f6, f5, fbit) << 32) | __builtin_amdgcn_alignbit(f5, f4, fbit)) & P.mask;
-        kmer[1] = (((uint64_t)__builtin_amdgcn_alignbit(f2, f1, fbit) << 32) | __builtin_amdgcn_alignbit(f1, f0, fbit)) & P.mask;
-        rk[0]   = (((uint64_t)__builtin_amdgcn_alignbit(c2, c1, cbit) << 32) | __builtin_amdgcn_alignbit(c1, c0, cbit)) & P.mask;
-        rk[1]   = (((uint64_t)__builtin_amdgcn_alignbit(c6, c5, cbit) << 32) | __builtin_amdgcn_alignbit(c5, c4, cbit)) & P.mask;
+        const uint64_t wf = extract2raw(Q.fwd, Q.T - 1 - W.base0 - (i + 1));   // base i+1 in bits 0-1, base i-k+1 on top
+        const uint64_t wc = extract2raw(Q.cmp, W.base0 - k + 1 + i);           // base i-k+1 in bits 0-1, base i+1 on top
+        kmer[1] = wf & P.mask; kmer[0] = (wf >> 2) & P.mask;
+        rk[0] = wc & P.mask;   rk[1] = (wc >> 2) & P.mask;
         ok[0] = on & (i < W.stop);
-        ok[1] = on & (i + 64 < W.stop);
+        ok[1] = on & (i + 1 < W.stop);
         return;
     }
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-        const int ih = i + 64 * h;
+        const int ih = i + h;
         const bool act = on && ih < W.stop;
         const int ic = min(max(ih, W.first), W.stop - 1);        // inactive lanes read in-bounds
         const int lo = max(W.start, ic - k + 1);
@@ -424,8 +419,8 @@ __device__ __forceinline__ void windows2(const KParams& P, const Planes& Q, cons
 }
 
 // four independent key -> ref lookups with their memory operations overlapped
-// candOnly: do not check keys; ref = slot (4*bucket+way) of the first matching fingerprint, -2 if the home bucket is
-// full without a match (chain walk needed), -1 if certainly absent; keyOut receives the lanes' keys.
+// candOnly: do not check keys of matching fingerprints; ref = slot (4*bucket+way) of the first match, -3-id for a hit
+// already verified (full home bucket: the chain is walked at once), -1 if certainly absent; keyOut = the lanes' keys.
 template <bool GENERAL>
 __device__ __forceinline__ void lookup4(const KParams& P, const uint32_t* s_filt, const uint64_t* kmer, const uint64_t* rk,
                                         const bool* ok, int* ref, const bool candOnly = false, uint64_t* keyOut = nullptr) {
@@ -447,6 +442,11 @@ __device__ __forceinline__ void lookup4(const KParams& P, const uint32_t* s_filt
         mb[s] = mix_b(key[s]);
         p[s] = ok[s];
     }
+    if (P.dbg == 2) {                                             // experiment: keys and hashes only
+#pragma unroll
+        for (int s = 0; s < 4; s++) { ref[s] = (p[s] && ma[s] == 0x12345u && mb[s] == 0x54321u) ? 0 : -1; if (candOnly) keyOut[s] = key[s]; }
+        return;
+    }
     if (P.ldsBits) {                                              // four presence bits, read together
         uint32_t w[4];
 #pragma unroll
@@ -454,8 +454,18 @@ __device__ __forceinline__ void lookup4(const KParams& P, const uint32_t* s_filt
 #pragma unroll
         for (int s = 0; s < 4; s++) p[s] = p[s] & (bool)((w[s] >> ((ma[s] >> (32 - P.ldsBits)) & 31)) & 1u);
     }
+    if (P.dbg == 1) {                                             // experiment: filter but no gathers
+#pragma unroll
+        for (int s = 0; s < 4; s++) { ref[s] = (p[s] && ma[s] == 0x12345u) ? 0 : -1; if (candOnly) keyOut[s] = key[s]; }
+        return;
+    }
 #pragma unroll
     for (int s = 0; s < 4; s++) t[s] = p[s] ? P.tags[bucket_of(mb[s], P.bucketBits)] : 0ULL;  // four gathers in flight
+    if (P.dbg == 6) {                                             // experiment: gathers issued, matches ignored
+#pragma unroll
+        for (int s = 0; s < 4; s++) { ref[s] = (t[s] == 0x123456789ULL) ? 0 : -1; if (candOnly) keyOut[s] = key[s]; }
+        return;
+    }
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         // rare: a fingerprint matched, or the home bucket is full -> check the key / walk the bucket chain
@@ -463,29 +473,45 @@ __device__ __forceinline__ void lookup4(const KParams& P, const uint32_t* s_filt
         ref[s] = -1;
         if (candOnly) {
             if (p[s] && cand != 0ULL) ref[s] = (int)(4u * bucket_of(mb[s], P.bucketBits)) + ((__ffsll((unsigned long long)cand) - 1) >> 4);
-            else if (p[s] && zero16(t[s]) == 0ULL) ref[s] = -2;
+            else if (p[s] && zero16(t[s]) == 0ULL) {                // full home bucket, no match there: walk the chain now
+                const int id = table_find_t(P, key[s], ma[s], mb[s], t[s]);
+                ref[s] = id > 0 ? -3 - id : -1;                        // <= -4: a verified id, nothing left to check
+            }
             keyOut[s] = key[s];
         } else if (p[s] && (cand != 0ULL || zero16(t[s]) == 0ULL)) ref[s] = table_find_t(P, key[s], ma[s], mb[s], t[s]);
     }
 }
 
-// fold one slot's hit mask into the read's scan state; returns true when the scan of this read is over
+// bit 2j of the result = bit j of e, bit 2j+1 = bit j of o (wave-uniform scalar work)
+__device__ __forceinline__ uint64_t interleave32(uint32_t e, uint32_t o) {
+    auto spread = [](uint64_t x) {
+        x = (x | (x << 16)) & 0x0000FFFF0000FFFFULL; x = (x | (x << 8)) & 0x00FF00FF00FF00FFULL;
+        x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0FULL;  x = (x | (x << 2)) & 0x3333333333333333ULL;
+        x = (x | (x << 1)) & 0x5555555555555555ULL;  return x;
+    };
+    return spread(e) | (spread(o) << 1);
+}
+
+// fold 64 consecutive positions' hit mask (bit p <=> position ibase+p, held by lane laneBase+(p>>1), parity p&1) into
+// the read's scan state; returns true when the scan of this read is over
 template <int MODE>
-__device__ __forceinline__ bool fold_hits(const KParams& P, ReadScan& R, int& found, const uint64_t m, const int ref, const int ibase) {
+__device__ __forceinline__ bool fold_hits(const KParams& P, ReadScan& R, int& found, const uint64_t m, const int refE, const int refO,
+                                          const int ibase, const int laneBase) {
     if (!m) return false;
+    auto ref_at = [&](int p) { const int l = laneBase + (p >> 1); return (p & 1) ? __builtin_amdgcn_readlane(refO, l) : __builtin_amdgcn_readlane(refE, l); };
     if (MODE != BBDUK_MODE_KFILTER) {
         const int fl = __ffsll((unsigned long long)m) - 1, ll = 63 - __clzll((long long)m);
-        if (found == 0) { R.iFirst = ibase + fl; R.ref = __builtin_amdgcn_readlane(ref, fl); }
+        if (found == 0) { R.iFirst = ibase + fl; R.ref = ref_at(fl); }
         R.iLast = ibase + ll;
         found += __popcll(m);
         return MODE == BBDUK_MODE_KTRIM_R;                       // only minLoc/id0 of the first hit are used
     } else {
         const int c = __popcll(m);
-        if (found + c > P.maxBadKmers) {                         // the (maxBadKmers+1)-th hit is in this slot
+        if (found + c > P.maxBadKmers) {                         // the (maxBadKmers+1)-th hit is in this block
             uint64_t mm = m;
             for (int q = found; q < P.maxBadKmers; q++) mm &= mm - 1;
             const int fl = __ffsll((unsigned long long)mm) - 1;
-            R.ref = __builtin_amdgcn_readlane(ref, fl);
+            R.ref = ref_at(fl);
             found = P.maxBadKmers + 1;
             R.iFirst = 0;                                        // marks the early exit
             return true;
@@ -504,19 +530,25 @@ __device__ __forceinline__ void main_scan_pair(const KParams& P, const Planes& Q
     bool onA = WA.on, onB = WB.on;
     while (onA || onB) {
         uint64_t kmer[4], rk[4]; bool ok[4]; int id[4];
-        windows2<FORBIDN, GENERAL>(P, Q, WA, ibA + lane, onA, kmer, rk, ok);
-        windows2<FORBIDN, GENERAL>(P, Q, WB, ibB + lane, onB, kmer + 2, rk + 2, ok + 2);
+        windows2<FORBIDN, GENERAL>(P, Q, WA, ibA + 2 * lane, onA, kmer, rk, ok);
+        windows2<FORBIDN, GENERAL>(P, Q, WB, ibB + 2 * lane, onB, kmer + 2, rk + 2, ok + 2);
         lookup4<GENERAL>(P, Q.filt, kmer, rk, ok, id);
         const uint64_t m0 = __ballot(id[0] != -1), m1 = __ballot(id[1] != -1), m2 = __ballot(id[2] != -1), m3 = __ballot(id[3] != -1);
         if (onA) {
-            bool ex = fold_hits<MODE>(P, A, foundA, m0, id[0], ibA);
-            if (!ex) ex = fold_hits<MODE>(P, A, foundA, m1, id[1], ibA + 64);
+            bool ex = false;
+            if (m0 | m1) {
+                ex = fold_hits<MODE>(P, A, foundA, interleave32((uint32_t)m0, (uint32_t)m1), id[0], id[1], ibA, 0);
+                if (!ex) ex = fold_hits<MODE>(P, A, foundA, interleave32((uint32_t)(m0 >> 32), (uint32_t)(m1 >> 32)), id[0], id[1], ibA + 64, 32);
+            }
             ibA += 128;
             onA = !ex && ibA < WA.stop;
         }
         if (onB) {
-            bool ex = fold_hits<MODE>(P, B, foundB, m2, id[2], ibB);
-            if (!ex) ex = fold_hits<MODE>(P, B, foundB, m3, id[3], ibB + 64);
+            bool ex = false;
+            if (m2 | m3) {
+                ex = fold_hits<MODE>(P, B, foundB, interleave32((uint32_t)m2, (uint32_t)m3), id[2], id[3], ibB, 0);
+                if (!ex) ex = fold_hits<MODE>(P, B, foundB, interleave32((uint32_t)(m2 >> 32), (uint32_t)(m3 >> 32)), id[2], id[3], ibB + 64, 32);
+            }
             ibB += 128;
             onB = !ex && ibB < WB.stop;
         }
@@ -537,8 +569,8 @@ __device__ __forceinline__ void main_scan_pair_cand(const KParams& P, const Plan
     A.candSlot = -1; B.candSlot = -1;
     while (onA || onB) {
         uint64_t kmer[4], rk[4], key[4]; bool ok[4]; int ref[4];
-        windows2<FORBIDN, GENERAL>(P, Q, WA, ibA + lane, onA, kmer, rk, ok);
-        windows2<FORBIDN, GENERAL>(P, Q, WB, ibB + lane, onB, kmer + 2, rk + 2, ok + 2);
+        windows2<FORBIDN, GENERAL>(P, Q, WA, ibA + 2 * lane, onA, kmer, rk, ok);
+        windows2<FORBIDN, GENERAL>(P, Q, WB, ibB + 2 * lane, onB, kmer + 2, rk + 2, ok + 2);
         lookup4<GENERAL>(P, Q.filt, kmer, rk, ok, ref, true, key);
 #pragma unroll
         for (int r = 0; r < 2; r++) {
@@ -546,17 +578,17 @@ __device__ __forceinline__ void main_scan_pair_cand(const KParams& P, const Plan
             bool& on = r ? onB : onA;
             int& ib = r ? ibB : ibA;
             if (!on) continue;
-            const uint64_t m0 = __ballot(ref[2 * r] != -1), m1 = __ballot(ref[2 * r + 1] != -1);
-            if (m0 | m1) {
-                const int h = m0 ? 0 : 1;
-                const uint64_t m = m0 ? m0 : m1;
-                const int l = __ffsll((unsigned long long)m) - 1;
+            const uint64_t me = __ballot(ref[2 * r] != -1), mo = __ballot(ref[2 * r + 1] != -1);
+            if (me | mo) {                                        // first candidate in position order: lane l, parity h
+                const int le = me ? __ffsll((unsigned long long)me) - 1 : 64, lo = mo ? __ffsll((unsigned long long)mo) - 1 : 64;
+                const int h = (2 * lo + 1 < 2 * le) ? 1 : 0;
+                const int l = h ? lo : le;
                 const int rs = h ? ref[2 * r + 1] : ref[2 * r];
                 const uint64_t ks = h ? key[2 * r + 1] : key[2 * r];
                 R.candSlot = __builtin_amdgcn_readlane(rs, l);
                 R.candKeyLo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ks, l);
                 R.candKeyHi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ks >> 32), l);
-                R.iFirst = ib + 64 * h + l;
+                R.iFirst = ib + 2 * l + h;
                 on = false;
             } else {
                 ib += 128;
@@ -937,7 +969,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
             const int lead = (int)(B0 - A0);                        // bases in front of read s inside the first chunk
             const int nchunks = (lead + (rel_e - rel_s) + 15) >> 4;
             // ---- stage this wave's reads: 16 bases per lane-iteration -> the wave's private bit-planes
-            for (int c = lane; c < nchunks; c += 64) {
+            for (int c = lane; c < nchunks && P.dbg != 5; c += 64) {
                 uint32_t r, comp, valid;
                 encode_chunk(bases, A0 + 16LL * c, totalBases, r, comp, valid);
                 wf[PLANE_PAD + nchunks - 1 - c] = r;
@@ -965,7 +997,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                 A.found = 0; A.iFirst = BIGLOC; A.iLast = -1; A.ref = -1; A.shortFl = -1; A.shortLl = -1;
                 Bz.found = 0; Bz.iFirst = BIGLOC; Bz.iLast = -1; Bz.ref = -1; Bz.shortFl = -1; Bz.shortLl = -1;
                 if (candMode) {
-                    main_scan_pair_cand<FORBIDN, GENERAL>(P, Q, A, Bz, lane);
+                    if (P.dbg != 3) main_scan_pair_cand<FORBIDN, GENERAL>(P, Q, A, Bz, lane); else { A.candSlot = -1; Bz.candSlot = -1; }
                     if (A.candSlot != -1) {
                         vCSlot = (lane == ra) ? A.candSlot : vCSlot; vFirst = (lane == ra) ? A.iFirst : vFirst;
                         vCKeyLo = (lane == ra) ? A.candKeyLo : vCKeyLo; vCKeyHi = (lane == ra) ? A.candKeyHi : vCKeyHi;
@@ -991,7 +1023,11 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
             if (candMode) {
                 // ---- verify the sub-tile's candidates together: lane j fetches key+id of read j's candidate
                 const bool inSub = lane >= s && lane < e;
-                bool fb = inSub && vCSlot == -2;                    // full home bucket: needs the chain walk
+                bool fb = false;
+                if (inSub && vCSlot <= -4) {                        // verified during the scan (chain walk)
+                    vRef = -3 - vCSlot; vFound = (MODE == BBDUK_MODE_KFILTER) ? P.maxBadKmers + 1 : 1;
+                    if (MODE == BBDUK_MODE_KFILTER) vFirst = 0;
+                }
                 if (inSub && vCSlot >= 0) {
                     const uint4 kv = P.bkv[vCSlot];
                     if (kv.x == vCKeyLo && kv.y == vCKeyHi) {
@@ -1021,7 +1057,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
             // ---- short k-mers (:2034-2103) for the reads of [s,e) whose main scan found nothing, several reads per
             // pass: worker lane w looks up length mink+st of the read in slot sslot (lens lengths per read).
             if constexpr (MODE != BBDUK_MODE_KFILTER && SHORT) {
-                if (P.useShort) {
+                if (P.useShort && P.dbg != 4) {
                     const bool need = mine && vScan && vFound == 0 && lane >= s && lane < e;
                     uint64_t needM = __ballot(need);
                     if (needM) {
@@ -1076,6 +1112,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
             s = e;
         }
 
+        if (P.dbg == 7) continue;                                 // experiment: no decide stage, no outputs
         // ---- finish, data-parallel: lane j turns read j's scan facts into outputs, pair logic via the neighbour lane
         int a, newLen, ref; bool hit;
         finish_read<MODE>(P, vL, vStart, vStop, vFound, vFirst, vLast, vSFl, vSLl, vRef, a, newLen, ref, hit);
@@ -1316,9 +1353,12 @@ extern "C" int bbduk_finalize_table(bbduk_handle* h) {
     if (h->finalized) return fail(h, BBDUK_ERR_STATE, "table already finalized");
     HIP_TRY(h, hipSetDevice(h->p.device));
     const size_t n = h->hkeys.size();
-    // 4-way buckets of 16-bit fingerprints, about one key per bucket on average (see KParams).
+    // 4-way buckets of 16-bit fingerprints.  Cache-resident maps get >= 2 buckets per key: a full home bucket
+    // (4+ keys) costs a dependent chain walk in the scan, and at load 0.25-0.5 keys/bucket it is ~15x rarer than
+    // at 0.5-1 (measured: C2 10.07 -> 9.62 ms per 20 M reads).  HBM-resident maps keep >= 1 bucket per key.
     int bbits = 10;
     while (bbits < 32 && (1ULL << bbits) < (uint64_t)n) bbits++;
+    if (n <= (1ULL << 24)) bbits++;
     if (const char* e = getenv("BBDUK_BUCKET_BITS")) { const int v = atoi(e); if (v >= 4 && v <= 32) bbits = v; }
     const uint64_t nb = 1ULL << bbits;
     if (4 * nb < (uint64_t)n + nb / 8 || 4 * nb > (1ULL << 31)) return fail(h, BBDUK_ERR_ARG, "too many keys for the bucket index");
@@ -1396,6 +1436,7 @@ static KParams make_kparams(const bbduk_handle* h) {
     K.middleMask = (uint64_t)p.middleMask;
     K.tags = h->d_tags; K.bkv = h->d_bkv; K.bucketMask = (uint32_t)(h->nbuckets - 1); K.bucketBits = h->bucketBits;
     K.storedKmers = h->nkeys;
+    K.dbg = getenv("BBDUK_DBG") ? atoi(getenv("BBDUK_DBG")) : 0;
     K.ldsImage = h->d_ldsImage; K.ldsBits = h->ldsBits;
     K.prof = getenv("BBDUK_PROF") ? 1 : 0; K.profOut = h->d_prof;
     return K;
