@@ -45,11 +45,12 @@ struct KParams {
     float   minLenFraction;
     int32_t rieb, trimPad, ktrimExclusive, restrictLeft, restrictRight, skipR1, skipR2, numScaffolds, useShort;
     uint64_t mask, kmask, middleMask;
-    // The map, device layout: 4-way buckets.  tags[b] packs four 16-bit fingerprints (0 = free way); the full key
-    // and its id live together in bkv[4*b+way] (16 bytes: one fetch verifies the key and yields the id) and are
-    // touched only when a fingerprint matches.  A key sits in the
-    // first bucket >= its home bucket that had a free way (bucket-granular linear probing), so a query stops at
-    // the first bucket that has a free way.  One 8-byte gather answers almost every absent k-mer.
+    // The map, device layout: 4-way buckets.  tags[b] packs four 15-bit fingerprints in 16-bit lanes (0 = free
+    // way) plus the bucket's continuation flag in bit 63; the full key and its id live together in bkv[4*b+way]
+    // (16 bytes: one fetch verifies the key and yields the id) and are touched only when a fingerprint matches.
+    // A key sits in the first bucket >= its home bucket that had a free way (bucket-granular linear probing);
+    // every full bucket it passed gets the continuation flag, so a query stops at the first unflagged bucket.
+    // One 8-byte gather answers almost every absent k-mer.
     const uint64_t* tags;
     const uint4*    bkv;        // {key lo, key hi, id, 0}
     uint32_t bucketMask;
@@ -101,7 +102,11 @@ __host__ __device__ __forceinline__ uint32_t mix_b(uint64_t key) {
     return mul24(lo, MB0) + mul24(p1, MB1) + mul24(p2, MB2);
 }
 __host__ __device__ __forceinline__ uint32_t bucket_of(uint32_t mb, int bucketBits) { return mb >> (32 - bucketBits); }
-__host__ __device__ __forceinline__ uint32_t tag_of(uint32_t ma) { const uint32_t t = (ma >> 3) & 0xFFFFu; return t ? t : 1u; }
+// 15-bit fingerprint, never 0 (0 = free way).  Bit 63 of a bucket's tag word is its continuation flag: some key
+// found this bucket full and was placed further along, so an unmatched lookup has to go on to the next bucket.
+__host__ __device__ __forceinline__ uint32_t tag_of(uint32_t ma) { const uint32_t t = (ma >> 3) & 0x7FFFu; return t ? t : 1u; }
+#define TAG_CONT  0x8000000000000000ULL
+#define TAG_FPS   0x7FFFFFFFFFFFFFFFULL
 
 // 0x8000 in every 16-bit lane of v that is zero (may also flag lanes above a true zero lane: callers verify)
 __device__ __forceinline__ uint64_t zero16(uint64_t v) { return (v - 0x0001000100010001ULL) & ~v & 0x8000800080008000ULL; }
@@ -112,14 +117,14 @@ __device__ __forceinline__ int table_find_t(const KParams& P, uint64_t key, uint
     const uint64_t pat = (uint64_t)tag_of(ma) * 0x0001000100010001ULL;
     uint64_t t = t0;
     for (;;) {
-        uint64_t cand = zero16(t ^ pat);
+        uint64_t cand = zero16((t & TAG_FPS) ^ pat);
         while (cand) {
             const int way = (__ffsll((unsigned long long)cand) - 1) >> 4;
             const uint4 kv = P.bkv[4ULL * b + way];
             if ((((uint64_t)kv.y << 32) | kv.x) == key) return (int)kv.z;
             cand &= cand - 1;
         }
-        if (zero16(t)) return -1;                 // a free way: the key cannot be further along
+        if (!(t & TAG_CONT)) return -1;           // nothing ever overflowed from here: the key cannot be further along
         b = (b + 1) & P.bucketMask;
         t = P.tags[b];
     }
@@ -469,16 +474,16 @@ __device__ __forceinline__ void lookup4(const KParams& P, const uint32_t* s_filt
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         // rare: a fingerprint matched, or the home bucket is full -> check the key / walk the bucket chain
-        const uint64_t cand = zero16(t[s] ^ ((uint64_t)tag_of(ma[s]) * 0x0001000100010001ULL));
+        const uint64_t cand = zero16((t[s] & TAG_FPS) ^ ((uint64_t)tag_of(ma[s]) * 0x0001000100010001ULL));
         ref[s] = -1;
         if (candOnly) {
             if (p[s] && cand != 0ULL) ref[s] = (int)(4u * bucket_of(mb[s], P.bucketBits)) + ((__ffsll((unsigned long long)cand) - 1) >> 4);
-            else if (p[s] && zero16(t[s]) == 0ULL) {                // full home bucket, no match there: walk the chain now
+            else if (p[s] && (t[s] & TAG_CONT)) {                   // home bucket overflowed, no match there: walk the chain now
                 const int id = table_find_t(P, key[s], ma[s], mb[s], t[s]);
                 ref[s] = id > 0 ? -3 - id : -1;                        // <= -4: a verified id, nothing left to check
             }
             keyOut[s] = key[s];
-        } else if (p[s] && (cand != 0ULL || zero16(t[s]) == 0ULL)) ref[s] = table_find_t(P, key[s], ma[s], mb[s], t[s]);
+        } else if (p[s] && (cand != 0ULL || (t[s] & TAG_CONT))) ref[s] = table_find_t(P, key[s], ma[s], mb[s], t[s]);
     }
 }
 
@@ -1353,12 +1358,10 @@ extern "C" int bbduk_finalize_table(bbduk_handle* h) {
     if (h->finalized) return fail(h, BBDUK_ERR_STATE, "table already finalized");
     HIP_TRY(h, hipSetDevice(h->p.device));
     const size_t n = h->hkeys.size();
-    // 4-way buckets of 16-bit fingerprints.  Cache-resident maps get >= 2 buckets per key: a full home bucket
-    // (4+ keys) costs a dependent chain walk in the scan, and at load 0.25-0.5 keys/bucket it is ~15x rarer than
-    // at 0.5-1 (measured: C2 10.07 -> 9.62 ms per 20 M reads).  HBM-resident maps keep >= 1 bucket per key.
+    // 4-way buckets of 15-bit fingerprints, >= 1 bucket per key (load 0.5-1 keys/bucket: ~0.1-0.4 % of buckets
+    // overflow and carry the continuation flag, so almost every lookup ends in its home bucket).
     int bbits = 10;
     while (bbits < 32 && (1ULL << bbits) < (uint64_t)n) bbits++;
-    if (n <= (1ULL << 24)) bbits++;
     if (const char* e = getenv("BBDUK_BUCKET_BITS")) { const int v = atoi(e); if (v >= 4 && v <= 32) bbits = v; }
     const uint64_t nb = 1ULL << bbits;
     if (4 * nb < (uint64_t)n + nb / 8 || 4 * nb > (1ULL << 31)) return fail(h, BBDUK_ERR_ARG, "too many keys for the bucket index");
@@ -1374,11 +1377,12 @@ extern "C" int bbduk_finalize_table(bbduk_handle* h) {
         for (;;) {
             bool done = false;
             for (int w = 0; w < 4 && !done; w++) {
-                const uint64_t tw = (tg[b] >> (16 * w)) & 0xFFFFULL;
+                const uint64_t tw = (tg[b] >> (16 * w)) & 0x7FFFULL;
                 if (tw == 0) { tg[b] |= tag << (16 * w); kvh[4ULL * b + w] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)h->hvals[i], 0u); distinct++; done = true; }
                 else if (tw == tag && key_at(4ULL * b + w) == key) done = true;
             }
             if (done) break;
+            tg[b] |= TAG_CONT;
             b = (b + 1) & bmask;
         }
     }
