@@ -284,6 +284,7 @@ struct ReadScan {
     int ref;                            // ref (see ref_to_id) of the hit whose id the reference reports
     int shortFl, shortLl;               // short k-mer scan: first / last hit lane (length index); shortFl<0: none
     int candSlot; uint32_t candKeyLo, candKeyHi;   // candidate mode: first unverified fingerprint match (slot, key)
+    int hasN;                           // undefined base inside [start,stop)?  1/0, or -1 = not known yet (forbidNs only)
 };
 
 template <int MODE, bool SHORT, bool GENERAL>
@@ -307,7 +308,7 @@ template <bool GENERAL> __device__ __forceinline__ int span_stop(const KParams& 
 }
 template <int MODE, bool SHORT, bool GENERAL>
 __device__ __forceinline__ void read_init(const KParams& P, ReadScan& R, int base0, int L, int pairnum, bool present) {
-    R.base0 = base0; R.L = L;
+    R.base0 = base0; R.L = L; R.hasN = -1;
     R.found = 0; R.iFirst = BIGLOC; R.iLast = -1; R.ref = -1; R.shortFl = -1; R.shortLl = -1;
     R.start = span_start<GENERAL>(P, L); R.stop = span_stop<GENERAL>(P, L);
     R.scan = scan_due<MODE, SHORT, GENERAL>(P, L, pairnum, present);
@@ -360,7 +361,7 @@ __device__ __forceinline__ void finish_read(const KParams& P, const int L, const
 // gathers are in flight together (the scan is latency-bound otherwise: LDS -> filter -> L2 gather per pass).
 // bbduk/BBDukProcessorS.java:2009-2029 (ktrim) == :1547-1591 (countSetKmers).
 
-struct ReadWin { int first, stop, start, base0; bool on, plain, hasN; };   // wave-uniform per read
+struct ReadWin { int first, stop, start, base0; bool on, full, hasN; };   // wave-uniform per read
 
 template <bool FORBIDN, bool GENERAL>
 __device__ __forceinline__ void win_init(const KParams& P, const Planes& Q, const ReadScan& R, ReadWin& W, const int lane) {
@@ -368,7 +369,8 @@ __device__ __forceinline__ void win_init(const KParams& P, const Planes& Q, cons
     W.first = max(R.start, P.k - 1);                             // i>=minlen (minlen=k-1)
     W.on = R.scan && W.first < W.stop;
     W.hasN = false;                                              // undefined base inside [start,stop)? (forbidNs only)
-    if (FORBIDN && P.forbidNs && W.on) {
+    if (FORBIDN && P.forbidNs && W.on && R.hasN >= 0) W.hasN = R.hasN != 0;
+    else if (FORBIDN && P.forbidNs && W.on) {
         const int b0 = W.base0 + W.start, b1 = W.base0 + W.stop;
         uint32_t acc = 0;
         for (int w = (b0 >> 5) + lane; w <= ((b1 - 1) >> 5); w += 64) {
@@ -380,7 +382,7 @@ __device__ __forceinline__ void win_init(const KParams& P, const Planes& Q, cons
         }
         W.hasN = __ballot(acc != 0) != 0;
     }
-    W.plain = (!GENERAL || W.start == 0) && !W.hasN;             // every window holds k bases and no reset
+    W.full = (!GENERAL || W.start == 0);                         // every window holds k bases
 }
 
 // kmer / rkmer of the windows ending at the ADJACENT positions i and i+1 of read W (lane-varying i); ok=false: no
@@ -390,13 +392,28 @@ template <bool FORBIDN, bool GENERAL>
 __device__ __forceinline__ void windows2(const KParams& P, const Planes& Q, const ReadWin& W, const int i, const bool on,
                                          uint64_t* kmer, uint64_t* rk, bool* ok) {
     const int k = P.k;
-    if (W.plain) {
+    if (W.full) {
         const uint64_t wf = extract2raw(Q.fwd, Q.T - 1 - W.base0 - (i + 1));   // base i+1 in bits 0-1, base i-k+1 on top
         const uint64_t wc = extract2raw(Q.cmp, W.base0 - k + 1 + i);           // base i-k+1 in bits 0-1, base i+1 on top
         kmer[1] = wf & P.mask; kmer[0] = (wf >> 2) & P.mask;
         rk[0] = wc & P.mask;   rk[1] = (wc >> 2) & P.mask;
         ok[0] = on & (i < W.stop);
         ok[1] = on & (i + 1 < W.stop);
+        if (FORBIDN && W.hasN) {                                 // the read holds an undefined base somewhere: patch the few windows that see it
+            const int nidx = min(W.base0 - k + 1 + i, Q.T);      // bit t <=> base i-k+1+t undefined
+            const uint32_t nw = __builtin_amdgcn_alignbit(Q.nm[(nidx >> 5) + 1], Q.nm[nidx >> 5], nidx);
+            if (__ballot(nw != 0u) != 0ULL) {
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const uint32_t nh = (nw >> h) & ((1u << k) - 1u);
+                    if (nh) {
+                        const int msb = 31 - __clz(nh);
+                        rk[h] &= ~0ULL << (2 * (msb + 1));       // rkmer was reset there; kmer keeps its history
+                        ok[h] = ok[h] && (k - 1 - msb) >= P.minlen2;   // len = bases after the last undefined one
+                    }
+                }
+            }
+        }
         return;
     }
 #pragma unroll
@@ -988,9 +1005,25 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
 
             Planes Q; Q.fwd = wf + PLANE_PAD; Q.cmp = wc + PLANE_PAD; Q.nm = wn; Q.filt = s_filt; Q.T = nchunks * 16;
             const int origin = lead - rel_s;                        // plane index of a base = origin + (its offset in the mini-tile)
+            uint64_t nMask = 0;                                     // reads of [s,e) with an undefined base inside their span
+            if (FORBIDN && P.forbidNs) {                            // lane j looks at read j's words of the undefined-plane
+                uint32_t acc = 0;
+                if (lane >= s && lane < e && vScan) {
+                    const int b0 = origin + rel + vStart, b1 = origin + rel + vStop;
+                    for (int w = b0 >> 5; w <= ((b1 - 1) >> 5); w++) {
+                        uint32_t v = wn[w];
+                        const int lo = w << 5;
+                        if (lo < b0) v &= ~0u << (b0 - lo);
+                        if (lo + 32 > b1) v &= ~0u >> (lo + 32 - b1);
+                        acc |= v;
+                    }
+                }
+                nMask = __ballot(acc != 0u);
+            }
             for (int ra = s; ra < e; ra += 2) {
                 const bool hasB = (ra + 1) < e;
                 ReadScan A, Bz;
+                A.hasN = (int)((nMask >> ra) & 1); Bz.hasN = (int)((nMask >> (ra + 1)) & 1);
                 A.base0 = origin + __builtin_amdgcn_readlane(rel, ra);
                 A.L = __builtin_amdgcn_readlane(vL, ra);
                 A.scan = (scanMask >> ra) & 1;
@@ -1046,6 +1079,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                     const int ra = s + ((j - s) & ~1);
                     const bool hasB = (ra + 1) < e;
                     ReadScan A, Bz;
+                    A.hasN = -1; Bz.hasN = -1;
                     A.base0 = origin + __builtin_amdgcn_readlane(rel, ra); A.L = __builtin_amdgcn_readlane(vL, ra); A.scan = (scanMask >> ra) & 1;
                     Bz.base0 = origin + __builtin_amdgcn_readlane(rel, ra + 1); Bz.L = hasB ? __builtin_amdgcn_readlane(vL, ra + 1) : 0;
                     Bz.scan = hasB && ((scanMask >> (ra + 1)) & 1);

@@ -14,12 +14,15 @@ CONFIGS = {
 
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--reads", type=int, default=20_000_000); ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--only", default=None, help="comma list of config names"); ap.add_argument("--args", default=None, help="override the BBDuk argument string (experiments)")
     a = ap.parse_args()
     import torch
     from bbtools_amd import bbduk as B
     phix = B.read_fasta(os.path.join(ROOT, "data", "phix2.fa.gz"))[0][1]
     n_pairs = a.reads // 2; n = 2 * n_pairs
     for name, (args, extra) in CONFIGS.items():
+        if a.only and name not in a.only.split(","): continue
+        if a.args: args = a.args
         duk = B.BBDuk(args)
         kw = dict(contam=phix, contam_frac=extra["phix"]) if "phix" in extra else {}
         sp = B.synth_params({"C1": 1, "C2": 2, "C3": 3, "C5": 5}[name], **kw)
