@@ -63,7 +63,7 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    path = lib_path()
+    path = os.environ.get("BBDUK_LIB_PATH") or lib_path()      # override: A/B timing of two builds in one process launch
     if not os.path.exists(path):
         raise BBDukError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                          "(there is no CPU fallback for this path)" % path)

@@ -74,37 +74,29 @@ __device__ __forceinline__ uint64_t dev_rcomp(uint64_t kmer, int len) {
     return x >> (64 - 2 * len);
 }
 
-// Two independent 32-bit mixes of a key, built from 24x24-bit multiplies only (v_mul_u32_u24 / v_mad_u32_u24 are
-// full-rate on CDNA; v_mul_lo_u32 is not).  A key (< 2^63) is cut into three 24-bit pieces; the top bits of each
-// sum are well mixed (measured on the adapter / phiX key sets: filter fill and bucket loads equal the ideal
-// Poisson figures).  mix_a feeds the LDS presence bit and the 8-bit fingerprint, mix_b the bucket index.
-#define MA0 0x9E3779u
-#define MA1 0x85EBCBu
-#define MA2 0xC2B2AFu
-#define MB0 0x27D4EBu
-#define MB1 0x165667u
-#define MB2 0xD3A265u
-__host__ __device__ __forceinline__ uint32_t mul24(uint32_t x, uint32_t c) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __umul24(x, c);
-#else
-    return (x & 0xFFFFFFu) * c;
-#endif
-}
-__host__ __device__ __forceinline__ uint32_t mix_a(uint64_t key) {
-    const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
-    const uint32_t p1 = (lo >> 24) | (hi << 8), p2 = hi >> 16;
-    return mul24(lo, MA0) + mul24(p1, MA1) + mul24(p2, MA2);
-}
-__host__ __device__ __forceinline__ uint32_t mix_b(uint64_t key) {
-    const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
-    const uint32_t p1 = (lo >> 24) | (hi << 8), p2 = hi >> 16;
-    return mul24(lo, MB0) + mul24(p1, MB1) + mul24(p2, MB2);
-}
+// Two independent 32-bit multiplicative mixes of a key (< 2^63): lo*A0 + hi*A1 with odd constants.  On gfx950
+// v_mul_lo_u32 issues at (almost) the rate of a simple integer op (profiles/ubench/valu_rate.hip: 2.6 vs 2.4
+// cycles per wave-instruction), so two multiplies and an add beat the three 24-bit pieces used before.  The top
+// bits of each sum are well mixed.  mix_a feeds the LDS presence filter (word index from its top bits, bit index
+// from its low 5 bits) and the 15-bit fingerprint (bits 16-30); mix_b feeds the bucket index (top bits).
+#define HA0 0x9E3779B1u
+#define HA1 0x85EBCA6Bu
+#define HB0 0xC2B2AE35u
+#define HB1 0x27D4EB2Fu
+__host__ __device__ __forceinline__ uint32_t mix_a(uint64_t key) { return (uint32_t)key * HA0 + (uint32_t)(key >> 32) * HA1; }
+__host__ __device__ __forceinline__ uint32_t mix_b(uint64_t key) { return (uint32_t)key * HB0 + (uint32_t)(key >> 32) * HB1; }
 __host__ __device__ __forceinline__ uint32_t bucket_of(uint32_t mb, int bucketBits) { return mb >> (32 - bucketBits); }
-// 15-bit fingerprint, never 0 (0 = free way).  Bit 63 of a bucket's tag word is its continuation flag: some key
-// found this bucket full and was placed further along, so an unmatched lookup has to go on to the next bucket.
-__host__ __device__ __forceinline__ uint32_t tag_of(uint32_t ma) { const uint32_t t = (ma >> 3) & 0x7FFFu; return t ? t : 1u; }
+// 15-bit fingerprint (0 is a legal value: a free way's lane also reads 0, so a query whose fingerprint is 0 sees
+// free ways as candidates and the key check rejects them).  Bit 63 of a bucket's tag word is its continuation flag:
+// some key found this bucket full and was placed further along, so an unmatched lookup goes on to the next bucket.
+__host__ __device__ __forceinline__ uint32_t tag_of(uint32_t ma) { return (ma >> 16) & 0x7FFFu; }
+// LDS presence filter of 2^ldsBits bits: byte address of the word, and the bit inside it (low 5 bits of ma; shifts
+// use only those bits of their count)
+__host__ __device__ __forceinline__ uint32_t filt_byte(uint32_t ma, int ldsBits) { return (ma >> (35 - ldsBits)) & ~3u; }
+__device__ __forceinline__ uint32_t filt_test(const uint32_t* s_filt, uint32_t ma, int ldsBits) {
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_filt) + filt_byte(ma, ldsBits));
+    return (w >> (ma & 31u)) & 1u;
+}
 #define TAG_CONT  0x8000000000000000ULL
 #define TAG_FPS   0x7FFFFFFFFFFFFFFFULL
 
@@ -140,10 +132,7 @@ __device__ __forceinline__ int ref_to_id(const KParams& P, int ref) { return ref
 __device__ __forceinline__ int probe_ref(const KParams& P, const uint32_t* s_filt, uint64_t key, bool ok) {
     const uint32_t ma = mix_a(key);
     bool p = ok;
-    if (P.ldsBits) {
-        const uint32_t h1 = ma >> (32 - P.ldsBits);
-        p = p & (bool)((s_filt[h1 >> 5] >> (h1 & 31)) & 1u);
-    }
+    if (P.ldsBits) p = p & (bool)filt_test(s_filt, ma, P.ldsBits);
     int ref = -1;
     if (p) ref = table_find_m(P, key, ma, mix_b(key));
     return ref;
@@ -441,11 +430,9 @@ __device__ __forceinline__ void windows2(const KParams& P, const Planes& Q, cons
 }
 
 // four independent key -> ref lookups with their memory operations overlapped
-// candOnly: do not check keys of matching fingerprints; ref = slot (4*bucket+way) of the first match, -3-id for a hit
-// already verified (full home bucket: the chain is walked at once), -1 if certainly absent; keyOut = the lanes' keys.
 template <bool GENERAL>
 __device__ __forceinline__ void lookup4(const KParams& P, const uint32_t* s_filt, const uint64_t* kmer, const uint64_t* rk,
-                                        const bool* ok, int* ref, const bool candOnly = false, uint64_t* keyOut = nullptr) {
+                                        const bool* ok, int* ref) {
     if constexpr (GENERAL) {
         if (P.qhdist > 0) {
 #pragma unroll
@@ -466,41 +453,97 @@ __device__ __forceinline__ void lookup4(const KParams& P, const uint32_t* s_filt
     }
     if (P.dbg == 2) {                                             // experiment: keys and hashes only
 #pragma unroll
-        for (int s = 0; s < 4; s++) { ref[s] = (p[s] && ma[s] == 0x12345u && mb[s] == 0x54321u) ? 0 : -1; if (candOnly) keyOut[s] = key[s]; }
+        for (int s = 0; s < 4; s++) ref[s] = (p[s] && ma[s] == 0x12345u && mb[s] == 0x54321u) ? 0 : -1;
         return;
     }
     if (P.ldsBits) {                                              // four presence bits, read together
         uint32_t w[4];
 #pragma unroll
-        for (int s = 0; s < 4; s++) w[s] = s_filt[(ma[s] >> (32 - P.ldsBits)) >> 5];
+        for (int s = 0; s < 4; s++) w[s] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_filt) + filt_byte(ma[s], P.ldsBits));
 #pragma unroll
-        for (int s = 0; s < 4; s++) p[s] = p[s] & (bool)((w[s] >> ((ma[s] >> (32 - P.ldsBits)) & 31)) & 1u);
+        for (int s = 0; s < 4; s++) p[s] = p[s] & (bool)((w[s] >> (ma[s] & 31u)) & 1u);
     }
     if (P.dbg == 1) {                                             // experiment: filter but no gathers
 #pragma unroll
-        for (int s = 0; s < 4; s++) { ref[s] = (p[s] && ma[s] == 0x12345u) ? 0 : -1; if (candOnly) keyOut[s] = key[s]; }
+        for (int s = 0; s < 4; s++) ref[s] = (p[s] && ma[s] == 0x12345u) ? 0 : -1;
         return;
     }
 #pragma unroll
     for (int s = 0; s < 4; s++) t[s] = p[s] ? P.tags[bucket_of(mb[s], P.bucketBits)] : 0ULL;  // four gathers in flight
     if (P.dbg == 6) {                                             // experiment: gathers issued, matches ignored
 #pragma unroll
-        for (int s = 0; s < 4; s++) { ref[s] = (t[s] == 0x123456789ULL) ? 0 : -1; if (candOnly) keyOut[s] = key[s]; }
+        for (int s = 0; s < 4; s++) ref[s] = (t[s] == 0x123456789ULL) ? 0 : -1;
         return;
     }
 #pragma unroll
     for (int s = 0; s < 4; s++) {
-        // rare: a fingerprint matched, or the home bucket is full -> check the key / walk the bucket chain
+        // rare: a fingerprint matched, or the home bucket overflowed -> check the key / walk the bucket chain
         const uint64_t cand = zero16((t[s] & TAG_FPS) ^ ((uint64_t)tag_of(ma[s]) * 0x0001000100010001ULL));
         ref[s] = -1;
-        if (candOnly) {
-            if (p[s] && cand != 0ULL) ref[s] = (int)(4u * bucket_of(mb[s], P.bucketBits)) + ((__ffsll((unsigned long long)cand) - 1) >> 4);
-            else if (p[s] && (t[s] & TAG_CONT)) {                   // home bucket overflowed, no match there: walk the chain now
-                const int id = table_find_t(P, key[s], ma[s], mb[s], t[s]);
-                ref[s] = id > 0 ? -3 - id : -1;                        // <= -4: a verified id, nothing left to check
+        if (p[s] && (cand != 0ULL || (t[s] & TAG_CONT))) ref[s] = table_find_t(P, key[s], ma[s], mb[s], t[s]);
+    }
+}
+
+// Candidate form of lookup4 for the first-hit-only scans: keys of matching fingerprints are NOT fetched.  ref = slot
+// (4*bucket+way) of the first fingerprint match, -3-id for a hit already verified (home bucket overflowed and no match
+// there: the chain is walked at once), -1 if certainly absent; keyOut = the lanes' keys.  There is no `ok` input:
+// every lane is looked up (the bucket index is always in range) and the caller masks the ballots instead, which keeps
+// per-lane predicates out of the straight-line code.  kmLo/kmHi = the length bit, held in VGPRs so that
+// (max & middleMask) | lengthBit is one v_and_or_b32 per half (a VOP3 takes a single SGPR operand).
+template <bool GENERAL>
+__device__ __forceinline__ void lookup4_cand(const KParams& P, const uint32_t* s_filt, const uint64_t* kmer, const uint64_t* rk,
+                                             const uint32_t kmLo, const uint32_t kmHi, int* ref, uint64_t* keyOut) {
+    uint32_t ma[4], mb[4], pv[4]; uint64_t t[4];
+    const uint32_t mmLo = (uint32_t)P.middleMask, mmHi = (uint32_t)(P.middleMask >> 32);
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const uint64_t mx = (!GENERAL || P.rcomp) ? (kmer[s] > rk[s] ? kmer[s] : rk[s]) : kmer[s];
+        const uint32_t klo = ((uint32_t)mx & mmLo) | kmLo, khi = ((uint32_t)(mx >> 32) & mmHi) | kmHi;
+        keyOut[s] = ((uint64_t)khi << 32) | klo;
+        ma[s] = klo * HA0 + khi * HA1;
+        mb[s] = klo * HB0 + khi * HB1;
+        pv[s] = 1u;
+    }
+    if (P.dbg == 2) {                                             // experiment: keys and hashes only
+#pragma unroll
+        for (int s = 0; s < 4; s++) ref[s] = (ma[s] == 0x12345u && mb[s] == 0x54321u) ? 0 : -1;
+        return;
+    }
+    if (P.ldsBits) {                                              // four presence bits, read together
+        uint32_t w[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) w[s] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_filt) + filt_byte(ma[s], P.ldsBits));
+#pragma unroll
+        for (int s = 0; s < 4; s++) pv[s] = (w[s] >> (ma[s] & 31u)) & 1u;
+    }
+    if (P.dbg == 1) {                                             // experiment: filter but no gathers
+#pragma unroll
+        for (int s = 0; s < 4; s++) ref[s] = (pv[s] && ma[s] == 0x12345u) ? 0 : -1;
+        return;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; s++) t[s] = pv[s] ? P.tags[bucket_of(mb[s], P.bucketBits)] : 0ULL;   // four gathers in flight
+    if (P.dbg == 6) {                                             // experiment: gathers issued, matches ignored
+#pragma unroll
+        for (int s = 0; s < 4; s++) ref[s] = (t[s] == 0x123456789ULL) ? 0 : -1;
+        return;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const uint32_t fp = tag_of(ma[s]), tlo = (uint32_t)t[s], thi = (uint32_t)(t[s] >> 32);
+        // four 16-bit compares (v_cmp_eq_u32_sdwa).  Lane 3 of an overflowed bucket carries the flag in its top bit
+        // and never compares equal: such buckets take the chain walk below, which masks the flag.
+        const bool m = ((tlo & 0xFFFFu) == fp) | ((tlo >> 16) == fp) | ((thi & 0xFFFFu) == fp) | ((thi >> 16) == fp);
+        const bool cont = (int32_t)thi < 0;
+        ref[s] = -1;
+        if (pv[s] && (m || cont)) {                               // rare
+            const uint64_t cand = zero16((t[s] & TAG_FPS) ^ ((uint64_t)fp * 0x0001000100010001ULL));
+            if (!cont) ref[s] = (int)(4u * bucket_of(mb[s], P.bucketBits)) + ((__ffsll((unsigned long long)cand) - 1) >> 4);
+            else {
+                const int id = table_find_t(P, keyOut[s], ma[s], mb[s], t[s]);
+                ref[s] = id > 0 ? -3 - id : -1;                    // <= -4: a verified id, nothing left to check
             }
-            keyOut[s] = key[s];
-        } else if (p[s] && (cand != 0ULL || (t[s] & TAG_CONT))) ref[s] = table_find_t(P, key[s], ma[s], mb[s], t[s]);
+        }
     }
 }
 
@@ -589,22 +632,30 @@ __device__ __forceinline__ void main_scan_pair_cand(const KParams& P, const Plan
     int ibA = WA.first, ibB = WB.first;
     bool onA = WA.on, onB = WB.on;
     A.candSlot = -1; B.candSlot = -1;
+    uint32_t kmLo = (uint32_t)P.kmask, kmHi = (uint32_t)(P.kmask >> 32);
+    asm volatile("" : "+v"(kmLo), "+v"(kmHi));                  // see lookup4_cand
+    // Lanes past a read's end look up whatever lies behind it in the planes.  When every window of the read is plain
+    // nothing masks them: positions grow with the lane, so a first candidate at a position >= stop means the read has
+    // none.  Reads with cut or reset windows (restrictRight, an undefined base) mask their ballots with `ok` instead.
+    const bool plainA = WA.full && !(FORBIDN && WA.hasN), plainB = WB.full && !(FORBIDN && WB.hasN);
     while (onA || onB) {
         uint64_t kmer[4], rk[4], key[4]; bool ok[4]; int ref[4];
         windows2<FORBIDN, GENERAL>(P, Q, WA, ibA + 2 * lane, onA, kmer, rk, ok);
         windows2<FORBIDN, GENERAL>(P, Q, WB, ibB + 2 * lane, onB, kmer + 2, rk + 2, ok + 2);
-        lookup4<GENERAL>(P, Q.filt, kmer, rk, ok, ref, true, key);
+        lookup4_cand<GENERAL>(P, Q.filt, kmer, rk, kmLo, kmHi, ref, key);
 #pragma unroll
         for (int r = 0; r < 2; r++) {
             ReadScan& R = r ? B : A;
             bool& on = r ? onB : onA;
             int& ib = r ? ibB : ibA;
             if (!on) continue;
-            const uint64_t me = __ballot(ref[2 * r] != -1), mo = __ballot(ref[2 * r + 1] != -1);
-            if (me | mo) {                                        // first candidate in position order: lane l, parity h
-                const int le = me ? __ffsll((unsigned long long)me) - 1 : 64, lo = mo ? __ffsll((unsigned long long)mo) - 1 : 64;
-                const int h = (2 * lo + 1 < 2 * le) ? 1 : 0;
-                const int l = h ? lo : le;
+            uint64_t me = __ballot(ref[2 * r] != -1), mo = __ballot(ref[2 * r + 1] != -1);
+            if (!(r ? plainB : plainA)) { me &= __ballot(ok[2 * r]); mo &= __ballot(ok[2 * r + 1]); }
+            const int stopR = r ? WB.stop : WA.stop;
+            const int le = me ? __ffsll((unsigned long long)me) - 1 : 64, lo = mo ? __ffsll((unsigned long long)mo) - 1 : 64;
+            const int h = (2 * lo + 1 < 2 * le) ? 1 : 0;
+            const int l = h ? lo : le;
+            if ((me | mo) && ib + 2 * l + h < stopR) {            // first candidate in position order: lane l, parity h
                 const int rs = h ? ref[2 * r + 1] : ref[2 * r];
                 const uint64_t ks = h ? key[2 * r + 1] : key[2 * r];
                 R.candSlot = __builtin_amdgcn_readlane(rs, l);
@@ -614,7 +665,7 @@ __device__ __forceinline__ void main_scan_pair_cand(const KParams& P, const Plan
                 on = false;
             } else {
                 ib += 128;
-                on = ib < (r ? WB.stop : WA.stop);
+                on = ib < stopR;
             }
         }
     }
@@ -1412,7 +1463,7 @@ extern "C" int bbduk_finalize_table(bbduk_handle* h) {
             bool done = false;
             for (int w = 0; w < 4 && !done; w++) {
                 const uint64_t tw = (tg[b] >> (16 * w)) & 0x7FFFULL;
-                if (tw == 0) { tg[b] |= tag << (16 * w); kvh[4ULL * b + w] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)h->hvals[i], 0u); distinct++; done = true; }
+                if (key_at(4ULL * b + w) == EMPTY_KEY) { tg[b] |= tag << (16 * w); kvh[4ULL * b + w] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)h->hvals[i], 0u); distinct++; done = true; }
                 else if (tw == tag && key_at(4ULL * b + w) == key) done = true;
             }
             if (done) break;
@@ -1439,8 +1490,8 @@ extern "C" int bbduk_finalize_table(bbduk_handle* h) {
             std::vector<uint32_t> f1((size_t)1 << (lb - 5), 0u);
             for (uint64_t s = 0; s < 4 * nb; s++) {
                 if (key_at(s) == EMPTY_KEY) continue;
-                const uint32_t h1 = mix_a(key_at(s)) >> (32 - lb);
-                f1[h1 >> 5] |= 1u << (h1 & 31);
+                const uint32_t ma = mix_a(key_at(s));
+                f1[filt_byte(ma, lb) >> 2] |= 1u << (ma & 31u);
             }
             HIP_TRY(h, hipMalloc(&h->d_ldsImage, f1.size() * 4));
             HIP_TRY(h, hipMemcpy(h->d_ldsImage, f1.data(), f1.size() * 4, hipMemcpyHostToDevice));
