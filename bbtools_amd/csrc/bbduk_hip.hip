@@ -83,8 +83,17 @@ __device__ __forceinline__ uint64_t dev_rcomp(uint64_t kmer, int len) {
 #define HA1 0x85EBCA6Bu
 #define HB0 0xC2B2AE35u
 #define HB1 0x27D4EB2Fu
-__host__ __device__ __forceinline__ uint32_t mix_a(uint64_t key) { return (uint32_t)key * HA0 + (uint32_t)(key >> 32) * HA1; }
-__host__ __device__ __forceinline__ uint32_t mix_b(uint64_t key) { return (uint32_t)key * HB0 + (uint32_t)(key >> 32) * HB1; }
+// Both are taken of a key's VALUE, i.e. the key without its length bit (the scans have the value first and would pay
+// two more instructions per position to hash the finished key); strip_len recovers the value from a stored key.
+__host__ __device__ __forceinline__ uint32_t mix_a(uint64_t value) { return (uint32_t)value * HA0 + (uint32_t)(value >> 32) * HA1; }
+__host__ __device__ __forceinline__ uint32_t mix_b(uint64_t value) { return (uint32_t)value * HB0 + (uint32_t)(value >> 32) * HB1; }
+__host__ __device__ __forceinline__ uint64_t strip_len(uint64_t key) {      // key = value | 1<<2*len, value < 1<<2*len
+#if defined(__HIP_DEVICE_COMPILE__)
+    return key ? key ^ (1ULL << (63 - __clzll((long long)key))) : 0ULL;
+#else
+    return key ? key ^ (1ULL << (63 - __builtin_clzll(key))) : 0ULL;
+#endif
+}
 __host__ __device__ __forceinline__ uint32_t bucket_of(uint32_t mb, int bucketBits) { return mb >> (32 - bucketBits); }
 // 15-bit fingerprint (0 is a legal value: a free way's lane also reads 0, so a query whose fingerprint is 0 sees
 // free ways as candidates and the key check rejects them).  Bit 63 of a bucket's tag word is its continuation flag:
@@ -124,26 +133,30 @@ __device__ __forceinline__ int table_find_t(const KParams& P, uint64_t key, uint
 __device__ __forceinline__ int table_find_m(const KParams& P, uint64_t key, uint32_t ma, uint32_t mb) {
     return table_find_t(P, key, ma, mb, P.tags[bucket_of(mb, P.bucketBits)]);
 }
-__device__ __forceinline__ int table_get(const KParams& P, uint64_t key) { return table_find_m(P, key, mix_a(key), mix_b(key)); }
+__device__ __forceinline__ int table_get(const KParams& P, uint64_t key) { const uint64_t v = strip_len(key); return table_find_m(P, key, mix_a(v), mix_b(v)); }
 // A lookup result ("ref") is -1 = absent or the id (>0) itself.
 __device__ __forceinline__ int ref_to_id(const KParams& P, int ref) { return ref; }
 
 // key -> ref through the cascade: LDS presence bit -> bucket fingerprints -> key.  `ok` = lane has a real query.
-__device__ __forceinline__ int probe_ref(const KParams& P, const uint32_t* s_filt, uint64_t key, bool ok) {
-    const uint32_t ma = mix_a(key);
+__device__ __forceinline__ int probe_ref(const KParams& P, const uint32_t* s_filt, uint64_t value, uint64_t lengthMask, bool ok) {
+    const uint32_t ma = mix_a(value);
     bool p = ok;
     if (P.ldsBits) p = p & (bool)filt_test(s_filt, ma, P.ldsBits);
     int ref = -1;
-    if (p) ref = table_find_m(P, key, ma, mix_b(key));
+    if (p) ref = table_find_m(P, value | lengthMask, ma, mix_b(value));
     return ref;
 }
 
 // getValueInner (bbduk/BBDukIndexMod.java:492-520): canonicalise, mask middle, add length bit
 template <bool GENERAL>
-__device__ __forceinline__ uint64_t make_key(const KParams& P, uint64_t kmer, uint64_t rkmer, uint64_t lengthMask) {
+__device__ __forceinline__ uint64_t make_value(const KParams& P, uint64_t kmer, uint64_t rkmer) {
     // values < 2^62: unsigned max == Java's signed Tools.max
     const uint64_t mx = (!GENERAL || P.rcomp) ? (kmer > rkmer ? kmer : rkmer) : kmer;
-    return (mx & P.middleMask) | lengthMask;
+    return mx & P.middleMask;
+}
+template <bool GENERAL>
+__device__ __forceinline__ uint64_t make_key(const KParams& P, uint64_t kmer, uint64_t rkmer, uint64_t lengthMask) {
+    return make_value<GENERAL>(P, kmer, rkmer) | lengthMask;
 }
 
 // getValue (bbduk/BBDukIndexMod.java:462-481): query-side Hamming expansion, same (j,i) order, first id>=1 wins
@@ -175,7 +188,7 @@ __device__ __forceinline__ int lookup(const KParams& P, const uint32_t* s_filt, 
             return id > 0 ? id : -1;
         }
     }
-    return probe_ref(P, s_filt, make_key<GENERAL>(P, kmer, rkmer, lengthMask), ok);
+    return probe_ref(P, s_filt, make_value<GENERAL>(P, kmer, rkmer), lengthMask, ok);
 }
 
 // symbols [idx, idx+32) of a little-endian 2-bit stream, as a 64-bit value (caller masks)
@@ -446,9 +459,10 @@ __device__ __forceinline__ void lookup4(const KParams& P, const uint32_t* s_filt
     uint64_t key[4], t[4]; uint32_t ma[4], mb[4]; bool p[4];
 #pragma unroll
     for (int s = 0; s < 4; s++) {
-        key[s] = make_key<GENERAL>(P, kmer[s], rk[s], P.kmask);
-        ma[s] = mix_a(key[s]);
-        mb[s] = mix_b(key[s]);
+        const uint64_t value = make_value<GENERAL>(P, kmer[s], rk[s]);
+        key[s] = value | P.kmask;
+        ma[s] = mix_a(value);
+        mb[s] = mix_b(value);
         p[s] = ok[s];
     }
     if (P.dbg == 2) {                                             // experiment: keys and hashes only
@@ -488,17 +502,17 @@ __device__ __forceinline__ void lookup4(const KParams& P, const uint32_t* s_filt
 // (4*bucket+way) of the first fingerprint match, -3-id for a hit already verified (home bucket overflowed and no match
 // there: the chain is walked at once), -1 if certainly absent; keyOut = the lanes' keys.  There is no `ok` input:
 // every lane is looked up (the bucket index is always in range) and the caller masks the ballots instead, which keeps
-// per-lane predicates out of the straight-line code.  kmLo/kmHi = the length bit, held in VGPRs so that
-// (max & middleMask) | lengthBit is one v_and_or_b32 per half (a VOP3 takes a single SGPR operand).
-template <bool GENERAL>
+// per-lane predicates out of the straight-line code.  keyOut = the lanes' key VALUES (no length bit).  NOMM: the
+// middle mask is known to be off.
+template <bool GENERAL, bool NOMM>
 __device__ __forceinline__ void lookup4_cand(const KParams& P, const uint32_t* s_filt, const uint64_t* kmer, const uint64_t* rk,
-                                             const uint32_t kmLo, const uint32_t kmHi, int* ref, uint64_t* keyOut) {
+                                             int* ref, uint64_t* keyOut) {
     uint32_t ma[4], mb[4], pv[4]; uint64_t t[4];
     const uint32_t mmLo = (uint32_t)P.middleMask, mmHi = (uint32_t)(P.middleMask >> 32);
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         const uint64_t mx = (!GENERAL || P.rcomp) ? (kmer[s] > rk[s] ? kmer[s] : rk[s]) : kmer[s];
-        const uint32_t klo = ((uint32_t)mx & mmLo) | kmLo, khi = ((uint32_t)(mx >> 32) & mmHi) | kmHi;
+        const uint32_t klo = NOMM ? (uint32_t)mx : ((uint32_t)mx & mmLo), khi = NOMM ? (uint32_t)(mx >> 32) : ((uint32_t)(mx >> 32) & mmHi);
         keyOut[s] = ((uint64_t)khi << 32) | klo;
         ma[s] = klo * HA0 + khi * HA1;
         mb[s] = klo * HB0 + khi * HB1;
@@ -540,7 +554,7 @@ __device__ __forceinline__ void lookup4_cand(const KParams& P, const uint32_t* s
             const uint64_t cand = zero16((t[s] & TAG_FPS) ^ ((uint64_t)fp * 0x0001000100010001ULL));
             if (!cont) ref[s] = (int)(4u * bucket_of(mb[s], P.bucketBits)) + ((__ffsll((unsigned long long)cand) - 1) >> 4);
             else {
-                const int id = table_find_t(P, keyOut[s], ma[s], mb[s], t[s]);
+                const int id = table_find_t(P, keyOut[s] | P.kmask, ma[s], mb[s], t[s]);
                 ref[s] = id > 0 ? -3 - id : -1;                    // <= -4: a verified id, nothing left to check
             }
         }
@@ -624,7 +638,7 @@ __device__ __forceinline__ void main_scan_pair(const KParams& P, const Planes& Q
 // Candidate form of the pair scan (ktrim=r, kfilter with maxbadkmers=0: only the first hit of a read matters): stop
 // at the first fingerprint match of each read WITHOUT fetching its key; the caller verifies the candidates of a whole
 // sub-tile in one overlapped batch (one lane per read) and falls back to main_scan_pair for the rare impostor.
-template <bool FORBIDN, bool GENERAL>
+template <bool FORBIDN, bool GENERAL, bool NOMM>
 __device__ __forceinline__ void main_scan_pair_cand(const KParams& P, const Planes& Q, ReadScan& A, ReadScan& B, const int lane) {
     ReadWin WA, WB;
     win_init<FORBIDN, GENERAL>(P, Q, A, WA, lane);
@@ -632,8 +646,6 @@ __device__ __forceinline__ void main_scan_pair_cand(const KParams& P, const Plan
     int ibA = WA.first, ibB = WB.first;
     bool onA = WA.on, onB = WB.on;
     A.candSlot = -1; B.candSlot = -1;
-    uint32_t kmLo = (uint32_t)P.kmask, kmHi = (uint32_t)(P.kmask >> 32);
-    asm volatile("" : "+v"(kmLo), "+v"(kmHi));                  // see lookup4_cand
     // Lanes past a read's end look up whatever lies behind it in the planes.  When every window of the read is plain
     // nothing masks them: positions grow with the lane, so a first candidate at a position >= stop means the read has
     // none.  Reads with cut or reset windows (restrictRight, an undefined base) mask their ballots with `ok` instead.
@@ -642,7 +654,7 @@ __device__ __forceinline__ void main_scan_pair_cand(const KParams& P, const Plan
         uint64_t kmer[4], rk[4], key[4]; bool ok[4]; int ref[4];
         windows2<FORBIDN, GENERAL>(P, Q, WA, ibA + 2 * lane, onA, kmer, rk, ok);
         windows2<FORBIDN, GENERAL>(P, Q, WB, ibB + 2 * lane, onB, kmer + 2, rk + 2, ok + 2);
-        lookup4_cand<GENERAL>(P, Q.filt, kmer, rk, kmLo, kmHi, ref, key);
+        lookup4_cand<GENERAL, NOMM>(P, Q.filt, kmer, rk, ref, key);
 #pragma unroll
         for (int r = 0; r < 2; r++) {
             ReadScan& R = r ? B : A;
@@ -1086,7 +1098,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                 A.found = 0; A.iFirst = BIGLOC; A.iLast = -1; A.ref = -1; A.shortFl = -1; A.shortLl = -1;
                 Bz.found = 0; Bz.iFirst = BIGLOC; Bz.iLast = -1; Bz.ref = -1; Bz.shortFl = -1; Bz.shortLl = -1;
                 if (candMode) {
-                    if (P.dbg != 3) main_scan_pair_cand<FORBIDN, GENERAL>(P, Q, A, Bz, lane); else { A.candSlot = -1; Bz.candSlot = -1; }
+                    if (P.dbg != 3) main_scan_pair_cand<FORBIDN, GENERAL, SHORT && !GENERAL>(P, Q, A, Bz, lane); else { A.candSlot = -1; Bz.candSlot = -1; }
                     if (A.candSlot != -1) {
                         vCSlot = (lane == ra) ? A.candSlot : vCSlot; vFirst = (lane == ra) ? A.iFirst : vFirst;
                         vCKeyLo = (lane == ra) ? A.candKeyLo : vCKeyLo; vCKeyHi = (lane == ra) ? A.candKeyHi : vCKeyHi;
@@ -1119,7 +1131,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                 }
                 if (inSub && vCSlot >= 0) {
                     const uint4 kv = P.bkv[vCSlot];
-                    if (kv.x == vCKeyLo && kv.y == vCKeyHi) {
+                    if (kv.x == (vCKeyLo | (uint32_t)P.kmask) && kv.y == (vCKeyHi | (uint32_t)(P.kmask >> 32))) {
                         vRef = (int)kv.z; vFound = (MODE == BBDUK_MODE_KFILTER) ? P.maxBadKmers + 1 : 1;
                         if (MODE == BBDUK_MODE_KFILTER) vFirst = 0;    // marks the early exit
                     } else fb = true;
@@ -1299,7 +1311,10 @@ static KernelPair pick_kernel_mode(bool general, bool useShort, bool forbidN) {
     return forbidN ? kpair<MODE, false, true, false>() : kpair<MODE, false, false, false>();
 }
 static KernelPair pick_kernel(const KParams& K) {
-    const bool general = K.qhdist > 0 || K.qhdist2 > 0 || K.restrictLeft > 0 || K.restrictRight > 0 || K.skipR1 || K.skipR2 || !K.rcomp;
+    // the specialised SHORT kernels assume what BBDukParser guarantees (mink turns maskMiddle off, :295-301);
+    // a caller that hands over both takes the general kernel
+    const bool general = K.qhdist > 0 || K.qhdist2 > 0 || K.restrictLeft > 0 || K.restrictRight > 0 || K.skipR1 || K.skipR2 || !K.rcomp ||
+                         (K.useShort && K.middleMask != ~0ULL);
     if (K.mode == BBDUK_MODE_KFILTER) return pick_kernel_mode<BBDUK_MODE_KFILTER>(general, false, K.forbidNs != 0);
     if (K.mode == BBDUK_MODE_KTRIM_L) return pick_kernel_mode<BBDUK_MODE_KTRIM_L>(general, K.useShort != 0, K.forbidNs != 0);
     return pick_kernel_mode<BBDUK_MODE_KTRIM_R>(general, K.useShort != 0, K.forbidNs != 0);
@@ -1457,8 +1472,8 @@ extern "C" int bbduk_finalize_table(bbduk_handle* h) {
     int64_t distinct = 0;
     for (size_t i = 0; i < n; i++) {                              // first writer wins (HashArray.setIfNotPresent)
         const uint64_t key = (uint64_t)h->hkeys[i];
-        const uint64_t tag = tag_of(mix_a(key));
-        uint32_t b = bucket_of(mix_b(key), bbits);
+        const uint64_t tag = tag_of(mix_a(strip_len(key)));
+        uint32_t b = bucket_of(mix_b(strip_len(key)), bbits);
         for (;;) {
             bool done = false;
             for (int w = 0; w < 4 && !done; w++) {
@@ -1490,7 +1505,7 @@ extern "C" int bbduk_finalize_table(bbduk_handle* h) {
             std::vector<uint32_t> f1((size_t)1 << (lb - 5), 0u);
             for (uint64_t s = 0; s < 4 * nb; s++) {
                 if (key_at(s) == EMPTY_KEY) continue;
-                const uint32_t ma = mix_a(key_at(s));
+                const uint32_t ma = mix_a(strip_len(key_at(s)));
                 f1[filt_byte(ma, lb) >> 2] |= 1u << (ma & 31u);
             }
             HIP_TRY(h, hipMalloc(&h->d_ldsImage, f1.size() * 4));
