@@ -28,12 +28,22 @@ def stale() -> bool:
     return any(os.path.getmtime(d) > t for d in _DEPS)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not stale():
-        return _SO
+def _compile(out: str, extra=(), verbose: bool = False) -> str:
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-value", "-Wno-unused-result", *_SRC, "-o", _SO]
+           "-Wno-unused-value", "-Wno-unused-result", *extra, *_SRC, "-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return _SO
+    return out
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not stale():
+        return _SO
+    return _compile(_SO, verbose=verbose)
+
+
+def build_timing_variant(verbose: bool = False) -> str:
+    """Experiment build with the BBDUK_DBG stage-deletion switches compiled in (profiles/ab.sh loads it through
+    BBDUK_LIB_PATH); never the product library."""
+    return _compile(os.path.join(_HERE, "ab_tsw.so"), ["-DBBDUK_TIMING_SWITCHES"], verbose)

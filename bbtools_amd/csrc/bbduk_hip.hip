@@ -40,6 +40,14 @@ static_assert(sizeof(bbduk_synth_params) == 80, "bbduk_synth_params layout is pa
 #define MAX_LDS_BITS    20                     // 128 KiB presence filter per workgroup
 #define BIGLOC          999999999
 
+// Deletion experiments (profiles/ab.sh): a build with -DBBDUK_TIMING_SWITCHES honours BBDUK_DBG=<n> and skips one
+// stage of the scan (results become wrong).  Production builds compile the switches out.
+#ifdef BBDUK_TIMING_SWITCHES
+#define TSW(P, n) ((P).dbg == (n))
+#else
+#define TSW(P, n) false
+#endif
+
 struct KParams {
     int32_t mode, k, mink, rcomp, forbidNs, minlen, minlen2, qhdist, qhdist2, maxBadKmers, minReadLength;
     float   minLenFraction;
@@ -59,7 +67,7 @@ struct KParams {
     // presence filter in front of the map: one bit per hash slot, copied into LDS by every workgroup
     const uint32_t* ldsImage;   // HBM copy of the LDS bitmap (2^ldsBits bits); 0 bits = absent
     int32_t  ldsBits;
-    int32_t  dbg;               // BBDUK_DBG: timing experiments only (results become wrong); 0 in production
+    int32_t  dbg;               // BBDUK_DBG: timing experiments only (results become wrong); needs -DBBDUK_TIMING_SWITCHES
     int32_t  prof;              // BBDUK_PROF=1: per-phase s_memtime sums into counters[] tail (timing experiments only)
     unsigned long long* profOut;
 };
@@ -397,8 +405,14 @@ __device__ __forceinline__ void windows2(const KParams& P, const Planes& Q, cons
     if (W.full) {
         const uint64_t wf = extract2raw(Q.fwd, Q.T - 1 - W.base0 - (i + 1));   // base i+1 in bits 0-1, base i-k+1 on top
         const uint64_t wc = extract2raw(Q.cmp, W.base0 - k + 1 + i);           // base i-k+1 in bits 0-1, base i+1 on top
-        kmer[1] = wf & P.mask; kmer[0] = (wf >> 2) & P.mask;
-        rk[0] = wc & P.mask;   rk[1] = (wc >> 2) & P.mask;
+        if constexpr (!GENERAL) {                                // specialised kernels run with k >= 16: the mask's low word is all ones
+            const uint64_t mh = P.mask | 0xFFFFFFFFULL;
+            kmer[1] = wf & mh; kmer[0] = (wf >> 2) & mh;
+            rk[0] = wc & mh;   rk[1] = (wc >> 2) & mh;
+        } else {
+            kmer[1] = wf & P.mask; kmer[0] = (wf >> 2) & P.mask;
+            rk[0] = wc & P.mask;   rk[1] = (wc >> 2) & P.mask;
+        }
         ok[0] = on & (i < W.stop);
         ok[1] = on & (i + 1 < W.stop);
         if (FORBIDN && W.hasN) {                                 // the read holds an undefined base somewhere: patch the few windows that see it
@@ -465,7 +479,7 @@ __device__ __forceinline__ void lookup4(const KParams& P, const uint32_t* s_filt
         mb[s] = mix_b(value);
         p[s] = ok[s];
     }
-    if (P.dbg == 2) {                                             // experiment: keys and hashes only
+    if (TSW(P, 2)) {                                             // experiment: keys and hashes only
 #pragma unroll
         for (int s = 0; s < 4; s++) ref[s] = (p[s] && ma[s] == 0x12345u && mb[s] == 0x54321u) ? 0 : -1;
         return;
@@ -477,14 +491,14 @@ __device__ __forceinline__ void lookup4(const KParams& P, const uint32_t* s_filt
 #pragma unroll
         for (int s = 0; s < 4; s++) p[s] = p[s] & (bool)((w[s] >> (ma[s] & 31u)) & 1u);
     }
-    if (P.dbg == 1) {                                             // experiment: filter but no gathers
+    if (TSW(P, 1)) {                                             // experiment: filter but no gathers
 #pragma unroll
         for (int s = 0; s < 4; s++) ref[s] = (p[s] && ma[s] == 0x12345u) ? 0 : -1;
         return;
     }
 #pragma unroll
     for (int s = 0; s < 4; s++) t[s] = p[s] ? P.tags[bucket_of(mb[s], P.bucketBits)] : 0ULL;  // four gathers in flight
-    if (P.dbg == 6) {                                             // experiment: gathers issued, matches ignored
+    if (TSW(P, 6)) {                                             // experiment: gathers issued, matches ignored
 #pragma unroll
         for (int s = 0; s < 4; s++) ref[s] = (t[s] == 0x123456789ULL) ? 0 : -1;
         return;
@@ -498,63 +512,83 @@ __device__ __forceinline__ void lookup4(const KParams& P, const uint32_t* s_filt
     }
 }
 
-// Candidate form of lookup4 for the first-hit-only scans: keys of matching fingerprints are NOT fetched.  ref = slot
-// (4*bucket+way) of the first fingerprint match, -3-id for a hit already verified (home bucket overflowed and no match
-// there: the chain is walked at once), -1 if certainly absent; keyOut = the lanes' keys.  There is no `ok` input:
-// every lane is looked up (the bucket index is always in range) and the caller masks the ballots instead, which keeps
-// per-lane predicates out of the straight-line code.  keyOut = the lanes' key VALUES (no length bit).  NOMM: the
-// middle mask is known to be off.
-template <bool GENERAL, bool NOMM>
-__device__ __forceinline__ void lookup4_cand(const KParams& P, const uint32_t* s_filt, const uint64_t* kmer, const uint64_t* rk,
-                                             int* ref, uint64_t* keyOut) {
-    uint32_t ma[4], mb[4], pv[4]; uint64_t t[4];
+// Candidate form of lookup4 for the first-hit-only scans, in two parts.  cand_probe4 is the straight-line part every
+// slot runs: key value, both mixes, LDS presence bit, fingerprint gather, four 16-bit compares; it returns the union
+// of the four ballots "this lane needs a closer look" (a fingerprint matched or the home bucket overflowed).  Keys of
+// matching fingerprints are NOT fetched.  There is no `ok` input: every lane is looked up (the bucket index is always
+// in range) and the caller rejects tail lanes by position, which keeps per-lane predicates out of the hot code.
+// cand_resolve4 runs only when that union is non-zero: ref = slot (4*bucket+way) of the first fingerprint match,
+// -3-id for a hit already verified (overflowed home bucket without a match: the chain is walked at once), -1 if
+// certainly absent.  C.key = the lanes' key VALUES (no length bit).  NOMM: the middle mask is known to be off.
+struct Cand4 { uint64_t key[4], t[4]; uint32_t ma[4], mb[4], pv[4]; };
+
+// FILT0: the filter starts at LDS address 0 (wave kernel), so a word's LDS address is its byte offset
+typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+__device__ __forceinline__ uint32_t lds_word_at(uint32_t byteAddr) { return *reinterpret_cast<lds_cu32*>(byteAddr); }
+template <bool GENERAL, bool NOMM, bool FILT0>
+__device__ __forceinline__ uint64_t cand_probe4(const KParams& P, const uint32_t* s_filt, const uint64_t* kmer, const uint64_t* rk, Cand4& C) {
     const uint32_t mmLo = (uint32_t)P.middleMask, mmHi = (uint32_t)(P.middleMask >> 32);
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         const uint64_t mx = (!GENERAL || P.rcomp) ? (kmer[s] > rk[s] ? kmer[s] : rk[s]) : kmer[s];
         const uint32_t klo = NOMM ? (uint32_t)mx : ((uint32_t)mx & mmLo), khi = NOMM ? (uint32_t)(mx >> 32) : ((uint32_t)(mx >> 32) & mmHi);
-        keyOut[s] = ((uint64_t)khi << 32) | klo;
-        ma[s] = klo * HA0 + khi * HA1;
-        mb[s] = klo * HB0 + khi * HB1;
-        pv[s] = 1u;
+        C.key[s] = ((uint64_t)khi << 32) | klo;
+        C.ma[s] = klo * HA0 + khi * HA1;
+        C.mb[s] = klo * HB0 + khi * HB1;
+        C.pv[s] = 1u;
     }
-    if (P.dbg == 2) {                                             // experiment: keys and hashes only
+    if (TSW(P, 2)) {                                              // experiment: keys and hashes only
+        uint64_t a = 0;
 #pragma unroll
-        for (int s = 0; s < 4; s++) ref[s] = (ma[s] == 0x12345u && mb[s] == 0x54321u) ? 0 : -1;
-        return;
+        for (int s = 0; s < 4; s++) { C.pv[s] = 0; C.t[s] = 0; a |= __ballot(C.ma[s] == 0x12345u && C.mb[s] == 0x54321u); }
+        return a;
     }
     if (P.ldsBits) {                                              // four presence bits, read together
         uint32_t w[4];
 #pragma unroll
-        for (int s = 0; s < 4; s++) w[s] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_filt) + filt_byte(ma[s], P.ldsBits));
+        for (int s = 0; s < 4; s++) w[s] = FILT0 ? lds_word_at(filt_byte(C.ma[s], P.ldsBits))
+                                                 : *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_filt) + filt_byte(C.ma[s], P.ldsBits));
 #pragma unroll
-        for (int s = 0; s < 4; s++) pv[s] = (w[s] >> (ma[s] & 31u)) & 1u;
+        for (int s = 0; s < 4; s++) C.pv[s] = __builtin_amdgcn_ubfe(w[s], C.ma[s], 1u);   // the offset operand uses ma[4:0] only
     }
-    if (P.dbg == 1) {                                             // experiment: filter but no gathers
+    if (TSW(P, 1)) {                                              // experiment: filter but no gathers
+        uint64_t a = 0;
 #pragma unroll
-        for (int s = 0; s < 4; s++) ref[s] = (pv[s] && ma[s] == 0x12345u) ? 0 : -1;
-        return;
+        for (int s = 0; s < 4; s++) { a |= __ballot(C.pv[s] && C.ma[s] == 0x12345u); C.pv[s] = 0; C.t[s] = 0; }
+        return a;
     }
 #pragma unroll
-    for (int s = 0; s < 4; s++) t[s] = pv[s] ? P.tags[bucket_of(mb[s], P.bucketBits)] : 0ULL;   // four gathers in flight
-    if (P.dbg == 6) {                                             // experiment: gathers issued, matches ignored
+    for (int s = 0; s < 4; s++) C.t[s] = C.pv[s] ? P.tags[bucket_of(C.mb[s], P.bucketBits)] : 0ULL;   // four gathers in flight
+    if (TSW(P, 6)) {                                              // experiment: gathers issued, matches ignored
+        uint64_t a = 0;
 #pragma unroll
-        for (int s = 0; s < 4; s++) ref[s] = (t[s] == 0x123456789ULL) ? 0 : -1;
-        return;
+        for (int s = 0; s < 4; s++) { a |= __ballot(C.t[s] == 0x123456789ULL); C.pv[s] = 0; }
+        return a;
     }
+    uint64_t any = 0;
 #pragma unroll
     for (int s = 0; s < 4; s++) {
-        const uint32_t fp = tag_of(ma[s]), tlo = (uint32_t)t[s], thi = (uint32_t)(t[s] >> 32);
-        // four 16-bit compares (v_cmp_eq_u32_sdwa).  Lane 3 of an overflowed bucket carries the flag in its top bit
-        // and never compares equal: such buckets take the chain walk below, which masks the flag.
-        const bool m = ((tlo & 0xFFFFu) == fp) | ((tlo >> 16) == fp) | ((thi & 0xFFFFu) == fp) | ((thi >> 16) == fp);
-        const bool cont = (int32_t)thi < 0;
+        const uint32_t fp = tag_of(C.ma[s]), tlo = (uint32_t)C.t[s], thi = (uint32_t)(C.t[s] >> 32);
+        // four 16-bit compares (v_cmp_eq_u32_sdwa) and the overflow flag, combined as wave masks on the scalar unit.
+        // Lane 3 of an overflowed bucket carries the flag in its top bit and never compares equal: such buckets take
+        // the chain walk, which masks the flag.
+        const uint64_t b = __ballot((tlo & 0xFFFFu) == fp) | __ballot((tlo >> 16) == fp) | __ballot((thi & 0xFFFFu) == fp) |
+                           __ballot((thi >> 16) == fp) | __ballot((int32_t)thi < 0);
+        any |= b & __ballot(C.pv[s] != 0u);
+    }
+    return any;
+}
+
+__device__ __forceinline__ void cand_resolve4(const KParams& P, const Cand4& C, int* ref) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
         ref[s] = -1;
-        if (pv[s] && (m || cont)) {                               // rare
-            const uint64_t cand = zero16((t[s] & TAG_FPS) ^ ((uint64_t)fp * 0x0001000100010001ULL));
-            if (!cont) ref[s] = (int)(4u * bucket_of(mb[s], P.bucketBits)) + ((__ffsll((unsigned long long)cand) - 1) >> 4);
+        const uint32_t fp = tag_of(C.ma[s]);
+        const uint64_t cand = zero16((C.t[s] & TAG_FPS) ^ ((uint64_t)fp * 0x0001000100010001ULL));
+        if (C.pv[s] && (cand != 0ULL || (C.t[s] & TAG_CONT))) {
+            if (!(C.t[s] & TAG_CONT)) ref[s] = (int)(4u * bucket_of(C.mb[s], P.bucketBits)) + ((__ffsll((unsigned long long)cand) - 1) >> 4);
             else {
-                const int id = table_find_t(P, keyOut[s] | P.kmask, ma[s], mb[s], t[s]);
+                const int id = table_find_t(P, C.key[s] | P.kmask, C.ma[s], C.mb[s], C.t[s]);
                 ref[s] = id > 0 ? -3 - id : -1;                    // <= -4: a verified id, nothing left to check
             }
         }
@@ -651,10 +685,16 @@ __device__ __forceinline__ void main_scan_pair_cand(const KParams& P, const Plan
     // none.  Reads with cut or reset windows (restrictRight, an undefined base) mask their ballots with `ok` instead.
     const bool plainA = WA.full && !(FORBIDN && WA.hasN), plainB = WB.full && !(FORBIDN && WB.hasN);
     while (onA || onB) {
-        uint64_t kmer[4], rk[4], key[4]; bool ok[4]; int ref[4];
+        uint64_t kmer[4], rk[4]; bool ok[4]; int ref[4]; Cand4 C;
         windows2<FORBIDN, GENERAL>(P, Q, WA, ibA + 2 * lane, onA, kmer, rk, ok);
         windows2<FORBIDN, GENERAL>(P, Q, WB, ibB + 2 * lane, onB, kmer + 2, rk + 2, ok + 2);
-        lookup4_cand<GENERAL, NOMM>(P, Q.filt, kmer, rk, ref, key);
+        if (cand_probe4<GENERAL, NOMM, true>(P, Q.filt, kmer, rk, C) == 0ULL) {   // the common block: nothing to look at
+            if (onA) { ibA += 128; onA = ibA < WA.stop; }
+            if (onB) { ibB += 128; onB = ibB < WB.stop; }
+            continue;
+        }
+        cand_resolve4(P, C, ref);
+        const uint64_t* key = C.key;
 #pragma unroll
         for (int r = 0; r < 2; r++) {
             ReadScan& R = r ? B : A;
@@ -962,6 +1002,8 @@ void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
 #define WCAP_BASES   2560                          // per-wave plane capacity in bases
 #define WCAP_CHUNKS  (WCAP_BASES / 16)
 #define WPLANE_WORDS (PLANE_PAD + WCAP_CHUNKS + PLANE_PAD)
+#define WNM_WORDS    (WCAP_CHUNKS / 2 + 4)
+#define WAVE_LDS_BYTES ((2 * NWAVES * WPLANE_WORDS + NWAVES * WNM_WORDS) * 4 + 6 * 8 + NWAVES * MT_READS * 4)   // behind the filter
 #define WUNIT_MAX    (WCAP_BASES - 48)             // longest unit (pair) the wave kernel accepts
 
 // sum of v over the lanes of a wave, returned wave-uniform
@@ -977,12 +1019,15 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                        const int64_t n, const int64_t totalBases, const int paired,
                        int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
                        int64_t* __restrict__ counters, const int* __restrict__ slowFlag) {
-    __shared__ uint32_t s_wf[NWAVES][WPLANE_WORDS];
-    __shared__ uint32_t s_wc[NWAVES][WPLANE_WORDS];
-    __shared__ uint32_t s_wn[NWAVES][WCAP_CHUNKS / 2 + 4];
-    __shared__ unsigned long long s_acc[6];                       // rkt, basesKTrimmed, readsOutm, basesOutm, readsIn, basesIn
-    __shared__ int s_sel[NWAVES][MT_READS];                       // short-scan: compacted list of participating reads
-    extern __shared__ uint32_t s_filt[];
+    // One dynamic LDS block, the presence filter FIRST: its words are then addressed by the hash bits alone (LDS
+    // address 0 + offset), which saves an add per lookup.  Behind it: per-wave planes, counters, short-scan lists.
+    extern __shared__ uint32_t s_dyn[];
+    uint32_t* const s_filt = s_dyn;
+    uint32_t* const s_wfAll = s_dyn + (P.ldsBits ? (1 << (P.ldsBits - 5)) : 0);
+    uint32_t* const s_wcAll = s_wfAll + NWAVES * WPLANE_WORDS;
+    uint32_t* const s_wnAll = s_wcAll + NWAVES * WPLANE_WORDS;
+    unsigned long long* const s_acc = reinterpret_cast<unsigned long long*>(s_wnAll + NWAVES * WNM_WORDS);   // rkt, basesKTrimmed, readsOutm, basesOutm, readsIn, basesIn
+    int* const s_selAll = reinterpret_cast<int*>(s_acc + 6);      // short-scan: compacted list of participating reads
 
     const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     if (tid < 6) s_acc[tid] = 0;
@@ -999,7 +1044,9 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
     const int rpp = max(1, 64 / lens);
     const int sslot = lane / lens, st = lane - sslot * lens;
 
-    uint32_t* const wf = s_wf[wave]; uint32_t* const wc = s_wc[wave]; uint32_t* const wn = s_wn[wave];
+    uint32_t* const wf = s_wfAll + wave * WPLANE_WORDS; uint32_t* const wc = s_wcAll + wave * WPLANE_WORDS;
+    uint32_t* const wn = s_wnAll + wave * WNM_WORDS;
+    int* const sel = s_selAll + wave * MT_READS;
     // scaffold-counter cache: lane w (< SCAF_LANES) owns one (id, reads, bases) entry in registers; a hit is one ballot
     // plus a predicated add, a miss evicts round-robin with two atomics.  The adapter library has ~6 frequent ids:
     // with the 4-entry scalar cache 4-15 % of the hit reads still caused evictions onto a dozen hot addresses.
@@ -1054,7 +1101,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
             const int lead = (int)(B0 - A0);                        // bases in front of read s inside the first chunk
             const int nchunks = (lead + (rel_e - rel_s) + 15) >> 4;
             // ---- stage this wave's reads: 16 bases per lane-iteration -> the wave's private bit-planes
-            for (int c = lane; c < nchunks && P.dbg != 5; c += 64) {
+            for (int c = lane; c < nchunks && !TSW(P, 5); c += 64) {
                 uint32_t r, comp, valid;
                 encode_chunk(bases, A0 + 16LL * c, totalBases, r, comp, valid);
                 wf[PLANE_PAD + nchunks - 1 - c] = r;
@@ -1098,7 +1145,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                 A.found = 0; A.iFirst = BIGLOC; A.iLast = -1; A.ref = -1; A.shortFl = -1; A.shortLl = -1;
                 Bz.found = 0; Bz.iFirst = BIGLOC; Bz.iLast = -1; Bz.ref = -1; Bz.shortFl = -1; Bz.shortLl = -1;
                 if (candMode) {
-                    if (P.dbg != 3) main_scan_pair_cand<FORBIDN, GENERAL, SHORT && !GENERAL>(P, Q, A, Bz, lane); else { A.candSlot = -1; Bz.candSlot = -1; }
+                    if (!TSW(P, 3)) main_scan_pair_cand<FORBIDN, GENERAL, SHORT && !GENERAL>(P, Q, A, Bz, lane); else { A.candSlot = -1; Bz.candSlot = -1; }
                     if (A.candSlot != -1) {
                         vCSlot = (lane == ra) ? A.candSlot : vCSlot; vFirst = (lane == ra) ? A.iFirst : vFirst;
                         vCKeyLo = (lane == ra) ? A.candKeyLo : vCKeyLo; vCKeyHi = (lane == ra) ? A.candKeyHi : vCKeyHi;
@@ -1159,12 +1206,12 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
             // ---- short k-mers (:2034-2103) for the reads of [s,e) whose main scan found nothing, several reads per
             // pass: worker lane w looks up length mink+st of the read in slot sslot (lens lengths per read).
             if constexpr (MODE != BBDUK_MODE_KFILTER && SHORT) {
-                if (P.useShort && P.dbg != 4) {
+                if (P.useShort && !TSW(P, 4)) {
                     const bool need = mine && vScan && vFound == 0 && lane >= s && lane < e;
                     uint64_t needM = __ballot(need);
                     if (needM) {
                         const int rank = __popcll(needM & ((1ULL << lane) - 1ULL));
-                        if (need) s_sel[wave][rank] = lane;            // compact list of the reads that take part
+                        if (need) sel[rank] = lane;            // compact list of the reads that take part
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1173,7 +1220,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                         for (int pb = 0; pb < nneed; pb += rpp) {
                             const int q = pb + sslot;
                             const bool have = sslot < rpp && q < nneed;
-                            const int j = have ? s_sel[wave][q] : 0;   // the read this worker lane serves
+                            const int j = have ? sel[q] : 0;   // the read this worker lane serves
                             const int jb = __shfl(vBase0, j), jstart = __shfl(vStart, j), jstop = __shfl(vStop, j);
                             const int Ls = P.mink + st;
                             uint64_t kmer = 0, rk = 0; bool act; int Lc;
@@ -1199,7 +1246,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                                 const int slot = l0 / lens;
                                 const uint64_t seg = (hm >> (slot * lens)) & ((1ULL << lens) - 1ULL);
                                 const int fl = __ffsll((unsigned long long)seg) - 1, ll = 63 - __clzll((long long)seg);
-                                const int jr = s_sel[wave][pb + slot];
+                                const int jr = sel[pb + slot];
                                 const int r1 = __builtin_amdgcn_readlane(sref, slot * lens + fl);   // first hit in scan order = shortest
                                 const int jru = __builtin_amdgcn_readfirstlane(jr);
                                 if (lane == jru) { vRef = r1; vFound = __popcll(seg); vSFl = fl; vSLl = ll; }
@@ -1214,7 +1261,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
             s = e;
         }
 
-        if (P.dbg == 7) continue;                                 // experiment: no decide stage, no outputs
+        if (TSW(P, 7)) continue;                                 // experiment: no decide stage, no outputs
         // ---- finish, data-parallel: lane j turns read j's scan facts into outputs, pair logic via the neighbour lane
         int a, newLen, ref; bool hit;
         finish_read<MODE>(P, vL, vStart, vStop, vFound, vFirst, vLast, vSFl, vSLl, vRef, a, newLen, ref, hit);
@@ -1311,10 +1358,10 @@ static KernelPair pick_kernel_mode(bool general, bool useShort, bool forbidN) {
     return forbidN ? kpair<MODE, false, true, false>() : kpair<MODE, false, false, false>();
 }
 static KernelPair pick_kernel(const KParams& K) {
-    // the specialised SHORT kernels assume what BBDukParser guarantees (mink turns maskMiddle off, :295-301);
-    // a caller that hands over both takes the general kernel
+    // the specialised kernels assume k >= 16 (BBDuk's usual 23-31) and what BBDukParser guarantees (mink turns
+    // maskMiddle off, :295-301); anything else takes the general kernel
     const bool general = K.qhdist > 0 || K.qhdist2 > 0 || K.restrictLeft > 0 || K.restrictRight > 0 || K.skipR1 || K.skipR2 || !K.rcomp ||
-                         (K.useShort && K.middleMask != ~0ULL);
+                         (K.useShort && K.middleMask != ~0ULL) || K.k < 16;
     if (K.mode == BBDUK_MODE_KFILTER) return pick_kernel_mode<BBDUK_MODE_KFILTER>(general, false, K.forbidNs != 0);
     if (K.mode == BBDUK_MODE_KTRIM_L) return pick_kernel_mode<BBDUK_MODE_KTRIM_L>(general, K.useShort != 0, K.forbidNs != 0);
     return pick_kernel_mode<BBDUK_MODE_KTRIM_R>(general, K.useShort != 0, K.forbidNs != 0);
@@ -1559,9 +1606,10 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     if (((uintptr_t)d_bases & 15) != 0) return fail(h, BBDUK_ERR_ARG, "d_bases must be 16-byte aligned");
     const KParams K = make_kparams(h);
     const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
-    const size_t dynLds = h->ldsBits ? ((size_t)1 << (h->ldsBits - 3)) : 0;
+    const size_t dynLds = h->ldsBits ? ((size_t)1 << (h->ldsBits - 3)) : 0;    // tile kernel: the filter only
+    const size_t waveLds = dynLds + WAVE_LDS_BYTES;                             // wave kernel: filter + its per-wave state
     const KernelPair kp = pick_kernel(K);
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)waveLds));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.tile), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
     // pre-pass: if some pair is longer than a wave's planes the tile kernel takes the whole batch, else the wave kernel
     HIP_TRY(h, hipMemsetAsync(h->d_slowFlag, 0, sizeof(int), st));
@@ -1577,13 +1625,13 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     const int tgrid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU * perCU);
     if (getenv("BBDUK_VERBOSE")) {
         int occ = -1;
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kp.wave), BLOCK_THREADS, dynLds);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kp.wave), BLOCK_THREADS, waveLds);
         fprintf(stderr, "[bbduk] wave grid=%d tile grid=%d block=%d dynLds=%zu occupancyAPI=%d numCU=%d\n", wgrid, tgrid, BLOCK_THREADS, dynLds, occ, h->numCU);
     }
     const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
     if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
     HIP_TRY(h, hipEventRecord(h->ev0[evi], st));
-    kp.wave<<<dim3(wgrid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, h->d_slowFlag);
+    kp.wave<<<dim3(wgrid), dim3(BLOCK_THREADS), waveLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, h->d_slowFlag);
     HIP_TRY(h, hipEventRecord(h->ev1[evi], st));
     h->evCount++;
     kp.tile<<<dim3(tgrid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, h->d_slowFlag);
