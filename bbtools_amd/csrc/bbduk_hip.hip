@@ -220,23 +220,19 @@ __device__ __forceinline__ uint32_t extract1(const uint32_t* plane, int idx, int
 // 4 ASCII bases -> 4x2-bit forward codes (base 0 in bits 0-1), 4x2-bit complement codes, 4 valid bits.
 // AminoAcid.baseToNumber0 / baseToComplementNumber0 / baseToNumber>=0 (dna/AminoAcid.java:1284-1311):
 // A/a C/c G/g T/t U/u are defined, every other byte is undefined and encodes as 0 in both tables.
-__device__ __forceinline__ void encode4(uint32_t w, uint32_t& code8, uint32_t& comp8, uint32_t& valid4) {
+// The results stay one byte per base here (x, c: 2-bit codes; y: 0x01 per defined base); encode_chunk packs four of
+// them at a time.  Validity: the 2-bit code picks the lower-case letter it stands for out of "acgt" (v_perm_b32) and
+// the byte must equal it -- or be 'u'.
+__device__ __forceinline__ void encode4(uint32_t w, uint32_t& x, uint32_t& c, uint32_t& y) {
     const uint32_t lower = w | 0x20202020u;
-    auto eqb = [](uint32_t v, uint32_t pat) {     // 0x80 in every byte of v equal to the pattern byte (exact, no carries)
-        const uint32_t t = v ^ pat;
-        return ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t) & 0x80808080u;
-    };
-    const uint32_t v = eqb(lower, 0x61616161u) | eqb(lower, 0x63636363u) | eqb(lower, 0x67676767u) |
-                       eqb(lower, 0x74747474u) | eqb(lower, 0x75757575u);
-    const uint32_t y = v >> 7;                    // 0x01 per valid byte
-    const uint32_t vm = y * 3u;                   // 0x03 per valid byte
-    uint32_t x = (w >> 1) & 0x03030303u;          // A:0 C:1 G:3 T/U:2
-    x = (x ^ ((x >> 1) & 0x01010101u)) & vm;      // A:0 C:1 G:2 T/U:3, undefined:0
-    const uint32_t c = (~x) & vm;                 // 3-x, undefined:0
-    auto pack = [](uint32_t z) { uint32_t t = (z | (z >> 6)) & 0x000F000Fu; return (t | (t >> 12)) & 0xFFu; };
-    code8 = pack(x);
-    comp8 = pack(c);
-    valid4 = (y | (y >> 7) | (y >> 14) | (y >> 21)) & 0xFu;
+    const uint32_t raw = (w >> 1) & 0x03030303u;                  // A:0 C:1 G:3 T/U:2
+    const uint32_t expect = __builtin_amdgcn_perm(0u, 0x67746361u, raw);   // byte = "actg"[raw]
+    auto zb = [](uint32_t t) { return ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t) & 0x80808080u; };   // 0x80 per zero byte (exact)
+    const uint32_t v = zb(lower ^ expect) | zb(lower ^ 0x75757575u);
+    y = v >> 7;                                                   // 0x01 per defined base
+    const uint32_t vm = y * 3u;                                   // 0x03 per defined base
+    x = (raw ^ ((raw >> 1) & 0x01010101u)) & vm;                  // A:0 C:1 G:2 T/U:3, undefined:0
+    c = (~x) & vm;                                                // 3-x, undefined:0
 }
 
 // 16 consecutive bases starting at byte a -> 32-bit reversed forward codes, 32-bit complement codes, 16 valid bits
@@ -259,13 +255,23 @@ __device__ __forceinline__ void encode_chunk(const uint8_t* __restrict__ bases, 
             w[q] = x;
         }
     }
-    uint32_t code = 0; comp = 0; valid = 0;
+    // Packing: a multiply moves the four 2-bit fields of a word (bits 8j) next to each other into the top byte
+    // (field j lands at 24+2j; all partial products fall on distinct bits, so nothing carries), and byte permutes
+    // collect the four top bytes.  The 1-bit validity fields pack the same way with a 7-bit stride.
+    uint32_t px[4], pc[4], py[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        uint32_t c8, m8, v4;
-        encode4(w[q], c8, m8, v4);
-        code |= c8 << (8 * q); comp |= m8 << (8 * q); valid |= v4 << (4 * q);
+        uint32_t x, c, y;
+        encode4(w[q], x, c, y);
+        px[q] = x * 0x01041040u; pc[q] = c * 0x01041040u; py[q] = y * 0x01020408u;
     }
+    auto top4 = [](const uint32_t* p) {                           // byte q of the result = top byte of p[q]
+        const uint32_t lo = __builtin_amdgcn_perm(p[1], p[0], 0x0c0c0703u), hi = __builtin_amdgcn_perm(p[3], p[2], 0x07030c0cu);
+        return lo | hi;
+    };
+    const uint32_t code = top4(px);
+    comp = top4(pc);
+    valid = ((py[0] >> 24) & 0xFu) | ((py[1] >> 20) & 0xF0u) | ((py[2] >> 16) & 0xF00u) | ((py[3] >> 12) & 0xF000u);
     uint32_t r = __brev(code);                                    // reverse the order of the 16 symbols
     fwdRev = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
 }
