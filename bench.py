@@ -127,8 +127,19 @@ def main():
     }
     algo_bytes = ALGO_BYTES_PER_READ * n
     ach = algo_bytes / (kern_ms * 1e-3) / 1e9
+    # HBM-side traffic per launch: PMC counters cannot be read from inside this process, so the figure is the one
+    # measured by profiles/run_profile.sh (separate rocprofv3 --pmc passes over this same command) and committed in
+    # profiles/pmc_traffic.json; it is reported only for the workload size it was measured on, else null.
+    traffic, traffic_src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            pt = json.load(fh)
+        if int(pt["reads_per_launch"]) == n:
+            traffic, traffic_src = int(pt["traffic_bytes"]), pt["source"]
+    except Exception:
+        pass
     out["roofline"] = {"bound": "hbm", "kernel": "bbduk_wave_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                       "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                       "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                        "kernel_ms": round(kern_ms, 3), "launch_ms": round(launch_ms, 3), "algorithmic_bytes_per_launch": algo_bytes}
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

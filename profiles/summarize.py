@@ -34,7 +34,14 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcc"):
             continue
         for c, vals in cs.items():
             print("  %-50s %-24s n=%d mean=%.6g" % (k[:50], c, len(vals), sum(vals) / len(vals)))
+import json
+print("== bench line of each profiled run (value, kernel_ms from the library's HIP events)")
 for f in sorted(glob.glob(os.path.join(out, "*_bench.json"))):
     txt = open(f).read().strip().splitlines()
     if txt:
-        print("== %s\n  %s" % (os.path.basename(f), txt[-1][:1500]))
+        try:
+            d = json.loads(txt[-1])
+            print("  %-22s value=%s %s ms_per_step=%s kernel_ms=%s reads=%s" % (os.path.basename(f), d["value"], d["unit"], d["ms_per_step"],
+                  d["roofline"]["kernel_ms"], d["config"].get("reads_per_gpu")))
+        except Exception:
+            print("  %-22s %s" % (os.path.basename(f), txt[-1][:300]))
