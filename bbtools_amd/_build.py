@@ -8,6 +8,8 @@ _SRC = [os.path.join(_HERE, "csrc", "bbduk_hip.hip"), os.path.join(_HERE, "csrc"
 _DEPS = _SRC + [os.path.join(_HERE, "csrc", "synth.h"),
                 os.path.join(_HERE, "..", "include", "bbduk_gpu.h"), os.path.join(_HERE, "..", "include", "bbduk_host.h")]
 _SO = os.path.join(_HERE, "libbbduk_hip.so")
+_CLI_SRC = os.path.join(_HERE, "csrc", "bbduk_cli.cpp")
+_CLI = os.path.join(_HERE, "bbduk_cli")
 
 
 def lib_path() -> str:
@@ -38,9 +40,27 @@ def _compile(out: str, extra=(), verbose: bool = False) -> str:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not stale():
-        return _SO
-    return _compile(_SO, verbose=verbose)
+    if force or stale():
+        _compile(_SO, verbose=verbose)
+    build_cli(force=force, verbose=verbose)
+    return _SO
+
+
+def cli_path() -> str:
+    return _CLI
+
+
+def build_cli(force: bool = False, verbose: bool = False) -> str:
+    """The non-JVM caller: plain C++ above the two C ABIs, linked against the library beside it."""
+    if not force and os.path.exists(_CLI) and os.path.getmtime(_CLI) > max(os.path.getmtime(_CLI_SRC), os.path.getmtime(_SO)):
+        return _CLI
+    rocm_lib = os.path.join(os.path.dirname(os.path.dirname(_hipcc())), "lib")
+    cmd = ["g++", "-O2", "-std=c++17", _CLI_SRC, "-o", _CLI, "-L" + _HERE, "-lbbduk_hip",
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + rocm_lib, "-Wl,-rpath," + rocm_lib]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return _CLI
 
 
 def build_timing_variant(verbose: bool = False) -> str:

@@ -1,0 +1,168 @@
+// bbduk_cli -- the non-JVM caller of SURVEY §8(b): plays the part of BBDukProcessorS.processList around the batch
+// operators of include/bbduk_gpu.h.  It owns nothing of the algorithm: flags go to bbduk_host_parse, the k-mer map
+// comes from bbduk_host_build_index, every per-read decision comes back from bbduk_ktrim_batch / bbduk_kfilter_batch.
+// What it does itself is what the Java caller keeps doing: read FASTQ, group mates, apply
+// TrimRead.trimByAmount to bases+qualities with the returned amounts, route removed pairs, print the counters.
+//
+//   bbduk_cli in=r1.fq [in2=r2.fq | int=t] [out=clean.fq] [outm=removed.fq] [tsv=per_read.tsv] [resources=DIR]
+//             [batch=N] [device=D] <BBDuk flags: ktrim= k= mink= hdist= ref= literal= ...>
+//
+// tsv columns: name, length, result (ktrim: bases removed | kfilter: k-mer hits counted), scaffold id or -1,
+// length after trimming, flags (1 = read discarded, 2 = pair removed).  Exit status 0 = OK, 1 = error (message on
+// stderr) -- like the reference, which sets errorState and exits non-zero (bbduk/BBDukS.java:199-202).
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/bbduk_gpu.h"
+#include "../../include/bbduk_host.h"
+
+namespace {
+
+struct Reader {                      // FASTQ, plain or .gz (through `gzip -dc`, as ByteFile does for .gz)
+    FILE* f = nullptr; bool piped = false; char* line = nullptr; size_t cap = 0;
+    bool open(const std::string& path) {
+        if (path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0) {
+            const std::string cmd = "gzip -dc '" + path + "'";
+            f = popen(cmd.c_str(), "r"); piped = true;
+        } else f = fopen(path.c_str(), "r");
+        return f != nullptr;
+    }
+    bool getline_(std::string& out) {
+        const ssize_t n = getline(&line, &cap, f);
+        if (n < 0) return false;
+        size_t m = (size_t)n;
+        while (m > 0 && (line[m - 1] == '\n' || line[m - 1] == '\r')) m--;
+        out.assign(line, m);
+        return true;
+    }
+    // one record; returns 0 = ok, 1 = clean EOF, -1 = malformed
+    int next(std::string& name, std::string& bases, std::string& quals) {
+        std::string plus;
+        if (!getline_(name)) return 1;
+        if (name.empty() || name[0] != '@') return -1;
+        if (!getline_(bases) || !getline_(plus) || !getline_(quals)) return -1;
+        if (plus.empty() || plus[0] != '+' || quals.size() != bases.size()) return -1;
+        name.erase(0, 1);
+        return 0;
+    }
+    void close() { if (f) { if (piped) pclose(f); else fclose(f); f = nullptr; } free(line); line = nullptr; }
+};
+
+struct Rec { std::string name, bases, quals; };
+
+int fail(const char* what, const char* detail) { fprintf(stderr, "bbduk_cli: %s%s%s\n", what, detail ? ": " : "", detail ? detail : ""); return 1; }
+
+bool parse_bool(const std::string& v) { return v.empty() || v == "t" || v == "true" || v == "1" || v == "T"; }
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    std::string in1, in2, out, outm, tsv, resources = "data", flags;
+    bool interleaved = false; long batch = 1000000; int device = 0;
+    for (int i = 1; i < argc; i++) {
+        const std::string tok = argv[i];
+        const size_t eq = tok.find('=');
+        const std::string a = tok.substr(0, eq), b = eq == std::string::npos ? "" : tok.substr(eq + 1);
+        if (a == "in" || a == "in1") in1 = b;
+        else if (a == "in2") in2 = b;
+        else if (a == "int" || a == "interleaved") interleaved = parse_bool(b);
+        else if (a == "out" || a == "out1" || a == "outu") out = b;
+        else if (a == "outm" || a == "outmatch") outm = b;
+        else if (a == "tsv") tsv = b;
+        else if (a == "resources") resources = b;
+        else if (a == "batch") batch = atol(b.c_str());
+        else if (a == "device") device = atoi(b.c_str());
+        else { flags += tok; flags += ' '; }
+    }
+    if (in1.empty()) {
+        fprintf(stderr, "usage: bbduk_cli in=r1.fq [in2=r2.fq|int=t] [out=clean.fq] [outm=removed.fq] [tsv=reads.tsv] "
+                        "[resources=DIR] [batch=N] [device=D] <BBDuk flags>\n");
+        return 1;
+    }
+    if (batch < 2) batch = 2;
+    const bool paired = interleaved || !in2.empty();
+
+    char err[512] = {0};
+    bbduk_host* host = nullptr;
+    if (bbduk_host_parse(flags.c_str(), &host, err, sizeof err) != BBDUK_OK) return fail("bad arguments", err);
+    if (bbduk_host_load_refs(host, resources.c_str()) < 0) return fail("cannot load ref=", resources.c_str());
+    const int64_t stored = bbduk_host_build_index(host);
+    if (stored < 0) return fail("index build failed", nullptr);
+    bbduk_params P;
+    if (bbduk_host_params(host, device, &P) != BBDUK_OK) return fail("unsupported parameter combination", nullptr);
+    bbduk_handle* dev = nullptr;
+    if (bbduk_create(&P, &dev) != BBDUK_OK) return fail("bbduk_create", dev ? bbduk_last_error(dev) : "no usable device (there is no CPU fallback)");
+    if (bbduk_host_upload_index(host, dev) != BBDUK_OK) return fail("table upload", bbduk_last_error(dev));
+    fprintf(stderr, "Added %lld kmers; %d scaffolds.\n", (long long)stored, bbduk_host_num_scaffolds(host) - 1);
+
+    Reader r1, r2;
+    if (!r1.open(in1)) return fail("cannot open", in1.c_str());
+    if (!in2.empty() && !r2.open(in2)) return fail("cannot open", in2.c_str());
+    FILE* fout = out.empty() ? nullptr : fopen(out.c_str(), "w");
+    FILE* foutm = outm.empty() ? nullptr : fopen(outm.c_str(), "w");
+    FILE* ftsv = tsv.empty() ? nullptr : fopen(tsv.c_str(), "w");
+    if ((!out.empty() && !fout) || (!outm.empty() && !foutm) || (!tsv.empty() && !ftsv)) return fail("cannot open an output file", nullptr);
+
+    const bool ktrim = P.mode != BBDUK_MODE_KFILTER;
+    std::vector<Rec> recs; std::vector<uint8_t> bases; std::vector<int64_t> offsets;
+    std::vector<int32_t> res, ids; std::vector<uint8_t> fl;
+    bool eof = false; long long nread = 0;
+    while (!eof) {
+        recs.clear(); bases.clear(); offsets.assign(1, 0);
+        while ((long)recs.size() + (paired ? 2 : 1) <= batch) {      // mates stay adjacent: reads 2i, 2i+1
+            Rec a, b;
+            int rc = r1.next(a.name, a.bases, a.quals);
+            if (rc == 1) { eof = true; break; }
+            if (rc < 0) return fail("malformed FASTQ record in", in1.c_str());
+            if (paired) {
+                rc = in2.empty() ? r1.next(b.name, b.bases, b.quals) : r2.next(b.name, b.bases, b.quals);
+                if (rc != 0) return fail("unpaired or malformed mate for read", a.name.c_str());
+            }
+            recs.push_back(std::move(a));
+            if (paired) recs.push_back(std::move(b));
+        }
+        if (recs.empty()) break;
+        for (const Rec& r : recs) { bases.insert(bases.end(), r.bases.begin(), r.bases.end()); offsets.push_back((int64_t)bases.size()); }
+        const int64_t n = (int64_t)recs.size();
+        res.resize(n); ids.resize(n); fl.resize(n);
+        if (bases.empty()) bases.push_back(0);                       // an all-empty batch still needs a valid pointer
+        const int rc = ktrim ? bbduk_ktrim_batch(dev, bases.data(), offsets.data(), n, paired, res.data(), ids.data(), fl.data())
+                             : bbduk_kfilter_batch(dev, bases.data(), offsets.data(), n, paired, res.data(), ids.data(), fl.data());
+        if (rc != BBDUK_OK) return fail("batch operator", bbduk_last_error(dev));
+        for (int64_t i = 0; i < n; i++) {
+            Rec& r = recs[i];
+            const int L = (int)r.bases.size();
+            int left = 0, right = 0;                                 // TrimRead.trimByAmount(r, left, right, 1) with the returned amount
+            if (P.mode == BBDUK_MODE_KTRIM_R) right = res[i]; else if (P.mode == BBDUK_MODE_KTRIM_L) left = res[i];
+            const int newLen = L - left - right;
+            if (ftsv) fprintf(ftsv, "%s\t%d\t%d\t%d\t%d\t%d\n", r.name.c_str(), L, res[i], ids[i], newLen, (int)fl[i]);
+            FILE* dst = (fl[i] & BBDUK_FLAG_REMOVED) ? foutm : fout;
+            if (dst) {
+                fprintf(dst, "@%s\n", r.name.c_str());
+                fwrite(r.bases.data() + left, 1, (size_t)newLen, dst); fputs("\n+\n", dst);
+                fwrite(r.quals.data() + left, 1, (size_t)newLen, dst); fputc('\n', dst);
+            }
+        }
+        nread += n;
+    }
+    r1.close(); r2.close();
+    if (fout) fclose(fout);
+    if (foutm) fclose(foutm);
+    if (ftsv) fclose(ftsv);
+
+    std::vector<int64_t> c((size_t)bbduk_counters_len(dev));
+    bbduk_get_counters(dev, c.data(), (int32_t)c.size());
+    // the lines BBDukS prints at the end of a run (bbduk/BBDukS.java:350-420), same wording for the shared counters
+    fprintf(stderr, "Input:                  \t%lld reads \t\t%lld bases.\n", (long long)c[BBDUK_READS_IN], (long long)c[BBDUK_BASES_IN]);
+    if (ktrim) fprintf(stderr, "KTrimmed:               \t%lld reads \t%lld bases\n", (long long)c[BBDUK_READS_KTRIMMED], (long long)c[BBDUK_BASES_KTRIMMED]);
+    else fprintf(stderr, "Contaminants:           \t%lld reads \t%lld bases\n", (long long)c[BBDUK_READS_KFILTERED], (long long)c[BBDUK_BASES_KFILTERED]);
+    fprintf(stderr, "Total Removed:          \t%lld reads \t%lld bases\n", (long long)(c[BBDUK_READS_IN] - c[BBDUK_READS_OUTU]),
+            (long long)(c[BBDUK_BASES_IN] - c[BBDUK_BASES_OUTU]));
+    fprintf(stderr, "Result:                 \t%lld reads \t%lld bases\n", (long long)c[BBDUK_READS_OUTU], (long long)c[BBDUK_BASES_OUTU]);
+    if (c[BBDUK_CTR_STATUS]) return fail("device reported an error status", nullptr);
+    bbduk_destroy(dev); bbduk_host_destroy(host);
+    return 0;
+}

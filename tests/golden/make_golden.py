@@ -80,6 +80,41 @@ def main():
              dict(k=23, mink=11, ktrimLeft=True), ADAPTERS,
              [ad[-30:] + g[:60], ad[-12:] + g[:60], g, ad, g[:40] + ad[:30] + g[40:70]], False)
 
+    cli_fixtures(phix)
+
+
+def write_fastq(path, names, reads):
+    with open(path, "w") as f:
+        for i, (nm, r) in enumerate(zip(names, reads)):
+            q = "".join(chr(33 + (7 * i + 3 * j) % 41) for j in range(len(r)))
+            f.write("@%s\n%s\n+\n%s\n" % (nm, r, q))
+
+
+def cli_fixtures(phix):
+    """FASTQ inputs + the per-read TSV bbduk_cli has to print for them (the non-JVM caller is pinned by
+    fixture FASTQs and the spec's per-read results).  Read names follow the AddAdapters truth convention."""
+    here = os.path.dirname(__file__)
+
+    def tsv(path, names, reads, out, ktrim):
+        with open(path, "w") as f:
+            for nm, r, t in zip(names, reads, out):
+                f.write("%s\t%d\t%d\t%d\t%d\t%d\n" % (nm, len(r), t[0], t[1], len(r) - (t[0] if ktrim else 0), t[2]))
+
+    # paired, two files, ktrim=r (configs[1] flags)
+    reads = synth_reads(12, 100, ins_min=30, ins_max=260, sub_rate=0.01, n_rate=0.002)
+    names = ["%d_%d_%d /%d" % (i // 2, len(reads[i - i % 2]), len(reads[i - i % 2 + 1]), i % 2 + 1) for i in range(len(reads))]
+    write_fastq(os.path.join(here, "cli_c2_r1.fq"), names[0::2], reads[0::2])
+    write_fastq(os.path.join(here, "cli_c2_r2.fq"), names[1::2], reads[1::2])
+    s = Spec(Args(k=23, mink=11, hdist=1, ktrimRight=True)); s.load_fasta(ADAPTERS)
+    tsv(os.path.join(here, "cli_c2.tsv"), names, reads, s.process_batch([r.encode() for r in reads], True), True)
+    # interleaved, kfilter against phiX (configs[2] flags)
+    reads = synth_reads(13, 100, contam=phix, contam_frac=0.3, sub_rate=0.01, n_rate=0.002)
+    names = ["%d_%d_%d /%d" % (i // 2, len(reads[i - i % 2]), len(reads[i - i % 2 + 1]), i % 2 + 1) for i in range(len(reads))]
+    write_fastq(os.path.join(here, "cli_c3_interleaved.fq"), names, reads)
+    s = Spec(Args(k=31, hdist=1)); s.load_fasta(PHIX)
+    tsv(os.path.join(here, "cli_c3.tsv"), names, reads, s.process_batch([r.encode() for r in reads], True), False)
+    print("cli fixtures written")
+
 
 if __name__ == "__main__":
     main()

@@ -1,0 +1,63 @@
+"""bbduk_cli: the non-JVM caller of SURVEY 8(b), pinned by fixture FASTQs and the spec's per-read TSV
+(tests/golden/cli_*.{fq,tsv}, written by tests/golden/make_golden.py from oracle/spec.py)."""
+import os
+import subprocess
+
+import pytest
+
+from bbtools_amd import _build
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def run_cli(args, cwd=ROOT):
+    return subprocess.run([_build.cli_path()] + args, cwd=cwd, capture_output=True, text=True, timeout=600)
+
+
+def test_cli_is_built_and_prints_usage():
+    _build.build_cli()
+    r = run_cli([])
+    assert r.returncode == 1 and "usage: bbduk_cli" in r.stderr
+
+
+def test_cli_rejects_unknown_flag_like_the_reference_parser():
+    r = run_cli(["in=" + os.path.join(GOLD, "cli_c2_r1.fq"), "ktrim=r", "k=23", "notaflag=1", "ref=adapters"])
+    assert r.returncode == 1 and "bad arguments" in r.stderr and "notaflag" in r.stderr
+
+
+def _read_fastq(path):
+    with open(path) as f:
+        lines = f.read().split("\n")
+    return [(lines[i][1:], lines[i + 1], lines[i + 3]) for i in range(0, len(lines) - 1, 4)]
+
+
+@pytest.mark.gpu
+def test_cli_ktrim_two_files_matches_spec_tsv(tmp_path):
+    tsv, out, outm = (str(tmp_path / n) for n in ("o.tsv", "clean.fq", "removed.fq"))
+    r = run_cli(["in=" + os.path.join(GOLD, "cli_c2_r1.fq"), "in2=" + os.path.join(GOLD, "cli_c2_r2.fq"), "tsv=" + tsv, "out=" + out,
+                 "outm=" + outm, "batch=64", "ktrim=r", "k=23", "mink=11", "hdist=1", "ref=adapters"])
+    assert r.returncode == 0, r.stderr
+    assert open(tsv).read() == open(os.path.join(GOLD, "cli_c2.tsv")).read()
+    rows = [l.split("\t") for l in open(tsv).read().splitlines()]
+    src = {}
+    for f in ("cli_c2_r1.fq", "cli_c2_r2.fq"):
+        src.update({n: (b, q) for n, b, q in _read_fastq(os.path.join(GOLD, f))})
+    kept = {n: (b, q) for n, b, q in _read_fastq(out)}
+    removed = {n: (b, q) for n, b, q in _read_fastq(outm)}
+    for name, L, a, _id, new_len, flags in rows:
+        dst = removed if int(flags) & 2 else kept
+        b, q = dst[name]
+        assert b == src[name][0][:int(new_len)] and q == src[name][1][:int(new_len)] and int(new_len) == int(L) - int(a)
+    assert len(kept) + len(removed) == len(rows)
+    trimmed = sum(1 for x in rows if int(x[2]) > 0)
+    assert "KTrimmed:" in r.stderr and "Input:" in r.stderr and trimmed > 0
+
+
+@pytest.mark.gpu
+def test_cli_kfilter_interleaved_matches_spec_tsv(tmp_path):
+    tsv = str(tmp_path / "o.tsv")
+    r = run_cli(["in=" + os.path.join(GOLD, "cli_c3_interleaved.fq"), "int=t", "tsv=" + tsv, "k=31", "hdist=1", "ref=phix"])
+    assert r.returncode == 0, r.stderr
+    assert open(tsv).read() == open(os.path.join(GOLD, "cli_c3.tsv")).read()
+    assert "Contaminants:" in r.stderr
