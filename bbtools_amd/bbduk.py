@@ -35,7 +35,8 @@ class Params(C.Structure):          # struct bbduk_params
                 ("removePairsIfEitherBad", C.c_int32), ("trimPad", C.c_int32), ("ktrimExclusive", C.c_int32),
                 ("restrictLeft", C.c_int32), ("restrictRight", C.c_int32), ("skipR1", C.c_int32),
                 ("skipR2", C.c_int32), ("numScaffolds", C.c_int32), ("device", C.c_int32),
-                ("reserved", C.c_int32 * 8)]
+                ("trimPairsEvenly", C.c_int32), ("qSkip", C.c_int32), ("speed", C.c_int32),
+                ("reserved", C.c_int32 * 5)]
 
 
 class SynthParams(C.Structure):     # struct bbduk_synth_params

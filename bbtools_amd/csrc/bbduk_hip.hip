@@ -52,6 +52,7 @@ struct KParams {
     int32_t mode, k, mink, rcomp, forbidNs, minlen, minlen2, qhdist, qhdist2, maxBadKmers, minReadLength;
     float   minLenFraction;
     int32_t rieb, trimPad, ktrimExclusive, restrictLeft, restrictRight, skipR1, skipR2, numScaffolds, useShort;
+    int32_t tpe, qskip, speed;   // trimpairsevenly; qskip (<2 = off) and speed (0 = off) run in the general kernels only
     uint64_t mask, kmask, middleMask;
     // The map, device layout: 4-way buckets.  tags[b] packs four 15-bit fingerprints in 16-bit lanes (0 = free
     // way) plus the bucket's continuation flag in bit 63; the full key and its id live together in bkv[4*b+way]
@@ -145,10 +146,15 @@ __device__ __forceinline__ int table_get(const KParams& P, uint64_t key) { const
 // A lookup result ("ref") is -1 = absent or the id (>0) itself.
 __device__ __forceinline__ int ref_to_id(const KParams& P, int ref) { return ref; }
 
+// passesSpeed (bbduk/BBDukIndexMod.java:562): with this index the gate sits on the query side only, so it has to
+// be applied here (keys that fail it ARE in the map).  General kernels only.
+__device__ __forceinline__ bool passes_speed(const KParams& P, uint64_t key) { return P.speed < 1 || (int)(key % 17ULL) >= P.speed; }
+
 // key -> ref through the cascade: LDS presence bit -> bucket fingerprints -> key.  `ok` = lane has a real query.
 __device__ __forceinline__ int probe_ref(const KParams& P, const uint32_t* s_filt, uint64_t value, uint64_t lengthMask, bool ok) {
     const uint32_t ma = mix_a(value);
     bool p = ok;
+    if (P.speed > 0) p = p && passes_speed(P, value | lengthMask);
     if (P.ldsBits) p = p & (bool)filt_test(s_filt, ma, P.ldsBits);
     int ref = -1;
     if (p) ref = table_find_m(P, value | lengthMask, ma, mix_b(value));
@@ -170,7 +176,8 @@ __device__ __forceinline__ uint64_t make_key(const KParams& P, uint64_t kmer, ui
 // getValue (bbduk/BBDukIndexMod.java:462-481): query-side Hamming expansion, same (j,i) order, first id>=1 wins
 template <int D>
 __device__ int get_value(const KParams& P, uint64_t kmer, uint64_t rkmer, uint64_t lengthMask, int len, int qh) {
-    int id = table_get(P, make_key<true>(P, kmer, rkmer, lengthMask));
+    const uint64_t key0 = make_key<true>(P, kmer, rkmer, lengthMask);
+    int id = passes_speed(P, key0) ? table_get(P, key0) : -1;
     if constexpr (D > 0) {
         if (id < 1 && qh > 0) {
             for (int j = 0; j < 4 && id < 1; j++) {
@@ -398,7 +405,7 @@ __device__ __forceinline__ void win_init(const KParams& P, const Planes& Q, cons
         }
         W.hasN = __ballot(acc != 0) != 0;
     }
-    W.full = (!GENERAL || W.start == 0);                         // every window holds k bases
+    W.full = (!GENERAL || (W.start == 0 && P.qskip < 2));        // every window holds k bases and every position is looked up
 }
 
 // kmer / rkmer of the windows ending at the ADJACENT positions i and i+1 of read W (lane-varying i); ok=false: no
@@ -459,6 +466,7 @@ __device__ __forceinline__ void windows2(const KParams& P, const Planes& Q, cons
         rr <<= 2 * (k - nb);                                     // base j sits at 2*(k-1-(i-j))
         kmer[h] = km; rk[h] = rr;
         ok[h] = act && len >= P.minlen2;
+        if constexpr (GENERAL) { if (P.qskip > 1) ok[h] = ok[h] && (ih % P.qskip) == 0; }            // BBDukIndexMod.java:494
     }
 }
 
@@ -484,6 +492,7 @@ __device__ __forceinline__ void lookup4(const KParams& P, const uint32_t* s_filt
         ma[s] = mix_a(value);
         mb[s] = mix_b(value);
         p[s] = ok[s];
+        if constexpr (GENERAL) { if (P.speed > 0) p[s] = p[s] && passes_speed(P, key[s]); }
     }
     if (TSW(P, 2)) {                                             // experiment: keys and hashes only
 #pragma unroll
@@ -543,6 +552,13 @@ __device__ __forceinline__ uint64_t cand_probe4(const KParams& P, const uint32_t
         C.mb[s] = klo * HB0 + khi * HB1;
         C.pv[s] = 1u;
     }
+    bool sp[4] = {true, true, true, true};
+    if constexpr (GENERAL) {
+        if (P.speed > 0) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) sp[s] = passes_speed(P, C.key[s] | P.kmask);
+        }
+    }
     if (TSW(P, 2)) {                                              // experiment: keys and hashes only
         uint64_t a = 0;
 #pragma unroll
@@ -556,6 +572,10 @@ __device__ __forceinline__ uint64_t cand_probe4(const KParams& P, const uint32_t
                                                  : *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_filt) + filt_byte(C.ma[s], P.ldsBits));
 #pragma unroll
         for (int s = 0; s < 4; s++) C.pv[s] = __builtin_amdgcn_ubfe(w[s], C.ma[s], 1u);   // the offset operand uses ma[4:0] only
+    }
+    if constexpr (GENERAL) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) C.pv[s] = sp[s] ? C.pv[s] : 0u;
     }
     if (TSW(P, 1)) {                                              // experiment: filter but no gathers
         uint64_t a = 0;
@@ -745,7 +765,8 @@ __device__ __forceinline__ void short_scan_pair(const KParams& P, const Planes& 
     int id = -1;
     if (MODE == BBDUK_MODE_KTRIM_L) {
         const int Lmax = min(k, stop) - start;                   // lengths 1..Lmax, i = start+Ls-1
-        const bool act = need && Ls <= Lmax;
+        bool act = need && Ls <= Lmax;
+        if constexpr (GENERAL) { if (P.qskip > 1) act = act && ((start + Ls - 1) % P.qskip) == 0; }
         const int Lc = act ? Ls : 1;
         uint64_t kmer = 0, rk = 0;
         if (act) {
@@ -755,7 +776,8 @@ __device__ __forceinline__ void short_scan_pair(const KParams& P, const Planes& 
         id = lookup<GENERAL>(P, Q.filt, kmer, rk, 1ULL << (2 * Lc), Lc, P.qhdist2, act);
     } else {
         const int Lmax = (stop >= k ? k - 1 : stop);             // lengths 1..Lmax, i = stop-Ls
-        const bool act = need && Ls <= Lmax;
+        bool act = need && Ls <= Lmax;
+        if constexpr (GENERAL) { if (P.qskip > 1) act = act && ((stop - Ls) % P.qskip) == 0; }
         const int Lc = act ? Ls : 1;
         uint64_t kmer = 0, rk = 0;
         if (act) {
@@ -830,10 +852,10 @@ __device__ __forceinline__ void read_finish(const KParams& P, const ReadScan& R,
 // bbduk/BBDukProcessorS.java:807-818, 948-1093, 1431-1443, 1464-1493.  acc[0]=readsKTrimmed acc[1]=basesKTrimmed
 // acc[2]=readsOutm acc[3]=basesOutm; the other counters follow from these and readsIn/basesIn (see kernel end).
 template <int MODE>
-__device__ __forceinline__ void record_stage(const KParams& P, const ReadOut& X, const ReadOut* Y, int* acc, uint8_t& f1, uint8_t& f2) {
+__device__ __forceinline__ void record_stage(const KParams& P, ReadOut& X, ReadOut* Y, int* acc, uint8_t& f1, uint8_t& f2) {
     const bool two = (Y != nullptr);
     const int l1 = X.L, l2 = two ? Y->L : 0;
-    const int n1 = X.newLen, n2 = two ? Y->newLen : 0;
+    int n1 = X.newLen, n2 = two ? Y->newLen : 0;
     const int pairCount = two ? 2 : 1;
     const float g1 = (float)l1 * P.minLenFraction, g2 = (float)l2 * P.minLenFraction;
     const int minlen1 = (int)(g1 > (float)P.minReadLength ? g1 : (float)P.minReadLength);
@@ -846,6 +868,13 @@ __device__ __forceinline__ void record_stage(const KParams& P, const ReadOut& X,
             d1 = n1 < minlen1;
             d2 = two && (n2 < minlen2);
             if ((P.rieb && (d1 || d2)) || (d1 && (!two || d2))) { xsum += n1 + n2; rkt = pairCount; remove = true; }
+            else if (MODE == BBDUK_MODE_KTRIM_R && P.tpe && xsum > 0 && two && n1 != n2) {   // trimpairsevenly (:1021-1031)
+                int x;
+                if (n1 > n2) { x = trim_by_amount(n1, 0, n1 - n2, 1, n1); X.a += x; X.newLen = n1; }
+                else { x = trim_by_amount(n2, 0, n2 - n1, 1, n2); Y->a += x; Y->newLen = n2; }
+                if (rkt < 2) rkt++;
+                xsum += x;
+            }
             acc[0] += rkt; acc[1] += xsum;
         } else {
             d1 = X.a > P.maxBadKmers;
@@ -1232,14 +1261,18 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                             uint64_t kmer = 0, rk = 0; bool act; int Lc;
                             if (MODE == BBDUK_MODE_KTRIM_L) {
                                 const int Lmax = min(P.k, jstop) - jstart;         // lengths 1..Lmax, i = start+Ls-1
-                                act = have && Ls <= Lmax; Lc = act ? Ls : 1;
+                                act = have && Ls <= Lmax;
+                                if constexpr (GENERAL) { if (P.qskip > 1) act = act && ((jstart + Ls - 1) % P.qskip) == 0; }
+                                Lc = act ? Ls : 1;
                                 if (act) {
                                     kmer = extract2(Q.fwd, Q.T - 1 - (jb + jstart + Lc - 1), Lc) & P.mask;
                                     rk   = extract2(Q.cmp, jb + jstart, Lc);
                                 }
                             } else {
                                 const int Lmax = (jstop >= P.k ? P.k - 1 : jstop);  // lengths 1..Lmax, i = stop-Ls
-                                act = have && Ls <= Lmax; Lc = act ? Ls : 1;
+                                act = have && Ls <= Lmax;
+                                if constexpr (GENERAL) { if (P.qskip > 1) act = act && ((jstop - Ls) % P.qskip) == 0; }
+                                Lc = act ? Ls : 1;
                                 if (act) {
                                     kmer = extract2(Q.fwd, Q.T - 1 - (jb + jstop - 1), Lc);          // base stop-1 in bits 0-1
                                     rk   = extract2(Q.cmp, jb + jstop - Lc, Lc) & P.mask;            // base i in bits 0-1
@@ -1285,11 +1318,17 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                 remove = (P.rieb && (d || dm)) || (d && dm);        // shouldRemove (:1489-1492)
             } else remove = d;
         }
+        bool evened = false;
+        if (MODE == BBDUK_MODE_KTRIM_R && P.tpe && paired && P.storedKmers > 0) {   // trimpairsevenly (:1021-1031)
+            const int am = __shfl_xor(a, 1), nm = __shfl_xor(newLen, 1);
+            evened = mine && !remove && (a + am) > 0 && newLen != nm;               // the same verdict in both mates' lanes
+            if (evened && newLen > nm) a += trim_by_amount(newLen, 0, newLen - nm, 1, newLen);
+        }
         if (mine) {
             outA[r0 + lane] = a; outId[r0 + lane] = id;
             outFlags[r0 + lane] = (uint8_t)((d ? BBDUK_FLAG_DISCARDED : 0) | (remove ? BBDUK_FLAG_REMOVED : 0));
             if (MODE != BBDUK_MODE_KFILTER) {                       // :1011-1029, per read: the pair's sums are the mates' sums
-                vRkt += remove ? 1u : (a > 0 ? 1u : 0u);
+                vRkt += (remove || evened) ? 1u : (a > 0 ? 1u : 0u);   // evened pairs count both mates (rktsum -> 2)
                 vXs += (unsigned)a + (remove ? (unsigned)newLen : 0u);
             }
             if (remove) { vRm += 1; vBm += (unsigned)newLen; }
@@ -1367,7 +1406,7 @@ static KernelPair pick_kernel(const KParams& K) {
     // the specialised kernels assume k >= 16 (BBDuk's usual 23-31) and what BBDukParser guarantees (mink turns
     // maskMiddle off, :295-301); anything else takes the general kernel
     const bool general = K.qhdist > 0 || K.qhdist2 > 0 || K.restrictLeft > 0 || K.restrictRight > 0 || K.skipR1 || K.skipR2 || !K.rcomp ||
-                         (K.useShort && K.middleMask != ~0ULL) || K.k < 16;
+                         (K.useShort && K.middleMask != ~0ULL) || K.k < 16 || K.qskip > 1 || K.speed > 0;
     if (K.mode == BBDUK_MODE_KFILTER) return pick_kernel_mode<BBDUK_MODE_KFILTER>(general, false, K.forbidNs != 0);
     if (K.mode == BBDUK_MODE_KTRIM_L) return pick_kernel_mode<BBDUK_MODE_KTRIM_L>(general, K.useShort != 0, K.forbidNs != 0);
     return pick_kernel_mode<BBDUK_MODE_KTRIM_R>(general, K.useShort != 0, K.forbidNs != 0);
@@ -1442,6 +1481,8 @@ extern "C" int bbduk_create(const bbduk_params* p, bbduk_handle** out) {
     if (useShort && p->mode == BBDUK_MODE_KFILTER) return BBDUK_ERR_ARG;      // BBDukParser.java:301
     if (useShort && p->middleMask != -1) return BBDUK_ERR_ARG;                // BBDukProcessorS.java:2035 assert
     if (p->minlen != p->k - 1) return BBDUK_ERR_ARG;
+    if (p->speed < 0 || p->speed > 16 || p->qSkip < 0) return BBDUK_ERR_ARG;    // BBDukParser.java:568
+    for (int i = 0; i < 5; i++) if (p->reserved[i] != 0) return BBDUK_ERR_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return BBDUK_ERR_DEVICE;
     if (p->device < 0 || p->device >= ndev) return BBDUK_ERR_ARG;
@@ -1586,6 +1627,7 @@ static KParams make_kparams(const bbduk_handle* h) {
     K.maxBadKmers = p.maxBadKmers; K.minReadLength = p.minReadLength; K.minLenFraction = p.minLenFraction;
     K.rieb = p.removePairsIfEitherBad; K.trimPad = p.trimPad; K.ktrimExclusive = p.ktrimExclusive;
     K.restrictLeft = p.restrictLeft; K.restrictRight = p.restrictRight; K.skipR1 = p.skipR1; K.skipR2 = p.skipR2;
+    K.tpe = (p.trimPairsEvenly && p.mode == BBDUK_MODE_KTRIM_R) ? 1 : 0; K.qskip = p.qSkip; K.speed = p.speed;
     K.numScaffolds = p.numScaffolds;
     K.useShort = (p.mink > 0 && p.mink < p.k) ? 1 : 0;
     K.mask = (2 * p.k > 63) ? ~0ULL : ~(~0ULL << (2 * p.k));

@@ -36,6 +36,8 @@ struct Parsed {                      // bbduk/BBDukParser.java fields (subset th
     int restrictLeft = 0, restrictRight = 0;
     bool skipR1 = false, skipR2 = false;
     int minSkip = 1, maxSkip = 1;
+    bool trimPairsEvenly = false;    // tpe
+    int qSkip = 1, speed = 0;        // :1373-1377
     std::vector<std::string> ref, literal;
     // derived (:130-312)
     int minlen = 0, minlen2 = 0;
@@ -203,6 +205,9 @@ extern "C" int bbduk_host_parse(const char* args, bbduk_host** out, char* errbuf
         else if (a == "restrictright") need_int(p.restrictRight);
         else if (a == "skipr1") need_bool(p.skipR1);
         else if (a == "skipr2") need_bool(p.skipR2);
+        else if (a == "tpe" || a == "trimpairsevenly") need_bool(p.trimPairsEvenly);
+        else if (a == "qskip") need_int(p.qSkip);
+        else if (a == "speed") { need_int(p.speed); if (ok && (p.speed < 0 || p.speed > 16)) { seterr("Speed range is 0 to 16.  Value: " + b); delete h; return BBDUK_ERR_ARG; } }
         else if (a == "maxskip" || a == "maxrskip" || a == "mxs") need_int(p.maxSkip);
         else if (a == "minskip" || a == "minrskip" || a == "mns") need_int(p.minSkip);
         else if (a == "skip" || a == "refskip" || a == "rskip") { need_int(p.minSkip); p.maxSkip = p.minSkip; }
@@ -333,6 +338,7 @@ extern "C" int bbduk_host_params(const bbduk_host* h, int32_t device, bbduk_para
     out->trimPad = p.trimPad; out->ktrimExclusive = p.ktrimExclusive;
     out->restrictLeft = p.restrictLeft; out->restrictRight = p.restrictRight;
     out->skipR1 = p.skipR1; out->skipR2 = p.skipR2;
+    out->trimPairsEvenly = p.trimPairsEvenly; out->qSkip = p.qSkip; out->speed = p.speed;
     out->numScaffolds = (int32_t)h->scaffolds.size() + 1;
     out->device = device;
     return BBDUK_OK;

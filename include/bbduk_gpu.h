@@ -87,7 +87,10 @@ typedef struct bbduk_params {
     int32_t skipR1, skipR2;
     int32_t numScaffolds;           /* scaffoldNames.size(): ids are 1..numScaffolds-1 */
     int32_t device;                 /* HIP device ordinal */
-    int32_t reserved[8];            /* must be zero */
+    int32_t trimPairsEvenly;        /* tpe (BBDukProcessorS.java:1021-1031; ktrim=r pairs) */
+    int32_t qSkip;                  /* qskip= (0 or 1 = off; BBDukIndexMod.java:494) */
+    int32_t speed;                  /* speed= 0..16 (query-side gate, BBDukIndexMod.java:506,562) */
+    int32_t reserved[5];            /* must be zero */
 } bbduk_params;
 
 typedef struct bbduk_handle bbduk_handle;

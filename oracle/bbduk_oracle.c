@@ -221,6 +221,7 @@ void bbo_default_args(bbo_args* a) {
     a->minReadLength = 10;    /* :437 */
     a->minLenFraction = 0.f;  /* :439 */
     a->minSkip = 1; a->maxSkip = 1;
+    a->trimPairsEvenly = 0; a->qSkip = 1; a->speed = 0;
 }
 
 static int imax(int a, int b) { return a > b ? a : b; }
@@ -520,14 +521,16 @@ int64_t bbo_dump_pairs(const bbo_ctx* c, int64_t* keys, int32_t* values, int64_t
 
 /* ------------------------------------------------------------------------------------------ */
 /* bbduk/BBDukIndexMod.java:492-520 getValueInner (qSkip=1, speed=0) */
-static int get_value_inner(const bbo_ctx* c, const int64_t kmer, const int64_t rkmer, const int64_t lengthMask) {
+static int get_value_inner(const bbo_ctx* c, const int64_t kmer, const int64_t rkmer, const int64_t lengthMask, const int qPos) {
+    if (c->a.qSkip > 1 && (qPos % c->a.qSkip != 0)) return -1;                        /* :494 */
     const int64_t max = (c->rcomp ? (kmer > rkmer ? kmer : rkmer) : kmer);
     const int64_t key = (max & c->middleMask) | lengthMask;
+    if (!(c->a.speed < 1 || ((key & INT64_MAX) % 17) >= c->a.speed)) return -1;     /* passesSpeed :506,562 */
     return ha_get_value(&c->keySets[(int)(key % WAYS)], key);
 }
 /* bbduk/BBDukIndexMod.java:462-481 getValue */
 int bbo_get_value(const bbo_ctx* c, const int64_t kmer, const int64_t rkmer, const int64_t lengthMask, const int qPos, const int len, const int qHDist) {
-    int id = get_value_inner(c, kmer, rkmer, lengthMask);
+    int id = get_value_inner(c, kmer, rkmer, lengthMask, qPos);
     if (id < 1 && qHDist > 0) {
         const int qHDist2 = qHDist - 1;
         for (int j = 0; j < SYMBOLS && id < 1; j++) {
@@ -749,6 +752,12 @@ static void process_pair(const bbo_ctx* c, tcounters* tc, const uint8_t* b1, int
             xsum += (rlen1 + rlen2);                                                  /* :1011-1014 (!ktrimN) */
             rktsum = pairCount;
             remove = 1;
+        } else if (c->a.ktrimRight && c->a.trimPairsEvenly && xsum > 0 && has2 && newLen1 != newLen2) {   /* :1021-1031 */
+            int x;
+            if (newLen1 > newLen2) { x = trim_to_position(newLen1, 0, newLen2 - 1, 1, &newLen1); a[0] += x; }
+            else { x = trim_to_position(newLen2, 0, newLen1 - 1, 1, &newLen2); a[1] += x; }
+            if (rktsum < 2) rktsum++;
+            xsum += x;
         }
         tc->counters[BBO_BASES_KTRIMMED] += xsum;                                     /* :1028-1029 */
         tc->counters[BBO_READS_KTRIMMED] += rktsum;

@@ -45,6 +45,9 @@ typedef struct bbo_args {
     int restrictLeft, restrictRight; /* restrictleft= restrictright= */
     int skipR1, skipR2; /* skipr1= skipr2= */
     int minSkip, maxSkip;/* rskip/minskip/maxskip (default 1,1) */
+    int trimPairsEvenly;/* tpe            (BBDukProcessorS.java:1021-1031) */
+    int qSkip;          /* qskip=         (default 1; BBDukIndexMod.java:494) */
+    int speed;          /* speed=         (default 0; query-side gate, BBDukIndexMod.java:506,562) */
 } bbo_args;
 
 #define BBO_NCOUNTERS 16

@@ -65,6 +65,9 @@ class Args:
     restrictRight: int = 0
     skipR1: bool = False
     skipR2: bool = False
+    trimPairsEvenly: bool = False   # tpe
+    qSkip: int = 1                  # qskip=
+    speed: int = 0                  # speed=
 
 
 COUNTER_NAMES = ["readsIn", "basesIn", "readsKTrimmed", "basesKTrimmed", "readsKFiltered", "basesKFiltered",
@@ -175,15 +178,19 @@ class Spec:
         return nrec
 
     # ---------------------------------------------------------------- lookup
-    def lookup(self, kmer: int, rkmer: int, length: int, qhdist: int) -> int:
-        """bbduk/BBDukIndexMod.java:462-520 getValue / getValueInner."""
-        vid = self.table.get(self.key_of(kmer, rkmer, length), -1)
+    def lookup(self, kmer: int, rkmer: int, length: int, qhdist: int, qpos: int) -> int:
+        """bbduk/BBDukIndexMod.java:462-520 getValue / getValueInner (qskip gate :494, passesSpeed :506,562:
+        with this index the speed gate sits on the query side only)."""
+        if self.a.qSkip > 1 and qpos % self.a.qSkip != 0:
+            return -1
+        key = self.key_of(kmer, rkmer, length)
+        vid = -1 if (self.a.speed > 0 and key % 17 < self.a.speed) else self.table.get(key, -1)
         if vid < 1 and qhdist > 0:
             for j in range(4):
                 for i in range(length):
                     t = (kmer & ~(3 << (2 * i))) | (j << (2 * i))
                     if t != kmer:
-                        vid = self.lookup(t, rcomp_int(t, length), length, qhdist - 1)
+                        vid = self.lookup(t, rcomp_int(t, length), length, qhdist - 1, qpos)
                         if vid >= 1:
                             return vid
         return vid
@@ -216,7 +223,7 @@ class Spec:
             rk = 0
             for j in range(max(lo, lastN + 1), i + 1):
                 rk |= comp_code(read[j]) << (2 * (k - 1 - (i - j)))
-            vid = self.lookup(kmer, rk, k, self.qhdist)
+            vid = self.lookup(kmer, rk, k, self.qhdist, i)
             if vid > 0:
                 yield i, vid
 
@@ -259,7 +266,7 @@ class Spec:
                     rk = 0
                     for t, c in enumerate(s):
                         rk |= comp_code(c) << (2 * t)
-                    vid = self.lookup(km, rk, L, self.qhdist2)
+                    vid = self.lookup(km, rk, L, self.qhdist2, i)
                     if vid > 0:
                         if id0 < 0: id0 = vid
                         minLoc = 0
@@ -280,7 +287,7 @@ class Spec:
                     for t, c in enumerate(s):
                         rk |= comp_code(c) << (2 * t)
                     rk &= (1 << (2 * k)) - 1
-                    vid = self.lookup(km, rk, L, self.qhdist2)
+                    vid = self.lookup(km, rk, L, self.qhdist2, i)
                     if vid > 0:
                         if id0 < 0: id0 = vid
                         minLoc = i
@@ -348,6 +355,13 @@ class Spec:
                 d2 = n2 < minlen2
             if (self.rieb and (d1 or d2)) or (d1 and (not has2 or d2)):
                 xsum += n1 + n2; rkt = pc; remove = True
+            elif a.ktrimRight and a.trimPairsEvenly and xsum > 0 and has2 and n1 != n2:        # :1021-1031
+                if n1 > n2:
+                    x, n1 = self._trim_by_amount(n1, 0, n1 - (n2 - 1) - 1, 1); x1 += x
+                else:
+                    x, n2 = self._trim_by_amount(n2, 0, n2 - (n1 - 1) - 1, 1); x2 += x
+                if rkt < 2: rkt += 1
+                xsum += x
             C[3] += xsum; C[2] += rkt
             res = [(x1, i1)] + ([(x2, i2)] if has2 else [])
         elif self.table:

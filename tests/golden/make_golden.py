@@ -53,6 +53,9 @@ def main():
     reads = synth_reads(2, 60, ins_min=30, ins_max=260, sub_rate=0.02, n_rate=0.004)
     run_case("c2_ktrimr_k23_mink11_hdist1_adapters", "ktrim=r k=23 mink=11 hdist=1 ref=adapters",
              dict(k=23, mink=11, hdist=1, ktrimRight=True), ADAPTERS, reads, True)
+    # C2 + trimpairsevenly (the canonical adapter-trimming command line: ktrim=r k=23 mink=11 hdist=1 tpe)
+    run_case("c2_ktrimr_k23_mink11_hdist1_tpe_adapters", "ktrim=r k=23 mink=11 hdist=1 tpe ref=adapters",
+             dict(k=23, mink=11, hdist=1, ktrimRight=True, trimPairsEvenly=True), ADAPTERS, reads, True)
     # C3: kfilter k=31 hdist=1 ref=phix
     reads = synth_reads(3, 60, contam=phix, contam_frac=0.3, sub_rate=0.02, n_rate=0.004)
     run_case("c3_kfilter_k31_hdist1_phix", "k=31 hdist=1 ref=phix", dict(k=31, hdist=1), PHIX, reads, True)

@@ -105,7 +105,12 @@ FUZZ = [("ktrim=r k=23", dict(k=23, ktrimRight=1)),
         ("ktrim=r k=14 ktrimexclusive=t mink=8 mlf=0.9", dict(k=14, ktrimRight=1, ktrimExclusive=1, mink=8, minLenFraction=0.9)),
         ("k=9 hdist=2 mm=f", dict(k=9, hdist=2, maskMiddle=0)), ("ktrim=r k=16 skipr2=t", dict(k=16, ktrimRight=1, skipR2=1)),
         ("k=10 qhdist=2 mm=f", dict(k=10, qhdist=2, maskMiddle=0)), ("k=1 mm=f", dict(k=1, maskMiddle=0)),
-        ("ktrim=l k=31 mink=1", dict(k=31, ktrimLeft=1, mink=1)), ("k=24", dict(k=24)), ("ktrim=r k=31 mink=30 tp=-3", dict(k=31, ktrimRight=1, mink=30, trimPad=-3))]
+        ("ktrim=l k=31 mink=1", dict(k=31, ktrimLeft=1, mink=1)), ("k=24", dict(k=24)), ("ktrim=r k=31 mink=30 tp=-3", dict(k=31, ktrimRight=1, mink=30, trimPad=-3)),
+        ("ktrim=r k=23 mink=11 hdist=1 tpe", dict(k=23, ktrimRight=1, mink=11, hdist=1, trimPairsEvenly=1)),
+        ("ktrim=r k=17 tpe=t rieb=f minlen=30", dict(k=17, ktrimRight=1, trimPairsEvenly=1, requireBothBad=1, minReadLength=30)),
+        ("k=21 qskip=3", dict(k=21, qSkip=3)), ("ktrim=r k=14 mink=6 qskip=2", dict(k=14, ktrimRight=1, mink=6, qSkip=2)),
+        ("k=25 speed=5 hdist=1", dict(k=25, speed=5, hdist=1)), ("ktrim=l k=15 mink=9 speed=9 qhdist=1", dict(k=15, ktrimLeft=1, mink=9, speed=9, qhdist=1)),
+        ("ktrim=r k=27 speed=12 qskip=2 tpe", dict(k=27, ktrimRight=1, speed=12, qSkip=2, trimPairsEvenly=1))]
 
 
 @pytest.mark.parametrize("ci", range(len(FUZZ)))
@@ -150,7 +155,7 @@ def test_edge_shapes():
 def test_tile_kernel_fallback_matches_wave_kernel(monkeypatch):
     """The tile-synchronous kernel only runs when a pair exceeds a wave's LDS slice; force it on ordinary reads so
     that both kernels stay interchangeable (same results, same counters as the oracle)."""
-    for cfg in ("c2", "c3", "c1"):
+    for cfg in ("c2", "c3", "c1", "c2tpe", "c3q"):
         args, okw, ref = util.CONFIGS[cfg]
         d, o = make_pair(args, okw, ref_fasta=ref)
         kw = dict(contam=B.read_fasta(util.PHIX)[0][1], contam_frac=0.05) if "phix" in args else {}

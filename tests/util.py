@@ -17,6 +17,8 @@ CONFIGS = {
     "c3": ("k=31 hdist=1 ref=phix", dict(k=31, hdist=1), PHIX),
     "c4s": ("k=31 hdist=0 ref=phix", dict(k=31), PHIX),
     "c5": ("ktrim=r k=23 hdist=1 ref=adapters", dict(k=23, hdist=1, ktrimRight=1), ADAPTERS),
+    "c2tpe": ("ktrim=r k=23 mink=11 hdist=1 tpe ref=adapters", dict(k=23, mink=11, hdist=1, ktrimRight=1, trimPairsEvenly=1), ADAPTERS),
+    "c3q": ("k=31 hdist=1 qskip=2 speed=3 ref=phix", dict(k=31, hdist=1, qSkip=2, speed=3), PHIX),
 }
 
 
