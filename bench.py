@@ -51,8 +51,16 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # Dry-run hooks for a 1-GPU box (never set by the driver): every rank on GPU 0 and a gloo rendezvous, so that the
+        # N>1 control flow (sharding, barrier, max-over-ranks clock, counter all-reduce) can be exercised without N GPUs.
+        if os.environ.get("BBDUK_BENCH_SHARE_GPU"):
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("BBDUK_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     dev = local if distributed else 0
     torch.cuda.set_device(dev)
     assert a.gpus == world, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run for N>1)"
