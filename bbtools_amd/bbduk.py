@@ -36,7 +36,7 @@ class Params(C.Structure):          # struct bbduk_params
                 ("restrictLeft", C.c_int32), ("restrictRight", C.c_int32), ("skipR1", C.c_int32),
                 ("skipR2", C.c_int32), ("numScaffolds", C.c_int32), ("device", C.c_int32),
                 ("trimPairsEvenly", C.c_int32), ("qSkip", C.c_int32), ("speed", C.c_int32),
-                ("reserved", C.c_int32 * 5)]
+                ("minKmerFraction", C.c_float), ("minCoveredFraction", C.c_float), ("reserved", C.c_int32 * 3)]
 
 
 class SynthParams(C.Structure):     # struct bbduk_synth_params

@@ -53,6 +53,7 @@ struct KParams {
     float   minLenFraction;
     int32_t rieb, trimPad, ktrimExclusive, restrictLeft, restrictRight, skipR1, skipR2, numScaffolds, useShort;
     int32_t tpe, qskip, speed;   // trimpairsevenly; qskip (<2 = off) and speed (0 = off) run in the general kernels only
+    float   mkf, mcf;            // kfilter: minkmerfraction / mincoveredfraction (general kernels only)
     uint64_t mask, kmask, middleMask;
     // The map, device layout: 4-way buckets.  tags[b] packs four 15-bit fingerprints in 16-bit lanes (0 = free
     // way) plus the bucket's continuation flag in bit 63; the full key and its id live together in bkv[4*b+way]
@@ -308,6 +309,7 @@ struct ReadScan {
     int shortFl, shortLl;               // short k-mer scan: first / last hit lane (length index); shortFl<0: none
     int candSlot; uint32_t candKeyLo, candKeyHi;   // candidate mode: first unverified fingerprint match (slot, key)
     int hasN;                           // undefined base inside [start,stop)?  1/0, or -1 = not known yet (forbidNs only)
+    int maxBad;                         // kfilter: this read's maxBadKmers (mkf) or minCoveredBases (mcf)
 };
 
 template <int MODE, bool SHORT, bool GENERAL>
@@ -331,7 +333,7 @@ template <bool GENERAL> __device__ __forceinline__ int span_stop(const KParams& 
 }
 template <int MODE, bool SHORT, bool GENERAL>
 __device__ __forceinline__ void read_init(const KParams& P, ReadScan& R, int base0, int L, int pairnum, bool present) {
-    R.base0 = base0; R.L = L; R.hasN = -1;
+    R.base0 = base0; R.L = L; R.hasN = -1; R.maxBad = P.maxBadKmers;
     R.found = 0; R.iFirst = BIGLOC; R.iLast = -1; R.ref = -1; R.shortFl = -1; R.shortLl = -1;
     R.start = span_start<GENERAL>(P, L); R.stop = span_stop<GENERAL>(P, L);
     R.scan = scan_due<MODE, SHORT, GENERAL>(P, L, pairnum, present);
@@ -645,19 +647,51 @@ __device__ __forceinline__ bool fold_hits(const KParams& P, ReadScan& R, int& fo
         found += __popcll(m);
         return MODE == BBDUK_MODE_KTRIM_R;                       // only minLoc/id0 of the first hit are used
     } else {
-        const int c = __popcll(m);
-        if (found + c > P.maxBadKmers) {                         // the (maxBadKmers+1)-th hit is in this block
+        if (P.mcf > 0.f) {                                       // countCoveredBases (:1631-1648): hits in position order
             uint64_t mm = m;
-            for (int q = found; q < P.maxBadKmers; q++) mm &= mm - 1;
+            while (mm) {
+                const int p = __ffsll((unsigned long long)mm) - 1, i = ibase + p;
+                found += min(P.k, i - R.iLast);
+                R.iLast = i;
+                if (found >= R.maxBad) { R.ref = ref_at(p); R.iFirst = 0; return true; }
+                mm &= mm - 1;
+            }
+            return false;
+        }
+        const int c = __popcll(m);
+        if (found + c > R.maxBad) {                              // the (maxBadKmers+1)-th hit is in this block
+            uint64_t mm = m;
+            for (int q = found; q < R.maxBad; q++) mm &= mm - 1;
             const int fl = __ffsll((unsigned long long)mm) - 1;
             R.ref = ref_at(fl);
-            found = P.maxBadKmers + 1;
+            found = R.maxBad + 1;
             R.iFirst = 0;                                        // marks the early exit
             return true;
         }
         found += c;
         return false;
     }
+}
+
+// kfilter thresholds that depend on the read (general kernels).  numValidKmers (stream/Read.java:1673-1683), wave-cooperative:
+// one lane per k-mer end position, valid = no undefined base in the window.
+__device__ __forceinline__ int valid_kmers_wave(const Planes& Q, const int base0, const int L, const int k, const int lane) {
+    int cnt = 0;
+    for (int i0 = k - 1; i0 < L; i0 += 64) {
+        const int i = i0 + lane;
+        const bool v = (i < L) && extract1(Q.nm, base0 + min(i, L - 1) - k + 1, k) == 0u;
+        cnt += __popcll(__ballot(v));
+    }
+    return cnt;
+}
+// maxBadKmersR (bbduk/BBDukProcessorS.java:1055-1062) or minCoveredBases (:1040,1045) of one read
+__device__ __forceinline__ int kfilter_threshold(const KParams& P, const Planes& Q, const int base0, const int L, const int lane) {
+    if (P.mcf > 0.f) return (int)ceilf(P.mcf * (float)L);
+    if (P.mkf != 0.f) {
+        const int vk = (L >= P.k) ? valid_kmers_wave(Q, base0, L, P.k, lane) : 0;
+        return max(P.maxBadKmers, (int)((float)(vk - 1) * P.mkf));
+    }
+    return P.maxBadKmers;
 }
 
 template <int MODE, bool FORBIDN, bool GENERAL>
@@ -838,10 +872,10 @@ __device__ __forceinline__ void scaf_add(const KParams& P, ScafAcc& S, int id, i
 }
 
 // Scalar (per-read) finish used by the tile kernel: outputs + scaffold counters.
-struct ReadOut { int L, a, id, newLen; };
+struct ReadOut { int L, a, id, newLen, thr; };   // thr: the read's kfilter threshold (maxBadKmers | minCoveredBases)
 template <int MODE>
 __device__ __forceinline__ void read_finish(const KParams& P, const ReadScan& R, ReadOut& O, const int lane, ScafAcc& S, int64_t* __restrict__ counters) {
-    O.L = R.L; O.a = 0; O.id = -1; O.newLen = R.L;
+    O.L = R.L; O.a = 0; O.id = -1; O.newLen = R.L; O.thr = R.maxBad;
     if (!R.scan) return;
     int ref; bool hit;
     finish_read<MODE>(P, R.L, R.start, R.stop, R.found, R.iFirst, R.iLast, R.shortFl, R.shortLl, R.ref, O.a, O.newLen, ref, hit);
@@ -877,8 +911,8 @@ __device__ __forceinline__ void record_stage(const KParams& P, ReadOut& X, ReadO
             }
             acc[0] += rkt; acc[1] += xsum;
         } else {
-            d1 = X.a > P.maxBadKmers;
-            d2 = two && (Y->a > P.maxBadKmers);
+            d1 = (P.mcf > 0.f) ? (X.a >= X.thr) : (X.a > X.thr);            // :1042,1047 | :1069-1070
+            d2 = two && ((P.mcf > 0.f) ? (Y->a >= Y->thr) : (Y->a > Y->thr));
             if ((P.rieb && (d1 || d2)) || (d1 && (!two || d2))) remove = true;
         }
     }
@@ -989,6 +1023,10 @@ void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
                 ReadScan A, Bz;
                 read_init<MODE, SHORT, GENERAL>(P, A, o0 - a0lo, o1 - o0, 0, true);
                 read_init<MODE, SHORT, GENERAL>(P, Bz, o1 - a0lo, o2 - o1, paired ? 1 : 0, hasB);
+                if constexpr (GENERAL && MODE == BBDUK_MODE_KFILTER) {
+                    A.maxBad = kfilter_threshold(P, Q, A.base0, A.L, lane);
+                    Bz.maxBad = kfilter_threshold(P, Q, Bz.base0, Bz.L, lane);
+                }
                 main_scan_pair<MODE, FORBIDN, GENERAL>(P, Q, A, Bz, lane);
                 if constexpr (MODE != BBDUK_MODE_KFILTER && SHORT) {
                     if (P.useShort) short_scan_pair<MODE, GENERAL>(P, Q, A, Bz, lane);
@@ -1074,7 +1112,8 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
     if (*slowFlag != 0) return;                                   // a unit does not fit a wave's planes: tile kernel's job
     // short-scan geometry: `lens` candidate lengths per read, rpp reads per 64-lane pass
     // first-hit-only operators verify candidates in batches (see main_scan_pair_cand)
-    const bool candMode = (!GENERAL || P.qhdist == 0) && (MODE == BBDUK_MODE_KTRIM_R || (MODE == BBDUK_MODE_KFILTER && P.maxBadKmers == 0));
+    const bool candMode = (!GENERAL || P.qhdist == 0) &&
+                          (MODE == BBDUK_MODE_KTRIM_R || (MODE == BBDUK_MODE_KFILTER && P.maxBadKmers == 0 && P.mkf == 0.f && P.mcf == 0.f));
     const int lens = max(1, (MODE == BBDUK_MODE_KTRIM_L) ? (P.k - P.mink + 1) : (P.k - P.mink));
     const int rpp = max(1, 64 / lens);
     const int sslot = lane / lens, st = lane - sslot * lens;
@@ -1117,6 +1156,8 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
         // raw scan facts of my read, filled in by v_writelane as the pairs are scanned
         int vFound = 0, vFirst = BIGLOC, vLast = -1, vRef = -1, vSFl = -1, vSLl = -1;
         int vCSlot = -1; uint32_t vCKeyLo = 0, vCKeyHi = 0;       // candidate mode: my read's first unverified match
+        int vThr = P.maxBadKmers;                                 // kfilter: my read's threshold (mkf: filled in when its pair is scanned)
+        if constexpr (GENERAL && MODE == BBDUK_MODE_KFILTER) { if (P.mcf > 0.f) vThr = (int)ceilf(P.mcf * (float)vL); }
 
         int s = 0;
         while (s < cnt) {
@@ -1169,6 +1210,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                 const bool hasB = (ra + 1) < e;
                 ReadScan A, Bz;
                 A.hasN = (int)((nMask >> ra) & 1); Bz.hasN = (int)((nMask >> (ra + 1)) & 1);
+                A.maxBad = P.maxBadKmers; Bz.maxBad = P.maxBadKmers;
                 A.base0 = origin + __builtin_amdgcn_readlane(rel, ra);
                 A.L = __builtin_amdgcn_readlane(vL, ra);
                 A.scan = (scanMask >> ra) & 1;
@@ -1190,6 +1232,13 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                         vCKeyLo = (lane == ra + 1) ? Bz.candKeyLo : vCKeyLo; vCKeyHi = (lane == ra + 1) ? Bz.candKeyHi : vCKeyHi;
                     }
                     continue;
+                }
+                if constexpr (GENERAL && MODE == BBDUK_MODE_KFILTER) {
+                    if (P.mkf != 0.f || P.mcf > 0.f) {
+                        A.maxBad = kfilter_threshold(P, Q, A.base0, A.L, lane);
+                        Bz.maxBad = hasB ? kfilter_threshold(P, Q, Bz.base0, Bz.L, lane) : P.maxBadKmers;
+                        vThr = (lane == ra) ? A.maxBad : ((lane == ra + 1) ? Bz.maxBad : vThr);
+                    }
                 }
                 main_scan_pair<MODE, FORBIDN, GENERAL>(P, Q, A, Bz, lane);
                 if (A.found) {                                      // hand the facts to lane ra (most reads have none)
@@ -1224,7 +1273,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                     const int ra = s + ((j - s) & ~1);
                     const bool hasB = (ra + 1) < e;
                     ReadScan A, Bz;
-                    A.hasN = -1; Bz.hasN = -1;
+                    A.hasN = -1; Bz.hasN = -1; A.maxBad = P.maxBadKmers; Bz.maxBad = P.maxBadKmers;
                     A.base0 = origin + __builtin_amdgcn_readlane(rel, ra); A.L = __builtin_amdgcn_readlane(vL, ra); A.scan = (scanMask >> ra) & 1;
                     Bz.base0 = origin + __builtin_amdgcn_readlane(rel, ra + 1); Bz.L = hasB ? __builtin_amdgcn_readlane(vL, ra + 1) : 0;
                     Bz.scan = hasB && ((scanMask >> (ra + 1)) & 1);
@@ -1312,7 +1361,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
         const int minlenR = (int)(g > (float)P.minReadLength ? g : (float)P.minReadLength);
         bool d = false, remove = false;
         if (P.storedKmers > 0) {
-            d = (MODE != BBDUK_MODE_KFILTER) ? (newLen < minlenR) : (a > P.maxBadKmers);
+            d = (MODE != BBDUK_MODE_KFILTER) ? (newLen < minlenR) : ((GENERAL && P.mcf > 0.f) ? (a >= vThr) : (a > vThr));
             if (paired) {
                 const bool dm = __shfl_xor((int)d, 1) != 0;         // my mate's verdict
                 remove = (P.rieb && (d || dm)) || (d && dm);        // shouldRemove (:1489-1492)
@@ -1406,7 +1455,7 @@ static KernelPair pick_kernel(const KParams& K) {
     // the specialised kernels assume k >= 16 (BBDuk's usual 23-31) and what BBDukParser guarantees (mink turns
     // maskMiddle off, :295-301); anything else takes the general kernel
     const bool general = K.qhdist > 0 || K.qhdist2 > 0 || K.restrictLeft > 0 || K.restrictRight > 0 || K.skipR1 || K.skipR2 || !K.rcomp ||
-                         (K.useShort && K.middleMask != ~0ULL) || K.k < 16 || K.qskip > 1 || K.speed > 0;
+                         (K.useShort && K.middleMask != ~0ULL) || K.k < 16 || K.qskip > 1 || K.speed > 0 || K.mkf != 0.f || K.mcf > 0.f;
     if (K.mode == BBDUK_MODE_KFILTER) return pick_kernel_mode<BBDUK_MODE_KFILTER>(general, false, K.forbidNs != 0);
     if (K.mode == BBDUK_MODE_KTRIM_L) return pick_kernel_mode<BBDUK_MODE_KTRIM_L>(general, K.useShort != 0, K.forbidNs != 0);
     return pick_kernel_mode<BBDUK_MODE_KTRIM_R>(general, K.useShort != 0, K.forbidNs != 0);
@@ -1482,7 +1531,8 @@ extern "C" int bbduk_create(const bbduk_params* p, bbduk_handle** out) {
     if (useShort && p->middleMask != -1) return BBDUK_ERR_ARG;                // BBDukProcessorS.java:2035 assert
     if (p->minlen != p->k - 1) return BBDUK_ERR_ARG;
     if (p->speed < 0 || p->speed > 16 || p->qSkip < 0) return BBDUK_ERR_ARG;    // BBDukParser.java:568
-    for (int i = 0; i < 5; i++) if (p->reserved[i] != 0) return BBDUK_ERR_ARG;
+    for (int i = 0; i < 3; i++) if (p->reserved[i] != 0) return BBDUK_ERR_ARG;
+    if (!(p->minKmerFraction >= 0.f && p->minKmerFraction <= 1.f) || !(p->minCoveredFraction >= 0.f && p->minCoveredFraction <= 1.f)) return BBDUK_ERR_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return BBDUK_ERR_DEVICE;
     if (p->device < 0 || p->device >= ndev) return BBDUK_ERR_ARG;
@@ -1628,6 +1678,7 @@ static KParams make_kparams(const bbduk_handle* h) {
     K.rieb = p.removePairsIfEitherBad; K.trimPad = p.trimPad; K.ktrimExclusive = p.ktrimExclusive;
     K.restrictLeft = p.restrictLeft; K.restrictRight = p.restrictRight; K.skipR1 = p.skipR1; K.skipR2 = p.skipR2;
     K.tpe = (p.trimPairsEvenly && p.mode == BBDUK_MODE_KTRIM_R) ? 1 : 0; K.qskip = p.qSkip; K.speed = p.speed;
+    K.mkf = p.mode == BBDUK_MODE_KFILTER ? p.minKmerFraction : 0.f; K.mcf = p.mode == BBDUK_MODE_KFILTER ? p.minCoveredFraction : 0.f;
     K.numScaffolds = p.numScaffolds;
     K.useShort = (p.mink > 0 && p.mink < p.k) ? 1 : 0;
     K.mask = (2 * p.k > 63) ? ~0ULL : ~(~0ULL << (2 * p.k));

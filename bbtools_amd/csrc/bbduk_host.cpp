@@ -38,6 +38,7 @@ struct Parsed {                      // bbduk/BBDukParser.java fields (subset th
     int minSkip = 1, maxSkip = 1;
     bool trimPairsEvenly = false;    // tpe
     int qSkip = 1, speed = 0;        // :1373-1377
+    float minKmerFraction = 0.f, minCoveredFraction = 0.f;   // :1234-1236
     std::vector<std::string> ref, literal;
     // derived (:130-312)
     int minlen = 0, minlen2 = 0;
@@ -207,6 +208,12 @@ extern "C" int bbduk_host_parse(const char* args, bbduk_host** out, char* errbuf
         else if (a == "skipr2") need_bool(p.skipR2);
         else if (a == "tpe" || a == "trimpairsevenly") need_bool(p.trimPairsEvenly);
         else if (a == "qskip") need_int(p.qSkip);
+        else if (a == "minkmerfraction" || a == "minfraction" || a == "mkf" || a == "mincoveredfraction" || a == "mincovfraction" || a == "mcf") {
+            char* e; float v = strtof(b.c_str(), &e); ok = !b.empty() && !*e;
+            if (ok && v > 1.f) { seterr(a + " must range from 0 to 1; value=" + b); delete h; return BBDUK_ERR_ARG; }    // :284,287
+            if (v < 0.f) v = 0.f;                                                                                      // :283,286
+            if (a == "minkmerfraction" || a == "minfraction" || a == "mkf") p.minKmerFraction = v; else p.minCoveredFraction = v;
+        }
         else if (a == "speed") { need_int(p.speed); if (ok && (p.speed < 0 || p.speed > 16)) { seterr("Speed range is 0 to 16.  Value: " + b); delete h; return BBDUK_ERR_ARG; } }
         else if (a == "maxskip" || a == "maxrskip" || a == "mxs") need_int(p.maxSkip);
         else if (a == "minskip" || a == "minrskip" || a == "mns") need_int(p.minSkip);
@@ -339,6 +346,7 @@ extern "C" int bbduk_host_params(const bbduk_host* h, int32_t device, bbduk_para
     out->restrictLeft = p.restrictLeft; out->restrictRight = p.restrictRight;
     out->skipR1 = p.skipR1; out->skipR2 = p.skipR2;
     out->trimPairsEvenly = p.trimPairsEvenly; out->qSkip = p.qSkip; out->speed = p.speed;
+    out->minKmerFraction = p.minKmerFraction; out->minCoveredFraction = p.minCoveredFraction;
     out->numScaffolds = (int32_t)h->scaffolds.size() + 1;
     out->device = device;
     return BBDUK_OK;

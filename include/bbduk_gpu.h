@@ -90,7 +90,9 @@ typedef struct bbduk_params {
     int32_t trimPairsEvenly;        /* tpe (BBDukProcessorS.java:1021-1031; ktrim=r pairs) */
     int32_t qSkip;                  /* qskip= (0 or 1 = off; BBDukIndexMod.java:494) */
     int32_t speed;                  /* speed= 0..16 (query-side gate, BBDukIndexMod.java:506,562) */
-    int32_t reserved[5];            /* must be zero */
+    float   minKmerFraction;        /* mkf= (kfilter; BBDukProcessorS.java:1055-1062) */
+    float   minCoveredFraction;     /* mcf= (kfilter; :1038-1049, countCoveredBases :1602-1651; out_found = covered bases) */
+    int32_t reserved[3];            /* must be zero */
 } bbduk_params;
 
 typedef struct bbduk_handle bbduk_handle;

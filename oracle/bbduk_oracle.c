@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 #include <pthread.h>
 
 /* ------------------------------------------------------------------------------------------ */
@@ -222,6 +223,7 @@ void bbo_default_args(bbo_args* a) {
     a->minLenFraction = 0.f;  /* :439 */
     a->minSkip = 1; a->maxSkip = 1;
     a->trimPairsEvenly = 0; a->qSkip = 1; a->speed = 0;
+    a->minKmerFraction = 0.f; a->minCoveredFraction = 0.f;
 }
 
 static int imax(int a, int b) { return a > b ? a : b; }
@@ -704,6 +706,51 @@ static int count_set_kmers(const bbo_ctx* c, tcounters* tc, const uint8_t* bases
     return found;
 }
 
+/* stream/Read.java:1673-1683 numValidKmers */
+static int num_valid_kmers(const uint8_t* bases, const int blen, const int k) {
+    int len = 0, counted = 0;
+    for (int i = 0; i < blen; i++) {
+        if (!is_fully_defined(bases[i])) len = 0; else len++;
+        if (len >= k) counted++;
+    }
+    return counted;
+}
+
+/* bbduk/BBDukProcessorS.java:1602-1651 countCoveredBases */
+static int count_covered_bases(const bbo_ctx* c, tcounters* tc, const uint8_t* bases, const int blen, const int pairnum,
+                               const int minCoveredBases, int* idout) {
+    const int k = c->k;
+    *idout = -1;
+    if (blen < k || c->storedKmers < 1) return 0;
+    if ((c->a.skipR1 && pairnum == 0) || (c->a.skipR2 && pairnum == 1)) return 0;
+    int64_t kmer = 0, rkmer = 0;
+    int found = 0, len = 0, lastFound = -1;
+    const int start = (c->a.restrictRight < 1 ? 0 : imax(0, blen - c->a.restrictRight));
+    const int stop  = (c->a.restrictLeft  < 1 ? blen : imin(blen, c->a.restrictLeft));
+    for (int i = start; i < stop; i++) {
+        uint8_t b = bases[i];
+        int64_t x = num0(b), x2 = cnum0(b);
+        kmer = (int64_t)((((uint64_t)kmer << 2) | (uint64_t)x) & (uint64_t)c->mask);
+        rkmer = (int64_t)((((uint64_t)rkmer >> 2) | ((uint64_t)x2 << c->shift2)) & (uint64_t)c->mask);
+        if (c->forbidNs && !is_fully_defined(b)) { len = 0; rkmer = 0; } else { len++; }
+        if (len >= c->minlen2 && i >= c->minlen) {
+            const int id = bbo_get_value(c, kmer, rkmer, c->kmask, i, k, c->qHammingDistance);
+            if (id > 0) {
+                const int extra = imin(k, i - lastFound);
+                found += extra;
+                lastFound = i;
+                if (found >= minCoveredBases) {
+                    tc->scafReads[id]++;
+                    tc->scafBases[id] += blen;
+                    *idout = id;
+                    return found;
+                }
+            }
+        }
+    }
+    return found;
+}
+
 static tcounters main_tc(bbo_ctx* c) { tcounters t; memset(&t, 0, sizeof t); t.scafReads = c->scafReads; t.scafBases = c->scafBases; return t; }
 
 int bbo_ktrim_read(bbo_ctx* c, const uint8_t* bases, int len, int pairnum, int* id0) {
@@ -761,8 +808,30 @@ static void process_pair(const bbo_ctx* c, tcounters* tc, const uint8_t* b1, int
         }
         tc->counters[BBO_BASES_KTRIMMED] += xsum;                                     /* :1028-1029 */
         tc->counters[BBO_READS_KTRIMMED] += rktsum;
+    } else if (doKmerFiltering && c->a.minCoveredFraction > 0) {                      /* :1038-1049 */
+        int id;
+        const int mc1 = (int)ceil((double)(c->a.minCoveredFraction * (float)l1));
+        const int cov1 = count_covered_bases(c, tc, b1, l1, 0, mc1, &id);
+        a[0] = cov1; ids[0] = id;
+        if (cov1 >= mc1) d1 = 1;
+        if (has2) {
+            const int mc2 = (int)ceil((double)(c->a.minCoveredFraction * (float)l2));
+            const int cov2 = count_covered_bases(c, tc, b2, l2, 1, mc2, &id);
+            a[1] = cov2; ids[1] = id;
+            if (cov2 >= mc2) d2 = 1;
+        }
+        if ((c->removePairsIfEitherBad && (d1 || d2)) || (d1 && (!has2 || d2))) {
+            remove = 1;
+            tc->counters[BBO_READS_KFILTERED]++; tc->counters[BBO_BASES_KFILTERED] += initialLength1;
+            if (has2) { tc->counters[BBO_READS_KFILTERED]++; tc->counters[BBO_BASES_KFILTERED] += initialLength2; }
+        }
     } else if (doKmerFiltering) {                                                     /* :1035-1093 */
-        const int maxBadKmersR1 = c->a.maxBadKmers0, maxBadKmersR2 = c->a.maxBadKmers0;   /* minKmerFraction==0 (:1056-1057) */
+        int maxBadKmersR1 = c->a.maxBadKmers0, maxBadKmersR2 = c->a.maxBadKmers0;     /* :1056-1057 */
+        if (c->a.minKmerFraction != 0) {                                              /* :1058-1062 */
+            const int vk1 = num_valid_kmers(b1, l1, c->k), vk2 = has2 ? num_valid_kmers(b2, l2, c->k) : 0;
+            maxBadKmersR1 = imax(c->a.maxBadKmers0, (int)((float)(vk1 - 1) * c->a.minKmerFraction));
+            maxBadKmersR2 = imax(c->a.maxBadKmers0, (int)((float)(vk2 - 1) * c->a.minKmerFraction));
+        }
         int id; const int av = count_set_kmers(c, tc, b1, l1, 0, maxBadKmersR1, &id);
         a[0] = av; ids[0] = id;
         if (av > maxBadKmersR1) d1 = 1;

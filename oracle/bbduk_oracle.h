@@ -48,6 +48,8 @@ typedef struct bbo_args {
     int trimPairsEvenly;/* tpe            (BBDukProcessorS.java:1021-1031) */
     int qSkip;          /* qskip=         (default 1; BBDukIndexMod.java:494) */
     int speed;          /* speed=         (default 0; query-side gate, BBDukIndexMod.java:506,562) */
+    float minKmerFraction;    /* mkf=     (default 0; BBDukProcessorS.java:1055-1062) */
+    float minCoveredFraction; /* mcf=     (default 0; :1038-1049, countCoveredBases :1602-1651) */
 } bbo_args;
 
 #define BBO_NCOUNTERS 16

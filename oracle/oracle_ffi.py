@@ -17,7 +17,8 @@ class BboArgs(C.Structure):
                  "rcomp", "forbidN", "ktrimRight", "ktrimLeft", "maxBadKmers0", "minReadLength")] + \
                [("minLenFraction", C.c_float)] + \
                [(n, C.c_int) for n in ("requireBothBad", "trimPad", "ktrimExclusive", "restrictLeft", "restrictRight",
-                                       "skipR1", "skipR2", "minSkip", "maxSkip", "trimPairsEvenly", "qSkip", "speed")]
+                                       "skipR1", "skipR2", "minSkip", "maxSkip", "trimPairsEvenly", "qSkip", "speed")] + \
+               [("minKmerFraction", C.c_float), ("minCoveredFraction", C.c_float)]
 
 
 def build(force: bool = False) -> str:

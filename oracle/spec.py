@@ -68,6 +68,8 @@ class Args:
     trimPairsEvenly: bool = False   # tpe
     qSkip: int = 1                  # qskip=
     speed: int = 0                  # speed=
+    minKmerFraction: float = 0.0    # mkf=
+    minCoveredFraction: float = 0.0 # mcf=
 
 
 COUNTER_NAMES = ["readsIn", "basesIn", "readsKTrimmed", "basesKTrimmed", "readsKFiltered", "basesKFiltered",
@@ -329,6 +331,33 @@ class Spec:
             found += 1
         return found, -1
 
+    def num_valid_kmers(self, read: bytes, k: int) -> int:
+        """stream/Read.java:1673-1683."""
+        ln = counted = 0
+        for c in read:
+            ln = ln + 1 if defined(c) else 0
+            if ln >= k:
+                counted += 1
+        return counted
+
+    def count_covered_bases(self, read: bytes, pairnum: int, minCovered: int):
+        """Returns (found, id).  bbduk/BBDukProcessorS.java:1602-1651."""
+        a, k, n = self.a, self.k, len(read)
+        if n < k or not self.table:
+            return 0, -1
+        if (a.skipR1 and pairnum == 0) or (a.skipR2 and pairnum == 1):
+            return 0, -1
+        start, stop = self._span(n)
+        found, last = 0, -1
+        for i, vid in self._main_hits(read, start, stop):
+            found += min(k, i - last)
+            last = i
+            if found >= minCovered:
+                self.scafReads[vid] += 1
+                self.scafBases[vid] += n
+                return found, vid
+        return found, -1
+
     # ---------------------------------------------------------------- pair stage
     def process_pair(self, r1: bytes, r2):
         """bbduk/BBDukProcessorS.java:807-818, 948-1093, 1431-1443.  Returns [(a, id, flags), ...] per mate."""
@@ -364,13 +393,32 @@ class Spec:
                 xsum += x
             C[3] += xsum; C[2] += rkt
             res = [(x1, i1)] + ([(x2, i2)] if has2 else [])
-        elif self.table:
-            f1, i1 = self.count_set_kmers(r1, 0, a.maxBadKmers0)
-            d1 = f1 > a.maxBadKmers0
+        elif self.table and a.minCoveredFraction > 0:                                  # :1038-1049
+            import math
+            mc1 = int(math.ceil(float(f32(a.minCoveredFraction) * f32(l1))))
+            f1, i1 = self.count_covered_bases(r1, 0, mc1)
+            d1 = f1 >= mc1
             res = [(f1, i1)]
             if has2:
-                f2, i2 = self.count_set_kmers(r2, 1, a.maxBadKmers0)
-                d2 = f2 > a.maxBadKmers0
+                mc2 = int(math.ceil(float(f32(a.minCoveredFraction) * f32(l2))))
+                f2, i2 = self.count_covered_bases(r2, 1, mc2)
+                d2 = f2 >= mc2
+                res.append((f2, i2))
+            if (self.rieb and (d1 or d2)) or (d1 and (not has2 or d2)):
+                remove = True
+                C[4] += pc; C[5] += l1 + l2
+        elif self.table:
+            mb1 = mb2 = a.maxBadKmers0                                                 # :1055-1062
+            if a.minKmerFraction != 0:
+                vk1, vk2 = self.num_valid_kmers(r1, self.k), (self.num_valid_kmers(r2, self.k) if has2 else 0)
+                mb1 = max(a.maxBadKmers0, int(f32(vk1 - 1) * f32(a.minKmerFraction)))
+                mb2 = max(a.maxBadKmers0, int(f32(vk2 - 1) * f32(a.minKmerFraction)))
+            f1, i1 = self.count_set_kmers(r1, 0, mb1)
+            d1 = f1 > mb1
+            res = [(f1, i1)]
+            if has2:
+                f2, i2 = self.count_set_kmers(r2, 1, mb2)
+                d2 = f2 > mb2
                 res.append((f2, i2))
             if (self.rieb and (d1 or d2)) or (d1 and (not has2 or d2)):
                 remove = True

@@ -110,7 +110,10 @@ FUZZ = [("ktrim=r k=23", dict(k=23, ktrimRight=1)),
         ("ktrim=r k=17 tpe=t rieb=f minlen=30", dict(k=17, ktrimRight=1, trimPairsEvenly=1, requireBothBad=1, minReadLength=30)),
         ("k=21 qskip=3", dict(k=21, qSkip=3)), ("ktrim=r k=14 mink=6 qskip=2", dict(k=14, ktrimRight=1, mink=6, qSkip=2)),
         ("k=25 speed=5 hdist=1", dict(k=25, speed=5, hdist=1)), ("ktrim=l k=15 mink=9 speed=9 qhdist=1", dict(k=15, ktrimLeft=1, mink=9, speed=9, qhdist=1)),
-        ("ktrim=r k=27 speed=12 qskip=2 tpe", dict(k=27, ktrimRight=1, speed=12, qSkip=2, trimPairsEvenly=1))]
+        ("ktrim=r k=27 speed=12 qskip=2 tpe", dict(k=27, ktrimRight=1, speed=12, qSkip=2, trimPairsEvenly=1)),
+        ("k=21 mkf=0.3", dict(k=21, minKmerFraction=0.3)), ("k=13 mkf=0.1 mbk=3 rieb=f forbidn=t", dict(k=13, minKmerFraction=0.1, maxBadKmers0=3, requireBothBad=1, forbidN=1)),
+        ("k=25 mcf=0.4", dict(k=25, minCoveredFraction=0.4)), ("k=15 mcf=0.9 hdist=1 restrictleft=60", dict(k=15, minCoveredFraction=0.9, hdist=1, restrictLeft=60)),
+        ("k=19 mcf=0.05 mkf=0.5 mm=f", dict(k=19, minCoveredFraction=0.05, minKmerFraction=0.5, maskMiddle=0))]
 
 
 @pytest.mark.parametrize("ci", range(len(FUZZ)))
@@ -155,7 +158,7 @@ def test_edge_shapes():
 def test_tile_kernel_fallback_matches_wave_kernel(monkeypatch):
     """The tile-synchronous kernel only runs when a pair exceeds a wave's LDS slice; force it on ordinary reads so
     that both kernels stay interchangeable (same results, same counters as the oracle)."""
-    for cfg in ("c2", "c3", "c1", "c2tpe", "c3q"):
+    for cfg in ("c2", "c3", "c1", "c2tpe", "c3q", "c3mkf", "c3mcf"):
         args, okw, ref = util.CONFIGS[cfg]
         d, o = make_pair(args, okw, ref_fasta=ref)
         kw = dict(contam=B.read_fasta(util.PHIX)[0][1], contam_frac=0.05) if "phix" in args else {}

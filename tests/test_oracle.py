@@ -122,7 +122,9 @@ FUZZ = [dict(k=23, ktrimRight=1), dict(k=23, ktrimRight=1, mink=11, hdist=1), di
         dict(k=14, ktrimRight=1, ktrimExclusive=1, mink=8, minLenFraction=0.9), dict(k=9, hdist=2, maskMiddle=0),
         dict(k=16, ktrimRight=1, skipR2=1), dict(k=10, qhdist=2, maskMiddle=0),
         dict(k=13, ktrimRight=1, mink=7, hdist=1, trimPairsEvenly=1), dict(k=17, ktrimRight=1, trimPairsEvenly=1, requireBothBad=1, minReadLength=30),
-        dict(k=12, qSkip=3), dict(k=14, ktrimRight=1, mink=6, qSkip=2), dict(k=11, speed=5, hdist=1), dict(k=15, ktrimLeft=1, mink=9, speed=9, qhdist=1)]
+        dict(k=12, qSkip=3), dict(k=14, ktrimRight=1, mink=6, qSkip=2), dict(k=11, speed=5, hdist=1), dict(k=15, ktrimLeft=1, mink=9, speed=9, qhdist=1),
+        dict(k=11, minKmerFraction=0.3), dict(k=13, minKmerFraction=0.1, maxBadKmers0=3, requireBothBad=1, forbidN=1), dict(k=12, minCoveredFraction=0.4),
+        dict(k=15, minCoveredFraction=0.9, hdist=1, restrictLeft=60), dict(k=9, minCoveredFraction=0.05, minKmerFraction=0.5, maskMiddle=0)]
 BOOLS = ("maskMiddle", "rcomp", "forbidN", "ktrimRight", "ktrimLeft", "requireBothBad", "ktrimExclusive", "skipR1", "skipR2", "trimPairsEvenly")
 
 

@@ -19,6 +19,8 @@ CONFIGS = {
     "c5": ("ktrim=r k=23 hdist=1 ref=adapters", dict(k=23, hdist=1, ktrimRight=1), ADAPTERS),
     "c2tpe": ("ktrim=r k=23 mink=11 hdist=1 tpe ref=adapters", dict(k=23, mink=11, hdist=1, ktrimRight=1, trimPairsEvenly=1), ADAPTERS),
     "c3q": ("k=31 hdist=1 qskip=2 speed=3 ref=phix", dict(k=31, hdist=1, qSkip=2, speed=3), PHIX),
+    "c3mkf": ("k=31 hdist=1 mkf=0.2 ref=phix", dict(k=31, hdist=1, minKmerFraction=0.2), PHIX),
+    "c3mcf": ("k=31 hdist=1 mcf=0.5 ref=phix", dict(k=31, hdist=1, minCoveredFraction=0.5), PHIX),
 }
 
 
