@@ -41,9 +41,9 @@ static_assert(sizeof(bbduk_synth_params) == 80, "bbduk_synth_params layout is pa
 #define BIGLOC          999999999
 
 // Deletion experiments (profiles/ab.sh): a build with -DBBDUK_TIMING_SWITCHES honours BBDUK_DBG=<n> and skips one
-// stage of the scan (results become wrong).  Production builds compile the switches out.
+// or more stages of the scan (results become wrong).  Production builds compile the switches out.
 #ifdef BBDUK_TIMING_SWITCHES
-#define TSW(P, n) ((P).dbg == (n))
+#define TSW(P, n) ((((P).dbg) >> (n)) & 1)      /* BBDUK_DBG is a bit mask: bit n deletes stage n */
 #else
 #define TSW(P, n) false
 #endif
@@ -296,7 +296,18 @@ __device__ __forceinline__ int trim_by_amount(int len, int left, int right, int 
 __device__ __forceinline__ int imid(int lo, int x, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }   // value known wave-uniform -> SGPR
 
-struct Planes { const uint32_t* fwd; const uint32_t* cmp; const uint32_t* nm; const uint32_t* filt; int T; };
+// fwdBits / cmpBits = 8 x the LDS byte address of the plane's symbol 0: "bit address" arithmetic lets a lane get from
+// a symbol index to (word address, shift) in three instructions (cut64_lds).
+struct Planes { const uint32_t* fwd; const uint32_t* cmp; const uint32_t* nm; const uint32_t* filt; int T; uint32_t fwdBits, cmpBits; };
+typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+__device__ __forceinline__ uint32_t lds_word_at(uint32_t byteAddr) { return *reinterpret_cast<lds_cu32*>(byteAddr); }
+__device__ __forceinline__ uint32_t lds_bits_of(const uint32_t* p) { return 8u * (uint32_t)(size_t)(lds_cu32*)p; }
+// 32 symbols of a 2-bit stream from LDS bit address tbits (shifts use tbits[4:0] only)
+__device__ __forceinline__ uint64_t cut64_lds(const uint32_t tbits) {
+    const uint32_t a = (tbits >> 3) & ~3u;
+    const uint32_t w0 = lds_word_at(a), w1 = lds_word_at(a + 4u), w2 = lds_word_at(a + 8u);
+    return ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, tbits) << 32) | __builtin_amdgcn_alignbit(w1, w0, tbits);
+}
 
 // Wave-uniform state of one read's scan (all fields live in SGPRs).  Only raw scan facts are kept here; the
 // trim / id arithmetic happens afterwards in finish_read(), which the wave kernel runs data-parallel over the
@@ -418,8 +429,8 @@ __device__ __forceinline__ void windows2(const KParams& P, const Planes& Q, cons
                                          uint64_t* kmer, uint64_t* rk, bool* ok) {
     const int k = P.k;
     if (W.full) {
-        const uint64_t wf = extract2raw(Q.fwd, Q.T - 1 - W.base0 - (i + 1));   // base i+1 in bits 0-1, base i-k+1 on top
-        const uint64_t wc = extract2raw(Q.cmp, W.base0 - k + 1 + i);           // base i-k+1 in bits 0-1, base i+1 on top
+        const uint64_t wf = cut64_lds(Q.fwdBits + 2u * (uint32_t)(Q.T - 1 - W.base0 - (i + 1)));   // base i+1 in bits 0-1, base i-k+1 on top
+        const uint64_t wc = cut64_lds(Q.cmpBits + 2u * (uint32_t)(W.base0 - k + 1 + i));           // base i-k+1 in bits 0-1, base i+1 on top
         if constexpr (!GENERAL) {                                // specialised kernels run with k >= 16: the mask's low word is all ones
             const uint64_t mh = P.mask | 0xFFFFFFFFULL;
             kmer[1] = wf & mh; kmer[0] = (wf >> 2) & mh;
@@ -540,8 +551,6 @@ __device__ __forceinline__ void lookup4(const KParams& P, const uint32_t* s_filt
 struct Cand4 { uint64_t key[4], t[4]; uint32_t ma[4], mb[4], pv[4]; };
 
 // FILT0: the filter starts at LDS address 0 (wave kernel), so a word's LDS address is its byte offset
-typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
-__device__ __forceinline__ uint32_t lds_word_at(uint32_t byteAddr) { return *reinterpret_cast<lds_cu32*>(byteAddr); }
 template <bool GENERAL, bool NOMM, bool FILT0>
 __device__ __forceinline__ uint64_t cand_probe4(const KParams& P, const uint32_t* s_filt, const uint64_t* kmer, const uint64_t* rk, Cand4& C) {
     const uint32_t mmLo = (uint32_t)P.middleMask, mmHi = (uint32_t)(P.middleMask >> 32);
@@ -586,7 +595,8 @@ __device__ __forceinline__ uint64_t cand_probe4(const KParams& P, const uint32_t
         return a;
     }
 #pragma unroll
-    for (int s = 0; s < 4; s++) C.t[s] = C.pv[s] ? P.tags[bucket_of(C.mb[s], P.bucketBits)] : 0ULL;   // four gathers in flight
+    for (int s = 0; s < 4; s++) C.t[s] = P.tags[C.pv[s] ? bucket_of(C.mb[s], P.bucketBits) : 0u];   // four gathers in flight; lanes the
+                                                                                              // filter rejected all read tags[0] (one line)
     if (TSW(P, 6)) {                                              // experiment: gathers issued, matches ignored
         uint64_t a = 0;
 #pragma unroll
@@ -1012,6 +1022,7 @@ void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
 
             // ---- scan: one wave per unit of two consecutive reads (a pair when paired)
             Planes Q; Q.fwd = s_fwd + PLANE_PAD; Q.cmp = s_cmp + PLANE_PAD; Q.nm = s_nm; Q.filt = s_filt; Q.T = nchunks * 16;
+            Q.fwdBits = lds_bits_of(Q.fwd); Q.cmpBits = lds_bits_of(Q.cmp);
             const int nunits = (e - s + 1) >> 1;
             const int a0lo = (int)(A0 - s_off[0]);                  // tile-relative origin of the planes (fits int)
             for (int u = wave; u < nunits; u += NWAVES) {
@@ -1190,6 +1201,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
             Planes Q; Q.fwd = wf + PLANE_PAD; Q.cmp = wc + PLANE_PAD; Q.nm = wn; Q.filt = s_filt; Q.T = nchunks * 16;
+            Q.fwdBits = lds_bits_of(Q.fwd); Q.cmpBits = lds_bits_of(Q.cmp);
             const int origin = lead - rel_s;                        // plane index of a base = origin + (its offset in the mini-tile)
             uint64_t nMask = 0;                                     // reads of [s,e) with an undefined base inside their span
             if (FORBIDN && P.forbidNs) {                            // lane j looks at read j's words of the undefined-plane

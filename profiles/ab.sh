@@ -9,5 +9,5 @@ for rep in 1 2; do
   echo -n "new "; $P 2>/dev/null | python -c "$J"
 done
 if [ -f bbtools_amd/ab_tsw.so ]; then
-  for d in 0 2 1 6 3 4 7; do echo -n "tsw dbg$d "; BBDUK_LIB_PATH=$PWD/bbtools_amd/ab_tsw.so BBDUK_DBG=$d $P 2>/dev/null | python -c "$J"; done
+  for d in 0 4 2 64 8 16 128 184; do echo -n "tsw mask$d "; BBDUK_LIB_PATH=$PWD/bbtools_amd/ab_tsw.so BBDUK_DBG=$d $P 2>/dev/null | python -c "$J"; done
 fi
