@@ -548,7 +548,7 @@ __device__ __forceinline__ void lookup4(const KParams& P, const uint32_t* s_filt
 // cand_resolve4 runs only when that union is non-zero: ref = slot (4*bucket+way) of the first fingerprint match,
 // -3-id for a hit already verified (overflowed home bucket without a match: the chain is walked at once), -1 if
 // certainly absent.  C.key = the lanes' key VALUES (no length bit).  NOMM: the middle mask is known to be off.
-struct Cand4 { uint64_t key[4], t[4]; uint32_t ma[4], mb[4], pv[4]; };
+struct Cand4 { uint64_t key[4], t[4]; uint32_t ma[4], mb[4], pv[4]; uint64_t hm[4]; };   // hm: per-slot wave masks of flagged lanes
 
 // FILT0: the filter starts at LDS address 0 (wave kernel), so a word's LDS address is its byte offset
 template <bool GENERAL, bool NOMM, bool FILT0>
@@ -573,7 +573,7 @@ __device__ __forceinline__ uint64_t cand_probe4(const KParams& P, const uint32_t
     if (TSW(P, 2)) {                                              // experiment: keys and hashes only
         uint64_t a = 0;
 #pragma unroll
-        for (int s = 0; s < 4; s++) { C.pv[s] = 0; C.t[s] = 0; a |= __ballot(C.ma[s] == 0x12345u && C.mb[s] == 0x54321u); }
+        for (int s = 0; s < 4; s++) { C.pv[s] = 0; C.t[s] = 0; C.hm[s] = __ballot(C.ma[s] == 0x12345u && C.mb[s] == 0x54321u); a |= C.hm[s]; }
         return a;
     }
     if (P.ldsBits) {                                              // four presence bits, read together
@@ -591,7 +591,7 @@ __device__ __forceinline__ uint64_t cand_probe4(const KParams& P, const uint32_t
     if (TSW(P, 1)) {                                              // experiment: filter but no gathers
         uint64_t a = 0;
 #pragma unroll
-        for (int s = 0; s < 4; s++) { a |= __ballot(C.pv[s] && C.ma[s] == 0x12345u); C.pv[s] = 0; C.t[s] = 0; }
+        for (int s = 0; s < 4; s++) { C.hm[s] = __ballot(C.pv[s] && C.ma[s] == 0x12345u); a |= C.hm[s]; C.pv[s] = 0; C.t[s] = 0; }
         return a;
     }
 #pragma unroll
@@ -600,7 +600,7 @@ __device__ __forceinline__ uint64_t cand_probe4(const KParams& P, const uint32_t
     if (TSW(P, 6)) {                                              // experiment: gathers issued, matches ignored
         uint64_t a = 0;
 #pragma unroll
-        for (int s = 0; s < 4; s++) { a |= __ballot(C.t[s] == 0x123456789ULL); C.pv[s] = 0; }
+        for (int s = 0; s < 4; s++) { C.hm[s] = __ballot(C.t[s] == 0x123456789ULL); a |= C.hm[s]; C.pv[s] = 0; }
         return a;
     }
     uint64_t any = 0;
@@ -612,7 +612,8 @@ __device__ __forceinline__ uint64_t cand_probe4(const KParams& P, const uint32_t
         // the chain walk, which masks the flag.
         const uint64_t b = __ballot((tlo & 0xFFFFu) == fp) | __ballot((tlo >> 16) == fp) | __ballot((thi & 0xFFFFu) == fp) |
                            __ballot((thi >> 16) == fp) | __ballot((int32_t)thi < 0);
-        any |= b & __ballot(C.pv[s] != 0u);
+        C.hm[s] = b & __ballot(C.pv[s] != 0u);
+        any |= C.hm[s];
     }
     return any;
 }
@@ -621,6 +622,7 @@ __device__ __forceinline__ void cand_resolve4(const KParams& P, const Cand4& C, 
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         ref[s] = -1;
+        if (C.hm[s] == 0ULL) continue;                            // nothing flagged in this slot (wave-uniform)
         const uint32_t fp = tag_of(C.ma[s]);
         const uint64_t cand = zero16((C.t[s] & TAG_FPS) ^ ((uint64_t)fp * 0x0001000100010001ULL));
         if (C.pv[s] && (cand != 0ULL || (C.t[s] & TAG_CONT))) {
