@@ -685,6 +685,26 @@ __device__ __forceinline__ bool fold_hits(const KParams& P, ReadScan& R, int& fo
     }
 }
 
+// Short k-mer lookup of the specialised wave kernel (no middle mask, no query expansion; filter at LDS address 0), in the
+// style of cand_probe4: straight-line probe for every lane, one scalar test, and only flagged lanes check keys.
+// Returns the id (>0) or -1.
+__device__ __forceinline__ int short_probe(const KParams& P, const uint64_t kmer, const uint64_t rk, const uint64_t lengthMask, const bool act) {
+    const uint64_t mx = kmer > rk ? kmer : rk;
+    const uint32_t ma = mix_a(mx), mb = mix_b(mx);
+    uint32_t pv = P.ldsBits ? __builtin_amdgcn_ubfe(lds_word_at(filt_byte(ma, P.ldsBits)), ma, 1u) : 1u;
+    pv = act ? pv : 0u;
+    const uint64_t t = P.tags[pv ? bucket_of(mb, P.bucketBits) : 0u];
+    const uint32_t fp = tag_of(ma), tlo = (uint32_t)t, thi = (uint32_t)(t >> 32);
+    const uint64_t b = __ballot((tlo & 0xFFFFu) == fp) | __ballot((tlo >> 16) == fp) | __ballot((thi & 0xFFFFu) == fp) |
+                       __ballot((thi >> 16) == fp) | __ballot((int32_t)thi < 0);
+    int sref = -1;
+    if ((b & __ballot(pv != 0u)) != 0ULL) {                       // rare
+        const uint64_t cand = zero16((t & TAG_FPS) ^ ((uint64_t)fp * 0x0001000100010001ULL));
+        if (pv && (cand != 0ULL || (t & TAG_CONT))) sref = table_find_t(P, mx | lengthMask, ma, mb, t);
+    }
+    return sref;
+}
+
 // kfilter thresholds that depend on the read (general kernels).  numValidKmers (stream/Read.java:1673-1683), wave-cooperative:
 // one lane per k-mer end position, valid = no undefined base in the window.
 __device__ __forceinline__ int valid_kmers_wave(const Planes& Q, const int base0, const int L, const int k, const int lane) {
@@ -1322,6 +1342,37 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                             const int jb = __shfl(vBase0, j), jstart = __shfl(vStart, j), jstop = __shfl(vStop, j);
                             const int Ls = P.mink + st;
                             uint64_t kmer = 0, rk = 0; bool act; int Lc;
+                            if constexpr (!GENERAL) {                  // unpredicated form: inactive lanes cut a 1-base window of read j
+                                int sref;
+                                if (MODE == BBDUK_MODE_KTRIM_L) {
+                                    const int Lmax = min(P.k, jstop) - jstart;
+                                    act = have && Ls <= Lmax; Lc = act ? Ls : 1;
+                                    const uint64_t lm = 1ULL << (2 * Lc);
+                                    kmer = cut64_lds(Q.fwdBits + 2u * (uint32_t)(Q.T - 1 - (jb + jstart + Lc - 1))) & (lm - 1ULL);
+                                    rk   = cut64_lds(Q.cmpBits + 2u * (uint32_t)(jb + jstart)) & (lm - 1ULL);
+                                    sref = short_probe(P, kmer, rk, lm, act);
+                                } else {
+                                    const int Lmax = (jstop >= P.k ? P.k - 1 : jstop);
+                                    act = have && Ls <= Lmax; Lc = act ? Ls : 1;
+                                    const uint64_t lm = 1ULL << (2 * Lc);
+                                    kmer = cut64_lds(Q.fwdBits + 2u * (uint32_t)(Q.T - 1 - (jb + jstop - 1))) & (lm - 1ULL);
+                                    rk   = cut64_lds(Q.cmpBits + 2u * (uint32_t)(jb + max(jstop - Lc, 0))) & (lm - 1ULL);
+                                    sref = short_probe(P, kmer, rk, lm, act);
+                                }
+                                uint64_t hm = __ballot(sref != -1);
+                                while (hm) {                            // rare: some read has a short hit
+                                    const int l0 = __ffsll((unsigned long long)hm) - 1;
+                                    const int slot = l0 / lens;
+                                    const uint64_t seg = (hm >> (slot * lens)) & ((1ULL << lens) - 1ULL);
+                                    const int fl = __ffsll((unsigned long long)seg) - 1, ll = 63 - __clzll((long long)seg);
+                                    const int jr = sel[pb + slot];
+                                    const int r1 = __builtin_amdgcn_readlane(sref, slot * lens + fl);   // first hit in scan order = shortest
+                                    const int jru = __builtin_amdgcn_readfirstlane(jr);
+                                    if (lane == jru) { vRef = r1; vFound = __popcll(seg); vSFl = fl; vSLl = ll; }
+                                    hm &= ~(((1ULL << lens) - 1ULL) << (slot * lens));
+                                }
+                                continue;
+                            }
                             if (MODE == BBDUK_MODE_KTRIM_L) {
                                 const int Lmax = min(P.k, jstop) - jstart;         // lengths 1..Lmax, i = start+Ls-1
                                 act = have && Ls <= Lmax;
