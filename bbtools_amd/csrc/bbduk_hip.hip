@@ -1104,7 +1104,7 @@ void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
 // which is what hides the latencies; with the tile-synchronous kernel above 52 % of all wave cycles were
 // waits, much of it at barriers behind the slowest wave.  Requires every unit (pair) to fit WCAP_BASES;
 // a pre-pass (bbduk_span_kernel) raises *slowFlag otherwise and the tile kernel takes the batch instead.
-#define MT_READS     12                            // reads per wave mini-tile (even: whole pairs)
+#define MT_READS     16                            // reads per wave mini-tile (even: whole pairs)
 #define WCAP_BASES   2560                          // per-wave plane capacity in bases
 #define WCAP_CHUNKS  (WCAP_BASES / 16)
 #define WPLANE_WORDS (PLANE_PAD + WCAP_CHUNKS + PLANE_PAD)
@@ -1339,7 +1339,11 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                             const int q = pb + sslot;
                             const bool have = sslot < rpp && q < nneed;
                             const int j = have ? sel[q] : 0;   // the read this worker lane serves
-                            const int jb = __shfl(vBase0, j), jstart = __shfl(vStart, j), jstop = __shfl(vStop, j);
+                            int jb, jstart, jstop;
+                            if constexpr (!GENERAL) {                   // start is 0 here: one shuffle carries base0 (< 2^16) and stop
+                                const int pk = __shfl(vBase0 | (vStop << 16), j);
+                                jb = pk & 0xFFFF; jstart = 0; jstop = (int)((unsigned)pk >> 16);
+                            } else { jb = __shfl(vBase0, j); jstart = __shfl(vStart, j); jstop = __shfl(vStop, j); }
                             const int Ls = P.mink + st;
                             uint64_t kmer = 0, rk = 0; bool act; int Lc;
                             if constexpr (!GENERAL) {                  // unpredicated form: inactive lanes cut a 1-base window of read j
