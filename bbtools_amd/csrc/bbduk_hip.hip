@@ -1104,12 +1104,13 @@ void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
 // which is what hides the latencies; with the tile-synchronous kernel above 52 % of all wave cycles were
 // waits, much of it at barriers behind the slowest wave.  Requires every unit (pair) to fit WCAP_BASES;
 // a pre-pass (bbduk_span_kernel) raises *slowFlag otherwise and the tile kernel takes the batch instead.
-#define MT_READS     16                            // reads per wave mini-tile (even: whole pairs)
+#define MT_READS     62                            // reads per wave mini-tile (even: whole pairs)
 #define WCAP_BASES   2560                          // per-wave plane capacity in bases
 #define WCAP_CHUNKS  (WCAP_BASES / 16)
 #define WPLANE_WORDS (PLANE_PAD + WCAP_CHUNKS + PLANE_PAD)
 #define WNM_WORDS    (WCAP_CHUNKS / 2 + 4)
-#define WAVE_LDS_BYTES ((2 * NWAVES * WPLANE_WORDS + NWAVES * WNM_WORDS) * 4 + 6 * 8 + NWAVES * MT_READS * 4)   // behind the filter
+#define SEL_BYTES    ((MT_READS + 3) & ~3)
+#define WAVE_LDS_BYTES ((2 * NWAVES * WPLANE_WORDS + NWAVES * WNM_WORDS) * 4 + 6 * 8 + NWAVES * SEL_BYTES)   // behind the filter
 #define WUNIT_MAX    (WCAP_BASES - 48)             // longest unit (pair) the wave kernel accepts
 
 // sum of v over the lanes of a wave, returned wave-uniform
@@ -1133,7 +1134,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
     uint32_t* const s_wcAll = s_wfAll + NWAVES * WPLANE_WORDS;
     uint32_t* const s_wnAll = s_wcAll + NWAVES * WPLANE_WORDS;
     unsigned long long* const s_acc = reinterpret_cast<unsigned long long*>(s_wnAll + NWAVES * WNM_WORDS);   // rkt, basesKTrimmed, readsOutm, basesOutm, readsIn, basesIn
-    int* const s_selAll = reinterpret_cast<int*>(s_acc + 6);      // short-scan: compacted list of participating reads
+    uint8_t* const s_selAll = reinterpret_cast<uint8_t*>(s_acc + 6);   // short-scan: compacted list of participating reads (lane ids)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     if (tid < 6) s_acc[tid] = 0;
@@ -1153,7 +1154,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
 
     uint32_t* const wf = s_wfAll + wave * WPLANE_WORDS; uint32_t* const wc = s_wcAll + wave * WPLANE_WORDS;
     uint32_t* const wn = s_wnAll + wave * WNM_WORDS;
-    int* const sel = s_selAll + wave * MT_READS;
+    uint8_t* const sel = s_selAll + wave * SEL_BYTES;
     // scaffold-counter cache: lane w (< SCAF_LANES) owns one (id, reads, bases) entry in registers; a hit is one ballot
     // plus a predicated add, a miss evicts round-robin with two atomics.  The adapter library has ~6 frequent ids:
     // with the 4-entry scalar cache 4-15 % of the hit reads still caused evictions onto a dozen hot addresses.
@@ -1329,7 +1330,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                     uint64_t needM = __ballot(need);
                     if (needM) {
                         const int rank = __popcll(needM & ((1ULL << lane) - 1ULL));
-                        if (need) sel[rank] = lane;            // compact list of the reads that take part
+                        if (need) sel[rank] = (uint8_t)lane;   // compact list of the reads that take part
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
