@@ -1,20 +1,23 @@
 // bbduk_hip.hip -- MI355X (gfx950) kernels + the C ABI of include/bbduk_gpu.h.
 //
 // Hot path: per-read 2-bit k-mer encode with reverse-complement
-// canonicalisation, optional query-side Hamming expansion, open-addressed lookup into an HBM-resident
-// image of the reference k-mer map, first-hit / hit-count reduction with wave ballots, trim / filter
-// decision, pair logic and counters.  Integer work only (no MFMA): the bounds are the HBM read stream of
-// the bases and the gather rate into the table.
+// canonicalisation, optional query-side Hamming expansion, lookup into a device image of the reference
+// k-mer map, first-hit / hit-count reduction with wave ballots, trim / filter decision, pair logic and
+// counters.  Integer work only (no MFMA).  With a cache-resident map the kernel is bound by VALU issue
+// (~130 VALU wave-instructions per read, every one ~4.8 SIMD cycles on gfx950), so the code
+// below is written to keep instructions -- vector AND scalar -- out of the per-position path.
 //
 // Design (not a translation of the Java loops):
-//   * a tile of reads is contiguous in the concatenated `bases` buffer, so it is staged with 16-byte
-//     coalesced loads and converted on the fly to three bit-planes in LDS (2-bit forward codes in
-//     *reversed* base order, 2-bit complement codes, 1-bit undefined mask);
-//   * the scan is position-parallel: one wave64 lane per k-mer end position; a lane cuts its k-mer and
-//     its reverse complement out of the planes with two funnel shifts each (closed form SURVEY A.12)
-//     instead of rolling them along the read;
-//   * hits are reduced with __ballot / ffs / popcount; everything per read is wave-uniform scalar work;
-//   * results are staged in LDS and written back coalesced; counters are reduced per block.
+//   * reads are contiguous in the concatenated `bases` buffer, so a wave stages its reads with 16-byte
+//     coalesced loads and converts them on the fly to three bit-planes in its own slice of LDS (2-bit
+//     forward codes in *reversed* base order, 2-bit complement codes, 1-bit undefined mask);
+//   * the scan is position-parallel: a lane serves two adjacent k-mer end positions and cuts both k-mers
+//     and their reverse complements out of the planes with two funnel shifts per plane (closed form,
+//     SURVEY A.12) instead of rolling them along the read;
+//   * lookups cascade LDS presence bit -> 8-byte fingerprint gather -> key record, and the hot block is
+//     predicate-free: compares write wave masks, the scalar unit combines them, one branch per 256 positions;
+//   * everything per read (bookkeeping, trim/filter decision, outputs, counters) is data-parallel, one lane
+//     per read of a 62-read mini-tile.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
