@@ -223,7 +223,7 @@ void bbo_default_args(bbo_args* a) {
     a->minLenFraction = 0.f;  /* :439 */
     a->minSkip = 1; a->maxSkip = 1;
     a->trimPairsEvenly = 0; a->qSkip = 1; a->speed = 0;
-    a->minKmerFraction = 0.f; a->minCoveredFraction = 0.f;
+    a->minKmerFraction = 0.f; a->minCoveredFraction = 0.f; a->ktrimN = 0;
 }
 
 static int imax(int a, int b) { return a > b ? a : b; }
@@ -276,8 +276,8 @@ bbo_ctx* bbo_create(const bbo_args* a) {
     if (c->mink > 0 && c->mink < c->k) c->useShortKmers = 1;
     if (c->useShortKmers && c->maskMiddle) { c->maskMiddle = 0; c->midMaskLen = 0; }
     /* :298 */
-    c->kfilter = !(a->ktrimRight || a->ktrimLeft);
-    if (c->useShortKmers && !(a->ktrimRight || a->ktrimLeft)) { free(c); return NULL; }   /* :301 assert */
+    c->kfilter = !(a->ktrimRight || a->ktrimLeft || a->ktrimN);
+    if (c->useShortKmers && !(a->ktrimRight || a->ktrimLeft || a->ktrimN)) { free(c); return NULL; }   /* :301 assert */
     /* :303-312 */
     if (c->maskMiddle) {
         if (!(c->k > c->midMaskLen + 1)) { free(c); return NULL; }
@@ -706,6 +706,100 @@ static int count_set_kmers(const bbo_ctx* c, tcounters* tc, const uint8_t* bases
     return found;
 }
 
+/* java.util.BitSet.set(from,to) on a word array */
+static void bs_set(uint64_t* bs, int from, int to) {
+    for (int i = from; i < to; i++) bs[i >> 6] |= 1ULL << (i & 63);
+}
+
+/* bbduk/BBDukProcessorS.java:2149-2323 kmask(Read), kmaskFullyCovered=false.  Returns bs.cardinality(); the masked
+ * positions < blen are OR-ed into gmask at bit offset gbase (atomically: neighbouring reads share words). */
+static int kmask_read(const bbo_ctx* c, tcounters* tc, const uint8_t* bases, const int blen, const int pairnum, int* id0out,
+                      uint32_t* gmask, const int64_t gbase) {
+    const int k = c->k;
+    *id0out = -1;
+    if (blen < imax(1, (c->useShortKmers ? imin(k, c->mink) : k)) || c->storedKmers < 1) return 0;
+    if ((c->a.skipR1 && pairnum == 0) || (c->a.skipR2 && pairnum == 1)) return 0;
+    if (blen < k) return 0;                                                          /* :2154 */
+    int64_t kmer = 0, rkmer = 0;
+    int found = 0, len = 0, id0 = -1;
+    const int trimPad = c->a.trimPad;
+    const int nbits = blen + (trimPad > 0 ? trimPad : 0) + 1;
+    uint64_t* bs = (uint64_t*)calloc((size_t)(nbits + 64) / 64 + 1, sizeof(uint64_t));
+    const int minus = k - 1 - trimPad, plus = trimPad + 1;
+    const int start = (c->a.restrictRight < 1 ? 0 : imax(0, blen - c->a.restrictRight));
+    const int stop  = (c->a.restrictLeft  < 1 ? blen : imin(blen, c->a.restrictLeft));
+    for (int i = start; i < stop; i++) {                                             /* :2171-2200 */
+        uint8_t b = bases[i];
+        int64_t x = num0(b), x2 = cnum0(b);
+        kmer = (int64_t)((((uint64_t)kmer << 2) | (uint64_t)x) & (uint64_t)c->mask);
+        rkmer = (int64_t)((((uint64_t)rkmer >> 2) | ((uint64_t)x2 << c->shift2)) & (uint64_t)c->mask);
+        if (c->forbidNs && !is_fully_defined(b)) { len = 0; rkmer = 0; } else { len++; }
+        if (i >= c->minlen) {
+            int id;
+            if (len >= c->minlen2) id = bbo_get_value(c, kmer, rkmer, c->kmask, i, k, c->qHammingDistance);
+            else id = -1;
+            if (id > 0) {
+                if (id0 < 0) id0 = id;
+                bs_set(bs, imax(0, i - minus), i + plus);
+                found++;
+            }
+        }
+    }
+    if (c->useShortKmers) {                                                          /* :2203-2291: always, both sides */
+        {
+            kmer = 0; rkmer = 0; len = 0;
+            const int lim = imin(k, stop);
+            for (int i = start; i < lim; i++) {
+                uint8_t b = bases[i];
+                int64_t x = num0(b), x2 = cnum0(b);
+                kmer = (int64_t)((((uint64_t)kmer << 2) | (uint64_t)x) & (uint64_t)c->mask);
+                rkmer = rkmer | (int64_t)((uint64_t)x2 << (2 * len));
+                len++;
+                if (len >= c->mink) {
+                    const int id = bbo_get_value(c, kmer, rkmer, c->lengthMasks[len], i, len, c->qHammingDistance2);
+                    if (id > 0) {
+                        if (id0 < 0) id0 = id;
+                        bs_set(bs, 0, imin(blen, i + trimPad + 1));
+                        found++;
+                    }
+                }
+            }
+        }
+        {
+            kmer = 0; rkmer = 0; len = 0;
+            const int lim = imax(-1, stop - k);
+            for (int i = stop - 1; i > lim; i--) {
+                uint8_t b = bases[i];
+                int64_t x = num0(b), x2 = cnum0(b);
+                kmer = kmer | (int64_t)((uint64_t)x << (2 * len));
+                rkmer = (int64_t)((((uint64_t)rkmer << 2) | (uint64_t)x2) & (uint64_t)c->mask);
+                len++;
+                if (len >= c->mink) {
+                    const int id = bbo_get_value(c, kmer, rkmer, c->lengthMasks[len], i, len, c->qHammingDistance2);
+                    if (id > 0) {
+                        if (id0 < 0) id0 = id;
+                        bs_set(bs, imax(0, i - trimPad), blen);
+                        found++;
+                    }
+                }
+            }
+        }
+    }
+    if (found == 0) { free(bs); return 0; }
+    tc->scafReads[id0]++;
+    tc->scafBases[id0] += blen;
+    *id0out = id0;
+    int cardinality = 0;
+    for (int w = 0; w <= (nbits + 63) / 64; w++) cardinality += __builtin_popcountll(bs[w]);
+    if (gmask) {
+        for (int i = 0; i < blen; i++) {                                             /* :2309-2320: the bases the caller replaces */
+            if ((bs[i >> 6] >> (i & 63)) & 1ULL) __atomic_fetch_or(&gmask[(gbase + i) >> 5], 1u << ((gbase + i) & 31), __ATOMIC_RELAXED);
+        }
+    }
+    free(bs);
+    return cardinality;
+}
+
 /* stream/Read.java:1673-1683 numValidKmers */
 static int num_valid_kmers(const uint8_t* bases, const int blen, const int k) {
     int len = 0, counted = 0;
@@ -766,7 +860,7 @@ int bbo_count_set_kmers(bbo_ctx* c, const uint8_t* bases, int len, int pairnum, 
  * Everything before the k-mer stage (junk/chastity/GC/force-trim...) and after it (tbo/qtrim/...) is off
  * in every BASELINE config and stays in the Java host. */
 static void process_pair(const bbo_ctx* c, tcounters* tc, const uint8_t* b1, int l1, const uint8_t* b2, int l2, int has2,
-                         int32_t* a, int32_t* ids, uint8_t* fl) {
+                         int32_t* a, int32_t* ids, uint8_t* fl, uint32_t* gmask, int64_t g1, int64_t g2) {
     const int initialLength1 = l1, initialLength2 = has2 ? l2 : 0;
     const int pairCount = has2 ? 2 : 1;
     const int minlen1 = (int)((float)initialLength1 * c->a.minLenFraction > (float)c->a.minReadLength ?
@@ -777,10 +871,26 @@ static void process_pair(const bbo_ctx* c, tcounters* tc, const uint8_t* b1, int
     tc->counters[BBO_BASES_IN] += initialLength1 + initialLength2;
     int d1 = 0, d2 = 0, remove = 0;
     int newLen1 = l1, newLen2 = initialLength2;
-    const int doKmerTrimming = c->storedKmers > 0 && (c->a.ktrimLeft || c->a.ktrimRight);   /* :772 */
+    const int ktrimN = c->a.ktrimN && !(c->a.ktrimLeft || c->a.ktrimRight);
+    const int doKmerTrimming = c->storedKmers > 0 && (c->a.ktrimLeft || c->a.ktrimRight || ktrimN);   /* :772 */
     const int doKmerFiltering = c->storedKmers > 0 && !doKmerTrimming;                      /* :773 */
     a[0] = 0; ids[0] = -1; if (has2) { a[1] = 0; ids[1] = -1; }
-    if (doKmerTrimming) {                                                             /* :948-1033 */
+    if (doKmerTrimming && ktrimN) {                                                   /* :984-998, 1009-1016, 1028-1029 */
+        int xsum = 0, rktsum = 0, id0;
+        int x = kmask_read(c, tc, b1, l1, 0, &id0, gmask, g1);
+        xsum += x; rktsum += (x > 0 ? 1 : 0);
+        if (l1 < minlen1) d1 = 1;
+        a[0] = x; ids[0] = id0;
+        if (has2) {
+            x = kmask_read(c, tc, b2, l2, 1, &id0, gmask, g2);
+            xsum += x; rktsum += (x > 0 ? 1 : 0);
+            if (l2 < minlen2) d2 = 1;
+            a[1] = x; ids[1] = id0;
+        }
+        if ((c->removePairsIfEitherBad && (d1 || d2)) || (d1 && (!has2 || d2))) remove = 1;   /* ktrimN: xsum/rktsum unchanged (:1011) */
+        tc->counters[BBO_BASES_KTRIMMED] += xsum;
+        tc->counters[BBO_READS_KTRIMMED] += rktsum;
+    } else if (doKmerTrimming) {                                                      /* :948-1033 */
         int rlen1 = 0, rlen2 = 0, xsum = 0, rktsum = 0;
         {
             int id0; int x = ktrim_read(c, tc, b1, l1, 0, &id0, &newLen1);
@@ -859,7 +969,7 @@ static void process_pair(const bbo_ctx* c, tcounters* tc, const uint8_t* b1, int
 
 typedef struct {
     const bbo_ctx* c; const uint8_t* bases; const int64_t* offsets; int64_t n; int paired;
-    int32_t* out_a; int32_t* out_id; uint8_t* out_flags; int64_t u0, u1; tcounters tc;
+    int32_t* out_a; int32_t* out_id; uint8_t* out_flags; uint32_t* out_mask; int64_t u0, u1; tcounters tc;
 } job;
 
 static void* job_run(void* p) {
@@ -870,13 +980,18 @@ static void* job_run(void* p) {
         const uint8_t* b1 = j->bases + j->offsets[r]; int l1 = (int)(j->offsets[r + 1] - j->offsets[r]);
         const uint8_t* b2 = NULL; int l2 = 0;
         if (j->paired) { b2 = j->bases + j->offsets[r + 1]; l2 = (int)(j->offsets[r + 2] - j->offsets[r + 1]); }
-        process_pair(j->c, &j->tc, b1, l1, b2, l2, j->paired, j->out_a + r, j->out_id + r, j->out_flags + r);
+        process_pair(j->c, &j->tc, b1, l1, b2, l2, j->paired, j->out_a + r, j->out_id + r, j->out_flags + r, j->out_mask,
+                     j->offsets[r], j->paired ? j->offsets[r + 1] : 0);
     }
     return NULL;
 }
 
 int bbo_process_batch(bbo_ctx* c, const uint8_t* bases, const int64_t* offsets, int64_t n, int paired,
                       int32_t* out_a, int32_t* out_id, uint8_t* out_flags, int nthreads) {
+    return bbo_process_batch_mask(c, bases, offsets, n, paired, out_a, out_id, out_flags, NULL, nthreads);
+}
+int bbo_process_batch_mask(bbo_ctx* c, const uint8_t* bases, const int64_t* offsets, int64_t n, int paired,
+                           int32_t* out_a, int32_t* out_id, uint8_t* out_flags, uint32_t* out_mask, int nthreads) {
     if (paired && (n & 1)) return -1;
     if (nthreads < 1) nthreads = 1;
     const int64_t units = paired ? n / 2 : n;
@@ -887,7 +1002,7 @@ int bbo_process_batch(bbo_ctx* c, const uint8_t* bases, const int64_t* offsets, 
     for (int t = 0; t < nthreads; t++) {
         job* j = &jobs[t];
         j->c = c; j->bases = bases; j->offsets = offsets; j->n = n; j->paired = paired;
-        j->out_a = out_a; j->out_id = out_id; j->out_flags = out_flags;
+        j->out_a = out_a; j->out_id = out_id; j->out_flags = out_flags; j->out_mask = out_mask;
         j->u0 = units * t / nthreads; j->u1 = units * (t + 1) / nthreads;
         j->tc.scafReads = (int64_t*)calloc((size_t)ns, sizeof(int64_t));             /* thread-local copies (:272-277) */
         j->tc.scafBases = (int64_t*)calloc((size_t)ns, sizeof(int64_t));

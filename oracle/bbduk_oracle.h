@@ -50,6 +50,7 @@ typedef struct bbo_args {
     int speed;          /* speed=         (default 0; query-side gate, BBDukIndexMod.java:506,562) */
     float minKmerFraction;    /* mkf=     (default 0; BBDukProcessorS.java:1055-1062) */
     float minCoveredFraction; /* mcf=     (default 0; :1038-1049, countCoveredBases :1602-1651) */
+    int ktrimN;         /* ktrim=n / kmask= (BBDukProcessorS.java:2149-2323 with kmaskFullyCovered=false) */
 } bbo_args;
 
 #define BBO_NCOUNTERS 16
@@ -112,6 +113,10 @@ int      bbo_count_set_kmers(bbo_ctx* c, const uint8_t* bases, int len, int pair
  * out_a[i]  = ktrim: bases trimmed x        | kfilter: found (countSetKmers return)
  * out_id[i] = ktrim: id0 (or -1)            | kfilter: id at exit hit (or -1)
  * out_flags[i] = BBO_FLAG_* bits.   Counters accumulate in ctx.   nthreads>=1 (pairs are sharded). */
+/* ktrim=n: like bbo_process_batch; out_a = number of masked bases per read, out_mask = bit i set <=> base i of the
+ * concatenated `bases` buffer is masked (caller zeroes the (offsets[n]+31)/32 words). */
+int      bbo_process_batch_mask(bbo_ctx* c, const uint8_t* bases, const int64_t* offsets, int64_t n, int paired,
+                                int32_t* out_a, int32_t* out_id, uint8_t* out_flags, uint32_t* out_mask, int nthreads);
 int      bbo_process_batch(bbo_ctx* c, const uint8_t* bases, const int64_t* offsets, int64_t n, int paired,
                            int32_t* out_a, int32_t* out_id, uint8_t* out_flags, int nthreads);
 

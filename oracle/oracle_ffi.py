@@ -18,7 +18,7 @@ class BboArgs(C.Structure):
                [("minLenFraction", C.c_float)] + \
                [(n, C.c_int) for n in ("requireBothBad", "trimPad", "ktrimExclusive", "restrictLeft", "restrictRight",
                                        "skipR1", "skipR2", "minSkip", "maxSkip", "trimPairsEvenly", "qSkip", "speed")] + \
-               [("minKmerFraction", C.c_float), ("minCoveredFraction", C.c_float)]
+               [("minKmerFraction", C.c_float), ("minCoveredFraction", C.c_float), ("ktrimN", C.c_int)]
 
 
 def build(force: bool = False) -> str:
@@ -58,6 +58,8 @@ def lib():
         L.bbo_get_value.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int]
         L.bbo_ktrim_read.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
         L.bbo_count_set_kmers.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.bbo_process_batch_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.bbo_process_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.bbo_counters_len.argtypes = [C.c_void_p]
@@ -173,6 +175,19 @@ class Oracle:
         if rc != 0:
             raise ValueError("bbo_process_batch rc=%d" % rc)
         return a, ids, fl
+
+    def process_batch_mask(self, bases: np.ndarray, offsets: np.ndarray, paired: bool, nthreads: int = 1):
+        """ktrim=n: (masked-count per read, ids, flags, uint32 bit mask over the concatenated bases)."""
+        n = len(offsets) - 1
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        a = np.empty(n, np.int32); ids = np.empty(n, np.int32); fl = np.zeros(n, np.uint8)
+        mask = np.zeros((int(offsets[-1]) + 31) // 32 + 1, np.uint32)
+        rc = lib().bbo_process_batch_mask(self.h, bases.ctypes.data, offsets.ctypes.data, n, int(paired),
+                                          a.ctypes.data, ids.ctypes.data, fl.ctypes.data, mask.ctypes.data, nthreads)
+        if rc != 0:
+            raise ValueError("bbo_process_batch_mask rc=%d" % rc)
+        return a, ids, fl, mask
 
     def counters(self) -> np.ndarray:
         out = np.zeros(lib().bbo_counters_len(self.h), np.int64)

@@ -70,6 +70,7 @@ class Args:
     speed: int = 0                  # speed=
     minKmerFraction: float = 0.0    # mkf=
     minCoveredFraction: float = 0.0 # mcf=
+    ktrimN: bool = False            # ktrim=n / kmask=  (mask instead of trim; kmaskfullycovered is not restated)
 
 
 COUNTER_NAMES = ["readsIn", "basesIn", "readsKTrimmed", "basesKTrimmed", "readsKFiltered", "basesKFiltered",
@@ -99,18 +100,19 @@ class Spec:
         self.useShortKmers = 0 < self.mink < k                                     # :289
         if self.useShortKmers:
             mm, mml = False, 0                                                     # :290-296
-            assert a.ktrimLeft or a.ktrimRight                                     # :301
+            assert a.ktrimLeft or a.ktrimRight or a.ktrimN                         # :301
         if mm:                                                                     # :303-312
             self.middleMask = ~(((1 << (2 * mml)) - 1) << (((k - mml) // 2) * 2))
         else:
             self.middleMask = -1
-        self.kfilter = not (a.ktrimLeft or a.ktrimRight)
+        self.kfilter = not (a.ktrimLeft or a.ktrimRight or a.ktrimN)
         self.rieb = not a.requireBothBad                                           # :109
         self.table = {}            # key -> id  (first writer wins == smallest id; ids ascend in file order)
         self.nscaf = 1             # scaffoldNames[0] reserved (bbduk/BBDukIndex.java:105-107)
         self.counters = [0] * NCOUNTERS
         self.scafReads = [0]
         self.scafBases = [0]
+        self.masks = []            # ktrim=n: per-read base masks of the reads processed so far (process order)
 
     # ---------------------------------------------------------------- keys
     def key_of(self, kmer: int, rkmer: int, length: int) -> int:
@@ -314,6 +316,68 @@ class Spec:
         x, newLen = self._trim_by_amount(n, leftLoc, n - rightLoc - 1, 1)   # TrimRead.java:273-276
         return x, id0, newLen
 
+    def kmask_read(self, read: bytes, pairnum: int):
+        """Returns (cardinality, id0, mask) with mask = int whose bit b says base b is masked.
+        bbduk/BBDukProcessorS.java:2149-2323 with kmaskFullyCovered=false."""
+        a, k, n = self.a, self.k, len(read)
+        if n < max(1, min(k, self.mink) if self.useShortKmers else k) or not self.table:
+            return 0, -1, 0
+        if (a.skipR1 and pairnum == 0) or (a.skipR2 and pairnum == 1):
+            return 0, -1, 0
+        if n < k:                                                                  # :2154
+            return 0, -1, 0
+        bs = 0                                                                     # BitSet(n + trimPad + 1)
+        def bset(lo, hi):
+            nonlocal bs
+            if hi > lo:
+                bs |= ((1 << (hi - lo)) - 1) << lo
+        minus, plus = k - 1 - a.trimPad, a.trimPad + 1
+        start, stop = self._span(n)
+        found, id0 = 0, -1
+        for i, vid in self._main_hits(read, start, stop):                          # :2171-2200
+            if id0 < 0: id0 = vid
+            bset(max(0, i - minus), i + plus)
+            found += 1
+        if self.useShortKmers:                                                     # :2203-2291 (always, not only when found==0)
+            for i in range(start, min(k, stop)):                                   # left side
+                sq = read[start:i + 1]
+                L = len(sq)
+                if L < self.mink:
+                    continue
+                km = 0
+                for c in sq:
+                    km = ((km << 2) | fwd_code(c)) & ((1 << (2 * k)) - 1)
+                rk = 0
+                for t, c in enumerate(sq):
+                    rk |= comp_code(c) << (2 * t)
+                vid = self.lookup(km, rk, L, self.qhdist2, i)
+                if vid > 0:
+                    if id0 < 0: id0 = vid
+                    bset(0, min(n, i + a.trimPad + 1))
+                    found += 1
+            for L in range(1, (k - 1 if stop >= k else stop) + 1):                 # right side: i = stop-1 .. > max(-1, stop-k)
+                i = stop - L
+                if L < self.mink:
+                    continue
+                sq = read[i:stop]
+                km = 0
+                for c in sq:
+                    km = (km << 2) | fwd_code(c)
+                rk = 0
+                for t, c in enumerate(sq):
+                    rk |= comp_code(c) << (2 * t)
+                rk &= (1 << (2 * k)) - 1
+                vid = self.lookup(km, rk, L, self.qhdist2, i)
+                if vid > 0:
+                    if id0 < 0: id0 = vid
+                    bset(max(0, i - a.trimPad), n)
+                    found += 1
+        if found == 0:
+            return 0, -1, 0
+        self.scafReads[id0] += 1
+        self.scafBases[id0] += n
+        return bin(bs).count("1"), id0, bs & ((1 << n) - 1)
+
     def count_set_kmers(self, read: bytes, pairnum: int, maxBad: int):
         """Returns (found, id).  bbduk/BBDukProcessorS.java:1534-1593."""
         a, k, n = self.a, self.k, len(read)
@@ -373,7 +437,21 @@ class Spec:
         d1 = d2 = remove = False
         n1, n2 = l1, l2
         res = []
-        if self.table and (a.ktrimLeft or a.ktrimRight):
+        if self.table and a.ktrimN and not (a.ktrimLeft or a.ktrimRight):              # :984-998, 1009-1016
+            x1, i1, m1 = self.kmask_read(r1, 0)
+            xsum, rkt = x1, int(x1 > 0)
+            d1 = n1 < minlen1
+            x2, i2, m2 = 0, -1, 0
+            if has2:
+                x2, i2, m2 = self.kmask_read(r2, 1)
+                xsum += x2; rkt += int(x2 > 0)
+                d2 = n2 < minlen2
+            if (self.rieb and (d1 or d2)) or (d1 and (not has2 or d2)):
+                remove = True
+            C[3] += xsum; C[2] += rkt
+            res = [(x1, i1)] + ([(x2, i2)] if has2 else [])
+            self.masks += [m1] + ([m2] if has2 else [])
+        elif self.table and (a.ktrimLeft or a.ktrimRight):
             x1, i1, n1 = self.ktrim(r1, 0)
             xsum, rkt = x1, int(x1 > 0)
             d1 = n1 < minlen1

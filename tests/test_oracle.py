@@ -125,7 +125,42 @@ FUZZ = [dict(k=23, ktrimRight=1), dict(k=23, ktrimRight=1, mink=11, hdist=1), di
         dict(k=12, qSkip=3), dict(k=14, ktrimRight=1, mink=6, qSkip=2), dict(k=11, speed=5, hdist=1), dict(k=15, ktrimLeft=1, mink=9, speed=9, qhdist=1),
         dict(k=11, minKmerFraction=0.3), dict(k=13, minKmerFraction=0.1, maxBadKmers0=3, requireBothBad=1, forbidN=1), dict(k=12, minCoveredFraction=0.4),
         dict(k=15, minCoveredFraction=0.9, hdist=1, restrictLeft=60), dict(k=9, minCoveredFraction=0.05, minKmerFraction=0.5, maskMiddle=0)]
-BOOLS = ("maskMiddle", "rcomp", "forbidN", "ktrimRight", "ktrimLeft", "requireBothBad", "ktrimExclusive", "skipR1", "skipR2", "trimPairsEvenly")
+BOOLS = ("maskMiddle", "rcomp", "forbidN", "ktrimRight", "ktrimLeft", "requireBothBad", "ktrimExclusive", "skipR1", "skipR2", "trimPairsEvenly", "ktrimN")
+KMASK_FUZZ = [dict(k=11, ktrimN=1), dict(k=13, ktrimN=1, mink=6, hdist=1), dict(k=15, ktrimN=1, trimPad=2, forbidN=1, restrictRight=50),
+              dict(k=12, ktrimN=1, mink=5, trimPad=-2, qhdist=1, maskMiddle=0), dict(k=17, ktrimN=1, requireBothBad=1, minReadLength=40, skipR1=1)]
+
+
+def spec_mask_words(reads, masks, nwords):
+    out = np.zeros(nwords, np.uint32); pos = 0
+    for r, m in zip(reads, masks):
+        for b in range(len(r)):
+            if (m >> b) & 1:
+                out[(pos + b) >> 5] |= np.uint32(1 << ((pos + b) & 31))
+        pos += len(r)
+    return out
+
+
+@pytest.mark.parametrize("ci", range(len(KMASK_FUZZ)))
+def test_differential_fuzz_kmask(ci):
+    """ktrim=n (kmask): masked-base counts, ids, flags, counters and the per-base masks of both restatements."""
+    kw = KMASK_FUZZ[ci]
+    for seed in range(5):
+        rng = random.Random(7000 + 100 * ci + seed)
+        refs = [util.rand_seq(rng, rng.randint(8, 80), 0.01) for _ in range(6)]
+        o = Oracle(**kw)
+        s = Spec(Args(**{k: (bool(v) if k in BOOLS else v) for k, v in kw.items()}))
+        for r in refs:
+            o.add_ref(r); s.add_ref(r)
+        reads = util.fuzz_reads(rng, refs, 40, [0, 1, 5, 10, 11, 22, 23, 30, 31, 40, 75, 150], junk=True)
+        for paired in (True, False):
+            o.reset_counters()
+            s.counters = [0] * 16; s.scafReads = [0] * s.nscaf; s.scafBases = [0] * s.nscaf; s.masks = []
+            b, off = pack_reads(reads)
+            a, ids, fl, mask = o.process_batch_mask(b, off, paired, nthreads=3)
+            assert list(zip(a.tolist(), ids.tolist(), fl.tolist())) == s.process_batch(reads, paired)
+            assert o.counters().tolist() == s.all_counters()
+            assert np.array_equal(mask, spec_mask_words(reads, s.masks, len(mask)))
+            assert paired is False or int(a.sum()) > 0          # the fuzz reads really get masked
 
 
 @pytest.mark.parametrize("ci", range(len(FUZZ)))
