@@ -15,7 +15,7 @@ import numpy as np
 from ._build import lib_path
 
 OK = 0
-MODE_KFILTER, MODE_KTRIM_R, MODE_KTRIM_L = 0, 1, 2
+MODE_KFILTER, MODE_KTRIM_R, MODE_KTRIM_L, MODE_KMASK = 0, 1, 2, 3
 FLAG_DISCARDED, FLAG_REMOVED = 1, 2
 NCOUNTERS = 16
 COUNTER_NAMES = ["readsIn", "basesIn", "readsKTrimmed", "basesKTrimmed", "readsKFiltered", "basesKFiltered",
@@ -50,7 +50,7 @@ class SynthParams(C.Structure):     # struct bbduk_synth_params
 GPU_SYMBOLS = ["bbduk_abi_version", "bbduk_create", "bbduk_destroy", "bbduk_last_error", "bbduk_upload_table_way",
                "bbduk_upload_pairs", "bbduk_finalize_table", "bbduk_table_size", "bbduk_table_bytes",
                "bbduk_table_lookup", "bbduk_ktrim_batch", "bbduk_kfilter_batch", "bbduk_ktrim_batch_device",
-               "bbduk_kfilter_batch_device", "bbduk_kernel_time_ms", "bbduk_counters_len", "bbduk_get_counters", "bbduk_reset_counters",
+               "bbduk_kfilter_batch_device", "bbduk_kmask_batch", "bbduk_kmask_batch_device", "bbduk_kernel_time_ms", "bbduk_counters_len", "bbduk_get_counters", "bbduk_reset_counters",
                "bbduk_synth_generate_device", "bbduk_synth_generate_host"]
 HOST_SYMBOLS = ["bbduk_host_parse", "bbduk_host_destroy", "bbduk_host_add_ref", "bbduk_host_load_fasta",
                 "bbduk_host_load_refs", "bbduk_host_build_index", "bbduk_host_index_pairs",
@@ -88,6 +88,8 @@ def lib():
     L.bbduk_table_lookup.argtypes = [vp, vp, i64, vp]
     for f in (L.bbduk_ktrim_batch, L.bbduk_kfilter_batch):
         f.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp]
+    L.bbduk_kmask_batch.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, vp]
+    L.bbduk_kmask_batch_device.argtypes = [vp, vp, vp, i64, i64, i32, vp, vp, vp, vp, vp, vp]
     for f in (L.bbduk_ktrim_batch_device, L.bbduk_kfilter_batch_device):
         f.argtypes = [vp, vp, vp, i64, i64, i32, vp, vp, vp, vp, vp]
     L.bbduk_kernel_time_ms.argtypes = [vp, i32, C.POINTER(C.c_float)]
@@ -258,7 +260,19 @@ class BBDukGpu:
     def kfilter_batch(self, bases, offsets, paired):
         return self._host_op(lib().bbduk_kfilter_batch, "kfilter_batch", bases, offsets, paired)
 
+    def kmask_batch(self, bases, offsets, paired):
+        """ktrim=n: (masked bases per read, ids, flags, uint32 bit mask over the concatenated bases)."""
+        bases = np.ascontiguousarray(bases, np.uint8); offsets = np.ascontiguousarray(offsets, np.int64)
+        n = len(offsets) - 1
+        a = np.empty(n, np.int32); ids = np.empty(n, np.int32); fl = np.empty(n, np.uint8)
+        mask = np.zeros((int(offsets[-1]) + 31) // 32 + 1, np.uint32)
+        self._check(lib().bbduk_kmask_batch(self.h, bases.ctypes.data if len(bases) else None, offsets.ctypes.data, n, int(paired),
+                                            a.ctypes.data, ids.ctypes.data, fl.ctypes.data, mask.ctypes.data), "kmask_batch")
+        return a, ids, fl, mask
+
     def process_batch(self, bases, offsets, paired):
+        if self.params.mode == MODE_KMASK:
+            return self.kmask_batch(bases, offsets, paired)[:3]
         if self.params.mode == MODE_KFILTER:
             return self.kfilter_batch(bases, offsets, paired)
         return self.ktrim_batch(bases, offsets, paired)

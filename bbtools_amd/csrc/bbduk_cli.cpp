@@ -7,9 +7,11 @@
 //   bbduk_cli in=r1.fq [in2=r2.fq | int=t] [out=clean.fq] [outm=removed.fq] [tsv=per_read.tsv] [resources=DIR]
 //             [batch=N] [device=D] <BBDuk flags: ktrim= k= mink= hdist= ref= literal= ...>
 //
-// tsv columns: name, length, result (ktrim: bases removed | kfilter: k-mer hits counted), scaffold id or -1,
-// length after trimming, flags (1 = read discarded, 2 = pair removed).  Exit status 0 = OK, 1 = error (message on
-// stderr) -- like the reference, which sets errorState and exits non-zero (bbduk/BBDukS.java:199-202).
+// tsv columns: name, length, result (ktrim: bases removed | kfilter: k-mer hits counted | ktrim=n: bases masked),
+// scaffold id or -1, length after trimming, flags (1 = read discarded, 2 = pair removed).  With ktrim=n / kmask= the
+// masked bases are replaced by the trim symbol (quality '!') or lower-cased (kmask=lc), BBDukProcessorS.java:2309-2320.
+// Exit status 0 = OK, 1 = error (message on stderr) -- like the reference, which sets errorState and exits non-zero
+// (bbduk/BBDukS.java:199-202).
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -62,6 +64,7 @@ bool parse_bool(const std::string& v) { return v.empty() || v == "t" || v == "tr
 int main(int argc, char** argv) {
     std::string in1, in2, out, outm, tsv, resources = "data", flags;
     bool interleaved = false; long batch = 1000000; int device = 0;
+    bool maskLower = false; char maskSymbol = 'N';
     for (int i = 1; i < argc; i++) {
         const std::string tok = argv[i];
         const size_t eq = tok.find('=');
@@ -75,7 +78,14 @@ int main(int argc, char** argv) {
         else if (a == "resources") resources = b;
         else if (a == "batch") batch = atol(b.c_str());
         else if (a == "device") device = atoi(b.c_str());
-        else { flags += tok; flags += ' '; }
+        else {
+            if (a == "ktrim" || a == "kmask" || a == "mask") {       // the replacement symbol is the caller's business (BBDukParser.java:619-644)
+                std::string v = b; for (auto& c : v) c = (char)tolower(c);
+                if (v == "lc" || v == "lowercase") maskLower = true;
+                else if (b.size() == 1 && v != "t" && v != "f" && !((a == "ktrim") && (v == "r" || v == "l" || v == "n"))) maskSymbol = b[0];
+            }
+            flags += tok; flags += ' ';
+        }
     }
     if (in1.empty()) {
         fprintf(stderr, "usage: bbduk_cli in=r1.fq [in2=r2.fq|int=t] [out=clean.fq] [outm=removed.fq] [tsv=reads.tsv] "
@@ -108,7 +118,7 @@ int main(int argc, char** argv) {
 
     const bool ktrim = P.mode != BBDUK_MODE_KFILTER;
     std::vector<Rec> recs; std::vector<uint8_t> bases; std::vector<int64_t> offsets;
-    std::vector<int32_t> res, ids; std::vector<uint8_t> fl;
+    std::vector<int32_t> res, ids; std::vector<uint8_t> fl; std::vector<uint32_t> mask;
     bool eof = false; long long nread = 0;
     while (!eof) {
         recs.clear(); bases.clear(); offsets.assign(1, 0);
@@ -129,8 +139,12 @@ int main(int argc, char** argv) {
         const int64_t n = (int64_t)recs.size();
         res.resize(n); ids.resize(n); fl.resize(n);
         if (bases.empty()) bases.push_back(0);                       // an all-empty batch still needs a valid pointer
-        const int rc = ktrim ? bbduk_ktrim_batch(dev, bases.data(), offsets.data(), n, paired, res.data(), ids.data(), fl.data())
-                             : bbduk_kfilter_batch(dev, bases.data(), offsets.data(), n, paired, res.data(), ids.data(), fl.data());
+        int rc;
+        if (P.mode == BBDUK_MODE_KMASK) {
+            mask.assign((size_t)(offsets[n] + 31) / 32 + 1, 0u);
+            rc = bbduk_kmask_batch(dev, bases.data(), offsets.data(), n, paired, res.data(), ids.data(), fl.data(), mask.data());
+        } else rc = ktrim ? bbduk_ktrim_batch(dev, bases.data(), offsets.data(), n, paired, res.data(), ids.data(), fl.data())
+                          : bbduk_kfilter_batch(dev, bases.data(), offsets.data(), n, paired, res.data(), ids.data(), fl.data());
         if (rc != BBDUK_OK) return fail("batch operator", bbduk_last_error(dev));
         for (int64_t i = 0; i < n; i++) {
             Rec& r = recs[i];
@@ -138,6 +152,14 @@ int main(int argc, char** argv) {
             int left = 0, right = 0;                                 // TrimRead.trimByAmount(r, left, right, 1) with the returned amount
             if (P.mode == BBDUK_MODE_KTRIM_R) right = res[i]; else if (P.mode == BBDUK_MODE_KTRIM_L) left = res[i];
             const int newLen = L - left - right;
+            if (P.mode == BBDUK_MODE_KMASK && res[i] > 0) {            // :2309-2320
+                for (int b = 0; b < L; b++) {
+                    const int64_t g = offsets[i] + b;
+                    if (!((mask[(size_t)(g >> 5)] >> (g & 31)) & 1u)) continue;
+                    if (maskLower) r.bases[b] = (char)tolower((unsigned char)r.bases[b]);
+                    else { r.bases[b] = maskSymbol; if (maskSymbol == 'N') r.quals[b] = '!'; }
+                }
+            }
             if (ftsv) fprintf(ftsv, "%s\t%d\t%d\t%d\t%d\t%d\n", r.name.c_str(), L, res[i], ids[i], newLen, (int)fl[i]);
             FILE* dst = (fl[i] & BBDUK_FLAG_REMOVED) ? foutm : fout;
             if (dst) {
@@ -157,7 +179,8 @@ int main(int argc, char** argv) {
     bbduk_get_counters(dev, c.data(), (int32_t)c.size());
     // the lines BBDukS prints at the end of a run (bbduk/BBDukS.java:350-420), same wording for the shared counters
     fprintf(stderr, "Input:                  \t%lld reads \t\t%lld bases.\n", (long long)c[BBDUK_READS_IN], (long long)c[BBDUK_BASES_IN]);
-    if (ktrim) fprintf(stderr, "KTrimmed:               \t%lld reads \t%lld bases\n", (long long)c[BBDUK_READS_KTRIMMED], (long long)c[BBDUK_BASES_KTRIMMED]);
+    if (P.mode == BBDUK_MODE_KMASK) fprintf(stderr, "KMasked:                \t%lld reads \t%lld bases\n", (long long)c[BBDUK_READS_KTRIMMED], (long long)c[BBDUK_BASES_KTRIMMED]);
+    else if (ktrim) fprintf(stderr, "KTrimmed:               \t%lld reads \t%lld bases\n", (long long)c[BBDUK_READS_KTRIMMED], (long long)c[BBDUK_BASES_KTRIMMED]);
     else fprintf(stderr, "Contaminants:           \t%lld reads \t%lld bases\n", (long long)c[BBDUK_READS_KFILTERED], (long long)c[BBDUK_BASES_KFILTERED]);
     fprintf(stderr, "Total Removed:          \t%lld reads \t%lld bases\n", (long long)(c[BBDUK_READS_IN] - c[BBDUK_READS_OUTU]),
             (long long)(c[BBDUK_BASES_IN] - c[BBDUK_BASES_OUTU]));

@@ -1101,6 +1101,199 @@ void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
 }
 
 // --------------------------------------------------------------------------------------------------
+// ktrim=n (kmask): bbduk/BBDukProcessorS.java:2149-2323 with kmaskFullyCovered=false.  A secondary operator, written
+// for clarity rather than speed on the run-time-general code paths (GENERAL scans, every flag honoured): tiles staged
+// like bbduk_batch_kernel, one wave per READ (mates only meet in the record stage), a fourth LDS bit-plane that
+// collects the k-mer END positions that hit.  A base b is masked iff some hit ends in [b-trimPad, b+k-1-trimPad]
+// (bs.set(max(0,i-minus), i+plus), :2190), or a short k-mer on either side covers it (:2236, :2279; the short scans run
+// always here, not only when the main scan found nothing).  out = number of masked bases (BitSet.cardinality(), which
+// also counts the bits a positive trimPad pushes past the read end), id0, flags, and the per-base mask.
+#define KM_CAP_BASES  32768                    // >= BBDUK_MAX_READ_LEN + 32: any single read fits
+#define KM_CAP_CHUNKS (KM_CAP_BASES / 16)
+__global__ __launch_bounds__(BLOCK_THREADS)
+void bbduk_kmask_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
+                        const int64_t n, const int64_t totalBases, const int paired,
+                        int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
+                        uint32_t* __restrict__ outMask, int64_t* __restrict__ counters) {
+    __shared__ uint32_t s_fwd[PLANE_PAD + KM_CAP_CHUNKS + PLANE_PAD];
+    __shared__ uint32_t s_cmp[PLANE_PAD + KM_CAP_CHUNKS + PLANE_PAD];
+    __shared__ uint32_t s_nm[KM_CAP_CHUNKS / 2 + 4];
+    __shared__ uint32_t s_hit[KM_CAP_CHUNKS / 2 + 4];             // bit p <=> a k-mer ending at plane position p matched
+    __shared__ int64_t  s_off[TILE_READS + 1];
+    __shared__ int32_t  s_a[TILE_READS];
+    __shared__ int32_t  s_id[TILE_READS];
+    __shared__ unsigned long long s_acc[6];                       // rkt, basesKTrimmed, readsOutm, basesOutm, readsIn, basesIn
+    extern __shared__ uint32_t s_filt[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+    const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
+    const int k = P.k, tp = P.trimPad;
+    ScafAcc scaf; scaf_init(scaf);
+    if (tid < 6) s_acc[tid] = 0;
+    if (P.ldsBits) {
+        const int words = 1 << (P.ldsBits - 5);
+        for (int w = tid; w < words; w += BLOCK_THREADS) s_filt[w] = P.ldsImage[w];
+    }
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t r0 = tile * TILE_READS;
+        const int cnt = (int)min((int64_t)TILE_READS, n - r0);
+        __syncthreads();
+        if (tid <= cnt) s_off[tid] = offsets[r0 + tid];
+        __syncthreads();
+        if (tid == 0) { s_acc[4] += (unsigned long long)cnt; s_acc[5] += (unsigned long long)(s_off[cnt] - s_off[0]); }
+        int s = 0;
+        while (s < cnt) {
+            const int64_t off_s = s_off[s];
+            const int cand = s + 1 + tid;
+            const int okc = (cand <= cnt) && (s_off[min(cand, cnt)] - off_s <= (int64_t)(KM_CAP_BASES - 32));
+            const int fit = uni(__syncthreads_count(okc));
+            if (fit == 0) {                                         // a read longer than BBDUK_MAX_READ_LEN
+                if (tid == 0) { atomicMax((unsigned long long*)&counters[BBDUK_CTR_STATUS], (unsigned long long)(-BBDUK_ERR_READ_TOO_LONG)); s_a[s] = 0; s_id[s] = -1; }
+                s += 1;
+                continue;
+            }
+            const int e = s + fit;
+            const int64_t B0 = off_s, B1 = s_off[e];
+            const int64_t A0 = B0 & ~15LL;
+            const int nchunks = (int)((B1 - A0 + 15) >> 4);
+            for (int c = tid; c < nchunks; c += BLOCK_THREADS) {
+                uint32_t r, comp, valid;
+                encode_chunk(bases, A0 + 16LL * c, totalBases, r, comp, valid);
+                s_fwd[PLANE_PAD + nchunks - 1 - c] = r;
+                s_cmp[PLANE_PAD + c] = comp;
+                reinterpret_cast<uint16_t*>(s_nm)[c] = (uint16_t)(~valid & 0xFFFFu);
+            }
+            if (tid == 0 && (nchunks & 1)) reinterpret_cast<uint16_t*>(s_nm)[nchunks] = 0;
+            for (int w = tid; w < (nchunks + 1) / 2 + 2; w += BLOCK_THREADS) s_hit[w] = 0;
+            __syncthreads();
+
+            Planes Q; Q.fwd = s_fwd + PLANE_PAD; Q.cmp = s_cmp + PLANE_PAD; Q.nm = s_nm; Q.filt = s_filt; Q.T = nchunks * 16;
+            Q.fwdBits = lds_bits_of(Q.fwd); Q.cmpBits = lds_bits_of(Q.cmp);
+            for (int rd = s + wave; rd < e; rd += NWAVES) {        // one wave per read
+                const int L = uni((int)(s_off[rd + 1] - s_off[rd]));
+                const int base0 = uni((int)(s_off[rd] - A0));
+                const int pairnum = paired ? (rd & 1) : 0;
+                ReadScan R;
+                R.base0 = base0; R.L = L; R.hasN = -1; R.maxBad = 0;
+                R.start = span_start<true>(P, L); R.stop = span_stop<true>(P, L);
+                R.scan = P.storedKmers > 0 && L >= k && !((P.skipR1 && pairnum == 0) || (P.skipR2 && pairnum == 1));   // :2151-2154
+                int found = 0, id0 = -1;
+                int leftEnd = 0, rightStart = L;                    // bases [0,leftEnd) and [rightStart,L) are masked by short k-mers
+                if (R.scan) {
+                    ReadWin W;
+                    win_init<true, true>(P, Q, R, W, lane);
+                    for (int ib = W.first; W.on && ib < W.stop; ib += 256) {       // 4 positions per lane and iteration
+                        uint64_t kmer[4], rk[4]; bool ok[4]; int ref[4];
+                        windows2<true, true>(P, Q, W, ib + 2 * lane, true, kmer, rk, ok);
+                        if (ib + 128 < W.stop) windows2<true, true>(P, Q, W, ib + 128 + 2 * lane, true, kmer + 2, rk + 2, ok + 2);
+                        else { kmer[2] = kmer[3] = 0; rk[2] = rk[3] = 0; ok[2] = ok[3] = false; }
+                        lookup4<true>(P, Q.filt, kmer, rk, ok, ref);
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int i = ib + 128 * (q >> 1) + 2 * lane + (q & 1);
+                            if (ref[q] != -1) atomicOr(&s_hit[(base0 + i) >> 5], 1u << ((base0 + i) & 31));
+                        }
+#pragma unroll
+                        for (int hb = 0; hb < 2; hb++) {            // id0 = id of the first hit in position order
+                            const uint64_t me = __ballot(ref[2 * hb] != -1), mo = __ballot(ref[2 * hb + 1] != -1);
+                            if (id0 < 0 && (me | mo)) {
+                                const int le = me ? __ffsll((unsigned long long)me) - 1 : 64, lo = mo ? __ffsll((unsigned long long)mo) - 1 : 64;
+                                id0 = (2 * lo + 1 < 2 * le) ? __builtin_amdgcn_readlane(ref[2 * hb + 1], lo) : __builtin_amdgcn_readlane(ref[2 * hb], le);
+                            }
+                            found += __popcll(me) + __popcll(mo);
+                        }
+                    }
+                    if (P.useShort) {                               // lanes 0-31: left side, lanes 32-63: right side; length mink + (lane&31)
+                        const bool right = lane >= 32;
+                        const int Ls = P.mink + (lane & 31);
+                        bool act; int i;
+                        uint64_t km = 0, rr = 0;
+                        if (!right) {
+                            const int Lmax = min(k, R.stop) - R.start;            // i = start+Ls-1 < min(k, stop)
+                            act = Ls <= Lmax; i = R.start + Ls - 1;
+                            const int Lc = act ? Ls : 1;
+                            if (act) { km = extract2(Q.fwd, Q.T - 1 - (base0 + R.start + Lc - 1), Lc) & P.mask; rr = extract2(Q.cmp, base0 + R.start, Lc); }
+                        } else {
+                            const int Lmax = (R.stop >= k ? k - 1 : R.stop);      // i = stop-Ls > max(-1, stop-k)
+                            act = Ls <= Lmax; i = R.stop - Ls;
+                            const int Lc = act ? Ls : 1;
+                            if (act) { km = extract2(Q.fwd, Q.T - 1 - (base0 + R.stop - 1), Lc); rr = extract2(Q.cmp, base0 + R.stop - Lc, Lc) & P.mask; }
+                        }
+                        if (P.qskip > 1) act = act && (i % P.qskip) == 0;
+                        const int Lc = act ? Ls : 1;
+                        const int sref = lookup<true>(P, Q.filt, km, rr, 1ULL << (2 * Lc), Lc, P.qhdist2, act);
+                        const uint64_t hm = __ballot(sref != -1);
+                        const uint32_t mL = (uint32_t)hm, mR = (uint32_t)(hm >> 32);
+                        if (id0 < 0 && mL) id0 = __builtin_amdgcn_readlane(sref, __ffs(mL) - 1);          // left hits first, shortest first
+                        if (id0 < 0 && mR) id0 = __builtin_amdgcn_readlane(sref, 32 + __ffs(mR) - 1);
+                        found += __popc(mL) + __popc(mR);
+                        if (mL) { const int iMax = R.start + (P.mink + (31 - __clz(mL))) - 1; leftEnd = max(0, min(L, iMax + tp + 1)); }     // :2236
+                        if (mR) { const int iMin = R.stop - (P.mink + (31 - __clz(mR))); rightStart = min(L, max(0, iMin - tp)); }           // :2279
+                    }
+                }
+                int card = 0;
+                if (found > 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    scaf_add(P, scaf, id0, L, lane, counters);
+                    const int64_t g0 = s_off[rd];                   // bit offset of the read in the output mask
+                    const int nb = L + max(tp, 0) + 1;              // BitSet size: bits >= L count but are not written
+                    for (int b0 = 0; b0 < nb; b0 += 64) {
+                        const int b = b0 + lane;
+                        bool cov = false;
+                        if (b < nb) {
+                            const int lo = max(0, b - tp), hi = min(L - 1, b + k - 1 - tp);
+                            if (lo <= hi) cov = extract1(s_hit, base0 + lo, hi - lo + 1) != 0u;      // hi-lo+1 <= k <= 31
+                            if (b < L) cov = cov || b < leftEnd || b >= rightStart;
+                        }
+                        const uint64_t cm = __ballot(cov);
+                        card += __popcll(cm);
+                        const uint64_t wm = cm & ((L - b0 >= 64) ? ~0ULL : ((L - b0 <= 0) ? 0ULL : ((1ULL << (L - b0)) - 1ULL)));   // bases only
+                        if (wm && lane < 3) {                       // up to three 32-bit words of the global mask
+                            const int64_t g = g0 + b0; const int sh = (int)(g & 31);
+                            const uint64_t plo = wm << sh, phi = sh ? (wm >> (64 - sh)) : 0ULL;
+                            const uint32_t piece = lane == 0 ? (uint32_t)plo : (lane == 1 ? (uint32_t)(plo >> 32) : (uint32_t)phi);
+                            if (piece) atomicOr(&outMask[(g >> 5) + lane], piece);
+                        }
+                    }
+                }
+                if (lane == 0) { s_a[rd] = card; s_id[rd] = found > 0 ? id0 : -1; }
+            }
+            __syncthreads();
+            s = e;
+        }
+        // ---- record stage (:984-998, 1009-1016, 1028-1029, 1431-1443): one thread per read, mates look at each other
+        if (tid < cnt) {
+            const int L1 = (int)(s_off[tid + 1] - s_off[tid]);
+            const float g1 = (float)L1 * P.minLenFraction;
+            const bool d = P.storedKmers > 0 && L1 < (int)(g1 > (float)P.minReadLength ? g1 : (float)P.minReadLength);
+            bool remove = d;
+            if (paired) {
+                const int m = tid ^ 1;
+                const int L2 = (int)(s_off[m + 1] - s_off[m]);
+                const float g2 = (float)L2 * P.minLenFraction;
+                const bool dm = P.storedKmers > 0 && L2 < (int)(g2 > (float)P.minReadLength ? g2 : (float)P.minReadLength);
+                remove = (P.rieb && (d || dm)) || (d && dm);
+            }
+            const int a = s_a[tid];
+            outA[r0 + tid] = a; outId[r0 + tid] = s_id[tid];
+            outFlags[r0 + tid] = (uint8_t)((d ? BBDUK_FLAG_DISCARDED : 0) | (remove ? BBDUK_FLAG_REMOVED : 0));
+            if (a > 0) { atomicAdd(&s_acc[0], 1ULL); atomicAdd(&s_acc[1], (unsigned long long)a); }     // rktsum / xsum: unchanged by removal (ktrimN)
+            if (remove) { atomicAdd(&s_acc[2], 1ULL); atomicAdd(&s_acc[3], (unsigned long long)L1); }
+        }
+    }
+    scaf_flush(P, scaf, lane, counters);
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long rkt = s_acc[0], xs = s_acc[1], rm = s_acc[2], bm = s_acc[3], rin = s_acc[4], bin = s_acc[5];
+        auto add = [&](int slot, unsigned long long v) { if (v) atomicAdd((unsigned long long*)&counters[slot], v); };
+        add(BBDUK_READS_IN, rin); add(BBDUK_BASES_IN, bin);
+        add(BBDUK_READS_KTRIMMED, rkt); add(BBDUK_BASES_KTRIMMED, xs);
+        add(BBDUK_READS_OUTM, rm); add(BBDUK_BASES_OUTM, bm);
+        add(BBDUK_READS_OUTU, rin - rm); add(BBDUK_BASES_OUTU, bin - bm);      // masking keeps every read's length
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
 // Wave-autonomous batch kernel (the fast path): every wave owns a mini-tile of MT_READS consecutive reads,
 // stages it into its private slice of LDS and scans it, with no workgroup barrier after the one that lands
 // the presence filter.  Waves of a CU therefore sit in different phases (HBM load, LDS extraction, L2 gather),
@@ -1596,7 +1789,7 @@ extern "C" int bbduk_create(const bbduk_params* p, bbduk_handle** out) {
     *out = nullptr;
     if (p->abi_version != BBDUK_ABI_VERSION) return BBDUK_ERR_ARG;
     if (p->k < 1 || p->k > 31) return BBDUK_ERR_ARG;
-    if (p->mode != BBDUK_MODE_KFILTER && p->mode != BBDUK_MODE_KTRIM_R && p->mode != BBDUK_MODE_KTRIM_L) return BBDUK_ERR_ARG;
+    if (p->mode != BBDUK_MODE_KFILTER && p->mode != BBDUK_MODE_KTRIM_R && p->mode != BBDUK_MODE_KTRIM_L && p->mode != BBDUK_MODE_KMASK) return BBDUK_ERR_ARG;
     if (p->qhdist < 0 || p->qhdist > 2 || p->qhdist2 < 0 || p->qhdist2 > 2) return BBDUK_ERR_ARG;
     if (p->numScaffolds < 1 || p->maxBadKmers < 0) return BBDUK_ERR_ARG;
     const bool useShort = p->mink > 0 && p->mink < p->k;
@@ -1770,7 +1963,7 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
                         int64_t* d_counters, hipStream_t st) {
     if (!h) return BBDUK_ERR_ARG;
     if (!h->finalized) return fail(h, BBDUK_ERR_STATE, "table not finalized");
-    if ((h->p.mode == BBDUK_MODE_KFILTER) != (wantKfilter != 0)) return fail(h, BBDUK_ERR_STATE, "operator does not match the mode given to bbduk_create");
+    if (h->p.mode == BBDUK_MODE_KMASK || (h->p.mode == BBDUK_MODE_KFILTER) != (wantKfilter != 0)) return fail(h, BBDUK_ERR_STATE, "operator does not match the mode given to bbduk_create");
     if (n < 0 || total_bases < 0 || (paired && (n & 1))) return fail(h, BBDUK_ERR_ARG, "bad batch shape");
     if (n == 0) return BBDUK_OK;
     if (!d_bases && total_bases > 0) return fail(h, BBDUK_ERR_ARG, "null bases");
@@ -1870,6 +2063,75 @@ extern "C" int bbduk_ktrim_batch(bbduk_handle* h, const uint8_t* bases, const in
 extern "C" int bbduk_kfilter_batch(bbduk_handle* h, const uint8_t* bases, const int64_t* offsets, int64_t n, int32_t paired,
                                    int32_t* out_found, int32_t* out_id, uint8_t* out_flags) {
     return host_batch(h, 1, bases, offsets, n, paired, out_found, out_id, out_flags);
+}
+
+// ---- ktrim=n
+static int launch_kmask(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d_offsets, int64_t n, int64_t total_bases, int32_t paired,
+                        int32_t* d_a, int32_t* d_id, uint8_t* d_fl, uint32_t* d_mask, int64_t* d_counters, hipStream_t st) {
+    if (!h) return BBDUK_ERR_ARG;
+    if (!h->finalized) return fail(h, BBDUK_ERR_STATE, "table not finalized");
+    if (h->p.mode != BBDUK_MODE_KMASK) return fail(h, BBDUK_ERR_STATE, "operator does not match the mode given to bbduk_create");
+    if (n < 0 || total_bases < 0 || (paired && (n & 1))) return fail(h, BBDUK_ERR_ARG, "bad batch shape");
+    if (n == 0) return BBDUK_OK;
+    if (!d_bases && total_bases > 0) return fail(h, BBDUK_ERR_ARG, "null bases");
+    if (!d_offsets || !d_a || !d_id || !d_fl || !d_mask || !d_counters) return fail(h, BBDUK_ERR_ARG, "null buffer");
+    if (((uintptr_t)d_bases & 15) != 0) return fail(h, BBDUK_ERR_ARG, "d_bases must be 16-byte aligned");
+    const KParams K = make_kparams(h);
+    const size_t dynLds = h->ldsBits ? ((size_t)1 << (h->ldsBits - 3)) : 0;
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bbduk_kmask_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
+    HIP_TRY(h, hipMemsetAsync(d_mask, 0, ((size_t)(total_bases + 31) / 32 + 2) * sizeof(uint32_t), st));
+    const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
+    const int grid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU);
+    const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
+    if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
+    HIP_TRY(h, hipEventRecord(h->ev0[evi], st));
+    bbduk_kmask_kernel<<<dim3(grid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_mask, d_counters);
+    HIP_TRY(h, hipEventRecord(h->ev1[evi], st));
+    h->evCount++;
+    HIP_TRY(h, hipGetLastError());
+    return BBDUK_OK;
+}
+extern "C" int bbduk_kmask_batch_device(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d_offsets, int64_t n,
+                                        int64_t total_bases, int32_t paired, int32_t* d_out_masked, int32_t* d_out_id0,
+                                        uint8_t* d_out_flags, uint32_t* d_out_mask, int64_t* d_counters, void* stream) {
+    return launch_kmask(h, d_bases, d_offsets, n, total_bases, paired, d_out_masked, d_out_id0, d_out_flags, d_out_mask, d_counters, (hipStream_t)stream);
+}
+extern "C" int bbduk_kmask_batch(bbduk_handle* h, const uint8_t* bases, const int64_t* offsets, int64_t n, int32_t paired,
+                                 int32_t* out_masked, int32_t* out_id0, uint8_t* out_flags, uint32_t* out_mask) {
+    if (!h) return BBDUK_ERR_ARG;
+    if (n < 0 || !offsets || (n > 0 && (!out_masked || !out_id0 || !out_flags || !out_mask))) return fail(h, BBDUK_ERR_ARG, "bad argument");
+    if (n == 0) return BBDUK_OK;
+    const int64_t total = offsets[n];
+    if (offsets[0] != 0 || total < 0 || (total > 0 && !bases)) return fail(h, BBDUK_ERR_ARG, "bad offsets");
+    std::lock_guard<std::mutex> g(h->mu);
+    HIP_TRY(h, hipSetDevice(h->p.device));
+    uint8_t* db = nullptr; int64_t* doff = nullptr; int32_t* da = nullptr; int32_t* did = nullptr; uint8_t* dfl = nullptr; uint32_t* dm = nullptr;
+    const size_t mwords = (size_t)(total + 31) / 32 + 2;
+    auto release = [&]() { hipFree(db); hipFree(doff); hipFree(da); hipFree(did); hipFree(dfl); hipFree(dm); };
+    if (hipMalloc(&db, (size_t)total + 16) != hipSuccess || hipMalloc(&doff, (size_t)(n + 1) * 8) != hipSuccess ||
+        hipMalloc(&da, (size_t)n * 4) != hipSuccess || hipMalloc(&did, (size_t)n * 4) != hipSuccess ||
+        hipMalloc(&dfl, (size_t)n) != hipSuccess || hipMalloc(&dm, mwords * 4) != hipSuccess) { release(); return fail(h, BBDUK_ERR_NOMEM, "hipMalloc"); }
+    hipError_t e = hipSuccess;
+    if (total > 0) e = hipMemcpyAsync(db, bases, (size_t)total, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(doff, offsets, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) { release(); h->err = hipGetErrorString(e); return BBDUK_ERR_DEVICE; }
+    const int rc = launch_kmask(h, db, doff, n, total, paired, da, did, dfl, dm, h->d_counters, h->stream);
+    if (rc != BBDUK_OK) { release(); return rc; }
+    hipMemcpyAsync(out_masked, da, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream);
+    hipMemcpyAsync(out_id0, did, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream);
+    hipMemcpyAsync(out_flags, dfl, (size_t)n, hipMemcpyDeviceToHost, h->stream);
+    hipMemcpyAsync(out_mask, dm, ((size_t)(total + 31) / 32) * 4, hipMemcpyDeviceToHost, h->stream);
+    e = hipStreamSynchronize(h->stream);
+    release();
+    if (e != hipSuccess) { h->err = hipGetErrorString(e); return BBDUK_ERR_DEVICE; }
+    int64_t status = 0;
+    HIP_TRY(h, hipMemcpy(&status, h->d_counters + BBDUK_CTR_STATUS, sizeof status, hipMemcpyDeviceToHost));
+    if (status != 0) {
+        int64_t z = 0;
+        hipMemcpy(h->d_counters + BBDUK_CTR_STATUS, &z, sizeof z, hipMemcpyHostToDevice);
+        return fail(h, -(int)status, "device reported an error (read longer than BBDUK_MAX_READ_LEN?)");
+    }
+    return BBDUK_OK;
 }
 
 extern "C" int bbduk_table_lookup(bbduk_handle* h, const int64_t* keys, int64_t n, int32_t* out_ids) {

@@ -27,7 +27,7 @@ struct Parsed {                      // bbduk/BBDukParser.java fields (subset th
     bool maskMiddle = true; int midMaskLen = 0;   // :1091
     bool rcomp = true;               // :1208
     bool forbidNs = false;
-    bool ktrimLeft = false, ktrimRight = false;
+    bool ktrimLeft = false, ktrimRight = false, ktrimN = false;
     int maxBadKmers0 = 0;            // :1232
     int minReadLength = 10;          // :437
     float minLenFraction = 0.f;      // :439
@@ -96,7 +96,7 @@ int derive(Parsed& p, std::string& err) {            // bbduk/BBDukParser.java:1
     p.minlen2 = (p.maskMiddle ? (p.k - p.midMaskLen) / 2 : p.k);        // before mink turns maskMiddle off
     if (p.mink > 0 && p.mink < p.k) p.useShortKmers = true;
     if (p.useShortKmers && p.maskMiddle) { p.maskMiddle = false; p.midMaskLen = 0; }
-    if (p.useShortKmers && !(p.ktrimLeft || p.ktrimRight)) { err = "Setting mink also requires setting a ktrim mode, such as 'r' or 'l'"; return BBDUK_ERR_ARG; }
+    if (p.useShortKmers && !(p.ktrimLeft || p.ktrimRight || p.ktrimN)) { err = "Setting mink also requires setting a ktrim mode, such as 'r' or 'l'"; return BBDUK_ERR_ARG; }
     if (p.ktrimLeft && p.ktrimRight) { err = "ktrim=rl (tips) is not supported by this path yet"; return BBDUK_ERR_ARG; }
     if (p.maskMiddle) {
         if (!(p.k > p.midMaskLen + 1)) { err = "k too small for maskmiddle"; return BBDUK_ERR_ARG; }
@@ -187,13 +187,24 @@ extern "C" int bbduk_host_parse(const char* args, bbduk_host** out, char* errbuf
         else if (a == "forbidns" || a == "forbidn" || a == "fn") need_bool(p.forbidNs);
         else if (a == "ktrim") {
             std::string v = b; for (auto& c : v) c = (char)tolower(c);
-            if (v == "rl" || v == "lr" || v == "tips") { p.ktrimLeft = p.ktrimRight = true; }
-            else if (v == "l" || v == "left") { p.ktrimLeft = true; p.ktrimRight = false; }
-            else if (v == "r" || v == "right") { p.ktrimLeft = false; p.ktrimRight = true; }
+            if (v == "rl" || v == "lr" || v == "tips") { p.ktrimLeft = p.ktrimRight = true; p.ktrimN = false; }
+            else if (v == "l" || v == "left") { p.ktrimLeft = true; p.ktrimRight = false; p.ktrimN = false; }
+            else if (v == "r" || v == "right") { p.ktrimLeft = false; p.ktrimRight = true; p.ktrimN = false; }
+            else if (v == "n" || (v.size() == 1 && v != "t" && v != "f")) { p.ktrimLeft = p.ktrimRight = false; p.ktrimN = true; }   // the symbol stays with the caller
             else if (v == "f" || v == "false") { p.ktrimLeft = p.ktrimRight = false; }
-            else { seterr("Invalid setting for ktrim - supported values are f (false), l (left), r (right)"); delete h; return BBDUK_ERR_ARG; }
+            else { seterr("Invalid setting for ktrim - values must be f (false), l (left), r (right), or n"); delete h; return BBDUK_ERR_ARG; }
         }
-        else if (a == "kfilter") { bool x = false; need_bool(x); if (x) p.ktrimLeft = p.ktrimRight = false; }
+        else if (a == "kmask" || a == "mask") {                      // BBDukParser.java:635-651: lc | t | a symbol | f
+            std::string v = b; for (auto& c : v) c = (char)tolower(c);
+            if (v == "f" || v == "false") p.ktrimN = false;
+            else { p.ktrimN = true; p.ktrimLeft = p.ktrimRight = false; }
+        }
+        else if (a == "ktrimn") { need_bool(p.ktrimN); if (ok) p.ktrimLeft = p.ktrimRight = !p.ktrimN; }
+        else if (a == "kmaskfullycovered" || a == "maskfullycovered" || a == "mfc") {
+            bool x = false; need_bool(x);
+            if (ok && x) { seterr("kmaskfullycovered=t is not supported by this path yet"); delete h; return BBDUK_ERR_ARG; }
+        }
+        else if (a == "kfilter") { bool x = false; need_bool(x); if (x) { p.ktrimLeft = p.ktrimRight = false; p.ktrimN = false; } }
         else if (a == "maxbadkmers" || a == "mbk") need_int(p.maxBadKmers0);
         else if (a == "minhits" || a == "minkmerhits" || a == "mkh") { need_int(p.maxBadKmers0); p.maxBadKmers0 -= 1; }
         else if (a == "ml" || a == "minlen" || a == "minlength") need_int(p.minReadLength);
@@ -336,7 +347,7 @@ extern "C" int bbduk_host_params(const bbduk_host* h, int32_t device, bbduk_para
     const Parsed& p = h->p;
     memset(out, 0, sizeof *out);
     out->abi_version = BBDUK_ABI_VERSION;
-    out->mode = p.ktrimRight ? BBDUK_MODE_KTRIM_R : (p.ktrimLeft ? BBDUK_MODE_KTRIM_L : BBDUK_MODE_KFILTER);
+    out->mode = p.ktrimRight ? BBDUK_MODE_KTRIM_R : (p.ktrimLeft ? BBDUK_MODE_KTRIM_L : (p.ktrimN ? BBDUK_MODE_KMASK : BBDUK_MODE_KFILTER));
     out->k = p.k; out->mink = p.mink; out->rcomp = p.rcomp; out->forbidNs = p.forbidNs;
     out->minlen = p.minlen; out->minlen2 = p.minlen2; out->middleMask = p.middleMask;
     out->qhdist = p.qhdist; out->qhdist2 = p.qhdist2; out->maxBadKmers = p.maxBadKmers0;

@@ -53,6 +53,7 @@ extern "C" {
 #define BBDUK_MODE_KFILTER   0       /* countSetKmers + filtering branch */
 #define BBDUK_MODE_KTRIM_R   1       /* ktrim=r */
 #define BBDUK_MODE_KTRIM_L   2       /* ktrim=l */
+#define BBDUK_MODE_KMASK     3       /* ktrim=n / kmask=: mask matched bases instead of trimming (kmaskfullycovered=f) */
 
 /* per-read output flags */
 #define BBDUK_FLAG_DISCARDED 1       /* setDiscarded(r)  (BBDukProcessorS.java:1464-1470)    */
@@ -130,6 +131,16 @@ int  bbduk_ktrim_batch_device(bbduk_handle* h, const uint8_t* d_bases, const int
 int  bbduk_kfilter_batch_device(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d_offsets, int64_t n,
                                 int64_t total_bases, int32_t paired, int32_t* d_out_found, int32_t* d_out_id,
                                 uint8_t* d_out_flags, int64_t* d_counters, void* stream);
+
+/* ---- ktrim=n (bbduk/BBDukProcessorS.java:2149-2323, kmaskFullyCovered=false).  out_masked[i] = kmask(Read)'s return
+ * (BitSet.cardinality()), out_mask = one bit per base of the concatenated `bases` buffer (bit b of word b/32 set <=> the
+ * caller replaces base b by trimSymbol / lower-cases it, :2309-2320); (offsets[n]+31)/32 words, the device variant needs
+ * two more words of slack and clears the buffer itself.  Pair flags as for ktrim (reads keep their length). */
+int  bbduk_kmask_batch(bbduk_handle* h, const uint8_t* bases, const int64_t* offsets, int64_t n, int32_t paired,
+                       int32_t* out_masked, int32_t* out_id0, uint8_t* out_flags, uint32_t* out_mask);
+int  bbduk_kmask_batch_device(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d_offsets, int64_t n,
+                              int64_t total_bases, int32_t paired, int32_t* d_out_masked, int32_t* d_out_id0,
+                              uint8_t* d_out_flags, uint32_t* d_out_mask, int64_t* d_counters, void* stream);
 
 /* Average duration (HIP events on the launch stream) of the dominant kernel over the last `last_k` batch launches
  * of this handle (at most 64 are remembered).  Synchronises on those launches.  For roofline reporting. */

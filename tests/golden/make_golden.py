@@ -56,6 +56,9 @@ def main():
     # C2 + trimpairsevenly (the canonical adapter-trimming command line: ktrim=r k=23 mink=11 hdist=1 tpe)
     run_case("c2_ktrimr_k23_mink11_hdist1_tpe_adapters", "ktrim=r k=23 mink=11 hdist=1 tpe ref=adapters",
              dict(k=23, mink=11, hdist=1, ktrimRight=True, trimPairsEvenly=True), ADAPTERS, reads, True)
+    # C2 flags with ktrim=n (kmask): expected = (masked bases, id0, flags)
+    run_case("c2_kmask_k23_mink11_hdist1_adapters", "ktrim=n k=23 mink=11 hdist=1 ref=adapters",
+             dict(k=23, mink=11, hdist=1, ktrimN=True), ADAPTERS, reads, True)
     # C3: kfilter k=31 hdist=1 ref=phix
     reads = synth_reads(3, 60, contam=phix, contam_frac=0.3, sub_rate=0.02, n_rate=0.004)
     run_case("c3_kfilter_k31_hdist1_phix", "k=31 hdist=1 ref=phix", dict(k=31, hdist=1), PHIX, reads, True)
@@ -110,6 +113,18 @@ def cli_fixtures(phix):
     write_fastq(os.path.join(here, "cli_c2_r2.fq"), names[1::2], reads[1::2])
     s = Spec(Args(k=23, mink=11, hdist=1, ktrimRight=True)); s.load_fasta(ADAPTERS)
     tsv(os.path.join(here, "cli_c2.tsv"), names, reads, s.process_batch([r.encode() for r in reads], True), True)
+    # the same pairs through ktrim=n: per-read TSV and the masked FASTQ (symbol N, quality '!')
+    s = Spec(Args(k=23, mink=11, hdist=1, ktrimN=True)); s.load_fasta(ADAPTERS)
+    out = s.process_batch([r.encode() for r in reads], True)
+    tsv(os.path.join(here, "cli_kmask.tsv"), names, reads, out, False)
+    with open(os.path.join(here, "cli_kmask_expected.fq"), "w") as f:
+        for i, (nm, r, m) in enumerate(zip(names, reads, s.masks)):
+            q = [chr(33 + (7 * (i // 2) + 3 * j) % 41) for j in range(len(r))]      # write_fastq's qualities (index within its file)
+            b = list(r)
+            for j in range(len(r)):
+                if (m >> j) & 1:
+                    b[j] = "N"; q[j] = "!"
+            f.write("@%s\n%s\n+\n%s\n" % (nm, "".join(b), "".join(q)))
     # interleaved, kfilter against phiX (configs[2] flags)
     reads = synth_reads(13, 100, contam=phix, contam_frac=0.3, sub_rate=0.01, n_rate=0.002)
     names = ["%d_%d_%d /%d" % (i // 2, len(reads[i - i % 2]), len(reads[i - i % 2 + 1]), i % 2 + 1) for i in range(len(reads))]

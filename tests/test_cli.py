@@ -61,3 +61,14 @@ def test_cli_kfilter_interleaved_matches_spec_tsv(tmp_path):
     assert r.returncode == 0, r.stderr
     assert open(tsv).read() == open(os.path.join(GOLD, "cli_c3.tsv")).read()
     assert "Contaminants:" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_kmask_masks_bases_like_the_spec(tmp_path):
+    tsv, out = str(tmp_path / "o.tsv"), str(tmp_path / "masked.fq")
+    r = run_cli(["in=" + os.path.join(GOLD, "cli_c2_r1.fq"), "in2=" + os.path.join(GOLD, "cli_c2_r2.fq"), "tsv=" + tsv, "out=" + out,
+                 "batch=50", "ktrim=n", "k=23", "mink=11", "hdist=1", "ref=adapters"])
+    assert r.returncode == 0, r.stderr
+    assert open(tsv).read() == open(os.path.join(GOLD, "cli_kmask.tsv")).read()
+    assert open(out).read() == open(os.path.join(GOLD, "cli_kmask_expected.fq")).read()
+    assert "KMasked:" in r.stderr

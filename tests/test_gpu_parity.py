@@ -243,3 +243,57 @@ def test_device_operator_and_full_size_properties():
     d.gpu.process_batch_device(db[half * 150:], off2, True, da[half:], di[half:], df[half:], dc2, st)
     torch.cuda.synchronize()
     assert np.array_equal(da.cpu().numpy(), a) and np.array_equal(df.cpu().numpy(), fl) and np.array_equal(dc2.cpu().numpy(), c)
+
+
+# ---- ktrim=n (kmask): counts, ids, flags, counters and the per-base masks
+KMASK = [("ktrim=n k=23", dict(k=23, ktrimN=1)), ("ktrim=N k=23 mink=11 hdist=1", dict(k=23, ktrimN=1, mink=11, hdist=1)),
+         ("kmask=lc k=15 tp=2 forbidn=t restrictright=50", dict(k=15, ktrimN=1, trimPad=2, forbidN=1, restrictRight=50)),
+         ("ktrim=n k=12 mink=5 tp=-2 qhdist=1 mm=f", dict(k=12, ktrimN=1, mink=5, trimPad=-2, qhdist=1, maskMiddle=0)),
+         ("kmask=t k=17 rieb=f minlen=40 skipr1=t", dict(k=17, ktrimN=1, requireBothBad=1, minReadLength=40, skipR1=1)),
+         ("ktrim=n k=31 mink=1 speed=3 qskip=2", dict(k=31, ktrimN=1, mink=1, speed=3, qSkip=2))]
+
+
+def check_kmask(d, o, reads, paired):
+    b, off = pack_reads(reads)
+    d.gpu.reset_counters(); o.reset_counters()
+    ga, gi, gf, gm = d.gpu.kmask_batch(b, off, paired)
+    oa, oi, of, om = o.process_batch_mask(b, off, paired, nthreads=4)
+    bad = np.nonzero((ga != oa) | (gi != oi) | (gf != of))[0]
+    assert len(bad) == 0, [(int(i), reads[i], (int(ga[i]), int(gi[i]), int(gf[i])), (int(oa[i]), int(oi[i]), int(of[i]))) for i in bad[:3]]
+    nw = (int(off[-1]) + 31) // 32
+    assert np.array_equal(gm[:nw], om[:nw])
+    assert np.array_equal(d.gpu.counters(), o.counters())
+    return int(ga.sum())
+
+
+@pytest.mark.parametrize("ci", range(len(KMASK)))
+def test_kmask_fuzz_parity(ci):
+    args, okw = KMASK[ci]
+    total = 0
+    for seed in range(3):
+        rng = random.Random(900 * ci + seed)
+        refs = [util.rand_seq(rng, rng.randint(8, 90), 0.01) for _ in range(8)]
+        d, o = make_pair(args, okw, refs=refs)
+        reads = util.fuzz_reads(rng, refs, 600, [0, 1, 2, 5, 10, 11, 22, 23, 30, 31, 32, 40, 63, 64, 65, 75, 150, 151, 300], junk=True)
+        total += check_kmask(d, o, reads, True)
+        total += check_kmask(d, o, reads[:301], False)
+        d.close()
+    assert total > 0
+
+
+def test_kmask_adapters_and_long_reads():
+    d, o = make_pair("ktrim=n k=23 mink=11 hdist=1 ref=adapters", dict(k=23, ktrimN=1, mink=11, hdist=1), ref_fasta=util.ADAPTERS)
+    b, off = B.synth_generate_host(B.synth_params(31), 0, 5000)
+    d.gpu.reset_counters(); o.reset_counters()
+    ga, gi, gf, gm = d.gpu.kmask_batch(b, off, True)
+    oa, oi, of, om = o.process_batch_mask(b, off, True, nthreads=8)
+    assert np.array_equal(ga, oa) and np.array_equal(gi, oi) and np.array_equal(gf, of)
+    assert np.array_equal(gm[:len(om) - 1], om[:-1]) and np.array_equal(d.gpu.counters(), o.counters())
+    assert int((ga > 0).sum()) > 1000
+    rng = random.Random(5)
+    ad = B.TRUSEQ_R1
+    longs = [util.rand_seq(rng, n, 0.001) + ad + util.rand_seq(rng, 40) for n in (1000, 5000, 16000 - len(ad) - 40)] + [ad, b"", ad[:12]]
+    assert check_kmask(d, o, longs, False) > 0
+    with pytest.raises(B.BBDukError):
+        d.gpu.ktrim_batch(b, off, True)                        # the handle was created for ktrim=n
+    d.close()
