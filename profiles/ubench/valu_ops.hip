@@ -63,6 +63,29 @@ __global__ void k(uint32_t* out, int iters, uint32_t seed) {
         if (KIND == 52) { CHAIN8("v_lshl_or_b32 %0, %0, 2, %1") }
         if (KIND == 53) { CHAIN8("v_ashrrev_i32 %0, 4, %0") }
         if (KIND == 54) { CHAIN8("v_subrev_u32 %0, s12, %0") }
+        if (KIND == 60) { CHAIN8("v_fma_f32 %0, %0, %2, %1") }
+        if (KIND == 61) { CHAIN8("v_add_f32 %0, %0, %2") }
+        if (KIND == 62) { CHAIN8("v_mul_f32 %0, %0, %2") }
+        if (KIND == 63) { CHAIN8("v_and_b32 %0, 0x0f0f0f0f, %0") }
+        if (KIND == 64) { CHAIN8("v_cvt_f32_u32 %0, %0") }
+        if (KIND == 70) { CHAIN8("v_and_b32 %0, %2, %0") }
+        if (KIND == 71) { CHAIN8("v_and_b32 %0, s12, %0") }
+        if (KIND == 72) { CHAIN8("v_and_b32 %0, 0x0f0f0f0f, %0") }
+        if (KIND == 73) { CHAIN8("v_and_b32 %0, 15, %0") }
+        if (KIND == 74) { CHAIN8("v_lshrrev_b32 %0, %2, %0") }
+        if (KIND == 75) { CHAIN8("v_lshrrev_b32 %0, s12, %0") }
+        if (KIND == 76) { CHAIN8("v_lshrrev_b32 %0, 3, %0") }
+        if (KIND == 77) { CHAIN8("v_mul_lo_u32 %0, %0, %2") }
+        if (KIND == 78) { CHAIN8("v_mul_lo_u32 %0, %0, s12") }
+        if (KIND == 79) { CHAIN8("v_add_u32 %0, %2, %0") }
+        if (KIND == 80) { CHAIN8("v_add_u32 %0, s12, %0") }
+        if (KIND == 81) { CHAIN8("v_add_u32 %0, 17, %0") }
+        if (KIND == 82) { CHAIN8("v_alignbit_b32 %0, %0, %1, s12") }
+        if (KIND == 83) { CHAIN8("v_alignbit_b32 %0, %0, %1, 7") }
+        if (KIND == 84) { CHAIN8("v_cndmask_b32 %0, %0, %1, s[10:11]") }
+        if (KIND == 85) { CHAIN8("v_cmp_gt_u32 s[10:11], %0, %2") }
+        if (KIND == 86) { CHAIN8("v_xor_b32 %0, %2, %0") }
+        if (KIND == 87) { CHAIN8("v_xor_b32 %0, s12, %0") }
         if (KIND == 20) {  // 64-bit: compare
             asm volatile("v_cmp_gt_u64 vcc, %0, %1" :: "v"(q0), "v"(q1)); asm volatile("v_cmp_gt_u64 vcc, %0, %1" :: "v"(q1), "v"(q2));
             asm volatile("v_cmp_gt_u64 vcc, %0, %1" :: "v"(q2), "v"(q3)); asm volatile("v_cmp_gt_u64 vcc, %0, %1" :: "v"(q3), "v"(q0));
@@ -114,6 +137,14 @@ int main() {
         run<40>("v_not_b32", w); run<41>("v_xad_u32", w); run<42>("v_or3_b32", w); run<43>("v_and_b32 sgpr", w); run<44>("v_lshrrev_b32 imm", w);
         run<45>("v_bfi_b32", w); run<46>("v_xor_b32 literal", w); run<47>("v_add_co_u32", w); run<48>("v_bitop3 sgpr", w); run<50>("v_bcnt_u32_b32", w);
         run<51>("v_mbcnt_lo", w); run<52>("v_lshl_or_b32", w); run<53>("v_ashrrev_i32", w); run<54>("v_subrev_u32 sgpr", w);
+        run<60>("v_fma_f32", w); run<61>("v_add_f32", w); run<62>("v_mul_f32", w); run<63>("v_and_b32 literal", w); run<64>("v_cvt_f32_u32", w);
+        printf("-- operand source --\n");
+        run<70>("and vgpr", w); run<71>("and sgpr", w); run<72>("and literal", w); run<73>("and inline", w);
+        run<74>("lshr vgpr", w); run<75>("lshr sgpr", w); run<76>("lshr imm", w);
+        run<77>("mul_lo vgpr", w); run<78>("mul_lo sgpr", w);
+        run<79>("add vgpr", w); run<80>("add sgpr", w); run<81>("add inline", w);
+        run<82>("alignbit sgpr", w); run<83>("alignbit imm", w); run<84>("cndmask sgprmask", w); run<85>("cmp->sgpr", w);
+        run<86>("xor vgpr", w); run<87>("xor sgpr", w);
         run<20>("v_cmp_gt_u64", w); run<21>("v_lshrrev_b64", w); run<22>("v_mad_u64_u32", w); run<23>("v_lshl_add_u64", w);
     }
     return 0;
