@@ -783,6 +783,21 @@ __device__ __forceinline__ void main_scan_pair_cand(const KParams& P, const Plan
         uint64_t kmer[4], rk[4]; bool ok[4]; int ref[4]; Cand4 C;
         windows2<FORBIDN, GENERAL>(P, Q, WA, ibA + 2 * lane, onA, kmer, rk, ok);
         windows2<FORBIDN, GENERAL>(P, Q, WB, ibB + 2 * lane, onB, kmer + 2, rk + 2, ok + 2);
+#ifdef BBDUK_TIMING_SWITCHES
+        if (TSW(P, 8)) {                                             // experiment: 16 extra dependent-free VALU ops per block
+            uint32_t z0 = (uint32_t)kmer[0], z1 = (uint32_t)kmer[1], z2 = (uint32_t)kmer[2], z3 = (uint32_t)kmer[3];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { asm volatile("v_xor_b32 %0, %0, %1" : "+v"(z0) : "v"(z1)); asm volatile("v_xor_b32 %0, %0, %1" : "+v"(z1) : "v"(z2));
+                                          asm volatile("v_xor_b32 %0, %0, %1" : "+v"(z2) : "v"(z3)); asm volatile("v_xor_b32 %0, %0, %1" : "+v"(z3) : "v"(z0)); }
+            if (z0 == 0x12345u && z1 == z2 && z3 == 7u) kmer[0] ^= 1;
+        }
+        if (TSW(P, 9)) {                                             // experiment: 16 extra SALU ops per block
+            uint32_t u0 = (uint32_t)__builtin_amdgcn_readfirstlane(ibA), u1 = (uint32_t)__builtin_amdgcn_readfirstlane(ibB);
+#pragma unroll
+            for (int q = 0; q < 8; q++) { asm volatile("s_xor_b32 %0, %0, %1" : "+s"(u0) : "s"(u1)); asm volatile("s_add_u32 %0, %0, %1" : "+s"(u1) : "s"(u0) : "scc"); }
+            if (u0 == 0x12345u && u1 == 99u) kmer[0] ^= 1;
+        }
+#endif
         if (cand_probe4<GENERAL, NOMM, true>(P, Q.filt, kmer, rk, C) == 0ULL) {   // the common block: nothing to look at
             if (onA) { ibA += 128; onA = ibA < WA.stop; }
             if (onB) { ibB += 128; onB = ibB < WB.stop; }
