@@ -297,3 +297,30 @@ def test_kmask_adapters_and_long_reads():
     with pytest.raises(B.BBDukError):
         d.gpu.ktrim_batch(b, off, True)                        # the handle was created for ktrim=n
     d.close()
+
+
+def test_concurrent_submitters_share_one_handle():
+    """The boundary promises what the JNI convention needs: many host threads may call the batch operator
+    on one handle at once; every caller gets its own batch's results and the counters add up."""
+    import threading
+    args, okw, ref = util.CONFIGS["c2"]
+    d, o = make_pair(args, okw, ref_fasta=ref)
+    batches = [B.synth_generate_host(B.synth_params(40 + t), 0, 3000 + 500 * t) for t in range(6)]
+    want = []
+    o.reset_counters()
+    for b, off in batches:
+        want.append(o.process_batch(b, off, True, nthreads=4))
+    d.gpu.reset_counters()
+    got = [None] * len(batches)
+
+    def work(t):
+        for _ in range(3):                                      # several calls per thread, interleaved with the others
+            got[t] = d.gpu.process_batch(batches[t][0], batches[t][1], True)
+    th = [threading.Thread(target=work, args=(t,)) for t in range(len(batches))]
+    for x in th: x.start()
+    for x in th: x.join()
+    for t in range(len(batches)):
+        for g, w in zip(got[t], want[t]):
+            assert np.array_equal(g, w), t
+    assert np.array_equal(d.gpu.counters(), 3 * o.counters())   # every batch was counted three times
+    d.close()
