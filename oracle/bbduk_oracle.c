@@ -573,12 +573,11 @@ static int trim_to_position(int len, int leftLoc, int rightLoc, int minResulting
 
 /* bbduk/BBDukProcessorS.java:1993-2140 ktrim(Read,start,stop).  *newLen = r.length() afterwards. */
 static int ktrim_span(const bbo_ctx* c, tcounters* tc, const uint8_t* bases, const int blen, const int pairnum,
-                      const int start, const int stop, int* id0out, int* newLen) {
+                      const int start, const int stop, const int ktrimLeft, const int ktrimRight, int* id0out, int* newLen) {
     const int k = c->k;
     *newLen = blen; *id0out = -1;
     if (blen < imax(1, (c->useShortKmers ? imin(k, c->mink) : k)) || c->storedKmers < 1) return 0;
     if ((c->a.skipR1 && pairnum == 0) || (c->a.skipR2 && pairnum == 1)) return 0;
-    const int ktrimLeft = c->a.ktrimLeft, ktrimRight = c->a.ktrimRight;
     int64_t kmer = 0, rkmer = 0;
     int found = 0, len = 0, id0 = -1;
     int minLoc = 999999999, minLocExclusive = 999999999;
@@ -670,7 +669,29 @@ static int ktrim_span(const bbo_ctx* c, tcounters* tc, const uint8_t* bases, con
 static int ktrim_read(const bbo_ctx* c, tcounters* tc, const uint8_t* bases, int len, int pairnum, int* id0, int* newLen) {
     const int start = (c->a.restrictRight < 1 ? 0 : imax(0, len - c->a.restrictRight));
     const int stop  = (c->a.restrictLeft  < 1 ? len : imin(len, c->a.restrictLeft));
-    return ktrim_span(c, tc, bases, len, pairnum, start, stop, id0, newLen);
+    return ktrim_span(c, tc, bases, len, pairnum, start, stop, c->a.ktrimLeft, c->a.ktrimRight, id0, newLen);
+}
+
+/* bbduk/BBDukProcessorS.java:1813-1828 ktrimTips: a right pass over [start,len), then a left pass over [0,stop) of the
+ * read as the right pass left it (its first *newLen bases).  ktrimTip (:1832-1985) is ktrim(Read,start,stop) with the
+ * side given explicitly.  *xLeft = what the left pass removed. */
+static int ktrim_tips_read(const bbo_ctx* c, tcounters* tc, const uint8_t* bases, int len, int pairnum, int* id0, int* newLen, int* xLeft) {
+    const int k = c->k;
+    const int mid = len / 2 - (k - 1) / 2;
+    int sum = 0, cur = len, idr = -1, idl = -1;
+    *xLeft = 0;
+    if (c->a.ktrimRight) {
+        const int start = imax(0, (c->a.restrictRight < 1 ? mid : len - c->a.restrictRight));
+        sum += ktrim_span(c, tc, bases, cur, pairnum, start, cur, 0, 1, &idr, &cur);
+    }
+    if (c->a.ktrimLeft) {
+        const int stop = imin(cur, (c->a.restrictLeft < 1 ? mid + k - 1 : c->a.restrictLeft));
+        const int x = ktrim_span(c, tc, bases, cur, pairnum, 0, stop, 1, 0, &idl, &cur);
+        sum += x; *xLeft = x;
+    }
+    *id0 = idr >= 0 ? idr : idl;
+    *newLen = cur;
+    return sum;
 }
 
 /* bbduk/BBDukProcessorS.java:1534-1593 countSetKmers */
@@ -860,7 +881,7 @@ int bbo_count_set_kmers(bbo_ctx* c, const uint8_t* bases, int len, int pairnum, 
  * Everything before the k-mer stage (junk/chastity/GC/force-trim...) and after it (tbo/qtrim/...) is off
  * in every BASELINE config and stays in the Java host. */
 static void process_pair(const bbo_ctx* c, tcounters* tc, const uint8_t* b1, int l1, const uint8_t* b2, int l2, int has2,
-                         int32_t* a, int32_t* ids, uint8_t* fl, uint32_t* gmask, int64_t g1, int64_t g2) {
+                         int32_t* a, int32_t* ids, uint8_t* fl, uint32_t* gmask, int64_t g1, int64_t g2, int32_t* xleft) {
     const int initialLength1 = l1, initialLength2 = has2 ? l2 : 0;
     const int pairCount = has2 ? 2 : 1;
     const int minlen1 = (int)((float)initialLength1 * c->a.minLenFraction > (float)c->a.minReadLength ?
@@ -892,14 +913,16 @@ static void process_pair(const bbo_ctx* c, tcounters* tc, const uint8_t* b1, int
         tc->counters[BBO_READS_KTRIMMED] += rktsum;
     } else if (doKmerTrimming) {                                                      /* :948-1033 */
         int rlen1 = 0, rlen2 = 0, xsum = 0, rktsum = 0;
+        const int tips = c->a.ktrimLeft && c->a.ktrimRight;                           /* :771, 954-967 */
+        int xl1 = 0, xl2 = 0;
         {
-            int id0; int x = ktrim_read(c, tc, b1, l1, 0, &id0, &newLen1);
+            int id0; int x = tips ? ktrim_tips_read(c, tc, b1, l1, 0, &id0, &newLen1, &xl1) : ktrim_read(c, tc, b1, l1, 0, &id0, &newLen1);
             xsum += x; rktsum += (x > 0 ? 1 : 0); rlen1 = newLen1;
             if (rlen1 < minlen1) d1 = 1;
             a[0] = x; ids[0] = id0;
         }
         if (has2) {
-            int id0; int x = ktrim_read(c, tc, b2, l2, 1, &id0, &newLen2);
+            int id0; int x = tips ? ktrim_tips_read(c, tc, b2, l2, 1, &id0, &newLen2, &xl2) : ktrim_read(c, tc, b2, l2, 1, &id0, &newLen2);
             xsum += x; rktsum += (x > 0 ? 1 : 0); rlen2 = newLen2;
             if (rlen2 < minlen2) d2 = 1;
             a[1] = x; ids[1] = id0;
@@ -918,6 +941,7 @@ static void process_pair(const bbo_ctx* c, tcounters* tc, const uint8_t* b1, int
         }
         tc->counters[BBO_BASES_KTRIMMED] += xsum;                                     /* :1028-1029 */
         tc->counters[BBO_READS_KTRIMMED] += rktsum;
+        if (xleft) { xleft[0] = xl1; if (has2) xleft[1] = xl2; }
     } else if (doKmerFiltering && c->a.minCoveredFraction > 0) {                      /* :1038-1049 */
         int id;
         const int mc1 = (int)ceil((double)(c->a.minCoveredFraction * (float)l1));
@@ -969,7 +993,7 @@ static void process_pair(const bbo_ctx* c, tcounters* tc, const uint8_t* b1, int
 
 typedef struct {
     const bbo_ctx* c; const uint8_t* bases; const int64_t* offsets; int64_t n; int paired;
-    int32_t* out_a; int32_t* out_id; uint8_t* out_flags; uint32_t* out_mask; int64_t u0, u1; tcounters tc;
+    int32_t* out_a; int32_t* out_id; uint8_t* out_flags; uint32_t* out_mask; int32_t* out_left; int64_t u0, u1; tcounters tc;
 } job;
 
 static void* job_run(void* p) {
@@ -981,7 +1005,7 @@ static void* job_run(void* p) {
         const uint8_t* b2 = NULL; int l2 = 0;
         if (j->paired) { b2 = j->bases + j->offsets[r + 1]; l2 = (int)(j->offsets[r + 2] - j->offsets[r + 1]); }
         process_pair(j->c, &j->tc, b1, l1, b2, l2, j->paired, j->out_a + r, j->out_id + r, j->out_flags + r, j->out_mask,
-                     j->offsets[r], j->paired ? j->offsets[r + 1] : 0);
+                     j->offsets[r], j->paired ? j->offsets[r + 1] : 0, j->out_left ? j->out_left + r : NULL);
     }
     return NULL;
 }
@@ -992,6 +1016,10 @@ int bbo_process_batch(bbo_ctx* c, const uint8_t* bases, const int64_t* offsets, 
 }
 int bbo_process_batch_mask(bbo_ctx* c, const uint8_t* bases, const int64_t* offsets, int64_t n, int paired,
                            int32_t* out_a, int32_t* out_id, uint8_t* out_flags, uint32_t* out_mask, int nthreads) {
+    return bbo_process_batch_ex(c, bases, offsets, n, paired, out_a, out_id, out_flags, out_mask, NULL, nthreads);
+}
+int bbo_process_batch_ex(bbo_ctx* c, const uint8_t* bases, const int64_t* offsets, int64_t n, int paired,
+                         int32_t* out_a, int32_t* out_id, uint8_t* out_flags, uint32_t* out_mask, int32_t* out_left, int nthreads) {
     if (paired && (n & 1)) return -1;
     if (nthreads < 1) nthreads = 1;
     const int64_t units = paired ? n / 2 : n;
@@ -1002,7 +1030,7 @@ int bbo_process_batch_mask(bbo_ctx* c, const uint8_t* bases, const int64_t* offs
     for (int t = 0; t < nthreads; t++) {
         job* j = &jobs[t];
         j->c = c; j->bases = bases; j->offsets = offsets; j->n = n; j->paired = paired;
-        j->out_a = out_a; j->out_id = out_id; j->out_flags = out_flags; j->out_mask = out_mask;
+        j->out_a = out_a; j->out_id = out_id; j->out_flags = out_flags; j->out_mask = out_mask; j->out_left = out_left;
         j->u0 = units * t / nthreads; j->u1 = units * (t + 1) / nthreads;
         j->tc.scafReads = (int64_t*)calloc((size_t)ns, sizeof(int64_t));             /* thread-local copies (:272-277) */
         j->tc.scafBases = (int64_t*)calloc((size_t)ns, sizeof(int64_t));

@@ -117,6 +117,9 @@ int      bbo_count_set_kmers(bbo_ctx* c, const uint8_t* bases, int len, int pair
  * concatenated `bases` buffer is masked (caller zeroes the (offsets[n]+31)/32 words). */
 int      bbo_process_batch_mask(bbo_ctx* c, const uint8_t* bases, const int64_t* offsets, int64_t n, int paired,
                                 int32_t* out_a, int32_t* out_id, uint8_t* out_flags, uint32_t* out_mask, int nthreads);
+/* everything at once: out_mask (ktrim=n) and out_left (ktrim=rl: what the left pass removed; out_a = right + left) may be NULL */
+int      bbo_process_batch_ex(bbo_ctx* c, const uint8_t* bases, const int64_t* offsets, int64_t n, int paired,
+                              int32_t* out_a, int32_t* out_id, uint8_t* out_flags, uint32_t* out_mask, int32_t* out_left, int nthreads);
 int      bbo_process_batch(bbo_ctx* c, const uint8_t* bases, const int64_t* offsets, int64_t n, int paired,
                            int32_t* out_a, int32_t* out_id, uint8_t* out_flags, int nthreads);
 

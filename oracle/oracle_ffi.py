@@ -58,6 +58,8 @@ def lib():
         L.bbo_get_value.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int]
         L.bbo_ktrim_read.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
         L.bbo_count_set_kmers.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.bbo_process_batch_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.bbo_process_batch_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.bbo_process_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
@@ -188,6 +190,18 @@ class Oracle:
         if rc != 0:
             raise ValueError("bbo_process_batch_mask rc=%d" % rc)
         return a, ids, fl, mask
+
+    def process_batch_tips(self, bases: np.ndarray, offsets: np.ndarray, paired: bool, nthreads: int = 1):
+        """ktrim=rl: (right amounts, left amounts, ids, flags)."""
+        n = len(offsets) - 1
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        a = np.empty(n, np.int32); ids = np.empty(n, np.int32); fl = np.zeros(n, np.uint8); left = np.zeros(n, np.int32)
+        rc = lib().bbo_process_batch_ex(self.h, bases.ctypes.data, offsets.ctypes.data, n, int(paired),
+                                        a.ctypes.data, ids.ctypes.data, fl.ctypes.data, None, left.ctypes.data, nthreads)
+        if rc != 0:
+            raise ValueError("bbo_process_batch_ex rc=%d" % rc)
+        return a - left, left, ids, fl
 
     def counters(self) -> np.ndarray:
         out = np.zeros(lib().bbo_counters_len(self.h), np.int64)

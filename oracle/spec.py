@@ -113,6 +113,7 @@ class Spec:
         self.scafReads = [0]
         self.scafBases = [0]
         self.masks = []            # ktrim=n: per-read base masks of the reads processed so far (process order)
+        self.tips = []             # ktrim=rl: per-read (right, left) trim amounts, process order
 
     # ---------------------------------------------------------------- keys
     def key_of(self, kmer: int, rkmer: int, length: int) -> int:
@@ -244,12 +245,33 @@ class Spec:
 
     def ktrim(self, read: bytes, pairnum: int):
         """Returns (x, id0, newLen).  bbduk/BBDukProcessorS.java:1806-1811, 1993-2140."""
+        start, stop = self._span(len(read))
+        return self._ktrim_span(read, pairnum, start, stop, self.a.ktrimLeft, self.a.ktrimRight)
+
+    def ktrim_tips(self, read: bytes, pairnum: int):
+        """ktrim=rl / ktrimtips.  Returns (x, id0, newLen, xRight, xLeft).  bbduk/BBDukProcessorS.java:1813-1985: a right
+        pass over [start, len) and then a left pass over [0, stop) of the already right-trimmed read."""
+        a, k, n = self.a, self.k, len(read)
+        mid = n // 2 - (k - 1) // 2
+        xr = xl = 0; id0 = -1; cur = read
+        if a.ktrimRight:
+            start = max(0, mid if a.restrictRight < 1 else n - a.restrictRight)
+            xr, id0, nl = self._ktrim_span(cur, pairnum, start, n, False, True)
+            cur = cur[:nl]
+        if a.ktrimLeft:
+            stop = min(len(cur), mid + k - 1 if a.restrictLeft < 1 else a.restrictLeft)
+            xl, idl, nl = self._ktrim_span(cur, pairnum, 0, stop, True, False)
+            cur = cur[len(cur) - nl:]
+            if id0 < 0: id0 = idl
+        return xr + xl, id0, len(cur), xr, xl
+
+    def _ktrim_span(self, read: bytes, pairnum: int, start: int, stop: int, left: bool, right: bool):
+        """ktrim(Read,start,stop) (:1993-2140) == ktrimTip(Read,start,stop,right,left) (:1832-1985)."""
         a, k, n = self.a, self.k, len(read)
         if n < max(1, min(k, self.mink) if self.useShortKmers else k) or not self.table:
             return 0, -1, n
         if (a.skipR1 and pairnum == 0) or (a.skipR2 and pairnum == 1):
             return 0, -1, n
-        start, stop = self._span(n)
         hits = list(self._main_hits(read, start, stop))
         BIG = 999999999
         found, id0 = len(hits), (hits[0][1] if hits else -1)
@@ -258,7 +280,7 @@ class Spec:
         minLocEx = minLoc + k if hits else BIG
         maxLocEx = maxLoc - k if hits else -1
         if self.useShortKmers and found == 0:
-            if a.ktrimLeft:                                   # :2037-2069
+            if left:                                          # :2037-2069
                 for i in range(start, min(k, stop)):
                     s = read[start:i + 1]
                     L = len(s)
@@ -278,7 +300,7 @@ class Spec:
                         maxLoc = max(maxLoc, i)
                         maxLocEx = max(maxLocEx, 0)
                         found += 1
-            if a.ktrimRight:                                  # :2072-2102
+            if right:                                         # :2072-2102
                 for L in range(1, (k - 1 if stop >= k else stop) + 1):
                     i = stop - L
                     if L < self.mink:
@@ -309,7 +331,7 @@ class Spec:
             minLoc = mid(0, minLoc - a.trimPad, n)
             maxLocEx = mid(0, maxLocEx + a.trimPad, n)
             minLocEx = mid(0, minLocEx - a.trimPad, n)
-        if a.ktrimLeft:
+        if left:
             leftLoc, rightLoc = (maxLocEx + 1 if a.ktrimExclusive else maxLoc + 1), n - 1
         else:
             leftLoc, rightLoc = 0, (minLocEx - 1 if a.ktrimExclusive else minLoc - 1)
@@ -452,12 +474,20 @@ class Spec:
             res = [(x1, i1)] + ([(x2, i2)] if has2 else [])
             self.masks += [m1] + ([m2] if has2 else [])
         elif self.table and (a.ktrimLeft or a.ktrimRight):
-            x1, i1, n1 = self.ktrim(r1, 0)
+            tips = a.ktrimLeft and a.ktrimRight                                        # :771, 954-967
+            if tips:
+                x1, i1, n1, xr1, xl1 = self.ktrim_tips(r1, 0)
+            else:
+                x1, i1, n1 = self.ktrim(r1, 0)
             xsum, rkt = x1, int(x1 > 0)
             d1 = n1 < minlen1
             x2 = 0; i2 = -1
+            xr2 = xl2 = 0
             if has2:
-                x2, i2, n2 = self.ktrim(r2, 1)
+                if tips:
+                    x2, i2, n2, xr2, xl2 = self.ktrim_tips(r2, 1)
+                else:
+                    x2, i2, n2 = self.ktrim(r2, 1)
                 xsum += x2; rkt += int(x2 > 0)
                 d2 = n2 < minlen2
             if (self.rieb and (d1 or d2)) or (d1 and (not has2 or d2)):
@@ -465,12 +495,16 @@ class Spec:
             elif a.ktrimRight and a.trimPairsEvenly and xsum > 0 and has2 and n1 != n2:        # :1021-1031
                 if n1 > n2:
                     x, n1 = self._trim_by_amount(n1, 0, n1 - (n2 - 1) - 1, 1); x1 += x
+                    if tips: xr1 += x
                 else:
                     x, n2 = self._trim_by_amount(n2, 0, n2 - (n1 - 1) - 1, 1); x2 += x
+                    if tips: xr2 += x
                 if rkt < 2: rkt += 1
                 xsum += x
             C[3] += xsum; C[2] += rkt
             res = [(x1, i1)] + ([(x2, i2)] if has2 else [])
+            if tips:
+                self.tips += [(xr1, xl1)] + ([(xr2, xl2)] if has2 else [])
         elif self.table and a.minCoveredFraction > 0:                                  # :1038-1049
             import math
             mc1 = int(math.ceil(float(f32(a.minCoveredFraction) * f32(l1))))

@@ -140,6 +140,36 @@ def spec_mask_words(reads, masks, nwords):
     return out
 
 
+TIPS_FUZZ = [dict(k=11, ktrimLeft=1, ktrimRight=1), dict(k=13, ktrimLeft=1, ktrimRight=1, mink=6, hdist=1),
+             dict(k=15, ktrimLeft=1, ktrimRight=1, restrictLeft=30, restrictRight=25, trimPad=1, forbidN=1),
+             dict(k=12, ktrimLeft=1, ktrimRight=1, mink=5, trimPairsEvenly=1, ktrimExclusive=1, maskMiddle=0),
+             dict(k=17, ktrimLeft=1, ktrimRight=1, requireBothBad=1, minReadLength=40, qhdist=1)]
+
+
+@pytest.mark.parametrize("ci", range(len(TIPS_FUZZ)))
+def test_differential_fuzz_ktrimtips(ci):
+    """ktrim=rl (tips): totals, ids, flags, counters and the (right, left) split of both restatements."""
+    kw = TIPS_FUZZ[ci]
+    for seed in range(5):
+        rng = random.Random(9000 + 100 * ci + seed)
+        refs = [util.rand_seq(rng, rng.randint(8, 80), 0.01) for _ in range(6)]
+        o = Oracle(**kw)
+        s = Spec(Args(**{k: (bool(v) if k in BOOLS else v) for k, v in kw.items()}))
+        for r in refs:
+            o.add_ref(r); s.add_ref(r)
+        reads = util.fuzz_reads(rng, refs, 40, [0, 1, 5, 10, 11, 22, 23, 30, 31, 40, 75, 150], junk=True)
+        for paired in (True, False):
+            o.reset_counters()
+            s.counters = [0] * 16; s.scafReads = [0] * s.nscaf; s.scafBases = [0] * s.nscaf; s.tips = []
+            b, off = pack_reads(reads)
+            xr, xl, ids, fl = o.process_batch_tips(b, off, paired, nthreads=3)
+            want = s.process_batch(reads, paired)
+            assert list(zip((xr + xl).tolist(), ids.tolist(), fl.tolist())) == want
+            assert list(zip(xr.tolist(), xl.tolist())) == s.tips
+            assert o.counters().tolist() == s.all_counters()
+        assert any(l > 0 or r > 0 for r, l in s.tips)
+
+
 @pytest.mark.parametrize("ci", range(len(KMASK_FUZZ)))
 def test_differential_fuzz_kmask(ci):
     """ktrim=n (kmask): masked-base counts, ids, flags, counters and the per-base masks of both restatements."""
