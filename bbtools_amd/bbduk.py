@@ -15,7 +15,7 @@ import numpy as np
 from ._build import lib_path
 
 OK = 0
-MODE_KFILTER, MODE_KTRIM_R, MODE_KTRIM_L, MODE_KMASK = 0, 1, 2, 3
+MODE_KFILTER, MODE_KTRIM_R, MODE_KTRIM_L, MODE_KMASK, MODE_KTRIM_TIPS = 0, 1, 2, 3, 4
 FLAG_DISCARDED, FLAG_REMOVED = 1, 2
 NCOUNTERS = 16
 COUNTER_NAMES = ["readsIn", "basesIn", "readsKTrimmed", "basesKTrimmed", "readsKFiltered", "basesKFiltered",
@@ -50,7 +50,7 @@ class SynthParams(C.Structure):     # struct bbduk_synth_params
 GPU_SYMBOLS = ["bbduk_abi_version", "bbduk_create", "bbduk_destroy", "bbduk_last_error", "bbduk_upload_table_way",
                "bbduk_upload_pairs", "bbduk_finalize_table", "bbduk_table_size", "bbduk_table_bytes",
                "bbduk_table_lookup", "bbduk_ktrim_batch", "bbduk_kfilter_batch", "bbduk_ktrim_batch_device",
-               "bbduk_kfilter_batch_device", "bbduk_kmask_batch", "bbduk_kmask_batch_device", "bbduk_kernel_time_ms", "bbduk_counters_len", "bbduk_get_counters", "bbduk_reset_counters",
+               "bbduk_kfilter_batch_device", "bbduk_kmask_batch", "bbduk_kmask_batch_device", "bbduk_ktrimtips_batch", "bbduk_ktrimtips_batch_device", "bbduk_kernel_time_ms", "bbduk_counters_len", "bbduk_get_counters", "bbduk_reset_counters",
                "bbduk_synth_generate_device", "bbduk_synth_generate_host"]
 HOST_SYMBOLS = ["bbduk_host_parse", "bbduk_host_destroy", "bbduk_host_add_ref", "bbduk_host_load_fasta",
                 "bbduk_host_load_refs", "bbduk_host_build_index", "bbduk_host_index_pairs",
@@ -89,6 +89,8 @@ def lib():
     for f in (L.bbduk_ktrim_batch, L.bbduk_kfilter_batch):
         f.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp]
     L.bbduk_kmask_batch.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, vp]
+    L.bbduk_ktrimtips_batch.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, vp]
+    L.bbduk_ktrimtips_batch_device.argtypes = [vp, vp, vp, i64, i64, i32, vp, vp, vp, vp, vp, vp]
     L.bbduk_kmask_batch_device.argtypes = [vp, vp, vp, i64, i64, i32, vp, vp, vp, vp, vp, vp]
     for f in (L.bbduk_ktrim_batch_device, L.bbduk_kfilter_batch_device):
         f.argtypes = [vp, vp, vp, i64, i64, i32, vp, vp, vp, vp, vp]
@@ -270,7 +272,19 @@ class BBDukGpu:
                                             a.ctypes.data, ids.ctypes.data, fl.ctypes.data, mask.ctypes.data), "kmask_batch")
         return a, ids, fl, mask
 
+    def ktrimtips_batch(self, bases, offsets, paired):
+        """ktrim=rl: (right amounts, left amounts, ids, flags)."""
+        bases = np.ascontiguousarray(bases, np.uint8); offsets = np.ascontiguousarray(offsets, np.int64)
+        n = len(offsets) - 1
+        xr = np.empty(n, np.int32); xl = np.empty(n, np.int32); ids = np.empty(n, np.int32); fl = np.empty(n, np.uint8)
+        self._check(lib().bbduk_ktrimtips_batch(self.h, bases.ctypes.data if len(bases) else None, offsets.ctypes.data, n, int(paired),
+                                                xr.ctypes.data, xl.ctypes.data, ids.ctypes.data, fl.ctypes.data), "ktrimtips_batch")
+        return xr, xl, ids, fl
+
     def process_batch(self, bases, offsets, paired):
+        if self.params.mode == MODE_KTRIM_TIPS:
+            xr, xl, ids, fl = self.ktrimtips_batch(bases, offsets, paired)
+            return xr + xl, ids, fl
         if self.params.mode == MODE_KMASK:
             return self.kmask_batch(bases, offsets, paired)[:3]
         if self.params.mode == MODE_KFILTER:

@@ -118,7 +118,7 @@ int main(int argc, char** argv) {
 
     const bool ktrim = P.mode != BBDUK_MODE_KFILTER;
     std::vector<Rec> recs; std::vector<uint8_t> bases; std::vector<int64_t> offsets;
-    std::vector<int32_t> res, ids; std::vector<uint8_t> fl; std::vector<uint32_t> mask;
+    std::vector<int32_t> res, ids, resL; std::vector<uint8_t> fl; std::vector<uint32_t> mask;
     bool eof = false; long long nread = 0;
     while (!eof) {
         recs.clear(); bases.clear(); offsets.assign(1, 0);
@@ -140,7 +140,10 @@ int main(int argc, char** argv) {
         res.resize(n); ids.resize(n); fl.resize(n);
         if (bases.empty()) bases.push_back(0);                       // an all-empty batch still needs a valid pointer
         int rc;
-        if (P.mode == BBDUK_MODE_KMASK) {
+        if (P.mode == BBDUK_MODE_KTRIM_TIPS) {
+            resL.resize(n);
+            rc = bbduk_ktrimtips_batch(dev, bases.data(), offsets.data(), n, paired, res.data(), resL.data(), ids.data(), fl.data());
+        } else if (P.mode == BBDUK_MODE_KMASK) {
             mask.assign((size_t)(offsets[n] + 31) / 32 + 1, 0u);
             rc = bbduk_kmask_batch(dev, bases.data(), offsets.data(), n, paired, res.data(), ids.data(), fl.data(), mask.data());
         } else rc = ktrim ? bbduk_ktrim_batch(dev, bases.data(), offsets.data(), n, paired, res.data(), ids.data(), fl.data())
@@ -151,6 +154,7 @@ int main(int argc, char** argv) {
             const int L = (int)r.bases.size();
             int left = 0, right = 0;                                 // TrimRead.trimByAmount(r, left, right, 1) with the returned amount
             if (P.mode == BBDUK_MODE_KTRIM_R) right = res[i]; else if (P.mode == BBDUK_MODE_KTRIM_L) left = res[i];
+            else if (P.mode == BBDUK_MODE_KTRIM_TIPS) { right = res[i]; left = resL[i]; res[i] += resL[i]; }     // the tsv shows the sum
             const int newLen = L - left - right;
             if (P.mode == BBDUK_MODE_KMASK && res[i] > 0) {            // :2309-2320
                 for (int b = 0; b < L; b++) {

@@ -1309,6 +1309,142 @@ void bbduk_kmask_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
 }
 
 // --------------------------------------------------------------------------------------------------
+// ktrim=rl / ktrimtips (bbduk/BBDukProcessorS.java:1813-1985): a right pass over [start, len) and then a left pass over
+// [0, stop) of the read as the right pass left it.  Like bbduk_kmask_kernel a secondary operator on the run-time-general
+// scan functions: one wave per read, the ktrim=r scan + finish with the right-hand span, then the ktrim=l scan + finish
+// on the shortened read (the planes still hold it: a right trim keeps a prefix).  Outputs the two amounts separately.
+__global__ __launch_bounds__(BLOCK_THREADS)
+void bbduk_ktrimtips_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
+                            const int64_t n, const int64_t totalBases, const int paired,
+                            int32_t* __restrict__ outRight, int32_t* __restrict__ outLeft, int32_t* __restrict__ outId,
+                            uint8_t* __restrict__ outFlags, int64_t* __restrict__ counters) {
+    __shared__ uint32_t s_fwd[PLANE_PAD + KM_CAP_CHUNKS + PLANE_PAD];
+    __shared__ uint32_t s_cmp[PLANE_PAD + KM_CAP_CHUNKS + PLANE_PAD];
+    __shared__ uint32_t s_nm[KM_CAP_CHUNKS / 2 + 4];
+    __shared__ int64_t  s_off[TILE_READS + 1];
+    __shared__ int32_t  s_xr[TILE_READS];
+    __shared__ int32_t  s_xl[TILE_READS];
+    __shared__ int32_t  s_len[TILE_READS];
+    __shared__ int32_t  s_id[TILE_READS];
+    __shared__ unsigned long long s_acc[6];                       // rkt, basesKTrimmed, readsOutm, basesOutm, readsIn, basesIn
+    extern __shared__ uint32_t s_filt[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+    const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
+    const int k = P.k;
+    ScafAcc scaf; scaf_init(scaf);
+    if (tid < 6) s_acc[tid] = 0;
+    if (P.ldsBits) {
+        const int words = 1 << (P.ldsBits - 5);
+        for (int w = tid; w < words; w += BLOCK_THREADS) s_filt[w] = P.ldsImage[w];
+    }
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t r0 = tile * TILE_READS;
+        const int cnt = (int)min((int64_t)TILE_READS, n - r0);
+        __syncthreads();
+        if (tid <= cnt) s_off[tid] = offsets[r0 + tid];
+        __syncthreads();
+        if (tid == 0) { s_acc[4] += (unsigned long long)cnt; s_acc[5] += (unsigned long long)(s_off[cnt] - s_off[0]); }
+        int s = 0;
+        while (s < cnt) {
+            const int64_t off_s = s_off[s];
+            const int cand = s + 1 + tid;
+            const int okc = (cand <= cnt) && (s_off[min(cand, cnt)] - off_s <= (int64_t)(KM_CAP_BASES - 32));
+            const int fit = uni(__syncthreads_count(okc));
+            if (fit == 0) {
+                if (tid == 0) { atomicMax((unsigned long long*)&counters[BBDUK_CTR_STATUS], (unsigned long long)(-BBDUK_ERR_READ_TOO_LONG));
+                                s_xr[s] = 0; s_xl[s] = 0; s_id[s] = -1; s_len[s] = (int)(s_off[s + 1] - s_off[s]); }
+                s += 1;
+                continue;
+            }
+            const int e = s + fit;
+            const int64_t B0 = off_s, B1 = s_off[e];
+            const int64_t A0 = B0 & ~15LL;
+            const int nchunks = (int)((B1 - A0 + 15) >> 4);
+            for (int c = tid; c < nchunks; c += BLOCK_THREADS) {
+                uint32_t r, comp, valid;
+                encode_chunk(bases, A0 + 16LL * c, totalBases, r, comp, valid);
+                s_fwd[PLANE_PAD + nchunks - 1 - c] = r;
+                s_cmp[PLANE_PAD + c] = comp;
+                reinterpret_cast<uint16_t*>(s_nm)[c] = (uint16_t)(~valid & 0xFFFFu);
+            }
+            if (tid == 0 && (nchunks & 1)) reinterpret_cast<uint16_t*>(s_nm)[nchunks] = 0;
+            __syncthreads();
+
+            Planes Q; Q.fwd = s_fwd + PLANE_PAD; Q.cmp = s_cmp + PLANE_PAD; Q.nm = s_nm; Q.filt = s_filt; Q.T = nchunks * 16;
+            Q.fwdBits = lds_bits_of(Q.fwd); Q.cmpBits = lds_bits_of(Q.cmp);
+            for (int rd = s + wave; rd < e; rd += NWAVES) {        // one wave per read
+                const int L = uni((int)(s_off[rd + 1] - s_off[rd]));
+                const int base0 = uni((int)(s_off[rd] - A0));
+                const int pairnum = paired ? (rd & 1) : 0;
+                const int mid = L / 2 - (k - 1) / 2;                // :1815
+                int cur = L, xr = 0, xl = 0, idr = -1, idl = -1;
+                ReadScan A, Bz;
+                auto reset = [&](ReadScan& R, int len, int start, int stop, bool scan) {
+                    R.base0 = base0; R.L = len; R.hasN = -1; R.maxBad = 0; R.start = start; R.stop = stop; R.scan = scan;
+                    R.found = 0; R.iFirst = BIGLOC; R.iLast = -1; R.ref = -1; R.shortFl = -1; R.shortLl = -1;
+                };
+                reset(Bz, 0, 0, 0, false);
+                {   // right tip (:1817-1820): ktrimTip(r, start, len, right)
+                    const int start = max(0, P.restrictRight < 1 ? mid : L - P.restrictRight);
+                    reset(A, cur, start, cur, scan_due<BBDUK_MODE_KTRIM_R, true, true>(P, cur, pairnum, true));
+                    main_scan_pair<BBDUK_MODE_KTRIM_R, true, true>(P, Q, A, Bz, lane);
+                    if (P.useShort) short_scan_pair<BBDUK_MODE_KTRIM_R, true>(P, Q, A, Bz, lane);
+                    int a, newLen, ref; bool hit;
+                    finish_read<BBDUK_MODE_KTRIM_R>(P, cur, A.start, A.stop, A.found, A.iFirst, A.iLast, A.shortFl, A.shortLl, A.ref, a, newLen, ref, hit);
+                    if (A.scan) { if (hit) { idr = ref; scaf_add(P, scaf, idr, cur, lane, counters); } xr = a; cur = newLen; }
+                }
+                {   // left tip (:1821-1824) on the read as it is now
+                    const int stop = min(cur, P.restrictLeft < 1 ? mid + k - 1 : P.restrictLeft);
+                    reset(A, cur, 0, stop, scan_due<BBDUK_MODE_KTRIM_L, true, true>(P, cur, pairnum, true));
+                    main_scan_pair<BBDUK_MODE_KTRIM_L, true, true>(P, Q, A, Bz, lane);
+                    if (P.useShort) short_scan_pair<BBDUK_MODE_KTRIM_L, true>(P, Q, A, Bz, lane);
+                    int a, newLen, ref; bool hit;
+                    finish_read<BBDUK_MODE_KTRIM_L>(P, cur, A.start, A.stop, A.found, A.iFirst, A.iLast, A.shortFl, A.shortLl, A.ref, a, newLen, ref, hit);
+                    if (A.scan) { if (hit) { idl = ref; scaf_add(P, scaf, idl, cur, lane, counters); } xl = a; cur = newLen; }
+                }
+                if (lane == 0) { s_xr[rd] = xr; s_xl[rd] = xl; s_len[rd] = cur; s_id[rd] = idr >= 0 ? idr : idl; }
+            }
+            __syncthreads();
+            s = e;
+        }
+        // ---- record stage (:954-967, 1009-1033, 1431-1443): the even thread of a pair (every thread when unpaired) decides
+        if (tid < cnt && (!paired || !(tid & 1))) {
+            const bool two = paired != 0;
+            const int l1 = (int)(s_off[tid + 1] - s_off[tid]), l2 = two ? (int)(s_off[tid + 2] - s_off[tid + 1]) : 0;
+            int n1 = s_len[tid], n2 = two ? s_len[tid + 1] : 0;
+            int xr1 = s_xr[tid], xr2 = two ? s_xr[tid + 1] : 0;
+            const int xl1 = s_xl[tid], xl2 = two ? s_xl[tid + 1] : 0;
+            const float g1 = (float)l1 * P.minLenFraction, g2 = (float)l2 * P.minLenFraction;
+            const int minlen1 = (int)(g1 > (float)P.minReadLength ? g1 : (float)P.minReadLength);
+            const int minlen2 = (int)(g2 > (float)P.minReadLength ? g2 : (float)P.minReadLength);
+            bool d1 = false, d2 = false, remove = false;
+            if (P.storedKmers > 0) {
+                int xsum = xr1 + xl1 + xr2 + xl2, rkt = ((xr1 + xl1) > 0) + ((xr2 + xl2) > 0);
+                d1 = n1 < minlen1; d2 = two && (n2 < minlen2);
+                if ((P.rieb && (d1 || d2)) || (d1 && (!two || d2))) { xsum += n1 + n2; rkt = two ? 2 : 1; remove = true; }
+                else if (P.tpe && xsum > 0 && two && n1 != n2) {      // trimpairsevenly: ktrimRight is set in this mode (:1021-1031)
+                    int x;
+                    if (n1 > n2) { x = trim_by_amount(n1, 0, n1 - n2, 1, n1); xr1 += x; }
+                    else { x = trim_by_amount(n2, 0, n2 - n1, 1, n2); xr2 += x; }
+                    if (rkt < 2) rkt++;
+                    xsum += x;
+                }
+                atomicAdd(&s_acc[0], (unsigned long long)rkt); atomicAdd(&s_acc[1], (unsigned long long)xsum);
+            }
+            if (remove) { atomicAdd(&s_acc[2], two ? 2ULL : 1ULL); atomicAdd(&s_acc[3], (unsigned long long)(n1 + n2)); }
+            const uint8_t f1 = (uint8_t)((d1 ? BBDUK_FLAG_DISCARDED : 0) | (remove ? BBDUK_FLAG_REMOVED : 0));
+            const uint8_t f2 = (uint8_t)((d2 ? BBDUK_FLAG_DISCARDED : 0) | (remove ? BBDUK_FLAG_REMOVED : 0));
+            outRight[r0 + tid] = xr1; outLeft[r0 + tid] = xl1; outId[r0 + tid] = s_id[tid]; outFlags[r0 + tid] = f1;
+            if (two) { outRight[r0 + tid + 1] = xr2; outLeft[r0 + tid + 1] = xl2; outId[r0 + tid + 1] = s_id[tid + 1]; outFlags[r0 + tid + 1] = f2; }
+        }
+    }
+    scaf_flush(P, scaf, lane, counters);
+    __syncthreads();
+    if (tid == 0) publish_counters<BBDUK_MODE_KTRIM_R>(s_acc, counters);
+}
+
+// --------------------------------------------------------------------------------------------------
 // Wave-autonomous batch kernel (the fast path): every wave owns a mini-tile of MT_READS consecutive reads,
 // stages it into its private slice of LDS and scans it, with no workgroup barrier after the one that lands
 // the presence filter.  Waves of a CU therefore sit in different phases (HBM load, LDS extraction, L2 gather),
@@ -1804,7 +1940,7 @@ extern "C" int bbduk_create(const bbduk_params* p, bbduk_handle** out) {
     *out = nullptr;
     if (p->abi_version != BBDUK_ABI_VERSION) return BBDUK_ERR_ARG;
     if (p->k < 1 || p->k > 31) return BBDUK_ERR_ARG;
-    if (p->mode != BBDUK_MODE_KFILTER && p->mode != BBDUK_MODE_KTRIM_R && p->mode != BBDUK_MODE_KTRIM_L && p->mode != BBDUK_MODE_KMASK) return BBDUK_ERR_ARG;
+    if (p->mode != BBDUK_MODE_KFILTER && p->mode != BBDUK_MODE_KTRIM_R && p->mode != BBDUK_MODE_KTRIM_L && p->mode != BBDUK_MODE_KMASK && p->mode != BBDUK_MODE_KTRIM_TIPS) return BBDUK_ERR_ARG;
     if (p->qhdist < 0 || p->qhdist > 2 || p->qhdist2 < 0 || p->qhdist2 > 2) return BBDUK_ERR_ARG;
     if (p->numScaffolds < 1 || p->maxBadKmers < 0) return BBDUK_ERR_ARG;
     const bool useShort = p->mink > 0 && p->mink < p->k;
@@ -1958,7 +2094,7 @@ static KParams make_kparams(const bbduk_handle* h) {
     K.maxBadKmers = p.maxBadKmers; K.minReadLength = p.minReadLength; K.minLenFraction = p.minLenFraction;
     K.rieb = p.removePairsIfEitherBad; K.trimPad = p.trimPad; K.ktrimExclusive = p.ktrimExclusive;
     K.restrictLeft = p.restrictLeft; K.restrictRight = p.restrictRight; K.skipR1 = p.skipR1; K.skipR2 = p.skipR2;
-    K.tpe = (p.trimPairsEvenly && p.mode == BBDUK_MODE_KTRIM_R) ? 1 : 0; K.qskip = p.qSkip; K.speed = p.speed;
+    K.tpe = (p.trimPairsEvenly && (p.mode == BBDUK_MODE_KTRIM_R || p.mode == BBDUK_MODE_KTRIM_TIPS)) ? 1 : 0; K.qskip = p.qSkip; K.speed = p.speed;
     K.mkf = p.mode == BBDUK_MODE_KFILTER ? p.minKmerFraction : 0.f; K.mcf = p.mode == BBDUK_MODE_KFILTER ? p.minCoveredFraction : 0.f;
     K.numScaffolds = p.numScaffolds;
     K.useShort = (p.mink > 0 && p.mink < p.k) ? 1 : 0;
@@ -1978,7 +2114,7 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
                         int64_t* d_counters, hipStream_t st) {
     if (!h) return BBDUK_ERR_ARG;
     if (!h->finalized) return fail(h, BBDUK_ERR_STATE, "table not finalized");
-    if (h->p.mode == BBDUK_MODE_KMASK || (h->p.mode == BBDUK_MODE_KFILTER) != (wantKfilter != 0)) return fail(h, BBDUK_ERR_STATE, "operator does not match the mode given to bbduk_create");
+    if (h->p.mode == BBDUK_MODE_KMASK || h->p.mode == BBDUK_MODE_KTRIM_TIPS || (h->p.mode == BBDUK_MODE_KFILTER) != (wantKfilter != 0)) return fail(h, BBDUK_ERR_STATE, "operator does not match the mode given to bbduk_create");
     if (n < 0 || total_bases < 0 || (paired && (n & 1))) return fail(h, BBDUK_ERR_ARG, "bad batch shape");
     if (n == 0) return BBDUK_OK;
     if (!d_bases && total_bases > 0) return fail(h, BBDUK_ERR_ARG, "null bases");
@@ -2078,6 +2214,73 @@ extern "C" int bbduk_ktrim_batch(bbduk_handle* h, const uint8_t* bases, const in
 extern "C" int bbduk_kfilter_batch(bbduk_handle* h, const uint8_t* bases, const int64_t* offsets, int64_t n, int32_t paired,
                                    int32_t* out_found, int32_t* out_id, uint8_t* out_flags) {
     return host_batch(h, 1, bases, offsets, n, paired, out_found, out_id, out_flags);
+}
+
+// ---- ktrim=rl
+static int launch_tips(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d_offsets, int64_t n, int64_t total_bases, int32_t paired,
+                       int32_t* d_r, int32_t* d_l, int32_t* d_id, uint8_t* d_fl, int64_t* d_counters, hipStream_t st) {
+    if (!h) return BBDUK_ERR_ARG;
+    if (!h->finalized) return fail(h, BBDUK_ERR_STATE, "table not finalized");
+    if (h->p.mode != BBDUK_MODE_KTRIM_TIPS) return fail(h, BBDUK_ERR_STATE, "operator does not match the mode given to bbduk_create");
+    if (n < 0 || total_bases < 0 || (paired && (n & 1))) return fail(h, BBDUK_ERR_ARG, "bad batch shape");
+    if (n == 0) return BBDUK_OK;
+    if (!d_bases && total_bases > 0) return fail(h, BBDUK_ERR_ARG, "null bases");
+    if (!d_offsets || !d_r || !d_l || !d_id || !d_fl || !d_counters) return fail(h, BBDUK_ERR_ARG, "null buffer");
+    if (((uintptr_t)d_bases & 15) != 0) return fail(h, BBDUK_ERR_ARG, "d_bases must be 16-byte aligned");
+    const KParams K = make_kparams(h);
+    const size_t dynLds = h->ldsBits ? ((size_t)1 << (h->ldsBits - 3)) : 0;
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bbduk_ktrimtips_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
+    const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
+    const int grid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU);
+    const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
+    if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
+    HIP_TRY(h, hipEventRecord(h->ev0[evi], st));
+    bbduk_ktrimtips_kernel<<<dim3(grid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_r, d_l, d_id, d_fl, d_counters);
+    HIP_TRY(h, hipEventRecord(h->ev1[evi], st));
+    h->evCount++;
+    HIP_TRY(h, hipGetLastError());
+    return BBDUK_OK;
+}
+extern "C" int bbduk_ktrimtips_batch_device(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d_offsets, int64_t n,
+                                            int64_t total_bases, int32_t paired, int32_t* d_out_right, int32_t* d_out_left,
+                                            int32_t* d_out_id0, uint8_t* d_out_flags, int64_t* d_counters, void* stream) {
+    return launch_tips(h, d_bases, d_offsets, n, total_bases, paired, d_out_right, d_out_left, d_out_id0, d_out_flags, d_counters, (hipStream_t)stream);
+}
+extern "C" int bbduk_ktrimtips_batch(bbduk_handle* h, const uint8_t* bases, const int64_t* offsets, int64_t n, int32_t paired,
+                                     int32_t* out_right, int32_t* out_left, int32_t* out_id0, uint8_t* out_flags) {
+    if (!h) return BBDUK_ERR_ARG;
+    if (n < 0 || !offsets || (n > 0 && (!out_right || !out_left || !out_id0 || !out_flags))) return fail(h, BBDUK_ERR_ARG, "bad argument");
+    if (n == 0) return BBDUK_OK;
+    const int64_t total = offsets[n];
+    if (offsets[0] != 0 || total < 0 || (total > 0 && !bases)) return fail(h, BBDUK_ERR_ARG, "bad offsets");
+    std::lock_guard<std::mutex> g(h->mu);
+    HIP_TRY(h, hipSetDevice(h->p.device));
+    uint8_t* db = nullptr; int64_t* doff = nullptr; int32_t* dr = nullptr; int32_t* dl = nullptr; int32_t* did = nullptr; uint8_t* dfl = nullptr;
+    auto release = [&]() { hipFree(db); hipFree(doff); hipFree(dr); hipFree(dl); hipFree(did); hipFree(dfl); };
+    if (hipMalloc(&db, (size_t)total + 16) != hipSuccess || hipMalloc(&doff, (size_t)(n + 1) * 8) != hipSuccess ||
+        hipMalloc(&dr, (size_t)n * 4) != hipSuccess || hipMalloc(&dl, (size_t)n * 4) != hipSuccess ||
+        hipMalloc(&did, (size_t)n * 4) != hipSuccess || hipMalloc(&dfl, (size_t)n) != hipSuccess) { release(); return fail(h, BBDUK_ERR_NOMEM, "hipMalloc"); }
+    hipError_t e = hipSuccess;
+    if (total > 0) e = hipMemcpyAsync(db, bases, (size_t)total, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(doff, offsets, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) { release(); h->err = hipGetErrorString(e); return BBDUK_ERR_DEVICE; }
+    const int rc = launch_tips(h, db, doff, n, total, paired, dr, dl, did, dfl, h->d_counters, h->stream);
+    if (rc != BBDUK_OK) { release(); return rc; }
+    hipMemcpyAsync(out_right, dr, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream);
+    hipMemcpyAsync(out_left, dl, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream);
+    hipMemcpyAsync(out_id0, did, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream);
+    hipMemcpyAsync(out_flags, dfl, (size_t)n, hipMemcpyDeviceToHost, h->stream);
+    e = hipStreamSynchronize(h->stream);
+    release();
+    if (e != hipSuccess) { h->err = hipGetErrorString(e); return BBDUK_ERR_DEVICE; }
+    int64_t status = 0;
+    HIP_TRY(h, hipMemcpy(&status, h->d_counters + BBDUK_CTR_STATUS, sizeof status, hipMemcpyDeviceToHost));
+    if (status != 0) {
+        int64_t z = 0;
+        hipMemcpy(h->d_counters + BBDUK_CTR_STATUS, &z, sizeof z, hipMemcpyHostToDevice);
+        return fail(h, -(int)status, "device reported an error (read longer than BBDUK_MAX_READ_LEN?)");
+    }
+    return BBDUK_OK;
 }
 
 // ---- ktrim=n

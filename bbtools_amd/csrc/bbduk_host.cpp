@@ -97,7 +97,7 @@ int derive(Parsed& p, std::string& err) {            // bbduk/BBDukParser.java:1
     if (p.mink > 0 && p.mink < p.k) p.useShortKmers = true;
     if (p.useShortKmers && p.maskMiddle) { p.maskMiddle = false; p.midMaskLen = 0; }
     if (p.useShortKmers && !(p.ktrimLeft || p.ktrimRight || p.ktrimN)) { err = "Setting mink also requires setting a ktrim mode, such as 'r' or 'l'"; return BBDUK_ERR_ARG; }
-    if (p.ktrimLeft && p.ktrimRight) { err = "ktrim=rl (tips) is not supported by this path yet"; return BBDUK_ERR_ARG; }
+    // ktrim=rl (tips): both flags stay set, the device runs the two passes (BBDUK_MODE_KTRIM_TIPS)
     if (p.maskMiddle) {
         if (!(p.k > p.midMaskLen + 1)) { err = "k too small for maskmiddle"; return BBDUK_ERR_ARG; }
         const int bits = p.midMaskLen * 2;
@@ -193,6 +193,9 @@ extern "C" int bbduk_host_parse(const char* args, bbduk_host** out, char* errbuf
             else if (v == "n" || (v.size() == 1 && v != "t" && v != "f")) { p.ktrimLeft = p.ktrimRight = false; p.ktrimN = true; }   // the symbol stays with the caller
             else if (v == "f" || v == "false") { p.ktrimLeft = p.ktrimRight = false; }
             else { seterr("Invalid setting for ktrim - values must be f (false), l (left), r (right), or n"); delete h; return BBDUK_ERR_ARG; }
+        }
+        else if (a == "trimtips" || a == "ktrimtips") {             // BBDukParser.java:626-632
+            if (!b.empty()) { int v = 0; need_int(v); if (ok) { p.ktrimLeft = p.ktrimRight = true; p.ktrimN = false; p.restrictLeft = p.restrictRight = v; } }
         }
         else if (a == "kmask" || a == "mask") {                      // BBDukParser.java:635-651: lc | t | a symbol | f
             std::string v = b; for (auto& c : v) c = (char)tolower(c);
@@ -347,7 +350,8 @@ extern "C" int bbduk_host_params(const bbduk_host* h, int32_t device, bbduk_para
     const Parsed& p = h->p;
     memset(out, 0, sizeof *out);
     out->abi_version = BBDUK_ABI_VERSION;
-    out->mode = p.ktrimRight ? BBDUK_MODE_KTRIM_R : (p.ktrimLeft ? BBDUK_MODE_KTRIM_L : (p.ktrimN ? BBDUK_MODE_KMASK : BBDUK_MODE_KFILTER));
+    out->mode = (p.ktrimRight && p.ktrimLeft) ? BBDUK_MODE_KTRIM_TIPS :
+                p.ktrimRight ? BBDUK_MODE_KTRIM_R : (p.ktrimLeft ? BBDUK_MODE_KTRIM_L : (p.ktrimN ? BBDUK_MODE_KMASK : BBDUK_MODE_KFILTER));
     out->k = p.k; out->mink = p.mink; out->rcomp = p.rcomp; out->forbidNs = p.forbidNs;
     out->minlen = p.minlen; out->minlen2 = p.minlen2; out->middleMask = p.middleMask;
     out->qhdist = p.qhdist; out->qhdist2 = p.qhdist2; out->maxBadKmers = p.maxBadKmers0;

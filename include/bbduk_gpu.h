@@ -54,6 +54,7 @@ extern "C" {
 #define BBDUK_MODE_KTRIM_R   1       /* ktrim=r */
 #define BBDUK_MODE_KTRIM_L   2       /* ktrim=l */
 #define BBDUK_MODE_KMASK     3       /* ktrim=n / kmask=: mask matched bases instead of trimming (kmaskfullycovered=f) */
+#define BBDUK_MODE_KTRIM_TIPS 4      /* ktrim=rl / ktrimtips=: a right pass, then a left pass on what is left */
 
 /* per-read output flags */
 #define BBDUK_FLAG_DISCARDED 1       /* setDiscarded(r)  (BBDukProcessorS.java:1464-1470)    */
@@ -141,6 +142,16 @@ int  bbduk_kmask_batch(bbduk_handle* h, const uint8_t* bases, const int64_t* off
 int  bbduk_kmask_batch_device(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d_offsets, int64_t n,
                               int64_t total_bases, int32_t paired, int32_t* d_out_masked, int32_t* d_out_id0,
                               uint8_t* d_out_flags, uint32_t* d_out_mask, int64_t* d_counters, void* stream);
+
+/* ---- ktrim=rl / ktrimtips (bbduk/BBDukProcessorS.java:1813-1985).  out_right[i] / out_left[i] = bases the right and the
+ * left pass removed (ktrimTips(r) returns their sum; trimpairsevenly adds to the right amount), out_id0[i] = the scaffold
+ * credited by the right pass, else by the left pass, else -1.  The caller applies TrimRead.trimByAmount(r, 0, right, 1)
+ * and then (r, left, 0, 1). */
+int  bbduk_ktrimtips_batch(bbduk_handle* h, const uint8_t* bases, const int64_t* offsets, int64_t n, int32_t paired,
+                           int32_t* out_right, int32_t* out_left, int32_t* out_id0, uint8_t* out_flags);
+int  bbduk_ktrimtips_batch_device(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d_offsets, int64_t n,
+                                  int64_t total_bases, int32_t paired, int32_t* d_out_right, int32_t* d_out_left,
+                                  int32_t* d_out_id0, uint8_t* d_out_flags, int64_t* d_counters, void* stream);
 
 /* Average duration (HIP events on the launch stream) of the dominant kernel over the last `last_k` batch launches
  * of this handle (at most 64 are remembered).  Synchronises on those launches.  For roofline reporting. */

@@ -324,3 +324,48 @@ def test_concurrent_submitters_share_one_handle():
             assert np.array_equal(g, w), t
     assert np.array_equal(d.gpu.counters(), 3 * o.counters())   # every batch was counted three times
     d.close()
+
+
+# ---- ktrim=rl (ktrimtips): the (right, left) amounts, ids, flags and counters
+TIPS = [("ktrim=rl k=23", dict(k=23, ktrimLeft=1, ktrimRight=1)), ("ktrim=lr k=23 mink=11 hdist=1 tpe", dict(k=23, ktrimLeft=1, ktrimRight=1, mink=11, hdist=1, trimPairsEvenly=1)),
+        ("ktrimtips=30 k=15 tp=1 forbidn=t", dict(k=15, ktrimLeft=1, ktrimRight=1, restrictLeft=30, restrictRight=30, trimPad=1, forbidN=1)),
+        ("ktrim=tips k=12 mink=5 ktrimexclusive=t mm=f", dict(k=12, ktrimLeft=1, ktrimRight=1, mink=5, ktrimExclusive=1, maskMiddle=0)),
+        ("ktrim=rl k=17 rieb=f minlen=40 qhdist=1", dict(k=17, ktrimLeft=1, ktrimRight=1, requireBothBad=1, minReadLength=40, qhdist=1))]
+
+
+def check_tips(d, o, reads, paired):
+    b, off = pack_reads(reads)
+    d.gpu.reset_counters(); o.reset_counters()
+    gr, gl, gi, gf = d.gpu.ktrimtips_batch(b, off, paired)
+    xr, xl, oi, of = o.process_batch_tips(b, off, paired, nthreads=4)
+    bad = np.nonzero((gr != xr) | (gl != xl) | (gi != oi) | (gf != of))[0]
+    assert len(bad) == 0, [(int(i), reads[i], (int(gr[i]), int(gl[i]), int(gi[i]), int(gf[i])), (int(xr[i]), int(xl[i]), int(oi[i]), int(of[i]))) for i in bad[:3]]
+    assert np.array_equal(d.gpu.counters(), o.counters())
+    return int(gr.sum()), int(gl.sum())
+
+
+@pytest.mark.parametrize("ci", range(len(TIPS)))
+def test_ktrimtips_fuzz_parity(ci):
+    args, okw = TIPS[ci]
+    tr = tl = 0
+    for seed in range(3):
+        rng = random.Random(1200 * ci + seed)
+        refs = [util.rand_seq(rng, rng.randint(8, 90), 0.01) for _ in range(8)]
+        d, o = make_pair(args, okw, refs=refs)
+        reads = util.fuzz_reads(rng, refs, 600, [0, 1, 2, 5, 10, 11, 22, 23, 30, 31, 32, 40, 63, 64, 65, 75, 150, 151, 300], junk=True)
+        for paired, rs in ((True, reads), (False, reads[:301])):
+            a, b = check_tips(d, o, rs, paired); tr += a; tl += b
+        d.close()
+    assert tr > 0 and tl > 0
+
+
+def test_ktrimtips_adapters_both_ends():
+    d, o = make_pair("ktrim=rl k=23 mink=11 hdist=1 ref=adapters", dict(k=23, ktrimLeft=1, ktrimRight=1, mink=11, hdist=1), ref_fasta=util.ADAPTERS)
+    rng = random.Random(8)
+    ad = B.TRUSEQ_R1
+    reads = [util.revcomp(ad)[-rng.randint(12, 33):] + util.rand_seq(rng, rng.randint(60, 120)) + ad[:rng.randint(0, 33)] for _ in range(2000)]
+    r, l = check_tips(d, o, reads, True)
+    assert r > 1000 and l > 1000
+    longs = [util.revcomp(ad) + util.rand_seq(rng, n, 0.001) + ad for n in (900, 5000, 16000 - 2 * len(ad))]
+    check_tips(d, o, longs, False)
+    d.close()
