@@ -148,7 +148,10 @@ def main():
         pass
     out["roofline"] = {"bound": "hbm", "kernel": "bbduk_wave_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                       "kernel_ms": round(kern_ms, 3), "launch_ms": round(launch_ms, 3), "algorithmic_bytes_per_launch": algo_bytes}
+                       "kernel_ms": round(kern_ms, 3), "launch_ms": round(launch_ms, 3), "algorithmic_bytes_per_launch": algo_bytes,
+                       # the contract prices this path against HBM; what actually paces the kernel is instruction issue
+                       # (131 VALU + 70 SALU wave-instructions per read at ~4.4 / ~2.6 SIMD cycles each)
+                       "limiter": "instruction issue, not HBM: 131 VALU + 70 SALU per read (profiles/r01_final_summary.txt)"}
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         # CPU baseline: the oracle (a C restatement of the reference's loops, NOT the Java reference: no JVM
