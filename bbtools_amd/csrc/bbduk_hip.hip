@@ -73,8 +73,6 @@ struct KParams {
     const uint32_t* ldsImage;   // HBM copy of the LDS bitmap (2^ldsBits bits); 0 bits = absent
     int32_t  ldsBits;
     int32_t  dbg;               // BBDUK_DBG: timing experiments only (results become wrong); needs -DBBDUK_TIMING_SWITCHES
-    int32_t  prof;              // BBDUK_PROF=1: per-phase s_memtime sums into counters[] tail (timing experiments only)
-    unsigned long long* profOut;
 };
 
 // --------------------------------------------------------------------------------------------------
@@ -1917,7 +1915,6 @@ struct bbduk_handle {
     int* d_slowFlag = nullptr;
     static const int EV_RING = 64;                                // HIP events around the dominant kernel of the last launches
     hipEvent_t ev0[EV_RING] = {}, ev1[EV_RING] = {}; int64_t evCount = 0;
-    unsigned long long* d_prof = nullptr;
     // host-operator staging
     uint8_t* d_bases = nullptr; size_t cap_bases = 0;
     int64_t* d_off = nullptr;   size_t cap_reads = 0;
@@ -1962,8 +1959,7 @@ extern "C" int bbduk_create(const bbduk_params* p, bbduk_handle** out) {
     if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return BBDUK_ERR_DEVICE; }
     const size_t nc = (size_t)(BBDUK_NCOUNTERS + 2 * p->numScaffolds);
     if (hipMalloc(&h->d_counters, nc * sizeof(int64_t)) != hipSuccess ||
-        hipMemset(h->d_counters, 0, nc * sizeof(int64_t)) != hipSuccess || hipMalloc(&h->d_slowFlag, sizeof(int)) != hipSuccess ||
-        hipMalloc(&h->d_prof, 16 * sizeof(unsigned long long)) != hipSuccess || hipMemset(h->d_prof, 0, 128) != hipSuccess) { hipStreamDestroy(h->stream); delete h; return BBDUK_ERR_DEVICE; }
+        hipMemset(h->d_counters, 0, nc * sizeof(int64_t)) != hipSuccess || hipMalloc(&h->d_slowFlag, sizeof(int)) != hipSuccess) { hipStreamDestroy(h->stream); delete h; return BBDUK_ERR_DEVICE; }
     *out = h;
     return BBDUK_OK;
 }
@@ -1972,15 +1968,7 @@ extern "C" int bbduk_destroy(bbduk_handle* h) {
     if (!h) return BBDUK_ERR_ARG;
     hipSetDevice(h->p.device);
     hipFree(h->d_tags); hipFree(h->d_bkv); hipFree(h->d_bases); hipFree(h->d_off);
-    if (getenv("BBDUK_PROF") && h->d_prof) {
-        unsigned long long ph[8];
-        if (hipMemcpy(ph, h->d_prof, sizeof ph, hipMemcpyDeviceToHost) == hipSuccess) {
-            unsigned long long t = 0; for (int q = 0; q < 8; q++) t += ph[q];
-            fprintf(stderr, "[bbduk prof] wave-cycle share: offsets %.1f%% stage %.1f%% init %.1f%% main %.1f%% short %.1f%% finish %.1f%% writeback %.1f%% (total %.3g wave-cycles)\n",
-                    100.0 * ph[0] / t, 100.0 * ph[1] / t, 100.0 * ph[2] / t, 100.0 * ph[3] / t, 100.0 * ph[4] / t, 100.0 * ph[5] / t, 100.0 * ph[6] / t, (double)t);
-        }
-    }
-    hipFree(h->d_ldsImage); hipFree(h->d_slowFlag); hipFree(h->d_prof);
+    hipFree(h->d_ldsImage); hipFree(h->d_slowFlag);
     for (int q = 0; q < bbduk_handle::EV_RING; q++) { if (h->ev0[q]) hipEventDestroy(h->ev0[q]); if (h->ev1[q]) hipEventDestroy(h->ev1[q]); }
     hipFree(h->d_a); hipFree(h->d_id); hipFree(h->d_fl); hipFree(h->d_counters);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -2105,7 +2093,6 @@ static KParams make_kparams(const bbduk_handle* h) {
     K.storedKmers = h->nkeys;
     K.dbg = getenv("BBDUK_DBG") ? atoi(getenv("BBDUK_DBG")) : 0;
     K.ldsImage = h->d_ldsImage; K.ldsBits = h->ldsBits;
-    K.prof = getenv("BBDUK_PROF") ? 1 : 0; K.profOut = h->d_prof;
     return K;
 }
 
