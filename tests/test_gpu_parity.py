@@ -369,3 +369,55 @@ def test_ktrimtips_adapters_both_ends():
     longs = [util.revcomp(ad) + util.rand_seq(rng, n, 0.001) + ad for n in (900, 5000, 16000 - 2 * len(ad))]
     check_tips(d, o, longs, False)
     d.close()
+
+
+# ---- random flag combinations (seeded): every draw is a legal BBDuk command line; device == oracle
+def random_config(rng):
+    k = rng.choice([9, 11, 13, 15, 16, 17, 20, 21, 23, 24, 25, 27, 31])
+    mode = rng.choice(["r", "l", "f", "f"])
+    okw, args = dict(k=k), ["k=%d" % k]
+    if mode == "r": okw["ktrimRight"] = 1; args.append("ktrim=r")
+    if mode == "l": okw["ktrimLeft"] = 1; args.append("ktrim=l")
+    if mode != "f" and rng.random() < 0.5:
+        mk = rng.randint(max(1, k - 14), k - 1); okw["mink"] = mk; args.append("mink=%d" % mk)
+    hd = rng.choice([0, 0, 1, 1, 2 if k <= 11 else 1])
+    if hd: okw["hdist"] = hd; args.append("hdist=%d" % hd)
+    if "mink" in okw and rng.random() < 0.3: okw["hdist2"] = 0; args.append("hdist2=0")
+    if k <= 13 and rng.random() < 0.3: okw["qhdist"] = 1; args.append("qhdist=1")
+    if "mink" not in okw and rng.random() < 0.3: okw["maskMiddle"] = 0; args.append("mm=f")
+    if rng.random() < 0.15: okw["rcomp"] = 0; args.append("rcomp=f")
+    if rng.random() < 0.25: okw["forbidN"] = 1; args.append("forbidn=t")
+    if rng.random() < 0.2: v = rng.randint(20, 120); okw["restrictLeft"] = v; args.append("restrictleft=%d" % v)
+    if rng.random() < 0.2: v = rng.randint(20, 120); okw["restrictRight"] = v; args.append("restrictright=%d" % v)
+    if rng.random() < 0.15: okw["requireBothBad"] = 1; args.append("rieb=f")
+    if rng.random() < 0.3: v = rng.choice([1, 20, 40]); okw["minReadLength"] = v; args.append("minlen=%d" % v)
+    if rng.random() < 0.2: okw["minLenFraction"] = 0.5; args.append("mlf=0.5")
+    if rng.random() < 0.1: okw["skipR1"] = 1; args.append("skipr1=t")
+    if rng.random() < 0.1: okw["qSkip"] = 2; args.append("qskip=2")
+    if rng.random() < 0.1: v = rng.randint(1, 8); okw["speed"] = v; args.append("speed=%d" % v)
+    if mode != "f":
+        if rng.random() < 0.3: v = rng.choice([-2, 1, 3]); okw["trimPad"] = v; args.append("tp=%d" % v)
+        if rng.random() < 0.2: okw["ktrimExclusive"] = 1; args.append("ktrimexclusive=t")
+        if mode == "r" and rng.random() < 0.4: okw["trimPairsEvenly"] = 1; args.append("tpe")
+    else:
+        r = rng.random()
+        if r < 0.25: v = rng.randint(1, 4); okw["maxBadKmers0"] = v; args.append("mbk=%d" % v)
+        elif r < 0.4: okw["minKmerFraction"] = 0.2; args.append("mkf=0.2")
+        elif r < 0.55: okw["minCoveredFraction"] = 0.3; args.append("mcf=0.3")
+    return " ".join(args), okw
+
+
+@pytest.mark.parametrize("block", range(6))
+def test_random_flag_combinations(block):
+    rng = random.Random(31337 + block)
+    for _ in range(6):
+        args, okw = random_config(rng)
+        refs = [util.rand_seq(rng, rng.randint(10, 90), 0.01) for _ in range(8)]
+        d, o = make_pair(args, okw, refs=refs)
+        reads = util.fuzz_reads(rng, refs, 400, [0, 1, 5, 10, 22, 23, 31, 40, 64, 75, 150, 151, 300], junk=True)
+        try:
+            check_batch(d, o, reads, True)
+            check_batch(d, o, reads[:201], False)
+        except AssertionError as e:
+            raise AssertionError("config %r: %s" % (args, e))
+        d.close()
