@@ -48,13 +48,13 @@ class SynthParams(C.Structure):     # struct bbduk_synth_params
 
 # every symbol include/bbduk_gpu.h and include/bbduk_host.h declare
 GPU_SYMBOLS = ["bbduk_abi_version", "bbduk_create", "bbduk_destroy", "bbduk_last_error", "bbduk_upload_table_way",
-               "bbduk_upload_pairs", "bbduk_finalize_table", "bbduk_table_size", "bbduk_table_bytes",
+               "bbduk_upload_pairs", "bbduk_finalize_table", "bbduk_build_table_device", "bbduk_table_size", "bbduk_table_bytes",
                "bbduk_table_lookup", "bbduk_ktrim_batch", "bbduk_kfilter_batch", "bbduk_ktrim_batch_device",
                "bbduk_kfilter_batch_device", "bbduk_kmask_batch", "bbduk_kmask_batch_device", "bbduk_ktrimtips_batch", "bbduk_ktrimtips_batch_device", "bbduk_kernel_time_ms", "bbduk_counters_len", "bbduk_get_counters", "bbduk_reset_counters",
                "bbduk_synth_generate_device", "bbduk_synth_generate_host"]
 HOST_SYMBOLS = ["bbduk_host_parse", "bbduk_host_destroy", "bbduk_host_add_ref", "bbduk_host_load_fasta",
                 "bbduk_host_load_refs", "bbduk_host_build_index", "bbduk_host_index_pairs",
-                "bbduk_host_num_scaffolds", "bbduk_host_params", "bbduk_host_upload_index"]
+                "bbduk_host_num_scaffolds", "bbduk_host_params", "bbduk_host_upload_index", "bbduk_host_build_on_device"]
 
 _lib = None
 
@@ -112,6 +112,8 @@ def lib():
     L.bbduk_host_num_scaffolds.argtypes = [vp]
     L.bbduk_host_params.argtypes = [vp, i32, C.POINTER(Params)]
     L.bbduk_host_upload_index.argtypes = [vp, vp]
+    L.bbduk_host_build_on_device.argtypes = [vp, vp]
+    L.bbduk_build_table_device.argtypes = [vp, vp, vp, i32, i32, i32]
     _lib = L
     return L
 
@@ -321,17 +323,24 @@ class BBDukGpu:
 class BBDuk:
     """`bbduk.sh <args>` minus the file streaming: parse, load refs, build the index, hold it on the GPU."""
 
-    def __init__(self, args: str, device: int = 0, resource_dir: str = DATA_DIR, refs=None):
+    def __init__(self, args: str, device: int = 0, resource_dir: str = DATA_DIR, refs=None, build: str = "host"):
+        """build="host": the C++ mirror of the Java index build + upload (what a JNI caller does with its own tables);
+        build="device": the reference sequences go to the GPU and the map is built there (bbduk_build_table_device)."""
         self.host = HostIndex(args)
         if refs is not None:
             for r in refs:
                 self.host.add_ref(r)
         else:
             self.host.load_refs(resource_dir)
-        self.stored_kmers = self.host.build_index()
-        self.gpu = BBDukGpu(self.host.params(device))
-        rc = lib().bbduk_host_upload_index(self.host.h, self.gpu.h)
-        self.gpu._check(rc, "upload_index")
+        if build == "device":
+            self.gpu = BBDukGpu(self.host.params(device))
+            self.gpu._check(lib().bbduk_host_build_on_device(self.host.h, self.gpu.h), "build_on_device")
+            self.stored_kmers = self.gpu.table_size
+        else:
+            self.stored_kmers = self.host.build_index()
+            self.gpu = BBDukGpu(self.host.params(device))
+            rc = lib().bbduk_host_upload_index(self.host.h, self.gpu.h)
+            self.gpu._check(rc, "upload_index")
 
     def process_reads(self, reads, paired: bool):
         bases, offsets = pack_reads(reads)

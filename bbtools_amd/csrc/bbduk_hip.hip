@@ -1114,6 +1114,123 @@ void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
 }
 
 // --------------------------------------------------------------------------------------------------
+// Device-side table build: reference sequences -> key -> id map, in HBM, without the host.
+// What BBDukLoader.addToMap (bbduk/BBDukLoader.java:416-494) and BBDukIndexMod.addToMap / mutate (:289-445) compute: every
+// k-mer of every scaffold whose k bases are all defined, all sequences within `hdist` substitutions of it (ref-side
+// Hamming expansion), for mink the prefixes of a scaffold's first k-mer and the suffixes of its last one (lengths
+// k-1..mink, `hdist2`), canonicalised, middle-masked, length-tagged; a key keeps the id of the FIRST scaffold that
+// produced it (HashArray.setIfNotPresent) -- ids ascend in file order, so that is the minimum id.
+//   pass 1  bbduk_build_enum_kernel: one thread per (reference position, first substitution); keys go into an
+//           open-addressed scratch set with atomicCAS, ids with atomicMin; distinct keys are counted.
+//   pass 2  bbduk_build_place_kernel: one thread per scratch slot; the keys are placed into the final 4-way
+//           fingerprint buckets (sized for the distinct count), the LDS presence filter is set with atomicOr.
+struct BuildParams { int32_t k, mink, useShort, hdist, hdist2, rcomp; uint64_t middleMask; int64_t totalBases; int32_t nrefs; };
+
+__device__ __forceinline__ int ref_code(uint8_t b) {              // dna/AminoAcid.java:1284-1298 baseToNumber (-1 undefined)
+    const uint8_t l = b | 0x20;
+    return l == 'a' ? 0 : l == 'c' ? 1 : l == 'g' ? 2 : (l == 't' || l == 'u') ? 3 : -1;
+}
+__device__ __forceinline__ uint64_t hash64(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; }
+
+__device__ __forceinline__ void scratch_insert(uint64_t* __restrict__ skeys, int32_t* __restrict__ sids, const uint64_t cmask,
+                                               const uint64_t key, const int id, unsigned long long* __restrict__ distinct) {
+    uint64_t hslot = hash64(key) & cmask;
+    for (;;) {
+        const unsigned long long prev = atomicCAS((unsigned long long*)&skeys[hslot], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+        if (prev == EMPTY_KEY || prev == key) {
+            atomicMin(&sids[hslot], id);
+            if (prev == EMPTY_KEY) atomicAdd(distinct, 1ULL);
+            return;
+        }
+        hslot = (hslot + 1) & cmask;
+    }
+}
+// one sequence v of `len` bases -> its key (toValue, BBDukIndexMod.java:532-544)
+__device__ __forceinline__ uint64_t build_key(const BuildParams& B, const uint64_t v, const int len) {
+    const uint64_t r = dev_rcomp(v, len);
+    const uint64_t mx = B.rcomp ? (v > r ? v : r) : v;
+    return (mx & B.middleMask) | (1ULL << (2 * len));
+}
+// v and everything within `dist` (0..2) substitutions of it, starting from first-level choice `v1` (0 = v itself,
+// 1+3*i+j = base i replaced by its j-th alternative); the caller spreads v1 over threads
+__device__ __forceinline__ void emit_variants(const BuildParams& B, const uint64_t v, const int len, const int dist, const int v1, const int id,
+                                              uint64_t* skeys, int32_t* sids, const uint64_t cmask, unsigned long long* distinct) {
+    uint64_t t1 = v;
+    if (v1 > 0) {
+        if (dist < 1) return;
+        const int i = (v1 - 1) / 3, j = (v1 - 1) % 3;
+        if (i >= len) return;
+        const uint64_t cur = (v >> (2 * i)) & 3ULL;
+        t1 = (v & ~(3ULL << (2 * i))) | (((cur + 1 + j) & 3ULL) << (2 * i));
+    }
+    scratch_insert(skeys, sids, cmask, build_key(B, t1, len), id, distinct);
+    if (dist >= 2 && v1 > 0) {                                    // second substitution at a lower position (each pair once)
+        const int i1 = (v1 - 1) / 3;
+        for (int i = 0; i < i1; i++) {
+            const uint64_t cur = (t1 >> (2 * i)) & 3ULL;
+            for (int j = 0; j < 3; j++) {
+                const uint64_t t2 = (t1 & ~(3ULL << (2 * i))) | (((cur + 1 + j) & 3ULL) << (2 * i));
+                scratch_insert(skeys, sids, cmask, build_key(B, t2, len), id, distinct);
+            }
+        }
+    }
+}
+
+__global__ void bbduk_build_enum_kernel(const BuildParams B, const uint8_t* __restrict__ refs, const int64_t* __restrict__ roff,
+                                        uint64_t* __restrict__ skeys, int32_t* __restrict__ sids, const uint64_t cmask,
+                                        unsigned long long* __restrict__ distinct) {
+    const int k = B.k;
+    const int V1 = 1 + 3 * k;                                     // first-level choices per position (also used for the short k-mers)
+    const int64_t work = B.totalBases * (int64_t)V1;
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < work; w += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t g = w / V1; const int v1 = (int)(w - g * V1);
+        int lo = 0, hi = B.nrefs;                                 // scaffold of base g: last s with roff[s] <= g
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (roff[mid] <= g) lo = mid; else hi = mid; }
+        const int64_t s0 = roff[lo], n = roff[lo + 1] - s0, i = g - s0;
+        if (n < k || i < k - 1) continue;
+        uint64_t fwd = 0; bool ok = true;
+        for (int q = k - 1; q >= 0; q--) {                        // window [i-k+1, i]: every base has to be defined (BBDukLoader.java:441-452)
+            const int c = ref_code(refs[g - q]);
+            ok = ok && c >= 0;
+            fwd = (fwd << 2) | (uint64_t)(c < 0 ? 0 : c);
+        }
+        if (!ok) continue;
+        const int id = lo + 1;                                    // scaffoldNames[0] is reserved (bbduk/BBDukIndex.java:105-107)
+        emit_variants(B, fwd, k, B.hdist, v1, id, skeys, sids, cmask, distinct);
+        if (B.useShort && (i == k - 1 || i == n - 1)) {
+            for (int L = k - 1; L >= B.mink; L--) {
+                if (i == k - 1) emit_variants(B, fwd >> (2 * (k - L)), L, B.hdist2, v1, id, skeys, sids, cmask, distinct);        // addToMapRightShift
+                if (i == n - 1) emit_variants(B, fwd & ((1ULL << (2 * L)) - 1ULL), L, B.hdist2, v1, id, skeys, sids, cmask, distinct);   // addToMapLeftShift
+            }
+        }
+    }
+}
+
+__global__ void bbduk_build_place_kernel(const uint64_t* __restrict__ skeys, const int32_t* __restrict__ sids, const uint64_t cslots,
+                                         uint64_t* __restrict__ tags, uint4* __restrict__ bkv, const int bucketBits, const uint32_t bucketMask,
+                                         uint32_t* __restrict__ ldsImage, const int ldsBits) {
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < cslots; q += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = skeys[q];
+        if (key == EMPTY_KEY) continue;
+        const uint64_t v = strip_len(key);
+        const uint32_t ma = mix_a(v), mb = mix_b(v);
+        uint32_t b = bucket_of(mb, bucketBits);
+        for (bool placed = false; !placed;) {
+            for (int w = 0; w < 4 && !placed; w++) {
+                unsigned long long* slot = reinterpret_cast<unsigned long long*>(&bkv[4ULL * b + w]);    // {key lo, key hi} are its first 8 bytes
+                if (atomicCAS(slot, (unsigned long long)EMPTY_KEY, (unsigned long long)key) == EMPTY_KEY) {
+                    bkv[4ULL * b + w].z = (uint32_t)sids[q]; bkv[4ULL * b + w].w = 0u;
+                    atomicOr((unsigned long long*)&tags[b], (unsigned long long)tag_of(ma) << (16 * w));
+                    placed = true;
+                }
+            }
+            if (!placed) { atomicOr((unsigned long long*)&tags[b], (unsigned long long)TAG_CONT); b = (b + 1) & bucketMask; }
+        }
+        if (ldsBits) atomicOr(&ldsImage[filt_byte(ma, ldsBits) >> 2], 1u << (ma & 31u));
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
 // ktrim=n (kmask): bbduk/BBDukProcessorS.java:2149-2323 with kmaskFullyCovered=false.  A secondary operator, written
 // for clarity rather than speed on the run-time-general code paths (GENERAL scans, every flag honoured): tiles staged
 // like bbduk_batch_kernel, one wave per READ (mates only meet in the record stage), a fourth LDS bit-plane that
@@ -2063,6 +2180,68 @@ extern "C" int bbduk_finalize_table(bbduk_handle* h) {
         h->ldsBits = lb;
     }
     h->hkeys.clear(); h->hkeys.shrink_to_fit(); h->hvals.clear(); h->hvals.shrink_to_fit();
+    h->finalized = true;
+    return BBDUK_OK;
+}
+
+// bbduk_build_table_device: see the kernels above.  refs/offsets are HOST pointers here (the sequences are copied once).
+extern "C" int bbduk_build_table_device(bbduk_handle* h, const uint8_t* refs, const int64_t* ref_offsets, int32_t n_refs,
+                                        int32_t hdist, int32_t hdist2) {
+    if (!h) return BBDUK_ERR_ARG;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (h->finalized) return fail(h, BBDUK_ERR_STATE, "table already finalized");
+    if (!h->hkeys.empty()) return fail(h, BBDUK_ERR_STATE, "pairs were uploaded already: finalize them instead");
+    if (n_refs < 0 || !ref_offsets || hdist < 0 || hdist > 2 || hdist2 < 0 || hdist2 > 2) return fail(h, BBDUK_ERR_ARG, "bad argument (device build serves hdist <= 2)");
+    const int64_t total = n_refs > 0 ? ref_offsets[n_refs] : 0;
+    if (n_refs > 0 && (ref_offsets[0] != 0 || total < 0 || (total > 0 && !refs))) return fail(h, BBDUK_ERR_ARG, "bad offsets");
+    if (n_refs + 1 != h->p.numScaffolds) return fail(h, BBDUK_ERR_ARG, "numScaffolds given to bbduk_create must be n_refs + 1");
+    HIP_TRY(h, hipSetDevice(h->p.device));
+    BuildParams B;
+    B.k = h->p.k; B.mink = h->p.mink; B.useShort = (h->p.mink > 0 && h->p.mink < h->p.k) ? 1 : 0; B.hdist = hdist; B.hdist2 = hdist2;
+    B.rcomp = h->p.rcomp; B.middleMask = (uint64_t)h->p.middleMask; B.totalBases = total; B.nrefs = n_refs;
+    // upper bound on candidates -> scratch capacity (a power of two, load <= 0.5)
+    auto variants = [](int len, int d) { const double t = 3.0 * len; return d == 0 ? 1.0 : d == 1 ? 1.0 + t : 1.0 + t + t * (t - 3.0) / 2.0 + 0.0 * t; };
+    double ub = (double)total * variants(B.k, hdist);
+    if (B.useShort) for (int L = B.mink; L < B.k; L++) ub += 2.0 * (double)n_refs * variants(L, hdist2);
+    uint64_t cslots = 1024; while ((double)cslots < 2.0 * ub + 16.0) cslots <<= 1;
+    if (cslots > (1ULL << 34)) return fail(h, BBDUK_ERR_NOMEM, "reference too large for the device-side build scratch set");
+    uint8_t* d_refs = nullptr; int64_t* d_roff = nullptr; uint64_t* d_sk = nullptr; int32_t* d_si = nullptr; unsigned long long* d_cnt = nullptr;
+    auto release = [&]() { hipFree(d_refs); hipFree(d_roff); hipFree(d_sk); hipFree(d_si); hipFree(d_cnt); };
+    if (hipMalloc(&d_refs, (size_t)total + 16) != hipSuccess || hipMalloc(&d_roff, (size_t)(n_refs + 1) * 8) != hipSuccess ||
+        hipMalloc(&d_sk, cslots * 8) != hipSuccess || hipMalloc(&d_si, cslots * 4) != hipSuccess || hipMalloc(&d_cnt, 8) != hipSuccess) { release(); return fail(h, BBDUK_ERR_NOMEM, "hipMalloc"); }
+    hipMemcpyAsync(d_refs, refs, (size_t)total, hipMemcpyHostToDevice, h->stream);
+    hipMemcpyAsync(d_roff, ref_offsets, (size_t)(n_refs + 1) * 8, hipMemcpyHostToDevice, h->stream);
+    hipMemsetAsync(d_sk, 0xFF, cslots * 8, h->stream);
+    hipMemsetAsync(d_si, 0x7F, cslots * 4, h->stream);                     // 0x7F7F7F7F: larger than any id
+    hipMemsetAsync(d_cnt, 0, 8, h->stream);
+    if (total > 0) {
+        const int64_t work = total * (int64_t)(1 + 3 * B.k);
+        const int grid = (int)std::min<int64_t>((work + 255) / 256, (int64_t)h->numCU * 32);
+        bbduk_build_enum_kernel<<<dim3(std::max(grid, 1)), dim3(256), 0, h->stream>>>(B, d_refs, d_roff, d_sk, d_si, cslots - 1, d_cnt);
+    }
+    unsigned long long distinct = 0;
+    hipMemcpyAsync(&distinct, d_cnt, 8, hipMemcpyDeviceToHost, h->stream);
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { release(); return fail(h, BBDUK_ERR_DEVICE, "device build (enumeration) failed"); }
+    int bbits = 10;
+    while (bbits < 32 && (1ULL << bbits) < distinct) bbits++;
+    const uint64_t nb = 1ULL << bbits;
+    if (4 * nb > (1ULL << 31)) { release(); return fail(h, BBDUK_ERR_ARG, "too many keys for the bucket index"); }
+    auto ceil_log2 = [](uint64_t x) { int b = 0; while ((1ULL << b) < x) b++; return b; };
+    int lb = 0;
+    if (distinct > 0 && distinct <= (1ULL << 22)) lb = std::min(MAX_LDS_BITS, std::max(10, ceil_log2(32ULL * distinct)));
+    if (hipMalloc(&h->d_tags, nb * sizeof(uint64_t)) != hipSuccess || hipMalloc(&h->d_bkv, 4 * nb * sizeof(uint4)) != hipSuccess ||
+        (lb && hipMalloc(&h->d_ldsImage, ((size_t)1 << (lb - 5)) * 4) != hipSuccess)) { release(); return fail(h, BBDUK_ERR_NOMEM, "hipMalloc (map)"); }
+    hipMemsetAsync(h->d_tags, 0, nb * sizeof(uint64_t), h->stream);
+    hipMemsetAsync(h->d_bkv, 0xFF, 4 * nb * sizeof(uint4), h->stream);
+    if (lb) hipMemsetAsync(h->d_ldsImage, 0, ((size_t)1 << (lb - 5)) * 4, h->stream);
+    {
+        const int grid = (int)std::min<uint64_t>((cslots + 255) / 256, (uint64_t)h->numCU * 32);
+        bbduk_build_place_kernel<<<dim3(grid), dim3(256), 0, h->stream>>>(d_sk, d_si, cslots, h->d_tags, h->d_bkv, bbits, (uint32_t)(nb - 1), h->d_ldsImage, lb);
+    }
+    const hipError_t e = hipStreamSynchronize(h->stream);
+    release();
+    if (e != hipSuccess) return fail(h, BBDUK_ERR_DEVICE, "device build (placement) failed");
+    h->nbuckets = nb; h->bucketBits = bbits; h->nkeys = (int64_t)distinct; h->ldsBits = lb;
     h->finalized = true;
     return BBDUK_OK;
 }

@@ -367,6 +367,17 @@ extern "C" int bbduk_host_params(const bbduk_host* h, int32_t device, bbduk_para
     return BBDUK_OK;
 }
 
+// The other way to fill the device map: hand the loaded scaffolds over and let the GPU build it (bbduk_build_table_device).
+extern "C" int bbduk_host_build_on_device(const bbduk_host* h, bbduk_handle* dev) {
+    if (!h || !dev) return BBDUK_ERR_ARG;
+    const Parsed& p = h->p;
+    if (p.edist > 0 || p.edist2 > 0 || p.hdist > 2 || p.hdist2 > 2) return BBDUK_ERR_ARG;      // the host builder / upload path serves those
+    std::vector<uint8_t> cat; std::vector<int64_t> off(1, 0);
+    for (const auto& s : h->scaffolds) { cat.insert(cat.end(), s.begin(), s.end()); off.push_back((int64_t)cat.size()); }
+    if (cat.empty()) cat.push_back(0);
+    return bbduk_build_table_device(dev, cat.data(), off.data(), (int32_t)h->scaffolds.size(), p.hdist, p.hdist2);
+}
+
 extern "C" int bbduk_host_upload_index(const bbduk_host* h, bbduk_handle* dev) {
     if (!h || !h->built || !dev) return BBDUK_ERR_ARG;
     int rc = bbduk_upload_pairs(dev, h->keys.data(), h->vals.data(), (int64_t)h->keys.size());

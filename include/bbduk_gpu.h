@@ -110,6 +110,13 @@ int  bbduk_upload_table_way(bbduk_handle* h, int32_t way, int32_t prime,
                             const int64_t* vkeys, const int32_t* vvals, int64_t nvictims);
 int  bbduk_upload_pairs(bbduk_handle* h, const int64_t* keys, const int32_t* values, int64_t n);
 int  bbduk_finalize_table(bbduk_handle* h);
+/* Alternative to upload + finalize: build the map ON the device from the reference sequences themselves (SURVEY 8f-4;
+ * BBDukLoader.addToMap bbduk/BBDukLoader.java:416-494, BBDukIndexMod.addToMap/mutate :289-445): refs = the scaffolds'
+ * bases concatenated in file order (host pointer), ref_offsets[n_refs+1]; scaffold s gets id s+1 and the first
+ * scaffold wins a shared key.  hdist/hdist2 (0..2) are the ref-side Hamming distances (BBDukParser.java:130-133);
+ * k, mink, rcomp, middleMask come from bbduk_create.  Leaves the handle finalized. */
+int  bbduk_build_table_device(bbduk_handle* h, const uint8_t* refs, const int64_t* ref_offsets, int32_t n_refs,
+                              int32_t hdist, int32_t hdist2);
 int64_t bbduk_table_size(const bbduk_handle* h);          /* distinct keys resident, or <0 */
 int64_t bbduk_table_bytes(const bbduk_handle* h);         /* HBM bytes held by the table image */
 /* point lookups through the device table (test hook): out_ids[i] = id or -1 */

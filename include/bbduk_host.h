@@ -45,6 +45,10 @@ int  bbduk_host_num_scaffolds(const bbduk_host* h);
 /* Fills the boundary struct from the parsed + derived fields (device ordinal as given). */
 int  bbduk_host_params(const bbduk_host* h, int32_t device, bbduk_params* out);
 
+/* Hands the loaded scaffolds to bbduk_build_table_device (the map is built on the GPU; bbduk_host_build_index is not
+ * needed).  BBDUK_ERR_ARG for edist>0 or hdist>2, which only the host builder serves. */
+int  bbduk_host_build_on_device(const bbduk_host* h, bbduk_handle* dev);
+
 /* Convenience for callers that hold a device handle: upload_pairs + finalize. */
 int  bbduk_host_upload_index(const bbduk_host* h, bbduk_handle* dev);
 

@@ -421,3 +421,51 @@ def test_random_flag_combinations(block):
         except AssertionError as e:
             raise AssertionError("config %r: %s" % (args, e))
         d.close()
+
+
+# ---- device-side table build (bbduk_build_table_device): same key -> id map as the oracle's loader, same results
+DEVBUILD = [("ktrim=r k=23 mink=11 hdist=1", dict(k=23, ktrimRight=1, mink=11, hdist=1)), ("k=31 hdist=1", dict(k=31, hdist=1)),
+            ("k=27", dict(k=27)), ("ktrim=l k=13 mink=6 hdist=1 hdist2=0", dict(k=13, ktrimLeft=1, mink=6, hdist=1, hdist2=0)),
+            ("k=11 hdist=2 mm=f", dict(k=11, hdist=2, maskMiddle=0)), ("ktrim=r k=12 mink=5 hdist=2 hdist2=2 rcomp=f", dict(k=12, ktrimRight=1, mink=5, hdist=2, hdist2=2, rcomp=0)),
+            ("k=20 hdist=1 mm=2", dict(k=20, hdist=1, midMaskLen=2)), ("ktrim=n k=16 mink=16 hdist=1", dict(k=16, ktrimN=1, mink=16, hdist=1))]
+
+
+@pytest.mark.parametrize("ci", range(len(DEVBUILD)))
+def test_device_built_table_equals_oracle_table(ci):
+    args, okw = DEVBUILD[ci]
+    rng = random.Random(500 + ci)
+    refs = [util.rand_seq(rng, rng.choice([3, 10, 11, 12, 23, 31, 40, 90, 200]), 0.02) for _ in range(12)] + [b"", b"ACGTN" * 9]
+    d = B.BBDuk(args, refs=refs, build="device")
+    o = Oracle(**okw)
+    for r in refs:
+        o.add_ref(r)
+    ks, vs = o.dump_pairs()
+    assert d.gpu.table_size == o.stored_kmers == len(ks)
+    assert np.array_equal(d.gpu.table_lookup(ks), vs)                    # every key, with the id of the first scaffold
+    have = set(ks.tolist())
+    absent = np.array([int(k) ^ 5 for k in ks[:2000].tolist() if (int(k) ^ 5) not in have], np.int64)
+    assert np.all(d.gpu.table_lookup(absent) == -1)
+    if okw.get("ktrimN"):
+        reads = util.fuzz_reads(rng, refs, 300, [0, 5, 16, 31, 64, 150], junk=True)
+        check_kmask(d, o, reads, True)
+    else:
+        reads = util.fuzz_reads(rng, refs, 400, [0, 1, 5, 10, 23, 31, 40, 64, 150, 300], junk=True)
+        check_batch(d, o, reads, True)
+    d.close()
+
+
+def test_device_built_adapter_and_phix_tables():
+    for cfg in ("c2", "c3", "c1"):
+        args, okw, ref = util.CONFIGS[cfg]
+        d = B.BBDuk(args, build="device")
+        o = Oracle(**okw); o.load_fasta(ref)
+        ks, vs = o.dump_pairs()
+        assert d.gpu.table_size == len(ks) and np.array_equal(d.gpu.table_lookup(ks), vs)
+        kw = dict(contam=B.read_fasta(util.PHIX)[0][1], contam_frac=0.05) if "phix" in args else {}
+        b, off = B.synth_generate_host(B.synth_params(51, **kw), 0, 5000)
+        d.gpu.reset_counters(); o.reset_counters()
+        ga, gi, gf = d.gpu.process_batch(b, off, True)
+        oa, oi, of = o.process_batch(b, off, True, nthreads=8)
+        assert np.array_equal(ga, oa) and np.array_equal(gi, oi) and np.array_equal(gf, of)
+        assert np.array_equal(d.gpu.counters(), o.counters())
+        d.close()
