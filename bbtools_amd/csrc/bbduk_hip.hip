@@ -2224,6 +2224,7 @@ extern "C" int bbduk_build_table_device(bbduk_handle* h, const uint8_t* refs, co
     if (hipStreamSynchronize(h->stream) != hipSuccess) { release(); return fail(h, BBDUK_ERR_DEVICE, "device build (enumeration) failed"); }
     int bbits = 10;
     while (bbits < 32 && (1ULL << bbits) < distinct) bbits++;
+    if (bbits == 30 && distinct <= (1ULL << 30)) bbits = 29;     // the slot index is 31 bits: the largest maps run at up to 2 keys per bucket
     const uint64_t nb = 1ULL << bbits;
     if (4 * nb > (1ULL << 31)) { release(); return fail(h, BBDUK_ERR_ARG, "too many keys for the bucket index"); }
     auto ceil_log2 = [](uint64_t x) { int b = 0; while ((1ULL << b) < x) b++; return b; };
