@@ -5,7 +5,7 @@
 // TrimRead.trimByAmount to bases+qualities with the returned amounts, route removed pairs, print the counters.
 //
 //   bbduk_cli in=r1.fq [in2=r2.fq | int=t] [out=clean.fq] [outm=removed.fq] [tsv=per_read.tsv] [resources=DIR]
-//             [batch=N] [device=D] <BBDuk flags: ktrim= k= mink= hdist= ref= literal= ...>
+//             [batch=N] [device=D] [devicebuild=t] <BBDuk flags: ktrim= k= mink= hdist= ref= literal= ...>
 //
 // tsv columns: name, length, result (ktrim: bases removed | kfilter: k-mer hits counted | ktrim=n: bases masked),
 // scaffold id or -1, length after trimming, flags (1 = read discarded, 2 = pair removed).  With ktrim=n / kmask= the
@@ -65,6 +65,7 @@ int main(int argc, char** argv) {
     std::string in1, in2, out, outm, tsv, resources = "data", flags;
     bool interleaved = false; long batch = 1000000; int device = 0;
     bool maskLower = false; char maskSymbol = 'N';
+    bool deviceBuild = false;        // devicebuild=t: the GPU builds the k-mer map from the reference sequences (bbduk_build_table_device)
     for (int i = 1; i < argc; i++) {
         const std::string tok = argv[i];
         const size_t eq = tok.find('=');
@@ -78,6 +79,7 @@ int main(int argc, char** argv) {
         else if (a == "resources") resources = b;
         else if (a == "batch") batch = atol(b.c_str());
         else if (a == "device") device = atoi(b.c_str());
+        else if (a == "devicebuild") deviceBuild = parse_bool(b);
         else {
             if (a == "ktrim" || a == "kmask" || a == "mask") {       // the replacement symbol is the caller's business (BBDukParser.java:619-644)
                 std::string v = b; for (auto& c : v) c = (char)tolower(c);
@@ -99,13 +101,16 @@ int main(int argc, char** argv) {
     bbduk_host* host = nullptr;
     if (bbduk_host_parse(flags.c_str(), &host, err, sizeof err) != BBDUK_OK) return fail("bad arguments", err);
     if (bbduk_host_load_refs(host, resources.c_str()) < 0) return fail("cannot load ref=", resources.c_str());
-    const int64_t stored = bbduk_host_build_index(host);
-    if (stored < 0) return fail("index build failed", nullptr);
+    int64_t stored = 0;
+    if (!deviceBuild) { stored = bbduk_host_build_index(host); if (stored < 0) return fail("index build failed", nullptr); }
     bbduk_params P;
     if (bbduk_host_params(host, device, &P) != BBDUK_OK) return fail("unsupported parameter combination", nullptr);
     bbduk_handle* dev = nullptr;
     if (bbduk_create(&P, &dev) != BBDUK_OK) return fail("bbduk_create", dev ? bbduk_last_error(dev) : "no usable device (there is no CPU fallback)");
-    if (bbduk_host_upload_index(host, dev) != BBDUK_OK) return fail("table upload", bbduk_last_error(dev));
+    if (deviceBuild) {
+        if (bbduk_host_build_on_device(host, dev) != BBDUK_OK) return fail("device-side table build (hdist <= 2, no edist)", bbduk_last_error(dev));
+        stored = bbduk_table_size(dev);
+    } else if (bbduk_host_upload_index(host, dev) != BBDUK_OK) return fail("table upload", bbduk_last_error(dev));
     fprintf(stderr, "Added %lld kmers; %d scaffolds.\n", (long long)stored, bbduk_host_num_scaffolds(host) - 1);
 
     Reader r1, r2;

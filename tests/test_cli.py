@@ -57,7 +57,7 @@ def test_cli_ktrim_two_files_matches_spec_tsv(tmp_path):
 @pytest.mark.gpu
 def test_cli_kfilter_interleaved_matches_spec_tsv(tmp_path):
     tsv = str(tmp_path / "o.tsv")
-    r = run_cli(["in=" + os.path.join(GOLD, "cli_c3_interleaved.fq"), "int=t", "tsv=" + tsv, "k=31", "hdist=1", "ref=phix"])
+    r = run_cli(["in=" + os.path.join(GOLD, "cli_c3_interleaved.fq"), "int=t", "tsv=" + tsv, "k=31", "hdist=1", "ref=phix", "devicebuild=t"])
     assert r.returncode == 0, r.stderr
     assert open(tsv).read() == open(os.path.join(GOLD, "cli_c3.tsv")).read()
     assert "Contaminants:" in r.stderr
