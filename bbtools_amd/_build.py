@@ -67,3 +67,9 @@ def build_timing_variant(verbose: bool = False) -> str:
     """Experiment build with the BBDUK_DBG stage-deletion switches compiled in (profiles/ab.sh loads it through
     BBDUK_LIB_PATH); never the product library."""
     return _compile(os.path.join(_HERE, "ab_tsw.so"), ["-DBBDUK_TIMING_SWITCHES"], verbose)
+
+
+def build_variant(name: str, flags, verbose: bool = False) -> str:
+    """Experiment build of the same sources with extra compiler flags (e.g. -DBBDUK_AB_ASCII_ONLY) as bbtools_amd/<name>.so,
+    for same-box A/B runs through BBDUK_LIB_PATH; never the product library."""
+    return _compile(os.path.join(_HERE, name + ".so"), list(flags), verbose)

@@ -50,13 +50,31 @@ class SynthParams(C.Structure):     # struct bbduk_synth_params
 GPU_SYMBOLS = ["bbduk_abi_version", "bbduk_create", "bbduk_destroy", "bbduk_last_error", "bbduk_upload_table_way",
                "bbduk_upload_pairs", "bbduk_finalize_table", "bbduk_build_table_device", "bbduk_table_size", "bbduk_table_bytes",
                "bbduk_table_lookup", "bbduk_ktrim_batch", "bbduk_kfilter_batch", "bbduk_ktrim_batch_device",
-               "bbduk_kfilter_batch_device", "bbduk_kmask_batch", "bbduk_kmask_batch_device", "bbduk_ktrimtips_batch", "bbduk_ktrimtips_batch_device", "bbduk_kernel_time_ms", "bbduk_counters_len", "bbduk_get_counters", "bbduk_reset_counters",
+               "bbduk_kfilter_batch_device", "bbduk_pack_bases_host", "bbduk_pack_bases_device", "bbduk_ktrim_batch_packed",
+               "bbduk_kfilter_batch_packed", "bbduk_ktrim_batch_packed_device", "bbduk_kfilter_batch_packed_device", "bbduk_kmask_batch", "bbduk_kmask_batch_device", "bbduk_ktrimtips_batch", "bbduk_ktrimtips_batch_device", "bbduk_kernel_time_ms", "bbduk_counters_len", "bbduk_get_counters", "bbduk_reset_counters",
                "bbduk_synth_generate_device", "bbduk_synth_generate_host"]
 HOST_SYMBOLS = ["bbduk_host_parse", "bbduk_host_destroy", "bbduk_host_add_ref", "bbduk_host_load_fasta",
                 "bbduk_host_load_refs", "bbduk_host_build_index", "bbduk_host_index_pairs",
                 "bbduk_host_num_scaffolds", "bbduk_host_params", "bbduk_host_upload_index", "bbduk_host_build_on_device"]
 
 _lib = None
+
+
+def pack_bases_host(bases):
+    """ASCII bases -> (codes uint32[(n+15)/16], undef uint32[(n+31)/32]) of the packed boundary format."""
+    bases = np.ascontiguousarray(bases, np.uint8)
+    n = len(bases)
+    codes = np.zeros((n + 15) // 16, np.uint32); undef = np.zeros((n + 31) // 32, np.uint32)
+    rc = lib().bbduk_pack_bases_host(bases.ctypes.data if n else None, n, codes.ctypes.data if n else None, undef.ctypes.data if n else None)
+    if rc != 0:
+        raise RuntimeError("bbduk_pack_bases_host failed (%d)" % rc)
+    return codes, undef
+
+
+def pack_bases_device(d_bases, d_codes, d_undef, device=0, stream_ptr=0):
+    rc = lib().bbduk_pack_bases_device(d_bases.data_ptr(), d_bases.numel(), d_codes.data_ptr(), d_undef.data_ptr(), device, stream_ptr)
+    if rc != 0:
+        raise RuntimeError("bbduk_pack_bases_device failed (%d)" % rc)
 
 
 def lib():
@@ -94,6 +112,12 @@ def lib():
     L.bbduk_kmask_batch_device.argtypes = [vp, vp, vp, i64, i64, i32, vp, vp, vp, vp, vp, vp]
     for f in (L.bbduk_ktrim_batch_device, L.bbduk_kfilter_batch_device):
         f.argtypes = [vp, vp, vp, i64, i64, i32, vp, vp, vp, vp, vp]
+    L.bbduk_pack_bases_host.argtypes = [vp, i64, vp, vp]
+    L.bbduk_pack_bases_device.argtypes = [vp, i64, vp, vp, i32, vp]
+    for f in (L.bbduk_ktrim_batch_packed, L.bbduk_kfilter_batch_packed):
+        f.argtypes = [vp, vp, vp, vp, i64, i32, vp, vp, vp]
+    for f in (L.bbduk_ktrim_batch_packed_device, L.bbduk_kfilter_batch_packed_device):
+        f.argtypes = [vp, vp, vp, vp, i64, i64, i32, vp, vp, vp, vp, vp]
     L.bbduk_kernel_time_ms.argtypes = [vp, i32, C.POINTER(C.c_float)]
     L.bbduk_counters_len.argtypes = [vp]
     L.bbduk_get_counters.argtypes = [vp, vp, i32]
@@ -292,6 +316,24 @@ class BBDukGpu:
         if self.params.mode == MODE_KFILTER:
             return self.kfilter_batch(bases, offsets, paired)
         return self.ktrim_batch(bases, offsets, paired)
+
+    # ---- packed boundary format (2-bit codes + undefined bits; offsets still count bases)
+    def process_batch_packed(self, codes, undef, offsets, paired):
+        codes = np.ascontiguousarray(codes, np.uint32); undef = np.ascontiguousarray(undef, np.uint32)
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        n = len(offsets) - 1
+        a = np.empty(n, np.int32); ids = np.empty(n, np.int32); fl = np.empty(n, np.uint8)
+        fn = lib().bbduk_kfilter_batch_packed if self.params.mode == MODE_KFILTER else lib().bbduk_ktrim_batch_packed
+        self._check(fn(self.h, codes.ctypes.data if len(codes) else None, undef.ctypes.data if len(undef) else None,
+                       offsets.ctypes.data, n, int(paired), a.ctypes.data, ids.ctypes.data, fl.ctypes.data), "batch_packed")
+        return a, ids, fl
+
+    def process_batch_packed_device(self, d_codes, d_undef, d_offsets, total_bases, paired, d_a, d_id, d_fl, d_counters, stream_ptr=0):
+        n = d_offsets.numel() - 1
+        fn = lib().bbduk_kfilter_batch_packed_device if self.params.mode == MODE_KFILTER else lib().bbduk_ktrim_batch_packed_device
+        self._check(fn(self.h, d_codes.data_ptr(), d_undef.data_ptr(), d_offsets.data_ptr(), n, int(total_bases), int(paired),
+                       d_a.data_ptr(), d_id.data_ptr(), d_fl.data_ptr(), d_counters.data_ptr(), stream_ptr),
+                    "batch_packed_device")
 
     # ---- device-buffer operators (torch tensors are only carriers of HBM pointers)
     def process_batch_device(self, d_bases, d_offsets, paired, d_a, d_id, d_fl, d_counters, stream_ptr=0):

@@ -57,6 +57,8 @@ struct KParams {
     int32_t rieb, trimPad, ktrimExclusive, restrictLeft, restrictRight, skipR1, skipR2, numScaffolds, useShort;
     int32_t tpe, qskip, speed;   // trimpairsevenly; qskip (<2 = off) and speed (0 = off) run in the general kernels only
     float   mkf, mcf;            // kfilter: minkmerfraction / mincoveredfraction (general kernels only)
+    const uint32_t* undef;      // packed input (bbduk_*_batch_packed): 1 bit per base, set = undefined; `bases` then points at
+                                // 2-bit codes, 16 bases per 32-bit word (A0 C1 G2 T/U3, undefined 0).  nullptr = ASCII bases
     uint64_t mask, kmask, middleMask;
     // The map, device layout: 4-way buckets.  tags[b] packs four 15-bit fingerprints in 16-bit lanes (0 = free
     // way) plus the bucket's continuation flag in bit 63; the full key and its id live together in bkv[4*b+way]
@@ -286,6 +288,35 @@ __device__ __forceinline__ void encode_chunk(const uint8_t* __restrict__ bases, 
 }
 
 // shared/TrimRead.java:304-345 trimByAmount on lengths
+// One 16-base chunk of the batch -> the three plane words, from either boundary format.  Packed input (0.375
+// B/base instead of 1) needs no character work at all: reverse the code word for the forward plane, complement it for
+// the other, and the undefined bits are already there.
+__device__ __forceinline__ uint32_t spread2(uint32_t v16) {        // bit j -> bits 2j and 2j+1
+    uint32_t x = v16;
+    x = (x | (x << 8)) & 0x00FF00FFu; x = (x | (x << 4)) & 0x0F0F0F0Fu; x = (x | (x << 2)) & 0x33333333u; x = (x | (x << 1)) & 0x55555555u;
+    return x * 3u;
+}
+// FMT: 0 = ASCII, 1 = packed (both fixed at compile time: the specialised wave kernels), 2 = decided per launch
+template <int FMT = 2>
+__device__ __forceinline__ void stage_chunk(const KParams& P, const uint8_t* __restrict__ bases, const int64_t a, const int64_t totalBases,
+                                            uint32_t& fwdRev, uint32_t& comp, uint32_t& valid) {
+    if (FMT == 0 || (FMT == 2 && P.undef == nullptr)) { encode_chunk(bases, a, totalBases, fwdRev, comp, valid); return; }
+    const int64_t w = a >> 4;
+    const int64_t left = totalBases - a;                             // bases of this chunk inside the batch
+    uint32_t code = 0, und = 0xFFFFu;
+    if (left > 0) {
+        code = reinterpret_cast<const uint32_t*>(bases)[w];
+        und = (P.undef[w >> 1] >> (16 * (int)(w & 1))) & 0xFFFFu;
+        if (left < 16) und |= 0xFFFFu << (int)left;
+    }
+    valid = ~und & 0xFFFFu;
+    const uint32_t vm = spread2(valid);
+    code &= vm;
+    comp = ~code & vm;
+    const uint32_t r = __brev(code);
+    fwdRev = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+}
+
 __device__ __forceinline__ int trim_by_amount(int len, int left, int right, int minRes, int& newLen) {
     left = max(left, 0); right = max(right, 0);
     if (len < 1) { newLen = len; return 0; }
@@ -1050,7 +1081,7 @@ void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
             // ---- stage: 16 bases per thread-iteration -> three bit-planes
             for (int c = tid; c < nchunks; c += BLOCK_THREADS) {
                 uint32_t r, comp, valid;
-                encode_chunk(bases, A0 + 16LL * c, totalBases, r, comp, valid);
+                stage_chunk(P, bases, A0 + 16LL * c, totalBases, r, comp, valid);
                 s_fwd[PLANE_PAD + nchunks - 1 - c] = r;
                 s_cmp[PLANE_PAD + c] = comp;
                 reinterpret_cast<uint16_t*>(s_nm)[c] = (uint16_t)(~valid & 0xFFFFu);
@@ -1288,7 +1319,7 @@ void bbduk_kmask_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
             const int nchunks = (int)((B1 - A0 + 15) >> 4);
             for (int c = tid; c < nchunks; c += BLOCK_THREADS) {
                 uint32_t r, comp, valid;
-                encode_chunk(bases, A0 + 16LL * c, totalBases, r, comp, valid);
+                stage_chunk(P, bases, A0 + 16LL * c, totalBases, r, comp, valid);
                 s_fwd[PLANE_PAD + nchunks - 1 - c] = r;
                 s_cmp[PLANE_PAD + c] = comp;
                 reinterpret_cast<uint16_t*>(s_nm)[c] = (uint16_t)(~valid & 0xFFFFu);
@@ -1478,7 +1509,7 @@ void bbduk_ktrimtips_kernel(const KParams P, const uint8_t* __restrict__ bases, 
             const int nchunks = (int)((B1 - A0 + 15) >> 4);
             for (int c = tid; c < nchunks; c += BLOCK_THREADS) {
                 uint32_t r, comp, valid;
-                encode_chunk(bases, A0 + 16LL * c, totalBases, r, comp, valid);
+                stage_chunk(P, bases, A0 + 16LL * c, totalBases, r, comp, valid);
                 s_fwd[PLANE_PAD + nchunks - 1 - c] = r;
                 s_cmp[PLANE_PAD + c] = comp;
                 reinterpret_cast<uint16_t*>(s_nm)[c] = (uint16_t)(~valid & 0xFFFFu);
@@ -1582,7 +1613,7 @@ __device__ __forceinline__ int wave_sum(int v) {
     return __builtin_amdgcn_readfirstlane(v);
 }
 
-template <int MODE, bool SHORT, bool FORBIDN, bool GENERAL>
+template <int MODE, bool SHORT, bool FORBIDN, bool GENERAL, int FMT>
 __global__ __launch_bounds__(BLOCK_THREADS)
 void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
                        const int64_t n, const int64_t totalBases, const int paired,
@@ -1675,7 +1706,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
             // ---- stage this wave's reads: 16 bases per lane-iteration -> the wave's private bit-planes
             for (int c = lane; c < nchunks && !TSW(P, 5); c += 64) {
                 uint32_t r, comp, valid;
-                encode_chunk(bases, A0 + 16LL * c, totalBases, r, comp, valid);
+                stage_chunk<FMT>(P, bases, A0 + 16LL * c, totalBases, r, comp, valid);
                 wf[PLANE_PAD + nchunks - 1 - c] = r;
                 wc[PLANE_PAD + c] = comp;
                 reinterpret_cast<uint16_t*>(wn)[c] = (uint16_t)(~valid & 0xFFFFu);
@@ -1973,9 +2004,15 @@ __global__ void bbduk_span_kernel(const int64_t* __restrict__ offsets, const int
 // runtime -> template dispatch
 typedef void (*batch_kernel_t)(const KParams, const uint8_t*, const int64_t*, const int64_t, const int64_t, const int,
                                int32_t*, int32_t*, uint8_t*, int64_t*, const int*);
-struct KernelPair { batch_kernel_t wave, tile; };
+struct KernelPair { batch_kernel_t wave, wavePacked, tile; };
 template <int MODE, bool SHORT, bool FORBIDN, bool GENERAL>
-static KernelPair kpair() { return KernelPair{bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL>, bbduk_batch_kernel<MODE, SHORT, FORBIDN, GENERAL>}; }
+static KernelPair kpair() {
+    // the specialised wave kernels exist once per input format; the general one and the tile fallback decide per launch
+    if (GENERAL) return KernelPair{bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL, 2>, bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL, 2>,
+                                   bbduk_batch_kernel<MODE, SHORT, FORBIDN, GENERAL>};
+    return KernelPair{bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL, 0>, bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL, 1>,
+                      bbduk_batch_kernel<MODE, SHORT, FORBIDN, GENERAL>};
+}
 template <int MODE>
 static KernelPair pick_kernel_mode(bool general, bool useShort, bool forbidN) {
     if (general) return kpair<MODE, true, true, true>();
@@ -1991,6 +2028,18 @@ static KernelPair pick_kernel(const KParams& K) {
     if (K.mode == BBDUK_MODE_KFILTER) return pick_kernel_mode<BBDUK_MODE_KFILTER>(general, false, K.forbidNs != 0);
     if (K.mode == BBDUK_MODE_KTRIM_L) return pick_kernel_mode<BBDUK_MODE_KTRIM_L>(general, K.useShort != 0, K.forbidNs != 0);
     return pick_kernel_mode<BBDUK_MODE_KTRIM_R>(general, K.useShort != 0, K.forbidNs != 0);
+}
+
+// ASCII bases -> the packed boundary format (one thread per 16-base word)
+__global__ void bbduk_pack_kernel(const uint8_t* __restrict__ bases, const int64_t total, uint32_t* __restrict__ codes, uint16_t* __restrict__ undef16) {
+    const int64_t words = (total + 15) >> 4;
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t r, comp, valid;
+        encode_chunk(bases, 16 * w, total, r, comp, valid);
+        const uint32_t x = __brev(r);                                 // undo the plane's symbol reversal: codes in base order
+        codes[w] = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+        undef16[w] = (uint16_t)(~valid & 0xFFFFu);
+    }
 }
 
 __global__ void bbduk_lookup_kernel(const KParams P, const int64_t* keys, int64_t n, int32_t* out) {
@@ -2034,6 +2083,7 @@ struct bbduk_handle {
     hipEvent_t ev0[EV_RING] = {}, ev1[EV_RING] = {}; int64_t evCount = 0;
     // host-operator staging
     uint8_t* d_bases = nullptr; size_t cap_bases = 0;
+    uint8_t* d_undef = nullptr; size_t cap_undef = 0;     // packed boundary: one undefined-base bit per base
     int64_t* d_off = nullptr;   size_t cap_reads = 0;
     int32_t* d_a = nullptr; int32_t* d_id = nullptr; uint8_t* d_fl = nullptr;
     int64_t* d_counters = nullptr;
@@ -2084,7 +2134,7 @@ extern "C" int bbduk_create(const bbduk_params* p, bbduk_handle** out) {
 extern "C" int bbduk_destroy(bbduk_handle* h) {
     if (!h) return BBDUK_ERR_ARG;
     hipSetDevice(h->p.device);
-    hipFree(h->d_tags); hipFree(h->d_bkv); hipFree(h->d_bases); hipFree(h->d_off);
+    hipFree(h->d_tags); hipFree(h->d_bkv); hipFree(h->d_bases); hipFree(h->d_undef); hipFree(h->d_off);
     hipFree(h->d_ldsImage); hipFree(h->d_slowFlag);
     for (int q = 0; q < bbduk_handle::EV_RING; q++) { if (h->ev0[q]) hipEventDestroy(h->ev0[q]); if (h->ev1[q]) hipEventDestroy(h->ev1[q]); }
     hipFree(h->d_a); hipFree(h->d_id); hipFree(h->d_fl); hipFree(h->d_counters);
@@ -2270,7 +2320,7 @@ static KParams make_kparams(const bbduk_handle* h) {
     K.kmask = 1ULL << (2 * p.k);
     K.middleMask = (uint64_t)p.middleMask;
     K.tags = h->d_tags; K.bkv = h->d_bkv; K.bucketMask = (uint32_t)(h->nbuckets - 1); K.bucketBits = h->bucketBits;
-    K.storedKmers = h->nkeys;
+    K.storedKmers = h->nkeys; K.undef = nullptr;
     K.dbg = getenv("BBDUK_DBG") ? atoi(getenv("BBDUK_DBG")) : 0;
     K.ldsImage = h->d_ldsImage; K.ldsBits = h->ldsBits;
     return K;
@@ -2278,7 +2328,7 @@ static KParams make_kparams(const bbduk_handle* h) {
 
 static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases, const int64_t* d_offsets, int64_t n,
                         int64_t total_bases, int32_t paired, int32_t* d_a, int32_t* d_id, uint8_t* d_fl,
-                        int64_t* d_counters, hipStream_t st) {
+                        int64_t* d_counters, hipStream_t st, const uint32_t* d_undef = nullptr, bool packed = false) {
     if (!h) return BBDUK_ERR_ARG;
     if (!h->finalized) return fail(h, BBDUK_ERR_STATE, "table not finalized");
     if (h->p.mode == BBDUK_MODE_KMASK || h->p.mode == BBDUK_MODE_KTRIM_TIPS || (h->p.mode == BBDUK_MODE_KFILTER) != (wantKfilter != 0)) return fail(h, BBDUK_ERR_STATE, "operator does not match the mode given to bbduk_create");
@@ -2286,12 +2336,15 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     if (n == 0) return BBDUK_OK;
     if (!d_bases && total_bases > 0) return fail(h, BBDUK_ERR_ARG, "null bases");
     if (!d_offsets || !d_a || !d_id || !d_fl || !d_counters) return fail(h, BBDUK_ERR_ARG, "null buffer");
-    if (((uintptr_t)d_bases & 15) != 0) return fail(h, BBDUK_ERR_ARG, "d_bases must be 16-byte aligned");
-    const KParams K = make_kparams(h);
+    if (!packed && ((uintptr_t)d_bases & 15) != 0) return fail(h, BBDUK_ERR_ARG, "d_bases must be 16-byte aligned");
+    if (packed && (!d_undef || ((uintptr_t)d_bases & 3) != 0)) return fail(h, BBDUK_ERR_ARG, "packed input needs both planes, 4-byte aligned");
+    KParams K = make_kparams(h);
+    K.undef = packed ? d_undef : nullptr;
     const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
     const size_t dynLds = h->ldsBits ? ((size_t)1 << (h->ldsBits - 3)) : 0;    // tile kernel: the filter only
     const size_t waveLds = dynLds + WAVE_LDS_BYTES;                             // wave kernel: filter + its per-wave state
-    const KernelPair kp = pick_kernel(K);
+    KernelPair kp = pick_kernel(K);
+    if (packed) kp.wave = kp.wavePacked;
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)waveLds));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.tile), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
     // pre-pass: if some pair is longer than a wave's planes the tile kernel takes the whole batch, else the wave kernel
@@ -2333,15 +2386,57 @@ extern "C" int bbduk_kfilter_batch_device(bbduk_handle* h, const uint8_t* d_base
     return launch_batch(h, 1, d_bases, d_offsets, n, total_bases, paired, d_out_found, d_out_id, d_out_flags, d_counters, (hipStream_t)stream);
 }
 
+// ---- packed boundary format (2-bit codes + undefined bits)
+extern "C" int bbduk_pack_bases_device(const uint8_t* d_bases, int64_t total_bases, uint32_t* d_codes, uint32_t* d_undef, int32_t device, void* stream) {
+    if (total_bases < 0 || (total_bases > 0 && (!d_bases || !d_codes || !d_undef))) return BBDUK_ERR_ARG;
+    if (total_bases == 0) return BBDUK_OK;
+    if (hipSetDevice(device) != hipSuccess) return BBDUK_ERR_DEVICE;
+    const int64_t words = (total_bases + 15) >> 4;
+    const int grid = (int)std::min<int64_t>((words + 255) / 256, 1 << 20);
+    bbduk_pack_kernel<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(d_bases, total_bases, d_codes, reinterpret_cast<uint16_t*>(d_undef));
+    return hipGetLastError() == hipSuccess ? BBDUK_OK : BBDUK_ERR_DEVICE;
+}
+extern "C" int bbduk_pack_bases_host(const uint8_t* bases, int64_t total_bases, uint32_t* codes, uint32_t* undef) {
+    if (total_bases < 0 || (total_bases > 0 && (!bases || !codes || !undef))) return BBDUK_ERR_ARG;
+    const int64_t cw = (total_bases + 15) >> 4, uw = (total_bases + 31) >> 5;
+    for (int64_t w = 0; w < cw; w++) codes[w] = 0;
+    for (int64_t w = 0; w < uw; w++) undef[w] = 0;
+    for (int64_t b = 0; b < total_bases; b++) {
+        const uint8_t l = bases[b] | 0x20;
+        const int c = l == 'a' ? 0 : l == 'c' ? 1 : l == 'g' ? 2 : (l == 't' || l == 'u') ? 3 : -1;      // dna/AminoAcid.java:1284-1298
+        if (c < 0) undef[b >> 5] |= 1u << (b & 31); else codes[b >> 4] |= (uint32_t)c << (2 * (b & 15));
+    }
+    for (int64_t b = total_bases; b < 32 * uw; b++) undef[b >> 5] |= 1u << (b & 31);                     // the tail of the last word is undefined
+    return BBDUK_OK;
+}
+extern "C" int bbduk_ktrim_batch_packed_device(bbduk_handle* h, const uint32_t* d_codes, const uint32_t* d_undef, const int64_t* d_offsets, int64_t n,
+                                               int64_t total_bases, int32_t paired, int32_t* d_out_trimmed, int32_t* d_out_id0,
+                                               uint8_t* d_out_flags, int64_t* d_counters, void* stream) {
+    return launch_batch(h, 0, reinterpret_cast<const uint8_t*>(d_codes), d_offsets, n, total_bases, paired, d_out_trimmed, d_out_id0, d_out_flags, d_counters, (hipStream_t)stream, d_undef, true);
+}
+extern "C" int bbduk_kfilter_batch_packed_device(bbduk_handle* h, const uint32_t* d_codes, const uint32_t* d_undef, const int64_t* d_offsets, int64_t n,
+                                                 int64_t total_bases, int32_t paired, int32_t* d_out_found, int32_t* d_out_id,
+                                                 uint8_t* d_out_flags, int64_t* d_counters, void* stream) {
+    return launch_batch(h, 1, reinterpret_cast<const uint8_t*>(d_codes), d_offsets, n, total_bases, paired, d_out_found, d_out_id, d_out_flags, d_counters, (hipStream_t)stream, d_undef, true);
+}
+
 static int host_batch(bbduk_handle* h, int wantKfilter, const uint8_t* bases, const int64_t* offsets, int64_t n, int32_t paired,
-                      int32_t* out_a, int32_t* out_id, uint8_t* out_fl) {
+                      int32_t* out_a, int32_t* out_id, uint8_t* out_fl, const uint32_t* undef = nullptr, bool packed = false) {
     if (!h) return BBDUK_ERR_ARG;
     if (n < 0 || !offsets || (n > 0 && (!out_a || !out_id || !out_fl))) return fail(h, BBDUK_ERR_ARG, "bad argument");
     if (n == 0) return BBDUK_OK;
     const int64_t total = offsets[n];
     if (offsets[0] != 0 || total < 0 || (total > 0 && !bases)) return fail(h, BBDUK_ERR_ARG, "bad offsets");
+    if (packed && total > 0 && !undef) return fail(h, BBDUK_ERR_ARG, "packed input needs the undefined-bit plane");
+    const size_t baseBytes = packed ? 4 * (size_t)((total + 15) >> 4) : (size_t)total;      // what crosses PCIe for the bases
+    const size_t undefBytes = packed ? 4 * (size_t)((total + 31) >> 5) : 0;
     std::lock_guard<std::mutex> g(h->mu);       // one staging area per handle: concurrent submitters serialise here
     HIP_TRY(h, hipSetDevice(h->p.device));
+    if (undefBytes + 8 > h->cap_undef) {
+        hipFree(h->d_undef); h->d_undef = nullptr;
+        h->cap_undef = undefBytes + 8 + undefBytes / 4;
+        HIP_TRY(h, hipMalloc(&h->d_undef, h->cap_undef));
+    }
     if ((size_t)total + 16 > h->cap_bases) {
         hipFree(h->d_bases); h->d_bases = nullptr;
         h->cap_bases = (size_t)total + 16 + (size_t)total / 4;
@@ -2356,9 +2451,11 @@ static int host_batch(bbduk_handle* h, int wantKfilter, const uint8_t* bases, co
         HIP_TRY(h, hipMalloc(&h->d_id, h->cap_reads * sizeof(int32_t)));
         HIP_TRY(h, hipMalloc(&h->d_fl, h->cap_reads));
     }
-    if (total > 0) HIP_TRY(h, hipMemcpyAsync(h->d_bases, bases, (size_t)total, hipMemcpyHostToDevice, h->stream));
+    if (total > 0) HIP_TRY(h, hipMemcpyAsync(h->d_bases, bases, baseBytes, hipMemcpyHostToDevice, h->stream));
+    if (undefBytes) HIP_TRY(h, hipMemcpyAsync(h->d_undef, undef, undefBytes, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_off, offsets, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
-    const int rc = launch_batch(h, wantKfilter, h->d_bases, h->d_off, n, total, paired, h->d_a, h->d_id, h->d_fl, h->d_counters, h->stream);
+    const int rc = launch_batch(h, wantKfilter, h->d_bases, h->d_off, n, total, paired, h->d_a, h->d_id, h->d_fl, h->d_counters, h->stream,
+                                reinterpret_cast<const uint32_t*>(h->d_undef), packed);
     if (rc != BBDUK_OK) return rc;
     HIP_TRY(h, hipMemcpyAsync(out_a, h->d_a, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(out_id, h->d_id, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
@@ -2517,6 +2614,15 @@ extern "C" int bbduk_kmask_batch(bbduk_handle* h, const uint8_t* bases, const in
         return fail(h, -(int)status, "device reported an error (read longer than BBDUK_MAX_READ_LEN?)");
     }
     return BBDUK_OK;
+}
+
+extern "C" int bbduk_ktrim_batch_packed(bbduk_handle* h, const uint32_t* codes, const uint32_t* undef, const int64_t* offsets, int64_t n, int32_t paired,
+                                        int32_t* out_trimmed, int32_t* out_id0, uint8_t* out_flags) {
+    return host_batch(h, 0, reinterpret_cast<const uint8_t*>(codes), offsets, n, paired, out_trimmed, out_id0, out_flags, undef, true);
+}
+extern "C" int bbduk_kfilter_batch_packed(bbduk_handle* h, const uint32_t* codes, const uint32_t* undef, const int64_t* offsets, int64_t n, int32_t paired,
+                                          int32_t* out_found, int32_t* out_id, uint8_t* out_flags) {
+    return host_batch(h, 1, reinterpret_cast<const uint8_t*>(codes), offsets, n, paired, out_found, out_id, out_flags, undef, true);
 }
 
 extern "C" int bbduk_table_lookup(bbduk_handle* h, const int64_t* keys, int64_t n, int32_t* out_ids) {

@@ -140,6 +140,33 @@ int  bbduk_kfilter_batch_device(bbduk_handle* h, const uint8_t* d_bases, const i
                                 int64_t total_bases, int32_t paired, int32_t* d_out_found, int32_t* d_out_id,
                                 uint8_t* d_out_flags, int64_t* d_counters, void* stream);
 
+/* ---- packed boundary format.  The reference keeps reads as one ASCII byte per base (`Read.bases`, stream/Read.java) and
+ * converts each base to its 2-bit code inside the rolling loops (AminoAcid.baseToNumber / baseToComplementNumber,
+ * bbduk/BBDukProcessorS.java:1752-1757); these entry points take the same reads with that conversion already done by
+ * the caller, which cuts the bytes over PCIe 2.7x and removes the character work from the kernel:
+ *   codes : 2 bits per base, 16 bases per uint32, base b of the concatenated buffer in bits 2*(b%16).. of word b/16
+ *           (A=0 C=1 G=2 T/U=3, dna/AminoAcid.java:1284-1298); undefined bases may hold any code; (total+15)/16 words
+ *   undef : 1 bit per base, bit b%32 of word b/32 set <=> baseToNumber[base] < 0 (N, IUPAC, junk); (total+31)/32 words;
+ *           bits past `total` in the last word are ignored
+ *   offsets, outputs, flags, counters: exactly as for the ASCII operators (offsets count BASES).
+ * bbduk_pack_bases_* produce the format from ASCII (host: plain C loop; device: one kernel).  Device buffers must be
+ * 16-byte aligned. */
+int  bbduk_pack_bases_host(const uint8_t* bases, int64_t total_bases, uint32_t* codes, uint32_t* undef);
+int  bbduk_pack_bases_device(const uint8_t* d_bases, int64_t total_bases, uint32_t* d_codes, uint32_t* d_undef,
+                             int32_t device, void* stream);
+int  bbduk_ktrim_batch_packed(bbduk_handle* h, const uint32_t* codes, const uint32_t* undef, const int64_t* offsets,
+                              int64_t n, int32_t paired, int32_t* out_trimmed, int32_t* out_id0, uint8_t* out_flags);
+int  bbduk_kfilter_batch_packed(bbduk_handle* h, const uint32_t* codes, const uint32_t* undef, const int64_t* offsets,
+                                int64_t n, int32_t paired, int32_t* out_found, int32_t* out_id, uint8_t* out_flags);
+int  bbduk_ktrim_batch_packed_device(bbduk_handle* h, const uint32_t* d_codes, const uint32_t* d_undef,
+                                     const int64_t* d_offsets, int64_t n, int64_t total_bases, int32_t paired,
+                                     int32_t* d_out_trimmed, int32_t* d_out_id0, uint8_t* d_out_flags,
+                                     int64_t* d_counters, void* stream);
+int  bbduk_kfilter_batch_packed_device(bbduk_handle* h, const uint32_t* d_codes, const uint32_t* d_undef,
+                                       const int64_t* d_offsets, int64_t n, int64_t total_bases, int32_t paired,
+                                       int32_t* d_out_found, int32_t* d_out_id, uint8_t* d_out_flags,
+                                       int64_t* d_counters, void* stream);
+
 /* ---- ktrim=n (bbduk/BBDukProcessorS.java:2149-2323, kmaskFullyCovered=false).  out_masked[i] = kmask(Read)'s return
  * (BitSet.cardinality()), out_mask = one bit per base of the concatenated `bases` buffer (bit b of word b/32 set <=> the
  * caller replaces base b by trimSymbol / lower-cases it, :2309-2320); (offsets[n]+31)/32 words, the device variant needs

@@ -35,6 +35,14 @@ def check_batch(d, o, reads, paired, nthreads=4):
     bad = np.nonzero((ga != oa) | (gi != oi) | (gf != of))[0]
     assert len(bad) == 0, [(int(i), reads[i], (int(ga[i]), int(gi[i]), int(gf[i])), (int(oa[i]), int(oi[i]), int(of[i]))) for i in bad[:3]]
     assert np.array_equal(d.gpu.counters(), o.counters())
+    if d.gpu.params.mode in (B.MODE_KTRIM_R, B.MODE_KTRIM_L, B.MODE_KFILTER):
+        # the packed boundary format (2-bit codes + undefined bits) must give the same answers as the ASCII one
+        codes, undef = B.pack_bases_host(b)
+        d.gpu.reset_counters()
+        pa, pi, pf = d.gpu.process_batch_packed(codes, undef, off, paired)
+        bad = np.nonzero((pa != oa) | (pi != oi) | (pf != of))[0]
+        assert len(bad) == 0, ("packed", [(int(i), reads[i], (int(pa[i]), int(pi[i]), int(pf[i])), (int(oa[i]), int(oi[i]), int(of[i]))) for i in bad[:3]])
+        assert np.array_equal(d.gpu.counters(), o.counters())
 
 
 # ---- golden fixtures
@@ -174,6 +182,58 @@ def test_tile_kernel_fallback_matches_wave_kernel(monkeypatch):
             assert np.array_equal(ga, oa) and np.array_equal(gi, oi) and np.array_equal(gf, of), (cfg, force)
             assert np.array_equal(d.gpu.counters(), o.counters()), (cfg, force)
         monkeypatch.delenv("BBDUK_FORCE_TILE", raising=False)
+        d.close()
+
+
+def test_packed_format_device_pack_and_operators(monkeypatch):
+    """bbduk_pack_bases_device == bbduk_pack_bases_host on arbitrary bytes; the device-buffer packed operators equal the
+    ASCII ones (wave kernel and forced tile kernel), including undefined code bits holding garbage."""
+    import torch
+    rng = np.random.default_rng(9)
+    for nb in (0, 1, 15, 16, 17, 31, 32, 33, 1000, 65537):
+        raw = rng.integers(0, 256, nb, dtype=np.uint8)
+        hc, hu = B.pack_bases_host(raw)
+        d_raw = torch.from_numpy(np.concatenate([raw, np.zeros(16, np.uint8)])).cuda()[:nb]
+        d_c = torch.full((len(hc) + 4,), -1, dtype=torch.int32, device="cuda"); d_u = torch.full((len(hu) + 4,), -1, dtype=torch.int32, device="cuda")
+        B.pack_bases_device(d_raw, d_c, d_u)
+        torch.cuda.synchronize()
+        gc = d_c.cpu().numpy().view(np.uint32); gu = d_u.cpu().numpy().view(np.uint32)
+        if nb:
+            defined = np.ones(16 * len(hc), bool); defined[:nb] = ((hu.view(np.uint8)[:, None] >> np.arange(8)) & 1).reshape(-1)[:nb] == 0; defined[nb:] = False
+            cm = np.repeat(defined, 2).reshape(-1, 32)
+            cmask = (cm.astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(axis=1).astype(np.uint32)
+            assert np.array_equal(gc[:len(hc)] & cmask, hc & cmask), nb
+            tail = nb % 32
+            um = np.full(len(hu), 0xFFFFFFFF, np.uint32)
+            if tail:
+                um[-1] = (1 << tail) - 1
+            assert np.array_equal(gu[:len(hu)] & um, hu & um), nb
+    for cfg in ("c2", "c3", "c2tpe", "c3mcf"):
+        args, okw, ref = util.CONFIGS[cfg]
+        d, o = make_pair(args, okw, ref_fasta=ref)
+        kw = dict(contam=B.read_fasta(util.PHIX)[0][1], contam_frac=0.05) if "phix" in args else {}
+        b, off = B.synth_generate_host(B.synth_params(33, **kw), 0, 5000)
+        b = b.copy(); b[rng.integers(0, len(b), 3000)] = ord("N")
+        o.reset_counters(); oa, oi, of = o.process_batch(b, off, True, nthreads=8)
+        n = len(off) - 1
+        codes, undef = B.pack_bases_host(b)
+        und_bits = ((undef.view(np.uint8)[:, None] >> np.arange(8)) & 1).reshape(-1)[:16 * len(codes)]
+        junk = np.repeat(und_bits.astype(np.uint32), 2).reshape(-1, 32)        # garbage in the code bits of undefined bases
+        junk = (junk.astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(axis=1).astype(np.uint32)
+        codes = codes | (junk & rng.integers(0, 2 ** 32, len(codes), dtype=np.uint64).astype(np.uint32))
+        d_c = torch.from_numpy(codes.view(np.int32)).cuda(); d_u = torch.from_numpy(undef.view(np.int32)).cuda()
+        d_off = torch.from_numpy(off).cuda()
+        for force in (False, True):
+            if force:
+                monkeypatch.setenv("BBDUK_FORCE_TILE", "1")
+            else:
+                monkeypatch.delenv("BBDUK_FORCE_TILE", raising=False)
+            d_a = torch.empty(n, dtype=torch.int32, device="cuda"); d_i = torch.empty(n, dtype=torch.int32, device="cuda")
+            d_f = torch.empty(n, dtype=torch.uint8, device="cuda"); d_ctr = torch.zeros(d.gpu.counters_len, dtype=torch.int64, device="cuda")
+            d.gpu.process_batch_packed_device(d_c, d_u, d_off, len(b), True, d_a, d_i, d_f, d_ctr)
+            torch.cuda.synchronize()
+            assert np.array_equal(d_a.cpu().numpy(), oa) and np.array_equal(d_i.cpu().numpy(), oi) and np.array_equal(d_f.cpu().numpy(), of), (cfg, force)
+            assert np.array_equal(d_ctr.cpu().numpy()[:len(o.counters())], o.counters()), (cfg, force)
         d.close()
 
 

@@ -108,3 +108,24 @@ def test_synth_generator_is_deterministic_and_shaped():
     sp1 = B.synth_params(7, n_rate=0.0, sub_rate=0.0, ins_min=100, ins_max=100)
     b, _ = B.synth_generate_host(sp1, 0, 2)
     assert bytes(b[100:150]) == B.TRUSEQ_R1[:50] and bytes(b[250:300]) == B.TRUSEQ_R2[:50]
+
+
+def test_pack_bases_host_layout():
+    """Packed boundary format: 2-bit codes in base order (16 per uint32), one undefined bit per base, tail of the last
+    undefined word set.  Host-only C loop (no device call)."""
+    rng = np.random.default_rng(5)
+    for nb in (0, 1, 15, 16, 17, 33, 1000):
+        raw = rng.choice(np.frombuffer(b"ACGTacgtUuNnRY.-*\x00\xff", np.uint8), nb)
+        codes, undef = B.pack_bases_host(raw)
+        assert len(codes) == (nb + 15) // 16 and len(undef) == (nb + 31) // 32
+        lut = np.full(256, -1, np.int64)
+        for ch, v in zip(b"ACGTUacgtu", [0, 1, 2, 3, 3] * 2):
+            lut[ch] = v
+        want = lut[raw]
+        for b in range(nb):
+            u = (int(undef[b >> 5]) >> (b & 31)) & 1
+            assert u == (want[b] < 0)
+            if not u:
+                assert (int(codes[b >> 4]) >> (2 * (b & 15))) & 3 == want[b]
+        for b in range(nb, 32 * len(undef)):
+            assert (int(undef[b >> 5]) >> (b & 31)) & 1 == 1
