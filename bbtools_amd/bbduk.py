@@ -15,7 +15,7 @@ import numpy as np
 from ._build import lib_path
 
 OK = 0
-MODE_KFILTER, MODE_KTRIM_R, MODE_KTRIM_L, MODE_KMASK, MODE_KTRIM_TIPS = 0, 1, 2, 3, 4
+MODE_KFILTER, MODE_KTRIM_R, MODE_KTRIM_L, MODE_KMASK, MODE_KTRIM_TIPS, MODE_KSPLIT = 0, 1, 2, 3, 4, 5
 FLAG_DISCARDED, FLAG_REMOVED = 1, 2
 NCOUNTERS = 16
 COUNTER_NAMES = ["readsIn", "basesIn", "readsKTrimmed", "basesKTrimmed", "readsKFiltered", "basesKFiltered",
@@ -36,7 +36,8 @@ class Params(C.Structure):          # struct bbduk_params
                 ("restrictLeft", C.c_int32), ("restrictRight", C.c_int32), ("skipR1", C.c_int32),
                 ("skipR2", C.c_int32), ("numScaffolds", C.c_int32), ("device", C.c_int32),
                 ("trimPairsEvenly", C.c_int32), ("qSkip", C.c_int32), ("speed", C.c_int32),
-                ("minKmerFraction", C.c_float), ("minCoveredFraction", C.c_float), ("reserved", C.c_int32 * 3)]
+                ("minKmerFraction", C.c_float), ("minCoveredFraction", C.c_float), ("kbig", C.c_int32), ("findBestMatch", C.c_int32),
+                ("reserved", C.c_int32 * 1)]
 
 
 class SynthParams(C.Structure):     # struct bbduk_synth_params
@@ -51,7 +52,7 @@ GPU_SYMBOLS = ["bbduk_abi_version", "bbduk_create", "bbduk_destroy", "bbduk_last
                "bbduk_upload_pairs", "bbduk_finalize_table", "bbduk_build_table_device", "bbduk_table_size", "bbduk_table_bytes",
                "bbduk_table_lookup", "bbduk_ktrim_batch", "bbduk_kfilter_batch", "bbduk_ktrim_batch_device",
                "bbduk_kfilter_batch_device", "bbduk_pack_bases_host", "bbduk_pack_bases_device", "bbduk_ktrim_batch_packed",
-               "bbduk_kfilter_batch_packed", "bbduk_ktrim_batch_packed_device", "bbduk_kfilter_batch_packed_device", "bbduk_kmask_batch", "bbduk_kmask_batch_device", "bbduk_ktrimtips_batch", "bbduk_ktrimtips_batch_device", "bbduk_kernel_time_ms", "bbduk_counters_len", "bbduk_get_counters", "bbduk_reset_counters",
+               "bbduk_kfilter_batch_packed", "bbduk_ktrim_batch_packed_device", "bbduk_kfilter_batch_packed_device", "bbduk_kmask_batch", "bbduk_kmask_batch_device", "bbduk_ktrimtips_batch", "bbduk_ktrimtips_batch_device", "bbduk_ksplit_batch", "bbduk_ksplit_batch_device", "bbduk_kernel_time_ms", "bbduk_counters_len", "bbduk_get_counters", "bbduk_reset_counters",
                "bbduk_synth_generate_device", "bbduk_synth_generate_host"]
 HOST_SYMBOLS = ["bbduk_host_parse", "bbduk_host_destroy", "bbduk_host_add_ref", "bbduk_host_load_fasta",
                 "bbduk_host_load_refs", "bbduk_host_build_index", "bbduk_host_index_pairs",
@@ -108,6 +109,8 @@ def lib():
         f.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp]
     L.bbduk_kmask_batch.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, vp]
     L.bbduk_ktrimtips_batch.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, vp]
+    L.bbduk_ksplit_batch.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp]
+    L.bbduk_ksplit_batch_device.argtypes = [vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp]
     L.bbduk_ktrimtips_batch_device.argtypes = [vp, vp, vp, i64, i64, i32, vp, vp, vp, vp, vp, vp]
     L.bbduk_kmask_batch_device.argtypes = [vp, vp, vp, i64, i64, i32, vp, vp, vp, vp, vp, vp]
     for f in (L.bbduk_ktrim_batch_device, L.bbduk_kfilter_batch_device):
@@ -307,7 +310,20 @@ class BBDukGpu:
                                                 xr.ctypes.data, xl.ctypes.data, ids.ctypes.data, fl.ctypes.data), "ktrimtips_batch")
         return xr, xl, ids, fl
 
+    def ksplit_batch(self, bases, offsets):
+        """ksplit (unpaired): (bases removed, ids, flags, leftmost, rightmost)."""
+        bases = np.ascontiguousarray(bases, np.uint8); offsets = np.ascontiguousarray(offsets, np.int64)
+        n = len(offsets) - 1
+        x = np.empty(n, np.int32); lm = np.empty(n, np.int32); rm = np.empty(n, np.int32); ids = np.empty(n, np.int32); fl = np.empty(n, np.uint8)
+        self._check(lib().bbduk_ksplit_batch(self.h, bases.ctypes.data if len(bases) else None, offsets.ctypes.data, n,
+                                             x.ctypes.data, lm.ctypes.data, rm.ctypes.data, ids.ctypes.data, fl.ctypes.data), "ksplit_batch")
+        return x, ids, fl, lm, rm
+
     def process_batch(self, bases, offsets, paired):
+        if self.params.mode == MODE_KSPLIT:
+            if paired:
+                raise BBDukError("ksplit works on unpaired reads (BBDukProcessorS.java:2334)")
+            return self.ksplit_batch(bases, offsets)[:3]
         if self.params.mode == MODE_KTRIM_TIPS:
             xr, xl, ids, fl = self.ktrimtips_batch(bases, offsets, paired)
             return xr + xl, ids, fl

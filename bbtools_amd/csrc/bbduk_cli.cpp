@@ -123,7 +123,8 @@ int main(int argc, char** argv) {
 
     const bool ktrim = P.mode != BBDUK_MODE_KFILTER;
     std::vector<Rec> recs; std::vector<uint8_t> bases; std::vector<int64_t> offsets;
-    std::vector<int32_t> res, ids, resL; std::vector<uint8_t> fl; std::vector<uint32_t> mask;
+    std::vector<int32_t> res, ids, resL, resR; std::vector<uint8_t> fl; std::vector<uint32_t> mask;
+    if (P.mode == BBDUK_MODE_KSPLIT && paired) return fail("ksplit works on unpaired reads (BBDukProcessorS.java:2334)", nullptr);
     bool eof = false; long long nread = 0;
     while (!eof) {
         recs.clear(); bases.clear(); offsets.assign(1, 0);
@@ -148,6 +149,9 @@ int main(int argc, char** argv) {
         if (P.mode == BBDUK_MODE_KTRIM_TIPS) {
             resL.resize(n);
             rc = bbduk_ktrimtips_batch(dev, bases.data(), offsets.data(), n, paired, res.data(), resL.data(), ids.data(), fl.data());
+        } else if (P.mode == BBDUK_MODE_KSPLIT) {
+            resL.resize(n); resR.resize(n);
+            rc = bbduk_ksplit_batch(dev, bases.data(), offsets.data(), n, res.data(), resL.data(), resR.data(), ids.data(), fl.data());
         } else if (P.mode == BBDUK_MODE_KMASK) {
             mask.assign((size_t)(offsets[n] + 31) / 32 + 1, 0u);
             rc = bbduk_kmask_batch(dev, bases.data(), offsets.data(), n, paired, res.data(), ids.data(), fl.data(), mask.data());
@@ -160,6 +164,23 @@ int main(int argc, char** argv) {
             int left = 0, right = 0;                                 // TrimRead.trimByAmount(r, left, right, 1) with the returned amount
             if (P.mode == BBDUK_MODE_KTRIM_R) right = res[i]; else if (P.mode == BBDUK_MODE_KTRIM_L) left = res[i];
             else if (P.mode == BBDUK_MODE_KTRIM_TIPS) { right = res[i]; left = resL[i]; res[i] += resL[i]; }     // the tsv shows the sum
+            if (P.mode == BBDUK_MODE_KSPLIT && res[i] > 0 && !(fl[i] & BBDUK_FLAG_REMOVED)) {     // :2485-2490: the match touches an end
+                if (resL[i] == 0) left = res[i]; else right = res[i];
+            }
+            if (P.mode == BBDUK_MODE_KSPLIT && (fl[i] & BBDUK_FLAG_REMOVED)) {                    // :2491-2498: two pieces, a pair for outm
+                const int lm = resL[i], rm = resR[i];
+                if (ftsv) fprintf(ftsv, "%s\t%d\t%d\t%d\t%d\t%d\n", r.name.c_str(), L, res[i], ids[i], L - res[i], (int)fl[i]);
+                if (foutm) {
+                    fprintf(foutm, "@%s\n", r.name.c_str());
+                    fwrite(r.bases.data(), 1, (size_t)lm, foutm); fputs("\n+\n", foutm);
+                    fwrite(r.quals.data(), 1, (size_t)lm, foutm); fputc('\n', foutm);
+                    const int n2 = (L - 1) - (rm + 1);                                             // subRead(rightmost+1, length-1)
+                    fprintf(foutm, "@%s\n", r.name.c_str());
+                    fwrite(r.bases.data() + rm + 1, 1, (size_t)n2, foutm); fputs("\n+\n", foutm);
+                    fwrite(r.quals.data() + rm + 1, 1, (size_t)n2, foutm); fputc('\n', foutm);
+                }
+                continue;
+            }
             const int newLen = L - left - right;
             if (P.mode == BBDUK_MODE_KMASK && res[i] > 0) {            // :2309-2320
                 for (int b = 0; b < L; b++) {

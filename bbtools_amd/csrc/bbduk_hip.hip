@@ -57,6 +57,7 @@ struct KParams {
     int32_t rieb, trimPad, ktrimExclusive, restrictLeft, restrictRight, skipR1, skipR2, numScaffolds, useShort;
     int32_t tpe, qskip, speed;   // trimpairsevenly; qskip (<2 = off) and speed (0 = off) run in the general kernels only
     float   mkf, mcf;            // kfilter: minkmerfraction / mincoveredfraction (general kernels only)
+    int32_t kbig, fbm;           // kfilter variants of bbduk_kscan_kernel: k>31 emulation (kbig>k), findBestMatch
     const uint32_t* undef;      // packed input (bbduk_*_batch_packed): 1 bit per base, set = undefined; `bases` then points at
                                 // 2-bit codes, 16 bases per 32-bit word (A0 C1 G2 T/U3, undefined 0).  nullptr = ASCII bases
     uint64_t mask, kmask, middleMask;
@@ -745,6 +746,27 @@ __device__ __forceinline__ int valid_kmers_wave(const Planes& Q, const int base0
         const int i = i0 + lane;
         const bool v = (i < L) && extract1(Q.nm, base0 + min(i, L - 1) - k + 1, k) == 0u;
         cnt += __popcll(__ballot(v));
+    }
+    return cnt;
+}
+// The same count for any k (keff = kbig may exceed a 32-bit window): 64 positions per step, the undefined bases of a
+// step split it into defined segments; a segment that takes the run of defined bases from r0 to r0+seg adds the
+// positions whose run length reaches k.
+__device__ __forceinline__ int valid_kmers_any_k(const Planes& Q, const int base0, const int L, const int k, const int lane) {
+    int cnt = 0, run = 0;
+    for (int i0 = 0; i0 < L; i0 += 64) {
+        const int b = base0 + min(i0 + lane, L - 1);
+        const uint64_t U = __ballot(((Q.nm[b >> 5] >> (b & 31)) & 1u) != 0u);
+        const int nv = min(64, L - i0);
+        int pos = 0;
+        while (pos < nv) {
+            const uint64_t rest = U >> pos;
+            const int nextU = rest ? min(nv, pos + __ffsll((unsigned long long)rest) - 1) : nv;
+            const int seg = nextU - pos;
+            cnt += max(0, run + seg - max(run, k - 1));
+            run += seg;
+            if (nextU < nv) { run = 0; pos = nextU + 1; } else pos = nv;
+        }
     }
     return cnt;
 }
@@ -1455,6 +1477,283 @@ void bbduk_kmask_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
 }
 
 // --------------------------------------------------------------------------------------------------
+// The remaining reductions over the same main scan, one kernel, one wave per read, staged like
+// bbduk_kmask_kernel and like it written for clarity on the run-time-general scan functions:
+//   RED_BIG   countSetKmersBig (bbduk/BBDukProcessorS.java:1726-1804): k > 31 emulated by runs of consecutive matching
+//             31-mers.  The run state machine is order dependent (positions that are not looked up neither extend nor
+//             close a run), so blocks that hold a hit or meet an open run are replayed position by position in scalar code,
+//             reading each lane's result with v_readlane; all other blocks cost nothing beyond the lookups.
+//   RED_BEST  findBestMatch (:1659-1719): every hit counts for its scaffold, the read goes to the scaffold with the most
+//             hits, the earliest-seen one among equals.  Lane j keeps the j-th distinct id of the read and its count.
+//   RED_SPLIT ksplit (:2332-2506): first and last hit of the main scan, or the short k-mers of the right end, or (if still
+//             nothing) of the left end, give (leftmost, rightmost); the caller trims or splits the read.
+#define RED_BIG   0
+#define RED_BEST  1
+#define RED_SPLIT 2
+#define KS_MAX_IDS 64
+template <int RED>
+__global__ __launch_bounds__(BLOCK_THREADS)
+void bbduk_kscan_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
+                        const int64_t n, const int64_t totalBases, const int paired,
+                        int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
+                        int32_t* __restrict__ outLeft, int32_t* __restrict__ outRight, int64_t* __restrict__ counters) {
+    __shared__ uint32_t s_fwd[PLANE_PAD + KM_CAP_CHUNKS + PLANE_PAD];
+    __shared__ uint32_t s_cmp[PLANE_PAD + KM_CAP_CHUNKS + PLANE_PAD];
+    __shared__ uint32_t s_nm[KM_CAP_CHUNKS / 2 + 4];
+    __shared__ int64_t  s_off[TILE_READS + 1];
+    __shared__ int32_t  s_a[TILE_READS];
+    __shared__ int32_t  s_id[TILE_READS];
+    __shared__ int32_t  s_thr[TILE_READS];                        // kfilter: maxBadKmersR of the read; ksplit: its new pair length
+    __shared__ uint8_t  s_split[TILE_READS];
+    __shared__ unsigned long long s_acc[6];                       // rkt, xsum, readsOutm, basesOutm, readsIn, basesIn
+    extern __shared__ uint32_t s_filt[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+    const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
+    const int k = P.k, tp = P.trimPad;
+    ScafAcc scaf; scaf_init(scaf);
+    if (tid < 6) s_acc[tid] = 0;
+    if (P.ldsBits) {
+        const int words = 1 << (P.ldsBits - 5);
+        for (int w = tid; w < words; w += BLOCK_THREADS) s_filt[w] = P.ldsImage[w];
+    }
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t r0 = tile * TILE_READS;
+        const int cnt = (int)min((int64_t)TILE_READS, n - r0);
+        __syncthreads();
+        if (tid <= cnt) s_off[tid] = offsets[r0 + tid];
+        __syncthreads();
+        if (tid == 0) { s_acc[4] += (unsigned long long)cnt; s_acc[5] += (unsigned long long)(s_off[cnt] - s_off[0]); }
+        int s = 0;
+        while (s < cnt) {
+            const int64_t off_s = s_off[s];
+            const int cand = s + 1 + tid;
+            const int okc = (cand <= cnt) && (s_off[min(cand, cnt)] - off_s <= (int64_t)(KM_CAP_BASES - 32));
+            const int fit = uni(__syncthreads_count(okc));
+            if (fit == 0) {                                         // a read longer than BBDUK_MAX_READ_LEN
+                if (tid == 0) {
+                    atomicMax((unsigned long long*)&counters[BBDUK_CTR_STATUS], (unsigned long long)(-BBDUK_ERR_READ_TOO_LONG));
+                    s_a[s] = 0; s_id[s] = -1; s_thr[s] = RED == RED_SPLIT ? (int)(s_off[s + 1] - s_off[s]) : P.maxBadKmers; s_split[s] = 0;
+                    if (RED == RED_SPLIT) { outLeft[r0 + s] = -1; outRight[r0 + s] = -1; }
+                }
+                s += 1;
+                continue;
+            }
+            const int e = s + fit;
+            const int64_t B0 = off_s, B1 = s_off[e];
+            const int64_t A0 = B0 & ~15LL;
+            const int nchunks = (int)((B1 - A0 + 15) >> 4);
+            for (int c = tid; c < nchunks; c += BLOCK_THREADS) {
+                uint32_t r, comp, valid;
+                stage_chunk(P, bases, A0 + 16LL * c, totalBases, r, comp, valid);
+                s_fwd[PLANE_PAD + nchunks - 1 - c] = r;
+                s_cmp[PLANE_PAD + c] = comp;
+                reinterpret_cast<uint16_t*>(s_nm)[c] = (uint16_t)(~valid & 0xFFFFu);
+            }
+            if (tid == 0 && (nchunks & 1)) reinterpret_cast<uint16_t*>(s_nm)[nchunks] = 0;
+            __syncthreads();
+
+            Planes Q; Q.fwd = s_fwd + PLANE_PAD; Q.cmp = s_cmp + PLANE_PAD; Q.nm = s_nm; Q.filt = s_filt; Q.T = nchunks * 16;
+            Q.fwdBits = lds_bits_of(Q.fwd); Q.cmpBits = lds_bits_of(Q.cmp);
+            for (int rd = s + wave; rd < e; rd += NWAVES) {        // one wave per read
+                const int L = uni((int)(s_off[rd + 1] - s_off[rd]));
+                const int base0 = uni((int)(s_off[rd] - A0));
+                const int pairnum = paired ? (rd & 1) : 0;
+                ReadScan R;
+                R.base0 = base0; R.L = L; R.hasN = -1; R.maxBad = 0;
+                R.start = span_start<true>(P, L); R.stop = span_stop<true>(P, L);
+                const bool skipped = (P.skipR1 && pairnum == 0) || (P.skipR2 && pairnum == 1);
+                if (RED == RED_BIG)       R.scan = P.storedKmers > 0 && L >= P.kbig && !skipped;                       // :1727-1728
+                else if (RED == RED_BEST) R.scan = P.storedKmers > 0 && L >= k && !skipped;                            // :1661-1662
+                else                      R.scan = P.storedKmers > 0 && L >= k;                                        // :2333, 2338 (unpaired)
+                int thr = P.maxBadKmers;                            // :1056-1062 with keff = max(k, kbig)
+                if (RED != RED_SPLIT && P.mkf != 0.f) {
+                    const int keff = max(k, P.kbig);
+                    const int vk = (L >= keff) ? valid_kmers_any_k(Q, base0, L, keff, lane) : 0;
+                    thr = max(P.maxBadKmers, (int)((float)(vk - 1) * P.mkf));
+                }
+                int found = 0, rid = -1;                            // what the reference's method returns / credits
+                int firstI = -1, lastI = -1, id0 = -1;              // RED_SPLIT: first and last hit of the main scan
+                int bkStart = -1, bkStop = -1, lastId = -1; bool done = false;   // RED_BIG run state
+                int myId = 0, myCnt = 0, nids = 0;                  // RED_BEST: lane j owns the j-th distinct id
+                if (R.scan) {
+                    ReadWin W;
+                    win_init<true, true>(P, Q, R, W, lane);
+                    const int sub = P.kbig - k - 1;
+                    for (int ib = W.first; W.on && !done && ib < W.stop; ib += 256) {
+                        uint64_t kmer[4], rk[4]; bool ok[4]; int ref[4];
+                        windows2<true, true>(P, Q, W, ib + 2 * lane, true, kmer, rk, ok);
+                        if (ib + 128 < W.stop) windows2<true, true>(P, Q, W, ib + 128 + 2 * lane, true, kmer + 2, rk + 2, ok + 2);
+                        else { kmer[2] = kmer[3] = 0; rk[2] = rk[3] = 0; ok[2] = ok[3] = false; }
+                        lookup4<true>(P, Q.filt, kmer, rk, ok, ref);
+#pragma unroll
+                        for (int hb = 0; hb < 2; hb++) {
+                            const uint64_t he = __ballot(ref[2 * hb] != -1), ho = __ballot(ref[2 * hb + 1] != -1);
+                            const int i0 = ib + 128 * hb;            // position of (lane j, parity p) = i0 + 2j + p
+                            if (RED == RED_SPLIT) {
+                                if (he | ho) {
+                                    const int le = he ? __ffsll((unsigned long long)he) - 1 : 64, lo = ho ? __ffsll((unsigned long long)ho) - 1 : 64;
+                                    if (firstI < 0) {
+                                        const bool odd = 2 * lo + 1 < 2 * le;
+                                        firstI = i0 + (odd ? 2 * lo + 1 : 2 * le);
+                                        id0 = odd ? __builtin_amdgcn_readlane(ref[2 * hb + 1], lo) : __builtin_amdgcn_readlane(ref[2 * hb], le);
+                                    }
+                                    const int me = he ? 63 - __clzll((unsigned long long)he) : -1, mo = ho ? 63 - __clzll((unsigned long long)ho) : -1;
+                                    lastI = i0 + max(2 * me, 2 * mo + 1);
+                                    found += __popcll(he) + __popcll(ho);
+                                }
+                            } else if (RED == RED_BEST) {
+                                uint64_t re = he, ro = ho;
+                                while (re | ro) {                   // hits in position order
+                                    const int le = re ? __ffsll((unsigned long long)re) - 1 : 64, lo = ro ? __ffsll((unsigned long long)ro) - 1 : 64;
+                                    const bool odd = 2 * lo + 1 < 2 * le;
+                                    const int id = odd ? __builtin_amdgcn_readlane(ref[2 * hb + 1], lo) : __builtin_amdgcn_readlane(ref[2 * hb], le);
+                                    // every remaining hit of this half-block with the same id is counted at once
+                                    const uint64_t se = re & __ballot(ref[2 * hb] == id), so = ro & __ballot(ref[2 * hb + 1] == id);
+                                    const int c = __popcll(se) + __popcll(so);
+                                    const uint64_t have = __ballot(lane < nids && myId == id);
+                                    if (have) { if (lane == __ffsll((unsigned long long)have) - 1) myCnt += c; }
+                                    else if (nids < KS_MAX_IDS) { if (lane == nids) { myId = id; myCnt = c; } nids++; }
+                                    else if (lane == 0) atomicMax((unsigned long long*)&counters[BBDUK_CTR_STATUS], (unsigned long long)(-BBDUK_ERR_ID_OVERFLOW));
+                                    found += c;
+                                    re &= ~se; ro &= ~so;
+                                }
+                            } else {
+                                if (!(he | ho) && bkStart < 0) continue;          // nothing to open, nothing to close
+                                const uint64_t ke = __ballot(ok[2 * hb]), ko = __ballot(ok[2 * hb + 1]);
+                                for (int j = 0; j < 64 && !done; j++) {            // the reference's loop body (:1749-1779), scalar
+#pragma unroll
+                                    for (int par = 0; par < 2; par++) {
+                                        if (done || !(((par ? ko : ke) >> j) & 1ULL)) continue;    // not looked up: transparent
+                                        const int i = i0 + 2 * j + par;
+                                        const int id = __builtin_amdgcn_readlane(ref[2 * hb + par], j);
+                                        if (id > 0) { lastId = id; if (bkStart == -1) bkStart = i; bkStop = i; }
+                                        else if (bkStart > -1) {
+                                            const int dif = bkStop - bkStart - sub;
+                                            bkStop = bkStart = -1;
+                                            if (dif > 0) {
+                                                const int old = found;
+                                                found += dif;
+                                                if (found > thr && old <= thr) { rid = lastId; done = true; }     // :1763-1773 early exit
+                                            }
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    if (RED == RED_BIG && !done && bkStart > -1) {                 // the run reaches the end of the read (:1783-1800)
+                        const int dif = bkStop - bkStart - sub;
+                        if (dif > 0) { const int old = found; found += dif; if (found > thr && old <= thr) rid = lastId; }
+                    }
+                    if (RED == RED_BEST && found > thr) {                          // condenseLoose + first maximum (:1694-1701)
+                        int mx = (lane < nids) ? myCnt : 0;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+                        const uint64_t best = __ballot(lane < nids && myCnt == mx);
+                        rid = __builtin_amdgcn_readlane(myId, __ffsll((unsigned long long)best) - 1);
+                    }
+                }
+                if (RED != RED_SPLIT) {
+                    if (rid > 0) scaf_add(P, scaf, rid, L, lane, counters);
+                    if (lane == 0) { s_a[rd] = found; s_id[rd] = rid; s_thr[rd] = thr; s_split[rd] = 0; }
+                    continue;
+                }
+                // ---- ksplit: span of the main hits, else the short k-mers (right end first, :2388-2474)
+                int leftmost = 0x7FFFFFFF, rightmost = -1;
+                if (found > 0) { leftmost = max(0, firstI - (k - 1 - tp)); rightmost = lastI + tp; }
+                if (R.scan && P.useShort && id0 == -1) {
+                    const bool right = lane >= 32;                  // lanes 0-31: left end, lanes 32-63: right end; length mink + (lane&31)
+                    const int Ls = P.mink + (lane & 31);
+                    bool act; int i;
+                    uint64_t km = 0, rr = 0;
+                    if (!right) {
+                        const int Lmax = min(k, R.stop) - R.start;
+                        act = Ls <= Lmax; i = R.start + Ls - 1;
+                        const int Lc = act ? Ls : 1;
+                        if (act) { km = extract2(Q.fwd, Q.T - 1 - (base0 + R.start + Lc - 1), Lc) & P.mask; rr = extract2(Q.cmp, base0 + R.start, Lc); }
+                    } else {
+                        const int Lmax = (R.stop >= k ? k - 1 : R.stop);
+                        act = Ls <= Lmax; i = R.stop - Ls;
+                        const int Lc = act ? Ls : 1;
+                        if (act) { km = extract2(Q.fwd, Q.T - 1 - (base0 + R.stop - 1), Lc); rr = extract2(Q.cmp, base0 + R.stop - Lc, Lc) & P.mask; }
+                    }
+                    if (P.qskip > 1) act = act && (i % P.qskip) == 0;
+                    const int Lc = act ? Ls : 1;
+                    const int sref = lookup<true>(P, Q.filt, km, rr, 1ULL << (2 * Lc), Lc, P.qhdist2, act);
+                    const uint64_t hm = __ballot(sref != -1);
+                    const uint32_t mL = (uint32_t)hm, mR = (uint32_t)(hm >> 32);
+                    if (mR) {                                       // :2417-2427: every hit counts, the longest one reaches furthest left
+                        id0 = __builtin_amdgcn_readlane(sref, 32 + __ffs(mR) - 1);        // first in loop order = shortest
+                        const int iMin = R.stop - (P.mink + (31 - __clz(mR)));
+                        leftmost = min(leftmost, max(0, iMin - tp)); rightmost = L - 1;
+                        found += __popc(mR);
+                    } else if (mL) {                                // :2434: only if the right end gave nothing
+                        id0 = __builtin_amdgcn_readlane(sref, __ffs(mL) - 1);
+                        const int iMax = R.start + (P.mink + (31 - __clz(mL))) - 1;
+                        leftmost = 0; rightmost = max(rightmost, iMax + tp);
+                        found += __popc(mL);
+                    }
+                }
+                int trimmed = 0, npl = L, split = 0;
+                if (found > 0) {
+                    scaf_add(P, scaf, id0, L, lane, counters);
+                    int n1 = L;
+                    if (leftmost == 0) { trim_by_amount(L, rightmost + 1, 0, 1, n1); npl = n1; }                        // :2485-2487
+                    else if (rightmost == L - 1) { trim_by_amount(L, 0, L - leftmost, 1, n1); npl = n1; }               // :2488-2490
+                    else {                                                                                                // :2491-2498
+                        const int n2 = (L - 1) - (rightmost + 1);   // subRead(rightmost+1, length-1): the copy excludes index length-1
+                        trim_by_amount(L, 0, L - leftmost, 1, n1);
+                        npl = n1 + n2; split = 1;
+                    }
+                    trimmed = L - npl;
+                }
+                if (lane == 0) {
+                    s_a[rd] = trimmed; s_id[rd] = found > 0 ? id0 : -1; s_thr[rd] = npl; s_split[rd] = (uint8_t)split;
+                    outLeft[r0 + rd] = found > 0 ? leftmost : -1; outRight[r0 + rd] = found > 0 ? rightmost : -1;
+                }
+            }
+            __syncthreads();
+            s = e;
+        }
+        // ---- record stage: one thread per read, mates look at each other
+        if (tid < cnt) {
+            const int L1 = (int)(s_off[tid + 1] - s_off[tid]);
+            const int a = s_a[tid];
+            outA[r0 + tid] = a; outId[r0 + tid] = s_id[tid];
+            if (RED == RED_SPLIT) {                                 // :999-1013, 1028-1029, 1431-1443
+                const bool remove = s_split[tid] != 0;             // remove=(r1.mate!=null): the two pieces go to outm together
+                outFlags[r0 + tid] = (uint8_t)(remove ? BBDUK_FLAG_REMOVED : 0);
+                if (a > 0) { atomicAdd(&s_acc[0], 1ULL); atomicAdd(&s_acc[1], (unsigned long long)a); }
+                if (remove) { atomicAdd(&s_acc[2], 1ULL); atomicAdd(&s_acc[3], (unsigned long long)s_thr[tid]); }
+            } else {                                                // :1064-1089
+                const bool d = P.storedKmers > 0 && (RED == RED_BEST ? s_id[tid] > 0 : a > s_thr[tid]);
+                bool remove = d;
+                if (paired) {
+                    const int m = tid ^ 1;
+                    const bool dm = P.storedKmers > 0 && (RED == RED_BEST ? s_id[m] > 0 : s_a[m] > s_thr[m]);
+                    remove = (P.rieb && (d || dm)) || (d && dm);
+                }
+                outFlags[r0 + tid] = (uint8_t)((d ? BBDUK_FLAG_DISCARDED : 0) | (remove ? BBDUK_FLAG_REMOVED : 0));
+                if (remove) { atomicAdd(&s_acc[2], 1ULL); atomicAdd(&s_acc[3], (unsigned long long)L1); }
+            }
+        }
+    }
+    scaf_flush(P, scaf, lane, counters);
+    __syncthreads();
+    if (tid == 0) {
+        if (RED == RED_SPLIT) {
+            const unsigned long long rkt = s_acc[0], xs = s_acc[1], rm = s_acc[2], bm = s_acc[3], rin = s_acc[4], bin = s_acc[5];
+            auto add = [&](int slot, unsigned long long v) { if (v) atomicAdd((unsigned long long*)&counters[slot], v); };
+            add(BBDUK_READS_IN, rin); add(BBDUK_BASES_IN, bin);
+            add(BBDUK_READS_KTRIMMED, rkt); add(BBDUK_BASES_KTRIMMED, xs);
+            add(BBDUK_READS_OUTM, rm); add(BBDUK_BASES_OUTM, bm);                // pairCount stays 1 for a split read (:1437)
+            add(BBDUK_READS_OUTU, rin - rm); add(BBDUK_BASES_OUTU, bin - xs - bm);
+        } else publish_counters<BBDUK_MODE_KFILTER>(s_acc, counters);
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
 // ktrim=rl / ktrimtips (bbduk/BBDukProcessorS.java:1813-1985): a right pass over [start, len) and then a left pass over
 // [0, stop) of the read as the right pass left it.  Like bbduk_kmask_kernel a secondary operator on the run-time-general
 // scan functions: one wave per read, the ktrim=r scan + finish with the right-hand span, then the ktrim=l scan + finish
@@ -2104,7 +2403,7 @@ extern "C" int bbduk_create(const bbduk_params* p, bbduk_handle** out) {
     *out = nullptr;
     if (p->abi_version != BBDUK_ABI_VERSION) return BBDUK_ERR_ARG;
     if (p->k < 1 || p->k > 31) return BBDUK_ERR_ARG;
-    if (p->mode != BBDUK_MODE_KFILTER && p->mode != BBDUK_MODE_KTRIM_R && p->mode != BBDUK_MODE_KTRIM_L && p->mode != BBDUK_MODE_KMASK && p->mode != BBDUK_MODE_KTRIM_TIPS) return BBDUK_ERR_ARG;
+    if (p->mode < BBDUK_MODE_KFILTER || p->mode > BBDUK_MODE_KSPLIT) return BBDUK_ERR_ARG;
     if (p->qhdist < 0 || p->qhdist > 2 || p->qhdist2 < 0 || p->qhdist2 > 2) return BBDUK_ERR_ARG;
     if (p->numScaffolds < 1 || p->maxBadKmers < 0) return BBDUK_ERR_ARG;
     const bool useShort = p->mink > 0 && p->mink < p->k;
@@ -2112,7 +2411,21 @@ extern "C" int bbduk_create(const bbduk_params* p, bbduk_handle** out) {
     if (useShort && p->middleMask != -1) return BBDUK_ERR_ARG;                // BBDukProcessorS.java:2035 assert
     if (p->minlen != p->k - 1) return BBDUK_ERR_ARG;
     if (p->speed < 0 || p->speed > 16 || p->qSkip < 0) return BBDUK_ERR_ARG;    // BBDukParser.java:568
-    for (int i = 0; i < 3; i++) if (p->reserved[i] != 0) return BBDUK_ERR_ARG;
+    if (p->reserved[0] != 0) return BBDUK_ERR_ARG;
+    const bool big = p->kbig > p->k;
+    if (big) {                                                                  // BBDukParser.java:164, 207-243, 299
+        if (p->k != 31 || p->kbig > BBDUK_MAX_READ_LEN) return BBDUK_ERR_ARG;
+        if (p->mode != BBDUK_MODE_KFILTER || p->speed > 0 || p->qSkip > 1) return BBDUK_ERR_ARG;    // the parser reduces kbig to k there
+        if (p->middleMask != -1 || p->minlen2 != p->k) return BBDUK_ERR_ARG;    // maskMiddle is disabled before minlen2 is derived
+        if (p->findBestMatch || p->minCoveredFraction > 0.f) return BBDUK_ERR_ARG;
+    }
+    if (p->findBestMatch) {
+        if (p->mode != BBDUK_MODE_KFILTER || p->minCoveredFraction > 0.f) return BBDUK_ERR_ARG;
+        // with found <= maxBadKmers the reference leaves findBestMatch's per-thread countArray dirty (:1694 is skipped), so
+        // its answers depend on which reads the thread saw before: only the history-free case is served
+        if (p->maxBadKmers != 0 || p->minKmerFraction != 0.f) return BBDUK_ERR_ARG;
+    }
+    if (p->mode == BBDUK_MODE_KSPLIT && p->trimPad > 0) return BBDUK_ERR_ARG;   // rightmost may pass the read end: Read.subRead throws there
     if (!(p->minKmerFraction >= 0.f && p->minKmerFraction <= 1.f) || !(p->minCoveredFraction >= 0.f && p->minCoveredFraction <= 1.f)) return BBDUK_ERR_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return BBDUK_ERR_DEVICE;
@@ -2314,6 +2627,7 @@ static KParams make_kparams(const bbduk_handle* h) {
     K.restrictLeft = p.restrictLeft; K.restrictRight = p.restrictRight; K.skipR1 = p.skipR1; K.skipR2 = p.skipR2;
     K.tpe = (p.trimPairsEvenly && (p.mode == BBDUK_MODE_KTRIM_R || p.mode == BBDUK_MODE_KTRIM_TIPS)) ? 1 : 0; K.qskip = p.qSkip; K.speed = p.speed;
     K.mkf = p.mode == BBDUK_MODE_KFILTER ? p.minKmerFraction : 0.f; K.mcf = p.mode == BBDUK_MODE_KFILTER ? p.minCoveredFraction : 0.f;
+    K.kbig = p.kbig > p.k ? p.kbig : p.k; K.fbm = p.findBestMatch ? 1 : 0;
     K.numScaffolds = p.numScaffolds;
     K.useShort = (p.mink > 0 && p.mink < p.k) ? 1 : 0;
     K.mask = (2 * p.k > 63) ? ~0ULL : ~(~0ULL << (2 * p.k));
@@ -2326,18 +2640,44 @@ static KParams make_kparams(const bbduk_handle* h) {
     return K;
 }
 
+// kbig / findBestMatch (through the kfilter operators) and ksplit: bbduk_kscan_kernel
+static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d_offsets, int64_t n, int64_t total_bases, int32_t paired,
+                        int32_t* d_a, int32_t* d_id, uint8_t* d_fl, int32_t* d_left, int32_t* d_right, int64_t* d_counters, hipStream_t st,
+                        const uint32_t* d_undef, bool packed) {
+    KParams K = make_kparams(h);
+    K.undef = packed ? d_undef : nullptr;
+    const int red = h->p.mode == BBDUK_MODE_KSPLIT ? RED_SPLIT : (K.fbm ? RED_BEST : RED_BIG);
+    typedef void (*kscan_t)(const KParams, const uint8_t*, const int64_t*, const int64_t, const int64_t, const int,
+                            int32_t*, int32_t*, uint8_t*, int32_t*, int32_t*, int64_t*);
+    const kscan_t fn = red == RED_SPLIT ? bbduk_kscan_kernel<RED_SPLIT> : (red == RED_BEST ? bbduk_kscan_kernel<RED_BEST> : bbduk_kscan_kernel<RED_BIG>);
+    const size_t dynLds = h->ldsBits ? ((size_t)1 << (h->ldsBits - 3)) : 0;
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
+    const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
+    const int grid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU);
+    const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
+    if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
+    HIP_TRY(h, hipEventRecord(h->ev0[evi], st));
+    fn<<<dim3(grid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_left, d_right, d_counters);
+    HIP_TRY(h, hipEventRecord(h->ev1[evi], st));
+    h->evCount++;
+    HIP_TRY(h, hipGetLastError());
+    return BBDUK_OK;
+}
+
 static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases, const int64_t* d_offsets, int64_t n,
                         int64_t total_bases, int32_t paired, int32_t* d_a, int32_t* d_id, uint8_t* d_fl,
                         int64_t* d_counters, hipStream_t st, const uint32_t* d_undef = nullptr, bool packed = false) {
     if (!h) return BBDUK_ERR_ARG;
     if (!h->finalized) return fail(h, BBDUK_ERR_STATE, "table not finalized");
-    if (h->p.mode == BBDUK_MODE_KMASK || h->p.mode == BBDUK_MODE_KTRIM_TIPS || (h->p.mode == BBDUK_MODE_KFILTER) != (wantKfilter != 0)) return fail(h, BBDUK_ERR_STATE, "operator does not match the mode given to bbduk_create");
+    if (h->p.mode == BBDUK_MODE_KMASK || h->p.mode == BBDUK_MODE_KTRIM_TIPS || h->p.mode == BBDUK_MODE_KSPLIT || (h->p.mode == BBDUK_MODE_KFILTER) != (wantKfilter != 0)) return fail(h, BBDUK_ERR_STATE, "operator does not match the mode given to bbduk_create");
     if (n < 0 || total_bases < 0 || (paired && (n & 1))) return fail(h, BBDUK_ERR_ARG, "bad batch shape");
     if (n == 0) return BBDUK_OK;
     if (!d_bases && total_bases > 0) return fail(h, BBDUK_ERR_ARG, "null bases");
     if (!d_offsets || !d_a || !d_id || !d_fl || !d_counters) return fail(h, BBDUK_ERR_ARG, "null buffer");
     if (!packed && ((uintptr_t)d_bases & 15) != 0) return fail(h, BBDUK_ERR_ARG, "d_bases must be 16-byte aligned");
     if (packed && (!d_undef || ((uintptr_t)d_bases & 3) != 0)) return fail(h, BBDUK_ERR_ARG, "packed input needs both planes, 4-byte aligned");
+    if (h->p.kbig > h->p.k || h->p.findBestMatch)                               // countSetKmersBig / findBestMatch behind the kfilter operators
+        return launch_kscan(h, d_bases, d_offsets, n, total_bases, paired, d_a, d_id, d_fl, nullptr, nullptr, d_counters, st, d_undef, packed);
     KParams K = make_kparams(h);
     K.undef = packed ? d_undef : nullptr;
     const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
@@ -2573,6 +2913,64 @@ static int launch_kmask(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     HIP_TRY(h, hipGetLastError());
     return BBDUK_OK;
 }
+// ---- ksplit (unpaired reads)
+static int check_ksplit(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d_offsets, int64_t n, int64_t total_bases,
+                        const void* a, const void* b, const void* c, const void* d, const void* e, const void* f) {
+    if (!h) return BBDUK_ERR_ARG;
+    if (!h->finalized) return fail(h, BBDUK_ERR_STATE, "table not finalized");
+    if (h->p.mode != BBDUK_MODE_KSPLIT) return fail(h, BBDUK_ERR_STATE, "operator does not match the mode given to bbduk_create");
+    if (n < 0 || total_bases < 0) return fail(h, BBDUK_ERR_ARG, "bad batch shape");
+    if (n == 0) return BBDUK_OK;
+    if (!d_bases && total_bases > 0) return fail(h, BBDUK_ERR_ARG, "null bases");
+    if (!d_offsets || !a || !b || !c || !d || !e || !f) return fail(h, BBDUK_ERR_ARG, "null buffer");
+    if (((uintptr_t)d_bases & 15) != 0) return fail(h, BBDUK_ERR_ARG, "d_bases must be 16-byte aligned");
+    return 1;
+}
+extern "C" int bbduk_ksplit_batch_device(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d_offsets, int64_t n, int64_t total_bases,
+                                         int32_t* d_out_trimmed, int32_t* d_out_leftmost, int32_t* d_out_rightmost, int32_t* d_out_id0,
+                                         uint8_t* d_out_flags, int64_t* d_counters, void* stream) {
+    const int rc = check_ksplit(h, d_bases, d_offsets, n, total_bases, d_out_trimmed, d_out_leftmost, d_out_rightmost, d_out_id0, d_out_flags, d_counters);
+    if (rc != 1) return rc;
+    return launch_kscan(h, d_bases, d_offsets, n, total_bases, 0, d_out_trimmed, d_out_id0, d_out_flags, d_out_leftmost, d_out_rightmost, d_counters, (hipStream_t)stream, nullptr, false);
+}
+extern "C" int bbduk_ksplit_batch(bbduk_handle* h, const uint8_t* bases, const int64_t* offsets, int64_t n,
+                                  int32_t* out_trimmed, int32_t* out_leftmost, int32_t* out_rightmost, int32_t* out_id0, uint8_t* out_flags) {
+    if (!h) return BBDUK_ERR_ARG;
+    if (n < 0 || !offsets || (n > 0 && (!out_trimmed || !out_leftmost || !out_rightmost || !out_id0 || !out_flags))) return fail(h, BBDUK_ERR_ARG, "bad argument");
+    if (n == 0) return BBDUK_OK;
+    const int64_t total = offsets[n];
+    if (offsets[0] != 0 || total < 0 || (total > 0 && !bases)) return fail(h, BBDUK_ERR_ARG, "bad offsets");
+    std::lock_guard<std::mutex> g(h->mu);
+    HIP_TRY(h, hipSetDevice(h->p.device));
+    uint8_t* db = nullptr; int64_t* doff = nullptr; int32_t* dx = nullptr; int32_t* dl = nullptr; int32_t* dr = nullptr; int32_t* did = nullptr; uint8_t* dfl = nullptr;
+    auto release = [&]() { hipFree(db); hipFree(doff); hipFree(dx); hipFree(dl); hipFree(dr); hipFree(did); hipFree(dfl); };
+    if (hipMalloc(&db, (size_t)total + 16) != hipSuccess || hipMalloc(&doff, (size_t)(n + 1) * 8) != hipSuccess ||
+        hipMalloc(&dx, (size_t)n * 4) != hipSuccess || hipMalloc(&dl, (size_t)n * 4) != hipSuccess || hipMalloc(&dr, (size_t)n * 4) != hipSuccess ||
+        hipMalloc(&did, (size_t)n * 4) != hipSuccess || hipMalloc(&dfl, (size_t)n) != hipSuccess) { release(); return fail(h, BBDUK_ERR_NOMEM, "hipMalloc"); }
+    hipError_t e = hipSuccess;
+    if (total > 0) e = hipMemcpyAsync(db, bases, (size_t)total, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(doff, offsets, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) { release(); h->err = hipGetErrorString(e); return BBDUK_ERR_DEVICE; }
+    const int rc = bbduk_ksplit_batch_device(h, db, doff, n, total, dx, dl, dr, did, dfl, h->d_counters, h->stream);
+    if (rc != BBDUK_OK) { release(); return rc; }
+    hipMemcpyAsync(out_trimmed, dx, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream);
+    hipMemcpyAsync(out_leftmost, dl, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream);
+    hipMemcpyAsync(out_rightmost, dr, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream);
+    hipMemcpyAsync(out_id0, did, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream);
+    hipMemcpyAsync(out_flags, dfl, (size_t)n, hipMemcpyDeviceToHost, h->stream);
+    e = hipStreamSynchronize(h->stream);
+    release();
+    if (e != hipSuccess) { h->err = hipGetErrorString(e); return BBDUK_ERR_DEVICE; }
+    int64_t status = 0;
+    HIP_TRY(h, hipMemcpy(&status, h->d_counters + BBDUK_CTR_STATUS, sizeof status, hipMemcpyDeviceToHost));
+    if (status != 0) {
+        int64_t z = 0;
+        hipMemcpy(h->d_counters + BBDUK_CTR_STATUS, &z, sizeof z, hipMemcpyHostToDevice);
+        return fail(h, -(int)status, "a read exceeds BBDUK_MAX_READ_LEN");
+    }
+    return BBDUK_OK;
+}
+
 extern "C" int bbduk_kmask_batch_device(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d_offsets, int64_t n,
                                         int64_t total_bases, int32_t paired, int32_t* d_out_masked, int32_t* d_out_id0,
                                         uint8_t* d_out_flags, uint32_t* d_out_mask, int64_t* d_counters, void* stream) {

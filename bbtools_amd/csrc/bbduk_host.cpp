@@ -39,6 +39,8 @@ struct Parsed {                      // bbduk/BBDukParser.java fields (subset th
     bool trimPairsEvenly = false;    // tpe
     int qSkip = 1, speed = 0;        // :1373-1377
     float minKmerFraction = 0.f, minCoveredFraction = 0.f;   // :1234-1236
+    bool ksplit = false, findBestMatch = false;              // :1313, 1323
+    int kbig = -1;                                           // :1226 (derived: the requested k when it exceeds 31)
     std::vector<std::string> ref, literal;
     // derived (:130-312)
     int minlen = 0, minlen2 = 0;
@@ -87,8 +89,12 @@ int derive(Parsed& p, std::string& err) {            // bbduk/BBDukParser.java:1
     p.restrictLeft = std::max(p.restrictLeft, 0);
     p.restrictRight = std::max(p.restrictRight, 0);
     if (!p.setk) p.k = 27;
-    if (p.k > 31) { err = "k>31 (kbig) is not supported by this path"; return BBDUK_ERR_ARG; }
     if (p.k < 1) { err = "k must be positive"; return BBDUK_ERR_ARG; }
+    p.kbig = (p.k > 31 ? p.k : -1);                                      // :164-165
+    p.k = std::min(p.k, 31);
+    if ((p.ktrimLeft || p.ktrimRight || p.ktrimN || p.ksplit) && p.kbig > p.k) p.kbig = p.k;   // :207-215 "K has been reduced"
+    if ((p.speed > 0 || p.qSkip > 1) && p.kbig > p.k) p.kbig = p.k;     // :217-223
+    if (p.kbig > p.k) p.maskMiddle = false;                              // :237-243, before minlen2 is derived
     if (p.maskMiddle) p.midMaskLen = (p.midMaskLen > 0 ? p.midMaskLen : 2 - (p.k & 1));
     else p.midMaskLen = 0;
     p.mink = std::min(p.mink, p.k);
@@ -96,7 +102,15 @@ int derive(Parsed& p, std::string& err) {            // bbduk/BBDukParser.java:1
     p.minlen2 = (p.maskMiddle ? (p.k - p.midMaskLen) / 2 : p.k);        // before mink turns maskMiddle off
     if (p.mink > 0 && p.mink < p.k) p.useShortKmers = true;
     if (p.useShortKmers && p.maskMiddle) { p.maskMiddle = false; p.midMaskLen = 0; }
-    if (p.useShortKmers && !(p.ktrimLeft || p.ktrimRight || p.ktrimN)) { err = "Setting mink also requires setting a ktrim mode, such as 'r' or 'l'"; return BBDUK_ERR_ARG; }
+    const bool kfilter = !(p.ktrimLeft || p.ktrimRight || p.ktrimN || p.ksplit);                     // :298
+    if (p.findBestMatch && kfilter && p.kbig > p.k) { err = "K must be less than 32 in 'findBestMatch' mode"; return BBDUK_ERR_ARG; }   // :299
+    if (p.findBestMatch && kfilter && (p.maxBadKmers0 != 0 || p.minKmerFraction != 0.f)) {
+        err = "findbestmatch with maxbadkmers>0 or minkmerfraction>0 is not supported by this path (the reference's answer depends on thread history there)";
+        return BBDUK_ERR_ARG;
+    }
+    if (p.kbig > p.k && p.minCoveredFraction > 0.f) { err = "mincoveredfraction with k>31 is not supported by this path"; return BBDUK_ERR_ARG; }
+    if (p.ksplit && p.trimPad > 0) { err = "ksplit with a positive trimpad is not supported by this path"; return BBDUK_ERR_ARG; }
+    if (p.useShortKmers && !(p.ktrimLeft || p.ktrimRight || p.ktrimN || p.ksplit)) { err = "Setting mink also requires setting a ktrim mode, such as 'r' or 'l'"; return BBDUK_ERR_ARG; }
     // ktrim=rl (tips): both flags stay set, the device runs the two passes (BBDUK_MODE_KTRIM_TIPS)
     if (p.maskMiddle) {
         if (!(p.k > p.midMaskLen + 1)) { err = "k too small for maskmiddle"; return BBDUK_ERR_ARG; }
@@ -187,27 +201,30 @@ extern "C" int bbduk_host_parse(const char* args, bbduk_host** out, char* errbuf
         else if (a == "forbidns" || a == "forbidn" || a == "fn") need_bool(p.forbidNs);
         else if (a == "ktrim") {
             std::string v = b; for (auto& c : v) c = (char)tolower(c);
-            if (v == "rl" || v == "lr" || v == "tips") { p.ktrimLeft = p.ktrimRight = true; p.ktrimN = false; }
-            else if (v == "l" || v == "left") { p.ktrimLeft = true; p.ktrimRight = false; p.ktrimN = false; }
-            else if (v == "r" || v == "right") { p.ktrimLeft = false; p.ktrimRight = true; p.ktrimN = false; }
-            else if (v == "n" || (v.size() == 1 && v != "t" && v != "f")) { p.ktrimLeft = p.ktrimRight = false; p.ktrimN = true; }   // the symbol stays with the caller
+            if (v == "rl" || v == "lr" || v == "tips") { p.ktrimLeft = p.ktrimRight = true; p.ktrimN = p.ksplit = false; }
+            else if (v == "l" || v == "left") { p.ktrimLeft = true; p.ktrimRight = false; p.ktrimN = p.ksplit = false; }
+            else if (v == "r" || v == "right") { p.ktrimLeft = false; p.ktrimRight = true; p.ktrimN = p.ksplit = false; }
+            else if (v == "n" || (v.size() == 1 && v != "t" && v != "f")) { p.ktrimLeft = p.ktrimRight = p.ksplit = false; p.ktrimN = true; }   // the symbol stays with the caller
             else if (v == "f" || v == "false") { p.ktrimLeft = p.ktrimRight = false; }
             else { seterr("Invalid setting for ktrim - values must be f (false), l (left), r (right), or n"); delete h; return BBDUK_ERR_ARG; }
         }
         else if (a == "trimtips" || a == "ktrimtips") {             // BBDukParser.java:626-632
-            if (!b.empty()) { int v = 0; need_int(v); if (ok) { p.ktrimLeft = p.ktrimRight = true; p.ktrimN = false; p.restrictLeft = p.restrictRight = v; } }
+            if (!b.empty()) { int v = 0; need_int(v); if (ok) { p.ktrimLeft = p.ktrimRight = true; p.ktrimN = p.ksplit = false; p.restrictLeft = p.restrictRight = v; } }
         }
         else if (a == "kmask" || a == "mask") {                      // BBDukParser.java:635-651: lc | t | a symbol | f
             std::string v = b; for (auto& c : v) c = (char)tolower(c);
             if (v == "f" || v == "false") p.ktrimN = false;
-            else { p.ktrimN = true; p.ktrimLeft = p.ktrimRight = false; }
+            else { p.ktrimN = true; p.ktrimLeft = p.ktrimRight = p.ksplit = false; }
         }
+        else if (a == "ksplit") { bool x = false; need_bool(x); if (ok) { p.ksplit = x; if (x) p.ktrimLeft = p.ktrimRight = p.ktrimN = false; } }   // :599-603
+        else if (a == "findbestmatch" || a == "fbm") need_bool(p.findBestMatch);                                                                       // :594-595
+        else if (a == "rename") { bool x = false; need_bool(x); if (ok && x) { seterr("rename=t is not supported by this path"); delete h; return BBDUK_ERR_ARG; } }
         else if (a == "ktrimn") { need_bool(p.ktrimN); if (ok) p.ktrimLeft = p.ktrimRight = !p.ktrimN; }
         else if (a == "kmaskfullycovered" || a == "maskfullycovered" || a == "mfc") {
             bool x = false; need_bool(x);
             if (ok && x) { seterr("kmaskfullycovered=t is not supported by this path yet"); delete h; return BBDUK_ERR_ARG; }
         }
-        else if (a == "kfilter") { bool x = false; need_bool(x); if (x) { p.ktrimLeft = p.ktrimRight = false; p.ktrimN = false; } }
+        else if (a == "kfilter") { bool x = false; need_bool(x); if (x) { p.ktrimLeft = p.ktrimRight = false; p.ktrimN = p.ksplit = false; } }
         else if (a == "maxbadkmers" || a == "mbk") need_int(p.maxBadKmers0);
         else if (a == "minhits" || a == "minkmerhits" || a == "mkh") { need_int(p.maxBadKmers0); p.maxBadKmers0 -= 1; }
         else if (a == "ml" || a == "minlen" || a == "minlength") need_int(p.minReadLength);
@@ -350,7 +367,7 @@ extern "C" int bbduk_host_params(const bbduk_host* h, int32_t device, bbduk_para
     const Parsed& p = h->p;
     memset(out, 0, sizeof *out);
     out->abi_version = BBDUK_ABI_VERSION;
-    out->mode = (p.ktrimRight && p.ktrimLeft) ? BBDUK_MODE_KTRIM_TIPS :
+    out->mode = p.ksplit ? BBDUK_MODE_KSPLIT : (p.ktrimRight && p.ktrimLeft) ? BBDUK_MODE_KTRIM_TIPS :
                 p.ktrimRight ? BBDUK_MODE_KTRIM_R : (p.ktrimLeft ? BBDUK_MODE_KTRIM_L : (p.ktrimN ? BBDUK_MODE_KMASK : BBDUK_MODE_KFILTER));
     out->k = p.k; out->mink = p.mink; out->rcomp = p.rcomp; out->forbidNs = p.forbidNs;
     out->minlen = p.minlen; out->minlen2 = p.minlen2; out->middleMask = p.middleMask;
@@ -362,6 +379,8 @@ extern "C" int bbduk_host_params(const bbduk_host* h, int32_t device, bbduk_para
     out->skipR1 = p.skipR1; out->skipR2 = p.skipR2;
     out->trimPairsEvenly = p.trimPairsEvenly; out->qSkip = p.qSkip; out->speed = p.speed;
     out->minKmerFraction = p.minKmerFraction; out->minCoveredFraction = p.minCoveredFraction;
+    out->kbig = p.kbig > p.k ? p.kbig : 0;
+    out->findBestMatch = (p.findBestMatch && out->mode == BBDUK_MODE_KFILTER) ? 1 : 0;
     out->numScaffolds = (int32_t)h->scaffolds.size() + 1;
     out->device = device;
     return BBDUK_OK;

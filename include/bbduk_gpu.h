@@ -46,6 +46,7 @@ extern "C" {
 #define BBDUK_ERR_NOMEM         -3
 #define BBDUK_ERR_DEVICE        -4   /* a HIP call failed; see bbduk_last_error           */
 #define BBDUK_ERR_READ_TOO_LONG -5   /* a read exceeds BBDUK_MAX_READ_LEN                  */
+#define BBDUK_ERR_ID_OVERFLOW   -6   /* findBestMatch: a read hit more than 64 distinct scaffolds */
 
 #define BBDUK_MAX_READ_LEN   16384   /* per-read limit of the LDS-staged kernel (bases)     */
 
@@ -55,6 +56,7 @@ extern "C" {
 #define BBDUK_MODE_KTRIM_L   2       /* ktrim=l */
 #define BBDUK_MODE_KMASK     3       /* ktrim=n / kmask=: mask matched bases instead of trimming (kmaskfullycovered=f) */
 #define BBDUK_MODE_KTRIM_TIPS 4      /* ktrim=rl / ktrimtips=: a right pass, then a left pass on what is left */
+#define BBDUK_MODE_KSPLIT    5       /* ksplit=t: cut the matched span out of an unpaired read (bbduk_ksplit_batch) */
 
 /* per-read output flags */
 #define BBDUK_FLAG_DISCARDED 1       /* setDiscarded(r)  (BBDukProcessorS.java:1464-1470)    */
@@ -94,7 +96,11 @@ typedef struct bbduk_params {
     int32_t speed;                  /* speed= 0..16 (query-side gate, BBDukIndexMod.java:506,562) */
     float   minKmerFraction;        /* mkf= (kfilter; BBDukProcessorS.java:1055-1062) */
     float   minCoveredFraction;     /* mcf= (kfilter; :1038-1049, countCoveredBases :1602-1651; out_found = covered bases) */
-    int32_t reserved[3];            /* must be zero */
+    int32_t kbig;                   /* the command line's k when it exceeds 31 (then k=31 and maskMiddle is off, BBDukParser.java:164,
+                                       237-243): kfilter counts runs of consecutive 31-mer hits (countSetKmersBig, :1726-1804); <= k = off */
+    int32_t findBestMatch;          /* findbestmatch/fbm (kfilter; BBDukProcessorS.java:1659-1719): out_id = the scaffold with the most
+                                       hits, out_found = hits counted; needs maxBadKmers == 0 and minKmerFraction == 0 */
+    int32_t reserved[1];            /* must be zero */
 } bbduk_params;
 
 typedef struct bbduk_handle bbduk_handle;
@@ -186,6 +192,17 @@ int  bbduk_ktrimtips_batch(bbduk_handle* h, const uint8_t* bases, const int64_t*
 int  bbduk_ktrimtips_batch_device(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d_offsets, int64_t n,
                                   int64_t total_bases, int32_t paired, int32_t* d_out_right, int32_t* d_out_left,
                                   int32_t* d_out_id0, uint8_t* d_out_flags, int64_t* d_counters, void* stream);
+
+/* ---- ksplit=t (bbduk/BBDukProcessorS.java:2332-2506; unpaired reads, trimPad <= 0).  out_leftmost/out_rightmost = the
+ * span ksplit() computes (-1,-1: nothing matched), out_trimmed = oldLen - r.pairLength() after the cut (:1005).  The caller
+ * applies :2485-2498: leftmost==0 -> trimToPosition(r, rightmost+1, len-1, 1); rightmost==len-1 -> trimToPosition(r, 0,
+ * leftmost-1, 1); else r2=r.subRead(rightmost+1, len-1), trimToPosition(r, 0, leftmost-1, 1), and the two pieces leave as a
+ * pair through outm (BBDUK_FLAG_REMOVED, :1011). */
+int  bbduk_ksplit_batch(bbduk_handle* h, const uint8_t* bases, const int64_t* offsets, int64_t n,
+                        int32_t* out_trimmed, int32_t* out_leftmost, int32_t* out_rightmost, int32_t* out_id0, uint8_t* out_flags);
+int  bbduk_ksplit_batch_device(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d_offsets, int64_t n, int64_t total_bases,
+                               int32_t* d_out_trimmed, int32_t* d_out_leftmost, int32_t* d_out_rightmost, int32_t* d_out_id0,
+                               uint8_t* d_out_flags, int64_t* d_counters, void* stream);
 
 /* Average duration (HIP events on the launch stream) of the dominant kernel over the last `last_k` batch launches
  * of this handle (at most 64 are remembered).  Synchronises on those launches.  For roofline reporting. */

@@ -194,7 +194,7 @@ struct bbo_ctx {
     bbo_args a;
     /* derived -- BBDukParser.java:130-312 */
     int k, mink, hammingDistance, hammingDistance2, editDistance, editDistance2, qHammingDistance, qHammingDistance2;
-    int forbidNs, rcomp, maskMiddle, midMaskLen, useShortKmers, kfilter;
+    int forbidNs, rcomp, maskMiddle, midMaskLen, useShortKmers, kfilter, kbig, keff;
     int minlen, minminlen, minlen2, shift, shift2, minSkip, maxSkip;
     int64_t mask, kmask, middleMask, symbolMask;
     int64_t clearMasks[SYMBOL_ARRAY_LEN], leftMasks[SYMBOL_ARRAY_LEN], rightMasks[SYMBOL_ARRAY_LEN], lengthMasks[SYMBOL_ARRAY_LEN];
@@ -224,6 +224,7 @@ void bbo_default_args(bbo_args* a) {
     a->minSkip = 1; a->maxSkip = 1;
     a->trimPairsEvenly = 0; a->qSkip = 1; a->speed = 0;
     a->minKmerFraction = 0.f; a->minCoveredFraction = 0.f; a->ktrimN = 0;
+    a->kbig = -1; a->findBestMatch = 0; a->ksplit = 0;
 }
 
 static int imax(int a, int b) { return a > b ? a : b; }
@@ -232,7 +233,7 @@ static int imid(int lo, int x, int hi) { return x < lo ? lo : (x > hi ? hi : x);
 
 bbo_ctx* bbo_create(const bbo_args* a) {
     init_tables();
-    if (a->k < 1 || a->k > 31) return NULL;                 /* maxSupportedK=31, kbig out of scope (:162-165) */
+    if (a->k < 1 || a->k > 31) return NULL;                 /* maxSupportedK=31; a longer k arrives as kbig (:162-165) */
     if (a->edist > 0 || a->edist2 > 0) { /* allowed: mutate() below restates Del/Ins too */ }
     bbo_ctx* c = (bbo_ctx*)calloc(1, sizeof *c);
     c->a = *a;
@@ -253,6 +254,12 @@ bbo_ctx* bbo_create(const bbo_args* a) {
     c->k = a->k;
     /* :230-245 */
     c->maskMiddle = a->maskMiddle;
+    c->kbig = (a->kbig > c->k ? a->kbig : c->k);
+    if (c->kbig > c->k && (a->ktrimRight || a->ktrimLeft || a->ktrimN || a->ksplit || a->speed > 0 || a->qSkip > 1)) { free(c); return NULL; }
+                                                            /* :207-223: the parser reduces kbig to k there (the caller passes that) */
+    c->keff = imax(c->k, c->kbig);                          /* :231 */
+    if (c->kbig > c->k) c->maskMiddle = 0;                  /* :237-243 */
+    if (a->findBestMatch && c->kbig > c->k) { free(c); return NULL; }   /* :299 assert */
     if (c->maskMiddle) c->midMaskLen = (a->midMaskLen > 0 ? a->midMaskLen : 2 - (c->k & 1));
     else c->midMaskLen = 0;
     c->mink = imin(a->mink, c->k);
@@ -276,8 +283,8 @@ bbo_ctx* bbo_create(const bbo_args* a) {
     if (c->mink > 0 && c->mink < c->k) c->useShortKmers = 1;
     if (c->useShortKmers && c->maskMiddle) { c->maskMiddle = 0; c->midMaskLen = 0; }
     /* :298 */
-    c->kfilter = !(a->ktrimRight || a->ktrimLeft || a->ktrimN);
-    if (c->useShortKmers && !(a->ktrimRight || a->ktrimLeft || a->ktrimN)) { free(c); return NULL; }   /* :301 assert */
+    c->kfilter = !(a->ktrimRight || a->ktrimLeft || a->ktrimN || a->ksplit);
+    if (c->useShortKmers && !(a->ktrimRight || a->ktrimLeft || a->ktrimN || a->ksplit)) { free(c); return NULL; }   /* :301 assert */
     /* :303-312 */
     if (c->maskMiddle) {
         if (!(c->k > c->midMaskLen + 1)) { free(c); return NULL; }
@@ -549,7 +556,8 @@ int bbo_get_value(const bbo_ctx* c, const int64_t kmer, const int64_t rkmer, con
 }
 
 /* per-thread counter block */
-typedef struct { int64_t counters[BBO_NCOUNTERS]; int64_t* scafReads; int64_t* scafBases; } tcounters;
+typedef struct { int64_t counters[BBO_NCOUNTERS]; int64_t* scafReads; int64_t* scafBases;
+                 int* countArray; int* idList; } tcounters;             /* findBestMatch's per-thread state (:3170-3172) */
 
 /* shared/TrimRead.java:304-345 trimByAmount, on lengths only (bases/quals are copied by the caller in Java).
  * Returns total trimmed; *newLen gets the resulting length. */
@@ -727,6 +735,194 @@ static int count_set_kmers(const bbo_ctx* c, tcounters* tc, const uint8_t* bases
     return found;
 }
 
+/* bbduk/BBDukProcessorS.java:1726-1804 countSetKmersBig */
+static int count_set_kmers_big(const bbo_ctx* c, tcounters* tc, const uint8_t* bases, const int blen, const int pairnum,
+                               const int maxBadKmers, int* idout) {
+    const int k = c->k, kbig = c->kbig;
+    *idout = -1;
+    if (blen < kbig || c->storedKmers < 1) return 0;
+    if ((c->a.skipR1 && pairnum == 0) || (c->a.skipR2 && pairnum == 1)) return 0;
+    const int sub = kbig - k - 1;
+    int64_t kmer = 0, rkmer = 0;
+    int found = 0, len = 0;
+    int bkStart = -1, bkStop = -1;
+    int id = -1, lastId = -1;
+    const int start = (c->a.restrictRight < 1 ? 0 : imax(0, blen - c->a.restrictRight));
+    const int stop  = (c->a.restrictLeft  < 1 ? blen : imin(blen, c->a.restrictLeft));
+    for (int i = start; i < stop; i++) {
+        uint8_t b = bases[i];
+        int64_t x = num0(b), x2 = cnum0(b);
+        kmer = (int64_t)((((uint64_t)kmer << 2) | (uint64_t)x) & (uint64_t)c->mask);
+        rkmer = (int64_t)((((uint64_t)rkmer >> 2) | ((uint64_t)x2 << c->shift2)) & (uint64_t)c->mask);
+        if (c->forbidNs && !is_fully_defined(b)) { len = 0; rkmer = 0; } else { len++; }
+        if (len >= c->minlen2 && i >= c->minlen) {
+            id = bbo_get_value(c, kmer, rkmer, c->kmask, i, k, c->qHammingDistance);
+            if (id > 0) {
+                lastId = id;
+                if (bkStart == -1) bkStart = i;
+                bkStop = i;
+            } else if (bkStart > -1) {
+                const int dif = bkStop - bkStart - sub;
+                bkStop = bkStart = -1;
+                if (dif > 0) {
+                    const int old = found;
+                    found += dif;
+                    if (found > maxBadKmers && old <= maxBadKmers) {
+                        tc->scafReads[lastId]++; tc->scafBases[lastId] += blen;
+                        *idout = lastId;
+                        return found;                                                     /* :1773 early exit */
+                    }
+                }
+            }
+        }
+    }
+    if (bkStart > -1) {                                                                   /* :1783-1800 */
+        const int dif = bkStop - bkStart - sub;
+        if (dif > 0) {
+            const int old = found;
+            found += dif;
+            if (found > maxBadKmers && old <= maxBadKmers) {
+                tc->scafReads[lastId]++; tc->scafBases[lastId] += blen;
+                *idout = lastId;
+            }
+        }
+    }
+    return found;
+}
+
+/* bbduk/BBDukProcessorS.java:1659-1719 findBestMatch.  Returns the id (or -1); *foundout = hits counted.  Restated for
+ * maxBadKmers == 0 only: with found <= maxBadKmers the reference skips condenseLoose and leaves countArray dirty. */
+static int find_best_match(const bbo_ctx* c, tcounters* tc, const uint8_t* bases, const int blen, const int pairnum,
+                           const int maxBadKmers, int* foundout) {
+    const int k = c->k;
+    *foundout = 0;
+    int nids = 0;
+    if (blen < k || c->storedKmers < 1) return -1;
+    if ((c->a.skipR1 && pairnum == 0) || (c->a.skipR2 && pairnum == 1)) return -1;
+    if (!tc->countArray) { tc->countArray = (int*)calloc((size_t)c->numScaffolds, sizeof(int)); tc->idList = (int*)calloc((size_t)c->numScaffolds, sizeof(int)); }
+    int64_t kmer = 0, rkmer = 0;
+    int found = 0, len = 0;
+    const int start = (c->a.restrictRight < 1 ? 0 : imax(0, blen - c->a.restrictRight));
+    const int stop  = (c->a.restrictLeft  < 1 ? blen : imin(blen, c->a.restrictLeft));
+    for (int i = start; i < stop; i++) {
+        uint8_t b = bases[i];
+        int64_t x = num0(b), x2 = cnum0(b);
+        kmer = (int64_t)((((uint64_t)kmer << 2) | (uint64_t)x) & (uint64_t)c->mask);
+        rkmer = (int64_t)((((uint64_t)rkmer >> 2) | ((uint64_t)x2 << c->shift2)) & (uint64_t)c->mask);
+        if (c->forbidNs && !is_fully_defined(b)) { len = 0; rkmer = 0; } else { len++; }
+        if (len >= c->minlen2 && i >= c->minlen) {
+            const int id = bbo_get_value(c, kmer, rkmer, c->kmask, i, k, c->qHammingDistance);
+            if (id > 0) {
+                tc->countArray[id]++;
+                if (tc->countArray[id] == 1) tc->idList[nids++] = id;
+                found++;
+            }
+        }
+    }
+    *foundout = found;
+    int id = -1;
+    if (found > maxBadKmers) {
+        int max = 0;                                                                      /* condenseLoose :2531-2544 */
+        for (int i = 0; i < nids; i++) { const int cnt = tc->countArray[tc->idList[i]]; if (cnt > max) max = cnt; }
+        for (int i = 0; i < nids; i++) if (tc->countArray[tc->idList[i]] == max) { id = tc->idList[i]; break; }
+        for (int i = 0; i < nids; i++) tc->countArray[tc->idList[i]] = 0;
+        tc->scafReads[id]++; tc->scafBases[id] += blen;
+    }
+    return id;
+}
+
+/* bbduk/BBDukProcessorS.java:2332-2506 ksplit, on lengths: returns 1 if the read is split; *trimmed = oldLen - new pairLength */
+static int ksplit_read(const bbo_ctx* c, tcounters* tc, const uint8_t* bases, const int blen, int* id0out, int* leftOut, int* rightOut,
+                       int* trimmed, int* newPairLen) {
+    const int k = c->k;
+    *id0out = -1; *leftOut = -1; *rightOut = -1; *trimmed = 0; *newPairLen = blen;
+    if (blen < imax(1, (c->useShortKmers ? imin(k, c->mink) : k)) || c->storedKmers < 1) return 0;
+    if (blen < k) return 0;
+    int64_t kmer = 0, rkmer = 0;
+    int64_t found = 0;
+    int len = 0, id0 = -1;
+    int leftmost = 2147483647, rightmost = -1;
+    const int minus = k - 1 - c->a.trimPad, plus = c->a.trimPad;
+    const int start = (c->a.restrictRight < 1 ? 0 : imax(0, blen - c->a.restrictRight));
+    const int stop  = (c->a.restrictLeft  < 1 ? blen : imin(blen, c->a.restrictLeft));
+    for (int i = start; i < stop; i++) {
+        uint8_t b = bases[i];
+        int64_t x = num0(b), x2 = cnum0(b);
+        kmer = (int64_t)((((uint64_t)kmer << 2) | (uint64_t)x) & (uint64_t)c->mask);
+        rkmer = (int64_t)((((uint64_t)rkmer >> 2) | ((uint64_t)x2 << c->shift2)) & (uint64_t)c->mask);
+        if (c->forbidNs && !is_fully_defined(b)) { len = 0; rkmer = 0; } else { len++; }
+        if (i >= c->minlen) {
+            const int id = (len >= c->minlen2) ? bbo_get_value(c, kmer, rkmer, c->kmask, i, k, c->qHammingDistance) : -1;
+            if (id > 0) {
+                if (id0 < 0) id0 = id;
+                leftmost = imin(leftmost, imax(0, i - minus));
+                rightmost = imax(rightmost, i + plus);
+                found++;
+            }
+        }
+    }
+    if (c->useShortKmers && id0 == -1) {
+        {                                                                                 /* right side :2391-2431 */
+            kmer = 0; rkmer = 0; len = 0;
+            const int lim = imax(-1, stop - k);
+            for (int i = stop - 1; i > lim; i--) {
+                uint8_t b = bases[i];
+                int64_t x = num0(b), x2 = cnum0(b);
+                kmer = kmer | (int64_t)((uint64_t)x << (2 * len));
+                rkmer = (int64_t)((((uint64_t)rkmer << 2) | (uint64_t)x2) & (uint64_t)c->mask);
+                len++;
+                if (len >= c->minminlen) {
+                    const int id = (len >= c->mink) ? bbo_get_value(c, kmer, rkmer, c->lengthMasks[len], i, len, c->qHammingDistance2) : -1;
+                    if (id > 0) {
+                        if (id0 < 0) id0 = id;
+                        leftmost = imin(leftmost, imax(0, i - c->a.trimPad));
+                        rightmost = blen - 1;
+                        found++;
+                    }
+                }
+            }
+        }
+        if (id0 == -1) {                                                                  /* left side :2434-2473 */
+            kmer = 0; rkmer = 0; len = 0;
+            const int lim = imin(k, stop);
+            for (int i = start; i < lim; i++) {
+                uint8_t b = bases[i];
+                int64_t x = num0(b), x2 = cnum0(b);
+                kmer = (int64_t)((((uint64_t)kmer << 2) | (uint64_t)x) & (uint64_t)c->mask);
+                rkmer = rkmer | (int64_t)((uint64_t)x2 << (2 * len));
+                len++;
+                if (len >= c->minminlen) {
+                    const int id = (len >= c->mink) ? bbo_get_value(c, kmer, rkmer, c->lengthMasks[len], i, len, c->qHammingDistance2) : -1;
+                    if (id > 0) {
+                        if (id0 < 0) id0 = id;
+                        leftmost = 0;
+                        rightmost = imax(rightmost, i + c->a.trimPad);
+                        found++;
+                    }
+                }
+            }
+        }
+    }
+    if (found == 0) return 0;
+    tc->scafReads[id0]++; tc->scafBases[id0] += blen;
+    *id0out = id0; *leftOut = leftmost; *rightOut = rightmost;
+    int n1 = blen;
+    if (leftmost == 0) {
+        trim_to_position(blen, rightmost + 1, blen - 1, 1, &n1);
+        *newPairLen = n1; *trimmed = blen - n1;
+        return 0;
+    } else if (rightmost == blen - 1) {
+        trim_to_position(blen, 0, leftmost - 1, 1, &n1);
+        *newPairLen = n1; *trimmed = blen - n1;
+        return 0;
+    }
+    const int n2 = (blen - 1) - (rightmost + 1);            /* subRead(rightmost+1, length-1): copyOfRange's `to` is exclusive */
+    if (n2 < 0) { *newPairLen = blen; return 0; }           /* rightmost beyond the end (trimPad>0): the reference throws; callers reject tp>0 */
+    trim_to_position(blen, 0, leftmost - 1, 1, &n1);
+    *newPairLen = n1 + n2; *trimmed = blen - (n1 + n2);
+    return 1;
+}
+
 /* java.util.BitSet.set(from,to) on a word array */
 static void bs_set(uint64_t* bs, int from, int to) {
     for (int i = from; i < to; i++) bs[i >> 6] |= 1ULL << (i & 63);
@@ -881,7 +1077,7 @@ int bbo_count_set_kmers(bbo_ctx* c, const uint8_t* bases, int len, int pairnum, 
  * Everything before the k-mer stage (junk/chastity/GC/force-trim...) and after it (tbo/qtrim/...) is off
  * in every BASELINE config and stays in the Java host. */
 static void process_pair(const bbo_ctx* c, tcounters* tc, const uint8_t* b1, int l1, const uint8_t* b2, int l2, int has2,
-                         int32_t* a, int32_t* ids, uint8_t* fl, uint32_t* gmask, int64_t g1, int64_t g2, int32_t* xleft) {
+                         int32_t* a, int32_t* ids, uint8_t* fl, uint32_t* gmask, int64_t g1, int64_t g2, int32_t* xleft, int32_t* xright) {
     const int initialLength1 = l1, initialLength2 = has2 ? l2 : 0;
     const int pairCount = has2 ? 2 : 1;
     const int minlen1 = (int)((float)initialLength1 * c->a.minLenFraction > (float)c->a.minReadLength ?
@@ -893,10 +1089,22 @@ static void process_pair(const bbo_ctx* c, tcounters* tc, const uint8_t* b1, int
     int d1 = 0, d2 = 0, remove = 0;
     int newLen1 = l1, newLen2 = initialLength2;
     const int ktrimN = c->a.ktrimN && !(c->a.ktrimLeft || c->a.ktrimRight);
-    const int doKmerTrimming = c->storedKmers > 0 && (c->a.ktrimLeft || c->a.ktrimRight || ktrimN);   /* :772 */
+    const int doKmerTrimming = c->storedKmers > 0 && (c->a.ktrimLeft || c->a.ktrimRight || ktrimN || c->a.ksplit);   /* :772 */
     const int doKmerFiltering = c->storedKmers > 0 && !doKmerTrimming;                      /* :773 */
     a[0] = 0; ids[0] = -1; if (has2) { a[1] = 0; ids[1] = -1; }
-    if (doKmerTrimming && ktrimN) {                                                   /* :984-998, 1009-1016, 1028-1029 */
+    if (xleft && xright) { xleft[0] = -1; xright[0] = -1; }
+    if (doKmerTrimming && c->a.ksplit && !(c->a.ktrimLeft || c->a.ktrimRight || ktrimN)) {     /* :999-1013, 1028-1029 */
+        int id0, lm, rm, trimmed, npl;
+        const int split = has2 ? 0 : ksplit_read(c, tc, b1, l1, &id0, &lm, &rm, &trimmed, &npl);   /* assert(r2==null) */
+        if (!has2) {
+            a[0] = trimmed; ids[0] = id0;
+            if (xleft && xright) { xleft[0] = lm; xright[0] = rm; }
+            tc->counters[BBO_BASES_KTRIMMED] += trimmed;
+            tc->counters[BBO_READS_KTRIMMED] += (trimmed > 0 ? 1 : 0);
+            newLen1 = npl;                                                            /* r1.pairLength() after the split */
+            remove = split;                                                           /* remove=(r1.mate!=null) */
+        }
+    } else if (doKmerTrimming && ktrimN) {                                                   /* :984-998, 1009-1016, 1028-1029 */
         int xsum = 0, rktsum = 0, id0;
         int x = kmask_read(c, tc, b1, l1, 0, &id0, gmask, g1);
         xsum += x; rktsum += (x > 0 ? 1 : 0);
@@ -962,17 +1170,28 @@ static void process_pair(const bbo_ctx* c, tcounters* tc, const uint8_t* b1, int
     } else if (doKmerFiltering) {                                                     /* :1035-1093 */
         int maxBadKmersR1 = c->a.maxBadKmers0, maxBadKmersR2 = c->a.maxBadKmers0;     /* :1056-1057 */
         if (c->a.minKmerFraction != 0) {                                              /* :1058-1062 */
-            const int vk1 = num_valid_kmers(b1, l1, c->k), vk2 = has2 ? num_valid_kmers(b2, l2, c->k) : 0;
+            const int vk1 = num_valid_kmers(b1, l1, c->keff), vk2 = has2 ? num_valid_kmers(b2, l2, c->keff) : 0;
             maxBadKmersR1 = imax(c->a.maxBadKmers0, (int)((float)(vk1 - 1) * c->a.minKmerFraction));
             maxBadKmersR2 = imax(c->a.maxBadKmers0, (int)((float)(vk2 - 1) * c->a.minKmerFraction));
         }
-        int id; const int av = count_set_kmers(c, tc, b1, l1, 0, maxBadKmersR1, &id);
-        a[0] = av; ids[0] = id;
-        if (av > maxBadKmersR1) d1 = 1;
-        if (has2) {
-            const int bv = count_set_kmers(c, tc, b2, l2, 1, maxBadKmersR2, &id);
-            a[1] = bv; ids[1] = id;
-            if (bv > maxBadKmersR2) d2 = 1;
+        if (c->a.findBestMatch) {                                                     /* :1072-1078 */
+            int f; const int av = find_best_match(c, tc, b1, l1, 0, maxBadKmersR1, &f);
+            a[0] = f; ids[0] = av;
+            if (av > 0) d1 = 1;
+            if (has2) {
+                const int bv = find_best_match(c, tc, b2, l2, 1, maxBadKmersR2, &f);
+                a[1] = f; ids[1] = bv;
+                if (bv > 0) d2 = 1;
+            }
+        } else {                                                                      /* :1064-1070 */
+            int id; const int av = (c->kbig <= c->k ? count_set_kmers(c, tc, b1, l1, 0, maxBadKmersR1, &id) : count_set_kmers_big(c, tc, b1, l1, 0, maxBadKmersR1, &id));
+            a[0] = av; ids[0] = id;
+            if (av > maxBadKmersR1) d1 = 1;
+            if (has2) {
+                const int bv = (c->kbig <= c->k ? count_set_kmers(c, tc, b2, l2, 1, maxBadKmersR2, &id) : count_set_kmers_big(c, tc, b2, l2, 1, maxBadKmersR2, &id));
+                a[1] = bv; ids[1] = id;
+                if (bv > maxBadKmersR2) d2 = 1;
+            }
         }
         if ((c->removePairsIfEitherBad && (d1 || d2)) || (d1 && (!has2 || d2))) {
             remove = 1;
@@ -993,7 +1212,7 @@ static void process_pair(const bbo_ctx* c, tcounters* tc, const uint8_t* b1, int
 
 typedef struct {
     const bbo_ctx* c; const uint8_t* bases; const int64_t* offsets; int64_t n; int paired;
-    int32_t* out_a; int32_t* out_id; uint8_t* out_flags; uint32_t* out_mask; int32_t* out_left; int64_t u0, u1; tcounters tc;
+    int32_t* out_a; int32_t* out_id; uint8_t* out_flags; uint32_t* out_mask; int32_t* out_left; int32_t* out_right; int64_t u0, u1; tcounters tc;
 } job;
 
 static void* job_run(void* p) {
@@ -1005,7 +1224,7 @@ static void* job_run(void* p) {
         const uint8_t* b2 = NULL; int l2 = 0;
         if (j->paired) { b2 = j->bases + j->offsets[r + 1]; l2 = (int)(j->offsets[r + 2] - j->offsets[r + 1]); }
         process_pair(j->c, &j->tc, b1, l1, b2, l2, j->paired, j->out_a + r, j->out_id + r, j->out_flags + r, j->out_mask,
-                     j->offsets[r], j->paired ? j->offsets[r + 1] : 0, j->out_left ? j->out_left + r : NULL);
+                     j->offsets[r], j->paired ? j->offsets[r + 1] : 0, j->out_left ? j->out_left + r : NULL, j->out_right ? j->out_right + r : NULL);
     }
     return NULL;
 }
@@ -1018,8 +1237,18 @@ int bbo_process_batch_mask(bbo_ctx* c, const uint8_t* bases, const int64_t* offs
                            int32_t* out_a, int32_t* out_id, uint8_t* out_flags, uint32_t* out_mask, int nthreads) {
     return bbo_process_batch_ex(c, bases, offsets, n, paired, out_a, out_id, out_flags, out_mask, NULL, nthreads);
 }
+static int process_batch_all(bbo_ctx* c, const uint8_t* bases, const int64_t* offsets, int64_t n, int paired,
+                             int32_t* out_a, int32_t* out_id, uint8_t* out_flags, uint32_t* out_mask, int32_t* out_left, int32_t* out_right, int nthreads);
 int bbo_process_batch_ex(bbo_ctx* c, const uint8_t* bases, const int64_t* offsets, int64_t n, int paired,
                          int32_t* out_a, int32_t* out_id, uint8_t* out_flags, uint32_t* out_mask, int32_t* out_left, int nthreads) {
+    return process_batch_all(c, bases, offsets, n, paired, out_a, out_id, out_flags, out_mask, out_left, NULL, nthreads);
+}
+int bbo_process_batch_split(bbo_ctx* c, const uint8_t* bases, const int64_t* offsets, int64_t n,
+                            int32_t* out_a, int32_t* out_id, uint8_t* out_flags, int32_t* out_leftmost, int32_t* out_rightmost, int nthreads) {
+    return process_batch_all(c, bases, offsets, n, 0, out_a, out_id, out_flags, NULL, out_leftmost, out_rightmost, nthreads);
+}
+static int process_batch_all(bbo_ctx* c, const uint8_t* bases, const int64_t* offsets, int64_t n, int paired,
+                             int32_t* out_a, int32_t* out_id, uint8_t* out_flags, uint32_t* out_mask, int32_t* out_left, int32_t* out_right, int nthreads) {
     if (paired && (n & 1)) return -1;
     if (nthreads < 1) nthreads = 1;
     const int64_t units = paired ? n / 2 : n;
@@ -1030,7 +1259,7 @@ int bbo_process_batch_ex(bbo_ctx* c, const uint8_t* bases, const int64_t* offset
     for (int t = 0; t < nthreads; t++) {
         job* j = &jobs[t];
         j->c = c; j->bases = bases; j->offsets = offsets; j->n = n; j->paired = paired;
-        j->out_a = out_a; j->out_id = out_id; j->out_flags = out_flags; j->out_mask = out_mask; j->out_left = out_left;
+        j->out_a = out_a; j->out_id = out_id; j->out_flags = out_flags; j->out_mask = out_mask; j->out_left = out_left; j->out_right = out_right;
         j->u0 = units * t / nthreads; j->u1 = units * (t + 1) / nthreads;
         j->tc.scafReads = (int64_t*)calloc((size_t)ns, sizeof(int64_t));             /* thread-local copies (:272-277) */
         j->tc.scafBases = (int64_t*)calloc((size_t)ns, sizeof(int64_t));
@@ -1040,7 +1269,7 @@ int bbo_process_batch_ex(bbo_ctx* c, const uint8_t* bases, const int64_t* offset
         if (nthreads > 1) pthread_join(th[t], NULL);
         for (int i = 0; i < BBO_NCOUNTERS; i++) c->counters[i] += jobs[t].tc.counters[i];   /* BBDukProcessorS.add :300-342 */
         for (int i = 0; i < ns; i++) { c->scafReads[i] += jobs[t].tc.scafReads[i]; c->scafBases[i] += jobs[t].tc.scafBases[i]; }
-        free(jobs[t].tc.scafReads); free(jobs[t].tc.scafBases);
+        free(jobs[t].tc.scafReads); free(jobs[t].tc.scafBases); free(jobs[t].tc.countArray); free(jobs[t].tc.idList);
     }
     free(jobs); free(th);
     return 0;

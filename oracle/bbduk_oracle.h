@@ -51,6 +51,9 @@ typedef struct bbo_args {
     float minKmerFraction;    /* mkf=     (default 0; BBDukProcessorS.java:1055-1062) */
     float minCoveredFraction; /* mcf=     (default 0; :1038-1049, countCoveredBases :1602-1651) */
     int ktrimN;         /* ktrim=n / kmask= (BBDukProcessorS.java:2149-2323 with kmaskFullyCovered=false) */
+    int kbig;           /* the k of the command line when it exceeds 31 (then k=31; BBDukParser.java:164-165), else <= k */
+    int findBestMatch;  /* findbestmatch / fbm (BBDukProcessorS.java:1659-1719; rename is not restated) */
+    int ksplit;         /* ksplit=t (BBDukProcessorS.java:2332-2506; unpaired reads) */
 } bbo_args;
 
 #define BBO_NCOUNTERS 16
@@ -122,6 +125,10 @@ int      bbo_process_batch_ex(bbo_ctx* c, const uint8_t* bases, const int64_t* o
                               int32_t* out_a, int32_t* out_id, uint8_t* out_flags, uint32_t* out_mask, int32_t* out_left, int nthreads);
 int      bbo_process_batch(bbo_ctx* c, const uint8_t* bases, const int64_t* offsets, int64_t n, int paired,
                            int32_t* out_a, int32_t* out_id, uint8_t* out_flags, int nthreads);
+/* ksplit (unpaired): out_a = bases removed, out_leftmost/out_rightmost = the span ksplit() computed (-1,-1: nothing found);
+ * BBO_FLAG_REMOVED <=> the read was split in two (both pieces go to outm). */
+int      bbo_process_batch_split(bbo_ctx* c, const uint8_t* bases, const int64_t* offsets, int64_t n,
+                                 int32_t* out_a, int32_t* out_id, uint8_t* out_flags, int32_t* out_leftmost, int32_t* out_rightmost, int nthreads);
 
 /* counters: out[0..15] as BBO_* then scaffoldReadCounts[0..nscaf) then scaffoldBaseCounts[0..nscaf). */
 int      bbo_counters_len(const bbo_ctx* c);

@@ -18,7 +18,8 @@ class BboArgs(C.Structure):
                [("minLenFraction", C.c_float)] + \
                [(n, C.c_int) for n in ("requireBothBad", "trimPad", "ktrimExclusive", "restrictLeft", "restrictRight",
                                        "skipR1", "skipR2", "minSkip", "maxSkip", "trimPairsEvenly", "qSkip", "speed")] + \
-               [("minKmerFraction", C.c_float), ("minCoveredFraction", C.c_float), ("ktrimN", C.c_int)]
+               [("minKmerFraction", C.c_float), ("minCoveredFraction", C.c_float), ("ktrimN", C.c_int),
+                ("kbig", C.c_int), ("findBestMatch", C.c_int), ("ksplit", C.c_int)]
 
 
 def build(force: bool = False) -> str:
@@ -60,6 +61,8 @@ def lib():
         L.bbo_count_set_kmers.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
         L.bbo_process_batch_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.bbo_process_batch_split.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.bbo_process_batch_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.bbo_process_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
@@ -202,6 +205,19 @@ class Oracle:
         if rc != 0:
             raise ValueError("bbo_process_batch_ex rc=%d" % rc)
         return a - left, left, ids, fl
+
+    def process_batch_split(self, bases: np.ndarray, offsets: np.ndarray, nthreads: int = 1):
+        """ksplit (unpaired): (bases removed, ids, flags, leftmost, rightmost)."""
+        n = len(offsets) - 1
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        a = np.empty(n, np.int32); ids = np.empty(n, np.int32); fl = np.zeros(n, np.uint8)
+        lm = np.empty(n, np.int32); rm = np.empty(n, np.int32)
+        rc = lib().bbo_process_batch_split(self.h, bases.ctypes.data, offsets.ctypes.data, n,
+                                           a.ctypes.data, ids.ctypes.data, fl.ctypes.data, lm.ctypes.data, rm.ctypes.data, nthreads)
+        if rc != 0:
+            raise ValueError("bbo_process_batch_split rc=%d" % rc)
+        return a, ids, fl, lm, rm
 
     def counters(self) -> np.ndarray:
         out = np.zeros(lib().bbo_counters_len(self.h), np.int64)

@@ -71,6 +71,9 @@ class Args:
     minKmerFraction: float = 0.0    # mkf=
     minCoveredFraction: float = 0.0 # mcf=
     ktrimN: bool = False            # ktrim=n / kmask=  (mask instead of trim; kmaskfullycovered is not restated)
+    kbig: int = -1                  # k>31 on the command line: k is then 31 and kbig the requested k (BBDukParser.java:164-165)
+    findBestMatch: bool = False     # findbestmatch / fbm (kfilter only; rename is not restated)
+    ksplit: bool = False            # ksplit=t (unpaired reads only)
 
 
 COUNTER_NAMES = ["readsIn", "basesIn", "readsKTrimmed", "basesKTrimmed", "readsKFiltered", "basesKFiltered",
@@ -91,7 +94,7 @@ class Spec:
         self.qhdist2 = a.qhdist if a.qhdist2 == -1 else a.qhdist2
         self.forbidNs = a.forbidN or self.hdist < 1
         self.k = k
-        mm = a.maskMiddle
+        mm = a.maskMiddle and not a.kbig > k                                      # :237-243 (before minlen2 is derived)
         mml = (a.midMaskLen if a.midMaskLen > 0 else 2 - (k & 1)) if mm else 0     # :230-236
         self.mink = min(a.mink, k)                                                 # :245
         self.minlen = k - 1                                                        # :274
@@ -100,12 +103,17 @@ class Spec:
         self.useShortKmers = 0 < self.mink < k                                     # :289
         if self.useShortKmers:
             mm, mml = False, 0                                                     # :290-296
-            assert a.ktrimLeft or a.ktrimRight or a.ktrimN                         # :301
+            assert a.ktrimLeft or a.ktrimRight or a.ktrimN or a.ksplit            # :301
         if mm:                                                                     # :303-312
             self.middleMask = ~(((1 << (2 * mml)) - 1) << (((k - mml) // 2) * 2))
         else:
             self.middleMask = -1
-        self.kfilter = not (a.ktrimLeft or a.ktrimRight or a.ktrimN)
+        self.kfilter = not (a.ktrimLeft or a.ktrimRight or a.ktrimN or a.ksplit)
+        self.kbig = a.kbig if a.kbig > k else k
+        self.keff = max(k, self.kbig)                                              # :231
+        assert not (self.kbig > k and not self.kfilter) and not (self.kbig > k and (a.speed > 0 or a.qSkip > 1))   # :207-223 reduce kbig to k
+        assert not (a.findBestMatch and self.kbig > k)                             # :299
+        self.splits = []           # ksplit: per-read (leftmost, rightmost) or (-1, -1), process order
         self.rieb = not a.requireBothBad                                           # :109
         self.table = {}            # key -> id  (first writer wins == smallest id; ids ascend in file order)
         self.nscaf = 1             # scaffoldNames[0] reserved (bbduk/BBDukIndex.java:105-107)
@@ -210,6 +218,12 @@ class Spec:
     def _main_hits(self, read: bytes, start: int, stop: int):
         """Yield (i, id) for every position of the main scan whose lookup returns id>0, in increasing i.
         bbduk/BBDukProcessorS.java:2009-2029 == :1547-1591."""
+        for i, vid in self._main_lookups(read, start, stop):
+            if vid > 0:
+                yield i, vid
+
+    def _main_lookups(self, read: bytes, start: int, stop: int):
+        """Yield (i, id) for every position of the main scan that is looked up at all (id may be -1)."""
         k = self.k
         for i in range(max(start, k - 1), stop):
             lo = max(start, i - k + 1)
@@ -228,9 +242,7 @@ class Spec:
             rk = 0
             for j in range(max(lo, lastN + 1), i + 1):
                 rk |= comp_code(read[j]) << (2 * (k - 1 - (i - j)))
-            vid = self.lookup(kmer, rk, k, self.qhdist, i)
-            if vid > 0:
-                yield i, vid
+            yield i, self.lookup(kmer, rk, k, self.qhdist, i)
 
     @staticmethod
     def _trim_by_amount(n, left, right, minres):
@@ -417,6 +429,110 @@ class Spec:
             found += 1
         return found, -1
 
+    def count_set_kmers_big(self, read: bytes, pairnum: int, maxBad: int):
+        """Returns (found, id).  bbduk/BBDukProcessorS.java:1726-1804: k-mers longer than 31 are emulated by runs of
+        consecutive matching 31-mers; positions that are not looked up neither extend nor close a run."""
+        from itertools import groupby
+        a, k, n = self.a, self.k, len(read)
+        if n < self.kbig or not self.table:
+            return 0, -1
+        if (a.skipR1 and pairnum == 0) or (a.skipR2 and pairnum == 1):
+            return 0, -1
+        sub = self.kbig - k - 1
+        start, stop = self._span(n)
+        found = 0
+        for hit, grp in groupby(self._main_lookups(read, start, stop), key=lambda t: t[1] > 0):
+            if not hit:
+                continue
+            grp = list(grp)
+            dif = grp[-1][0] - grp[0][0] - sub
+            if dif > 0:
+                old, found = found, found + dif
+                if found > maxBad and old <= maxBad:            # both exits credit the run's last id; the early return
+                    vid = grp[-1][1]                             # (:1763-1773) and the tail (:1783-1800) return the same count
+                    self.scafReads[vid] += 1
+                    self.scafBases[vid] += n
+                    return found, vid
+        return found, -1
+
+    def find_best_match(self, read: bytes, pairnum: int, maxBad: int):
+        """Returns (found, id).  bbduk/BBDukProcessorS.java:1659-1719 (length gate k, no early exit; the id with the most
+        hits, the earliest-seen one among equals).  Only maxBad==0 is restated: with found<=maxBad the reference leaves its
+        per-thread countArray dirty, which makes later answers depend on the thread's history."""
+        a, k, n = self.a, self.k, len(read)
+        assert maxBad == 0
+        if n < k or not self.table:
+            return 0, -1
+        if (a.skipR1 and pairnum == 0) or (a.skipR2 and pairnum == 1):
+            return 0, -1
+        start, stop = self._span(n)
+        counts = {}
+        for _, vid in self._main_hits(read, start, stop):
+            counts[vid] = counts.get(vid, 0) + 1               # dicts keep first-insertion order == idList order
+        if not counts:
+            return 0, -1
+        best = max(counts.values())
+        vid = next(i for i, c in counts.items() if c == best)
+        self.scafReads[vid] += 1
+        self.scafBases[vid] += n
+        return sum(counts.values()), vid
+
+    def ksplit_read(self, read: bytes):
+        """Returns (trimmed, id0, leftmost, rightmost, split, newPairLength).  bbduk/BBDukProcessorS.java:2332-2506."""
+        a, k, n = self.a, self.k, len(read)
+        none = (0, -1, -1, -1, False, n)
+        if n < max(1, min(k, self.mink) if self.useShortKmers else k) or not self.table or n < k:
+            return none
+        assert a.trimPad <= 0          # a positive trimPad can push rightmost past the read end, where subRead throws
+        minus, plus = k - 1 - a.trimPad, a.trimPad
+        start, stop = self._span(n)
+        hits = list(self._main_hits(read, start, stop))
+        leftmost, rightmost, id0 = 1 << 31, -1, -1
+        if hits:
+            id0 = hits[0][1]
+            leftmost = max(0, hits[0][0] - minus)
+            rightmost = hits[-1][0] + plus
+        found = len(hits)
+        if self.useShortKmers and id0 == -1:
+            # right side (:2391-2431): suffix read[i:stop] of every length >= mink, longest i first in the loop but all hits count
+            for i in range(stop - 1, max(-1, stop - k), -1):
+                L = stop - i
+                if L < self.mink:
+                    continue
+                vid = self._short_lookup(read[i:stop], L, i)
+                if vid > 0:
+                    if id0 < 0: id0 = vid
+                    leftmost = min(leftmost, max(0, i - a.trimPad)); rightmost = n - 1; found += 1
+            if id0 == -1:                                       # left side (:2434-2473)
+                for i in range(start, min(k, stop)):
+                    L = i - start + 1
+                    if L < self.mink:
+                        continue
+                    vid = self._short_lookup(read[start:i + 1], L, i)
+                    if vid > 0:
+                        if id0 < 0: id0 = vid
+                        leftmost = 0; rightmost = max(rightmost, i + a.trimPad); found += 1
+        if found == 0:
+            return none
+        self.scafReads[id0] += 1
+        self.scafBases[id0] += n
+        if leftmost == 0:
+            x, n1 = self._trim_by_amount(n, rightmost + 1, n - (n - 1) - 1, 1)
+            return n - n1, id0, leftmost, rightmost, False, n1
+        if rightmost == n - 1:
+            x, n1 = self._trim_by_amount(n, 0, n - (leftmost - 1) - 1, 1)
+            return n - n1, id0, leftmost, rightmost, False, n1
+        n2 = (n - 1) - (rightmost + 1)                          # subRead(rightmost+1, n-1): copyOfRange excludes index n-1
+        x, n1 = self._trim_by_amount(n, 0, n - (leftmost - 1) - 1, 1)
+        return n - (n1 + n2), id0, leftmost, rightmost, True, n1 + n2
+
+    def _short_lookup(self, sub: bytes, L: int, qpos: int) -> int:
+        kmer = rk = 0
+        for j, c in enumerate(sub):
+            kmer |= fwd_code(c) << (2 * (L - 1 - j))
+            rk |= comp_code(c) << (2 * j)
+        return self.lookup(kmer, rk, L, self.qhdist2, qpos)
+
     def num_valid_kmers(self, read: bytes, k: int) -> int:
         """stream/Read.java:1673-1683."""
         ln = counted = 0
@@ -473,6 +589,13 @@ class Spec:
             C[3] += xsum; C[2] += rkt
             res = [(x1, i1)] + ([(x2, i2)] if has2 else [])
             self.masks += [m1] + ([m2] if has2 else [])
+        elif self.table and a.ksplit:                                                  # :999-1013
+            assert not has2
+            x1, i1, lm, rm, split, n1 = self.ksplit_read(r1)
+            C[3] += x1; C[2] += int(x1 > 0)
+            remove = split                                                             # remove=(r1.mate!=null): both pieces go to outm
+            res = [(x1, i1)]
+            self.splits.append((lm, rm))
         elif self.table and (a.ktrimLeft or a.ktrimRight):
             tips = a.ktrimLeft and a.ktrimRight                                        # :771, 954-967
             if tips:
@@ -522,15 +645,16 @@ class Spec:
         elif self.table:
             mb1 = mb2 = a.maxBadKmers0                                                 # :1055-1062
             if a.minKmerFraction != 0:
-                vk1, vk2 = self.num_valid_kmers(r1, self.k), (self.num_valid_kmers(r2, self.k) if has2 else 0)
+                vk1, vk2 = self.num_valid_kmers(r1, self.keff), (self.num_valid_kmers(r2, self.keff) if has2 else 0)
                 mb1 = max(a.maxBadKmers0, int(f32(vk1 - 1) * f32(a.minKmerFraction)))
                 mb2 = max(a.maxBadKmers0, int(f32(vk2 - 1) * f32(a.minKmerFraction)))
-            f1, i1 = self.count_set_kmers(r1, 0, mb1)
-            d1 = f1 > mb1
+            count = self.find_best_match if a.findBestMatch else (self.count_set_kmers_big if self.kbig > self.k else self.count_set_kmers)
+            f1, i1 = count(r1, 0, mb1)                                                 # :1064-1076
+            d1 = i1 > 0 if a.findBestMatch else f1 > mb1
             res = [(f1, i1)]
             if has2:
-                f2, i2 = self.count_set_kmers(r2, 1, mb2)
-                d2 = f2 > mb2
+                f2, i2 = count(r2, 1, mb2)
+                d2 = i2 > 0 if a.findBestMatch else f2 > mb2
                 res.append((f2, i2))
             if (self.rieb and (d1 or d2)) or (d1 and (not has2 or d2)):
                 remove = True

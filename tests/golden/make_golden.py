@@ -86,7 +86,27 @@ def main():
              dict(k=23, mink=11, ktrimLeft=True), ADAPTERS,
              [ad[-30:] + g[:60], ad[-12:] + g[:60], g, ad, g[:40] + ad[:30] + g[40:70]], False)
 
-    cli_fixtures(phix)
+    # k>31 (kbig): the C3 reads, k=40 counted as runs of 31-mer hits; expected = (countSetKmersBig return, credited id, flags)
+    reads = synth_reads(3, 60, contam=phix, contam_frac=0.3, sub_rate=0.02, n_rate=0.004)
+    run_case("c3_kfilter_k40_hdist1_phix", "k=40 hdist=1 ref=phix", dict(k=31, kbig=40, hdist=1), PHIX, reads, True)
+    # findBestMatch over scaffolds that share sequence: expected = (hits, best id, flags)
+    import random
+    rng = random.Random(31)
+    rs = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    sc = [rs(120) for _ in range(4)]
+    sc.append(sc[0][:70] + sc[1][50:])                      # shares k-mers with scaffolds 1 and 2: first-writer-wins ids, ties
+    fb = [sc[0][10:100], sc[1][:60] + sc[2][30:110], sc[2][:40] + rs(20) + sc[3][60:], rs(150), sc[4], sc[3][5:30] + "N" + sc[3][31:80],
+          sc[1][80:] + sc[0][:45], sc[0][:26] + sc[1][:26] + sc[2][:26] + sc[3][:26], sc[2][50:74], ""]
+    run_case("fbm_k25_literal", "k=25 fbm=t", dict(k=25, findBestMatch=True), sc, fb, True)
+    # ksplit: adapters in the middle (split), at either end (trim), short k-mers at the 3' end, nothing
+    ad = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCACATCACGATCTCGTATGCCGTCTTCTGCTTG"
+    g = rs(400)
+    ks = [g[:70] + ad[:40] + g[70:150], ad[:35] + g[:90], g[:90] + ad[:35], g[:100] + ad[:13], g[:100] + ad[:9], g[:150],
+          g[:60] + ad[:30] + g[60:61], g[:1] + ad[5:40] + g[100:180], ad, g[:40] + ad[:25] + g[40:80] + ad[10:40] + g[80:120], "", "ACGT"]
+    run_case("ksplit_k23_mink11_hdist1_adapters", "ksplit=t k=23 mink=11 hdist=1 ref=adapters",
+             dict(k=23, mink=11, hdist=1, ksplit=True), ADAPTERS, ks, False)
+
+    cli_fixtures(phix, ks)
 
 
 def write_fastq(path, names, reads):
@@ -96,7 +116,7 @@ def write_fastq(path, names, reads):
             f.write("@%s\n%s\n+\n%s\n" % (nm, r, q))
 
 
-def cli_fixtures(phix):
+def cli_fixtures(phix, ks):
     """FASTQ inputs + the per-read TSV bbduk_cli has to print for them (the non-JVM caller is pinned by
     fixture FASTQs and the spec's per-read results).  Read names follow the AddAdapters truth convention."""
     here = os.path.dirname(__file__)
@@ -131,6 +151,25 @@ def cli_fixtures(phix):
     write_fastq(os.path.join(here, "cli_c3_interleaved.fq"), names, reads)
     s = Spec(Args(k=31, hdist=1)); s.load_fasta(PHIX)
     tsv(os.path.join(here, "cli_c3.tsv"), names, reads, s.process_batch([r.encode() for r in reads], True), False)
+    # the same file with k=40: K is split into k=31 + runs (countSetKmersBig)
+    s = Spec(Args(k=31, kbig=40, hdist=1)); s.load_fasta(PHIX)
+    tsv(os.path.join(here, "cli_c3_k40.tsv"), names, reads, s.process_batch([r.encode() for r in reads], True), False)
+    # ksplit: unpaired input; kept reads (trimmed at an end or untouched) and the split pairs that leave through outm
+    names = ["split%d" % i for i in range(len(ks))]
+    write_fastq(os.path.join(here, "cli_ksplit.fq"), names, ks)
+    s = Spec(Args(k=23, mink=11, hdist=1, ksplit=True)); s.load_fasta(ADAPTERS)
+    out = s.process_batch([r.encode() for r in ks], False)
+    tsv(os.path.join(here, "cli_ksplit.tsv"), names, ks, out, True)
+    with open(os.path.join(here, "cli_ksplit_expected_out.fq"), "w") as fo, open(os.path.join(here, "cli_ksplit_expected_outm.fq"), "w") as fm:
+        for i, (nm, r, t, (lm, rm)) in enumerate(zip(names, ks, out, s.splits)):
+            q = "".join(chr(33 + (7 * i + 3 * j) % 41) for j in range(len(r)))
+            if t[2] & 2:                                         # split: [0,leftmost) and [rightmost+1, len-1)
+                fm.write("@%s\n%s\n+\n%s\n" % (nm, r[:lm], q[:lm]))
+                fm.write("@%s\n%s\n+\n%s\n" % (nm, r[rm + 1:len(r) - 1], q[rm + 1:len(r) - 1]))
+            elif t[0] > 0 and lm == 0:
+                fo.write("@%s\n%s\n+\n%s\n" % (nm, r[t[0]:], q[t[0]:]))
+            else:
+                fo.write("@%s\n%s\n+\n%s\n" % (nm, r[:len(r) - t[0]], q[:len(r) - t[0]]))
     print("cli fixtures written")
 
 

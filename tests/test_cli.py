@@ -72,3 +72,24 @@ def test_cli_kmask_masks_bases_like_the_spec(tmp_path):
     assert open(tsv).read() == open(os.path.join(GOLD, "cli_kmask.tsv")).read()
     assert open(out).read() == open(os.path.join(GOLD, "cli_kmask_expected.fq")).read()
     assert "KMasked:" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_k40_counts_runs_of_31mers(tmp_path):
+    tsv = str(tmp_path / "o.tsv")
+    r = run_cli(["in=" + os.path.join(GOLD, "cli_c3_interleaved.fq"), "int=t", "tsv=" + tsv, "k=40", "hdist=1", "ref=phix"])
+    assert r.returncode == 0, r.stderr
+    assert open(tsv).read() == open(os.path.join(GOLD, "cli_c3_k40.tsv")).read()
+
+
+@pytest.mark.gpu
+def test_cli_ksplit_trims_or_splits_like_the_spec(tmp_path):
+    tsv, out, outm = (str(tmp_path / n) for n in ("o.tsv", "kept.fq", "split.fq"))
+    r = run_cli(["in=" + os.path.join(GOLD, "cli_ksplit.fq"), "tsv=" + tsv, "out=" + out, "outm=" + outm, "batch=5",
+                 "ksplit=t", "k=23", "mink=11", "hdist=1", "ref=adapters"])
+    assert r.returncode == 0, r.stderr
+    assert open(tsv).read() == open(os.path.join(GOLD, "cli_ksplit.tsv")).read()
+    assert open(out).read() == open(os.path.join(GOLD, "cli_ksplit_expected_out.fq")).read()
+    assert open(outm).read() == open(os.path.join(GOLD, "cli_ksplit_expected_outm.fq")).read()
+    r = run_cli(["in=" + os.path.join(GOLD, "cli_c2_r1.fq"), "in2=" + os.path.join(GOLD, "cli_c2_r2.fq"), "ksplit=t", "k=23", "ref=adapters"])
+    assert r.returncode == 1 and "unpaired" in r.stderr

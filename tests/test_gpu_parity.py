@@ -529,3 +529,93 @@ def test_device_built_adapter_and_phix_tables():
         assert np.array_equal(ga, oa) and np.array_equal(gi, oi) and np.array_equal(gf, of)
         assert np.array_equal(d.gpu.counters(), o.counters())
         d.close()
+
+
+# ---- kbig (k>31 by runs of 31-mers), findBestMatch: behind the kfilter operators; ksplit: its own operator
+BIG = [("k=40", dict(k=31, kbig=40)), ("k=32 hdist=1", dict(k=31, kbig=32, hdist=1)), ("k=50 mbk=3 rieb=f", dict(k=31, kbig=50, maxBadKmers0=3, requireBothBad=1)),
+       ("k=45 forbidn=t restrictleft=120", dict(k=31, kbig=45, forbidN=1, restrictLeft=120)), ("k=36 mkf=0.2 qhdist=1", dict(k=31, kbig=36, minKmerFraction=0.2, qhdist=1)),
+       ("k=25 fbm", dict(k=25, findBestMatch=1)), ("k=13 findbestmatch=t hdist=1 mm=f rieb=f", dict(k=13, findBestMatch=1, hdist=1, maskMiddle=0, requireBothBad=1)),
+       ("k=19 fbm=t skipr1=t restrictright=90", dict(k=19, findBestMatch=1, skipR1=1, restrictRight=90))]
+SPLIT = [("k=23 ksplit=t", dict(k=23, ksplit=1)), ("k=15 ksplit mink=7 hdist=1", dict(k=15, ksplit=1, mink=7, hdist=1)),
+         ("k=13 ksplit=t tp=-2 forbidn=t", dict(k=13, ksplit=1, trimPad=-2, forbidN=1)), ("k=17 ksplit mink=9 restrictleft=100 qhdist=1", dict(k=17, ksplit=1, mink=9, restrictLeft=100, qhdist=1)),
+         ("k=11 ksplit mink=5 restrictright=60 rcomp=f", dict(k=11, ksplit=1, mink=5, restrictRight=60, rcomp=0))]
+
+
+@pytest.mark.parametrize("ci", range(len(BIG)))
+def test_kbig_findbestmatch_fuzz_parity(ci):
+    args, okw = BIG[ci]
+    hits = 0
+    for seed in range(4):
+        rng = random.Random(21000 + 100 * ci + seed)
+        refs, reads = util.long_refs_and_reads(rng)
+        reads = reads * 8 + [rng.choice(refs)[:rng.randint(30, 200)] + util.rand_seq(rng, rng.randint(0, 300)) for _ in range(80)]
+        if len(reads) % 2:
+            reads.append(b"")
+        d, o = make_pair(args, okw, refs=refs)
+        check_batch(d, o, reads[:203], False)
+        check_batch(d, o, reads, True)                     # ASCII and packed formats, per-read results and counters
+        hits += int(d.gpu.counters()[B.NCOUNTERS:B.NCOUNTERS + d.gpu.params.numScaffolds].sum())
+        d.close()
+    assert hits > 20
+
+
+def test_kbig_long_reads_and_phix():
+    """Runs that span several 256-position blocks and many reads per tile: phiX pieces of 300..6000 bases, k=40 and k=100."""
+    rng = random.Random(8)
+    phix = B.read_fasta(util.PHIX)[0][1]
+    for args, okw in (("k=40 ref=phix", dict(k=31, kbig=40)), ("k=100 hdist=1 ref=phix mbk=700", dict(k=31, kbig=100, hdist=1, maxBadKmers0=700))):
+        d, o = make_pair(args, okw, ref_fasta=util.PHIX)
+        reads = []
+        for _ in range(300):
+            L = rng.choice([300, 700, 1500, 4000]); a = rng.randrange(len(phix) - L)
+            piece = bytearray(phix[a:a + L])
+            for _ in range(rng.randint(0, 6)):             # substitutions / Ns break the runs
+                piece[rng.randrange(L)] = rng.choice(b"ACGTN")
+            reads.append(util.rand_seq(rng, rng.randint(0, 200)) + (util.revcomp(bytes(piece)) if rng.random() < 0.5 else bytes(piece)) + util.rand_seq(rng, rng.randint(0, 200)))
+        check_batch(d, o, reads, True, nthreads=8)
+        assert d.gpu.counters()[4] > 100                    # readsKFiltered
+        d.close()
+
+
+def test_findbestmatch_id_overflow_is_an_error():
+    rng = random.Random(5)
+    refs = [util.rand_seq(rng, 40) for _ in range(70)]     # one read made of 70 scaffolds: more distinct ids than a wave keeps
+    d = B.BBDuk("k=21 fbm", refs=refs)
+    b, off = pack_reads([b"".join(refs)])
+    with pytest.raises(B.BBDukError):
+        d.gpu.process_batch(b, off, False)
+    b, off = pack_reads([b"".join(refs[:64])])             # exactly 64 still fits
+    a, ids, fl = d.gpu.process_batch(b, off, False)
+    assert ids[0] == 1 and a[0] == 64 * 20
+    d.close()
+
+
+def check_split(d, o, reads):
+    b, off = pack_reads(reads)
+    d.gpu.reset_counters(); o.reset_counters()
+    gx, gi, gf, gl, gr = d.gpu.ksplit_batch(b, off)
+    ox, oi, of, ol, orr = o.process_batch_split(b, off, nthreads=4)
+    bad = np.nonzero((gx != ox) | (gi != oi) | (gf != of) | (gl != ol) | (gr != orr))[0]
+    assert len(bad) == 0, [(int(i), reads[i], (int(gx[i]), int(gi[i]), int(gf[i]), int(gl[i]), int(gr[i])),
+                            (int(ox[i]), int(oi[i]), int(of[i]), int(ol[i]), int(orr[i]))) for i in bad[:3]]
+    assert np.array_equal(d.gpu.counters(), o.counters())
+    return gf
+
+
+@pytest.mark.parametrize("ci", range(len(SPLIT)))
+def test_ksplit_fuzz_parity(ci):
+    args, okw = SPLIT[ci]
+    nsplit = 0
+    for seed in range(4):
+        rng = random.Random(22000 + 100 * ci + seed)
+        refs, reads = util.long_refs_and_reads(rng)
+        refs = [r[:rng.randint(12, 60)] for r in refs]
+        reads = reads * 4 + [util.rand_seq(rng, rng.randint(0, 80)) + rng.choice(refs) + util.rand_seq(rng, rng.randint(0, 80)) for _ in range(200)]
+        d, o = make_pair(args, okw, refs=refs)
+        nsplit += int((check_split(d, o, reads) & 2).astype(bool).sum())
+        check_split(d, o, [])
+        with pytest.raises(B.BBDukError):
+            d.gpu.process_batch(*pack_reads(reads[:4]), True)          # ksplit is for unpaired reads
+        d.close()
+    assert nsplit > 20
+

@@ -73,8 +73,26 @@ def test_parser_errors_like_the_reference():
         B.HostIndex("k=23 bogus=1")                       # BBDukParser.java:870-872
     with pytest.raises(B.BBDukError):
         B.HostIndex("k=23 mink=11")                       # mink needs a ktrim mode (:301)
+    p = B.HostIndex("k=40").params()                      # k>31: k=31, kbig=40, maskMiddle off before minlen2 (:164-165, 237-243)
+    assert (p.k, p.kbig, p.middleMask, p.minlen2, p.mode) == (31, 40, -1, 31, B.MODE_KFILTER)
+    p = B.HostIndex("k=40 ktrim=r").params()              # trimming modes reduce K to 31 (:207-215): maskMiddle stays on
+    assert (p.k, p.kbig, p.minlen2, p.mode) == (31, 0, 15, B.MODE_KTRIM_R) and p.middleMask == ~(3 << 30)
+    p = B.HostIndex("k=35 speed=3").params()              # so do speed / qskip (:217-223)
+    assert (p.k, p.kbig) == (31, 0)
+    with pytest.raises(B.BBDukError, match="findBestMatch"):
+        B.HostIndex("k=40 fbm=t")                         # :299
     with pytest.raises(B.BBDukError):
-        B.HostIndex("k=40")                               # kbig out of scope
+        B.HostIndex("k=25 fbm=t mbk=2")                   # thread-history dependent in the reference: refused
+    with pytest.raises(B.BBDukError):
+        B.HostIndex("k=25 rename=t")
+    p = B.HostIndex("k=25 fbm").params()
+    assert (p.findBestMatch, p.mode) == (1, B.MODE_KFILTER)
+    assert B.HostIndex("k=25 fbm ktrim=r").params().findBestMatch == 0     # only the filtering branch consults it (:1072)
+    p = B.HostIndex("k=23 mink=11 ksplit=t").params()     # ksplit is a trimming mode: mink allowed (:301)
+    assert p.mode == B.MODE_KSPLIT
+    assert B.HostIndex("k=23 ksplit=t ktrim=r").params().mode == B.MODE_KTRIM_R    # a later ktrim= clears it (:604-620)
+    with pytest.raises(B.BBDukError):
+        B.HostIndex("k=23 ksplit tp=2")
     h = B.HostIndex("ktrim=r")                            # k defaults to 27 (:163)
     assert h.params().k == 27
     h = B.HostIndex("ktrim=r k=23 mkh=3 rieb=f mlf=0.5 minlen=20 tp=1")

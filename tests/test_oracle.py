@@ -193,6 +193,80 @@ def test_differential_fuzz_kmask(ci):
             assert paired is False or int(a.sum()) > 0          # the fuzz reads really get masked
 
 
+# kbig (k>31 emulated by runs of 31-mers), findBestMatch, ksplit: longer references so that runs and several scaffolds occur
+BIG_FUZZ = [dict(k=31, kbig=40), dict(k=31, kbig=32, hdist=1), dict(k=31, kbig=50, maxBadKmers0=3, requireBothBad=1), dict(k=31, kbig=45, forbidN=1, restrictLeft=120),
+            dict(k=31, kbig=36, minKmerFraction=0.2, qhdist=1), dict(k=25, findBestMatch=1), dict(k=13, findBestMatch=1, hdist=1, maskMiddle=0, requireBothBad=1),
+            dict(k=19, findBestMatch=1, skipR1=1, restrictRight=90)]
+SPLIT_FUZZ = [dict(k=23, ksplit=1), dict(k=15, ksplit=1, mink=7, hdist=1), dict(k=13, ksplit=1, trimPad=-2, forbidN=1),
+              dict(k=17, ksplit=1, mink=9, restrictLeft=100, qhdist=1), dict(k=11, ksplit=1, mink=5, restrictRight=60, rcomp=0)]
+
+
+@pytest.mark.parametrize("ci", range(len(BIG_FUZZ)))
+def test_differential_fuzz_kbig_findbestmatch(ci):
+    kw = BIG_FUZZ[ci]
+    hits = 0
+    for seed in range(4):
+        rng = random.Random(11000 + 100 * ci + seed)
+        refs, reads = util.long_refs_and_reads(rng)
+        o = Oracle(**kw)
+        s = Spec(Args(**{k: (bool(v) if k in BOOLS else v) for k, v in kw.items()}))
+        for r in refs:
+            o.add_ref(r); s.add_ref(r)
+        for paired in (True, False):
+            o.reset_counters()
+            s.counters = [0] * 16; s.scafReads = [0] * s.nscaf; s.scafBases = [0] * s.nscaf
+            b, off = pack_reads(reads)
+            a, ids, fl = o.process_batch(b, off, paired, nthreads=3)
+            assert list(zip(a.tolist(), ids.tolist(), fl.tolist())) == s.process_batch(reads, paired)
+            assert o.counters().tolist() == s.all_counters()
+            hits += int((ids > 0).sum())
+    assert hits > 20
+
+
+@pytest.mark.parametrize("ci", range(len(SPLIT_FUZZ)))
+def test_differential_fuzz_ksplit(ci):
+    kw = SPLIT_FUZZ[ci]
+    nsplit = 0
+    for seed in range(4):
+        rng = random.Random(12000 + 100 * ci + seed)
+        refs, reads = util.long_refs_and_reads(rng)
+        refs = [r[:rng.randint(12, 60)] for r in refs]           # short inserts so that reads keep flanks on both sides
+        reads += [util.rand_seq(rng, rng.randint(20, 80)) + rng.choice(refs) + util.rand_seq(rng, rng.randint(20, 80)) for _ in range(10)]
+        o = Oracle(**kw)
+        s = Spec(Args(**{k: (bool(v) if k in BOOLS else v) for k, v in kw.items()}))
+        for r in refs:
+            o.add_ref(r); s.add_ref(r)
+        o.reset_counters()
+        b, off = pack_reads(reads)
+        a, ids, fl, lm, rm = o.process_batch_split(b, off, nthreads=3)
+        assert list(zip(a.tolist(), ids.tolist(), fl.tolist())) == s.process_batch(reads, False)
+        assert list(zip(lm.tolist(), rm.tolist())) == s.splits
+        assert o.counters().tolist() == s.all_counters()
+        nsplit += int((fl & 2).astype(bool).sum())
+    assert nsplit > 3
+
+
+def test_kbig_known_answers():
+    """A read holding 70 bases of a scaffold has 70-40+1 = 31 40-mers of it: bkStop-bkStart-(kbig-k-1) (:1758); shorter than
+    kbig -> 0 (:1727); 39 shared bases -> nine 31-mer hits but no 40-mer."""
+    rng = random.Random(3)
+    ref = util.rand_seq(rng, 200)
+    o = Oracle(k=31, kbig=40); o.add_ref(ref)
+    assert o.constant("maskMiddle") == 0 and o.constant("minlen2") == 31
+    flank = lambda n: bytes(rng.choice(b"AC") for _ in range(n))       # cannot extend a G/T-flanked match
+    sub = lambda a, b: b"G" + ref[a:b] + b"G"
+    for piece, want in ((70, 31), (40, 1), (39, 0)):
+        a0 = 50
+        while ref[a0 - 1:a0] in b"G" or ref[a0 + piece:a0 + piece + 1] in b"G":
+            a0 += 1
+        rd = flank(20) + sub(a0, a0 + piece) + flank(20)
+        b, off = pack_reads([rd])
+        a, ids, fl = o.process_batch(b, off, False)
+        assert (int(a[0]), int(ids[0]), int(fl[0])) == ((want, 1, 3) if want else (0, -1, 0)), piece
+    b, off = pack_reads([ref[:39]])
+    assert o.process_batch(b, off, False)[0][0] == 0
+
+
 @pytest.mark.parametrize("ci", range(len(FUZZ)))
 def test_differential_fuzz(ci):
     kw = FUZZ[ci]

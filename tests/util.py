@@ -76,3 +76,16 @@ def fuzz_reads(rng, refs, n, lengths, p_insert=0.7, p_n=0.02, junk=False):
                 g[rng.randrange(L)] = rng.choice(b"acgtunRYKM.-*X\x00\x7f\x80\xff")
         reads.append(bytes(g))
     return reads
+
+
+def long_refs_and_reads(rng):
+    refs = [rand_seq(rng, rng.randint(40, 220), 0.005) for _ in range(5)]
+    refs.append(refs[0][:60] + refs[1][-50:])                   # scaffolds sharing k-mers: ties and first-writer-wins ids
+    reads = fuzz_reads(rng, refs, 30, [0, 1, 12, 30, 31, 32, 40, 41, 60, 100, 150, 151, 250, 300], junk=True)
+    for _ in range(10):                                          # chimeras: pieces of two or three scaffolds in one read
+        parts = []
+        for _ in range(rng.randint(2, 3)):
+            r = rng.choice(refs)
+            a = rng.randrange(len(r)); parts.append(r[a:a + rng.randint(20, 90)]); parts.append(rand_seq(rng, rng.randint(0, 25)))
+        reads.append(b"".join(parts))
+    return refs, reads
