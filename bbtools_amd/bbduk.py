@@ -52,13 +52,60 @@ GPU_SYMBOLS = ["bbduk_abi_version", "bbduk_create", "bbduk_destroy", "bbduk_last
                "bbduk_upload_pairs", "bbduk_finalize_table", "bbduk_build_table_device", "bbduk_table_size", "bbduk_table_bytes",
                "bbduk_table_lookup", "bbduk_ktrim_batch", "bbduk_kfilter_batch", "bbduk_ktrim_batch_device",
                "bbduk_kfilter_batch_device", "bbduk_pack_bases_host", "bbduk_pack_bases_device", "bbduk_ktrim_batch_packed",
-               "bbduk_kfilter_batch_packed", "bbduk_ktrim_batch_packed_device", "bbduk_kfilter_batch_packed_device", "bbduk_kmask_batch", "bbduk_kmask_batch_device", "bbduk_ktrimtips_batch", "bbduk_ktrimtips_batch_device", "bbduk_ksplit_batch", "bbduk_ksplit_batch_device", "bbduk_kernel_time_ms", "bbduk_counters_len", "bbduk_get_counters", "bbduk_reset_counters",
+               "bbduk_kfilter_batch_packed", "bbduk_ktrim_batch_packed_device", "bbduk_kfilter_batch_packed_device", "bbduk_kmask_batch", "bbduk_kmask_batch_device", "bbduk_ktrimtips_batch", "bbduk_ktrimtips_batch_device", "bbduk_ksplit_batch", "bbduk_ksplit_batch_device", "bbduk_fastq_ingest_device", "bbduk_fastq_write_device", "bbduk_kernel_time_ms", "bbduk_counters_len", "bbduk_get_counters", "bbduk_reset_counters",
                "bbduk_synth_generate_device", "bbduk_synth_generate_host"]
 HOST_SYMBOLS = ["bbduk_host_parse", "bbduk_host_destroy", "bbduk_host_add_ref", "bbduk_host_load_fasta",
                 "bbduk_host_load_refs", "bbduk_host_build_index", "bbduk_host_index_pairs",
                 "bbduk_host_num_scaffolds", "bbduk_host_params", "bbduk_host_upload_index", "bbduk_host_build_on_device"]
 
 _lib = None
+
+
+class FastqResult(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("n_reads", "total_bases", "consumed1", "consumed2", "first_bad_read")]
+
+
+class FastqBatch:
+    """Device-resident result of fastq_ingest_device: torch tensors (HBM) + the host-side counts."""
+    pass
+
+
+def fastq_ingest_device(d_text1, d_text2=None, is_final=True, max_reads=None, device=0, stream_ptr=0):
+    """Raw FASTQ text in HBM (uint8 torch tensors, one or two files) -> FastqBatch with lines1/lines2 (int64 line offsets),
+    offsets (int64 base offsets), codes/undef (packed boundary format), n, total_bases, consumed (per text)."""
+    import torch
+    ns = 2 if d_text2 is not None else 1
+    nb1 = d_text1.numel(); nb2 = d_text2.numel() if ns == 2 else 0
+    if max_reads is None:
+        max_reads = (max(nb1, nb2) // 4 + 1) * ns          # a record has at least four bytes
+    cap_bases = (nb1 + nb2) // 2 + 32
+    kw = dict(device=d_text1.device)
+    fb = FastqBatch()
+    fb.lines1 = torch.empty(4 * (max_reads // ns) + 1, dtype=torch.int64, **kw)
+    fb.lines2 = torch.empty(4 * (max_reads // ns) + 1, dtype=torch.int64, **kw) if ns == 2 else None
+    fb.offsets = torch.empty(max_reads + 1, dtype=torch.int64, **kw)
+    fb.codes = torch.empty(cap_bases // 16 + 8, dtype=torch.int32, **kw)
+    fb.undef = torch.empty(cap_bases // 32 + 8, dtype=torch.int32, **kw)
+    res = FastqResult()
+    rc = lib().bbduk_fastq_ingest_device(d_text1.data_ptr(), nb1, d_text2.data_ptr() if ns == 2 else None, nb2, int(bool(is_final)),
+                                         max_reads, cap_bases, fb.lines1.data_ptr(), fb.lines2.data_ptr() if ns == 2 else None,
+                                         fb.offsets.data_ptr(), fb.codes.data_ptr(), fb.undef.data_ptr(), device, stream_ptr, C.byref(res))
+    fb.rc = rc; fb.n = res.n_reads; fb.total_bases = res.total_bases; fb.consumed = (res.consumed1, res.consumed2)
+    fb.first_bad_read = res.first_bad_read
+    if rc != 0:
+        raise BBDukError("bbduk_fastq_ingest_device rc=%d (first bad read %d)" % (rc, res.first_bad_read))
+    return fb
+
+
+def fastq_write_device(d_text1, fb, d_left, d_right, d_flags, want_removed, d_out, d_text2=None, device=0, stream_ptr=0):
+    """Selected reads of an ingested batch back to FASTQ text in d_out (uint8 torch tensor); returns the byte count."""
+    nbytes = C.c_int64(0)
+    p = lambda t: t.data_ptr() if t is not None else None
+    rc = lib().bbduk_fastq_write_device(p(d_text1), p(fb.lines1), p(d_text2), p(fb.lines2), fb.n, p(d_left), p(d_right), p(d_flags),
+                                        int(bool(want_removed)), p(d_out), d_out.numel(), device, stream_ptr, C.byref(nbytes))
+    if rc != 0:
+        raise BBDukError("bbduk_fastq_write_device rc=%d (needs %d bytes)" % (rc, nbytes.value))
+    return nbytes.value
 
 
 def pack_bases_host(bases):
@@ -121,6 +168,8 @@ def lib():
         f.argtypes = [vp, vp, vp, vp, i64, i32, vp, vp, vp]
     for f in (L.bbduk_ktrim_batch_packed_device, L.bbduk_kfilter_batch_packed_device):
         f.argtypes = [vp, vp, vp, vp, i64, i64, i32, vp, vp, vp, vp, vp]
+    L.bbduk_fastq_ingest_device.argtypes = [vp, i64, vp, i64, i32, i64, i64, vp, vp, vp, vp, vp, i32, vp, C.POINTER(FastqResult)]
+    L.bbduk_fastq_write_device.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i32, vp, i64, i32, vp, C.POINTER(i64)]
     L.bbduk_kernel_time_ms.argtypes = [vp, i32, C.POINTER(C.c_float)]
     L.bbduk_counters_len.argtypes = [vp]
     L.bbduk_get_counters.argtypes = [vp, vp, i32]

@@ -47,6 +47,7 @@ extern "C" {
 #define BBDUK_ERR_DEVICE        -4   /* a HIP call failed; see bbduk_last_error           */
 #define BBDUK_ERR_READ_TOO_LONG -5   /* a read exceeds BBDUK_MAX_READ_LEN                  */
 #define BBDUK_ERR_ID_OVERFLOW   -6   /* findBestMatch: a read hit more than 64 distinct scaffolds */
+#define BBDUK_ERR_FORMAT        -7   /* FASTQ ingest: a record without '@' / '+' or with unequal base and quality lines */
 
 #define BBDUK_MAX_READ_LEN   16384   /* per-read limit of the LDS-staged kernel (bases)     */
 
@@ -172,6 +173,36 @@ int  bbduk_kfilter_batch_packed_device(bbduk_handle* h, const uint32_t* d_codes,
                                        const int64_t* d_offsets, int64_t n, int64_t total_bases, int32_t paired,
                                        int32_t* d_out_found, int32_t* d_out_id, uint8_t* d_out_flags,
                                        int64_t* d_counters, void* stream);
+
+/* ---- device-side FASTQ ingest: raw FASTQ text in HBM -> line offsets, base offsets and the packed
+ * boundary format, without the host looking at a base.  Restates the record splitting of stream/FASTQ.java:778-853
+ * (toReadList: every four lines that fileIO/ByteFile.nextLine returns -- a line ends at '\n', one preceding '\r' is
+ * dropped -- are one read: '@' header, bases, '+' line, qualities; the '@' and '+' are asserted at :1047-1049).
+ *   d_text1 (, d_text2)  16-byte aligned text; with two texts read 2i comes from record i of text 1 and read 2i+1 from
+ *                        record i of text 2 (the two-file pairing of the reference's input stream); one interleaved text
+ *                        gives the same layout by itself
+ *   is_final             nonzero: an unterminated last line counts as a line (end of file); zero: the text is a chunk, the
+ *                        bytes behind out->consumed{1,2} (an incomplete record) are the caller's to resubmit
+ *   d_lines1/2           int64[4*(max_reads/texts)+1]: byte offset of every line of the records taken; line 4r is the
+ *                        header of record r, 4r+1 its bases, 4r+3 its qualities, lines[4*records] == consumed
+ *   d_offsets            int64[max_reads+1] base offsets; d_codes / d_undef as for bbduk_*_batch_packed_device
+ *                        (capacity max_bases bases; bases <= text bytes / 2 always holds)
+ * Synchronous on `stream`.  BBDUK_ERR_FORMAT: out->first_bad_read names the first malformed read. */
+typedef struct bbduk_fastq_result {
+    int64_t n_reads, total_bases, consumed1, consumed2, first_bad_read;
+} bbduk_fastq_result;
+int  bbduk_fastq_ingest_device(const uint8_t* d_text1, int64_t nbytes1, const uint8_t* d_text2, int64_t nbytes2, int32_t is_final,
+                               int64_t max_reads, int64_t max_bases, int64_t* d_lines1, int64_t* d_lines2,
+                               int64_t* d_offsets, uint32_t* d_codes, uint32_t* d_undef,
+                               int32_t device, void* stream, bbduk_fastq_result* out);
+
+/* The other end: the reads of an ingested batch back to FASTQ text (stream/FASTQ.java:474-490 toFASTQ: '@' id, bases, a
+ * bare '+', qualities), trimmed by d_left[i] / d_right[i] bases (TrimRead.trimByAmount with the operators' amounts; NULL =
+ * 0), in input order.  want_removed == 0 writes the reads without BBDUK_FLAG_REMOVED (out=), != 0 those with it (outm=).
+ * *out_bytes = text length; BBDUK_ERR_ARG if it exceeds cap_out (the input text length always suffices).  Synchronous. */
+int  bbduk_fastq_write_device(const uint8_t* d_text1, const int64_t* d_lines1, const uint8_t* d_text2, const int64_t* d_lines2,
+                              int64_t n, const int32_t* d_left, const int32_t* d_right, const uint8_t* d_flags, int32_t want_removed,
+                              uint8_t* d_out, int64_t cap_out, int32_t device, void* stream, int64_t* out_bytes);
 
 /* ---- ktrim=n (bbduk/BBDukProcessorS.java:2149-2323, kmaskFullyCovered=false).  out_masked[i] = kmask(Read)'s return
  * (BitSet.cardinality()), out_mask = one bit per base of the concatenated `bases` buffer (bit b of word b/32 set <=> the
