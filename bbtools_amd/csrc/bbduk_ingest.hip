@@ -35,6 +35,45 @@ __device__ __forceinline__ uint32_t eq_bytes(uint32_t x, uint32_t c4) {
     return ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);
 }
 
+// 16-byte values as two 64-bit halves; byte j of the value is byte j of the text
+struct U128 { uint64_t lo, hi; };
+__device__ __forceinline__ U128 shl_bytes(const U128 v, const int sft) {          // s in [0, 16]
+    if (sft == 0) return v;
+    if (sft >= 16) return U128{0, 0};
+    if (sft < 8) return U128{v.lo << (8 * sft), (v.hi << (8 * sft)) | (v.lo >> (64 - 8 * sft))};
+    return U128{0, v.lo << (8 * (sft - 8))};
+}
+__device__ __forceinline__ U128 low_bytes(const U128 v, const int c) {            // keep the c lowest bytes, c in [0, 16]
+    if (c >= 16) return v;
+    if (c > 8) return U128{v.lo, v.hi & (~0ULL >> (8 * (16 - c)))};
+    if (c == 8) return U128{v.lo, 0};
+    if (c == 0) return U128{0, 0};
+    return U128{v.lo & (~0ULL >> (8 * (8 - c))), 0};
+}
+// 16 bytes at t+src; bytes at or past `lim` (the end of the indexed text) read as 0 without being touched
+__device__ __forceinline__ U128 load16(const uint8_t* __restrict__ t, const int64_t src, const int64_t lim) {
+    U128 v;
+    if (src + 16 <= lim) { __builtin_memcpy(&v, t + src, 16); return v; }
+    v.lo = v.hi = 0;
+    for (int j = 0; j < 16 && src + j < lim; j++) { if (j < 8) v.lo |= (uint64_t)t[src + j] << (8 * j); else v.hi |= (uint64_t)t[src + j] << (8 * (j - 8)); }
+    return v;
+}
+// 16 ASCII bases -> 32 code bits + 16 undefined bits (dna/AminoAcid.java:1284-1298), SWAR
+__device__ __forceinline__ void encode16(const U128 v, uint32_t& code, uint32_t& und) {
+    const uint32_t x[4] = {(uint32_t)v.lo, (uint32_t)(v.lo >> 32), (uint32_t)v.hi, (uint32_t)(v.hi >> 32)};
+    code = 0; und = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t y = x[q] | 0x20202020u;
+        const uint32_t ok = (eq_bytes(y, 0x61616161u) | eq_bytes(y, 0x63636363u) | eq_bytes(y, 0x67676767u) | eq_bytes(y, 0x74747474u) | eq_bytes(y, 0x75757575u)) >> 7;
+        uint32_t z = (y >> 1) & 0x03030303u;          // a 0, c 1, g 3, t/u 2 ...
+        z ^= (z >> 1) & 0x01010101u;                  // ... -> a 0, c 1, g 2, t/u 3
+        z &= ok * 3u;
+        code |= ((z | (z >> 6) | (z >> 12) | (z >> 18)) & 0xFFu) << (8 * q);
+        und |= ((~(ok | (ok >> 7) | (ok >> 14) | (ok >> 21))) & 0xFu) << (4 * q);
+    }
+}
+
 // 64 bytes of text starting at byte `a` (a multiple of 16; the buffer is 16-byte aligned), zero past nbytes
 __device__ __forceinline__ void load64(const uint8_t* __restrict__ text, const int64_t a, const int64_t nbytes, uint32_t* w) {
 #pragma unroll
@@ -196,46 +235,82 @@ __device__ __forceinline__ int64_t read_of_base(const int64_t* __restrict__ offs
     }
     return lo;
 }
+// Which item (read / output record) owns position k*4096, for every k: one thread per item scatters its index to the
+// workgroup slots its span covers.  The consumers then start from two table reads instead of a search over all items
+// (a binary search over 10^8 offsets is ~27 dependent loads; one per workgroup at its start paced these kernels).
+constexpr int64_t FQ_UNIT = 16 * FQ_THREADS;                     // output positions per workgroup
+__global__ void block_first_kernel(const int64_t* __restrict__ offsets, const int64_t n, int64_t* __restrict__ first) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int64_t lo = offsets[r], hi = offsets[r + 1];
+    for (int64_t k = (lo + FQ_UNIT - 1) / FQ_UNIT; k * FQ_UNIT < hi; k++) first[k] = r;
+}
+// The offsets of the items a workgroup can touch, staged in LDS: s_off[j] = offsets[r0 + j], j = 0 .. r1-r0+1.
+// Returns false (nothing staged) when they do not fit; the caller then searches in HBM.
+constexpr int FQ_STAGE = 512;
+__device__ __forceinline__ bool stage_offsets(const int64_t* __restrict__ offsets, const int64_t* __restrict__ first, const int64_t nblk,
+                                              const int64_t n, int64_t& r0, int64_t& r1, int64_t* s_off) {
+    r0 = first[blockIdx.x];
+    r1 = ((int64_t)blockIdx.x + 1 < nblk) ? first[blockIdx.x + 1] : n - 1;
+    const bool fits = (r1 - r0 + 2) <= FQ_STAGE;
+    if (fits) for (int j = threadIdx.x; j < (int)(r1 - r0 + 2); j += FQ_THREADS) s_off[j] = offsets[r0 + j];
+    __syncthreads();
+    return fits;
+}
+__device__ __forceinline__ int lds_item_of(const int64_t* s_off, int hi, const int64_t b) {     // largest j in [0, hi] with s_off[j] <= b
+    int lo = 0;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_off[mid] <= b) lo = mid; else hi = mid - 1; }
+    return lo;
+}
 __global__ __launch_bounds__(FQ_THREADS)
 void fq_pack_kernel(const uint8_t* __restrict__ t1, const int64_t* __restrict__ l1, const uint8_t* __restrict__ t2, const int64_t* __restrict__ l2,
                     const int ns, const int64_t* __restrict__ offsets, const int64_t n, const int64_t total,
+                    const int64_t* __restrict__ first, const int64_t nblk, const int64_t* __restrict__ plim1, const int64_t* __restrict__ plim2,
                     uint32_t* __restrict__ codes, uint16_t* __restrict__ undef16) {
-    __shared__ int64_t s_range[2];
+    __shared__ int64_t s_off[FQ_STAGE];
+    const int64_t lim1 = *plim1 - 1, lim2 = plim2 ? *plim2 - 1 : 0;   // lines[4*records] - 1: the last indexed byte is a (possibly virtual) newline, never data
     const int64_t w0 = (int64_t)blockIdx.x * FQ_THREADS;
     const int64_t words = (total + 15) >> 4;
-    if (threadIdx.x == 0) {                           // the reads this workgroup's 4096 bases can belong to
-        s_range[0] = read_of_base(offsets, 0, n - 1, (16 * w0 < total - 1 ? 16 * w0 : total - 1));
-        s_range[1] = read_of_base(offsets, 0, n - 1, (16 * (w0 + FQ_THREADS) - 1 < total - 1 ? 16 * (w0 + FQ_THREADS) - 1 : total - 1));
-    }
-    __syncthreads();
+    int64_t r0, r1;
+    const bool staged = stage_offsets(offsets, first, nblk, n, r0, r1, s_off);    // the reads this workgroup's 4096 bases can belong to
     const int64_t w = w0 + threadIdx.x;
     if (w >= words) return;
     int64_t b = 16 * w;
-    int64_t r = read_of_base(offsets, s_range[0], s_range[1], b);
-    int64_t rEnd = offsets[r + 1];
+    int64_t r, rEnd, rBeg;
+    if (staged) { const int j = lds_item_of(s_off, (int)(r1 - r0), b); r = r0 + j; rBeg = s_off[j]; rEnd = s_off[j + 1]; }
+    else { r = read_of_base(offsets, r0, r1, b); rBeg = offsets[r]; rEnd = offsets[r + 1]; }
     auto src_of = [&](int64_t rd, const uint8_t*& t) -> int64_t {
         const bool second = (ns == 2) && (rd & 1);
         t = second ? t2 : t1;
         return (second ? l2 : l1)[4 * ((ns == 2) ? (rd >> 1) : rd) + 1];
     };
-    const uint8_t* t; int64_t src = src_of(r, t) + (b - offsets[r]);
-    uint32_t code = 0, und = 0;
-    for (int j = 0; j < 16; j++, b++) {
-        if (b >= total) { und |= 0xFFFFu << j; break; }
+    const uint8_t* t; int64_t src = src_of(r, t) + (b - rBeg);
+    // assemble the 16 bases run by run (a run = the part of one read inside this word; nearly always one or two runs),
+    // one unaligned 16-byte load per run, then one SWAR encode
+    U128 acc{0, 0};
+    int filled = 0;
+    const int want = (int)((total - b) < 16 ? (total - b) : 16);
+    while (filled < want) {
         while (b >= rEnd) { r++; rEnd = offsets[r + 1]; src = src_of(r, t); }     // empty reads are stepped over
-        const uint32_t ch = t[src++] | 0x20u;
-        const int c = ch == 'a' ? 0 : ch == 'c' ? 1 : ch == 'g' ? 2 : (ch == 't' || ch == 'u') ? 3 : -1;   // AminoAcid.java:1284-1298
-        if (c < 0) und |= 1u << j; else code |= (uint32_t)c << (2 * j);
+        const int c = (int)((rEnd - b) < (int64_t)(want - filled) ? (rEnd - b) : (int64_t)(want - filled));
+        const U128 v = low_bytes(load16(t, src, (t == t1) ? lim1 : lim2), c);
+        const U128 sh = shl_bytes(v, filled);
+        acc.lo |= sh.lo; acc.hi |= sh.hi;
+        filled += c; b += c; src += c;
     }
+    uint32_t code, und;
+    encode16(acc, code, und);
+    if (want < 16) und |= 0xFFFFu << want;                       // past the end of the batch
     codes[w] = code;
     undef16[w] = (uint16_t)und;
 }
 
 // ---- writer: trimmed records back to FASTQ text (stream/FASTQ.java:474-490 toFASTQ: '@' id, bases, a bare '+', qualities)
-// sizes[i] = bytes read i occupies in the output (0 if it is not selected)
+// Output layout of one selected read: header[hl] '\n' bases[nl] '\n' '+' '\n' qualities[nl] '\n'  = hl + 2*nl + 5 bytes.
+struct OutRec { int64_t h, s, q; int32_t hl, nl; };               // source offsets (trim applied) and lengths; 32 bytes
 __global__ void fq_out_sizes_kernel(const uint8_t* __restrict__ t1, const int64_t* __restrict__ l1, const uint8_t* __restrict__ t2, const int64_t* __restrict__ l2,
                                     const int ns, const int64_t n, const int32_t* __restrict__ left, const int32_t* __restrict__ right,
-                                    const uint8_t* __restrict__ flags, const int wantRemoved, int32_t* __restrict__ sizes) {
+                                    const uint8_t* __restrict__ flags, const int wantRemoved, int32_t* __restrict__ sizes, OutRec* __restrict__ recs) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const bool second = (ns == 2) && (i & 1);
@@ -244,39 +319,66 @@ __global__ void fq_out_sizes_kernel(const uint8_t* __restrict__ t1, const int64_
     const int64_t r = (ns == 2) ? (i >> 1) : i;
     const bool sel = (((flags ? flags[i] : 0) & BBDUK_FLAG_REMOVED) != 0) == (wantRemoved != 0);
     int sz = 0;
+    OutRec R; R.h = R.s = R.q = 0; R.hl = R.nl = 0;
     if (sel) {
-        const int hl = line_len(t, l[4 * r], l[4 * r + 1]);
-        const int L = line_len(t, l[4 * r + 1], l[4 * r + 2]);
+        const int64_t h = l[4 * r], sq = l[4 * r + 1];
+        const int L = line_len(t, sq, l[4 * r + 2]);
         const int a = left ? max(left[i], 0) : 0, b = right ? max(right[i], 0) : 0;
-        const int nl = max(L - a - b, 0);
-        sz = hl + 1 + nl + 3 + nl + 1;
+        R.hl = line_len(t, h, sq);
+        R.nl = max(L - a - b, 0);
+        R.h = h; R.s = sq + a; R.q = l[4 * r + 3] + a;
+        sz = R.hl + 2 * R.nl + 5;
     }
     sizes[i] = sz;
+    recs[i] = R;
 }
-// one wave per selected read: header line, bases[left, L-right), "+", qualities[left, L-right)
-__global__ __launch_bounds__(256)
-void fq_write_kernel(const uint8_t* __restrict__ t1, const int64_t* __restrict__ l1, const uint8_t* __restrict__ t2, const int64_t* __restrict__ l2,
-                     const int ns, const int64_t n, const int32_t* __restrict__ left, const int32_t* __restrict__ right,
-                     const int64_t* __restrict__ outOff, uint8_t* __restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wavesPerGrid = (int64_t)gridDim.x * (blockDim.x >> 6);
-    for (int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n; i += wavesPerGrid) {
-        const int64_t o0 = outOff[i], o1 = outOff[i + 1];
-        if (o1 == o0) continue;
-        const bool second = (ns == 2) && (i & 1);
-        const uint8_t* t = second ? t2 : t1;
-        const int64_t* l = second ? l2 : l1;
-        const int64_t r = (ns == 2) ? (i >> 1) : i;
-        const int64_t h = l[4 * r], s = l[4 * r + 1], q = l[4 * r + 3];
-        const int hl = line_len(t, h, s);
-        const int L = line_len(t, s, l[4 * r + 2]);
-        const int a = left ? max(left[i], 0) : 0, b = right ? max(right[i], 0) : 0;
-        const int nl = max(L - a - b, 0);
-        uint8_t* dst = out + o0;
-        for (int j = lane; j < hl; j += 64) dst[j] = t[h + j];
-        for (int j = lane; j < nl; j += 64) { dst[hl + 1 + j] = t[s + a + j]; dst[hl + 1 + nl + 3 + j] = t[q + a + j]; }
-        if (lane == 0) { dst[hl] = '\n'; dst[hl + 1 + nl] = '\n'; dst[hl + 1 + nl + 1] = '+'; dst[hl + 1 + nl + 2] = '\n'; dst[hl + 1 + nl + 3 + nl] = '\n'; }
+// one thread per 16 output bytes: locate the record, then either one unaligned 16-byte load (the chunk lies inside a header,
+// a bases or a qualities run) or sixteen single bytes (it crosses a seam); one aligned 16-byte store either way
+__global__ __launch_bounds__(FQ_THREADS)
+void fq_write_kernel(const uint8_t* __restrict__ t1, const uint8_t* __restrict__ t2, const int ns, const int64_t n,
+                     const OutRec* __restrict__ recs, const int64_t* __restrict__ outOff, const int64_t total,
+                     const int64_t* __restrict__ first, const int64_t nblk, const int64_t* __restrict__ plim1, const int64_t* __restrict__ plim2,
+                     uint8_t* __restrict__ out) {
+    __shared__ int64_t s_off[FQ_STAGE];
+    const int64_t lim1 = *plim1 - 1, lim2 = plim2 ? *plim2 - 1 : 0;
+    const int64_t c0 = (int64_t)blockIdx.x * FQ_THREADS;
+    int64_t r0, r1;
+    const bool staged = stage_offsets(outOff, first, nblk, n, r0, r1, s_off);
+    const int64_t p = 16 * (c0 + threadIdx.x);
+    if (p >= total) return;
+    int64_t i; int rel;
+    if (staged) { const int j = lds_item_of(s_off, (int)(r1 - r0), p); i = r0 + j; rel = (int)(p - s_off[j]); }
+    else { i = read_of_base(outOff, r0, r1, p); rel = (int)(p - outOff[i]); }
+    OutRec R = recs[i];
+    const uint8_t* t = ((ns == 2) && (i & 1)) ? t2 : t1;
+    // assemble the 16 output bytes run by run: header, '\n', bases, "\n+\n", qualities, '\n', next record ...
+    // (a chunk inside one run -- the common case -- is a single unaligned 16-byte load)
+    U128 acc{0, 0};
+    int filled = 0;
+    const int want = (int)((total - p) < 16 ? (total - p) : 16);
+    int size = R.hl + 2 * R.nl + 5;
+    while (filled < want) {
+        if (rel >= size) {                            // next selected record (unselected ones own no output byte)
+            rel -= size;
+            do { i++; R = recs[i]; } while (outOff[i + 1] == outOff[i]);
+            size = R.hl + 2 * R.nl + 5;
+            t = ((ns == 2) && (i & 1)) ? t2 : t1;
+        }
+        const int room = want - filled;
+        int c; U128 v;
+        const int64_t lim = (t == t1) ? lim1 : lim2;
+        if (rel < R.hl) { c = min(R.hl - rel, room); v = load16(t, R.h + rel, lim); }
+        else if (rel == R.hl) { c = 1; v = U128{0x0AULL, 0}; }
+        else if (rel < R.hl + 1 + R.nl) { const int x = rel - R.hl - 1; c = min(R.nl - x, room); v = load16(t, R.s + x, lim); }
+        else if (rel < R.hl + 4 + R.nl) { const int x = rel - (R.hl + 1 + R.nl); c = min(3 - x, room); v = U128{0x0A2B0AULL >> (8 * x), 0}; }
+        else if (rel < R.hl + 4 + 2 * R.nl) { const int x = rel - (R.hl + 4 + R.nl); c = min(R.nl - x, room); v = load16(t, R.q + x, lim); }
+        else { c = 1; v = U128{0x0AULL, 0}; }
+        const U128 sh = shl_bytes(low_bytes(v, c), filled);
+        acc.lo |= sh.lo; acc.hi |= sh.hi;
+        filled += c; rel += c;
     }
+    if (want == 16) { uint4 o = make_uint4((uint32_t)acc.lo, (uint32_t)(acc.lo >> 32), (uint32_t)acc.hi, (uint32_t)(acc.hi >> 32)); *reinterpret_cast<uint4*>(out + p) = o; }
+    else for (int j = 0; j < want; j++) out[p + j] = (uint8_t)((j < 8 ? acc.lo >> (8 * j) : acc.hi >> (8 * (j - 8))) & 0xFF);
 }
 
 }  // namespace
@@ -352,8 +454,15 @@ extern "C" int bbduk_fastq_ingest_device(const uint8_t* d_text1, int64_t nbytes1
     if (total > max_bases) { release(); return BBDUK_ERR_ARG; }
     if (total > 0) {
         const int64_t words = (total + 15) >> 4;
-        fq_pack_kernel<<<dim3((unsigned)((words + FQ_THREADS - 1) / FQ_THREADS)), dim3(FQ_THREADS), 0, st>>>(
-            d_text1, d_lines1, d_text2, d_lines2, ns, d_offsets, n, total, d_codes, reinterpret_cast<uint16_t*>(d_undef));
+        const int64_t nblk = (words + FQ_THREADS - 1) / FQ_THREADS;
+        int64_t* d_first = nullptr;
+        if (hipMalloc(&d_first, (size_t)(nblk + 1) * 8) != hipSuccess) { release(); return BBDUK_ERR_NOMEM; }
+        block_first_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(d_offsets, n, d_first);
+        fq_pack_kernel<<<dim3((unsigned)nblk), dim3(FQ_THREADS), 0, st>>>(
+            d_text1, d_lines1, d_text2, d_lines2, ns, d_offsets, n, total, d_first, nblk, d_lines1 + 4 * rec, ns == 2 ? d_lines2 + 4 * rec : nullptr,
+            d_codes, reinterpret_cast<uint16_t*>(d_undef));
+        hipStreamSynchronize(st);
+        hipFree(d_first);
         if ((words & 1) != 0) {                                   // the upper half of the last undefined word: past the end
             const uint16_t ones = 0xFFFFu;
             hipMemcpyAsync(reinterpret_cast<uint16_t*>(d_undef) + words, &ones, 2, hipMemcpyHostToDevice, st);
@@ -377,12 +486,13 @@ extern "C" int bbduk_fastq_write_device(const uint8_t* d_text1, const int64_t* d
     if (n == 0) return BBDUK_OK;
     if (hipSetDevice(device) != hipSuccess) return BBDUK_ERR_DEVICE;
     hipStream_t st = (hipStream_t)stream;
-    int32_t* d_sizes = nullptr; int64_t* d_sums = nullptr; int64_t* d_off = nullptr;
-    auto release = [&]() { hipFree(d_sizes); hipFree(d_sums); hipFree(d_off); };
+    if ((uintptr_t)d_out & 15) return BBDUK_ERR_ARG;
+    int32_t* d_sizes = nullptr; int64_t* d_sums = nullptr; int64_t* d_off = nullptr; OutRec* d_recs = nullptr;
+    auto release = [&]() { hipFree(d_sizes); hipFree(d_sums); hipFree(d_off); hipFree(d_recs); };
     const int64_t sb = (n + 1 + SC_BLOCK - 1) / SC_BLOCK;
     if (hipMalloc(&d_sizes, (size_t)(n + 1) * 4) != hipSuccess || hipMalloc(&d_sums, (size_t)(sb + 2) * 8) != hipSuccess ||
-        hipMalloc(&d_off, (size_t)(n + 1) * 8) != hipSuccess) { release(); return BBDUK_ERR_NOMEM; }
-    fq_out_sizes_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(d_text1, d_lines1, d_text2, d_lines2, ns, n, d_left, d_right, d_flags, want_removed, d_sizes);
+        hipMalloc(&d_off, (size_t)(n + 1) * 8) != hipSuccess || hipMalloc(&d_recs, (size_t)n * sizeof(OutRec)) != hipSuccess) { release(); return BBDUK_ERR_NOMEM; }
+    fq_out_sizes_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(d_text1, d_lines1, d_text2, d_lines2, ns, n, d_left, d_right, d_flags, want_removed, d_sizes, d_recs);
     block_sum_kernel<<<dim3((unsigned)sb), dim3(FQ_THREADS), 0, st>>>(d_sizes, n, d_sums);
     scan_sums_kernel<<<dim3(1), dim3(1024), 0, st>>>(d_sums, sb);
     scan_final_kernel<<<dim3((unsigned)sb), dim3(FQ_THREADS), 0, st>>>(d_sizes, n, d_sums, d_off);
@@ -391,8 +501,16 @@ extern "C" int bbduk_fastq_write_device(const uint8_t* d_text1, const int64_t* d
     *out_bytes = total;
     if (total > cap_out) { release(); return BBDUK_ERR_ARG; }
     if (total > 0) {
-        const int64_t blocks = std::min<int64_t>((n + 3) / 4, 1 << 20);
-        fq_write_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(d_text1, d_lines1, d_text2, d_lines2, ns, n, d_left, d_right, d_off, d_out);
+        const int64_t chunks = (total + 15) >> 4;
+        const int64_t nblk = (chunks + FQ_THREADS - 1) / FQ_THREADS;
+        int64_t* d_first = nullptr;
+        if (hipMalloc(&d_first, (size_t)(nblk + 1) * 8) != hipSuccess) { release(); return BBDUK_ERR_NOMEM; }
+        block_first_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(d_off, n, d_first);
+        const int64_t rec = n / ns;
+        fq_write_kernel<<<dim3((unsigned)nblk), dim3(FQ_THREADS), 0, st>>>(d_text1, d_text2, ns, n, d_recs, d_off, total, d_first, nblk,
+                                                                           d_lines1 + 4 * rec, ns == 2 ? d_lines2 + 4 * rec : nullptr, d_out);
+        hipStreamSynchronize(st);
+        hipFree(d_first);
     }
     const hipError_t e = hipStreamSynchronize(st);
     release();
