@@ -5,7 +5,11 @@
 // TrimRead.trimByAmount to bases+qualities with the returned amounts, route removed pairs, print the counters.
 //
 //   bbduk_cli in=r1.fq [in2=r2.fq | int=t] [out=clean.fq] [outm=removed.fq] [tsv=per_read.tsv] [resources=DIR]
-//             [batch=N] [device=D] [devicebuild=t] <BBDuk flags: ktrim= k= mink= hdist= ref= literal= ...>
+//             [batch=N] [device=D] [devicebuild=t] [deviceingest=t [chunk=BYTES]] <BBDuk flags: ktrim= k= mink= hdist= ref= literal= ...>
+//
+// deviceingest=t (ktrim=r|l, kfilter): the FASTQ text itself goes to the GPU in chunks; record splitting, 2-bit packing,
+// matching and the writing of the trimmed records all happen there (bbduk_fastq_ingest_device, bbduk_*_batch_packed_device,
+// bbduk_fastq_write_device); the host only moves bytes between the files and pinned buffers.
 //
 // tsv columns: name, length, result (ktrim: bases removed | kfilter: k-mer hits counted | ktrim=n: bases masked),
 // scaffold id or -1, length after trimming, flags (1 = read discarded, 2 = pair removed).  With ktrim=n / kmask= the
@@ -59,12 +63,124 @@ int fail(const char* what, const char* detail) { fprintf(stderr, "bbduk_cli: %s%
 
 bool parse_bool(const std::string& v) { return v.empty() || v == "t" || v == "true" || v == "1" || v == "T"; }
 
+struct TextIn {                      // one input file streamed through a pinned buffer; `have` bytes wait at the front
+    FILE* f = nullptr; bool piped = false, eof = false; uint8_t* h = nullptr; uint8_t* d = nullptr; int64_t have = 0; int64_t* d_lines = nullptr;
+    bool open(const std::string& path) {
+        if (path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0) { f = popen(("gzip -dc '" + path + "'").c_str(), "r"); piped = true; }
+        else f = fopen(path.c_str(), "rb");
+        return f != nullptr;
+    }
+    void fill(int64_t cap) { while (!eof && have < cap) { const size_t g = fread(h + have, 1, (size_t)(cap - have), f); if (g == 0) eof = true; have += (int64_t)g; } }
+    void close() { if (f) { if (piped) pclose(f); else fclose(f); f = nullptr; } }
+};
+
+// The deviceingest=t pipeline.  Returns 0 or an error exit status; prints the same closing lines as the host path.
+int run_device_ingest(bbduk_handle* dev, const bbduk_params& P, const std::string& in1, const std::string& in2, bool paired,
+                      const std::string& out, const std::string& outm, const std::string& tsv, int64_t chunk, int device) {
+    if (P.mode != BBDUK_MODE_KTRIM_R && P.mode != BBDUK_MODE_KTRIM_L && P.mode != BBDUK_MODE_KFILTER) return fail("deviceingest=t serves ktrim=r, ktrim=l and kfilter", nullptr);
+    const int ns = in2.empty() ? 1 : 2;
+    TextIn T[2];
+    if (!T[0].open(in1)) return fail("cannot open", in1.c_str());
+    if (ns == 2 && !T[1].open(in2)) return fail("cannot open", in2.c_str());
+    FILE* fout = out.empty() ? nullptr : fopen(out.c_str(), "wb");
+    FILE* foutm = outm.empty() ? nullptr : fopen(outm.c_str(), "wb");
+    FILE* ftsv = tsv.empty() ? nullptr : fopen(tsv.c_str(), "w");
+    if ((!out.empty() && !fout) || (!outm.empty() && !foutm) || (!tsv.empty() && !ftsv)) return fail("cannot open an output file", nullptr);
+    const int64_t maxRec = chunk / 40 + 16;                       // records taken per text and round; more just wait for the next round
+    const int64_t maxReads = maxRec * ns, capBases = (chunk * ns) / 2 + 64, capOut = chunk * ns + 64;
+    void* p = nullptr;
+    auto dmal = [&](int64_t bytes) -> void* { return bbduk_device_malloc(device, bytes, &p) == BBDUK_OK ? p : nullptr; };
+    auto pmal = [&](int64_t bytes) -> void* { return bbduk_pinned_malloc(bytes, &p) == BBDUK_OK ? p : nullptr; };
+    for (int s = 0; s < ns; s++) {
+        T[s].h = (uint8_t*)pmal(chunk + 16); T[s].d = (uint8_t*)dmal(chunk + 64); T[s].d_lines = (int64_t*)dmal((4 * maxRec + 1) * 8);
+        if (!T[s].h || !T[s].d || !T[s].d_lines) return fail("out of memory (chunk= too large?)", nullptr);
+    }
+    int64_t* d_off = (int64_t*)dmal((maxReads + 1) * 8); uint32_t* d_codes = (uint32_t*)dmal(capBases / 4 + 64); uint32_t* d_undef = (uint32_t*)dmal(capBases / 8 + 64);
+    int32_t* d_a = (int32_t*)dmal(maxReads * 4); int32_t* d_id = (int32_t*)dmal(maxReads * 4); uint8_t* d_fl = (uint8_t*)dmal(maxReads);
+    const int nctr = bbduk_counters_len(dev);
+    int64_t* d_ctr = (int64_t*)dmal((int64_t)nctr * 8);
+    uint8_t* d_out = (uint8_t*)dmal(capOut); uint8_t* h_out = (uint8_t*)pmal(capOut);
+    if (!d_off || !d_codes || !d_undef || !d_a || !d_id || !d_fl || !d_ctr || !d_out || !h_out) return fail("out of memory (chunk= too large?)", nullptr);
+    bbduk_device_memset(device, d_ctr, 0, (int64_t)nctr * 8, nullptr);
+    std::vector<int64_t> lines[2]; std::vector<int32_t> ra, rid; std::vector<uint8_t> rfl;
+    const bool kfilter = P.mode == BBDUK_MODE_KFILTER;
+    long long nread = 0;
+    for (;;) {
+        for (int s = 0; s < ns; s++) T[s].fill(chunk);
+        if (T[0].have == 0 && (ns == 1 || T[1].have == 0)) break;
+        const bool fin = T[0].eof && (ns == 1 || T[1].eof);
+        for (int s = 0; s < ns; s++) if (bbduk_copy_to_device(device, T[s].d, T[s].h, T[s].have, nullptr) != BBDUK_OK) return fail("host to device copy", nullptr);
+        bbduk_fastq_result R;
+        const int rc = bbduk_fastq_ingest_device(T[0].d, T[0].have, ns == 2 ? T[1].d : nullptr, ns == 2 ? T[1].have : 0, fin ? 1 : 0, maxReads, capBases,
+                                                 T[0].d_lines, ns == 2 ? T[1].d_lines : nullptr, d_off, d_codes, d_undef, device, nullptr, &R);
+        if (rc == BBDUK_ERR_FORMAT) { char m[64]; snprintf(m, sizeof m, "read %lld", nread + (long long)R.first_bad_read); return fail("malformed FASTQ record at", m); }
+        if (rc != BBDUK_OK) return fail("bbduk_fastq_ingest_device", nullptr);
+        int64_t n = R.n_reads;
+        if (paired && ns == 1 && (n & 1)) {                       // interleaved text: a pair stays together; its second record comes next round
+            if (fin) return fail("unpaired or malformed mate at the end of", in1.c_str());
+            n--;
+            if (bbduk_copy_from_device(device, &R.consumed1, T[0].d_lines + 4 * n, 8, nullptr) != BBDUK_OK) return fail("device to host copy", nullptr);
+        }
+        if (n == 0) {
+            if (fin) return fail("truncated FASTQ record at the end of", in1.c_str());
+            if (T[0].have >= chunk || (ns == 2 && T[1].have >= chunk)) return fail("a FASTQ record exceeds chunk=", nullptr);
+            if (ns == 2 && (T[0].eof != T[1].eof) && (T[0].have == 0 || T[1].have == 0)) return fail("the two input files hold different numbers of reads", nullptr);
+            continue;
+        }
+        const int64_t total = [&]() { int64_t v = 0; bbduk_copy_from_device(device, &v, d_off + n, 8, nullptr); return v; }();
+        const int orc = kfilter ? bbduk_kfilter_batch_packed_device(dev, d_codes, d_undef, d_off, n, total, paired ? 1 : 0, d_a, d_id, d_fl, d_ctr, nullptr)
+                                : bbduk_ktrim_batch_packed_device(dev, d_codes, d_undef, d_off, n, total, paired ? 1 : 0, d_a, d_id, d_fl, d_ctr, nullptr);
+        if (orc != BBDUK_OK) return fail("batch operator", bbduk_last_error(dev));
+        const int32_t* dl = P.mode == BBDUK_MODE_KTRIM_L ? d_a : nullptr; const int32_t* dr = P.mode == BBDUK_MODE_KTRIM_R ? d_a : nullptr;
+        for (int sel = 0; sel < 2; sel++) {
+            FILE* dst = sel ? foutm : fout;
+            if (!dst) continue;
+            int64_t nb = 0;
+            if (bbduk_fastq_write_device(T[0].d, T[0].d_lines, ns == 2 ? T[1].d : nullptr, ns == 2 ? T[1].d_lines : nullptr, n, dl, dr, d_fl, sel, d_out, capOut, device, nullptr, &nb) != BBDUK_OK)
+                return fail("bbduk_fastq_write_device", nullptr);
+            if (bbduk_copy_from_device(device, h_out, d_out, nb, nullptr) != BBDUK_OK) return fail("device to host copy", nullptr);
+            if (nb > 0 && fwrite(h_out, 1, (size_t)nb, dst) != (size_t)nb) return fail("write error", nullptr);
+        }
+        if (ftsv) {                                               // names and lengths come straight out of the text the host still holds
+            const int64_t rec = n / ns;
+            ra.resize(n); rid.resize(n); rfl.resize(n);
+            bbduk_copy_from_device(device, ra.data(), d_a, n * 4, nullptr); bbduk_copy_from_device(device, rid.data(), d_id, n * 4, nullptr);
+            bbduk_copy_from_device(device, rfl.data(), d_fl, n, nullptr);
+            for (int s = 0; s < ns; s++) { lines[s].resize(4 * rec + 1); bbduk_copy_from_device(device, lines[s].data(), T[s].d_lines, (4 * rec + 1) * 8, nullptr); }
+            for (int64_t i = 0; i < n; i++) {
+                const int s = ns == 2 ? (int)(i & 1) : 0; const int64_t r = ns == 2 ? (i >> 1) : i;
+                const uint8_t* t = T[s].h; const int64_t* l = lines[s].data();
+                auto len = [&](int64_t a, int64_t b) { int64_t m = b - a - 1; if (m > 0 && t[b - 2] == '\r') m--; return (int)m; };
+                const int hl = len(l[4 * r], l[4 * r + 1]), L = len(l[4 * r + 1], l[4 * r + 2]);
+                fprintf(ftsv, "%.*s\t%d\t%d\t%d\t%d\t%d\n", hl - 1, (const char*)t + l[4 * r] + 1, L, ra[i], rid[i], L - (kfilter ? 0 : ra[i]), (int)rfl[i]);
+            }
+        }
+        nread += n;
+        const int64_t used[2] = {R.consumed1, R.consumed2};
+        for (int s = 0; s < ns; s++) { memmove(T[s].h, T[s].h + used[s], (size_t)(T[s].have - used[s])); T[s].have -= used[s]; }
+    }
+    for (int s = 0; s < ns; s++) T[s].close();
+    if (fout) fclose(fout);
+    if (foutm) fclose(foutm);
+    if (ftsv) fclose(ftsv);
+    std::vector<int64_t> c((size_t)nctr);
+    bbduk_copy_from_device(device, c.data(), d_ctr, (int64_t)nctr * 8, nullptr);
+    fprintf(stderr, "Input:                  \t%lld reads \t\t%lld bases.\n", (long long)c[BBDUK_READS_IN], (long long)c[BBDUK_BASES_IN]);
+    if (!kfilter) fprintf(stderr, "KTrimmed:               \t%lld reads \t%lld bases\n", (long long)c[BBDUK_READS_KTRIMMED], (long long)c[BBDUK_BASES_KTRIMMED]);
+    else fprintf(stderr, "Contaminants:           \t%lld reads \t%lld bases\n", (long long)c[BBDUK_READS_KFILTERED], (long long)c[BBDUK_BASES_KFILTERED]);
+    fprintf(stderr, "Total Removed:          \t%lld reads \t%lld bases\n", (long long)(c[BBDUK_READS_IN] - c[BBDUK_READS_OUTU]), (long long)(c[BBDUK_BASES_IN] - c[BBDUK_BASES_OUTU]));
+    fprintf(stderr, "Result:                 \t%lld reads \t%lld bases\n", (long long)c[BBDUK_READS_OUTU], (long long)c[BBDUK_BASES_OUTU]);
+    if (c[BBDUK_CTR_STATUS]) return fail("device reported an error status", nullptr);
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
     std::string in1, in2, out, outm, tsv, resources = "data", flags;
     bool interleaved = false; long batch = 1000000; int device = 0;
     bool maskLower = false; char maskSymbol = 'N';
+    bool deviceIngest = false; long long chunk = 256LL << 20;     // deviceingest=t: FASTQ text to the GPU, chunk= bytes per file and round
     bool deviceBuild = false;        // devicebuild=t: the GPU builds the k-mer map from the reference sequences (bbduk_build_table_device)
     for (int i = 1; i < argc; i++) {
         const std::string tok = argv[i];
@@ -80,6 +196,8 @@ int main(int argc, char** argv) {
         else if (a == "batch") batch = atol(b.c_str());
         else if (a == "device") device = atoi(b.c_str());
         else if (a == "devicebuild") deviceBuild = parse_bool(b);
+        else if (a == "deviceingest") deviceIngest = parse_bool(b);
+        else if (a == "chunk") chunk = atoll(b.c_str());
         else {
             if (a == "ktrim" || a == "kmask" || a == "mask") {       // the replacement symbol is the caller's business (BBDukParser.java:619-644)
                 std::string v = b; for (auto& c : v) c = (char)tolower(c);
@@ -113,6 +231,12 @@ int main(int argc, char** argv) {
     } else if (bbduk_host_upload_index(host, dev) != BBDUK_OK) return fail("table upload", bbduk_last_error(dev));
     fprintf(stderr, "Added %lld kmers; %d scaffolds.\n", (long long)stored, bbduk_host_num_scaffolds(host) - 1);
 
+    if (deviceIngest) {
+        if (chunk < 4096) chunk = 4096;
+        const int rc = run_device_ingest(dev, P, in1, in2, paired, out, outm, tsv, (int64_t)chunk, device);
+        if (rc == 0) { bbduk_destroy(dev); bbduk_host_destroy(host); }
+        return rc;
+    }
     Reader r1, r2;
     if (!r1.open(in1)) return fail("cannot open", in1.c_str());
     if (!in2.empty() && !r2.open(in2)) return fail("cannot open", in2.c_str());

@@ -517,3 +517,42 @@ extern "C" int bbduk_fastq_write_device(const uint8_t* d_text1, const int64_t* d
     if (e != hipSuccess || hipGetLastError() != hipSuccess) return BBDUK_ERR_DEVICE;
     return BBDUK_OK;
 }
+
+// ---- memory helpers for callers without HIP bindings
+extern "C" int bbduk_device_malloc(int32_t device, int64_t bytes, void** out) {
+    if (!out || bytes < 0) return BBDUK_ERR_ARG;
+    *out = nullptr;
+    if (hipSetDevice(device) != hipSuccess) return BBDUK_ERR_DEVICE;
+    return hipMalloc(out, (size_t)std::max<int64_t>(bytes, 16)) == hipSuccess ? BBDUK_OK : BBDUK_ERR_NOMEM;
+}
+extern "C" int bbduk_device_free(int32_t device, void* p) {
+    if (hipSetDevice(device) != hipSuccess) return BBDUK_ERR_DEVICE;
+    return hipFree(p) == hipSuccess ? BBDUK_OK : BBDUK_ERR_DEVICE;
+}
+extern "C" int bbduk_pinned_malloc(int64_t bytes, void** out) {
+    if (!out || bytes < 0) return BBDUK_ERR_ARG;
+    *out = nullptr;
+    return hipHostMalloc(out, (size_t)std::max<int64_t>(bytes, 16), hipHostMallocDefault) == hipSuccess ? BBDUK_OK : BBDUK_ERR_NOMEM;
+}
+extern "C" int bbduk_pinned_free(void* p) { return hipHostFree(p) == hipSuccess ? BBDUK_OK : BBDUK_ERR_DEVICE; }
+extern "C" int bbduk_copy_to_device(int32_t device, void* d_dst, const void* src, int64_t bytes, void* stream) {
+    if (bytes < 0 || (bytes > 0 && (!d_dst || !src))) return BBDUK_ERR_ARG;
+    if (bytes == 0) return BBDUK_OK;
+    if (hipSetDevice(device) != hipSuccess) return BBDUK_ERR_DEVICE;
+    if (hipMemcpyAsync(d_dst, src, (size_t)bytes, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) return BBDUK_ERR_DEVICE;
+    return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? BBDUK_OK : BBDUK_ERR_DEVICE;
+}
+extern "C" int bbduk_copy_from_device(int32_t device, void* dst, const void* d_src, int64_t bytes, void* stream) {
+    if (bytes < 0 || (bytes > 0 && (!dst || !d_src))) return BBDUK_ERR_ARG;
+    if (bytes == 0) return BBDUK_OK;
+    if (hipSetDevice(device) != hipSuccess) return BBDUK_ERR_DEVICE;
+    if (hipMemcpyAsync(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return BBDUK_ERR_DEVICE;
+    return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? BBDUK_OK : BBDUK_ERR_DEVICE;
+}
+extern "C" int bbduk_device_memset(int32_t device, void* d_dst, int32_t value, int64_t bytes, void* stream) {
+    if (bytes < 0 || (bytes > 0 && !d_dst)) return BBDUK_ERR_ARG;
+    if (bytes == 0) return BBDUK_OK;
+    if (hipSetDevice(device) != hipSuccess) return BBDUK_ERR_DEVICE;
+    if (hipMemsetAsync(d_dst, value, (size_t)bytes, (hipStream_t)stream) != hipSuccess) return BBDUK_ERR_DEVICE;
+    return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? BBDUK_OK : BBDUK_ERR_DEVICE;
+}

@@ -174,6 +174,16 @@ int  bbduk_kfilter_batch_packed_device(bbduk_handle* h, const uint32_t* d_codes,
                                        int32_t* d_out_found, int32_t* d_out_id, uint8_t* d_out_flags,
                                        int64_t* d_counters, void* stream);
 
+/* ---- memory helpers for callers without HIP bindings (the JNI shim, bbduk_cli): thin wrappers over hipMalloc / hipFree,
+ * hipHostMalloc / hipHostFree (pinned staging) and hipMemcpyAsync + hipStreamSynchronize on the given stream (NULL = default). */
+int  bbduk_device_malloc(int32_t device, int64_t bytes, void** out);
+int  bbduk_device_free(int32_t device, void* p);
+int  bbduk_pinned_malloc(int64_t bytes, void** out);
+int  bbduk_pinned_free(void* p);
+int  bbduk_copy_to_device(int32_t device, void* d_dst, const void* src, int64_t bytes, void* stream);     /* returns after the copy */
+int  bbduk_copy_from_device(int32_t device, void* dst, const void* d_src, int64_t bytes, void* stream);
+int  bbduk_device_memset(int32_t device, void* d_dst, int32_t value, int64_t bytes, void* stream);
+
 /* ---- device-side FASTQ ingest: raw FASTQ text in HBM -> line offsets, base offsets and the packed
  * boundary format, without the host looking at a base.  Restates the record splitting of stream/FASTQ.java:778-853
  * (toReadList: every four lines that fileIO/ByteFile.nextLine returns -- a line ends at '\n', one preceding '\r' is

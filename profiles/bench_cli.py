@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""
+Secondary measurement: bbduk_cli wall clock on an interleaved FASTQ file in /tmp (configs[1] reads and flags), host parser
+path against deviceingest=t, with and without out=.  Whole process time (start-up, table build, file I/O on tmpfs/disk).
+One JSON line.
+"""
+import argparse, json, os, subprocess, sys, time
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "profiles"))
+
+
+def main():
+    ap = argparse.ArgumentParser(); ap.add_argument("--reads", type=int, default=4_000_000); ap.add_argument("--dir", default="/tmp")
+    a = ap.parse_args()
+    from bbtools_amd import bbduk as B, _build
+    from bench_ingest import fastq_text
+    text, _, _ = fastq_text(B, a.reads // 2)
+    path = os.path.join(a.dir, "bench_cli_in.fq"); outp = os.path.join(a.dir, "bench_cli_out.fq")
+    text.tofile(path)
+    flags = ["ktrim=r", "k=23", "mink=11", "hdist=1", "ref=adapters", "int=t", "devicebuild=t", "resources=" + os.path.join(ROOT, "data")]
+    res = {}
+    for name, extra in (("host_parse", []), ("host_parse_out", ["out=" + outp]), ("deviceingest", ["deviceingest=t"]), ("deviceingest_out", ["deviceingest=t", "out=" + outp])):
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            r = subprocess.run([_build.cli_path(), "in=" + path] + flags + extra, capture_output=True, text=True)
+            dt = time.perf_counter() - t0
+            assert r.returncode == 0, r.stderr
+            best = dt if best is None else min(best, dt)
+        res[name] = {"s": round(best, 3), "Gbases_per_s": round(a.reads * 150 / best / 1e9, 3)}
+        if "out" in name:
+            res[name]["out_bytes"] = os.path.getsize(outp)
+    os.remove(path)
+    if os.path.exists(outp):
+        os.remove(outp)
+    print(json.dumps({"workload": "bbduk_cli, interleaved FASTQ file of %d reads x 150 bp (%.2f GB) in %s, ktrim=r k=23 mink=11 hdist=1 ref=adapters"
+                                  % (a.reads, len(text) / 1e9, a.dir), "wall": res}))
+
+
+if __name__ == "__main__":
+    main()

@@ -93,3 +93,46 @@ def test_cli_ksplit_trims_or_splits_like_the_spec(tmp_path):
     assert open(outm).read() == open(os.path.join(GOLD, "cli_ksplit_expected_outm.fq")).read()
     r = run_cli(["in=" + os.path.join(GOLD, "cli_c2_r1.fq"), "in2=" + os.path.join(GOLD, "cli_c2_r2.fq"), "ksplit=t", "k=23", "ref=adapters"])
     assert r.returncode == 1 and "unpaired" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", ["4096", "20000", "268435456"])
+def test_cli_deviceingest_equals_the_host_path(tmp_path, chunk):
+    """deviceingest=t: FASTQ text -> GPU (record splitting, packing, matching, writing).  Same TSV as the spec, same out= /
+    outm= bytes as the host-parser path, also when records straddle chunk borders."""
+    f1, f2 = os.path.join(GOLD, "cli_c2_r1.fq"), os.path.join(GOLD, "cli_c2_r2.fq")
+    flags = ["ktrim=r", "k=23", "mink=11", "hdist=1", "ref=adapters"]
+    base = {}
+    for mode in ("host", "dev"):
+        tsv, out, outm = (str(tmp_path / (mode + n)) for n in ("o.tsv", "clean.fq", "removed.fq"))
+        extra = ["deviceingest=t", "chunk=" + chunk] if mode == "dev" else []
+        r = run_cli(["in=" + f1, "in2=" + f2, "tsv=" + tsv, "out=" + out, "outm=" + outm] + flags + extra)
+        assert r.returncode == 0, r.stderr
+        base[mode] = (open(tsv).read(), open(out, "rb").read(), open(outm, "rb").read(), [l for l in r.stderr.splitlines() if "reads" in l])
+    assert base["dev"] == base["host"]
+    assert base["dev"][0] == open(os.path.join(GOLD, "cli_c2.tsv")).read()
+    # interleaved kfilter, ktrim=l, k=40 through the same pipeline
+    tsv = str(tmp_path / "c3.tsv")
+    r = run_cli(["in=" + os.path.join(GOLD, "cli_c3_interleaved.fq"), "int=t", "tsv=" + tsv, "k=31", "hdist=1", "ref=phix", "deviceingest=t", "chunk=" + chunk])
+    assert r.returncode == 0, r.stderr
+    assert open(tsv).read() == open(os.path.join(GOLD, "cli_c3.tsv")).read()
+    r = run_cli(["in=" + os.path.join(GOLD, "cli_c3_interleaved.fq"), "int=t", "tsv=" + tsv, "k=40", "hdist=1", "ref=phix", "deviceingest=t", "chunk=" + chunk])
+    assert r.returncode == 0 and open(tsv).read() == open(os.path.join(GOLD, "cli_c3_k40.tsv")).read()
+    outs = {}
+    for mode in ("host", "dev"):
+        out = str(tmp_path / (mode + "_l.fq"))
+        r = run_cli(["in=" + f1, "out=" + out, "ktrim=l", "k=23", "mink=11", "ref=adapters"] + (["deviceingest=t", "chunk=" + chunk] if mode == "dev" else []))
+        assert r.returncode == 0, r.stderr
+        outs[mode] = open(out, "rb").read()
+    assert outs["dev"] == outs["host"] and len(outs["dev"]) > 1000
+
+
+@pytest.mark.gpu
+def test_cli_deviceingest_rejects_what_it_cannot_serve(tmp_path):
+    f1 = os.path.join(GOLD, "cli_c2_r1.fq")
+    r = run_cli(["in=" + f1, "ktrim=n", "k=23", "ref=adapters", "deviceingest=t"])
+    assert r.returncode == 1 and "deviceingest" in r.stderr
+    bad = tmp_path / "bad.fq"
+    bad.write_text("@a\nACGT\n+\nIIII\n@b\nACGT\nIIII\n+\n")
+    r = run_cli(["in=" + str(bad), "k=23", "ref=adapters", "deviceingest=t"])
+    assert r.returncode == 1 and "malformed FASTQ record" in r.stderr
