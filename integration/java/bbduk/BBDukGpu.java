@@ -10,7 +10,7 @@ import shared.Shared;
  * Usage from BBDukProcessorS.processList (split into pass A / device call / pass B, SURVEY.md section 8b):
  *   long h = BBDukGpu.create(parser, index.scaffoldNames.size(), deviceOrdinal);
  *   for each way w: BBDukGpu.uploadWay(h, w, table.prime(), table.array(), table.values(), victimKeys, victimVals);
- *   BBDukGpu.finalizeTable(h);
+ *   BBDukGpu.finalizeTable(h);            // or BBDukGpu.buildTable(h, refBases, refOffsets, hdist, hdist2)
  *   ... per >=1e5 reads: concatenate r.bases into one byte[] + long[] offsets, mates adjacent ...
  *   BBDukGpu.ktrimBatch(h, bases, offsets, n, paired, outTrimmed, outId0, outFlags);
  *   ... TrimRead.trimByAmount(r, 0, outTrimmed[i], 1) for ktrim=r; discard/remove from outFlags[i] ...
@@ -22,28 +22,44 @@ public final class BBDukGpu {
 	}
 
 	/** ip = {mode,k,mink,rcomp,forbidNs,minlen,minlen2,qhdist,qhdist2,maxBadKmers,minReadLength,
-	 *  removePairsIfEitherBad,trimPad,ktrimExclusive,restrictLeft,restrictRight,skipR1,skipR2,numScaffolds,device} */
-	private static native long createJNI(int[] ip, long middleMask, float minLenFraction);
+	 *  removePairsIfEitherBad,trimPad,ktrimExclusive,restrictLeft,restrictRight,skipR1,skipR2,numScaffolds,device,
+	 *  trimPairsEvenly,qSkip,speed,kbig,findBestMatch};  fp = {minLenFraction,minKmerFraction,minCoveredFraction} */
+	private static native long createJNI(int[] ip, long middleMask, float[] fp);
 	private static native int uploadWayJNI(long h, int way, int prime, long[] keys, int[] values, long[] vkeys, int[] vvals);
 	private static native int uploadPairsJNI(long h, long[] keys, int[] values);
 	private static native int finalizeJNI(long h);
+	private static native int buildTableJNI(long h, byte[] refs, long[] refOffsets, int nRefs, int hdist, int hdist2);
 	private static native int ktrimBatchJNI(long h, byte[] bases, long[] offsets, int n, boolean paired,
 			int[] outTrimmed, int[] outId0, byte[] outFlags);
 	private static native int kfilterBatchJNI(long h, byte[] bases, long[] offsets, int n, boolean paired,
 			int[] outFound, int[] outId, byte[] outFlags);
+	private static native int ktrimBatchPackedJNI(long h, int[] codes, int[] undef, long[] offsets, int n, boolean paired,
+			int[] outTrimmed, int[] outId0, byte[] outFlags);
+	private static native int kfilterBatchPackedJNI(long h, int[] codes, int[] undef, long[] offsets, int n, boolean paired,
+			int[] outFound, int[] outId, byte[] outFlags);
+	private static native int kmaskBatchJNI(long h, byte[] bases, long[] offsets, int n, boolean paired,
+			int[] outMasked, int[] outId0, byte[] outFlags, int[] outMask);
+	private static native int ktrimTipsBatchJNI(long h, byte[] bases, long[] offsets, int n, boolean paired,
+			int[] outRight, int[] outLeft, int[] outId0, byte[] outFlags);
+	private static native int ksplitBatchJNI(long h, byte[] bases, long[] offsets, int n,
+			int[] outTrimmed, int[] outLeftmost, int[] outRightmost, int[] outId0, byte[] outFlags);
 	private static native int countersJNI(long h, long[] out);
 	private static native void destroyJNI(long h);
 
-	public static final int MODE_KFILTER=0, MODE_KTRIM_R=1, MODE_KTRIM_L=2;
+	public static final int MODE_KFILTER=0, MODE_KTRIM_R=1, MODE_KTRIM_L=2, MODE_KMASK=3, MODE_KTRIM_TIPS=4, MODE_KSPLIT=5;
 	public static final int FLAG_DISCARDED=1, FLAG_REMOVED=2;
 
+	/** Copies BBDukParser's fields as they stand AFTER its own derivations (BBDukParser.java:130-312). */
 	public static long create(BBDukParser p, int numScaffolds, int device){
-		final int mode=(p.ktrimRight ? MODE_KTRIM_R : p.ktrimLeft ? MODE_KTRIM_L : MODE_KFILTER);
+		final int mode=(p.ksplit ? MODE_KSPLIT : (p.ktrimRight && p.ktrimLeft) ? MODE_KTRIM_TIPS : p.ktrimRight ? MODE_KTRIM_R :
+			p.ktrimLeft ? MODE_KTRIM_L : p.ktrimN ? MODE_KMASK : MODE_KFILTER);
 		final int[] ip={mode, p.k, p.mink, p.rcomp ? 1 : 0, p.forbidNs ? 1 : 0, p.minlen, p.minlen2,
 				p.qHammingDistance, p.qHammingDistance2, p.maxBadKmers0, p.minReadLength,
 				p.removePairsIfEitherBad ? 1 : 0, p.trimPad, p.ktrimExclusive ? 1 : 0,
-				p.restrictLeft, p.restrictRight, p.skipR1 ? 1 : 0, p.skipR2 ? 1 : 0, numScaffolds, device};
-		final long h=createJNI(ip, p.middleMask, p.minLenFraction);
+				p.restrictLeft, p.restrictRight, p.skipR1 ? 1 : 0, p.skipR2 ? 1 : 0, numScaffolds, device,
+				p.trimPairsEvenly ? 1 : 0, p.qSkip, p.speed, (p.kbig>p.k ? p.kbig : 0), (p.findBestMatch && mode==MODE_KFILTER) ? 1 : 0};
+		final float[] fp={p.minLenFraction, p.minKmerFraction, p.minCoveredFraction};
+		final long h=createJNI(ip, p.middleMask, fp);
 		if(h<=0){throw new RuntimeException("bbduk_create failed: "+h);}
 		return h;
 	}
@@ -52,11 +68,33 @@ public final class BBDukGpu {
 	}
 	public static void uploadPairs(long h, long[] keys, int[] values){check(uploadPairsJNI(h, keys, values), "bbduk_upload_pairs");}
 	public static void finalizeTable(long h){check(finalizeJNI(h), "bbduk_finalize_table");}
+	/** The GPU builds the map itself from the scaffolds' bases (hdist <= 2, no edist) instead of receiving the finished tables. */
+	public static void buildTable(long h, byte[] refs, long[] refOffsets, int nRefs, int hdist, int hdist2){
+		check(buildTableJNI(h, refs, refOffsets, nRefs, hdist, hdist2), "bbduk_build_table_device");
+	}
 	public static void ktrimBatch(long h, byte[] bases, long[] offsets, int n, boolean paired, int[] outTrimmed, int[] outId0, byte[] outFlags){
 		check(ktrimBatchJNI(h, bases, offsets, n, paired, outTrimmed, outId0, outFlags), "bbduk_ktrim_batch");
 	}
+	/** Also serves k>31 (countSetKmersBig) and findBestMatch when the parser set kbig / findBestMatch. */
 	public static void kfilterBatch(long h, byte[] bases, long[] offsets, int n, boolean paired, int[] outFound, int[] outId, byte[] outFlags){
 		check(kfilterBatchJNI(h, bases, offsets, n, paired, outFound, outId, outFlags), "bbduk_kfilter_batch");
+	}
+	/** codes: 2 bits per base, 16 per int; undef: 1 bit per base (baseToNumber<0); offsets still count bases. */
+	public static void ktrimBatchPacked(long h, int[] codes, int[] undef, long[] offsets, int n, boolean paired, int[] outTrimmed, int[] outId0, byte[] outFlags){
+		check(ktrimBatchPackedJNI(h, codes, undef, offsets, n, paired, outTrimmed, outId0, outFlags), "bbduk_ktrim_batch_packed");
+	}
+	public static void kfilterBatchPacked(long h, int[] codes, int[] undef, long[] offsets, int n, boolean paired, int[] outFound, int[] outId, byte[] outFlags){
+		check(kfilterBatchPackedJNI(h, codes, undef, offsets, n, paired, outFound, outId, outFlags), "bbduk_kfilter_batch_packed");
+	}
+	/** outMask: one bit per base of the concatenated batch, (offsets[n]+31)/32+1 ints; the caller runs :2309-2320 over it. */
+	public static void kmaskBatch(long h, byte[] bases, long[] offsets, int n, boolean paired, int[] outMasked, int[] outId0, byte[] outFlags, int[] outMask){
+		check(kmaskBatchJNI(h, bases, offsets, n, paired, outMasked, outId0, outFlags, outMask), "bbduk_kmask_batch");
+	}
+	public static void ktrimTipsBatch(long h, byte[] bases, long[] offsets, int n, boolean paired, int[] outRight, int[] outLeft, int[] outId0, byte[] outFlags){
+		check(ktrimTipsBatchJNI(h, bases, offsets, n, paired, outRight, outLeft, outId0, outFlags), "bbduk_ktrimtips_batch");
+	}
+	public static void ksplitBatch(long h, byte[] bases, long[] offsets, int n, int[] outTrimmed, int[] outLeftmost, int[] outRightmost, int[] outId0, byte[] outFlags){
+		check(ksplitBatchJNI(h, bases, offsets, n, outTrimmed, outLeftmost, outRightmost, outId0, outFlags), "bbduk_ksplit_batch");
 	}
 	public static void counters(long h, long[] out){check(countersJNI(h, out), "bbduk_get_counters");}
 	public static void destroy(long h){destroyJNI(h);}

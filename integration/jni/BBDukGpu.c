@@ -11,18 +11,27 @@
 #include <string.h>
 #include "bbduk_gpu.h"
 
-JNIEXPORT jlong JNICALL Java_bbduk_BBDukGpu_createJNI(JNIEnv* env, jclass cls, jintArray ip, jlong middleMask, jfloat minLenFraction) {
-    if ((*env)->GetArrayLength(env, ip) < 20) return BBDUK_ERR_ARG;
-    jint* v = (jint*)(*env)->GetPrimitiveArrayCritical(env, ip, NULL);
+#define H(h) ((bbduk_handle*)(intptr_t)(h))
+#define PIN(a) ((a) ? (*env)->GetPrimitiveArrayCritical(env, (a), NULL) : NULL)
+#define UNPIN_IN(a, p)  do { if (a) (*env)->ReleasePrimitiveArrayCritical(env, (a), (p), JNI_ABORT); } while (0)   /* inputs: no copy-back */
+#define UNPIN_OUT(a, p) do { if (a) (*env)->ReleasePrimitiveArrayCritical(env, (a), (p), 0); } while (0)           /* outputs: copy back   */
+
+JNIEXPORT jlong JNICALL Java_bbduk_BBDukGpu_createJNI(JNIEnv* env, jclass cls, jintArray ip, jlong middleMask, jfloatArray fp) {
+    if ((*env)->GetArrayLength(env, ip) < 25 || (*env)->GetArrayLength(env, fp) < 3) return BBDUK_ERR_ARG;
+    jint* v = (jint*)PIN(ip);
+    jfloat* f = (jfloat*)PIN(fp);
     bbduk_params p;
     memset(&p, 0, sizeof p);
     p.abi_version = BBDUK_ABI_VERSION;
     p.mode = v[0]; p.k = v[1]; p.mink = v[2]; p.rcomp = v[3]; p.forbidNs = v[4]; p.minlen = v[5]; p.minlen2 = v[6];
     p.middleMask = (int64_t)middleMask;
-    p.qhdist = v[7]; p.qhdist2 = v[8]; p.maxBadKmers = v[9]; p.minReadLength = v[10]; p.minLenFraction = minLenFraction;
+    p.qhdist = v[7]; p.qhdist2 = v[8]; p.maxBadKmers = v[9]; p.minReadLength = v[10];
     p.removePairsIfEitherBad = v[11]; p.trimPad = v[12]; p.ktrimExclusive = v[13];
     p.restrictLeft = v[14]; p.restrictRight = v[15]; p.skipR1 = v[16]; p.skipR2 = v[17]; p.numScaffolds = v[18]; p.device = v[19];
-    (*env)->ReleasePrimitiveArrayCritical(env, ip, v, JNI_ABORT);
+    p.trimPairsEvenly = v[20]; p.qSkip = v[21]; p.speed = v[22]; p.kbig = v[23]; p.findBestMatch = v[24];
+    p.minLenFraction = f[0]; p.minKmerFraction = f[1]; p.minCoveredFraction = f[2];
+    UNPIN_IN(fp, f);
+    UNPIN_IN(ip, v);
     bbduk_handle* h = NULL;
     const int rc = bbduk_create(&p, &h);
     return rc == BBDUK_OK ? (jlong)(intptr_t)h : (jlong)rc;
@@ -32,51 +41,56 @@ JNIEXPORT jint JNICALL Java_bbduk_BBDukGpu_uploadWayJNI(JNIEnv* env, jclass cls,
         jlongArray keys, jintArray values, jlongArray vkeys, jintArray vvals) {
     const jint nc = (*env)->GetArrayLength(env, keys);
     const jint nv = vkeys ? (*env)->GetArrayLength(env, vkeys) : 0;
-    jlong* k = (jlong*)(*env)->GetPrimitiveArrayCritical(env, keys, NULL);
-    jint*  v = (jint*)(*env)->GetPrimitiveArrayCritical(env, values, NULL);
-    jlong* vk = nv ? (jlong*)(*env)->GetPrimitiveArrayCritical(env, vkeys, NULL) : NULL;
-    jint*  vv = nv ? (jint*)(*env)->GetPrimitiveArrayCritical(env, vvals, NULL) : NULL;
-    const jint rc = bbduk_upload_table_way((bbduk_handle*)(intptr_t)h, way, prime, (const int64_t*)k, (const int32_t*)v, nc,
-                                           (const int64_t*)vk, (const int32_t*)vv, nv);
-    if (nv) { (*env)->ReleasePrimitiveArrayCritical(env, vvals, vv, JNI_ABORT); (*env)->ReleasePrimitiveArrayCritical(env, vkeys, vk, JNI_ABORT); }
-    (*env)->ReleasePrimitiveArrayCritical(env, values, v, JNI_ABORT);
-    (*env)->ReleasePrimitiveArrayCritical(env, keys, k, JNI_ABORT);
+    jlong* k = (jlong*)PIN(keys);
+    jint*  v = (jint*)PIN(values);
+    jlong* vk = nv ? (jlong*)PIN(vkeys) : NULL;
+    jint*  vv = nv ? (jint*)PIN(vvals) : NULL;
+    const jint rc = bbduk_upload_table_way(H(h), way, prime, (const int64_t*)k, (const int32_t*)v, nc, (const int64_t*)vk, (const int32_t*)vv, nv);
+    if (nv) { UNPIN_IN(vvals, vv); UNPIN_IN(vkeys, vk); }
+    UNPIN_IN(values, v);
+    UNPIN_IN(keys, k);
     return rc;
 }
 
 JNIEXPORT jint JNICALL Java_bbduk_BBDukGpu_uploadPairsJNI(JNIEnv* env, jclass cls, jlong h, jlongArray keys, jintArray values) {
     const jint n = (*env)->GetArrayLength(env, keys);
-    jlong* k = (jlong*)(*env)->GetPrimitiveArrayCritical(env, keys, NULL);
-    jint*  v = (jint*)(*env)->GetPrimitiveArrayCritical(env, values, NULL);
-    const jint rc = bbduk_upload_pairs((bbduk_handle*)(intptr_t)h, (const int64_t*)k, (const int32_t*)v, n);
-    (*env)->ReleasePrimitiveArrayCritical(env, values, v, JNI_ABORT);
-    (*env)->ReleasePrimitiveArrayCritical(env, keys, k, JNI_ABORT);
+    jlong* k = (jlong*)PIN(keys);
+    jint*  v = (jint*)PIN(values);
+    const jint rc = bbduk_upload_pairs(H(h), (const int64_t*)k, (const int32_t*)v, n);
+    UNPIN_IN(values, v);
+    UNPIN_IN(keys, k);
     return rc;
 }
 
-JNIEXPORT jint JNICALL Java_bbduk_BBDukGpu_finalizeJNI(JNIEnv* env, jclass cls, jlong h) {
-    return bbduk_finalize_table((bbduk_handle*)(intptr_t)h);
+JNIEXPORT jint JNICALL Java_bbduk_BBDukGpu_finalizeJNI(JNIEnv* env, jclass cls, jlong h) { return bbduk_finalize_table(H(h)); }
+
+JNIEXPORT jint JNICALL Java_bbduk_BBDukGpu_buildTableJNI(JNIEnv* env, jclass cls, jlong h, jbyteArray refs, jlongArray refOffsets,
+        jint nRefs, jint hdist, jint hdist2) {
+    jbyte* r = (jbyte*)PIN(refs);
+    jlong* o = (jlong*)PIN(refOffsets);
+    const jint rc = bbduk_build_table_device(H(h), (const uint8_t*)r, (const int64_t*)o, nRefs, hdist, hdist2);
+    UNPIN_IN(refOffsets, o);
+    UNPIN_IN(refs, r);
+    return rc;
+}
+
+/* every batch operator: two or three input arrays, three to five output arrays */
+typedef struct { jarray a; void* p; } pinned;
+static void pin_all(JNIEnv* env, pinned* x, int n) { for (int i = 0; i < n; i++) x[i].p = PIN(x[i].a); }
+static void unpin_all(JNIEnv* env, pinned* x, int n, int first_out) {
+    for (int i = n - 1; i >= 0; i--) { if (i >= first_out) UNPIN_OUT(x[i].a, x[i].p); else UNPIN_IN(x[i].a, x[i].p); }
 }
 
 static jint batch(JNIEnv* env, jlong h, int kfilter, jbyteArray bases, jlongArray offsets, jint n, jboolean paired,
                   jintArray outA, jintArray outId, jbyteArray outFlags) {
-    jbyte* jb = (jbyte*)(*env)->GetPrimitiveArrayCritical(env, bases, NULL);
-    jlong* jo = (jlong*)(*env)->GetPrimitiveArrayCritical(env, offsets, NULL);
-    jint*  ja = (jint*)(*env)->GetPrimitiveArrayCritical(env, outA, NULL);
-    jint*  ji = (jint*)(*env)->GetPrimitiveArrayCritical(env, outId, NULL);
-    jbyte* jf = (jbyte*)(*env)->GetPrimitiveArrayCritical(env, outFlags, NULL);
-    bbduk_handle* hh = (bbduk_handle*)(intptr_t)h;
+    pinned x[5] = {{bases, 0}, {offsets, 0}, {outA, 0}, {outId, 0}, {outFlags, 0}};
+    pin_all(env, x, 5);
     const jint rc = kfilter
-        ? bbduk_kfilter_batch(hh, (const uint8_t*)jb, (const int64_t*)jo, n, paired, (int32_t*)ja, (int32_t*)ji, (uint8_t*)jf)
-        : bbduk_ktrim_batch(hh, (const uint8_t*)jb, (const int64_t*)jo, n, paired, (int32_t*)ja, (int32_t*)ji, (uint8_t*)jf);
-    (*env)->ReleasePrimitiveArrayCritical(env, outFlags, jf, 0);          /* outputs: copy back   */
-    (*env)->ReleasePrimitiveArrayCritical(env, outId, ji, 0);
-    (*env)->ReleasePrimitiveArrayCritical(env, outA, ja, 0);
-    (*env)->ReleasePrimitiveArrayCritical(env, offsets, jo, JNI_ABORT);   /* inputs: no copy-back */
-    (*env)->ReleasePrimitiveArrayCritical(env, bases, jb, JNI_ABORT);
+        ? bbduk_kfilter_batch(H(h), (const uint8_t*)x[0].p, (const int64_t*)x[1].p, n, paired, (int32_t*)x[2].p, (int32_t*)x[3].p, (uint8_t*)x[4].p)
+        : bbduk_ktrim_batch(H(h), (const uint8_t*)x[0].p, (const int64_t*)x[1].p, n, paired, (int32_t*)x[2].p, (int32_t*)x[3].p, (uint8_t*)x[4].p);
+    unpin_all(env, x, 5, 2);
     return rc;
 }
-
 JNIEXPORT jint JNICALL Java_bbduk_BBDukGpu_ktrimBatchJNI(JNIEnv* env, jclass cls, jlong h, jbyteArray bases, jlongArray offsets,
         jint n, jboolean paired, jintArray outTrimmed, jintArray outId0, jbyteArray outFlags) {
     return batch(env, h, 0, bases, offsets, n, paired, outTrimmed, outId0, outFlags);
@@ -86,14 +100,58 @@ JNIEXPORT jint JNICALL Java_bbduk_BBDukGpu_kfilterBatchJNI(JNIEnv* env, jclass c
     return batch(env, h, 1, bases, offsets, n, paired, outFound, outId, outFlags);
 }
 
-JNIEXPORT jint JNICALL Java_bbduk_BBDukGpu_countersJNI(JNIEnv* env, jclass cls, jlong h, jlongArray out) {
-    const jint n = (*env)->GetArrayLength(env, out);
-    jlong* o = (jlong*)(*env)->GetPrimitiveArrayCritical(env, out, NULL);
-    const jint rc = bbduk_get_counters((bbduk_handle*)(intptr_t)h, (int64_t*)o, n);
-    (*env)->ReleasePrimitiveArrayCritical(env, out, o, 0);
+static jint batch_packed(JNIEnv* env, jlong h, int kfilter, jintArray codes, jintArray undef, jlongArray offsets, jint n, jboolean paired,
+                         jintArray outA, jintArray outId, jbyteArray outFlags) {
+    pinned x[6] = {{codes, 0}, {undef, 0}, {offsets, 0}, {outA, 0}, {outId, 0}, {outFlags, 0}};
+    pin_all(env, x, 6);
+    const jint rc = kfilter
+        ? bbduk_kfilter_batch_packed(H(h), (const uint32_t*)x[0].p, (const uint32_t*)x[1].p, (const int64_t*)x[2].p, n, paired, (int32_t*)x[3].p, (int32_t*)x[4].p, (uint8_t*)x[5].p)
+        : bbduk_ktrim_batch_packed(H(h), (const uint32_t*)x[0].p, (const uint32_t*)x[1].p, (const int64_t*)x[2].p, n, paired, (int32_t*)x[3].p, (int32_t*)x[4].p, (uint8_t*)x[5].p);
+    unpin_all(env, x, 6, 3);
+    return rc;
+}
+JNIEXPORT jint JNICALL Java_bbduk_BBDukGpu_ktrimBatchPackedJNI(JNIEnv* env, jclass cls, jlong h, jintArray codes, jintArray undef, jlongArray offsets,
+        jint n, jboolean paired, jintArray outTrimmed, jintArray outId0, jbyteArray outFlags) {
+    return batch_packed(env, h, 0, codes, undef, offsets, n, paired, outTrimmed, outId0, outFlags);
+}
+JNIEXPORT jint JNICALL Java_bbduk_BBDukGpu_kfilterBatchPackedJNI(JNIEnv* env, jclass cls, jlong h, jintArray codes, jintArray undef, jlongArray offsets,
+        jint n, jboolean paired, jintArray outFound, jintArray outId, jbyteArray outFlags) {
+    return batch_packed(env, h, 1, codes, undef, offsets, n, paired, outFound, outId, outFlags);
+}
+
+JNIEXPORT jint JNICALL Java_bbduk_BBDukGpu_kmaskBatchJNI(JNIEnv* env, jclass cls, jlong h, jbyteArray bases, jlongArray offsets, jint n, jboolean paired,
+        jintArray outMasked, jintArray outId0, jbyteArray outFlags, jintArray outMask) {
+    pinned x[6] = {{bases, 0}, {offsets, 0}, {outMasked, 0}, {outId0, 0}, {outFlags, 0}, {outMask, 0}};
+    pin_all(env, x, 6);
+    const jint rc = bbduk_kmask_batch(H(h), (const uint8_t*)x[0].p, (const int64_t*)x[1].p, n, paired, (int32_t*)x[2].p, (int32_t*)x[3].p, (uint8_t*)x[4].p, (uint32_t*)x[5].p);
+    unpin_all(env, x, 6, 2);
     return rc;
 }
 
-JNIEXPORT void JNICALL Java_bbduk_BBDukGpu_destroyJNI(JNIEnv* env, jclass cls, jlong h) {
-    bbduk_destroy((bbduk_handle*)(intptr_t)h);
+JNIEXPORT jint JNICALL Java_bbduk_BBDukGpu_ktrimTipsBatchJNI(JNIEnv* env, jclass cls, jlong h, jbyteArray bases, jlongArray offsets, jint n, jboolean paired,
+        jintArray outRight, jintArray outLeft, jintArray outId0, jbyteArray outFlags) {
+    pinned x[6] = {{bases, 0}, {offsets, 0}, {outRight, 0}, {outLeft, 0}, {outId0, 0}, {outFlags, 0}};
+    pin_all(env, x, 6);
+    const jint rc = bbduk_ktrimtips_batch(H(h), (const uint8_t*)x[0].p, (const int64_t*)x[1].p, n, paired, (int32_t*)x[2].p, (int32_t*)x[3].p, (int32_t*)x[4].p, (uint8_t*)x[5].p);
+    unpin_all(env, x, 6, 2);
+    return rc;
 }
+
+JNIEXPORT jint JNICALL Java_bbduk_BBDukGpu_ksplitBatchJNI(JNIEnv* env, jclass cls, jlong h, jbyteArray bases, jlongArray offsets, jint n,
+        jintArray outTrimmed, jintArray outLeftmost, jintArray outRightmost, jintArray outId0, jbyteArray outFlags) {
+    pinned x[7] = {{bases, 0}, {offsets, 0}, {outTrimmed, 0}, {outLeftmost, 0}, {outRightmost, 0}, {outId0, 0}, {outFlags, 0}};
+    pin_all(env, x, 7);
+    const jint rc = bbduk_ksplit_batch(H(h), (const uint8_t*)x[0].p, (const int64_t*)x[1].p, n, (int32_t*)x[2].p, (int32_t*)x[3].p, (int32_t*)x[4].p, (int32_t*)x[5].p, (uint8_t*)x[6].p);
+    unpin_all(env, x, 7, 2);
+    return rc;
+}
+
+JNIEXPORT jint JNICALL Java_bbduk_BBDukGpu_countersJNI(JNIEnv* env, jclass cls, jlong h, jlongArray out) {
+    const jint n = (*env)->GetArrayLength(env, out);
+    jlong* o = (jlong*)PIN(out);
+    const jint rc = bbduk_get_counters(H(h), (int64_t*)o, n);
+    UNPIN_OUT(out, o);
+    return rc;
+}
+
+JNIEXPORT void JNICALL Java_bbduk_BBDukGpu_destroyJNI(JNIEnv* env, jclass cls, jlong h) { bbduk_destroy(H(h)); }
