@@ -57,7 +57,7 @@ GPU_SYMBOLS = ["bbduk_abi_version", "bbduk_create", "bbduk_destroy", "bbduk_last
                "bbduk_synth_generate_device", "bbduk_synth_generate_host"]
 HOST_SYMBOLS = ["bbduk_host_parse", "bbduk_host_destroy", "bbduk_host_add_ref", "bbduk_host_load_fasta",
                 "bbduk_host_load_refs", "bbduk_host_build_index", "bbduk_host_index_pairs",
-                "bbduk_host_num_scaffolds", "bbduk_host_params", "bbduk_host_upload_index", "bbduk_host_build_on_device"]
+                "bbduk_host_num_scaffolds", "bbduk_host_scaffold_info", "bbduk_host_params", "bbduk_host_upload_index", "bbduk_host_build_on_device"]
 
 _lib = None
 
@@ -187,6 +187,7 @@ def lib():
     L.bbduk_host_build_index.argtypes = [vp]
     L.bbduk_host_index_pairs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64)]
     L.bbduk_host_num_scaffolds.argtypes = [vp]
+    L.bbduk_host_scaffold_info.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(i64)]
     L.bbduk_host_params.argtypes = [vp, i32, C.POINTER(Params)]
     L.bbduk_host_upload_index.argtypes = [vp, vp]
     L.bbduk_host_build_on_device.argtypes = [vp, vp]
@@ -254,6 +255,13 @@ class HostIndex:
     @property
     def num_scaffolds(self) -> int:
         return lib().bbduk_host_num_scaffolds(self.h)
+
+    def scaffold_info(self, sid: int):
+        """(name, length) of scaffold sid (1-based), as BBDukLoader records them."""
+        name = C.c_char_p(); ln = C.c_int64()
+        if lib().bbduk_host_scaffold_info(self.h, sid, C.byref(name), C.byref(ln)) != OK:
+            raise BBDukError("bbduk_host_scaffold_info failed")
+        return name.value.decode(), ln.value
 
     def params(self, device: int = 0) -> Params:
         p = Params()

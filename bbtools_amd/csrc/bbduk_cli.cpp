@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <vector>
 #include "../../include/bbduk_gpu.h"
@@ -63,6 +64,64 @@ int fail(const char* what, const char* detail) { fprintf(stderr, "bbduk_cli: %s%
 
 bool parse_bool(const std::string& v) { return v.empty() || v == "t" || v == "true" || v == "1" || v == "T"; }
 
+// stats= and rpkm= (bbduk/BBDukProcessorS.java:572-655): per-scaffold hit statistics from the counter vector.
+struct StatsOut { std::string stats, rpkm; int columns = 3; bool nonZeroOnly = true; };   // BBDukParser.java:1508, 1363
+int write_stats(const StatsOut& so, const bbduk_host* host, const std::vector<int64_t>& c, const std::string& in1, const std::string& in2) {
+    const int ns = bbduk_host_num_scaffolds(host);
+    const int64_t readsIn = c[BBDUK_READS_IN], basesIn = c[BBDUK_BASES_IN];
+    const int64_t* reads = c.data() + BBDUK_NCOUNTERS; const int64_t* bases = reads + ns;
+    const std::string fileLine = "#File\t" + in1 + (in2.empty() ? "" : "\t" + in2) + "\n";
+    if (!so.stats.empty()) {                                                       // writeStats :572-617
+        FILE* f = fopen(so.stats.c_str(), "w");
+        if (!f) return fail("cannot open", so.stats.c_str());
+        struct SC { std::string name; int64_t reads, bases; };
+        std::vector<SC> list; int64_t rsum = 0, bsum = 0;
+        for (int i = 1; i < ns; i++) {
+            if (reads[i] > 0 || !so.nonZeroOnly) {
+                const char* nm = ""; bbduk_host_scaffold_info(host, i, &nm, nullptr);
+                rsum += reads[i]; bsum += bases[i];
+                list.push_back(SC{nm, reads[i], bases[i]});
+            }
+        }
+        std::sort(list.begin(), list.end(), [](const SC& a, const SC& b) {         // structures/StringCount.java:36-40
+            if (a.bases != b.bases) return a.bases > b.bases;
+            if (a.reads != b.reads) return a.reads > b.reads;
+            return a.name < b.name;
+        });
+        const double rmult = 100.0 / (readsIn > 0 ? readsIn : 1), bmult = 100.0 / (basesIn > 0 ? basesIn : 1);
+        fputs(fileLine.c_str(), f);
+        if (so.columns == 3) {
+            fprintf(f, "#Total\t%lld\n", (long long)readsIn);
+            fprintf(f, "#Matched\t%lld\t%.5f%%\n", (long long)rsum, rmult * rsum);
+            fputs("#Name\tReads\tReadsPct\n", f);
+            for (const SC& x : list) fprintf(f, "%s\t%lld\t%.5f%%\n", x.name.c_str(), (long long)x.reads, x.reads * rmult);
+        } else {
+            fprintf(f, "#Total\t%lld\t%lld\n", (long long)readsIn, (long long)basesIn);
+            fprintf(f, "#Matched\t%lld\t%.5f%%\n", (long long)rsum, rmult * rsum);  // the reference's format string ends here too (:602)
+            fputs("#Name\tReads\tReadsPct\tBases\tBasesPct\n", f);
+            for (const SC& x : list) fprintf(f, "%s\t%lld\t%.5f%%\t%lld\t%.5f%%\n", x.name.c_str(), (long long)x.reads, x.reads * rmult, (long long)x.bases, x.bases * bmult);
+        }
+        fclose(f);
+    }
+    if (!so.rpkm.empty()) {                                                        // writeRPKM :622-655
+        FILE* f = fopen(so.rpkm.c_str(), "w");
+        if (!f) return fail("cannot open", so.rpkm.c_str());
+        int64_t mapped = 0;
+        for (int i = 0; i < ns; i++) mapped += reads[i];
+        fputs(fileLine.c_str(), f);
+        fprintf(f, "#Reads\t%lld\n#Mapped\t%lld\n#RefSequences\t%d\n#Name\tLength\tBases\tCoverage\tReads\tRPKM\n", (long long)readsIn, (long long)mapped, ns - 1 > 0 ? ns - 1 : 0);
+        const float mult = 1000000000.0f / (float)(mapped > 1 ? mapped : 1);        // float arithmetic in the reference (:640)
+        for (int i = 1; i < ns; i++) {
+            const char* nm = ""; int64_t len = 0; bbduk_host_scaffold_info(host, i, &nm, &len);
+            const double invlen = 1.0 / (double)(len > 1 ? len : 1);
+            const double mult2 = (double)mult * invlen;
+            if (reads[i] > 0 || !so.nonZeroOnly) fprintf(f, "%s\t%lld\t%lld\t%.4f\t%lld\t%.4f\n", nm, (long long)len, (long long)bases[i], bases[i] * invlen, (long long)reads[i], reads[i] * mult2);
+        }
+        fclose(f);
+    }
+    return 0;
+}
+
 struct TextIn {                      // one input file streamed through a pinned buffer; `have` bytes wait at the front
     FILE* f = nullptr; bool piped = false, eof = false; uint8_t* h = nullptr; uint8_t* d = nullptr; int64_t have = 0; int64_t* d_lines = nullptr;
     bool open(const std::string& path) {
@@ -75,7 +134,7 @@ struct TextIn {                      // one input file streamed through a pinned
 };
 
 // The deviceingest=t pipeline.  Returns 0 or an error exit status; prints the same closing lines as the host path.
-int run_device_ingest(bbduk_handle* dev, const bbduk_params& P, const std::string& in1, const std::string& in2, bool paired,
+int run_device_ingest(bbduk_handle* dev, const bbduk_host* host, const StatsOut& so, const bbduk_params& P, const std::string& in1, const std::string& in2, bool paired,
                       const std::string& out, const std::string& outm, const std::string& tsv, int64_t chunk, int device) {
     if (P.mode != BBDUK_MODE_KTRIM_R && P.mode != BBDUK_MODE_KTRIM_L && P.mode != BBDUK_MODE_KFILTER) return fail("deviceingest=t serves ktrim=r, ktrim=l and kfilter", nullptr);
     const int ns = in2.empty() ? 1 : 2;
@@ -171,7 +230,7 @@ int run_device_ingest(bbduk_handle* dev, const bbduk_params& P, const std::strin
     fprintf(stderr, "Total Removed:          \t%lld reads \t%lld bases\n", (long long)(c[BBDUK_READS_IN] - c[BBDUK_READS_OUTU]), (long long)(c[BBDUK_BASES_IN] - c[BBDUK_BASES_OUTU]));
     fprintf(stderr, "Result:                 \t%lld reads \t%lld bases\n", (long long)c[BBDUK_READS_OUTU], (long long)c[BBDUK_BASES_OUTU]);
     if (c[BBDUK_CTR_STATUS]) return fail("device reported an error status", nullptr);
-    return 0;
+    return write_stats(so, host, c, in1, in2);
 }
 
 }  // namespace
@@ -180,6 +239,7 @@ int main(int argc, char** argv) {
     std::string in1, in2, out, outm, tsv, resources = "data", flags;
     bool interleaved = false; long batch = 1000000; int device = 0;
     bool maskLower = false; char maskSymbol = 'N';
+    StatsOut so;
     bool deviceIngest = false; long long chunk = 256LL << 20;     // deviceingest=t: FASTQ text to the GPU, chunk= bytes per file and round
     bool deviceBuild = false;        // devicebuild=t: the GPU builds the k-mer map from the reference sequences (bbduk_build_table_device)
     for (int i = 1; i < argc; i++) {
@@ -198,6 +258,10 @@ int main(int argc, char** argv) {
         else if (a == "devicebuild") deviceBuild = parse_bool(b);
         else if (a == "deviceingest") deviceIngest = parse_bool(b);
         else if (a == "chunk") chunk = atoll(b.c_str());
+        else if (a == "stats" || a == "scafstats") so.stats = b;     // BBDukParser.java:486-494, 689-693
+        else if (a == "rpkm" || a == "fpkm" || a == "cov" || a == "coverage") so.rpkm = b;
+        else if (a == "statscolumns" || a == "columns" || a == "cols") so.columns = atoi(b.c_str());
+        else if (a == "nzo" || a == "nonzeroonly") so.nonZeroOnly = parse_bool(b);
         else {
             if (a == "ktrim" || a == "kmask" || a == "mask") {       // the replacement symbol is the caller's business (BBDukParser.java:619-644)
                 std::string v = b; for (auto& c : v) c = (char)tolower(c);
@@ -233,7 +297,7 @@ int main(int argc, char** argv) {
 
     if (deviceIngest) {
         if (chunk < 4096) chunk = 4096;
-        const int rc = run_device_ingest(dev, P, in1, in2, paired, out, outm, tsv, (int64_t)chunk, device);
+        const int rc = run_device_ingest(dev, host, so, P, in1, in2, paired, out, outm, tsv, (int64_t)chunk, device);
         if (rc == 0) { bbduk_destroy(dev); bbduk_host_destroy(host); }
         return rc;
     }
@@ -340,6 +404,7 @@ int main(int argc, char** argv) {
             (long long)(c[BBDUK_BASES_IN] - c[BBDUK_BASES_OUTU]));
     fprintf(stderr, "Result:                 \t%lld reads \t%lld bases\n", (long long)c[BBDUK_READS_OUTU], (long long)c[BBDUK_BASES_OUTU]);
     if (c[BBDUK_CTR_STATUS]) return fail("device reported an error status", nullptr);
+    if (write_stats(so, host, c, in1, in2) != 0) return 1;
     bbduk_destroy(dev); bbduk_host_destroy(host);
     return 0;
 }

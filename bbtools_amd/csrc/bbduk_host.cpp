@@ -53,6 +53,7 @@ struct Parsed {                      // bbduk/BBDukParser.java fields (subset th
 struct bbduk_host {
     Parsed p;
     std::vector<std::vector<uint8_t>> scaffolds;     // id = index+1
+    std::vector<std::string> names;                  // scaffoldNames[id] (BBDukLoader.java:224, 275): FASTA header, or the id as text
     std::vector<KV> cand;
     std::vector<int64_t> keys;
     std::vector<int32_t> vals;
@@ -266,22 +267,29 @@ extern "C" void bbduk_host_destroy(bbduk_host* h) { delete h; }
 extern "C" int bbduk_host_add_ref(bbduk_host* h, const uint8_t* seq, int64_t len) {
     if (!h || len < 0 || (len > 0 && !seq) || h->built) return BBDUK_ERR_ARG;
     h->scaffolds.emplace_back(seq, seq + len);
+    h->names.push_back(std::to_string(h->scaffolds.size()));
     return BBDUK_OK;
 }
 
 static int load_stream(bbduk_host* h, FILE* f) {
     std::vector<uint8_t> seq; bool have = false; int nrec = 0; int ch; bool bol = true, inhdr = false;
+    std::string name;                                    // header of the record being read (without '>')
+    auto flush = [&]() {                                 // scaffoldNames.add(r1.id==null ? id.toString() : r1.id), BBDukLoader.java:224
+        h->scaffolds.push_back(seq);
+        h->names.push_back(name.empty() ? std::to_string(h->scaffolds.size()) : name);
+        nrec++;
+    };
     while ((ch = fgetc(f)) != EOF) {
-        if (inhdr) { if (ch == '\n') { inhdr = false; bol = true; } continue; }
+        if (inhdr) { if (ch == '\n') { inhdr = false; bol = true; } else if (ch != '\r') name.push_back((char)ch); continue; }
         if (bol && ch == '>') {
-            if (have && !seq.empty()) { h->scaffolds.push_back(seq); nrec++; }     // records shorter than 1 base are dropped
-            have = true; seq.clear(); inhdr = true; continue;
+            if (have && !seq.empty()) flush();           // records shorter than 1 base are dropped
+            have = true; seq.clear(); name.clear(); inhdr = true; continue;
         }
         if (ch == '\n' || ch == '\r') { bol = true; continue; }
         bol = false;
         if (ch > '\r') seq.push_back((uint8_t)ch);
     }
-    if (have && !seq.empty()) { h->scaffolds.push_back(seq); nrec++; }
+    if (have && !seq.empty()) flush();
     return nrec;
 }
 
@@ -315,7 +323,9 @@ extern "C" int bbduk_host_load_refs(bbduk_host* h, const char* resource_dir) {
         if (n < 0) return n;
         total += n;
     }
-    for (const std::string& l : h->p.literal) { h->scaffolds.emplace_back(l.begin(), l.end()); total++; }
+    for (const std::string& l : h->p.literal) {                      // BBDukLoader.java:272-277: a literal's name is its id
+        h->scaffolds.emplace_back(l.begin(), l.end()); h->names.push_back(std::to_string(h->scaffolds.size())); total++;
+    }
     return total;
 }
 
@@ -361,6 +371,12 @@ extern "C" int bbduk_host_index_pairs(const bbduk_host* h, const int64_t** keys,
     return BBDUK_OK;
 }
 extern "C" int bbduk_host_num_scaffolds(const bbduk_host* h) { return h ? (int)h->scaffolds.size() + 1 : BBDUK_ERR_ARG; }
+extern "C" int bbduk_host_scaffold_info(const bbduk_host* h, int32_t id, const char** name, int64_t* length) {
+    if (!h || id < 1 || id > (int32_t)h->scaffolds.size()) return BBDUK_ERR_ARG;
+    if (name) *name = h->names[(size_t)id - 1].c_str();
+    if (length) *length = (int64_t)h->scaffolds[(size_t)id - 1].size();
+    return BBDUK_OK;
+}
 
 extern "C" int bbduk_host_params(const bbduk_host* h, int32_t device, bbduk_params* out) {
     if (!h || !out) return BBDUK_ERR_ARG;

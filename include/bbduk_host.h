@@ -41,6 +41,9 @@ int  bbduk_host_load_refs(bbduk_host* h, const char* resource_dir);
 int64_t bbduk_host_build_index(bbduk_host* h);
 int  bbduk_host_index_pairs(const bbduk_host* h, const int64_t** keys, const int32_t** values, int64_t* n);
 int  bbduk_host_num_scaffolds(const bbduk_host* h);
+/* scaffoldNames[id] / scaffoldLengths[id] (bbduk/BBDukLoader.java:224-232, 275-276): the FASTA header (a literal: its id as
+ * text) and the number of bases; id in 1..num_scaffolds-1.  *name stays valid until bbduk_host_destroy. */
+int  bbduk_host_scaffold_info(const bbduk_host* h, int32_t id, const char** name, int64_t* length);
 
 /* Fills the boundary struct from the parsed + derived fields (device ordinal as given). */
 int  bbduk_host_params(const bbduk_host* h, int32_t device, bbduk_params* out);

@@ -109,6 +109,34 @@ def main():
     cli_fixtures(phix, ks)
 
 
+def write_stats_files(here, stem, s, scaffolds):
+    """stats= (3 and 5 columns) and rpkm= as BBDukProcessorS.writeStats / writeRPKM print them (:572-655); the #File line
+    carries placeholders because it echoes the command line's paths."""
+    import numpy as np
+    names = [""] + [n for n, _ in scaffolds]; lens = [0] + [len(q) for _, q in scaffolds]
+    readsIn, basesIn = s.counters[0], s.counters[1]
+    rows = [(names[i], s.scafReads[i], s.scafBases[i]) for i in range(1, s.nscaf) if s.scafReads[i] > 0]
+    rows.sort(key=lambda t: (-t[2], -t[1], t[0]))                # structures/StringCount.java:36-40
+    rsum = sum(t[1] for t in rows)
+    rmult, bmult = 100.0 / max(readsIn, 1), 100.0 / max(basesIn, 1)
+    with open(os.path.join(here, stem + "_stats3.txt"), "w") as f:
+        f.write("#File\tIN1\tIN2\n#Total\t%d\n#Matched\t%d\t%.5f%%\n#Name\tReads\tReadsPct\n" % (readsIn, rsum, rmult * rsum))
+        for nm, r, b in rows:
+            f.write("%s\t%d\t%.5f%%\n" % (nm, r, r * rmult))
+    with open(os.path.join(here, stem + "_stats5.txt"), "w") as f:
+        f.write("#File\tIN1\tIN2\n#Total\t%d\t%d\n#Matched\t%d\t%.5f%%\n#Name\tReads\tReadsPct\tBases\tBasesPct\n" % (readsIn, basesIn, rsum, rmult * rsum))
+        for nm, r, b in rows:
+            f.write("%s\t%d\t%.5f%%\t%d\t%.5f%%\n" % (nm, r, r * rmult, b, b * bmult))
+    mapped = sum(s.scafReads)
+    mult = np.float32(1000000000.0) / np.float32(max(1, mapped))
+    with open(os.path.join(here, stem + "_rpkm.txt"), "w") as f:
+        f.write("#File\tIN1\tIN2\n#Reads\t%d\n#Mapped\t%d\n#RefSequences\t%d\n#Name\tLength\tBases\tCoverage\tReads\tRPKM\n" % (readsIn, mapped, max(0, s.nscaf - 1)))
+        for i in range(1, s.nscaf):
+            if s.scafReads[i] > 0:
+                invlen = 1.0 / max(1, lens[i])
+                f.write("%s\t%d\t%d\t%.4f\t%d\t%.4f\n" % (names[i], lens[i], s.scafBases[i], s.scafBases[i] * invlen, s.scafReads[i], s.scafReads[i] * (float(mult) * invlen)))
+
+
 def write_fastq(path, names, reads):
     with open(path, "w") as f:
         for i, (nm, r) in enumerate(zip(names, reads)):
@@ -133,6 +161,7 @@ def cli_fixtures(phix, ks):
     write_fastq(os.path.join(here, "cli_c2_r2.fq"), names[1::2], reads[1::2])
     s = Spec(Args(k=23, mink=11, hdist=1, ktrimRight=True)); s.load_fasta(ADAPTERS)
     tsv(os.path.join(here, "cli_c2.tsv"), names, reads, s.process_batch([r.encode() for r in reads], True), True)
+    write_stats_files(here, "cli_c2", s, read_fasta(ADAPTERS))
     # the same pairs through ktrim=n: per-read TSV and the masked FASTQ (symbol N, quality '!')
     s = Spec(Args(k=23, mink=11, hdist=1, ktrimN=True)); s.load_fasta(ADAPTERS)
     out = s.process_batch([r.encode() for r in reads], True)

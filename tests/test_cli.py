@@ -136,3 +136,18 @@ def test_cli_deviceingest_rejects_what_it_cannot_serve(tmp_path):
     bad.write_text("@a\nACGT\n+\nIIII\n@b\nACGT\nIIII\n+\n")
     r = run_cli(["in=" + str(bad), "k=23", "ref=adapters", "deviceingest=t"])
     assert r.returncode == 1 and "malformed FASTQ record" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ingest", [[], ["deviceingest=t"]])
+def test_cli_stats_and_rpkm_files(tmp_path, ingest):
+    """stats= (3 and 5 columns) and rpkm= as BBDukProcessorS.writeStats / writeRPKM format the per-scaffold counters
+    (:572-655); expected files come from the spec's counters (tests/golden/make_golden.py write_stats_files)."""
+    f1, f2 = os.path.join(GOLD, "cli_c2_r1.fq"), os.path.join(GOLD, "cli_c2_r2.fq")
+    for cols, stem in (("3", "cli_c2_stats3.txt"), ("5", "cli_c2_stats5.txt")):
+        st, rp = str(tmp_path / "stats.txt"), str(tmp_path / "rpkm.txt")
+        r = run_cli(["in=" + f1, "in2=" + f2, "stats=" + st, "rpkm=" + rp, "statscolumns=" + cols, "ktrim=r", "k=23", "mink=11", "hdist=1", "ref=adapters"] + ingest)
+        assert r.returncode == 0, r.stderr
+        want = open(os.path.join(GOLD, stem)).read().replace("IN1", f1).replace("IN2", f2)
+        assert open(st).read() == want
+        assert open(rp).read() == open(os.path.join(GOLD, "cli_c2_rpkm.txt")).read().replace("IN1", f1).replace("IN2", f2)

@@ -147,3 +147,17 @@ def test_pack_bases_host_layout():
                 assert (int(codes[b >> 4]) >> (2 * (b & 15))) & 3 == want[b]
         for b in range(nb, 32 * len(undef)):
             assert (int(undef[b >> 5]) >> (b & 31)) & 1 == 1
+
+
+def test_scaffold_names_and_lengths():
+    """scaffoldNames / scaffoldLengths as BBDukLoader records them: FASTA headers, literals named by their id."""
+    h = B.HostIndex("k=23 ref=adapters literal=ACGTACGTACGTACGTACGTACGTACGT,GGGGGGGGGGGGGGGGGGGGGGGGGGGGG")
+    h.load_refs()
+    fa = B.read_fasta(util.ADAPTERS)
+    assert h.num_scaffolds == len(fa) + 2 + 1
+    for i, (name, seq) in enumerate(fa):
+        assert h.scaffold_info(i + 1) == (name, len(seq))
+    assert h.scaffold_info(len(fa) + 1) == (str(len(fa) + 1), 28)
+    assert h.scaffold_info(len(fa) + 2) == (str(len(fa) + 2), 29)
+    with pytest.raises(B.BBDukError):
+        h.scaffold_info(0)
