@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--format", choices=["ascii", "packed"], default="ascii",
+                    help="boundary format of the resident batch: ascii = the reference's byte per base (the headline), "
+                         "packed = 2-bit codes + undefined bits (DESIGN.md 4.7; secondary)")
     a = ap.parse_args()
 
     import numpy as np
@@ -83,12 +86,21 @@ def main():
     d_fl = torch.empty(n, dtype=torch.uint8, device="cuda")
     d_ctr = torch.zeros(duk.gpu.counters_len, dtype=torch.int64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
+    packed = a.format == "packed"
+    if packed:                                       # converted once, outside the timed region, like the generator
+        d_codes = torch.empty((n * READ_LEN + 15) // 16 + 4, dtype=torch.int32, device="cuda")
+        d_undef = torch.empty((n * READ_LEN + 31) // 32 + 4, dtype=torch.int32, device="cuda")
+        B.pack_bases_device(d_bases, d_codes, d_undef, dev)
+        torch.cuda.synchronize()
 
     def step(ev0=None, ev1=None):
         d_ctr.zero_()
         if ev0 is not None:
             ev0.record()
-        duk.gpu.process_batch_device(d_bases, d_off, True, d_a, d_id, d_fl, d_ctr, stream)
+        if packed:
+            duk.gpu.process_batch_packed_device(d_codes, d_undef, d_off, n * READ_LEN, True, d_a, d_id, d_fl, d_ctr, stream)
+        else:
+            duk.gpu.process_batch_device(d_bases, d_off, True, d_a, d_id, d_fl, d_ctr, stream)
         if ev1 is not None:
             ev1.record()
         total = d_ctr.clone()
@@ -126,14 +138,14 @@ def main():
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int64", "data": "synthetic",
         "config": {"workload": "BBDuk ktrim=r k=23 mink=11 hdist=1 ref=adapters, %d synthetic 2x150bp reads per GPU "
-                               "(configs[1]), device-resident batch" % n,
+                               "(configs[1]), device-resident batch%s" % (n, ", packed 2-bit boundary format" if packed else ""),
                    "args": ARGS_C2, "reads_per_gpu": n, "read_len": READ_LEN, "seed": a.seed,
                    "table_keys": int(duk.stored_kmers), "table_bytes": int(duk.gpu.table_bytes),
                    "parallelism": "reads sharded x%d, table replicated, 1 counter all-reduce/step" % world},
         "counters": {k: int(v) for k, v in zip(B.COUNTER_NAMES, ctr[:10])},
         "device_status": status,
     }
-    algo_bytes = ALGO_BYTES_PER_READ * n
+    algo_bytes = (ALGO_BYTES_PER_READ if not packed else READ_LEN * 0.375 + 8 + 8) * n     # 0.375 B/base with 2-bit + mask
     ach = algo_bytes / (kern_ms * 1e-3) / 1e9
     # HBM-side traffic per launch: PMC counters cannot be read from inside this process, so the figure is the one
     # measured by profiles/run_profile.sh (separate rocprofv3 --pmc passes over this same command) and committed in
@@ -142,13 +154,13 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             pt = json.load(fh)
-        if int(pt["reads_per_launch"]) == n:
+        if int(pt["reads_per_launch"]) == n and not packed:
             traffic, traffic_src = int(pt["traffic_bytes"]), pt["source"]
     except Exception:
         pass
     out["roofline"] = {"bound": "hbm", "kernel": "bbduk_wave_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                       "kernel_ms": round(kern_ms, 3), "launch_ms": round(launch_ms, 3), "algorithmic_bytes_per_launch": algo_bytes,
+                       "kernel_ms": round(kern_ms, 3), "launch_ms": round(launch_ms, 3), "algorithmic_bytes_per_launch": int(algo_bytes),
                        # the contract prices this path against HBM; what actually paces the kernel is instruction issue
                        # (131 VALU + 70 SALU wave-instructions per read at ~4.4 / ~2.6 SIMD cycles each)
                        "limiter": "instruction issue, not HBM: 131 VALU + 70 SALU per read (profiles/r01_final_summary.txt)"}
