@@ -85,7 +85,6 @@ int derive(Parsed& p, std::string& err) {            // bbduk/BBDukParser.java:1
     p.hdist2 = std::max(p.edist2, p.hdist2);
     p.minSkip = std::max(1, std::min(p.minSkip, p.maxSkip));
     p.maxSkip = std::max(p.minSkip, p.maxSkip);
-    if (p.minSkip != 1 || p.maxSkip != 1) { err = "rskip/minskip/maxskip other than 1 are not supported by this path"; return BBDUK_ERR_ARG; }
     p.forbidNs = (p.forbidNs || p.hdist < 1);
     p.restrictLeft = std::max(p.restrictLeft, 0);
     p.restrictRight = std::max(p.restrictRight, 0);
@@ -95,7 +94,7 @@ int derive(Parsed& p, std::string& err) {            // bbduk/BBDukParser.java:1
     p.k = std::min(p.k, 31);
     if ((p.ktrimLeft || p.ktrimRight || p.ktrimN || p.ksplit) && p.kbig > p.k) p.kbig = p.k;   // :207-215 "K has been reduced"
     if ((p.speed > 0 || p.qSkip > 1) && p.kbig > p.k) p.kbig = p.k;     // :217-223
-    if (p.kbig > p.k) p.maskMiddle = false;                              // :237-243, before minlen2 is derived
+    if (p.kbig > p.k) { p.maskMiddle = false; p.minSkip = p.maxSkip = 0; }   // :237-243, before minlen2 is derived
     if (p.maskMiddle) p.midMaskLen = (p.midMaskLen > 0 ? p.midMaskLen : 2 - (p.k & 1));
     else p.midMaskLen = 0;
     p.mink = std::min(p.mink, p.k);
@@ -340,12 +339,17 @@ extern "C" int64_t bbduk_host_build_index(bbduk_host* h) {
         const int id = (int)s + 1;
         const int64_t n = (int64_t)b.size();
         if (n < k) continue;
+        // reference-side skipping (BBDukLoader.java:397, 417, 432-449): with skip > 1 only every skip-th k-mer of a run of
+        // defined bases is stored (len%skip==0), the short k-mers of the ends included
+        const int heur = n > 20000000 ? k : n > 5000000 ? 11 : n > 500000 ? 2 : 0;
+        const int skip = std::max(p.minSkip, std::min(p.maxSkip, heur));
         uint64_t fwd = 0; int64_t run = 0;               // run = defined bases ending here
         for (int64_t i = 0; i < n; i++) {
             const int c = code_of(b[i]);
             fwd = ((fwd << 2) | (uint64_t)(c < 0 ? 0 : c)) & mask;
             run = (c < 0) ? 0 : run + 1;
             if (run < k) continue;
+            if (skip > 1 && run % skip != 0) continue;
             emit(h, fwd, k, p.hdist, id, tmp);
             if (p.useShortKmers) {
                 if (i == k - 1)                          // prefixes of the scaffold's first k-mer (addToMapRightShift)
@@ -407,6 +411,11 @@ extern "C" int bbduk_host_build_on_device(const bbduk_host* h, bbduk_handle* dev
     if (!h || !dev) return BBDUK_ERR_ARG;
     const Parsed& p = h->p;
     if (p.edist > 0 || p.edist2 > 0 || p.hdist > 2 || p.hdist2 > 2) return BBDUK_ERR_ARG;      // the host builder / upload path serves those
+    for (const auto& sc : h->scaffolds) {                                                       // so does it serve reference-side skipping
+        const int64_t n = (int64_t)sc.size();
+        const int heur = n > 20000000 ? p.k : n > 5000000 ? 11 : n > 500000 ? 2 : 0;
+        if (std::max(p.minSkip, std::min(p.maxSkip, heur)) > 1) return BBDUK_ERR_ARG;
+    }
     std::vector<uint8_t> cat; std::vector<int64_t> off(1, 0);
     for (const auto& s : h->scaffolds) { cat.insert(cat.end(), s.begin(), s.end()); off.push_back((int64_t)cat.size()); }
     if (cat.empty()) cat.push_back(0);

@@ -74,6 +74,8 @@ class Args:
     kbig: int = -1                  # k>31 on the command line: k is then 31 and kbig the requested k (BBDukParser.java:164-165)
     findBestMatch: bool = False     # findbestmatch / fbm (kfilter only; rename is not restated)
     ksplit: bool = False            # ksplit=t (unpaired reads only)
+    minSkip: int = 1                # rskip / minskip / maxskip: reference-side k-mer skipping (BBDukLoader.java:417, 432-449)
+    maxSkip: int = 1
 
 
 COUNTER_NAMES = ["readsIn", "basesIn", "readsKTrimmed", "basesKTrimmed", "readsKFiltered", "basesKFiltered",
@@ -148,7 +150,7 @@ class Spec:
 
     # ---------------------------------------------------------------- reference
     def add_ref(self, seq: bytes) -> None:
-        """bbduk/BBDukLoader.java:416-494 for skip==1, by slicing instead of rolling."""
+        """bbduk/BBDukLoader.java:416-494 (both branches: all k-mers, or every skip-th of a run), by slicing instead of rolling."""
         sid = self.nscaf
         self.nscaf += 1
         self.scafReads.append(0)
@@ -157,10 +159,21 @@ class Spec:
         if n < k:
             return
         ok = [defined(c) for c in seq]
+        a = self.a
+        mn = max(1, min(a.minSkip, a.maxSkip)); mx = max(mn, a.maxSkip)             # BBDukParser.java:148-149
+        if self.kbig > k:
+            mn = mx = 0                                                               # :238
+        skip = max(mn, min(mx, k if n > 20000000 else 11 if n > 5000000 else 2 if n > 500000 else 0))   # BBDukLoader.java:397, 417
         for i in range(k - 1, n):
             win = seq[i - k + 1:i + 1]
             if not all(ok[i - k + 1:i + 1]):          # len>=k <=> the last k bases are all defined
                 continue
+            if skip > 1:                              # len = defined bases ending at i; only every skip-th k-mer of a run
+                run = 0
+                while run <= i and ok[i - run]:
+                    run += 1
+                if run % skip != 0:
+                    continue
             kmer = 0
             for c in win:
                 kmer = (kmer << 2) | fwd_code(c)

@@ -121,7 +121,8 @@ FUZZ = [("ktrim=r k=23", dict(k=23, ktrimRight=1)),
         ("ktrim=r k=27 speed=12 qskip=2 tpe", dict(k=27, ktrimRight=1, speed=12, qSkip=2, trimPairsEvenly=1)),
         ("k=21 mkf=0.3", dict(k=21, minKmerFraction=0.3)), ("k=13 mkf=0.1 mbk=3 rieb=f forbidn=t", dict(k=13, minKmerFraction=0.1, maxBadKmers0=3, requireBothBad=1, forbidN=1)),
         ("k=25 mcf=0.4", dict(k=25, minCoveredFraction=0.4)), ("k=15 mcf=0.9 hdist=1 restrictleft=60", dict(k=15, minCoveredFraction=0.9, hdist=1, restrictLeft=60)),
-        ("k=19 mcf=0.05 mkf=0.5 mm=f", dict(k=19, minCoveredFraction=0.05, minKmerFraction=0.5, maskMiddle=0))]
+        ("k=19 mcf=0.05 mkf=0.5 mm=f", dict(k=19, minCoveredFraction=0.05, minKmerFraction=0.5, maskMiddle=0)),
+        ("ktrim=r k=21 mink=9 rskip=3 hdist=1", dict(k=21, ktrimRight=1, mink=9, minSkip=3, maxSkip=3, hdist=1))]
 
 
 @pytest.mark.parametrize("ci", range(len(FUZZ)))
@@ -512,6 +513,11 @@ def test_device_built_table_equals_oracle_table(ci):
         reads = util.fuzz_reads(rng, refs, 400, [0, 1, 5, 10, 23, 31, 40, 64, 150, 300], junk=True)
         check_batch(d, o, reads, True)
     d.close()
+
+
+def test_device_build_refuses_reference_side_skipping():
+    with pytest.raises(B.BBDukError):
+        B.BBDuk("k=21 rskip=3", refs=[b"ACGTTGCATGCATGCATGGGATCGATCGATTTACGAC"], build="device")
 
 
 def test_device_built_adapter_and_phix_tables():

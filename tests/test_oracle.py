@@ -124,7 +124,8 @@ FUZZ = [dict(k=23, ktrimRight=1), dict(k=23, ktrimRight=1, mink=11, hdist=1), di
         dict(k=13, ktrimRight=1, mink=7, hdist=1, trimPairsEvenly=1), dict(k=17, ktrimRight=1, trimPairsEvenly=1, requireBothBad=1, minReadLength=30),
         dict(k=12, qSkip=3), dict(k=14, ktrimRight=1, mink=6, qSkip=2), dict(k=11, speed=5, hdist=1), dict(k=15, ktrimLeft=1, mink=9, speed=9, qhdist=1),
         dict(k=11, minKmerFraction=0.3), dict(k=13, minKmerFraction=0.1, maxBadKmers0=3, requireBothBad=1, forbidN=1), dict(k=12, minCoveredFraction=0.4),
-        dict(k=15, minCoveredFraction=0.9, hdist=1, restrictLeft=60), dict(k=9, minCoveredFraction=0.05, minKmerFraction=0.5, maskMiddle=0)]
+        dict(k=15, minCoveredFraction=0.9, hdist=1, restrictLeft=60), dict(k=9, minCoveredFraction=0.05, minKmerFraction=0.5, maskMiddle=0),
+        dict(k=13, minSkip=3, maxSkip=3, ktrimRight=1, mink=6), dict(k=11, minSkip=2, maxSkip=5, hdist=1), dict(k=9, minSkip=4, maxSkip=4, ktrimLeft=1, mink=5, hdist=1, hdist2=0)]
 BOOLS = ("maskMiddle", "rcomp", "forbidN", "ktrimRight", "ktrimLeft", "requireBothBad", "ktrimExclusive", "skipR1", "skipR2", "trimPairsEvenly", "ktrimN")
 KMASK_FUZZ = [dict(k=11, ktrimN=1), dict(k=13, ktrimN=1, mink=6, hdist=1), dict(k=15, ktrimN=1, trimPad=2, forbidN=1, restrictRight=50),
               dict(k=12, ktrimN=1, mink=5, trimPad=-2, qhdist=1, maskMiddle=0), dict(k=17, ktrimN=1, requireBothBad=1, minReadLength=40, skipR1=1)]
