@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""
+Randomised parity soak (GPU box): for --seconds S keeps drawing flag combinations (every mode served: ktrim r/l/rl, ktrim=n,
+ksplit, kfilter with mbk/mkf/mcf, k>31, findbestmatch; host- or device-built map; rskip), references and reads (lengths
+0..6000, junk bytes, Ns, chimeras) and compares the device operators -- ASCII and packed boundary -- with the CPU oracle,
+per read and counter by counter.  Prints one JSON line; exits non-zero at the first mismatch (config and seed in the message).
+"""
+import argparse, json, os, random, sys, time
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=300.0); ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    from bbtools_amd import bbduk as B
+    from oracle.oracle_ffi import Oracle
+    from tests import util
+    from tests import test_gpu_parity as T
+    t0 = time.time(); n_cfg = 0; n_reads = 0; fam_count = {}
+    it = 0
+    while time.time() - t0 < a.seconds:
+        seed = a.seed * 1_000_003 + it; it += 1
+        rng = random.Random(seed)
+        fam = rng.choice(["base", "base", "base", "kmask", "tips", "ksplit", "big", "fbm"])
+        args, okw = T.random_config(rng)
+        toks = [t for t in args.split() if not t.startswith("ktrim=") and t != "tpe"]
+        for key in ("ktrimRight", "ktrimLeft", "trimPairsEvenly"):
+            if fam != "base":
+                okw.pop(key, None)
+        if fam == "base":
+            toks = args.split()
+        elif fam == "kmask":
+            toks.append("ktrim=n"); okw["ktrimN"] = 1
+            for kk in ("maxBadKmers0", "minKmerFraction", "minCoveredFraction", "ktrimExclusive"):
+                okw.pop(kk, None)
+            toks = [t for t in toks if not t.startswith(("mbk=", "mkf=", "mcf=", "ktrimexclusive"))]
+        elif fam == "tips":
+            toks.append("ktrim=rl"); okw["ktrimRight"] = okw["ktrimLeft"] = 1
+            for kk in ("maxBadKmers0", "minKmerFraction", "minCoveredFraction"):
+                okw.pop(kk, None)
+            toks = [t for t in toks if not t.startswith(("mbk=", "mkf=", "mcf="))]
+            if rng.random() < 0.4: toks.append("tpe"); okw["trimPairsEvenly"] = 1
+        elif fam == "ksplit":
+            toks.append("ksplit=t"); okw["ksplit"] = 1
+            for kk in ("maxBadKmers0", "minKmerFraction", "minCoveredFraction", "ktrimExclusive", "skipR1"):
+                okw.pop(kk, None)
+            toks = [t for t in toks if not t.startswith(("mbk=", "mkf=", "mcf=", "ktrimexclusive", "skipr1"))]
+            if okw.get("trimPad", 0) > 0:
+                okw["trimPad"] = -okw["trimPad"]; toks = [("tp=%d" % okw["trimPad"]) if t.startswith("tp=") else t for t in toks]
+        elif fam in ("big", "fbm"):
+            for kk in ("mink", "hdist2", "trimPad", "ktrimExclusive", "minCoveredFraction", "qSkip", "speed"):
+                okw.pop(kk, None)
+            toks = [t for t in toks if not t.startswith(("mink=", "hdist2=", "tp=", "ktrimexclusive", "mcf=", "qskip=", "speed="))]
+            if fam == "big":
+                kb = rng.randint(32, 60); okw["k"] = 31; okw["kbig"] = kb
+                okw.pop("maskMiddle", None); okw.pop("qhdist", None)
+                toks = [("k=%d" % kb) if t.startswith("k=") else t for t in toks if not t.startswith(("mm=", "qhdist="))]
+                if okw.get("hdist", 0) > 1: okw["hdist"] = 1; toks = [t if not t.startswith("hdist=") else "hdist=1" for t in toks]
+            else:
+                okw["findBestMatch"] = 1; toks.append("fbm=t")
+                okw.pop("maxBadKmers0", None); okw.pop("minKmerFraction", None)
+                toks = [t for t in toks if not t.startswith(("mbk=", "mkf="))]
+        if "mink" in okw and fam in ("base",) and not (okw.get("ktrimRight") or okw.get("ktrimLeft")):
+            okw.pop("mink"); toks = [t for t in toks if not t.startswith("mink=")]
+        if rng.random() < 0.15 and fam not in ("big",):
+            sk = rng.randint(2, 4); okw["minSkip"] = okw["maxSkip"] = sk; toks.append("rskip=%d" % sk)
+        args = " ".join(toks)
+        k = okw["k"]
+        refs = [util.rand_seq(rng, rng.randint(10, 260 if fam in ("big", "fbm", "ksplit") else 90), 0.01) for _ in range(rng.randint(1, 10))]
+        lengths = [0, 1, 5, 10, 22, 23, 31, 40, 64, 75, 150, 151, 300, 1000] + ([2500, 6000] if rng.random() < 0.3 else [])
+        reads = util.fuzz_reads(rng, refs, rng.choice([50, 400, 1500]), lengths, junk=True)
+        if fam in ("big", "fbm", "ksplit"):
+            reads += util.long_refs_and_reads(rng)[1][:0]
+            reads += [util.rand_seq(rng, rng.randint(0, 60)) + rng.choice(refs)[:rng.randint(20, 260)] + util.rand_seq(rng, rng.randint(0, 60)) for _ in range(100)]
+        if len(reads) % 2: reads.append(b"")
+        build = "device" if (rng.random() < 0.4 and okw.get("hdist", 0) <= 2 and "minSkip" not in okw) else "host"
+        try:
+            d = B.BBDuk(args, refs=refs, build=build)
+            o = Oracle(**okw)
+            for r in refs: o.add_ref(r)
+            assert d.stored_kmers == o.stored_kmers, ("stored", d.stored_kmers, o.stored_kmers)
+            if fam == "kmask":
+                T.check_kmask(d, o, reads, True); T.check_kmask(d, o, reads[:101], False)
+            elif fam == "tips":
+                T.check_tips(d, o, reads, True); T.check_tips(d, o, reads[:101], False)
+            elif fam == "ksplit":
+                T.check_split(d, o, reads)
+            else:
+                T.check_batch(d, o, reads, True); T.check_batch(d, o, reads[:101], False)
+            d.close()
+        except Exception as e:
+            print(json.dumps({"FAILED": True, "seed": seed, "family": fam, "args": args, "okw": okw, "build": build, "error": str(e)[:2000]}))
+            sys.exit(1)
+        n_cfg += 1; n_reads += len(reads); fam_count[fam] = fam_count.get(fam, 0) + 1
+    print(json.dumps({"soak_seconds": round(time.time() - t0, 1), "configs": n_cfg, "reads_checked": n_reads * 3, "families": fam_count, "mismatches": 0, "seed": a.seed}))
+
+
+if __name__ == "__main__":
+    main()
