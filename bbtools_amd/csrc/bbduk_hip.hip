@@ -780,12 +780,14 @@ __device__ __forceinline__ int kfilter_threshold(const KParams& P, const Planes&
     return P.maxBadKmers;
 }
 
+// firstA >= 0 (bbduk_long_kernel): read A is scanned in chunks; this call resumes at position firstA with A.found hits so far.
 template <int MODE, bool FORBIDN, bool GENERAL>
-__device__ __forceinline__ void main_scan_pair(const KParams& P, const Planes& Q, ReadScan& A, ReadScan& B, const int lane) {
+__device__ __forceinline__ void main_scan_pair(const KParams& P, const Planes& Q, ReadScan& A, ReadScan& B, const int lane, const int firstA = -1) {
     ReadWin WA, WB;
     win_init<FORBIDN, GENERAL>(P, Q, A, WA, lane);
     win_init<FORBIDN, GENERAL>(P, Q, B, WB, lane);
-    int ibA = WA.first, ibB = WB.first, foundA = 0, foundB = 0;
+    if (firstA >= 0) { WA.first = max(WA.first, firstA); WA.on = A.scan && WA.first < WA.stop; }
+    int ibA = WA.first, ibB = WB.first, foundA = (firstA >= 0) ? A.found : 0, foundB = 0;
     bool onA = WA.on, onB = WB.on;
     while (onA || onB) {
         uint64_t kmer[4], rk[4]; bool ok[4]; int id[4];
@@ -1051,7 +1053,8 @@ void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
                         const int64_t n, const int64_t totalBases, const int paired,
                         int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
                         int64_t* __restrict__ counters, const int* __restrict__ slowFlag) {
-    if (*slowFlag == 0) return;                                   // every unit fits a wave's planes: the wave kernel ran
+    if (*slowFlag != 1) return;                                   // 0: every unit fits a wave's planes, the wave kernel ran; 2/3: a unit
+                                                                  // exceeds this kernel's planes too, bbduk_long_kernel takes the batch
     __shared__ uint32_t s_fwd[PLANE_PAD + CAP_CHUNKS + PLANE_PAD];   // padded both ends: the plain path reads past a read's end unclamped
     __shared__ uint32_t s_cmp[PLANE_PAD + CAP_CHUNKS + PLANE_PAD];
     __shared__ uint32_t s_nm[CAP_CHUNKS / 2 + 4];
@@ -2289,15 +2292,153 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
     if (tid == 0) publish_counters<MODE>(s_acc, counters);
 }
 
+// --------------------------------------------------------------------------------------------------
+// Reads longer than the LDS tiles (BBDUK_MAX_READ_LEN): one wave per unit again, but a read streams through the wave's
+// private planes in chunks of LCHUNK k-mer end positions; each chunk is staged with the k-1 bases in front of it, the scan
+// state (hits so far, first / last hit, credited id) is carried across chunks in the ReadScan, and the scan stops early
+// where the reference's loop would not need to go on (ktrim=r after its first hit, kfilter at its exit).  The short k-mers
+// of an end are looked up on a small chunk staged for that end.  Run-time-general scan functions; any read length that
+// fits an int.  Takes the whole batch when the pre-pass finds such a read (long-read data sets consist of them).
+#define LCHUNK (WCAP_BASES - 128)
+template <int MODE>
+__global__ __launch_bounds__(BLOCK_THREADS)
+void bbduk_long_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
+                       const int64_t n, const int64_t totalBases, const int paired,
+                       int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
+                       int64_t* __restrict__ counters, const int* __restrict__ slowFlag) {
+    if ((*slowFlag & 2) == 0) return;
+    __shared__ uint32_t s_wf[NWAVES * WPLANE_WORDS];
+    __shared__ uint32_t s_wc[NWAVES * WPLANE_WORDS];
+    __shared__ uint32_t s_wn[NWAVES * WNM_WORDS];
+    __shared__ unsigned long long s_acc[6];                       // rkt, basesKTrimmed, readsOutm, basesOutm, readsIn, basesIn
+    extern __shared__ uint32_t s_filt[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+    const int k = P.k;
+    ScafAcc scaf; scaf_init(scaf);
+    if (tid < 6) s_acc[tid] = 0;
+    if (P.ldsBits) {
+        const int words = 1 << (P.ldsBits - 5);
+        for (int w = tid; w < words; w += BLOCK_THREADS) s_filt[w] = P.ldsImage[w];
+    }
+    __syncthreads();
+    uint32_t* const wf = s_wf + wave * WPLANE_WORDS; uint32_t* const wc = s_wc + wave * WPLANE_WORDS; uint32_t* const wn = s_wn + wave * WNM_WORDS;
+    Planes Q; Q.fwd = wf + PLANE_PAD; Q.cmp = wc + PLANE_PAD; Q.nm = wn; Q.filt = s_filt; Q.T = 0;
+    Q.fwdBits = lds_bits_of(Q.fwd); Q.cmpBits = lds_bits_of(Q.cmp);
+    // stage bases [lo, hi) of the read at `off` into this wave's planes; returns the plane index of the read's base 0
+    auto stage = [&](const int64_t off, const int lo, const int hi) -> int {
+        const int64_t B0 = off + lo;
+        const int64_t A0 = B0 & ~15LL;
+        const int nchunks = (int)((off + hi - A0 + 15) >> 4);
+        for (int c = lane; c < nchunks; c += 64) {
+            uint32_t r, comp, valid;
+            stage_chunk(P, bases, A0 + 16LL * c, totalBases, r, comp, valid);
+            wf[PLANE_PAD + nchunks - 1 - c] = r;
+            wc[PLANE_PAD + c] = comp;
+            reinterpret_cast<uint16_t*>(wn)[c] = (uint16_t)(~valid & 0xFFFFu);
+        }
+        if (lane == 0) { reinterpret_cast<uint16_t*>(wn)[nchunks] = 0; reinterpret_cast<uint16_t*>(wn)[nchunks + 1] = 0; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        Q.T = nchunks * 16;
+        return (int)(off - A0);
+    };
+    auto scan_read = [&](ReadScan& R, const int64_t off, const int pairnum, const bool present) {
+        const int L = R.L;
+        ReadScan none; read_init<MODE, true, true>(P, none, 0, 0, 0, false);
+        if (MODE == BBDUK_MODE_KFILTER && P.mcf > 0.f) R.maxBad = (int)ceilf(P.mcf * (float)L);    // :1040 (also for reads that are not scanned)
+        if (MODE == BBDUK_MODE_KFILTER && P.mkf != 0.f && L < k) R.maxBad = max(P.maxBadKmers, (int)((float)(0 - 1) * P.mkf));
+        if (!R.scan) return;
+        if (MODE == BBDUK_MODE_KFILTER) {                           // thresholds that depend on the whole read
+            if (P.mcf > 0.f) {}
+            else if (P.mkf != 0.f) {                                // numValidKmers over the chunks, the run of defined bases carried along
+                int cnt = 0, run = 0;
+                for (int c0 = 0; c0 < L; c0 += LCHUNK) {
+                    const int c1 = min(L, c0 + LCHUNK);
+                    const int b0 = stage(off, c0, c1);
+                    for (int i0 = c0; i0 < c1; i0 += 64) {
+                        const int b = b0 + min(i0 + lane, c1 - 1);
+                        const uint64_t U = __ballot(((Q.nm[b >> 5] >> (b & 31)) & 1u) != 0u);
+                        const int nv = min(64, c1 - i0);
+                        int pos = 0;
+                        while (pos < nv) {
+                            const uint64_t rest = U >> pos;
+                            const int nextU = rest ? min(nv, pos + __ffsll((unsigned long long)rest) - 1) : nv;
+                            const int seg = nextU - pos;
+                            cnt += max(0, run + seg - max(run, k - 1));
+                            run += seg;
+                            if (nextU < nv) { run = 0; pos = nextU + 1; } else pos = nv;
+                        }
+                    }
+                }
+                R.maxBad = max(P.maxBadKmers, (int)((float)((L >= k ? cnt : 0) - 1) * P.mkf));
+            }
+        }
+        const int start = R.start, stop = R.stop;
+        bool staged = false; int lastLo = 0;
+        for (int ci = max(start, k - 1); ci < stop; ci += LCHUNK) {
+            const int ce = min(stop, ci + LCHUNK);
+            const int lo = max(start, ci - (k - 1));
+            R.base0 = stage(off, lo, ce); staged = true; lastLo = lo;
+            R.start = lo; R.stop = ce; R.hasN = -1;
+            main_scan_pair<MODE, true, true>(P, Q, R, none, lane, ci);
+            R.start = start; R.stop = stop;
+            if (MODE == BBDUK_MODE_KTRIM_R && R.found > 0) break;                  // only the first hit matters (:2019-2030)
+            if (MODE == BBDUK_MODE_KFILTER && R.iFirst == 0) break;                // countSetKmers / countCoveredBases returned
+        }
+        if (MODE != BBDUK_MODE_KFILTER && P.useShort && R.found == 0) {            // :2034-2103: the end's short k-mers
+            if (MODE == BBDUK_MODE_KTRIM_L) R.base0 = stage(off, start, min(stop, start + k));
+            else if (!staged || lastLo > max(start, stop - k)) R.base0 = stage(off, max(start, stop - k), stop);
+            short_scan_pair<MODE, true>(P, Q, R, none, lane);
+        }
+    };
+    const int step = paired ? 2 : 1;
+    const int64_t units = (n + step - 1) / step;
+    unsigned long long rIn = 0, bIn = 0;
+    int acc[4] = {0, 0, 0, 0};
+    for (int64_t u = (int64_t)blockIdx.x * NWAVES + wave; u < units; u += (int64_t)gridDim.x * NWAVES) {
+        const int64_t ra = u * step;
+        const bool hasB = paired && (ra + 1) < n;
+        const int64_t o0 = offsets[ra], o1 = offsets[ra + 1], o2 = hasB ? offsets[ra + 2] : o1;
+        ReadScan A, Bz;
+        read_init<MODE, true, true>(P, A, 0, (int)(o1 - o0), 0, true);
+        read_init<MODE, true, true>(P, Bz, 0, (int)(o2 - o1), 1, hasB);
+        rIn += hasB ? 2 : 1; bIn += (unsigned long long)(o2 - o0);
+        scan_read(A, o0, 0, true);
+        if (hasB) scan_read(Bz, o1, 1, true);
+        ReadOut OA, OB;
+        read_finish<MODE>(P, A, OA, lane, scaf, counters);
+        read_finish<MODE>(P, Bz, OB, lane, scaf, counters);
+        uint8_t f1 = 0, f2 = 0;
+        record_stage<MODE>(P, OA, hasB ? &OB : nullptr, acc, f1, f2);
+        if (lane == 0) {
+            outA[ra] = OA.a; outId[ra] = OA.id; outFlags[ra] = f1;
+            if (hasB) { outA[ra + 1] = OB.a; outId[ra + 1] = OB.id; outFlags[ra + 1] = f2; }
+#pragma unroll
+            for (int q = 0; q < 4; q++) { if (acc[q]) atomicAdd(&s_acc[q], (unsigned long long)acc[q]); }     // per unit: these sums outgrow an int
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[q] = 0;
+    }
+    scaf_flush(P, scaf, lane, counters);
+    if (lane == 0) { atomicAdd(&s_acc[4], rIn); atomicAdd(&s_acc[5], bIn); }
+    __syncthreads();
+    if (tid == 0) publish_counters<MODE>(s_acc, counters);
+}
+
 // Pre-pass: does every unit (mate pair, or single read) fit a wave's planes?  One thread per unit.
 __global__ void bbduk_span_kernel(const int64_t* __restrict__ offsets, const int64_t n, const int paired, int* __restrict__ slowFlag) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int step = paired ? 2 : 1;
     const int64_t units = n / step;
-    bool bad = false;
-    for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += stride)
-        bad |= (offsets[u * step + step] - offsets[u * step]) > (int64_t)WUNIT_MAX;
+    bool bad = false, huge = false;
+    for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += stride) {
+        const int64_t len = offsets[u * step + step] - offsets[u * step];
+        bad |= len > (int64_t)WUNIT_MAX;
+        huge |= len > (int64_t)(CAP_BASES - 64);                  // not even the tile kernel's planes hold this unit: bbduk_long_kernel
+    }
     if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(slowFlag, 1);
+    if (__ballot(huge) && (threadIdx.x & 63) == 0) atomicOr(slowFlag, 2);
 }
 
 // runtime -> template dispatch
@@ -2711,6 +2852,14 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     HIP_TRY(h, hipEventRecord(h->ev1[evi], st));
     h->evCount++;
     kp.tile<<<dim3(tgrid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, h->d_slowFlag);
+    {   // reads beyond BBDUK_MAX_READ_LEN: chunked scan, one wave per unit (returns at once unless the pre-pass asked for it)
+        const batch_kernel_t lk = K.mode == BBDUK_MODE_KFILTER ? bbduk_long_kernel<BBDUK_MODE_KFILTER> :
+                                  (K.mode == BBDUK_MODE_KTRIM_L ? bbduk_long_kernel<BBDUK_MODE_KTRIM_L> : bbduk_long_kernel<BBDUK_MODE_KTRIM_R>);
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(lk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
+        const int64_t units = paired ? n / 2 : n;
+        const int lgrid = (int)std::min<int64_t>((units + NWAVES - 1) / NWAVES, (int64_t)h->numCU);
+        lk<<<dim3(std::max(lgrid, 1)), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, h->d_slowFlag);
+    }
     HIP_TRY(h, hipGetLastError());
     return BBDUK_OK;
 }

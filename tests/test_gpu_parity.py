@@ -152,10 +152,12 @@ def test_edge_shapes():
     longs = [util.rand_seq(rng, n, 0.001) + ad for n in (1000, 5000, 9000, 16000 - len(ad))]
     check_batch(d, o, longs, True)
     check_batch(d, o, longs + [util.rand_seq(rng, 40) + ad[:30]] * 301, False)
-    # too long -> explicit error, not a silent wrong answer
-    b, off = pack_reads([util.rand_seq(rng, 50000)])
+    # beyond BBDUK_MAX_READ_LEN the chunked kernel takes over (test_long_reads_*); the mask / tips / split operators say no
+    check_batch(d, o, [util.rand_seq(rng, 50000) + ad], False)
+    dm = B.BBDuk("ktrim=n k=23 ref=adapters")
     with pytest.raises(B.BBDukError):
-        d.gpu.process_batch(b, off, False)
+        dm.gpu.kmask_batch(*pack_reads([util.rand_seq(rng, 50000)]), False)
+    dm.close()
     # wrong operator for the mode, odd paired batch
     b, off = pack_reads([ad, ad, ad])
     with pytest.raises(B.BBDukError):
@@ -624,4 +626,50 @@ def test_ksplit_fuzz_parity(ci):
             d.gpu.process_batch(*pack_reads(reads[:4]), True)          # ksplit is for unpaired reads
         d.close()
     assert nsplit > 20
+
+
+# ---- reads longer than the LDS tiles: bbduk_long_kernel (chunked scan, state carried across chunks)
+LONG = [("ktrim=r k=23 mink=11 hdist=1", dict(k=23, ktrimRight=1, mink=11, hdist=1)), ("ktrim=l k=23 mink=11", dict(k=23, ktrimLeft=1, mink=11)),
+        ("ktrim=r k=25 forbidn=t tp=2 ktrimexclusive=t", dict(k=25, ktrimRight=1, forbidN=1, trimPad=2, ktrimExclusive=1)),
+        ("ktrim=l k=19 restrictleft=30000 qhdist=1", dict(k=19, ktrimLeft=1, restrictLeft=30000, qhdist=1)),
+        ("k=31 hdist=1", dict(k=31, hdist=1)), ("k=27 mbk=40 rieb=f", dict(k=27, maxBadKmers0=40, requireBothBad=1)),
+        ("k=25 mcf=0.01", dict(k=25, minCoveredFraction=0.01)), ("k=21 mkf=0.002 forbidn=t", dict(k=21, minKmerFraction=0.002, forbidN=1)),
+        ("k=31 restrictright=45000 qskip=3", dict(k=31, restrictRight=45000, qSkip=3)), ("ktrim=r k=21 mink=8 tpe minlen=100", dict(k=21, ktrimRight=1, mink=8, trimPairsEvenly=1, minReadLength=100))]
+
+
+@pytest.mark.parametrize("ci", range(len(LONG)))
+def test_long_reads_chunked_kernel(ci):
+    args, okw = LONG[ci]
+    rng = random.Random(33000 + ci)
+    refs = [util.rand_seq(rng, rng.randint(30, 120)) for _ in range(6)]
+    d, o = make_pair(args, okw, refs=refs)
+    reads = []
+    for L in (41000, 50000, 16385 * 3, 120000, 2432 * 20 + 7, 90000, 45000, 70001):
+        g = bytearray(util.rand_seq(rng, L, 0.0005))
+        for _ in range(rng.randint(0, 4)):                      # reference pieces anywhere, also across chunk borders and at the ends
+            r = rng.choice(refs); r = util.revcomp(r) if rng.random() < 0.5 else r
+            pos = rng.choice([0, L - len(r), rng.randrange(L - len(r)), 2432 * rng.randint(1, 15) - rng.randint(0, 40)])
+            g[pos:pos + len(r)] = r
+        if rng.random() < 0.5:
+            g[L - 14:] = rng.choice(refs)[:14]                   # a short k-mer at the very end
+        if rng.random() < 0.5:
+            g[:15] = rng.choice(refs)[-15:]
+        reads.append(bytes(g))
+    reads += util.fuzz_reads(rng, refs, 20, [0, 10, 150, 3000], junk=True)      # short mates ride along with long ones
+    rng.shuffle(reads)
+    check_batch(d, o, reads, True, nthreads=8)
+    check_batch(d, o, reads[:15], False, nthreads=8)
+    assert d.gpu.counters()[B.NCOUNTERS:].sum() > 0
+    d.close()
+
+
+def test_long_read_phix_genome_as_one_read():
+    """The whole phiX genome (5386 bases) repeated 40 times = one 215 kb read, against ref=phix: every k-mer hits."""
+    phix = B.read_fasta(util.PHIX)[0][1]
+    d, o = make_pair("k=31 mbk=100000 ref=phix", dict(k=31, maxBadKmers0=100000), ref_fasta=util.PHIX)
+    read = bytes(phix) * 40
+    check_batch(d, o, [read, read[:100000]], False)
+    a, ids, fl = d.gpu.process_batch(*pack_reads([read]), False)
+    assert a[0] == 100001 and fl[0] == 3                       # the early exit at maxBadKmers+1 (BBDukProcessorS.java:1572-1590)
+    d.close()
 
