@@ -73,6 +73,14 @@ def main():
         if fam in ("big", "fbm", "ksplit"):
             reads += util.long_refs_and_reads(rng)[1][:0]
             reads += [util.rand_seq(rng, rng.randint(0, 60)) + rng.choice(refs)[:rng.randint(20, 260)] + util.rand_seq(rng, rng.randint(0, 60)) for _ in range(100)]
+        if fam == "base" and rng.random() < 0.2:                # a few reads beyond the LDS tiles: the chunked long-read kernel takes the batch
+            for _ in range(rng.randint(1, 4)):
+                L = rng.randint(41000, 110000)
+                g = bytearray(util.rand_seq(rng, L, 0.0005))
+                for _ in range(rng.randint(0, 3)):
+                    r = rng.choice(refs); pos = rng.choice([0, L - len(r), rng.randrange(L - len(r)), 2432 * rng.randint(1, 15) - rng.randint(0, 40)])
+                    g[pos:pos + len(r)] = r
+                reads.insert(rng.randrange(len(reads) + 1), bytes(g))
         if len(reads) % 2: reads.append(b"")
         build = "device" if (rng.random() < 0.4 and okw.get("hdist", 0) <= 2 and "minSkip" not in okw) else "host"
         try:
