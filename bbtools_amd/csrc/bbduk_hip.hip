@@ -2521,6 +2521,9 @@ struct bbduk_handle {
     int* d_slowFlag = nullptr;
     static const int EV_RING = 64;                                // HIP events around the dominant kernel of the last launches
     hipEvent_t ev0[EV_RING] = {}, ev1[EV_RING] = {}; int64_t evCount = 0;
+    std::mutex launchMu;                                          // device-buffer operators may be issued from several host threads /
+                                                                  // streams at once: slot choice and enqueue of one launch are atomic,
+                                                                  // and every launch in flight has its own pre-pass flag (d_slowFlag[slot])
     // host-operator staging
     uint8_t* d_bases = nullptr; size_t cap_bases = 0;
     uint8_t* d_undef = nullptr; size_t cap_undef = 0;     // packed boundary: one undefined-base bit per base
@@ -2580,7 +2583,7 @@ extern "C" int bbduk_create(const bbduk_params* p, bbduk_handle** out) {
     if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return BBDUK_ERR_DEVICE; }
     const size_t nc = (size_t)(BBDUK_NCOUNTERS + 2 * p->numScaffolds);
     if (hipMalloc(&h->d_counters, nc * sizeof(int64_t)) != hipSuccess ||
-        hipMemset(h->d_counters, 0, nc * sizeof(int64_t)) != hipSuccess || hipMalloc(&h->d_slowFlag, sizeof(int)) != hipSuccess) { hipStreamDestroy(h->stream); delete h; return BBDUK_ERR_DEVICE; }
+        hipMemset(h->d_counters, 0, nc * sizeof(int64_t)) != hipSuccess || hipMalloc(&h->d_slowFlag, bbduk_handle::EV_RING * sizeof(int)) != hipSuccess) { hipStreamDestroy(h->stream); delete h; return BBDUK_ERR_DEVICE; }
     *out = h;
     return BBDUK_OK;
 }
@@ -2795,6 +2798,7 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
     const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
     const int grid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU);
+    std::lock_guard<std::mutex> lg(h->launchMu);
     const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
     if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
     HIP_TRY(h, hipEventRecord(h->ev0[evi], st));
@@ -2829,12 +2833,15 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)waveLds));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.tile), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
     // pre-pass: if some pair is longer than a wave's planes the tile kernel takes the whole batch, else the wave kernel
-    HIP_TRY(h, hipMemsetAsync(h->d_slowFlag, 0, sizeof(int), st));
-    if (getenv("BBDUK_FORCE_TILE")) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(h->d_slowFlag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }
+    std::lock_guard<std::mutex> lg(h->launchMu);
+    const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
+    int* const d_flag = h->d_slowFlag + evi;
+    HIP_TRY(h, hipMemsetAsync(d_flag, 0, sizeof(int), st));
+    if (getenv("BBDUK_FORCE_TILE")) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }
     else {
         const int64_t units = paired ? n / 2 : n;
         const int sgrid = (int)std::min<int64_t>((units + 255) / 256, (int64_t)h->numCU * 8);
-        bbduk_span_kernel<<<dim3(std::max(sgrid, 1)), dim3(256), 0, st>>>(d_offsets, n, (int)paired, h->d_slowFlag);
+        bbduk_span_kernel<<<dim3(std::max(sgrid, 1)), dim3(256), 0, st>>>(d_offsets, n, (int)paired, d_flag);
     }
     const int perCU = 1;                                            // 1024-thread workgroups; VGPR budget admits one per CU
     const int64_t nmt = (n + MT_READS - 1) / MT_READS;
@@ -2845,20 +2852,19 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kp.wave), BLOCK_THREADS, waveLds);
         fprintf(stderr, "[bbduk] wave grid=%d tile grid=%d block=%d dynLds=%zu occupancyAPI=%d numCU=%d\n", wgrid, tgrid, BLOCK_THREADS, dynLds, occ, h->numCU);
     }
-    const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
     if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
     HIP_TRY(h, hipEventRecord(h->ev0[evi], st));
-    kp.wave<<<dim3(wgrid), dim3(BLOCK_THREADS), waveLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, h->d_slowFlag);
+    kp.wave<<<dim3(wgrid), dim3(BLOCK_THREADS), waveLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
     HIP_TRY(h, hipEventRecord(h->ev1[evi], st));
     h->evCount++;
-    kp.tile<<<dim3(tgrid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, h->d_slowFlag);
+    kp.tile<<<dim3(tgrid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
     {   // reads beyond BBDUK_MAX_READ_LEN: chunked scan, one wave per unit (returns at once unless the pre-pass asked for it)
         const batch_kernel_t lk = K.mode == BBDUK_MODE_KFILTER ? bbduk_long_kernel<BBDUK_MODE_KFILTER> :
                                   (K.mode == BBDUK_MODE_KTRIM_L ? bbduk_long_kernel<BBDUK_MODE_KTRIM_L> : bbduk_long_kernel<BBDUK_MODE_KTRIM_R>);
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(lk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
         const int64_t units = paired ? n / 2 : n;
         const int lgrid = (int)std::min<int64_t>((units + NWAVES - 1) / NWAVES, (int64_t)h->numCU);
-        lk<<<dim3(std::max(lgrid, 1)), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, h->d_slowFlag);
+        lk<<<dim3(std::max(lgrid, 1)), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
     }
     HIP_TRY(h, hipGetLastError());
     return BBDUK_OK;
@@ -2985,6 +2991,7 @@ static int launch_tips(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bbduk_ktrimtips_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
     const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
     const int grid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU);
+    std::lock_guard<std::mutex> lg(h->launchMu);
     const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
     if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
     HIP_TRY(h, hipEventRecord(h->ev0[evi], st));
@@ -3053,6 +3060,7 @@ static int launch_kmask(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     HIP_TRY(h, hipMemsetAsync(d_mask, 0, ((size_t)(total_bases + 31) / 32 + 2) * sizeof(uint32_t), st));
     const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
     const int grid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU);
+    std::lock_guard<std::mutex> lg(h->launchMu);
     const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
     if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
     HIP_TRY(h, hipEventRecord(h->ev0[evi], st));

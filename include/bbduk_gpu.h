@@ -140,7 +140,8 @@ int  bbduk_kfilter_batch(bbduk_handle* h, const uint8_t* bases, const int64_t* o
                          uint8_t* out_flags);
 
 /* ---- device-buffer operators: every pointer is HBM; d_bases must be 16-byte aligned; `stream` is a
- * hipStream_t (NULL = default stream).  Asynchronous: returns after enqueue.  d_counters is an int64
+ * hipStream_t (NULL = default stream).  Asynchronous: returns after enqueue.  One handle may be driven from several
+ * host threads on several streams at once (at most 64 launches in flight per handle).  d_counters is an int64
  * vector of bbduk_counters_len(h) that the kernel accumulates into (caller zeroes it).                 */
 int  bbduk_ktrim_batch_device(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d_offsets, int64_t n,
                               int64_t total_bases, int32_t paired, int32_t* d_out_trimmed, int32_t* d_out_id0,

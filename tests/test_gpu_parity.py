@@ -673,3 +673,48 @@ def test_long_read_phix_genome_as_one_read():
     assert a[0] == 100001 and fl[0] == 3                       # the early exit at maxBadKmers+1 (BBDukProcessorS.java:1572-1590)
     d.close()
 
+
+
+def test_concurrent_device_operators_on_streams():
+    """Device-buffer operators of ONE handle issued from several host threads on their own streams: every launch has its own
+    pre-pass flag, so a batch that needs the tile / long-read kernel cannot redirect a neighbour's launch."""
+    import threading
+    import torch
+    args, okw, ref = util.CONFIGS["c2"]
+    d, o = make_pair(args, okw, ref_fasta=ref)
+    rng = random.Random(12)
+    ad = B.TRUSEQ_R1
+    plain = [util.rand_seq(rng, 150) if i % 3 else util.rand_seq(rng, 100) + ad[:50] for i in range(4000)]
+    tile = plain[:2000] + [util.rand_seq(rng, 3000) + ad, util.rand_seq(rng, 100)]                  # one pair beyond a wave's planes
+    longb = plain[:1000] + [util.rand_seq(rng, 60000) + ad, util.rand_seq(rng, 90)]                 # one read beyond the LDS tiles
+    batches = [plain, tile, longb, plain[:1500], tile[100:], longb[200:]]
+    want = []
+    for rd in batches:
+        b, off = pack_reads(rd)
+        want.append(o.process_batch(b, off, True, nthreads=4))
+    got = [None] * len(batches)
+    errs = []
+
+    def work(t):
+        try:
+            b, off = pack_reads(batches[t])
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                db = torch.from_numpy(np.concatenate([b, np.zeros(16, np.uint8)])).cuda()[:len(b)]; do = torch.from_numpy(off).cuda()
+                n = len(off) - 1
+                da = torch.empty(n, dtype=torch.int32, device="cuda"); di = torch.empty_like(da); df = torch.empty(n, dtype=torch.uint8, device="cuda")
+                dc = torch.zeros(d.gpu.counters_len, dtype=torch.int64, device="cuda")
+                for _ in range(20):
+                    d.gpu.process_batch_device(db, do, True, da, di, df, dc, st.cuda_stream)
+                st.synchronize()
+                got[t] = (da.cpu().numpy(), di.cpu().numpy(), df.cpu().numpy())
+        except Exception as e:                                   # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(t,)) for t in range(len(batches))]
+    for x in th: x.start()
+    for x in th: x.join()
+    assert not errs, errs
+    for t in range(len(batches)):
+        for g, w in zip(got[t], want[t]):
+            assert np.array_equal(g, w), t
+    d.close()
