@@ -1300,7 +1300,7 @@ __global__ __launch_bounds__(BLOCK_THREADS)
 void bbduk_kmask_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
                         const int64_t n, const int64_t totalBases, const int paired,
                         int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
-                        uint32_t* __restrict__ outMask, int64_t* __restrict__ counters) {
+                        uint32_t* __restrict__ outMask, int64_t* __restrict__ counters, int* __restrict__ longFlag) {
     __shared__ uint32_t s_fwd[PLANE_PAD + KM_CAP_CHUNKS + PLANE_PAD];
     __shared__ uint32_t s_cmp[PLANE_PAD + KM_CAP_CHUNKS + PLANE_PAD];
     __shared__ uint32_t s_nm[KM_CAP_CHUNKS / 2 + 4];
@@ -1333,8 +1333,8 @@ void bbduk_kmask_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
             const int cand = s + 1 + tid;
             const int okc = (cand <= cnt) && (s_off[min(cand, cnt)] - off_s <= (int64_t)(KM_CAP_BASES - 32));
             const int fit = uni(__syncthreads_count(okc));
-            if (fit == 0) {                                         // a read longer than BBDUK_MAX_READ_LEN
-                if (tid == 0) { atomicMax((unsigned long long*)&counters[BBDUK_CTR_STATUS], (unsigned long long)(-BBDUK_ERR_READ_TOO_LONG)); s_a[s] = 0; s_id[s] = -1; }
+            if (fit == 0) {                                         // a read beyond these planes: bbduk_kmask_long_kernel masks it (its
+                if (tid == 0) { *longFlag = 1; s_a[s] = -1; s_id[s] = -1; }    // flags depend on lengths only and are written below)
                 s += 1;
                 continue;
             }
@@ -1461,7 +1461,7 @@ void bbduk_kmask_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
                 remove = (P.rieb && (d || dm)) || (d && dm);
             }
             const int a = s_a[tid];
-            outA[r0 + tid] = a; outId[r0 + tid] = s_id[tid];
+            if (a >= 0) { outA[r0 + tid] = a; outId[r0 + tid] = s_id[tid]; }       // a < 0: left to bbduk_kmask_long_kernel
             outFlags[r0 + tid] = (uint8_t)((d ? BBDUK_FLAG_DISCARDED : 0) | (remove ? BBDUK_FLAG_REMOVED : 0));
             if (a > 0) { atomicAdd(&s_acc[0], 1ULL); atomicAdd(&s_acc[1], (unsigned long long)a); }     // rktsum / xsum: unchanged by removal (ktrimN)
             if (remove) { atomicAdd(&s_acc[2], 1ULL); atomicAdd(&s_acc[3], (unsigned long long)L1); }
@@ -2426,6 +2426,176 @@ void bbduk_long_kernel(const KParams P, const uint8_t* __restrict__ bases, const
     if (tid == 0) publish_counters<MODE>(s_acc, counters);
 }
 
+// ktrim=n for sequences beyond bbduk_kmask_kernel's planes (contigs, long reads): one wave per such read, chunked like
+// bbduk_long_kernel.  Every hit ORs its k (+trimPad) bases straight into the output mask (hits are rare; the in-LDS
+// coverage pass of the tiled kernel needs the whole read), the short k-mers of both ends add their end ranges, and
+// BitSet.cardinality() is read back from the mask words of this read plus the bits a positive trimPad pushes past the
+// end.  Pair flags depend on lengths only and were written by bbduk_kmask_kernel; this kernel adds the read's counters.
+__global__ __launch_bounds__(BLOCK_THREADS)
+void bbduk_kmask_long_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
+                             const int64_t n, const int64_t totalBases, const int paired,
+                             int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint32_t* __restrict__ outMask,
+                             int64_t* __restrict__ counters, const int* __restrict__ longFlag) {
+    if (*longFlag == 0) return;
+    __shared__ uint32_t s_wf[NWAVES * WPLANE_WORDS];
+    __shared__ uint32_t s_wc[NWAVES * WPLANE_WORDS];
+    __shared__ uint32_t s_wn[NWAVES * WNM_WORDS];
+    extern __shared__ uint32_t s_filt[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+    const int k = P.k, tp = P.trimPad;
+    ScafAcc scaf; scaf_init(scaf);
+    if (P.ldsBits) {
+        const int words = 1 << (P.ldsBits - 5);
+        for (int w = tid; w < words; w += BLOCK_THREADS) s_filt[w] = P.ldsImage[w];
+    }
+    __syncthreads();
+    uint32_t* const wf = s_wf + wave * WPLANE_WORDS; uint32_t* const wc = s_wc + wave * WPLANE_WORDS; uint32_t* const wn = s_wn + wave * WNM_WORDS;
+    Planes Q; Q.fwd = wf + PLANE_PAD; Q.cmp = wc + PLANE_PAD; Q.nm = wn; Q.filt = s_filt; Q.T = 0;
+    Q.fwdBits = lds_bits_of(Q.fwd); Q.cmpBits = lds_bits_of(Q.cmp);
+    auto stage = [&](const int64_t off, const int lo, const int hi) -> int {
+        const int64_t A0 = (off + lo) & ~15LL;
+        const int nchunks = (int)((off + hi - A0 + 15) >> 4);
+        for (int c = lane; c < nchunks; c += 64) {
+            uint32_t r, comp, valid;
+            stage_chunk(P, bases, A0 + 16LL * c, totalBases, r, comp, valid);
+            wf[PLANE_PAD + nchunks - 1 - c] = r;
+            wc[PLANE_PAD + c] = comp;
+            reinterpret_cast<uint16_t*>(wn)[c] = (uint16_t)(~valid & 0xFFFFu);
+        }
+        if (lane == 0) { reinterpret_cast<uint16_t*>(wn)[nchunks] = 0; reinterpret_cast<uint16_t*>(wn)[nchunks + 1] = 0; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        Q.T = nchunks * 16;
+        return (int)(off - A0);
+    };
+    // set mask bits [g0+lo, g0+hi) (read-relative lo/hi clipped to [0, L)); wave-cooperative, 32 bits per lane
+    auto set_range = [&](const int64_t g0, int lo, int hi, const int L) {
+        lo = max(lo, 0); hi = min(hi, L);
+        if (lo >= hi) return;
+        const int64_t a = g0 + lo, b = g0 + hi;
+        for (int64_t w = (a >> 5) + lane; w <= ((b - 1) >> 5); w += 64) {
+            uint32_t m = ~0u;
+            if ((w << 5) < a) m &= ~0u << (int)(a - (w << 5));
+            if ((w << 5) + 32 > b) m &= ~0u >> (int)((w << 5) + 32 - b);
+            atomicOr(&outMask[w], m);
+        }
+    };
+    unsigned long long rkt = 0, xs = 0;
+    for (int64_t rd = (int64_t)blockIdx.x * NWAVES + wave; rd < n; rd += (int64_t)gridDim.x * NWAVES) {
+        const int64_t off = offsets[rd];
+        const int64_t L64 = offsets[rd + 1] - off;
+        if (L64 <= (int64_t)(KM_CAP_BASES - 32)) continue;          // bbduk_kmask_kernel did this one
+        const int L = (int)L64;
+        const int pairnum = paired ? (int)(rd & 1) : 0;
+        ReadScan R;
+        R.L = L; R.hasN = -1; R.maxBad = 0; R.base0 = 0;
+        R.start = span_start<true>(P, L); R.stop = span_stop<true>(P, L);
+        R.scan = P.storedKmers > 0 && L >= k && !((P.skipR1 && pairnum == 0) || (P.skipR2 && pairnum == 1));   // :2151-2154
+        int found = 0, id0 = -1, iLast = -1;
+        if (R.scan) {
+            const int start = R.start, stop = R.stop;
+            for (int ci = max(start, k - 1); ci < stop; ci += LCHUNK) {
+                const int ce = min(stop, ci + LCHUNK);
+                const int lo = max(start, ci - (k - 1));
+                ReadScan C = R; C.base0 = stage(off, lo, ce); C.start = lo; C.stop = ce; C.hasN = -1;
+                ReadWin W;
+                win_init<true, true>(P, Q, C, W, lane);
+                W.first = max(W.first, ci); W.on = W.first < W.stop;
+                for (int ib = W.first; W.on && ib < W.stop; ib += 256) {
+                    uint64_t kmer[4], rk[4]; bool ok[4]; int ref[4];
+                    windows2<true, true>(P, Q, W, ib + 2 * lane, true, kmer, rk, ok);
+                    if (ib + 128 < W.stop) windows2<true, true>(P, Q, W, ib + 128 + 2 * lane, true, kmer + 2, rk + 2, ok + 2);
+                    else { kmer[2] = kmer[3] = 0; rk[2] = rk[3] = 0; ok[2] = ok[3] = false; }
+                    lookup4<true>(P, Q.filt, kmer, rk, ok, ref);
+#pragma unroll
+                    for (int hb = 0; hb < 2; hb++) {
+                        const uint64_t me = __ballot(ref[2 * hb] != -1), mo = __ballot(ref[2 * hb + 1] != -1);
+                        if (!(me | mo)) continue;
+                        const int i0 = ib + 128 * hb;
+                        if (id0 < 0) {
+                            const int le = me ? __ffsll((unsigned long long)me) - 1 : 64, lo2 = mo ? __ffsll((unsigned long long)mo) - 1 : 64;
+                            id0 = (2 * lo2 + 1 < 2 * le) ? __builtin_amdgcn_readlane(ref[2 * hb + 1], lo2) : __builtin_amdgcn_readlane(ref[2 * hb], le);
+                        }
+                        const int he = me ? 63 - __clzll((unsigned long long)me) : -1, ho = mo ? 63 - __clzll((unsigned long long)mo) : -1;
+                        iLast = max(iLast, i0 + max(2 * he, 2 * ho + 1));
+                        found += __popcll(me) + __popcll(mo);
+#pragma unroll
+                        for (int par = 0; par < 2; par++) {            // bs.set(max(0,i-minus), i+plus) for this lane's hit (:2190)
+                            if (ref[2 * hb + par] != -1) {
+                                const int i = i0 + 2 * lane + par;
+                                const int b0 = max(0, i - (k - 1 - tp)), b1 = min(L, i + tp + 1);
+                                if (b0 < b1) {
+                                    const int64_t a = off + b0, b = off + b1;   // at most k+|tp| <= 64 bits: up to three words
+                                    for (int64_t w = a >> 5; w <= ((b - 1) >> 5); w++) {
+                                        uint32_t m = ~0u;
+                                        if ((w << 5) < a) m &= ~0u << (int)(a - (w << 5));
+                                        if ((w << 5) + 32 > b) m &= ~0u >> (int)((w << 5) + 32 - b);
+                                        atomicOr(&outMask[w], m);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (P.useShort) {                                       // both ends, always (:2199-2283); see bbduk_kmask_kernel
+                int leftEnd = 0, rightStart = L;
+                for (int side = 0; side < 2; side++) {
+                    const bool right = side == 1;
+                    const int Ls = P.mink + lane;                   // one length per lane (k - mink < 64)
+                    bool act; int i; uint64_t km = 0, rr = 0;
+                    const int b0 = right ? stage(off, max(R.start, R.stop - k), R.stop) : stage(off, R.start, min(R.stop, R.start + k));
+                    if (!right) {
+                        const int Lmax = min(k, R.stop) - R.start;
+                        act = Ls <= Lmax; i = R.start + Ls - 1;
+                        const int Lc = act ? Ls : 1;
+                        if (act) { km = extract2(Q.fwd, Q.T - 1 - (b0 + R.start + Lc - 1), Lc) & P.mask; rr = extract2(Q.cmp, b0 + R.start, Lc); }
+                    } else {
+                        const int Lmax = (R.stop >= k ? k - 1 : R.stop);
+                        act = Ls <= Lmax; i = R.stop - Ls;
+                        const int Lc = act ? Ls : 1;
+                        if (act) { km = extract2(Q.fwd, Q.T - 1 - (b0 + R.stop - 1), Lc); rr = extract2(Q.cmp, b0 + R.stop - Lc, Lc) & P.mask; }
+                    }
+                    if (P.qskip > 1) act = act && (i % P.qskip) == 0;
+                    const int Lc = act ? Ls : 1;
+                    const int sref = lookup<true>(P, Q.filt, km, rr, 1ULL << (2 * Lc), Lc, P.qhdist2, act);
+                    const uint64_t hm = __ballot(sref != -1);
+                    if (hm) {
+                        if (id0 < 0) id0 = __builtin_amdgcn_readlane(sref, __ffsll((unsigned long long)hm) - 1);     // left side first, shortest first
+                        found += __popcll(hm);
+                        const int longest = P.mink + (63 - __clzll((unsigned long long)hm));
+                        if (!right) leftEnd = max(0, min(L, R.start + longest - 1 + tp + 1));                           // :2236
+                        else rightStart = min(L, max(0, R.stop - longest - tp));                                        // :2279
+                    }
+                }
+                if (found > 0) { set_range(off, 0, leftEnd, L); set_range(off, rightStart, L, L); }
+            }
+        }
+        int card = 0;
+        if (found > 0) {
+            scaf_add(P, scaf, id0, L, lane, counters);
+            __threadfence();
+            int c = 0;
+            const int64_t a = off, b = off + L;
+            for (int64_t w = (a >> 5) + lane; w <= ((b - 1) >> 5); w += 64) {
+                uint32_t v = atomicOr(&outMask[w], 0u);             // read at the coherence point: this wave's own atomics are in
+                if ((w << 5) < a) v &= ~0u << (int)(a - (w << 5));
+                if ((w << 5) + 32 > b) v &= ~0u >> (int)((w << 5) + 32 - b);
+                c += __popc(v);
+            }
+            card = wave_sum(c) + max(0, min(iLast + tp + 1, L + max(tp, 0) + 1) - L);   // bits a positive trimPad pushes past the end
+        }
+        if (lane == 0) { outA[rd] = card; outId[rd] = found > 0 ? id0 : -1; }
+        if (card > 0) { rkt += 1; xs += (unsigned long long)card; }
+    }
+    scaf_flush(P, scaf, lane, counters);
+    if (lane == 0) {
+        if (rkt) atomicAdd((unsigned long long*)&counters[BBDUK_READS_KTRIMMED], rkt);
+        if (xs) atomicAdd((unsigned long long*)&counters[BBDUK_BASES_KTRIMMED], xs);
+    }
+}
+
 // Pre-pass: does every unit (mate pair, or single read) fit a wave's planes?  One thread per unit.
 __global__ void bbduk_span_kernel(const int64_t* __restrict__ offsets, const int64_t n, const int paired, int* __restrict__ slowFlag) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -3062,11 +3232,16 @@ static int launch_kmask(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     const int grid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU);
     std::lock_guard<std::mutex> lg(h->launchMu);
     const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
+    int* const d_flag = h->d_slowFlag + evi;
+    HIP_TRY(h, hipMemsetAsync(d_flag, 0, sizeof(int), st));
     if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
     HIP_TRY(h, hipEventRecord(h->ev0[evi], st));
-    bbduk_kmask_kernel<<<dim3(grid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_mask, d_counters);
+    bbduk_kmask_kernel<<<dim3(grid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_mask, d_counters, d_flag);
     HIP_TRY(h, hipEventRecord(h->ev1[evi], st));
     h->evCount++;
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bbduk_kmask_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
+    const int lgrid = (int)std::min<int64_t>((n + NWAVES - 1) / NWAVES, (int64_t)h->numCU);     // sequences beyond the tiled kernel's planes
+    bbduk_kmask_long_kernel<<<dim3(std::max(lgrid, 1)), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_mask, d_counters, d_flag);
     HIP_TRY(h, hipGetLastError());
     return BBDUK_OK;
 }

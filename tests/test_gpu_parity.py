@@ -152,11 +152,11 @@ def test_edge_shapes():
     longs = [util.rand_seq(rng, n, 0.001) + ad for n in (1000, 5000, 9000, 16000 - len(ad))]
     check_batch(d, o, longs, True)
     check_batch(d, o, longs + [util.rand_seq(rng, 40) + ad[:30]] * 301, False)
-    # beyond BBDUK_MAX_READ_LEN the chunked kernel takes over (test_long_reads_*); the mask / tips / split operators say no
+    # beyond BBDUK_MAX_READ_LEN the chunked kernels take over (test_long_reads_*, test_kmask_long_sequences); tips / split say no
     check_batch(d, o, [util.rand_seq(rng, 50000) + ad], False)
-    dm = B.BBDuk("ktrim=n k=23 ref=adapters")
+    dm = B.BBDuk("ktrim=rl k=23 ref=adapters")
     with pytest.raises(B.BBDukError):
-        dm.gpu.kmask_batch(*pack_reads([util.rand_seq(rng, 50000)]), False)
+        dm.gpu.ktrimtips_batch(*pack_reads([util.rand_seq(rng, 50000)]), False)
     dm.close()
     # wrong operator for the mode, odd paired batch
     b, off = pack_reads([ad, ad, ad])
@@ -718,3 +718,36 @@ def test_concurrent_device_operators_on_streams():
         for g, w in zip(got[t], want[t]):
             assert np.array_equal(g, w), t
     d.close()
+
+
+KMASK_LONG = [("ktrim=n k=23", dict(k=23, ktrimN=1)), ("ktrim=N k=21 mink=9 hdist=1 tp=2", dict(k=21, ktrimN=1, mink=9, hdist=1, trimPad=2)),
+              ("kmask=lc k=25 tp=-3 forbidn=t", dict(k=25, ktrimN=1, trimPad=-3, forbidN=1)), ("ktrim=n k=19 mink=7 restrictleft=60000 qhdist=1 skipr2=t", dict(k=19, ktrimN=1, mink=7, restrictLeft=60000, qhdist=1, skipR2=1)),
+              ("ktrim=n k=27 restrictright=50000 minlen=45000 rieb=f", dict(k=27, ktrimN=1, restrictRight=50000, minReadLength=45000, requireBothBad=1))]
+
+
+@pytest.mark.parametrize("ci", range(len(KMASK_LONG)))
+def test_kmask_long_sequences(ci):
+    """ktrim=n on sequences beyond the tiled kernel's planes (contigs): bbduk_kmask_long_kernel, mixed with short reads."""
+    args, okw = KMASK_LONG[ci]
+    rng = random.Random(44000 + ci)
+    refs = [util.rand_seq(rng, rng.randint(30, 120)) for _ in range(6)]
+    d, o = make_pair(args, okw, refs=refs)
+    reads = []
+    for L in (33000, 50000, 2432 * 20 + 7, 120000, 70001, 40000):
+        g = bytearray(util.rand_seq(rng, L, 0.0005))
+        for _ in range(rng.randint(0, 5)):
+            r = rng.choice(refs); r = util.revcomp(r) if rng.random() < 0.5 else r
+            pos = rng.choice([0, L - len(r), rng.randrange(L - len(r)), 2432 * rng.randint(1, 13) - rng.randint(0, 40)])
+            g[pos:pos + len(r)] = r
+        if rng.random() < 0.6:
+            g[L - 14:] = rng.choice(refs)[:14]
+        if rng.random() < 0.6:
+            g[:15] = rng.choice(refs)[-15:]
+        reads.append(bytes(g))
+    reads += util.fuzz_reads(rng, refs, 30, [0, 10, 150, 3000], junk=True)
+    rng.shuffle(reads)
+    check_kmask(d, o, reads, True)
+    check_kmask(d, o, reads[:17], False)
+    assert d.gpu.counters()[3] > 0
+    d.close()
+
