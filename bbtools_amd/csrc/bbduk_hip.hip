@@ -1765,7 +1765,8 @@ __global__ __launch_bounds__(BLOCK_THREADS)
 void bbduk_ktrimtips_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
                             const int64_t n, const int64_t totalBases, const int paired,
                             int32_t* __restrict__ outRight, int32_t* __restrict__ outLeft, int32_t* __restrict__ outId,
-                            uint8_t* __restrict__ outFlags, int64_t* __restrict__ counters) {
+                            uint8_t* __restrict__ outFlags, int64_t* __restrict__ counters, const int* __restrict__ longFlag) {
+    if (*longFlag & 2) return;                                    // a read beyond these planes: bbduk_long_tips_kernel takes the batch
     __shared__ uint32_t s_fwd[PLANE_PAD + KM_CAP_CHUNKS + PLANE_PAD];
     __shared__ uint32_t s_cmp[PLANE_PAD + KM_CAP_CHUNKS + PLANE_PAD];
     __shared__ uint32_t s_nm[KM_CAP_CHUNKS / 2 + 4];
@@ -2300,6 +2301,32 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
 // of an end are looked up on a small chunk staged for that end.  Run-time-general scan functions; any read length that
 // fits an int.  Takes the whole batch when the pre-pass finds such a read (long-read data sets consist of them).
 #define LCHUNK (WCAP_BASES - 128)
+// The chunk loop of a long read for one scan span [R.start, R.stop) (bbduk_long_kernel, bbduk_long_tips_kernel).
+// stage(off, lo, hi) puts bases [lo, hi) of the read at `off` into the wave's planes and returns the plane index of base 0.
+template <int MODE, class Stage>
+__device__ __forceinline__ void long_scan(const KParams& P, const Planes& Q, Stage& stage, ReadScan& R, const int64_t off, const int lane) {
+    if (!R.scan) return;
+    const int k = P.k;
+    ReadScan none; read_init<MODE, true, true>(P, none, 0, 0, 0, false);
+    const int start = R.start, stop = R.stop;
+    bool staged = false; int lastLo = 0;
+    for (int ci = max(start, k - 1); ci < stop; ci += LCHUNK) {
+        const int ce = min(stop, ci + LCHUNK);
+        const int lo = max(start, ci - (k - 1));
+        R.base0 = stage(off, lo, ce); staged = true; lastLo = lo;
+        R.start = lo; R.stop = ce; R.hasN = -1;
+        main_scan_pair<MODE, true, true>(P, Q, R, none, lane, ci);
+        R.start = start; R.stop = stop;
+        if (MODE == BBDUK_MODE_KTRIM_R && R.found > 0) break;                  // only the first hit matters (:2019-2030)
+        if (MODE == BBDUK_MODE_KFILTER && R.iFirst == 0) break;                // countSetKmers / countCoveredBases returned
+    }
+    if (MODE != BBDUK_MODE_KFILTER && P.useShort && R.found == 0) {            // :2034-2103: the end's short k-mers
+        if (MODE == BBDUK_MODE_KTRIM_L) R.base0 = stage(off, start, min(stop, start + k));
+        else if (!staged || lastLo > max(start, stop - k)) R.base0 = stage(off, max(start, stop - k), stop);
+        short_scan_pair<MODE, true>(P, Q, R, none, lane);
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(BLOCK_THREADS)
 void bbduk_long_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
@@ -2345,7 +2372,6 @@ void bbduk_long_kernel(const KParams P, const uint8_t* __restrict__ bases, const
     };
     auto scan_read = [&](ReadScan& R, const int64_t off, const int pairnum, const bool present) {
         const int L = R.L;
-        ReadScan none; read_init<MODE, true, true>(P, none, 0, 0, 0, false);
         if (MODE == BBDUK_MODE_KFILTER && P.mcf > 0.f) R.maxBad = (int)ceilf(P.mcf * (float)L);    // :1040 (also for reads that are not scanned)
         if (MODE == BBDUK_MODE_KFILTER && P.mkf != 0.f && L < k) R.maxBad = max(P.maxBadKmers, (int)((float)(0 - 1) * P.mkf));
         if (!R.scan) return;
@@ -2374,23 +2400,7 @@ void bbduk_long_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                 R.maxBad = max(P.maxBadKmers, (int)((float)((L >= k ? cnt : 0) - 1) * P.mkf));
             }
         }
-        const int start = R.start, stop = R.stop;
-        bool staged = false; int lastLo = 0;
-        for (int ci = max(start, k - 1); ci < stop; ci += LCHUNK) {
-            const int ce = min(stop, ci + LCHUNK);
-            const int lo = max(start, ci - (k - 1));
-            R.base0 = stage(off, lo, ce); staged = true; lastLo = lo;
-            R.start = lo; R.stop = ce; R.hasN = -1;
-            main_scan_pair<MODE, true, true>(P, Q, R, none, lane, ci);
-            R.start = start; R.stop = stop;
-            if (MODE == BBDUK_MODE_KTRIM_R && R.found > 0) break;                  // only the first hit matters (:2019-2030)
-            if (MODE == BBDUK_MODE_KFILTER && R.iFirst == 0) break;                // countSetKmers / countCoveredBases returned
-        }
-        if (MODE != BBDUK_MODE_KFILTER && P.useShort && R.found == 0) {            // :2034-2103: the end's short k-mers
-            if (MODE == BBDUK_MODE_KTRIM_L) R.base0 = stage(off, start, min(stop, start + k));
-            else if (!staged || lastLo > max(start, stop - k)) R.base0 = stage(off, max(start, stop - k), stop);
-            short_scan_pair<MODE, true>(P, Q, R, none, lane);
-        }
+        long_scan<MODE>(P, Q, stage, R, off, lane);
     };
     const int step = paired ? 2 : 1;
     const int64_t units = (n + step - 1) / step;
@@ -2596,16 +2606,131 @@ void bbduk_kmask_long_kernel(const KParams P, const uint8_t* __restrict__ bases,
     }
 }
 
+// ktrim=rl / ktrimtips for reads beyond bbduk_ktrimtips_kernel's planes (long-read adapter trimming): one wave per unit,
+// the right pass and then the left pass of every read through long_scan, pair logic as in the tiled kernel's record stage.
+__global__ __launch_bounds__(BLOCK_THREADS)
+void bbduk_long_tips_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
+                            const int64_t n, const int64_t totalBases, const int paired,
+                            int32_t* __restrict__ outRight, int32_t* __restrict__ outLeft, int32_t* __restrict__ outId,
+                            uint8_t* __restrict__ outFlags, int64_t* __restrict__ counters, const int* __restrict__ longFlag) {
+    if ((*longFlag & 2) == 0) return;
+    __shared__ uint32_t s_wf[NWAVES * WPLANE_WORDS];
+    __shared__ uint32_t s_wc[NWAVES * WPLANE_WORDS];
+    __shared__ uint32_t s_wn[NWAVES * WNM_WORDS];
+    __shared__ unsigned long long s_acc[6];
+    extern __shared__ uint32_t s_filt[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+    const int k = P.k;
+    ScafAcc scaf; scaf_init(scaf);
+    if (tid < 6) s_acc[tid] = 0;
+    if (P.ldsBits) {
+        const int words = 1 << (P.ldsBits - 5);
+        for (int w = tid; w < words; w += BLOCK_THREADS) s_filt[w] = P.ldsImage[w];
+    }
+    __syncthreads();
+    uint32_t* const wf = s_wf + wave * WPLANE_WORDS; uint32_t* const wc = s_wc + wave * WPLANE_WORDS; uint32_t* const wn = s_wn + wave * WNM_WORDS;
+    Planes Q; Q.fwd = wf + PLANE_PAD; Q.cmp = wc + PLANE_PAD; Q.nm = wn; Q.filt = s_filt; Q.T = 0;
+    Q.fwdBits = lds_bits_of(Q.fwd); Q.cmpBits = lds_bits_of(Q.cmp);
+    auto stage = [&](const int64_t off, const int lo, const int hi) -> int {
+        const int64_t A0 = (off + lo) & ~15LL;
+        const int nchunks = (int)((off + hi - A0 + 15) >> 4);
+        for (int c = lane; c < nchunks; c += 64) {
+            uint32_t r, comp, valid;
+            stage_chunk(P, bases, A0 + 16LL * c, totalBases, r, comp, valid);
+            wf[PLANE_PAD + nchunks - 1 - c] = r;
+            wc[PLANE_PAD + c] = comp;
+            reinterpret_cast<uint16_t*>(wn)[c] = (uint16_t)(~valid & 0xFFFFu);
+        }
+        if (lane == 0) { reinterpret_cast<uint16_t*>(wn)[nchunks] = 0; reinterpret_cast<uint16_t*>(wn)[nchunks + 1] = 0; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        Q.T = nchunks * 16;
+        return (int)(off - A0);
+    };
+    auto reset = [&](ReadScan& R, int len, int start, int stop, bool scan) {
+        R.base0 = 0; R.L = len; R.hasN = -1; R.maxBad = 0; R.start = start; R.stop = stop; R.scan = scan;
+        R.found = 0; R.iFirst = BIGLOC; R.iLast = -1; R.ref = -1; R.shortFl = -1; R.shortLl = -1;
+    };
+    // ktrimTips of one read (:1813-1828): returns the two amounts, the new length and the credited id
+    auto tips = [&](const int64_t off, const int L, const int pairnum, int& xr, int& xl, int& cur, int& id) {
+        const int mid = L / 2 - (k - 1) / 2;
+        int idr = -1, idl = -1;
+        xr = 0; xl = 0; cur = L;
+        ReadScan A;
+        {
+            const int start = max(0, P.restrictRight < 1 ? mid : L - P.restrictRight);
+            reset(A, cur, start, cur, scan_due<BBDUK_MODE_KTRIM_R, true, true>(P, cur, pairnum, true));
+            long_scan<BBDUK_MODE_KTRIM_R>(P, Q, stage, A, off, lane);
+            int a, newLen, ref; bool hit;
+            finish_read<BBDUK_MODE_KTRIM_R>(P, cur, A.start, A.stop, A.found, A.iFirst, A.iLast, A.shortFl, A.shortLl, A.ref, a, newLen, ref, hit);
+            if (A.scan) { if (hit) { idr = ref; scaf_add(P, scaf, idr, cur, lane, counters); } xr = a; cur = newLen; }
+        }
+        {
+            const int stop = min(cur, P.restrictLeft < 1 ? mid + k - 1 : P.restrictLeft);
+            reset(A, cur, 0, stop, scan_due<BBDUK_MODE_KTRIM_L, true, true>(P, cur, pairnum, true));
+            long_scan<BBDUK_MODE_KTRIM_L>(P, Q, stage, A, off, lane);
+            int a, newLen, ref; bool hit;
+            finish_read<BBDUK_MODE_KTRIM_L>(P, cur, A.start, A.stop, A.found, A.iFirst, A.iLast, A.shortFl, A.shortLl, A.ref, a, newLen, ref, hit);
+            if (A.scan) { if (hit) { idl = ref; scaf_add(P, scaf, idl, cur, lane, counters); } xl = a; cur = newLen; }
+        }
+        id = idr >= 0 ? idr : idl;
+    };
+    const int step = paired ? 2 : 1;
+    const int64_t units = (n + step - 1) / step;
+    for (int64_t u = (int64_t)blockIdx.x * NWAVES + wave; u < units; u += (int64_t)gridDim.x * NWAVES) {
+        const int64_t ra = u * step;
+        const bool two = paired && (ra + 1) < n;
+        const int64_t o0 = offsets[ra], o1 = offsets[ra + 1], o2 = two ? offsets[ra + 2] : o1;
+        const int l1 = (int)(o1 - o0), l2 = (int)(o2 - o1);
+        int xr1, xl1, n1, id1, xr2 = 0, xl2 = 0, n2 = 0, id2 = -1;
+        tips(o0, l1, 0, xr1, xl1, n1, id1);
+        if (two) tips(o1, l2, 1, xr2, xl2, n2, id2);
+        // record stage (:954-967, 1009-1033, 1431-1443), wave-uniform
+        const float g1 = (float)l1 * P.minLenFraction, g2 = (float)l2 * P.minLenFraction;
+        const int minlen1 = (int)(g1 > (float)P.minReadLength ? g1 : (float)P.minReadLength);
+        const int minlen2 = (int)(g2 > (float)P.minReadLength ? g2 : (float)P.minReadLength);
+        bool d1 = false, d2 = false, remove = false;
+        long long xsum = 0; int rkt = 0;
+        if (P.storedKmers > 0) {
+            xsum = (long long)xr1 + xl1 + xr2 + xl2; rkt = ((xr1 + xl1) > 0) + ((xr2 + xl2) > 0);
+            d1 = n1 < minlen1; d2 = two && (n2 < minlen2);
+            if ((P.rieb && (d1 || d2)) || (d1 && (!two || d2))) { xsum += (long long)n1 + n2; rkt = two ? 2 : 1; remove = true; }
+            else if (P.tpe && xsum > 0 && two && n1 != n2) {
+                int x;
+                if (n1 > n2) { x = trim_by_amount(n1, 0, n1 - n2, 1, n1); xr1 += x; }
+                else { x = trim_by_amount(n2, 0, n2 - n1, 1, n2); xr2 += x; }
+                if (rkt < 2) rkt++;
+                xsum += x;
+            }
+        }
+        if (lane == 0) {
+            atomicAdd(&s_acc[0], (unsigned long long)rkt); atomicAdd(&s_acc[1], (unsigned long long)xsum);
+            if (remove) { atomicAdd(&s_acc[2], two ? 2ULL : 1ULL); atomicAdd(&s_acc[3], (unsigned long long)((long long)n1 + n2)); }
+            atomicAdd(&s_acc[4], two ? 2ULL : 1ULL); atomicAdd(&s_acc[5], (unsigned long long)(o2 - o0));
+            const uint8_t f1 = (uint8_t)((d1 ? BBDUK_FLAG_DISCARDED : 0) | (remove ? BBDUK_FLAG_REMOVED : 0));
+            const uint8_t f2 = (uint8_t)((d2 ? BBDUK_FLAG_DISCARDED : 0) | (remove ? BBDUK_FLAG_REMOVED : 0));
+            outRight[ra] = xr1; outLeft[ra] = xl1; outId[ra] = id1; outFlags[ra] = f1;
+            if (two) { outRight[ra + 1] = xr2; outLeft[ra + 1] = xl2; outId[ra + 1] = id2; outFlags[ra + 1] = f2; }
+        }
+    }
+    scaf_flush(P, scaf, lane, counters);
+    __syncthreads();
+    if (tid == 0) publish_counters<BBDUK_MODE_KTRIM_R>(s_acc, counters);
+}
+
 // Pre-pass: does every unit (mate pair, or single read) fit a wave's planes?  One thread per unit.
-__global__ void bbduk_span_kernel(const int64_t* __restrict__ offsets, const int64_t n, const int paired, int* __restrict__ slowFlag) {
+// wmax / hmax: longest unit the first / the second kernel of the operator accepts (flag bit 0 / bit 1 otherwise).
+__global__ void bbduk_span_kernel(const int64_t* __restrict__ offsets, const int64_t n, const int paired, int* __restrict__ slowFlag,
+                                  const int64_t wmax = WUNIT_MAX, const int64_t hmax = CAP_BASES - 64) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int step = paired ? 2 : 1;
     const int64_t units = n / step;
     bool bad = false, huge = false;
     for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += stride) {
         const int64_t len = offsets[u * step + step] - offsets[u * step];
-        bad |= len > (int64_t)WUNIT_MAX;
-        huge |= len > (int64_t)(CAP_BASES - 64);                  // not even the tile kernel's planes hold this unit: bbduk_long_kernel
+        bad |= len > wmax;
+        huge |= len > hmax;                                       // not even the tile kernel's planes hold this unit: bbduk_long_kernel
     }
     if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(slowFlag, 1);
     if (__ballot(huge) && (threadIdx.x & 63) == 0) atomicOr(slowFlag, 2);
@@ -3163,11 +3288,21 @@ static int launch_tips(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d
     const int grid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU);
     std::lock_guard<std::mutex> lg(h->launchMu);
     const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
+    int* const d_flag = h->d_slowFlag + evi;
+    HIP_TRY(h, hipMemsetAsync(d_flag, 0, sizeof(int), st));
+    {   // pre-pass per READ: one beyond the tiled kernel's planes sends the batch to bbduk_long_tips_kernel
+        const int sgrid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)h->numCU * 8);
+        bbduk_span_kernel<<<dim3(std::max(sgrid, 1)), dim3(256), 0, st>>>(d_offsets, n, 0, d_flag, (int64_t)(KM_CAP_BASES - 32), (int64_t)(KM_CAP_BASES - 32));
+    }
     if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
     HIP_TRY(h, hipEventRecord(h->ev0[evi], st));
-    bbduk_ktrimtips_kernel<<<dim3(grid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_r, d_l, d_id, d_fl, d_counters);
+    bbduk_ktrimtips_kernel<<<dim3(grid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_r, d_l, d_id, d_fl, d_counters, d_flag);
     HIP_TRY(h, hipEventRecord(h->ev1[evi], st));
     h->evCount++;
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bbduk_long_tips_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
+    const int64_t units = paired ? n / 2 : n;
+    const int lgrid = (int)std::min<int64_t>((units + NWAVES - 1) / NWAVES, (int64_t)h->numCU);
+    bbduk_long_tips_kernel<<<dim3(std::max(lgrid, 1)), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_r, d_l, d_id, d_fl, d_counters, d_flag);
     HIP_TRY(h, hipGetLastError());
     return BBDUK_OK;
 }

@@ -152,11 +152,11 @@ def test_edge_shapes():
     longs = [util.rand_seq(rng, n, 0.001) + ad for n in (1000, 5000, 9000, 16000 - len(ad))]
     check_batch(d, o, longs, True)
     check_batch(d, o, longs + [util.rand_seq(rng, 40) + ad[:30]] * 301, False)
-    # beyond BBDUK_MAX_READ_LEN the chunked kernels take over (test_long_reads_*, test_kmask_long_sequences); tips / split say no
+    # beyond BBDUK_MAX_READ_LEN the chunked kernels take over (test_long_reads_*, test_kmask_long_sequences, test_ktrimtips_long_reads); ksplit, k>31 and findbestmatch say no
     check_batch(d, o, [util.rand_seq(rng, 50000) + ad], False)
-    dm = B.BBDuk("ktrim=rl k=23 ref=adapters")
+    dm = B.BBDuk("ksplit=t k=23 ref=adapters")
     with pytest.raises(B.BBDukError):
-        dm.gpu.ktrimtips_batch(*pack_reads([util.rand_seq(rng, 50000)]), False)
+        dm.gpu.ksplit_batch(*pack_reads([util.rand_seq(rng, 50000)]))
     dm.close()
     # wrong operator for the mode, odd paired batch
     b, off = pack_reads([ad, ad, ad])
@@ -748,6 +748,40 @@ def test_kmask_long_sequences(ci):
     rng.shuffle(reads)
     check_kmask(d, o, reads, True)
     check_kmask(d, o, reads[:17], False)
+    assert d.gpu.counters()[3] > 0
+    d.close()
+
+
+TIPS_LONG = [("ktrim=rl k=23 mink=11 hdist=1", dict(k=23, ktrimLeft=1, ktrimRight=1, mink=11, hdist=1)),
+             ("ktrimtips=150 k=21 mink=9", dict(k=21, ktrimLeft=1, ktrimRight=1, mink=9, restrictLeft=150, restrictRight=150)),
+             ("ktrim=lr k=25 tp=1 forbidn=t ktrimexclusive=t tpe minlen=20000", dict(k=25, ktrimLeft=1, ktrimRight=1, trimPad=1, forbidN=1, ktrimExclusive=1, trimPairsEvenly=1, minReadLength=20000)),
+             ("ktrimtips=40000 k=19 qhdist=1 rieb=f", dict(k=19, ktrimLeft=1, ktrimRight=1, restrictLeft=40000, restrictRight=40000, qhdist=1, requireBothBad=1))]
+
+
+@pytest.mark.parametrize("ci", range(len(TIPS_LONG)))
+def test_ktrimtips_long_reads(ci):
+    """ktrim=rl / ktrimtips on reads beyond the tiled kernel's planes (long-read adapter trimming): bbduk_long_tips_kernel."""
+    args, okw = TIPS_LONG[ci]
+    rng = random.Random(55000 + ci)
+    refs = [util.rand_seq(rng, rng.randint(30, 120)) for _ in range(6)]
+    d, o = make_pair(args, okw, refs=refs)
+    reads = []
+    for L in (33000, 50000, 2432 * 20 + 7, 120000, 70001, 40000, 90011, 35000):
+        g = bytearray(util.rand_seq(rng, L, 0.0005))
+        for _ in range(rng.randint(0, 5)):
+            r = rng.choice(refs); r = util.revcomp(r) if rng.random() < 0.5 else r
+            pos = rng.choice([0, L - len(r), rng.randrange(L - len(r)), rng.randint(0, 120), L - len(r) - rng.randint(0, 120),
+                              L // 2 + rng.randint(-60, 60), 2432 * rng.randint(1, 13) - rng.randint(0, 40)])
+            g[pos:pos + len(r)] = r
+        if rng.random() < 0.6:
+            g[L - 14:] = rng.choice(refs)[:14]
+        if rng.random() < 0.6:
+            g[:15] = rng.choice(refs)[-15:]
+        reads.append(bytes(g))
+    reads += util.fuzz_reads(rng, refs, 30, [0, 10, 150, 3000], junk=True)
+    rng.shuffle(reads)
+    check_tips(d, o, reads, True)
+    check_tips(d, o, reads[:17], False)
     assert d.gpu.counters()[3] > 0
     d.close()
 
