@@ -1494,6 +1494,101 @@ void bbduk_kmask_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
 #define RED_BEST  1
 #define RED_SPLIT 2
 #define KS_MAX_IDS 64
+// Scan state of bbduk_kscan_kernel's reductions, carried across the blocks (and, for long reads, the chunks) of one read.
+struct KScanState {
+    int found, rid;                       // what the reference's method returns / credits
+    int firstI, lastI, id0;               // RED_SPLIT: first and last hit of the main scan, id of the first
+    int bkStart, bkStop, lastId; bool done;   // RED_BIG run state
+    int myId, myCnt, nids;                // RED_BEST: lane j owns the j-th distinct id
+};
+__device__ __forceinline__ void kscan_init(KScanState& S) {
+    S.found = 0; S.rid = -1; S.firstI = -1; S.lastI = -1; S.id0 = -1; S.bkStart = -1; S.bkStop = -1; S.lastId = -1; S.done = false;
+    S.myId = 0; S.myCnt = 0; S.nids = 0;
+}
+// the positions [W.first, W.stop) of one read (or of one chunk of it), 256 per step
+template <int RED>
+__device__ __forceinline__ void kscan_window(const KParams& P, const Planes& Q, const ReadWin& W, KScanState& S, const int thr, const int lane,
+                                             int64_t* __restrict__ counters) {
+    const int sub = P.kbig - P.k - 1;
+    for (int ib = W.first; W.on && !S.done && ib < W.stop; ib += 256) {
+        uint64_t kmer[4], rk[4]; bool ok[4]; int ref[4];
+        windows2<true, true>(P, Q, W, ib + 2 * lane, true, kmer, rk, ok);
+        if (ib + 128 < W.stop) windows2<true, true>(P, Q, W, ib + 128 + 2 * lane, true, kmer + 2, rk + 2, ok + 2);
+        else { kmer[2] = kmer[3] = 0; rk[2] = rk[3] = 0; ok[2] = ok[3] = false; }
+        lookup4<true>(P, Q.filt, kmer, rk, ok, ref);
+#pragma unroll
+        for (int hb = 0; hb < 2; hb++) {
+            const uint64_t he = __ballot(ref[2 * hb] != -1), ho = __ballot(ref[2 * hb + 1] != -1);
+            const int i0 = ib + 128 * hb;            // position of (lane j, parity p) = i0 + 2j + p
+            if (RED == RED_SPLIT) {
+                if (he | ho) {
+                    const int le = he ? __ffsll((unsigned long long)he) - 1 : 64, lo = ho ? __ffsll((unsigned long long)ho) - 1 : 64;
+                    if (S.firstI < 0) {
+                        const bool odd = 2 * lo + 1 < 2 * le;
+                        S.firstI = i0 + (odd ? 2 * lo + 1 : 2 * le);
+                        S.id0 = odd ? __builtin_amdgcn_readlane(ref[2 * hb + 1], lo) : __builtin_amdgcn_readlane(ref[2 * hb], le);
+                    }
+                    const int me = he ? 63 - __clzll((unsigned long long)he) : -1, mo = ho ? 63 - __clzll((unsigned long long)ho) : -1;
+                    S.lastI = i0 + max(2 * me, 2 * mo + 1);
+                    S.found += __popcll(he) + __popcll(ho);
+                }
+            } else if (RED == RED_BEST) {
+                uint64_t re = he, ro = ho;
+                while (re | ro) {                   // hits in position order
+                    const int le = re ? __ffsll((unsigned long long)re) - 1 : 64, lo = ro ? __ffsll((unsigned long long)ro) - 1 : 64;
+                    const bool odd = 2 * lo + 1 < 2 * le;
+                    const int id = odd ? __builtin_amdgcn_readlane(ref[2 * hb + 1], lo) : __builtin_amdgcn_readlane(ref[2 * hb], le);
+                    // every remaining hit of this half-block with the same id is counted at once
+                    const uint64_t se = re & __ballot(ref[2 * hb] == id), so = ro & __ballot(ref[2 * hb + 1] == id);
+                    const int c = __popcll(se) + __popcll(so);
+                    const uint64_t have = __ballot(lane < S.nids && S.myId == id);
+                    if (have) { if (lane == __ffsll((unsigned long long)have) - 1) S.myCnt += c; }
+                    else if (S.nids < KS_MAX_IDS) { if (lane == S.nids) { S.myId = id; S.myCnt = c; } S.nids++; }
+                    else if (lane == 0) atomicMax((unsigned long long*)&counters[BBDUK_CTR_STATUS], (unsigned long long)(-BBDUK_ERR_ID_OVERFLOW));
+                    S.found += c;
+                    re &= ~se; ro &= ~so;
+                }
+            } else {
+                if (!(he | ho) && S.bkStart < 0) continue;          // nothing to open, nothing to close
+                const uint64_t ke = __ballot(ok[2 * hb]), ko = __ballot(ok[2 * hb + 1]);
+                for (int j = 0; j < 64 && !S.done; j++) {            // the reference's loop body (:1749-1779), scalar
+#pragma unroll
+                    for (int par = 0; par < 2; par++) {
+                        if (S.done || !(((par ? ko : ke) >> j) & 1ULL)) continue;    // not looked up: transparent
+                        const int i = i0 + 2 * j + par;
+                        const int id = __builtin_amdgcn_readlane(ref[2 * hb + par], j);
+                        if (id > 0) { S.lastId = id; if (S.bkStart == -1) S.bkStart = i; S.bkStop = i; }
+                        else if (S.bkStart > -1) {
+                            const int dif = S.bkStop - S.bkStart - sub;
+                            S.bkStop = S.bkStart = -1;
+                            if (dif > 0) {
+                                const int old = S.found;
+                                S.found += dif;
+                                if (S.found > thr && old <= thr) { S.rid = S.lastId; S.done = true; }     // :1763-1773 early exit
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+// after the last position: a run that reaches the end of the read (RED_BIG), the best scaffold (RED_BEST)
+template <int RED>
+__device__ __forceinline__ void kscan_finish(KScanState& S, const int thr, const int sub, const int lane) {
+    if (RED == RED_BIG && !S.done && S.bkStart > -1) {                 // :1783-1800
+        const int dif = S.bkStop - S.bkStart - sub;
+        if (dif > 0) { const int old = S.found; S.found += dif; if (S.found > thr && old <= thr) S.rid = S.lastId; }
+    }
+    if (RED == RED_BEST && S.found > thr) {                            // condenseLoose + first maximum (:1694-1701)
+        int mx = (lane < S.nids) ? S.myCnt : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+        const uint64_t best = __ballot(lane < S.nids && S.myCnt == mx);
+        S.rid = __builtin_amdgcn_readlane(S.myId, __ffsll((unsigned long long)best) - 1);
+    }
+}
+
 template <int RED>
 __global__ __launch_bounds__(BLOCK_THREADS)
 void bbduk_kscan_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
@@ -1575,88 +1670,15 @@ void bbduk_kscan_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
                     const int vk = (L >= keff) ? valid_kmers_any_k(Q, base0, L, keff, lane) : 0;
                     thr = max(P.maxBadKmers, (int)((float)(vk - 1) * P.mkf));
                 }
-                int found = 0, rid = -1;                            // what the reference's method returns / credits
-                int firstI = -1, lastI = -1, id0 = -1;              // RED_SPLIT: first and last hit of the main scan
-                int bkStart = -1, bkStop = -1, lastId = -1; bool done = false;   // RED_BIG run state
-                int myId = 0, myCnt = 0, nids = 0;                  // RED_BEST: lane j owns the j-th distinct id
+                KScanState S; kscan_init(S);
                 if (R.scan) {
                     ReadWin W;
                     win_init<true, true>(P, Q, R, W, lane);
-                    const int sub = P.kbig - k - 1;
-                    for (int ib = W.first; W.on && !done && ib < W.stop; ib += 256) {
-                        uint64_t kmer[4], rk[4]; bool ok[4]; int ref[4];
-                        windows2<true, true>(P, Q, W, ib + 2 * lane, true, kmer, rk, ok);
-                        if (ib + 128 < W.stop) windows2<true, true>(P, Q, W, ib + 128 + 2 * lane, true, kmer + 2, rk + 2, ok + 2);
-                        else { kmer[2] = kmer[3] = 0; rk[2] = rk[3] = 0; ok[2] = ok[3] = false; }
-                        lookup4<true>(P, Q.filt, kmer, rk, ok, ref);
-#pragma unroll
-                        for (int hb = 0; hb < 2; hb++) {
-                            const uint64_t he = __ballot(ref[2 * hb] != -1), ho = __ballot(ref[2 * hb + 1] != -1);
-                            const int i0 = ib + 128 * hb;            // position of (lane j, parity p) = i0 + 2j + p
-                            if (RED == RED_SPLIT) {
-                                if (he | ho) {
-                                    const int le = he ? __ffsll((unsigned long long)he) - 1 : 64, lo = ho ? __ffsll((unsigned long long)ho) - 1 : 64;
-                                    if (firstI < 0) {
-                                        const bool odd = 2 * lo + 1 < 2 * le;
-                                        firstI = i0 + (odd ? 2 * lo + 1 : 2 * le);
-                                        id0 = odd ? __builtin_amdgcn_readlane(ref[2 * hb + 1], lo) : __builtin_amdgcn_readlane(ref[2 * hb], le);
-                                    }
-                                    const int me = he ? 63 - __clzll((unsigned long long)he) : -1, mo = ho ? 63 - __clzll((unsigned long long)ho) : -1;
-                                    lastI = i0 + max(2 * me, 2 * mo + 1);
-                                    found += __popcll(he) + __popcll(ho);
-                                }
-                            } else if (RED == RED_BEST) {
-                                uint64_t re = he, ro = ho;
-                                while (re | ro) {                   // hits in position order
-                                    const int le = re ? __ffsll((unsigned long long)re) - 1 : 64, lo = ro ? __ffsll((unsigned long long)ro) - 1 : 64;
-                                    const bool odd = 2 * lo + 1 < 2 * le;
-                                    const int id = odd ? __builtin_amdgcn_readlane(ref[2 * hb + 1], lo) : __builtin_amdgcn_readlane(ref[2 * hb], le);
-                                    // every remaining hit of this half-block with the same id is counted at once
-                                    const uint64_t se = re & __ballot(ref[2 * hb] == id), so = ro & __ballot(ref[2 * hb + 1] == id);
-                                    const int c = __popcll(se) + __popcll(so);
-                                    const uint64_t have = __ballot(lane < nids && myId == id);
-                                    if (have) { if (lane == __ffsll((unsigned long long)have) - 1) myCnt += c; }
-                                    else if (nids < KS_MAX_IDS) { if (lane == nids) { myId = id; myCnt = c; } nids++; }
-                                    else if (lane == 0) atomicMax((unsigned long long*)&counters[BBDUK_CTR_STATUS], (unsigned long long)(-BBDUK_ERR_ID_OVERFLOW));
-                                    found += c;
-                                    re &= ~se; ro &= ~so;
-                                }
-                            } else {
-                                if (!(he | ho) && bkStart < 0) continue;          // nothing to open, nothing to close
-                                const uint64_t ke = __ballot(ok[2 * hb]), ko = __ballot(ok[2 * hb + 1]);
-                                for (int j = 0; j < 64 && !done; j++) {            // the reference's loop body (:1749-1779), scalar
-#pragma unroll
-                                    for (int par = 0; par < 2; par++) {
-                                        if (done || !(((par ? ko : ke) >> j) & 1ULL)) continue;    // not looked up: transparent
-                                        const int i = i0 + 2 * j + par;
-                                        const int id = __builtin_amdgcn_readlane(ref[2 * hb + par], j);
-                                        if (id > 0) { lastId = id; if (bkStart == -1) bkStart = i; bkStop = i; }
-                                        else if (bkStart > -1) {
-                                            const int dif = bkStop - bkStart - sub;
-                                            bkStop = bkStart = -1;
-                                            if (dif > 0) {
-                                                const int old = found;
-                                                found += dif;
-                                                if (found > thr && old <= thr) { rid = lastId; done = true; }     // :1763-1773 early exit
-                                            }
-                                        }
-                                    }
-                                }
-                            }
-                        }
-                    }
-                    if (RED == RED_BIG && !done && bkStart > -1) {                 // the run reaches the end of the read (:1783-1800)
-                        const int dif = bkStop - bkStart - sub;
-                        if (dif > 0) { const int old = found; found += dif; if (found > thr && old <= thr) rid = lastId; }
-                    }
-                    if (RED == RED_BEST && found > thr) {                          // condenseLoose + first maximum (:1694-1701)
-                        int mx = (lane < nids) ? myCnt : 0;
-#pragma unroll
-                        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
-                        const uint64_t best = __ballot(lane < nids && myCnt == mx);
-                        rid = __builtin_amdgcn_readlane(myId, __ffsll((unsigned long long)best) - 1);
-                    }
+                    kscan_window<RED>(P, Q, W, S, thr, lane, counters);
+                    kscan_finish<RED>(S, thr, P.kbig - k - 1, lane);
                 }
+                const int rid = S.rid, firstI = S.firstI, lastI = S.lastI;
+                int found = S.found, id0 = S.id0;
                 if (RED != RED_SPLIT) {
                     if (rid > 0) scaf_add(P, scaf, rid, L, lane, counters);
                     if (lane == 0) { s_a[rd] = found; s_id[rd] = rid; s_thr[rd] = thr; s_split[rd] = 0; }
