@@ -1594,7 +1594,8 @@ __global__ __launch_bounds__(BLOCK_THREADS)
 void bbduk_kscan_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
                         const int64_t n, const int64_t totalBases, const int paired,
                         int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
-                        int32_t* __restrict__ outLeft, int32_t* __restrict__ outRight, int64_t* __restrict__ counters) {
+                        int32_t* __restrict__ outLeft, int32_t* __restrict__ outRight, int64_t* __restrict__ counters, const int* __restrict__ longFlag) {
+    if (*longFlag & 2) return;                                    // a read beyond these planes: bbduk_kscan_long_kernel takes the batch
     __shared__ uint32_t s_fwd[PLANE_PAD + KM_CAP_CHUNKS + PLANE_PAD];
     __shared__ uint32_t s_cmp[PLANE_PAD + KM_CAP_CHUNKS + PLANE_PAD];
     __shared__ uint32_t s_nm[KM_CAP_CHUNKS / 2 + 4];
@@ -2628,6 +2629,186 @@ void bbduk_kmask_long_kernel(const KParams P, const uint8_t* __restrict__ bases,
     }
 }
 
+// k>31, findBestMatch and ksplit for reads beyond bbduk_kscan_kernel's planes (ksplit's natural input are long reads with
+// an adapter somewhere inside): one wave per unit, the reductions' state carried across chunks by kscan_window.
+template <int RED>
+__global__ __launch_bounds__(BLOCK_THREADS)
+void bbduk_kscan_long_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
+                             const int64_t n, const int64_t totalBases, const int paired,
+                             int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
+                             int32_t* __restrict__ outLeft, int32_t* __restrict__ outRight, int64_t* __restrict__ counters, const int* __restrict__ longFlag) {
+    if ((*longFlag & 2) == 0) return;
+    __shared__ uint32_t s_wf[NWAVES * WPLANE_WORDS];
+    __shared__ uint32_t s_wc[NWAVES * WPLANE_WORDS];
+    __shared__ uint32_t s_wn[NWAVES * WNM_WORDS];
+    __shared__ unsigned long long s_acc[6];
+    extern __shared__ uint32_t s_filt[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+    const int k = P.k, tp = P.trimPad;
+    ScafAcc scaf; scaf_init(scaf);
+    if (tid < 6) s_acc[tid] = 0;
+    if (P.ldsBits) {
+        const int words = 1 << (P.ldsBits - 5);
+        for (int w = tid; w < words; w += BLOCK_THREADS) s_filt[w] = P.ldsImage[w];
+    }
+    __syncthreads();
+    uint32_t* const wf = s_wf + wave * WPLANE_WORDS; uint32_t* const wc = s_wc + wave * WPLANE_WORDS; uint32_t* const wn = s_wn + wave * WNM_WORDS;
+    Planes Q; Q.fwd = wf + PLANE_PAD; Q.cmp = wc + PLANE_PAD; Q.nm = wn; Q.filt = s_filt; Q.T = 0;
+    Q.fwdBits = lds_bits_of(Q.fwd); Q.cmpBits = lds_bits_of(Q.cmp);
+    auto stage = [&](const int64_t off, const int lo, const int hi) -> int {
+        const int64_t A0 = (off + lo) & ~15LL;
+        const int nchunks = (int)((off + hi - A0 + 15) >> 4);
+        for (int c = lane; c < nchunks; c += 64) {
+            uint32_t r, comp, valid;
+            stage_chunk(P, bases, A0 + 16LL * c, totalBases, r, comp, valid);
+            wf[PLANE_PAD + nchunks - 1 - c] = r;
+            wc[PLANE_PAD + c] = comp;
+            reinterpret_cast<uint16_t*>(wn)[c] = (uint16_t)(~valid & 0xFFFFu);
+        }
+        if (lane == 0) { reinterpret_cast<uint16_t*>(wn)[nchunks] = 0; reinterpret_cast<uint16_t*>(wn)[nchunks + 1] = 0; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        Q.T = nchunks * 16;
+        return (int)(off - A0);
+    };
+    // one read: found / credited id (kfilter variants) or trimmed / id0 / leftmost / rightmost / new pair length / split (ksplit)
+    auto one = [&](const int64_t off, const int L, const int pairnum, int& found, int& rid, int& thr, int& lm, int& rm, int& npl, int& split) {
+        ReadScan R;
+        R.base0 = 0; R.L = L; R.hasN = -1; R.maxBad = 0;
+        R.start = span_start<true>(P, L); R.stop = span_stop<true>(P, L);
+        const bool skipped = (P.skipR1 && pairnum == 0) || (P.skipR2 && pairnum == 1);
+        if (RED == RED_BIG)       R.scan = P.storedKmers > 0 && L >= P.kbig && !skipped;
+        else if (RED == RED_BEST) R.scan = P.storedKmers > 0 && L >= k && !skipped;
+        else                      R.scan = P.storedKmers > 0 && L >= k;
+        thr = P.maxBadKmers; lm = -1; rm = -1; npl = L; split = 0;
+        if (RED != RED_SPLIT && P.mkf != 0.f) {                     // numValidKmers(keff) over the chunks
+            const int keff = max(k, P.kbig);
+            int cnt = 0, run = 0;
+            for (int c0 = 0; c0 < L && L >= keff; c0 += LCHUNK) {
+                const int c1 = min(L, c0 + LCHUNK);
+                const int b0 = stage(off, c0, c1);
+                for (int i0 = c0; i0 < c1; i0 += 64) {
+                    const int b = b0 + min(i0 + lane, c1 - 1);
+                    const uint64_t U = __ballot(((Q.nm[b >> 5] >> (b & 31)) & 1u) != 0u);
+                    const int nv = min(64, c1 - i0);
+                    int pos = 0;
+                    while (pos < nv) {
+                        const uint64_t rest = U >> pos;
+                        const int nextU = rest ? min(nv, pos + __ffsll((unsigned long long)rest) - 1) : nv;
+                        const int seg = nextU - pos;
+                        cnt += max(0, run + seg - max(run, keff - 1));
+                        run += seg;
+                        if (nextU < nv) { run = 0; pos = nextU + 1; } else pos = nv;
+                    }
+                }
+            }
+            thr = max(P.maxBadKmers, (int)((float)(cnt - 1) * P.mkf));
+        }
+        KScanState S; kscan_init(S);
+        if (R.scan) {
+            const int start = R.start, stop = R.stop;
+            for (int ci = max(start, k - 1); ci < stop && !S.done; ci += LCHUNK) {
+                const int ce = min(stop, ci + LCHUNK);
+                const int lo = max(start, ci - (k - 1));
+                ReadScan C = R; C.base0 = stage(off, lo, ce); C.start = lo; C.stop = ce; C.hasN = -1;
+                ReadWin W;
+                win_init<true, true>(P, Q, C, W, lane);
+                W.first = max(W.first, ci); W.on = W.first < W.stop;
+                kscan_window<RED>(P, Q, W, S, thr, lane, counters);
+            }
+            kscan_finish<RED>(S, thr, P.kbig - k - 1, lane);
+        }
+        found = S.found; rid = S.rid;
+        if (RED != RED_SPLIT) { if (rid > 0) scaf_add(P, scaf, rid, L, lane, counters); return; }
+        // ---- ksplit: span of the main hits, else the short k-mers of the right end, else of the left end (:2388-2474)
+        int id0 = S.id0, leftmost = 0x7FFFFFFF, rightmost = -1;
+        if (found > 0) { leftmost = max(0, S.firstI - (k - 1 - tp)); rightmost = S.lastI + tp; }
+        if (R.scan && P.useShort && id0 == -1) {
+            for (int side = 1; side >= 0 && id0 == -1; side--) {    // right first
+                const bool right = side == 1;
+                const int Ls = P.mink + lane;
+                bool act; int i; uint64_t km = 0, rr = 0;
+                const int b0 = right ? stage(off, max(R.start, R.stop - k), R.stop) : stage(off, R.start, min(R.stop, R.start + k));
+                if (!right) {
+                    const int Lmax = min(k, R.stop) - R.start;
+                    act = Ls <= Lmax; i = R.start + Ls - 1;
+                    const int Lc = act ? Ls : 1;
+                    if (act) { km = extract2(Q.fwd, Q.T - 1 - (b0 + R.start + Lc - 1), Lc) & P.mask; rr = extract2(Q.cmp, b0 + R.start, Lc); }
+                } else {
+                    const int Lmax = (R.stop >= k ? k - 1 : R.stop);
+                    act = Ls <= Lmax; i = R.stop - Ls;
+                    const int Lc = act ? Ls : 1;
+                    if (act) { km = extract2(Q.fwd, Q.T - 1 - (b0 + R.stop - 1), Lc); rr = extract2(Q.cmp, b0 + R.stop - Lc, Lc) & P.mask; }
+                }
+                if (P.qskip > 1) act = act && (i % P.qskip) == 0;
+                const int Lc = act ? Ls : 1;
+                const int sref = lookup<true>(P, Q.filt, km, rr, 1ULL << (2 * Lc), Lc, P.qhdist2, act);
+                const uint64_t hm = __ballot(sref != -1);
+                if (!hm) continue;
+                id0 = __builtin_amdgcn_readlane(sref, __ffsll((unsigned long long)hm) - 1);      // first in loop order = shortest
+                const int longest = P.mink + (63 - __clzll((unsigned long long)hm));
+                if (right) { leftmost = min(leftmost, max(0, R.stop - longest - tp)); rightmost = L - 1; }
+                else { leftmost = 0; rightmost = max(rightmost, R.start + longest - 1 + tp); }
+                found += __popcll(hm);
+            }
+        }
+        int trimmed = 0;
+        if (found > 0) {
+            scaf_add(P, scaf, id0, L, lane, counters);
+            int n1 = L;
+            if (leftmost == 0) { trim_by_amount(L, rightmost + 1, 0, 1, n1); npl = n1; }
+            else if (rightmost == L - 1) { trim_by_amount(L, 0, L - leftmost, 1, n1); npl = n1; }
+            else { const int n2 = (L - 1) - (rightmost + 1); trim_by_amount(L, 0, L - leftmost, 1, n1); npl = n1 + n2; split = 1; }
+            trimmed = L - npl;
+            lm = leftmost; rm = rightmost;
+        }
+        rid = found > 0 ? id0 : -1;
+        found = trimmed;                                            // out_trimmed
+    };
+    const int step = (paired && RED != RED_SPLIT) ? 2 : 1;
+    const int64_t units = (n + step - 1) / step;
+    for (int64_t u = (int64_t)blockIdx.x * NWAVES + wave; u < units; u += (int64_t)gridDim.x * NWAVES) {
+        const int64_t ra = u * step;
+        const bool two = step == 2 && (ra + 1) < n;
+        const int64_t o0 = offsets[ra], o1 = offsets[ra + 1], o2 = two ? offsets[ra + 2] : o1;
+        const int l1 = (int)(o1 - o0), l2 = (int)(o2 - o1);
+        int f1v, id1, thr1, lm1, rm1, npl1, sp1, f2v = 0, id2 = -1, thr2 = 0, lm2, rm2, npl2, sp2;
+        one(o0, l1, 0, f1v, id1, thr1, lm1, rm1, npl1, sp1);
+        if (two) one(o1, l2, 1, f2v, id2, thr2, lm2, rm2, npl2, sp2);
+        if (lane == 0) {
+            atomicAdd(&s_acc[4], two ? 2ULL : 1ULL); atomicAdd(&s_acc[5], (unsigned long long)(o2 - o0));
+            outA[ra] = f1v; outId[ra] = id1;
+            if (two) { outA[ra + 1] = f2v; outId[ra + 1] = id2; }
+            if (RED == RED_SPLIT) {
+                outLeft[ra] = lm1; outRight[ra] = rm1;
+                outFlags[ra] = (uint8_t)(sp1 ? BBDUK_FLAG_REMOVED : 0);
+                if (f1v > 0) { atomicAdd(&s_acc[0], 1ULL); atomicAdd(&s_acc[1], (unsigned long long)f1v); }
+                if (sp1) { atomicAdd(&s_acc[2], 1ULL); atomicAdd(&s_acc[3], (unsigned long long)npl1); }
+            } else {
+                const bool d1 = P.storedKmers > 0 && (RED == RED_BEST ? id1 > 0 : f1v > thr1);
+                const bool d2 = two && P.storedKmers > 0 && (RED == RED_BEST ? id2 > 0 : f2v > thr2);
+                const bool remove = two ? ((P.rieb && (d1 || d2)) || (d1 && d2)) : d1;
+                outFlags[ra] = (uint8_t)((d1 ? BBDUK_FLAG_DISCARDED : 0) | (remove ? BBDUK_FLAG_REMOVED : 0));
+                if (two) outFlags[ra + 1] = (uint8_t)((d2 ? BBDUK_FLAG_DISCARDED : 0) | (remove ? BBDUK_FLAG_REMOVED : 0));
+                if (remove) { atomicAdd(&s_acc[2], two ? 2ULL : 1ULL); atomicAdd(&s_acc[3], (unsigned long long)(o2 - o0)); }
+            }
+        }
+    }
+    scaf_flush(P, scaf, lane, counters);
+    __syncthreads();
+    if (tid == 0) {
+        if (RED == RED_SPLIT) {
+            const unsigned long long rkt = s_acc[0], xs = s_acc[1], rm = s_acc[2], bm = s_acc[3], rin = s_acc[4], bin = s_acc[5];
+            auto add = [&](int slot, unsigned long long v) { if (v) atomicAdd((unsigned long long*)&counters[slot], v); };
+            add(BBDUK_READS_IN, rin); add(BBDUK_BASES_IN, bin);
+            add(BBDUK_READS_KTRIMMED, rkt); add(BBDUK_BASES_KTRIMMED, xs);
+            add(BBDUK_READS_OUTM, rm); add(BBDUK_BASES_OUTM, bm);
+            add(BBDUK_READS_OUTU, rin - rm); add(BBDUK_BASES_OUTU, bin - xs - bm);
+        } else publish_counters<BBDUK_MODE_KFILTER>(s_acc, counters);
+    }
+}
+
 // ktrim=rl / ktrimtips for reads beyond bbduk_ktrimtips_kernel's planes (long-read adapter trimming): one wave per unit,
 // the right pass and then the left pass of every read through long_scan, pair logic as in the tiled kernel's record stage.
 __global__ __launch_bounds__(BLOCK_THREADS)
@@ -3110,7 +3291,10 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     const int red = h->p.mode == BBDUK_MODE_KSPLIT ? RED_SPLIT : (K.fbm ? RED_BEST : RED_BIG);
     typedef void (*kscan_t)(const KParams, const uint8_t*, const int64_t*, const int64_t, const int64_t, const int,
                             int32_t*, int32_t*, uint8_t*, int32_t*, int32_t*, int64_t*);
-    const kscan_t fn = red == RED_SPLIT ? bbduk_kscan_kernel<RED_SPLIT> : (red == RED_BEST ? bbduk_kscan_kernel<RED_BEST> : bbduk_kscan_kernel<RED_BIG>);
+    typedef void (*kscan_full_t)(const KParams, const uint8_t*, const int64_t*, const int64_t, const int64_t, const int,
+                                 int32_t*, int32_t*, uint8_t*, int32_t*, int32_t*, int64_t*, const int*);
+    const kscan_full_t fn = red == RED_SPLIT ? bbduk_kscan_kernel<RED_SPLIT> : (red == RED_BEST ? bbduk_kscan_kernel<RED_BEST> : bbduk_kscan_kernel<RED_BIG>);
+    const kscan_full_t lfn = red == RED_SPLIT ? bbduk_kscan_long_kernel<RED_SPLIT> : (red == RED_BEST ? bbduk_kscan_long_kernel<RED_BEST> : bbduk_kscan_long_kernel<RED_BIG>);
     const size_t dynLds = h->ldsBits ? ((size_t)1 << (h->ldsBits - 3)) : 0;
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
     const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
@@ -3119,9 +3303,19 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
     if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
     HIP_TRY(h, hipEventRecord(h->ev0[evi], st));
-    fn<<<dim3(grid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_left, d_right, d_counters);
+    int* const d_flag = h->d_slowFlag + evi;
+    HIP_TRY(h, hipMemsetAsync(d_flag, 0, sizeof(int), st));
+    {   // pre-pass per READ: one beyond the tiled kernel's planes sends the batch to bbduk_kscan_long_kernel
+        const int sgrid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)h->numCU * 8);
+        bbduk_span_kernel<<<dim3(std::max(sgrid, 1)), dim3(256), 0, st>>>(d_offsets, n, 0, d_flag, (int64_t)(KM_CAP_BASES - 32), (int64_t)(KM_CAP_BASES - 32));
+    }
+    fn<<<dim3(grid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_left, d_right, d_counters, d_flag);
     HIP_TRY(h, hipEventRecord(h->ev1[evi], st));
     h->evCount++;
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(lfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
+    const int64_t lunits = (paired && red != RED_SPLIT) ? n / 2 : n;
+    const int lgrid = (int)std::min<int64_t>((lunits + NWAVES - 1) / NWAVES, (int64_t)h->numCU);
+    lfn<<<dim3(std::max(lgrid, 1)), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_left, d_right, d_counters, d_flag);
     HIP_TRY(h, hipGetLastError());
     return BBDUK_OK;
 }

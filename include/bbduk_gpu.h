@@ -49,9 +49,8 @@ extern "C" {
 #define BBDUK_ERR_ID_OVERFLOW   -6   /* findBestMatch: a read hit more than 64 distinct scaffolds */
 #define BBDUK_ERR_FORMAT        -7   /* FASTQ ingest: a record without '@' / '+' or with unequal base and quality lines */
 
-#define BBDUK_MAX_READ_LEN   16384   /* reads up to this length go through the LDS-tiled kernels; ktrim=r|l and kfilter serve longer
-                                        reads too (chunked scan, any length that fits an int); ktrim=n, ktrim=rl, ksplit,
-                                        k>31 and findBestMatch report BBDUK_ERR_READ_TOO_LONG beyond 32 736 bases */
+#define BBDUK_MAX_READ_LEN   16384   /* reads up to this length go through the LDS-tiled kernels; longer ones (any length that
+                                        fits an int) through the chunked long-read kernels of every operator */
 
 /* operator selected at create time */
 #define BBDUK_MODE_KFILTER   0       /* countSetKmers + filtering branch */

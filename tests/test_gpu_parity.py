@@ -152,12 +152,8 @@ def test_edge_shapes():
     longs = [util.rand_seq(rng, n, 0.001) + ad for n in (1000, 5000, 9000, 16000 - len(ad))]
     check_batch(d, o, longs, True)
     check_batch(d, o, longs + [util.rand_seq(rng, 40) + ad[:30]] * 301, False)
-    # beyond BBDUK_MAX_READ_LEN the chunked kernels take over (test_long_reads_*, test_kmask_long_sequences, test_ktrimtips_long_reads); ksplit, k>31 and findbestmatch say no
+    # beyond BBDUK_MAX_READ_LEN the chunked kernels take over (test_long_reads_*, test_kmask_long_sequences, test_ktrimtips_long_reads, test_kscan_long_reads)
     check_batch(d, o, [util.rand_seq(rng, 50000) + ad], False)
-    dm = B.BBDuk("ksplit=t k=23 ref=adapters")
-    with pytest.raises(B.BBDukError):
-        dm.gpu.ksplit_batch(*pack_reads([util.rand_seq(rng, 50000)]))
-    dm.close()
     # wrong operator for the mode, odd paired batch
     b, off = pack_reads([ad, ad, ad])
     with pytest.raises(B.BBDukError):
@@ -783,5 +779,57 @@ def test_ktrimtips_long_reads(ci):
     check_tips(d, o, reads, True)
     check_tips(d, o, reads[:17], False)
     assert d.gpu.counters()[3] > 0
+    d.close()
+
+
+KSCAN_LONG = [("k=40", dict(k=31, kbig=40)), ("k=45 mbk=30 rieb=f forbidn=t", dict(k=31, kbig=45, maxBadKmers0=30, requireBothBad=1, forbidN=1)),
+              ("k=36 mkf=0.0005 hdist=1", dict(k=31, kbig=36, minKmerFraction=0.0005, hdist=1)),
+              ("k=25 fbm", dict(k=25, findBestMatch=1)), ("k=21 fbm=t restrictright=60000 skipr1=t", dict(k=21, findBestMatch=1, restrictRight=60000, skipR1=1))]
+KSPLIT_LONG = [("k=23 ksplit=t", dict(k=23, ksplit=1)), ("k=21 ksplit mink=9 hdist=1", dict(k=21, ksplit=1, mink=9, hdist=1)),
+               ("k=19 ksplit=t tp=-2 forbidn=t restrictleft=70000", dict(k=19, ksplit=1, trimPad=-2, forbidN=1, restrictLeft=70000))]
+
+
+def _long_mix(rng, refs, short_lens):
+    reads = []
+    for L in (33000, 50000, 2432 * 20 + 7, 120000, 70001, 40000, 90011, 35000):
+        g = bytearray(util.rand_seq(rng, L, 0.0005))
+        for _ in range(rng.randint(0, 5)):
+            r = rng.choice(refs); r = util.revcomp(r) if rng.random() < 0.5 else r
+            r = r[:rng.randint(20, len(r))]
+            pos = rng.choice([0, L - len(r), rng.randrange(L - len(r)), 2432 * rng.randint(1, 13) - rng.randint(0, 60)])
+            g[pos:pos + len(r)] = r
+        if rng.random() < 0.5:
+            g[L - 14:] = rng.choice(refs)[:14]
+        if rng.random() < 0.5:
+            g[:15] = rng.choice(refs)[-15:]
+        reads.append(bytes(g))
+    reads += util.fuzz_reads(rng, refs, 30, short_lens, junk=True)
+    rng.shuffle(reads)
+    return reads
+
+
+@pytest.mark.parametrize("ci", range(len(KSCAN_LONG)))
+def test_kscan_long_reads(ci):
+    """k>31 and findBestMatch on reads beyond the tiled kernel's planes: bbduk_kscan_long_kernel (runs across chunk borders)."""
+    args, okw = KSCAN_LONG[ci]
+    rng = random.Random(66000 + ci)
+    refs = [util.rand_seq(rng, rng.randint(60, 400)) for _ in range(6)]
+    d, o = make_pair(args, okw, refs=refs)
+    reads = _long_mix(rng, refs, [0, 10, 150, 3000])
+    check_batch(d, o, reads[:17], False, nthreads=8)
+    check_batch(d, o, reads, True, nthreads=8)
+    assert d.gpu.counters()[B.NCOUNTERS:].sum() > 0
+    d.close()
+
+
+@pytest.mark.parametrize("ci", range(len(KSPLIT_LONG)))
+def test_ksplit_long_reads(ci):
+    args, okw = KSPLIT_LONG[ci]
+    rng = random.Random(77000 + ci)
+    refs = [util.rand_seq(rng, rng.randint(30, 90)) for _ in range(6)]
+    d, o = make_pair(args, okw, refs=refs)
+    reads = _long_mix(rng, refs, [0, 10, 150, 3000])
+    fl = check_split(d, o, reads)
+    assert int((fl & 2).astype(bool).sum()) > 0
     d.close()
 
