@@ -2344,8 +2344,9 @@ __device__ __forceinline__ void long_scan(const KParams& P, const Planes& Q, Sta
         if (MODE == BBDUK_MODE_KFILTER && R.iFirst == 0) break;                // countSetKmers / countCoveredBases returned
     }
     if (MODE != BBDUK_MODE_KFILTER && P.useShort && R.found == 0) {            // :2034-2103: the end's short k-mers
-        if (MODE == BBDUK_MODE_KTRIM_L) R.base0 = stage(off, start, min(stop, start + k));
-        else if (!staged || lastLo > max(start, stop - k)) R.base0 = stage(off, max(start, stop - k), stop);
+        // the end scans take the bases next to stop (right, regardless of start: :2072-2076) / between start and min(k, stop) (left)
+        if (MODE == BBDUK_MODE_KTRIM_L) { if (start < min(k, stop)) R.base0 = stage(off, start, min(k, stop)); }
+        else if (stop > 0 && (!staged || lastLo > max(0, stop - k))) R.base0 = stage(off, max(0, stop - k), stop);
         short_scan_pair<MODE, true>(P, Q, R, none, lane);
     }
 }
@@ -2578,7 +2579,8 @@ void bbduk_kmask_long_kernel(const KParams P, const uint8_t* __restrict__ bases,
                     const bool right = side == 1;
                     const int Ls = P.mink + lane;                   // one length per lane (k - mink < 64)
                     bool act; int i; uint64_t km = 0, rr = 0;
-                    const int b0 = right ? stage(off, max(R.start, R.stop - k), R.stop) : stage(off, R.start, min(R.stop, R.start + k));
+                    const int b0 = right ? (R.stop > 0 ? stage(off, max(0, R.stop - k), R.stop) : 0)
+                                         : (R.start < min(k, R.stop) ? stage(off, R.start, min(k, R.stop)) : 0);   // nothing to stage: no lane is active
                     if (!right) {
                         const int Lmax = min(k, R.stop) - R.start;
                         act = Ls <= Lmax; i = R.start + Ls - 1;
@@ -2729,7 +2731,8 @@ void bbduk_kscan_long_kernel(const KParams P, const uint8_t* __restrict__ bases,
                 const bool right = side == 1;
                 const int Ls = P.mink + lane;
                 bool act; int i; uint64_t km = 0, rr = 0;
-                const int b0 = right ? stage(off, max(R.start, R.stop - k), R.stop) : stage(off, R.start, min(R.stop, R.start + k));
+                const int b0 = right ? (R.stop > 0 ? stage(off, max(0, R.stop - k), R.stop) : 0)
+                                         : (R.start < min(k, R.stop) ? stage(off, R.start, min(k, R.stop)) : 0);   // nothing to stage: no lane is active
                 if (!right) {
                     const int Lmax = min(k, R.stop) - R.start;
                     act = Ls <= Lmax; i = R.start + Ls - 1;

@@ -73,7 +73,7 @@ def main():
         if fam in ("big", "fbm", "ksplit"):
             reads += util.long_refs_and_reads(rng)[1][:0]
             reads += [util.rand_seq(rng, rng.randint(0, 60)) + rng.choice(refs)[:rng.randint(20, 260)] + util.rand_seq(rng, rng.randint(0, 60)) for _ in range(100)]
-        if fam == "base" and rng.random() < 0.2:                # a few reads beyond the LDS tiles: the chunked long-read kernel takes the batch
+        if rng.random() < 0.2:                                  # a few reads beyond the LDS tiles: the chunked long-read kernels take over
             for _ in range(rng.randint(1, 4)):
                 L = rng.randint(41000, 110000)
                 g = bytearray(util.rand_seq(rng, L, 0.0005))
