@@ -84,9 +84,20 @@ def main():
         if len(reads) % 2: reads.append(b"")
         build = "device" if (rng.random() < 0.4 and okw.get("hdist", 0) <= 2 and "minSkip" not in okw) else "host"
         try:
-            d = B.BBDuk(args, refs=refs, build=build)
             o = Oracle(**okw)
             for r in refs: o.add_ref(r)
+            os.environ.pop("BBDUK_BUCKET_BITS", None); os.environ.pop("BBDUK_LDS_BITS", None)
+            squeeze = ""
+            if build == "host" and rng.random() < 0.35 and o.stored_kmers > 64:
+                # crowd the map (about 3.4 keys per 4-way bucket: long overflow chains, continuation flags everywhere) and / or
+                # shrink or drop the LDS presence filter: the rarely taken lookup paths
+                import math
+                bb = max(4, math.ceil(math.log2(o.stored_kmers / 3.4)))
+                if rng.random() < 0.7: os.environ["BBDUK_BUCKET_BITS"] = str(bb); squeeze += " bucketbits=%d" % bb
+                if rng.random() < 0.6: lb = rng.choice([0, 10, 12]); os.environ["BBDUK_LDS_BITS"] = str(lb); squeeze += " ldsbits=%d" % lb
+            d = B.BBDuk(args, refs=refs, build=build)
+            os.environ.pop("BBDUK_BUCKET_BITS", None); os.environ.pop("BBDUK_LDS_BITS", None)
+            if squeeze: fam_count["squeezed"] = fam_count.get("squeezed", 0) + 1
             assert d.stored_kmers == o.stored_kmers, ("stored", d.stored_kmers, o.stored_kmers)
             if fam == "kmask":
                 T.check_kmask(d, o, reads, True); T.check_kmask(d, o, reads[:101], False)
@@ -98,7 +109,7 @@ def main():
                 T.check_batch(d, o, reads, True); T.check_batch(d, o, reads[:101], False)
             d.close()
         except Exception as e:
-            print(json.dumps({"FAILED": True, "seed": seed, "family": fam, "args": args, "okw": okw, "build": build, "error": str(e)[:2000]}))
+            print(json.dumps({"FAILED": True, "seed": seed, "family": fam, "args": args, "okw": okw, "build": build, "squeeze": locals().get("squeeze", ""), "error": str(e)[:2000]}))
             sys.exit(1)
         n_cfg += 1; n_reads += len(reads); fam_count[fam] = fam_count.get(fam, 0) + 1
     print(json.dumps({"soak_seconds": round(time.time() - t0, 1), "configs": n_cfg, "reads_checked": n_reads * 3, "families": fam_count, "mismatches": 0, "seed": a.seed}))

@@ -837,3 +837,30 @@ def test_ksplit_long_reads(ci):
     assert int((fl & 2).astype(bool).sum()) > 0
     d.close()
 
+
+
+@pytest.mark.parametrize("lds", ["0", "10", None])
+def test_crowded_map_and_reduced_filter(monkeypatch, lds):
+    """The rarely taken lookup paths: a map squeezed to ~3.4 keys per 4-way bucket (long overflow chains, continuation flags
+    nearly everywhere) with the LDS presence filter dropped, tiny or as usual (BBDUK_BUCKET_BITS / BBDUK_LDS_BITS, read by
+    bbduk_finalize_table)."""
+    import math
+    for cfg in ("c2", "c3", "c1"):
+        args, okw, ref = util.CONFIGS[cfg]
+        o = Oracle(**okw); o.load_fasta(ref)
+        monkeypatch.setenv("BBDUK_BUCKET_BITS", str(max(4, math.ceil(math.log2(o.stored_kmers / 3.4)))))
+        if lds is not None:
+            monkeypatch.setenv("BBDUK_LDS_BITS", lds)
+        d = B.BBDuk(args)
+        monkeypatch.delenv("BBDUK_BUCKET_BITS"); monkeypatch.delenv("BBDUK_LDS_BITS", raising=False)
+        assert d.stored_kmers == o.stored_kmers
+        kw = dict(contam=B.read_fasta(util.PHIX)[0][1], contam_frac=0.05) if "phix" in args else {}
+        b, off = B.synth_generate_host(B.synth_params(77, **kw), 0, 20000)
+        o.reset_counters(); oa, oi, of = o.process_batch(b, off, True, nthreads=8)
+        ga, gi, gf = d.gpu.process_batch(b, off, True)
+        assert np.array_equal(ga, oa) and np.array_equal(gi, oi) and np.array_equal(gf, of), cfg
+        assert np.array_equal(d.gpu.counters(), o.counters())
+        ks, vs = o.dump_pairs()
+        sel = np.random.default_rng(1).choice(len(ks), min(5000, len(ks)), replace=False)
+        assert np.array_equal(d.gpu.table_lookup(ks[sel]), vs[sel])                     # every key is still found, with its id
+        d.close()
