@@ -864,3 +864,26 @@ def test_crowded_map_and_reduced_filter(monkeypatch, lds):
         sel = np.random.default_rng(1).choice(len(ks), min(5000, len(ks)), replace=False)
         assert np.array_equal(d.gpu.table_lookup(ks[sel]), vs[sel])                     # every key is still found, with its id
         d.close()
+
+
+@pytest.mark.parametrize("build", ["host", "device"])
+def test_large_map_without_lds_filter(build):
+    """More than 2^22 keys: the map gets no LDS presence filter (the HBM-resident regime of BASELINE config 4, in small).
+    One 4.6 Mbase random scaffold, k=31, reads half drawn from it."""
+    rng = np.random.default_rng(5)
+    ref = rng.choice(np.frombuffer(b"ACGT", np.uint8), 4_600_000).tobytes()
+    d, o = make_pair("k=31", dict(k=31), refs=[ref]) if build == "host" else (B.BBDuk("k=31", refs=[ref], build="device"), None)
+    if o is None:
+        o = Oracle(k=31); o.add_ref(ref)
+    assert d.stored_kmers == o.stored_kmers > (1 << 22)
+    prng = random.Random(9)
+    reads = []
+    for i in range(20000):
+        if i % 2:
+            a = prng.randrange(len(ref) - 150); r = ref[a:a + 150]
+            reads.append(util.revcomp(r) if prng.random() < 0.5 else r)
+        else:
+            reads.append(util.rand_seq(prng, 150, 0.002))
+    check_batch(d, o, reads, True, nthreads=8)
+    assert d.gpu.counters()[4] > 9000
+    d.close()
