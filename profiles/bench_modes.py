@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Secondary measurement: the secondary operators (ktrim=n, ktrim=rl, ksplit) on the configs[1] reads, device-resident,
+operator time by HIP events around the call.  One JSON line per mode."""
+import argparse, json, os, sys
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+import ctypes as C
+
+
+def main():
+    ap = argparse.ArgumentParser(); ap.add_argument("--reads", type=int, default=20_000_000)
+    a = ap.parse_args()
+    import torch
+    from bbtools_amd import bbduk as B
+    n = a.reads // 2 * 2
+    d_bases = torch.empty(n * 150, dtype=torch.uint8, device="cuda"); d_off = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    B.synth_generate_device(B.synth_params(2), 0, n // 2, d_bases, d_off, 0)
+    L = B.lib()
+    for args, mode in (("ktrim=n k=23 mink=11 hdist=1 ref=adapters", "kmask"), ("ktrim=rl k=23 mink=11 hdist=1 ref=adapters", "tips"),
+                       ("ksplit=t k=23 mink=11 hdist=1 ref=adapters", "ksplit")):
+        duk = B.BBDuk(args)
+        d_a = torch.empty(n, dtype=torch.int32, device="cuda"); d_b = torch.empty(n, dtype=torch.int32, device="cuda"); d_c2 = torch.empty(n, dtype=torch.int32, device="cuda")
+        d_i = torch.empty(n, dtype=torch.int32, device="cuda"); d_f = torch.empty(n, dtype=torch.uint8, device="cuda")
+        d_m = torch.zeros(n * 150 // 32 + 8, dtype=torch.int32, device="cuda")
+        d_ctr = torch.zeros(duk.gpu.counters_len, dtype=torch.int64, device="cuda")
+        h = duk.gpu.h
+        ts = []
+        for _ in range(4):
+            d_ctr.zero_(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
+            if mode == "kmask":
+                rc = L.bbduk_kmask_batch_device(h, d_bases.data_ptr(), d_off.data_ptr(), n, n * 150, 1, d_a.data_ptr(), d_i.data_ptr(), d_f.data_ptr(), d_m.data_ptr(), d_ctr.data_ptr(), None)
+            elif mode == "tips":
+                rc = L.bbduk_ktrimtips_batch_device(h, d_bases.data_ptr(), d_off.data_ptr(), n, n * 150, 1, d_a.data_ptr(), d_b.data_ptr(), d_i.data_ptr(), d_f.data_ptr(), d_ctr.data_ptr(), None)
+            else:
+                rc = L.bbduk_ksplit_batch_device(h, d_bases.data_ptr(), d_off.data_ptr(), n, n * 150, d_a.data_ptr(), d_b.data_ptr(), d_c2.data_ptr(), d_i.data_ptr(), d_f.data_ptr(), d_ctr.data_ptr(), None)
+            e1.record(); torch.cuda.synchronize()
+            assert rc == 0, rc
+            ts.append(e0.elapsed_time(e1))
+        ms = min(ts[1:]); c = d_ctr.cpu().numpy()
+        print(json.dumps({"mode": mode, "args": args, "reads": n, "operator_ms": round(ms, 2), "Gbases_per_s": round(n * 150 / ms / 1e6, 1), "readsKTrimmed": int(c[2]), "status": int(c[15])}))
+        duk.close()
+
+
+if __name__ == "__main__":
+    main()
