@@ -1845,37 +1845,54 @@ void bbduk_ktrimtips_kernel(const KParams P, const uint8_t* __restrict__ bases, 
 
             Planes Q; Q.fwd = s_fwd + PLANE_PAD; Q.cmp = s_cmp + PLANE_PAD; Q.nm = s_nm; Q.filt = s_filt; Q.T = nchunks * 16;
             Q.fwdBits = lds_bits_of(Q.fwd); Q.cmpBits = lds_bits_of(Q.cmp);
-            for (int rd = s + wave; rd < e; rd += NWAVES) {        // one wave per read
-                const int L = uni((int)(s_off[rd + 1] - s_off[rd]));
-                const int base0 = uni((int)(s_off[rd] - A0));
-                const int pairnum = paired ? (rd & 1) : 0;
-                const int mid = L / 2 - (k - 1) / 2;                // :1815
-                int cur = L, xr = 0, xl = 0, idr = -1, idl = -1;
-                ReadScan A, Bz;
-                auto reset = [&](ReadScan& R, int len, int start, int stop, bool scan) {
-                    R.base0 = base0; R.L = len; R.hasN = -1; R.maxBad = 0; R.start = start; R.stop = stop; R.scan = scan;
-                    R.found = 0; R.iFirst = BIGLOC; R.iLast = -1; R.ref = -1; R.shortFl = -1; R.shortLl = -1;
+            for (int ra = s + 2 * wave; ra < e; ra += 2 * NWAVES) {   // one wave per TWO consecutive reads: all four scan slots busy
+                const bool hasB = (ra + 1) < e;
+                const int rb = hasB ? ra + 1 : ra;
+                int L[2], base0[2], pn[2], mid[2], cur[2], xr[2] = {0, 0}, xl[2] = {0, 0}, idr[2] = {-1, -1}, idl[2] = {-1, -1};
+                L[0] = uni((int)(s_off[ra + 1] - s_off[ra])); L[1] = hasB ? uni((int)(s_off[rb + 1] - s_off[rb])) : 0;
+                base0[0] = uni((int)(s_off[ra] - A0)); base0[1] = uni((int)(s_off[rb] - A0));
+                pn[0] = paired ? (ra & 1) : 0; pn[1] = paired ? (rb & 1) : 0;
+#pragma unroll
+                for (int q = 0; q < 2; q++) { mid[q] = L[q] / 2 - (k - 1) / 2; cur[q] = L[q]; }      // :1815
+                ReadScan R[2];
+                auto reset = [&](ReadScan& X, int b0, int len, int start, int stop, bool scan) {
+                    X.base0 = b0; X.L = len; X.hasN = -1; X.maxBad = 0; X.start = start; X.stop = stop; X.scan = scan;
+                    X.found = 0; X.iFirst = BIGLOC; X.iLast = -1; X.ref = -1; X.shortFl = -1; X.shortLl = -1;
                 };
-                reset(Bz, 0, 0, 0, false);
-                {   // right tip (:1817-1820): ktrimTip(r, start, len, right)
-                    const int start = max(0, P.restrictRight < 1 ? mid : L - P.restrictRight);
-                    reset(A, cur, start, cur, scan_due<BBDUK_MODE_KTRIM_R, true, true>(P, cur, pairnum, true));
-                    main_scan_pair<BBDUK_MODE_KTRIM_R, true, true>(P, Q, A, Bz, lane);
-                    if (P.useShort) short_scan_pair<BBDUK_MODE_KTRIM_R, true>(P, Q, A, Bz, lane);
-                    int a, newLen, ref; bool hit;
-                    finish_read<BBDUK_MODE_KTRIM_R>(P, cur, A.start, A.stop, A.found, A.iFirst, A.iLast, A.shortFl, A.shortLl, A.ref, a, newLen, ref, hit);
-                    if (A.scan) { if (hit) { idr = ref; scaf_add(P, scaf, idr, cur, lane, counters); } xr = a; cur = newLen; }
+                {   // right tips (:1817-1820): ktrimTip(r, start, len, right)
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const int start = max(0, P.restrictRight < 1 ? mid[q] : L[q] - P.restrictRight);
+                        reset(R[q], base0[q], cur[q], start, cur[q], (q == 0 || hasB) && scan_due<BBDUK_MODE_KTRIM_R, true, true>(P, cur[q], pn[q], true));
+                    }
+                    main_scan_pair<BBDUK_MODE_KTRIM_R, true, true>(P, Q, R[0], R[1], lane);
+                    if (P.useShort) short_scan_pair<BBDUK_MODE_KTRIM_R, true>(P, Q, R[0], R[1], lane);
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        int a, newLen, ref; bool hit;
+                        finish_read<BBDUK_MODE_KTRIM_R>(P, cur[q], R[q].start, R[q].stop, R[q].found, R[q].iFirst, R[q].iLast, R[q].shortFl, R[q].shortLl, R[q].ref, a, newLen, ref, hit);
+                        if (R[q].scan) { if (hit) { idr[q] = ref; scaf_add(P, scaf, idr[q], cur[q], lane, counters); } xr[q] = a; cur[q] = newLen; }
+                    }
                 }
-                {   // left tip (:1821-1824) on the read as it is now
-                    const int stop = min(cur, P.restrictLeft < 1 ? mid + k - 1 : P.restrictLeft);
-                    reset(A, cur, 0, stop, scan_due<BBDUK_MODE_KTRIM_L, true, true>(P, cur, pairnum, true));
-                    main_scan_pair<BBDUK_MODE_KTRIM_L, true, true>(P, Q, A, Bz, lane);
-                    if (P.useShort) short_scan_pair<BBDUK_MODE_KTRIM_L, true>(P, Q, A, Bz, lane);
-                    int a, newLen, ref; bool hit;
-                    finish_read<BBDUK_MODE_KTRIM_L>(P, cur, A.start, A.stop, A.found, A.iFirst, A.iLast, A.shortFl, A.shortLl, A.ref, a, newLen, ref, hit);
-                    if (A.scan) { if (hit) { idl = ref; scaf_add(P, scaf, idl, cur, lane, counters); } xl = a; cur = newLen; }
+                {   // left tips (:1821-1824) on the reads as they are now
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const int stop = min(cur[q], P.restrictLeft < 1 ? mid[q] + k - 1 : P.restrictLeft);
+                        reset(R[q], base0[q], cur[q], 0, stop, (q == 0 || hasB) && scan_due<BBDUK_MODE_KTRIM_L, true, true>(P, cur[q], pn[q], true));
+                    }
+                    main_scan_pair<BBDUK_MODE_KTRIM_L, true, true>(P, Q, R[0], R[1], lane);
+                    if (P.useShort) short_scan_pair<BBDUK_MODE_KTRIM_L, true>(P, Q, R[0], R[1], lane);
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        int a, newLen, ref; bool hit;
+                        finish_read<BBDUK_MODE_KTRIM_L>(P, cur[q], R[q].start, R[q].stop, R[q].found, R[q].iFirst, R[q].iLast, R[q].shortFl, R[q].shortLl, R[q].ref, a, newLen, ref, hit);
+                        if (R[q].scan) { if (hit) { idl[q] = ref; scaf_add(P, scaf, idl[q], cur[q], lane, counters); } xl[q] = a; cur[q] = newLen; }
+                    }
                 }
-                if (lane == 0) { s_xr[rd] = xr; s_xl[rd] = xl; s_len[rd] = cur; s_id[rd] = idr >= 0 ? idr : idl; }
+                if (lane == 0) {
+                    s_xr[ra] = xr[0]; s_xl[ra] = xl[0]; s_len[ra] = cur[0]; s_id[ra] = idr[0] >= 0 ? idr[0] : idl[0];
+                    if (hasB) { s_xr[rb] = xr[1]; s_xl[rb] = xl[1]; s_len[rb] = cur[1]; s_id[rb] = idr[1] >= 0 ? idr[1] : idl[1]; }
+                }
             }
             __syncthreads();
             s = e;
