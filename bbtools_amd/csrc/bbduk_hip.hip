@@ -57,6 +57,7 @@ struct KParams {
     int32_t rieb, trimPad, ktrimExclusive, restrictLeft, restrictRight, skipR1, skipR2, numScaffolds, useShort;
     int32_t tpe, qskip, speed;   // trimpairsevenly; qskip (<2 = off) and speed (0 = off) run in the general kernels only
     float   mkf, mcf;            // kfilter: minkmerfraction / mincoveredfraction (general kernels only)
+    int32_t mfc;                 // kmaskfullycovered (ktrim=n): mask only bases all of whose covering k-mers match
     int32_t kbig, fbm;           // kfilter variants of bbduk_kscan_kernel: k>31 emulation (kbig>k), findBestMatch
     const uint32_t* undef;      // packed input (bbduk_*_batch_packed): 1 bit per base, set = undefined; `bases` then points at
                                 // 2-bit codes, 16 bases per 32-bit word (A0 C1 G2 T/U3, undefined 0).  nullptr = ASCII bases
@@ -1377,7 +1378,9 @@ void bbduk_kmask_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
                             const int i = ib + 128 * (q >> 1) + 2 * lane + (q & 1);
-                            if (ref[q] != -1) atomicOr(&s_hit[(base0 + i) >> 5], 1u << ((base0 + i) & 31));
+                            // the plane marks hits -- or, with kmaskfullycovered, the positions that do NOT match (looked up or
+                            // not, :2193-2195): every one of those clears its window of the initially full bit set
+                            if (P.mfc ? (i < W.stop && ref[q] == -1) : (ref[q] != -1)) atomicOr(&s_hit[(base0 + i) >> 5], 1u << ((base0 + i) & 31));
                         }
 #pragma unroll
                         for (int hb = 0; hb < 2; hb++) {            // id0 = id of the first hit in position order
@@ -1413,8 +1416,22 @@ void bbduk_kmask_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
                         if (id0 < 0 && mL) id0 = __builtin_amdgcn_readlane(sref, __ffs(mL) - 1);          // left hits first, shortest first
                         if (id0 < 0 && mR) id0 = __builtin_amdgcn_readlane(sref, 32 + __ffs(mR) - 1);
                         found += __popc(mL) + __popc(mR);
-                        if (mL) { const int iMax = R.start + (P.mink + (31 - __clz(mL))) - 1; leftEnd = max(0, min(L, iMax + tp + 1)); }     // :2236
-                        if (mR) { const int iMin = R.stop - (P.mink + (31 - __clz(mR))); rightStart = min(L, max(0, iMin - tp)); }           // :2279
+                        if (!P.mfc) {
+                            if (mL) { const int iMax = R.start + (P.mink + (31 - __clz(mL))) - 1; leftEnd = max(0, min(L, iMax + tp + 1)); }     // :2236
+                            if (mR) { const int iMin = R.stop - (P.mink + (31 - __clz(mR))); rightStart = min(L, max(0, iMin - tp)); }           // :2279
+                        } else {
+                            // fully covered: a length that does not match clears its end (:2243-2245, 2286-2288); the length mink-1 is
+                            // examined (len2>=minminlen) but never looked up, so it always clears.  leftEnd / rightStart become the
+                            // borders of the CLEARED prefix / suffix: the longest non-matching length decides.
+                            const int LmaxL = min(k, R.stop) - R.start, LmaxR = (R.stop >= k ? k - 1 : R.stop);
+                            const uint32_t actL = LmaxL >= P.mink ? (LmaxL - P.mink >= 31 ? ~0u : ((2u << (LmaxL - P.mink)) - 1u)) : 0u;
+                            const uint32_t actR = LmaxR >= P.mink ? (LmaxR - P.mink >= 31 ? ~0u : ((2u << (LmaxR - P.mink)) - 1u)) : 0u;
+                            const uint32_t missL = actL & ~mL, missR = actR & ~mR;
+                            const int lenL = missL ? P.mink + (31 - __clz(missL)) : ((P.mink - 1 >= 1 && LmaxL >= P.mink - 1) ? P.mink - 1 : 0);
+                            const int lenR = missR ? P.mink + (31 - __clz(missR)) : ((P.mink - 1 >= 1 && LmaxR >= P.mink - 1) ? P.mink - 1 : 0);
+                            if (lenL > 0) leftEnd = max(0, min(L, R.start + lenL - 1 + tp + 1));
+                            if (lenR > 0) rightStart = min(L, max(0, R.stop - lenR - tp));
+                        }
                     }
                 }
                 int card = 0;
@@ -1422,14 +1439,15 @@ void bbduk_kmask_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     scaf_add(P, scaf, id0, L, lane, counters);
                     const int64_t g0 = s_off[rd];                   // bit offset of the read in the output mask
-                    const int nb = L + max(tp, 0) + 1;              // BitSet size: bits >= L count but are not written
+                    const int nb = P.mfc ? L : L + max(tp, 0) + 1;   // BitSet size: bits >= L count but are not written
                     for (int b0 = 0; b0 < nb; b0 += 64) {
                         const int b = b0 + lane;
                         bool cov = false;
                         if (b < nb) {
                             const int lo = max(0, b - tp), hi = min(L - 1, b + k - 1 - tp);
                             if (lo <= hi) cov = extract1(s_hit, base0 + lo, hi - lo + 1) != 0u;      // hi-lo+1 <= k <= 31
-                            if (b < L) cov = cov || b < leftEnd || b >= rightStart;
+                            if (!P.mfc) { if (b < L) cov = cov || b < leftEnd || b >= rightStart; }
+                            else cov = !cov && b >= leftEnd && b < rightStart;                        // nothing cleared this base
                         }
                         const uint64_t cm = __ballot(cov);
                         card += __popcll(cm);
@@ -2562,6 +2580,10 @@ void bbduk_kmask_long_kernel(const KParams P, const uint8_t* __restrict__ bases,
 #pragma unroll
                     for (int hb = 0; hb < 2; hb++) {
                         const uint64_t me = __ballot(ref[2 * hb] != -1), mo = __ballot(ref[2 * hb + 1] != -1);
+                        if (P.mfc && !(me | mo)) {                  // fully covered, no match in these 128 positions: they clear one span
+                            const int iA = ib + 128 * hb, iB = min(iA + 128, W.stop);
+                            if (iA < iB) set_range(off, iA - (k - 1 - tp), iB - 1 + tp + 1, L);
+                        }
                         if (!(me | mo)) continue;
                         const int i0 = ib + 128 * hb;
                         if (id0 < 0) {
@@ -2572,9 +2594,10 @@ void bbduk_kmask_long_kernel(const KParams P, const uint8_t* __restrict__ bases,
                         iLast = max(iLast, i0 + max(2 * he, 2 * ho + 1));
                         found += __popcll(me) + __popcll(mo);
 #pragma unroll
-                        for (int par = 0; par < 2; par++) {            // bs.set(max(0,i-minus), i+plus) for this lane's hit (:2190)
-                            if (ref[2 * hb + par] != -1) {
-                                const int i = i0 + 2 * lane + par;
+                        for (int par = 0; par < 2; par++) {            // bs.set(max(0,i-minus), i+plus) for this lane's hit (:2190);
+                            const int ip = i0 + 2 * lane + par;        // fully covered: the lanes that do NOT match mark what they clear (:2194)
+                            if (P.mfc ? (ip < W.stop && ref[2 * hb + par] == -1) : (ref[2 * hb + par] != -1)) {
+                                const int i = ip;
                                 const int b0 = max(0, i - (k - 1 - tp)), b1 = min(L, i + tp + 1);
                                 if (b0 < b1) {
                                     const int64_t a = off + b0, b = off + b1;   // at most k+|tp| <= 64 bits: up to three words
@@ -2616,16 +2639,37 @@ void bbduk_kmask_long_kernel(const KParams P, const uint8_t* __restrict__ bases,
                     if (hm) {
                         if (id0 < 0) id0 = __builtin_amdgcn_readlane(sref, __ffsll((unsigned long long)hm) - 1);     // left side first, shortest first
                         found += __popcll(hm);
-                        const int longest = P.mink + (63 - __clzll((unsigned long long)hm));
-                        if (!right) leftEnd = max(0, min(L, R.start + longest - 1 + tp + 1));                           // :2236
-                        else rightStart = min(L, max(0, R.stop - longest - tp));                                        // :2279
+                    }
+                    if (!P.mfc) {
+                        if (hm) {
+                            const int longest = P.mink + (63 - __clzll((unsigned long long)hm));
+                            if (!right) leftEnd = max(0, min(L, R.start + longest - 1 + tp + 1));                       // :2236
+                            else rightStart = min(L, max(0, R.stop - longest - tp));                                    // :2279
+                        }
+                    } else {                                        // the longest length that does not match clears its end (see bbduk_kmask_kernel)
+                        const int Lmax = right ? (R.stop >= k ? k - 1 : R.stop) : (min(k, R.stop) - R.start);
+                        const uint64_t actM = Lmax >= P.mink ? (Lmax - P.mink >= 63 ? ~0ULL : ((2ULL << (Lmax - P.mink)) - 1ULL)) : 0ULL;
+                        const uint64_t miss = actM & ~hm;
+                        const int lenM = miss ? P.mink + (63 - __clzll((unsigned long long)miss)) : ((P.mink - 1 >= 1 && Lmax >= P.mink - 1) ? P.mink - 1 : 0);
+                        if (lenM > 0) { if (!right) leftEnd = max(0, min(L, R.start + lenM - 1 + tp + 1)); else rightStart = min(L, max(0, R.stop - lenM - tp)); }
                     }
                 }
-                if (found > 0) { set_range(off, 0, leftEnd, L); set_range(off, rightStart, L, L); }
+                if (found > 0 || P.mfc) { set_range(off, 0, leftEnd, L); set_range(off, rightStart, L, L); }
             }
         }
         int card = 0;
-        if (found > 0) {
+        if (P.mfc && R.scan) {                                      // what was marked is what is CLEARED: flip the read's bits, or drop them
+            __threadfence();
+            int c = 0;
+            const int64_t a = off, b = off + L;
+            for (int64_t w = (a >> 5) + lane; w <= ((b - 1) >> 5); w += 64) {
+                uint32_t m = ~0u;
+                if ((w << 5) < a) m &= ~0u << (int)(a - (w << 5));
+                if ((w << 5) + 32 > b) m &= ~0u >> (int)((w << 5) + 32 - b);
+                if (found > 0) c += __popc((atomicXor(&outMask[w], m) ^ m) & m); else atomicAnd(&outMask[w], ~m);
+            }
+            if (found > 0) { scaf_add(P, scaf, id0, L, lane, counters); card = wave_sum(c); }
+        } else if (found > 0) {
             scaf_add(P, scaf, id0, L, lane, counters);
             __threadfence();
             int c = 0;
@@ -3073,7 +3117,7 @@ extern "C" int bbduk_create(const bbduk_params* p, bbduk_handle** out) {
     if (useShort && p->middleMask != -1) return BBDUK_ERR_ARG;                // BBDukProcessorS.java:2035 assert
     if (p->minlen != p->k - 1) return BBDUK_ERR_ARG;
     if (p->speed < 0 || p->speed > 16 || p->qSkip < 0) return BBDUK_ERR_ARG;    // BBDukParser.java:568
-    if (p->reserved[0] != 0) return BBDUK_ERR_ARG;
+    if (p->kmaskFullyCovered && p->mode != BBDUK_MODE_KMASK) return BBDUK_ERR_ARG;
     const bool big = p->kbig > p->k;
     if (big) {                                                                  // BBDukParser.java:164, 207-243, 299
         if (p->k != 31 || p->kbig > BBDUK_MAX_READ_LEN) return BBDUK_ERR_ARG;
@@ -3290,6 +3334,7 @@ static KParams make_kparams(const bbduk_handle* h) {
     K.tpe = (p.trimPairsEvenly && (p.mode == BBDUK_MODE_KTRIM_R || p.mode == BBDUK_MODE_KTRIM_TIPS)) ? 1 : 0; K.qskip = p.qSkip; K.speed = p.speed;
     K.mkf = p.mode == BBDUK_MODE_KFILTER ? p.minKmerFraction : 0.f; K.mcf = p.mode == BBDUK_MODE_KFILTER ? p.minCoveredFraction : 0.f;
     K.kbig = p.kbig > p.k ? p.kbig : p.k; K.fbm = p.findBestMatch ? 1 : 0;
+    K.mfc = (p.kmaskFullyCovered && p.mode == BBDUK_MODE_KMASK) ? 1 : 0;
     K.numScaffolds = p.numScaffolds;
     K.useShort = (p.mink > 0 && p.mink < p.k) ? 1 : 0;
     K.mask = (2 * p.k > 63) ? ~0ULL : ~(~0ULL << (2 * p.k));

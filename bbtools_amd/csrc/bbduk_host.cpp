@@ -40,6 +40,7 @@ struct Parsed {                      // bbduk/BBDukParser.java fields (subset th
     int qSkip = 1, speed = 0;        // :1373-1377
     float minKmerFraction = 0.f, minCoveredFraction = 0.f;   // :1234-1236
     bool ksplit = false, findBestMatch = false;              // :1313, 1323
+    bool kmaskFullyCovered = false;                          // :1317
     int kbig = -1;                                           // :1226 (derived: the requested k when it exceeds 31)
     std::vector<std::string> ref, literal;
     // derived (:130-312)
@@ -221,8 +222,7 @@ extern "C" int bbduk_host_parse(const char* args, bbduk_host** out, char* errbuf
         else if (a == "rename") { bool x = false; need_bool(x); if (ok && x) { seterr("rename=t is not supported by this path"); delete h; return BBDUK_ERR_ARG; } }
         else if (a == "ktrimn") { need_bool(p.ktrimN); if (ok) p.ktrimLeft = p.ktrimRight = !p.ktrimN; }
         else if (a == "kmaskfullycovered" || a == "maskfullycovered" || a == "mfc") {
-            bool x = false; need_bool(x);
-            if (ok && x) { seterr("kmaskfullycovered=t is not supported by this path yet"); delete h; return BBDUK_ERR_ARG; }
+            need_bool(p.kmaskFullyCovered);
         }
         else if (a == "kfilter") { bool x = false; need_bool(x); if (x) { p.ktrimLeft = p.ktrimRight = false; p.ktrimN = p.ksplit = false; } }
         else if (a == "maxbadkmers" || a == "mbk") need_int(p.maxBadKmers0);
@@ -399,6 +399,7 @@ extern "C" int bbduk_host_params(const bbduk_host* h, int32_t device, bbduk_para
     out->skipR1 = p.skipR1; out->skipR2 = p.skipR2;
     out->trimPairsEvenly = p.trimPairsEvenly; out->qSkip = p.qSkip; out->speed = p.speed;
     out->minKmerFraction = p.minKmerFraction; out->minCoveredFraction = p.minCoveredFraction;
+    out->kmaskFullyCovered = (p.kmaskFullyCovered && out->mode == BBDUK_MODE_KMASK) ? 1 : 0;
     out->kbig = p.kbig > p.k ? p.kbig : 0;
     out->findBestMatch = (p.findBestMatch && out->mode == BBDUK_MODE_KFILTER) ? 1 : 0;
     out->numScaffolds = (int32_t)h->scaffolds.size() + 1;

@@ -102,7 +102,8 @@ typedef struct bbduk_params {
                                        237-243): kfilter counts runs of consecutive 31-mer hits (countSetKmersBig, :1726-1804); <= k = off */
     int32_t findBestMatch;          /* findbestmatch/fbm (kfilter; BBDukProcessorS.java:1659-1719): out_id = the scaffold with the most
                                        hits, out_found = hits counted; needs maxBadKmers == 0 and minKmerFraction == 0 */
-    int32_t reserved[1];            /* must be zero */
+    int32_t kmaskFullyCovered;      /* kmaskfullycovered / mfc (ktrim=n; BBDukProcessorS.java:2163, 2193-2195, 2243-2245, 2286-2288): only
+                                       bases all of whose covering k-mers match stay masked */
 } bbduk_params;
 
 typedef struct bbduk_handle bbduk_handle;
@@ -216,7 +217,7 @@ int  bbduk_fastq_write_device(const uint8_t* d_text1, const int64_t* d_lines1, c
                               int64_t n, const int32_t* d_left, const int32_t* d_right, const uint8_t* d_flags, int32_t want_removed,
                               uint8_t* d_out, int64_t cap_out, int32_t device, void* stream, int64_t* out_bytes);
 
-/* ---- ktrim=n (bbduk/BBDukProcessorS.java:2149-2323, kmaskFullyCovered=false).  out_masked[i] = kmask(Read)'s return
+/* ---- ktrim=n (bbduk/BBDukProcessorS.java:2149-2323; bbduk_params.kmaskFullyCovered selects the fully-covered variant).  out_masked[i] = kmask(Read)'s return
  * (BitSet.cardinality()), out_mask = one bit per base of the concatenated `bases` buffer (bit b of word b/32 set <=> the
  * caller replaces base b by trimSymbol / lower-cases it, :2309-2320); (offsets[n]+31)/32 words, the device variant needs
  * two more words of slack and clears the buffer itself.  Pair flags as for ktrim (reads keep their length). */

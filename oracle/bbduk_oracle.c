@@ -224,7 +224,7 @@ void bbo_default_args(bbo_args* a) {
     a->minSkip = 1; a->maxSkip = 1;
     a->trimPairsEvenly = 0; a->qSkip = 1; a->speed = 0;
     a->minKmerFraction = 0.f; a->minCoveredFraction = 0.f; a->ktrimN = 0;
-    a->kbig = -1; a->findBestMatch = 0; a->ksplit = 0;
+    a->kbig = -1; a->findBestMatch = 0; a->ksplit = 0; a->kmaskFullyCovered = 0;
 }
 
 static int imax(int a, int b) { return a > b ? a : b; }
@@ -930,6 +930,9 @@ static void bs_set(uint64_t* bs, int from, int to) {
 
 /* bbduk/BBDukProcessorS.java:2149-2323 kmask(Read), kmaskFullyCovered=false.  Returns bs.cardinality(); the masked
  * positions < blen are OR-ed into gmask at bit offset gbase (atomically: neighbouring reads share words). */
+static void bs_clear(uint64_t* bs, int from, int to) {       /* java.util.BitSet.clear(from,to) */
+    for (int i = from; i < to; i++) bs[i >> 6] &= ~(1ULL << (i & 63));
+}
 static int kmask_read(const bbo_ctx* c, tcounters* tc, const uint8_t* bases, const int blen, const int pairnum, int* id0out,
                       uint32_t* gmask, const int64_t gbase) {
     const int k = c->k;
@@ -943,6 +946,8 @@ static int kmask_read(const bbo_ctx* c, tcounters* tc, const uint8_t* bases, con
     const int nbits = blen + (trimPad > 0 ? trimPad : 0) + 1;
     uint64_t* bs = (uint64_t*)calloc((size_t)(nbits + 64) / 64 + 1, sizeof(uint64_t));
     const int minus = k - 1 - trimPad, plus = trimPad + 1;
+    const int mfc = c->a.kmaskFullyCovered;
+    if (mfc) bs_set(bs, 0, blen);                                                    /* :2163 */
     const int start = (c->a.restrictRight < 1 ? 0 : imax(0, blen - c->a.restrictRight));
     const int stop  = (c->a.restrictLeft  < 1 ? blen : imin(blen, c->a.restrictLeft));
     for (int i = start; i < stop; i++) {                                             /* :2171-2200 */
@@ -957,9 +962,9 @@ static int kmask_read(const bbo_ctx* c, tcounters* tc, const uint8_t* bases, con
             else id = -1;
             if (id > 0) {
                 if (id0 < 0) id0 = id;
-                bs_set(bs, imax(0, i - minus), i + plus);
+                if (!mfc) bs_set(bs, imax(0, i - minus), i + plus);
                 found++;
-            }
+            } else if (mfc) bs_clear(bs, imax(0, i - minus), imin(nbits, i + plus));
         }
     }
     if (c->useShortKmers) {                                                          /* :2203-2291: always, both sides */
@@ -972,13 +977,13 @@ static int kmask_read(const bbo_ctx* c, tcounters* tc, const uint8_t* bases, con
                 kmer = (int64_t)((((uint64_t)kmer << 2) | (uint64_t)x) & (uint64_t)c->mask);
                 rkmer = rkmer | (int64_t)((uint64_t)x2 << (2 * len));
                 len++;
-                if (len >= c->mink) {
-                    const int id = bbo_get_value(c, kmer, rkmer, c->lengthMasks[len], i, len, c->qHammingDistance2);
+                if (len >= c->minminlen) {                                             /* len2>=minminlen; looked up from mink on */
+                    const int id = (len >= c->mink) ? bbo_get_value(c, kmer, rkmer, c->lengthMasks[len], i, len, c->qHammingDistance2) : -1;
                     if (id > 0) {
                         if (id0 < 0) id0 = id;
-                        bs_set(bs, 0, imin(blen, i + trimPad + 1));
+                        if (!mfc) bs_set(bs, 0, imin(blen, i + trimPad + 1));
                         found++;
-                    }
+                    } else if (mfc) bs_clear(bs, 0, imin(blen, i + trimPad + 1));
                 }
             }
         }
@@ -991,13 +996,13 @@ static int kmask_read(const bbo_ctx* c, tcounters* tc, const uint8_t* bases, con
                 kmer = kmer | (int64_t)((uint64_t)x << (2 * len));
                 rkmer = (int64_t)((((uint64_t)rkmer << 2) | (uint64_t)x2) & (uint64_t)c->mask);
                 len++;
-                if (len >= c->mink) {
-                    const int id = bbo_get_value(c, kmer, rkmer, c->lengthMasks[len], i, len, c->qHammingDistance2);
+                if (len >= c->minminlen) {
+                    const int id = (len >= c->mink) ? bbo_get_value(c, kmer, rkmer, c->lengthMasks[len], i, len, c->qHammingDistance2) : -1;
                     if (id > 0) {
                         if (id0 < 0) id0 = id;
-                        bs_set(bs, imax(0, i - trimPad), blen);
+                        if (!mfc) bs_set(bs, imax(0, i - trimPad), blen);
                         found++;
-                    }
+                    } else if (mfc) bs_clear(bs, imax(0, i - trimPad), blen);
                 }
             }
         }

@@ -54,6 +54,7 @@ typedef struct bbo_args {
     int kbig;           /* the k of the command line when it exceeds 31 (then k=31; BBDukParser.java:164-165), else <= k */
     int findBestMatch;  /* findbestmatch / fbm (BBDukProcessorS.java:1659-1719; rename is not restated) */
     int ksplit;         /* ksplit=t (BBDukProcessorS.java:2332-2506; unpaired reads) */
+    int kmaskFullyCovered; /* kmaskfullycovered / mfc (:2163, 2193-2195, 2243-2245, 2286-2288) */
 } bbo_args;
 
 #define BBO_NCOUNTERS 16

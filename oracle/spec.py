@@ -74,6 +74,7 @@ class Args:
     kbig: int = -1                  # k>31 on the command line: k is then 31 and kbig the requested k (BBDukParser.java:164-165)
     findBestMatch: bool = False     # findbestmatch / fbm (kfilter only; rename is not restated)
     ksplit: bool = False            # ksplit=t (unpaired reads only)
+    kmaskFullyCovered: bool = False # kmaskfullycovered / mfc: mask only bases covered by matching k-mers in every window
     minSkip: int = 1                # rskip / minskip / maxskip: reference-side k-mer skipping (BBDukLoader.java:417, 432-449)
     maxSkip: int = 1
 
@@ -373,6 +374,8 @@ class Spec:
             return 0, -1, 0
         if n < k:                                                                  # :2154
             return 0, -1, 0
+        if a.kmaskFullyCovered:
+            return self._kmask_fully_covered(read)
         bs = 0                                                                     # BitSet(n + trimPad + 1)
         def bset(lo, hi):
             nonlocal bs
@@ -424,6 +427,63 @@ class Spec:
         self.scafReads[id0] += 1
         self.scafBases[id0] += n
         return bin(bs).count("1"), id0, bs & ((1 << n) - 1)
+
+    def _kmask_fully_covered(self, read: bytes):
+        """kmask with kmaskFullyCovered=true (:2163, 2193-2195, 2243-2245, 2286-2288): the bit set starts full and every k-mer
+        position that does NOT match (looked up or not) clears its window; short k-mer positions that do not match clear
+        their end of the read, the length mink-1 included (it is examined, len2>=minminlen, but never looked up).  Only
+        clears happen, so the result is the complement of a union of ranges."""
+        a, k, n = self.a, self.k, len(read)
+        minus, plus = k - 1 - a.trimPad, a.trimPad + 1
+        start, stop = self._span(n)
+        cleared = [False] * (n + max(plus, 0) + 2)
+        def clr(lo, hi):
+            for b in range(max(lo, 0), min(hi, len(cleared))):
+                cleared[b] = True
+        found, id0 = 0, -1
+        hit_at = dict(self._main_hits(read, start, stop))
+        for i in range(max(start, k - 1), stop):                                   # if(i>=minlen): a hit, or a clear
+            if i in hit_at:
+                if id0 < 0: id0 = hit_at[i]
+                found += 1
+            else:
+                clr(max(0, i - minus), i + plus)
+        if self.useShortKmers:
+            for i in range(start, min(k, stop)):                                   # left side
+                L = i - start + 1
+                if L < self.mink - 1:
+                    continue
+                vid = self._short_lookup_left(read[start:i + 1], L, i) if L >= self.mink else -1
+                if vid > 0:
+                    if id0 < 0: id0 = vid
+                    found += 1
+                else:
+                    clr(0, min(n, i + a.trimPad + 1))
+            for L in range(1, (k - 1 if stop >= k else stop) + 1):                 # right side
+                i = stop - L
+                if L < self.mink - 1:
+                    continue
+                vid = self._short_lookup(read[i:stop], L, i) if L >= self.mink else -1
+                if vid > 0:
+                    if id0 < 0: id0 = vid
+                    found += 1
+                else:
+                    clr(max(0, i - a.trimPad), n)
+        if found == 0:
+            return 0, -1, 0
+        self.scafReads[id0] += 1
+        self.scafBases[id0] += n
+        bs = sum(1 << b for b in range(n) if not cleared[b])
+        return bin(bs).count("1"), id0, bs
+
+    def _short_lookup_left(self, sub: bytes, L: int, qpos: int) -> int:
+        km = 0
+        for c in sub:
+            km = ((km << 2) | fwd_code(c)) & ((1 << (2 * self.k)) - 1)
+        rk = 0
+        for t, c in enumerate(sub):
+            rk |= comp_code(c) << (2 * t)
+        return self.lookup(km, rk, L, self.qhdist2, qpos)
 
     def count_set_kmers(self, read: bytes, pairnum: int, maxBad: int):
         """Returns (found, id).  bbduk/BBDukProcessorS.java:1534-1593."""

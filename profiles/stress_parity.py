@@ -32,6 +32,7 @@ def main():
             toks = args.split()
         elif fam == "kmask":
             toks.append("ktrim=n"); okw["ktrimN"] = 1
+            if rng.random() < 0.4: toks.append("mfc=t"); okw["kmaskFullyCovered"] = 1
             for kk in ("maxBadKmers0", "minKmerFraction", "minCoveredFraction", "ktrimExclusive"):
                 okw.pop(kk, None)
             toks = [t for t in toks if not t.startswith(("mbk=", "mkf=", "mcf=", "ktrimexclusive"))]

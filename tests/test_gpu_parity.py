@@ -305,7 +305,10 @@ def test_device_operator_and_full_size_properties():
 
 
 # ---- ktrim=n (kmask): counts, ids, flags, counters and the per-base masks
-KMASK = [("ktrim=n k=23", dict(k=23, ktrimN=1)), ("ktrim=N k=23 mink=11 hdist=1", dict(k=23, ktrimN=1, mink=11, hdist=1)),
+KMASK = [("ktrim=n k=11 mfc=t", dict(k=11, ktrimN=1, kmaskFullyCovered=1)), ("ktrim=n k=13 mink=6 hdist=1 kmaskfullycovered=t", dict(k=13, ktrimN=1, mink=6, hdist=1, kmaskFullyCovered=1)),
+         ("ktrim=n k=15 tp=2 forbidn=t restrictright=50 mfc", dict(k=15, ktrimN=1, trimPad=2, forbidN=1, restrictRight=50, kmaskFullyCovered=1)),
+         ("ktrim=n k=12 mink=5 tp=-2 restrictleft=70 mfc=t qhdist=1 qskip=2", dict(k=12, ktrimN=1, mink=5, trimPad=-2, restrictLeft=70, kmaskFullyCovered=1, qhdist=1, qSkip=2)),
+         ("ktrim=n k=23", dict(k=23, ktrimN=1)), ("ktrim=N k=23 mink=11 hdist=1", dict(k=23, ktrimN=1, mink=11, hdist=1)),
          ("kmask=lc k=15 tp=2 forbidn=t restrictright=50", dict(k=15, ktrimN=1, trimPad=2, forbidN=1, restrictRight=50)),
          ("ktrim=n k=12 mink=5 tp=-2 qhdist=1 mm=f", dict(k=12, ktrimN=1, mink=5, trimPad=-2, qhdist=1, maskMiddle=0)),
          ("kmask=t k=17 rieb=f minlen=40 skipr1=t", dict(k=17, ktrimN=1, requireBothBad=1, minReadLength=40, skipR1=1)),
@@ -337,7 +340,7 @@ def test_kmask_fuzz_parity(ci):
         total += check_kmask(d, o, reads, True)
         total += check_kmask(d, o, reads[:301], False)
         d.close()
-    assert total > 0
+    assert total > 0 or okw.get("kmaskFullyCovered")            # (with mink the fully-covered variant clears both ends of every read)
 
 
 def test_kmask_adapters_and_long_reads():
@@ -720,7 +723,8 @@ def test_concurrent_device_operators_on_streams():
     d.close()
 
 
-KMASK_LONG = [("ktrim=n k=13 mink=7 restrictleft=118 restrictright=60", dict(k=13, ktrimN=1, mink=7, restrictLeft=118, restrictRight=60)), ("ktrim=n k=23", dict(k=23, ktrimN=1)), ("ktrim=N k=21 mink=9 hdist=1 tp=2", dict(k=21, ktrimN=1, mink=9, hdist=1, trimPad=2)),
+KMASK_LONG = [("ktrim=n k=21 mfc=t", dict(k=21, ktrimN=1, kmaskFullyCovered=1)), ("ktrim=n k=17 mink=8 tp=1 mfc=t hdist=1", dict(k=17, ktrimN=1, mink=8, trimPad=1, kmaskFullyCovered=1, hdist=1)),
+              ("ktrim=n k=13 mink=7 restrictleft=118 restrictright=60", dict(k=13, ktrimN=1, mink=7, restrictLeft=118, restrictRight=60)), ("ktrim=n k=23", dict(k=23, ktrimN=1)), ("ktrim=N k=21 mink=9 hdist=1 tp=2", dict(k=21, ktrimN=1, mink=9, hdist=1, trimPad=2)),
               ("kmask=lc k=25 tp=-3 forbidn=t", dict(k=25, ktrimN=1, trimPad=-3, forbidN=1)), ("ktrim=n k=19 mink=7 restrictleft=60000 qhdist=1 skipr2=t", dict(k=19, ktrimN=1, mink=7, restrictLeft=60000, qhdist=1, skipR2=1)),
               ("ktrim=n k=27 restrictright=50000 minlen=45000 rieb=f", dict(k=27, ktrimN=1, restrictRight=50000, minReadLength=45000, requireBothBad=1))]
 

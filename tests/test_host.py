@@ -94,6 +94,8 @@ def test_parser_errors_like_the_reference():
     assert B.HostIndex("k=23 ksplit=t ktrim=r").params().mode == B.MODE_KTRIM_R    # a later ktrim= clears it (:604-620)
     with pytest.raises(B.BBDukError):
         B.HostIndex("k=23 ksplit tp=2")
+    assert B.HostIndex("ktrim=n k=23 mfc=t").params().kmaskFullyCovered == 1
+    assert B.HostIndex("ktrim=r k=23 kmaskfullycovered=t").params().kmaskFullyCovered == 0     # only kmask() consults it
     h = B.HostIndex("ktrim=r")                            # k defaults to 27 (:163)
     assert h.params().k == 27
     h = B.HostIndex("ktrim=r k=23 mkh=3 rieb=f mlf=0.5 minlen=20 tp=1")
