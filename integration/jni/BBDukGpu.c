@@ -17,7 +17,7 @@
 #define UNPIN_OUT(a, p) do { if (a) (*env)->ReleasePrimitiveArrayCritical(env, (a), (p), 0); } while (0)           /* outputs: copy back   */
 
 JNIEXPORT jlong JNICALL Java_bbduk_BBDukGpu_createJNI(JNIEnv* env, jclass cls, jintArray ip, jlong middleMask, jfloatArray fp) {
-    if ((*env)->GetArrayLength(env, ip) < 25 || (*env)->GetArrayLength(env, fp) < 3) return BBDUK_ERR_ARG;
+    if ((*env)->GetArrayLength(env, ip) < 26 || (*env)->GetArrayLength(env, fp) < 3) return BBDUK_ERR_ARG;
     jint* v = (jint*)PIN(ip);
     jfloat* f = (jfloat*)PIN(fp);
     bbduk_params p;
@@ -28,7 +28,7 @@ JNIEXPORT jlong JNICALL Java_bbduk_BBDukGpu_createJNI(JNIEnv* env, jclass cls, j
     p.qhdist = v[7]; p.qhdist2 = v[8]; p.maxBadKmers = v[9]; p.minReadLength = v[10];
     p.removePairsIfEitherBad = v[11]; p.trimPad = v[12]; p.ktrimExclusive = v[13];
     p.restrictLeft = v[14]; p.restrictRight = v[15]; p.skipR1 = v[16]; p.skipR2 = v[17]; p.numScaffolds = v[18]; p.device = v[19];
-    p.trimPairsEvenly = v[20]; p.qSkip = v[21]; p.speed = v[22]; p.kbig = v[23]; p.findBestMatch = v[24];
+    p.trimPairsEvenly = v[20]; p.qSkip = v[21]; p.speed = v[22]; p.kbig = v[23]; p.findBestMatch = v[24]; p.kmaskFullyCovered = v[25];
     p.minLenFraction = f[0]; p.minKmerFraction = f[1]; p.minCoveredFraction = f[2];
     UNPIN_IN(fp, f);
     UNPIN_IN(ip, v);
