@@ -81,7 +81,7 @@ int derive(Parsed& p, std::string& err) {            // bbduk/BBDukParser.java:1
     if (p.hdist2 == -1) p.hdist2 = p.hdist;
     if (p.qhdist2 == -1) p.qhdist2 = p.qhdist;
     if (p.edist2 == -1) p.edist2 = p.edist;
-    if (p.edist > 0 || p.edist2 > 0) { err = "edist>0 is not supported by this path"; return BBDUK_ERR_ARG; }
+    if (p.edist > 1 || p.edist2 > 1) { err = "edist>1 is not supported by this path (the expansion is quadratic per k-mer)"; return BBDUK_ERR_ARG; }
     p.hdist = std::max(p.edist, p.hdist);
     p.hdist2 = std::max(p.edist2, p.hdist2);
     p.minSkip = std::max(1, std::min(p.minSkip, p.maxSkip));
@@ -161,6 +161,50 @@ void expand(uint64_t v, int len, int dist, std::vector<uint64_t>& out) {
 void emit(bbduk_host* h, uint64_t v, int len, int dist, int id, std::vector<uint64_t>& tmp) {
     const Parsed& p = h->p;
     expand(v, len, dist, tmp);
+    const uint64_t lmask = 1ULL << (2 * len);
+    for (uint64_t t : tmp) {
+        const uint64_t r = rcomp_bits(t, len);
+        const uint64_t mx = p.rcomp ? std::max(t, r) : t;
+        h->cand.push_back(KV{(mx & (uint64_t)p.middleMask) | lmask, id});
+    }
+}
+
+// Reference-side EDIT expansion (bbduk/BBDukIndexMod.java:383-445 mutate with editDistance>0): substitutions, deletions (the
+// base behind the k-mer moves in: extraBase) and insertions (the last base falls out and becomes the next level's extraBase).
+// indels: the reference tests the GLOBAL editDistance there (:415), also for the short k-mers that run with editDistance2.
+void edits(uint64_t kmer, int len, int dist, int64_t extraBase, bool indels, std::vector<uint64_t>& out) {
+    out.push_back(kmer);
+    if (dist <= 0) return;
+    const int d2 = dist - 1;
+    for (uint64_t j = 0; j < 4; j++)                                  // Sub (:404-412)
+        for (int i = 0; i < len; i++) {
+            const uint64_t t = (kmer & ~(3ULL << (2 * i))) | (j << (2 * i));
+            if (t != kmer) edits(t, len, d2, extraBase, indels, out);
+        }
+    if (!indels) return;
+    if (extraBase >= 0 && extraBase <= 3)                             // Del (:415-425)
+        for (int i = 1; i < len; i++) {
+            const uint64_t left = ~0ULL << (2 * i), right = ~left;
+            const uint64_t t = (kmer & left) | ((kmer << 2) & right) | (uint64_t)extraBase;
+            if (t != kmer) edits(t, len, d2, -1, indels, out);
+        }
+    const int64_t eb2 = (int64_t)(kmer & 3ULL);                       // Ins (:427-439)
+    for (int i = 1; i < len; i++) {
+        const uint64_t left = ~0ULL << (2 * i), right = ~left;
+        const uint64_t t0 = (kmer & left) | ((kmer & right) >> 2);
+        for (uint64_t j = 0; j < 4; j++) {
+            const uint64_t t = t0 | (j << (2 * (i - 1)));
+            if (t != kmer) edits(t, len, d2, eb2, indels, out);
+        }
+    }
+}
+// addToMap's dispatch (:351-373): hdist==0 -> the k-mer itself; editDistance>0 -> mutate(edist, extraBase); else mutate(hdist)
+void emit_any(bbduk_host* h, uint64_t v, int len, int hdist, int edist, int64_t extraBase, int id, std::vector<uint64_t>& tmp) {
+    if (hdist == 0 || edist <= 0) { emit(h, v, len, hdist, id, tmp); return; }
+    const Parsed& p = h->p;
+    tmp.clear();
+    edits(v, len, edist, extraBase, p.edist > 0, tmp);
+    std::sort(tmp.begin(), tmp.end()); tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
     const uint64_t lmask = 1ULL << (2 * len);
     for (uint64_t t : tmp) {
         const uint64_t r = rcomp_bits(t, len);
@@ -350,12 +394,14 @@ extern "C" int64_t bbduk_host_build_index(bbduk_host* h) {
             run = (c < 0) ? 0 : run + 1;
             if (run < k) continue;
             if (skip > 1 && run % skip != 0) continue;
-            emit(h, fwd, k, p.hdist, id, tmp);
+            const int64_t extraBase = (i >= n - 1) ? -1 : (int64_t)code_of(b[i + 1]);    // BBDukLoader.java:443, 481
+            emit_any(h, fwd, k, p.hdist, p.edist, extraBase, id, tmp);
             if (p.useShortKmers) {
-                if (i == k - 1)                          // prefixes of the scaffold's first k-mer (addToMapRightShift)
-                    for (int L = k - 1; L >= p.mink; L--) emit(h, fwd >> (2 * (k - L)), L, p.hdist2, id, tmp);
-                if (i == n - 1)                          // suffixes of its last k-mer (addToMapLeftShift)
-                    for (int L = k - 1; L >= p.mink; L--) emit(h, fwd & ((1ULL << (2 * L)) - 1), L, p.hdist2, id, tmp);
+                if (i == k - 1)                          // prefixes of the scaffold's first k-mer (addToMapRightShift :320-341): the
+                    for (int L = k - 1; L >= p.mink; L--)                                  // base shifted out is the extra base
+                        emit_any(h, fwd >> (2 * (k - L)), L, p.hdist2, p.edist2, (int64_t)((fwd >> (2 * (k - L - 1))) & 3ULL), id, tmp);
+                if (i == n - 1)                          // suffixes of its last k-mer (addToMapLeftShift :289-310)
+                    for (int L = k - 1; L >= p.mink; L--) emit_any(h, fwd & ((1ULL << (2 * L)) - 1), L, p.hdist2, p.edist2, extraBase, id, tmp);
             }
         }
     }

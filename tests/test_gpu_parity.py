@@ -122,7 +122,8 @@ FUZZ = [("ktrim=r k=23", dict(k=23, ktrimRight=1)),
         ("k=21 mkf=0.3", dict(k=21, minKmerFraction=0.3)), ("k=13 mkf=0.1 mbk=3 rieb=f forbidn=t", dict(k=13, minKmerFraction=0.1, maxBadKmers0=3, requireBothBad=1, forbidN=1)),
         ("k=25 mcf=0.4", dict(k=25, minCoveredFraction=0.4)), ("k=15 mcf=0.9 hdist=1 restrictleft=60", dict(k=15, minCoveredFraction=0.9, hdist=1, restrictLeft=60)),
         ("k=19 mcf=0.05 mkf=0.5 mm=f", dict(k=19, minCoveredFraction=0.05, minKmerFraction=0.5, maskMiddle=0)),
-        ("ktrim=r k=21 mink=9 rskip=3 hdist=1", dict(k=21, ktrimRight=1, mink=9, minSkip=3, maxSkip=3, hdist=1))]
+        ("ktrim=r k=21 mink=9 rskip=3 hdist=1", dict(k=21, ktrimRight=1, mink=9, minSkip=3, maxSkip=3, hdist=1)),
+        ("ktrim=r k=13 mink=7 edist=1", dict(k=13, ktrimRight=1, mink=7, edist=1)), ("k=15 edist=1 mm=f", dict(k=15, edist=1, maskMiddle=0))]
 
 
 @pytest.mark.parametrize("ci", range(len(FUZZ)))

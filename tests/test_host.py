@@ -59,6 +59,8 @@ def test_host_index_random_refs_vs_oracle():
                       ("ktrim=l k=13 mink=6 hdist=1 hdist2=0", dict(k=13, mink=6, hdist=1, hdist2=0, ktrimLeft=1)),
                       ("k=24 hdist=1", dict(k=24, hdist=1)), ("k=12 rcomp=f", dict(k=12, rcomp=0)),
                       ("k=25 mm=3", dict(k=25, midMaskLen=3)), ("k=13 rskip=3", dict(k=13, minSkip=3, maxSkip=3)),
+                      ("k=11 edist=1", dict(k=11, edist=1)), ("ktrim=r k=12 mink=6 edist=1 mm=f", dict(k=12, mink=6, edist=1, ktrimRight=1, maskMiddle=0)),
+                      ("k=13 hdist=2 edist=1 rcomp=f", dict(k=13, hdist=2, edist=1, rcomp=0)), ("ktrim=l k=10 mink=5 hdist=1 edist2=1", dict(k=10, mink=5, hdist=1, edist2=1, ktrimLeft=1)),
                       ("ktrim=r k=13 mink=6 hdist=1 minskip=2 maxskip=4", dict(k=13, mink=6, hdist=1, ktrimRight=1, minSkip=2, maxSkip=4))):
         refs = [util.rand_seq(rng, rng.randint(3, 90), 0.02) for _ in range(8)] + [b"acgtunACGTUNacgtacgtacgtaacc"]
         h = B.HostIndex(args); o = Oracle(**okw)
