@@ -381,6 +381,28 @@ void fq_write_kernel(const uint8_t* __restrict__ t1, const uint8_t* __restrict__
     else for (int j = 0; j < want; j++) out[p + j] = (uint8_t)((j < 8 ? acc.lo >> (8 * j) : acc.hi >> (8 * (j - 8))) & 0xFF);
 }
 
+// Scratch for the ingest / write calls: per host thread and device, grown on demand and kept.  hipMalloc / hipFree
+// synchronise the whole device, which would serialise callers that pipeline chunks from several host threads (one stream
+// each: the H2D of one chunk then overlaps the kernels and the D2H of another).
+struct ScratchPool {
+    static constexpr int SLOTS = 8;
+    void* p[SLOTS] = {}; size_t cap[SLOTS] = {}; int device = -1;
+    void* get(int slot, size_t bytes, int dev) {
+        if (dev != device) { drop(); device = dev; }
+        if (cap[slot] < bytes) {
+            if (p[slot]) hipFree(p[slot]);
+            p[slot] = nullptr; cap[slot] = 0;
+            const size_t want = bytes + bytes / 8 + 256;
+            if (hipMalloc(&p[slot], want) != hipSuccess) return nullptr;
+            cap[slot] = want;
+        }
+        return p[slot];
+    }
+    void drop() { for (int i = 0; i < SLOTS; i++) { if (p[i]) hipFree(p[i]); p[i] = nullptr; cap[i] = 0; } }
+    ~ScratchPool() { /* the runtime may already be gone at thread exit: leave the buffers to process teardown */ }
+};
+thread_local ScratchPool g_scratch;
+
 }  // namespace
 
 extern "C" int bbduk_fastq_ingest_device(const uint8_t* d_text1, int64_t nbytes1, const uint8_t* d_text2, int64_t nbytes2, int32_t is_final,
@@ -398,12 +420,13 @@ extern "C" int bbduk_fastq_ingest_device(const uint8_t* d_text1, int64_t nbytes1
     const int64_t recCap = max_reads / ns;                       // records per text
     const uint8_t* texts[2] = {d_text1, d_text2}; const int64_t nbytes[2] = {nbytes1, nbytes2}; int64_t* lines[2] = {d_lines1, d_lines2};
     int64_t nrec[2] = {0, 0};
-    int64_t* d_sums = nullptr; int32_t* d_lens = nullptr; unsigned long long* d_bad = nullptr;
-    auto release = [&]() { hipFree(d_sums); hipFree(d_lens); hipFree(d_bad); };
+    auto release = [&]() {};                                      // scratch stays with the calling thread (g_scratch)
     const int64_t nbMax = (std::max(nbytes1, nbytes2) + FQ_BLOCK_BYTES - 1) / FQ_BLOCK_BYTES;
     const int64_t sbMax = (max_reads + SC_BLOCK - 1) / SC_BLOCK;
-    if (hipMalloc(&d_sums, (size_t)(std::max(nbMax, sbMax) + 2) * 8) != hipSuccess || hipMalloc(&d_lens, (size_t)(max_reads + 1) * 4) != hipSuccess ||
-        hipMalloc(&d_bad, 8) != hipSuccess) { release(); return BBDUK_ERR_NOMEM; }
+    int64_t* d_sums = (int64_t*)g_scratch.get(0, (size_t)(std::max(nbMax, sbMax) + 2) * 8, device);
+    int32_t* d_lens = (int32_t*)g_scratch.get(1, (size_t)(max_reads + 1) * 4, device);
+    unsigned long long* d_bad = (unsigned long long*)g_scratch.get(2, 8, device);
+    if (!d_sums || !d_lens || !d_bad) return BBDUK_ERR_NOMEM;
     for (int s = 0; s < ns; s++) {
         const int64_t nb = (nbytes[s] + FQ_BLOCK_BYTES - 1) / FQ_BLOCK_BYTES;
         int64_t nl = 0;
@@ -455,14 +478,12 @@ extern "C" int bbduk_fastq_ingest_device(const uint8_t* d_text1, int64_t nbytes1
     if (total > 0) {
         const int64_t words = (total + 15) >> 4;
         const int64_t nblk = (words + FQ_THREADS - 1) / FQ_THREADS;
-        int64_t* d_first = nullptr;
-        if (hipMalloc(&d_first, (size_t)(nblk + 1) * 8) != hipSuccess) { release(); return BBDUK_ERR_NOMEM; }
+        int64_t* d_first = (int64_t*)g_scratch.get(3, (size_t)(nblk + 1) * 8, device);
+        if (!d_first) return BBDUK_ERR_NOMEM;
         block_first_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(d_offsets, n, d_first);
         fq_pack_kernel<<<dim3((unsigned)nblk), dim3(FQ_THREADS), 0, st>>>(
             d_text1, d_lines1, d_text2, d_lines2, ns, d_offsets, n, total, d_first, nblk, d_lines1 + 4 * rec, ns == 2 ? d_lines2 + 4 * rec : nullptr,
             d_codes, reinterpret_cast<uint16_t*>(d_undef));
-        hipStreamSynchronize(st);
-        hipFree(d_first);
         if ((words & 1) != 0) {                                   // the upper half of the last undefined word: past the end
             const uint16_t ones = 0xFFFFu;
             hipMemcpyAsync(reinterpret_cast<uint16_t*>(d_undef) + words, &ones, 2, hipMemcpyHostToDevice, st);
@@ -487,11 +508,13 @@ extern "C" int bbduk_fastq_write_device(const uint8_t* d_text1, const int64_t* d
     if (hipSetDevice(device) != hipSuccess) return BBDUK_ERR_DEVICE;
     hipStream_t st = (hipStream_t)stream;
     if ((uintptr_t)d_out & 15) return BBDUK_ERR_ARG;
-    int32_t* d_sizes = nullptr; int64_t* d_sums = nullptr; int64_t* d_off = nullptr; OutRec* d_recs = nullptr;
-    auto release = [&]() { hipFree(d_sizes); hipFree(d_sums); hipFree(d_off); hipFree(d_recs); };
+    auto release = [&]() {};
     const int64_t sb = (n + 1 + SC_BLOCK - 1) / SC_BLOCK;
-    if (hipMalloc(&d_sizes, (size_t)(n + 1) * 4) != hipSuccess || hipMalloc(&d_sums, (size_t)(sb + 2) * 8) != hipSuccess ||
-        hipMalloc(&d_off, (size_t)(n + 1) * 8) != hipSuccess || hipMalloc(&d_recs, (size_t)n * sizeof(OutRec)) != hipSuccess) { release(); return BBDUK_ERR_NOMEM; }
+    int32_t* d_sizes = (int32_t*)g_scratch.get(4, (size_t)(n + 1) * 4, device);
+    int64_t* d_sums = (int64_t*)g_scratch.get(0, (size_t)(sb + 2) * 8, device);
+    int64_t* d_off = (int64_t*)g_scratch.get(5, (size_t)(n + 1) * 8, device);
+    OutRec* d_recs = (OutRec*)g_scratch.get(6, (size_t)n * sizeof(OutRec), device);
+    if (!d_sizes || !d_sums || !d_off || !d_recs) return BBDUK_ERR_NOMEM;
     fq_out_sizes_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(d_text1, d_lines1, d_text2, d_lines2, ns, n, d_left, d_right, d_flags, want_removed, d_sizes, d_recs);
     block_sum_kernel<<<dim3((unsigned)sb), dim3(FQ_THREADS), 0, st>>>(d_sizes, n, d_sums);
     scan_sums_kernel<<<dim3(1), dim3(1024), 0, st>>>(d_sums, sb);
@@ -503,14 +526,12 @@ extern "C" int bbduk_fastq_write_device(const uint8_t* d_text1, const int64_t* d
     if (total > 0) {
         const int64_t chunks = (total + 15) >> 4;
         const int64_t nblk = (chunks + FQ_THREADS - 1) / FQ_THREADS;
-        int64_t* d_first = nullptr;
-        if (hipMalloc(&d_first, (size_t)(nblk + 1) * 8) != hipSuccess) { release(); return BBDUK_ERR_NOMEM; }
+        int64_t* d_first = (int64_t*)g_scratch.get(3, (size_t)(nblk + 1) * 8, device);
+        if (!d_first) return BBDUK_ERR_NOMEM;
         block_first_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(d_off, n, d_first);
         const int64_t rec = n / ns;
         fq_write_kernel<<<dim3((unsigned)nblk), dim3(FQ_THREADS), 0, st>>>(d_text1, d_text2, ns, n, d_recs, d_off, total, d_first, nblk,
                                                                            d_lines1 + 4 * rec, ns == 2 ? d_lines2 + 4 * rec : nullptr, d_out);
-        hipStreamSynchronize(st);
-        hipFree(d_first);
     }
     const hipError_t e = hipStreamSynchronize(st);
     release();

@@ -84,12 +84,56 @@ def main():
         torch.cuda.synchronize(); e2e.append(time.perf_counter() - t0)
     dt = min(e2e[1:])
     gb = len(text) / 1e9
+    # the same work pipelined: the text in chunks (whole records), a few host threads with a stream each; the H2D of one chunk
+    # overlaps the kernels and the D2H of another (the link is full duplex), nothing in the calls synchronises the device
+    import threading
+    rec_bytes = len(text) // n
+    n_chunks, n_thr = 8, 3
+    per = (n // n_chunks) // 2 * 2
+    bounds = [(c * per, (c + 1) * per if c < n_chunks - 1 else n) for c in range(n_chunks)]
+    cap = max(b - a for a, b in bounds)
+    class Slot: pass
+    slots = []
+    for t in range(n_thr):
+        S = Slot(); S.st = torch.cuda.Stream()
+        S.d_text = torch.empty(cap * rec_bytes + 64, dtype=torch.uint8, device="cuda")
+        S.d_a = torch.empty(cap, dtype=torch.int32, device="cuda"); S.d_i = torch.empty(cap, dtype=torch.int32, device="cuda"); S.d_f = torch.empty(cap, dtype=torch.uint8, device="cuda")
+        S.d_c = torch.zeros(duk.gpu.counters_len, dtype=torch.int64, device="cuda")
+        S.d_out = torch.empty(cap * rec_bytes + 64, dtype=torch.uint8, device="cuda"); S.d_outm = torch.empty(cap * rec_bytes + 64, dtype=torch.uint8, device="cuda")
+        slots.append(S)
+    out_bytes = [0] * n_chunks
+
+    def worker(t):
+        S = slots[t]
+        with torch.cuda.stream(S.st):
+            for c in range(t, n_chunks, n_thr):
+                a0, a1 = bounds[c]; nb_in = (a1 - a0) * rec_bytes
+                dtx = S.d_text[:nb_in]
+                dtx.copy_(h_text[a0 * rec_bytes:a1 * rec_bytes], non_blocking=True)
+                fbc = B.fastq_ingest_device(dtx, None, True, a1 - a0, stream_ptr=S.st.cuda_stream)
+                duk.gpu.process_batch_packed_device(fbc.codes, fbc.undef, fbc.offsets, fbc.total_bases, True, S.d_a, S.d_i, S.d_f, S.d_c, S.st.cuda_stream)
+                k1 = B.fastq_write_device(dtx, fbc, None, S.d_a, S.d_f, False, S.d_out, stream_ptr=S.st.cuda_stream)
+                k2 = B.fastq_write_device(dtx, fbc, None, S.d_a, S.d_f, True, S.d_outm, stream_ptr=S.st.cuda_stream)
+                h_out[a0 * rec_bytes:a0 * rec_bytes + k1].copy_(S.d_out[:k1], non_blocking=True)     # kept reads of this chunk (dense enough for the bench)
+                if k2: h_outm[a0 * rec_bytes:a0 * rec_bytes + k2].copy_(S.d_outm[:k2], non_blocking=True)
+                out_bytes[c] = k1 + k2
+            S.st.synchronize()
+    pipe = []
+    for _ in range(1 + a.steps):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(n_thr)]
+        for x in th: x.start()
+        for x in th: x.join()
+        torch.cuda.synchronize(); pipe.append(time.perf_counter() - t0)
+    pdt = min(pipe[1:])
     print(json.dumps({"workload": "interleaved FASTQ text, %d reads of 150 bp (configs[1] generator), %.2f GB" % (n, gb),
                       "resident_ms": {k: round(v * 1e3, 2) for k, v in best.items()},
                       "resident_text_GBps": {k: round(gb / v, 1) for k, v in best.items()},
                       "resident_Gbases_per_s": round(n * 150 / sum(best.values()) / 1e9, 1),
                       "end_to_end_pinned": {"ms": round(dt * 1e3, 1), "Gbases_per_s": round(n * 150 / dt / 1e9, 2), "text_in_GBps": round(gb / dt, 1),
                                             "out_bytes": int(nb), "outm_bytes": int(nbm)},
+                      "end_to_end_pinned_pipelined": {"ms": round(pdt * 1e3, 1), "Gbases_per_s": round(n * 150 / pdt / 1e9, 2), "text_in_GBps": round(gb / pdt, 1),
+                                                      "chunks": n_chunks, "host_threads": n_thr, "out_bytes": int(sum(out_bytes))},
                       "results_equal_host_operator": same}))
 
 
