@@ -52,7 +52,7 @@ GPU_SYMBOLS = ["bbduk_abi_version", "bbduk_create", "bbduk_destroy", "bbduk_last
                "bbduk_upload_pairs", "bbduk_finalize_table", "bbduk_build_table_device", "bbduk_table_size", "bbduk_table_bytes",
                "bbduk_table_lookup", "bbduk_ktrim_batch", "bbduk_kfilter_batch", "bbduk_ktrim_batch_device",
                "bbduk_kfilter_batch_device", "bbduk_pack_bases_host", "bbduk_pack_bases_device", "bbduk_ktrim_batch_packed",
-               "bbduk_kfilter_batch_packed", "bbduk_ktrim_batch_packed_device", "bbduk_kfilter_batch_packed_device", "bbduk_kmask_batch", "bbduk_kmask_batch_device", "bbduk_ktrimtips_batch", "bbduk_ktrimtips_batch_device", "bbduk_ksplit_batch", "bbduk_ksplit_batch_device", "bbduk_fastq_ingest_device", "bbduk_fastq_write_device", "bbduk_device_malloc", "bbduk_device_free", "bbduk_pinned_malloc", "bbduk_pinned_free",
+               "bbduk_kfilter_batch_packed", "bbduk_ktrim_batch_packed_device", "bbduk_kfilter_batch_packed_device", "bbduk_kmask_batch", "bbduk_kmask_batch_device", "bbduk_ktrimtips_batch", "bbduk_ktrimtips_batch_device", "bbduk_ksplit_batch", "bbduk_ksplit_batch_device", "bbduk_kmask_batch_packed_device", "bbduk_ktrimtips_batch_packed_device", "bbduk_fastq_ingest_device", "bbduk_fastq_write_device", "bbduk_fastq_write_masked_device", "bbduk_device_malloc", "bbduk_device_free", "bbduk_pinned_malloc", "bbduk_pinned_free",
                "bbduk_copy_to_device", "bbduk_copy_from_device", "bbduk_device_memset", "bbduk_kernel_time_ms", "bbduk_counters_len", "bbduk_get_counters", "bbduk_reset_counters",
                "bbduk_synth_generate_device", "bbduk_synth_generate_host"]
 HOST_SYMBOLS = ["bbduk_host_parse", "bbduk_host_destroy", "bbduk_host_add_ref", "bbduk_host_load_fasta",
@@ -169,8 +169,11 @@ def lib():
         f.argtypes = [vp, vp, vp, vp, i64, i32, vp, vp, vp]
     for f in (L.bbduk_ktrim_batch_packed_device, L.bbduk_kfilter_batch_packed_device):
         f.argtypes = [vp, vp, vp, vp, i64, i64, i32, vp, vp, vp, vp, vp]
+    L.bbduk_kmask_batch_packed_device.argtypes = [vp, vp, vp, vp, i64, i64, i32, vp, vp, vp, vp, vp, vp]
+    L.bbduk_ktrimtips_batch_packed_device.argtypes = [vp, vp, vp, vp, i64, i64, i32, vp, vp, vp, vp, vp, vp]
     L.bbduk_fastq_ingest_device.argtypes = [vp, i64, vp, i64, i32, i64, i64, vp, vp, vp, vp, vp, i32, vp, C.POINTER(FastqResult)]
     L.bbduk_fastq_write_device.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i32, vp, i64, i32, vp, C.POINTER(i64)]
+    L.bbduk_fastq_write_masked_device.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i32, vp, vp, i32, vp, i64, i32, vp, C.POINTER(i64)]
     L.bbduk_kernel_time_ms.argtypes = [vp, i32, C.POINTER(C.c_float)]
     L.bbduk_counters_len.argtypes = [vp]
     L.bbduk_get_counters.argtypes = [vp, vp, i32]

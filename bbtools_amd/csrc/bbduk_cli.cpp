@@ -135,8 +135,8 @@ struct TextIn {                      // one input file streamed through a pinned
 
 // The deviceingest=t pipeline.  Returns 0 or an error exit status; prints the same closing lines as the host path.
 int run_device_ingest(bbduk_handle* dev, const bbduk_host* host, const StatsOut& so, const bbduk_params& P, const std::string& in1, const std::string& in2, bool paired,
-                      const std::string& out, const std::string& outm, const std::string& tsv, int64_t chunk, int device) {
-    if (P.mode != BBDUK_MODE_KTRIM_R && P.mode != BBDUK_MODE_KTRIM_L && P.mode != BBDUK_MODE_KFILTER) return fail("deviceingest=t serves ktrim=r, ktrim=l and kfilter", nullptr);
+                      const std::string& out, const std::string& outm, const std::string& tsv, int64_t chunk, int device, bool maskLower, char maskSymbol) {
+    if (P.mode == BBDUK_MODE_KSPLIT) return fail("deviceingest=t serves ktrim=r|l|rl|n and kfilter, not ksplit", nullptr);
     const int ns = in2.empty() ? 1 : 2;
     TextIn T[2];
     if (!T[0].open(in1)) return fail("cannot open", in1.c_str());
@@ -156,6 +156,10 @@ int run_device_ingest(bbduk_handle* dev, const bbduk_host* host, const StatsOut&
     }
     int64_t* d_off = (int64_t*)dmal((maxReads + 1) * 8); uint32_t* d_codes = (uint32_t*)dmal(capBases / 4 + 64); uint32_t* d_undef = (uint32_t*)dmal(capBases / 8 + 64);
     int32_t* d_a = (int32_t*)dmal(maxReads * 4); int32_t* d_id = (int32_t*)dmal(maxReads * 4); uint8_t* d_fl = (uint8_t*)dmal(maxReads);
+    int32_t* d_b = P.mode == BBDUK_MODE_KTRIM_TIPS ? (int32_t*)dmal(maxReads * 4) : nullptr;                 // ktrim=rl: the left amounts
+    uint32_t* d_mask = P.mode == BBDUK_MODE_KMASK ? (uint32_t*)dmal((capBases / 32 + 4) * 4) : nullptr;      // ktrim=n: one bit per base
+    if ((P.mode == BBDUK_MODE_KTRIM_TIPS && !d_b) || (P.mode == BBDUK_MODE_KMASK && !d_mask)) return fail("out of memory (chunk= too large?)", nullptr);
+    std::vector<int32_t> rb;
     const int nctr = bbduk_counters_len(dev);
     int64_t* d_ctr = (int64_t*)dmal((int64_t)nctr * 8);
     uint8_t* d_out = (uint8_t*)dmal(capOut); uint8_t* h_out = (uint8_t*)pmal(capOut);
@@ -188,14 +192,18 @@ int run_device_ingest(bbduk_handle* dev, const bbduk_host* host, const StatsOut&
         }
         const int64_t total = [&]() { int64_t v = 0; bbduk_copy_from_device(device, &v, d_off + n, 8, nullptr); return v; }();
         const int orc = kfilter ? bbduk_kfilter_batch_packed_device(dev, d_codes, d_undef, d_off, n, total, paired ? 1 : 0, d_a, d_id, d_fl, d_ctr, nullptr)
-                                : bbduk_ktrim_batch_packed_device(dev, d_codes, d_undef, d_off, n, total, paired ? 1 : 0, d_a, d_id, d_fl, d_ctr, nullptr);
+                      : P.mode == BBDUK_MODE_KTRIM_TIPS ? bbduk_ktrimtips_batch_packed_device(dev, d_codes, d_undef, d_off, n, total, paired ? 1 : 0, d_a, d_b, d_id, d_fl, d_ctr, nullptr)
+                      : P.mode == BBDUK_MODE_KMASK ? bbduk_kmask_batch_packed_device(dev, d_codes, d_undef, d_off, n, total, paired ? 1 : 0, d_a, d_id, d_fl, d_mask, d_ctr, nullptr)
+                      : bbduk_ktrim_batch_packed_device(dev, d_codes, d_undef, d_off, n, total, paired ? 1 : 0, d_a, d_id, d_fl, d_ctr, nullptr);
         if (orc != BBDUK_OK) return fail("batch operator", bbduk_last_error(dev));
-        const int32_t* dl = P.mode == BBDUK_MODE_KTRIM_L ? d_a : nullptr; const int32_t* dr = P.mode == BBDUK_MODE_KTRIM_R ? d_a : nullptr;
+        const int32_t* dl = P.mode == BBDUK_MODE_KTRIM_L ? d_a : (P.mode == BBDUK_MODE_KTRIM_TIPS ? d_b : nullptr);
+        const int32_t* dr = (P.mode == BBDUK_MODE_KTRIM_R || P.mode == BBDUK_MODE_KTRIM_TIPS) ? d_a : nullptr;
         for (int sel = 0; sel < 2; sel++) {
             FILE* dst = sel ? foutm : fout;
             if (!dst) continue;
             int64_t nb = 0;
-            if (bbduk_fastq_write_device(T[0].d, T[0].d_lines, ns == 2 ? T[1].d : nullptr, ns == 2 ? T[1].d_lines : nullptr, n, dl, dr, d_fl, sel, d_out, capOut, device, nullptr, &nb) != BBDUK_OK)
+            if (bbduk_fastq_write_masked_device(T[0].d, T[0].d_lines, ns == 2 ? T[1].d : nullptr, ns == 2 ? T[1].d_lines : nullptr, n, dl, dr, d_fl, sel,
+                                                d_mask ? d_off : nullptr, d_mask, maskLower ? -1 : (int)(unsigned char)maskSymbol, d_out, capOut, device, nullptr, &nb) != BBDUK_OK)
                 return fail("bbduk_fastq_write_device", nullptr);
             if (bbduk_copy_from_device(device, h_out, d_out, nb, nullptr) != BBDUK_OK) return fail("device to host copy", nullptr);
             if (nb > 0 && fwrite(h_out, 1, (size_t)nb, dst) != (size_t)nb) return fail("write error", nullptr);
@@ -205,13 +213,14 @@ int run_device_ingest(bbduk_handle* dev, const bbduk_host* host, const StatsOut&
             ra.resize(n); rid.resize(n); rfl.resize(n);
             bbduk_copy_from_device(device, ra.data(), d_a, n * 4, nullptr); bbduk_copy_from_device(device, rid.data(), d_id, n * 4, nullptr);
             bbduk_copy_from_device(device, rfl.data(), d_fl, n, nullptr);
+            if (d_b) { rb.resize(n); bbduk_copy_from_device(device, rb.data(), d_b, n * 4, nullptr); for (int64_t i = 0; i < n; i++) ra[i] += rb[i]; }   // the tsv shows right + left
             for (int s = 0; s < ns; s++) { lines[s].resize(4 * rec + 1); bbduk_copy_from_device(device, lines[s].data(), T[s].d_lines, (4 * rec + 1) * 8, nullptr); }
             for (int64_t i = 0; i < n; i++) {
                 const int s = ns == 2 ? (int)(i & 1) : 0; const int64_t r = ns == 2 ? (i >> 1) : i;
                 const uint8_t* t = T[s].h; const int64_t* l = lines[s].data();
                 auto len = [&](int64_t a, int64_t b) { int64_t m = b - a - 1; if (m > 0 && t[b - 2] == '\r') m--; return (int)m; };
                 const int hl = len(l[4 * r], l[4 * r + 1]), L = len(l[4 * r + 1], l[4 * r + 2]);
-                fprintf(ftsv, "%.*s\t%d\t%d\t%d\t%d\t%d\n", hl - 1, (const char*)t + l[4 * r] + 1, L, ra[i], rid[i], L - (kfilter ? 0 : ra[i]), (int)rfl[i]);
+                fprintf(ftsv, "%.*s\t%d\t%d\t%d\t%d\t%d\n", hl - 1, (const char*)t + l[4 * r] + 1, L, ra[i], rid[i], L - ((kfilter || d_mask) ? 0 : ra[i]), (int)rfl[i]);
             }
         }
         nread += n;
@@ -225,7 +234,8 @@ int run_device_ingest(bbduk_handle* dev, const bbduk_host* host, const StatsOut&
     std::vector<int64_t> c((size_t)nctr);
     bbduk_copy_from_device(device, c.data(), d_ctr, (int64_t)nctr * 8, nullptr);
     fprintf(stderr, "Input:                  \t%lld reads \t\t%lld bases.\n", (long long)c[BBDUK_READS_IN], (long long)c[BBDUK_BASES_IN]);
-    if (!kfilter) fprintf(stderr, "KTrimmed:               \t%lld reads \t%lld bases\n", (long long)c[BBDUK_READS_KTRIMMED], (long long)c[BBDUK_BASES_KTRIMMED]);
+    if (d_mask) fprintf(stderr, "KMasked:                \t%lld reads \t%lld bases\n", (long long)c[BBDUK_READS_KTRIMMED], (long long)c[BBDUK_BASES_KTRIMMED]);
+    else if (!kfilter) fprintf(stderr, "KTrimmed:               \t%lld reads \t%lld bases\n", (long long)c[BBDUK_READS_KTRIMMED], (long long)c[BBDUK_BASES_KTRIMMED]);
     else fprintf(stderr, "Contaminants:           \t%lld reads \t%lld bases\n", (long long)c[BBDUK_READS_KFILTERED], (long long)c[BBDUK_BASES_KFILTERED]);
     fprintf(stderr, "Total Removed:          \t%lld reads \t%lld bases\n", (long long)(c[BBDUK_READS_IN] - c[BBDUK_READS_OUTU]), (long long)(c[BBDUK_BASES_IN] - c[BBDUK_BASES_OUTU]));
     fprintf(stderr, "Result:                 \t%lld reads \t%lld bases\n", (long long)c[BBDUK_READS_OUTU], (long long)c[BBDUK_BASES_OUTU]);
@@ -297,7 +307,7 @@ int main(int argc, char** argv) {
 
     if (deviceIngest) {
         if (chunk < 4096) chunk = 4096;
-        const int rc = run_device_ingest(dev, host, so, P, in1, in2, paired, out, outm, tsv, (int64_t)chunk, device);
+        const int rc = run_device_ingest(dev, host, so, P, in1, in2, paired, out, outm, tsv, (int64_t)chunk, device, maskLower, maskSymbol);
         if (rc == 0) { bbduk_destroy(dev); bbduk_host_destroy(host); }
         return rc;
     }

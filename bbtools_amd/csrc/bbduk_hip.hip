@@ -3553,7 +3553,8 @@ extern "C" int bbduk_kfilter_batch(bbduk_handle* h, const uint8_t* bases, const 
 
 // ---- ktrim=rl
 static int launch_tips(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d_offsets, int64_t n, int64_t total_bases, int32_t paired,
-                       int32_t* d_r, int32_t* d_l, int32_t* d_id, uint8_t* d_fl, int64_t* d_counters, hipStream_t st) {
+                       int32_t* d_r, int32_t* d_l, int32_t* d_id, uint8_t* d_fl, int64_t* d_counters, hipStream_t st,
+                       const uint32_t* d_undef = nullptr, bool packed = false) {
     if (!h) return BBDUK_ERR_ARG;
     if (!h->finalized) return fail(h, BBDUK_ERR_STATE, "table not finalized");
     if (h->p.mode != BBDUK_MODE_KTRIM_TIPS) return fail(h, BBDUK_ERR_STATE, "operator does not match the mode given to bbduk_create");
@@ -3561,8 +3562,10 @@ static int launch_tips(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d
     if (n == 0) return BBDUK_OK;
     if (!d_bases && total_bases > 0) return fail(h, BBDUK_ERR_ARG, "null bases");
     if (!d_offsets || !d_r || !d_l || !d_id || !d_fl || !d_counters) return fail(h, BBDUK_ERR_ARG, "null buffer");
-    if (((uintptr_t)d_bases & 15) != 0) return fail(h, BBDUK_ERR_ARG, "d_bases must be 16-byte aligned");
-    const KParams K = make_kparams(h);
+    if (!packed && ((uintptr_t)d_bases & 15) != 0) return fail(h, BBDUK_ERR_ARG, "d_bases must be 16-byte aligned");
+    if (packed && (!d_undef || ((uintptr_t)d_bases & 3) != 0)) return fail(h, BBDUK_ERR_ARG, "packed input needs both planes, 4-byte aligned");
+    KParams K = make_kparams(h);
+    K.undef = packed ? d_undef : nullptr;
     const size_t dynLds = h->ldsBits ? ((size_t)1 << (h->ldsBits - 3)) : 0;
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bbduk_ktrimtips_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
     const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
@@ -3591,6 +3594,12 @@ extern "C" int bbduk_ktrimtips_batch_device(bbduk_handle* h, const uint8_t* d_ba
                                             int64_t total_bases, int32_t paired, int32_t* d_out_right, int32_t* d_out_left,
                                             int32_t* d_out_id0, uint8_t* d_out_flags, int64_t* d_counters, void* stream) {
     return launch_tips(h, d_bases, d_offsets, n, total_bases, paired, d_out_right, d_out_left, d_out_id0, d_out_flags, d_counters, (hipStream_t)stream);
+}
+extern "C" int bbduk_ktrimtips_batch_packed_device(bbduk_handle* h, const uint32_t* d_codes, const uint32_t* d_undef, const int64_t* d_offsets, int64_t n,
+                                                   int64_t total_bases, int32_t paired, int32_t* d_out_right, int32_t* d_out_left,
+                                                   int32_t* d_out_id0, uint8_t* d_out_flags, int64_t* d_counters, void* stream) {
+    return launch_tips(h, reinterpret_cast<const uint8_t*>(d_codes), d_offsets, n, total_bases, paired, d_out_right, d_out_left, d_out_id0, d_out_flags, d_counters,
+                       (hipStream_t)stream, d_undef, true);
 }
 extern "C" int bbduk_ktrimtips_batch(bbduk_handle* h, const uint8_t* bases, const int64_t* offsets, int64_t n, int32_t paired,
                                      int32_t* out_right, int32_t* out_left, int32_t* out_id0, uint8_t* out_flags) {
@@ -3631,7 +3640,8 @@ extern "C" int bbduk_ktrimtips_batch(bbduk_handle* h, const uint8_t* bases, cons
 
 // ---- ktrim=n
 static int launch_kmask(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d_offsets, int64_t n, int64_t total_bases, int32_t paired,
-                        int32_t* d_a, int32_t* d_id, uint8_t* d_fl, uint32_t* d_mask, int64_t* d_counters, hipStream_t st) {
+                        int32_t* d_a, int32_t* d_id, uint8_t* d_fl, uint32_t* d_mask, int64_t* d_counters, hipStream_t st,
+                        const uint32_t* d_undef = nullptr, bool packed = false) {
     if (!h) return BBDUK_ERR_ARG;
     if (!h->finalized) return fail(h, BBDUK_ERR_STATE, "table not finalized");
     if (h->p.mode != BBDUK_MODE_KMASK) return fail(h, BBDUK_ERR_STATE, "operator does not match the mode given to bbduk_create");
@@ -3639,8 +3649,10 @@ static int launch_kmask(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     if (n == 0) return BBDUK_OK;
     if (!d_bases && total_bases > 0) return fail(h, BBDUK_ERR_ARG, "null bases");
     if (!d_offsets || !d_a || !d_id || !d_fl || !d_mask || !d_counters) return fail(h, BBDUK_ERR_ARG, "null buffer");
-    if (((uintptr_t)d_bases & 15) != 0) return fail(h, BBDUK_ERR_ARG, "d_bases must be 16-byte aligned");
-    const KParams K = make_kparams(h);
+    if (!packed && ((uintptr_t)d_bases & 15) != 0) return fail(h, BBDUK_ERR_ARG, "d_bases must be 16-byte aligned");
+    if (packed && (!d_undef || ((uintptr_t)d_bases & 3) != 0)) return fail(h, BBDUK_ERR_ARG, "packed input needs both planes, 4-byte aligned");
+    KParams K = make_kparams(h);
+    K.undef = packed ? d_undef : nullptr;
     const size_t dynLds = h->ldsBits ? ((size_t)1 << (h->ldsBits - 3)) : 0;
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bbduk_kmask_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
     HIP_TRY(h, hipMemsetAsync(d_mask, 0, ((size_t)(total_bases + 31) / 32 + 2) * sizeof(uint32_t), st));
@@ -3723,6 +3735,12 @@ extern "C" int bbduk_kmask_batch_device(bbduk_handle* h, const uint8_t* d_bases,
                                         int64_t total_bases, int32_t paired, int32_t* d_out_masked, int32_t* d_out_id0,
                                         uint8_t* d_out_flags, uint32_t* d_out_mask, int64_t* d_counters, void* stream) {
     return launch_kmask(h, d_bases, d_offsets, n, total_bases, paired, d_out_masked, d_out_id0, d_out_flags, d_out_mask, d_counters, (hipStream_t)stream);
+}
+extern "C" int bbduk_kmask_batch_packed_device(bbduk_handle* h, const uint32_t* d_codes, const uint32_t* d_undef, const int64_t* d_offsets, int64_t n,
+                                               int64_t total_bases, int32_t paired, int32_t* d_out_masked, int32_t* d_out_id0,
+                                               uint8_t* d_out_flags, uint32_t* d_out_mask, int64_t* d_counters, void* stream) {
+    return launch_kmask(h, reinterpret_cast<const uint8_t*>(d_codes), d_offsets, n, total_bases, paired, d_out_masked, d_out_id0, d_out_flags, d_out_mask, d_counters,
+                        (hipStream_t)stream, d_undef, true);
 }
 extern "C" int bbduk_kmask_batch(bbduk_handle* h, const uint8_t* bases, const int64_t* offsets, int64_t n, int32_t paired,
                                  int32_t* out_masked, int32_t* out_id0, uint8_t* out_flags, uint32_t* out_mask) {

@@ -307,10 +307,38 @@ void fq_pack_kernel(const uint8_t* __restrict__ t1, const int64_t* __restrict__ 
 
 // ---- writer: trimmed records back to FASTQ text (stream/FASTQ.java:474-490 toFASTQ: '@' id, bases, a bare '+', qualities)
 // Output layout of one selected read: header[hl] '\n' bases[nl] '\n' '+' '\n' qualities[nl] '\n'  = hl + 2*nl + 5 bytes.
-struct OutRec { int64_t h, s, q; int32_t hl, nl; };               // source offsets (trim applied) and lengths; 32 bytes
+struct OutRec { int64_t h, s, q, mbit; int32_t hl, nl; };         // source offsets (trim applied), bit index of the first written base in
+                                                                  // the batch's base mask (ktrim=n), lengths; 40 bytes
+// 8 mask bits -> 8 bytes of 0xFF / 0x00
+__device__ __forceinline__ uint64_t spread8(const uint32_t m8) {
+    uint64_t t = ((uint64_t)m8 * 0x0101010101010101ULL) & 0x8040201008040201ULL;
+    t = ((t + 0x7F7F7F7F7F7F7F7FULL) | t) & 0x8080808080808080ULL;
+    return (t >> 7) * 0xFFULL;
+}
+__device__ __forceinline__ uint32_t mask16(const uint32_t* __restrict__ mask, const int64_t bit) {
+    const int64_t w = bit >> 5; const int sh = (int)(bit & 31);
+    const uint64_t two = ((uint64_t)mask[w + 1] << 32) | mask[w];
+    return (uint32_t)(two >> sh) & 0xFFFFu;
+}
+// the masked bytes of v become `sym` (sym >= 0) or, for A-Z, lower case (sym < 0): BBDukProcessorS.java:2309-2320
+__device__ __forceinline__ U128 apply_mask(U128 v, const uint32_t m16, const int sym) {
+    const uint64_t bm[2] = {spread8(m16 & 0xFFu), spread8(m16 >> 8)};
+    uint64_t x[2] = {v.lo, v.hi};
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        if (sym >= 0) x[q] = (x[q] & ~bm[q]) | (((uint64_t)(uint32_t)sym * 0x0101010101010101ULL) & bm[q]);
+        else {
+            const uint64_t lo7 = x[q] & 0x7F7F7F7F7F7F7F7FULL;
+            const uint64_t upper = (lo7 + 0x3F3F3F3F3F3F3F3FULL) & ~(lo7 + 0x2525252525252525ULL) & ~x[q] & 0x8080808080808080ULL;   // 'A'..'Z'
+            x[q] |= (upper >> 2) & bm[q];
+        }
+    }
+    return U128{x[0], x[1]};
+}
 __global__ void fq_out_sizes_kernel(const uint8_t* __restrict__ t1, const int64_t* __restrict__ l1, const uint8_t* __restrict__ t2, const int64_t* __restrict__ l2,
                                     const int ns, const int64_t n, const int32_t* __restrict__ left, const int32_t* __restrict__ right,
-                                    const uint8_t* __restrict__ flags, const int wantRemoved, int32_t* __restrict__ sizes, OutRec* __restrict__ recs) {
+                                    const uint8_t* __restrict__ flags, const int wantRemoved, const int64_t* __restrict__ baseOff,
+                                    int32_t* __restrict__ sizes, OutRec* __restrict__ recs) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const bool second = (ns == 2) && (i & 1);
@@ -319,7 +347,7 @@ __global__ void fq_out_sizes_kernel(const uint8_t* __restrict__ t1, const int64_
     const int64_t r = (ns == 2) ? (i >> 1) : i;
     const bool sel = (((flags ? flags[i] : 0) & BBDUK_FLAG_REMOVED) != 0) == (wantRemoved != 0);
     int sz = 0;
-    OutRec R; R.h = R.s = R.q = 0; R.hl = R.nl = 0;
+    OutRec R; R.h = R.s = R.q = 0; R.mbit = 0; R.hl = R.nl = 0;
     if (sel) {
         const int64_t h = l[4 * r], sq = l[4 * r + 1];
         const int L = line_len(t, sq, l[4 * r + 2]);
@@ -327,6 +355,7 @@ __global__ void fq_out_sizes_kernel(const uint8_t* __restrict__ t1, const int64_
         R.hl = line_len(t, h, sq);
         R.nl = max(L - a - b, 0);
         R.h = h; R.s = sq + a; R.q = l[4 * r + 3] + a;
+        R.mbit = baseOff ? baseOff[i] + a : 0;
         sz = R.hl + 2 * R.nl + 5;
     }
     sizes[i] = sz;
@@ -338,7 +367,7 @@ __global__ __launch_bounds__(FQ_THREADS)
 void fq_write_kernel(const uint8_t* __restrict__ t1, const uint8_t* __restrict__ t2, const int ns, const int64_t n,
                      const OutRec* __restrict__ recs, const int64_t* __restrict__ outOff, const int64_t total,
                      const int64_t* __restrict__ first, const int64_t nblk, const int64_t* __restrict__ plim1, const int64_t* __restrict__ plim2,
-                     uint8_t* __restrict__ out) {
+                     const uint32_t* __restrict__ mask, const int sym, uint8_t* __restrict__ out) {
     __shared__ int64_t s_off[FQ_STAGE];
     const int64_t lim1 = *plim1 - 1, lim2 = plim2 ? *plim2 - 1 : 0;
     const int64_t c0 = (int64_t)blockIdx.x * FQ_THREADS;
@@ -369,9 +398,15 @@ void fq_write_kernel(const uint8_t* __restrict__ t1, const uint8_t* __restrict__
         const int64_t lim = (t == t1) ? lim1 : lim2;
         if (rel < R.hl) { c = min(R.hl - rel, room); v = load16(t, R.h + rel, lim); }
         else if (rel == R.hl) { c = 1; v = U128{0x0AULL, 0}; }
-        else if (rel < R.hl + 1 + R.nl) { const int x = rel - R.hl - 1; c = min(R.nl - x, room); v = load16(t, R.s + x, lim); }
+        else if (rel < R.hl + 1 + R.nl) {
+            const int x = rel - R.hl - 1; c = min(R.nl - x, room); v = load16(t, R.s + x, lim);
+            if (mask) { const uint32_t m16 = mask16(mask, R.mbit + x); if (m16) v = apply_mask(v, m16, sym); }
+        }
         else if (rel < R.hl + 4 + R.nl) { const int x = rel - (R.hl + 1 + R.nl); c = min(3 - x, room); v = U128{0x0A2B0AULL >> (8 * x), 0}; }
-        else if (rel < R.hl + 4 + 2 * R.nl) { const int x = rel - (R.hl + 4 + R.nl); c = min(R.nl - x, room); v = load16(t, R.q + x, lim); }
+        else if (rel < R.hl + 4 + 2 * R.nl) {
+            const int x = rel - (R.hl + 4 + R.nl); c = min(R.nl - x, room); v = load16(t, R.q + x, lim);
+            if (mask && sym == 'N') { const uint32_t m16 = mask16(mask, R.mbit + x); if (m16) v = apply_mask(v, m16, '!'); }    // quals[i]=0 (:2318)
+        }
         else { c = 1; v = U128{0x0AULL, 0}; }
         const U128 sh = shl_bytes(low_bytes(v, c), filled);
         acc.lo |= sh.lo; acc.hi |= sh.hi;
@@ -497,10 +532,14 @@ extern "C" int bbduk_fastq_ingest_device(const uint8_t* d_text1, int64_t nbytes1
 
 // Writes the selected reads (want_removed == 0: those without BBDUK_FLAG_REMOVED; != 0: those with it), trimmed by
 // d_left[i] / d_right[i] bases (either may be NULL = 0), as FASTQ text into d_out, in input order (mates stay adjacent).
-extern "C" int bbduk_fastq_write_device(const uint8_t* d_text1, const int64_t* d_lines1, const uint8_t* d_text2, const int64_t* d_lines2,
-                                        int64_t n, const int32_t* d_left, const int32_t* d_right, const uint8_t* d_flags, int32_t want_removed,
-                                        uint8_t* d_out, int64_t cap_out, int32_t device, void* stream, int64_t* out_bytes) {
+// With d_mask (one bit per base of the batch, as bbduk_kmask_batch* return it) and d_base_offsets the masked bases are written as
+// `symbol` (their qualities as '!' when the symbol is 'N') or, symbol < 0, in lower case: BBDukProcessorS.java:2309-2320.
+extern "C" int bbduk_fastq_write_masked_device(const uint8_t* d_text1, const int64_t* d_lines1, const uint8_t* d_text2, const int64_t* d_lines2,
+                                               int64_t n, const int32_t* d_left, const int32_t* d_right, const uint8_t* d_flags, int32_t want_removed,
+                                               const int64_t* d_base_offsets, const uint32_t* d_mask, int32_t symbol,
+                                               uint8_t* d_out, int64_t cap_out, int32_t device, void* stream, int64_t* out_bytes) {
     if (!out_bytes) return BBDUK_ERR_ARG;
+    if ((d_mask != nullptr) != (d_base_offsets != nullptr) || symbol > 255) return BBDUK_ERR_ARG;
     *out_bytes = 0;
     const int ns = d_text2 ? 2 : 1;
     if (n < 0 || cap_out < 0 || (n > 0 && (!d_text1 || !d_lines1 || (ns == 2 && !d_lines2) || !d_out))) return BBDUK_ERR_ARG;
@@ -515,7 +554,7 @@ extern "C" int bbduk_fastq_write_device(const uint8_t* d_text1, const int64_t* d
     int64_t* d_off = (int64_t*)g_scratch.get(5, (size_t)(n + 1) * 8, device);
     OutRec* d_recs = (OutRec*)g_scratch.get(6, (size_t)n * sizeof(OutRec), device);
     if (!d_sizes || !d_sums || !d_off || !d_recs) return BBDUK_ERR_NOMEM;
-    fq_out_sizes_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(d_text1, d_lines1, d_text2, d_lines2, ns, n, d_left, d_right, d_flags, want_removed, d_sizes, d_recs);
+    fq_out_sizes_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(d_text1, d_lines1, d_text2, d_lines2, ns, n, d_left, d_right, d_flags, want_removed, d_base_offsets, d_sizes, d_recs);
     block_sum_kernel<<<dim3((unsigned)sb), dim3(FQ_THREADS), 0, st>>>(d_sizes, n, d_sums);
     scan_sums_kernel<<<dim3(1), dim3(1024), 0, st>>>(d_sums, sb);
     scan_final_kernel<<<dim3((unsigned)sb), dim3(FQ_THREADS), 0, st>>>(d_sizes, n, d_sums, d_off);
@@ -531,12 +570,19 @@ extern "C" int bbduk_fastq_write_device(const uint8_t* d_text1, const int64_t* d
         block_first_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(d_off, n, d_first);
         const int64_t rec = n / ns;
         fq_write_kernel<<<dim3((unsigned)nblk), dim3(FQ_THREADS), 0, st>>>(d_text1, d_text2, ns, n, d_recs, d_off, total, d_first, nblk,
-                                                                           d_lines1 + 4 * rec, ns == 2 ? d_lines2 + 4 * rec : nullptr, d_out);
+                                                                           d_lines1 + 4 * rec, ns == 2 ? d_lines2 + 4 * rec : nullptr, d_mask, (int)symbol, d_out);
     }
     const hipError_t e = hipStreamSynchronize(st);
     release();
     if (e != hipSuccess || hipGetLastError() != hipSuccess) return BBDUK_ERR_DEVICE;
     return BBDUK_OK;
+}
+
+extern "C" int bbduk_fastq_write_device(const uint8_t* d_text1, const int64_t* d_lines1, const uint8_t* d_text2, const int64_t* d_lines2,
+                                        int64_t n, const int32_t* d_left, const int32_t* d_right, const uint8_t* d_flags, int32_t want_removed,
+                                        uint8_t* d_out, int64_t cap_out, int32_t device, void* stream, int64_t* out_bytes) {
+    return bbduk_fastq_write_masked_device(d_text1, d_lines1, d_text2, d_lines2, n, d_left, d_right, d_flags, want_removed, nullptr, nullptr, 0,
+                                           d_out, cap_out, device, stream, out_bytes);
 }
 
 // ---- memory helpers for callers without HIP bindings

@@ -177,6 +177,15 @@ int  bbduk_kfilter_batch_packed_device(bbduk_handle* h, const uint32_t* d_codes,
                                        int32_t* d_out_found, int32_t* d_out_id, uint8_t* d_out_flags,
                                        int64_t* d_counters, void* stream);
 
+/* packed-input variants of the ktrim=n and ktrim=rl operators (same outputs as bbduk_kmask_batch_device / bbduk_ktrimtips_batch_device;
+ * the output mask still has one bit per base of the batch) */
+int  bbduk_kmask_batch_packed_device(bbduk_handle* h, const uint32_t* d_codes, const uint32_t* d_undef, const int64_t* d_offsets, int64_t n,
+                                     int64_t total_bases, int32_t paired, int32_t* d_out_masked, int32_t* d_out_id0,
+                                     uint8_t* d_out_flags, uint32_t* d_out_mask, int64_t* d_counters, void* stream);
+int  bbduk_ktrimtips_batch_packed_device(bbduk_handle* h, const uint32_t* d_codes, const uint32_t* d_undef, const int64_t* d_offsets, int64_t n,
+                                         int64_t total_bases, int32_t paired, int32_t* d_out_right, int32_t* d_out_left,
+                                         int32_t* d_out_id0, uint8_t* d_out_flags, int64_t* d_counters, void* stream);
+
 /* ---- memory helpers for callers without HIP bindings (the JNI shim, bbduk_cli): thin wrappers over hipMalloc / hipFree,
  * hipHostMalloc / hipHostFree (pinned staging) and hipMemcpyAsync + hipStreamSynchronize on the given stream (NULL = default). */
 int  bbduk_device_malloc(int32_t device, int64_t bytes, void** out);
@@ -216,6 +225,14 @@ int  bbduk_fastq_ingest_device(const uint8_t* d_text1, int64_t nbytes1, const ui
 int  bbduk_fastq_write_device(const uint8_t* d_text1, const int64_t* d_lines1, const uint8_t* d_text2, const int64_t* d_lines2,
                               int64_t n, const int32_t* d_left, const int32_t* d_right, const uint8_t* d_flags, int32_t want_removed,
                               uint8_t* d_out, int64_t cap_out, int32_t device, void* stream, int64_t* out_bytes);
+
+/* The same writer for ktrim=n: d_mask = the base mask bbduk_kmask_batch*_device returned for this batch, d_base_offsets = the batch's
+ * base offsets; masked bases are written as `symbol` (qualities '!' when it is 'N') or, symbol < 0, in lower case
+ * (BBDukProcessorS.java:2309-2320). */
+int  bbduk_fastq_write_masked_device(const uint8_t* d_text1, const int64_t* d_lines1, const uint8_t* d_text2, const int64_t* d_lines2,
+                                     int64_t n, const int32_t* d_left, const int32_t* d_right, const uint8_t* d_flags, int32_t want_removed,
+                                     const int64_t* d_base_offsets, const uint32_t* d_mask, int32_t symbol,
+                                     uint8_t* d_out, int64_t cap_out, int32_t device, void* stream, int64_t* out_bytes);
 
 /* ---- ktrim=n (bbduk/BBDukProcessorS.java:2149-2323; bbduk_params.kmaskFullyCovered selects the fully-covered variant).  out_masked[i] = kmask(Read)'s return
  * (BitSet.cardinality()), out_mask = one bit per base of the concatenated `bases` buffer (bit b of word b/32 set <=> the

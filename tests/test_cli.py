@@ -128,9 +128,30 @@ def test_cli_deviceingest_equals_the_host_path(tmp_path, chunk):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("chunk", ["6000", "268435456"])
+def test_cli_deviceingest_kmask_and_tips(tmp_path, chunk):
+    """ktrim=n (symbol N, a custom symbol, lower case) and ktrim=rl through the device pipeline: the masked / trimmed FASTQ and the
+    TSV equal what the host path writes."""
+    f1, f2 = os.path.join(GOLD, "cli_c2_r1.fq"), os.path.join(GOLD, "cli_c2_r2.fq")
+    for flags in (["ktrim=n", "k=23", "mink=11", "hdist=1"], ["ktrim=X", "k=23", "mink=11", "hdist=1"], ["kmask=lc", "k=21", "hdist=1"],
+                  ["ktrim=n", "k=23", "mfc=t"], ["ktrim=rl", "k=23", "mink=11", "hdist=1", "tpe"], ["ktrimtips=60", "k=19", "mink=9"]):
+        got = {}
+        for mode in ("host", "dev"):
+            tsv, out, outm = (str(tmp_path / (mode + n)) for n in ("o.tsv", "o.fq", "m.fq"))
+            r = run_cli(["in=" + f1, "in2=" + f2, "tsv=" + tsv, "out=" + out, "outm=" + outm, "ref=adapters"] + flags + (["deviceingest=t", "chunk=" + chunk] if mode == "dev" else []))
+            assert r.returncode == 0, (flags, r.stderr)
+            got[mode] = (open(tsv).read(), open(out, "rb").read(), open(outm, "rb").read(), [l for l in r.stderr.splitlines() if "reads" in l])
+        assert got["dev"] == got["host"], flags
+    assert got["dev"][0] != "" and b"@" in got["dev"][1]
+    r = run_cli(["in=" + f1, "in2=" + f2, "tsv=" + str(tmp_path / "k.tsv"), "out=" + str(tmp_path / "k.fq"), "ktrim=n", "k=23", "mink=11", "hdist=1", "ref=adapters", "deviceingest=t", "chunk=" + chunk])
+    assert r.returncode == 0 and open(str(tmp_path / "k.fq")).read() == open(os.path.join(GOLD, "cli_kmask_expected.fq")).read()
+    assert open(str(tmp_path / "k.tsv")).read() == open(os.path.join(GOLD, "cli_kmask.tsv")).read()
+
+
+@pytest.mark.gpu
 def test_cli_deviceingest_rejects_what_it_cannot_serve(tmp_path):
     f1 = os.path.join(GOLD, "cli_c2_r1.fq")
-    r = run_cli(["in=" + f1, "ktrim=n", "k=23", "ref=adapters", "deviceingest=t"])
+    r = run_cli(["in=" + f1, "ksplit=t", "k=23", "ref=adapters", "deviceingest=t"])
     assert r.returncode == 1 and "deviceingest" in r.stderr
     bad = tmp_path / "bad.fq"
     bad.write_text("@a\nACGT\n+\nIIII\n@b\nACGT\nIIII\n+\n")

@@ -326,6 +326,19 @@ def check_kmask(d, o, reads, paired):
     nw = (int(off[-1]) + 31) // 32
     assert np.array_equal(gm[:nw], om[:nw])
     assert np.array_equal(d.gpu.counters(), o.counters())
+    if len(reads) and int(off[-1]) > 0:                           # the packed-input variant of the operator: same answers
+        import torch
+        codes, undef = B.pack_bases_host(b)
+        n = len(off) - 1
+        d_c = torch.from_numpy(codes.view(np.int32)).cuda(); d_u = torch.from_numpy(undef.view(np.int32)).cuda(); d_o = torch.from_numpy(off).cuda()
+        d_a = torch.empty(n, dtype=torch.int32, device="cuda"); d_i = torch.empty_like(d_a); d_f = torch.empty(n, dtype=torch.uint8, device="cuda")
+        d_m = torch.zeros(nw + 4, dtype=torch.int32, device="cuda"); d_ctr = torch.zeros(d.gpu.counters_len, dtype=torch.int64, device="cuda")
+        rc = B.lib().bbduk_kmask_batch_packed_device(d.gpu.h, d_c.data_ptr(), d_u.data_ptr(), d_o.data_ptr(), n, int(off[-1]), int(paired),
+                                                     d_a.data_ptr(), d_i.data_ptr(), d_f.data_ptr(), d_m.data_ptr(), d_ctr.data_ptr(), None)
+        torch.cuda.synchronize()
+        assert rc == 0
+        assert np.array_equal(d_a.cpu().numpy(), oa) and np.array_equal(d_i.cpu().numpy(), oi) and np.array_equal(d_f.cpu().numpy(), of)
+        assert np.array_equal(d_m.cpu().numpy().view(np.uint32)[:nw], om[:nw]) and np.array_equal(d_ctr.cpu().numpy(), o.counters())
     return int(ga.sum())
 
 
@@ -404,6 +417,19 @@ def check_tips(d, o, reads, paired):
     bad = np.nonzero((gr != xr) | (gl != xl) | (gi != oi) | (gf != of))[0]
     assert len(bad) == 0, [(int(i), reads[i], (int(gr[i]), int(gl[i]), int(gi[i]), int(gf[i])), (int(xr[i]), int(xl[i]), int(oi[i]), int(of[i]))) for i in bad[:3]]
     assert np.array_equal(d.gpu.counters(), o.counters())
+    if len(reads) and int(off[-1]) > 0:                           # the packed-input variant of the operator: same answers
+        import torch
+        codes, undef = B.pack_bases_host(b)
+        n = len(off) - 1
+        d_c = torch.from_numpy(codes.view(np.int32)).cuda(); d_u = torch.from_numpy(undef.view(np.int32)).cuda(); d_o = torch.from_numpy(off).cuda()
+        d_r = torch.empty(n, dtype=torch.int32, device="cuda"); d_l = torch.empty_like(d_r); d_i = torch.empty_like(d_r); d_f = torch.empty(n, dtype=torch.uint8, device="cuda")
+        d_ctr = torch.zeros(d.gpu.counters_len, dtype=torch.int64, device="cuda")
+        rc = B.lib().bbduk_ktrimtips_batch_packed_device(d.gpu.h, d_c.data_ptr(), d_u.data_ptr(), d_o.data_ptr(), n, int(off[-1]), int(paired),
+                                                         d_r.data_ptr(), d_l.data_ptr(), d_i.data_ptr(), d_f.data_ptr(), d_ctr.data_ptr(), None)
+        torch.cuda.synchronize()
+        assert rc == 0
+        assert np.array_equal(d_r.cpu().numpy(), xr) and np.array_equal(d_l.cpu().numpy(), xl) and np.array_equal(d_i.cpu().numpy(), oi) and np.array_equal(d_f.cpu().numpy(), of)
+        assert np.array_equal(d_ctr.cpu().numpy(), o.counters())
     return int(gr.sum()), int(gl.sum())
 
 
