@@ -5,13 +5,48 @@ ksplit, kfilter with mbk/mkf/mcf, k>31, findbestmatch; host- or device-built map
 0..6000, junk bytes, Ns, chimeras) and compares the device operators -- ASCII and packed boundary -- with the CPU oracle,
 per read and counter by counter.  Prints one JSON line; exits non-zero at the first mismatch (config and seed in the message).
 """
-import argparse, json, os, random, sys, time
+import argparse, json, os, random, sys, time, traceback
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
 
 
+def ingest_roundtrip(B, d, o, okw, reads, rng):
+    import numpy as np, torch
+    from oracle import fastq_oracle as FQ
+    from oracle.oracle_ffi import pack_reads
+    eol = b"\r\n" if rng.random() < 0.3 else b"\n"
+    recs = []
+    for i, r in enumerate(reads):
+        r = bytes(c if c not in (10, 13) else 78 for c in r)
+        q = bytes(33 + rng.randrange(41) for _ in range(len(r)))
+        recs.append(eol.join([b"@r%d x" % i, r, b"+", q]))
+    final = eol if (rng.random() < 0.7 or not reads[-1]) else b""     # an empty last quality line only exists with its terminator
+    text = np.frombuffer(eol.join(recs) + final, np.uint8).copy()
+    dt = torch.from_numpy(np.concatenate([text, np.zeros(16, np.uint8)])).cuda()[:len(text)]
+    fb = B.fastq_ingest_device(dt, None, True, len(reads))
+    want = FQ.ingest([text], True, len(reads))
+    n = fb.n
+    assert n == want["n"] == len(reads) and np.array_equal(fb.offsets[:n + 1].cpu().numpy(), want["offsets"])
+    b, off = pack_reads([bytes(want["bases"][want["offsets"][i]:want["offsets"][i + 1]]) for i in range(n)])
+    o.reset_counters(); oa, oi, of = o.process_batch(b, off, True, nthreads=4)
+    d_a = torch.empty(n, dtype=torch.int32, device="cuda"); d_i = torch.empty_like(d_a); d_f = torch.empty(n, dtype=torch.uint8, device="cuda")
+    d_c = torch.zeros(d.gpu.counters_len, dtype=torch.int64, device="cuda")
+    d.gpu.process_batch_packed_device(fb.codes, fb.undef, fb.offsets[:n + 1].contiguous(), fb.total_bases, True, d_a, d_i, d_f, d_c)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_a.cpu().numpy(), oa) and np.array_equal(d_i.cpu().numpy(), oi) and np.array_equal(d_f.cpu().numpy(), of), "ingest->operator"
+    assert np.array_equal(d_c.cpu().numpy(), o.counters())
+    d_out = torch.empty(len(text) + 64, dtype=torch.uint8, device="cuda")
+    left = d_a if okw.get("ktrimLeft") else None; right = d_a if okw.get("ktrimRight") else None
+    z = np.zeros(n, np.int32)
+    for rem in (False, True):
+        nb = B.fastq_write_device(dt, fb, left, right, d_f, rem, d_out)
+        exp = FQ.write_records([text], want["lines"], n, oa if left is not None else z, oa if right is not None else z, of, rem)
+        assert bytes(d_out[:nb].cpu().numpy()) == exp, "writer"
+
+
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=300.0); ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--only", type=int, default=None, help="re-run the one configuration a FAILED line names by its seed")
     a = ap.parse_args()
     from bbtools_amd import bbduk as B
     from oracle.oracle_ffi import Oracle
@@ -19,8 +54,8 @@ def main():
     from tests import test_gpu_parity as T
     t0 = time.time(); n_cfg = 0; n_reads = 0; fam_count = {}
     it = 0
-    while time.time() - t0 < a.seconds:
-        seed = a.seed * 1_000_003 + it; it += 1
+    while time.time() - t0 < a.seconds and not (a.only is not None and it):
+        seed = a.seed * 1_000_003 + it if a.only is None else a.only; it += 1
         rng = random.Random(seed)
         fam = rng.choice(["base", "base", "base", "kmask", "tips", "ksplit", "big", "fbm"])
         args, okw = T.random_config(rng)
@@ -108,9 +143,11 @@ def main():
                 T.check_split(d, o, reads)
             else:
                 T.check_batch(d, o, reads, True); T.check_batch(d, o, reads[:101], False)
+                if fam == "base" and rng.random() < 0.2:        # the same reads as FASTQ text through ingest -> packed operator -> writer
+                    ingest_roundtrip(B, d, o, okw, reads, rng); fam_count["fastq_text"] = fam_count.get("fastq_text", 0) + 1
             d.close()
         except Exception as e:
-            print(json.dumps({"FAILED": True, "seed": seed, "family": fam, "args": args, "okw": okw, "build": build, "squeeze": locals().get("squeeze", ""), "error": str(e)[:2000]}))
+            print(json.dumps({"FAILED": True, "seed": seed, "family": fam, "args": args, "okw": okw, "build": build, "squeeze": locals().get("squeeze", ""), "error": (str(e) or traceback.format_exc())[-2000:]}))
             sys.exit(1)
         n_cfg += 1; n_reads += len(reads); fam_count[fam] = fam_count.get(fam, 0) + 1
     print(json.dumps({"soak_seconds": round(time.time() - t0, 1), "configs": n_cfg, "reads_checked": n_reads * 3, "families": fam_count, "mismatches": 0, "seed": a.seed}))
