@@ -3503,24 +3503,28 @@ static int host_batch(bbduk_handle* h, int wantKfilter, const uint8_t* bases, co
     const size_t undefBytes = packed ? 4 * (size_t)((total + 31) >> 5) : 0;
     std::lock_guard<std::mutex> g(h->mu);       // one staging area per handle: concurrent submitters serialise here
     HIP_TRY(h, hipSetDevice(h->p.device));
+    // a capacity is recorded only once its buffers exist: a failed hipMalloc leaves the handle usable for a smaller batch
     if (undefBytes + 8 > h->cap_undef) {
-        hipFree(h->d_undef); h->d_undef = nullptr;
-        h->cap_undef = undefBytes + 8 + undefBytes / 4;
-        HIP_TRY(h, hipMalloc(&h->d_undef, h->cap_undef));
+        hipFree(h->d_undef); h->d_undef = nullptr; h->cap_undef = 0;
+        const size_t cap = undefBytes + 8 + undefBytes / 4;
+        HIP_TRY(h, hipMalloc(&h->d_undef, cap));
+        h->cap_undef = cap;
     }
     if ((size_t)total + 16 > h->cap_bases) {
-        hipFree(h->d_bases); h->d_bases = nullptr;
-        h->cap_bases = (size_t)total + 16 + (size_t)total / 4;
-        HIP_TRY(h, hipMalloc(&h->d_bases, h->cap_bases));
+        hipFree(h->d_bases); h->d_bases = nullptr; h->cap_bases = 0;
+        const size_t cap = (size_t)total + 16 + (size_t)total / 4;
+        HIP_TRY(h, hipMalloc(&h->d_bases, cap));
+        h->cap_bases = cap;
     }
     if ((size_t)n + 1 > h->cap_reads) {
         hipFree(h->d_off); hipFree(h->d_a); hipFree(h->d_id); hipFree(h->d_fl);
-        h->d_off = nullptr; h->d_a = nullptr; h->d_id = nullptr; h->d_fl = nullptr;
-        h->cap_reads = (size_t)n + 1 + (size_t)n / 4;
-        HIP_TRY(h, hipMalloc(&h->d_off, h->cap_reads * sizeof(int64_t)));
-        HIP_TRY(h, hipMalloc(&h->d_a, h->cap_reads * sizeof(int32_t)));
-        HIP_TRY(h, hipMalloc(&h->d_id, h->cap_reads * sizeof(int32_t)));
-        HIP_TRY(h, hipMalloc(&h->d_fl, h->cap_reads));
+        h->d_off = nullptr; h->d_a = nullptr; h->d_id = nullptr; h->d_fl = nullptr; h->cap_reads = 0;
+        const size_t cap = (size_t)n + 1 + (size_t)n / 4;
+        HIP_TRY(h, hipMalloc(&h->d_off, cap * sizeof(int64_t)));
+        HIP_TRY(h, hipMalloc(&h->d_a, cap * sizeof(int32_t)));
+        HIP_TRY(h, hipMalloc(&h->d_id, cap * sizeof(int32_t)));
+        HIP_TRY(h, hipMalloc(&h->d_fl, cap));
+        h->cap_reads = cap;
     }
     if (total > 0) HIP_TRY(h, hipMemcpyAsync(h->d_bases, bases, baseBytes, hipMemcpyHostToDevice, h->stream));
     if (undefBytes) HIP_TRY(h, hipMemcpyAsync(h->d_undef, undef, undefBytes, hipMemcpyHostToDevice, h->stream));

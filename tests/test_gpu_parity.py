@@ -918,3 +918,37 @@ def test_large_map_without_lds_filter(build):
     check_batch(d, o, reads, True, nthreads=8)
     assert d.gpu.counters()[4] > 9000
     d.close()
+
+
+# ---- the C ABI's error behaviour (include/bbduk_gpu.h: BBDUK_ERR_*): a bad call returns its code, sets bbduk_last_error and
+# leaves the handle usable; nothing is computed on the CPU instead.
+def test_abi_error_codes():
+    L = B.lib()
+    host = B.HostIndex("ktrim=r k=23 mink=11 hdist=1")
+    host.add_ref(b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCAC")
+    host.build_index()
+    g = B.BBDukGpu(host.params(0))
+    reads = [b"ACGTACGTACGTAGATCGGAAGAGCACACGTCTGAACTCCAGTCAC", b"TTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTT"]
+    b, off = pack_reads(reads)
+    a = np.empty(2, np.int32); ids = np.empty(2, np.int32); fl = np.empty(2, np.uint8)
+    call = lambda fn, bases, offs, n, paired: fn(g.h, bases.ctypes.data, offs.ctypes.data, n, paired, a.ctypes.data, ids.ctypes.data, fl.ctypes.data)
+    assert call(L.bbduk_ktrim_batch, b, off, 2, 0) == -2 and b"finalized" in L.bbduk_last_error(g.h)     # BBDUK_ERR_STATE: batch before the map
+    g._check(L.bbduk_host_upload_index(host.h, g.h), "upload_index")
+    assert call(L.bbduk_kfilter_batch, b, off, 2, 0) == -2                       # the other mode's operator
+    m = np.zeros(8, np.uint32)
+    assert L.bbduk_kmask_batch(g.h, b.ctypes.data, off.ctypes.data, 2, 0, a.ctypes.data, ids.ctypes.data, fl.ctypes.data, m.ctypes.data) == -2
+    assert call(L.bbduk_ktrim_batch, b, off, -1, 0) == -1                        # BBDUK_ERR_ARG from here on
+    assert L.bbduk_ktrim_batch(g.h, b.ctypes.data, None, 2, 0, a.ctypes.data, ids.ctypes.data, fl.ctypes.data) == -1
+    assert L.bbduk_ktrim_batch(g.h, b.ctypes.data, off.ctypes.data, 2, 0, None, ids.ctypes.data, fl.ctypes.data) == -1
+    assert L.bbduk_ktrim_batch(g.h, None, off.ctypes.data, 2, 0, a.ctypes.data, ids.ctypes.data, fl.ctypes.data) == -1
+    assert L.bbduk_ktrim_batch(None, b.ctypes.data, off.ctypes.data, 2, 0, a.ctypes.data, ids.ctypes.data, fl.ctypes.data) == -1
+    b3, off3 = pack_reads(reads + [b"ACGT"])
+    assert call(L.bbduk_ktrim_batch, b3, off3, 3, 1) == -1                       # an odd number of reads cannot be pairs
+    shifted = off + 1
+    assert call(L.bbduk_ktrim_batch, b, shifted, 2, 0) == -1                     # offsets[0] != 0
+    assert L.bbduk_get_counters(g.h, None, 0) == -1
+    assert L.bbduk_upload_pairs(g.h, None, None, 0) == -2                        # the map is final
+    assert call(L.bbduk_ktrim_batch, b, off, 0, 0) == 0                          # an empty batch is fine
+    assert call(L.bbduk_ktrim_batch, b, off, 2, 0) == 0 and a[0] == len(reads[0]) - 12 and a[1] == 0     # and the handle still works
+    g.close(); g.close()                                                          # closing twice is harmless
+    host.close()
