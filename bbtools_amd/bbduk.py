@@ -52,7 +52,7 @@ GPU_SYMBOLS = ["bbduk_abi_version", "bbduk_create", "bbduk_destroy", "bbduk_last
                "bbduk_upload_pairs", "bbduk_finalize_table", "bbduk_build_table_device", "bbduk_table_size", "bbduk_table_bytes",
                "bbduk_table_lookup", "bbduk_ktrim_batch", "bbduk_kfilter_batch", "bbduk_ktrim_batch_device",
                "bbduk_kfilter_batch_device", "bbduk_pack_bases_host", "bbduk_pack_bases_device", "bbduk_ktrim_batch_packed",
-               "bbduk_kfilter_batch_packed", "bbduk_ktrim_batch_packed_device", "bbduk_kfilter_batch_packed_device", "bbduk_kmask_batch", "bbduk_kmask_batch_device", "bbduk_ktrimtips_batch", "bbduk_ktrimtips_batch_device", "bbduk_ksplit_batch", "bbduk_ksplit_batch_device", "bbduk_kmask_batch_packed_device", "bbduk_ktrimtips_batch_packed_device", "bbduk_fastq_ingest_device", "bbduk_fastq_write_device", "bbduk_fastq_write_masked_device", "bbduk_device_malloc", "bbduk_device_free", "bbduk_pinned_malloc", "bbduk_pinned_free",
+               "bbduk_kfilter_batch_packed", "bbduk_ktrim_batch_packed_device", "bbduk_kfilter_batch_packed_device", "bbduk_kmask_batch", "bbduk_kmask_batch_device", "bbduk_ktrimtips_batch", "bbduk_ktrimtips_batch_device", "bbduk_ksplit_batch", "bbduk_kfilter_batch_matches", "bbduk_kfilter_batch_matches_device", "bbduk_ksplit_batch_device", "bbduk_kmask_batch_packed_device", "bbduk_ktrimtips_batch_packed_device", "bbduk_fastq_ingest_device", "bbduk_fastq_write_device", "bbduk_fastq_write_masked_device", "bbduk_device_malloc", "bbduk_device_free", "bbduk_pinned_malloc", "bbduk_pinned_free",
                "bbduk_copy_to_device", "bbduk_copy_from_device", "bbduk_device_memset", "bbduk_kernel_time_ms", "bbduk_counters_len", "bbduk_get_counters", "bbduk_reset_counters",
                "bbduk_synth_generate_device", "bbduk_synth_generate_host"]
 HOST_SYMBOLS = ["bbduk_host_parse", "bbduk_host_destroy", "bbduk_host_add_ref", "bbduk_host_load_fasta",
@@ -158,6 +158,8 @@ def lib():
     L.bbduk_kmask_batch.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, vp]
     L.bbduk_ktrimtips_batch.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, vp]
     L.bbduk_ksplit_batch.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp]
+    L.bbduk_kfilter_batch_matches.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, i32, vp, vp, vp]
+    L.bbduk_kfilter_batch_matches_device.argtypes = [vp, vp, vp, i64, i64, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     L.bbduk_ksplit_batch_device.argtypes = [vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp]
     L.bbduk_ktrimtips_batch_device.argtypes = [vp, vp, vp, i64, i64, i32, vp, vp, vp, vp, vp, vp]
     L.bbduk_kmask_batch_device.argtypes = [vp, vp, vp, i64, i64, i32, vp, vp, vp, vp, vp, vp]
@@ -379,6 +381,18 @@ class BBDukGpu:
         self._check(lib().bbduk_ksplit_batch(self.h, bases.ctypes.data if len(bases) else None, offsets.ctypes.data, n,
                                              x.ctypes.data, lm.ctypes.data, rm.ctypes.data, ids.ctypes.data, fl.ctypes.data), "ksplit_batch")
         return x, ids, fl, lm, rm
+
+    def kfilter_batch_matches(self, bases, offsets, paired, max_ids):
+        """findBestMatch + the per-read lists rename=t prints (BBDukProcessorS.java:1702, 2508-2522):
+        (found, ids, flags, nids, match_ids[n,max_ids], match_counts[n,max_ids]); entries past a read's list are 0."""
+        bases = np.ascontiguousarray(bases, np.uint8); offsets = np.ascontiguousarray(offsets, np.int64)
+        n = len(offsets) - 1
+        a = np.empty(n, np.int32); ids = np.empty(n, np.int32); fl = np.empty(n, np.uint8)
+        nids = np.zeros(n, np.int32); mi = np.zeros((n, max_ids), np.int32); mc = np.zeros((n, max_ids), np.int32)
+        self._check(lib().bbduk_kfilter_batch_matches(self.h, bases.ctypes.data if len(bases) else None, offsets.ctypes.data, n, int(paired),
+                                                      a.ctypes.data, ids.ctypes.data, fl.ctypes.data, max_ids, nids.ctypes.data,
+                                                      mi.ctypes.data, mc.ctypes.data), "kfilter_batch_matches")
+        return a, ids, fl, nids, mi, mc
 
     def process_batch(self, bases, offsets, paired):
         if self.params.mode == MODE_KSPLIT:

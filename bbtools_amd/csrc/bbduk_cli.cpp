@@ -249,6 +249,7 @@ int main(int argc, char** argv) {
     std::string in1, in2, out, outm, tsv, resources = "data", flags;
     bool interleaved = false; long batch = 1000000; int device = 0;
     bool maskLower = false; char maskSymbol = 'N';
+    bool rename = false;                                          // rename=t: matched reads get "\tscaffold=hits" appended (BBDukProcessorS.java:2508-2522)
     StatsOut so;
     bool deviceIngest = false; long long chunk = 256LL << 20;     // deviceingest=t: FASTQ text to the GPU, chunk= bytes per file and round
     bool deviceBuild = false;        // devicebuild=t: the GPU builds the k-mer map from the reference sequences (bbduk_build_table_device)
@@ -273,6 +274,7 @@ int main(int argc, char** argv) {
         else if (a == "statscolumns" || a == "columns" || a == "cols") so.columns = atoi(b.c_str());
         else if (a == "nzo" || a == "nonzeroonly") so.nonZeroOnly = parse_bool(b);
         else {
+            if (a == "rename") rename = parse_bool(b);               // also goes to the parser: it implies findbestmatch (BBDukParser.java:153)
             if (a == "ktrim" || a == "kmask" || a == "mask") {       // the replacement symbol is the caller's business (BBDukParser.java:619-644)
                 std::string v = b; for (auto& c : v) c = (char)tolower(c);
                 if (v == "lc" || v == "lowercase") maskLower = true;
@@ -306,6 +308,7 @@ int main(int argc, char** argv) {
     fprintf(stderr, "Added %lld kmers; %d scaffolds.\n", (long long)stored, bbduk_host_num_scaffolds(host) - 1);
 
     if (deviceIngest) {
+        if (rename && P.findBestMatch) return fail("deviceingest=t does not rewrite read names: use rename=t without it", nullptr);
         if (chunk < 4096) chunk = 4096;
         const int rc = run_device_ingest(dev, host, so, P, in1, in2, paired, out, outm, tsv, (int64_t)chunk, device, maskLower, maskSymbol);
         if (rc == 0) { bbduk_destroy(dev); bbduk_host_destroy(host); }
@@ -321,7 +324,7 @@ int main(int argc, char** argv) {
 
     const bool ktrim = P.mode != BBDUK_MODE_KFILTER;
     std::vector<Rec> recs; std::vector<uint8_t> bases; std::vector<int64_t> offsets;
-    std::vector<int32_t> res, ids, resL, resR; std::vector<uint8_t> fl; std::vector<uint32_t> mask;
+    std::vector<int32_t> res, ids, resL, resR, mN, mIds, mCnt; std::vector<uint8_t> fl; std::vector<uint32_t> mask;
     if (P.mode == BBDUK_MODE_KSPLIT && paired) return fail("ksplit works on unpaired reads (BBDukProcessorS.java:2334)", nullptr);
     bool eof = false; long long nread = 0;
     while (!eof) {
@@ -353,6 +356,16 @@ int main(int argc, char** argv) {
         } else if (P.mode == BBDUK_MODE_KMASK) {
             mask.assign((size_t)(offsets[n] + 31) / 32 + 1, 0u);
             rc = bbduk_kmask_batch(dev, bases.data(), offsets.data(), n, paired, res.data(), ids.data(), fl.data(), mask.data());
+        } else if (rename && P.findBestMatch) {                     // rename() :2508-2522 on the lists findBestMatch left
+            const int cap = 64;
+            mN.resize(n); mIds.resize((size_t)n * cap); mCnt.resize((size_t)n * cap);
+            rc = bbduk_kfilter_batch_matches(dev, bases.data(), offsets.data(), n, paired, res.data(), ids.data(), fl.data(), cap, mN.data(), mIds.data(), mCnt.data());
+            for (int64_t i = 0; rc == BBDUK_OK && i < n; i++) {
+                for (int j = 0; j < mN[i]; j++) {
+                    const char* nm = ""; bbduk_host_scaffold_info(host, mIds[(size_t)i * cap + j], &nm, nullptr);
+                    recs[i].name += '\t'; recs[i].name += nm; recs[i].name += '='; recs[i].name += std::to_string(mCnt[(size_t)i * cap + j]);
+                }
+            }
         } else rc = ktrim ? bbduk_ktrim_batch(dev, bases.data(), offsets.data(), n, paired, res.data(), ids.data(), fl.data())
                           : bbduk_kfilter_batch(dev, bases.data(), offsets.data(), n, paired, res.data(), ids.data(), fl.data());
         if (rc != BBDUK_OK) return fail("batch operator", bbduk_last_error(dev));

@@ -59,6 +59,7 @@ struct KParams {
     float   mkf, mcf;            // kfilter: minkmerfraction / mincoveredfraction (general kernels only)
     int32_t mfc;                 // kmaskfullycovered (ktrim=n): mask only bases all of whose covering k-mers match
     int32_t kbig, fbm;           // kfilter variants of bbduk_kscan_kernel: k>31 emulation (kbig>k), findBestMatch
+    int32_t* matchN; int32_t* matchIds; int32_t* matchCnt; int32_t matchCap;    // findBestMatch's idList / countList per read (rename, :2508-2522), or null
     const uint32_t* undef;      // packed input (bbduk_*_batch_packed): 1 bit per base, set = undefined; `bases` then points at
                                 // 2-bit codes, 16 bases per 32-bit word (A0 C1 G2 T/U3, undefined 0).  nullptr = ASCII bases
     uint64_t mask, kmask, middleMask;
@@ -1607,6 +1608,18 @@ __device__ __forceinline__ void kscan_finish(KScanState& S, const int thr, const
     }
 }
 
+// rename's input (:1702, 2508-2522): the distinct scaffolds a matched read hit, in first-hit order, with their hit counts.
+// matchN = idList.size (0 for a read that did not match); at most matchCap entries are written.
+__device__ __forceinline__ void kscan_write_matches(const KParams& P, const KScanState& S, const int thr, const int64_t read, const int lane) {
+    if (!P.matchN) return;
+    const bool m = S.found > thr;
+    if (lane == 0) P.matchN[read] = m ? S.nids : 0;
+    if (m && lane < S.nids && lane < P.matchCap) {
+        P.matchIds[read * P.matchCap + lane] = S.myId;
+        P.matchCnt[read * P.matchCap + lane] = S.myCnt;
+    }
+}
+
 template <int RED>
 __global__ __launch_bounds__(BLOCK_THREADS)
 void bbduk_kscan_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
@@ -1696,6 +1709,7 @@ void bbduk_kscan_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
                     kscan_window<RED>(P, Q, W, S, thr, lane, counters);
                     kscan_finish<RED>(S, thr, P.kbig - k - 1, lane);
                 }
+                if (RED == RED_BEST) kscan_write_matches(P, S, thr, r0 + rd, lane);
                 const int rid = S.rid, firstI = S.firstI, lastI = S.lastI;
                 int found = S.found, id0 = S.id0;
                 if (RED != RED_SPLIT) {
@@ -2736,7 +2750,7 @@ void bbduk_kscan_long_kernel(const KParams P, const uint8_t* __restrict__ bases,
         return (int)(off - A0);
     };
     // one read: found / credited id (kfilter variants) or trimmed / id0 / leftmost / rightmost / new pair length / split (ksplit)
-    auto one = [&](const int64_t off, const int L, const int pairnum, int& found, int& rid, int& thr, int& lm, int& rm, int& npl, int& split) {
+    auto one = [&](const int64_t read, const int64_t off, const int L, const int pairnum, int& found, int& rid, int& thr, int& lm, int& rm, int& npl, int& split) {
         ReadScan R;
         R.base0 = 0; R.L = L; R.hasN = -1; R.maxBad = 0;
         R.start = span_start<true>(P, L); R.stop = span_stop<true>(P, L);
@@ -2782,6 +2796,7 @@ void bbduk_kscan_long_kernel(const KParams P, const uint8_t* __restrict__ bases,
             }
             kscan_finish<RED>(S, thr, P.kbig - k - 1, lane);
         }
+        if (RED == RED_BEST) kscan_write_matches(P, S, thr, read, lane);
         found = S.found; rid = S.rid;
         if (RED != RED_SPLIT) { if (rid > 0) scaf_add(P, scaf, rid, L, lane, counters); return; }
         // ---- ksplit: span of the main hits, else the short k-mers of the right end, else of the left end (:2388-2474)
@@ -2838,8 +2853,8 @@ void bbduk_kscan_long_kernel(const KParams P, const uint8_t* __restrict__ bases,
         const int64_t o0 = offsets[ra], o1 = offsets[ra + 1], o2 = two ? offsets[ra + 2] : o1;
         const int l1 = (int)(o1 - o0), l2 = (int)(o2 - o1);
         int f1v, id1, thr1, lm1, rm1, npl1, sp1, f2v = 0, id2 = -1, thr2 = 0, lm2, rm2, npl2, sp2;
-        one(o0, l1, 0, f1v, id1, thr1, lm1, rm1, npl1, sp1);
-        if (two) one(o1, l2, 1, f2v, id2, thr2, lm2, rm2, npl2, sp2);
+        one(ra, o0, l1, 0, f1v, id1, thr1, lm1, rm1, npl1, sp1);
+        if (two) one(ra + 1, o1, l2, 1, f2v, id2, thr2, lm2, rm2, npl2, sp2);
         if (lane == 0) {
             atomicAdd(&s_acc[4], two ? 2ULL : 1ULL); atomicAdd(&s_acc[5], (unsigned long long)(o2 - o0));
             outA[ra] = f1v; outId[ra] = id1;
@@ -3342,17 +3357,21 @@ static KParams make_kparams(const bbduk_handle* h) {
     K.middleMask = (uint64_t)p.middleMask;
     K.tags = h->d_tags; K.bkv = h->d_bkv; K.bucketMask = (uint32_t)(h->nbuckets - 1); K.bucketBits = h->bucketBits;
     K.storedKmers = h->nkeys; K.undef = nullptr;
+    K.matchN = nullptr; K.matchIds = nullptr; K.matchCnt = nullptr; K.matchCap = 0;
     K.dbg = getenv("BBDUK_DBG") ? atoi(getenv("BBDUK_DBG")) : 0;
     K.ldsImage = h->d_ldsImage; K.ldsBits = h->ldsBits;
     return K;
 }
 
+struct MatchOut { int32_t* n; int32_t* ids; int32_t* counts; int32_t cap; };     // device buffers of bbduk_kfilter_batch_matches*
+
 // kbig / findBestMatch (through the kfilter operators) and ksplit: bbduk_kscan_kernel
 static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d_offsets, int64_t n, int64_t total_bases, int32_t paired,
                         int32_t* d_a, int32_t* d_id, uint8_t* d_fl, int32_t* d_left, int32_t* d_right, int64_t* d_counters, hipStream_t st,
-                        const uint32_t* d_undef, bool packed) {
+                        const uint32_t* d_undef, bool packed, const MatchOut* mo = nullptr) {
     KParams K = make_kparams(h);
     K.undef = packed ? d_undef : nullptr;
+    if (mo) { K.matchN = mo->n; K.matchIds = mo->ids; K.matchCnt = mo->counts; K.matchCap = mo->cap; }
     const int red = h->p.mode == BBDUK_MODE_KSPLIT ? RED_SPLIT : (K.fbm ? RED_BEST : RED_BIG);
     typedef void (*kscan_t)(const KParams, const uint8_t*, const int64_t*, const int64_t, const int64_t, const int,
                             int32_t*, int32_t*, uint8_t*, int32_t*, int32_t*, int64_t*);
@@ -3387,9 +3406,11 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
 
 static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases, const int64_t* d_offsets, int64_t n,
                         int64_t total_bases, int32_t paired, int32_t* d_a, int32_t* d_id, uint8_t* d_fl,
-                        int64_t* d_counters, hipStream_t st, const uint32_t* d_undef = nullptr, bool packed = false) {
+                        int64_t* d_counters, hipStream_t st, const uint32_t* d_undef = nullptr, bool packed = false, const MatchOut* mo = nullptr) {
     if (!h) return BBDUK_ERR_ARG;
     if (!h->finalized) return fail(h, BBDUK_ERR_STATE, "table not finalized");
+    if (mo && !h->p.findBestMatch) return fail(h, BBDUK_ERR_STATE, "match lists need findBestMatch (rename / fbm) in the parameters given to bbduk_create");
+    if (mo && n > 0 && (!mo->n || mo->cap < 1 || mo->cap > KS_MAX_IDS || !mo->ids || !mo->counts)) return fail(h, BBDUK_ERR_ARG, "match lists: null buffer or max_ids outside 1..64");
     if (h->p.mode == BBDUK_MODE_KMASK || h->p.mode == BBDUK_MODE_KTRIM_TIPS || h->p.mode == BBDUK_MODE_KSPLIT || (h->p.mode == BBDUK_MODE_KFILTER) != (wantKfilter != 0)) return fail(h, BBDUK_ERR_STATE, "operator does not match the mode given to bbduk_create");
     if (n < 0 || total_bases < 0 || (paired && (n & 1))) return fail(h, BBDUK_ERR_ARG, "bad batch shape");
     if (n == 0) return BBDUK_OK;
@@ -3398,7 +3419,7 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     if (!packed && ((uintptr_t)d_bases & 15) != 0) return fail(h, BBDUK_ERR_ARG, "d_bases must be 16-byte aligned");
     if (packed && (!d_undef || ((uintptr_t)d_bases & 3) != 0)) return fail(h, BBDUK_ERR_ARG, "packed input needs both planes, 4-byte aligned");
     if (h->p.kbig > h->p.k || h->p.findBestMatch)                               // countSetKmersBig / findBestMatch behind the kfilter operators
-        return launch_kscan(h, d_bases, d_offsets, n, total_bases, paired, d_a, d_id, d_fl, nullptr, nullptr, d_counters, st, d_undef, packed);
+        return launch_kscan(h, d_bases, d_offsets, n, total_bases, paired, d_a, d_id, d_fl, nullptr, nullptr, d_counters, st, d_undef, packed, mo);
     KParams K = make_kparams(h);
     K.undef = packed ? d_undef : nullptr;
     const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
@@ -3457,6 +3478,14 @@ extern "C" int bbduk_kfilter_batch_device(bbduk_handle* h, const uint8_t* d_base
     return launch_batch(h, 1, d_bases, d_offsets, n, total_bases, paired, d_out_found, d_out_id, d_out_flags, d_counters, (hipStream_t)stream);
 }
 
+extern "C" int bbduk_kfilter_batch_matches_device(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d_offsets, int64_t n,
+                                                  int64_t total_bases, int32_t paired, int32_t* d_out_found, int32_t* d_out_id,
+                                                  uint8_t* d_out_flags, int32_t max_ids, int32_t* d_out_nids, int32_t* d_out_match_ids,
+                                                  int32_t* d_out_match_counts, int64_t* d_counters, void* stream) {
+    const MatchOut mo{d_out_nids, d_out_match_ids, d_out_match_counts, max_ids};
+    return launch_batch(h, 1, d_bases, d_offsets, n, total_bases, paired, d_out_found, d_out_id, d_out_flags, d_counters, (hipStream_t)stream, nullptr, false, &mo);
+}
+
 // ---- packed boundary format (2-bit codes + undefined bits)
 extern "C" int bbduk_pack_bases_device(const uint8_t* d_bases, int64_t total_bases, uint32_t* d_codes, uint32_t* d_undef, int32_t device, void* stream) {
     if (total_bases < 0 || (total_bases > 0 && (!d_bases || !d_codes || !d_undef))) return BBDUK_ERR_ARG;
@@ -3492,9 +3521,12 @@ extern "C" int bbduk_kfilter_batch_packed_device(bbduk_handle* h, const uint32_t
 }
 
 static int host_batch(bbduk_handle* h, int wantKfilter, const uint8_t* bases, const int64_t* offsets, int64_t n, int32_t paired,
-                      int32_t* out_a, int32_t* out_id, uint8_t* out_fl, const uint32_t* undef = nullptr, bool packed = false) {
+                      int32_t* out_a, int32_t* out_id, uint8_t* out_fl, const uint32_t* undef = nullptr, bool packed = false,
+                      const MatchOut* hostMatches = nullptr) {
     if (!h) return BBDUK_ERR_ARG;
     if (n < 0 || !offsets || (n > 0 && (!out_a || !out_id || !out_fl))) return fail(h, BBDUK_ERR_ARG, "bad argument");
+    if (hostMatches && n > 0 && (!hostMatches->n || !hostMatches->ids || !hostMatches->counts || hostMatches->cap < 1 || hostMatches->cap > KS_MAX_IDS))
+        return fail(h, BBDUK_ERR_ARG, "match lists: null buffer or max_ids outside 1..64");
     if (n == 0) return BBDUK_OK;
     const int64_t total = offsets[n];
     if (offsets[0] != 0 || total < 0 || (total > 0 && !bases)) return fail(h, BBDUK_ERR_ARG, "bad offsets");
@@ -3529,9 +3561,26 @@ static int host_batch(bbduk_handle* h, int wantKfilter, const uint8_t* bases, co
     if (total > 0) HIP_TRY(h, hipMemcpyAsync(h->d_bases, bases, baseBytes, hipMemcpyHostToDevice, h->stream));
     if (undefBytes) HIP_TRY(h, hipMemcpyAsync(h->d_undef, undef, undefBytes, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_off, offsets, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    MatchOut dm{nullptr, nullptr, nullptr, 0};                  // match lists: device buffers of this call only
+    auto release = [&]() { hipFree(dm.n); hipFree(dm.ids); hipFree(dm.counts); };
+    if (hostMatches) {
+        dm.cap = hostMatches->cap;
+        const size_t lw = (size_t)n * (size_t)dm.cap * sizeof(int32_t);
+        if (hipMalloc(&dm.n, (size_t)n * sizeof(int32_t)) != hipSuccess || hipMalloc(&dm.ids, lw) != hipSuccess || hipMalloc(&dm.counts, lw) != hipSuccess ||
+            hipMemsetAsync(dm.ids, 0, lw, h->stream) != hipSuccess || hipMemsetAsync(dm.counts, 0, lw, h->stream) != hipSuccess) { release(); return fail(h, BBDUK_ERR_NOMEM, "hipMalloc (match lists)"); }
+    }
     const int rc = launch_batch(h, wantKfilter, h->d_bases, h->d_off, n, total, paired, h->d_a, h->d_id, h->d_fl, h->d_counters, h->stream,
-                                reinterpret_cast<const uint32_t*>(h->d_undef), packed);
-    if (rc != BBDUK_OK) return rc;
+                                reinterpret_cast<const uint32_t*>(h->d_undef), packed, hostMatches ? &dm : nullptr);
+    if (rc != BBDUK_OK) { release(); return rc; }
+    if (hostMatches) {
+        const size_t lw = (size_t)n * (size_t)dm.cap * sizeof(int32_t);
+        const bool okc = hipMemcpyAsync(hostMatches->n, dm.n, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
+                         hipMemcpyAsync(hostMatches->ids, dm.ids, lw, hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
+                         hipMemcpyAsync(hostMatches->counts, dm.counts, lw, hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
+                         hipStreamSynchronize(h->stream) == hipSuccess;
+        release();
+        if (!okc) return fail(h, BBDUK_ERR_DEVICE, "copying the match lists back");
+    }
     HIP_TRY(h, hipMemcpyAsync(out_a, h->d_a, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(out_id, h->d_id, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(out_fl, h->d_fl, (size_t)n, hipMemcpyDeviceToHost, h->stream));
@@ -3553,6 +3602,13 @@ extern "C" int bbduk_ktrim_batch(bbduk_handle* h, const uint8_t* bases, const in
 extern "C" int bbduk_kfilter_batch(bbduk_handle* h, const uint8_t* bases, const int64_t* offsets, int64_t n, int32_t paired,
                                    int32_t* out_found, int32_t* out_id, uint8_t* out_flags) {
     return host_batch(h, 1, bases, offsets, n, paired, out_found, out_id, out_flags);
+}
+
+extern "C" int bbduk_kfilter_batch_matches(bbduk_handle* h, const uint8_t* bases, const int64_t* offsets, int64_t n, int32_t paired,
+                                           int32_t* out_found, int32_t* out_id, uint8_t* out_flags, int32_t max_ids, int32_t* out_nids,
+                                           int32_t* out_match_ids, int32_t* out_match_counts) {
+    const MatchOut mo{out_nids, out_match_ids, out_match_counts, max_ids};
+    return host_batch(h, 1, bases, offsets, n, paired, out_found, out_id, out_flags, nullptr, false, &mo);
 }
 
 // ---- ktrim=rl

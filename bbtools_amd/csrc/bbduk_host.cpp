@@ -39,7 +39,7 @@ struct Parsed {                      // bbduk/BBDukParser.java fields (subset th
     bool trimPairsEvenly = false;    // tpe
     int qSkip = 1, speed = 0;        // :1373-1377
     float minKmerFraction = 0.f, minCoveredFraction = 0.f;   // :1234-1236
-    bool ksplit = false, findBestMatch = false;              // :1313, 1323
+    bool ksplit = false, findBestMatch = false, rename = false;   // :1313, 1323, 1367
     bool kmaskFullyCovered = false;                          // :1317
     int kbig = -1;                                           // :1226 (derived: the requested k when it exceeds 31)
     std::vector<std::string> ref, literal;
@@ -103,7 +103,9 @@ int derive(Parsed& p, std::string& err) {            // bbduk/BBDukParser.java:1
     p.minlen2 = (p.maskMiddle ? (p.k - p.midMaskLen) / 2 : p.k);        // before mink turns maskMiddle off
     if (p.mink > 0 && p.mink < p.k) p.useShortKmers = true;
     if (p.useShortKmers && p.maskMiddle) { p.maskMiddle = false; p.midMaskLen = 0; }
+    p.findBestMatch = p.rename || p.findBestMatch;                                                   // :153
     const bool kfilter = !(p.ktrimLeft || p.ktrimRight || p.ktrimN || p.ksplit);                     // :298
+    if (p.rename && kfilter && p.minCoveredFraction > 0.f) { err = "rename with mincoveredfraction is not supported by this path"; return BBDUK_ERR_ARG; }   // :1049-1052
     if (p.findBestMatch && kfilter && p.kbig > p.k) { err = "K must be less than 32 in 'findBestMatch' mode"; return BBDUK_ERR_ARG; }   // :299
     if (p.findBestMatch && kfilter && (p.maxBadKmers0 != 0 || p.minKmerFraction != 0.f)) {
         err = "findbestmatch with maxbadkmers>0 or minkmerfraction>0 is not supported by this path (the reference's answer depends on thread history there)";
@@ -263,7 +265,7 @@ extern "C" int bbduk_host_parse(const char* args, bbduk_host** out, char* errbuf
         }
         else if (a == "ksplit") { bool x = false; need_bool(x); if (ok) { p.ksplit = x; if (x) p.ktrimLeft = p.ktrimRight = p.ktrimN = false; } }   // :599-603
         else if (a == "findbestmatch" || a == "fbm") need_bool(p.findBestMatch);                                                                       // :594-595
-        else if (a == "rename") { bool x = false; need_bool(x); if (ok && x) { seterr("rename=t is not supported by this path"); delete h; return BBDUK_ERR_ARG; } }
+        else if (a == "rename") need_bool(p.rename);                                                                                                   // :694-695
         else if (a == "ktrimn") { need_bool(p.ktrimN); if (ok) p.ktrimLeft = p.ktrimRight = !p.ktrimN; }
         else if (a == "kmaskfullycovered" || a == "maskfullycovered" || a == "mfc") {
             need_bool(p.kmaskFullyCovered);

@@ -150,6 +150,21 @@ int  bbduk_kfilter_batch_device(bbduk_handle* h, const uint8_t* d_bases, const i
                                 int64_t total_bases, int32_t paired, int32_t* d_out_found, int32_t* d_out_id,
                                 uint8_t* d_out_flags, int64_t* d_counters, void* stream);
 
+/* findBestMatch with the per-read match lists that `rename=t` prints (BBDukProcessorS.findBestMatch :1659-1719 fills
+ * idList / countList, rename() :2508-2522 appends "\tname=count" for each entry to the read's id).  The handle must have
+ * been created with findBestMatch=1 (BBDukParser.java:153: rename implies it).  Besides bbduk_kfilter_batch's outputs:
+ *   out_nids[i]                          idList.size of read i when it matched (found > maxBadKmers), else 0
+ *   out_match_ids[i*max_ids + j], out_match_counts[...]   j < min(out_nids[i], max_ids): the j-th distinct scaffold id in
+ *                                        first-hit order and its number of hits; entries past the list are not written
+ * max_ids in 1..64 (a read that hits more than 64 scaffolds is BBDUK_ERR_ID_OVERFLOW as for plain findBestMatch). */
+int  bbduk_kfilter_batch_matches(bbduk_handle* h, const uint8_t* bases, const int64_t* offsets, int64_t n, int32_t paired,
+                                 int32_t* out_found, int32_t* out_id, uint8_t* out_flags, int32_t max_ids, int32_t* out_nids,
+                                 int32_t* out_match_ids, int32_t* out_match_counts);
+int  bbduk_kfilter_batch_matches_device(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d_offsets, int64_t n,
+                                        int64_t total_bases, int32_t paired, int32_t* d_out_found, int32_t* d_out_id,
+                                        uint8_t* d_out_flags, int32_t max_ids, int32_t* d_out_nids, int32_t* d_out_match_ids,
+                                        int32_t* d_out_match_counts, int64_t* d_counters, void* stream);
+
 /* ---- packed boundary format.  The reference keeps reads as one ASCII byte per base (`Read.bases`, stream/Read.java) and
  * converts each base to its 2-bit code inside the rolling loops (AminoAcid.baseToNumber / baseToComplementNumber,
  * bbduk/BBDukProcessorS.java:1752-1757); these entry points take the same reads with that conversion already done by

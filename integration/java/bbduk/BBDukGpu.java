@@ -43,6 +43,8 @@ public final class BBDukGpu {
 			int[] outRight, int[] outLeft, int[] outId0, byte[] outFlags);
 	private static native int ksplitBatchJNI(long h, byte[] bases, long[] offsets, int n,
 			int[] outTrimmed, int[] outLeftmost, int[] outRightmost, int[] outId0, byte[] outFlags);
+	private static native int kfilterBatchMatchesJNI(long h, byte[] bases, long[] offsets, int n, boolean paired,
+			int[] outFound, int[] outId, byte[] outFlags, int maxIds, int[] outNids, int[] outMatchIds, int[] outMatchCounts);
 	private static native int countersJNI(long h, long[] out);
 	private static native void destroyJNI(long h);
 
@@ -79,6 +81,12 @@ public final class BBDukGpu {
 	/** Also serves k>31 (countSetKmersBig) and findBestMatch when the parser set kbig / findBestMatch. */
 	public static void kfilterBatch(long h, byte[] bases, long[] offsets, int n, boolean paired, int[] outFound, int[] outId, byte[] outFlags){
 		check(kfilterBatchJNI(h, bases, offsets, n, paired, outFound, outId, outFlags), "bbduk_kfilter_batch");
+	}
+	/** findBestMatch plus idList/countList per read for rename() (BBDukProcessorS.java:1702, 2508-2522): read i matched outNids[i] scaffolds,
+	 *  outMatchIds/outMatchCounts[i*maxIds+j] are the j-th of them in first-hit order (maxIds in 1..64). */
+	public static void kfilterBatchMatches(long h, byte[] bases, long[] offsets, int n, boolean paired, int[] outFound, int[] outId, byte[] outFlags,
+			int maxIds, int[] outNids, int[] outMatchIds, int[] outMatchCounts){
+		check(kfilterBatchMatchesJNI(h, bases, offsets, n, paired, outFound, outId, outFlags, maxIds, outNids, outMatchIds, outMatchCounts), "bbduk_kfilter_batch_matches");
 	}
 	/** codes: 2 bits per base, 16 per int; undef: 1 bit per base (baseToNumber<0); offsets still count bases. */
 	public static void ktrimBatchPacked(long h, int[] codes, int[] undef, long[] offsets, int n, boolean paired, int[] outTrimmed, int[] outId0, byte[] outFlags){

@@ -146,6 +146,16 @@ JNIEXPORT jint JNICALL Java_bbduk_BBDukGpu_ksplitBatchJNI(JNIEnv* env, jclass cl
     return rc;
 }
 
+JNIEXPORT jint JNICALL Java_bbduk_BBDukGpu_kfilterBatchMatchesJNI(JNIEnv* env, jclass cls, jlong h, jbyteArray bases, jlongArray offsets, jint n,
+        jboolean paired, jintArray outFound, jintArray outId, jbyteArray outFlags, jint maxIds, jintArray outNids, jintArray outMatchIds, jintArray outMatchCounts) {
+    pinned x[8] = {{bases, 0}, {offsets, 0}, {outFound, 0}, {outId, 0}, {outFlags, 0}, {outNids, 0}, {outMatchIds, 0}, {outMatchCounts, 0}};
+    pin_all(env, x, 8);
+    const jint rc = bbduk_kfilter_batch_matches(H(h), (const uint8_t*)x[0].p, (const int64_t*)x[1].p, n, paired ? 1 : 0, (int32_t*)x[2].p, (int32_t*)x[3].p,
+                                                (uint8_t*)x[4].p, maxIds, (int32_t*)x[5].p, (int32_t*)x[6].p, (int32_t*)x[7].p);
+    unpin_all(env, x, 8, 2);
+    return rc;
+}
+
 JNIEXPORT jint JNICALL Java_bbduk_BBDukGpu_countersJNI(JNIEnv* env, jclass cls, jlong h, jlongArray out) {
     const jint n = (*env)->GetArrayLength(env, out);
     jlong* o = (jlong*)PIN(out);

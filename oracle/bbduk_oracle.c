@@ -557,7 +557,8 @@ int bbo_get_value(const bbo_ctx* c, const int64_t kmer, const int64_t rkmer, con
 
 /* per-thread counter block */
 typedef struct { int64_t counters[BBO_NCOUNTERS]; int64_t* scafReads; int64_t* scafBases;
-                 int* countArray; int* idList; } tcounters;             /* findBestMatch's per-thread state (:3170-3172) */
+                 int* countArray; int* idList;
+                 int32_t* mN; int32_t* mIds; int32_t* mCnt; int mCap; int64_t mRead; } tcounters;             /* findBestMatch's per-thread state (:3170-3172) */
 
 /* shared/TrimRead.java:304-345 trimByAmount, on lengths only (bases/quals are copied by the caller in Java).
  * Returns total trimmed; *newLen gets the resulting length. */
@@ -797,6 +798,7 @@ static int find_best_match(const bbo_ctx* c, tcounters* tc, const uint8_t* bases
     const int k = c->k;
     *foundout = 0;
     int nids = 0;
+    if (tc->mN) tc->mN[tc->mRead + pairnum] = 0;                                           /* rename's lists (:1702, 2508-2522) */
     if (blen < k || c->storedKmers < 1) return -1;
     if ((c->a.skipR1 && pairnum == 0) || (c->a.skipR2 && pairnum == 1)) return -1;
     if (!tc->countArray) { tc->countArray = (int*)calloc((size_t)c->numScaffolds, sizeof(int)); tc->idList = (int*)calloc((size_t)c->numScaffolds, sizeof(int)); }
@@ -825,6 +827,11 @@ static int find_best_match(const bbo_ctx* c, tcounters* tc, const uint8_t* bases
         int max = 0;                                                                      /* condenseLoose :2531-2544 */
         for (int i = 0; i < nids; i++) { const int cnt = tc->countArray[tc->idList[i]]; if (cnt > max) max = cnt; }
         for (int i = 0; i < nids; i++) if (tc->countArray[tc->idList[i]] == max) { id = tc->idList[i]; break; }
+        if (tc->mN) {                                                                     /* idList / countList as rename() walks them */
+            const int64_t rd = tc->mRead + pairnum;
+            tc->mN[rd] = nids;
+            for (int i = 0; i < nids && i < tc->mCap; i++) { tc->mIds[rd * tc->mCap + i] = tc->idList[i]; tc->mCnt[rd * tc->mCap + i] = tc->countArray[tc->idList[i]]; }
+        }
         for (int i = 0; i < nids; i++) tc->countArray[tc->idList[i]] = 0;
         tc->scafReads[id]++; tc->scafBases[id] += blen;
     }
@@ -1219,6 +1226,7 @@ typedef struct {
     const bbo_ctx* c; const uint8_t* bases; const int64_t* offsets; int64_t n; int paired;
     int32_t* out_a; int32_t* out_id; uint8_t* out_flags; uint32_t* out_mask; int32_t* out_left; int32_t* out_right; int64_t u0, u1; tcounters tc;
 } job;
+typedef struct { int32_t* n; int32_t* ids; int32_t* counts; int cap; } match_out;
 
 static void* job_run(void* p) {
     job* j = (job*)p;
@@ -1228,6 +1236,7 @@ static void* job_run(void* p) {
         const uint8_t* b1 = j->bases + j->offsets[r]; int l1 = (int)(j->offsets[r + 1] - j->offsets[r]);
         const uint8_t* b2 = NULL; int l2 = 0;
         if (j->paired) { b2 = j->bases + j->offsets[r + 1]; l2 = (int)(j->offsets[r + 2] - j->offsets[r + 1]); }
+        j->tc.mRead = r;
         process_pair(j->c, &j->tc, b1, l1, b2, l2, j->paired, j->out_a + r, j->out_id + r, j->out_flags + r, j->out_mask,
                      j->offsets[r], j->paired ? j->offsets[r + 1] : 0, j->out_left ? j->out_left + r : NULL, j->out_right ? j->out_right + r : NULL);
     }
@@ -1243,17 +1252,27 @@ int bbo_process_batch_mask(bbo_ctx* c, const uint8_t* bases, const int64_t* offs
     return bbo_process_batch_ex(c, bases, offsets, n, paired, out_a, out_id, out_flags, out_mask, NULL, nthreads);
 }
 static int process_batch_all(bbo_ctx* c, const uint8_t* bases, const int64_t* offsets, int64_t n, int paired,
-                             int32_t* out_a, int32_t* out_id, uint8_t* out_flags, uint32_t* out_mask, int32_t* out_left, int32_t* out_right, int nthreads);
+                             int32_t* out_a, int32_t* out_id, uint8_t* out_flags, uint32_t* out_mask, int32_t* out_left, int32_t* out_right, int nthreads,
+                             const match_out* mo);
 int bbo_process_batch_ex(bbo_ctx* c, const uint8_t* bases, const int64_t* offsets, int64_t n, int paired,
                          int32_t* out_a, int32_t* out_id, uint8_t* out_flags, uint32_t* out_mask, int32_t* out_left, int nthreads) {
-    return process_batch_all(c, bases, offsets, n, paired, out_a, out_id, out_flags, out_mask, out_left, NULL, nthreads);
+    return process_batch_all(c, bases, offsets, n, paired, out_a, out_id, out_flags, out_mask, out_left, NULL, nthreads, NULL);
+}
+int bbo_process_batch_matches(bbo_ctx* c, const uint8_t* bases, const int64_t* offsets, int64_t n, int paired,
+                              int32_t* out_a, int32_t* out_id, uint8_t* out_flags, int max_ids, int32_t* out_nids,
+                              int32_t* out_match_ids, int32_t* out_match_counts, int nthreads) {
+    const match_out mo = { out_nids, out_match_ids, out_match_counts, max_ids };
+    if (!c->a.findBestMatch || max_ids < 1) return -1;
+    for (int64_t i = 0; i < n; i++) out_nids[i] = 0;
+    return process_batch_all(c, bases, offsets, n, paired, out_a, out_id, out_flags, NULL, NULL, NULL, nthreads, &mo);
 }
 int bbo_process_batch_split(bbo_ctx* c, const uint8_t* bases, const int64_t* offsets, int64_t n,
                             int32_t* out_a, int32_t* out_id, uint8_t* out_flags, int32_t* out_leftmost, int32_t* out_rightmost, int nthreads) {
-    return process_batch_all(c, bases, offsets, n, 0, out_a, out_id, out_flags, NULL, out_leftmost, out_rightmost, nthreads);
+    return process_batch_all(c, bases, offsets, n, 0, out_a, out_id, out_flags, NULL, out_leftmost, out_rightmost, nthreads, NULL);
 }
 static int process_batch_all(bbo_ctx* c, const uint8_t* bases, const int64_t* offsets, int64_t n, int paired,
-                             int32_t* out_a, int32_t* out_id, uint8_t* out_flags, uint32_t* out_mask, int32_t* out_left, int32_t* out_right, int nthreads) {
+                             int32_t* out_a, int32_t* out_id, uint8_t* out_flags, uint32_t* out_mask, int32_t* out_left, int32_t* out_right, int nthreads,
+                             const match_out* mo) {
     if (paired && (n & 1)) return -1;
     if (nthreads < 1) nthreads = 1;
     const int64_t units = paired ? n / 2 : n;
@@ -1266,6 +1285,7 @@ static int process_batch_all(bbo_ctx* c, const uint8_t* bases, const int64_t* of
         j->c = c; j->bases = bases; j->offsets = offsets; j->n = n; j->paired = paired;
         j->out_a = out_a; j->out_id = out_id; j->out_flags = out_flags; j->out_mask = out_mask; j->out_left = out_left; j->out_right = out_right;
         j->u0 = units * t / nthreads; j->u1 = units * (t + 1) / nthreads;
+        if (mo) { j->tc.mN = mo->n; j->tc.mIds = mo->ids; j->tc.mCnt = mo->counts; j->tc.mCap = mo->cap; }
         j->tc.scafReads = (int64_t*)calloc((size_t)ns, sizeof(int64_t));             /* thread-local copies (:272-277) */
         j->tc.scafBases = (int64_t*)calloc((size_t)ns, sizeof(int64_t));
         if (nthreads > 1) pthread_create(&th[t], NULL, job_run, j); else job_run(j);

@@ -126,6 +126,11 @@ int      bbo_process_batch_ex(bbo_ctx* c, const uint8_t* bases, const int64_t* o
                               int32_t* out_a, int32_t* out_id, uint8_t* out_flags, uint32_t* out_mask, int32_t* out_left, int nthreads);
 int      bbo_process_batch(bbo_ctx* c, const uint8_t* bases, const int64_t* offsets, int64_t n, int paired,
                            int32_t* out_a, int32_t* out_id, uint8_t* out_flags, int nthreads);
+/* findBestMatch with the lists rename() prints (:1702, 2508-2522): out_nids[i] = idList.size when read i matched, else 0;
+ * out_match_ids / out_match_counts [i*max_ids + j], j < min(out_nids[i], max_ids) = idList / countList in first-hit order. */
+int      bbo_process_batch_matches(bbo_ctx* c, const uint8_t* bases, const int64_t* offsets, int64_t n, int paired,
+                                   int32_t* out_a, int32_t* out_id, uint8_t* out_flags, int max_ids, int32_t* out_nids,
+                                   int32_t* out_match_ids, int32_t* out_match_counts, int nthreads);
 /* ksplit (unpaired): out_a = bases removed, out_leftmost/out_rightmost = the span ksplit() computed (-1,-1: nothing found);
  * BBO_FLAG_REMOVED <=> the read was split in two (both pieces go to outm). */
 int      bbo_process_batch_split(bbo_ctx* c, const uint8_t* bases, const int64_t* offsets, int64_t n,

@@ -63,6 +63,8 @@ def lib():
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.bbo_process_batch_split.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.bbo_process_batch_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.bbo_process_batch_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.bbo_process_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
@@ -218,6 +220,19 @@ class Oracle:
         if rc != 0:
             raise ValueError("bbo_process_batch_split rc=%d" % rc)
         return a, ids, fl, lm, rm
+
+    def process_batch_matches(self, bases: np.ndarray, offsets: np.ndarray, paired: bool, max_ids: int, nthreads: int = 1):
+        """findBestMatch + rename's lists: (found, ids, flags, nids, match_ids[n,max_ids], match_counts[n,max_ids]); unused entries 0."""
+        n = len(offsets) - 1
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        a = np.zeros(n, np.int32); ids = np.zeros(n, np.int32); fl = np.zeros(n, np.uint8)
+        nids = np.zeros(n, np.int32); mi = np.zeros((n, max_ids), np.int32); mc = np.zeros((n, max_ids), np.int32)
+        rc = lib().bbo_process_batch_matches(self.h, bases.ctypes.data, offsets.ctypes.data, n, int(paired), a.ctypes.data, ids.ctypes.data,
+                                             fl.ctypes.data, max_ids, nids.ctypes.data, mi.ctypes.data, mc.ctypes.data, nthreads)
+        if rc != 0:
+            raise ValueError("bbo_process_batch_matches rc=%d" % rc)
+        return a, ids, fl, nids, mi, mc
 
     def counters(self) -> np.ndarray:
         out = np.zeros(lib().bbo_counters_len(self.h), np.int64)

@@ -534,6 +534,7 @@ class Spec:
         per-thread countArray dirty, which makes later answers depend on the thread's history."""
         a, k, n = self.a, self.k, len(read)
         assert maxBad == 0
+        self.last_matches = []
         if n < k or not self.table:
             return 0, -1
         if (a.skipR1 and pairnum == 0) or (a.skipR2 and pairnum == 1):
@@ -546,6 +547,7 @@ class Spec:
             return 0, -1
         best = max(counts.values())
         vid = next(i for i, c in counts.items() if c == best)
+        self.last_matches = list(counts.items())               # idList / countList as rename() prints them (:2508-2522)
         self.scafReads[vid] += 1
         self.scafBases[vid] += n
         return sum(counts.values()), vid

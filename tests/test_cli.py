@@ -172,3 +172,37 @@ def test_cli_stats_and_rpkm_files(tmp_path, ingest):
         want = open(os.path.join(GOLD, stem)).read().replace("IN1", f1).replace("IN2", f2)
         assert open(st).read() == want
         assert open(rp).read() == open(os.path.join(GOLD, "cli_c2_rpkm.txt")).read().replace("IN1", f1).replace("IN2", f2)
+
+
+@pytest.mark.gpu
+def test_cli_rename_appends_scaffolds_and_hit_counts(tmp_path):
+    """rename=t (implies findbestmatch, BBDukParser.java:153): a matched read's header gets "\\tscaffold=hits" for every
+    scaffold it hit, in first-hit order (BBDukProcessorS.java:2508-2522).  Expected headers come from oracle/spec.py."""
+    from oracle.spec import Spec, Args
+    from tests import util
+    names = [None]
+    for line in open(util.ADAPTERS, "rb"):
+        if line.startswith(b">"):
+            names.append(line[1:].rstrip(b"\r\n").decode())
+    s = Spec(Args(k=23, findBestMatch=True)); s.load_fasta(util.ADAPTERS)
+    f1, f2 = os.path.join(GOLD, "cli_c2_r1.fq"), os.path.join(GOLD, "cli_c2_r2.fq")
+    l1, l2 = open(f1).read().splitlines(), open(f2).read().splitlines()
+    expect_m, expect_u, renamed = [], [], 0
+    for i in range(0, len(l1), 4):
+        pair = []
+        for pairnum, l in ((0, l1), (1, l2)):
+            found, vid = s.find_best_match(l[i + 1].encode(), pairnum, 0)
+            hdr = l[i] + "".join("\t%s=%d" % (names[sid], c) for sid, c in (s.last_matches if found > 0 else []))
+            renamed += found > 0
+            pair.append((vid > 0, "\n".join([hdr, l[i + 1], "+", l[i + 3]]) + "\n"))
+        (expect_m if (pair[0][0] or pair[1][0]) else expect_u).extend(p[1] for p in pair)     # rieb=t: either mate removes the pair
+    out, outm = str(tmp_path / "clean.fq"), str(tmp_path / "matched.fq")
+    r = run_cli(["in=" + f1, "in2=" + f2, "out=" + out, "outm=" + outm, "k=23", "rename=t", "ref=adapters", "batch=7"])
+    assert r.returncode == 0, r.stderr
+    assert renamed > 5 and any(h.count("\t") >= 2 for h in expect_m)                         # some reads hit several adapters
+    assert open(outm).read() == "".join(expect_m)
+    assert open(out).read() == "".join(expect_u)
+    r = run_cli(["in=" + f1, "k=23", "rename=t", "mcf=0.5", "ref=adapters"])
+    assert r.returncode == 1 and "rename" in r.stderr
+    r = run_cli(["in=" + f1, "k=23", "rename=t", "ref=adapters", "deviceingest=t"])
+    assert r.returncode == 1 and "rename" in r.stderr

@@ -35,6 +35,16 @@ def check_batch(d, o, reads, paired, nthreads=4):
     bad = np.nonzero((ga != oa) | (gi != oi) | (gf != of))[0]
     assert len(bad) == 0, [(int(i), reads[i], (int(ga[i]), int(gi[i]), int(gf[i])), (int(oa[i]), int(oi[i]), int(of[i]))) for i in bad[:3]]
     assert np.array_equal(d.gpu.counters(), o.counters())
+    if d.gpu.params.mode == B.MODE_KFILTER and d.gpu.params.findBestMatch:
+        # the per-read match lists rename=t prints (bbduk_kfilter_batch_matches), whole and truncated to three entries
+        for cap in (64, 3):
+            d.gpu.reset_counters(); o.reset_counters()
+            ma, mi_, mf, nids, mids, mcnt = d.gpu.kfilter_batch_matches(b, off, paired, cap)
+            oa2, oi2, of2, onids, omids, omcnt = o.process_batch_matches(b, off, paired, cap, nthreads=nthreads)
+            assert np.array_equal(ma, oa) and np.array_equal(mi_, oi) and np.array_equal(mf, of)
+            bad = np.nonzero((nids != onids) | (mids != omids).any(axis=1) | (mcnt != omcnt).any(axis=1))[0]
+            assert len(bad) == 0, ("matches", cap, [(int(i), reads[i], int(nids[i]), mids[i].tolist(), mcnt[i].tolist(), int(onids[i]), omids[i].tolist(), omcnt[i].tolist()) for i in bad[:2]])
+            assert np.array_equal(d.gpu.counters(), o.counters())
     if d.gpu.params.mode in (B.MODE_KTRIM_R, B.MODE_KTRIM_L, B.MODE_KFILTER):
         # the packed boundary format (2-bit codes + undefined bits) must give the same answers as the ASCII one
         codes, undef = B.pack_bases_host(b)

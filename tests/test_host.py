@@ -86,8 +86,9 @@ def test_parser_errors_like_the_reference():
         B.HostIndex("k=40 fbm=t")                         # :299
     with pytest.raises(B.BBDukError):
         B.HostIndex("k=25 fbm=t mbk=2")                   # thread-history dependent in the reference: refused
-    with pytest.raises(B.BBDukError):
-        B.HostIndex("k=25 rename=t")
+    assert B.HostIndex("k=25 rename=t").params().findBestMatch == 1        # rename implies findbestmatch (:153)
+    with pytest.raises(B.BBDukError, match="rename"):
+        B.HostIndex("k=25 rename=t mcf=0.5")                              # :1049-1052 re-runs findBestMatch on covered reads: refused
     p = B.HostIndex("k=25 fbm").params()
     assert (p.findBestMatch, p.mode) == (1, B.MODE_KFILTER)
     assert B.HostIndex("k=25 fbm ktrim=r").params().findBestMatch == 0     # only the filtering branch consults it (:1072)

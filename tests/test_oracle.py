@@ -225,6 +225,17 @@ def test_differential_fuzz_kbig_findbestmatch(ci):
             assert list(zip(a.tolist(), ids.tolist(), fl.tolist())) == s.process_batch(reads, paired)
             assert o.counters().tolist() == s.all_counters()
             hits += int((ids > 0).sum())
+            if kw.get("findBestMatch"):                          # the lists rename=t prints (:1702, 2508-2522), whole and truncated
+                for cap in (64, 2):
+                    o.reset_counters()
+                    a2, ids2, fl2, nids, mi, mc = o.process_batch_matches(b, off, paired, cap, nthreads=3)
+                    assert np.array_equal(a2, a) and np.array_equal(ids2, ids) and np.array_equal(fl2, fl)
+                    for i, r in enumerate(reads):
+                        found, _ = s.find_best_match(r, (i & 1) if paired else 0, 0)
+                        want = s.last_matches if found > 0 else []
+                        assert nids[i] == len(want), (i, r)
+                        assert [(int(mi[i, j]), int(mc[i, j])) for j in range(min(cap, len(want)))] == want[:cap]
+                        assert not mi[i, len(want):].any() and not mc[i, len(want):].any()
     assert hits > 20
 
 
