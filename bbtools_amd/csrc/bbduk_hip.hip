@@ -3138,7 +3138,7 @@ extern "C" int bbduk_create(const bbduk_params* p, bbduk_handle** out) {
         if (p->k != 31 || p->kbig > BBDUK_MAX_READ_LEN) return BBDUK_ERR_ARG;
         if (p->mode != BBDUK_MODE_KFILTER || p->speed > 0 || p->qSkip > 1) return BBDUK_ERR_ARG;    // the parser reduces kbig to k there
         if (p->middleMask != -1 || p->minlen2 != p->k) return BBDUK_ERR_ARG;    // maskMiddle is disabled before minlen2 is derived
-        if (p->findBestMatch || p->minCoveredFraction > 0.f) return BBDUK_ERR_ARG;
+        if (p->findBestMatch) return BBDUK_ERR_ARG;                             // mcf: countCoveredBases never looks at kbig (:1038-1049, 1602-1651)
     }
     if (p->findBestMatch) {
         if (p->mode != BBDUK_MODE_KFILTER || p->minCoveredFraction > 0.f) return BBDUK_ERR_ARG;
@@ -3418,7 +3418,8 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     if (!d_offsets || !d_a || !d_id || !d_fl || !d_counters) return fail(h, BBDUK_ERR_ARG, "null buffer");
     if (!packed && ((uintptr_t)d_bases & 15) != 0) return fail(h, BBDUK_ERR_ARG, "d_bases must be 16-byte aligned");
     if (packed && (!d_undef || ((uintptr_t)d_bases & 3) != 0)) return fail(h, BBDUK_ERR_ARG, "packed input needs both planes, 4-byte aligned");
-    if (h->p.kbig > h->p.k || h->p.findBestMatch)                               // countSetKmersBig / findBestMatch behind the kfilter operators
+    if ((h->p.kbig > h->p.k && !(h->p.minCoveredFraction > 0.f)) || h->p.findBestMatch)   // countSetKmersBig / findBestMatch behind the kfilter operators;
+                                                                                // with mcf the reference runs countCoveredBases on the 31-mers instead (:1038)
         return launch_kscan(h, d_bases, d_offsets, n, total_bases, paired, d_a, d_id, d_fl, nullptr, nullptr, d_counters, st, d_undef, packed, mo);
     KParams K = make_kparams(h);
     K.undef = packed ? d_undef : nullptr;

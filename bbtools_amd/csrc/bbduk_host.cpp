@@ -111,7 +111,6 @@ int derive(Parsed& p, std::string& err) {            // bbduk/BBDukParser.java:1
         err = "findbestmatch with maxbadkmers>0 or minkmerfraction>0 is not supported by this path (the reference's answer depends on thread history there)";
         return BBDUK_ERR_ARG;
     }
-    if (p.kbig > p.k && p.minCoveredFraction > 0.f) { err = "mincoveredfraction with k>31 is not supported by this path"; return BBDUK_ERR_ARG; }
     if (p.ksplit && p.trimPad > 0) { err = "ksplit with a positive trimpad is not supported by this path"; return BBDUK_ERR_ARG; }
     if (p.useShortKmers && !(p.ktrimLeft || p.ktrimRight || p.ktrimN || p.ksplit)) { err = "Setting mink also requires setting a ktrim mode, such as 'r' or 'l'"; return BBDUK_ERR_ARG; }
     // ktrim=rl (tips): both flags stay set, the device runs the two passes (BBDUK_MODE_KTRIM_TIPS)

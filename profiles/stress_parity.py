@@ -85,9 +85,9 @@ def main():
             if okw.get("trimPad", 0) > 0:
                 okw["trimPad"] = -okw["trimPad"]; toks = [("tp=%d" % okw["trimPad"]) if t.startswith("tp=") else t for t in toks]
         elif fam in ("big", "fbm"):
-            for kk in ("mink", "hdist2", "trimPad", "ktrimExclusive", "minCoveredFraction", "qSkip", "speed"):
-                okw.pop(kk, None)
-            toks = [t for t in toks if not t.startswith(("mink=", "hdist2=", "tp=", "ktrimexclusive", "mcf=", "qskip=", "speed="))]
+            for kk in ("mink", "hdist2", "trimPad", "ktrimExclusive", "qSkip", "speed") + (("minCoveredFraction",) if fam == "fbm" else ()):
+                okw.pop(kk, None)                                # k>31 keeps mcf: countCoveredBases then runs on the 31-mers
+            toks = [t for t in toks if not t.startswith(("mink=", "hdist2=", "tp=", "ktrimexclusive", "qskip=", "speed=") + (("mcf=",) if fam == "fbm" else ()))]
             if fam == "big":
                 kb = rng.randint(32, 60); okw["k"] = 31; okw["kbig"] = kb
                 okw.pop("maskMiddle", None); okw.pop("qhdist", None)

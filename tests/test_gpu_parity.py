@@ -579,7 +579,8 @@ def test_device_built_adapter_and_phix_tables():
 BIG = [("k=40", dict(k=31, kbig=40)), ("k=32 hdist=1", dict(k=31, kbig=32, hdist=1)), ("k=50 mbk=3 rieb=f", dict(k=31, kbig=50, maxBadKmers0=3, requireBothBad=1)),
        ("k=45 forbidn=t restrictleft=120", dict(k=31, kbig=45, forbidN=1, restrictLeft=120)), ("k=36 mkf=0.2 qhdist=1", dict(k=31, kbig=36, minKmerFraction=0.2, qhdist=1)),
        ("k=25 fbm", dict(k=25, findBestMatch=1)), ("k=13 findbestmatch=t hdist=1 mm=f rieb=f", dict(k=13, findBestMatch=1, hdist=1, maskMiddle=0, requireBothBad=1)),
-       ("k=19 fbm=t skipr1=t restrictright=90", dict(k=19, findBestMatch=1, skipR1=1, restrictRight=90))]
+       ("k=19 fbm=t skipr1=t restrictright=90", dict(k=19, findBestMatch=1, skipR1=1, restrictRight=90)),
+       ("k=40 mcf=0.3", dict(k=31, kbig=40, minCoveredFraction=0.3))]
 SPLIT = [("k=23 ksplit=t", dict(k=23, ksplit=1)), ("k=15 ksplit mink=7 hdist=1", dict(k=15, ksplit=1, mink=7, hdist=1)),
          ("k=13 ksplit=t tp=-2 forbidn=t", dict(k=13, ksplit=1, trimPad=-2, forbidN=1)), ("k=17 ksplit mink=9 restrictleft=100 qhdist=1", dict(k=17, ksplit=1, mink=9, restrictLeft=100, qhdist=1)),
          ("k=11 ksplit mink=5 restrictright=60 rcomp=f", dict(k=11, ksplit=1, mink=5, restrictRight=60, rcomp=0))]

@@ -201,7 +201,8 @@ def test_differential_fuzz_kmask(ci):
 # kbig (k>31 emulated by runs of 31-mers), findBestMatch, ksplit: longer references so that runs and several scaffolds occur
 BIG_FUZZ = [dict(k=31, kbig=40), dict(k=31, kbig=32, hdist=1), dict(k=31, kbig=50, maxBadKmers0=3, requireBothBad=1), dict(k=31, kbig=45, forbidN=1, restrictLeft=120),
             dict(k=31, kbig=36, minKmerFraction=0.2, qhdist=1), dict(k=25, findBestMatch=1), dict(k=13, findBestMatch=1, hdist=1, maskMiddle=0, requireBothBad=1),
-            dict(k=19, findBestMatch=1, skipR1=1, restrictRight=90)]
+            dict(k=19, findBestMatch=1, skipR1=1, restrictRight=90),
+            dict(k=31, kbig=40, minCoveredFraction=0.3)]       # mcf wins over the run counting: countCoveredBases on the 31-mers (:1038)
 SPLIT_FUZZ = [dict(k=23, ksplit=1), dict(k=15, ksplit=1, mink=7, hdist=1), dict(k=13, ksplit=1, trimPad=-2, forbidN=1),
               dict(k=17, ksplit=1, mink=9, restrictLeft=100, qhdist=1), dict(k=11, ksplit=1, mink=5, restrictRight=60, rcomp=0)]
 
