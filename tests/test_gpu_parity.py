@@ -957,9 +957,22 @@ def test_abi_error_codes():
     assert call(L.bbduk_ktrim_batch, b3, off3, 3, 1) == -1                       # an odd number of reads cannot be pairs
     shifted = off + 1
     assert call(L.bbduk_ktrim_batch, b, shifted, 2, 0) == -1                     # offsets[0] != 0
+    nid = np.zeros(2, np.int32); mi = np.zeros((2, 4), np.int32); mc = np.zeros((2, 4), np.int32)
+    assert L.bbduk_kfilter_batch_matches(g.h, b.ctypes.data, off.ctypes.data, 2, 0, a.ctypes.data, ids.ctypes.data, fl.ctypes.data, 4,
+                                         nid.ctypes.data, mi.ctypes.data, mc.ctypes.data) == -2     # match lists need a findBestMatch handle
     assert L.bbduk_get_counters(g.h, None, 0) == -1
     assert L.bbduk_upload_pairs(g.h, None, None, 0) == -2                        # the map is final
     assert call(L.bbduk_ktrim_batch, b, off, 0, 0) == 0                          # an empty batch is fine
     assert call(L.bbduk_ktrim_batch, b, off, 2, 0) == 0 and a[0] == len(reads[0]) - 12 and a[1] == 0     # and the handle still works
     g.close(); g.close()                                                          # closing twice is harmless
     host.close()
+    d = B.BBDuk("k=23 rename=t", refs=[b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCAC"])
+    for cap in (0, 65):                                                           # max_ids outside 1..64
+        assert L.bbduk_kfilter_batch_matches(d.gpu.h, b.ctypes.data, off.ctypes.data, 2, 0, a.ctypes.data, ids.ctypes.data, fl.ctypes.data, cap,
+                                             nid.ctypes.data, mi.ctypes.data, mc.ctypes.data) == -1
+    assert L.bbduk_kfilter_batch_matches(d.gpu.h, b.ctypes.data, off.ctypes.data, 2, 0, a.ctypes.data, ids.ctypes.data, fl.ctypes.data, 4,
+                                         None, mi.ctypes.data, mc.ctypes.data) == -1
+    assert L.bbduk_kfilter_batch_matches(d.gpu.h, b.ctypes.data, off.ctypes.data, 2, 0, a.ctypes.data, ids.ctypes.data, fl.ctypes.data, 4,
+                                         nid.ctypes.data, mi.ctypes.data, mc.ctypes.data) == 0
+    assert nid.tolist() == [1, 0] and mi[0, 0] == 1 and mc[0, 0] == 34 - 23 + 1 and ids[0] == 1
+    d.close()
