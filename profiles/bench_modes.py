@@ -17,11 +17,13 @@ def main():
     B.synth_generate_device(B.synth_params(2), 0, n // 2, d_bases, d_off, 0)
     L = B.lib()
     for args, mode in (("ktrim=n k=23 mink=11 hdist=1 ref=adapters", "kmask"), ("ktrim=rl k=23 mink=11 hdist=1 ref=adapters", "tips"),
-                       ("ksplit=t k=23 mink=11 hdist=1 ref=adapters", "ksplit")):
+                       ("ksplit=t k=23 mink=11 hdist=1 ref=adapters", "ksplit"),
+                       ("k=23 hdist=1 fbm ref=adapters", "fbm"), ("k=23 hdist=1 rename=t ref=adapters", "fbm+matches")):
         duk = B.BBDuk(args)
         d_a = torch.empty(n, dtype=torch.int32, device="cuda"); d_b = torch.empty(n, dtype=torch.int32, device="cuda"); d_c2 = torch.empty(n, dtype=torch.int32, device="cuda")
         d_i = torch.empty(n, dtype=torch.int32, device="cuda"); d_f = torch.empty(n, dtype=torch.uint8, device="cuda")
         d_m = torch.zeros(n * 150 // 32 + 8, dtype=torch.int32, device="cuda")
+        d_mi = torch.zeros(n * 8 if mode == "fbm+matches" else 1, dtype=torch.int32, device="cuda"); d_mc = torch.zeros_like(d_mi)
         d_ctr = torch.zeros(duk.gpu.counters_len, dtype=torch.int64, device="cuda")
         h = duk.gpu.h
         ts = []
@@ -31,13 +33,18 @@ def main():
                 rc = L.bbduk_kmask_batch_device(h, d_bases.data_ptr(), d_off.data_ptr(), n, n * 150, 1, d_a.data_ptr(), d_i.data_ptr(), d_f.data_ptr(), d_m.data_ptr(), d_ctr.data_ptr(), None)
             elif mode == "tips":
                 rc = L.bbduk_ktrimtips_batch_device(h, d_bases.data_ptr(), d_off.data_ptr(), n, n * 150, 1, d_a.data_ptr(), d_b.data_ptr(), d_i.data_ptr(), d_f.data_ptr(), d_ctr.data_ptr(), None)
+            elif mode == "fbm":
+                rc = L.bbduk_kfilter_batch_device(h, d_bases.data_ptr(), d_off.data_ptr(), n, n * 150, 1, d_a.data_ptr(), d_i.data_ptr(), d_f.data_ptr(), d_ctr.data_ptr(), None)
+            elif mode == "fbm+matches":                       # the lists rename=t prints, eight entries per read
+                rc = L.bbduk_kfilter_batch_matches_device(h, d_bases.data_ptr(), d_off.data_ptr(), n, n * 150, 1, d_a.data_ptr(), d_i.data_ptr(), d_f.data_ptr(),
+                                                          8, d_b.data_ptr(), d_mi.data_ptr(), d_mc.data_ptr(), d_ctr.data_ptr(), None)
             else:
                 rc = L.bbduk_ksplit_batch_device(h, d_bases.data_ptr(), d_off.data_ptr(), n, n * 150, d_a.data_ptr(), d_b.data_ptr(), d_c2.data_ptr(), d_i.data_ptr(), d_f.data_ptr(), d_ctr.data_ptr(), None)
             e1.record(); torch.cuda.synchronize()
             assert rc == 0, rc
             ts.append(e0.elapsed_time(e1))
         ms = min(ts[1:]); c = d_ctr.cpu().numpy()
-        print(json.dumps({"mode": mode, "args": args, "reads": n, "operator_ms": round(ms, 2), "Gbases_per_s": round(n * 150 / ms / 1e6, 1), "readsKTrimmed": int(c[2]), "status": int(c[15])}))
+        print(json.dumps({"mode": mode, "args": args, "reads": n, "operator_ms": round(ms, 2), "Gbases_per_s": round(n * 150 / ms / 1e6, 1), "readsKTrimmed": int(c[2]), "readsKFiltered": int(c[4]), "status": int(c[15])}))
         duk.close()
 
 
