@@ -4,8 +4,9 @@ import shutil
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SRC = [os.path.join(_HERE, "csrc", "bbduk_hip.hip"), os.path.join(_HERE, "csrc", "bbduk_ingest.hip"), os.path.join(_HERE, "csrc", "bbduk_host.cpp")]
-_DEPS = _SRC + [os.path.join(_HERE, "csrc", "synth.h"),
+_SRC = [os.path.join(_HERE, "csrc", "bbduk_hip.hip"), os.path.join(_HERE, "csrc", "bbduk_ingest.hip"),
+        os.path.join(_HERE, "csrc", "bbduk_comm.hip"), os.path.join(_HERE, "csrc", "bbduk_host.cpp")]
+_DEPS = _SRC + [os.path.join(_HERE, "csrc", "synth.h"), os.path.join(_HERE, "csrc", "bbduk_internal.h"),
                 os.path.join(_HERE, "..", "include", "bbduk_gpu.h"), os.path.join(_HERE, "..", "include", "bbduk_host.h")]
 _SO = os.path.join(_HERE, "libbbduk_hip.so")
 _CLI_SRC = os.path.join(_HERE, "csrc", "bbduk_cli.cpp")
@@ -30,12 +31,31 @@ def stale() -> bool:
     return any(os.path.getmtime(d) > t for d in _DEPS)
 
 
-def _compile(out: str, extra=(), verbose: bool = False) -> str:
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-value", "-Wno-unused-result", *extra, *_SRC, "-o", out]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+def _obj_dir(tag: str) -> str:
+    d = os.path.join(_HERE, "build", tag)
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def _compile(out: str, extra=(), verbose: bool = False, tag: str = "product") -> str:
+    """One object per translation unit (rebuilt only when it or a header changed, all stale ones in parallel), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+    hdrs = [d for d in _DEPS if d not in _SRC]
+    newest_hdr = max(os.path.getmtime(h) for h in hdrs)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result", *extra]
+    objs, jobs = [], []
+    for src in _SRC:
+        obj = os.path.join(_obj_dir(tag), os.path.basename(src) + ".o")
+        objs.append(obj)
+        if not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_hdr):
+            jobs.append([_hipcc(), *flags, "-x", "hip", "-c", src, "-o", obj])
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    with ThreadPoolExecutor(max_workers=max(1, len(jobs))) as ex:
+        list(ex.map(run, jobs))
+    run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", out])
     return out
 
 
@@ -66,10 +86,10 @@ def build_cli(force: bool = False, verbose: bool = False) -> str:
 def build_timing_variant(verbose: bool = False) -> str:
     """Experiment build with the BBDUK_DBG stage-deletion switches compiled in (profiles/ab.sh loads it through
     BBDUK_LIB_PATH); never the product library."""
-    return _compile(os.path.join(_HERE, "ab_tsw.so"), ["-DBBDUK_TIMING_SWITCHES"], verbose)
+    return _compile(os.path.join(_HERE, "ab_tsw.so"), ["-DBBDUK_TIMING_SWITCHES"], verbose, tag="tsw")
 
 
 def build_variant(name: str, flags, verbose: bool = False) -> str:
     """Experiment build of the same sources with extra compiler flags (e.g. -DBBDUK_AB_ASCII_ONLY) as bbtools_amd/<name>.so,
     for same-box A/B runs through BBDUK_LIB_PATH; never the product library."""
-    return _compile(os.path.join(_HERE, name + ".so"), list(flags), verbose)
+    return _compile(os.path.join(_HERE, name + ".so"), list(flags), verbose, tag=name)

@@ -18,6 +18,7 @@ OK = 0
 MODE_KFILTER, MODE_KTRIM_R, MODE_KTRIM_L, MODE_KMASK, MODE_KTRIM_TIPS, MODE_KSPLIT = 0, 1, 2, 3, 4, 5
 FLAG_DISCARDED, FLAG_REMOVED = 1, 2
 NCOUNTERS = 16
+HOOK_FORCE_TILE, HOOK_BUCKET_BITS, HOOK_LDS_BITS, HOOK_TIMING_MASK, HOOK_BIG_LAYOUT = 1, 2, 3, 4, 5      # include/bbduk_test_hooks.h
 COUNTER_NAMES = ["readsIn", "basesIn", "readsKTrimmed", "basesKTrimmed", "readsKFiltered", "basesKFiltered",
                  "readsOutu", "basesOutu", "readsOutm", "basesOutm"]
 DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "data")
@@ -54,12 +55,25 @@ GPU_SYMBOLS = ["bbduk_abi_version", "bbduk_create", "bbduk_destroy", "bbduk_last
                "bbduk_kfilter_batch_device", "bbduk_pack_bases_host", "bbduk_pack_bases_device", "bbduk_ktrim_batch_packed",
                "bbduk_kfilter_batch_packed", "bbduk_ktrim_batch_packed_device", "bbduk_kfilter_batch_packed_device", "bbduk_kmask_batch", "bbduk_kmask_batch_device", "bbduk_ktrimtips_batch", "bbduk_ktrimtips_batch_device", "bbduk_ksplit_batch", "bbduk_kfilter_batch_matches", "bbduk_kfilter_batch_matches_device", "bbduk_ksplit_batch_device", "bbduk_kmask_batch_packed_device", "bbduk_ktrimtips_batch_packed_device", "bbduk_fastq_ingest_device", "bbduk_fastq_write_device", "bbduk_fastq_write_masked_device", "bbduk_device_malloc", "bbduk_device_free", "bbduk_pinned_malloc", "bbduk_pinned_free",
                "bbduk_copy_to_device", "bbduk_copy_from_device", "bbduk_device_memset", "bbduk_kernel_time_ms", "bbduk_counters_len", "bbduk_get_counters", "bbduk_reset_counters",
-               "bbduk_synth_generate_device", "bbduk_synth_generate_host"]
+               "bbduk_synth_generate_device", "bbduk_synth_generate_host",
+               "bbduk_comm_unique_id", "bbduk_comm_create", "bbduk_comm_create_local", "bbduk_comm_destroy", "bbduk_comm_size",
+               "bbduk_allreduce_counters", "bbduk_allreduce_counters_device", "bbduk_allreduce_counters_local",
+               "bbduk_test_hook"]
 HOST_SYMBOLS = ["bbduk_host_parse", "bbduk_host_destroy", "bbduk_host_add_ref", "bbduk_host_load_fasta",
                 "bbduk_host_load_refs", "bbduk_host_build_index", "bbduk_host_index_pairs",
                 "bbduk_host_num_scaffolds", "bbduk_host_scaffold_info", "bbduk_host_params", "bbduk_host_upload_index", "bbduk_host_build_on_device"]
 
 _lib = None
+_lib_override = None
+
+
+def use_library(path):
+    """Experiments only (profiles/ab_*.py): bind to another build of the same sources, e.g. bbtools_amd/ab_tsw.so.  Must be
+    called before the first lib(); the product path never calls it."""
+    global _lib_override
+    if _lib is not None:
+        raise BBDukError("library already loaded")
+    _lib_override = path
 
 
 class FastqResult(C.Structure):
@@ -131,7 +145,7 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    path = os.environ.get("BBDUK_LIB_PATH") or lib_path()      # override: A/B timing of two builds in one process launch
+    path = _lib_override or lib_path()
     if not os.path.exists(path):
         raise BBDukError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                          "(there is no CPU fallback for this path)" % path)
@@ -197,6 +211,15 @@ def lib():
     L.bbduk_host_upload_index.argtypes = [vp, vp]
     L.bbduk_host_build_on_device.argtypes = [vp, vp]
     L.bbduk_build_table_device.argtypes = [vp, vp, vp, i32, i32, i32]
+    L.bbduk_test_hook.argtypes = [vp, i32, i64]
+    L.bbduk_comm_unique_id.argtypes = [vp]
+    L.bbduk_comm_create.argtypes = [vp, i32, i32, vp]
+    L.bbduk_comm_create_local.argtypes = [C.POINTER(vp), i32]
+    L.bbduk_comm_destroy.argtypes = [vp]
+    L.bbduk_comm_size.argtypes = [vp]
+    L.bbduk_allreduce_counters.argtypes = [vp]
+    L.bbduk_allreduce_counters_device.argtypes = [vp, vp, vp]
+    L.bbduk_allreduce_counters_local.argtypes = [C.POINTER(vp), i32]
     _lib = L
     return L
 
@@ -308,6 +331,10 @@ class BBDukGpu:
     def _check(self, rc, what):
         if rc != OK:
             raise BBDukError("%s rc=%d: %s" % (what, rc, lib().bbduk_last_error(self.h).decode()))
+
+    def test_hook(self, which: int, value: int):
+        """include/bbduk_test_hooks.h: tests and experiments only."""
+        self._check(lib().bbduk_test_hook(self.h, which, value), "test_hook")
 
     # ---- table
     def upload_pairs(self, keys: np.ndarray, values: np.ndarray):
@@ -452,11 +479,51 @@ class BBDukGpu:
     def reset_counters(self):
         self._check(lib().bbduk_reset_counters(self.h), "reset_counters")
 
+    # ---- multi-GPU: the counter all-reduce (RCCL) behind the C ABI
+    def comm_create(self, nranks: int, rank: int, unique_id: bytes):
+        """One process per GPU: join the communicator rank 0 opened with comm_unique_id()."""
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(lib().bbduk_comm_create(self.h, nranks, rank, buf), "comm_create")
+
+    def allreduce_counters(self):
+        """Sum of the handle's own counter vector over the communicator (blocking)."""
+        self._check(lib().bbduk_allreduce_counters(self.h), "allreduce_counters")
+
+    def allreduce_counters_device(self, d_counters, stream_ptr=0):
+        self._check(lib().bbduk_allreduce_counters_device(self.h, d_counters.data_ptr(), stream_ptr), "allreduce_counters_device")
+
+    @property
+    def comm_size(self) -> int:
+        return lib().bbduk_comm_size(self.h)
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId through the C ABI: 128 bytes rank 0 hands to every rank."""
+    buf = (C.c_uint8 * 128)()
+    if lib().bbduk_comm_unique_id(buf) != OK:
+        raise BBDukError("bbduk_comm_unique_id failed (librccl not loadable?)")
+    return bytes(buf)
+
+
+def comm_create_local(gpus):
+    """One process, several handles (on one or several devices): form their local group."""
+    arr = (C.c_void_p * len(gpus))(*[g.h for g in gpus])
+    rc = lib().bbduk_comm_create_local(arr, len(gpus))
+    if rc != OK:
+        raise BBDukError("comm_create_local rc=%d: %s" % (rc, lib().bbduk_last_error(gpus[0].h).decode()))
+
+
+def allreduce_counters_local(gpus):
+    arr = (C.c_void_p * len(gpus))(*[g.h for g in gpus])
+    rc = lib().bbduk_allreduce_counters_local(arr, len(gpus))
+    if rc != OK:
+        raise BBDukError("allreduce_counters_local rc=%d: %s" % (rc, lib().bbduk_last_error(gpus[0].h).decode()))
+
 
 class BBDuk:
     """`bbduk.sh <args>` minus the file streaming: parse, load refs, build the index, hold it on the GPU."""
 
-    def __init__(self, args: str, device: int = 0, resource_dir: str = DATA_DIR, refs=None, build: str = "host"):
+    def __init__(self, args: str, device: int = 0, resource_dir: str = DATA_DIR, refs=None, build: str = "host", hooks=None):
         """build="host": the C++ mirror of the Java index build + upload (what a JNI caller does with its own tables);
         build="device": the reference sequences go to the GPU and the map is built there (bbduk_build_table_device)."""
         self.host = HostIndex(args)
@@ -467,11 +534,15 @@ class BBDuk:
             self.host.load_refs(resource_dir)
         if build == "device":
             self.gpu = BBDukGpu(self.host.params(device))
+            for k_, v_ in (hooks or {}).items():
+                self.gpu.test_hook(k_, v_)
             self.gpu._check(lib().bbduk_host_build_on_device(self.host.h, self.gpu.h), "build_on_device")
             self.stored_kmers = self.gpu.table_size
         else:
             self.stored_kmers = self.host.build_index()
             self.gpu = BBDukGpu(self.host.params(device))
+            for k_, v_ in (hooks or {}).items():
+                self.gpu.test_hook(k_, v_)
             rc = lib().bbduk_host_upload_index(self.host.h, self.gpu.h)
             self.gpu._check(rc, "upload_index")
 

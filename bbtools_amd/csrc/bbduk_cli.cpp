@@ -5,7 +5,12 @@
 // TrimRead.trimByAmount to bases+qualities with the returned amounts, route removed pairs, print the counters.
 //
 //   bbduk_cli in=r1.fq [in2=r2.fq | int=t] [out=clean.fq] [outm=removed.fq] [tsv=per_read.tsv] [resources=DIR]
-//             [batch=N] [device=D] [devicebuild=t] [deviceingest=t [chunk=BYTES]] <BBDuk flags: ktrim= k= mink= hdist= ref= literal= ...>
+//             [batch=N] [device=D | devices=0,1,..] [devicebuild=t] [deviceingest=t [chunk=BYTES]] <BBDuk flags: ktrim= k= mink= hdist= ref= literal= ...>
+//
+// devices=0,1,..: one handle per listed device (a device may be listed twice), the map replicated on each; every batch
+// is cut into contiguous blocks of whole pairs, one block per handle, submitted from one host thread per handle; output keeps the
+// input order; at the end ONE counter all-reduce (bbduk_comm_create_local + bbduk_allreduce_counters_local: RCCL) merges the
+// per-device counters, as BBDukProcessorS.add merges the per-thread processors (bbduk/BBDukProcessorS.java:300-342).
 //
 // deviceingest=t (ktrim=r|l, kfilter): the FASTQ text itself goes to the GPU in chunks; record splitting, 2-bit packing,
 // matching and the writing of the trimmed records all happen there (bbduk_fastq_ingest_device, bbduk_*_batch_packed_device,
@@ -22,6 +27,7 @@
 #include <cstring>
 #include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../include/bbduk_gpu.h"
 #include "../../include/bbduk_host.h"
@@ -32,6 +38,7 @@ struct Reader {                      // FASTQ, plain or .gz (through `gzip -dc`,
     FILE* f = nullptr; bool piped = false; char* line = nullptr; size_t cap = 0;
     bool open(const std::string& path) {
         if (path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0) {
+            if (path.find('\'') != std::string::npos) return false;       // the path goes through a shell: no quote can be allowed in it
             const std::string cmd = "gzip -dc '" + path + "'";
             f = popen(cmd.c_str(), "r"); piped = true;
         } else f = fopen(path.c_str(), "r");
@@ -55,7 +62,8 @@ struct Reader {                      // FASTQ, plain or .gz (through `gzip -dc`,
         name.erase(0, 1);
         return 0;
     }
-    void close() { if (f) { if (piped) pclose(f); else fclose(f); f = nullptr; } free(line); line = nullptr; }
+    // false: the decompressor failed (truncated or corrupt .gz): what was read so far is not the whole file
+    bool close() { bool ok = true; if (f) { if (piped) ok = pclose(f) == 0; else fclose(f); f = nullptr; } free(line); line = nullptr; return ok; }
 };
 
 struct Rec { std::string name, bases, quals; };
@@ -125,12 +133,14 @@ int write_stats(const StatsOut& so, const bbduk_host* host, const std::vector<in
 struct TextIn {                      // one input file streamed through a pinned buffer; `have` bytes wait at the front
     FILE* f = nullptr; bool piped = false, eof = false; uint8_t* h = nullptr; uint8_t* d = nullptr; int64_t have = 0; int64_t* d_lines = nullptr;
     bool open(const std::string& path) {
-        if (path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0) { f = popen(("gzip -dc '" + path + "'").c_str(), "r"); piped = true; }
-        else f = fopen(path.c_str(), "rb");
+        if (path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0) {
+            if (path.find('\'') != std::string::npos) return false;
+            f = popen(("gzip -dc '" + path + "'").c_str(), "r"); piped = true;
+        } else f = fopen(path.c_str(), "rb");
         return f != nullptr;
     }
     void fill(int64_t cap) { while (!eof && have < cap) { const size_t g = fread(h + have, 1, (size_t)(cap - have), f); if (g == 0) eof = true; have += (int64_t)g; } }
-    void close() { if (f) { if (piped) pclose(f); else fclose(f); f = nullptr; } }
+    bool close() { bool ok = true; if (f) { if (piped) ok = pclose(f) == 0; else fclose(f); f = nullptr; } return ok; }
 };
 
 // The deviceingest=t pipeline.  Returns 0 or an error exit status; prints the same closing lines as the host path.
@@ -227,7 +237,7 @@ int run_device_ingest(bbduk_handle* dev, const bbduk_host* host, const StatsOut&
         const int64_t used[2] = {R.consumed1, R.consumed2};
         for (int s = 0; s < ns; s++) { memmove(T[s].h, T[s].h + used[s], (size_t)(T[s].have - used[s])); T[s].have -= used[s]; }
     }
-    for (int s = 0; s < ns; s++) T[s].close();
+    for (int s = 0; s < ns; s++) if (!T[s].close()) return fail("gzip reported an error (truncated or corrupt input?) on", s ? in2.c_str() : in1.c_str());
     if (fout) fclose(fout);
     if (foutm) fclose(foutm);
     if (ftsv) fclose(ftsv);
@@ -247,7 +257,7 @@ int run_device_ingest(bbduk_handle* dev, const bbduk_host* host, const StatsOut&
 
 int main(int argc, char** argv) {
     std::string in1, in2, out, outm, tsv, resources = "data", flags;
-    bool interleaved = false; long batch = 1000000; int device = 0;
+    bool interleaved = false; long batch = 1000000; int device = 0; std::vector<int> devices;
     bool maskLower = false; char maskSymbol = 'N';
     bool rename = false;                                          // rename=t: matched reads get "\tscaffold=hits" appended (BBDukProcessorS.java:2508-2522)
     StatsOut so;
@@ -266,6 +276,7 @@ int main(int argc, char** argv) {
         else if (a == "resources") resources = b;
         else if (a == "batch") batch = atol(b.c_str());
         else if (a == "device") device = atoi(b.c_str());
+        else if (a == "devices") { devices.clear(); size_t q = 0; while (q <= b.size()) { const size_t c = b.find(',', q); const std::string t = b.substr(q, c == std::string::npos ? std::string::npos : c - q); if (!t.empty()) devices.push_back(atoi(t.c_str())); if (c == std::string::npos) break; q = c + 1; } }
         else if (a == "devicebuild") deviceBuild = parse_bool(b);
         else if (a == "deviceingest") deviceIngest = parse_bool(b);
         else if (a == "chunk") chunk = atoll(b.c_str());
@@ -297,21 +308,31 @@ int main(int argc, char** argv) {
     if (bbduk_host_load_refs(host, resources.c_str()) < 0) return fail("cannot load ref=", resources.c_str());
     int64_t stored = 0;
     if (!deviceBuild) { stored = bbduk_host_build_index(host); if (stored < 0) return fail("index build failed", nullptr); }
+    if (devices.empty()) devices.push_back(device);
+    device = devices[0];
     bbduk_params P;
     if (bbduk_host_params(host, device, &P) != BBDUK_OK) return fail("unsupported parameter combination", nullptr);
-    bbduk_handle* dev = nullptr;
-    if (bbduk_create(&P, &dev) != BBDUK_OK) return fail("bbduk_create", dev ? bbduk_last_error(dev) : "no usable device (there is no CPU fallback)");
-    if (deviceBuild) {
-        if (bbduk_host_build_on_device(host, dev) != BBDUK_OK) return fail("device-side table build (hdist <= 2, no edist)", bbduk_last_error(dev));
-        stored = bbduk_table_size(dev);
-    } else if (bbduk_host_upload_index(host, dev) != BBDUK_OK) return fail("table upload", bbduk_last_error(dev));
+    std::vector<bbduk_handle*> devs;                               // one handle per entry of devices=, the map replicated on each
+    for (size_t q = 0; q < devices.size(); q++) {
+        bbduk_params Pq = P; Pq.device = devices[q];
+        bbduk_handle* hq = nullptr;
+        if (bbduk_create(&Pq, &hq) != BBDUK_OK) return fail("bbduk_create", hq ? bbduk_last_error(hq) : "no usable device (there is no CPU fallback)");
+        if (deviceBuild) {
+            if (bbduk_host_build_on_device(host, hq) != BBDUK_OK) return fail("device-side table build (hdist <= 2, no edist)", bbduk_last_error(hq));
+            stored = bbduk_table_size(hq);
+        } else if (bbduk_host_upload_index(host, hq) != BBDUK_OK) return fail("table upload", bbduk_last_error(hq));
+        devs.push_back(hq);
+    }
+    bbduk_handle* dev = devs[0];
+    const int ndev = (int)devs.size();
     fprintf(stderr, "Added %lld kmers; %d scaffolds.\n", (long long)stored, bbduk_host_num_scaffolds(host) - 1);
 
     if (deviceIngest) {
         if (rename && P.findBestMatch) return fail("deviceingest=t does not rewrite read names: use rename=t without it", nullptr);
+        if (ndev > 1) return fail("deviceingest=t drives one device: use device=", nullptr);
         if (chunk < 4096) chunk = 4096;
         const int rc = run_device_ingest(dev, host, so, P, in1, in2, paired, out, outm, tsv, (int64_t)chunk, device, maskLower, maskSymbol);
-        if (rc == 0) { bbduk_destroy(dev); bbduk_host_destroy(host); }
+        if (rc == 0) { for (bbduk_handle* hq : devs) bbduk_destroy(hq); bbduk_host_destroy(host); }
         return rc;
     }
     Reader r1, r2;
@@ -323,13 +344,14 @@ int main(int argc, char** argv) {
     if ((!out.empty() && !fout) || (!outm.empty() && !foutm) || (!tsv.empty() && !ftsv)) return fail("cannot open an output file", nullptr);
 
     const bool ktrim = P.mode != BBDUK_MODE_KFILTER;
-    std::vector<Rec> recs; std::vector<uint8_t> bases; std::vector<int64_t> offsets;
-    std::vector<int32_t> res, ids, resL, resR, mN, mIds, mCnt; std::vector<uint8_t> fl; std::vector<uint32_t> mask;
+    struct Shard { int64_t lo = 0, hi = 0; std::vector<uint8_t> bases; std::vector<int64_t> offsets; std::vector<uint32_t> mask; int rc = 0; };
+    std::vector<Rec> recs; std::vector<Shard> shards;
+    std::vector<int32_t> res, ids, resL, resR, mN, mIds, mCnt; std::vector<uint8_t> fl;
     if (P.mode == BBDUK_MODE_KSPLIT && paired) return fail("ksplit works on unpaired reads (BBDukProcessorS.java:2334)", nullptr);
     bool eof = false; long long nread = 0;
     while (!eof) {
-        recs.clear(); bases.clear(); offsets.assign(1, 0);
-        while ((long)recs.size() + (paired ? 2 : 1) <= batch) {      // mates stay adjacent: reads 2i, 2i+1
+        recs.clear();
+        while ((long)recs.size() + (paired ? 2 : 1) <= batch * ndev) {      // mates stay adjacent: reads 2i, 2i+1
             Rec a, b;
             int rc = r1.next(a.name, a.bases, a.quals);
             if (rc == 1) { eof = true; break; }
@@ -342,35 +364,55 @@ int main(int argc, char** argv) {
             if (paired) recs.push_back(std::move(b));
         }
         if (recs.empty()) break;
-        for (const Rec& r : recs) { bases.insert(bases.end(), r.bases.begin(), r.bases.end()); offsets.push_back((int64_t)bases.size()); }
         const int64_t n = (int64_t)recs.size();
         res.resize(n); ids.resize(n); fl.resize(n);
-        if (bases.empty()) bases.push_back(0);                       // an all-empty batch still needs a valid pointer
-        int rc;
-        if (P.mode == BBDUK_MODE_KTRIM_TIPS) {
-            resL.resize(n);
-            rc = bbduk_ktrimtips_batch(dev, bases.data(), offsets.data(), n, paired, res.data(), resL.data(), ids.data(), fl.data());
-        } else if (P.mode == BBDUK_MODE_KSPLIT) {
-            resL.resize(n); resR.resize(n);
-            rc = bbduk_ksplit_batch(dev, bases.data(), offsets.data(), n, res.data(), resL.data(), resR.data(), ids.data(), fl.data());
-        } else if (P.mode == BBDUK_MODE_KMASK) {
-            mask.assign((size_t)(offsets[n] + 31) / 32 + 1, 0u);
-            rc = bbduk_kmask_batch(dev, bases.data(), offsets.data(), n, paired, res.data(), ids.data(), fl.data(), mask.data());
-        } else if (rename && P.findBestMatch) {                     // rename() :2508-2522 on the lists findBestMatch left
-            const int cap = 64;
-            mN.resize(n); mIds.resize((size_t)n * cap); mCnt.resize((size_t)n * cap);
-            rc = bbduk_kfilter_batch_matches(dev, bases.data(), offsets.data(), n, paired, res.data(), ids.data(), fl.data(), cap, mN.data(), mIds.data(), mCnt.data());
-            for (int64_t i = 0; rc == BBDUK_OK && i < n; i++) {
-                for (int j = 0; j < mN[i]; j++) {
-                    const char* nm = ""; bbduk_host_scaffold_info(host, mIds[(size_t)i * cap + j], &nm, nullptr);
-                    recs[i].name += '\t'; recs[i].name += nm; recs[i].name += '='; recs[i].name += std::to_string(mCnt[(size_t)i * cap + j]);
-                }
+        if (P.mode == BBDUK_MODE_KTRIM_TIPS || P.mode == BBDUK_MODE_KSPLIT) resL.resize(n);
+        if (P.mode == BBDUK_MODE_KSPLIT) resR.resize(n);
+        const bool wantLists = rename && P.findBestMatch;             // rename() :2508-2522 on the lists findBestMatch left
+        const int cap = 64;
+        if (wantLists) { mN.resize(n); mIds.resize((size_t)n * cap); mCnt.resize((size_t)n * cap); }
+        // contiguous blocks of whole pairs, one per handle; a block's buffers are its own, offsets start at 0
+        const int64_t units = paired ? n / 2 : n, per = paired ? 2 : 1;
+        shards.resize(ndev);
+        for (int q = 0; q < ndev; q++) {
+            Shard& S = shards[q];
+            S.lo = per * (units * q / ndev); S.hi = per * (units * (q + 1) / ndev); S.rc = BBDUK_OK;
+            S.bases.clear(); S.offsets.assign(1, 0);
+            for (int64_t i = S.lo; i < S.hi; i++) { S.bases.insert(S.bases.end(), recs[i].bases.begin(), recs[i].bases.end()); S.offsets.push_back((int64_t)S.bases.size()); }
+            if (S.bases.empty()) S.bases.push_back(0);                // an all-empty block still needs a valid pointer
+        }
+        auto run_shard = [&](int q) {
+            Shard& S = shards[q]; bbduk_handle* h = devs[q];
+            const int64_t m = S.hi - S.lo, lo = S.lo;
+            if (m == 0) return;
+            if (P.mode == BBDUK_MODE_KTRIM_TIPS) S.rc = bbduk_ktrimtips_batch(h, S.bases.data(), S.offsets.data(), m, paired, res.data() + lo, resL.data() + lo, ids.data() + lo, fl.data() + lo);
+            else if (P.mode == BBDUK_MODE_KSPLIT) S.rc = bbduk_ksplit_batch(h, S.bases.data(), S.offsets.data(), m, res.data() + lo, resL.data() + lo, resR.data() + lo, ids.data() + lo, fl.data() + lo);
+            else if (P.mode == BBDUK_MODE_KMASK) {
+                S.mask.assign((size_t)(S.offsets[m] + 31) / 32 + 1, 0u);
+                S.rc = bbduk_kmask_batch(h, S.bases.data(), S.offsets.data(), m, paired, res.data() + lo, ids.data() + lo, fl.data() + lo, S.mask.data());
+            } else if (wantLists) S.rc = bbduk_kfilter_batch_matches(h, S.bases.data(), S.offsets.data(), m, paired, res.data() + lo, ids.data() + lo, fl.data() + lo, cap,
+                                                                  mN.data() + lo, mIds.data() + (size_t)lo * cap, mCnt.data() + (size_t)lo * cap);
+            else S.rc = ktrim ? bbduk_ktrim_batch(h, S.bases.data(), S.offsets.data(), m, paired, res.data() + lo, ids.data() + lo, fl.data() + lo)
+                              : bbduk_kfilter_batch(h, S.bases.data(), S.offsets.data(), m, paired, res.data() + lo, ids.data() + lo, fl.data() + lo);
+        };
+        if (ndev == 1) run_shard(0);
+        else {
+            std::vector<std::thread> th;
+            for (int q = 0; q < ndev; q++) th.emplace_back(run_shard, q);
+            for (auto& t : th) t.join();
+        }
+        for (int q = 0; q < ndev; q++) if (shards[q].rc != BBDUK_OK) return fail("batch operator", bbduk_last_error(devs[q]));
+        if (wantLists) for (int64_t i = 0; i < n; i++) {
+            for (int j = 0; j < mN[i]; j++) {
+                const char* nm = ""; bbduk_host_scaffold_info(host, mIds[(size_t)i * cap + j], &nm, nullptr);
+                recs[i].name += '\t'; recs[i].name += nm; recs[i].name += '='; recs[i].name += std::to_string(mCnt[(size_t)i * cap + j]);
             }
-        } else rc = ktrim ? bbduk_ktrim_batch(dev, bases.data(), offsets.data(), n, paired, res.data(), ids.data(), fl.data())
-                          : bbduk_kfilter_batch(dev, bases.data(), offsets.data(), n, paired, res.data(), ids.data(), fl.data());
-        if (rc != BBDUK_OK) return fail("batch operator", bbduk_last_error(dev));
+        }
+        int shardOf = 0;
         for (int64_t i = 0; i < n; i++) {
             Rec& r = recs[i];
+            while (i >= shards[shardOf].hi) shardOf++;
+            const Shard& S = shards[shardOf];
             const int L = (int)r.bases.size();
             int left = 0, right = 0;                                 // TrimRead.trimByAmount(r, left, right, 1) with the returned amount
             if (P.mode == BBDUK_MODE_KTRIM_R) right = res[i]; else if (P.mode == BBDUK_MODE_KTRIM_L) left = res[i];
@@ -395,8 +437,8 @@ int main(int argc, char** argv) {
             const int newLen = L - left - right;
             if (P.mode == BBDUK_MODE_KMASK && res[i] > 0) {            // :2309-2320
                 for (int b = 0; b < L; b++) {
-                    const int64_t g = offsets[i] + b;
-                    if (!((mask[(size_t)(g >> 5)] >> (g & 31)) & 1u)) continue;
+                    const int64_t g = S.offsets[i - S.lo] + b;
+                    if (!((S.mask[(size_t)(g >> 5)] >> (g & 31)) & 1u)) continue;
                     if (maskLower) r.bases[b] = (char)tolower((unsigned char)r.bases[b]);
                     else { r.bases[b] = maskSymbol; if (maskSymbol == 'N') r.quals[b] = '!'; }
                 }
@@ -411,11 +453,16 @@ int main(int argc, char** argv) {
         }
         nread += n;
     }
-    r1.close(); r2.close();
+    if (!r1.close()) return fail("gzip reported an error (truncated or corrupt input?) on", in1.c_str());
+    if (!r2.close()) return fail("gzip reported an error (truncated or corrupt input?) on", in2.c_str());
     if (fout) fclose(fout);
     if (foutm) fclose(foutm);
     if (ftsv) fclose(ftsv);
 
+    if (ndev > 1) {       // the path's only exchange: one all-reduce (sum, int64) of the counter vectors over the devices
+        if (bbduk_comm_create_local(devs.data(), ndev) != BBDUK_OK || bbduk_allreduce_counters_local(devs.data(), ndev) != BBDUK_OK)
+            return fail("counter all-reduce", bbduk_last_error(dev));
+    }
     std::vector<int64_t> c((size_t)bbduk_counters_len(dev));
     bbduk_get_counters(dev, c.data(), (int32_t)c.size());
     // the lines BBDukS prints at the end of a run (bbduk/BBDukS.java:350-420), same wording for the shared counters
@@ -428,6 +475,7 @@ int main(int argc, char** argv) {
     fprintf(stderr, "Result:                 \t%lld reads \t%lld bases\n", (long long)c[BBDUK_READS_OUTU], (long long)c[BBDUK_BASES_OUTU]);
     if (c[BBDUK_CTR_STATUS]) return fail("device reported an error status", nullptr);
     if (write_stats(so, host, c, in1, in2) != 0) return 1;
-    bbduk_destroy(dev); bbduk_host_destroy(host);
+    for (bbduk_handle* hq : devs) bbduk_destroy(hq);
+    bbduk_host_destroy(host);
     return 0;
 }

@@ -28,6 +28,8 @@
 #include <algorithm>
 #include <mutex>
 #include "../../include/bbduk_gpu.h"
+#include "../../include/bbduk_test_hooks.h"
+#include "bbduk_internal.h"
 #include "synth.h"
 
 static_assert(sizeof(bbduk_params) == 128, "bbduk_params layout is part of the ABI");
@@ -43,42 +45,14 @@ static_assert(sizeof(bbduk_synth_params) == 80, "bbduk_synth_params layout is pa
 #define MAX_LDS_BITS    20                     // 128 KiB presence filter per workgroup
 #define BIGLOC          999999999
 
-// Deletion experiments (profiles/ab.sh): a build with -DBBDUK_TIMING_SWITCHES honours BBDUK_DBG=<n> and skips one
+// Deletion experiments (profiles/ab.sh): a build with -DBBDUK_TIMING_SWITCHES honours bbduk_test_hook(BBDUK_HOOK_TIMING_MASK, n) and skips one
 // or more stages of the scan (results become wrong).  Production builds compile the switches out.
 #ifdef BBDUK_TIMING_SWITCHES
-#define TSW(P, n) ((((P).dbg) >> (n)) & 1)      /* BBDUK_DBG is a bit mask: bit n deletes stage n */
+#define TSW(P, n) ((((P).dbg) >> (n)) & 1)      /* the timing mask: bit n deletes stage n */
 #else
 #define TSW(P, n) false
 #endif
 
-struct KParams {
-    int32_t mode, k, mink, rcomp, forbidNs, minlen, minlen2, qhdist, qhdist2, maxBadKmers, minReadLength;
-    float   minLenFraction;
-    int32_t rieb, trimPad, ktrimExclusive, restrictLeft, restrictRight, skipR1, skipR2, numScaffolds, useShort;
-    int32_t tpe, qskip, speed;   // trimpairsevenly; qskip (<2 = off) and speed (0 = off) run in the general kernels only
-    float   mkf, mcf;            // kfilter: minkmerfraction / mincoveredfraction (general kernels only)
-    int32_t mfc;                 // kmaskfullycovered (ktrim=n): mask only bases all of whose covering k-mers match
-    int32_t kbig, fbm;           // kfilter variants of bbduk_kscan_kernel: k>31 emulation (kbig>k), findBestMatch
-    int32_t* matchN; int32_t* matchIds; int32_t* matchCnt; int32_t matchCap;    // findBestMatch's idList / countList per read (rename, :2508-2522), or null
-    const uint32_t* undef;      // packed input (bbduk_*_batch_packed): 1 bit per base, set = undefined; `bases` then points at
-                                // 2-bit codes, 16 bases per 32-bit word (A0 C1 G2 T/U3, undefined 0).  nullptr = ASCII bases
-    uint64_t mask, kmask, middleMask;
-    // The map, device layout: 4-way buckets.  tags[b] packs four 15-bit fingerprints in 16-bit lanes (0 = free
-    // way) plus the bucket's continuation flag in bit 63; the full key and its id live together in bkv[4*b+way]
-    // (16 bytes: one fetch verifies the key and yields the id) and are touched only when a fingerprint matches.
-    // A key sits in the first bucket >= its home bucket that had a free way (bucket-granular linear probing);
-    // every full bucket it passed gets the continuation flag, so a query stops at the first unflagged bucket.
-    // One 8-byte gather answers almost every absent k-mer.
-    const uint64_t* tags;
-    const uint4*    bkv;        // {key lo, key hi, id, 0}
-    uint32_t bucketMask;
-    int32_t  bucketBits;
-    int64_t  storedKmers;
-    // presence filter in front of the map: one bit per hash slot, copied into LDS by every workgroup
-    const uint32_t* ldsImage;   // HBM copy of the LDS bitmap (2^ldsBits bits); 0 bits = absent
-    int32_t  ldsBits;
-    int32_t  dbg;               // BBDUK_DBG: timing experiments only (results become wrong); needs -DBBDUK_TIMING_SWITCHES
-};
 
 // --------------------------------------------------------------------------------------------------
 // device helpers
@@ -3085,36 +3059,6 @@ __global__ void bbduk_synth_kernel(const bb_synth_dev sp, const int64_t firstPai
 // --------------------------------------------------------------------------------------------------
 // host side of the C ABI
 
-struct bbduk_handle {
-    bbduk_params p;
-    std::string err;
-    std::mutex mu;
-    bool finalized = false;
-    std::vector<int64_t> hkeys;          // staged (key,value) pairs before finalize
-    std::vector<int32_t> hvals;
-    int64_t nkeys = 0;
-    uint64_t* d_tags = nullptr; uint4* d_bkv = nullptr; uint64_t nbuckets = 0; int bucketBits = 0;
-    uint32_t* d_ldsImage = nullptr; int ldsBits = 0;
-    int* d_slowFlag = nullptr;
-    static const int EV_RING = 64;                                // HIP events around the dominant kernel of the last launches
-    hipEvent_t ev0[EV_RING] = {}, ev1[EV_RING] = {}; int64_t evCount = 0;
-    std::mutex launchMu;                                          // device-buffer operators may be issued from several host threads /
-                                                                  // streams at once: slot choice and enqueue of one launch are atomic,
-                                                                  // and every launch in flight has its own pre-pass flag (d_slowFlag[slot])
-    // host-operator staging
-    uint8_t* d_bases = nullptr; size_t cap_bases = 0;
-    uint8_t* d_undef = nullptr; size_t cap_undef = 0;     // packed boundary: one undefined-base bit per base
-    int64_t* d_off = nullptr;   size_t cap_reads = 0;
-    int32_t* d_a = nullptr; int32_t* d_id = nullptr; uint8_t* d_fl = nullptr;
-    int64_t* d_counters = nullptr;
-    hipStream_t stream = nullptr;
-    int numCU = 256;
-};
-
-#define HIP_TRY(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
-    (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return BBDUK_ERR_DEVICE; } } while (0)
-
-static int fail(bbduk_handle* h, int code, const char* msg) { if (h) h->err = msg; return code; }
 
 extern "C" int bbduk_abi_version(void) { return BBDUK_ABI_VERSION; }
 extern "C" const char* bbduk_last_error(const bbduk_handle* h) { return h ? h->err.c_str() : "null handle"; }
@@ -3165,8 +3109,27 @@ extern "C" int bbduk_create(const bbduk_params* p, bbduk_handle** out) {
     return BBDUK_OK;
 }
 
+// Test-only controls (include/bbduk_test_hooks.h): explicit calls on a handle instead of environment variables.
+extern "C" int bbduk_test_hook(bbduk_handle* h, int32_t which, int64_t value) {
+    if (!h) return BBDUK_ERR_ARG;
+    std::lock_guard<std::mutex> g(h->mu);
+    switch (which) {
+    case BBDUK_HOOK_FORCE_TILE:  h->hookForceTile = value != 0; return BBDUK_OK;
+    case BBDUK_HOOK_BUCKET_BITS: if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookBucketBits = (int)value; return BBDUK_OK;
+    case BBDUK_HOOK_LDS_BITS:    if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookLdsBits = (int)value; return BBDUK_OK;
+    case BBDUK_HOOK_TIMING_MASK:
+#ifdef BBDUK_TIMING_SWITCHES
+        h->hookDbg = (int)value; return BBDUK_OK;
+#else
+        return fail(h, BBDUK_ERR_ARG, "this build has no timing switches (-DBBDUK_TIMING_SWITCHES)");
+#endif
+    default: return fail(h, BBDUK_ERR_ARG, "unknown hook");
+    }
+}
+
 extern "C" int bbduk_destroy(bbduk_handle* h) {
     if (!h) return BBDUK_ERR_ARG;
+    bbduk_comm_destroy(h);
     hipSetDevice(h->p.device);
     hipFree(h->d_tags); hipFree(h->d_bkv); hipFree(h->d_bases); hipFree(h->d_undef); hipFree(h->d_off);
     hipFree(h->d_ldsImage); hipFree(h->d_slowFlag);
@@ -3181,10 +3144,13 @@ extern "C" int bbduk_upload_pairs(bbduk_handle* h, const int64_t* keys, const in
     if (!h || n < 0 || (n > 0 && (!keys || !values))) return fail(h, BBDUK_ERR_ARG, "upload_pairs: bad argument");
     std::lock_guard<std::mutex> g(h->mu);
     if (h->finalized) return fail(h, BBDUK_ERR_STATE, "table already finalized");
+    // ids index the counter vector on the device (scaffoldReadCounts[id], scaffoldBaseCounts[id]): one outside
+    // 1..numScaffolds-1 would write outside the caller's vector, one <= 0 would turn hits into misses
     for (int64_t i = 0; i < n; i++) {
         if (keys[i] < 0) return fail(h, BBDUK_ERR_ARG, "upload_pairs: negative key");
-        h->hkeys.push_back(keys[i]); h->hvals.push_back(values[i]);
+        if (values[i] < 1 || values[i] >= h->p.numScaffolds) return fail(h, BBDUK_ERR_ARG, "upload_pairs: scaffold id outside 1..numScaffolds-1");
     }
+    for (int64_t i = 0; i < n; i++) { h->hkeys.push_back(keys[i]); h->hvals.push_back(values[i]); }
     return BBDUK_OK;
 }
 
@@ -3195,6 +3161,10 @@ extern "C" int bbduk_upload_table_way(bbduk_handle* h, int32_t way, int32_t prim
         return fail(h, BBDUK_ERR_ARG, "upload_table_way: bad argument");
     std::lock_guard<std::mutex> g(h->mu);
     if (h->finalized) return fail(h, BBDUK_ERR_STATE, "table already finalized");
+    for (int64_t i = 0; i < ncells; i++) if (keys[i] >= 0 && (values[i] < 1 || values[i] >= h->p.numScaffolds))
+        return fail(h, BBDUK_ERR_ARG, "upload_table_way: scaffold id outside 1..numScaffolds-1 (stale table, or numScaffolds too small?)");
+    for (int64_t i = 0; i < nvictims; i++) if (vkeys[i] >= 0 && (vvals[i] < 1 || vvals[i] >= h->p.numScaffolds))
+        return fail(h, BBDUK_ERR_ARG, "upload_table_way: victim scaffold id outside 1..numScaffolds-1");
     for (int64_t i = 0; i < ncells; i++) if (keys[i] >= 0) {     // NOT_PRESENT = -1 (kmer/AbstractKmerTable.java:807)
         h->hkeys.push_back(keys[i]); h->hvals.push_back(values[i]);
     }
@@ -3212,7 +3182,7 @@ extern "C" int bbduk_finalize_table(bbduk_handle* h) {
     // overflow and carry the continuation flag, so almost every lookup ends in its home bucket).
     int bbits = 10;
     while (bbits < 32 && (1ULL << bbits) < (uint64_t)n) bbits++;
-    if (const char* e = getenv("BBDUK_BUCKET_BITS")) { const int v = atoi(e); if (v >= 4 && v <= 32) bbits = v; }
+    if (h->hookBucketBits >= 4 && h->hookBucketBits <= 32) bbits = h->hookBucketBits;      // bbduk_test_hook
     const uint64_t nb = 1ULL << bbits;
     if (4 * nb < (uint64_t)n + nb / 8 || 4 * nb > (1ULL << 31)) return fail(h, BBDUK_ERR_ARG, "too many keys for the bucket index");
     std::vector<uint64_t> tg(nb, 0ULL);
@@ -3244,13 +3214,13 @@ extern "C" int bbduk_finalize_table(bbduk_handle* h) {
     h->nbuckets = nb; h->bucketBits = bbits; h->nkeys = distinct;
     // Presence filter in front of the map.  Most query k-mers are absent, so one bit per hash slot held in LDS
     // (<=128 KiB per workgroup) answers most of them without leaving the CU.  Size follows the key count;
-    // BBDUK_LDS_BITS (log2 bits, 0 = off) overrides for experiments.  Huge maps (HBM-resident, SURVEY config 4)
+    // bbduk_test_hook(BBDUK_HOOK_LDS_BITS) (log2 bits, 0 = off) overrides for tests.  Huge maps (HBM-resident, SURVEY config 4)
     // skip it: a filter that small would be all ones.
     {
         auto ceil_log2 = [](uint64_t x) { int b = 0; while ((1ULL << b) < x) b++; return b; };
         int lb = 0;
         if (distinct > 0 && distinct <= (1LL << 22)) lb = std::min(MAX_LDS_BITS, std::max(10, ceil_log2(32ULL * (uint64_t)distinct)));
-        if (const char* e = getenv("BBDUK_LDS_BITS")) { const int v = atoi(e); if (v >= 0) lb = v == 0 ? 0 : std::min(MAX_LDS_BITS, std::max(10, v)); }
+        if (h->hookLdsBits >= 0) lb = h->hookLdsBits == 0 ? 0 : std::min(MAX_LDS_BITS, std::max(10, h->hookLdsBits));   // bbduk_test_hook
         if (lb) {
             std::vector<uint32_t> f1((size_t)1 << (lb - 5), 0u);
             for (uint64_t s = 0; s < 4 * nb; s++) {
@@ -3358,7 +3328,7 @@ static KParams make_kparams(const bbduk_handle* h) {
     K.tags = h->d_tags; K.bkv = h->d_bkv; K.bucketMask = (uint32_t)(h->nbuckets - 1); K.bucketBits = h->bucketBits;
     K.storedKmers = h->nkeys; K.undef = nullptr;
     K.matchN = nullptr; K.matchIds = nullptr; K.matchCnt = nullptr; K.matchCap = 0;
-    K.dbg = getenv("BBDUK_DBG") ? atoi(getenv("BBDUK_DBG")) : 0;
+    K.dbg = h->hookDbg;
     K.ldsImage = h->d_ldsImage; K.ldsBits = h->ldsBits;
     return K;
 }
@@ -3435,7 +3405,7 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
     int* const d_flag = h->d_slowFlag + evi;
     HIP_TRY(h, hipMemsetAsync(d_flag, 0, sizeof(int), st));
-    if (getenv("BBDUK_FORCE_TILE")) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }
+    if (h->hookForceTile) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }
     else {
         const int64_t units = paired ? n / 2 : n;
         const int sgrid = (int)std::min<int64_t>((units + 255) / 256, (int64_t)h->numCU * 8);
@@ -3445,11 +3415,6 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     const int64_t nmt = (n + MT_READS - 1) / MT_READS;
     const int wgrid = (int)std::min<int64_t>((nmt + NWAVES - 1) / NWAVES, (int64_t)h->numCU * perCU);
     const int tgrid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU * perCU);
-    if (getenv("BBDUK_VERBOSE")) {
-        int occ = -1;
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kp.wave), BLOCK_THREADS, waveLds);
-        fprintf(stderr, "[bbduk] wave grid=%d tile grid=%d block=%d dynLds=%zu occupancyAPI=%d numCU=%d\n", wgrid, tgrid, BLOCK_THREADS, dynLds, occ, h->numCU);
-    }
     if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
     HIP_TRY(h, hipEventRecord(h->ev0[evi], st));
     kp.wave<<<dim3(wgrid), dim3(BLOCK_THREADS), waveLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
@@ -3521,6 +3486,15 @@ extern "C" int bbduk_kfilter_batch_packed_device(bbduk_handle* h, const uint32_t
     return launch_batch(h, 1, reinterpret_cast<const uint8_t*>(d_codes), d_offsets, n, total_bases, paired, d_out_found, d_out_id, d_out_flags, d_counters, (hipStream_t)stream, d_undef, true);
 }
 
+// The host-buffer operators take their offsets from an untrusted caller (the JNI shim): they must ascend from 0 and no read may
+// exceed an int, or the kernels would stage from negative / oversized lengths.  O(n), next to a PCIe copy of the same array.
+// (The *_device operators trust their caller: the offsets are in HBM.)
+static bool offsets_ok(const int64_t* offsets, int64_t n) {
+    if (offsets[0] != 0) return false;
+    for (int64_t i = 0; i < n; i++) { const int64_t d = offsets[i + 1] - offsets[i]; if (d < 0 || d > 0x7FFFFFFFLL) return false; }
+    return true;
+}
+
 static int host_batch(bbduk_handle* h, int wantKfilter, const uint8_t* bases, const int64_t* offsets, int64_t n, int32_t paired,
                       int32_t* out_a, int32_t* out_id, uint8_t* out_fl, const uint32_t* undef = nullptr, bool packed = false,
                       const MatchOut* hostMatches = nullptr) {
@@ -3530,7 +3504,7 @@ static int host_batch(bbduk_handle* h, int wantKfilter, const uint8_t* bases, co
         return fail(h, BBDUK_ERR_ARG, "match lists: null buffer or max_ids outside 1..64");
     if (n == 0) return BBDUK_OK;
     const int64_t total = offsets[n];
-    if (offsets[0] != 0 || total < 0 || (total > 0 && !bases)) return fail(h, BBDUK_ERR_ARG, "bad offsets");
+    if (!offsets_ok(offsets, n) || (total > 0 && !bases)) return fail(h, BBDUK_ERR_ARG, "bad offsets (must ascend from 0, reads <= INT_MAX bases)");
     if (packed && total > 0 && !undef) return fail(h, BBDUK_ERR_ARG, "packed input needs the undefined-bit plane");
     const size_t baseBytes = packed ? 4 * (size_t)((total + 15) >> 4) : (size_t)total;      // what crosses PCIe for the bases
     const size_t undefBytes = packed ? 4 * (size_t)((total + 31) >> 5) : 0;
@@ -3668,7 +3642,7 @@ extern "C" int bbduk_ktrimtips_batch(bbduk_handle* h, const uint8_t* bases, cons
     if (n < 0 || !offsets || (n > 0 && (!out_right || !out_left || !out_id0 || !out_flags))) return fail(h, BBDUK_ERR_ARG, "bad argument");
     if (n == 0) return BBDUK_OK;
     const int64_t total = offsets[n];
-    if (offsets[0] != 0 || total < 0 || (total > 0 && !bases)) return fail(h, BBDUK_ERR_ARG, "bad offsets");
+    if (!offsets_ok(offsets, n) || (total > 0 && !bases)) return fail(h, BBDUK_ERR_ARG, "bad offsets (must ascend from 0, reads <= INT_MAX bases)");
     std::lock_guard<std::mutex> g(h->mu);
     HIP_TRY(h, hipSetDevice(h->p.device));
     uint8_t* db = nullptr; int64_t* doff = nullptr; int32_t* dr = nullptr; int32_t* dl = nullptr; int32_t* did = nullptr; uint8_t* dfl = nullptr;
@@ -3760,7 +3734,7 @@ extern "C" int bbduk_ksplit_batch(bbduk_handle* h, const uint8_t* bases, const i
     if (n < 0 || !offsets || (n > 0 && (!out_trimmed || !out_leftmost || !out_rightmost || !out_id0 || !out_flags))) return fail(h, BBDUK_ERR_ARG, "bad argument");
     if (n == 0) return BBDUK_OK;
     const int64_t total = offsets[n];
-    if (offsets[0] != 0 || total < 0 || (total > 0 && !bases)) return fail(h, BBDUK_ERR_ARG, "bad offsets");
+    if (!offsets_ok(offsets, n) || (total > 0 && !bases)) return fail(h, BBDUK_ERR_ARG, "bad offsets (must ascend from 0, reads <= INT_MAX bases)");
     std::lock_guard<std::mutex> g(h->mu);
     HIP_TRY(h, hipSetDevice(h->p.device));
     uint8_t* db = nullptr; int64_t* doff = nullptr; int32_t* dx = nullptr; int32_t* dl = nullptr; int32_t* dr = nullptr; int32_t* did = nullptr; uint8_t* dfl = nullptr;
@@ -3809,7 +3783,7 @@ extern "C" int bbduk_kmask_batch(bbduk_handle* h, const uint8_t* bases, const in
     if (n < 0 || !offsets || (n > 0 && (!out_masked || !out_id0 || !out_flags || !out_mask))) return fail(h, BBDUK_ERR_ARG, "bad argument");
     if (n == 0) return BBDUK_OK;
     const int64_t total = offsets[n];
-    if (offsets[0] != 0 || total < 0 || (total > 0 && !bases)) return fail(h, BBDUK_ERR_ARG, "bad offsets");
+    if (!offsets_ok(offsets, n) || (total > 0 && !bases)) return fail(h, BBDUK_ERR_ARG, "bad offsets (must ascend from 0, reads <= INT_MAX bases)");
     std::lock_guard<std::mutex> g(h->mu);
     HIP_TRY(h, hipSetDevice(h->p.device));
     uint8_t* db = nullptr; int64_t* doff = nullptr; int32_t* da = nullptr; int32_t* did = nullptr; uint8_t* dfl = nullptr; uint32_t* dm = nullptr;

@@ -1,0 +1,77 @@
+// bbduk_internal.h -- shared by the translation units of libbbduk_hip.so (not part of the ABI).
+#ifndef BBDUK_INTERNAL_H
+#define BBDUK_INTERNAL_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <mutex>
+#include <memory>
+#include "../../include/bbduk_gpu.h"
+
+struct KParams {
+    int32_t mode, k, mink, rcomp, forbidNs, minlen, minlen2, qhdist, qhdist2, maxBadKmers, minReadLength;
+    float   minLenFraction;
+    int32_t rieb, trimPad, ktrimExclusive, restrictLeft, restrictRight, skipR1, skipR2, numScaffolds, useShort;
+    int32_t tpe, qskip, speed;   // trimpairsevenly; qskip (<2 = off) and speed (0 = off) run in the general kernels only
+    float   mkf, mcf;            // kfilter: minkmerfraction / mincoveredfraction (general kernels only)
+    int32_t mfc;                 // kmaskfullycovered (ktrim=n): mask only bases all of whose covering k-mers match
+    int32_t kbig, fbm;           // kfilter variants of bbduk_kscan_kernel: k>31 emulation (kbig>k), findBestMatch
+    int32_t* matchN; int32_t* matchIds; int32_t* matchCnt; int32_t matchCap;    // findBestMatch's idList / countList per read (rename, :2508-2522), or null
+    const uint32_t* undef;      // packed input (bbduk_*_batch_packed): 1 bit per base, set = undefined; `bases` then points at
+                                // 2-bit codes, 16 bases per 32-bit word (A0 C1 G2 T/U3, undefined 0).  nullptr = ASCII bases
+    uint64_t mask, kmask, middleMask;
+    // The map, device layout: 4-way buckets.  tags[b] packs four 15-bit fingerprints in 16-bit lanes (0 = free
+    // way) plus the bucket's continuation flag in bit 63; the full key and its id live together in bkv[4*b+way]
+    // (16 bytes: one fetch verifies the key and yields the id) and are touched only when a fingerprint matches.
+    // A key sits in the first bucket >= its home bucket that had a free way (bucket-granular linear probing);
+    // every full bucket it passed gets the continuation flag, so a query stops at the first unflagged bucket.
+    // One 8-byte gather answers almost every absent k-mer.
+    const uint64_t* tags;
+    const uint4*    bkv;        // {key lo, key hi, id, 0}
+    uint32_t bucketMask;
+    int32_t  bucketBits;
+    int64_t  storedKmers;
+    // presence filter in front of the map: one bit per hash slot, copied into LDS by every workgroup
+    const uint32_t* ldsImage;   // HBM copy of the LDS bitmap (2^ldsBits bits); 0 bits = absent
+    int32_t  ldsBits;
+    int32_t  dbg;               // timing mask (bbduk_test_hook): timing experiments only (results become wrong); needs -DBBDUK_TIMING_SWITCHES
+};
+
+struct bbduk_comm;                   // bbduk_comm.cpp: the RCCL communicator(s) a handle belongs to
+
+struct bbduk_handle {
+    bbduk_params p;
+    std::string err;
+    std::mutex mu;
+    bool finalized = false;
+    std::vector<int64_t> hkeys;          // staged (key,value) pairs before finalize
+    std::vector<int32_t> hvals;
+    int64_t nkeys = 0;
+    uint64_t* d_tags = nullptr; uint4* d_bkv = nullptr; uint64_t nbuckets = 0; int bucketBits = 0;
+    uint32_t* d_ldsImage = nullptr; int ldsBits = 0;
+    int* d_slowFlag = nullptr;
+    static const int EV_RING = 64;                                // HIP events around the dominant kernel of the last launches
+    hipEvent_t ev0[EV_RING] = {}, ev1[EV_RING] = {}; int64_t evCount = 0;
+    std::mutex launchMu;                                          // device-buffer operators may be issued from several host threads /
+                                                                  // streams at once: slot choice and enqueue of one launch are atomic,
+                                                                  // and every launch in flight has its own pre-pass flag (d_slowFlag[slot])
+    // host-operator staging
+    uint8_t* d_bases = nullptr; size_t cap_bases = 0;
+    uint8_t* d_undef = nullptr; size_t cap_undef = 0;     // packed boundary: one undefined-base bit per base
+    int64_t* d_off = nullptr;   size_t cap_reads = 0;
+    int32_t* d_a = nullptr; int32_t* d_id = nullptr; uint8_t* d_fl = nullptr;
+    int64_t* d_counters = nullptr;
+    hipStream_t stream = nullptr;
+    int numCU = 256;
+    bbduk_comm* comm = nullptr;          // set by bbduk_comm_create / bbduk_comm_create_local
+    // include/bbduk_test_hooks.h (tests and experiments only)
+    bool hookForceTile = false; int hookBucketBits = 0, hookLdsBits = -1, hookDbg = 0;
+};
+
+#define HIP_TRY(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return BBDUK_ERR_DEVICE; } } while (0)
+
+static inline int fail(bbduk_handle* h, int code, const char* msg) { if (h) h->err = msg; return code; }
+
+#endif

@@ -9,7 +9,16 @@ all-reduce.  N>1: one process per GPU (torch.distributed, backend nccl = RCCL), 
 every rank owns the next 100 M reads of the counter-based synthetic stream), k-mer map replicated, no
 data-path collective.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--no-cpu-baseline]
+With --gpus N > 1 and no WORLD_SIZE in the environment the script launches its own N ranks (torch.distributed.run, one
+process per GPU, 127.0.0.1 rendezvous); under an external launcher (RANK/LOCAL_RANK/WORLD_SIZE set) it is one of the ranks.
+The counter all-reduce is the library's own (bbduk_allreduce_counters_device: RCCL ncclAllReduce behind the C ABI);
+torch.distributed is used for the rendezvous (handing the 128-byte RCCL id to the ranks), the barrier and the max-over-ranks clock.
+
+Besides the contract's line for configs[1] (device-resident, ASCII boundary), rank 0 at N=1 adds:
+  "end_to_end": Gbases/s THROUGH the C ABI's host-buffer operators (H2D + kernel + D2H inside the call), ASCII and packed
+  "configs":    kernel Gbases/s of the other BASELINE configurations (C1, C3, C5 at 20 M reads; C4 = HBM-resident map, scaled)
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--no-cpu-baseline] [--no-extras]
 """
 import argparse
 import json
@@ -27,6 +36,95 @@ ALGO_BYTES_PER_READ = READ_LEN + 8 + 8          # bases + int64 offset + (trimme
 HBM_PEAK_GBS = 8000.0                           # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script, one per GPU, and pass rank 0's JSON line on."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def measure_end_to_end(B, duk, reads, seed):
+    """Gbases/s through bbduk_ktrim_batch / bbduk_ktrim_batch_packed -- host buffers in, H2D + kernel + D2H inside
+    the call.  Two submitting threads keep both staging slots of the handle busy (copies of one call under the kernel of the other)."""
+    import threading
+    import numpy as np
+    import torch
+    n_pairs = reads // 2; n = 2 * n_pairs
+    sp = B.synth_params(seed)
+    d_b = torch.empty(n * READ_LEN, dtype=torch.uint8, device="cuda"); d_o = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    B.synth_generate_device(sp, 0, n_pairs, d_b, d_o, duk.gpu.params.device)
+    torch.cuda.synchronize()
+    hb = d_b.cpu().numpy(); hoff = d_o.cpu().numpy()
+    del d_b, d_o
+    codes, undef = B.pack_bases_host(hb)
+    res = {"reads_per_call": n, "note": "PCIe-inclusive; never the headline `value`"}
+    for name, fn in (("ascii", lambda: duk.gpu.process_batch(hb, hoff, True)), ("packed", lambda: duk.gpu.process_batch_packed(codes, undef, hoff, True))):
+        fn()                                                         # warm-up: staging buffers get allocated
+        t = time.perf_counter(); fn(); one = time.perf_counter() - t
+        calls = 3
+        def worker():
+            for _ in range(calls):
+                fn()
+        th = [threading.Thread(target=worker) for _ in range(2)]
+        t = time.perf_counter()
+        for x in th: x.start()
+        for x in th: x.join()
+        two = (time.perf_counter() - t) / (2 * calls)
+        res[name] = {"Gbases_per_s_1_thread": round(n * READ_LEN / one / 1e9, 2), "Gbases_per_s_2_threads": round(n * READ_LEN / two / 1e9, 2),
+                     "ms_per_call_1_thread": round(one * 1e3, 2), "ms_per_call_2_threads": round(two * 1e3, 2),
+                     "bytes_in_per_read": 158 if name == "ascii" else round((len(codes) * 4 + len(undef) * 4) / n + 8, 2), "bytes_out_per_read": 9}
+    return res
+
+
+def measure_configs(B, reads, c4_ref_bases):
+    """Kernel Gbases/s (HIP events inside the library) of the other BASELINE configurations, device-resident batches."""
+    import numpy as np
+    import torch
+    phix = B.read_fasta(os.path.join(ROOT, "data", "phix2.fa.gz"))[0][1]
+    n_pairs = reads // 2; n = 2 * n_pairs
+    res = {}
+    d_bases = torch.empty(n * READ_LEN, dtype=torch.uint8, device="cuda"); d_off = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    d_a = torch.empty(n, dtype=torch.int32, device="cuda"); d_id = torch.empty_like(d_a); d_fl = torch.empty(n, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(duk_gpu, sp, steps=3):
+        B.synth_generate_device(sp, 0, n_pairs, d_bases, d_off, 0)
+        d_c = torch.zeros(duk_gpu.counters_len, dtype=torch.int64, device="cuda")
+        for _ in range(1 + steps):
+            d_c.zero_(); duk_gpu.process_batch_device(d_bases, d_off, True, d_a, d_id, d_fl, d_c, st)
+        torch.cuda.synchronize()
+        return duk_gpu.kernel_time_ms(steps), d_c.cpu().numpy()
+
+    for name, args, seed, kw in (("C1", "ktrim=r k=23 hdist=0 ref=adapters", 1, {}),
+                                 ("C3", "k=31 hdist=1 ref=phix", 3, dict(contam=phix, contam_frac=0.01)),
+                                 ("C5", "ktrim=r k=23 hdist=1 ref=adapters", 5, {})):
+        duk = B.BBDuk(args)
+        ms, c = run(duk.gpu, B.synth_params(seed, **kw))
+        res[name] = {"args": args, "reads": n, "keys": int(duk.stored_kmers), "kernel_ms": round(ms, 3),
+                     "Gbases_per_s": round(n * READ_LEN / (ms * 1e-3) / 1e9, 1), "readsKTrimmed": int(c[2]), "readsKFiltered": int(c[4])}
+        duk.close()
+    if c4_ref_bases > 0:
+        # BASELINE configs[3] scaled: kfilter k=31 hdist=0 against a seeded uniform-random reference, map resident in HBM, 1 % of the
+        # pairs drawn from the reference.  (The full 10 Gbase point takes minutes to build: profiles/bench_c4_full.py.)
+        rng = np.random.default_rng(40)
+        ref = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, c4_ref_bases, dtype=np.uint8)].tobytes()
+        t = time.perf_counter(); duk = B.BBDuk("k=31 hdist=0", refs=[ref], build="device"); tb = time.perf_counter() - t
+        ms, c = run(duk.gpu, B.synth_params(4, contam=ref, contam_frac=0.01))
+        algo = n * (READ_LEN + 8 + 8 + 120 * 8) + 4 * int(c[4])
+        res["C4_scaled"] = {"args": "k=31 hdist=0, %d-base random reference" % c4_ref_bases, "reads": n, "keys": int(duk.gpu.table_size),
+                            "table_bytes": int(duk.gpu.table_bytes), "device_build_s": round(tb, 2), "kernel_ms": round(ms, 3),
+                            "Gbases_per_s": round(n * READ_LEN / (ms * 1e-3) / 1e9, 1), "algorithmic_GBps": round(algo / (ms * 1e-3) / 1e9, 1),
+                            "frac_of_8TBps": round(algo / (ms * 1e-3) / 8e12, 4), "readsKFiltered": int(c[4])}
+        duk.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -39,7 +137,16 @@ def main():
     ap.add_argument("--format", choices=["ascii", "packed"], default="ascii",
                     help="boundary format of the resident batch: ascii = the reference's byte per base (the headline), "
                          "packed = 2-bit codes + undefined bits (DESIGN.md 4.7; secondary)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the end_to_end and configs measurements")
+    ap.add_argument("--extra-reads", type=int, default=20_000_000, help="reads per call / launch of the extra measurements")
+    ap.add_argument("--c4-ref-bases", type=int, default=1_000_000_000, help="reference size of the HBM-resident point in `configs` (0 = skip)")
+    ap.add_argument("--dry-run-share-gpu", action="store_true", help="N>1 control-flow rehearsal on one GPU (gloo; not a measurement)")
+    ap.add_argument("--insert-range", default=None, help="experiments: 'min,max' insert size of the synthetic pairs")
+    ap.add_argument("--lib", default=None, help="experiments: bind to another build of the library (bbtools_amd/<name>.so)")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(a.gpus)
 
     import numpy as np
     import torch
@@ -48,32 +155,41 @@ def main():
         bbtools_amd.build()
     from bbtools_amd import bbduk as B
     from bbtools_amd import dist as D
+    if a.lib:
+        B.use_library(a.lib)
 
     rank, world, local = D.env_rank_world()
     distributed = world > 1
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # Dry-run hooks for a 1-GPU box (never set by the driver): every rank on GPU 0 and a gloo rendezvous, so that the
-        # N>1 control flow (sharding, barrier, max-over-ranks clock, counter all-reduce) can be exercised without N GPUs.
-        if os.environ.get("BBDUK_BENCH_SHARE_GPU"):
+        # --dry-run-share-gpu (never passed by the driver): every rank on GPU 0 with a gloo rendezvous, so that the N>1 control
+        # flow (self-launch, sharding, barrier, max-over-ranks clock) can be exercised on a 1-GPU box.  RCCL refuses two ranks on
+        # one device, so in that mode -- and only there -- the counters are summed by gloo and the line says "dry_run".
+        if a.dry_run_share_gpu:
             local = 0
         torch.cuda.set_device(local)
-        backend = os.environ.get("BBDUK_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.dry_run_share_gpu:
+            dist.init_process_group("gloo")
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))       # "nccl" is RCCL on ROCm
     dev = local if distributed else 0
     torch.cuda.set_device(dev)
-    assert a.gpus == world, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run for N>1)"
+    if a.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if torch.cuda.device_count() <= dev:
+        raise SystemExit("bench.py: rank %d needs GPU %d but only %d visible" % (rank, dev, torch.cuda.device_count()))
 
     n_pairs = a.reads // 2
     n = 2 * n_pairs
     duk = B.BBDuk(ARGS_C2, device=dev)
+    if distributed and not a.dry_run_share_gpu:       # the RCCL communicator behind the C ABI: rank 0's id goes to every rank
+        box = [B.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        duk.gpu.comm_create(world, rank, box[0])
     sp_kw = {}
-    if os.environ.get("BBDUK_BENCH_INS"):            # experiments only: "min,max" insert range (default 50,350)
-        lo_, hi_ = os.environ["BBDUK_BENCH_INS"].split(",")
+    if a.insert_range:                               # experiments only: "min,max" insert range (default 50,350)
+        lo_, hi_ = a.insert_range.split(",")
         sp_kw = dict(ins_min=int(lo_), ins_max=int(hi_))
     sp = B.synth_params(a.seed, **sp_kw)
     lo, hi = D.weak_shard(n_pairs, rank)
@@ -104,7 +220,10 @@ def main():
         if ev1 is not None:
             ev1.record()
         total = d_ctr.clone()
-        D.all_reduce_counters(total)             # the path's only collective: global hit/trim counters
+        if distributed and not a.dry_run_share_gpu:   # the path's only collective: global hit/trim counters (ncclAllReduce, int64 sum)
+            duk.gpu.allreduce_counters_device(total, stream)
+        elif distributed:
+            t_ = total.cpu(); dist.all_reduce(t_); total = t_.cuda()
         return total
 
     def barrier():
@@ -122,7 +241,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if a.dry_run_share_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     launch_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(1, a.steps)     # span pre-pass + wave kernel + no-op fallback
@@ -141,8 +260,9 @@ def main():
                                "(configs[1]), device-resident batch%s" % (n, ", packed 2-bit boundary format" if packed else ""),
                    "args": ARGS_C2, "reads_per_gpu": n, "read_len": READ_LEN, "seed": a.seed,
                    "table_keys": int(duk.stored_kmers), "table_bytes": int(duk.gpu.table_bytes),
-                   "parallelism": "reads sharded x%d, table replicated, 1 counter all-reduce/step" % world},
+                   "parallelism": "reads sharded x%d, table replicated, 1 counter all-reduce/step (RCCL via bbduk_allreduce_counters_device)" % world},
         "counters": {k: int(v) for k, v in zip(B.COUNTER_NAMES, ctr[:10])},
+        **({"dry_run": "all ranks share GPU 0, counters summed by gloo: control-flow rehearsal, not a measurement"} if a.dry_run_share_gpu else {}),
         "device_status": status,
     }
     algo_bytes = (ALGO_BYTES_PER_READ if not packed else READ_LEN * 0.375 + 8 + 8) * n     # 0.375 B/base with 2-bit + mask
@@ -188,7 +308,22 @@ def main():
             out["parity_sample_ok"] = ok
         except Exception as e:                        # the bench line must not depend on the checker building / running
             out["cpu_baseline"] = {"value": None, "unit": "Gbases/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
-    duk.close()
+    if rank == 0 and world == 1 and not a.no_extras:
+        del d_bases, d_off, d_a, d_id, d_fl
+        if packed:
+            del d_codes, d_undef
+        torch.cuda.empty_cache()
+        try:
+            out["end_to_end"] = measure_end_to_end(B, duk, a.extra_reads, a.seed)
+        except Exception as e:
+            out["end_to_end"] = {"error": repr(e)}
+        duk.close(); duk = None
+        try:
+            out["configs"] = measure_configs(B, a.extra_reads, a.c4_ref_bases)
+        except Exception as e:
+            out["configs"] = {"error": repr(e)}
+    if duk is not None:
+        duk.close()
     if rank == 0:
         print(json.dumps(out))
     if distributed:
@@ -196,4 +331,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

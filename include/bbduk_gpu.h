@@ -289,6 +289,28 @@ int  bbduk_counters_len(const bbduk_handle* h);           /* 16 + 2*numScaffolds
 int  bbduk_get_counters(bbduk_handle* h, int64_t* out, int32_t n);
 int  bbduk_reset_counters(bbduk_handle* h);
 
+/* ---- multi-GPU (SURVEY 8b "allreduce_counters", 8e).  Reads shard across GPUs in contiguous blocks of whole pairs, the
+ * k-mer map is replicated per GPU, and the only exchange is ONE sum of the counter vector at the end of a run: the
+ * device-side form of BBDukProcessorS.add merging the per-thread processors (bbduk/BBDukProcessorS.java:300-342).  It is
+ * one RCCL ncclAllReduce(ncclInt64, ncclSum) over xGMI.  librccl is dlopen'ed at the first of these calls.
+ *   one process per GPU : rank 0 calls bbduk_comm_unique_id and its launcher hands the 128 bytes to every rank (MPI,
+ *                         torch.distributed's store, a file ...); every rank calls bbduk_comm_create on its handle; then
+ *                         bbduk_allreduce_counters(h) (the handle's own counters, blocking) or _device (any int64 vector of
+ *                         bbduk_counters_len(h) on the handle's device; asynchronous on `stream`).  Every rank must call.
+ *   one process, N GPUs : (the JVM host, bbduk_cli devices=) bbduk_comm_create_local(handles, n) once, then
+ *                         bbduk_allreduce_counters_local(handles, n) from ONE thread: handles that share a device are summed
+ *                         on it first, the device leaders run the all-reduce, every handle ends with the global sums.
+ * The status slot (BBDUK_CTR_STATUS) is summed like the rest: nonzero anywhere stays nonzero. */
+#define BBDUK_COMM_ID_BYTES 128
+int  bbduk_comm_unique_id(uint8_t* id128);
+int  bbduk_comm_create(bbduk_handle* h, int32_t nranks, int32_t rank, const uint8_t* id128);
+int  bbduk_comm_create_local(bbduk_handle** handles, int32_t n);
+int  bbduk_comm_destroy(bbduk_handle* h);                 /* also done by bbduk_destroy; a local group ends for all its members */
+int  bbduk_comm_size(const bbduk_handle* h);              /* ranks (distinct devices) of the handle's communicator, 0 = none */
+int  bbduk_allreduce_counters(bbduk_handle* h);
+int  bbduk_allreduce_counters_device(bbduk_handle* h, int64_t* d_counters, void* stream);
+int  bbduk_allreduce_counters_local(bbduk_handle** handles, int32_t n);
+
 /* ---- deterministic synthetic read generator, device side; the bit-identical host side is
  * bbduk_synth_generate_host.  Reads are fixed length; pair p = reads 2p, 2p+1.                        */
 typedef struct bbduk_synth_params {

@@ -1,0 +1,21 @@
+/*
+ * bbduk_test_hooks.h -- controls for tests and experiments; NOT part of the drop-in boundary (include/bbduk_gpu.h) and never
+ * called by a product caller (bbduk_cli, the JNI shim, bench.py's timed path).  They replace the environment variables an
+ * earlier build read on its hot host path: the library itself reads no environment variable.
+ */
+#ifndef BBDUK_TEST_HOOKS_H
+#define BBDUK_TEST_HOOKS_H
+#include "bbduk_gpu.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+#define BBDUK_HOOK_FORCE_TILE   1   /* value != 0: every ktrim/kfilter batch of this handle takes the tile-synchronous fallback kernel */
+#define BBDUK_HOOK_BUCKET_BITS  2   /* before finalize / device build: log2 of the map's bucket count (4..32; 0 = sized by key count) */
+#define BBDUK_HOOK_LDS_BITS     3   /* before finalize: log2 bits of the LDS presence filter (0 = no filter, -1 = sized by key count) */
+#define BBDUK_HOOK_TIMING_MASK  4   /* -DBBDUK_TIMING_SWITCHES builds only: bit n deletes stage n of the scan (results become wrong) */
+#define BBDUK_HOOK_BIG_LAYOUT   5   /* before finalize / device build: value != 0 forces the HBM-resident map layout at any size */
+int  bbduk_test_hook(bbduk_handle* h, int32_t which, int64_t value);
+#ifdef __cplusplus
+}
+#endif
+#endif

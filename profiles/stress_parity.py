@@ -122,17 +122,16 @@ def main():
         try:
             o = Oracle(**okw)
             for r in refs: o.add_ref(r)
-            os.environ.pop("BBDUK_BUCKET_BITS", None); os.environ.pop("BBDUK_LDS_BITS", None)
+            hooks = {}
             squeeze = ""
             if build == "host" and rng.random() < 0.35 and o.stored_kmers > 64:
                 # crowd the map (about 3.4 keys per 4-way bucket: long overflow chains, continuation flags everywhere) and / or
                 # shrink or drop the LDS presence filter: the rarely taken lookup paths
                 import math
                 bb = max(4, math.ceil(math.log2(o.stored_kmers / 3.4)))
-                if rng.random() < 0.7: os.environ["BBDUK_BUCKET_BITS"] = str(bb); squeeze += " bucketbits=%d" % bb
-                if rng.random() < 0.6: lb = rng.choice([0, 10, 12]); os.environ["BBDUK_LDS_BITS"] = str(lb); squeeze += " ldsbits=%d" % lb
-            d = B.BBDuk(args, refs=refs, build=build)
-            os.environ.pop("BBDUK_BUCKET_BITS", None); os.environ.pop("BBDUK_LDS_BITS", None)
+                if rng.random() < 0.7: hooks[B.HOOK_BUCKET_BITS] = bb; squeeze += " bucketbits=%d" % bb
+                if rng.random() < 0.6: lb = rng.choice([0, 10, 12]); hooks[B.HOOK_LDS_BITS] = lb; squeeze += " ldsbits=%d" % lb
+            d = B.BBDuk(args, refs=refs, build=build, hooks=hooks)
             if squeeze: fam_count["squeezed"] = fam_count.get("squeezed", 0) + 1
             assert d.stored_kmers == o.stored_kmers, ("stored", d.stored_kmers, o.stored_kmers)
             if fam == "kmask":

@@ -206,3 +206,27 @@ def test_cli_rename_appends_scaffolds_and_hit_counts(tmp_path):
     assert r.returncode == 1 and "rename" in r.stderr
     r = run_cli(["in=" + f1, "k=23", "rename=t", "ref=adapters", "deviceingest=t"])
     assert r.returncode == 1 and "rename" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["ktrim", "kmask", "kfilter"])
+def test_cli_devices_shards_batches_and_allreduces_counters(tmp_path, mode):
+    """devices=0,0,0: three handles, every batch cut into three blocks of whole pairs, one counter all-reduce at the end
+    (bbduk_comm_create_local + bbduk_allreduce_counters_local).  Files, TSV, closing lines and stats equal the one-handle run."""
+    flags = {"ktrim": ["ktrim=r", "k=23", "mink=11", "hdist=1", "ref=adapters"], "kmask": ["ktrim=n", "k=23", "mink=11", "hdist=1", "ref=adapters"],
+             "kfilter": ["k=31", "hdist=1", "ref=phix"]}[mode]
+    ins = ["in=" + os.path.join(GOLD, "cli_c3_interleaved.fq"), "int=t"] if mode == "kfilter" else \
+          ["in=" + os.path.join(GOLD, "cli_c2_r1.fq"), "in2=" + os.path.join(GOLD, "cli_c2_r2.fq")]
+    got = {}
+    for tag, extra in (("one", ["batch=14"]), ("three", ["batch=14", "devices=0,0,0"])):
+        tsv, out, outm, st = (str(tmp_path / (tag + n)) for n in (".tsv", ".fq", ".m.fq", ".stats"))
+        r = run_cli(ins + ["tsv=" + tsv, "out=" + out, "outm=" + outm, "stats=" + st] + extra + flags)
+        assert r.returncode == 0, r.stderr
+        got[tag] = (open(tsv).read(), open(out).read(), open(outm).read(), open(st).read(), r.stderr)
+    assert got["one"] == got["three"]
+    assert "Input:" in got["three"][4] and len(got["three"][0]) > 0
+
+
+def test_cli_refuses_a_quote_in_a_gz_path(tmp_path):
+    r = run_cli(["in=" + str(tmp_path / "x';touch PWNED;'.fq.gz"), "ktrim=r", "k=23", "ref=adapters"])
+    assert r.returncode == 1 and not os.path.exists(os.path.join(ROOT, "PWNED"))

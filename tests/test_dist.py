@@ -61,3 +61,69 @@ def test_counter_allreduce_world2():
     b, off = B.synth_generate_host(B.synth_params(2), 0, n_pairs)
     o.process_batch(b, off, True, nthreads=4)
     assert got == o.counters().tolist()
+
+
+@pytest.mark.gpu
+def test_two_shards_through_the_hip_path_and_the_abi_allreduce():
+    """SURVEY 8e on the product path: contiguous blocks of whole pairs go through SEPARATE handles (two on device 0, plus one per
+    further visible device), each accumulates its own counters, and one bbduk_allreduce_counters_local (same-device handles
+    summed on the device, device leaders through RCCL) leaves every handle with the counters of a single-shot run -- which in
+    turn equal the oracle's."""
+    import torch
+    from oracle.oracle_ffi import Oracle
+    args, okw, ref = util.CONFIGS["c2"]
+    n_pairs = 20000
+    b, off = B.synth_generate_host(B.synth_params(2), 0, n_pairs)
+    o = Oracle(**okw); o.load_fasta(ref)
+    oa, oi, of = o.process_batch(b, off, True, nthreads=8)
+    single = B.BBDuk(args)
+    sa, si, sf = single.gpu.process_batch(b, off, True)
+    want = single.gpu.counters()
+    assert np.array_equal(want, o.counters()) and np.array_equal(sa, oa)
+    devices = [0, 0] + list(range(1, torch.cuda.device_count()))
+    duks = [B.BBDuk(args, device=d) for d in devices]
+    world = len(duks)
+    for r, d in enumerate(duks):
+        lo, hi = D.shard_pairs(n_pairs, r, world)
+        sb = b[off[2 * lo]:off[2 * hi]]; so = off[2 * lo:2 * hi + 1] - off[2 * lo]
+        ga, gi, gf = d.gpu.process_batch(sb, so, True)
+        assert np.array_equal(ga, oa[2 * lo:2 * hi]) and np.array_equal(gi, oi[2 * lo:2 * hi]) and np.array_equal(gf, of[2 * lo:2 * hi])
+        assert not np.array_equal(d.gpu.counters(), want)
+    gpus = [d.gpu for d in duks]
+    B.comm_create_local(gpus)
+    assert gpus[0].comm_size == len(set(devices))
+    B.allreduce_counters_local(gpus)
+    for g in gpus:
+        assert np.array_equal(g.counters(), want)
+    with pytest.raises(B.BBDukError):
+        B.comm_create_local(gpus)                      # already in a group
+    for d in duks:
+        d.close()
+    single.close()
+
+
+@pytest.mark.gpu
+def test_multi_process_form_of_the_communicator_world1():
+    """The one-process-per-GPU entry points (bbduk_comm_unique_id / bbduk_comm_create / bbduk_allreduce_counters[_device]) with
+    the only world a 1-GPU box can form: the all-reduce of one rank leaves the vector as it is."""
+    import torch
+    args, okw, ref = util.CONFIGS["c2"]
+    d = B.BBDuk(args)
+    b, off = B.synth_generate_host(B.synth_params(2), 0, 3000)
+    d.gpu.process_batch(b, off, True)
+    before = d.gpu.counters()
+    with pytest.raises(B.BBDukError):
+        d.gpu.allreduce_counters()                     # no communicator yet
+    uid = B.comm_unique_id()
+    assert len(uid) == 128
+    d.gpu.comm_create(1, 0, uid)
+    assert d.gpu.comm_size == 1
+    d.gpu.allreduce_counters()
+    assert np.array_equal(d.gpu.counters(), before) and before[0] == 6000
+    t = torch.from_numpy(before.copy()).cuda()
+    d.gpu.allreduce_counters_device(t, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(t.cpu().numpy(), before)
+    with pytest.raises(B.BBDukError):
+        d.gpu.comm_create(1, 0, uid)                   # one communicator per handle
+    d.close()

@@ -183,15 +183,11 @@ def test_tile_kernel_fallback_matches_wave_kernel(monkeypatch):
         b, off = B.synth_generate_host(B.synth_params(21, **kw), 0, 6000)
         o.reset_counters(); oa, oi, of = o.process_batch(b, off, True, nthreads=8)
         for force in (False, True):
-            if force:
-                monkeypatch.setenv("BBDUK_FORCE_TILE", "1")
-            else:
-                monkeypatch.delenv("BBDUK_FORCE_TILE", raising=False)
+            d.gpu.test_hook(B.HOOK_FORCE_TILE, int(force))
             d.gpu.reset_counters()
             ga, gi, gf = d.gpu.process_batch(b, off, True)
             assert np.array_equal(ga, oa) and np.array_equal(gi, oi) and np.array_equal(gf, of), (cfg, force)
             assert np.array_equal(d.gpu.counters(), o.counters()), (cfg, force)
-        monkeypatch.delenv("BBDUK_FORCE_TILE", raising=False)
         d.close()
 
 
@@ -234,10 +230,7 @@ def test_packed_format_device_pack_and_operators(monkeypatch):
         d_c = torch.from_numpy(codes.view(np.int32)).cuda(); d_u = torch.from_numpy(undef.view(np.int32)).cuda()
         d_off = torch.from_numpy(off).cuda()
         for force in (False, True):
-            if force:
-                monkeypatch.setenv("BBDUK_FORCE_TILE", "1")
-            else:
-                monkeypatch.delenv("BBDUK_FORCE_TILE", raising=False)
+            d.gpu.test_hook(B.HOOK_FORCE_TILE, int(force))
             d_a = torch.empty(n, dtype=torch.int32, device="cuda"); d_i = torch.empty(n, dtype=torch.int32, device="cuda")
             d_f = torch.empty(n, dtype=torch.uint8, device="cuda"); d_ctr = torch.zeros(d.gpu.counters_len, dtype=torch.int64, device="cuda")
             d.gpu.process_batch_packed_device(d_c, d_u, d_off, len(b), True, d_a, d_i, d_f, d_ctr)
@@ -884,17 +877,16 @@ def test_ksplit_long_reads(ci):
 @pytest.mark.parametrize("lds", ["0", "10", None])
 def test_crowded_map_and_reduced_filter(monkeypatch, lds):
     """The rarely taken lookup paths: a map squeezed to ~3.4 keys per 4-way bucket (long overflow chains, continuation flags
-    nearly everywhere) with the LDS presence filter dropped, tiny or as usual (BBDUK_BUCKET_BITS / BBDUK_LDS_BITS, read by
-    bbduk_finalize_table)."""
+    nearly everywhere) with the LDS presence filter dropped, tiny or as usual (bbduk_test_hook BUCKET_BITS / LDS_BITS, honoured
+    by bbduk_finalize_table)."""
     import math
     for cfg in ("c2", "c3", "c1"):
         args, okw, ref = util.CONFIGS[cfg]
         o = Oracle(**okw); o.load_fasta(ref)
-        monkeypatch.setenv("BBDUK_BUCKET_BITS", str(max(4, math.ceil(math.log2(o.stored_kmers / 3.4)))))
+        hooks = {B.HOOK_BUCKET_BITS: max(4, math.ceil(math.log2(o.stored_kmers / 3.4)))}
         if lds is not None:
-            monkeypatch.setenv("BBDUK_LDS_BITS", lds)
-        d = B.BBDuk(args)
-        monkeypatch.delenv("BBDUK_BUCKET_BITS"); monkeypatch.delenv("BBDUK_LDS_BITS", raising=False)
+            hooks[B.HOOK_LDS_BITS] = int(lds)
+        d = B.BBDuk(args, hooks=hooks)
         assert d.stored_kmers == o.stored_kmers
         kw = dict(contam=B.read_fasta(util.PHIX)[0][1], contam_frac=0.05) if "phix" in args else {}
         b, off = B.synth_generate_host(B.synth_params(77, **kw), 0, 20000)
@@ -957,6 +949,10 @@ def test_abi_error_codes():
     assert call(L.bbduk_ktrim_batch, b3, off3, 3, 1) == -1                       # an odd number of reads cannot be pairs
     shifted = off + 1
     assert call(L.bbduk_ktrim_batch, b, shifted, 2, 0) == -1                     # offsets[0] != 0
+    bad = off.copy(); bad[1] = bad[2] + 5                                         # not ascending: read 1 would get a negative length
+    assert call(L.bbduk_ktrim_batch, b, bad, 2, 0) == -1 and b"ascend" in L.bbduk_last_error(g.h)
+    bad = off.copy(); bad[1] = -3
+    assert call(L.bbduk_ktrim_batch, b, bad, 2, 0) == -1
     nid = np.zeros(2, np.int32); mi = np.zeros((2, 4), np.int32); mc = np.zeros((2, 4), np.int32)
     assert L.bbduk_kfilter_batch_matches(g.h, b.ctypes.data, off.ctypes.data, 2, 0, a.ctypes.data, ids.ctypes.data, fl.ctypes.data, 4,
                                          nid.ctypes.data, mi.ctypes.data, mc.ctypes.data) == -2     # match lists need a findBestMatch handle
@@ -965,6 +961,19 @@ def test_abi_error_codes():
     assert call(L.bbduk_ktrim_batch, b, off, 0, 0) == 0                          # an empty batch is fine
     assert call(L.bbduk_ktrim_batch, b, off, 2, 0) == 0 and a[0] == len(reads[0]) - 12 and a[1] == 0     # and the handle still works
     g.close(); g.close()                                                          # closing twice is harmless
+    # scaffold ids index the counter vector on the device: anything outside 1..numScaffolds-1 is refused at upload
+    g2 = B.BBDukGpu(host.params(0))
+    ns = host.num_scaffolds
+    k1 = np.array([5, 6], np.int64)
+    for badv in (0, -1, ns, ns + 7):
+        v = np.array([1, badv], np.int32)
+        assert L.bbduk_upload_pairs(g2.h, k1.ctypes.data, v.ctypes.data, 2) == -1 and b"scaffold id" in L.bbduk_last_error(g2.h)
+        assert L.bbduk_upload_table_way(g2.h, 0, 7, k1.ctypes.data, v.ctypes.data, 2, None, None, 0) == -1
+        assert L.bbduk_upload_table_way(g2.h, 0, 7, None, None, 0, k1.ctypes.data, v.ctypes.data, 2) == -1
+    v = np.array([1, ns - 1], np.int32)
+    assert L.bbduk_upload_pairs(g2.h, k1.ctypes.data, v.ctypes.data, 2) == 0      # a refused call stored nothing
+    g2.finalize_table(); assert g2.table_size == 2
+    g2.close()
     host.close()
     d = B.BBDuk("k=23 rename=t", refs=[b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCAC"])
     for cap in (0, 65):                                                           # max_ids outside 1..64

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, s), s
     # and the list itself matches the headers
     decl = set()
-    for hdr in ("bbduk_gpu.h", "bbduk_host.h"):
+    for hdr in ("bbduk_gpu.h", "bbduk_host.h", "bbduk_test_hooks.h"):
         txt = open(os.path.join(util.ROOT, "include", hdr)).read()
         decl |= set(re.findall(r"\b(bbduk_[a-z0-9_]+)\s*\(", txt))
     decl -= {"bbduk_params", "bbduk_synth_params", "bbduk_handle", "bbduk_host"}
