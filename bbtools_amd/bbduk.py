@@ -58,7 +58,7 @@ GPU_SYMBOLS = ["bbduk_abi_version", "bbduk_create", "bbduk_destroy", "bbduk_last
                "bbduk_synth_generate_device", "bbduk_synth_generate_host",
                "bbduk_comm_unique_id", "bbduk_comm_create", "bbduk_comm_create_local", "bbduk_comm_destroy", "bbduk_comm_size",
                "bbduk_allreduce_counters", "bbduk_allreduce_counters_device", "bbduk_allreduce_counters_local",
-               "bbduk_test_hook"]
+               "bbduk_test_hook", "bbduk_build_begin", "bbduk_build_add_device", "bbduk_build_end"]
 HOST_SYMBOLS = ["bbduk_host_parse", "bbduk_host_destroy", "bbduk_host_add_ref", "bbduk_host_load_fasta",
                 "bbduk_host_load_refs", "bbduk_host_build_index", "bbduk_host_index_pairs",
                 "bbduk_host_num_scaffolds", "bbduk_host_scaffold_info", "bbduk_host_params", "bbduk_host_upload_index", "bbduk_host_build_on_device"]
@@ -212,6 +212,9 @@ def lib():
     L.bbduk_host_build_on_device.argtypes = [vp, vp]
     L.bbduk_build_table_device.argtypes = [vp, vp, vp, i32, i32, i32]
     L.bbduk_test_hook.argtypes = [vp, i32, i64]
+    L.bbduk_build_begin.argtypes = [vp, i64, i32, i32]
+    L.bbduk_build_add_device.argtypes = [vp, vp, vp, i32, i32]
+    L.bbduk_build_end.argtypes = [vp]
     L.bbduk_comm_unique_id.argtypes = [vp]
     L.bbduk_comm_create.argtypes = [vp, i32, i32, vp]
     L.bbduk_comm_create_local.argtypes = [C.POINTER(vp), i32]
@@ -351,6 +354,17 @@ class BBDukGpu:
 
     def finalize_table(self):
         self._check(lib().bbduk_finalize_table(self.h), "finalize_table")
+
+    # streaming device-side build: whole scaffolds already in HBM, chunk by chunk
+    def build_begin(self, max_keys: int, hdist: int = 0, hdist2: int = 0):
+        self._check(lib().bbduk_build_begin(self.h, max_keys, hdist, hdist2), "build_begin")
+
+    def build_add_device(self, d_refs, ref_offsets, first_id: int):
+        ref_offsets = np.ascontiguousarray(ref_offsets, np.int64)
+        self._check(lib().bbduk_build_add_device(self.h, d_refs.data_ptr(), ref_offsets.ctypes.data, len(ref_offsets) - 1, first_id), "build_add_device")
+
+    def build_end(self):
+        self._check(lib().bbduk_build_end(self.h), "build_end")
 
     @property
     def table_size(self) -> int:

@@ -102,6 +102,91 @@ __device__ __forceinline__ uint32_t filt_test(const uint32_t* s_filt, uint32_t m
 // 0x8000 in every 16-bit lane of v that is zero (may also flag lanes above a true zero lane: callers verify)
 __device__ __forceinline__ uint64_t zero16(uint64_t v) { return (v - 0x0001000100010001ULL) & ~v & 0x8000800080008000ULL; }
 
+// ---- big layout (HBM-resident maps, KParams::big) -------------------------------------------------------------------
+// Where a key lives must be a function of the key alone (the build sees only keys), yet consecutive k-mers of a read
+// should land in the same 64-byte HBM sector.  A k-mer key is max(kmer, rkmer) with its middle base(s) masked
+// (BBDukIndexMod.java:532-544), so its two clean halves of H = (k - midMaskLen)/2 bases are all it has in common with its
+// neighbours.  Candidates: the W = H-m+1 gapped (m+m)-mers  G(p) = key[p, p+m) ++ key[p+D, p+D+m),  D = k-H  (one m-mer in
+// each half, both clear of the masked middle).  The reverse complement of the key holds rc(G(p)) at position H-m-p, so
+//     h(p) = gap_f(G(p)) + gap_f(rc(G(p)))
+// is the same multiset whichever strand became the key, and  hmin = min_p h(p)  picks the key's line.  Windows i and i+1 of a
+// read share W-1 of their candidates: a read of 120 31-mers touches ~31 lines instead of 120 (m = 9, W = 7).
+// Per-orientation mix of a gapped-mer given as its two m-mers (m <= 12: they fit 24 bits), then an avalanche: the ORDER of
+// these values decides which candidate wins, so they should look random.
+__host__ __device__ __forceinline__ uint32_t gap_f(uint32_t l, uint32_t r) {
+    uint32_t x = l * 0x9E3779B1u + r * 0x85EBCA6Bu;
+    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 13;
+    return x;
+}
+// minima are biased towards 0: re-mix before the multiply-shift that maps onto [0, nlines)
+__host__ __device__ __forceinline__ uint32_t gap_line(uint32_t hmin, uint32_t nlines) {
+    uint32_t y = hmin * 0x297A2D39u; y ^= y >> 15; y *= 0xC2B2AE35u; y ^= y >> 16;
+    return (uint32_t)(((uint64_t)y * (uint64_t)nlines) >> 32);
+}
+__host__ __device__ __forceinline__ uint64_t rcomp_hd(uint64_t kmer, int len) {      // dev_rcomp, host and device
+    uint64_t x = ~kmer;
+    x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+    x = ((x >> 8) & 0x00FF00FF00FF00FFULL) | ((x & 0x00FF00FF00FF00FFULL) << 8);
+    x = ((x >> 16) & 0x0000FFFF0000FFFFULL) | ((x & 0x0000FFFF0000FFFFULL) << 16);
+    x = (x >> 32) | (x << 32);
+    return x >> (64 - 2 * len);
+}
+struct BigGeom { int32_t k, m, W, H, D; uint32_t nlines; uint64_t middleMask; };
+// hmin of a full-length key value (the slow, exact form: every kernel's generic path, the build, the host).  A = the value,
+// B = its reverse complement with the same middle mask: {A, B} = {kmer & mm, rkmer & mm} whichever one the key is.
+__host__ __device__ __forceinline__ uint32_t gap_hmin_value(const BigGeom& G, const uint64_t A) {
+    const uint64_t B = rcomp_hd(A, G.k) & G.middleMask;
+    const uint32_t mk = (1u << (2 * G.m)) - 1u;
+    uint32_t best = 0xFFFFFFFFu;
+    for (int p = 0; p < G.W; p++) {
+        const int q = G.H - G.m - p;
+        const uint32_t la = (uint32_t)(A >> (2 * (G.k - G.m - p))) & mk, ra = (uint32_t)(A >> (2 * (G.k - G.D - G.m - p))) & mk;
+        const uint32_t lb = (uint32_t)(B >> (2 * (G.k - G.m - q))) & mk, rb = (uint32_t)(B >> (2 * (G.k - G.D - G.m - q))) & mk;
+        const uint32_t h = gap_f(la, ra) + gap_f(lb, rb);
+        best = h < best ? h : best;
+    }
+    return best;
+}
+// home word (8 * line + word in line) of any key (with its length bit): full-length keys by their gapped minimizer, the short
+// k-mers of mink (other lengths) by a plain hash
+__host__ __device__ __forceinline__ uint64_t big_home_word(const BigGeom& G, const uint64_t key, const uint32_t ma, const uint32_t mb) {
+    const uint64_t v = strip_len(key);
+    const uint32_t h = (key >> (2 * G.k)) == 1ULL ? gap_hmin_value(G, v) : (ma ^ 0x5BD1E995u);
+    return 8ULL * gap_line(h, G.nlines) + (mb >> 29);
+}
+// i-th word of the probe sequence that starts at `home`: the line's words cyclically, then the next line
+__host__ __device__ __forceinline__ uint64_t big_probe_word(const uint64_t home, const uint32_t i, const uint32_t nlines) {
+    uint64_t line = (home >> 3) + (i >> 3);
+    if (line >= nlines) line -= nlines;
+    return 8ULL * line + (((uint32_t)home + i) & 7u);
+}
+__device__ __forceinline__ BigGeom big_geom(const KParams& P) { BigGeom G; G.k = P.k; G.m = P.gm; G.W = P.gW; G.H = P.gH; G.D = P.gD; G.nlines = P.bigLines; G.middleMask = P.middleMask; return G; }
+__device__ __forceinline__ int big_id_at(const KParams& P, const uint64_t slot) {
+    return P.bigIdBytes == 2 ? (int)reinterpret_cast<const uint16_t*>(P.bigIds)[slot] : (int)reinterpret_cast<const uint32_t*>(P.bigIds)[slot];
+}
+// lookup from a given home word; t0 = its tags
+__device__ __forceinline__ int big_find_from(const KParams& P, const uint64_t key, const uint32_t ma, const uint64_t home, uint64_t t) {
+    const uint64_t pat = (uint64_t)tag_of(ma) * 0x0001000100010001ULL;
+    uint64_t word = home;
+    for (uint32_t i = 0;;) {
+        uint64_t cand = zero16((t & TAG_FPS) ^ pat);
+        while (cand) {
+            const int way = (__ffsll((unsigned long long)cand) - 1) >> 4;
+            if (P.bigKeys[4ULL * word + way] == key) return big_id_at(P, 4ULL * word + way);
+            cand &= cand - 1;
+        }
+        if (!(t & TAG_CONT)) return -1;
+        i++;
+        word = big_probe_word(home, i, P.bigLines);
+        t = P.tags[word];
+    }
+}
+__device__ __forceinline__ int big_find(const KParams& P, const uint64_t key, const uint32_t ma, const uint32_t mb) {
+    const uint64_t home = big_home_word(big_geom(P), key, ma, mb);
+    return big_find_from(P, key, ma, home, P.tags[home]);
+}
+
 // map lookup with the mixes already computed: id (>0) of the key, or -1.  t0 = tags of the home bucket.
 __device__ __forceinline__ int table_find_t(const KParams& P, uint64_t key, uint32_t ma, uint32_t mb, uint64_t t0) {
     uint32_t b = bucket_of(mb, P.bucketBits);
@@ -121,6 +206,7 @@ __device__ __forceinline__ int table_find_t(const KParams& P, uint64_t key, uint
     }
 }
 __device__ __forceinline__ int table_find_m(const KParams& P, uint64_t key, uint32_t ma, uint32_t mb) {
+    if (P.big) return big_find(P, key, ma, mb);
     return table_find_t(P, key, ma, mb, P.tags[bucket_of(mb, P.bucketBits)]);
 }
 __device__ __forceinline__ int table_get(const KParams& P, uint64_t key) { const uint64_t v = strip_len(key); return table_find_m(P, key, mix_a(v), mix_b(v)); }
@@ -172,7 +258,7 @@ __device__ int get_value(const KParams& P, uint64_t kmer, uint64_t rkmer, uint64
     return id;
 }
 __device__ __noinline__ int get_value_expand(const KParams& P, uint64_t kmer, uint64_t rkmer, uint64_t lengthMask, int len, int qh) {
-    return get_value<2>(P, kmer, rkmer, lengthMask, len, qh);
+    return get_value<3>(P, kmer, rkmer, lengthMask, len, qh);       // qhdist <= 3 (bbduk_create refuses more)
 }
 // index.getValue(kmer, rkmer, lengthMask, qPos, len, qHDist) as a ref: filtered fast path when there is no query expansion
 template <bool GENERAL>
@@ -328,6 +414,7 @@ struct ReadScan {
     int ref;                            // ref (see ref_to_id) of the hit whose id the reference reports
     int shortFl, shortLl;               // short k-mer scan: first / last hit lane (length index); shortFl<0: none
     int candSlot; uint32_t candKeyLo, candKeyHi;   // candidate mode: first unverified fingerprint match (slot, key)
+    uint32_t candWord;                  // big layout: the candidate's tag word (candSlot is then its way 0..3)
     int hasN;                           // undefined base inside [start,stop)?  1/0, or -1 = not known yet (forbidNs only)
     int maxBad;                         // kfilter: this read's maxBadKmers (mkf) or minCoveredBases (mcf)
 };
@@ -408,14 +495,14 @@ __device__ __forceinline__ void finish_read(const KParams& P, const int L, const
 
 struct ReadWin { int first, stop, start, base0; bool on, full, hasN; };   // wave-uniform per read
 
-template <bool FORBIDN, bool GENERAL>
+template <bool FORBIDN, bool GENERAL, bool BIG = false>
 __device__ __forceinline__ void win_init(const KParams& P, const Planes& Q, const ReadScan& R, ReadWin& W, const int lane) {
     W.start = R.start; W.stop = R.stop; W.base0 = R.base0;
     W.first = max(R.start, P.k - 1);                             // i>=minlen (minlen=k-1)
     W.on = R.scan && W.first < W.stop;
-    W.hasN = false;                                              // undefined base inside [start,stop)? (forbidNs only)
-    if (FORBIDN && P.forbidNs && W.on && R.hasN >= 0) W.hasN = R.hasN != 0;
-    else if (FORBIDN && P.forbidNs && W.on) {
+    W.hasN = false;                                              // undefined base inside [start,stop)? (forbidNs; big layout: always)
+    if (((FORBIDN && P.forbidNs) || BIG) && W.on && R.hasN >= 0) W.hasN = R.hasN != 0;
+    else if (((FORBIDN && P.forbidNs) || BIG) && W.on) {
         const int b0 = W.base0 + W.start, b1 = W.base0 + W.stop;
         uint32_t acc = 0;
         for (int w = (b0 >> 5) + lane; w <= ((b1 - 1) >> 5); w += 64) {
@@ -450,7 +537,7 @@ __device__ __forceinline__ void windows2(const KParams& P, const Planes& Q, cons
         }
         ok[0] = on & (i < W.stop);
         ok[1] = on & (i + 1 < W.stop);
-        if (FORBIDN && W.hasN) {                                 // the read holds an undefined base somewhere: patch the few windows that see it
+        if (FORBIDN && P.forbidNs && W.hasN) {                   // the read holds an undefined base somewhere: patch the few windows that see it
             const int nidx = min(W.base0 - k + 1 + i, Q.T);      // bit t <=> base i-k+1+t undefined
             const uint32_t nw = __builtin_amdgcn_alignbit(Q.nm[(nidx >> 5) + 1], Q.nm[nidx >> 5], nidx);
             if (__ballot(nw != 0u) != 0ULL) {
@@ -519,6 +606,11 @@ __device__ __forceinline__ void lookup4(const KParams& P, const uint32_t* s_filt
     if (TSW(P, 2)) {                                             // experiment: keys and hashes only
 #pragma unroll
         for (int s = 0; s < 4; s++) ref[s] = (p[s] && ma[s] == 0x12345u && mb[s] == 0x54321u) ? 0 : -1;
+        return;
+    }
+    if (P.big) {                                                  // HBM-resident layout: the exact generic lookup (the first-hit scans of the
+#pragma unroll                                                    // plain configurations have their own fast form, cand_probe4<.., BIG>)
+        for (int s = 0; s < 4; s++) ref[s] = p[s] ? big_find(P, key[s], ma[s], mb[s]) : -1;
         return;
     }
     if (P.ldsBits) {                                              // four presence bits, read together
@@ -639,6 +731,99 @@ __device__ __forceinline__ void cand_resolve4(const KParams& P, const Cand4& C, 
             else {
                 const int id = table_find_t(P, C.key[s] | P.kmask, C.ma[s], C.mb[s], C.t[s]);
                 ref[s] = id > 0 ? -3 - id : -1;                    // <= -4: a verified id, nothing left to check
+            }
+        }
+    }
+}
+
+// ---- big layout, fast form of the candidate probe (specialised kernels, plain k >= 16 configurations) -----------------
+// value of the next lane (lane+1); lane 63 gets `fill`.  wave_shl:1 (DPP, gfx9): one instruction, no LDS crossbar.
+__device__ __forceinline__ uint32_t next_lane(const uint32_t v, const uint32_t fill) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130, 0xF, 0xF, false);
+}
+// Sliding minimum over W consecutive POSITIONS of per-position values held two per lane (e = position 2l, o = 2l+1):
+// me / mo = min over positions [2l, 2l+W) / [2l+1, 2l+1+W).  Lanes near the top of the wave see `fill` (= +inf) beyond it.
+__device__ __forceinline__ void window_min(const int W, const uint32_t e, const uint32_t o, uint32_t& me, uint32_t& mo) {
+    const uint32_t INF = 0xFFFFFFFFu;
+    if (W == 7) {                                                 // k = 31: H = 15, m = 9
+        const uint32_t s1e = min(e, o), s1o = min(o, next_lane(e, INF));                  // 2 positions
+        const uint32_t s2e = min(s1e, next_lane(s1e, INF)), s2o = min(s1o, next_lane(s1o, INF));   // 4 positions
+        me = min(s2e, next_lane(s2o, INF));                       // [2l,2l+4) + [2l+3,2l+7)
+        mo = min(s2o, next_lane(next_lane(s2e, INF), INF));       // [2l+1,2l+5) + [2l+4,2l+8)
+        return;
+    }
+    uint32_t ce = e, co = o; me = e; mo = o;
+    for (int d = 1; d < W; d++) {                                 // shift by one position: (e, o) <- (o, next lane's e)
+        const uint32_t ne = co, no = next_lane(ce, INF);
+        ce = ne; co = no;
+        me = min(me, ce); mo = min(mo, co);
+    }
+}
+// h(0) of the window whose forward / reverse-complement k-mers are kmer / rk: its left-most gapped-mer, read from kmer, and the
+// reverse complement of that gapped-mer, which is the right-most candidate of rk (see "big layout" above)
+__device__ __forceinline__ uint32_t gap_h0(const KParams& P, const uint64_t kmer, const uint64_t rk) {
+    const uint32_t mk = (1u << (2 * P.gm)) - 1u;
+    const uint32_t la = (uint32_t)(kmer >> (2 * (P.k - P.gm))) & mk, ra = (uint32_t)(kmer >> (2 * (P.k - P.gD - P.gm))) & mk;
+    const uint32_t lb = (uint32_t)(rk >> (2 * (P.k - P.gH))) & mk, rb = (uint32_t)rk & mk;
+    return gap_f(la, ra) + gap_f(lb, rb);
+}
+// Candidate probe on the big layout.  Slots 0/1 = read A's positions 2l / 2l+1, slots 2/3 = read B's.  The line of a window comes
+// from the minimum over W consecutive per-position values, shared across lanes (window_min) instead of recomputed per key; that
+// is exact only for windows whose kmer / rkmer are true reverse complements, so windows that see an undefined base (nf) are
+// flagged and looked up by the generic exact path in cand_resolve4_big.  Windows at the top of the block (position >= 128 - W
+// within it) lack their successors: the caller advances by BIG_STEP positions and ignores them.
+#define BIG_STEP 120
+struct Cand4Big { uint64_t key[4], t[4]; uint32_t ma[4], mb[4], word[4]; uint64_t hm[4]; bool nf[4]; };
+template <bool NOMM>
+__device__ __forceinline__ uint64_t cand_probe4_big(const KParams& P, const uint64_t* kmer, const uint64_t* rk, const bool* nf, Cand4Big& C) {
+    const uint32_t mmLo = (uint32_t)P.middleMask, mmHi = (uint32_t)(P.middleMask >> 32);
+    uint32_t h0[4], hw[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const uint64_t mx = kmer[s] > rk[s] ? kmer[s] : rk[s];
+        const uint32_t klo = NOMM ? (uint32_t)mx : ((uint32_t)mx & mmLo), khi = NOMM ? (uint32_t)(mx >> 32) : ((uint32_t)(mx >> 32) & mmHi);
+        C.key[s] = ((uint64_t)khi << 32) | klo;
+        C.ma[s] = klo * HA0 + khi * HA1;
+        C.mb[s] = klo * HB0 + khi * HB1;
+        h0[s] = gap_h0(P, kmer[s], rk[s]);
+        C.nf[s] = nf[s];
+    }
+    window_min(P.gW, h0[0], h0[1], hw[0], hw[1]);
+    window_min(P.gW, h0[2], h0[3], hw[2], hw[3]);
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        C.word[s] = 8u * gap_line(hw[s], P.bigLines) + (C.mb[s] >> 29);
+        C.t[s] = P.tags[C.word[s]];                                // four gathers in flight; neighbours share 64-byte sectors
+    }
+    uint64_t any = 0;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const uint32_t fp = tag_of(C.ma[s]), tlo = (uint32_t)C.t[s], thi = (uint32_t)(C.t[s] >> 32);
+        C.hm[s] = __ballot((tlo & 0xFFFFu) == fp) | __ballot((tlo >> 16) == fp) | __ballot((thi & 0xFFFFu) == fp) |
+                  __ballot((thi >> 16) == fp) | __ballot((int32_t)thi < 0) | __ballot(nf[s]);
+        any |= C.hm[s];
+    }
+    return any;
+}
+// ref: way (0..3) of the first fingerprint match in C.word (unverified), -3-id for a hit verified here (chain walk, or the exact
+// lookup of a window with an undefined base), -1 = certainly absent
+__device__ __forceinline__ void cand_resolve4_big(const KParams& P, const Cand4Big& C, int* ref) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        ref[s] = -1;
+        if (C.hm[s] == 0ULL) continue;                            // nothing flagged in this slot (wave-uniform)
+        if (C.nf[s]) {                                            // kmer / rkmer are not each other's reverse complement: the key's own line
+            const int id = big_find(P, C.key[s] | P.kmask, C.ma[s], C.mb[s]);
+            ref[s] = id > 0 ? -3 - id : -1;
+            continue;
+        }
+        const uint32_t fp = tag_of(C.ma[s]);
+        const uint64_t cand = zero16((C.t[s] & TAG_FPS) ^ ((uint64_t)fp * 0x0001000100010001ULL));
+        if (cand != 0ULL || (C.t[s] & TAG_CONT)) {
+            if (!(C.t[s] & TAG_CONT)) ref[s] = (__ffsll((unsigned long long)cand) - 1) >> 4;
+            else {
+                const int id = big_find_from(P, C.key[s] | P.kmask, C.ma[s], (uint64_t)C.word[s], C.t[s]);
+                ref[s] = id > 0 ? -3 - id : -1;
             }
         }
     }
@@ -796,18 +981,19 @@ __device__ __forceinline__ void main_scan_pair(const KParams& P, const Planes& Q
 // Candidate form of the pair scan (ktrim=r, kfilter with maxbadkmers=0: only the first hit of a read matters): stop
 // at the first fingerprint match of each read WITHOUT fetching its key; the caller verifies the candidates of a whole
 // sub-tile in one overlapped batch (one lane per read) and falls back to main_scan_pair for the rare impostor.
-template <bool FORBIDN, bool GENERAL, bool NOMM>
+template <bool FORBIDN, bool GENERAL, bool NOMM, bool BIG = false>
 __device__ __forceinline__ void main_scan_pair_cand(const KParams& P, const Planes& Q, ReadScan& A, ReadScan& B, const int lane) {
     ReadWin WA, WB;
-    win_init<FORBIDN, GENERAL>(P, Q, A, WA, lane);
-    win_init<FORBIDN, GENERAL>(P, Q, B, WB, lane);
+    win_init<FORBIDN, GENERAL, BIG>(P, Q, A, WA, lane);
+    win_init<FORBIDN, GENERAL, BIG>(P, Q, B, WB, lane);
     int ibA = WA.first, ibB = WB.first;
     bool onA = WA.on, onB = WB.on;
     A.candSlot = -1; B.candSlot = -1;
+    constexpr int STEP = BIG ? BIG_STEP : 128;                   // big layout: the top lanes' windows lack their successors (cand_probe4_big)
     // Lanes past a read's end look up whatever lies behind it in the planes.  When every window of the read is plain
     // nothing masks them: positions grow with the lane, so a first candidate at a position >= stop means the read has
     // none.  Reads with cut or reset windows (restrictRight, an undefined base) mask their ballots with `ok` instead.
-    const bool plainA = WA.full && !(FORBIDN && WA.hasN), plainB = WB.full && !(FORBIDN && WB.hasN);
+    const bool plainA = WA.full && !((FORBIDN || BIG) && WA.hasN), plainB = WB.full && !((FORBIDN || BIG) && WB.hasN);
     while (onA || onB) {
         uint64_t kmer[4], rk[4]; bool ok[4]; int ref[4]; Cand4 C;
         windows2<FORBIDN, GENERAL>(P, Q, WA, ibA + 2 * lane, onA, kmer, rk, ok);
@@ -827,13 +1013,32 @@ __device__ __forceinline__ void main_scan_pair_cand(const KParams& P, const Plan
             if (u0 == 0x12345u && u1 == 99u) kmer[0] ^= 1;
         }
 #endif
-        if (cand_probe4<GENERAL, NOMM, true>(P, Q.filt, kmer, rk, C) == 0ULL) {   // the common block: nothing to look at
-            if (onA) { ibA += 128; onA = ibA < WA.stop; }
-            if (onB) { ibB += 128; onB = ibB < WB.stop; }
+        Cand4Big CB; uint64_t anyFlag; const uint64_t* key;
+        if constexpr (BIG) {
+            bool nf[4] = {false, false, false, false};
+            if (WA.hasN | WB.hasN) {                                 // which windows see an undefined base (bit t of nw <=> base i-k+1+t)
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const ReadWin& W = r ? WB : WA;
+                    if (!W.hasN) continue;
+                    const int nidx = min(W.base0 - P.k + 1 + (r ? ibB : ibA) + 2 * lane, Q.T);
+                    const uint32_t nw = __builtin_amdgcn_alignbit(Q.nm[(nidx >> 5) + 1], Q.nm[nidx >> 5], nidx);
+                    const uint32_t km = (P.k >= 32) ? ~0u : ((1u << P.k) - 1u);
+                    nf[2 * r] = ok[2 * r] && (nw & km) != 0u; nf[2 * r + 1] = ok[2 * r + 1] && ((nw >> 1) & km) != 0u;
+                }
+            }
+            anyFlag = cand_probe4_big<NOMM>(P, kmer, rk, nf, CB);
+            key = CB.key;
+        } else {
+            anyFlag = cand_probe4<GENERAL, NOMM, true>(P, Q.filt, kmer, rk, C);
+            key = C.key;
+        }
+        if (anyFlag == 0ULL) {                                       // the common block: nothing to look at
+            if (onA) { ibA += STEP; onA = ibA < WA.stop; }
+            if (onB) { ibB += STEP; onB = ibB < WB.stop; }
             continue;
         }
-        cand_resolve4(P, C, ref);
-        const uint64_t* key = C.key;
+        if constexpr (BIG) cand_resolve4_big(P, CB, ref); else cand_resolve4(P, C, ref);
 #pragma unroll
         for (int r = 0; r < 2; r++) {
             ReadScan& R = r ? B : A;
@@ -846,16 +1051,17 @@ __device__ __forceinline__ void main_scan_pair_cand(const KParams& P, const Plan
             const int le = me ? __ffsll((unsigned long long)me) - 1 : 64, lo = mo ? __ffsll((unsigned long long)mo) - 1 : 64;
             const int h = (2 * lo + 1 < 2 * le) ? 1 : 0;
             const int l = h ? lo : le;
-            if ((me | mo) && ib + 2 * l + h < stopR) {            // first candidate in position order: lane l, parity h
+            if ((me | mo) && ib + 2 * l + h < stopR && (!BIG || 2 * l + h < BIG_STEP)) {   // first candidate in position order: lane l, parity h
                 const int rs = h ? ref[2 * r + 1] : ref[2 * r];
                 const uint64_t ks = h ? key[2 * r + 1] : key[2 * r];
                 R.candSlot = __builtin_amdgcn_readlane(rs, l);
+                if constexpr (BIG) { const uint32_t ws = h ? CB.word[2 * r + 1] : CB.word[2 * r]; R.candWord = (uint32_t)__builtin_amdgcn_readlane((int)ws, l); }
                 R.candKeyLo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ks, l);
                 R.candKeyHi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ks >> 32), l);
                 R.iFirst = ib + 2 * l + h;
                 on = false;
             } else {
-                ib += 128;
+                ib += STEP;
                 on = ib < stopR;
             }
         }
@@ -1164,18 +1370,68 @@ __device__ __forceinline__ int ref_code(uint8_t b) {              // dna/AminoAc
 }
 __device__ __forceinline__ uint64_t hash64(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; }
 
-__device__ __forceinline__ void scratch_insert(uint64_t* __restrict__ skeys, int32_t* __restrict__ sids, const uint64_t cmask,
-                                               const uint64_t key, const int id, unsigned long long* __restrict__ distinct) {
-    uint64_t hslot = hash64(key) & cmask;
+// Where the build kernels put a (key, id): the open-addressed scratch set of the two-pass build (cache-resident layout), or the
+// final big-layout table itself, in place (an HBM-resident map leaves no room for a second copy).  Both keep the SMALLEST id of
+// a key: ids ascend in file order, so that is the first scaffold that holds the k-mer (HashArray.setIfNotPresent).
+struct Sink {
+    int32_t big;
+    uint64_t* skeys; int32_t* sids; uint64_t cmask;              // scratch set
+    uint64_t* tags; uint64_t* keys; void* ids; int32_t idBytes; BigGeom G;     // big layout
+    unsigned long long* distinct;                                // [0] distinct keys, [1] != 0: a key found no slot (table full)
+};
+__device__ __forceinline__ void scratch_insert(const Sink& S, const uint64_t key, const int id) {
+    uint64_t hslot = hash64(key) & S.cmask;
     for (;;) {
-        const unsigned long long prev = atomicCAS((unsigned long long*)&skeys[hslot], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+        const unsigned long long prev = atomicCAS((unsigned long long*)&S.skeys[hslot], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
         if (prev == EMPTY_KEY || prev == key) {
-            atomicMin(&sids[hslot], id);
-            if (prev == EMPTY_KEY) atomicAdd(distinct, 1ULL);
+            atomicMin(&S.sids[hslot], id);
+            if (prev == EMPTY_KEY) atomicAdd(S.distinct, 1ULL);
             return;
         }
-        hslot = (hslot + 1) & cmask;
+        hslot = (hslot + 1) & S.cmask;
     }
+}
+__device__ __forceinline__ void big_id_min(const Sink& S, const uint64_t slot, const int id) {
+    if (S.idBytes == 4) {
+        uint32_t* p = reinterpret_cast<uint32_t*>(S.ids) + slot;
+        if (*reinterpret_cast<volatile uint32_t*>(p) > (uint32_t)id) atomicMin(p, (uint32_t)id);
+        return;
+    }
+    uint32_t* wp = reinterpret_cast<uint32_t*>(S.ids) + (slot >> 1);            // two 16-bit ids per word
+    const int sh = (int)(slot & 1ULL) * 16;
+    for (;;) {
+        const uint32_t old = *reinterpret_cast<volatile uint32_t*>(wp);
+        if (((old >> sh) & 0xFFFFu) <= (uint32_t)id) return;
+        const uint32_t nw = (old & ~(0xFFFFu << sh)) | ((uint32_t)id << sh);
+        if (atomicCAS(wp, old, nw) == old) return;
+    }
+}
+#define BIG_MAX_PROBE_WORDS 4096                                  // 512 lines: a key that finds no slot that far has met a full table
+__device__ __forceinline__ void big_insert(const Sink& S, const uint64_t key, const int id) {
+    const uint64_t v = strip_len(key);
+    const uint32_t ma = mix_a(v), mb = mix_b(v);
+    const uint64_t home = big_home_word(S.G, key, ma, mb);
+    const unsigned long long fp = (unsigned long long)tag_of(ma);
+    for (uint32_t i = 0; i < BIG_MAX_PROBE_WORDS; i++) {
+        const uint64_t word = big_probe_word(home, i, S.G.nlines);
+        for (int way = 0; way < 4; way++) {
+            const uint64_t slot = 4ULL * word + way;
+            unsigned long long prev = *reinterpret_cast<volatile unsigned long long*>(&S.keys[slot]);
+            if (prev == EMPTY_KEY) prev = atomicCAS((unsigned long long*)&S.keys[slot], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+            if (prev == EMPTY_KEY) {                              // claimed: fingerprint, id, count
+                atomicOr((unsigned long long*)&S.tags[word], fp << (16 * way));
+                big_id_min(S, slot, id);
+                atomicAdd(S.distinct, 1ULL);
+                return;
+            }
+            if (prev == key) { big_id_min(S, slot, id); return; }
+        }
+        atomicOr((unsigned long long*)&S.tags[word], (unsigned long long)TAG_CONT);
+    }
+    atomicOr(S.distinct + 1, 1ULL);
+}
+__device__ __forceinline__ void sink_insert(const Sink& S, const uint64_t key, const int id) {
+    if (S.big) big_insert(S, key, id); else scratch_insert(S, key, id);
 }
 // one sequence v of `len` bases -> its key (toValue, BBDukIndexMod.java:532-544)
 __device__ __forceinline__ uint64_t build_key(const BuildParams& B, const uint64_t v, const int len) {
@@ -1183,10 +1439,9 @@ __device__ __forceinline__ uint64_t build_key(const BuildParams& B, const uint64
     const uint64_t mx = B.rcomp ? (v > r ? v : r) : v;
     return (mx & B.middleMask) | (1ULL << (2 * len));
 }
-// v and everything within `dist` (0..2) substitutions of it, starting from first-level choice `v1` (0 = v itself,
+// v and everything within `dist` (0..3) substitutions of it, starting from first-level choice `v1` (0 = v itself,
 // 1+3*i+j = base i replaced by its j-th alternative); the caller spreads v1 over threads
-__device__ __forceinline__ void emit_variants(const BuildParams& B, const uint64_t v, const int len, const int dist, const int v1, const int id,
-                                              uint64_t* skeys, int32_t* sids, const uint64_t cmask, unsigned long long* distinct) {
+__device__ __forceinline__ void emit_variants(const BuildParams& B, const uint64_t v, const int len, const int dist, const int v1, const int id, const Sink& S) {
     uint64_t t1 = v;
     if (v1 > 0) {
         if (dist < 1) return;
@@ -1195,28 +1450,37 @@ __device__ __forceinline__ void emit_variants(const BuildParams& B, const uint64
         const uint64_t cur = (v >> (2 * i)) & 3ULL;
         t1 = (v & ~(3ULL << (2 * i))) | (((cur + 1 + j) & 3ULL) << (2 * i));
     }
-    scratch_insert(skeys, sids, cmask, build_key(B, t1, len), id, distinct);
+    sink_insert(S, build_key(B, t1, len), id);
     if (dist >= 2 && v1 > 0) {                                    // second substitution at a lower position (each pair once)
         const int i1 = (v1 - 1) / 3;
         for (int i = 0; i < i1; i++) {
             const uint64_t cur = (t1 >> (2 * i)) & 3ULL;
             for (int j = 0; j < 3; j++) {
                 const uint64_t t2 = (t1 & ~(3ULL << (2 * i))) | (((cur + 1 + j) & 3ULL) << (2 * i));
-                scratch_insert(skeys, sids, cmask, build_key(B, t2, len), id, distinct);
+                sink_insert(S, build_key(B, t2, len), id);
+                if (dist >= 3) {                                  // third substitution, lower still
+                    for (int i3 = 0; i3 < i; i3++) {
+                        const uint64_t cur3 = (t2 >> (2 * i3)) & 3ULL;
+                        for (int j3 = 0; j3 < 3; j3++)
+                            sink_insert(S, build_key(B, (t2 & ~(3ULL << (2 * i3))) | (((cur3 + 1 + j3) & 3ULL) << (2 * i3)), len), id);
+                    }
+                }
             }
         }
     }
 }
 
+// refs = the pieces' bases concatenated, roff[nrefs+1] their offsets, rid[nrefs] the scaffold id of each piece, rfl[nrefs] bit 0 /
+// bit 1 = the piece holds its scaffold's first / last base (a scaffold longer than one upload chunk arrives as overlapping pieces;
+// the short k-mers of mink belong to the scaffold's first and last k-mer only).  V1 = first-level choices per position: 1 + 3k with
+// a Hamming distance, 1 without (so a plain 10 Gbase reference is not paid for 94 times).
 __global__ void bbduk_build_enum_kernel(const BuildParams B, const uint8_t* __restrict__ refs, const int64_t* __restrict__ roff,
-                                        uint64_t* __restrict__ skeys, int32_t* __restrict__ sids, const uint64_t cmask,
-                                        unsigned long long* __restrict__ distinct) {
+                                        const int32_t* __restrict__ rid, const uint8_t* __restrict__ rfl, const int V1, const Sink S) {
     const int k = B.k;
-    const int V1 = 1 + 3 * k;                                     // first-level choices per position (also used for the short k-mers)
     const int64_t work = B.totalBases * (int64_t)V1;
     for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < work; w += (int64_t)gridDim.x * blockDim.x) {
         const int64_t g = w / V1; const int v1 = (int)(w - g * V1);
-        int lo = 0, hi = B.nrefs;                                 // scaffold of base g: last s with roff[s] <= g
+        int lo = 0, hi = B.nrefs;                                 // piece of base g: last s with roff[s] <= g
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (roff[mid] <= g) lo = mid; else hi = mid; }
         const int64_t s0 = roff[lo], n = roff[lo + 1] - s0, i = g - s0;
         if (n < k || i < k - 1) continue;
@@ -1227,15 +1491,22 @@ __global__ void bbduk_build_enum_kernel(const BuildParams B, const uint8_t* __re
             fwd = (fwd << 2) | (uint64_t)(c < 0 ? 0 : c);
         }
         if (!ok) continue;
-        const int id = lo + 1;                                    // scaffoldNames[0] is reserved (bbduk/BBDukIndex.java:105-107)
-        emit_variants(B, fwd, k, B.hdist, v1, id, skeys, sids, cmask, distinct);
-        if (B.useShort && (i == k - 1 || i == n - 1)) {
+        const int id = rid[lo];                                   // scaffoldNames[0] is reserved (bbduk/BBDukIndex.java:105-107): ids start at 1
+        emit_variants(B, fwd, k, B.hdist, v1, id, S);
+        const bool first = (i == k - 1) && (rfl[lo] & 1), last = (i == n - 1) && (rfl[lo] & 2);
+        if (B.useShort && (first || last)) {
             for (int L = k - 1; L >= B.mink; L--) {
-                if (i == k - 1) emit_variants(B, fwd >> (2 * (k - L)), L, B.hdist2, v1, id, skeys, sids, cmask, distinct);        // addToMapRightShift
-                if (i == n - 1) emit_variants(B, fwd & ((1ULL << (2 * L)) - 1ULL), L, B.hdist2, v1, id, skeys, sids, cmask, distinct);   // addToMapLeftShift
+                if (first) emit_variants(B, fwd >> (2 * (k - L)), L, B.hdist2, v1, id, S);        // addToMapRightShift
+                if (last) emit_variants(B, fwd & ((1ULL << (2 * L)) - 1ULL), L, B.hdist2, v1, id, S);   // addToMapLeftShift
             }
         }
     }
+}
+
+// (key, id) pairs a host built (bbduk_upload_pairs / bbduk_upload_table_way) -> the same sinks
+__global__ void bbduk_insert_pairs_kernel(const int64_t* __restrict__ keys, const int32_t* __restrict__ vals, const int64_t n, const Sink S) {
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x)
+        sink_insert(S, (uint64_t)keys[q], vals[q]);
 }
 
 __global__ void bbduk_build_place_kernel(const uint64_t* __restrict__ skeys, const int32_t* __restrict__ sids, const uint64_t cslots,
@@ -1962,7 +2233,7 @@ __device__ __forceinline__ int wave_sum(int v) {
     return __builtin_amdgcn_readfirstlane(v);
 }
 
-template <int MODE, bool SHORT, bool FORBIDN, bool GENERAL, int FMT>
+template <int MODE, bool SHORT, bool FORBIDN, bool GENERAL, int FMT, bool BIG = false>
 __global__ __launch_bounds__(BLOCK_THREADS)
 void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
                        const int64_t n, const int64_t totalBases, const int paired,
@@ -1988,7 +2259,8 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
     if (*slowFlag != 0) return;                                   // a unit does not fit a wave's planes: tile kernel's job
     // short-scan geometry: `lens` candidate lengths per read, rpp reads per 64-lane pass
     // first-hit-only operators verify candidates in batches (see main_scan_pair_cand)
-    const bool candMode = (!GENERAL || P.qhdist == 0) &&
+    // (a big-layout map has its fast candidate form in the BIG instantiations only; elsewhere it takes the exact scans)
+    const bool candMode = (!GENERAL || P.qhdist == 0) && (BIG || !P.big) &&
                           (MODE == BBDUK_MODE_KTRIM_R || (MODE == BBDUK_MODE_KFILTER && P.maxBadKmers == 0 && P.mkf == 0.f && P.mcf == 0.f));
     const int lens = max(1, (MODE == BBDUK_MODE_KTRIM_L) ? (P.k - P.mink + 1) : (P.k - P.mink));
     const int rpp = max(1, 64 / lens);
@@ -2032,6 +2304,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
         // raw scan facts of my read, filled in by v_writelane as the pairs are scanned
         int vFound = 0, vFirst = BIGLOC, vLast = -1, vRef = -1, vSFl = -1, vSLl = -1;
         int vCSlot = -1; uint32_t vCKeyLo = 0, vCKeyHi = 0;       // candidate mode: my read's first unverified match
+        uint32_t vCWord = 0;                                      // big layout: its tag word (vCSlot = way)
         int vThr = P.maxBadKmers;                                 // kfilter: my read's threshold (mkf: filled in when its pair is scanned)
         if constexpr (GENERAL && MODE == BBDUK_MODE_KFILTER) { if (P.mcf > 0.f) vThr = (int)ceilf(P.mcf * (float)vL); }
 
@@ -2069,7 +2342,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
             Q.fwdBits = lds_bits_of(Q.fwd); Q.cmpBits = lds_bits_of(Q.cmp);
             const int origin = lead - rel_s;                        // plane index of a base = origin + (its offset in the mini-tile)
             uint64_t nMask = 0;                                     // reads of [s,e) with an undefined base inside their span
-            if (FORBIDN && P.forbidNs) {                            // lane j looks at read j's words of the undefined-plane
+            if ((FORBIDN && P.forbidNs) || BIG) {                   // lane j looks at read j's words of the undefined-plane
                 uint32_t acc = 0;
                 if (lane >= s && lane < e && vScan) {
                     const int b0 = origin + rel + vStart, b1 = origin + rel + vStop;
@@ -2099,14 +2372,16 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                 A.found = 0; A.iFirst = BIGLOC; A.iLast = -1; A.ref = -1; A.shortFl = -1; A.shortLl = -1;
                 Bz.found = 0; Bz.iFirst = BIGLOC; Bz.iLast = -1; Bz.ref = -1; Bz.shortFl = -1; Bz.shortLl = -1;
                 if (candMode) {
-                    if (!TSW(P, 3)) main_scan_pair_cand<FORBIDN, GENERAL, SHORT && !GENERAL>(P, Q, A, Bz, lane); else { A.candSlot = -1; Bz.candSlot = -1; }
+                    if (!TSW(P, 3)) main_scan_pair_cand<FORBIDN, GENERAL, SHORT && !GENERAL, BIG>(P, Q, A, Bz, lane); else { A.candSlot = -1; Bz.candSlot = -1; }
                     if (A.candSlot != -1) {
                         vCSlot = (lane == ra) ? A.candSlot : vCSlot; vFirst = (lane == ra) ? A.iFirst : vFirst;
                         vCKeyLo = (lane == ra) ? A.candKeyLo : vCKeyLo; vCKeyHi = (lane == ra) ? A.candKeyHi : vCKeyHi;
+                        if constexpr (BIG) vCWord = (lane == ra) ? A.candWord : vCWord;
                     }
                     if (Bz.candSlot != -1) {
                         vCSlot = (lane == ra + 1) ? Bz.candSlot : vCSlot; vFirst = (lane == ra + 1) ? Bz.iFirst : vFirst;
                         vCKeyLo = (lane == ra + 1) ? Bz.candKeyLo : vCKeyLo; vCKeyHi = (lane == ra + 1) ? Bz.candKeyHi : vCKeyHi;
+                        if constexpr (BIG) vCWord = (lane == ra + 1) ? Bz.candWord : vCWord;
                     }
                     continue;
                 }
@@ -2138,9 +2413,18 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                     if (MODE == BBDUK_MODE_KFILTER) vFirst = 0;
                 }
                 if (inSub && vCSlot >= 0) {
-                    const uint4 kv = P.bkv[vCSlot];
-                    if (kv.x == (vCKeyLo | (uint32_t)P.kmask) && kv.y == (vCKeyHi | (uint32_t)(P.kmask >> 32))) {
-                        vRef = (int)kv.z; vFound = (MODE == BBDUK_MODE_KFILTER) ? P.maxBadKmers + 1 : 1;
+                    bool same; int idv;
+                    if constexpr (BIG) {                            // slot-parallel arrays: the key, and the id only if it is the key
+                        const uint64_t slot = 4ULL * vCWord + (uint32_t)vCSlot;
+                        same = P.bigKeys[slot] == ((((uint64_t)vCKeyHi << 32) | vCKeyLo) | P.kmask);
+                        idv = same ? big_id_at(P, slot) : -1;
+                    } else {
+                        const uint4 kv = P.bkv[vCSlot];
+                        same = kv.x == (vCKeyLo | (uint32_t)P.kmask) && kv.y == (vCKeyHi | (uint32_t)(P.kmask >> 32));
+                        idv = (int)kv.z;
+                    }
+                    if (same) {
+                        vRef = idv; vFound = (MODE == BBDUK_MODE_KFILTER) ? P.maxBadKmers + 1 : 1;
                         if (MODE == BBDUK_MODE_KFILTER) vFirst = 0;    // marks the early exit
                     } else fb = true;
                 }
@@ -3016,6 +3300,18 @@ static KernelPair pick_kernel(const KParams& K) {
     // maskMiddle off, :295-301); anything else takes the general kernel
     const bool general = K.qhdist > 0 || K.qhdist2 > 0 || K.restrictLeft > 0 || K.restrictRight > 0 || K.skipR1 || K.skipR2 || !K.rcomp ||
                          (K.useShort && K.middleMask != ~0ULL) || K.k < 16 || K.qskip > 1 || K.speed > 0 || K.mkf != 0.f || K.mcf > 0.f;
+    if (K.big) {
+        // HBM-resident layout: the plain kfilter configurations (BASELINE configs[3]) have the fast minimizer-sharing candidate scan;
+        // every other configuration runs the general kernels, whose lookups take the exact per-key path (big_find)
+        if (!general && K.mode == BBDUK_MODE_KFILTER && K.gW <= 8) {
+            const batch_kernel_t tile = bbduk_batch_kernel<BBDUK_MODE_KFILTER, true, true, true>;
+            if (K.forbidNs) return KernelPair{bbduk_wave_kernel<BBDUK_MODE_KFILTER, false, true, false, 0, true>, bbduk_wave_kernel<BBDUK_MODE_KFILTER, false, true, false, 1, true>, tile};
+            return KernelPair{bbduk_wave_kernel<BBDUK_MODE_KFILTER, false, false, false, 0, true>, bbduk_wave_kernel<BBDUK_MODE_KFILTER, false, false, false, 1, true>, tile};
+        }
+        if (K.mode == BBDUK_MODE_KFILTER) return kpair<BBDUK_MODE_KFILTER, true, true, true>();
+        if (K.mode == BBDUK_MODE_KTRIM_L) return kpair<BBDUK_MODE_KTRIM_L, true, true, true>();
+        return kpair<BBDUK_MODE_KTRIM_R, true, true, true>();
+    }
     if (K.mode == BBDUK_MODE_KFILTER) return pick_kernel_mode<BBDUK_MODE_KFILTER>(general, false, K.forbidNs != 0);
     if (K.mode == BBDUK_MODE_KTRIM_L) return pick_kernel_mode<BBDUK_MODE_KTRIM_L>(general, K.useShort != 0, K.forbidNs != 0);
     return pick_kernel_mode<BBDUK_MODE_KTRIM_R>(general, K.useShort != 0, K.forbidNs != 0);
@@ -3069,7 +3365,7 @@ extern "C" int bbduk_create(const bbduk_params* p, bbduk_handle** out) {
     if (p->abi_version != BBDUK_ABI_VERSION) return BBDUK_ERR_ARG;
     if (p->k < 1 || p->k > 31) return BBDUK_ERR_ARG;
     if (p->mode < BBDUK_MODE_KFILTER || p->mode > BBDUK_MODE_KSPLIT) return BBDUK_ERR_ARG;
-    if (p->qhdist < 0 || p->qhdist > 2 || p->qhdist2 < 0 || p->qhdist2 > 2) return BBDUK_ERR_ARG;
+    if (p->qhdist < 0 || p->qhdist > 3 || p->qhdist2 < 0 || p->qhdist2 > 3) return BBDUK_ERR_ARG;
     if (p->numScaffolds < 1 || p->maxBadKmers < 0) return BBDUK_ERR_ARG;
     const bool useShort = p->mink > 0 && p->mink < p->k;
     if (useShort && p->mode == BBDUK_MODE_KFILTER) return BBDUK_ERR_ARG;      // BBDukParser.java:301
@@ -3109,6 +3405,8 @@ extern "C" int bbduk_create(const bbduk_params* p, bbduk_handle** out) {
     return BBDUK_OK;
 }
 
+static void build_release(bbduk_handle* h);
+
 // Test-only controls (include/bbduk_test_hooks.h): explicit calls on a handle instead of environment variables.
 extern "C" int bbduk_test_hook(bbduk_handle* h, int32_t which, int64_t value) {
     if (!h) return BBDUK_ERR_ARG;
@@ -3117,6 +3415,7 @@ extern "C" int bbduk_test_hook(bbduk_handle* h, int32_t which, int64_t value) {
     case BBDUK_HOOK_FORCE_TILE:  h->hookForceTile = value != 0; return BBDUK_OK;
     case BBDUK_HOOK_BUCKET_BITS: if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookBucketBits = (int)value; return BBDUK_OK;
     case BBDUK_HOOK_LDS_BITS:    if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookLdsBits = (int)value; return BBDUK_OK;
+    case BBDUK_HOOK_BIG_LAYOUT:  if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookBigLayout = value != 0; return BBDUK_OK;
     case BBDUK_HOOK_TIMING_MASK:
 #ifdef BBDUK_TIMING_SWITCHES
         h->hookDbg = (int)value; return BBDUK_OK;
@@ -3131,6 +3430,8 @@ extern "C" int bbduk_destroy(bbduk_handle* h) {
     if (!h) return BBDUK_ERR_ARG;
     bbduk_comm_destroy(h);
     hipSetDevice(h->p.device);
+    build_release(h);
+    hipFree(h->d_bigKeys); hipFree(h->d_bigIds);
     hipFree(h->d_tags); hipFree(h->d_bkv); hipFree(h->d_bases); hipFree(h->d_undef); hipFree(h->d_off);
     hipFree(h->d_ldsImage); hipFree(h->d_slowFlag);
     for (int q = 0; q < bbduk_handle::EV_RING; q++) { if (h->ev0[q]) hipEventDestroy(h->ev0[q]); if (h->ev1[q]) hipEventDestroy(h->ev1[q]); }
@@ -3172,138 +3473,279 @@ extern "C" int bbduk_upload_table_way(bbduk_handle* h, int32_t way, int32_t prim
     return BBDUK_OK;
 }
 
-extern "C" int bbduk_finalize_table(bbduk_handle* h) {
-    if (!h) return BBDUK_ERR_ARG;
-    std::lock_guard<std::mutex> g(h->mu);
-    if (h->finalized) return fail(h, BBDUK_ERR_STATE, "table already finalized");
-    HIP_TRY(h, hipSetDevice(h->p.device));
-    const size_t n = h->hkeys.size();
-    // 4-way buckets of 15-bit fingerprints, >= 1 bucket per key (load 0.5-1 keys/bucket: ~0.1-0.4 % of buckets
-    // overflow and carry the continuation flag, so almost every lookup ends in its home bucket).
-    int bbits = 10;
-    while (bbits < 32 && (1ULL << bbits) < (uint64_t)n) bbits++;
-    if (h->hookBucketBits >= 4 && h->hookBucketBits <= 32) bbits = h->hookBucketBits;      // bbduk_test_hook
-    const uint64_t nb = 1ULL << bbits;
-    if (4 * nb < (uint64_t)n + nb / 8 || 4 * nb > (1ULL << 31)) return fail(h, BBDUK_ERR_ARG, "too many keys for the bucket index");
-    std::vector<uint64_t> tg(nb, 0ULL);
-    std::vector<uint4> kvh(4 * nb, make_uint4(~0u, ~0u, 0u, 0u));  // {key lo, key hi, id, 0}; all-ones key = free
-    auto key_at = [&](uint64_t q) { return ((uint64_t)kvh[q].y << 32) | kvh[q].x; };
-    const uint32_t bmask = (uint32_t)(nb - 1);
-    int64_t distinct = 0;
-    for (size_t i = 0; i < n; i++) {                              // first writer wins (HashArray.setIfNotPresent)
-        const uint64_t key = (uint64_t)h->hkeys[i];
-        const uint64_t tag = tag_of(mix_a(strip_len(key)));
-        uint32_t b = bucket_of(mix_b(strip_len(key)), bbits);
-        for (;;) {
-            bool done = false;
-            for (int w = 0; w < 4 && !done; w++) {
-                const uint64_t tw = (tg[b] >> (16 * w)) & 0x7FFFULL;
-                if (key_at(4ULL * b + w) == EMPTY_KEY) { tg[b] |= tag << (16 * w); kvh[4ULL * b + w] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)h->hvals[i], 0u); distinct++; done = true; }
-                else if (tw == tag && key_at(4ULL * b + w) == key) done = true;
-            }
-            if (done) break;
-            tg[b] |= TAG_CONT;
-            b = (b + 1) & bmask;
-        }
+// ---- table construction, all of it on the device ---------------------------------------------------------------------------
+// Two sources -- (key, id) pairs a host built (bbduk_upload_pairs / bbduk_upload_table_way + bbduk_finalize_table: the JVM's own
+// tables) or the reference sequences themselves (bbduk_build_table_device, or the streaming bbduk_build_begin / _add_device / _end)
+// -- and two layouts, chosen by the expected key count: the cache-resident one (scratch set, then placement into buckets sized for
+// the distinct count, LDS filter) and the big one (in place).  BuildState lives from begin to end.
+struct BuildState {
+    bool big = false; int hdist = 0, hdist2 = 0;
+    uint64_t* d_sk = nullptr; int32_t* d_si = nullptr; uint64_t cslots = 0;     // scratch set of the two-pass build
+    unsigned long long* d_cnt = nullptr;                                        // [0] distinct, [1] overflow flag
+    uint8_t* d_stage = nullptr; size_t stageCap = 0;                            // upload staging of bbduk_build_table_device / finalize
+    int64_t* d_roff = nullptr; int32_t* d_rid = nullptr; uint8_t* d_rfl = nullptr; size_t pieceCap = 0;
+};
+static void build_release(bbduk_handle* h) {
+    BuildState* st = h->build;
+    if (!st) return;
+    hipFree(st->d_sk); hipFree(st->d_si); hipFree(st->d_cnt); hipFree(st->d_stage); hipFree(st->d_roff); hipFree(st->d_rid); hipFree(st->d_rfl);
+    delete st; h->build = nullptr;
+}
+static void table_release(bbduk_handle* h) {       // a failed build leaves no half-made map behind
+    hipFree(h->d_tags); hipFree(h->d_bkv); hipFree(h->d_ldsImage); hipFree(h->d_bigKeys); hipFree(h->d_bigIds);
+    h->d_tags = nullptr; h->d_bkv = nullptr; h->d_ldsImage = nullptr; h->d_bigKeys = nullptr; h->d_bigIds = nullptr;
+    h->big = false; h->nbuckets = 0; h->bigLines = 0; h->ldsBits = 0; h->nkeys = 0;
+}
+// gapped-minimizer geometry of the big layout for this k and middle mask (see "big layout"); false: k too small for it
+static bool big_geometry(bbduk_handle* h) {
+    const int k = h->p.k;
+    const uint64_t full = (2 * k > 63) ? ~0ULL : ~(~0ULL << (2 * k));
+    const uint64_t masked = ~(uint64_t)h->p.middleMask & full;           // 2 bits per masked base
+    int H;
+    if (!masked) H = k / 2;
+    else {
+        const int loBit = __builtin_ctzll(masked), hiBit = 63 - __builtin_clzll(masked);
+        const int firstMasked = k - 1 - hiBit / 2, lastMasked = k - 1 - loBit / 2;       // base indices, 0 = the k-mer's first base
+        H = std::min(firstMasked, k - 1 - lastMasked);
     }
-    HIP_TRY(h, hipMalloc(&h->d_tags, nb * sizeof(uint64_t)));
-    h->hkeys.clear(); h->hkeys.shrink_to_fit(); h->hvals.clear(); h->hvals.shrink_to_fit();
-    HIP_TRY(h, hipMalloc(&h->d_bkv, 4 * nb * sizeof(uint4)));
-    HIP_TRY(h, hipMemcpy(h->d_bkv, kvh.data(), 4 * nb * sizeof(uint4), hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->d_tags, tg.data(), nb * sizeof(uint64_t), hipMemcpyHostToDevice));
-    h->nbuckets = nb; h->bucketBits = bbits; h->nkeys = distinct;
-    // Presence filter in front of the map.  Most query k-mers are absent, so one bit per hash slot held in LDS
-    // (<=128 KiB per workgroup) answers most of them without leaving the CU.  Size follows the key count;
-    // bbduk_test_hook(BBDUK_HOOK_LDS_BITS) (log2 bits, 0 = off) overrides for tests.  Huge maps (HBM-resident, SURVEY config 4)
-    // skip it: a filter that small would be all ones.
-    {
+    if (H < 4) return false;
+    h->gH = H; h->gD = k - H; h->gm = std::min(9, H - 1); h->gW = H - h->gm + 1;
+    return true;
+}
+static BigGeom host_geom(const bbduk_handle* h) { BigGeom G; G.k = h->p.k; G.m = h->gm; G.W = h->gW; G.H = h->gH; G.D = h->gD; G.nlines = h->bigLines; G.middleMask = (uint64_t)h->p.middleMask; return G; }
+static Sink make_sink(const bbduk_handle* h, const BuildState* st) {
+    Sink S; memset(&S, 0, sizeof S);
+    S.big = st->big ? 1 : 0; S.skeys = st->d_sk; S.sids = st->d_si; S.cmask = st->cslots ? st->cslots - 1 : 0;
+    S.tags = h->d_tags; S.keys = h->d_bigKeys; S.ids = h->d_bigIds; S.idBytes = h->bigIdBytes; S.G = host_geom(h);
+    S.distinct = st->d_cnt;
+    return S;
+}
+#define BIG_LAYOUT_MIN_KEYS (1LL << 25)            // beyond ~3e7 keys the fingerprints alone outgrow L2 + Infinity Cache
+
+// expected number of keys (an upper bound is fine) -> layout, allocations
+static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdist2) {
+    if (h->finalized) return fail(h, BBDUK_ERR_STATE, "table already finalized");
+    if (h->build) return fail(h, BBDUK_ERR_STATE, "a table build is already in progress");
+    HIP_TRY(h, hipSetDevice(h->p.device));
+    BuildState* st = new (std::nothrow) BuildState();
+    if (!st) return BBDUK_ERR_NOMEM;
+    h->build = st; st->hdist = hdist; st->hdist2 = hdist2;
+    st->big = (maxKeys > (double)BIG_LAYOUT_MIN_KEYS || h->hookBigLayout) && big_geometry(h);
+    auto bail = [&](int code, const char* msg) { build_release(h); table_release(h); return fail(h, code, msg); };
+    if (hipMalloc(&st->d_cnt, 16) != hipSuccess || hipMemsetAsync(st->d_cnt, 0, 16, h->stream) != hipSuccess) return bail(BBDUK_ERR_NOMEM, "hipMalloc");
+    if (st->big) {
+        // 32-slot lines at ~0.6 keys per slot (the lines' loads vary with the minimizers: 10 % of them overflow into the next line
+        // there, 3 % of the keys); a tighter fit is tried when HBM is short.  12 or 14 bytes per slot: 10^10 keys = 200-233 GB.
+        const int idBytes = h->p.numScaffolds <= 65535 ? 2 : 4;
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return bail(BBDUK_ERR_DEVICE, "hipMemGetInfo");
+        const double perLine = 64.0 + 256.0 + 32.0 * idBytes;
+        uint64_t nlines = 0;
+        for (const double load : {0.6, 0.7, 0.8, 0.9}) {
+            nlines = std::max<uint64_t>(64, (uint64_t)(maxKeys / (32.0 * load)) + 1);
+            if ((double)nlines * perLine + 3e9 < (double)freeB) break;
+            nlines = 0;
+        }
+        if (!nlines) return bail(BBDUK_ERR_NOMEM, "the map does not fit this device's memory");
+        if (nlines >= (1ULL << 29)) return bail(BBDUK_ERR_ARG, "too many keys for the 32-bit tag word index");
+        if (hipMalloc(&h->d_tags, nlines * 64) != hipSuccess || hipMalloc(&h->d_bigKeys, nlines * 256) != hipSuccess ||
+            hipMalloc(&h->d_bigIds, nlines * 32 * (size_t)idBytes) != hipSuccess) return bail(BBDUK_ERR_NOMEM, "hipMalloc (map)");
+        h->big = true; h->bigLines = (uint32_t)nlines; h->bigIdBytes = idBytes;
+        hipMemsetAsync(h->d_tags, 0, nlines * 64, h->stream);
+        hipMemsetAsync(h->d_bigKeys, 0xFF, nlines * 256, h->stream);
+        hipMemsetAsync(h->d_bigIds, 0xFF, nlines * 32 * (size_t)idBytes, h->stream);
+    } else {
+        uint64_t cslots = 1024; while ((double)cslots < 2.0 * maxKeys + 16.0) cslots <<= 1;      // a power of two, load <= 0.5
+        if (cslots > (1ULL << 34)) return bail(BBDUK_ERR_NOMEM, "key set too large for the scratch set");
+        if (hipMalloc(&st->d_sk, cslots * 8) != hipSuccess || hipMalloc(&st->d_si, cslots * 4) != hipSuccess) return bail(BBDUK_ERR_NOMEM, "hipMalloc (scratch set)");
+        st->cslots = cslots;
+        hipMemsetAsync(st->d_sk, 0xFF, cslots * 8, h->stream);
+        hipMemsetAsync(st->d_si, 0x7F, cslots * 4, h->stream);                   // 0x7F7F7F7F: larger than any id
+    }
+    return BBDUK_OK;
+}
+
+// pieces of reference sequence already in HBM -> the sink
+static int build_add_pieces(bbduk_handle* h, const uint8_t* d_refs, const int64_t* roff, const int32_t* rid, const uint8_t* rfl, int32_t npieces) {
+    BuildState* st = h->build;
+    const int64_t total = roff[npieces];
+    if (npieces == 0 || total == 0) return BBDUK_OK;
+    if ((size_t)npieces > st->pieceCap) {
+        hipFree(st->d_roff); hipFree(st->d_rid); hipFree(st->d_rfl); st->d_roff = nullptr; st->d_rid = nullptr; st->d_rfl = nullptr; st->pieceCap = 0;
+        const size_t cap = (size_t)npieces + 1024;
+        if (hipMalloc(&st->d_roff, (cap + 1) * 8) != hipSuccess || hipMalloc(&st->d_rid, cap * 4) != hipSuccess || hipMalloc(&st->d_rfl, cap) != hipSuccess)
+            return fail(h, BBDUK_ERR_NOMEM, "hipMalloc (piece table)");
+        st->pieceCap = cap;
+    }
+    HIP_TRY(h, hipMemcpyAsync(st->d_roff, roff, (size_t)(npieces + 1) * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(st->d_rid, rid, (size_t)npieces * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(st->d_rfl, rfl, (size_t)npieces, hipMemcpyHostToDevice, h->stream));
+    BuildParams B;
+    B.k = h->p.k; B.mink = h->p.mink; B.useShort = (h->p.mink > 0 && h->p.mink < h->p.k) ? 1 : 0; B.hdist = st->hdist; B.hdist2 = st->hdist2;
+    B.rcomp = h->p.rcomp; B.middleMask = (uint64_t)h->p.middleMask; B.totalBases = total; B.nrefs = npieces;
+    const int V1 = (st->hdist > 0 || (B.useShort && st->hdist2 > 0)) ? 1 + 3 * B.k : 1;
+    const int64_t work = total * (int64_t)V1;
+    const int grid = (int)std::min<int64_t>((work + 255) / 256, (int64_t)h->numCU * 32);
+    bbduk_build_enum_kernel<<<dim3(std::max(grid, 1)), dim3(256), 0, h->stream>>>(B, d_refs, st->d_roff, st->d_rid, st->d_rfl, V1, make_sink(h, st));
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));                 // the caller may reuse d_refs and the host arrays
+    return BBDUK_OK;
+}
+
+static int build_end_impl(bbduk_handle* h) {
+    BuildState* st = h->build;
+    auto bail = [&](int code, const char* msg) { build_release(h); table_release(h); return fail(h, code, msg); };
+    unsigned long long cnt[2] = {0, 0};
+    if (hipMemcpyAsync(cnt, st->d_cnt, 16, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
+        return bail(BBDUK_ERR_DEVICE, "table build failed on the device");
+    const unsigned long long distinct = cnt[0];
+    if (st->big) {
+        if (cnt[1]) return bail(BBDUK_ERR_NOMEM, "the map overflowed: more keys than announced to bbduk_build_begin");
+        h->nkeys = (int64_t)distinct; h->ldsBits = 0;
+    } else {
+        // 4-way buckets of 15-bit fingerprints, >= 1 bucket per key (load 0.5-1 keys/bucket: ~0.1-0.4 % of buckets
+        // overflow and carry the continuation flag, so almost every lookup ends in its home bucket).
+        int bbits = 10;
+        while (bbits < 32 && (1ULL << bbits) < distinct) bbits++;
+        if (bbits == 30 && distinct <= (1ULL << 30)) bbits = 29;     // the slot index is 31 bits: the largest maps of this layout run at up to 2 keys per bucket
+        if (h->hookBucketBits >= 4 && h->hookBucketBits <= 32) bbits = h->hookBucketBits;      // bbduk_test_hook
+        const uint64_t nb = 1ULL << bbits;
+        if (4 * nb < distinct + nb / 8 || 4 * nb > (1ULL << 31)) return bail(BBDUK_ERR_ARG, "too many keys for the bucket index");
+        // Presence filter in front of the map.  Most query k-mers are absent, so one bit per hash slot held in LDS
+        // (<=128 KiB per workgroup) answers most of them without leaving the CU.  Size follows the key count.
         auto ceil_log2 = [](uint64_t x) { int b = 0; while ((1ULL << b) < x) b++; return b; };
         int lb = 0;
-        if (distinct > 0 && distinct <= (1LL << 22)) lb = std::min(MAX_LDS_BITS, std::max(10, ceil_log2(32ULL * (uint64_t)distinct)));
+        if (distinct > 0 && distinct <= (1ULL << 22)) lb = std::min(MAX_LDS_BITS, std::max(10, ceil_log2(32ULL * distinct)));
         if (h->hookLdsBits >= 0) lb = h->hookLdsBits == 0 ? 0 : std::min(MAX_LDS_BITS, std::max(10, h->hookLdsBits));   // bbduk_test_hook
-        if (lb) {
-            std::vector<uint32_t> f1((size_t)1 << (lb - 5), 0u);
-            for (uint64_t s = 0; s < 4 * nb; s++) {
-                if (key_at(s) == EMPTY_KEY) continue;
-                const uint32_t ma = mix_a(strip_len(key_at(s)));
-                f1[filt_byte(ma, lb) >> 2] |= 1u << (ma & 31u);
-            }
-            HIP_TRY(h, hipMalloc(&h->d_ldsImage, f1.size() * 4));
-            HIP_TRY(h, hipMemcpy(h->d_ldsImage, f1.data(), f1.size() * 4, hipMemcpyHostToDevice));
-        }
-        h->ldsBits = lb;
+        if (hipMalloc(&h->d_tags, nb * sizeof(uint64_t)) != hipSuccess || hipMalloc(&h->d_bkv, 4 * nb * sizeof(uint4)) != hipSuccess ||
+            (lb && hipMalloc(&h->d_ldsImage, ((size_t)1 << (lb - 5)) * 4) != hipSuccess)) return bail(BBDUK_ERR_NOMEM, "hipMalloc (map)");
+        hipMemsetAsync(h->d_tags, 0, nb * sizeof(uint64_t), h->stream);
+        hipMemsetAsync(h->d_bkv, 0xFF, 4 * nb * sizeof(uint4), h->stream);
+        if (lb) hipMemsetAsync(h->d_ldsImage, 0, ((size_t)1 << (lb - 5)) * 4, h->stream);
+        const int grid = (int)std::min<uint64_t>((st->cslots + 255) / 256, (uint64_t)h->numCU * 32);
+        bbduk_build_place_kernel<<<dim3(grid), dim3(256), 0, h->stream>>>(st->d_sk, st->d_si, st->cslots, h->d_tags, h->d_bkv, bbits, (uint32_t)(nb - 1), h->d_ldsImage, lb);
+        if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(BBDUK_ERR_DEVICE, "device build (placement) failed");
+        h->nbuckets = nb; h->bucketBits = bbits; h->nkeys = (int64_t)distinct; h->ldsBits = lb;
     }
-    h->hkeys.clear(); h->hkeys.shrink_to_fit(); h->hvals.clear(); h->hvals.shrink_to_fit();
+    build_release(h);
     h->finalized = true;
     return BBDUK_OK;
 }
 
-// bbduk_build_table_device: see the kernels above.  refs/offsets are HOST pointers here (the sequences are copied once).
+extern "C" int bbduk_build_begin(bbduk_handle* h, int64_t max_keys, int32_t hdist, int32_t hdist2) {
+    if (!h) return BBDUK_ERR_ARG;
+    if (max_keys < 0 || hdist < 0 || hdist > 3 || hdist2 < 0 || hdist2 > 3) return fail(h, BBDUK_ERR_ARG, "build_begin: bad argument (the device build serves hdist <= 3)");
+    std::lock_guard<std::mutex> g(h->mu);
+    if (!h->hkeys.empty()) return fail(h, BBDUK_ERR_STATE, "pairs were uploaded already: finalize them instead");
+    return build_begin_impl(h, (double)max_keys, hdist, hdist2);
+}
+extern "C" int bbduk_build_add_device(bbduk_handle* h, const uint8_t* d_refs, const int64_t* ref_offsets, int32_t n_refs, int32_t first_id) {
+    if (!h) return BBDUK_ERR_ARG;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (!h->build) return fail(h, BBDUK_ERR_STATE, "build_add_device without bbduk_build_begin");
+    if (n_refs < 0 || !ref_offsets || ref_offsets[0] != 0 || (n_refs > 0 && ref_offsets[n_refs] > 0 && !d_refs)) return fail(h, BBDUK_ERR_ARG, "build_add_device: bad argument");
+    if (first_id < 1 || (int64_t)first_id + n_refs > (int64_t)h->p.numScaffolds) return fail(h, BBDUK_ERR_ARG, "build_add_device: scaffold ids must stay within 1..numScaffolds-1");
+    for (int32_t i = 0; i < n_refs; i++) if (ref_offsets[i + 1] < ref_offsets[i]) return fail(h, BBDUK_ERR_ARG, "build_add_device: offsets must ascend");
+    HIP_TRY(h, hipSetDevice(h->p.device));
+    std::vector<int32_t> rid((size_t)n_refs); std::vector<uint8_t> rfl((size_t)n_refs, (uint8_t)3);
+    for (int32_t i = 0; i < n_refs; i++) rid[i] = first_id + i;
+    return build_add_pieces(h, d_refs, ref_offsets, rid.data(), rfl.data(), n_refs);
+}
+extern "C" int bbduk_build_end(bbduk_handle* h) {
+    if (!h) return BBDUK_ERR_ARG;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (!h->build) return fail(h, BBDUK_ERR_STATE, "build_end without bbduk_build_begin");
+    HIP_TRY(h, hipSetDevice(h->p.device));
+    return build_end_impl(h);
+}
+
+// The pairs a host staged with bbduk_upload_pairs / bbduk_upload_table_way go to the device in chunks and are placed there (one
+// thread per pair; 10^8 keys took 17.8 s in a serial host loop, they take about a second this way).
+extern "C" int bbduk_finalize_table(bbduk_handle* h) {
+    if (!h) return BBDUK_ERR_ARG;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (h->finalized) return fail(h, BBDUK_ERR_STATE, "table already finalized");
+    if (h->build) return fail(h, BBDUK_ERR_STATE, "a device-side build is in progress: end it with bbduk_build_end");
+    const int64_t n = (int64_t)h->hkeys.size();
+    int rc = build_begin_impl(h, (double)n, 0, 0);
+    if (rc != BBDUK_OK) return rc;
+    BuildState* st = h->build;
+    auto bail = [&](int code, const char* msg) { build_release(h); table_release(h); return fail(h, code, msg); };
+    const int64_t CH = 32LL << 20;                                  // pairs per upload: 384 MB of staging
+    if (n > 0) {
+        const int64_t cap = std::min<int64_t>(n, CH);
+        if (hipMalloc(&st->d_stage, (size_t)cap * 12) != hipSuccess) return bail(BBDUK_ERR_NOMEM, "hipMalloc (upload staging)");
+        int64_t* dk = reinterpret_cast<int64_t*>(st->d_stage); int32_t* dv = reinterpret_cast<int32_t*>(st->d_stage + (size_t)cap * 8);
+        const Sink S = make_sink(h, st);
+        for (int64_t q = 0; q < n; q += CH) {
+            const int64_t m = std::min<int64_t>(CH, n - q);
+            if (hipMemcpyAsync(dk, h->hkeys.data() + q, (size_t)m * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+                hipMemcpyAsync(dv, h->hvals.data() + q, (size_t)m * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess) return bail(BBDUK_ERR_DEVICE, "uploading the pairs");
+            const int grid = (int)std::min<int64_t>((m + 255) / 256, (int64_t)h->numCU * 32);
+            bbduk_insert_pairs_kernel<<<dim3(std::max(grid, 1)), dim3(256), 0, h->stream>>>(dk, dv, m, S);
+            if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(BBDUK_ERR_DEVICE, "placing the pairs");
+        }
+    }
+    h->hkeys.clear(); h->hkeys.shrink_to_fit(); h->hvals.clear(); h->hvals.shrink_to_fit();
+    return build_end_impl(h);
+}
+
+// bbduk_build_table_device: the reference sequences are HOST memory here; they go to the device in chunks of whole scaffolds
+// (a scaffold longer than a chunk as pieces that overlap by k-1 bases) through bbduk_build_begin / build_add_pieces / bbduk_build_end.
 extern "C" int bbduk_build_table_device(bbduk_handle* h, const uint8_t* refs, const int64_t* ref_offsets, int32_t n_refs,
                                         int32_t hdist, int32_t hdist2) {
     if (!h) return BBDUK_ERR_ARG;
     std::lock_guard<std::mutex> g(h->mu);
     if (h->finalized) return fail(h, BBDUK_ERR_STATE, "table already finalized");
     if (!h->hkeys.empty()) return fail(h, BBDUK_ERR_STATE, "pairs were uploaded already: finalize them instead");
-    if (n_refs < 0 || !ref_offsets || hdist < 0 || hdist > 2 || hdist2 < 0 || hdist2 > 2) return fail(h, BBDUK_ERR_ARG, "bad argument (device build serves hdist <= 2)");
+    if (n_refs < 0 || !ref_offsets || hdist < 0 || hdist > 3 || hdist2 < 0 || hdist2 > 3) return fail(h, BBDUK_ERR_ARG, "bad argument (device build serves hdist <= 3)");
     const int64_t total = n_refs > 0 ? ref_offsets[n_refs] : 0;
     if (n_refs > 0 && (ref_offsets[0] != 0 || total < 0 || (total > 0 && !refs))) return fail(h, BBDUK_ERR_ARG, "bad offsets");
+    for (int32_t i = 0; i < n_refs; i++) if (ref_offsets[i + 1] < ref_offsets[i]) return fail(h, BBDUK_ERR_ARG, "bad offsets");
     if (n_refs + 1 != h->p.numScaffolds) return fail(h, BBDUK_ERR_ARG, "numScaffolds given to bbduk_create must be n_refs + 1");
-    HIP_TRY(h, hipSetDevice(h->p.device));
-    BuildParams B;
-    B.k = h->p.k; B.mink = h->p.mink; B.useShort = (h->p.mink > 0 && h->p.mink < h->p.k) ? 1 : 0; B.hdist = hdist; B.hdist2 = hdist2;
-    B.rcomp = h->p.rcomp; B.middleMask = (uint64_t)h->p.middleMask; B.totalBases = total; B.nrefs = n_refs;
-    // upper bound on candidates -> scratch capacity (a power of two, load <= 0.5)
-    auto variants = [](int len, int d) { const double t = 3.0 * len; return d == 0 ? 1.0 : d == 1 ? 1.0 + t : 1.0 + t + t * (t - 3.0) / 2.0 + 0.0 * t; };
-    double ub = (double)total * variants(B.k, hdist);
-    if (B.useShort) for (int L = B.mink; L < B.k; L++) ub += 2.0 * (double)n_refs * variants(L, hdist2);
-    uint64_t cslots = 1024; while ((double)cslots < 2.0 * ub + 16.0) cslots <<= 1;
-    if (cslots > (1ULL << 34)) return fail(h, BBDUK_ERR_NOMEM, "reference too large for the device-side build scratch set");
-    uint8_t* d_refs = nullptr; int64_t* d_roff = nullptr; uint64_t* d_sk = nullptr; int32_t* d_si = nullptr; unsigned long long* d_cnt = nullptr;
-    auto release = [&]() { hipFree(d_refs); hipFree(d_roff); hipFree(d_sk); hipFree(d_si); hipFree(d_cnt); };
-    if (hipMalloc(&d_refs, (size_t)total + 16) != hipSuccess || hipMalloc(&d_roff, (size_t)(n_refs + 1) * 8) != hipSuccess ||
-        hipMalloc(&d_sk, cslots * 8) != hipSuccess || hipMalloc(&d_si, cslots * 4) != hipSuccess || hipMalloc(&d_cnt, 8) != hipSuccess) { release(); return fail(h, BBDUK_ERR_NOMEM, "hipMalloc"); }
-    hipMemcpyAsync(d_refs, refs, (size_t)total, hipMemcpyHostToDevice, h->stream);
-    hipMemcpyAsync(d_roff, ref_offsets, (size_t)(n_refs + 1) * 8, hipMemcpyHostToDevice, h->stream);
-    hipMemsetAsync(d_sk, 0xFF, cslots * 8, h->stream);
-    hipMemsetAsync(d_si, 0x7F, cslots * 4, h->stream);                     // 0x7F7F7F7F: larger than any id
-    hipMemsetAsync(d_cnt, 0, 8, h->stream);
-    if (total > 0) {
-        const int64_t work = total * (int64_t)(1 + 3 * B.k);
-        const int grid = (int)std::min<int64_t>((work + 255) / 256, (int64_t)h->numCU * 32);
-        bbduk_build_enum_kernel<<<dim3(std::max(grid, 1)), dim3(256), 0, h->stream>>>(B, d_refs, d_roff, d_sk, d_si, cslots - 1, d_cnt);
+    const int k = h->p.k; const bool useShort = h->p.mink > 0 && h->p.mink < k;
+    // upper bound on the keys: every position times the variants within hdist substitutions, plus the short k-mers of mink
+    auto variants = [](int len, int d) { const double t = 3.0 * len; double v = 1.0; if (d >= 1) v += t; if (d >= 2) v += t * (t - 3.0) / 2.0; if (d >= 3) v += t * (t - 3.0) * (t - 6.0) / 6.0; return v; };
+    double ub = (double)total * variants(k, hdist);
+    if (useShort) for (int L = h->p.mink; L < k; L++) ub += 2.0 * (double)n_refs * variants(L, hdist2);
+    int rc = build_begin_impl(h, ub, hdist, hdist2);
+    if (rc != BBDUK_OK) return rc;
+    BuildState* st = h->build;
+    auto bail = [&](int code, const char* msg) { build_release(h); table_release(h); return fail(h, code, msg); };
+    const int64_t CH = 256LL << 20;                                 // bases per upload
+    st->stageCap = (size_t)std::min<int64_t>(std::max<int64_t>(total, 16), CH) + 64;
+    if (hipMalloc(&st->d_stage, st->stageCap) != hipSuccess) return bail(BBDUK_ERR_NOMEM, "hipMalloc (reference staging)");
+    std::vector<int64_t> srcOff, roff(1, 0); std::vector<int32_t> rid; std::vector<uint8_t> rfl;
+    auto flush = [&]() -> int {
+        if (rid.empty()) return BBDUK_OK;
+        for (size_t q = 0; q < rid.size(); q++) {
+            const int64_t len = roff[q + 1] - roff[q];
+            if (len > 0 && hipMemcpyAsync(st->d_stage + roff[q], refs + srcOff[q], (size_t)len, hipMemcpyHostToDevice, h->stream) != hipSuccess) return BBDUK_ERR_DEVICE;
+        }
+        const int r = build_add_pieces(h, st->d_stage, roff.data(), rid.data(), rfl.data(), (int32_t)rid.size());
+        srcOff.clear(); roff.assign(1, 0); rid.clear(); rfl.clear();
+        return r;
+    };
+    for (int32_t sidx = 0; sidx < n_refs; sidx++) {
+        const int64_t s0 = ref_offsets[sidx], n = ref_offsets[sidx + 1] - s0;
+        int64_t pos = 0;
+        do {                                                        // pieces of at most CH bases, consecutive ones share k-1 bases
+            const int64_t len = std::min<int64_t>(n - pos, CH);
+            if (roff.back() + len > CH && (rc = flush()) != BBDUK_OK) return bail(rc, "device build (upload)");
+            srcOff.push_back(s0 + pos); roff.push_back(roff.back() + len); rid.push_back(sidx + 1);
+            rfl.push_back((uint8_t)((pos == 0 ? 1 : 0) | (pos + len == n ? 2 : 0)));
+            if (pos + len == n) break;
+            pos += len - (k - 1);
+        } while (true);
     }
-    unsigned long long distinct = 0;
-    hipMemcpyAsync(&distinct, d_cnt, 8, hipMemcpyDeviceToHost, h->stream);
-    if (hipStreamSynchronize(h->stream) != hipSuccess) { release(); return fail(h, BBDUK_ERR_DEVICE, "device build (enumeration) failed"); }
-    int bbits = 10;
-    while (bbits < 32 && (1ULL << bbits) < distinct) bbits++;
-    if (bbits == 30 && distinct <= (1ULL << 30)) bbits = 29;     // the slot index is 31 bits: the largest maps run at up to 2 keys per bucket
-    const uint64_t nb = 1ULL << bbits;
-    if (4 * nb > (1ULL << 31)) { release(); return fail(h, BBDUK_ERR_ARG, "too many keys for the bucket index"); }
-    auto ceil_log2 = [](uint64_t x) { int b = 0; while ((1ULL << b) < x) b++; return b; };
-    int lb = 0;
-    if (distinct > 0 && distinct <= (1ULL << 22)) lb = std::min(MAX_LDS_BITS, std::max(10, ceil_log2(32ULL * distinct)));
-    if (hipMalloc(&h->d_tags, nb * sizeof(uint64_t)) != hipSuccess || hipMalloc(&h->d_bkv, 4 * nb * sizeof(uint4)) != hipSuccess ||
-        (lb && hipMalloc(&h->d_ldsImage, ((size_t)1 << (lb - 5)) * 4) != hipSuccess)) { release(); return fail(h, BBDUK_ERR_NOMEM, "hipMalloc (map)"); }
-    hipMemsetAsync(h->d_tags, 0, nb * sizeof(uint64_t), h->stream);
-    hipMemsetAsync(h->d_bkv, 0xFF, 4 * nb * sizeof(uint4), h->stream);
-    if (lb) hipMemsetAsync(h->d_ldsImage, 0, ((size_t)1 << (lb - 5)) * 4, h->stream);
-    {
-        const int grid = (int)std::min<uint64_t>((cslots + 255) / 256, (uint64_t)h->numCU * 32);
-        bbduk_build_place_kernel<<<dim3(grid), dim3(256), 0, h->stream>>>(d_sk, d_si, cslots, h->d_tags, h->d_bkv, bbits, (uint32_t)(nb - 1), h->d_ldsImage, lb);
-    }
-    const hipError_t e = hipStreamSynchronize(h->stream);
-    release();
-    if (e != hipSuccess) return fail(h, BBDUK_ERR_DEVICE, "device build (placement) failed");
-    h->nbuckets = nb; h->bucketBits = bbits; h->nkeys = (int64_t)distinct; h->ldsBits = lb;
-    h->finalized = true;
-    return BBDUK_OK;
+    if ((rc = flush()) != BBDUK_OK) return bail(rc, "device build (enumeration)");
+    return build_end_impl(h);
 }
 
 extern "C" int64_t bbduk_table_size(const bbduk_handle* h) { return (h && h->finalized) ? h->nkeys : -1; }
 extern "C" int64_t bbduk_table_bytes(const bbduk_handle* h) {
     if (!h || !h->finalized) return -1;
+    if (h->big) return (int64_t)h->bigLines * (64 + 256 + 32 * h->bigIdBytes);
     return (int64_t)(h->nbuckets * (8 + 4 * 16)) + (h->ldsBits ? (1LL << (h->ldsBits - 3)) : 0);
 }
 
@@ -3327,6 +3769,8 @@ static KParams make_kparams(const bbduk_handle* h) {
     K.middleMask = (uint64_t)p.middleMask;
     K.tags = h->d_tags; K.bkv = h->d_bkv; K.bucketMask = (uint32_t)(h->nbuckets - 1); K.bucketBits = h->bucketBits;
     K.storedKmers = h->nkeys; K.undef = nullptr;
+    K.big = h->big ? 1 : 0; K.bigKeys = h->d_bigKeys; K.bigIds = h->d_bigIds; K.bigIdBytes = h->bigIdBytes; K.bigLines = h->bigLines;
+    K.gm = h->gm; K.gW = h->gW; K.gH = h->gH; K.gD = h->gD;
     K.matchN = nullptr; K.matchIds = nullptr; K.matchCnt = nullptr; K.matchCap = 0;
     K.dbg = h->hookDbg;
     K.ldsImage = h->d_ldsImage; K.ldsBits = h->ldsBits;

@@ -458,7 +458,7 @@ extern "C" int bbduk_host_params(const bbduk_host* h, int32_t device, bbduk_para
 extern "C" int bbduk_host_build_on_device(const bbduk_host* h, bbduk_handle* dev) {
     if (!h || !dev) return BBDUK_ERR_ARG;
     const Parsed& p = h->p;
-    if (p.edist > 0 || p.edist2 > 0 || p.hdist > 2 || p.hdist2 > 2) return BBDUK_ERR_ARG;      // the host builder / upload path serves those
+    if (p.edist > 0 || p.edist2 > 0 || p.hdist > 3 || p.hdist2 > 3) return BBDUK_ERR_ARG;      // the host builder / upload path serves those
     for (const auto& sc : h->scaffolds) {                                                       // so does it serve reference-side skipping
         const int64_t n = (int64_t)sc.size();
         const int heur = n > 20000000 ? p.k : n > 5000000 ? 11 : n > 500000 ? 2 : 0;

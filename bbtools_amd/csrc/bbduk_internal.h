@@ -32,6 +32,17 @@ struct KParams {
     uint32_t bucketMask;
     int32_t  bucketBits;
     int64_t  storedKmers;
+    // The HBM-resident layout for maps far beyond the caches (BASELINE configs[3]; `big` != 0): the same 4-way tag words, eight of
+    // them (32 slots) per 64-byte line; a full-length key's LINE comes from the minimum over its gapped (gm+gm)-mers of a strand-
+    // symmetric hash -- consecutive k-mers of a read share it, so they share one HBM sector -- its WORD in the line from mix_b, its
+    // fingerprint from mix_a; probing walks the line's words cyclically, then the next line.  Keys and ids live in two slot-parallel
+    // arrays (8 + 2|4 bytes) touched only on a fingerprint match.  See "big layout" in bbduk_hip.hip.
+    int32_t  big;
+    const uint64_t* bigKeys;    // [32 * bigLines], EMPTY_KEY = free
+    const void*     bigIds;     // uint16 or uint32 per slot
+    int32_t  bigIdBytes;
+    uint32_t bigLines;
+    int32_t  gm, gW, gH, gD;    // gapped minimizer: m bases from each half, W candidates, half length H, right half starts at D = k-H
     // presence filter in front of the map: one bit per hash slot, copied into LDS by every workgroup
     const uint32_t* ldsImage;   // HBM copy of the LDS bitmap (2^ldsBits bits); 0 bits = absent
     int32_t  ldsBits;
@@ -49,6 +60,11 @@ struct bbduk_handle {
     std::vector<int32_t> hvals;
     int64_t nkeys = 0;
     uint64_t* d_tags = nullptr; uint4* d_bkv = nullptr; uint64_t nbuckets = 0; int bucketBits = 0;
+    // big layout (HBM-resident maps): d_tags holds 8 * bigLines words, keys / ids are slot-parallel arrays
+    bool big = false; uint64_t* d_bigKeys = nullptr; void* d_bigIds = nullptr; int bigIdBytes = 0; uint32_t bigLines = 0;
+    int gm = 0, gW = 0, gH = 0, gD = 0;
+    // streaming device-side build (bbduk_build_begin / _add_device / _end)
+    struct BuildState* build = nullptr;
     uint32_t* d_ldsImage = nullptr; int ldsBits = 0;
     int* d_slowFlag = nullptr;
     static const int EV_RING = 64;                                // HIP events around the dominant kernel of the last launches
@@ -66,7 +82,7 @@ struct bbduk_handle {
     int numCU = 256;
     bbduk_comm* comm = nullptr;          // set by bbduk_comm_create / bbduk_comm_create_local
     // include/bbduk_test_hooks.h (tests and experiments only)
-    bool hookForceTile = false; int hookBucketBits = 0, hookLdsBits = -1, hookDbg = 0;
+    bool hookForceTile = false, hookBigLayout = false; int hookBucketBits = 0, hookLdsBits = -1, hookDbg = 0;
 };
 
 #define HIP_TRY(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \

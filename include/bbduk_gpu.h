@@ -113,7 +113,9 @@ int  bbduk_create(const bbduk_params* p, bbduk_handle** out);
 int  bbduk_destroy(bbduk_handle* h);
 const char* bbduk_last_error(const bbduk_handle* h);      /* valid until the next call on h */
 
-/* ---- table: key -> scaffold id (>0).  May be called repeatedly before finalize; first writer wins. */
+/* ---- table: key -> scaffold id (1..numScaffolds-1; anything else is BBDUK_ERR_ARG).  The upload calls may be repeated before
+ * finalize; a key uploaded more than once keeps its SMALLEST id -- the first scaffold in file order, which is what
+ * HashArray.setIfNotPresent leaves in the reference's own tables.  bbduk_finalize_table places the pairs on the device. */
 int  bbduk_upload_table_way(bbduk_handle* h, int32_t way, int32_t prime,
                             const int64_t* keys, const int32_t* values, int64_t ncells,   /* keys[i]==-1: empty */
                             const int64_t* vkeys, const int32_t* vvals, int64_t nvictims);
@@ -122,10 +124,18 @@ int  bbduk_finalize_table(bbduk_handle* h);
 /* Alternative to upload + finalize: build the map ON the device from the reference sequences themselves (SURVEY 8f-4;
  * BBDukLoader.addToMap bbduk/BBDukLoader.java:416-494, BBDukIndexMod.addToMap/mutate :289-445): refs = the scaffolds'
  * bases concatenated in file order (host pointer), ref_offsets[n_refs+1]; scaffold s gets id s+1 and the first
- * scaffold wins a shared key.  hdist/hdist2 (0..2) are the ref-side Hamming distances (BBDukParser.java:130-133);
+ * scaffold wins a shared key.  hdist/hdist2 (0..3) are the ref-side Hamming distances (BBDukParser.java:130-133);
  * k, mink, rcomp, middleMask come from bbduk_create.  Leaves the handle finalized. */
 int  bbduk_build_table_device(bbduk_handle* h, const uint8_t* refs, const int64_t* ref_offsets, int32_t n_refs,
                               int32_t hdist, int32_t hdist2);
+/* The same build, streamed, for references that are produced or ingested on the device or do not fit one host buffer (the 10 GB
+ * reference of BASELINE configs[3]): begin announces an upper bound on the number of keys (for hdist 0: the number of reference
+ * bases) -- beyond 2^25 keys the map takes the HBM-resident layout, 12-14 bytes per slot at ~0.6 keys per slot, built in place;
+ * every add hands over WHOLE scaffolds already in HBM (d_refs device pointer, ref_offsets HOST array of n_refs+1 values starting at
+ * 0; scaffold i of the call gets id first_id + i); end leaves the handle finalized.  An error ends the build and frees the map. */
+int  bbduk_build_begin(bbduk_handle* h, int64_t max_keys, int32_t hdist, int32_t hdist2);
+int  bbduk_build_add_device(bbduk_handle* h, const uint8_t* d_refs, const int64_t* ref_offsets, int32_t n_refs, int32_t first_id);
+int  bbduk_build_end(bbduk_handle* h);
 int64_t bbduk_table_size(const bbduk_handle* h);          /* distinct keys resident, or <0 */
 int64_t bbduk_table_bytes(const bbduk_handle* h);         /* HBM bytes held by the table image */
 /* point lookups through the device table (test hook): out_ids[i] = id or -1 */

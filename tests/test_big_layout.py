@@ -1,0 +1,167 @@
+"""The HBM-resident map layout (BASELINE configs[3]: a 10 GB reference) forced onto small maps with bbduk_test_hook, so that its
+build (in place, on the device), its exact per-key lookup (every kernel's generic path) and its fast minimizer-sharing candidate
+scan (bbduk_wave_kernel<.., BIG>) are compared with the oracle on inputs the oracle finishes in seconds.  The full-size run is
+profiles/bench_c4_full.py."""
+import random
+
+import numpy as np
+import pytest
+
+from bbtools_amd import bbduk as B
+from oracle.oracle_ffi import Oracle, pack_reads
+from tests import util
+from tests.test_gpu_parity import check_batch, FUZZ
+
+pytestmark = pytest.mark.gpu
+BIG = {B.HOOK_BIG_LAYOUT: 1}
+
+
+def big_pair(args, okw, refs=None, ref_fasta=None, build="host"):
+    o = Oracle(**okw)
+    if refs is not None:
+        d = B.BBDuk(args, refs=refs, hooks=BIG, build=build)
+        for r in refs:
+            o.add_ref(r)
+    else:
+        d = B.BBDuk(args, hooks=BIG, build=build)
+        o.load_fasta(ref_fasta)
+    assert d.gpu.table_size == o.stored_kmers
+    return d, o
+
+
+@pytest.mark.parametrize("build", ["host", "device"])
+@pytest.mark.parametrize("cfg", ["c4s", "c3", "c2", "c1", "c5", "c3q", "c3mcf", "c3mkf"])
+def test_big_layout_on_the_baseline_configs(cfg, build):
+    args, okw, ref = util.CONFIGS[cfg]
+    d, o = big_pair(args, okw, ref_fasta=ref, build=build)
+    assert d.gpu.table_bytes >= 64 * (64 + 256 + 64)               # whole 32-slot lines
+    ks, vs = o.dump_pairs()
+    rng = np.random.default_rng(3)
+    probe = np.concatenate([ks, rng.integers(0, 1 << 62, 50000, dtype=np.int64), np.array([-1, 0, 1 << 62], np.int64)])
+    exp = np.concatenate([vs, np.array([o.table_get(int(x)) for x in probe[len(ks):]], np.int32)])
+    assert np.array_equal(d.gpu.table_lookup(probe), exp)          # every key with its id, nothing else
+    kw = dict(contam=B.read_fasta(util.PHIX)[0][1], contam_frac=0.05) if "phix" in args else {}
+    b, off = B.synth_generate_host(B.synth_params(13, n_rate=0.004, **kw), 500, 20000)      # Ns in most reads' neighbourhoods
+    for paired in (True, False):
+        d.gpu.reset_counters(); o.reset_counters()
+        ga, gi, gf = d.gpu.process_batch(b, off, paired)
+        oa, oi, of = o.process_batch(b, off, paired, nthreads=8)
+        bad = np.nonzero((ga != oa) | (gi != oi) | (gf != of))[0]
+        assert len(bad) == 0, (cfg, build, paired, bad[:5], ga[bad[:5]], oa[bad[:5]])
+        assert np.array_equal(d.gpu.counters(), o.counters())
+    codes, undef = B.pack_bases_host(b)
+    d.gpu.reset_counters()
+    pa, pi, pf = d.gpu.process_batch_packed(codes, undef, off, True)
+    oa, oi, of = o.process_batch(b, off, True, nthreads=8)
+    assert np.array_equal(pa, oa) and np.array_equal(pi, oi) and np.array_equal(pf, of)
+    assert int((oa > 0).sum()) > 100
+    d.close()
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2, 3, 4, 7, 9, 15, 16, 17, 20, 22, 24, 26])
+def test_big_layout_fuzz(ci):
+    """Ragged, empty, junk-laden reads and the flag combinations of the general kernels on the big layout (k too small for its
+    minimizer geometry falls back to the cache-resident layout, which is fine: the hook only asks)."""
+    args, okw = FUZZ[ci]
+    for seed in range(2):
+        rng = random.Random(7000 + 100 * ci + seed)
+        refs = [util.rand_seq(rng, rng.randint(5, 90), 0.01) for _ in range(8)]
+        d, o = big_pair(args, okw, refs=refs, build="host")
+        reads = util.fuzz_reads(rng, refs, 600, [0, 1, 2, 5, 10, 11, 22, 23, 30, 31, 32, 40, 63, 64, 65, 75, 150, 151, 300], junk=True)
+        check_batch(d, o, reads, True)
+        check_batch(d, o, reads[:301], False)
+        d.close()
+
+
+def test_big_layout_long_reads_cross_the_block_seam():
+    """Reads of several hundred bases: the fast scan advances 120 positions per block and hands the top lanes' windows to the next
+    block; reference pieces are planted across those seams and at both ends, on both strands, with and without an N nearby."""
+    rng = random.Random(5)
+    ref = util.rand_seq(rng, 3000)
+    for args, okw in (("k=31", dict(k=31)), ("k=31 hdist=1", dict(k=31, hdist=1)), ("k=27 mm=f", dict(k=27, maskMiddle=0)), ("k=24", dict(k=24))):
+        d, o = big_pair(args, okw, refs=[ref], build="device")
+        k = okw["k"]
+        reads = []
+        for L in (150, 151, 269, 270, 271, 300, 389, 390, 391, 520, 1000, 2400):
+            for pos in (0, 1, L - k, L - k - 1, 119 + 30 - k + 1, 120 + 30 - k, 121 + 30 - k, 239 + 30 - k, 240 + 30 - k, 241 + 30 - k, L // 2):
+                if pos < 0 or pos + k > L:
+                    continue
+                g = bytearray(util.rand_seq(rng, L))
+                a = rng.randrange(len(ref) - k); piece = ref[a:a + k]
+                g[pos:pos + k] = util.revcomp(piece) if rng.random() < 0.5 else piece
+                if rng.random() < 0.4:
+                    g[rng.randrange(L)] = ord("N")
+                reads.append(bytes(g))
+        reads += [util.rand_seq(rng, L, 0.003) for L in (150, 300, 1000) for _ in range(20)]
+        check_batch(d, o, reads, True)
+        check_batch(d, o, reads, False)
+        d.close()
+
+
+@pytest.mark.parametrize("mode", ["stream", "oneshot", "pairs"])
+def test_big_layout_five_million_keys(mode):
+    """A map the size at which the layout would be chosen without the hook's help is 2^25 keys; 4.6 M keys here (the oracle builds
+    its own table), three ways in: the streaming device build (whole scaffolds per call), the one-shot device build from host
+    memory, and uploaded pairs placed on the device."""
+    import torch
+    rng = np.random.default_rng(5)
+    refs = [rng.choice(np.frombuffer(b"ACGT", np.uint8), n).tobytes() for n in (2_000_000, 1_500_000, 31, 30, 1_100_000)]
+    o = Oracle(k=31)
+    for r in refs:
+        o.add_ref(r)
+    if mode == "oneshot":
+        d = B.BBDuk("k=31", refs=refs, hooks=BIG, build="device")
+    elif mode == "pairs":
+        d = B.BBDuk("k=31", refs=refs, hooks=BIG, build="host")
+    else:
+        d = B.BBDuk.__new__(B.BBDuk)
+        d.host = B.HostIndex("k=31")
+        for r in refs:
+            d.host.add_ref(r)
+        d.gpu = B.BBDukGpu(d.host.params(0))
+        d.gpu.test_hook(B.HOOK_BIG_LAYOUT, 1)
+        d.gpu.build_begin(sum(len(r) for r in refs), 0, 0)
+        with pytest.raises(B.BBDukError):
+            d.gpu.finalize_table()                                  # a build is in progress
+        for first, group in ((1, refs[:2]), (3, refs[2:4]), (5, refs[4:])):
+            cat = np.frombuffer(b"".join(group), np.uint8)
+            offs = np.concatenate([[0], np.cumsum([len(r) for r in group])]).astype(np.int64)
+            d.gpu.build_add_device(torch.from_numpy(cat.copy()).cuda(), offs, first)
+        with pytest.raises(B.BBDukError):
+            d.gpu.build_add_device(torch.zeros(40, dtype=torch.uint8).cuda(), np.array([0, 40], np.int64), 6)     # id beyond numScaffolds-1
+        d.gpu.build_end()
+        d.stored_kmers = d.gpu.table_size
+    assert d.gpu.table_size == o.stored_kmers > (1 << 22)
+    prng = random.Random(9)
+    reads = []
+    for i in range(20000):
+        if i % 2:
+            r = refs[prng.choice([0, 1, 4])]
+            a = prng.randrange(len(r) - 150); s = r[a:a + 150]
+            reads.append(util.revcomp(s) if prng.random() < 0.5 else s)
+        else:
+            reads.append(util.rand_seq(prng, 150, 0.002))
+    check_batch(d, o, reads, True, nthreads=8)
+    assert d.gpu.counters()[4] > 9000
+    ks, vs = o.dump_pairs()
+    sel = np.random.default_rng(1).choice(len(ks), 200000, replace=False)
+    assert np.array_equal(d.gpu.table_lookup(ks[sel]), vs[sel])
+    d.close()
+
+
+def test_big_layout_secondary_operators():
+    """ktrim=n, ktrim=rl, ksplit, k>31 and findbestmatch run the general scan functions: on the big layout their lookups take
+    the exact per-key path."""
+    rng = random.Random(11)
+    refs, reads = util.long_refs_and_reads(rng)
+    for args, okw in (("ktrim=n k=23 mink=11 hdist=1", dict(k=23, mink=11, hdist=1, ktrimN=1)), ("ktrim=rl k=23 mink=11", dict(k=23, mink=11, ktrimRight=1, ktrimLeft=1)),
+                      ("k=40", dict(k=31, kbig=40, maskMiddle=0)), ("k=25 fbm=t", dict(k=25, findBestMatch=1)),
+                      ("ksplit=t k=23 mink=11 hdist=1", dict(k=23, mink=11, hdist=1, ksplit=1))):
+        o = Oracle(**okw)
+        d = B.BBDuk(args, refs=refs, hooks=BIG)
+        for r in refs:
+            o.add_ref(r)
+        assert d.gpu.table_size == o.stored_kmers
+        rr = reads + reads[:1] * (len(reads) % 2)
+        check_batch(d, o, rr, "ksplit" not in args)
+        d.close()
