@@ -148,43 +148,49 @@ __host__ __device__ __forceinline__ uint32_t gap_hmin_value(const BigGeom& G, co
     }
     return best;
 }
-// home word (8 * line + word in line) of any key (with its length bit): full-length keys by their gapped minimizer, the short
-// k-mers of mink (other lengths) by a plain hash
-__host__ __device__ __forceinline__ uint64_t big_home_word(const BigGeom& G, const uint64_t key, const uint32_t ma, const uint32_t mb) {
+// line of any key (with its length bit): full-length keys by their gapped minimizer, the short k-mers of mink (other lengths)
+// by a plain hash
+__host__ __device__ __forceinline__ uint32_t big_line_of_key(const BigGeom& G, const uint64_t key, const uint32_t ma) {
     const uint64_t v = strip_len(key);
     const uint32_t h = (key >> (2 * G.k)) == 1ULL ? gap_hmin_value(G, v) : (ma ^ 0x5BD1E995u);
-    return 8ULL * gap_line(h, G.nlines) + (mb >> 29);
+    return gap_line(h, G.nlines);
 }
-// i-th word of the probe sequence that starts at `home`: the line's words cyclically, then the next line
-__host__ __device__ __forceinline__ uint64_t big_probe_word(const uint64_t home, const uint32_t i, const uint32_t nlines) {
-    uint64_t line = (home >> 3) + (i >> 3);
-    if (line >= nlines) line -= nlines;
-    return 8ULL * line + (((uint32_t)home + i) & 7u);
+// A key has two words in its line: the primary (top 3 bits of mix_b) and an alternate (the next 3 bits, made distinct).  It lives
+// in the first free way of the primary, else of the alternate; if both are full it is SPILLED into the secondary map (the
+// cache-resident layout's buckets: KParams::tags / bkv) and the primary word gets the flag bit.  So a lookup is: both words (one
+// 64-byte sector), and only if the primary carries the flag one more gather.  No probe chains: an overloaded line costs its
+// absent keys nothing more.  (~6 % of the keys spill at 0.6 keys per slot, ~9 % of the words carry the flag.)
+__host__ __device__ __forceinline__ void big_words(const uint32_t line, const uint32_t mb, uint32_t& w1, uint32_t& w2) {
+    const uint32_t a = mb >> 29; uint32_t b = (mb >> 26) & 7u;
+    b = (b == a) ? (b ^ 1u) : b;
+    w1 = 8u * line + a; w2 = 8u * line + b;
 }
 __device__ __forceinline__ BigGeom big_geom(const KParams& P) { BigGeom G; G.k = P.k; G.m = P.gm; G.W = P.gW; G.H = P.gH; G.D = P.gD; G.nlines = P.bigLines; G.middleMask = P.middleMask; return G; }
 __device__ __forceinline__ int big_id_at(const KParams& P, const uint64_t slot) {
     return P.bigIdBytes == 2 ? (int)reinterpret_cast<const uint16_t*>(P.bigIds)[slot] : (int)reinterpret_cast<const uint32_t*>(P.bigIds)[slot];
 }
-// lookup from a given home word; t0 = its tags
-__device__ __forceinline__ int big_find_from(const KParams& P, const uint64_t key, const uint32_t ma, const uint64_t home, uint64_t t) {
+__device__ __forceinline__ int table_find_t(const KParams& P, uint64_t key, uint32_t ma, uint32_t mb, uint64_t t0);
+// exact lookup given the key's two words and their tags
+__device__ __forceinline__ int big_find_in(const KParams& P, const uint64_t key, const uint32_t ma, const uint32_t mb,
+                                           const uint32_t w1, const uint32_t w2, const uint64_t t1, const uint64_t t2) {
     const uint64_t pat = (uint64_t)tag_of(ma) * 0x0001000100010001ULL;
-    uint64_t word = home;
-    for (uint32_t i = 0;;) {
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const uint64_t t = q ? t2 : t1; const uint32_t word = q ? w2 : w1;
         uint64_t cand = zero16((t & TAG_FPS) ^ pat);
         while (cand) {
             const int way = (__ffsll((unsigned long long)cand) - 1) >> 4;
             if (P.bigKeys[4ULL * word + way] == key) return big_id_at(P, 4ULL * word + way);
             cand &= cand - 1;
         }
-        if (!(t & TAG_CONT)) return -1;
-        i++;
-        word = big_probe_word(home, i, P.bigLines);
-        t = P.tags[word];
     }
+    if (!(t1 & TAG_CONT)) return -1;                               // nothing was ever spilled from the primary word
+    return table_find_t(P, key, ma, mb, P.tags[bucket_of(mb, P.bucketBits)]);
 }
 __device__ __forceinline__ int big_find(const KParams& P, const uint64_t key, const uint32_t ma, const uint32_t mb) {
-    const uint64_t home = big_home_word(big_geom(P), key, ma, mb);
-    return big_find_from(P, key, ma, home, P.tags[home]);
+    uint32_t w1, w2;
+    big_words(big_line_of_key(big_geom(P), key, ma), mb, w1, w2);
+    return big_find_in(P, key, ma, mb, w1, w2, P.bigTags[w1], P.bigTags[w2]);
 }
 
 // map lookup with the mixes already computed: id (>0) of the key, or -1.  t0 = tags of the home bucket.
@@ -522,7 +528,7 @@ __device__ __forceinline__ void win_init(const KParams& P, const Planes& Q, cons
 // fit the 64-bit cut); the planes are padded, so no clamping -- out-of-read lanes are simply not ok.
 template <bool FORBIDN, bool GENERAL>
 __device__ __forceinline__ void windows2(const KParams& P, const Planes& Q, const ReadWin& W, const int i, const bool on,
-                                         uint64_t* kmer, uint64_t* rk, bool* ok) {
+                                         uint64_t* kmer, uint64_t* rk, bool* ok, uint64_t* rkRaw = nullptr) {
     const int k = P.k;
     if (W.full) {
         const uint64_t wf = cut64_lds(Q.fwdBits + 2u * (uint32_t)(Q.T - 1 - W.base0 - (i + 1)));   // base i+1 in bits 0-1, base i-k+1 on top
@@ -537,6 +543,7 @@ __device__ __forceinline__ void windows2(const KParams& P, const Planes& Q, cons
         }
         ok[0] = on & (i < W.stop);
         ok[1] = on & (i + 1 < W.stop);
+        if (rkRaw) { rkRaw[0] = rk[0]; rkRaw[1] = rk[1]; }        // before any reset (big layout: the neighbours' minimizer hashes)
         if (FORBIDN && P.forbidNs && W.hasN) {                   // the read holds an undefined base somewhere: patch the few windows that see it
             const int nidx = min(W.base0 - k + 1 + i, Q.T);      // bit t <=> base i-k+1+t undefined
             const uint32_t nw = __builtin_amdgcn_alignbit(Q.nm[(nidx >> 5) + 1], Q.nm[nidx >> 5], nidx);
@@ -773,9 +780,9 @@ __device__ __forceinline__ uint32_t gap_h0(const KParams& P, const uint64_t kmer
 // flagged and looked up by the generic exact path in cand_resolve4_big.  Windows at the top of the block (position >= 128 - W
 // within it) lack their successors: the caller advances by BIG_STEP positions and ignores them.
 #define BIG_STEP 120
-struct Cand4Big { uint64_t key[4], t[4]; uint32_t ma[4], mb[4], word[4]; uint64_t hm[4]; bool nf[4]; };
+struct Cand4Big { uint64_t key[4], t1[4], t2[4]; uint32_t ma[4], mb[4], w1[4], w2[4]; uint64_t hm[4]; bool nf[4]; };
 template <bool NOMM>
-__device__ __forceinline__ uint64_t cand_probe4_big(const KParams& P, const uint64_t* kmer, const uint64_t* rk, const bool* nf, Cand4Big& C) {
+__device__ __forceinline__ uint64_t cand_probe4_big(const KParams& P, const uint64_t* kmer, const uint64_t* rk, const uint64_t* rkRaw, const bool* nf, Cand4Big& C) {
     const uint32_t mmLo = (uint32_t)P.middleMask, mmHi = (uint32_t)(P.middleMask >> 32);
     uint32_t h0[4], hw[4];
 #pragma unroll
@@ -785,28 +792,32 @@ __device__ __forceinline__ uint64_t cand_probe4_big(const KParams& P, const uint
         C.key[s] = ((uint64_t)khi << 32) | klo;
         C.ma[s] = klo * HA0 + khi * HA1;
         C.mb[s] = klo * HB0 + khi * HB1;
-        h0[s] = gap_h0(P, kmer[s], rk[s]);
+        h0[s] = gap_h0(P, kmer[s], rkRaw[s]);                      // the raw complement cut: a reset further right does not touch these bases
         C.nf[s] = nf[s];
     }
     window_min(P.gW, h0[0], h0[1], hw[0], hw[1]);
     window_min(P.gW, h0[2], h0[3], hw[2], hw[3]);
 #pragma unroll
     for (int s = 0; s < 4; s++) {
-        C.word[s] = 8u * gap_line(hw[s], P.bigLines) + (C.mb[s] >> 29);
-        C.t[s] = P.tags[C.word[s]];                                // four gathers in flight; neighbours share 64-byte sectors
+        big_words(gap_line(hw[s], P.bigLines), C.mb[s], C.w1[s], C.w2[s]);
+        C.t1[s] = P.bigTags[C.w1[s]];                              // eight gathers in flight; a lane's two words and its neighbours' share a sector
+        C.t2[s] = P.bigTags[C.w2[s]];
     }
     uint64_t any = 0;
 #pragma unroll
     for (int s = 0; s < 4; s++) {
-        const uint32_t fp = tag_of(C.ma[s]), tlo = (uint32_t)C.t[s], thi = (uint32_t)(C.t[s] >> 32);
-        C.hm[s] = __ballot((tlo & 0xFFFFu) == fp) | __ballot((tlo >> 16) == fp) | __ballot((thi & 0xFFFFu) == fp) |
-                  __ballot((thi >> 16) == fp) | __ballot((int32_t)thi < 0) | __ballot(nf[s]);
+        const uint32_t fp = tag_of(C.ma[s]);
+        const uint32_t alo = (uint32_t)C.t1[s], ahi = (uint32_t)(C.t1[s] >> 32), blo = (uint32_t)C.t2[s], bhi = (uint32_t)(C.t2[s] >> 32);
+        // eight 16-bit compares and the primary word's spill flag (its lane 3 then never compares equal: the resolve path masks it)
+        C.hm[s] = __ballot((alo & 0xFFFFu) == fp) | __ballot((alo >> 16) == fp) | __ballot((ahi & 0xFFFFu) == fp) | __ballot((ahi >> 16) == fp) |
+                  __ballot((blo & 0xFFFFu) == fp) | __ballot((blo >> 16) == fp) | __ballot((bhi & 0xFFFFu) == fp) | __ballot((bhi >> 16) == fp) |
+                  __ballot((int32_t)ahi < 0) | __ballot(nf[s]);
         any |= C.hm[s];
     }
     return any;
 }
-// ref: way (0..3) of the first fingerprint match in C.word (unverified), -3-id for a hit verified here (chain walk, or the exact
-// lookup of a window with an undefined base), -1 = certainly absent
+// ref: way (0..3) of the first fingerprint match, in word C.w1 (ref < 4) or C.w2 (ref - 4), unverified; -3-id for a hit verified
+// here (a spilled key found in the secondary map, or the exact lookup of a window with an undefined base); -1 = certainly absent
 __device__ __forceinline__ void cand_resolve4_big(const KParams& P, const Cand4Big& C, int* ref) {
 #pragma unroll
     for (int s = 0; s < 4; s++) {
@@ -817,14 +828,13 @@ __device__ __forceinline__ void cand_resolve4_big(const KParams& P, const Cand4B
             ref[s] = id > 0 ? -3 - id : -1;
             continue;
         }
-        const uint32_t fp = tag_of(C.ma[s]);
-        const uint64_t cand = zero16((C.t[s] & TAG_FPS) ^ ((uint64_t)fp * 0x0001000100010001ULL));
-        if (cand != 0ULL || (C.t[s] & TAG_CONT)) {
-            if (!(C.t[s] & TAG_CONT)) ref[s] = (__ffsll((unsigned long long)cand) - 1) >> 4;
-            else {
-                const int id = big_find_from(P, C.key[s] | P.kmask, C.ma[s], (uint64_t)C.word[s], C.t[s]);
-                ref[s] = id > 0 ? -3 - id : -1;
-            }
+        const uint64_t pat = (uint64_t)tag_of(C.ma[s]) * 0x0001000100010001ULL;
+        const uint64_t c1 = zero16((C.t1[s] & TAG_FPS) ^ pat), c2 = zero16((C.t2[s] & TAG_FPS) ^ pat);
+        if (c1) ref[s] = (__ffsll((unsigned long long)c1) - 1) >> 4;
+        else if (c2) ref[s] = 4 + ((__ffsll((unsigned long long)c2) - 1) >> 4);
+        else if (C.t1[s] & TAG_CONT) {                            // the key may have been spilled: the secondary map answers
+            const int id = table_find_t(P, C.key[s] | P.kmask, C.ma[s], C.mb[s], P.tags[bucket_of(C.mb[s], P.bucketBits)]);
+            ref[s] = id > 0 ? -3 - id : -1;
         }
     }
 }
@@ -995,9 +1005,9 @@ __device__ __forceinline__ void main_scan_pair_cand(const KParams& P, const Plan
     // none.  Reads with cut or reset windows (restrictRight, an undefined base) mask their ballots with `ok` instead.
     const bool plainA = WA.full && !((FORBIDN || BIG) && WA.hasN), plainB = WB.full && !((FORBIDN || BIG) && WB.hasN);
     while (onA || onB) {
-        uint64_t kmer[4], rk[4]; bool ok[4]; int ref[4]; Cand4 C;
-        windows2<FORBIDN, GENERAL>(P, Q, WA, ibA + 2 * lane, onA, kmer, rk, ok);
-        windows2<FORBIDN, GENERAL>(P, Q, WB, ibB + 2 * lane, onB, kmer + 2, rk + 2, ok + 2);
+        uint64_t kmer[4], rk[4], rkRaw[4]; bool ok[4]; int ref[4]; Cand4 C;
+        windows2<FORBIDN, GENERAL>(P, Q, WA, ibA + 2 * lane, onA, kmer, rk, ok, BIG ? rkRaw : nullptr);
+        windows2<FORBIDN, GENERAL>(P, Q, WB, ibB + 2 * lane, onB, kmer + 2, rk + 2, ok + 2, BIG ? rkRaw + 2 : nullptr);
 #ifdef BBDUK_TIMING_SWITCHES
         if (TSW(P, 8)) {                                             // experiment: 16 extra dependent-free VALU ops per block
             uint32_t z0 = (uint32_t)kmer[0], z1 = (uint32_t)kmer[1], z2 = (uint32_t)kmer[2], z3 = (uint32_t)kmer[3];
@@ -1027,7 +1037,7 @@ __device__ __forceinline__ void main_scan_pair_cand(const KParams& P, const Plan
                     nf[2 * r] = ok[2 * r] && (nw & km) != 0u; nf[2 * r + 1] = ok[2 * r + 1] && ((nw >> 1) & km) != 0u;
                 }
             }
-            anyFlag = cand_probe4_big<NOMM>(P, kmer, rk, nf, CB);
+            anyFlag = cand_probe4_big<NOMM>(P, kmer, rk, rkRaw, nf, CB);
             key = CB.key;
         } else {
             anyFlag = cand_probe4<GENERAL, NOMM, true>(P, Q.filt, kmer, rk, C);
@@ -1055,7 +1065,13 @@ __device__ __forceinline__ void main_scan_pair_cand(const KParams& P, const Plan
                 const int rs = h ? ref[2 * r + 1] : ref[2 * r];
                 const uint64_t ks = h ? key[2 * r + 1] : key[2 * r];
                 R.candSlot = __builtin_amdgcn_readlane(rs, l);
-                if constexpr (BIG) { const uint32_t ws = h ? CB.word[2 * r + 1] : CB.word[2 * r]; R.candWord = (uint32_t)__builtin_amdgcn_readlane((int)ws, l); }
+                if constexpr (BIG) {                             // way 0..3 of the primary word, 4..7 = of the alternate
+                    const int sl = 2 * r + h;
+                    const uint32_t ws = (rs >= 4) ? (h ? CB.w2[2 * r + 1] : CB.w2[2 * r]) : (h ? CB.w1[2 * r + 1] : CB.w1[2 * r]);
+                    (void)sl;
+                    R.candWord = (uint32_t)__builtin_amdgcn_readlane((int)ws, l);
+                    if (R.candSlot >= 4) R.candSlot -= 4;
+                }
                 R.candKeyLo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ks, l);
                 R.candKeyHi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ks >> 32), l);
                 R.iFirst = ib + 2 * l + h;
@@ -1376,8 +1392,9 @@ __device__ __forceinline__ uint64_t hash64(uint64_t x) { x ^= x >> 33; x *= 0xff
 struct Sink {
     int32_t big;
     uint64_t* skeys; int32_t* sids; uint64_t cmask;              // scratch set
-    uint64_t* tags; uint64_t* keys; void* ids; int32_t idBytes; BigGeom G;     // big layout
-    unsigned long long* distinct;                                // [0] distinct keys, [1] != 0: a key found no slot (table full)
+    uint64_t* tags; uint64_t* keys; void* ids; int32_t idBytes; BigGeom G;     // big layout: the lines
+    uint64_t* tags2; uint4* bkv2; int32_t bucketBits2; uint32_t bucketMask2;    // big layout: the secondary map of the spilled keys
+    unsigned long long* distinct;                                // [0] distinct keys, [1] != 0: a key found no slot (map full), [2] spilled keys
 };
 __device__ __forceinline__ void scratch_insert(const Sink& S, const uint64_t key, const int id) {
     uint64_t hslot = hash64(key) & S.cmask;
@@ -1406,14 +1423,39 @@ __device__ __forceinline__ void big_id_min(const Sink& S, const uint64_t slot, c
         if (atomicCAS(wp, old, nw) == old) return;
     }
 }
-#define BIG_MAX_PROBE_WORDS 4096                                  // 512 lines: a key that finds no slot that far has met a full table
+// Insert into the secondary map (the cache-resident layout's buckets, filled in place here): first free way at or after the home
+// bucket, continuation flags on the full buckets passed; an existing copy of the key keeps the smaller id.
+#define SPILL_MAX_BUCKETS 4096
+__device__ __forceinline__ void spill_insert(const Sink& S, const uint64_t key, const uint32_t ma, const uint32_t mb, const int id) {
+    uint32_t b = bucket_of(mb, S.bucketBits2);
+    for (int i = 0; i < SPILL_MAX_BUCKETS; i++) {
+        for (int w = 0; w < 4; w++) {
+            unsigned long long* slot = reinterpret_cast<unsigned long long*>(&S.bkv2[4ULL * b + w]);       // {key lo, key hi}
+            unsigned long long prev = *reinterpret_cast<volatile unsigned long long*>(slot);
+            if (prev == EMPTY_KEY) prev = atomicCAS(slot, (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+            if (prev == EMPTY_KEY || prev == key) {
+                atomicMin(&S.bkv2[4ULL * b + w].z, (uint32_t)id);     // .z starts at 0xFFFFFFFF
+                if (prev == EMPTY_KEY) {
+                    atomicOr((unsigned long long*)&S.tags2[b], (unsigned long long)tag_of(ma) << (16 * w));
+                    atomicAdd(S.distinct, 1ULL); atomicAdd(S.distinct + 2, 1ULL);
+                }
+                return;
+            }
+        }
+        atomicOr((unsigned long long*)&S.tags2[b], (unsigned long long)TAG_CONT);
+        b = (b + 1) & S.bucketMask2;
+    }
+    atomicOr(S.distinct + 1, 1ULL);                                // the secondary map is full
+}
 __device__ __forceinline__ void big_insert(const Sink& S, const uint64_t key, const int id) {
     const uint64_t v = strip_len(key);
     const uint32_t ma = mix_a(v), mb = mix_b(v);
-    const uint64_t home = big_home_word(S.G, key, ma, mb);
+    uint32_t w1, w2;
+    big_words(big_line_of_key(S.G, key, ma), mb, w1, w2);
     const unsigned long long fp = (unsigned long long)tag_of(ma);
-    for (uint32_t i = 0; i < BIG_MAX_PROBE_WORDS; i++) {
-        const uint64_t word = big_probe_word(home, i, S.G.nlines);
+#pragma unroll
+    for (int q = 0; q < 2; q++) {                                 // the same order for every inserter of this key: no duplicates
+        const uint32_t word = q ? w2 : w1;
         for (int way = 0; way < 4; way++) {
             const uint64_t slot = 4ULL * word + way;
             unsigned long long prev = *reinterpret_cast<volatile unsigned long long*>(&S.keys[slot]);
@@ -1426,9 +1468,9 @@ __device__ __forceinline__ void big_insert(const Sink& S, const uint64_t key, co
             }
             if (prev == key) { big_id_min(S, slot, id); return; }
         }
-        atomicOr((unsigned long long*)&S.tags[word], (unsigned long long)TAG_CONT);
     }
-    atomicOr(S.distinct + 1, 1ULL);
+    atomicOr((unsigned long long*)&S.tags[w1], (unsigned long long)TAG_CONT);       // both words full: the key is spilled
+    spill_insert(S, key, ma, mb, id);
 }
 __device__ __forceinline__ void sink_insert(const Sink& S, const uint64_t key, const int id) {
     if (S.big) big_insert(S, key, id); else scratch_insert(S, key, id);
@@ -3431,7 +3473,7 @@ extern "C" int bbduk_destroy(bbduk_handle* h) {
     bbduk_comm_destroy(h);
     hipSetDevice(h->p.device);
     build_release(h);
-    hipFree(h->d_bigKeys); hipFree(h->d_bigIds);
+    hipFree(h->d_bigTags); hipFree(h->d_bigKeys); hipFree(h->d_bigIds);
     hipFree(h->d_tags); hipFree(h->d_bkv); hipFree(h->d_bases); hipFree(h->d_undef); hipFree(h->d_off);
     hipFree(h->d_ldsImage); hipFree(h->d_slowFlag);
     for (int q = 0; q < bbduk_handle::EV_RING; q++) { if (h->ev0[q]) hipEventDestroy(h->ev0[q]); if (h->ev1[q]) hipEventDestroy(h->ev1[q]); }
@@ -3492,8 +3534,8 @@ static void build_release(bbduk_handle* h) {
     delete st; h->build = nullptr;
 }
 static void table_release(bbduk_handle* h) {       // a failed build leaves no half-made map behind
-    hipFree(h->d_tags); hipFree(h->d_bkv); hipFree(h->d_ldsImage); hipFree(h->d_bigKeys); hipFree(h->d_bigIds);
-    h->d_tags = nullptr; h->d_bkv = nullptr; h->d_ldsImage = nullptr; h->d_bigKeys = nullptr; h->d_bigIds = nullptr;
+    hipFree(h->d_tags); hipFree(h->d_bkv); hipFree(h->d_ldsImage); hipFree(h->d_bigTags); hipFree(h->d_bigKeys); hipFree(h->d_bigIds);
+    h->d_tags = nullptr; h->d_bkv = nullptr; h->d_ldsImage = nullptr; h->d_bigTags = nullptr; h->d_bigKeys = nullptr; h->d_bigIds = nullptr;
     h->big = false; h->nbuckets = 0; h->bigLines = 0; h->ldsBits = 0; h->nkeys = 0;
 }
 // gapped-minimizer geometry of the big layout for this k and middle mask (see "big layout"); false: k too small for it
@@ -3516,7 +3558,8 @@ static BigGeom host_geom(const bbduk_handle* h) { BigGeom G; G.k = h->p.k; G.m =
 static Sink make_sink(const bbduk_handle* h, const BuildState* st) {
     Sink S; memset(&S, 0, sizeof S);
     S.big = st->big ? 1 : 0; S.skeys = st->d_sk; S.sids = st->d_si; S.cmask = st->cslots ? st->cslots - 1 : 0;
-    S.tags = h->d_tags; S.keys = h->d_bigKeys; S.ids = h->d_bigIds; S.idBytes = h->bigIdBytes; S.G = host_geom(h);
+    S.tags = h->d_bigTags; S.keys = h->d_bigKeys; S.ids = h->d_bigIds; S.idBytes = h->bigIdBytes; S.G = host_geom(h);
+    S.tags2 = h->d_tags; S.bkv2 = h->d_bkv; S.bucketBits2 = h->bucketBits; S.bucketMask2 = (uint32_t)(h->nbuckets - 1);
     S.distinct = st->d_cnt;
     return S;
 }
@@ -3532,28 +3575,36 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
     h->build = st; st->hdist = hdist; st->hdist2 = hdist2;
     st->big = (maxKeys > (double)BIG_LAYOUT_MIN_KEYS || h->hookBigLayout) && big_geometry(h);
     auto bail = [&](int code, const char* msg) { build_release(h); table_release(h); return fail(h, code, msg); };
-    if (hipMalloc(&st->d_cnt, 16) != hipSuccess || hipMemsetAsync(st->d_cnt, 0, 16, h->stream) != hipSuccess) return bail(BBDUK_ERR_NOMEM, "hipMalloc");
+    if (hipMalloc(&st->d_cnt, 32) != hipSuccess || hipMemsetAsync(st->d_cnt, 0, 32, h->stream) != hipSuccess) return bail(BBDUK_ERR_NOMEM, "hipMalloc");
     if (st->big) {
         // 32-slot lines at ~0.6 keys per slot (the lines' loads vary with the minimizers: 10 % of them overflow into the next line
         // there, 3 % of the keys); a tighter fit is tried when HBM is short.  12 or 14 bytes per slot: 10^10 keys = 200-233 GB.
         const int idBytes = h->p.numScaffolds <= 65535 ? 2 : 4;
         size_t freeB = 0, totalB = 0;
         if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return bail(BBDUK_ERR_DEVICE, "hipMemGetInfo");
-        const double perLine = 64.0 + 256.0 + 32.0 * idBytes;
+        // the secondary map holds what the lines spill (both words of a key full): ~6 % of the keys at 0.6 keys per slot; its
+        // buckets are sized for twice that at 2.5 keys per bucket (it keeps working, with longer chains, until it is full)
+        int sbits = 10;
+        while (sbits < 29 && (double)(1ULL << sbits) < 0.12 * maxKeys / 2.5) sbits++;
+        const uint64_t snb = 1ULL << sbits;
+        const double perLine = 64.0 + 256.0 + 32.0 * idBytes, spillBytes = (double)snb * (8.0 + 64.0);
         uint64_t nlines = 0;
-        for (const double load : {0.6, 0.7, 0.8, 0.9}) {
+        for (const double load : {0.6, 0.7, 0.8}) {
             nlines = std::max<uint64_t>(64, (uint64_t)(maxKeys / (32.0 * load)) + 1);
-            if ((double)nlines * perLine + 3e9 < (double)freeB) break;
+            if ((double)nlines * perLine + spillBytes + 3e9 < (double)freeB) break;
             nlines = 0;
         }
         if (!nlines) return bail(BBDUK_ERR_NOMEM, "the map does not fit this device's memory");
         if (nlines >= (1ULL << 29)) return bail(BBDUK_ERR_ARG, "too many keys for the 32-bit tag word index");
-        if (hipMalloc(&h->d_tags, nlines * 64) != hipSuccess || hipMalloc(&h->d_bigKeys, nlines * 256) != hipSuccess ||
-            hipMalloc(&h->d_bigIds, nlines * 32 * (size_t)idBytes) != hipSuccess) return bail(BBDUK_ERR_NOMEM, "hipMalloc (map)");
-        h->big = true; h->bigLines = (uint32_t)nlines; h->bigIdBytes = idBytes;
-        hipMemsetAsync(h->d_tags, 0, nlines * 64, h->stream);
+        if (hipMalloc(&h->d_bigTags, nlines * 64) != hipSuccess || hipMalloc(&h->d_bigKeys, nlines * 256) != hipSuccess ||
+            hipMalloc(&h->d_bigIds, nlines * 32 * (size_t)idBytes) != hipSuccess ||
+            hipMalloc(&h->d_tags, snb * 8) != hipSuccess || hipMalloc(&h->d_bkv, 4 * snb * sizeof(uint4)) != hipSuccess) return bail(BBDUK_ERR_NOMEM, "hipMalloc (map)");
+        h->big = true; h->bigLines = (uint32_t)nlines; h->bigIdBytes = idBytes; h->nbuckets = snb; h->bucketBits = sbits;
+        hipMemsetAsync(h->d_bigTags, 0, nlines * 64, h->stream);
         hipMemsetAsync(h->d_bigKeys, 0xFF, nlines * 256, h->stream);
         hipMemsetAsync(h->d_bigIds, 0xFF, nlines * 32 * (size_t)idBytes, h->stream);
+        hipMemsetAsync(h->d_tags, 0, snb * 8, h->stream);
+        hipMemsetAsync(h->d_bkv, 0xFF, 4 * snb * sizeof(uint4), h->stream);
     } else {
         uint64_t cslots = 1024; while ((double)cslots < 2.0 * maxKeys + 16.0) cslots <<= 1;      // a power of two, load <= 0.5
         if (cslots > (1ULL << 34)) return bail(BBDUK_ERR_NOMEM, "key set too large for the scratch set");
@@ -3595,13 +3646,13 @@ static int build_add_pieces(bbduk_handle* h, const uint8_t* d_refs, const int64_
 static int build_end_impl(bbduk_handle* h) {
     BuildState* st = h->build;
     auto bail = [&](int code, const char* msg) { build_release(h); table_release(h); return fail(h, code, msg); };
-    unsigned long long cnt[2] = {0, 0};
-    if (hipMemcpyAsync(cnt, st->d_cnt, 16, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
+    unsigned long long cnt[3] = {0, 0, 0};
+    if (hipMemcpyAsync(cnt, st->d_cnt, 24, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
         return bail(BBDUK_ERR_DEVICE, "table build failed on the device");
     const unsigned long long distinct = cnt[0];
     if (st->big) {
         if (cnt[1]) return bail(BBDUK_ERR_NOMEM, "the map overflowed: more keys than announced to bbduk_build_begin");
-        h->nkeys = (int64_t)distinct; h->ldsBits = 0;
+        h->nkeys = (int64_t)distinct; h->ldsBits = 0; h->nspilled = (int64_t)cnt[2];
     } else {
         // 4-way buckets of 15-bit fingerprints, >= 1 bucket per key (load 0.5-1 keys/bucket: ~0.1-0.4 % of buckets
         // overflow and carry the continuation flag, so almost every lookup ends in its home bucket).
@@ -3742,10 +3793,11 @@ extern "C" int bbduk_build_table_device(bbduk_handle* h, const uint8_t* refs, co
     return build_end_impl(h);
 }
 
+extern "C" int64_t bbduk_table_spilled(const bbduk_handle* h) { return (h && h->finalized && h->big) ? h->nspilled : 0; }
 extern "C" int64_t bbduk_table_size(const bbduk_handle* h) { return (h && h->finalized) ? h->nkeys : -1; }
 extern "C" int64_t bbduk_table_bytes(const bbduk_handle* h) {
     if (!h || !h->finalized) return -1;
-    if (h->big) return (int64_t)h->bigLines * (64 + 256 + 32 * h->bigIdBytes);
+    if (h->big) return (int64_t)h->bigLines * (64 + 256 + 32 * h->bigIdBytes) + (int64_t)(h->nbuckets * (8 + 4 * 16));
     return (int64_t)(h->nbuckets * (8 + 4 * 16)) + (h->ldsBits ? (1LL << (h->ldsBits - 3)) : 0);
 }
 
@@ -3769,7 +3821,7 @@ static KParams make_kparams(const bbduk_handle* h) {
     K.middleMask = (uint64_t)p.middleMask;
     K.tags = h->d_tags; K.bkv = h->d_bkv; K.bucketMask = (uint32_t)(h->nbuckets - 1); K.bucketBits = h->bucketBits;
     K.storedKmers = h->nkeys; K.undef = nullptr;
-    K.big = h->big ? 1 : 0; K.bigKeys = h->d_bigKeys; K.bigIds = h->d_bigIds; K.bigIdBytes = h->bigIdBytes; K.bigLines = h->bigLines;
+    K.big = h->big ? 1 : 0; K.bigTags = h->d_bigTags; K.bigKeys = h->d_bigKeys; K.bigIds = h->d_bigIds; K.bigIdBytes = h->bigIdBytes; K.bigLines = h->bigLines;
     K.gm = h->gm; K.gW = h->gW; K.gH = h->gH; K.gD = h->gD;
     K.matchN = nullptr; K.matchIds = nullptr; K.matchCnt = nullptr; K.matchCap = 0;
     K.dbg = h->hookDbg;

@@ -38,6 +38,7 @@ struct KParams {
     // fingerprint from mix_a; probing walks the line's words cyclically, then the next line.  Keys and ids live in two slot-parallel
     // arrays (8 + 2|4 bytes) touched only on a fingerprint match.  See "big layout" in bbduk_hip.hip.
     int32_t  big;
+    const uint64_t* bigTags;    // [8 * bigLines] tag words; `tags` / `bkv` above then hold the secondary map of the spilled keys
     const uint64_t* bigKeys;    // [32 * bigLines], EMPTY_KEY = free
     const void*     bigIds;     // uint16 or uint32 per slot
     int32_t  bigIdBytes;
@@ -60,9 +61,9 @@ struct bbduk_handle {
     std::vector<int32_t> hvals;
     int64_t nkeys = 0;
     uint64_t* d_tags = nullptr; uint4* d_bkv = nullptr; uint64_t nbuckets = 0; int bucketBits = 0;
-    // big layout (HBM-resident maps): d_tags holds 8 * bigLines words, keys / ids are slot-parallel arrays
-    bool big = false; uint64_t* d_bigKeys = nullptr; void* d_bigIds = nullptr; int bigIdBytes = 0; uint32_t bigLines = 0;
-    int gm = 0, gW = 0, gH = 0, gD = 0;
+    // big layout (HBM-resident maps): 8 * bigLines tag words, slot-parallel keys / ids; d_tags / d_bkv = the secondary map of the spilled keys
+    bool big = false; uint64_t* d_bigTags = nullptr; uint64_t* d_bigKeys = nullptr; void* d_bigIds = nullptr; int bigIdBytes = 0; uint32_t bigLines = 0;
+    int gm = 0, gW = 0, gH = 0, gD = 0; int64_t nspilled = 0;
     // streaming device-side build (bbduk_build_begin / _add_device / _end)
     struct BuildState* build = nullptr;
     uint32_t* d_ldsImage = nullptr; int ldsBits = 0;

@@ -15,6 +15,8 @@ extern "C" {
 #define BBDUK_HOOK_TIMING_MASK  4   /* -DBBDUK_TIMING_SWITCHES builds only: bit n deletes stage n of the scan (results become wrong) */
 #define BBDUK_HOOK_BIG_LAYOUT   5   /* before finalize / device build: value != 0 forces the HBM-resident map layout at any size */
 int  bbduk_test_hook(bbduk_handle* h, int32_t which, int64_t value);
+/* big layout: keys that found both of their words full and live in the secondary map (0 for the cache-resident layout) */
+int64_t bbduk_table_spilled(const bbduk_handle* h);
 #ifdef __cplusplus
 }
 #endif

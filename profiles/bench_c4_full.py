@@ -77,7 +77,7 @@ def main():
     nkeys = gpu.table_size
     out = {"workload": "BASELINE configs[3]: kfilter k=31 hdist=0 vs %d-base synthetic reference (%d scaffolds), map resident in HBM" % (ref_bases, n_scaf),
            "keys": int(nkeys), "windows": int(n_scaf * (a.scaffold_bases - 30)), "table_bytes": int(gpu.table_bytes),
-           "bytes_per_key": round(gpu.table_bytes / max(1, nkeys), 2),
+           "bytes_per_key": round(gpu.table_bytes / max(1, nkeys), 2), "spilled_keys": int(gpu.table_spilled),
            "build_s": round(t_build, 2), "build_detail_s": {"alloc+clear": round(t_alloc, 2), "generate_reference": round(t_gen, 2), "insert": round(t_add, 2), "end": round(t_end, 2)}}
     # ---- table checks
     W = np.concatenate([w for w, _ in samples]); ids = np.concatenate([i for _, i in samples])
