@@ -152,7 +152,8 @@ __host__ __device__ __forceinline__ uint32_t gap_hmin_value(const BigGeom& G, co
 // by a plain hash
 __host__ __device__ __forceinline__ uint32_t big_line_of_key(const BigGeom& G, const uint64_t key, const uint32_t ma) {
     const uint64_t v = strip_len(key);
-    const uint32_t h = (key >> (2 * G.k)) == 1ULL ? gap_hmin_value(G, v) : (ma ^ 0x5BD1E995u);
+    // G.W == 0: lines by a plain hash of the key (maps whose keys crowd on few minimizers: reference-side Hamming neighbourhoods)
+    const uint32_t h = ((key >> (2 * G.k)) == 1ULL && G.W > 0) ? gap_hmin_value(G, v) : (ma ^ 0x5BD1E995u);
     return gap_line(h, G.nlines);
 }
 // A key has two words in its line: the primary (top 3 bits of mix_b) and an alternate (the next 3 bits, made distinct).  It lives
@@ -792,11 +793,17 @@ __device__ __forceinline__ uint64_t cand_probe4_big(const KParams& P, const uint
         C.key[s] = ((uint64_t)khi << 32) | klo;
         C.ma[s] = klo * HA0 + khi * HA1;
         C.mb[s] = klo * HB0 + khi * HB1;
-        h0[s] = gap_h0(P, kmer[s], rkRaw[s]);                      // the raw complement cut: a reset further right does not touch these bases
         C.nf[s] = nf[s];
     }
-    window_min(P.gW, h0[0], h0[1], hw[0], hw[1]);
-    window_min(P.gW, h0[2], h0[3], hw[2], hw[3]);
+    if (P.gW > 0) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) h0[s] = gap_h0(P, kmer[s], rkRaw[s]);     // the raw complement cut: a reset further right does not touch these bases
+        window_min(P.gW, h0[0], h0[1], hw[0], hw[1]);
+        window_min(P.gW, h0[2], h0[3], hw[2], hw[3]);
+    } else {                                                      // plain lines: a function of the key itself
+#pragma unroll
+        for (int s = 0; s < 4; s++) hw[s] = C.ma[s] ^ 0x5BD1E995u;
+    }
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         big_words(gap_line(hw[s], P.bigLines), C.mb[s], C.w1[s], C.w2[s]);
@@ -1026,7 +1033,7 @@ __device__ __forceinline__ void main_scan_pair_cand(const KParams& P, const Plan
         Cand4Big CB; uint64_t anyFlag; const uint64_t* key;
         if constexpr (BIG) {
             bool nf[4] = {false, false, false, false};
-            if (WA.hasN | WB.hasN) {                                 // which windows see an undefined base (bit t of nw <=> base i-k+1+t)
+            if ((WA.hasN | WB.hasN) && P.gW > 0) {                   // which windows see an undefined base (bit t of nw <=> base i-k+1+t)
 #pragma unroll
                 for (int r = 0; r < 2; r++) {
                     const ReadWin& W = r ? WB : WA;
@@ -3551,7 +3558,7 @@ static bool big_geometry(bbduk_handle* h) {
         H = std::min(firstMasked, k - 1 - lastMasked);
     }
     if (H < 4) return false;
-    h->gH = H; h->gD = k - H; h->gm = std::min(9, H - 1); h->gW = H - h->gm + 1;
+    h->gH = H; h->gD = k - H; h->gm = std::min(9, H - 1); h->gW = h->bigPlain ? 0 : H - h->gm + 1;
     return true;
 }
 static BigGeom host_geom(const bbduk_handle* h) { BigGeom G; G.k = h->p.k; G.m = h->gm; G.W = h->gW; G.H = h->gH; G.D = h->gD; G.nlines = h->bigLines; G.middleMask = (uint64_t)h->p.middleMask; return G; }
@@ -3573,6 +3580,8 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
     BuildState* st = new (std::nothrow) BuildState();
     if (!st) return BBDUK_ERR_NOMEM;
     h->build = st; st->hdist = hdist; st->hdist2 = hdist2;
+    // reference-side Hamming neighbourhoods put ~2/3 of a k-mer's 1+3k variants on one minimizer: such maps take plain lines
+    if (hdist > 0) h->bigPlain = true;
     st->big = (maxKeys > (double)BIG_LAYOUT_MIN_KEYS || h->hookBigLayout) && big_geometry(h);
     auto bail = [&](int code, const char* msg) { build_release(h); table_release(h); return fail(h, code, msg); };
     if (hipMalloc(&st->d_cnt, 32) != hipSuccess || hipMemsetAsync(st->d_cnt, 0, 32, h->stream) != hipSuccess) return bail(BBDUK_ERR_NOMEM, "hipMalloc");
@@ -3718,7 +3727,9 @@ extern "C" int bbduk_finalize_table(bbduk_handle* h) {
     if (h->finalized) return fail(h, BBDUK_ERR_STATE, "table already finalized");
     if (h->build) return fail(h, BBDUK_ERR_STATE, "a device-side build is in progress: end it with bbduk_build_end");
     const int64_t n = (int64_t)h->hkeys.size();
-    int rc = build_begin_impl(h, (double)n, 0, 0);
+    int rc = BBDUK_OK;
+  for (int attempt = 0; attempt < 2; attempt++) {                  // second attempt: plain lines, if the minimizer lines spilled too much
+    rc = build_begin_impl(h, (double)n, 0, 0);
     if (rc != BBDUK_OK) return rc;
     BuildState* st = h->build;
     auto bail = [&](int code, const char* msg) { build_release(h); table_release(h); return fail(h, code, msg); };
@@ -3737,8 +3748,12 @@ extern "C" int bbduk_finalize_table(bbduk_handle* h) {
             if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(BBDUK_ERR_DEVICE, "placing the pairs");
         }
     }
-    h->hkeys.clear(); h->hkeys.shrink_to_fit(); h->hvals.clear(); h->hvals.shrink_to_fit();
-    return build_end_impl(h);
+    rc = build_end_impl(h);
+    if (rc == BBDUK_ERR_NOMEM && !h->bigPlain && !h->finalized) { h->bigPlain = true; continue; }
+    break;
+  }
+    if (rc == BBDUK_OK) { h->hkeys.clear(); h->hkeys.shrink_to_fit(); h->hvals.clear(); h->hvals.shrink_to_fit(); }
+    return rc;
 }
 
 // bbduk_build_table_device: the reference sequences are HOST memory here; they go to the device in chunks of whole scaffolds
@@ -3759,7 +3774,9 @@ extern "C" int bbduk_build_table_device(bbduk_handle* h, const uint8_t* refs, co
     auto variants = [](int len, int d) { const double t = 3.0 * len; double v = 1.0; if (d >= 1) v += t; if (d >= 2) v += t * (t - 3.0) / 2.0; if (d >= 3) v += t * (t - 3.0) * (t - 6.0) / 6.0; return v; };
     double ub = (double)total * variants(k, hdist);
     if (useShort) for (int L = h->p.mink; L < k; L++) ub += 2.0 * (double)n_refs * variants(L, hdist2);
-    int rc = build_begin_impl(h, ub, hdist, hdist2);
+    int rc = BBDUK_OK;
+  for (int attempt = 0; attempt < 2; attempt++) {                  // second attempt: plain lines, if the minimizer lines spilled too much
+    rc = build_begin_impl(h, ub, hdist, hdist2);
     if (rc != BBDUK_OK) return rc;
     BuildState* st = h->build;
     auto bail = [&](int code, const char* msg) { build_release(h); table_release(h); return fail(h, code, msg); };
@@ -3790,7 +3807,11 @@ extern "C" int bbduk_build_table_device(bbduk_handle* h, const uint8_t* refs, co
         } while (true);
     }
     if ((rc = flush()) != BBDUK_OK) return bail(rc, "device build (enumeration)");
-    return build_end_impl(h);
+    rc = build_end_impl(h);
+    if (rc == BBDUK_ERR_NOMEM && !h->bigPlain && !h->finalized) { h->bigPlain = true; continue; }
+    break;
+  }
+    return rc;
 }
 
 extern "C" int64_t bbduk_table_spilled(const bbduk_handle* h) { return (h && h->finalized && h->big) ? h->nspilled : 0; }
