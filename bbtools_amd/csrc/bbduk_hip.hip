@@ -97,6 +97,8 @@ __device__ __forceinline__ uint32_t filt_test(const uint32_t* s_filt, uint32_t m
     return (w >> (ma & 31u)) & 1u;
 }
 #define TAG_CONT  0x8000000000000000ULL
+#define TAG_FPS15 0x7FFF7FFF7FFF7FFFULL           /* big layout: the four fingerprints without the lanes' top bits (spill bits) */
+#define TAG_TOPS  0x8000800080008000ULL
 #define TAG_FPS   0x7FFFFFFFFFFFFFFFULL
 
 // 0x8000 in every 16-bit lane of v that is zero (may also flag lanes above a true zero lane: callers verify)
@@ -158,9 +160,12 @@ __host__ __device__ __forceinline__ uint32_t big_line_of_key(const BigGeom& G, c
 }
 // A key has two words in its line: the primary (top 3 bits of mix_b) and an alternate (the next 3 bits, made distinct).  It lives
 // in the first free way of the primary, else of the alternate; if both are full it is SPILLED into the secondary map (the
-// cache-resident layout's buckets: KParams::tags / bkv) and the primary word gets the flag bit.  So a lookup is: both words (one
-// 64-byte sector), and only if the primary carries the flag one more gather.  No probe chains: an overloaded line costs its
+// cache-resident layout's buckets: KParams::tags / bkv) and the primary word gets one of its four spill bits.  So a lookup is: both
+// words (one 64-byte sector), and only if the primary carries the key's spill bit one more gather.  No probe chains: an overloaded line costs its
 // absent keys nothing more.  (~6 % of the keys spill at 0.6 keys per slot, ~9 % of the words carry the flag.)
+// The lanes' top bits of a tag word form a 4-bit filter over the keys spilled from it (the word being their primary): a spilled key
+// sets bit 16*j+15, j = two hash bits of its own; a lookup goes to the secondary map only if ITS bit is set.
+__host__ __device__ __forceinline__ int spill_bit(const uint32_t ma) { return 16 * (int)((ma >> 13) & 3u) + 15; }
 __host__ __device__ __forceinline__ void big_words(const uint32_t line, const uint32_t mb, uint32_t& w1, uint32_t& w2) {
     const uint32_t a = mb >> 29; uint32_t b = (mb >> 26) & 7u;
     b = (b == a) ? (b ^ 1u) : b;
@@ -178,14 +183,14 @@ __device__ __forceinline__ int big_find_in(const KParams& P, const uint64_t key,
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         const uint64_t t = q ? t2 : t1; const uint32_t word = q ? w2 : w1;
-        uint64_t cand = zero16((t & TAG_FPS) ^ pat);
+        uint64_t cand = zero16((t & TAG_FPS15) ^ pat);
         while (cand) {
             const int way = (__ffsll((unsigned long long)cand) - 1) >> 4;
             if (P.bigKeys[4ULL * word + way] == key) return big_id_at(P, 4ULL * word + way);
             cand &= cand - 1;
         }
     }
-    if (!(t1 & TAG_CONT)) return -1;                               // nothing was ever spilled from the primary word
+    if (!((t1 >> spill_bit(ma)) & 1ULL)) return -1;                // no key of this key's kind was ever spilled from the primary word
     return table_find_t(P, key, ma, mb, P.tags[bucket_of(mb, P.bucketBits)]);
 }
 __device__ __forceinline__ int big_find(const KParams& P, const uint64_t key, const uint32_t ma, const uint32_t mb) {
@@ -753,11 +758,16 @@ __device__ __forceinline__ uint32_t next_lane(const uint32_t v, const uint32_t f
 // me / mo = min over positions [2l, 2l+W) / [2l+1, 2l+1+W).  Lanes near the top of the wave see `fill` (= +inf) beyond it.
 __device__ __forceinline__ void window_min(const int W, const uint32_t e, const uint32_t o, uint32_t& me, uint32_t& mo) {
     const uint32_t INF = 0xFFFFFFFFu;
-    if (W == 7) {                                                 // k = 31: H = 15, m = 9
-        const uint32_t s1e = min(e, o), s1o = min(o, next_lane(e, INF));                  // 2 positions
+    if (W == 6 || W == 7) {                                       // k = 31: H = 15, m = 10 / 9
+        const uint32_t s1e = min(e, o), s1o = min(o, next_lane(e, INF));                  // 2 positions: [2l,2l+2), [2l+1,2l+3)
         const uint32_t s2e = min(s1e, next_lane(s1e, INF)), s2o = min(s1o, next_lane(s1o, INF));   // 4 positions
-        me = min(s2e, next_lane(s2o, INF));                       // [2l,2l+4) + [2l+3,2l+7)
-        mo = min(s2o, next_lane(next_lane(s2e, INF), INF));       // [2l+1,2l+5) + [2l+4,2l+8)
+        if (W == 6) {
+            me = min(s2e, next_lane(next_lane(s1e, INF), INF));   // [2l,2l+4) + [2l+4,2l+6)
+            mo = min(s2o, next_lane(next_lane(s1o, INF), INF));   // [2l+1,2l+5) + [2l+5,2l+7)
+        } else {
+            me = min(s2e, next_lane(s2o, INF));                   // [2l,2l+4) + [2l+3,2l+7)
+            mo = min(s2o, next_lane(next_lane(s2e, INF), INF));   // [2l+1,2l+5) + [2l+4,2l+8)
+        }
         return;
     }
     uint32_t ce = e, co = o; me = e; mo = o;
@@ -771,6 +781,10 @@ __device__ __forceinline__ void window_min(const int W, const uint32_t e, const 
 // reverse complement of that gapped-mer, which is the right-most candidate of rk (see "big layout" above)
 __device__ __forceinline__ uint32_t gap_h0(const KParams& P, const uint64_t kmer, const uint64_t rk) {
     const uint32_t mk = (1u << (2 * P.gm)) - 1u;
+    if (P.k == 31 && P.gH == 15) {                                // halves = bases 0-14 (high word) and 16-30 (low word): 32-bit cuts
+        const uint32_t sh = 2u * (uint32_t)(15 - P.gm), hi = (uint32_t)(kmer >> 32), lo = (uint32_t)kmer;
+        return gap_f(hi >> sh, (lo >> sh) & mk) + gap_f((uint32_t)(rk >> 32) & mk, (uint32_t)rk & mk);
+    }
     const uint32_t la = (uint32_t)(kmer >> (2 * (P.k - P.gm))) & mk, ra = (uint32_t)(kmer >> (2 * (P.k - P.gD - P.gm))) & mk;
     const uint32_t lb = (uint32_t)(rk >> (2 * (P.k - P.gH))) & mk, rb = (uint32_t)rk & mk;
     return gap_f(la, ra) + gap_f(lb, rb);
@@ -815,10 +829,11 @@ __device__ __forceinline__ uint64_t cand_probe4_big(const KParams& P, const uint
     for (int s = 0; s < 4; s++) {
         const uint32_t fp = tag_of(C.ma[s]);
         const uint32_t alo = (uint32_t)C.t1[s], ahi = (uint32_t)(C.t1[s] >> 32), blo = (uint32_t)C.t2[s], bhi = (uint32_t)(C.t2[s] >> 32);
-        // eight 16-bit compares and the primary word's spill flag (its lane 3 then never compares equal: the resolve path masks it)
+        // eight 16-bit compares; a word that carries spill bits (the top bit of a lane) may hide a match from them: such lanes go to
+        // the resolve path, which masks the bits and looks at the key's own spill bit
         C.hm[s] = __ballot((alo & 0xFFFFu) == fp) | __ballot((alo >> 16) == fp) | __ballot((ahi & 0xFFFFu) == fp) | __ballot((ahi >> 16) == fp) |
                   __ballot((blo & 0xFFFFu) == fp) | __ballot((blo >> 16) == fp) | __ballot((bhi & 0xFFFFu) == fp) | __ballot((bhi >> 16) == fp) |
-                  __ballot((int32_t)ahi < 0) | __ballot(nf[s]);
+                  __ballot((((alo | ahi) | (blo | bhi)) & 0x80008000u) != 0u) | __ballot(nf[s]);
         any |= C.hm[s];
     }
     return any;
@@ -836,10 +851,10 @@ __device__ __forceinline__ void cand_resolve4_big(const KParams& P, const Cand4B
             continue;
         }
         const uint64_t pat = (uint64_t)tag_of(C.ma[s]) * 0x0001000100010001ULL;
-        const uint64_t c1 = zero16((C.t1[s] & TAG_FPS) ^ pat), c2 = zero16((C.t2[s] & TAG_FPS) ^ pat);
+        const uint64_t c1 = zero16((C.t1[s] & TAG_FPS15) ^ pat), c2 = zero16((C.t2[s] & TAG_FPS15) ^ pat);
         if (c1) ref[s] = (__ffsll((unsigned long long)c1) - 1) >> 4;
         else if (c2) ref[s] = 4 + ((__ffsll((unsigned long long)c2) - 1) >> 4);
-        else if (C.t1[s] & TAG_CONT) {                            // the key may have been spilled: the secondary map answers
+        else if ((C.t1[s] >> spill_bit(C.ma[s])) & 1ULL) {        // a key of this kind was spilled from the primary word: the secondary map answers
             const int id = table_find_t(P, C.key[s] | P.kmask, C.ma[s], C.mb[s], P.tags[bucket_of(C.mb[s], P.bucketBits)]);
             ref[s] = id > 0 ? -3 - id : -1;
         }
@@ -1476,7 +1491,7 @@ __device__ __forceinline__ void big_insert(const Sink& S, const uint64_t key, co
             if (prev == key) { big_id_min(S, slot, id); return; }
         }
     }
-    atomicOr((unsigned long long*)&S.tags[w1], (unsigned long long)TAG_CONT);       // both words full: the key is spilled
+    atomicOr((unsigned long long*)&S.tags[w1], 1ULL << spill_bit(ma));              // both words full: the key is spilled
     spill_insert(S, key, ma, mb, id);
 }
 __device__ __forceinline__ void sink_insert(const Sink& S, const uint64_t key, const int id) {
@@ -3558,7 +3573,7 @@ static bool big_geometry(bbduk_handle* h) {
         H = std::min(firstMasked, k - 1 - lastMasked);
     }
     if (H < 4) return false;
-    h->gH = H; h->gD = k - H; h->gm = std::min(9, H - 1); h->gW = h->bigPlain ? 0 : H - h->gm + 1;
+    h->gH = H; h->gD = k - H; h->gm = std::min(10, H - 1); h->gW = h->bigPlain ? 0 : H - h->gm + 1;
     return true;
 }
 static BigGeom host_geom(const bbduk_handle* h) { BigGeom G; G.k = h->p.k; G.m = h->gm; G.W = h->gW; G.H = h->gH; G.D = h->gD; G.nlines = h->bigLines; G.middleMask = (uint64_t)h->p.middleMask; return G; }
