@@ -117,12 +117,12 @@ __device__ __forceinline__ uint64_t zero16(uint64_t v) { return (v - 0x000100010
 // these values decides which candidate wins, so they should look random.
 __host__ __device__ __forceinline__ uint32_t gap_f(uint32_t l, uint32_t r) {
     uint32_t x = l * 0x9E3779B1u + r * 0x85EBCA6Bu;
-    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 13;
+    x ^= x >> 15; x *= 0x2C1B3C6Du;                               // the product's high bits carry the order
     return x;
 }
 // minima are biased towards 0: re-mix before the multiply-shift that maps onto [0, nlines)
 __host__ __device__ __forceinline__ uint32_t gap_line(uint32_t hmin, uint32_t nlines) {
-    uint32_t y = hmin * 0x297A2D39u; y ^= y >> 15; y *= 0xC2B2AE35u; y ^= y >> 16;
+    uint32_t y = hmin * 0x297A2D39u; y ^= y >> 15; y *= 0xC2B2AE35u;
     return (uint32_t)(((uint64_t)y * (uint64_t)nlines) >> 32);
 }
 __host__ __device__ __forceinline__ uint64_t rcomp_hd(uint64_t kmer, int len) {      // dev_rcomp, host and device
@@ -795,7 +795,7 @@ __device__ __forceinline__ uint32_t gap_h0(const KParams& P, const uint64_t kmer
 // flagged and looked up by the generic exact path in cand_resolve4_big.  Windows at the top of the block (position >= 128 - W
 // within it) lack their successors: the caller advances by BIG_STEP positions and ignores them.
 #define BIG_STEP 120
-struct Cand4Big { uint64_t key[4], t1[4], t2[4]; uint32_t ma[4], mb[4], w1[4], w2[4]; uint64_t hm[4]; bool nf[4]; };
+struct Cand4Big { uint64_t key[4], t1[4], t2[4], ts[4]; uint32_t ma[4], mb[4], w1[4], w2[4]; uint64_t hm[4]; bool nf[4], sp[4]; };
 template <bool NOMM>
 __device__ __forceinline__ uint64_t cand_probe4_big(const KParams& P, const uint64_t* kmer, const uint64_t* rk, const uint64_t* rkRaw, const bool* nf, Cand4Big& C) {
     const uint32_t mmLo = (uint32_t)P.middleMask, mmHi = (uint32_t)(P.middleMask >> 32);
@@ -824,16 +824,26 @@ __device__ __forceinline__ uint64_t cand_probe4_big(const KParams& P, const uint
         C.t1[s] = P.bigTags[C.w1[s]];                              // eight gathers in flight; a lane's two words and its neighbours' share a sector
         C.t2[s] = P.bigTags[C.w2[s]];
     }
+    // the key's spill bit in its primary word: only those lanes (~5 %) look into the secondary map, the others re-read its bucket 0
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const uint32_t half = (C.ma[s] & 0x4000u) ? (uint32_t)(C.t1[s] >> 32) : (uint32_t)C.t1[s];    // spill_bit(ma) = 16*((ma>>13)&3)+15
+        C.sp[s] = ((half >> ((C.ma[s] & 0x2000u) ? 31 : 15)) & 1u) != 0u;
+        C.ts[s] = P.tags[C.sp[s] ? bucket_of(C.mb[s], P.bucketBits) : 0u];
+    }
     uint64_t any = 0;
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         const uint32_t fp = tag_of(C.ma[s]);
-        const uint32_t alo = (uint32_t)C.t1[s], ahi = (uint32_t)(C.t1[s] >> 32), blo = (uint32_t)C.t2[s], bhi = (uint32_t)(C.t2[s] >> 32);
-        // eight 16-bit compares; a word that carries spill bits (the top bit of a lane) may hide a match from them: such lanes go to
-        // the resolve path, which masks the bits and looks at the key's own spill bit
-        C.hm[s] = __ballot((alo & 0xFFFFu) == fp) | __ballot((alo >> 16) == fp) | __ballot((ahi & 0xFFFFu) == fp) | __ballot((ahi >> 16) == fp) |
-                  __ballot((blo & 0xFFFFu) == fp) | __ballot((blo >> 16) == fp) | __ballot((bhi & 0xFFFFu) == fp) | __ballot((bhi >> 16) == fp) |
-                  __ballot((((alo | ahi) | (blo | bhi)) & 0x80008000u) != 0u) | __ballot(nf[s]);
+        const uint32_t alo = (uint32_t)C.t1[s] & 0x7FFF7FFFu, ahi = (uint32_t)(C.t1[s] >> 32) & 0x7FFF7FFFu;      // without the spill bits
+        const uint32_t blo = (uint32_t)C.t2[s] & 0x7FFF7FFFu, bhi = (uint32_t)(C.t2[s] >> 32) & 0x7FFF7FFFu;
+        const uint32_t slo = (uint32_t)C.ts[s], shi = (uint32_t)(C.ts[s] >> 32);
+        // twelve 16-bit compares; in the secondary map's bucket lane 3 carries the continuation flag and never compares equal then
+        const uint64_t prim = __ballot((alo & 0xFFFFu) == fp) | __ballot((alo >> 16) == fp) | __ballot((ahi & 0xFFFFu) == fp) | __ballot((ahi >> 16) == fp) |
+                              __ballot((blo & 0xFFFFu) == fp) | __ballot((blo >> 16) == fp) | __ballot((bhi & 0xFFFFu) == fp) | __ballot((bhi >> 16) == fp);
+        const uint64_t sec = (__ballot((slo & 0xFFFFu) == fp) | __ballot((slo >> 16) == fp) | __ballot((shi & 0xFFFFu) == fp) | __ballot((shi >> 16) == fp) |
+                              __ballot((int32_t)shi < 0)) & __ballot(C.sp[s]);
+        C.hm[s] = prim | sec | __ballot(nf[s]);
         any |= C.hm[s];
     }
     return any;
@@ -854,9 +864,12 @@ __device__ __forceinline__ void cand_resolve4_big(const KParams& P, const Cand4B
         const uint64_t c1 = zero16((C.t1[s] & TAG_FPS15) ^ pat), c2 = zero16((C.t2[s] & TAG_FPS15) ^ pat);
         if (c1) ref[s] = (__ffsll((unsigned long long)c1) - 1) >> 4;
         else if (c2) ref[s] = 4 + ((__ffsll((unsigned long long)c2) - 1) >> 4);
-        else if ((C.t1[s] >> spill_bit(C.ma[s])) & 1ULL) {        // a key of this kind was spilled from the primary word: the secondary map answers
-            const int id = table_find_t(P, C.key[s] | P.kmask, C.ma[s], C.mb[s], P.tags[bucket_of(C.mb[s], P.bucketBits)]);
-            ref[s] = id > 0 ? -3 - id : -1;
+        else if (C.sp[s]) {                                       // a key of this kind was spilled from the primary word: the secondary map answers
+            const uint64_t c3 = zero16((C.ts[s] & TAG_FPS) ^ pat);
+            if (c3 != 0ULL || (C.ts[s] & TAG_CONT)) {
+                const int id = table_find_t(P, C.key[s] | P.kmask, C.ma[s], C.mb[s], C.ts[s]);
+                ref[s] = id > 0 ? -3 - id : -1;
+            }
         }
     }
 }
@@ -1014,10 +1027,11 @@ __device__ __forceinline__ void main_scan_pair(const KParams& P, const Planes& Q
 // at the first fingerprint match of each read WITHOUT fetching its key; the caller verifies the candidates of a whole
 // sub-tile in one overlapped batch (one lane per read) and falls back to main_scan_pair for the rare impostor.
 template <bool FORBIDN, bool GENERAL, bool NOMM, bool BIG = false>
-__device__ __forceinline__ void main_scan_pair_cand(const KParams& P, const Planes& Q, ReadScan& A, ReadScan& B, const int lane) {
+__device__ __forceinline__ void main_scan_pair_cand(const KParams& P, const Planes& Q, ReadScan& A, ReadScan& B, const int lane, const int firstA = -1) {
     ReadWin WA, WB;
     win_init<FORBIDN, GENERAL, BIG>(P, Q, A, WA, lane);
     win_init<FORBIDN, GENERAL, BIG>(P, Q, B, WB, lane);
+    if (firstA >= 0) { WA.first = max(WA.first, firstA); WA.on = A.scan && WA.first < WA.stop; }     // resume behind an impostor
     int ibA = WA.first, ibB = WB.first;
     bool onA = WA.on, onB = WB.on;
     A.candSlot = -1; B.candSlot = -1;
@@ -2493,6 +2507,32 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                     } else fb = true;
                 }
                 uint64_t fbm = __ballot(fb);
+                if constexpr (BIG) {
+                    // an impostor fingerprint (twelve 15-bit fingerprints are compared per window: ~4 % of the pairs meet one): the
+                    // read's candidate scan resumes right behind it, and its next candidate is verified at once
+                    while (fbm) {
+                        const int j = __ffsll((unsigned long long)fbm) - 1;
+                        ReadScan A, Bz;
+                        A.hasN = (int)((nMask >> j) & 1); A.maxBad = P.maxBadKmers;
+                        A.base0 = origin + __builtin_amdgcn_readlane(rel, j); A.L = __builtin_amdgcn_readlane(vL, j); A.scan = true;
+                        A.start = span_start<GENERAL>(P, A.L); A.stop = span_stop<GENERAL>(P, A.L);
+                        A.found = 0; A.iFirst = BIGLOC; A.iLast = -1; A.ref = -1; A.shortFl = -1; A.shortLl = -1;
+                        Bz = A; Bz.scan = false; Bz.L = 0; Bz.start = 0; Bz.stop = 0; Bz.hasN = 0;
+                        main_scan_pair_cand<FORBIDN, GENERAL, SHORT && !GENERAL, true>(P, Q, A, Bz, lane, __builtin_amdgcn_readlane(vFirst, j) + 1);
+                        bool done = true, hitNow = false; int nref = -1;
+                        if (A.candSlot <= -4) { nref = -3 - A.candSlot; hitNow = true; }
+                        else if (A.candSlot >= 0) {
+                            const uint64_t slot = 4ULL * A.candWord + (uint32_t)A.candSlot;          // wave-uniform: every lane reads the same slot
+                            if (P.bigKeys[slot] == ((((uint64_t)A.candKeyHi << 32) | A.candKeyLo) | P.kmask)) { nref = big_id_at(P, slot); hitNow = true; }
+                            else done = false;                                                       // another impostor: go on behind it
+                        }
+                        if (hitNow) {
+                            vRef = (lane == j) ? nref : vRef; vFound = (lane == j) ? ((MODE == BBDUK_MODE_KFILTER) ? P.maxBadKmers + 1 : 1) : vFound;
+                            vFirst = (lane == j) ? ((MODE == BBDUK_MODE_KFILTER) ? 0 : A.iFirst) : vFirst;
+                        } else vFirst = (lane == j) ? (done ? BIGLOC : A.iFirst) : vFirst;
+                        if (done) fbm &= ~(1ULL << j);
+                    }
+                }
                 while (fbm) {                                       // rare: an impostor fingerprint; rescan that pair exactly
                     const int j = __ffsll((unsigned long long)fbm) - 1;
                     const int ra = s + ((j - s) & ~1);
