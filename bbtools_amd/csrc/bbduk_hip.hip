@@ -120,9 +120,14 @@ __host__ __device__ __forceinline__ uint32_t gap_f(uint32_t l, uint32_t r) {
     x ^= x >> 15; x *= 0x2C1B3C6Du;                               // the product's high bits carry the order
     return x;
 }
+// The two orientations' values combine symmetrically into 52 bits (the candidates are ordered by them): 32 bits alone leave 10^10 keys'
+// ~3e9 runs of shared minimizers only ~1e9 distinct minima (minima crowd near 0), whole runs would then share lines and overload them.
+__host__ __device__ __forceinline__ uint64_t gap_pair(const uint32_t fa, const uint32_t fb) {
+    return ((uint64_t)((fa ^ fb) & 0xFFFFFu) << 32) | (uint32_t)(fa + fb);
+}
 // minima are biased towards 0: re-mix before the multiply-shift that maps onto [0, nlines)
-__host__ __device__ __forceinline__ uint32_t gap_line(uint32_t hmin, uint32_t nlines) {
-    uint32_t y = hmin * 0x297A2D39u; y ^= y >> 15; y *= 0xC2B2AE35u;
+__host__ __device__ __forceinline__ uint32_t gap_line(const uint64_t hmin, const uint32_t nlines) {
+    uint32_t y = (uint32_t)hmin * 0x297A2D39u + (uint32_t)(hmin >> 32) * 0x9E3779B1u; y ^= y >> 15; y *= 0xC2B2AE35u;
     return (uint32_t)(((uint64_t)y * (uint64_t)nlines) >> 32);
 }
 __host__ __device__ __forceinline__ uint64_t rcomp_hd(uint64_t kmer, int len) {      // dev_rcomp, host and device
@@ -137,15 +142,15 @@ __host__ __device__ __forceinline__ uint64_t rcomp_hd(uint64_t kmer, int len) { 
 struct BigGeom { int32_t k, m, W, H, D; uint32_t nlines; uint64_t middleMask; };
 // hmin of a full-length key value (the slow, exact form: every kernel's generic path, the build, the host).  A = the value,
 // B = its reverse complement with the same middle mask: {A, B} = {kmer & mm, rkmer & mm} whichever one the key is.
-__host__ __device__ __forceinline__ uint32_t gap_hmin_value(const BigGeom& G, const uint64_t A) {
+__host__ __device__ __forceinline__ uint64_t gap_hmin_value(const BigGeom& G, const uint64_t A) {
     const uint64_t B = rcomp_hd(A, G.k) & G.middleMask;
     const uint32_t mk = (1u << (2 * G.m)) - 1u;
-    uint32_t best = 0xFFFFFFFFu;
+    uint64_t best = ~0ULL;
     for (int p = 0; p < G.W; p++) {
         const int q = G.H - G.m - p;
         const uint32_t la = (uint32_t)(A >> (2 * (G.k - G.m - p))) & mk, ra = (uint32_t)(A >> (2 * (G.k - G.D - G.m - p))) & mk;
         const uint32_t lb = (uint32_t)(B >> (2 * (G.k - G.m - q))) & mk, rb = (uint32_t)(B >> (2 * (G.k - G.D - G.m - q))) & mk;
-        const uint32_t h = gap_f(la, ra) + gap_f(lb, rb);
+        const uint64_t h = gap_pair(gap_f(la, ra), gap_f(lb, rb));
         best = h < best ? h : best;
     }
     return best;
@@ -155,7 +160,7 @@ __host__ __device__ __forceinline__ uint32_t gap_hmin_value(const BigGeom& G, co
 __host__ __device__ __forceinline__ uint32_t big_line_of_key(const BigGeom& G, const uint64_t key, const uint32_t ma) {
     const uint64_t v = strip_len(key);
     // G.W == 0: lines by a plain hash of the key (maps whose keys crowd on few minimizers: reference-side Hamming neighbourhoods)
-    const uint32_t h = ((key >> (2 * G.k)) == 1ULL && G.W > 0) ? gap_hmin_value(G, v) : (ma ^ 0x5BD1E995u);
+    const uint64_t h = ((key >> (2 * G.k)) == 1ULL && G.W > 0) ? gap_hmin_value(G, v) : (uint64_t)(ma ^ 0x5BD1E995u);
     return gap_line(h, G.nlines);
 }
 // A key has two words in its line: the primary (top 3 bits of mix_b) and an alternate (the next 3 bits, made distinct).  It lives
@@ -750,44 +755,52 @@ __device__ __forceinline__ void cand_resolve4(const KParams& P, const Cand4& C, 
 }
 
 // ---- big layout, fast form of the candidate probe (specialised kernels, plain k >= 16 configurations) -----------------
-// value of the next lane (lane+1); lane 63 gets `fill`.  wave_shl:1 (DPP, gfx9): one instruction, no LDS crossbar.
-__device__ __forceinline__ uint32_t next_lane(const uint32_t v, const uint32_t fill) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130, 0xF, 0xF, false);
+// The 52-bit candidate values travel as the mantissas of doubles in [1, 2): positive normal doubles order like their bit patterns, so
+// one v_min_f64 (full rate on CDNA) is the 52-bit minimum.  next_lane: the value of lane+1 (wave_shl:1, DPP, gfx9: no LDS crossbar);
+// lane 63 gets +inf-like `fill`.
+typedef double gapv;
+__device__ __forceinline__ gapv gap_pack(const uint64_t h52) { return __longlong_as_double((long long)(h52 | 0x3FF0000000000000ULL)); }
+__device__ __forceinline__ uint64_t gap_unpack(const gapv v) { return (uint64_t)__double_as_longlong(v) & 0x000FFFFFFFFFFFFFULL; }
+__device__ __forceinline__ gapv gmin(const gapv a, const gapv b) { gapv d; asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ gapv next_lane(const gapv v) {
+    const uint64_t u = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)(uint32_t)u, 0x130, 0xF, 0xF, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)0x3FFFFFFFu, (int)(uint32_t)(u >> 32), 0x130, 0xF, 0xF, false);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 // Sliding minimum over W consecutive POSITIONS of per-position values held two per lane (e = position 2l, o = 2l+1):
-// me / mo = min over positions [2l, 2l+W) / [2l+1, 2l+1+W).  Lanes near the top of the wave see `fill` (= +inf) beyond it.
-__device__ __forceinline__ void window_min(const int W, const uint32_t e, const uint32_t o, uint32_t& me, uint32_t& mo) {
-    const uint32_t INF = 0xFFFFFFFFu;
+// me / mo = min over positions [2l, 2l+W) / [2l+1, 2l+1+W).  Lanes near the top of the wave see the fill value beyond it.
+__device__ __forceinline__ void window_min(const int W, const gapv e, const gapv o, gapv& me, gapv& mo) {
     if (W == 6 || W == 7) {                                       // k = 31: H = 15, m = 10 / 9
-        const uint32_t s1e = min(e, o), s1o = min(o, next_lane(e, INF));                  // 2 positions: [2l,2l+2), [2l+1,2l+3)
-        const uint32_t s2e = min(s1e, next_lane(s1e, INF)), s2o = min(s1o, next_lane(s1o, INF));   // 4 positions
+        const gapv s1e = gmin(e, o), s1o = gmin(o, next_lane(e));                     // 2 positions: [2l,2l+2), [2l+1,2l+3)
+        const gapv s2e = gmin(s1e, next_lane(s1e)), s2o = gmin(s1o, next_lane(s1o));  // 4 positions
         if (W == 6) {
-            me = min(s2e, next_lane(next_lane(s1e, INF), INF));   // [2l,2l+4) + [2l+4,2l+6)
-            mo = min(s2o, next_lane(next_lane(s1o, INF), INF));   // [2l+1,2l+5) + [2l+5,2l+7)
+            me = gmin(s2e, next_lane(next_lane(s1e)));            // [2l,2l+4) + [2l+4,2l+6)
+            mo = gmin(s2o, next_lane(next_lane(s1o)));            // [2l+1,2l+5) + [2l+5,2l+7)
         } else {
-            me = min(s2e, next_lane(s2o, INF));                   // [2l,2l+4) + [2l+3,2l+7)
-            mo = min(s2o, next_lane(next_lane(s2e, INF), INF));   // [2l+1,2l+5) + [2l+4,2l+8)
+            me = gmin(s2e, next_lane(s2o));                       // [2l,2l+4) + [2l+3,2l+7)
+            mo = gmin(s2o, next_lane(next_lane(s2e)));            // [2l+1,2l+5) + [2l+4,2l+8)
         }
         return;
     }
-    uint32_t ce = e, co = o; me = e; mo = o;
+    gapv ce = e, co = o; me = e; mo = o;
     for (int d = 1; d < W; d++) {                                 // shift by one position: (e, o) <- (o, next lane's e)
-        const uint32_t ne = co, no = next_lane(ce, INF);
+        const gapv ne = co, no = next_lane(ce);
         ce = ne; co = no;
-        me = min(me, ce); mo = min(mo, co);
+        me = gmin(me, ce); mo = gmin(mo, co);
     }
 }
 // h(0) of the window whose forward / reverse-complement k-mers are kmer / rk: its left-most gapped-mer, read from kmer, and the
 // reverse complement of that gapped-mer, which is the right-most candidate of rk (see "big layout" above)
-__device__ __forceinline__ uint32_t gap_h0(const KParams& P, const uint64_t kmer, const uint64_t rk) {
+__device__ __forceinline__ uint64_t gap_h0(const KParams& P, const uint64_t kmer, const uint64_t rk) {
     const uint32_t mk = (1u << (2 * P.gm)) - 1u;
     if (P.k == 31 && P.gH == 15) {                                // halves = bases 0-14 (high word) and 16-30 (low word): 32-bit cuts
         const uint32_t sh = 2u * (uint32_t)(15 - P.gm), hi = (uint32_t)(kmer >> 32), lo = (uint32_t)kmer;
-        return gap_f(hi >> sh, (lo >> sh) & mk) + gap_f((uint32_t)(rk >> 32) & mk, (uint32_t)rk & mk);
+        return gap_pair(gap_f(hi >> sh, (lo >> sh) & mk), gap_f((uint32_t)(rk >> 32) & mk, (uint32_t)rk & mk));
     }
     const uint32_t la = (uint32_t)(kmer >> (2 * (P.k - P.gm))) & mk, ra = (uint32_t)(kmer >> (2 * (P.k - P.gD - P.gm))) & mk;
     const uint32_t lb = (uint32_t)(rk >> (2 * (P.k - P.gH))) & mk, rb = (uint32_t)rk & mk;
-    return gap_f(la, ra) + gap_f(lb, rb);
+    return gap_pair(gap_f(la, ra), gap_f(lb, rb));
 }
 // Candidate probe on the big layout.  Slots 0/1 = read A's positions 2l / 2l+1, slots 2/3 = read B's.  The line of a window comes
 // from the minimum over W consecutive per-position values, shared across lanes (window_min) instead of recomputed per key; that
@@ -799,7 +812,7 @@ struct Cand4Big { uint64_t key[4], t1[4], t2[4], ts[4]; uint32_t ma[4], mb[4], w
 template <bool NOMM>
 __device__ __forceinline__ uint64_t cand_probe4_big(const KParams& P, const uint64_t* kmer, const uint64_t* rk, const uint64_t* rkRaw, const bool* nf, Cand4Big& C) {
     const uint32_t mmLo = (uint32_t)P.middleMask, mmHi = (uint32_t)(P.middleMask >> 32);
-    uint32_t h0[4], hw[4];
+    uint64_t hw[4];
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         const uint64_t mx = kmer[s] > rk[s] ? kmer[s] : rk[s];
@@ -810,13 +823,16 @@ __device__ __forceinline__ uint64_t cand_probe4_big(const KParams& P, const uint
         C.nf[s] = nf[s];
     }
     if (P.gW > 0) {
+        gapv h0[4], hm_[4];
 #pragma unroll
-        for (int s = 0; s < 4; s++) h0[s] = gap_h0(P, kmer[s], rkRaw[s]);     // the raw complement cut: a reset further right does not touch these bases
-        window_min(P.gW, h0[0], h0[1], hw[0], hw[1]);
-        window_min(P.gW, h0[2], h0[3], hw[2], hw[3]);
+        for (int s = 0; s < 4; s++) h0[s] = gap_pack(gap_h0(P, kmer[s], rkRaw[s]));     // the raw complement cut: a reset further right does not touch these bases
+        window_min(P.gW, h0[0], h0[1], hm_[0], hm_[1]);
+        window_min(P.gW, h0[2], h0[3], hm_[2], hm_[3]);
+#pragma unroll
+        for (int s = 0; s < 4; s++) hw[s] = gap_unpack(hm_[s]);
     } else {                                                      // plain lines: a function of the key itself
 #pragma unroll
-        for (int s = 0; s < 4; s++) hw[s] = C.ma[s] ^ 0x5BD1E995u;
+        for (int s = 0; s < 4; s++) hw[s] = (uint64_t)(C.ma[s] ^ 0x5BD1E995u);
     }
 #pragma unroll
     for (int s = 0; s < 4; s++) {
@@ -3536,10 +3552,11 @@ extern "C" int bbduk_destroy(bbduk_handle* h) {
     hipSetDevice(h->p.device);
     build_release(h);
     hipFree(h->d_bigTags); hipFree(h->d_bigKeys); hipFree(h->d_bigIds);
-    hipFree(h->d_tags); hipFree(h->d_bkv); hipFree(h->d_bases); hipFree(h->d_undef); hipFree(h->d_off);
+    for (auto& q : h->slot) { hipFree(q.d_bases); hipFree(q.d_undef); hipFree(q.d_off); hipFree(q.d_a); hipFree(q.d_id); hipFree(q.d_fl); if (q.stream) hipStreamDestroy(q.stream); }
+    hipFree(h->d_tags); hipFree(h->d_bkv);
     hipFree(h->d_ldsImage); hipFree(h->d_slowFlag);
     for (int q = 0; q < bbduk_handle::EV_RING; q++) { if (h->ev0[q]) hipEventDestroy(h->ev0[q]); if (h->ev1[q]) hipEventDestroy(h->ev1[q]); }
-    hipFree(h->d_a); hipFree(h->d_id); hipFree(h->d_fl); hipFree(h->d_counters);
+    hipFree(h->d_counters);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
     return BBDUK_OK;
@@ -4080,63 +4097,74 @@ static int host_batch(bbduk_handle* h, int wantKfilter, const uint8_t* bases, co
     if (packed && total > 0 && !undef) return fail(h, BBDUK_ERR_ARG, "packed input needs the undefined-bit plane");
     const size_t baseBytes = packed ? 4 * (size_t)((total + 15) >> 4) : (size_t)total;      // what crosses PCIe for the bases
     const size_t undefBytes = packed ? 4 * (size_t)((total + 31) >> 5) : 0;
-    std::lock_guard<std::mutex> g(h->mu);       // one staging area per handle: concurrent submitters serialise here
     HIP_TRY(h, hipSetDevice(h->p.device));
+    // take one of the handle's staging slots (a third submitter waits for the first free one)
+    bbduk_handle::Slot* S = nullptr;
+    {
+        std::unique_lock<std::mutex> lk(h->slotMu);
+        h->slotCv.wait(lk, [&] { for (auto& q : h->slot) if (!q.busy) return true; return false; });
+        for (auto& q : h->slot) if (!q.busy) { S = &q; break; }
+        S->busy = true;
+    }
+    struct Release { bbduk_handle* h; bbduk_handle::Slot* S; ~Release() { { std::lock_guard<std::mutex> lk(h->slotMu); S->busy = false; } h->slotCv.notify_one(); } } rel{h, S};
+    if (!S->stream) HIP_TRY(h, hipStreamCreateWithFlags(&S->stream, hipStreamNonBlocking));
     // a capacity is recorded only once its buffers exist: a failed hipMalloc leaves the handle usable for a smaller batch
-    if (undefBytes + 8 > h->cap_undef) {
-        hipFree(h->d_undef); h->d_undef = nullptr; h->cap_undef = 0;
+    if (undefBytes + 8 > S->cap_undef) {
+        hipFree(S->d_undef); S->d_undef = nullptr; S->cap_undef = 0;
         const size_t cap = undefBytes + 8 + undefBytes / 4;
-        HIP_TRY(h, hipMalloc(&h->d_undef, cap));
-        h->cap_undef = cap;
+        HIP_TRY(h, hipMalloc(&S->d_undef, cap));
+        S->cap_undef = cap;
     }
-    if ((size_t)total + 16 > h->cap_bases) {
-        hipFree(h->d_bases); h->d_bases = nullptr; h->cap_bases = 0;
+    if ((size_t)total + 16 > S->cap_bases) {
+        hipFree(S->d_bases); S->d_bases = nullptr; S->cap_bases = 0;
         const size_t cap = (size_t)total + 16 + (size_t)total / 4;
-        HIP_TRY(h, hipMalloc(&h->d_bases, cap));
-        h->cap_bases = cap;
+        HIP_TRY(h, hipMalloc(&S->d_bases, cap));
+        S->cap_bases = cap;
     }
-    if ((size_t)n + 1 > h->cap_reads) {
-        hipFree(h->d_off); hipFree(h->d_a); hipFree(h->d_id); hipFree(h->d_fl);
-        h->d_off = nullptr; h->d_a = nullptr; h->d_id = nullptr; h->d_fl = nullptr; h->cap_reads = 0;
+    if ((size_t)n + 1 > S->cap_reads) {
+        hipFree(S->d_off); hipFree(S->d_a); hipFree(S->d_id); hipFree(S->d_fl);
+        S->d_off = nullptr; S->d_a = nullptr; S->d_id = nullptr; S->d_fl = nullptr; S->cap_reads = 0;
         const size_t cap = (size_t)n + 1 + (size_t)n / 4;
-        HIP_TRY(h, hipMalloc(&h->d_off, cap * sizeof(int64_t)));
-        HIP_TRY(h, hipMalloc(&h->d_a, cap * sizeof(int32_t)));
-        HIP_TRY(h, hipMalloc(&h->d_id, cap * sizeof(int32_t)));
-        HIP_TRY(h, hipMalloc(&h->d_fl, cap));
-        h->cap_reads = cap;
+        HIP_TRY(h, hipMalloc(&S->d_off, cap * sizeof(int64_t)));
+        HIP_TRY(h, hipMalloc(&S->d_a, cap * sizeof(int32_t)));
+        HIP_TRY(h, hipMalloc(&S->d_id, cap * sizeof(int32_t)));
+        HIP_TRY(h, hipMalloc(&S->d_fl, cap));
+        S->cap_reads = cap;
     }
-    if (total > 0) HIP_TRY(h, hipMemcpyAsync(h->d_bases, bases, baseBytes, hipMemcpyHostToDevice, h->stream));
-    if (undefBytes) HIP_TRY(h, hipMemcpyAsync(h->d_undef, undef, undefBytes, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_off, offsets, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    const hipStream_t st = S->stream;
+    if (total > 0) HIP_TRY(h, hipMemcpyAsync(S->d_bases, bases, baseBytes, hipMemcpyHostToDevice, st));
+    if (undefBytes) HIP_TRY(h, hipMemcpyAsync(S->d_undef, undef, undefBytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(S->d_off, offsets, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
     MatchOut dm{nullptr, nullptr, nullptr, 0};                  // match lists: device buffers of this call only
     auto release = [&]() { hipFree(dm.n); hipFree(dm.ids); hipFree(dm.counts); };
     if (hostMatches) {
         dm.cap = hostMatches->cap;
         const size_t lw = (size_t)n * (size_t)dm.cap * sizeof(int32_t);
         if (hipMalloc(&dm.n, (size_t)n * sizeof(int32_t)) != hipSuccess || hipMalloc(&dm.ids, lw) != hipSuccess || hipMalloc(&dm.counts, lw) != hipSuccess ||
-            hipMemsetAsync(dm.ids, 0, lw, h->stream) != hipSuccess || hipMemsetAsync(dm.counts, 0, lw, h->stream) != hipSuccess) { release(); return fail(h, BBDUK_ERR_NOMEM, "hipMalloc (match lists)"); }
+            hipMemsetAsync(dm.ids, 0, lw, st) != hipSuccess || hipMemsetAsync(dm.counts, 0, lw, st) != hipSuccess) { release(); return fail(h, BBDUK_ERR_NOMEM, "hipMalloc (match lists)"); }
     }
-    const int rc = launch_batch(h, wantKfilter, h->d_bases, h->d_off, n, total, paired, h->d_a, h->d_id, h->d_fl, h->d_counters, h->stream,
-                                reinterpret_cast<const uint32_t*>(h->d_undef), packed, hostMatches ? &dm : nullptr);
+    const int rc = launch_batch(h, wantKfilter, S->d_bases, S->d_off, n, total, paired, S->d_a, S->d_id, S->d_fl, h->d_counters, st,
+                                reinterpret_cast<const uint32_t*>(S->d_undef), packed, hostMatches ? &dm : nullptr);
     if (rc != BBDUK_OK) { release(); return rc; }
     if (hostMatches) {
         const size_t lw = (size_t)n * (size_t)dm.cap * sizeof(int32_t);
-        const bool okc = hipMemcpyAsync(hostMatches->n, dm.n, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
-                         hipMemcpyAsync(hostMatches->ids, dm.ids, lw, hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
-                         hipMemcpyAsync(hostMatches->counts, dm.counts, lw, hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
-                         hipStreamSynchronize(h->stream) == hipSuccess;
+        const bool okc = hipMemcpyAsync(hostMatches->n, dm.n, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st) == hipSuccess &&
+                         hipMemcpyAsync(hostMatches->ids, dm.ids, lw, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                         hipMemcpyAsync(hostMatches->counts, dm.counts, lw, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                         hipStreamSynchronize(st) == hipSuccess;
         release();
         if (!okc) return fail(h, BBDUK_ERR_DEVICE, "copying the match lists back");
     }
-    HIP_TRY(h, hipMemcpyAsync(out_a, h->d_a, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(out_id, h->d_id, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(out_fl, h->d_fl, (size_t)n, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpyAsync(out_a, S->d_a, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(out_id, S->d_id, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(out_fl, S->d_fl, (size_t)n, hipMemcpyDeviceToHost, st));
     int64_t status = 0;
-    HIP_TRY(h, hipMemcpy(&status, h->d_counters + BBDUK_CTR_STATUS, sizeof status, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpyAsync(&status, h->d_counters + BBDUK_CTR_STATUS, sizeof status, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
     if (status != 0) {
         int64_t z = 0;
-        hipMemcpy(h->d_counters + BBDUK_CTR_STATUS, &z, sizeof z, hipMemcpyHostToDevice);
+        hipMemcpyAsync(h->d_counters + BBDUK_CTR_STATUS, &z, sizeof z, hipMemcpyHostToDevice, st);
+        hipStreamSynchronize(st);
         return fail(h, -(int)status, "device reported an error (read longer than BBDUK_MAX_READ_LEN?)");
     }
     return BBDUK_OK;

@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 #include <mutex>
+#include <condition_variable>
 #include <memory>
 #include "../../include/bbduk_gpu.h"
 
@@ -74,13 +75,20 @@ struct bbduk_handle {
     std::mutex launchMu;                                          // device-buffer operators may be issued from several host threads /
                                                                   // streams at once: slot choice and enqueue of one launch are atomic,
                                                                   // and every launch in flight has its own pre-pass flag (d_slowFlag[slot])
-    // host-operator staging
-    uint8_t* d_bases = nullptr; size_t cap_bases = 0;
-    uint8_t* d_undef = nullptr; size_t cap_undef = 0;     // packed boundary: one undefined-base bit per base
-    int64_t* d_off = nullptr;   size_t cap_reads = 0;
-    int32_t* d_a = nullptr; int32_t* d_id = nullptr; uint8_t* d_fl = nullptr;
+    // host-operator staging: two slots, each with its own device buffers and stream, so that two submitting host threads overlap --
+    // the H2D copy of one call runs under the kernel and the D2H copy of the other (the copy engines and the CUs are different units)
+    struct Slot {
+        uint8_t* d_bases = nullptr; size_t cap_bases = 0;
+        uint8_t* d_undef = nullptr; size_t cap_undef = 0;     // packed boundary: one undefined-base bit per base
+        int64_t* d_off = nullptr;   size_t cap_reads = 0;
+        int32_t* d_a = nullptr; int32_t* d_id = nullptr; uint8_t* d_fl = nullptr;
+        hipStream_t stream = nullptr; bool busy = false;
+    };
+    static const int NSLOTS = 2;
+    Slot slot[NSLOTS];
+    std::mutex slotMu; std::condition_variable slotCv;
     int64_t* d_counters = nullptr;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;                                 // table builds, counters, the one-off operators
     int numCU = 256;
     bbduk_comm* comm = nullptr;          // set by bbduk_comm_create / bbduk_comm_create_local
     // include/bbduk_test_hooks.h (tests and experiments only)
