@@ -120,14 +120,16 @@ __host__ __device__ __forceinline__ uint32_t gap_f(uint32_t l, uint32_t r) {
     x ^= x >> 15; x *= 0x2C1B3C6Du;                               // the product's high bits carry the order
     return x;
 }
-// The two orientations' values combine symmetrically into 52 bits (the candidates are ordered by them): 32 bits alone leave 10^10 keys'
-// ~3e9 runs of shared minimizers only ~1e9 distinct minima (minima crowd near 0), whole runs would then share lines and overload them.
+// The two orientations' values combine symmetrically into 52 bits, their sum below and the top of their product above (sum and
+// xor would be linearly related bit by bit: measured, the line hash then behaved like a 30-bit one and whole runs shared lines at
+// 10^10 keys).  The candidates are ordered by these values.
 __host__ __device__ __forceinline__ uint64_t gap_pair(const uint32_t fa, const uint32_t fb) {
-    return ((uint64_t)((fa ^ fb) & 0xFFFFFu) << 32) | (uint32_t)(fa + fb);
+    return ((uint64_t)((fa * fb) >> 12) << 32) | (uint32_t)(fa + fb);
 }
-// minima are biased towards 0: re-mix before the multiply-shift that maps onto [0, nlines)
+// minima are biased towards 0: scramble before the multiply-shift that maps onto [0, nlines)
 __host__ __device__ __forceinline__ uint32_t gap_line(const uint64_t hmin, const uint32_t nlines) {
-    uint32_t y = (uint32_t)hmin * 0x297A2D39u + (uint32_t)(hmin >> 32) * 0x9E3779B1u; y ^= y >> 15; y *= 0xC2B2AE35u;
+    uint32_t y = (uint32_t)hmin * 0x297A2D39u; y ^= y >> 15;
+    y = y * 0xC2B2AE35u + (uint32_t)(hmin >> 32) * 0x9E3779B1u; y ^= y >> 13; y *= 0x85EBCA6Bu;
     return (uint32_t)(((uint64_t)y * (uint64_t)nlines) >> 32);
 }
 __host__ __device__ __forceinline__ uint64_t rcomp_hd(uint64_t kmer, int len) {      // dev_rcomp, host and device
@@ -3886,6 +3888,28 @@ extern "C" int bbduk_build_table_device(bbduk_handle* h, const uint8_t* refs, co
     return rc;
 }
 
+// diagnostics of the big layout (include/bbduk_test_hooks.h): how many lines hold 0..32 keys
+__global__ void bbduk_line_hist_kernel(const uint64_t* __restrict__ keys, const uint32_t nlines, unsigned long long* __restrict__ hist) {
+    for (uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; l < nlines; l += (uint64_t)gridDim.x * blockDim.x) {
+        int c = 0;
+        for (int q = 0; q < 32; q++) c += keys[32ULL * l + q] != EMPTY_KEY;
+        atomicAdd(&hist[c], 1ULL);
+    }
+}
+extern "C" int bbduk_table_line_histogram(bbduk_handle* h, int64_t* out33) {
+    if (!h || !out33) return BBDUK_ERR_ARG;
+    if (!h->finalized || !h->big) return fail(h, BBDUK_ERR_STATE, "no big-layout map");
+    std::lock_guard<std::mutex> g(h->mu);
+    HIP_TRY(h, hipSetDevice(h->p.device));
+    unsigned long long* d = nullptr;
+    HIP_TRY(h, hipMalloc(&d, 33 * 8));
+    hipMemsetAsync(d, 0, 33 * 8, h->stream);
+    bbduk_line_hist_kernel<<<dim3(h->numCU * 16), dim3(256), 0, h->stream>>>(h->d_bigKeys, h->bigLines, d);
+    hipMemcpyAsync(out33, d, 33 * 8, hipMemcpyDeviceToHost, h->stream);
+    const hipError_t e = hipStreamSynchronize(h->stream);
+    hipFree(d);
+    return e == hipSuccess ? BBDUK_OK : BBDUK_ERR_DEVICE;
+}
 extern "C" int64_t bbduk_table_spilled(const bbduk_handle* h) { return (h && h->finalized && h->big) ? h->nspilled : 0; }
 extern "C" int64_t bbduk_table_size(const bbduk_handle* h) { return (h && h->finalized) ? h->nkeys : -1; }
 extern "C" int64_t bbduk_table_bytes(const bbduk_handle* h) {

@@ -17,6 +17,8 @@ extern "C" {
 int  bbduk_test_hook(bbduk_handle* h, int32_t which, int64_t value);
 /* big layout: keys that found both of their words full and live in the secondary map (0 for the cache-resident layout) */
 int64_t bbduk_table_spilled(const bbduk_handle* h);
+/* big layout: out33[c] = number of 32-slot lines that hold c keys */
+int  bbduk_table_line_histogram(bbduk_handle* h, int64_t* out33);
 #ifdef __cplusplus
 }
 #endif

@@ -79,6 +79,9 @@ def main():
            "keys": int(nkeys), "windows": int(n_scaf * (a.scaffold_bases - 30)), "table_bytes": int(gpu.table_bytes),
            "bytes_per_key": round(gpu.table_bytes / max(1, nkeys), 2), "spilled_keys": int(gpu.table_spilled),
            "build_s": round(t_build, 2), "build_detail_s": {"alloc+clear": round(t_alloc, 2), "generate_reference": round(t_gen, 2), "insert": round(t_add, 2), "end": round(t_end, 2)}}
+    hist = gpu.line_histogram()
+    out["line_load_histogram"] = hist.tolist(); out["lines"] = int(hist.sum())
+    out["line_load_mean"] = round(float((hist * np.arange(33)).sum() / hist.sum()), 3)
     # ---- table checks
     W = np.concatenate([w for w, _ in samples]); ids = np.concatenate([i for _, i in samples])
     got = gpu.table_lookup(keys_of(W))
