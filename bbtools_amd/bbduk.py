@@ -55,7 +55,7 @@ GPU_SYMBOLS = ["bbduk_abi_version", "bbduk_create", "bbduk_destroy", "bbduk_last
                "bbduk_kfilter_batch_device", "bbduk_pack_bases_host", "bbduk_pack_bases_device", "bbduk_ktrim_batch_packed",
                "bbduk_kfilter_batch_packed", "bbduk_ktrim_batch_packed_device", "bbduk_kfilter_batch_packed_device", "bbduk_kmask_batch", "bbduk_kmask_batch_device", "bbduk_ktrimtips_batch", "bbduk_ktrimtips_batch_device", "bbduk_ksplit_batch", "bbduk_kfilter_batch_matches", "bbduk_kfilter_batch_matches_device", "bbduk_ksplit_batch_device", "bbduk_kmask_batch_packed_device", "bbduk_ktrimtips_batch_packed_device", "bbduk_fastq_ingest_device", "bbduk_fastq_write_device", "bbduk_fastq_write_masked_device", "bbduk_device_malloc", "bbduk_device_free", "bbduk_pinned_malloc", "bbduk_pinned_free",
                "bbduk_copy_to_device", "bbduk_copy_from_device", "bbduk_device_memset", "bbduk_kernel_time_ms", "bbduk_counters_len", "bbduk_get_counters", "bbduk_reset_counters",
-               "bbduk_synth_generate_device", "bbduk_synth_generate_host",
+               "bbduk_synth_generate_device", "bbduk_synth_generate_host", "bbduk_synth_pair_inserts",
                "bbduk_comm_unique_id", "bbduk_comm_create", "bbduk_comm_create_local", "bbduk_comm_destroy", "bbduk_comm_size",
                "bbduk_allreduce_counters", "bbduk_allreduce_counters_device", "bbduk_allreduce_counters_local",
                "bbduk_test_hook", "bbduk_table_spilled", "bbduk_table_line_histogram", "bbduk_build_begin", "bbduk_build_add_device", "bbduk_build_end"]
@@ -196,6 +196,7 @@ def lib():
     L.bbduk_reset_counters.argtypes = [vp]
     L.bbduk_synth_generate_device.argtypes = [C.POINTER(SynthParams), i64, i64, vp, vp, i32, vp]
     L.bbduk_synth_generate_host.argtypes = [C.POINTER(SynthParams), i64, i64, vp, vp]
+    L.bbduk_synth_pair_inserts.argtypes = [C.POINTER(SynthParams), i64, i64, vp]
     L.bbduk_host_parse.argtypes = [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_int]
     L.bbduk_host_destroy.argtypes = [vp]
     L.bbduk_host_destroy.restype = None
@@ -608,6 +609,14 @@ def synth_generate_host(sp: SynthParams, first_pair: int, n_pairs: int):
     if rc != OK:
         raise BBDukError("synth_generate_host rc=%d" % rc)
     return bases, offsets
+
+
+def synth_pair_inserts(sp: SynthParams, first_pair: int, n_pairs: int) -> np.ndarray:
+    """Insert size of every pair: the generator's truth (a read keeps min(read_len, insert) genome bases)."""
+    out = np.empty(n_pairs, np.int32)
+    if lib().bbduk_synth_pair_inserts(C.byref(sp), first_pair, n_pairs, out.ctypes.data) != OK:
+        raise BBDukError("synth_pair_inserts failed")
+    return out
 
 
 def synth_generate_device(sp: SynthParams, first_pair: int, n_pairs: int, d_bases, d_offsets, device: int, stream_ptr=0):

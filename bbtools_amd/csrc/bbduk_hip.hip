@@ -4527,6 +4527,13 @@ extern "C" int bbduk_synth_generate_host(const bbduk_synth_params* sp, int64_t f
     return BBDUK_OK;
 }
 
+extern "C" int bbduk_synth_pair_inserts(const bbduk_synth_params* sp, int64_t first_pair, int64_t n_pairs, int32_t* out_insert) {
+    if (!synth_ok(sp) || n_pairs < 0 || (n_pairs > 0 && !out_insert)) return BBDUK_ERR_ARG;
+    const bb_synth_dev d = to_dev(sp);
+    for (int64_t p = 0; p < n_pairs; p++) out_insert[p] = bb_synth_pair_header(d, (uint64_t)(first_pair + p)).ins;
+    return BBDUK_OK;
+}
+
 extern "C" int bbduk_synth_generate_device(const bbduk_synth_params* sp, int64_t first_pair, int64_t n_pairs,
                                            uint8_t* d_bases, int64_t* d_offsets, int32_t device, void* stream) {
     if (!synth_ok(sp) || n_pairs < 0 || !d_offsets || (n_pairs > 0 && !d_bases)) return BBDUK_ERR_ARG;

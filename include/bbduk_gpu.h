@@ -341,6 +341,9 @@ int  bbduk_synth_generate_device(const bbduk_synth_params* sp, int64_t first_pai
                                  uint8_t* d_bases, int64_t* d_offsets /* 2*n_pairs+1 */, int32_t device, void* stream);
 int  bbduk_synth_generate_host(const bbduk_synth_params* sp, int64_t first_pair, int64_t n_pairs,
                                uint8_t* bases, int64_t* offsets);
+/* the truth behind the generator: out_insert[p] = insert size of pair first_pair + p (a read keeps min(read_len, insert) genome bases,
+ * adapter read-through follows) -- what AddAdapters writes into read names as <initial>_<remaining> (jgi/AddAdapters.java:485) */
+int  bbduk_synth_pair_inserts(const bbduk_synth_params* sp, int64_t first_pair, int64_t n_pairs, int32_t* out_insert);
 
 #ifdef __cplusplus
 }

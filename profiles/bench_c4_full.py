@@ -32,6 +32,12 @@ def keys_of(windows, k=31, mm=True):
     return (v | (np.uint64(1) << np.uint64(2 * k))).astype(np.int64)
 
 
+def run(ref_bases=1e10, scaffold_bases=10_000_000, chunk_scaffolds=50, reads=20_000_000, steps=3, check_reads=50_000, oracle_bases=50_000_000):
+    import types
+    return _run(types.SimpleNamespace(ref_bases=ref_bases, scaffold_bases=scaffold_bases, chunk_scaffolds=chunk_scaffolds, reads=reads, steps=steps,
+                                      check_reads=check_reads, oracle_bases=oracle_bases))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref-bases", type=float, default=1e10)
@@ -42,6 +48,10 @@ def main():
     ap.add_argument("--check-reads", type=int, default=50_000)
     ap.add_argument("--oracle-bases", type=int, default=50_000_000, help="prefix of scaffold 1.. the contaminated reads are drawn from (and the oracle indexes)")
     a = ap.parse_args()
+    print(json.dumps(_run(a)))
+
+
+def _run(a):
     import torch
     from bbtools_amd import bbduk as B
     ref_bases = int(a.ref_bases)
@@ -119,7 +129,10 @@ def main():
         out["checked_reads"] = int(m); out["checked_reads_differ"] = int(len(diff)); out["checked_reads_hit"] = int((oa > 0).sum())
         # a difference is legitimate only if the device found a k-mer of the reference OUTSIDE the oracle's part of it
         out["differ_device_hit_oracle_miss"] = int(((ga[diff] > 0) & (oa[diff] == 0)).sum()) if len(diff) else 0
-    print(json.dumps(out))
+    gpu.close(); host.close()
+    del d_bases, d_off, d_a, d_id, d_fl
+    torch.cuda.empty_cache()
+    return out
 
 
 if __name__ == "__main__":

@@ -12,7 +12,7 @@ import sys
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
 sys.path.insert(0, ROOT)
 from oracle.spec import Spec, Args  # noqa: E402
-from bbtools_amd.bbduk import synth_params, synth_generate_host, read_fasta  # noqa: E402
+from bbtools_amd.bbduk import synth_params, synth_generate_host, synth_pair_inserts, read_fasta  # noqa: E402
 
 ADAPTERS = os.path.join(ROOT, "data", "adapters.fa")
 PHIX = os.path.join(ROOT, "data", "phix2.fa.gz")
@@ -137,6 +137,15 @@ def write_stats_files(here, stem, s, scaffolds):
                 f.write("%s\t%d\t%d\t%.4f\t%d\t%.4f\n" % (names[i], lens[i], s.scafBases[i], s.scafBases[i] * invlen, s.scafReads[i], s.scafReads[i] * (float(mult) * invlen)))
 
 
+def truth_names(seed, n_pairs, reads, **kw):
+    """Read names in the AddAdapters truth convention (jgi/AddAdapters.java:485: r.id = initial + "_" + remaining): the read's length
+    and the number of its bases that are genome, i.e. before the adapter read-through starts -- so that the real bbduk.sh's output on
+    these files can be graded (addadapters.sh grade) and compared (tools/verify_with_reference.sh).  A running pair index and the
+    mate number follow after a blank, which keeps the names unique."""
+    ins = synth_pair_inserts(synth_params(seed, **kw), 0, n_pairs)
+    return ["%d_%d %d /%d" % (len(reads[i]), min(len(reads[i]), int(ins[i // 2])), i // 2, i % 2 + 1) for i in range(len(reads))]
+
+
 def write_fastq(path, names, reads):
     with open(path, "w") as f:
         for i, (nm, r) in enumerate(zip(names, reads)):
@@ -156,7 +165,7 @@ def cli_fixtures(phix, ks):
 
     # paired, two files, ktrim=r (configs[1] flags)
     reads = synth_reads(12, 100, ins_min=30, ins_max=260, sub_rate=0.01, n_rate=0.002)
-    names = ["%d_%d_%d /%d" % (i // 2, len(reads[i - i % 2]), len(reads[i - i % 2 + 1]), i % 2 + 1) for i in range(len(reads))]
+    names = truth_names(12, 100, reads, ins_min=30, ins_max=260, sub_rate=0.01, n_rate=0.002)
     write_fastq(os.path.join(here, "cli_c2_r1.fq"), names[0::2], reads[0::2])
     write_fastq(os.path.join(here, "cli_c2_r2.fq"), names[1::2], reads[1::2])
     s = Spec(Args(k=23, mink=11, hdist=1, ktrimRight=True)); s.load_fasta(ADAPTERS)
@@ -176,7 +185,7 @@ def cli_fixtures(phix, ks):
             f.write("@%s\n%s\n+\n%s\n" % (nm, "".join(b), "".join(q)))
     # interleaved, kfilter against phiX (configs[2] flags)
     reads = synth_reads(13, 100, contam=phix, contam_frac=0.3, sub_rate=0.01, n_rate=0.002)
-    names = ["%d_%d_%d /%d" % (i // 2, len(reads[i - i % 2]), len(reads[i - i % 2 + 1]), i % 2 + 1) for i in range(len(reads))]
+    names = truth_names(13, 100, reads, contam=phix, contam_frac=0.3, sub_rate=0.01, n_rate=0.002)
     write_fastq(os.path.join(here, "cli_c3_interleaved.fq"), names, reads)
     s = Spec(Args(k=31, hdist=1)); s.load_fasta(PHIX)
     tsv(os.path.join(here, "cli_c3.tsv"), names, reads, s.process_batch([r.encode() for r in reads], True), False)
