@@ -61,7 +61,7 @@ GPU_SYMBOLS = ["bbduk_abi_version", "bbduk_create", "bbduk_destroy", "bbduk_last
                "bbduk_test_hook", "bbduk_table_spilled", "bbduk_table_line_histogram", "bbduk_build_begin", "bbduk_build_add_device", "bbduk_build_end"]
 HOST_SYMBOLS = ["bbduk_host_parse", "bbduk_host_destroy", "bbduk_host_add_ref", "bbduk_host_load_fasta",
                 "bbduk_host_load_refs", "bbduk_host_build_index", "bbduk_host_index_pairs",
-                "bbduk_host_num_scaffolds", "bbduk_host_scaffold_info", "bbduk_host_params", "bbduk_host_upload_index", "bbduk_host_build_on_device"]
+                "bbduk_host_num_scaffolds", "bbduk_host_scaffold_info", "bbduk_host_num_refs", "bbduk_host_ref_info", "bbduk_host_params", "bbduk_host_upload_index", "bbduk_host_build_on_device"]
 
 _lib = None
 _lib_override = None
@@ -208,6 +208,8 @@ def lib():
     L.bbduk_host_index_pairs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64)]
     L.bbduk_host_num_scaffolds.argtypes = [vp]
     L.bbduk_host_scaffold_info.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(i64)]
+    L.bbduk_host_num_refs.argtypes = [vp]
+    L.bbduk_host_ref_info.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(i32)]
     L.bbduk_host_params.argtypes = [vp, i32, C.POINTER(Params)]
     L.bbduk_host_upload_index.argtypes = [vp, vp]
     L.bbduk_host_build_on_device.argtypes = [vp, vp]

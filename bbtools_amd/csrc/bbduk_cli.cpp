@@ -73,7 +73,7 @@ int fail(const char* what, const char* detail) { fprintf(stderr, "bbduk_cli: %s%
 bool parse_bool(const std::string& v) { return v.empty() || v == "t" || v == "true" || v == "1" || v == "T"; }
 
 // stats= and rpkm= (bbduk/BBDukProcessorS.java:572-655): per-scaffold hit statistics from the counter vector.
-struct StatsOut { std::string stats, rpkm; int columns = 3; bool nonZeroOnly = true; };   // BBDukParser.java:1508, 1363
+struct StatsOut { std::string stats, rpkm, refstats; int columns = 3; bool nonZeroOnly = true; };   // BBDukParser.java:1508, 1363
 int write_stats(const StatsOut& so, const bbduk_host* host, const std::vector<int64_t>& c, const std::string& in1, const std::string& in2) {
     const int ns = bbduk_host_num_scaffolds(host);
     const int64_t readsIn = c[BBDUK_READS_IN], basesIn = c[BBDUK_BASES_IN];
@@ -124,6 +124,31 @@ int write_stats(const StatsOut& so, const bbduk_host* host, const std::vector<in
             const double invlen = 1.0 / (double)(len > 1 ? len : 1);
             const double mult2 = (double)mult * invlen;
             if (reads[i] > 0 || !so.nonZeroOnly) fprintf(f, "%s\t%lld\t%lld\t%.4f\t%lld\t%.4f\n", nm, (long long)len, (long long)bases[i], bases[i] * invlen, (long long)reads[i], reads[i] * mult2);
+        }
+        fclose(f);
+    }
+    if (!so.refstats.empty()) {                                                    // writeRefStats, bbduk/BBDukIndexMod.java:196-245
+        FILE* f = fopen(so.refstats.c_str(), "w");
+        if (!f) return fail("cannot open", so.refstats.c_str());
+        int64_t mapped = 0;
+        for (int i = 0; i < ns; i++) mapped += reads[i];
+        const int nr = bbduk_host_num_refs(host);
+        fputs(fileLine.c_str(), f);
+        fprintf(f, "#Reads\t%lld\n#Mapped\t%lld\n#References\t%d\n#Name\tLength\tScaffolds\tBases\tCoverage\tReads\tRPKM\n", (long long)readsIn, (long long)mapped, nr > 0 ? nr : 0);
+        const float mult = 1000000000.0f / (float)(mapped > 1 ? mapped : 1);
+        static const char* const exts[] = {"fq", "fastq", "fa", "fasta", "fas", "fna", "ffn", "frn", "seq", "fsa", "faa", "gz", "bz2", "zip", "xz", "zst", "txt", nullptr};
+        for (int r = 0, sidx = 1; r < nr; r++) {
+            const char* nm = ""; int32_t scafs = 0; bbduk_host_ref_info(host, r, &nm, &scafs);
+            int64_t rr = 0, rb = 0, len = 0;
+            for (const int lim = sidx + scafs; sidx < lim; sidx++) { int64_t L = 0; bbduk_host_scaffold_info(host, sidx, nullptr, &L); rr += reads[sidx]; rb += bases[sidx]; len += L; }
+            std::string core = nm;                                                 // ReadWrite.stripToCore: no directories, no (stacked) extensions
+            const size_t sl = core.find_last_of("/\\"); if (sl != std::string::npos) core.erase(0, sl + 1);
+            for (bool again = true; again;) {
+                again = false;
+                for (int e = 0; exts[e]; e++) { const std::string x = std::string(".") + exts[e]; if (core.size() > x.size() && core.compare(core.size() - x.size(), x.size(), x) == 0) { core.erase(core.size() - x.size()); again = true; } }
+            }
+            const double invlen = 1.0 / (double)(len > 1 ? len : 1), mult2 = (double)mult * invlen;
+            if (rr > 0 || !so.nonZeroOnly) fprintf(f, "%s\t%lld\t%d\t%lld\t%.4f\t%lld\t%.4f\n", core.c_str(), (long long)len, scafs, (long long)rb, rb * invlen, (long long)rr, rr * mult2);
         }
         fclose(f);
     }
@@ -282,6 +307,7 @@ int main(int argc, char** argv) {
         else if (a == "chunk") chunk = atoll(b.c_str());
         else if (a == "stats" || a == "scafstats") so.stats = b;     // BBDukParser.java:486-494, 689-693
         else if (a == "rpkm" || a == "fpkm" || a == "cov" || a == "coverage") so.rpkm = b;
+        else if (a == "refstats") so.refstats = b;                   // BBDukParser.java:493
         else if (a == "statscolumns" || a == "columns" || a == "cols") so.columns = atoi(b.c_str());
         else if (a == "nzo" || a == "nonzeroonly") so.nonZeroOnly = parse_bool(b);
         else {

@@ -55,6 +55,8 @@ struct bbduk_host {
     Parsed p;
     std::vector<std::vector<uint8_t>> scaffolds;     // id = index+1
     std::vector<std::string> names;                  // scaffoldNames[id] (BBDukLoader.java:224, 275): FASTA header, or the id as text
+    std::vector<std::string> refNames;               // one per ref= file, then "literal" (BBDukParser.java:330-340); refstats= groups by these
+    std::vector<int> refScafCounts;                  // scaffolds each of them contributed (BBDukLoader.java:224, 275)
     std::vector<KV> cand;
     std::vector<int64_t> keys;
     std::vector<int32_t> vals;
@@ -366,11 +368,21 @@ extern "C" int bbduk_host_load_refs(bbduk_host* h, const char* resource_dir) {
         const int n = bbduk_host_load_fasta(h, path.c_str());
         if (n < 0) return n;
         total += n;
+        h->refNames.push_back(path); h->refScafCounts.push_back(n);
     }
+    if (!h->p.literal.empty()) { h->refNames.push_back("literal"); h->refScafCounts.push_back((int)h->p.literal.size()); }
     for (const std::string& l : h->p.literal) {                      // BBDukLoader.java:272-277: a literal's name is its id
         h->scaffolds.emplace_back(l.begin(), l.end()); h->names.push_back(std::to_string(h->scaffolds.size())); total++;
     }
     return total;
+}
+
+extern "C" int bbduk_host_num_refs(const bbduk_host* h) { return h ? (int)h->refNames.size() : BBDUK_ERR_ARG; }
+extern "C" int bbduk_host_ref_info(const bbduk_host* h, int32_t r, const char** name, int32_t* num_scaffolds) {
+    if (!h || r < 0 || r >= (int)h->refNames.size()) return BBDUK_ERR_ARG;
+    if (name) *name = h->refNames[(size_t)r].c_str();
+    if (num_scaffolds) *num_scaffolds = h->refScafCounts[(size_t)r];
+    return BBDUK_OK;
 }
 
 extern "C" int64_t bbduk_host_build_index(bbduk_host* h) {

@@ -45,11 +45,17 @@ int  bbduk_host_num_scaffolds(const bbduk_host* h);
  * text) and the number of bases; id in 1..num_scaffolds-1.  *name stays valid until bbduk_host_destroy. */
 int  bbduk_host_scaffold_info(const bbduk_host* h, int32_t id, const char** name, int64_t* length);
 
+/* The reference FILES behind the scaffolds, in load order (refNames / refScafCounts, bbduk/BBDukParser.java:330-340,
+ * bbduk/BBDukLoader.java:224, 275): every ref= file, then one entry "literal" for all literal= sequences.  Scaffold ids run
+ * through them consecutively; refstats= sums the scaffold counters per entry (bbduk/BBDukIndexMod.java:196-245). */
+int  bbduk_host_num_refs(const bbduk_host* h);
+int  bbduk_host_ref_info(const bbduk_host* h, int32_t r, const char** name, int32_t* num_scaffolds);
+
 /* Fills the boundary struct from the parsed + derived fields (device ordinal as given). */
 int  bbduk_host_params(const bbduk_host* h, int32_t device, bbduk_params* out);
 
 /* Hands the loaded scaffolds to bbduk_build_table_device (the map is built on the GPU; bbduk_host_build_index is not
- * needed).  BBDUK_ERR_ARG for edist>0 or hdist>2, which only the host builder serves. */
+ * needed).  BBDUK_ERR_ARG for edist>0 or hdist>3, which only the host builder serves. */
 int  bbduk_host_build_on_device(const bbduk_host* h, bbduk_handle* dev);
 
 /* Convenience for callers that hold a device handle: upload_pairs + finalize. */

@@ -137,6 +137,15 @@ def write_stats_files(here, stem, s, scaffolds):
                 f.write("%s\t%d\t%d\t%.4f\t%d\t%.4f\n" % (names[i], lens[i], s.scafBases[i], s.scafBases[i] * invlen, s.scafReads[i], s.scafReads[i] * (float(mult) * invlen)))
 
 
+    # refstats= (BBDukIndexMod.writeRefStats :196-245): the scaffold counters summed per reference FILE; here one file, "adapters"
+    tot_len = sum(lens[1:]); tot_r = sum(s.scafReads[1:]); tot_b = sum(s.scafBases[1:])
+    invlen = 1.0 / max(1, tot_len)
+    with open(os.path.join(here, stem + "_refstats.txt"), "w") as f:
+        f.write("#File\tIN1\tIN2\n#Reads\t%d\n#Mapped\t%d\n#References\t1\n#Name\tLength\tScaffolds\tBases\tCoverage\tReads\tRPKM\n" % (readsIn, mapped))
+        if tot_r > 0:
+            f.write("%s\t%d\t%d\t%d\t%.4f\t%d\t%.4f\n" % ("adapters", tot_len, s.nscaf - 1, tot_b, tot_b * invlen, tot_r, tot_r * (float(mult) * invlen)))
+
+
 def truth_names(seed, n_pairs, reads, **kw):
     """Read names in the AddAdapters truth convention (jgi/AddAdapters.java:485: r.id = initial + "_" + remaining): the read's length
     and the number of its bases that are genome, i.e. before the adapter read-through starts -- so that the real bbduk.sh's output on

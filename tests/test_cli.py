@@ -162,13 +162,14 @@ def test_cli_deviceingest_rejects_what_it_cannot_serve(tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("ingest", [[], ["deviceingest=t"]])
 def test_cli_stats_and_rpkm_files(tmp_path, ingest):
-    """stats= (3 and 5 columns) and rpkm= as BBDukProcessorS.writeStats / writeRPKM format the per-scaffold counters
-    (:572-655); expected files come from the spec's counters (tests/golden/make_golden.py write_stats_files)."""
+    """stats= (3 and 5 columns), rpkm= and refstats= as BBDukProcessorS.writeStats / writeRPKM (:572-655) and BBDukIndexMod.writeRefStats
+    (:196-245) format the per-scaffold counters; expected files come from the spec's counters (tests/golden/make_golden.py write_stats_files)."""
     f1, f2 = os.path.join(GOLD, "cli_c2_r1.fq"), os.path.join(GOLD, "cli_c2_r2.fq")
     for cols, stem in (("3", "cli_c2_stats3.txt"), ("5", "cli_c2_stats5.txt")):
-        st, rp = str(tmp_path / "stats.txt"), str(tmp_path / "rpkm.txt")
-        r = run_cli(["in=" + f1, "in2=" + f2, "stats=" + st, "rpkm=" + rp, "statscolumns=" + cols, "ktrim=r", "k=23", "mink=11", "hdist=1", "ref=adapters"] + ingest)
+        st, rp, rs = str(tmp_path / "stats.txt"), str(tmp_path / "rpkm.txt"), str(tmp_path / "refstats.txt")
+        r = run_cli(["in=" + f1, "in2=" + f2, "stats=" + st, "rpkm=" + rp, "refstats=" + rs, "statscolumns=" + cols, "ktrim=r", "k=23", "mink=11", "hdist=1", "ref=adapters"] + ingest)
         assert r.returncode == 0, r.stderr
+        assert open(rs).read() == open(os.path.join(GOLD, "cli_c2_refstats.txt")).read().replace("IN1", f1).replace("IN2", f2)
         want = open(os.path.join(GOLD, stem)).read().replace("IN1", f1).replace("IN2", f2)
         assert open(st).read() == want
         assert open(rp).read() == open(os.path.join(GOLD, "cli_c2_rpkm.txt")).read().replace("IN1", f1).replace("IN2", f2)

@@ -28,10 +28,11 @@ cmp_stats() {   # the reference's stats / rpkm file vs the committed one, withou
 
 # 1. configs[1] flags: paired, two files, ktrim=r k=23 mink=11 hdist=1 (+ stats=, 5-column stats, rpkm=)
 run "$DUK" in="$G/cli_c2_r1.fq" in2="$G/cli_c2_r2.fq" out="$W/c2_o1.fq" out2="$W/c2_o2.fq" outm="$W/c2_m1.fq" outm2="$W/c2_m2.fq" \
-    stats="$W/c2_stats.txt" rpkm="$W/c2_rpkm.txt" ktrim=r k=23 mink=11 hdist=1 ref="$REFA" $COMMON
+    stats="$W/c2_stats.txt" rpkm="$W/c2_rpkm.txt" refstats="$W/c2_refstats.txt" ktrim=r k=23 mink=11 hdist=1 ref="$REFA" $COMMON
 python3 "$ROOT/tools/compare_with_reference.py" --tsv "$G/cli_c2.tsv" --out "$W/c2_o1.fq" "$W/c2_o2.fq" --outm "$W/c2_m1.fq" "$W/c2_m2.fq" || fail=1
 cmp_stats "$W/c2_stats.txt" "$G/cli_c2_stats3.txt"
 cmp_stats "$W/c2_rpkm.txt" "$G/cli_c2_rpkm.txt"
+cmp_stats "$W/c2_refstats.txt" "$G/cli_c2_refstats.txt"
 run "$DUK" in="$G/cli_c2_r1.fq" in2="$G/cli_c2_r2.fq" stats="$W/c2_stats5.txt" statscolumns=5 ktrim=r k=23 mink=11 hdist=1 ref="$REFA" $COMMON
 cmp_stats "$W/c2_stats5.txt" "$G/cli_c2_stats5.txt"
 
