@@ -200,6 +200,9 @@ __device__ __forceinline__ int big_find_in(const KParams& P, const uint64_t key,
     if (!((t1 >> spill_bit(ma)) & 1ULL)) return -1;                // no key of this key's kind was ever spilled from the primary word
     return table_find_t(P, key, ma, mb, P.tags[bucket_of(mb, P.bucketBits)]);
 }
+// The exact per-key lookup.  Only the kernels that serve big-layout maps contain it (bbduk_wave_kernel<.., BIG>, the BIG instantiations
+// of its tile / long-read fallbacks, the point-lookup test hook): threaded through every general kernel's probe sites it cost those
+// kernels 100-500 spilled VGPRs and half their speed, so the big layout is chosen only for the configurations these kernels run.
 __device__ __forceinline__ int big_find(const KParams& P, const uint64_t key, const uint32_t ma, const uint32_t mb) {
     uint32_t w1, w2;
     big_words(big_line_of_key(big_geom(P), key, ma), mb, w1, w2);
@@ -225,7 +228,6 @@ __device__ __forceinline__ int table_find_t(const KParams& P, uint64_t key, uint
     }
 }
 __device__ __forceinline__ int table_find_m(const KParams& P, uint64_t key, uint32_t ma, uint32_t mb) {
-    if (P.big) return big_find(P, key, ma, mb);
     return table_find_t(P, key, ma, mb, P.tags[bucket_of(mb, P.bucketBits)]);
 }
 __device__ __forceinline__ int table_get(const KParams& P, uint64_t key) { const uint64_t v = strip_len(key); return table_find_m(P, key, mix_a(v), mix_b(v)); }
@@ -276,8 +278,13 @@ __device__ int get_value(const KParams& P, uint64_t kmer, uint64_t rkmer, uint64
     }
     return id;
 }
+// qhdist 3 has its own (deeper, fatter) body so that the usual qhdist <= 2 callers keep their register budget
+__device__ __noinline__ int get_value_expand3(const KParams& P, uint64_t kmer, uint64_t rkmer, uint64_t lengthMask, int len, int qh) {
+    return get_value<3>(P, kmer, rkmer, lengthMask, len, qh);
+}
 __device__ __noinline__ int get_value_expand(const KParams& P, uint64_t kmer, uint64_t rkmer, uint64_t lengthMask, int len, int qh) {
-    return get_value<3>(P, kmer, rkmer, lengthMask, len, qh);       // qhdist <= 3 (bbduk_create refuses more)
+    if (qh > 2) return get_value_expand3(P, kmer, rkmer, lengthMask, len, qh);       // qhdist <= 3 (bbduk_create refuses more)
+    return get_value<2>(P, kmer, rkmer, lengthMask, len, qh);
 }
 // index.getValue(kmer, rkmer, lengthMask, qPos, len, qHDist) as a ref: filtered fast path when there is no query expansion
 template <bool GENERAL>
@@ -600,7 +607,7 @@ __device__ __forceinline__ void windows2(const KParams& P, const Planes& Q, cons
 }
 
 // four independent key -> ref lookups with their memory operations overlapped
-template <bool GENERAL>
+template <bool GENERAL, bool BIG = false>
 __device__ __forceinline__ void lookup4(const KParams& P, const uint32_t* s_filt, const uint64_t* kmer, const uint64_t* rk,
                                         const bool* ok, int* ref) {
     if constexpr (GENERAL) {
@@ -628,10 +635,11 @@ __device__ __forceinline__ void lookup4(const KParams& P, const uint32_t* s_filt
         for (int s = 0; s < 4; s++) ref[s] = (p[s] && ma[s] == 0x12345u && mb[s] == 0x54321u) ? 0 : -1;
         return;
     }
-    if (P.big) {                                                  // HBM-resident layout: the exact generic lookup (the first-hit scans of the
-#pragma unroll                                                    // plain configurations have their own fast form, cand_probe4<.., BIG>)
-        for (int s = 0; s < 4; s++) ref[s] = p[s] ? big_find(P, key[s], ma[s], mb[s]) : -1;
-        return;
+    if constexpr (BIG) {                                          // (no other kernel ever meets a big map: see big_find)
+        if (P.big) {                                              // HBM-resident layout: the exact generic lookup (the first-hit scans of the
+            for (int s = 0; s < 4; s++) ref[s] = p[s] ? big_find(P, key[s], ma[s], mb[s]) : -1;     // plain configurations have cand_probe4_big)
+            return;
+        }
     }
     if (P.ldsBits) {                                              // four presence bits, read together
         uint32_t w[4];
@@ -1005,7 +1013,7 @@ __device__ __forceinline__ int kfilter_threshold(const KParams& P, const Planes&
 }
 
 // firstA >= 0 (bbduk_long_kernel): read A is scanned in chunks; this call resumes at position firstA with A.found hits so far.
-template <int MODE, bool FORBIDN, bool GENERAL>
+template <int MODE, bool FORBIDN, bool GENERAL, bool BIG = false>
 __device__ __forceinline__ void main_scan_pair(const KParams& P, const Planes& Q, ReadScan& A, ReadScan& B, const int lane, const int firstA = -1) {
     ReadWin WA, WB;
     win_init<FORBIDN, GENERAL>(P, Q, A, WA, lane);
@@ -1017,7 +1025,7 @@ __device__ __forceinline__ void main_scan_pair(const KParams& P, const Planes& Q
         uint64_t kmer[4], rk[4]; bool ok[4]; int id[4];
         windows2<FORBIDN, GENERAL>(P, Q, WA, ibA + 2 * lane, onA, kmer, rk, ok);
         windows2<FORBIDN, GENERAL>(P, Q, WB, ibB + 2 * lane, onB, kmer + 2, rk + 2, ok + 2);
-        lookup4<GENERAL>(P, Q.filt, kmer, rk, ok, id);
+        lookup4<GENERAL, BIG>(P, Q.filt, kmer, rk, ok, id);
         const uint64_t m0 = __ballot(id[0] != -1), m1 = __ballot(id[1] != -1), m2 = __ballot(id[2] != -1), m3 = __ballot(id[3] != -1);
         if (onA) {
             bool ex = false;
@@ -1299,7 +1307,7 @@ __device__ __forceinline__ void publish_counters(const unsigned long long* s_acc
 // The batch kernel: persistent workgroups (one per CU when the LDS filter is large) walk tiles of reads.
 // Template flags strip what a configuration cannot need: SHORT (mink), FORBIDN (undefined-base resets),
 // GENERAL (qhdist, restrictleft/right, skipr1/2, rcomp=f).
-template <int MODE, bool SHORT, bool FORBIDN, bool GENERAL>
+template <int MODE, bool SHORT, bool FORBIDN, bool GENERAL, bool BIG = false>
 __global__ __launch_bounds__(BLOCK_THREADS)
 void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
                         const int64_t n, const int64_t totalBases, const int paired,
@@ -1384,7 +1392,7 @@ void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
                     A.maxBad = kfilter_threshold(P, Q, A.base0, A.L, lane);
                     Bz.maxBad = kfilter_threshold(P, Q, Bz.base0, Bz.L, lane);
                 }
-                main_scan_pair<MODE, FORBIDN, GENERAL>(P, Q, A, Bz, lane);
+                main_scan_pair<MODE, FORBIDN, GENERAL, BIG>(P, Q, A, Bz, lane);
                 if constexpr (MODE != BBDUK_MODE_KFILTER && SHORT) {
                     if (P.useShort) short_scan_pair<MODE, GENERAL>(P, Q, A, Bz, lane);
                 }
@@ -2488,7 +2496,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                         vThr = (lane == ra) ? A.maxBad : ((lane == ra + 1) ? Bz.maxBad : vThr);
                     }
                 }
-                main_scan_pair<MODE, FORBIDN, GENERAL>(P, Q, A, Bz, lane);
+                main_scan_pair<MODE, FORBIDN, GENERAL, BIG>(P, Q, A, Bz, lane);
                 if (A.found) {                                      // hand the facts to lane ra (most reads have none)
                     vFound = (lane == ra) ? A.found : vFound; vFirst = (lane == ra) ? A.iFirst : vFirst;
                     vLast = (lane == ra) ? A.iLast : vLast;   vRef = (lane == ra) ? A.ref : vRef;
@@ -2564,7 +2572,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                     Bz.start = span_start<GENERAL>(P, Bz.L); Bz.stop = span_stop<GENERAL>(P, Bz.L);
                     A.found = 0; A.iFirst = BIGLOC; A.iLast = -1; A.ref = -1; A.shortFl = -1; A.shortLl = -1;
                     Bz.found = 0; Bz.iFirst = BIGLOC; Bz.iLast = -1; Bz.ref = -1; Bz.shortFl = -1; Bz.shortLl = -1;
-                    main_scan_pair<MODE, FORBIDN, GENERAL>(P, Q, A, Bz, lane);
+                    main_scan_pair<MODE, FORBIDN, GENERAL, BIG>(P, Q, A, Bz, lane);
                     vFound = (lane == ra) ? A.found : vFound; vFirst = (lane == ra) ? A.iFirst : vFirst; vRef = (lane == ra) ? A.ref : vRef;
                     if (hasB) { vFound = (lane == ra + 1) ? Bz.found : vFound; vFirst = (lane == ra + 1) ? Bz.iFirst : vFirst; vRef = (lane == ra + 1) ? Bz.ref : vRef; }
                     fbm &= ~(3ULL << ra);
@@ -2755,7 +2763,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
 #define LCHUNK (WCAP_BASES - 128)
 // The chunk loop of a long read for one scan span [R.start, R.stop) (bbduk_long_kernel, bbduk_long_tips_kernel).
 // stage(off, lo, hi) puts bases [lo, hi) of the read at `off` into the wave's planes and returns the plane index of base 0.
-template <int MODE, class Stage>
+template <int MODE, bool BIG = false, class Stage>
 __device__ __forceinline__ void long_scan(const KParams& P, const Planes& Q, Stage& stage, ReadScan& R, const int64_t off, const int lane) {
     if (!R.scan) return;
     const int k = P.k;
@@ -2767,7 +2775,7 @@ __device__ __forceinline__ void long_scan(const KParams& P, const Planes& Q, Sta
         const int lo = max(start, ci - (k - 1));
         R.base0 = stage(off, lo, ce); staged = true; lastLo = lo;
         R.start = lo; R.stop = ce; R.hasN = -1;
-        main_scan_pair<MODE, true, true>(P, Q, R, none, lane, ci);
+        main_scan_pair<MODE, true, true, BIG>(P, Q, R, none, lane, ci);
         R.start = start; R.stop = stop;
         if (MODE == BBDUK_MODE_KTRIM_R && R.found > 0) break;                  // only the first hit matters (:2019-2030)
         if (MODE == BBDUK_MODE_KFILTER && R.iFirst == 0) break;                // countSetKmers / countCoveredBases returned
@@ -2780,7 +2788,7 @@ __device__ __forceinline__ void long_scan(const KParams& P, const Planes& Q, Sta
     }
 }
 
-template <int MODE>
+template <int MODE, bool BIG = false>
 __global__ __launch_bounds__(BLOCK_THREADS)
 void bbduk_long_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
                        const int64_t n, const int64_t totalBases, const int paired,
@@ -2853,7 +2861,7 @@ void bbduk_long_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                 R.maxBad = max(P.maxBadKmers, (int)((float)((L >= k ? cnt : 0) - 1) * P.mkf));
             }
         }
-        long_scan<MODE>(P, Q, stage, R, off, lane);
+        long_scan<MODE, BIG>(P, Q, stage, R, off, lane);
     };
     const int step = paired ? 2 : 1;
     const int64_t units = (n + step - 1) / step;
@@ -3423,16 +3431,12 @@ static KernelPair pick_kernel(const KParams& K) {
     const bool general = K.qhdist > 0 || K.qhdist2 > 0 || K.restrictLeft > 0 || K.restrictRight > 0 || K.skipR1 || K.skipR2 || !K.rcomp ||
                          (K.useShort && K.middleMask != ~0ULL) || K.k < 16 || K.qskip > 1 || K.speed > 0 || K.mkf != 0.f || K.mcf > 0.f;
     if (K.big) {
-        // HBM-resident layout: the plain kfilter configurations (BASELINE configs[3]) have the fast minimizer-sharing candidate scan;
-        // every other configuration runs the general kernels, whose lookups take the exact per-key path (big_find)
-        if (!general && K.mode == BBDUK_MODE_KFILTER && K.gW <= 8) {
-            const batch_kernel_t tile = bbduk_batch_kernel<BBDUK_MODE_KFILTER, true, true, true>;
-            if (K.forbidNs) return KernelPair{bbduk_wave_kernel<BBDUK_MODE_KFILTER, false, true, false, 0, true>, bbduk_wave_kernel<BBDUK_MODE_KFILTER, false, true, false, 1, true>, tile};
-            return KernelPair{bbduk_wave_kernel<BBDUK_MODE_KFILTER, false, false, false, 0, true>, bbduk_wave_kernel<BBDUK_MODE_KFILTER, false, false, false, 1, true>, tile};
-        }
-        if (K.mode == BBDUK_MODE_KFILTER) return kpair<BBDUK_MODE_KFILTER, true, true, true>();
-        if (K.mode == BBDUK_MODE_KTRIM_L) return kpair<BBDUK_MODE_KTRIM_L, true, true, true>();
-        return kpair<BBDUK_MODE_KTRIM_R, true, true, true>();
+        // HBM-resident layout: chosen at build time only for the plain kfilter configurations (big_layout_eligible: BASELINE
+        // configs[3]), whose first-hit scan has the minimizer-sharing candidate form; the exact scans (maxbadkmers > 0, impostors) and
+        // the tile / long-read fallbacks are the BIG instantiations of the same functions
+        const batch_kernel_t tile = bbduk_batch_kernel<BBDUK_MODE_KFILTER, true, true, true, true>;
+        if (K.forbidNs) return KernelPair{bbduk_wave_kernel<BBDUK_MODE_KFILTER, false, true, false, 0, true>, bbduk_wave_kernel<BBDUK_MODE_KFILTER, false, true, false, 1, true>, tile};
+        return KernelPair{bbduk_wave_kernel<BBDUK_MODE_KFILTER, false, false, false, 0, true>, bbduk_wave_kernel<BBDUK_MODE_KFILTER, false, false, false, 1, true>, tile};
     }
     if (K.mode == BBDUK_MODE_KFILTER) return pick_kernel_mode<BBDUK_MODE_KFILTER>(general, false, K.forbidNs != 0);
     if (K.mode == BBDUK_MODE_KTRIM_L) return pick_kernel_mode<BBDUK_MODE_KTRIM_L>(general, K.useShort != 0, K.forbidNs != 0);
@@ -3453,7 +3457,10 @@ __global__ void bbduk_pack_kernel(const uint8_t* __restrict__ bases, const int64
 
 __global__ void bbduk_lookup_kernel(const KParams P, const int64_t* keys, int64_t n, int32_t* out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (keys[i] < 0) ? -1 : table_get(P, (uint64_t)keys[i]);
+    if (i < n) {
+        const uint64_t key = (uint64_t)keys[i], v = strip_len(key);
+        out[i] = (keys[i] < 0) ? -1 : (P.big ? big_find(P, key, mix_a(v), mix_b(v)) : table_get(P, key));
+    }
 }
 
 __global__ void bbduk_synth_kernel(const bb_synth_dev sp, const int64_t firstPair, const int64_t nPairs,
@@ -3644,6 +3651,14 @@ static Sink make_sink(const bbduk_handle* h, const BuildState* st) {
     S.distinct = st->d_cnt;
     return S;
 }
+// The configurations the big-layout kernels run: plain kfilter (what pick_kernel calls "not general"), no k>31 runs, no findBestMatch.
+// Every other configuration keeps the cache-resident layout at any size it can index (2^29 buckets, ~10^9 keys), as before.
+static bool big_layout_eligible(const bbduk_params& p) {
+    const bool useShort = p.mink > 0 && p.mink < p.k;
+    const bool general = p.qhdist > 0 || p.qhdist2 > 0 || p.restrictLeft > 0 || p.restrictRight > 0 || p.skipR1 || p.skipR2 || !p.rcomp ||
+                         (useShort && p.middleMask != -1) || p.k < 16 || p.qSkip > 1 || p.speed > 0 || p.minKmerFraction != 0.f || p.minCoveredFraction > 0.f;
+    return p.mode == BBDUK_MODE_KFILTER && !general && !(p.kbig > p.k) && !p.findBestMatch;
+}
 #define BIG_LAYOUT_MIN_KEYS (1LL << 25)            // beyond ~3e7 keys the fingerprints alone outgrow L2 + Infinity Cache
 
 // expected number of keys (an upper bound is fine) -> layout, allocations
@@ -3656,7 +3671,7 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
     h->build = st; st->hdist = hdist; st->hdist2 = hdist2;
     // reference-side Hamming neighbourhoods put ~2/3 of a k-mer's 1+3k variants on one minimizer: such maps take plain lines
     if (hdist > 0) h->bigPlain = true;
-    st->big = (maxKeys > (double)BIG_LAYOUT_MIN_KEYS || h->hookBigLayout) && big_geometry(h);
+    st->big = (maxKeys > (double)BIG_LAYOUT_MIN_KEYS || h->hookBigLayout) && big_layout_eligible(h->p) && big_geometry(h);
     auto bail = [&](int code, const char* msg) { build_release(h); table_release(h); return fail(h, code, msg); };
     if (hipMalloc(&st->d_cnt, 32) != hipSuccess || hipMemsetAsync(st->d_cnt, 0, 32, h->stream) != hipSuccess) return bail(BBDUK_ERR_NOMEM, "hipMalloc");
     if (st->big) {
@@ -4035,7 +4050,7 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     h->evCount++;
     kp.tile<<<dim3(tgrid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
     {   // reads beyond BBDUK_MAX_READ_LEN: chunked scan, one wave per unit (returns at once unless the pre-pass asked for it)
-        const batch_kernel_t lk = K.mode == BBDUK_MODE_KFILTER ? bbduk_long_kernel<BBDUK_MODE_KFILTER> :
+        const batch_kernel_t lk = K.mode == BBDUK_MODE_KFILTER ? (K.big ? bbduk_long_kernel<BBDUK_MODE_KFILTER, true> : bbduk_long_kernel<BBDUK_MODE_KFILTER>) :
                                   (K.mode == BBDUK_MODE_KTRIM_L ? bbduk_long_kernel<BBDUK_MODE_KTRIM_L> : bbduk_long_kernel<BBDUK_MODE_KTRIM_R>);
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(lk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
         const int64_t units = paired ? n / 2 : n;
