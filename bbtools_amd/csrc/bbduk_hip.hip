@@ -27,6 +27,7 @@
 #include <vector>
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
 #include "../../include/bbduk_gpu.h"
 #include "../../include/bbduk_test_hooks.h"
 #include "bbduk_internal.h"
@@ -449,7 +450,7 @@ template <int MODE, bool SHORT, bool GENERAL>
 __device__ __forceinline__ bool scan_due(const KParams& P, int L, int pairnum, bool present) {
     const int k = P.k;
     bool s = present && P.storedKmers > 0;
-    if (MODE == BBDUK_MODE_KFILTER) s = s && (L >= k);                                     // BBDukProcessorS.java:1535
+    if (MODE == BBDUK_MODE_KFILTER || MODE == BBDUK_MODE_KSPLIT) s = s && (L >= k);        // BBDukProcessorS.java:1535; ksplit :2333, 2338
     else s = s && (L >= max(1, (SHORT && P.useShort) ? min(k, P.mink) : k));               // :1995
     if constexpr (GENERAL) {
         if ((P.skipR1 && pairnum == 0) || (P.skipR2 && pairnum == 1)) s = false;           // :1536, :1996
@@ -1294,7 +1295,10 @@ __device__ __forceinline__ void publish_counters(const unsigned long long* s_acc
     add(BBDUK_READS_IN, rin); add(BBDUK_BASES_IN, bin);
     add(BBDUK_READS_OUTM, rm); add(BBDUK_BASES_OUTM, bm);
     add(BBDUK_READS_OUTU, rin - rm);
-    if (MODE != BBDUK_MODE_KFILTER) {
+    if (MODE == BBDUK_MODE_KSPLIT) {                              // :999-1013, 1431-1443: the split pieces leave through outm
+        add(BBDUK_READS_KTRIMMED, rkt); add(BBDUK_BASES_KTRIMMED, xs);
+        add(BBDUK_BASES_OUTU, bin - xs - bm);
+    } else if (MODE != BBDUK_MODE_KFILTER) {
         add(BBDUK_READS_KTRIMMED, rkt); add(BBDUK_BASES_KTRIMMED, xs);
         add(BBDUK_BASES_OUTU, bin - xs);
     } else {
@@ -1976,6 +1980,7 @@ void bbduk_kscan_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
                         int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
                         int32_t* __restrict__ outLeft, int32_t* __restrict__ outRight, int64_t* __restrict__ counters, const int* __restrict__ longFlag) {
     if (*longFlag & 2) return;                                    // a read beyond these planes: bbduk_kscan_long_kernel takes the batch
+    if (P.waveFirst && *longFlag == 0) return;                    // every read fits a wave's planes: bbduk_wave_kernel<KSPLIT> did the batch
     __shared__ uint32_t s_fwd[PLANE_PAD + KM_CAP_CHUNKS + PLANE_PAD];
     __shared__ uint32_t s_cmp[PLANE_PAD + KM_CAP_CHUNKS + PLANE_PAD];
     __shared__ uint32_t s_nm[KM_CAP_CHUNKS / 2 + 4];
@@ -2366,7 +2371,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
     // (a big-layout map has its fast candidate form in the BIG instantiations only; elsewhere it takes the exact scans)
     const bool candMode = (!GENERAL || P.qhdist == 0) && (BIG || !P.big) &&
                           (MODE == BBDUK_MODE_KTRIM_R || (MODE == BBDUK_MODE_KFILTER && P.maxBadKmers == 0 && P.mkf == 0.f && P.mcf == 0.f));
-    const int lens = max(1, (MODE == BBDUK_MODE_KTRIM_L) ? (P.k - P.mink + 1) : (P.k - P.mink));
+    const int lens = max(1, (MODE == BBDUK_MODE_KTRIM_L || MODE == BBDUK_MODE_KSPLIT) ? (P.k - P.mink + 1) : (P.k - P.mink));
     const int rpp = max(1, 64 / lens);
     const int sslot = lane / lens, st = lane - sslot * lens;
 
@@ -2407,6 +2412,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
         const int vStart = span_start<GENERAL>(P, vL), vStop = span_stop<GENERAL>(P, vL);
         // raw scan facts of my read, filled in by v_writelane as the pairs are scanned
         int vFound = 0, vFirst = BIGLOC, vLast = -1, vRef = -1, vSFl = -1, vSLl = -1;
+        int vSide = 0;                                            // where vFound comes from: 0 main scan, 1 / 2 short k-mers of the right / left end
         int vCSlot = -1; uint32_t vCKeyLo = 0, vCKeyHi = 0;       // candidate mode: my read's first unverified match
         uint32_t vCWord = 0;                                      // big layout: its tag word (vCSlot = way)
         int vThr = P.maxBadKmers;                                 // kfilter: my read's threshold (mkf: filled in when its pair is scanned)
@@ -2579,65 +2585,54 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                 }
             }
             // ---- short k-mers (:2034-2103) for the reads of [s,e) whose main scan found nothing, several reads per
-            // pass: worker lane w looks up length mink+st of the read in slot sslot (lens lengths per read).
+            // pass: worker lane w looks up length mink+st of the read in slot sslot (lens lengths per read).  One pass serves one END
+            // of the reads (LEFT: ktrim=l, :2037-2069; right: ktrim=r, :2072-2102); ksplit takes the right end first and the left end for
+            // the reads that still have nothing (:2388-2474).
             if constexpr (MODE != BBDUK_MODE_KFILTER && SHORT) {
-                if (P.useShort && !TSW(P, 4)) {
-                    const bool need = mine && vScan && vFound == 0 && lane >= s && lane < e;
+                auto short_pass = [&](auto leftTag, const bool need, const int side) {
+                    constexpr bool LEFT = decltype(leftTag)::value;
                     uint64_t needM = __ballot(need);
-                    if (needM) {
-                        const int rank = __popcll(needM & ((1ULL << lane) - 1ULL));
-                        if (need) sel[rank] = (uint8_t)lane;   // compact list of the reads that take part
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        const int nneed = __popcll(needM);
-                        const int vBase0 = origin + rel;
-                        for (int pb = 0; pb < nneed; pb += rpp) {
-                            const int q = pb + sslot;
-                            const bool have = sslot < rpp && q < nneed;
-                            const int j = have ? sel[q] : 0;   // the read this worker lane serves
-                            int jb, jstart, jstop;
-                            if constexpr (!GENERAL) {                   // start is 0 here: one shuffle carries base0 (< 2^16) and stop
-                                const int pk = __shfl(vBase0 | (vStop << 16), j);
-                                jb = pk & 0xFFFF; jstart = 0; jstop = (int)((unsigned)pk >> 16);
-                            } else { jb = __shfl(vBase0, j); jstart = __shfl(vStart, j); jstop = __shfl(vStop, j); }
-                            const int Ls = P.mink + st;
-                            uint64_t kmer = 0, rk = 0; bool act; int Lc;
-                            if constexpr (!GENERAL) {                  // unpredicated form: inactive lanes cut a 1-base window of read j
-                                int sref;
-                                if (MODE == BBDUK_MODE_KTRIM_L) {
-                                    const int Lmax = min(P.k, jstop) - jstart;
-                                    act = have && Ls <= Lmax; Lc = act ? Ls : 1;
-                                    const uint64_t lm = 1ULL << (2 * Lc);
-                                    kmer = cut64_lds(Q.fwdBits + 2u * (uint32_t)(Q.T - 1 - (jb + jstart + Lc - 1))) & (lm - 1ULL);
-                                    rk   = cut64_lds(Q.cmpBits + 2u * (uint32_t)(jb + jstart)) & (lm - 1ULL);
-                                    sref = short_probe(P, kmer, rk, lm, act);
-                                } else {
-                                    const int Lmax = (jstop >= P.k ? P.k - 1 : jstop);
-                                    act = have && Ls <= Lmax; Lc = act ? Ls : 1;
-                                    const uint64_t lm = 1ULL << (2 * Lc);
-                                    kmer = cut64_lds(Q.fwdBits + 2u * (uint32_t)(Q.T - 1 - (jb + jstop - 1))) & (lm - 1ULL);
-                                    rk   = cut64_lds(Q.cmpBits + 2u * (uint32_t)(jb + max(jstop - Lc, 0))) & (lm - 1ULL);
-                                    sref = short_probe(P, kmer, rk, lm, act);
-                                }
-                                uint64_t hm = __ballot(sref != -1);
-                                while (hm) {                            // rare: some read has a short hit
-                                    const int l0 = __ffsll((unsigned long long)hm) - 1;
-                                    const int slot = l0 / lens;
-                                    const uint64_t seg = (hm >> (slot * lens)) & ((1ULL << lens) - 1ULL);
-                                    const int fl = __ffsll((unsigned long long)seg) - 1, ll = 63 - __clzll((long long)seg);
-                                    const int jr = sel[pb + slot];
-                                    const int r1 = __builtin_amdgcn_readlane(sref, slot * lens + fl);   // first hit in scan order = shortest
-                                    const int jru = __builtin_amdgcn_readfirstlane(jr);
-                                    if (lane == jru) { vRef = r1; vFound = __popcll(seg); vSFl = fl; vSLl = ll; }
-                                    hm &= ~(((1ULL << lens) - 1ULL) << (slot * lens));
-                                }
-                                continue;
+                    if (!needM) return;
+                    const int rank = __popcll(needM & ((1ULL << lane) - 1ULL));
+                    if (need) sel[rank] = (uint8_t)lane;   // compact list of the reads that take part
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const int nneed = __popcll(needM);
+                    const int vBase0 = origin + rel;
+                    for (int pb = 0; pb < nneed; pb += rpp) {
+                        const int q = pb + sslot;
+                        const bool have = sslot < rpp && q < nneed;
+                        const int j = have ? sel[q] : 0;   // the read this worker lane serves
+                        int jb, jstart, jstop;
+                        if constexpr (!GENERAL) {                   // start is 0 here: one shuffle carries base0 (< 2^16) and stop
+                            const int pk = __shfl(vBase0 | (vStop << 16), j);
+                            jb = pk & 0xFFFF; jstart = 0; jstop = (int)((unsigned)pk >> 16);
+                        } else { jb = __shfl(vBase0, j); jstart = __shfl(vStart, j); jstop = __shfl(vStop, j); }
+                        const int Ls = P.mink + st;
+                        uint64_t kmer = 0, rk = 0; bool act; int Lc;
+                        int sref;
+                        if constexpr (!GENERAL) {                  // unpredicated form: inactive lanes cut a 1-base window of read j
+                            if (LEFT) {
+                                const int Lmax = min(P.k, jstop) - jstart;
+                                act = have && Ls <= Lmax; Lc = act ? Ls : 1;
+                                const uint64_t lm = 1ULL << (2 * Lc);
+                                kmer = cut64_lds(Q.fwdBits + 2u * (uint32_t)(Q.T - 1 - (jb + jstart + Lc - 1))) & (lm - 1ULL);
+                                rk   = cut64_lds(Q.cmpBits + 2u * (uint32_t)(jb + jstart)) & (lm - 1ULL);
+                                sref = short_probe(P, kmer, rk, lm, act);
+                            } else {
+                                const int Lmax = (jstop >= P.k ? P.k - 1 : jstop);
+                                act = have && Ls <= Lmax; Lc = act ? Ls : 1;
+                                const uint64_t lm = 1ULL << (2 * Lc);
+                                kmer = cut64_lds(Q.fwdBits + 2u * (uint32_t)(Q.T - 1 - (jb + jstop - 1))) & (lm - 1ULL);
+                                rk   = cut64_lds(Q.cmpBits + 2u * (uint32_t)(jb + max(jstop - Lc, 0))) & (lm - 1ULL);
+                                sref = short_probe(P, kmer, rk, lm, act);
                             }
-                            if (MODE == BBDUK_MODE_KTRIM_L) {
+                        } else {
+                            if (LEFT) {
                                 const int Lmax = min(P.k, jstop) - jstart;         // lengths 1..Lmax, i = start+Ls-1
                                 act = have && Ls <= Lmax;
-                                if constexpr (GENERAL) { if (P.qskip > 1) act = act && ((jstart + Ls - 1) % P.qskip) == 0; }
+                                if (P.qskip > 1) act = act && ((jstart + Ls - 1) % P.qskip) == 0;
                                 Lc = act ? Ls : 1;
                                 if (act) {
                                     kmer = extract2(Q.fwd, Q.T - 1 - (jb + jstart + Lc - 1), Lc) & P.mask;
@@ -2646,28 +2641,36 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                             } else {
                                 const int Lmax = (jstop >= P.k ? P.k - 1 : jstop);  // lengths 1..Lmax, i = stop-Ls
                                 act = have && Ls <= Lmax;
-                                if constexpr (GENERAL) { if (P.qskip > 1) act = act && ((jstop - Ls) % P.qskip) == 0; }
+                                if (P.qskip > 1) act = act && ((jstop - Ls) % P.qskip) == 0;
                                 Lc = act ? Ls : 1;
                                 if (act) {
                                     kmer = extract2(Q.fwd, Q.T - 1 - (jb + jstop - 1), Lc);          // base stop-1 in bits 0-1
                                     rk   = extract2(Q.cmp, jb + jstop - Lc, Lc) & P.mask;            // base i in bits 0-1
                                 }
                             }
-                            const int sref = lookup<GENERAL>(P, Q.filt, kmer, rk, 1ULL << (2 * Lc), Lc, P.qhdist2, act);
-                            uint64_t hm = __ballot(sref != -1);
-                            while (hm) {                                // rare: some read has a short hit
-                                const int l0 = __ffsll((unsigned long long)hm) - 1;
-                                const int slot = l0 / lens;
-                                const uint64_t seg = (hm >> (slot * lens)) & ((1ULL << lens) - 1ULL);
-                                const int fl = __ffsll((unsigned long long)seg) - 1, ll = 63 - __clzll((long long)seg);
-                                const int jr = sel[pb + slot];
-                                const int r1 = __builtin_amdgcn_readlane(sref, slot * lens + fl);   // first hit in scan order = shortest
-                                const int jru = __builtin_amdgcn_readfirstlane(jr);
-                                if (lane == jru) { vRef = r1; vFound = __popcll(seg); vSFl = fl; vSLl = ll; }
-                                hm &= ~(((1ULL << lens) - 1ULL) << (slot * lens));
-                            }
+                            sref = lookup<GENERAL>(P, Q.filt, kmer, rk, 1ULL << (2 * Lc), Lc, P.qhdist2, act);
+                        }
+                        uint64_t hm = __ballot(sref != -1);
+                        while (hm) {                                // rare: some read has a short hit
+                            const int l0 = __ffsll((unsigned long long)hm) - 1;
+                            const int slot = l0 / lens;
+                            const uint64_t seg = (hm >> (slot * lens)) & ((1ULL << lens) - 1ULL);
+                            const int fl = __ffsll((unsigned long long)seg) - 1, ll = 63 - __clzll((long long)seg);
+                            const int jr = sel[pb + slot];
+                            const int r1 = __builtin_amdgcn_readlane(sref, slot * lens + fl);   // first hit in scan order = shortest
+                            const int jru = __builtin_amdgcn_readfirstlane(jr);
+                            if (lane == jru) { vRef = r1; vFound = __popcll(seg); vSFl = fl; vSLl = ll; vSide = side; }
+                            hm &= ~(((1ULL << lens) - 1ULL) << (slot * lens));
                         }
                     }
+                };
+                if (P.useShort && !TSW(P, 4)) {
+                    const bool need = mine && vScan && vFound == 0 && lane >= s && lane < e;
+                    if constexpr (MODE == BBDUK_MODE_KSPLIT) {
+                        short_pass(std::false_type{}, need, 1);
+                        short_pass(std::true_type{}, mine && vScan && vFound == 0 && lane >= s && lane < e, 2);
+                    } else if constexpr (MODE == BBDUK_MODE_KTRIM_L) short_pass(std::true_type{}, need, 2);
+                    else short_pass(std::false_type{}, need, 1);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // scans done before the planes are overwritten
@@ -2678,14 +2681,45 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
         if (TSW(P, 7)) continue;                                 // experiment: no decide stage, no outputs
         // ---- finish, data-parallel: lane j turns read j's scan facts into outputs, pair logic via the neighbour lane
         int a, newLen, ref; bool hit;
+        bool d = false, remove = false;
+        int id = -1;
+        if constexpr (MODE == BBDUK_MODE_KSPLIT) {
+            // ksplit (:2332-2506, unpaired): the span of the main hits, else of the right end's short k-mers, else of the left end's
+            // (vSide); then :2485-2498 -- trim at an end, or cut the span out and send the two pieces to outm as a pair
+            const int tp = P.trimPad, k = P.k, L = vL;
+            const bool any = mine && vScan && vFound > 0;
+            int leftmost = 0x7FFFFFFF, rightmost = -1;
+            if (vSide == 0) { leftmost = max(0, vFirst - (k - 1 - tp)); rightmost = vLast + tp; }
+            else if (vSide == 1) { leftmost = max(0, (vStop - (P.mink + vSLl)) - tp); rightmost = L - 1; }
+            else { leftmost = 0; rightmost = (vStart + (P.mink + vSLl) - 1) + tp; }
+            int npl = L, split = 0;
+            if (any) {
+                int n1 = L;
+                if (leftmost == 0) { trim_by_amount(L, rightmost + 1, 0, 1, n1); npl = n1; }                        // :2485-2487
+                else if (rightmost == L - 1) { trim_by_amount(L, 0, L - leftmost, 1, n1); npl = n1; }               // :2488-2490
+                else {                                                                                                // :2491-2498
+                    const int n2 = (L - 1) - (rightmost + 1);   // subRead(rightmost+1, length-1): the copy excludes index length-1
+                    trim_by_amount(L, 0, L - leftmost, 1, n1);
+                    npl = n1 + n2; split = 1;
+                }
+            }
+            a = any ? L - npl : 0; newLen = npl; hit = any; ref = vRef;
+            if (hit) id = ref_to_id(P, ref);
+            remove = split != 0;                                    // remove=(r1.mate!=null): the two pieces go to outm together
+            if (mine) {
+                outA[r0 + lane] = a; outId[r0 + lane] = id;
+                outFlags[r0 + lane] = (uint8_t)(remove ? BBDUK_FLAG_REMOVED : 0);
+                P.outLeft[r0 + lane] = any ? leftmost : -1; P.outRight[r0 + lane] = any ? rightmost : -1;
+                vRkt += a > 0 ? 1u : 0u; vXs += (unsigned)a;
+                if (remove) { vRm += 1; vBm += (unsigned)npl; }
+            }
+        } else {
         finish_read<MODE>(P, vL, vStart, vStop, vFound, vFirst, vLast, vSFl, vSLl, vRef, a, newLen, ref, hit);
         hit = hit && mine && vScan;
         if (!(mine && vScan)) { a = 0; newLen = vL; }
-        int id = -1;
         if (hit) id = ref_to_id(P, ref);
         const float g = (float)vL * P.minLenFraction;              // BBDukProcessorS.java:812-813
         const int minlenR = (int)(g > (float)P.minReadLength ? g : (float)P.minReadLength);
-        bool d = false, remove = false;
         if (P.storedKmers > 0) {
             d = (MODE != BBDUK_MODE_KFILTER) ? (newLen < minlenR) : ((GENERAL && P.mcf > 0.f) ? (a >= vThr) : (a > vThr));
             if (paired) {
@@ -2707,6 +2741,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                 vXs += (unsigned)a + (remove ? (unsigned)newLen : 0u);
             }
             if (remove) { vRm += 1; vBm += (unsigned)newLen; }
+        }
         }
         // scaffold counters (:2111-2119, :1577-1583): group the hit lanes by id, one cache update per distinct id
         uint64_t hm = __ballot(hit);
@@ -3653,11 +3688,13 @@ static Sink make_sink(const bbduk_handle* h, const BuildState* st) {
 }
 // The configurations the big-layout kernels run: plain kfilter (what pick_kernel calls "not general"), no k>31 runs, no findBestMatch.
 // Every other configuration keeps the cache-resident layout at any size it can index (2^29 buckets, ~10^9 keys), as before.
-static bool big_layout_eligible(const bbduk_params& p) {
+static bool params_general(const bbduk_params& p) {               // the same predicate as pick_kernel's, on the boundary struct
     const bool useShort = p.mink > 0 && p.mink < p.k;
-    const bool general = p.qhdist > 0 || p.qhdist2 > 0 || p.restrictLeft > 0 || p.restrictRight > 0 || p.skipR1 || p.skipR2 || !p.rcomp ||
-                         (useShort && p.middleMask != -1) || p.k < 16 || p.qSkip > 1 || p.speed > 0 || p.minKmerFraction != 0.f || p.minCoveredFraction > 0.f;
-    return p.mode == BBDUK_MODE_KFILTER && !general && !(p.kbig > p.k) && !p.findBestMatch;
+    return p.qhdist > 0 || p.qhdist2 > 0 || p.restrictLeft > 0 || p.restrictRight > 0 || p.skipR1 || p.skipR2 || !p.rcomp ||
+           (useShort && p.middleMask != -1) || p.k < 16 || p.qSkip > 1 || p.speed > 0 || p.minKmerFraction != 0.f || p.minCoveredFraction > 0.f;
+}
+static bool big_layout_eligible(const bbduk_params& p) {
+    return p.mode == BBDUK_MODE_KFILTER && !params_general(p) && !(p.kbig > p.k) && !p.findBestMatch;
 }
 #define BIG_LAYOUT_MIN_KEYS (1LL << 25)            // beyond ~3e7 keys the fingerprints alone outgrow L2 + Infinity Cache
 
@@ -3987,9 +4024,21 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     HIP_TRY(h, hipEventRecord(h->ev0[evi], st));
     int* const d_flag = h->d_slowFlag + evi;
     HIP_TRY(h, hipMemsetAsync(d_flag, 0, sizeof(int), st));
-    {   // pre-pass per READ: one beyond the tiled kernel's planes sends the batch to bbduk_kscan_long_kernel
+    {   // pre-pass per READ: one beyond the tiled kernel's planes sends the batch to bbduk_kscan_long_kernel; ksplit: one beyond a
+        // wave's planes (bit 0) sends it to the tiled kernel, else bbduk_wave_kernel<KSPLIT> takes it
         const int sgrid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)h->numCU * 8);
-        bbduk_span_kernel<<<dim3(std::max(sgrid, 1)), dim3(256), 0, st>>>(d_offsets, n, 0, d_flag, (int64_t)(KM_CAP_BASES - 32), (int64_t)(KM_CAP_BASES - 32));
+        bbduk_span_kernel<<<dim3(std::max(sgrid, 1)), dim3(256), 0, st>>>(d_offsets, n, 0, d_flag, red == RED_SPLIT && !packed ? (int64_t)WUNIT_MAX : (int64_t)(KM_CAP_BASES - 32), (int64_t)(KM_CAP_BASES - 32));
+    }
+    if (red == RED_SPLIT && !packed) {                              // the main kernel's shape: wave-autonomous mini-tiles, one lane per read in the finish
+        K.waveFirst = 1; K.outLeft = d_left; K.outRight = d_right;
+        const bool general = params_general(h->p);
+        const batch_kernel_t wk = general ? bbduk_wave_kernel<BBDUK_MODE_KSPLIT, true, true, true, 2>
+                                : (K.forbidNs ? bbduk_wave_kernel<BBDUK_MODE_KSPLIT, true, true, false, 0> : bbduk_wave_kernel<BBDUK_MODE_KSPLIT, true, false, false, 0>);
+        const size_t waveLds = dynLds + WAVE_LDS_BYTES;
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(wk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)waveLds));
+        const int64_t nmt = (n + MT_READS - 1) / MT_READS;
+        const int wgrid = (int)std::min<int64_t>((nmt + NWAVES - 1) / NWAVES, (int64_t)h->numCU);
+        wk<<<dim3(std::max(wgrid, 1)), dim3(BLOCK_THREADS), waveLds, st>>>(K, d_bases, d_offsets, n, total_bases, 0, d_a, d_id, d_fl, d_counters, d_flag);
     }
     fn<<<dim3(grid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_left, d_right, d_counters, d_flag);
     HIP_TRY(h, hipEventRecord(h->ev1[evi], st));
