@@ -547,7 +547,10 @@ __device__ __forceinline__ void win_init(const KParams& P, const Planes& Q, cons
 // kmer / rkmer of the windows ending at the ADJACENT positions i and i+1 of read W (lane-varying i); ok=false: no
 // lookup due.  Plain reads (no reset, no cut): one (k+1)-symbol cut per plane serves both positions (k+1 <= 32 symbols
 // fit the 64-bit cut); the planes are padded, so no clamping -- out-of-read lanes are simply not ok.
-template <bool FORBIDN, bool GENERAL>
+// SPAN (specialised kernels of ktrim=rl): the scan span may start inside the read.  The reference starts its rolling k-mer at `start`, so
+// the first k-1 windows of the span hold fewer than k bases -- bases in front of `start` are cut out of both k-mers and such a window is
+// looked up only from minlen2 bases on (:2010-2019 with the loop's own start).
+template <bool FORBIDN, bool GENERAL, bool SPAN = false>
 __device__ __forceinline__ void windows2(const KParams& P, const Planes& Q, const ReadWin& W, const int i, const bool on,
                                          uint64_t* kmer, uint64_t* rk, bool* ok, uint64_t* rkRaw = nullptr) {
     const int k = P.k;
@@ -565,13 +568,27 @@ __device__ __forceinline__ void windows2(const KParams& P, const Planes& Q, cons
         ok[0] = on & (i < W.stop);
         ok[1] = on & (i + 1 < W.stop);
         if (rkRaw) { rkRaw[0] = rk[0]; rkRaw[1] = rk[1]; }        // before any reset (big layout: the neighbours' minimizer hashes)
+        int cut[2] = {0, 0};                                      // SPAN: bases of the window that lie in front of the span
+        if constexpr (SPAN) {
+            if (W.start > 0 && __ballot(i - k + 1 < W.start) != 0ULL) {
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int c = min(max(W.start - (i + h - k + 1), 0), k);     // window [i+h-k+1, i+h], span from W.start
+                    cut[h] = c;
+                    kmer[h] &= (1ULL << (2 * (k - c))) - 1ULL;                    // the k-c bases inside the span are the low ones
+                    rk[h] &= ~((1ULL << (2 * c)) - 1ULL);                         // complement of base i+h-k+1+t sits at bits 2t
+                    ok[h] = ok[h] && (k - c) >= P.minlen2;
+                }
+            }
+        }
         if (FORBIDN && P.forbidNs && W.hasN) {                   // the read holds an undefined base somewhere: patch the few windows that see it
             const int nidx = min(W.base0 - k + 1 + i, Q.T);      // bit t <=> base i-k+1+t undefined
             const uint32_t nw = __builtin_amdgcn_alignbit(Q.nm[(nidx >> 5) + 1], Q.nm[nidx >> 5], nidx);
             if (__ballot(nw != 0u) != 0ULL) {
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    const uint32_t nh = (nw >> h) & ((1u << k) - 1u);
+                    uint32_t nh = (nw >> h) & ((1u << k) - 1u);
+                    if constexpr (SPAN) nh &= ~0u << cut[h];     // an undefined base in front of the span does not count
                     if (nh) {
                         const int msb = 31 - __clz(nh);
                         rk[h] &= ~0ULL << (2 * (msb + 1));       // rkmer was reset there; kmer keeps its history
@@ -1014,7 +1031,7 @@ __device__ __forceinline__ int kfilter_threshold(const KParams& P, const Planes&
 }
 
 // firstA >= 0 (bbduk_long_kernel): read A is scanned in chunks; this call resumes at position firstA with A.found hits so far.
-template <int MODE, bool FORBIDN, bool GENERAL, bool BIG = false>
+template <int MODE, bool FORBIDN, bool GENERAL, bool BIG = false, bool SPAN = false>
 __device__ __forceinline__ void main_scan_pair(const KParams& P, const Planes& Q, ReadScan& A, ReadScan& B, const int lane, const int firstA = -1) {
     ReadWin WA, WB;
     win_init<FORBIDN, GENERAL>(P, Q, A, WA, lane);
@@ -1024,8 +1041,8 @@ __device__ __forceinline__ void main_scan_pair(const KParams& P, const Planes& Q
     bool onA = WA.on, onB = WB.on;
     while (onA || onB) {
         uint64_t kmer[4], rk[4]; bool ok[4]; int id[4];
-        windows2<FORBIDN, GENERAL>(P, Q, WA, ibA + 2 * lane, onA, kmer, rk, ok);
-        windows2<FORBIDN, GENERAL>(P, Q, WB, ibB + 2 * lane, onB, kmer + 2, rk + 2, ok + 2);
+        windows2<FORBIDN, GENERAL, SPAN>(P, Q, WA, ibA + 2 * lane, onA, kmer, rk, ok);
+        windows2<FORBIDN, GENERAL, SPAN>(P, Q, WB, ibB + 2 * lane, onB, kmer + 2, rk + 2, ok + 2);
         lookup4<GENERAL, BIG>(P, Q.filt, kmer, rk, ok, id);
         const uint64_t m0 = __ballot(id[0] != -1), m1 = __ballot(id[1] != -1), m2 = __ballot(id[2] != -1), m3 = __ballot(id[3] != -1);
         if (onA) {
@@ -1053,7 +1070,7 @@ __device__ __forceinline__ void main_scan_pair(const KParams& P, const Planes& Q
 // Candidate form of the pair scan (ktrim=r, kfilter with maxbadkmers=0: only the first hit of a read matters): stop
 // at the first fingerprint match of each read WITHOUT fetching its key; the caller verifies the candidates of a whole
 // sub-tile in one overlapped batch (one lane per read) and falls back to main_scan_pair for the rare impostor.
-template <bool FORBIDN, bool GENERAL, bool NOMM, bool BIG = false>
+template <bool FORBIDN, bool GENERAL, bool NOMM, bool BIG = false, bool SPAN = false>
 __device__ __forceinline__ void main_scan_pair_cand(const KParams& P, const Planes& Q, ReadScan& A, ReadScan& B, const int lane, const int firstA = -1) {
     ReadWin WA, WB;
     win_init<FORBIDN, GENERAL, BIG>(P, Q, A, WA, lane);
@@ -1066,11 +1083,11 @@ __device__ __forceinline__ void main_scan_pair_cand(const KParams& P, const Plan
     // Lanes past a read's end look up whatever lies behind it in the planes.  When every window of the read is plain
     // nothing masks them: positions grow with the lane, so a first candidate at a position >= stop means the read has
     // none.  Reads with cut or reset windows (restrictRight, an undefined base) mask their ballots with `ok` instead.
-    const bool plainA = WA.full && !((FORBIDN || BIG) && WA.hasN), plainB = WB.full && !((FORBIDN || BIG) && WB.hasN);
+    const bool plainA = WA.full && !((FORBIDN || BIG) && WA.hasN) && !(SPAN && WA.start > 0), plainB = WB.full && !((FORBIDN || BIG) && WB.hasN) && !(SPAN && WB.start > 0);
     while (onA || onB) {
         uint64_t kmer[4], rk[4], rkRaw[4]; bool ok[4]; int ref[4]; Cand4 C;
-        windows2<FORBIDN, GENERAL>(P, Q, WA, ibA + 2 * lane, onA, kmer, rk, ok, BIG ? rkRaw : nullptr);
-        windows2<FORBIDN, GENERAL>(P, Q, WB, ibB + 2 * lane, onB, kmer + 2, rk + 2, ok + 2, BIG ? rkRaw + 2 : nullptr);
+        windows2<FORBIDN, GENERAL, SPAN>(P, Q, WA, ibA + 2 * lane, onA, kmer, rk, ok, BIG ? rkRaw : nullptr);
+        windows2<FORBIDN, GENERAL, SPAN>(P, Q, WB, ibB + 2 * lane, onB, kmer + 2, rk + 2, ok + 2, BIG ? rkRaw + 2 : nullptr);
 #ifdef BBDUK_TIMING_SWITCHES
         if (TSW(P, 8)) {                                             // experiment: 16 extra dependent-free VALU ops per block
             uint32_t z0 = (uint32_t)kmer[0], z1 = (uint32_t)kmer[1], z2 = (uint32_t)kmer[2], z3 = (uint32_t)kmer[3];
@@ -2176,6 +2193,7 @@ void bbduk_ktrimtips_kernel(const KParams P, const uint8_t* __restrict__ bases, 
                             int32_t* __restrict__ outRight, int32_t* __restrict__ outLeft, int32_t* __restrict__ outId,
                             uint8_t* __restrict__ outFlags, int64_t* __restrict__ counters, const int* __restrict__ longFlag) {
     if (*longFlag & 2) return;                                    // a read beyond these planes: bbduk_long_tips_kernel takes the batch
+    if (P.waveFirst && *longFlag == 0) return;                    // every unit fits a wave's planes: bbduk_wave_kernel<KTRIM_TIPS> did the batch
     __shared__ uint32_t s_fwd[PLANE_PAD + KM_CAP_CHUNKS + PLANE_PAD];
     __shared__ uint32_t s_cmp[PLANE_PAD + KM_CAP_CHUNKS + PLANE_PAD];
     __shared__ uint32_t s_nm[KM_CAP_CHUNKS / 2 + 4];
@@ -2371,7 +2389,8 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
     // (a big-layout map has its fast candidate form in the BIG instantiations only; elsewhere it takes the exact scans)
     const bool candMode = (!GENERAL || P.qhdist == 0) && (BIG || !P.big) &&
                           (MODE == BBDUK_MODE_KTRIM_R || (MODE == BBDUK_MODE_KFILTER && P.maxBadKmers == 0 && P.mkf == 0.f && P.mcf == 0.f));
-    const int lens = max(1, (MODE == BBDUK_MODE_KTRIM_L || MODE == BBDUK_MODE_KSPLIT) ? (P.k - P.mink + 1) : (P.k - P.mink));
+    constexpr bool TIPS = MODE == BBDUK_MODE_KTRIM_TIPS;          // ktrim=rl: a right pass over [mid, L), then a left pass over [0, mid+k-1) of what is left (:1813-1826)
+    const int lens = max(1, (MODE == BBDUK_MODE_KTRIM_L || MODE == BBDUK_MODE_KSPLIT || TIPS) ? (P.k - P.mink + 1) : (P.k - P.mink));
     const int rpp = max(1, 64 / lens);
     const int sslot = lane / lens, st = lane - sslot * lens;
 
@@ -2404,12 +2423,21 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
         const int relEnd = __builtin_amdgcn_readlane(rel, cnt);
         sIn += (unsigned long long)cnt; sBin += (unsigned long long)relEnd;
         // per-lane view of "my read" (lane j < cnt)
-        const int vL = __shfl_down(rel, 1) - rel;                  // length of read j
+        int vL = __shfl_down(rel, 1) - rel;                        // length of read j (ktrim=rl: as the right pass left it, in the left pass)
+        const int vL0 = vL;
         const bool mine = lane < cnt;
         const int vPairnum = paired ? (lane & 1) : 0;
-        const bool vScan = scan_due<MODE, SHORT, GENERAL>(P, vL, vPairnum, mine);
-        const uint64_t scanMask = __ballot(vScan);
-        const int vStart = span_start<GENERAL>(P, vL), vStop = span_stop<GENERAL>(P, vL);
+        bool vScan; int vStart, vStop;
+        const int vMid = vL0 / 2 - (P.k - 1) / 2;                   // :1815
+        if constexpr (TIPS) {
+            vScan = scan_due<BBDUK_MODE_KTRIM_R, SHORT, GENERAL>(P, vL, vPairnum, mine);
+            vStart = max(0, (!GENERAL || P.restrictRight < 1) ? vMid : vL - P.restrictRight); vStop = vL;       // :1817-1820
+        } else {
+            vScan = scan_due<MODE, SHORT, GENERAL>(P, vL, vPairnum, mine);
+            vStart = span_start<GENERAL>(P, vL); vStop = span_stop<GENERAL>(P, vL);
+        }
+        uint64_t scanMask = __ballot(vScan);
+        int tXr = 0, tIdr = -1, tHitLen = 0;                        // ktrim=rl: what the right pass of my read gave (amount, scaffold, length it was credited with)
         // raw scan facts of my read, filled in by v_writelane as the pairs are scanned
         int vFound = 0, vFirst = BIGLOC, vLast = -1, vRef = -1, vSFl = -1, vSLl = -1;
         int vSide = 0;                                            // where vFound comes from: 0 main scan, 1 / 2 short k-mers of the right / left end
@@ -2451,6 +2479,23 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
             Planes Q; Q.fwd = wf + PLANE_PAD; Q.cmp = wc + PLANE_PAD; Q.nm = wn; Q.filt = s_filt; Q.T = nchunks * 16;
             Q.fwdBits = lds_bits_of(Q.fwd); Q.cmpBits = lds_bits_of(Q.cmp);
             const int origin = lead - rel_s;                        // plane index of a base = origin + (its offset in the mini-tile)
+          for (int pass = 0; pass < (TIPS ? 2 : 1); pass++) {
+            if constexpr (TIPS) {
+                if (pass == 1) {                                    // the right pass is over for the reads of [s,e): its outcome, then the left pass's span
+                    int a0, n0, ref0; bool hit0;
+                    finish_read<BBDUK_MODE_KTRIM_R>(P, vL, vStart, vStop, vFound, vFirst, vLast, vSFl, vSLl, vRef, a0, n0, ref0, hit0);
+                    if (lane >= s && lane < e) {
+                        const bool sc = mine && vScan;
+                        tXr = sc ? a0 : 0; tIdr = (sc && hit0) ? ref0 : -1; tHitLen = vL;
+                        vL = sc ? n0 : vL;
+                        vStart = 0; vStop = min(vL, (!GENERAL || P.restrictLeft < 1) ? vMid + P.k - 1 : P.restrictLeft);        // :1821-1824
+                        vScan = scan_due<BBDUK_MODE_KTRIM_L, SHORT, GENERAL>(P, vL, vPairnum, mine);
+                        vFound = 0; vFirst = BIGLOC; vLast = -1; vRef = -1; vSFl = -1; vSLl = -1; vSide = 0; vCSlot = -1;
+                    }
+                    scanMask = __ballot(vScan);
+                }
+            }
+            const bool candP = TIPS ? (pass == 0 && (!GENERAL || P.qhdist == 0)) : candMode;
             uint64_t nMask = 0;                                     // reads of [s,e) with an undefined base inside their span
             if ((FORBIDN && P.forbidNs) || BIG) {                   // lane j looks at read j's words of the undefined-plane
                 uint32_t acc = 0;
@@ -2479,10 +2524,14 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                 Bz.scan = hasB && ((scanMask >> (ra + 1)) & 1);
                 A.start = span_start<GENERAL>(P, A.L); A.stop = span_stop<GENERAL>(P, A.L);
                 Bz.start = span_start<GENERAL>(P, Bz.L); Bz.stop = span_stop<GENERAL>(P, Bz.L);
+                if constexpr (TIPS) {
+                    A.start = __builtin_amdgcn_readlane(vStart, ra); A.stop = __builtin_amdgcn_readlane(vStop, ra);
+                    Bz.start = hasB ? __builtin_amdgcn_readlane(vStart, ra + 1) : 0; Bz.stop = hasB ? __builtin_amdgcn_readlane(vStop, ra + 1) : 0;
+                }
                 A.found = 0; A.iFirst = BIGLOC; A.iLast = -1; A.ref = -1; A.shortFl = -1; A.shortLl = -1;
                 Bz.found = 0; Bz.iFirst = BIGLOC; Bz.iLast = -1; Bz.ref = -1; Bz.shortFl = -1; Bz.shortLl = -1;
-                if (candMode) {
-                    if (!TSW(P, 3)) main_scan_pair_cand<FORBIDN, GENERAL, SHORT && !GENERAL, BIG>(P, Q, A, Bz, lane); else { A.candSlot = -1; Bz.candSlot = -1; }
+                if (candP) {
+                    if (!TSW(P, 3)) main_scan_pair_cand<FORBIDN, GENERAL, SHORT && !GENERAL && !TIPS, BIG, TIPS>(P, Q, A, Bz, lane); else { A.candSlot = -1; Bz.candSlot = -1; }
                     if (A.candSlot != -1) {
                         vCSlot = (lane == ra) ? A.candSlot : vCSlot; vFirst = (lane == ra) ? A.iFirst : vFirst;
                         vCKeyLo = (lane == ra) ? A.candKeyLo : vCKeyLo; vCKeyHi = (lane == ra) ? A.candKeyHi : vCKeyHi;
@@ -2502,7 +2551,10 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                         vThr = (lane == ra) ? A.maxBad : ((lane == ra + 1) ? Bz.maxBad : vThr);
                     }
                 }
-                main_scan_pair<MODE, FORBIDN, GENERAL, BIG>(P, Q, A, Bz, lane);
+                if constexpr (TIPS) {
+                    if (pass == 0) main_scan_pair<BBDUK_MODE_KTRIM_R, FORBIDN, GENERAL, false, true>(P, Q, A, Bz, lane);
+                    else main_scan_pair<BBDUK_MODE_KTRIM_L, FORBIDN, GENERAL, false, true>(P, Q, A, Bz, lane);
+                } else main_scan_pair<MODE, FORBIDN, GENERAL, BIG>(P, Q, A, Bz, lane);
                 if (A.found) {                                      // hand the facts to lane ra (most reads have none)
                     vFound = (lane == ra) ? A.found : vFound; vFirst = (lane == ra) ? A.iFirst : vFirst;
                     vLast = (lane == ra) ? A.iLast : vLast;   vRef = (lane == ra) ? A.ref : vRef;
@@ -2514,7 +2566,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                     vSFl = (lane == ra + 1) ? Bz.shortFl : vSFl;   vSLl = (lane == ra + 1) ? Bz.shortLl : vSLl;
                 }
             }
-            if (candMode) {
+            if (candP) {
                 // ---- verify the sub-tile's candidates together: lane j fetches key+id of read j's candidate
                 const bool inSub = lane >= s && lane < e;
                 bool fb = false;
@@ -2576,9 +2628,14 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                     Bz.scan = hasB && ((scanMask >> (ra + 1)) & 1);
                     A.start = span_start<GENERAL>(P, A.L); A.stop = span_stop<GENERAL>(P, A.L);
                     Bz.start = span_start<GENERAL>(P, Bz.L); Bz.stop = span_stop<GENERAL>(P, Bz.L);
+                    if constexpr (TIPS) {
+                        A.start = __builtin_amdgcn_readlane(vStart, ra); A.stop = __builtin_amdgcn_readlane(vStop, ra);
+                        Bz.start = hasB ? __builtin_amdgcn_readlane(vStart, ra + 1) : 0; Bz.stop = hasB ? __builtin_amdgcn_readlane(vStop, ra + 1) : 0;
+                    }
                     A.found = 0; A.iFirst = BIGLOC; A.iLast = -1; A.ref = -1; A.shortFl = -1; A.shortLl = -1;
                     Bz.found = 0; Bz.iFirst = BIGLOC; Bz.iLast = -1; Bz.ref = -1; Bz.shortFl = -1; Bz.shortLl = -1;
-                    main_scan_pair<MODE, FORBIDN, GENERAL, BIG>(P, Q, A, Bz, lane);
+                    if constexpr (TIPS) main_scan_pair<BBDUK_MODE_KTRIM_R, FORBIDN, GENERAL, false, true>(P, Q, A, Bz, lane);
+                    else main_scan_pair<MODE, FORBIDN, GENERAL, BIG>(P, Q, A, Bz, lane);
                     vFound = (lane == ra) ? A.found : vFound; vFirst = (lane == ra) ? A.iFirst : vFirst; vRef = (lane == ra) ? A.ref : vRef;
                     if (hasB) { vFound = (lane == ra + 1) ? Bz.found : vFound; vFirst = (lane == ra + 1) ? Bz.iFirst : vFirst; vRef = (lane == ra + 1) ? Bz.ref : vRef; }
                     fbm &= ~(3ULL << ra);
@@ -2669,10 +2726,12 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                     if constexpr (MODE == BBDUK_MODE_KSPLIT) {
                         short_pass(std::false_type{}, need, 1);
                         short_pass(std::true_type{}, mine && vScan && vFound == 0 && lane >= s && lane < e, 2);
-                    } else if constexpr (MODE == BBDUK_MODE_KTRIM_L) short_pass(std::true_type{}, need, 2);
+                    } else if constexpr (TIPS) { if (pass == 0) short_pass(std::false_type{}, need, 1); else short_pass(std::true_type{}, need, 2); }
+                    else if constexpr (MODE == BBDUK_MODE_KTRIM_L) short_pass(std::true_type{}, need, 2);
                     else short_pass(std::false_type{}, need, 1);
                 }
             }
+          }   // pass
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // scans done before the planes are overwritten
             __builtin_amdgcn_wave_barrier();
             s = e;
@@ -2713,6 +2772,39 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                 vRkt += a > 0 ? 1u : 0u; vXs += (unsigned)a;
                 if (remove) { vRm += 1; vBm += (unsigned)npl; }
             }
+        } else if constexpr (TIPS) {
+            // ktrim=rl (:954-967, 1009-1033): the left pass's outcome on the read as the right pass left it, then the pair rules on the final
+            // lengths (minlen from the ORIGINAL lengths, :812-813); outA = the right amount, P.outLeft = the left amount
+            int aL, nL; bool hitL;
+            finish_read<BBDUK_MODE_KTRIM_L>(P, vL, vStart, vStop, vFound, vFirst, vLast, vSFl, vSLl, vRef, aL, nL, ref, hitL);
+            const bool scL = mine && vScan;
+            hit = hitL && scL;                                      // (the left pass's credit; the right pass's is tIdr)
+            int xr = tXr; const int xl = scL ? aL : 0;
+            int n1 = scL ? nL : vL;
+            id = tIdr >= 0 ? tIdr : (hit ? ref : -1);
+            const float g = (float)vL0 * P.minLenFraction;
+            const int minlenR = (int)(g > (float)P.minReadLength ? g : (float)P.minReadLength);
+            if (P.storedKmers > 0) {
+                d = n1 < minlenR;
+                if (paired) { const bool dm = __shfl_xor((int)d, 1) != 0; remove = (P.rieb && (d || dm)) || (d && dm); }
+                else remove = d;
+            }
+            bool evened = false;
+            if (P.tpe && paired && P.storedKmers > 0) {             // trimpairsevenly: ktrimRight is set in this mode (:1021-1031)
+                const int xm = __shfl_xor(xr + xl, 1), nm = __shfl_xor(n1, 1);
+                evened = mine && !remove && (xr + xl + xm) > 0 && n1 != nm;
+                if (evened && n1 > nm) xr += trim_by_amount(n1, 0, n1 - nm, 1, n1);
+            }
+            a = xr; newLen = n1;
+            if (mine) {
+                outA[r0 + lane] = xr; P.outLeft[r0 + lane] = xl; outId[r0 + lane] = id;
+                outFlags[r0 + lane] = (uint8_t)((d ? BBDUK_FLAG_DISCARDED : 0) | (remove ? BBDUK_FLAG_REMOVED : 0));
+                if (P.storedKmers > 0) {
+                    vRkt += (remove || evened) ? 1u : ((xr + xl) > 0 ? 1u : 0u);
+                    vXs += (unsigned)(xr + xl) + (remove ? (unsigned)n1 : 0u);
+                }
+                if (remove) { vRm += 1; vBm += (unsigned)n1; }
+            }
         } else {
         finish_read<MODE>(P, vL, vStart, vStop, vFound, vFirst, vLast, vSFl, vSLl, vRef, a, newLen, ref, hit);
         hit = hit && mine && vScan;
@@ -2744,27 +2836,31 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
         }
         }
         // scaffold counters (:2111-2119, :1577-1583): group the hit lanes by id, one cache update per distinct id
-        uint64_t hm = __ballot(hit);
-        while (hm) {
-            const int l0 = __ffsll((unsigned long long)hm) - 1;
-            const int sid = __builtin_amdgcn_readlane(id, l0);
-            const bool same = hit && id == sid;
-            const uint64_t sm = __ballot(same);
-            const int nrd = __popcll(sm), nbs = wave_sum(same ? vL : 0);
-            const uint64_t mt_ = __ballot(lane < SCAF_LANES && scId == sid);
-            if (mt_) { if (lane < SCAF_LANES && scId == sid) { scReads += nrd; scBases += nbs; } }
-            else {
-                if (lane == scNext) {
-                    if (scId > 0) {
-                        atomicAdd((unsigned long long*)&counters[BBDUK_NCOUNTERS + scId], (unsigned long long)scReads);
-                        atomicAdd((unsigned long long*)&counters[BBDUK_NCOUNTERS + P.numScaffolds + scId], (unsigned long long)scBases);
+        auto credit = [&](const bool hit_, const int id_, const int len_) {
+            uint64_t hm = __ballot(hit_);
+            while (hm) {
+                const int l0 = __ffsll((unsigned long long)hm) - 1;
+                const int sid = __builtin_amdgcn_readlane(id_, l0);
+                const bool same = hit_ && id_ == sid;
+                const uint64_t sm = __ballot(same);
+                const int nrd = __popcll(sm), nbs = wave_sum(same ? len_ : 0);
+                const uint64_t mt_ = __ballot(lane < SCAF_LANES && scId == sid);
+                if (mt_) { if (lane < SCAF_LANES && scId == sid) { scReads += nrd; scBases += nbs; } }
+                else {
+                    if (lane == scNext) {
+                        if (scId > 0) {
+                            atomicAdd((unsigned long long*)&counters[BBDUK_NCOUNTERS + scId], (unsigned long long)scReads);
+                            atomicAdd((unsigned long long*)&counters[BBDUK_NCOUNTERS + P.numScaffolds + scId], (unsigned long long)scBases);
+                        }
+                        scId = sid; scReads = nrd; scBases = nbs;
                     }
-                    scId = sid; scReads = nrd; scBases = nbs;
+                    scNext = (scNext + 1) & (SCAF_LANES - 1);
                 }
-                scNext = (scNext + 1) & (SCAF_LANES - 1);
+                hm &= ~sm;
             }
-            hm &= ~sm;
-        }
+        };
+        if constexpr (TIPS) { credit(tIdr >= 0, tIdr, tHitLen); credit(hit, ref, vL); }     // each pass credits its own scaffold (:1817-1824)
+        else credit(hit, id, vL);
     }
     if (lane < SCAF_LANES && scId > 0) {
         atomicAdd((unsigned long long*)&counters[BBDUK_NCOUNTERS + scId], (unsigned long long)scReads);
@@ -2785,7 +2881,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
         }
     }
     __syncthreads();
-    if (tid == 0) publish_counters<MODE>(s_acc, counters);
+    if (tid == 0) publish_counters<MODE == BBDUK_MODE_KTRIM_TIPS ? BBDUK_MODE_KTRIM_R : MODE>(s_acc, counters);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -4297,12 +4393,28 @@ static int launch_tips(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d
     const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
     int* const d_flag = h->d_slowFlag + evi;
     HIP_TRY(h, hipMemsetAsync(d_flag, 0, sizeof(int), st));
-    {   // pre-pass per READ: one beyond the tiled kernel's planes sends the batch to bbduk_long_tips_kernel
+    {   // pre-pass: a unit (pair) beyond a wave's planes (bit 0) sends the batch to the tiled kernel, a READ beyond the tiled kernel's
+        // planes (bit 1) to bbduk_long_tips_kernel; else bbduk_wave_kernel<KTRIM_TIPS> takes it
+        const int64_t units = paired ? n / 2 : n;
+        const int ugrid = (int)std::min<int64_t>((units + 255) / 256, (int64_t)h->numCU * 8);
+        bbduk_span_kernel<<<dim3(std::max(ugrid, 1)), dim3(256), 0, st>>>(d_offsets, n, (int)paired, d_flag, (int64_t)WUNIT_MAX, (int64_t)0x7FFFFFFFFFFFLL);
         const int sgrid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)h->numCU * 8);
-        bbduk_span_kernel<<<dim3(std::max(sgrid, 1)), dim3(256), 0, st>>>(d_offsets, n, 0, d_flag, (int64_t)(KM_CAP_BASES - 32), (int64_t)(KM_CAP_BASES - 32));
+        bbduk_span_kernel<<<dim3(std::max(sgrid, 1)), dim3(256), 0, st>>>(d_offsets, n, 0, d_flag, (int64_t)0x7FFFFFFFFFFFLL, (int64_t)(KM_CAP_BASES - 32));
     }
     if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
     HIP_TRY(h, hipEventRecord(h->ev0[evi], st));
+    {   // the main kernel's shape: wave-autonomous mini-tiles, candidate scan for the right pass, one lane per read in the finish
+        K.waveFirst = 1; K.outLeft = d_l;
+        const bool general = params_general(h->p);
+        const batch_kernel_t wk = general ? bbduk_wave_kernel<BBDUK_MODE_KTRIM_TIPS, true, true, true, 2>
+                                : (packed ? (K.forbidNs ? bbduk_wave_kernel<BBDUK_MODE_KTRIM_TIPS, true, true, false, 1> : bbduk_wave_kernel<BBDUK_MODE_KTRIM_TIPS, true, false, false, 1>)
+                                          : (K.forbidNs ? bbduk_wave_kernel<BBDUK_MODE_KTRIM_TIPS, true, true, false, 0> : bbduk_wave_kernel<BBDUK_MODE_KTRIM_TIPS, true, false, false, 0>));
+        const size_t waveLds = dynLds + WAVE_LDS_BYTES;
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(wk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)waveLds));
+        const int64_t nmt = (n + MT_READS - 1) / MT_READS;
+        const int wgrid = (int)std::min<int64_t>((nmt + NWAVES - 1) / NWAVES, (int64_t)h->numCU);
+        wk<<<dim3(std::max(wgrid, 1)), dim3(BLOCK_THREADS), waveLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_r, d_id, d_fl, d_counters, d_flag);
+    }
     bbduk_ktrimtips_kernel<<<dim3(grid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_r, d_l, d_id, d_fl, d_counters, d_flag);
     HIP_TRY(h, hipEventRecord(h->ev1[evi], st));
     h->evCount++;
