@@ -450,7 +450,7 @@ template <int MODE, bool SHORT, bool GENERAL>
 __device__ __forceinline__ bool scan_due(const KParams& P, int L, int pairnum, bool present) {
     const int k = P.k;
     bool s = present && P.storedKmers > 0;
-    if (MODE == BBDUK_MODE_KFILTER || MODE == BBDUK_MODE_KSPLIT) s = s && (L >= k);        // BBDukProcessorS.java:1535; ksplit :2333, 2338
+    if (MODE == BBDUK_MODE_KFILTER || MODE == BBDUK_MODE_KSPLIT || MODE == BBDUK_MODE_KMASK) s = s && (L >= k);   // BBDukProcessorS.java:1535; ksplit :2333, 2338; kmask :2151
     else s = s && (L >= max(1, (SHORT && P.useShort) ? min(k, P.mink) : k));               // :1995
     if constexpr (GENERAL) {
         if ((P.skipR1 && pairnum == 0) || (P.skipR2 && pairnum == 1)) s = false;           // :1536, :1996
@@ -1031,8 +1031,11 @@ __device__ __forceinline__ int kfilter_threshold(const KParams& P, const Planes&
 }
 
 // firstA >= 0 (bbduk_long_kernel): read A is scanned in chunks; this call resumes at position firstA with A.found hits so far.
-template <int MODE, bool FORBIDN, bool GENERAL, bool BIG = false, bool SPAN = false>
-__device__ __forceinline__ void main_scan_pair(const KParams& P, const Planes& Q, ReadScan& A, ReadScan& B, const int lane, const int firstA = -1) {
+// MASK (ktrim=n): every position that matches -- with kmaskfullycovered every position of the span that does NOT -- sets its bit of
+// `hitPlane` (plane coordinates, like the undefined-plane), see bbduk_kmask_kernel.
+template <int MODE, bool FORBIDN, bool GENERAL, bool BIG = false, bool SPAN = false, bool MASK = false>
+__device__ __forceinline__ void main_scan_pair(const KParams& P, const Planes& Q, ReadScan& A, ReadScan& B, const int lane, const int firstA = -1,
+                                               uint32_t* hitPlane = nullptr) {
     ReadWin WA, WB;
     win_init<FORBIDN, GENERAL>(P, Q, A, WA, lane);
     win_init<FORBIDN, GENERAL>(P, Q, B, WB, lane);
@@ -1045,6 +1048,15 @@ __device__ __forceinline__ void main_scan_pair(const KParams& P, const Planes& Q
         windows2<FORBIDN, GENERAL, SPAN>(P, Q, WB, ibB + 2 * lane, onB, kmer + 2, rk + 2, ok + 2);
         lookup4<GENERAL, BIG>(P, Q.filt, kmer, rk, ok, id);
         const uint64_t m0 = __ballot(id[0] != -1), m1 = __ballot(id[1] != -1), m2 = __ballot(id[2] != -1), m3 = __ballot(id[3] != -1);
+        if constexpr (MASK) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const ReadWin& W = q < 2 ? WA : WB;
+                const int i = (q < 2 ? ibA : ibB) + 2 * lane + (q & 1);
+                const bool mark = P.mfc ? ((q < 2 ? onA : onB) && i < W.stop && id[q] == -1) : (id[q] != -1);
+                if (mark) atomicOr(&hitPlane[(W.base0 + i) >> 5], 1u << ((W.base0 + i) & 31));
+            }
+        }
         if (onA) {
             bool ex = false;
             if (m0 | m1) {
@@ -1315,6 +1327,9 @@ __device__ __forceinline__ void publish_counters(const unsigned long long* s_acc
     if (MODE == BBDUK_MODE_KSPLIT) {                              // :999-1013, 1431-1443: the split pieces leave through outm
         add(BBDUK_READS_KTRIMMED, rkt); add(BBDUK_BASES_KTRIMMED, xs);
         add(BBDUK_BASES_OUTU, bin - xs - bm);
+    } else if (MODE == BBDUK_MODE_KMASK) {                        // masking keeps every read's length
+        add(BBDUK_READS_KTRIMMED, rkt); add(BBDUK_BASES_KTRIMMED, xs);
+        add(BBDUK_BASES_OUTU, bin - bm);
     } else if (MODE != BBDUK_MODE_KFILTER) {
         add(BBDUK_READS_KTRIMMED, rkt); add(BBDUK_BASES_KTRIMMED, xs);
         add(BBDUK_BASES_OUTU, bin - xs);
@@ -1683,6 +1698,7 @@ void bbduk_kmask_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
     __shared__ unsigned long long s_acc[6];                       // rkt, basesKTrimmed, readsOutm, basesOutm, readsIn, basesIn
     extern __shared__ uint32_t s_filt[];
 
+    if (P.waveFirst && *longFlag == 0) return;                    // every unit fits a wave's planes: bbduk_wave_kernel<KMASK> did the batch
     const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
     const int k = P.k, tp = P.trimPad;
@@ -2352,6 +2368,12 @@ void bbduk_ktrimtips_kernel(const KParams P, const uint8_t* __restrict__ bases, 
 #define SEL_BYTES    ((MT_READS + 3) & ~3)
 #define WAVE_LDS_BYTES ((2 * NWAVES * WPLANE_WORDS + NWAVES * WNM_WORDS) * 4 + 6 * 8 + NWAVES * SEL_BYTES)   // behind the filter
 #define WUNIT_MAX    (WCAP_BASES - 48)             // longest unit (pair) the wave kernel accepts
+// ktrim=n keeps a fourth per-wave plane (the k-mer end positions that hit); its planes are a little shorter so that all of it still
+// fits behind a 128 KiB filter
+#define WCAP_BASES_KM 2304
+#define WAVE_LDS_BYTES_KM ((2 * NWAVES * (PLANE_PAD + WCAP_BASES_KM / 16 + PLANE_PAD) + 2 * NWAVES * (WCAP_BASES_KM / 32 + 4)) * 4 + 6 * 8 + NWAVES * SEL_BYTES)
+#define WUNIT_MAX_KM (WCAP_BASES_KM - 48)
+static_assert((128 << 10) + WAVE_LDS_BYTES_KM <= (160 << 10), "ktrim=n wave kernel: LDS budget");
 
 // sum of v over the lanes of a wave, returned wave-uniform
 __device__ __forceinline__ int wave_sum(int v) {
@@ -2370,10 +2392,14 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
     // address 0 + offset), which saves an add per lookup.  Behind it: per-wave planes, counters, short-scan lists.
     extern __shared__ uint32_t s_dyn[];
     uint32_t* const s_filt = s_dyn;
+    constexpr bool KMASK = MODE == BBDUK_MODE_KMASK;              // ktrim=n: every hit of the main scan, both ends' short k-mers, a mask per base
+    constexpr int CAPB = KMASK ? WCAP_BASES_KM : WCAP_BASES;      // per-wave plane capacity in bases
+    constexpr int PLW = PLANE_PAD + CAPB / 16 + PLANE_PAD, NMW = CAPB / 32 + 4;
     uint32_t* const s_wfAll = s_dyn + (P.ldsBits ? (1 << (P.ldsBits - 5)) : 0);
-    uint32_t* const s_wcAll = s_wfAll + NWAVES * WPLANE_WORDS;
-    uint32_t* const s_wnAll = s_wcAll + NWAVES * WPLANE_WORDS;
-    unsigned long long* const s_acc = reinterpret_cast<unsigned long long*>(s_wnAll + NWAVES * WNM_WORDS);   // rkt, basesKTrimmed, readsOutm, basesOutm, readsIn, basesIn
+    uint32_t* const s_wcAll = s_wfAll + NWAVES * PLW;
+    uint32_t* const s_wnAll = s_wcAll + NWAVES * PLW;
+    uint32_t* const s_whAll = s_wnAll + NWAVES * NMW;             // ktrim=n: bit p <=> a k-mer ending at plane position p matched
+    unsigned long long* const s_acc = reinterpret_cast<unsigned long long*>(s_whAll + (KMASK ? NWAVES * NMW : 0));   // rkt, basesKTrimmed, readsOutm, basesOutm, readsIn, basesIn
     uint8_t* const s_selAll = reinterpret_cast<uint8_t*>(s_acc + 6);   // short-scan: compacted list of participating reads (lane ids)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
@@ -2390,12 +2416,13 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
     const bool candMode = (!GENERAL || P.qhdist == 0) && (BIG || !P.big) &&
                           (MODE == BBDUK_MODE_KTRIM_R || (MODE == BBDUK_MODE_KFILTER && P.maxBadKmers == 0 && P.mkf == 0.f && P.mcf == 0.f));
     constexpr bool TIPS = MODE == BBDUK_MODE_KTRIM_TIPS;          // ktrim=rl: a right pass over [mid, L), then a left pass over [0, mid+k-1) of what is left (:1813-1826)
-    const int lens = max(1, (MODE == BBDUK_MODE_KTRIM_L || MODE == BBDUK_MODE_KSPLIT || TIPS) ? (P.k - P.mink + 1) : (P.k - P.mink));
+    const int lens = max(1, (MODE == BBDUK_MODE_KTRIM_L || MODE == BBDUK_MODE_KSPLIT || TIPS || KMASK) ? (P.k - P.mink + 1) : (P.k - P.mink));
     const int rpp = max(1, 64 / lens);
     const int sslot = lane / lens, st = lane - sslot * lens;
 
-    uint32_t* const wf = s_wfAll + wave * WPLANE_WORDS; uint32_t* const wc = s_wcAll + wave * WPLANE_WORDS;
-    uint32_t* const wn = s_wnAll + wave * WNM_WORDS;
+    uint32_t* const wf = s_wfAll + wave * PLW; uint32_t* const wc = s_wcAll + wave * PLW;
+    uint32_t* const wn = s_wnAll + wave * NMW;
+    uint32_t* const wh = s_whAll + wave * NMW;
     uint8_t* const sel = s_selAll + wave * SEL_BYTES;
     // scaffold-counter cache: lane w (< SCAF_LANES) owns one (id, reads, bases) entry in registers; a hit is one ballot
     // plus a predicated add, a miss evicts round-robin with two atomics.  The adapter library has ~6 frequent ids:
@@ -2443,13 +2470,16 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
         int vSide = 0;                                            // where vFound comes from: 0 main scan, 1 / 2 short k-mers of the right / left end
         int vCSlot = -1; uint32_t vCKeyLo = 0, vCKeyHi = 0;       // candidate mode: my read's first unverified match
         uint32_t vCWord = 0;                                      // big layout: its tag word (vCSlot = way)
+        // ktrim=n: the lengths of my read's left / right end that matched (bit t <=> length mink+t) with the id of the shortest,
+        // then hits in all, id of the first, masked bases
+        uint32_t kSegL = 0, kSegR = 0; int kIdL = -1, kIdR = -1, kFound = 0, kId0 = -1, kCard = 0;
         int vThr = P.maxBadKmers;                                 // kfilter: my read's threshold (mkf: filled in when its pair is scanned)
         if constexpr (GENERAL && MODE == BBDUK_MODE_KFILTER) { if (P.mcf > 0.f) vThr = (int)ceilf(P.mcf * (float)vL); }
 
         int s = 0;
         while (s < cnt) {
             const int rel_s = __builtin_amdgcn_readlane(rel, s);
-            const uint64_t okm = __ballot(lane > s && lane <= cnt && (rel - rel_s) <= (WCAP_BASES - 32));
+            const uint64_t okm = __ballot(lane > s && lane <= cnt && (rel - rel_s) <= (CAPB - 32));
             int fit = __popcll(okm);
             if (paired) fit &= ~1;
             if (fit == 0) {                                         // cannot happen when the span pre-pass ran
@@ -2472,6 +2502,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                 reinterpret_cast<uint16_t*>(wn)[c] = (uint16_t)(~valid & 0xFFFFu);
             }
             if (lane == 0 && (nchunks & 1)) reinterpret_cast<uint16_t*>(wn)[nchunks] = 0;
+            if constexpr (KMASK) { for (int w = lane; w < NMW; w += 64) wh[w] = 0; }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // LDS is in-order per wave; keep the compiler honest
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -2554,7 +2585,8 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                 if constexpr (TIPS) {
                     if (pass == 0) main_scan_pair<BBDUK_MODE_KTRIM_R, FORBIDN, GENERAL, false, true>(P, Q, A, Bz, lane);
                     else main_scan_pair<BBDUK_MODE_KTRIM_L, FORBIDN, GENERAL, false, true>(P, Q, A, Bz, lane);
-                } else main_scan_pair<MODE, FORBIDN, GENERAL, BIG>(P, Q, A, Bz, lane);
+                } else if constexpr (KMASK) main_scan_pair<BBDUK_MODE_KTRIM_L, FORBIDN, GENERAL, false, false, true>(P, Q, A, Bz, lane, -1, wh);   // hits counted, first id kept, none ends the scan
+                else main_scan_pair<MODE, FORBIDN, GENERAL, BIG>(P, Q, A, Bz, lane);
                 if (A.found) {                                      // hand the facts to lane ra (most reads have none)
                     vFound = (lane == ra) ? A.found : vFound; vFirst = (lane == ra) ? A.iFirst : vFirst;
                     vLast = (lane == ra) ? A.iLast : vLast;   vRef = (lane == ra) ? A.ref : vRef;
@@ -2716,7 +2748,9 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                             const int jr = sel[pb + slot];
                             const int r1 = __builtin_amdgcn_readlane(sref, slot * lens + fl);   // first hit in scan order = shortest
                             const int jru = __builtin_amdgcn_readfirstlane(jr);
-                            if (lane == jru) { vRef = r1; vFound = __popcll(seg); vSFl = fl; vSLl = ll; vSide = side; }
+                            if constexpr (KMASK) {
+                                if (lane == jru) { if (side == 2) { kSegL = (uint32_t)seg; kIdL = r1; } else { kSegR = (uint32_t)seg; kIdR = r1; } }
+                            } else if (lane == jru) { vRef = r1; vFound = __popcll(seg); vSFl = fl; vSLl = ll; vSide = side; }
                             hm &= ~(((1ULL << lens) - 1ULL) << (slot * lens));
                         }
                     }
@@ -2726,9 +2760,69 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                     if constexpr (MODE == BBDUK_MODE_KSPLIT) {
                         short_pass(std::false_type{}, need, 1);
                         short_pass(std::true_type{}, mine && vScan && vFound == 0 && lane >= s && lane < e, 2);
+                    } else if constexpr (KMASK) {                   // both ends, whatever the main scan found (:2200-2290)
+                        const bool both = mine && vScan && lane >= s && lane < e;
+                        short_pass(std::true_type{}, both, 2);
+                        short_pass(std::false_type{}, both, 1);
                     } else if constexpr (TIPS) { if (pass == 0) short_pass(std::false_type{}, need, 1); else short_pass(std::true_type{}, need, 2); }
                     else if constexpr (MODE == BBDUK_MODE_KTRIM_L) short_pass(std::true_type{}, need, 2);
                     else short_pass(std::false_type{}, need, 1);
+                }
+            }
+            if constexpr (KMASK) {
+                // ---- the mask of the sub-tile's reads that met a hit, while their plane of hit positions is still here (:2190, 2236, 2279;
+                // see bbduk_kmask_kernel): the wave takes them one at a time, 64 bases per step
+                const int k = P.k, tp = P.trimPad;
+                const bool inSub = mine && vScan && lane >= s && lane < e;
+                int leftEnd = 0, rightStart = vL;                   // bases [0,leftEnd) and [rightStart,L) are masked by short k-mers
+                if (inSub) {
+                    kFound = vFound + __popc(kSegL) + __popc(kSegR);
+                    kId0 = vFound > 0 ? vRef : (kSegL ? kIdL : kIdR);                       // main scan, then left hits, shortest first
+                    if (!P.mfc) {
+                        if (kSegL) { const int iMax = vStart + (P.mink + (31 - __clz(kSegL))) - 1; leftEnd = max(0, min(vL, iMax + tp + 1)); }
+                        if (kSegR) { const int iMin = vStop - (P.mink + (31 - __clz(kSegR))); rightStart = min(vL, max(0, iMin - tp)); }
+                    } else if (P.useShort) {
+                        const int LmaxL = min(k, vStop) - vStart, LmaxR = (vStop >= k ? k - 1 : vStop);
+                        const uint32_t actL = LmaxL >= P.mink ? (LmaxL - P.mink >= 31 ? ~0u : ((2u << (LmaxL - P.mink)) - 1u)) : 0u;
+                        const uint32_t actR = LmaxR >= P.mink ? (LmaxR - P.mink >= 31 ? ~0u : ((2u << (LmaxR - P.mink)) - 1u)) : 0u;
+                        const uint32_t missL = actL & ~kSegL, missR = actR & ~kSegR;
+                        const int lenL = missL ? P.mink + (31 - __clz(missL)) : ((P.mink - 1 >= 1 && LmaxL >= P.mink - 1) ? P.mink - 1 : 0);
+                        const int lenR = missR ? P.mink + (31 - __clz(missR)) : ((P.mink - 1 >= 1 && LmaxR >= P.mink - 1) ? P.mink - 1 : 0);
+                        if (lenL > 0) leftEnd = max(0, min(vL, vStart + lenL - 1 + tp + 1));
+                        if (lenR > 0) rightStart = min(vL, max(0, vStop - lenR - tp));
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                uint64_t hm = __ballot(inSub && kFound > 0);
+                while (hm) {
+                    const int j = __ffsll((unsigned long long)hm) - 1;
+                    hm &= hm - 1;
+                    const int L = __builtin_amdgcn_readlane(vL, j), relj = __builtin_amdgcn_readlane(rel, j);
+                    const int base0 = origin + relj;
+                    const int le = __builtin_amdgcn_readlane(leftEnd, j), rs = __builtin_amdgcn_readlane(rightStart, j);
+                    const int64_t g0 = O0 + relj;                   // bit offset of the read in the output mask
+                    const int nb = P.mfc ? L : L + max(tp, 0) + 1;  // BitSet size: bits >= L count but are not written
+                    int card = 0;
+                    for (int b0 = 0; b0 < nb; b0 += 64) {
+                        const int b = b0 + lane;
+                        bool cov = false;
+                        if (b < nb) {
+                            const int lo = max(0, b - tp), hi = min(L - 1, b + k - 1 - tp);
+                            if (lo <= hi) cov = extract1(wh, base0 + lo, hi - lo + 1) != 0u;          // hi-lo+1 <= k <= 31
+                            if (!P.mfc) { if (b < L) cov = cov || b < le || b >= rs; }
+                            else cov = !cov && b >= le && b < rs;                                     // nothing cleared this base
+                        }
+                        const uint64_t cm = __ballot(cov);
+                        card += __popcll(cm);
+                        const uint64_t wm = cm & ((L - b0 >= 64) ? ~0ULL : ((L - b0 <= 0) ? 0ULL : ((1ULL << (L - b0)) - 1ULL)));   // bases only
+                        if (wm && lane < 3) {                       // up to three 32-bit words of the global mask
+                            const int64_t g = g0 + b0; const int sh = (int)(g & 31);
+                            const uint64_t plo = wm << sh, phi = sh ? (wm >> (64 - sh)) : 0ULL;
+                            const uint32_t piece = lane == 0 ? (uint32_t)plo : (lane == 1 ? (uint32_t)(plo >> 32) : (uint32_t)phi);
+                            if (piece) atomicOr(&P.outMask[(g >> 5) + lane], piece);
+                        }
+                    }
+                    kCard = (lane == j) ? card : kCard;
                 }
             }
           }   // pass
@@ -2771,6 +2865,24 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                 P.outLeft[r0 + lane] = any ? leftmost : -1; P.outRight[r0 + lane] = any ? rightmost : -1;
                 vRkt += a > 0 ? 1u : 0u; vXs += (unsigned)a;
                 if (remove) { vRm += 1; vBm += (unsigned)npl; }
+            }
+        } else if constexpr (KMASK) {
+            // ktrim=n (:984-998, 1009-1016, 1028-1029, 1431-1443): lengths stay, so the verdicts depend on them alone; the counters take the
+            // masked bases whether or not the pair is removed
+            hit = mine && vScan && kFound > 0; ref = kId0; a = hit ? kCard : 0; newLen = vL;
+            if (hit) id = ref_to_id(P, ref);
+            const float g = (float)vL * P.minLenFraction;
+            const int minlenR = (int)(g > (float)P.minReadLength ? g : (float)P.minReadLength);
+            if (P.storedKmers > 0) {
+                d = vL < minlenR;
+                if (paired) { const bool dm = __shfl_xor((int)d, 1) != 0; remove = (P.rieb && (d || dm)) || (d && dm); }
+                else remove = d;
+            }
+            if (mine) {
+                outA[r0 + lane] = a; outId[r0 + lane] = id;
+                outFlags[r0 + lane] = (uint8_t)((d ? BBDUK_FLAG_DISCARDED : 0) | (remove ? BBDUK_FLAG_REMOVED : 0));
+                vRkt += a > 0 ? 1u : 0u; vXs += (unsigned)a;
+                if (remove) { vRm += 1; vBm += (unsigned)vL; }
             }
         } else if constexpr (TIPS) {
             // ktrim=rl (:954-967, 1009-1033): the left pass's outcome on the read as the right pass left it, then the pair rules on the final
@@ -4498,7 +4610,25 @@ static int launch_kmask(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     int* const d_flag = h->d_slowFlag + evi;
     HIP_TRY(h, hipMemsetAsync(d_flag, 0, sizeof(int), st));
     if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
+    {   // pre-pass: a unit (pair) beyond a wave's planes sends the batch to the tiled kernel (which in turn leaves the reads beyond ITS planes
+        // to bbduk_kmask_long_kernel); else bbduk_wave_kernel<KMASK> takes it
+        const int64_t units = paired ? n / 2 : n;
+        const int ugrid = (int)std::min<int64_t>((units + 255) / 256, (int64_t)h->numCU * 8);
+        bbduk_span_kernel<<<dim3(std::max(ugrid, 1)), dim3(256), 0, st>>>(d_offsets, n, (int)paired, d_flag, (int64_t)WUNIT_MAX_KM, (int64_t)0x7FFFFFFFFFFFLL);
+    }
     HIP_TRY(h, hipEventRecord(h->ev0[evi], st));
+    {   // the main kernel's shape: wave-autonomous mini-tiles, a fourth plane for the hit positions, one lane per read in the finish
+        K.waveFirst = 1; K.outMask = d_mask;
+        const bool general = params_general(h->p);
+        const batch_kernel_t wk = general ? bbduk_wave_kernel<BBDUK_MODE_KMASK, true, true, true, 2>
+                                : (packed ? (K.forbidNs ? bbduk_wave_kernel<BBDUK_MODE_KMASK, true, true, false, 1> : bbduk_wave_kernel<BBDUK_MODE_KMASK, true, false, false, 1>)
+                                          : (K.forbidNs ? bbduk_wave_kernel<BBDUK_MODE_KMASK, true, true, false, 0> : bbduk_wave_kernel<BBDUK_MODE_KMASK, true, false, false, 0>));
+        const size_t waveLds = dynLds + WAVE_LDS_BYTES_KM;
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(wk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)waveLds));
+        const int64_t nmt = (n + MT_READS - 1) / MT_READS;
+        const int wgrid = (int)std::min<int64_t>((nmt + NWAVES - 1) / NWAVES, (int64_t)h->numCU);
+        wk<<<dim3(std::max(wgrid, 1)), dim3(BLOCK_THREADS), waveLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
+    }
     bbduk_kmask_kernel<<<dim3(grid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_mask, d_counters, d_flag);
     HIP_TRY(h, hipEventRecord(h->ev1[evi], st));
     h->evCount++;

@@ -20,6 +20,7 @@ struct KParams {
     int32_t kbig, fbm;           // kfilter variants of bbduk_kscan_kernel: k>31 emulation (kbig>k), findBestMatch
     int32_t* matchN; int32_t* matchIds; int32_t* matchCnt; int32_t matchCap;    // findBestMatch's idList / countList per read (rename, :2508-2522), or null
     int32_t* outLeft; int32_t* outRight;   // ksplit: the span it computes per read (leftmost, rightmost), or -1, -1
+    uint32_t* outMask;          // ktrim=n on the wave kernel: the per-base mask, bit offsets[read]+b
     int32_t waveFirst;          // the tiled secondary kernel runs only if the span pre-pass found a read beyond a wave's planes
     const uint32_t* undef;      // packed input (bbduk_*_batch_packed): 1 bit per base, set = undefined; `bases` then points at
                                 // 2-bit codes, 16 bases per 32-bit word (A0 C1 G2 T/U3, undefined 0).  nullptr = ASCII bases
