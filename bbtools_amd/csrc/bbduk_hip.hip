@@ -1079,6 +1079,41 @@ __device__ __forceinline__ void main_scan_pair(const KParams& P, const Planes& Q
     A.found = foundA; B.found = foundB;
 }
 
+// The left pass of ktrim=rl scans about half a read (:1821-1824: [0, mid+k-1)), i.e. at most 64 positions of a 150-base read where the pair
+// scan above gives every read 128: FOUR reads share a block here.  R[0] and R[1] sit in lanes 0-31 of the slot pairs (0,1) and (2,3), R[2] and
+// R[3] in lanes 32-63; the windows are cut with lane-varying read coordinates and each read folds its half of the ballots.  Spans that start
+// at 0 and are looked up at every position only (W.full).
+template <bool FORBIDN, bool GENERAL>
+__device__ __forceinline__ void left_scan_quad(const KParams& P, const Planes& Q, ReadScan* R, const int lane) {
+    const bool hi = lane >= 32; const int l5 = lane & 31;
+    ReadWin W[2];
+#pragma unroll
+    for (int sp = 0; sp < 2; sp++) {
+        W[sp].base0 = hi ? R[2 + sp].base0 : R[sp].base0; W[sp].stop = hi ? R[2 + sp].stop : R[sp].stop;
+        W[sp].start = 0; W[sp].first = P.k - 1; W[sp].on = true; W[sp].full = true;
+        W[sp].hasN = (FORBIDN && P.forbidNs) && (R[sp].hasN != 0 || R[2 + sp].hasN != 0);
+    }
+    int found[4] = {0, 0, 0, 0};
+    for (int ib = P.k - 1; ; ib += 64) {
+        bool on[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) on[q] = R[q].scan && ib < R[q].stop;
+        if (!(on[0] || on[1] || on[2] || on[3])) break;
+        uint64_t kmer[4], rk[4]; bool ok[4]; int id[4];
+        windows2<FORBIDN, GENERAL, false>(P, Q, W[0], ib + 2 * l5, hi ? on[2] : on[0], kmer, rk, ok);
+        windows2<FORBIDN, GENERAL, false>(P, Q, W[1], ib + 2 * l5, hi ? on[3] : on[1], kmer + 2, rk + 2, ok + 2);
+        lookup4<GENERAL, false>(P, Q.filt, kmer, rk, ok, id);
+        const uint64_t m0 = __ballot(id[0] != -1), m1 = __ballot(id[1] != -1), m2 = __ballot(id[2] != -1), m3 = __ballot(id[3] != -1);
+        if (!(m0 | m1 | m2 | m3)) continue;
+        fold_hits<BBDUK_MODE_KTRIM_L>(P, R[0], found[0], interleave32((uint32_t)m0, (uint32_t)m1), id[0], id[1], ib, 0);
+        fold_hits<BBDUK_MODE_KTRIM_L>(P, R[2], found[2], interleave32((uint32_t)(m0 >> 32), (uint32_t)(m1 >> 32)), id[0], id[1], ib, 32);
+        fold_hits<BBDUK_MODE_KTRIM_L>(P, R[1], found[1], interleave32((uint32_t)m2, (uint32_t)m3), id[2], id[3], ib, 0);
+        fold_hits<BBDUK_MODE_KTRIM_L>(P, R[3], found[3], interleave32((uint32_t)(m2 >> 32), (uint32_t)(m3 >> 32)), id[2], id[3], ib, 32);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) R[q].found = found[q];
+}
+
 // Candidate form of the pair scan (ktrim=r, kfilter with maxbadkmers=0: only the first hit of a read matters): stop
 // at the first fingerprint match of each read WITHOUT fetching its key; the caller verifies the candidates of a whole
 // sub-tile in one overlapped batch (one lane per read) and falls back to main_scan_pair for the rare impostor.
@@ -2542,7 +2577,34 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                 }
                 nMask = __ballot(acc != 0u);
             }
-            for (int ra = s; ra < e; ra += 2) {
+            bool quadDone = false;
+            if constexpr (TIPS) {
+                if (pass == 1 && (!GENERAL || P.qskip < 2)) {       // the left pass: four reads per block (left_scan_quad)
+                    quadDone = true;
+                    for (int ra = s; ra < e; ra += 4) {
+                        ReadScan R4[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int rd = min(ra + q, 63); const bool has = (ra + q) < e;
+                            R4[q].hasN = (int)((nMask >> rd) & 1); R4[q].maxBad = P.maxBadKmers;
+                            R4[q].base0 = origin + __builtin_amdgcn_readlane(rel, rd);
+                            R4[q].L = has ? __builtin_amdgcn_readlane(vL, rd) : 0;
+                            R4[q].scan = has && ((scanMask >> rd) & 1);
+                            R4[q].start = 0; R4[q].stop = has ? __builtin_amdgcn_readlane(vStop, rd) : 0;
+                            R4[q].found = 0; R4[q].iFirst = BIGLOC; R4[q].iLast = -1; R4[q].ref = -1; R4[q].shortFl = -1; R4[q].shortLl = -1;
+                        }
+                        left_scan_quad<FORBIDN, GENERAL>(P, Q, R4, lane);
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            if (R4[q].found) {
+                                vFound = (lane == ra + q) ? R4[q].found : vFound; vFirst = (lane == ra + q) ? R4[q].iFirst : vFirst;
+                                vLast = (lane == ra + q) ? R4[q].iLast : vLast;   vRef = (lane == ra + q) ? R4[q].ref : vRef;
+                            }
+                        }
+                    }
+                }
+            }
+            for (int ra = s; ra < e && !quadDone; ra += 2) {
                 const bool hasB = (ra + 1) < e;
                 ReadScan A, Bz;
                 A.hasN = (int)((nMask >> ra) & 1); Bz.hasN = (int)((nMask >> (ra + 1)) & 1);
