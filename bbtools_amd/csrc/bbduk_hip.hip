@@ -782,6 +782,26 @@ __device__ __forceinline__ void cand_resolve4(const KParams& P, const Cand4& C, 
     }
 }
 
+// lookup4 in the candidate probe's style, for the wave kernel's scans that need EVERY hit (ktrim=l, ktrim=n, ksplit, the left pass of
+// ktrim=rl): the straight-line probe, one scalar test that ends most blocks, and only flagged lanes fetch keys.  Exact like lookup4.
+template <bool GENERAL>
+__device__ __forceinline__ void lookup4_probe(const KParams& P, const uint32_t* s_filt, const uint64_t* kmer, const uint64_t* rk, const bool* ok, int* ref) {
+    if constexpr (GENERAL) {
+        if (P.qhdist > 0) { lookup4<GENERAL>(P, s_filt, kmer, rk, ok, ref); return; }
+    }
+    Cand4 C;
+    const uint64_t any = cand_probe4<GENERAL, false, true>(P, s_filt, kmer, rk, C);
+#pragma unroll
+    for (int s = 0; s < 4; s++) ref[s] = -1;
+    if (any == 0ULL) return;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        if (C.hm[s] == 0ULL) continue;                            // nothing flagged in this slot (wave-uniform)
+        const uint64_t cand = zero16((C.t[s] & TAG_FPS) ^ ((uint64_t)tag_of(C.ma[s]) * 0x0001000100010001ULL));
+        if (ok[s] && C.pv[s] && (cand != 0ULL || (C.t[s] & TAG_CONT))) ref[s] = table_find_t(P, C.key[s] | P.kmask, C.ma[s], C.mb[s], C.t[s]);
+    }
+}
+
 // ---- big layout, fast form of the candidate probe (specialised kernels, plain k >= 16 configurations) -----------------
 // The 52-bit candidate values travel as the mantissas of doubles in [1, 2): positive normal doubles order like their bit patterns, so
 // one v_min_f64 (full rate on CDNA) is the 52-bit minimum.  next_lane: the value of lane+1 (wave_shl:1, DPP, gfx9: no LDS crossbar);
@@ -988,6 +1008,31 @@ __device__ __forceinline__ int short_probe(const KParams& P, const uint64_t kmer
     return sref;
 }
 
+// Two short k-mer probes with their filter reads and fingerprint gathers in flight together (the short scans are latency-bound: one
+// dependent L2 access per pass otherwise).
+__device__ __forceinline__ void short_probe2(const KParams& P, const uint64_t* kmer, const uint64_t* rk, const uint64_t* lengthMask, const bool* act, int* sref) {
+    uint64_t mx[2], t[2]; uint32_t ma[2], mb[2], pv[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        mx[q] = kmer[q] > rk[q] ? kmer[q] : rk[q];
+        ma[q] = mix_a(mx[q]); mb[q] = mix_b(mx[q]);
+        pv[q] = P.ldsBits ? __builtin_amdgcn_ubfe(lds_word_at(filt_byte(ma[q], P.ldsBits)), ma[q], 1u) : 1u;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) { pv[q] = act[q] ? pv[q] : 0u; t[q] = P.tags[pv[q] ? bucket_of(mb[q], P.bucketBits) : 0u]; }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const uint32_t fp = tag_of(ma[q]), tlo = (uint32_t)t[q], thi = (uint32_t)(t[q] >> 32);
+        const uint64_t b = __ballot((tlo & 0xFFFFu) == fp) | __ballot((tlo >> 16) == fp) | __ballot((thi & 0xFFFFu) == fp) |
+                           __ballot((thi >> 16) == fp) | __ballot((int32_t)thi < 0);
+        sref[q] = -1;
+        if ((b & __ballot(pv[q] != 0u)) != 0ULL) {                // rare
+            const uint64_t cand = zero16((t[q] & TAG_FPS) ^ ((uint64_t)fp * 0x0001000100010001ULL));
+            if (pv[q] && (cand != 0ULL || (t[q] & TAG_CONT))) sref[q] = table_find_t(P, mx[q] | lengthMask[q], ma[q], mb[q], t[q]);
+        }
+    }
+}
+
 // kfilter thresholds that depend on the read (general kernels).  numValidKmers (stream/Read.java:1673-1683), wave-cooperative:
 // one lane per k-mer end position, valid = no undefined base in the window.
 __device__ __forceinline__ int valid_kmers_wave(const Planes& Q, const int base0, const int L, const int k, const int lane) {
@@ -1033,7 +1078,8 @@ __device__ __forceinline__ int kfilter_threshold(const KParams& P, const Planes&
 // firstA >= 0 (bbduk_long_kernel): read A is scanned in chunks; this call resumes at position firstA with A.found hits so far.
 // MASK (ktrim=n): every position that matches -- with kmaskfullycovered every position of the span that does NOT -- sets its bit of
 // `hitPlane` (plane coordinates, like the undefined-plane), see bbduk_kmask_kernel.
-template <int MODE, bool FORBIDN, bool GENERAL, bool BIG = false, bool SPAN = false, bool MASK = false>
+// FAST (wave kernel only: the filter sits at LDS address 0): lookup4_probe instead of lookup4.
+template <int MODE, bool FORBIDN, bool GENERAL, bool BIG = false, bool SPAN = false, bool MASK = false, bool FAST = false>
 __device__ __forceinline__ void main_scan_pair(const KParams& P, const Planes& Q, ReadScan& A, ReadScan& B, const int lane, const int firstA = -1,
                                                uint32_t* hitPlane = nullptr) {
     ReadWin WA, WB;
@@ -1046,7 +1092,8 @@ __device__ __forceinline__ void main_scan_pair(const KParams& P, const Planes& Q
         uint64_t kmer[4], rk[4]; bool ok[4]; int id[4];
         windows2<FORBIDN, GENERAL, SPAN>(P, Q, WA, ibA + 2 * lane, onA, kmer, rk, ok);
         windows2<FORBIDN, GENERAL, SPAN>(P, Q, WB, ibB + 2 * lane, onB, kmer + 2, rk + 2, ok + 2);
-        lookup4<GENERAL, BIG>(P, Q.filt, kmer, rk, ok, id);
+        if constexpr (FAST && !BIG) lookup4_probe<GENERAL>(P, Q.filt, kmer, rk, ok, id);
+        else lookup4<GENERAL, BIG>(P, Q.filt, kmer, rk, ok, id);
         const uint64_t m0 = __ballot(id[0] != -1), m1 = __ballot(id[1] != -1), m2 = __ballot(id[2] != -1), m3 = __ballot(id[3] != -1);
         if constexpr (MASK) {
 #pragma unroll
@@ -1102,7 +1149,7 @@ __device__ __forceinline__ void left_scan_quad(const KParams& P, const Planes& Q
         uint64_t kmer[4], rk[4]; bool ok[4]; int id[4];
         windows2<FORBIDN, GENERAL, false>(P, Q, W[0], ib + 2 * l5, hi ? on[2] : on[0], kmer, rk, ok);
         windows2<FORBIDN, GENERAL, false>(P, Q, W[1], ib + 2 * l5, hi ? on[3] : on[1], kmer + 2, rk + 2, ok + 2);
-        lookup4<GENERAL, false>(P, Q.filt, kmer, rk, ok, id);
+        lookup4_probe<GENERAL>(P, Q.filt, kmer, rk, ok, id);
         const uint64_t m0 = __ballot(id[0] != -1), m1 = __ballot(id[1] != -1), m2 = __ballot(id[2] != -1), m3 = __ballot(id[3] != -1);
         if (!(m0 | m1 | m2 | m3)) continue;
         fold_hits<BBDUK_MODE_KTRIM_L>(P, R[0], found[0], interleave32((uint32_t)m0, (uint32_t)m1), id[0], id[1], ib, 0);
@@ -2403,12 +2450,17 @@ void bbduk_ktrimtips_kernel(const KParams P, const uint8_t* __restrict__ bases, 
 #define SEL_BYTES    ((MT_READS + 3) & ~3)
 #define WAVE_LDS_BYTES ((2 * NWAVES * WPLANE_WORDS + NWAVES * WNM_WORDS) * 4 + 6 * 8 + NWAVES * SEL_BYTES)   // behind the filter
 #define WUNIT_MAX    (WCAP_BASES - 48)             // longest unit (pair) the wave kernel accepts
-// ktrim=n keeps a fourth per-wave plane (the k-mer end positions that hit); its planes are a little shorter so that all of it still
-// fits behind a 128 KiB filter
-#define WCAP_BASES_KM 2304
-#define WAVE_LDS_BYTES_KM ((2 * NWAVES * (PLANE_PAD + WCAP_BASES_KM / 16 + PLANE_PAD) + 2 * NWAVES * (WCAP_BASES_KM / 32 + 4)) * 4 + 6 * 8 + NWAVES * SEL_BYTES)
+// ktrim=n keeps a fourth per-wave plane (the k-mer end positions that hit).  To fit behind a 128 KiB filter its planes are a little shorter
+// (sixteen 150-base reads still fit) and its short-scan lists live in the undefined-plane, which is dead once the main scan of the
+// sub-tile is over.
+#define WCAP_BASES_KM 2432
+#define WPLANE_WORDS_KM (PLANE_PAD + WCAP_BASES_KM / 16 + PLANE_PAD)
+#define WNM_WORDS_KM (WCAP_BASES_KM / 32 + 4)
+#define WHIT_WORDS   (WCAP_BASES_KM / 32 + 2)
+#define WAVE_LDS_BYTES_KM ((2 * NWAVES * WPLANE_WORDS_KM + NWAVES * WNM_WORDS_KM + NWAVES * WHIT_WORDS) * 4 + 6 * 8)
 #define WUNIT_MAX_KM (WCAP_BASES_KM - 48)
 static_assert((128 << 10) + WAVE_LDS_BYTES_KM <= (160 << 10), "ktrim=n wave kernel: LDS budget");
+static_assert(WNM_WORDS_KM * 4 >= SEL_BYTES, "short-scan list fits the undefined-plane");
 
 // sum of v over the lanes of a wave, returned wave-uniform
 __device__ __forceinline__ int wave_sum(int v) {
@@ -2429,12 +2481,12 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
     uint32_t* const s_filt = s_dyn;
     constexpr bool KMASK = MODE == BBDUK_MODE_KMASK;              // ktrim=n: every hit of the main scan, both ends' short k-mers, a mask per base
     constexpr int CAPB = KMASK ? WCAP_BASES_KM : WCAP_BASES;      // per-wave plane capacity in bases
-    constexpr int PLW = PLANE_PAD + CAPB / 16 + PLANE_PAD, NMW = CAPB / 32 + 4;
+    constexpr int PLW = KMASK ? WPLANE_WORDS_KM : WPLANE_WORDS, NMW = KMASK ? WNM_WORDS_KM : WNM_WORDS, HW = KMASK ? WHIT_WORDS : 0;
     uint32_t* const s_wfAll = s_dyn + (P.ldsBits ? (1 << (P.ldsBits - 5)) : 0);
     uint32_t* const s_wcAll = s_wfAll + NWAVES * PLW;
     uint32_t* const s_wnAll = s_wcAll + NWAVES * PLW;
     uint32_t* const s_whAll = s_wnAll + NWAVES * NMW;             // ktrim=n: bit p <=> a k-mer ending at plane position p matched
-    unsigned long long* const s_acc = reinterpret_cast<unsigned long long*>(s_whAll + (KMASK ? NWAVES * NMW : 0));   // rkt, basesKTrimmed, readsOutm, basesOutm, readsIn, basesIn
+    unsigned long long* const s_acc = reinterpret_cast<unsigned long long*>(s_whAll + NWAVES * HW);   // rkt, basesKTrimmed, readsOutm, basesOutm, readsIn, basesIn
     uint8_t* const s_selAll = reinterpret_cast<uint8_t*>(s_acc + 6);   // short-scan: compacted list of participating reads (lane ids)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
@@ -2457,8 +2509,8 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
 
     uint32_t* const wf = s_wfAll + wave * PLW; uint32_t* const wc = s_wcAll + wave * PLW;
     uint32_t* const wn = s_wnAll + wave * NMW;
-    uint32_t* const wh = s_whAll + wave * NMW;
-    uint8_t* const sel = s_selAll + wave * SEL_BYTES;
+    uint32_t* const wh = s_whAll + wave * HW;
+    uint8_t* const sel = KMASK ? reinterpret_cast<uint8_t*>(wn) : s_selAll + wave * SEL_BYTES;   // (ktrim=n: see WAVE_LDS_BYTES_KM)
     // scaffold-counter cache: lane w (< SCAF_LANES) owns one (id, reads, bases) entry in registers; a hit is one ballot
     // plus a predicated add, a miss evicts round-robin with two atomics.  The adapter library has ~6 frequent ids:
     // with the 4-entry scalar cache 4-15 % of the hit reads still caused evictions onto a dozen hot addresses.
@@ -2537,7 +2589,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                 reinterpret_cast<uint16_t*>(wn)[c] = (uint16_t)(~valid & 0xFFFFu);
             }
             if (lane == 0 && (nchunks & 1)) reinterpret_cast<uint16_t*>(wn)[nchunks] = 0;
-            if constexpr (KMASK) { for (int w = lane; w < NMW; w += 64) wh[w] = 0; }
+            if constexpr (KMASK) { for (int w = lane; w < HW; w += 64) wh[w] = 0; }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // LDS is in-order per wave; keep the compiler honest
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -2645,10 +2697,10 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                     }
                 }
                 if constexpr (TIPS) {
-                    if (pass == 0) main_scan_pair<BBDUK_MODE_KTRIM_R, FORBIDN, GENERAL, false, true>(P, Q, A, Bz, lane);
-                    else main_scan_pair<BBDUK_MODE_KTRIM_L, FORBIDN, GENERAL, false, true>(P, Q, A, Bz, lane);
-                } else if constexpr (KMASK) main_scan_pair<BBDUK_MODE_KTRIM_L, FORBIDN, GENERAL, false, false, true>(P, Q, A, Bz, lane, -1, wh);   // hits counted, first id kept, none ends the scan
-                else main_scan_pair<MODE, FORBIDN, GENERAL, BIG>(P, Q, A, Bz, lane);
+                    if (pass == 0) main_scan_pair<BBDUK_MODE_KTRIM_R, FORBIDN, GENERAL, false, true, false, true>(P, Q, A, Bz, lane);
+                    else main_scan_pair<BBDUK_MODE_KTRIM_L, FORBIDN, GENERAL, false, true, false, true>(P, Q, A, Bz, lane);
+                } else if constexpr (KMASK) main_scan_pair<BBDUK_MODE_KTRIM_L, FORBIDN, GENERAL, false, false, true, true>(P, Q, A, Bz, lane, -1, wh);   // hits counted, first id kept, none ends the scan
+                else main_scan_pair<MODE, FORBIDN, GENERAL, BIG, false, false, true>(P, Q, A, Bz, lane);
                 if (A.found) {                                      // hand the facts to lane ra (most reads have none)
                     vFound = (lane == ra) ? A.found : vFound; vFirst = (lane == ra) ? A.iFirst : vFirst;
                     vLast = (lane == ra) ? A.iLast : vLast;   vRef = (lane == ra) ? A.ref : vRef;
@@ -2751,35 +2803,63 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     const int nneed = __popcll(needM);
                     const int vBase0 = origin + rel;
-                    for (int pb = 0; pb < nneed; pb += rpp) {
-                        const int q = pb + sslot;
-                        const bool have = sslot < rpp && q < nneed;
-                        const int j = have ? sel[q] : 0;   // the read this worker lane serves
-                        int jb, jstart, jstop;
-                        if constexpr (!GENERAL) {                   // start is 0 here: one shuffle carries base0 (< 2^16) and stop
-                            const int pk = __shfl(vBase0 | (vStop << 16), j);
-                            jb = pk & 0xFFFF; jstart = 0; jstop = (int)((unsigned)pk >> 16);
-                        } else { jb = __shfl(vBase0, j); jstart = __shfl(vStart, j); jstop = __shfl(vStop, j); }
+                    // what the hits of one pass (reads sel[pb ..]) mean for their reads
+                    auto take_hits = [&](uint64_t hm, const int sref, const int pb) {
+                        while (hm) {                                // rare: some read has a short hit
+                            const int l0 = __ffsll((unsigned long long)hm) - 1;
+                            const int slot = l0 / lens;
+                            const uint64_t seg = (hm >> (slot * lens)) & ((1ULL << lens) - 1ULL);
+                            const int fl = __ffsll((unsigned long long)seg) - 1, ll = 63 - __clzll((long long)seg);
+                            const int jr = sel[pb + slot];
+                            const int r1 = __builtin_amdgcn_readlane(sref, slot * lens + fl);   // first hit in scan order = shortest
+                            const int jru = __builtin_amdgcn_readfirstlane(jr);
+                            if constexpr (KMASK) {
+                                if (lane == jru) { if (side == 2) { kSegL = (uint32_t)seg; kIdL = r1; } else { kSegR = (uint32_t)seg; kIdR = r1; } }
+                            } else if (lane == jru) { vRef = r1; vFound = __popcll(seg); vSFl = fl; vSLl = ll; vSide = side; }
+                            hm &= ~(((1ULL << lens) - 1ULL) << (slot * lens));
+                        }
+                    };
+                    if constexpr (!GENERAL) {
+                        // specialised kernels: two passes' probes in flight together.  Unpredicated cuts: inactive lanes cut a 1-base window.
                         const int Ls = P.mink + st;
-                        uint64_t kmer = 0, rk = 0; bool act; int Lc;
-                        int sref;
-                        if constexpr (!GENERAL) {                  // unpredicated form: inactive lanes cut a 1-base window of read j
-                            if (LEFT) {
-                                const int Lmax = min(P.k, jstop) - jstart;
-                                act = have && Ls <= Lmax; Lc = act ? Ls : 1;
-                                const uint64_t lm = 1ULL << (2 * Lc);
-                                kmer = cut64_lds(Q.fwdBits + 2u * (uint32_t)(Q.T - 1 - (jb + jstart + Lc - 1))) & (lm - 1ULL);
-                                rk   = cut64_lds(Q.cmpBits + 2u * (uint32_t)(jb + jstart)) & (lm - 1ULL);
-                                sref = short_probe(P, kmer, rk, lm, act);
-                            } else {
-                                const int Lmax = (jstop >= P.k ? P.k - 1 : jstop);
-                                act = have && Ls <= Lmax; Lc = act ? Ls : 1;
-                                const uint64_t lm = 1ULL << (2 * Lc);
-                                kmer = cut64_lds(Q.fwdBits + 2u * (uint32_t)(Q.T - 1 - (jb + jstop - 1))) & (lm - 1ULL);
-                                rk   = cut64_lds(Q.cmpBits + 2u * (uint32_t)(jb + max(jstop - Lc, 0))) & (lm - 1ULL);
-                                sref = short_probe(P, kmer, rk, lm, act);
+                        for (int pb = 0; pb < nneed; pb += 2 * rpp) {
+                            uint64_t kmer[2], rk[2], lm[2]; bool act[2]; int sref[2];
+                            const bool two = pb + rpp < nneed;      // (wave-uniform) an odd pass at the end goes alone
+#pragma unroll
+                            for (int u = 0; u < 2; u++) {
+                                if (u == 1 && !two) break;
+                                const int q = pb + u * rpp + sslot;
+                                const bool have = sslot < rpp && q < nneed;
+                                const int j = have ? sel[q] : 0;   // the read this worker lane serves
+                                const int pk = __shfl(vBase0 | (vStop << 16), j);       // start is 0 here: one shuffle carries base0 (< 2^16) and stop
+                                const int jb = pk & 0xFFFF, jstop = (int)((unsigned)pk >> 16);
+                                if (LEFT) {
+                                    const int Lmax = min(P.k, jstop);
+                                    act[u] = have && Ls <= Lmax; const int Lc = act[u] ? Ls : 1;
+                                    lm[u] = 1ULL << (2 * Lc);
+                                    kmer[u] = cut64_lds(Q.fwdBits + 2u * (uint32_t)(Q.T - 1 - (jb + Lc - 1))) & (lm[u] - 1ULL);
+                                    rk[u]   = cut64_lds(Q.cmpBits + 2u * (uint32_t)jb) & (lm[u] - 1ULL);
+                                } else {
+                                    const int Lmax = (jstop >= P.k ? P.k - 1 : jstop);
+                                    act[u] = have && Ls <= Lmax; const int Lc = act[u] ? Ls : 1;
+                                    lm[u] = 1ULL << (2 * Lc);
+                                    kmer[u] = cut64_lds(Q.fwdBits + 2u * (uint32_t)(Q.T - 1 - (jb + jstop - 1))) & (lm[u] - 1ULL);
+                                    rk[u]   = cut64_lds(Q.cmpBits + 2u * (uint32_t)(jb + max(jstop - Lc, 0))) & (lm[u] - 1ULL);
+                                }
                             }
-                        } else {
+                            if (two) short_probe2(P, kmer, rk, lm, act, sref);
+                            else { sref[0] = short_probe(P, kmer[0], rk[0], lm[0], act[0]); sref[1] = -1; }
+                            take_hits(__ballot(sref[0] != -1), sref[0], pb);
+                            if (two) take_hits(__ballot(sref[1] != -1), sref[1], pb + rpp);
+                        }
+                    } else {
+                        for (int pb = 0; pb < nneed; pb += rpp) {
+                            const int q = pb + sslot;
+                            const bool have = sslot < rpp && q < nneed;
+                            const int j = have ? sel[q] : 0;   // the read this worker lane serves
+                            const int jb = __shfl(vBase0, j), jstart = __shfl(vStart, j), jstop = __shfl(vStop, j);
+                            const int Ls = P.mink + st;
+                            uint64_t kmer = 0, rk = 0; bool act; int Lc;
                             if (LEFT) {
                                 const int Lmax = min(P.k, jstop) - jstart;         // lengths 1..Lmax, i = start+Ls-1
                                 act = have && Ls <= Lmax;
@@ -2799,21 +2879,8 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                                     rk   = extract2(Q.cmp, jb + jstop - Lc, Lc) & P.mask;            // base i in bits 0-1
                                 }
                             }
-                            sref = lookup<GENERAL>(P, Q.filt, kmer, rk, 1ULL << (2 * Lc), Lc, P.qhdist2, act);
-                        }
-                        uint64_t hm = __ballot(sref != -1);
-                        while (hm) {                                // rare: some read has a short hit
-                            const int l0 = __ffsll((unsigned long long)hm) - 1;
-                            const int slot = l0 / lens;
-                            const uint64_t seg = (hm >> (slot * lens)) & ((1ULL << lens) - 1ULL);
-                            const int fl = __ffsll((unsigned long long)seg) - 1, ll = 63 - __clzll((long long)seg);
-                            const int jr = sel[pb + slot];
-                            const int r1 = __builtin_amdgcn_readlane(sref, slot * lens + fl);   // first hit in scan order = shortest
-                            const int jru = __builtin_amdgcn_readfirstlane(jr);
-                            if constexpr (KMASK) {
-                                if (lane == jru) { if (side == 2) { kSegL = (uint32_t)seg; kIdL = r1; } else { kSegR = (uint32_t)seg; kIdR = r1; } }
-                            } else if (lane == jru) { vRef = r1; vFound = __popcll(seg); vSFl = fl; vSLl = ll; vSide = side; }
-                            hm &= ~(((1ULL << lens) - 1ULL) << (slot * lens));
+                            const int sref = lookup<GENERAL>(P, Q.filt, kmer, rk, 1ULL << (2 * Lc), Lc, P.qhdist2, act);
+                            take_hits(__ballot(sref != -1), sref, pb);
                         }
                     }
                 };
