@@ -281,7 +281,7 @@ def main():
                        "kernel_ms": round(kern_ms, 3), "launch_ms": round(launch_ms, 3), "algorithmic_bytes_per_launch": int(algo_bytes),
                        # the contract prices this path against HBM; what actually paces the kernel is instruction issue
                        # (131 VALU + 70 SALU wave-instructions per read at ~4.4 / ~2.6 SIMD cycles each)
-                       "limiter": "instruction issue, not HBM: 131 VALU + 70 SALU per read (profiles/r01_final_summary.txt)"}
+                       "limiter": "instruction issue, not HBM: 133 VALU + 71 SALU per read (profiles/r02_final_summary.txt)"}
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
