@@ -7,6 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SRC = [os.path.join(_HERE, "csrc", "bbduk_hip.hip"), os.path.join(_HERE, "csrc", "bbduk_ingest.hip"),
         os.path.join(_HERE, "csrc", "bbduk_comm.hip"), os.path.join(_HERE, "csrc", "bbduk_host.cpp")]
 _DEPS = _SRC + [os.path.join(_HERE, "csrc", "synth.h"), os.path.join(_HERE, "csrc", "bbduk_internal.h"),
+                os.path.join(_HERE, "csrc", "bbduk_seal.inc"), os.path.join(_HERE, "..", "include", "seal_gpu.h"),
                 os.path.join(_HERE, "..", "include", "bbduk_gpu.h"), os.path.join(_HERE, "..", "include", "bbduk_host.h")]
 _SO = os.path.join(_HERE, "libbbduk_hip.so")
 _CLI_SRC = os.path.join(_HERE, "csrc", "bbduk_cli.cpp")

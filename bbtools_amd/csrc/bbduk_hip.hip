@@ -4045,7 +4045,7 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
     h->build = st; st->hdist = hdist; st->hdist2 = hdist2;
     // reference-side Hamming neighbourhoods put ~2/3 of a k-mer's 1+3k variants on one minimizer: such maps take plain lines
     if (hdist > 0) h->bigPlain = true;
-    st->big = (maxKeys > (double)BIG_LAYOUT_MIN_KEYS || h->hookBigLayout) && big_layout_eligible(h->p) && big_geometry(h);
+    st->big = (maxKeys > (double)BIG_LAYOUT_MIN_KEYS || h->hookBigLayout) && big_layout_eligible(h->p) && !h->sealTable && big_geometry(h);
     auto bail = [&](int code, const char* msg) { build_release(h); table_release(h); return fail(h, code, msg); };
     if (hipMalloc(&st->d_cnt, 32) != hipSuccess || hipMemsetAsync(st->d_cnt, 0, 32, h->stream) != hipSuccess) return bail(BBDUK_ERR_NOMEM, "hipMalloc");
     if (st->big) {
@@ -4993,3 +4993,6 @@ extern "C" int bbduk_synth_generate_device(const bbduk_synth_params* sp, int64_t
     hipFree(da1); hipFree(da2); hipFree(dc);
     return rc;
 }
+
+// ---- jgi/Seal.java on the same core (include/seal_gpu.h)
+#include "bbduk_seal.inc"

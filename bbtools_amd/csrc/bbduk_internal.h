@@ -69,6 +69,7 @@ struct bbduk_handle {
     bool big = false; uint64_t* d_bigTags = nullptr; uint64_t* d_bigKeys = nullptr; void* d_bigIds = nullptr; int bigIdBytes = 0; uint32_t bigLines = 0;
     int gm = 0, gW = 0, gH = 0, gD = 0; int64_t nspilled = 0;
     bool bigPlain = false;               // lines by a plain key hash instead of the gapped minimizer (gW = 0)
+    bool sealTable = false;              // the map of a seal_handle: record ids may be SEAL_MULTI | offset; always the cache-resident layout
     // streaming device-side build (bbduk_build_begin / _add_device / _end)
     struct BuildState* build = nullptr;
     uint32_t* d_ldsImage = nullptr; int ldsBits = 0;
