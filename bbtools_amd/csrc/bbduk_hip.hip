@@ -450,7 +450,7 @@ template <int MODE, bool SHORT, bool GENERAL>
 __device__ __forceinline__ bool scan_due(const KParams& P, int L, int pairnum, bool present) {
     const int k = P.k;
     bool s = present && P.storedKmers > 0;
-    if (MODE == BBDUK_MODE_KFILTER || MODE == BBDUK_MODE_KSPLIT || MODE == BBDUK_MODE_KMASK) s = s && (L >= k);   // BBDukProcessorS.java:1535; ksplit :2333, 2338; kmask :2151
+    if (MODE == BBDUK_MODE_KFILTER || MODE == BBDUK_MODE_KSPLIT || MODE == BBDUK_MODE_KMASK || MODE == 6 /* BBDUK_MODE_FBM */) s = s && (L >= k);   // BBDukProcessorS.java:1535; ksplit :2333, 2338; kmask :2151
     else s = s && (L >= max(1, (SHORT && P.useShort) ? min(k, P.mink) : k));               // :1995
     if constexpr (GENERAL) {
         if ((P.skipR1 && pairnum == 0) || (P.skipR2 && pairnum == 1)) s = false;           // :1536, :1996
@@ -1992,6 +1992,25 @@ __device__ __forceinline__ void kscan_init(KScanState& S) {
     S.found = 0; S.rid = -1; S.firstI = -1; S.lastI = -1; S.id0 = -1; S.bkStart = -1; S.bkStop = -1; S.lastId = -1; S.done = false;
     S.myId = 0; S.myCnt = 0; S.nids = 0;
 }
+// findBestMatch's counting (:1672-1690) over 128 positions (he / ho: the lanes whose even / odd position hit, refE / refO their ids):
+// hits in position order, every remaining hit with the same id counted at once; lane j owns the j-th distinct id
+__device__ __forceinline__ void best_fold(KScanState& S, const uint64_t he, const uint64_t ho, const int refE, const int refO, const int lane,
+                                          int64_t* __restrict__ counters) {
+    uint64_t re = he, ro = ho;
+    while (re | ro) {
+        const int le = re ? __ffsll((unsigned long long)re) - 1 : 64, lo = ro ? __ffsll((unsigned long long)ro) - 1 : 64;
+        const bool odd = 2 * lo + 1 < 2 * le;
+        const int id = odd ? __builtin_amdgcn_readlane(refO, lo) : __builtin_amdgcn_readlane(refE, le);
+        const uint64_t se = re & __ballot(refE == id), so = ro & __ballot(refO == id);
+        const int c = __popcll(se) + __popcll(so);
+        const uint64_t have = __ballot(lane < S.nids && S.myId == id);
+        if (have) { if (lane == __ffsll((unsigned long long)have) - 1) S.myCnt += c; }
+        else if (S.nids < KS_MAX_IDS) { if (lane == S.nids) { S.myId = id; S.myCnt = c; } S.nids++; }
+        else if (lane == 0) atomicMax((unsigned long long*)&counters[BBDUK_CTR_STATUS], (unsigned long long)(-BBDUK_ERR_ID_OVERFLOW));
+        S.found += c;
+        re &= ~se; ro &= ~so;
+    }
+}
 // the positions [W.first, W.stop) of one read (or of one chunk of it), 256 per step
 template <int RED>
 __device__ __forceinline__ void kscan_window(const KParams& P, const Planes& Q, const ReadWin& W, KScanState& S, const int thr, const int lane,
@@ -2020,21 +2039,7 @@ __device__ __forceinline__ void kscan_window(const KParams& P, const Planes& Q, 
                     S.found += __popcll(he) + __popcll(ho);
                 }
             } else if (RED == RED_BEST) {
-                uint64_t re = he, ro = ho;
-                while (re | ro) {                   // hits in position order
-                    const int le = re ? __ffsll((unsigned long long)re) - 1 : 64, lo = ro ? __ffsll((unsigned long long)ro) - 1 : 64;
-                    const bool odd = 2 * lo + 1 < 2 * le;
-                    const int id = odd ? __builtin_amdgcn_readlane(ref[2 * hb + 1], lo) : __builtin_amdgcn_readlane(ref[2 * hb], le);
-                    // every remaining hit of this half-block with the same id is counted at once
-                    const uint64_t se = re & __ballot(ref[2 * hb] == id), so = ro & __ballot(ref[2 * hb + 1] == id);
-                    const int c = __popcll(se) + __popcll(so);
-                    const uint64_t have = __ballot(lane < S.nids && S.myId == id);
-                    if (have) { if (lane == __ffsll((unsigned long long)have) - 1) S.myCnt += c; }
-                    else if (S.nids < KS_MAX_IDS) { if (lane == S.nids) { S.myId = id; S.myCnt = c; } S.nids++; }
-                    else if (lane == 0) atomicMax((unsigned long long*)&counters[BBDUK_CTR_STATUS], (unsigned long long)(-BBDUK_ERR_ID_OVERFLOW));
-                    S.found += c;
-                    re &= ~se; ro &= ~so;
-                }
+                best_fold(S, he, ho, ref[2 * hb], ref[2 * hb + 1], lane, counters);
             } else {
                 if (!(he | ho) && S.bkStart < 0) continue;          // nothing to open, nothing to close
                 const uint64_t ke = __ballot(ok[2 * hb]), ko = __ballot(ok[2 * hb + 1]);
@@ -2435,6 +2440,33 @@ void bbduk_ktrimtips_kernel(const KParams P, const uint8_t* __restrict__ bases, 
     if (tid == 0) publish_counters<BBDUK_MODE_KTRIM_R>(s_acc, counters);
 }
 
+// findBestMatch on the wave kernel's pair scan: the two reads of a block keep their own id lists (lane j = the j-th distinct id of that
+// read); readA / readB = their batch indices for the match lists of rename.  A.found / A.ref = hits counted / the scaffold returned.
+#define BBDUK_MODE_FBM 6                            // internal: kfilter with findBestMatch, as a mode of bbduk_wave_kernel
+template <bool FORBIDN, bool GENERAL>
+__device__ __forceinline__ void main_scan_pair_best(const KParams& P, const Planes& Q, ReadScan& A, ReadScan& B, const int lane,
+                                                    int64_t* __restrict__ counters, const int64_t readA, const int64_t readB, const bool hasB) {
+    ReadWin WA, WB;
+    win_init<FORBIDN, GENERAL>(P, Q, A, WA, lane);
+    win_init<FORBIDN, GENERAL>(P, Q, B, WB, lane);
+    int ibA = WA.first, ibB = WB.first;
+    bool onA = WA.on, onB = WB.on;
+    KScanState SA, SB; kscan_init(SA); kscan_init(SB);
+    while (onA || onB) {
+        uint64_t kmer[4], rk[4]; bool ok[4]; int id[4];
+        windows2<FORBIDN, GENERAL>(P, Q, WA, ibA + 2 * lane, onA, kmer, rk, ok);
+        windows2<FORBIDN, GENERAL>(P, Q, WB, ibB + 2 * lane, onB, kmer + 2, rk + 2, ok + 2);
+        lookup4_probe<GENERAL>(P, Q.filt, kmer, rk, ok, id);
+        const uint64_t m0 = __ballot(id[0] != -1), m1 = __ballot(id[1] != -1), m2 = __ballot(id[2] != -1), m3 = __ballot(id[3] != -1);
+        if (onA) { if (m0 | m1) best_fold(SA, m0, m1, id[0], id[1], lane, counters); ibA += 128; onA = ibA < WA.stop; }
+        if (onB) { if (m2 | m3) best_fold(SB, m2, m3, id[2], id[3], lane, counters); ibB += 128; onB = ibB < WB.stop; }
+    }
+    kscan_finish<RED_BEST>(SA, A.maxBad, 0, lane); kscan_finish<RED_BEST>(SB, B.maxBad, 0, lane);
+    kscan_write_matches(P, SA, A.maxBad, readA, lane);
+    if (hasB) kscan_write_matches(P, SB, B.maxBad, readB, lane);
+    A.found = SA.found; A.ref = SA.rid; B.found = SB.found; B.ref = SB.rid;
+}
+
 // --------------------------------------------------------------------------------------------------
 // Wave-autonomous batch kernel (the fast path): every wave owns a mini-tile of MT_READS consecutive reads,
 // stages it into its private slice of LDS and scans it, with no workgroup barrier after the one that lands
@@ -2479,6 +2511,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
     // address 0 + offset), which saves an add per lookup.  Behind it: per-wave planes, counters, short-scan lists.
     extern __shared__ uint32_t s_dyn[];
     uint32_t* const s_filt = s_dyn;
+    constexpr bool FBM = MODE == BBDUK_MODE_FBM;                  // kfilter with findBestMatch: per-read id lists in the pair scan (main_scan_pair_best)
     constexpr bool KMASK = MODE == BBDUK_MODE_KMASK;              // ktrim=n: every hit of the main scan, both ends' short k-mers, a mask per base
     constexpr int CAPB = KMASK ? WCAP_BASES_KM : WCAP_BASES;      // per-wave plane capacity in bases
     constexpr int PLW = KMASK ? WPLANE_WORDS_KM : WPLANE_WORDS, NMW = KMASK ? WNM_WORDS_KM : WNM_WORDS, HW = KMASK ? WHIT_WORDS : 0;
@@ -2699,7 +2732,8 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                 if constexpr (TIPS) {
                     if (pass == 0) main_scan_pair<BBDUK_MODE_KTRIM_R, FORBIDN, GENERAL, false, true, false, true>(P, Q, A, Bz, lane);
                     else main_scan_pair<BBDUK_MODE_KTRIM_L, FORBIDN, GENERAL, false, true, false, true>(P, Q, A, Bz, lane);
-                } else if constexpr (KMASK) main_scan_pair<BBDUK_MODE_KTRIM_L, FORBIDN, GENERAL, false, false, true, true>(P, Q, A, Bz, lane, -1, wh);   // hits counted, first id kept, none ends the scan
+                } else if constexpr (FBM) main_scan_pair_best<FORBIDN, GENERAL>(P, Q, A, Bz, lane, counters, r0 + ra, r0 + ra + 1, hasB);
+                else if constexpr (KMASK) main_scan_pair<BBDUK_MODE_KTRIM_L, FORBIDN, GENERAL, false, false, true, true>(P, Q, A, Bz, lane, -1, wh);   // hits counted, first id kept, none ends the scan
                 else main_scan_pair<MODE, FORBIDN, GENERAL, BIG, false, false, true>(P, Q, A, Bz, lane);
                 if (A.found) {                                      // hand the facts to lane ra (most reads have none)
                     vFound = (lane == ra) ? A.found : vFound; vFirst = (lane == ra) ? A.iFirst : vFirst;
@@ -2995,6 +3029,21 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                 vRkt += a > 0 ? 1u : 0u; vXs += (unsigned)a;
                 if (remove) { vRm += 1; vBm += (unsigned)npl; }
             }
+        } else if constexpr (FBM) {
+            // findBestMatch (:1064-1089): discard iff a scaffold was returned; the counters are kfilter's
+            hit = mine && vScan && vRef > 0; ref = vRef; a = (mine && vScan) ? vFound : 0; newLen = vL;
+            if (hit) id = ref_to_id(P, ref);
+            if (P.matchN && mine && !vScan) P.matchN[r0 + lane] = 0;
+            if (P.storedKmers > 0) {
+                d = hit;
+                if (paired) { const bool dm = __shfl_xor((int)d, 1) != 0; remove = (P.rieb && (d || dm)) || (d && dm); }
+                else remove = d;
+            }
+            if (mine) {
+                outA[r0 + lane] = a; outId[r0 + lane] = (mine && vScan) ? vRef : -1;
+                outFlags[r0 + lane] = (uint8_t)((d ? BBDUK_FLAG_DISCARDED : 0) | (remove ? BBDUK_FLAG_REMOVED : 0));
+                if (remove) { vRm += 1; vBm += (unsigned)vL; }
+            }
         } else if constexpr (KMASK) {
             // ktrim=n (:984-998, 1009-1016, 1028-1029, 1431-1443): lengths stay, so the verdicts depend on them alone; the counters take the
             // masked bases whether or not the pair is removed
@@ -3122,7 +3171,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
         }
     }
     __syncthreads();
-    if (tid == 0) publish_counters<MODE == BBDUK_MODE_KTRIM_TIPS ? BBDUK_MODE_KTRIM_R : MODE>(s_acc, counters);
+    if (tid == 0) publish_counters<MODE == BBDUK_MODE_KTRIM_TIPS ? BBDUK_MODE_KTRIM_R : (MODE == BBDUK_MODE_FBM ? BBDUK_MODE_KFILTER : MODE)>(s_acc, counters);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -4365,6 +4414,23 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
         // wave's planes (bit 0) sends it to the tiled kernel, else bbduk_wave_kernel<KSPLIT> takes it
         const int sgrid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)h->numCU * 8);
         bbduk_span_kernel<<<dim3(std::max(sgrid, 1)), dim3(256), 0, st>>>(d_offsets, n, 0, d_flag, red == RED_SPLIT && !packed ? (int64_t)WUNIT_MAX : (int64_t)(KM_CAP_BASES - 32), (int64_t)(KM_CAP_BASES - 32));
+        if (red == RED_BEST) {                                      // findBestMatch: a unit (pair) beyond a wave's planes (bit 0) -> the tiled kernel
+            const int64_t units = paired ? n / 2 : n;
+            const int ugrid = (int)std::min<int64_t>((units + 255) / 256, (int64_t)h->numCU * 8);
+            bbduk_span_kernel<<<dim3(std::max(ugrid, 1)), dim3(256), 0, st>>>(d_offsets, n, (int)paired, d_flag, (int64_t)WUNIT_MAX, (int64_t)0x7FFFFFFFFFFFLL);
+        }
+    }
+    if (red == RED_BEST) {                                          // the main kernel's shape; the pair scan keeps an id list per read (main_scan_pair_best)
+        K.waveFirst = 1;
+        const bool general = params_general(h->p);
+        const batch_kernel_t wk = general ? bbduk_wave_kernel<BBDUK_MODE_FBM, false, true, true, 2>
+                                : (packed ? (K.forbidNs ? bbduk_wave_kernel<BBDUK_MODE_FBM, false, true, false, 1> : bbduk_wave_kernel<BBDUK_MODE_FBM, false, false, false, 1>)
+                                          : (K.forbidNs ? bbduk_wave_kernel<BBDUK_MODE_FBM, false, true, false, 0> : bbduk_wave_kernel<BBDUK_MODE_FBM, false, false, false, 0>));
+        const size_t waveLds = dynLds + WAVE_LDS_BYTES;
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(wk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)waveLds));
+        const int64_t nmt = (n + MT_READS - 1) / MT_READS;
+        const int wgrid = (int)std::min<int64_t>((nmt + NWAVES - 1) / NWAVES, (int64_t)h->numCU);
+        wk<<<dim3(std::max(wgrid, 1)), dim3(BLOCK_THREADS), waveLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
     }
     if (red == RED_SPLIT && !packed) {                              // the main kernel's shape: wave-autonomous mini-tiles, one lane per read in the finish
         K.waveFirst = 1; K.outLeft = d_left; K.outRight = d_right;
