@@ -2956,37 +2956,52 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                uint64_t hm = __ballot(inSub && kFound > 0);
-                while (hm) {
-                    const int j = __ffsll((unsigned long long)hm) - 1;
-                    hm &= hm - 1;
-                    const int L = __builtin_amdgcn_readlane(vL, j), relj = __builtin_amdgcn_readlane(rel, j);
-                    const int base0 = origin + relj;
-                    const int le = __builtin_amdgcn_readlane(leftEnd, j), rs = __builtin_amdgcn_readlane(rightStart, j);
-                    const int64_t g0 = O0 + relj;                   // bit offset of the read in the output mask
-                    const int nb = P.mfc ? L : L + max(tp, 0) + 1;  // BitSet size: bits >= L count but are not written
-                    int card = 0;
-                    for (int b0 = 0; b0 < nb; b0 += 64) {
-                        const int b = b0 + lane;
-                        bool cov = false;
-                        if (b < nb) {
-                            const int lo = max(0, b - tp), hi = min(L - 1, b + k - 1 - tp);
-                            if (lo <= hi) cov = extract1(wh, base0 + lo, hi - lo + 1) != 0u;          // hi-lo+1 <= k <= 31
-                            if (!P.mfc) { if (b < L) cov = cov || b < le || b >= rs; }
-                            else cov = !cov && b >= le && b < rs;                                     // nothing cleared this base
+                // one lane per read, 64 bases per step: H = the read's hit bits (zero outside [0, L)), the mask word = H dilated over the k
+                // positions [b - tp, b + k - 1 - tp] (log-step OR of shifted copies), then the short k-mers' prefix / suffix
+                const bool doCov = inSub && kFound > 0;
+                const int L = vL, base0 = origin + rel;
+                const int nb = P.mfc ? L : L + max(tp, 0) + 1;      // BitSet size: bits >= L count but are not written
+                int myWords = doCov ? (nb + 63) >> 6 : 0;
+                int maxWords = myWords;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) maxWords = max(maxWords, __shfl_xor(maxWords, o));
+                maxWords = __builtin_amdgcn_readfirstlane(maxWords);
+                auto prefix = [](const int n) -> uint64_t { return n <= 0 ? 0ULL : (n >= 64 ? ~0ULL : ((1ULL << n) - 1ULL)); };
+                auto hits64 = [&](const int p0) -> uint64_t {       // hit bits of read positions [p0, p0 + 64)
+                    if (p0 >= L || p0 + 64 <= 0) return 0ULL;
+                    const int q = max(p0, 0), pos = base0 + q;
+                    const uint32_t w0 = wh[pos >> 5], w1 = wh[(pos >> 5) + 1], w2 = wh[(pos >> 5) + 2];
+                    uint64_t v = ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, pos & 31) << 32) | __builtin_amdgcn_alignbit(w1, w0, pos & 31);
+                    v &= prefix(L - q);
+                    return p0 < 0 ? (v << (-p0)) : v;
+                };
+                int card = 0;
+                const int64_t g0 = O0 + rel;                        // bit offset of my read in the output mask
+                for (int w = 0; w < maxWords; w++) {
+                    if (w < myWords) {
+                        const int b0 = 64 * w;
+                        uint64_t lo = hits64(b0 - tp), hi = hits64(b0 - tp + 64);
+                        for (int cover = 1; cover < k;) {           // after the step the word ORs `cover` consecutive positions
+                            const int c = min(cover, k - cover);
+                            lo |= (lo >> c) | (hi << (64 - c)); hi |= hi >> c;
+                            cover += c;
                         }
-                        const uint64_t cm = __ballot(cov);
-                        card += __popcll(cm);
-                        const uint64_t wm = cm & ((L - b0 >= 64) ? ~0ULL : ((L - b0 <= 0) ? 0ULL : ((1ULL << (L - b0)) - 1ULL)));   // bases only
-                        if (wm && lane < 3) {                       // up to three 32-bit words of the global mask
+                        uint64_t cov = lo & prefix(nb - b0);
+                        if (!P.mfc) cov |= (prefix(leftEnd - b0) | ~prefix(rightStart - b0)) & prefix(L - b0);
+                        else cov = ~lo & ~prefix(leftEnd - b0) & prefix(rightStart - b0) & prefix(nb - b0);   // nothing cleared this base
+                        card += __popcll(cov);
+                        const uint64_t wm = cov & prefix(L - b0);   // bases only
+                        if (wm) {                                   // up to three 32-bit words of the global mask
                             const int64_t g = g0 + b0; const int sh = (int)(g & 31);
-                            const uint64_t plo = wm << sh, phi = sh ? (wm >> (64 - sh)) : 0ULL;
-                            const uint32_t piece = lane == 0 ? (uint32_t)plo : (lane == 1 ? (uint32_t)(plo >> 32) : (uint32_t)phi);
-                            if (piece) atomicOr(&P.outMask[(g >> 5) + lane], piece);
+                            const uint64_t plo = wm << sh; const uint32_t phi = sh ? (uint32_t)(wm >> (64 - sh)) : 0u;
+                            uint32_t* const dst = P.outMask + (g >> 5);
+                            if ((uint32_t)plo) atomicOr(dst, (uint32_t)plo);
+                            if ((uint32_t)(plo >> 32)) atomicOr(dst + 1, (uint32_t)(plo >> 32));
+                            if (phi) atomicOr(dst + 2, phi);
                         }
                     }
-                    kCard = (lane == j) ? card : kCard;
                 }
+                if (doCov) kCard = card;
             }
           }   // pass
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // scans done before the planes are overwritten
