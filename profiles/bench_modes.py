@@ -7,12 +7,12 @@ sys.path.insert(0, ROOT)
 import ctypes as C
 
 
-def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("--reads", type=int, default=20_000_000)
-    a = ap.parse_args()
+def run(reads=20_000_000):
+    """-> one dict per operator (bench.py's `operators` block calls this too)"""
     import torch
     from bbtools_amd import bbduk as B
-    n = a.reads // 2 * 2
+    n = reads // 2 * 2
+    out = []
     d_bases = torch.empty(n * 150, dtype=torch.uint8, device="cuda"); d_off = torch.empty(n + 1, dtype=torch.int64, device="cuda")
     B.synth_generate_device(B.synth_params(2), 0, n // 2, d_bases, d_off, 0)
     L = B.lib()
@@ -44,8 +44,16 @@ def main():
             assert rc == 0, rc
             ts.append(e0.elapsed_time(e1))
         ms = min(ts[1:]); c = d_ctr.cpu().numpy()
-        print(json.dumps({"mode": mode, "args": args, "reads": n, "operator_ms": round(ms, 2), "Gbases_per_s": round(n * 150 / ms / 1e6, 1), "readsKTrimmed": int(c[2]), "readsKFiltered": int(c[4]), "status": int(c[15])}))
+        out.append({"mode": mode, "args": args, "reads": n, "operator_ms": round(ms, 2), "Gbases_per_s": round(n * 150 / ms / 1e6, 1), "readsKTrimmed": int(c[2]), "readsKFiltered": int(c[4]), "status": int(c[15])})
         duk.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser(); ap.add_argument("--reads", type=int, default=20_000_000)
+    a = ap.parse_args()
+    for r in run(a.reads):
+        print(json.dumps(r))
 
 
 if __name__ == "__main__":

@@ -9,12 +9,9 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--pairs", type=int, default=2_000_000); ap.add_argument("--scaffolds", type=int, default=64)
-    ap.add_argument("--scaffold-len", type=int, default=100_000); ap.add_argument("--args", default="")
-    ap.add_argument("--check", type=int, default=2000)
-    a = ap.parse_args()
+def run(pairs=2_000_000, scaffolds=64, scaffold_len=100_000, args="", check=2000):
+    import types
+    a = types.SimpleNamespace(pairs=pairs, scaffolds=scaffolds, scaffold_len=scaffold_len, args=args, check=check)
     import torch
     from bbtools_amd.seal import Seal
     rng = np.random.default_rng(11)
@@ -55,17 +52,25 @@ def main():
     ok = None
     if a.check:
         from oracle.seal_ffi import SealOracle
-        from tests.test_seal import cfg_oracle
         o = SealOracle(ref_bytes)                       # defaults; --args is for experiments only
         if not a.args:
             k = 2 * a.check
             want = o.process_reads([reads[i].tobytes() for i in range(k)], True, 0, max_ids=cap)
             got = (d_s[:k].cpu().numpy(), d_a[:k].cpu().numpy(), d_m[:k].cpu().numpy(), d_i[:k * cap].cpu().numpy().reshape(k, cap), d_f[:k].cpu().numpy())
             ok = all(np.array_equal(w, h) for w, h in zip(want, got))
-    print(json.dumps({"workload": "seal %s: %d scaffolds x %d bases, %d pairs 2x150" % (a.args or "(defaults: k=31 mm=t ambig=random)", S, G, n),
+    return ({"workload": "seal %s: %d scaffolds x %d bases, %d pairs 2x150" % (a.args or "(defaults: k=31 mm=t ambig=random)", S, G, n),
                       "table_keys": int(g.table_keys), "table_pairs": int(g.table_pairs), "host_build_s": round(build_s, 2),
                       "kernel_ms": round(ms, 3), "Gbases_per_s": round(nr * L / ms / 1e6, 2), "readsMatched": int(c[3]), "readsUnmatched": int(c[5]),
-                      "ambiguous_pairs": int((d_s[0::2] > 1).sum().item()), "sample_equals_restatement": ok, "status": int(c[15])}))
+                      "ambiguous_pairs": int((d_s[0::2] > 1).sum().item()), "sample_equals_restatement": ok, "status": int(c[15])})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pairs", type=int, default=2_000_000); ap.add_argument("--scaffolds", type=int, default=64)
+    ap.add_argument("--scaffold-len", type=int, default=100_000); ap.add_argument("--args", default="")
+    ap.add_argument("--check", type=int, default=2000)
+    a = ap.parse_args()
+    print(json.dumps(run(a.pairs, a.scaffolds, a.scaffold_len, a.args, a.check)))
 
 
 if __name__ == "__main__":

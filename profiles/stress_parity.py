@@ -57,7 +57,16 @@ def main():
     while time.time() - t0 < a.seconds and not (a.only is not None and it):
         seed = a.seed * 1_000_003 + it if a.only is None else a.only; it += 1
         rng = random.Random(seed)
-        fam = rng.choice(["base", "base", "base", "kmask", "tips", "ksplit", "big", "fbm"])
+        fam = rng.choice(["base", "base", "base", "kmask", "tips", "ksplit", "big", "fbm", "seal"])
+        if fam == "seal":                                      # Seal's k-mer path (include/seal_gpu.h) against oracle/seal_oracle.c
+            from tests import test_seal
+            try:
+                test_seal.run_case(seed, nreads=rng.choice([60, 300, 1200]))
+            except Exception as e:
+                print(json.dumps({"FAILED": True, "seed": seed, "family": fam, "error": (str(e) or traceback.format_exc())[-2000:]}))
+                sys.exit(1)
+            n_cfg += 1; n_reads += 300; fam_count[fam] = fam_count.get(fam, 0) + 1
+            continue
         args, okw = T.random_config(rng)
         toks = [t for t in args.split() if not t.startswith("ktrim=") and t != "tpe"]
         for key in ("ktrimRight", "ktrimLeft", "trimPairsEvenly"):
