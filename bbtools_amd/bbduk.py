@@ -38,7 +38,7 @@ class Params(C.Structure):          # struct bbduk_params
                 ("skipR2", C.c_int32), ("numScaffolds", C.c_int32), ("device", C.c_int32),
                 ("trimPairsEvenly", C.c_int32), ("qSkip", C.c_int32), ("speed", C.c_int32),
                 ("minKmerFraction", C.c_float), ("minCoveredFraction", C.c_float), ("kbig", C.c_int32), ("findBestMatch", C.c_int32),
-                ("kmaskFullyCovered", C.c_int32)]
+                ("kmaskFullyCovered", C.c_int32), ("trimFailuresTo1bp", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class SynthParams(C.Structure):     # struct bbduk_synth_params

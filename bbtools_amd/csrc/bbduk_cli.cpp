@@ -356,6 +356,7 @@ int main(int argc, char** argv) {
     if (deviceIngest) {
         if (rename && P.findBestMatch) return fail("deviceingest=t does not rewrite read names: use rename=t without it", nullptr);
         if (ndev > 1) return fail("deviceingest=t drives one device: use device=", nullptr);
+        if (P.trimFailuresTo1bp) return fail("deviceingest=t does not cut discarded reads to one base: use trimfailuresto1bp without it", nullptr);
         if (chunk < 4096) chunk = 4096;
         const int rc = run_device_ingest(dev, host, so, P, in1, in2, paired, out, outm, tsv, (int64_t)chunk, device, maskLower, maskSymbol);
         if (rc == 0) { for (bbduk_handle* hq : devs) bbduk_destroy(hq); bbduk_host_destroy(host); }
@@ -443,24 +444,30 @@ int main(int argc, char** argv) {
             int left = 0, right = 0;                                 // TrimRead.trimByAmount(r, left, right, 1) with the returned amount
             if (P.mode == BBDUK_MODE_KTRIM_R) right = res[i]; else if (P.mode == BBDUK_MODE_KTRIM_L) left = res[i];
             else if (P.mode == BBDUK_MODE_KTRIM_TIPS) { right = res[i]; left = resL[i]; res[i] += resL[i]; }     // the tsv shows the sum
-            if (P.mode == BBDUK_MODE_KSPLIT && res[i] > 0 && !(fl[i] & BBDUK_FLAG_REMOVED)) {     // :2485-2490: the match touches an end
+            // ksplit: the span lies inside the read (two pieces) iff it touches neither end; the pieces leave through outm -- or stay, with
+            // trimfailuresto1bp, where nothing is evicted (:1431)
+            const bool split = P.mode == BBDUK_MODE_KSPLIT && resL[i] > 0 && resR[i] >= 0 && resR[i] != L - 1;
+            if (P.mode == BBDUK_MODE_KSPLIT && res[i] > 0 && !split) {                              // :2485-2490: the match touches an end
                 if (resL[i] == 0) left = res[i]; else right = res[i];
             }
-            if (P.mode == BBDUK_MODE_KSPLIT && (fl[i] & BBDUK_FLAG_REMOVED)) {                    // :2491-2498: two pieces, a pair for outm
+            if (split) {                                                                            // :2491-2498: two pieces, a pair
                 const int lm = resL[i], rm = resR[i];
                 if (ftsv) fprintf(ftsv, "%s\t%d\t%d\t%d\t%d\t%d\n", r.name.c_str(), L, res[i], ids[i], L - res[i], (int)fl[i]);
-                if (foutm) {
-                    fprintf(foutm, "@%s\n", r.name.c_str());
-                    fwrite(r.bases.data(), 1, (size_t)lm, foutm); fputs("\n+\n", foutm);
-                    fwrite(r.quals.data(), 1, (size_t)lm, foutm); fputc('\n', foutm);
+                FILE* const foutm0 = foutm;
+                FILE* const fpieces = (fl[i] & BBDUK_FLAG_REMOVED) ? foutm0 : fout;
+                if (fpieces) {
+                    fprintf(fpieces, "@%s\n", r.name.c_str());
+                    fwrite(r.bases.data(), 1, (size_t)lm, fpieces); fputs("\n+\n", fpieces);
+                    fwrite(r.quals.data(), 1, (size_t)lm, fpieces); fputc('\n', fpieces);
                     const int n2 = (L - 1) - (rm + 1);                                             // subRead(rightmost+1, length-1)
-                    fprintf(foutm, "@%s\n", r.name.c_str());
-                    fwrite(r.bases.data() + rm + 1, 1, (size_t)n2, foutm); fputs("\n+\n", foutm);
-                    fwrite(r.quals.data() + rm + 1, 1, (size_t)n2, foutm); fputc('\n', foutm);
+                    fprintf(fpieces, "@%s\n", r.name.c_str());
+                    fwrite(r.bases.data() + rm + 1, 1, (size_t)n2, fpieces); fputs("\n+\n", fpieces);
+                    fwrite(r.quals.data() + rm + 1, 1, (size_t)n2, fpieces); fputc('\n', fpieces);
                 }
                 continue;
             }
-            const int newLen = L - left - right;
+            int newLen = L - left - right;
+            if (P.trimFailuresTo1bp && (fl[i] & BBDUK_FLAG_DISCARDED) && newLen > 1) { right = L - left - 1; newLen = 1; }   // setDiscarded (:1464-1470)
             if (P.mode == BBDUK_MODE_KMASK && res[i] > 0) {            // :2309-2320
                 for (int b = 0; b < L; b++) {
                     const int64_t g = S.offsets[i - S.lo] + b;

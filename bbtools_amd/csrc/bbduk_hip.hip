@@ -33,7 +33,7 @@
 #include "bbduk_internal.h"
 #include "synth.h"
 
-static_assert(sizeof(bbduk_params) == 128, "bbduk_params layout is part of the ABI");
+static_assert(sizeof(bbduk_params) == 136, "bbduk_params layout is part of the ABI");
 static_assert(sizeof(bbduk_synth_params) == 80, "bbduk_synth_params layout is part of the ABI");
 
 #define BLOCK_THREADS   1024
@@ -415,6 +415,9 @@ __device__ __forceinline__ int trim_by_amount(int len, int left, int right, int 
     newLen = len - (left + right);
     return left + right;
 }
+// setDiscarded / isDiscarded with trimfailuresto1bp (BBDukProcessorS.java:1464-1482): a read that was to be discarded is cut to one base
+// (if it is longer), and "discarded" then means "exactly one base long" -- also for a read that is one base long for any other reason
+__device__ __forceinline__ void tf1bp(const KParams& P, bool& d, int& len) { if (P.tf) { if (d && len > 1) len = 1; d = (len == 1); } }
 __device__ __forceinline__ int imid(int lo, int x, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }   // value known wave-uniform -> SGPR
 
@@ -1399,11 +1402,19 @@ __device__ __forceinline__ void record_stage(const KParams& P, ReadOut& X, ReadO
 // counters (BBDukProcessorS.add, :300-342).  With rkt/xsum/outm and in-totals known, the rest follows:
 // readsOutu = readsIn - readsOutm; ktrim: basesOutu = basesIn - basesKTrimmed (every base either survives in a
 // kept pair or is counted as k-trimmed); kfilter: basesOutu = basesIn - basesOutm, filtered == removed.
+// trimfailuresto1bp (tf): nothing is evicted; the accumulators then hold rkt / xs = readsKTrimmed / basesKTrimmed or, for kfilter,
+// readsKFiltered / basesKFiltered, and bm = the bases that remain (rm = 0).
 template <int MODE>
-__device__ __forceinline__ void publish_counters(const unsigned long long* s_acc, int64_t* __restrict__ counters) {
+__device__ __forceinline__ void publish_counters(const unsigned long long* s_acc, int64_t* __restrict__ counters, const bool tf = false) {
     const unsigned long long rkt = s_acc[0], xs = s_acc[1], rm = s_acc[2], bm = s_acc[3], rin = s_acc[4], bin = s_acc[5];
     auto add = [&](int slot, unsigned long long v) { if (v) atomicAdd((unsigned long long*)&counters[slot], v); };
     add(BBDUK_READS_IN, rin); add(BBDUK_BASES_IN, bin);
+    if (tf) {
+        add(BBDUK_READS_OUTU, rin); add(BBDUK_BASES_OUTU, bm);
+        if (MODE == BBDUK_MODE_KFILTER) { add(BBDUK_READS_KFILTERED, rkt); add(BBDUK_BASES_KFILTERED, xs); }
+        else { add(BBDUK_READS_KTRIMMED, rkt); add(BBDUK_BASES_KTRIMMED, xs); }
+        return;
+    }
     add(BBDUK_READS_OUTM, rm); add(BBDUK_BASES_OUTM, bm);
     add(BBDUK_READS_OUTU, rin - rm);
     if (MODE == BBDUK_MODE_KSPLIT) {                              // :999-1013, 1431-1443: the split pieces leave through outm
@@ -1431,6 +1442,7 @@ void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
                         const int64_t n, const int64_t totalBases, const int paired,
                         int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
                         int64_t* __restrict__ counters, const int* __restrict__ slowFlag) {
+    if (P.tf) return;                                             // trimfailuresto1bp: bbduk_wave_kernel reports BBDUK_ERR_UNSUPPORTED for such batches
     if (*slowFlag != 1) return;                                   // 0: every unit fits a wave's planes, the wave kernel ran; 2/3: a unit
                                                                   // exceeds this kernel's planes too, bbduk_long_kernel takes the batch
     __shared__ uint32_t s_fwd[PLANE_PAD + CAP_CHUNKS + PLANE_PAD];   // padded both ends: the plain path reads past a read's end unclamped
@@ -1780,6 +1792,7 @@ void bbduk_kmask_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
     __shared__ unsigned long long s_acc[6];                       // rkt, basesKTrimmed, readsOutm, basesOutm, readsIn, basesIn
     extern __shared__ uint32_t s_filt[];
 
+    if (P.tf) return;                                             // trimfailuresto1bp: bbduk_wave_kernel reports BBDUK_ERR_UNSUPPORTED for such batches
     if (P.waveFirst && *longFlag == 0) return;                    // every unit fits a wave's planes: bbduk_wave_kernel<KMASK> did the batch
     const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
@@ -2099,6 +2112,7 @@ void bbduk_kscan_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
                         const int64_t n, const int64_t totalBases, const int paired,
                         int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
                         int32_t* __restrict__ outLeft, int32_t* __restrict__ outRight, int64_t* __restrict__ counters, const int* __restrict__ longFlag) {
+    if (P.tf) return;                                             // trimfailuresto1bp: bbduk_wave_kernel reports BBDUK_ERR_UNSUPPORTED for such batches
     if (*longFlag & 2) return;                                    // a read beyond these planes: bbduk_kscan_long_kernel takes the batch
     if (P.waveFirst && *longFlag == 0) return;                    // every read fits a wave's planes: bbduk_wave_kernel<KSPLIT> did the batch
     __shared__ uint32_t s_fwd[PLANE_PAD + KM_CAP_CHUNKS + PLANE_PAD];
@@ -2295,6 +2309,7 @@ void bbduk_ktrimtips_kernel(const KParams P, const uint8_t* __restrict__ bases, 
                             const int64_t n, const int64_t totalBases, const int paired,
                             int32_t* __restrict__ outRight, int32_t* __restrict__ outLeft, int32_t* __restrict__ outId,
                             uint8_t* __restrict__ outFlags, int64_t* __restrict__ counters, const int* __restrict__ longFlag) {
+    if (P.tf) return;                                             // trimfailuresto1bp: bbduk_wave_kernel reports BBDUK_ERR_UNSUPPORTED for such batches
     if (*longFlag & 2) return;                                    // a read beyond these planes: bbduk_long_tips_kernel takes the batch
     if (P.waveFirst && *longFlag == 0) return;                    // every unit fits a wave's planes: bbduk_wave_kernel<KTRIM_TIPS> did the batch
     __shared__ uint32_t s_fwd[PLANE_PAD + KM_CAP_CHUNKS + PLANE_PAD];
@@ -2529,7 +2544,10 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
         for (int w = tid; w < words; w += BLOCK_THREADS) s_filt[w] = P.ldsImage[w];
     }
     __syncthreads();
-    if (*slowFlag != 0) return;                                   // a unit does not fit a wave's planes: tile kernel's job
+    if (*slowFlag != 0) {                                         // a unit does not fit a wave's planes: tile kernel's job
+        if (P.tf && tid == 0 && blockIdx.x == 0) atomicMax((unsigned long long*)&counters[BBDUK_CTR_STATUS], (unsigned long long)(-BBDUK_ERR_UNSUPPORTED));
+        return;                                                   // (trimfailuresto1bp is served by this kernel only: the others stand back)
+    }
     // short-scan geometry: `lens` candidate lengths per read, rpp reads per 64-lane pass
     // first-hit-only operators verify candidates in batches (see main_scan_pair_cand)
     // (a big-layout map has its fast candidate form in the BIG instantiations only; elsewhere it takes the exact scans)
@@ -3036,28 +3054,31 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
             }
             a = any ? L - npl : 0; newLen = npl; hit = any; ref = vRef;
             if (hit) id = ref_to_id(P, ref);
-            remove = split != 0;                                    // remove=(r1.mate!=null): the two pieces go to outm together
+            remove = split != 0 && !P.tf;                           // remove=(r1.mate!=null): the two pieces go to outm together (trimfailuresto1bp: they stay, :1431)
             if (mine) {
                 outA[r0 + lane] = a; outId[r0 + lane] = id;
                 outFlags[r0 + lane] = (uint8_t)(remove ? BBDUK_FLAG_REMOVED : 0);
                 P.outLeft[r0 + lane] = any ? leftmost : -1; P.outRight[r0 + lane] = any ? rightmost : -1;
                 vRkt += a > 0 ? 1u : 0u; vXs += (unsigned)a;
                 if (remove) { vRm += 1; vBm += (unsigned)npl; }
+                if (P.tf) vBm += (unsigned)npl;
             }
         } else if constexpr (FBM) {
             // findBestMatch (:1064-1089): discard iff a scaffold was returned; the counters are kfilter's
             hit = mine && vScan && vRef > 0; ref = vRef; a = (mine && vScan) ? vFound : 0; newLen = vL;
             if (hit) id = ref_to_id(P, ref);
             if (P.matchN && mine && !vScan) P.matchN[r0 + lane] = 0;
+            int fLen = vL;
             if (P.storedKmers > 0) {
-                d = hit;
+                d = hit; tf1bp(P, d, fLen);
                 if (paired) { const bool dm = __shfl_xor((int)d, 1) != 0; remove = (P.rieb && (d || dm)) || (d && dm); }
                 else remove = d;
             }
             if (mine) {
                 outA[r0 + lane] = a; outId[r0 + lane] = (mine && vScan) ? vRef : -1;
-                outFlags[r0 + lane] = (uint8_t)((d ? BBDUK_FLAG_DISCARDED : 0) | (remove ? BBDUK_FLAG_REMOVED : 0));
-                if (remove) { vRm += 1; vBm += (unsigned)vL; }
+                outFlags[r0 + lane] = (uint8_t)((d ? BBDUK_FLAG_DISCARDED : 0) | ((remove && !P.tf) ? BBDUK_FLAG_REMOVED : 0));
+                if (P.tf) { if (remove) { vRkt += 1; vXs += (unsigned)vL; } vBm += (unsigned)fLen; }
+                else if (remove) { vRm += 1; vBm += (unsigned)vL; }
             }
         } else if constexpr (KMASK) {
             // ktrim=n (:984-998, 1009-1016, 1028-1029, 1431-1443): lengths stay, so the verdicts depend on them alone; the counters take the
@@ -3066,16 +3087,18 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
             if (hit) id = ref_to_id(P, ref);
             const float g = (float)vL * P.minLenFraction;
             const int minlenR = (int)(g > (float)P.minReadLength ? g : (float)P.minReadLength);
+            int fLen = vL;
             if (P.storedKmers > 0) {
-                d = vL < minlenR;
+                d = vL < minlenR; tf1bp(P, d, fLen);
                 if (paired) { const bool dm = __shfl_xor((int)d, 1) != 0; remove = (P.rieb && (d || dm)) || (d && dm); }
                 else remove = d;
             }
             if (mine) {
                 outA[r0 + lane] = a; outId[r0 + lane] = id;
-                outFlags[r0 + lane] = (uint8_t)((d ? BBDUK_FLAG_DISCARDED : 0) | (remove ? BBDUK_FLAG_REMOVED : 0));
+                outFlags[r0 + lane] = (uint8_t)((d ? BBDUK_FLAG_DISCARDED : 0) | ((remove && !P.tf) ? BBDUK_FLAG_REMOVED : 0));
                 vRkt += a > 0 ? 1u : 0u; vXs += (unsigned)a;
-                if (remove) { vRm += 1; vBm += (unsigned)vL; }
+                if (P.tf) vBm += (unsigned)fLen;
+                else if (remove) { vRm += 1; vBm += (unsigned)vL; }
             }
         } else if constexpr (TIPS) {
             // ktrim=rl (:954-967, 1009-1033): the left pass's outcome on the read as the right pass left it, then the pair rules on the final
@@ -3089,8 +3112,9 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
             id = tIdr >= 0 ? tIdr : (hit ? ref : -1);
             const float g = (float)vL0 * P.minLenFraction;
             const int minlenR = (int)(g > (float)P.minReadLength ? g : (float)P.minReadLength);
+            const int nPre = n1;                                    // rlen: what the two passes left (:960, 966)
             if (P.storedKmers > 0) {
-                d = n1 < minlenR;
+                d = n1 < minlenR; tf1bp(P, d, n1);
                 if (paired) { const bool dm = __shfl_xor((int)d, 1) != 0; remove = (P.rieb && (d || dm)) || (d && dm); }
                 else remove = d;
             }
@@ -3103,12 +3127,13 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
             a = xr; newLen = n1;
             if (mine) {
                 outA[r0 + lane] = xr; P.outLeft[r0 + lane] = xl; outId[r0 + lane] = id;
-                outFlags[r0 + lane] = (uint8_t)((d ? BBDUK_FLAG_DISCARDED : 0) | (remove ? BBDUK_FLAG_REMOVED : 0));
+                outFlags[r0 + lane] = (uint8_t)((d ? BBDUK_FLAG_DISCARDED : 0) | ((remove && !P.tf) ? BBDUK_FLAG_REMOVED : 0));
                 if (P.storedKmers > 0) {
                     vRkt += (remove || evened) ? 1u : ((xr + xl) > 0 ? 1u : 0u);
-                    vXs += (unsigned)(xr + xl) + (remove ? (unsigned)n1 : 0u);
+                    vXs += (unsigned)(xr + xl) + (remove ? (unsigned)nPre : 0u);
                 }
-                if (remove) { vRm += 1; vBm += (unsigned)n1; }
+                if (P.tf) vBm += (unsigned)n1;
+                else if (remove) { vRm += 1; vBm += (unsigned)n1; }
             }
         } else {
         finish_read<MODE>(P, vL, vStart, vStop, vFound, vFirst, vLast, vSFl, vSLl, vRef, a, newLen, ref, hit);
@@ -3117,8 +3142,10 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
         if (hit) id = ref_to_id(P, ref);
         const float g = (float)vL * P.minLenFraction;              // BBDukProcessorS.java:812-813
         const int minlenR = (int)(g > (float)P.minReadLength ? g : (float)P.minReadLength);
+        const int nPre = newLen;                                   // rlen: the length the k-trim left (:974, 980)
         if (P.storedKmers > 0) {
             d = (MODE != BBDUK_MODE_KFILTER) ? (newLen < minlenR) : ((GENERAL && P.mcf > 0.f) ? (a >= vThr) : (a > vThr));
+            tf1bp(P, d, newLen);
             if (paired) {
                 const bool dm = __shfl_xor((int)d, 1) != 0;         // my mate's verdict
                 remove = (P.rieb && (d || dm)) || (d && dm);        // shouldRemove (:1489-1492)
@@ -3132,12 +3159,13 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
         }
         if (mine) {
             outA[r0 + lane] = a; outId[r0 + lane] = id;
-            outFlags[r0 + lane] = (uint8_t)((d ? BBDUK_FLAG_DISCARDED : 0) | (remove ? BBDUK_FLAG_REMOVED : 0));
+            outFlags[r0 + lane] = (uint8_t)((d ? BBDUK_FLAG_DISCARDED : 0) | ((remove && !P.tf) ? BBDUK_FLAG_REMOVED : 0));
             if (MODE != BBDUK_MODE_KFILTER) {                       // :1011-1029, per read: the pair's sums are the mates' sums
                 vRkt += (remove || evened) ? 1u : (a > 0 ? 1u : 0u);   // evened pairs count both mates (rktsum -> 2)
-                vXs += (unsigned)a + (remove ? (unsigned)newLen : 0u);
-            }
-            if (remove) { vRm += 1; vBm += (unsigned)newLen; }
+                vXs += (unsigned)a + (remove ? (unsigned)nPre : 0u);
+            } else if (P.tf && remove) { vRkt += 1; vXs += (unsigned)vL; }        // readsKFiltered / basesKFiltered (:1079-1088)
+            if (P.tf) vBm += (unsigned)newLen;
+            else if (remove) { vRm += 1; vBm += (unsigned)newLen; }
         }
         }
         // scaffold counters (:2111-2119, :1577-1583): group the hit lanes by id, one cache update per distinct id
@@ -3186,7 +3214,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
         }
     }
     __syncthreads();
-    if (tid == 0) publish_counters<MODE == BBDUK_MODE_KTRIM_TIPS ? BBDUK_MODE_KTRIM_R : (MODE == BBDUK_MODE_FBM ? BBDUK_MODE_KFILTER : MODE)>(s_acc, counters);
+    if (tid == 0) publish_counters<MODE == BBDUK_MODE_KTRIM_TIPS ? BBDUK_MODE_KTRIM_R : (MODE == BBDUK_MODE_FBM ? BBDUK_MODE_KFILTER : MODE)>(s_acc, counters, P.tf != 0);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -3230,6 +3258,7 @@ void bbduk_long_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                        const int64_t n, const int64_t totalBases, const int paired,
                        int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
                        int64_t* __restrict__ counters, const int* __restrict__ slowFlag) {
+    if (P.tf) return;                                             // trimfailuresto1bp: bbduk_wave_kernel reports BBDUK_ERR_UNSUPPORTED for such batches
     if ((*slowFlag & 2) == 0) return;
     __shared__ uint32_t s_wf[NWAVES * WPLANE_WORDS];
     __shared__ uint32_t s_wc[NWAVES * WPLANE_WORDS];
@@ -3343,6 +3372,7 @@ void bbduk_kmask_long_kernel(const KParams P, const uint8_t* __restrict__ bases,
                              const int64_t n, const int64_t totalBases, const int paired,
                              int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint32_t* __restrict__ outMask,
                              int64_t* __restrict__ counters, const int* __restrict__ longFlag) {
+    if (P.tf) return;                                             // trimfailuresto1bp: bbduk_wave_kernel reports BBDUK_ERR_UNSUPPORTED for such batches
     if (*longFlag == 0) return;
     __shared__ uint32_t s_wf[NWAVES * WPLANE_WORDS];
     __shared__ uint32_t s_wc[NWAVES * WPLANE_WORDS];
@@ -3538,6 +3568,7 @@ void bbduk_kscan_long_kernel(const KParams P, const uint8_t* __restrict__ bases,
                              const int64_t n, const int64_t totalBases, const int paired,
                              int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
                              int32_t* __restrict__ outLeft, int32_t* __restrict__ outRight, int64_t* __restrict__ counters, const int* __restrict__ longFlag) {
+    if (P.tf) return;                                             // trimfailuresto1bp: bbduk_wave_kernel reports BBDUK_ERR_UNSUPPORTED for such batches
     if ((*longFlag & 2) == 0) return;
     __shared__ uint32_t s_wf[NWAVES * WPLANE_WORDS];
     __shared__ uint32_t s_wc[NWAVES * WPLANE_WORDS];
@@ -3719,6 +3750,7 @@ void bbduk_long_tips_kernel(const KParams P, const uint8_t* __restrict__ bases, 
                             const int64_t n, const int64_t totalBases, const int paired,
                             int32_t* __restrict__ outRight, int32_t* __restrict__ outLeft, int32_t* __restrict__ outId,
                             uint8_t* __restrict__ outFlags, int64_t* __restrict__ counters, const int* __restrict__ longFlag) {
+    if (P.tf) return;                                             // trimfailuresto1bp: bbduk_wave_kernel reports BBDUK_ERR_UNSUPPORTED for such batches
     if ((*longFlag & 2) == 0) return;
     __shared__ uint32_t s_wf[NWAVES * WPLANE_WORDS];
     __shared__ uint32_t s_wc[NWAVES * WPLANE_WORDS];
@@ -3938,6 +3970,8 @@ extern "C" int bbduk_create(const bbduk_params* p, bbduk_handle** out) {
     if (p->minlen != p->k - 1) return BBDUK_ERR_ARG;
     if (p->speed < 0 || p->speed > 16 || p->qSkip < 0) return BBDUK_ERR_ARG;    // BBDukParser.java:568
     if (p->kmaskFullyCovered && p->mode != BBDUK_MODE_KMASK) return BBDUK_ERR_ARG;
+    if (p->trimFailuresTo1bp && p->kbig > p->k && !(p->minCoveredFraction > 0.f)) return BBDUK_ERR_ARG;   // k>31 runs on the tiled kernel only
+    if (p->reserved0 != 0) return BBDUK_ERR_ARG;
     const bool big = p->kbig > p->k;
     if (big) {                                                                  // BBDukParser.java:164, 207-243, 299
         if (p->k != 31 || p->kbig > BBDUK_MAX_READ_LEN) return BBDUK_ERR_ARG;
@@ -4384,6 +4418,8 @@ static KParams make_kparams(const bbduk_handle* h) {
     K.mkf = p.mode == BBDUK_MODE_KFILTER ? p.minKmerFraction : 0.f; K.mcf = p.mode == BBDUK_MODE_KFILTER ? p.minCoveredFraction : 0.f;
     K.kbig = p.kbig > p.k ? p.kbig : p.k; K.fbm = p.findBestMatch ? 1 : 0;
     K.mfc = (p.kmaskFullyCovered && p.mode == BBDUK_MODE_KMASK) ? 1 : 0;
+    K.tf = p.trimFailuresTo1bp ? 1 : 0;
+    if (K.tf) K.rieb = 0;                                          // BBDukParser.java:109
     K.numScaffolds = p.numScaffolds;
     K.useShort = (p.mink > 0 && p.mink < p.k) ? 1 : 0;
     K.mask = (2 * p.k > 63) ? ~0ULL : ~(~0ULL << (2 * p.k));
@@ -4671,7 +4707,7 @@ static int host_batch(bbduk_handle* h, int wantKfilter, const uint8_t* bases, co
         int64_t z = 0;
         hipMemcpyAsync(h->d_counters + BBDUK_CTR_STATUS, &z, sizeof z, hipMemcpyHostToDevice, st);
         hipStreamSynchronize(st);
-        return fail(h, -(int)status, "device reported an error (read longer than BBDUK_MAX_READ_LEN?)");
+        return fail(h, -(int)status, "device reported an error (a read longer than BBDUK_MAX_READ_LEN, or trimfailuresto1bp on a unit beyond the main kernel's planes)");
     }
     return BBDUK_OK;
 }
@@ -4790,7 +4826,7 @@ extern "C" int bbduk_ktrimtips_batch(bbduk_handle* h, const uint8_t* bases, cons
     if (status != 0) {
         int64_t z = 0;
         hipMemcpy(h->d_counters + BBDUK_CTR_STATUS, &z, sizeof z, hipMemcpyHostToDevice);
-        return fail(h, -(int)status, "device reported an error (read longer than BBDUK_MAX_READ_LEN?)");
+        return fail(h, -(int)status, "device reported an error (a read longer than BBDUK_MAX_READ_LEN, or trimfailuresto1bp on a unit beyond the main kernel's planes)");
     }
     return BBDUK_OK;
 }
@@ -4950,7 +4986,7 @@ extern "C" int bbduk_kmask_batch(bbduk_handle* h, const uint8_t* bases, const in
     if (status != 0) {
         int64_t z = 0;
         hipMemcpy(h->d_counters + BBDUK_CTR_STATUS, &z, sizeof z, hipMemcpyHostToDevice);
-        return fail(h, -(int)status, "device reported an error (read longer than BBDUK_MAX_READ_LEN?)");
+        return fail(h, -(int)status, "device reported an error (a read longer than BBDUK_MAX_READ_LEN, or trimfailuresto1bp on a unit beyond the main kernel's planes)");
     }
     return BBDUK_OK;
 }

@@ -41,6 +41,7 @@ struct Parsed {                      // bbduk/BBDukParser.java fields (subset th
     float minKmerFraction = 0.f, minCoveredFraction = 0.f;   // :1234-1236
     bool ksplit = false, findBestMatch = false, rename = false;   // :1313, 1323, 1367
     bool kmaskFullyCovered = false;                          // :1317
+    bool trimFailuresTo1bp = false;                          // BBDukParser.java:774, 1359
     int kbig = -1;                                           // :1226 (derived: the requested k when it exceeds 31)
     std::vector<std::string> ref, literal;
     // derived (:130-312)
@@ -276,6 +277,7 @@ extern "C" int bbduk_host_parse(const char* args, bbduk_host** out, char* errbuf
         else if (a == "minhits" || a == "minkmerhits" || a == "mkh") { need_int(p.maxBadKmers0); p.maxBadKmers0 -= 1; }
         else if (a == "ml" || a == "minlen" || a == "minlength") need_int(p.minReadLength);
         else if (a == "mlf" || a == "minlenfrac" || a == "minlenfraction" || a == "minlengthfraction") { char* e; p.minLenFraction = strtof(b.c_str(), &e); ok = !b.empty() && !*e; }
+        else if (a == "trimfailures" || a == "trimfailuresto1bp") need_bool(p.trimFailuresTo1bp);                   // BBDukParser.java:773-774
         else if (a == "requirebothbad" || a == "rbb") need_bool(p.requireBothBad);
         else if (a == "removeifeitherbad" || a == "rieb") { bool x = true; need_bool(x); p.requireBothBad = !x; }
         else if (a == "trimextra" || a == "trimpad" || a == "tp") need_int(p.trimPad);
@@ -452,7 +454,8 @@ extern "C" int bbduk_host_params(const bbduk_host* h, int32_t device, bbduk_para
     out->minlen = p.minlen; out->minlen2 = p.minlen2; out->middleMask = p.middleMask;
     out->qhdist = p.qhdist; out->qhdist2 = p.qhdist2; out->maxBadKmers = p.maxBadKmers0;
     out->minReadLength = p.minReadLength; out->minLenFraction = p.minLenFraction;
-    out->removePairsIfEitherBad = !p.requireBothBad;                        // BBDukParser.java:109 (trimFailuresTo1bp=false)
+    out->removePairsIfEitherBad = (!p.requireBothBad) && (!p.trimFailuresTo1bp);   // BBDukParser.java:109
+    out->trimFailuresTo1bp = p.trimFailuresTo1bp ? 1 : 0;
     out->trimPad = p.trimPad; out->ktrimExclusive = p.ktrimExclusive;
     out->restrictLeft = p.restrictLeft; out->restrictRight = p.restrictRight;
     out->skipR1 = p.skipR1; out->skipR2 = p.skipR2;

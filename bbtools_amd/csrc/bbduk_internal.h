@@ -17,6 +17,7 @@ struct KParams {
     int32_t tpe, qskip, speed;   // trimpairsevenly; qskip (<2 = off) and speed (0 = off) run in the general kernels only
     float   mkf, mcf;            // kfilter: minkmerfraction / mincoveredfraction (general kernels only)
     int32_t mfc;                 // kmaskfullycovered (ktrim=n): mask only bases all of whose covering k-mers match
+    int32_t tf;                  // trimfailuresto1bp (rieb is then off): see tf1bp()
     int32_t kbig, fbm;           // kfilter variants of bbduk_kscan_kernel: k>31 emulation (kbig>k), findBestMatch
     int32_t* matchN; int32_t* matchIds; int32_t* matchCnt; int32_t matchCap;    // findBestMatch's idList / countList per read (rename, :2508-2522), or null
     int32_t* outLeft; int32_t* outRight;   // ksplit: the span it computes per read (leftmost, rightmost), or -1, -1

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define BBDUK_ABI_VERSION 1
+#define BBDUK_ABI_VERSION 2
 
 /* status codes */
 #define BBDUK_OK                 0
@@ -47,6 +47,7 @@ extern "C" {
 #define BBDUK_ERR_DEVICE        -4   /* a HIP call failed; see bbduk_last_error           */
 #define BBDUK_ERR_READ_TOO_LONG -5   /* a read exceeds BBDUK_MAX_READ_LEN                  */
 #define BBDUK_ERR_ID_OVERFLOW   -6   /* findBestMatch: a read hit more than 64 distinct scaffolds */
+#define BBDUK_ERR_UNSUPPORTED   -8   /* trimfailuresto1bp on a batch with a unit beyond the main kernel's planes (2512 bases per pair) */
 #define BBDUK_ERR_FORMAT        -7   /* FASTQ ingest: a record without '@' / '+' or with unequal base and quality lines */
 
 #define BBDUK_MAX_READ_LEN   16384   /* reads up to this length go through the LDS-tiled kernels; longer ones (any length that
@@ -104,6 +105,12 @@ typedef struct bbduk_params {
                                        hits, out_found = hits counted; needs maxBadKmers == 0 and minKmerFraction == 0 */
     int32_t kmaskFullyCovered;      /* kmaskfullycovered / mfc (ktrim=n; BBDukProcessorS.java:2163, 2193-2195, 2243-2245, 2286-2288): only
                                        bases all of whose covering k-mers match stay masked */
+    int32_t trimFailuresTo1bp;      /* trimfailures / trimfailuresto1bp (BBDukParser.java:105-109, 774; BBDukProcessorS.java:1431, 1464-1488): a read that
+                                       would be discarded is cut to its FIRST base instead, "discarded" then means "one base long", pairs are
+                                       removed only when both mates are, and nothing is evicted: BBDUK_FLAG_DISCARDED marks the reads to cut
+                                       (after the k-trim the operator reports), BBDUK_FLAG_REMOVED is never set, readsOutm stays 0.  Served
+                                       by the main kernel (every unit <= 2512 bases); longer units and k>31: BBDUK_ERR_UNSUPPORTED / _ARG */
+    int32_t reserved0;              /* 0 */
 } bbduk_params;
 
 typedef struct bbduk_handle bbduk_handle;

@@ -38,7 +38,7 @@ public final class BBDukGpu {
 
 	/** ip = {mode,k,mink,rcomp,forbidNs,minlen,minlen2,qhdist,qhdist2,maxBadKmers,minReadLength,
 	 *  removePairsIfEitherBad,trimPad,ktrimExclusive,restrictLeft,restrictRight,skipR1,skipR2,numScaffolds,device,
-	 *  trimPairsEvenly,qSkip,speed,kbig,findBestMatch,kmaskFullyCovered};  fp = {minLenFraction,minKmerFraction,minCoveredFraction} */
+	 *  trimPairsEvenly,qSkip,speed,kbig,findBestMatch,kmaskFullyCovered,trimFailuresTo1bp};  fp = {minLenFraction,minKmerFraction,minCoveredFraction} */
 	private static native long createJNI(int[] ip, long middleMask, float[] fp);
 	private static native int uploadWayJNI(long h, int way, int prime, long[] keys, int[] values, long[] vkeys, int[] vvals);
 	private static native int uploadPairsJNI(long h, long[] keys, int[] values);
@@ -81,7 +81,7 @@ public final class BBDukGpu {
 				p.removePairsIfEitherBad ? 1 : 0, p.trimPad, p.ktrimExclusive ? 1 : 0,
 				p.restrictLeft, p.restrictRight, p.skipR1 ? 1 : 0, p.skipR2 ? 1 : 0, numScaffolds, device,
 				p.trimPairsEvenly ? 1 : 0, p.qSkip, p.speed, (p.kbig>p.k ? p.kbig : 0), (p.findBestMatch && mode==MODE_KFILTER) ? 1 : 0,
-				(p.kmaskFullyCovered && mode==MODE_KMASK) ? 1 : 0};
+				(p.kmaskFullyCovered && mode==MODE_KMASK) ? 1 : 0, p.trimFailuresTo1bp ? 1 : 0};
 		final float[] fp={p.minLenFraction, p.minKmerFraction, p.minCoveredFraction};
 		final long h=createJNI(ip, p.middleMask, fp);
 		if(h<=0){throw new RuntimeException("bbduk_create failed: "+h);}

@@ -32,9 +32,9 @@ static void* dbuf(JNIEnv* env, jobject buf, jlong need, int* bad) {
 }
 
 JNIEXPORT jlong JNICALL Java_bbduk_BBDukGpu_createJNI(JNIEnv* env, jclass cls, jintArray ip, jlong middleMask, jfloatArray fp) {
-    jint v[26]; jfloat f[3];
-    if ((*env)->GetArrayLength(env, ip) < 26 || (*env)->GetArrayLength(env, fp) < 3) return BBDUK_ERR_ARG;
-    (*env)->GetIntArrayRegion(env, ip, 0, 26, v);
+    jint v[27]; jfloat f[3];
+    if ((*env)->GetArrayLength(env, ip) < 27 || (*env)->GetArrayLength(env, fp) < 3) return BBDUK_ERR_ARG;
+    (*env)->GetIntArrayRegion(env, ip, 0, 27, v);
     (*env)->GetFloatArrayRegion(env, fp, 0, 3, f);
     bbduk_params p;
     memset(&p, 0, sizeof p);
@@ -45,6 +45,7 @@ JNIEXPORT jlong JNICALL Java_bbduk_BBDukGpu_createJNI(JNIEnv* env, jclass cls, j
     p.removePairsIfEitherBad = v[11]; p.trimPad = v[12]; p.ktrimExclusive = v[13];
     p.restrictLeft = v[14]; p.restrictRight = v[15]; p.skipR1 = v[16]; p.skipR2 = v[17]; p.numScaffolds = v[18]; p.device = v[19];
     p.trimPairsEvenly = v[20]; p.qSkip = v[21]; p.speed = v[22]; p.kbig = v[23]; p.findBestMatch = v[24]; p.kmaskFullyCovered = v[25];
+    p.trimFailuresTo1bp = v[26];
     p.minLenFraction = f[0]; p.minKmerFraction = f[1]; p.minCoveredFraction = f[2];
     bbduk_handle* h = NULL;
     const int rc = bbduk_create(&p, &h);

@@ -224,7 +224,7 @@ void bbo_default_args(bbo_args* a) {
     a->minSkip = 1; a->maxSkip = 1;
     a->trimPairsEvenly = 0; a->qSkip = 1; a->speed = 0;
     a->minKmerFraction = 0.f; a->minCoveredFraction = 0.f; a->ktrimN = 0;
-    a->kbig = -1; a->findBestMatch = 0; a->ksplit = 0; a->kmaskFullyCovered = 0;
+    a->kbig = -1; a->findBestMatch = 0; a->ksplit = 0; a->kmaskFullyCovered = 0; a->trimFailuresTo1bp = 0;
 }
 
 static int imax(int a, int b) { return a > b ? a : b; }
@@ -293,7 +293,7 @@ bbo_ctx* bbo_create(const bbo_args* a) {
         c->middleMask = (int64_t)~((~(~0ULL << bits)) << shift);
     } else c->middleMask = -1LL;
     /* :105-109 */
-    c->trimFailuresTo1bp = 0;
+    c->trimFailuresTo1bp = a->trimFailuresTo1bp ? 1 : 0;
     c->removePairsIfEitherBad = (!a->requireBothBad) && (!c->trimFailuresTo1bp);
     for (int w = 0; w < WAYS; w++) ha_init(&c->keySets[w]);
     c->numScaffolds = 1;                                    /* scaffoldNames.add("") : first id is 1 */
@@ -1088,6 +1088,10 @@ int bbo_count_set_kmers(bbo_ctx* c, const uint8_t* bases, int len, int pairnum, 
 /* bbduk/BBDukProcessorS.java:778-1093,1431-1443 -- one pair (r2len<0 => unpaired), k-mer stage only.
  * Everything before the k-mer stage (junk/chastity/GC/force-trim...) and after it (tbo/qtrim/...) is off
  * in every BASELINE config and stays in the Java host. */
+/* setDiscarded / isDiscarded with trimFailuresTo1bp (:1464-1482): a read that was to be discarded is cut to one base (if it is longer),
+ * and from then on "discarded" means "exactly one base long" -- which also holds for a read that is one base long for any other reason */
+#define TF1BP(d, len) do { if (c->trimFailuresTo1bp) { if ((d) && (len) > 1) (len) = 1; (d) = ((len) == 1); } } while (0)
+
 static void process_pair(const bbo_ctx* c, tcounters* tc, const uint8_t* b1, int l1, const uint8_t* b2, int l2, int has2,
                          int32_t* a, int32_t* ids, uint8_t* fl, uint32_t* gmask, int64_t g1, int64_t g2, int32_t* xleft, int32_t* xright) {
     const int initialLength1 = l1, initialLength2 = has2 ? l2 : 0;
@@ -1128,6 +1132,7 @@ static void process_pair(const bbo_ctx* c, tcounters* tc, const uint8_t* b1, int
             if (l2 < minlen2) d2 = 1;
             a[1] = x; ids[1] = id0;
         }
+        TF1BP(d1, newLen1); if (has2) TF1BP(d2, newLen2);
         if ((c->removePairsIfEitherBad && (d1 || d2)) || (d1 && (!has2 || d2))) remove = 1;   /* ktrimN: xsum/rktsum unchanged (:1011) */
         tc->counters[BBO_BASES_KTRIMMED] += xsum;
         tc->counters[BBO_READS_KTRIMMED] += rktsum;
@@ -1147,6 +1152,7 @@ static void process_pair(const bbo_ctx* c, tcounters* tc, const uint8_t* b1, int
             if (rlen2 < minlen2) d2 = 1;
             a[1] = x; ids[1] = id0;
         }
+        TF1BP(d1, newLen1); if (has2) TF1BP(d2, newLen2);                             /* rlen1 / rlen2 keep the lengths ktrim left (:960, 966) */
         /* shouldRemove (:1489-1492) */
         if ((c->removePairsIfEitherBad && (d1 || d2)) || (d1 && (!has2 || d2))) {
             xsum += (rlen1 + rlen2);                                                  /* :1011-1014 (!ktrimN) */
@@ -1174,6 +1180,7 @@ static void process_pair(const bbo_ctx* c, tcounters* tc, const uint8_t* b1, int
             a[1] = cov2; ids[1] = id;
             if (cov2 >= mc2) d2 = 1;
         }
+        TF1BP(d1, newLen1); if (has2) TF1BP(d2, newLen2);                             /* (a one-base read is "discarded" before it is looked at, :1040) */
         if ((c->removePairsIfEitherBad && (d1 || d2)) || (d1 && (!has2 || d2))) {
             remove = 1;
             tc->counters[BBO_READS_KFILTERED]++; tc->counters[BBO_BASES_KFILTERED] += initialLength1;
@@ -1205,12 +1212,14 @@ static void process_pair(const bbo_ctx* c, tcounters* tc, const uint8_t* b1, int
                 if (bv > maxBadKmersR2) d2 = 1;
             }
         }
+        TF1BP(d1, newLen1); if (has2) TF1BP(d2, newLen2);
         if ((c->removePairsIfEitherBad && (d1 || d2)) || (d1 && (!has2 || d2))) {
             remove = 1;
             tc->counters[BBO_READS_KFILTERED]++; tc->counters[BBO_BASES_KFILTERED] += initialLength1;
             if (has2) { tc->counters[BBO_READS_KFILTERED]++; tc->counters[BBO_BASES_KFILTERED] += initialLength2; }
         }
     }
+    if (remove && c->trimFailuresTo1bp) remove = 0;                                   /* :1431: flagged, counted above, but not evicted */
     if (remove) {                                                                     /* :1431-1443 */
         tc->counters[BBO_READS_OUTM] += pairCount;
         tc->counters[BBO_BASES_OUTM] += newLen1 + newLen2;

@@ -55,6 +55,8 @@ typedef struct bbo_args {
     int findBestMatch;  /* findbestmatch / fbm (BBDukProcessorS.java:1659-1719; rename is not restated) */
     int ksplit;         /* ksplit=t (BBDukProcessorS.java:2332-2506; unpaired reads) */
     int kmaskFullyCovered; /* kmaskfullycovered / mfc (:2163, 2193-2195, 2243-2245, 2286-2288) */
+    int trimFailuresTo1bp; /* trimfailures / trimfailuresto1bp (BBDukParser.java:105-109, 774; BBDukProcessorS.java:1431, 1464-1488): a discarded read
+                              is cut to its first base instead, "discarded" means "one base long", and nothing is evicted */
 } bbo_args;
 
 #define BBO_NCOUNTERS 16

@@ -19,7 +19,7 @@ class BboArgs(C.Structure):
                [(n, C.c_int) for n in ("requireBothBad", "trimPad", "ktrimExclusive", "restrictLeft", "restrictRight",
                                        "skipR1", "skipR2", "minSkip", "maxSkip", "trimPairsEvenly", "qSkip", "speed")] + \
                [("minKmerFraction", C.c_float), ("minCoveredFraction", C.c_float), ("ktrimN", C.c_int),
-                ("kbig", C.c_int), ("findBestMatch", C.c_int), ("ksplit", C.c_int), ("kmaskFullyCovered", C.c_int)]
+                ("kbig", C.c_int), ("findBestMatch", C.c_int), ("ksplit", C.c_int), ("kmaskFullyCovered", C.c_int), ("trimFailuresTo1bp", C.c_int)]
 
 
 def build(force: bool = False) -> str:

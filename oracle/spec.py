@@ -75,6 +75,7 @@ class Args:
     findBestMatch: bool = False     # findbestmatch / fbm (kfilter only; rename is not restated)
     ksplit: bool = False            # ksplit=t (unpaired reads only)
     kmaskFullyCovered: bool = False # kmaskfullycovered / mfc: mask only bases covered by matching k-mers in every window
+    trimFailuresTo1bp: bool = False # trimfailures: discarded reads are cut to one base instead; nothing is evicted (:1431, 1464-1488)
     minSkip: int = 1                # rskip / minskip / maxskip: reference-side k-mer skipping (BBDukLoader.java:417, 432-449)
     maxSkip: int = 1
 
@@ -117,7 +118,7 @@ class Spec:
         assert not (self.kbig > k and not self.kfilter) and not (self.kbig > k and (a.speed > 0 or a.qSkip > 1))   # :207-223 reduce kbig to k
         assert not (a.findBestMatch and self.kbig > k)                             # :299
         self.splits = []           # ksplit: per-read (leftmost, rightmost) or (-1, -1), process order
-        self.rieb = not a.requireBothBad                                           # :109
+        self.rieb = (not a.requireBothBad) and (not a.trimFailuresTo1bp)           # :109
         self.table = {}            # key -> id  (first writer wins == smallest id; ids ascend in file order)
         self.nscaf = 1             # scaffoldNames[0] reserved (bbduk/BBDukIndex.java:105-107)
         self.counters = [0] * NCOUNTERS
@@ -650,6 +651,14 @@ class Spec:
         d1 = d2 = remove = False
         n1, n2 = l1, l2
         res = []
+
+        def tf(d, n):
+            """setDiscarded / isDiscarded under trimfailuresto1bp (:1464-1482): cut to one base, and 'discarded' = one base long"""
+            if not a.trimFailuresTo1bp:
+                return d, n
+            if d and n > 1:
+                n = 1
+            return n == 1, n
         if self.table and a.ktrimN and not (a.ktrimLeft or a.ktrimRight):              # :984-998, 1009-1016
             x1, i1, m1 = self.kmask_read(r1, 0)
             xsum, rkt = x1, int(x1 > 0)
@@ -659,6 +668,8 @@ class Spec:
                 x2, i2, m2 = self.kmask_read(r2, 1)
                 xsum += x2; rkt += int(x2 > 0)
                 d2 = n2 < minlen2
+            d1, n1 = tf(d1, n1)
+            if has2: d2, n2 = tf(d2, n2)
             if (self.rieb and (d1 or d2)) or (d1 and (not has2 or d2)):
                 remove = True
             C[3] += xsum; C[2] += rkt
@@ -688,8 +699,11 @@ class Spec:
                     x2, i2, n2 = self.ktrim(r2, 1)
                 xsum += x2; rkt += int(x2 > 0)
                 d2 = n2 < minlen2
+            rl1, rl2 = n1, n2                                                          # rlen1 / rlen2: what ktrim left
+            d1, n1 = tf(d1, n1)
+            if has2: d2, n2 = tf(d2, n2)
             if (self.rieb and (d1 or d2)) or (d1 and (not has2 or d2)):
-                xsum += n1 + n2; rkt = pc; remove = True
+                xsum += rl1 + rl2; rkt = pc; remove = True
             elif a.ktrimRight and a.trimPairsEvenly and xsum > 0 and has2 and n1 != n2:        # :1021-1031
                 if n1 > n2:
                     x, n1 = self._trim_by_amount(n1, 0, n1 - (n2 - 1) - 1, 1); x1 += x
@@ -714,6 +728,8 @@ class Spec:
                 f2, i2 = self.count_covered_bases(r2, 1, mc2)
                 d2 = f2 >= mc2
                 res.append((f2, i2))
+            d1, n1 = tf(d1, n1)
+            if has2: d2, n2 = tf(d2, n2)
             if (self.rieb and (d1 or d2)) or (d1 and (not has2 or d2)):
                 remove = True
                 C[4] += pc; C[5] += l1 + l2
@@ -731,11 +747,15 @@ class Spec:
                 f2, i2 = count(r2, 1, mb2)
                 d2 = i2 > 0 if a.findBestMatch else f2 > mb2
                 res.append((f2, i2))
+            d1, n1 = tf(d1, n1)
+            if has2: d2, n2 = tf(d2, n2)
             if (self.rieb and (d1 or d2)) or (d1 and (not has2 or d2)):
                 remove = True
                 C[4] += pc; C[5] += l1 + l2
         else:
             res = [(0, -1)] * pc
+        if remove and a.trimFailuresTo1bp:
+            remove = False                                                             # :1431: flagged and counted, not evicted
         if remove:
             C[8] += pc; C[9] += n1 + n2
         else:

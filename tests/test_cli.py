@@ -231,3 +231,29 @@ def test_cli_devices_shards_batches_and_allreduces_counters(tmp_path, mode):
 def test_cli_refuses_a_quote_in_a_gz_path(tmp_path):
     r = run_cli(["in=" + str(tmp_path / "x';touch PWNED;'.fq.gz"), "ktrim=r", "k=23", "ref=adapters"])
     assert r.returncode == 1 and not os.path.exists(os.path.join(ROOT, "PWNED"))
+
+
+@pytest.mark.gpu
+def test_cli_trimfailuresto1bp_cuts_instead_of_removing(tmp_path):
+    """trimfailures=t (BBDukParser.java:774): what the plain run sends to outm stays, cut to one base; nothing is evicted (:1431)."""
+    tsv0, tsv1, out, outm = (str(tmp_path / n) for n in ("plain.tsv", "tf.tsv", "clean.fq", "removed.fq"))
+    base = ["in=" + os.path.join(GOLD, "cli_c3_interleaved.fq"), "int=t", "k=31", "hdist=1", "ref=phix"]
+    r0 = run_cli(base + ["tsv=" + tsv0, "rieb=f"])
+    r1 = run_cli(base + ["tsv=" + tsv1, "out=" + out, "outm=" + outm, "trimfailures=t"])
+    assert r0.returncode == 0 and r1.returncode == 0, r0.stderr + r1.stderr
+    plain = [l.split("\t") for l in open(tsv0).read().splitlines()]
+    tf = [l.split("\t") for l in open(tsv1).read().splitlines()]
+    src = {n: (b, q) for n, b, q in _read_fastq(os.path.join(GOLD, "cli_c3_interleaved.fq"))}
+    kept = _read_fastq(out)
+    assert len(kept) == len(tf) and len(_read_fastq(outm)) == 0
+    ncut = 0
+    for (name, L, a, _id, new_len, flags), p, (kn, kb, kq) in zip(tf, plain, kept):
+        assert name == p[0] == kn and a == p[2] and int(flags) & 2 == 0
+        discarded = int(p[5]) & 1                    # the same k-mer verdict per read (rieb=f: the discard bit alone)
+        assert (int(flags) & 1) == discarded
+        want = 1 if (discarded and int(L) > 1) else int(L)
+        assert int(new_len) == want and kb == src[name][0][:want] and kq == src[name][1][:want]
+        ncut += discarded
+    assert ncut > 0 and "Contaminants:" in r1.stderr
+    r = run_cli(base + ["trimfailures=t", "deviceingest=t"])
+    assert r.returncode != 0 and "trimfailuresto1bp" in r.stderr

@@ -985,3 +985,73 @@ def test_abi_error_codes():
                                          nid.ctypes.data, mi.ctypes.data, mc.ctypes.data) == 0
     assert nid.tolist() == [1, 0] and mi[0, 0] == 1 and mc[0, 0] == 34 - 23 + 1 and ids[0] == 1
     d.close()
+
+
+# ---------------------------------------------------------------------------------------------- trimfailuresto1bp (BBDukParser.java:105-109, 774)
+def tf1bp_config(rng):
+    """One random configuration of every operator family with trimfailures=t on top."""
+    fam = rng.choice(["r", "r", "l", "rl", "n", "f", "f", "fbm", "mcf", "ksplit"])
+    k = rng.choice([11, 13, 17, 21, 23, 27])
+    okw, args = dict(k=k, trimFailuresTo1bp=1), ["k=%d" % k, "trimfailures=t"]
+    if fam in ("r", "l", "rl", "n", "ksplit") and rng.random() < 0.6:
+        mk = rng.randint(max(1, k - 12), k - 1); okw["mink"] = mk; args.append("mink=%d" % mk)
+    if fam == "r": okw["ktrimRight"] = 1; args.append("ktrim=r")
+    elif fam == "l": okw["ktrimLeft"] = 1; args.append("ktrim=l")
+    elif fam == "rl": okw["ktrimRight"] = okw["ktrimLeft"] = 1; args.append("ktrim=rl")
+    elif fam == "n": okw["ktrimN"] = 1; args.append("ktrim=n")
+    elif fam == "ksplit": okw["ksplit"] = 1; args.append("ksplit=t")
+    elif fam == "fbm": okw["findBestMatch"] = 1; args.append("fbm=t")
+    elif fam == "mcf": okw["minCoveredFraction"] = 0.3; args.append("mcf=0.3")
+    elif rng.random() < 0.4: v = rng.randint(1, 3); okw["maxBadKmers0"] = v; args.append("mbk=%d" % v)
+    if fam in ("r", "rl") and rng.random() < 0.6: okw["trimPairsEvenly"] = 1; args.append("tpe")
+    if rng.random() < 0.5: okw["hdist"] = 1; args.append("hdist=1")
+    if rng.random() < 0.3: okw["requireBothBad"] = 1; args.append("rieb=f")          # (off anyway: trimfailures turns rieb off, :109)
+    v = rng.choice([1, 2, 10, 10, 40, 100]); okw["minReadLength"] = v; args.append("minlen=%d" % v)
+    if rng.random() < 0.3: okw["minLenFraction"] = 0.6; args.append("mlf=0.6")
+    if rng.random() < 0.2: okw["forbidN"] = 1; args.append("forbidn=t")
+    if rng.random() < 0.15: okw["restrictRight"] = 60; args.append("restrictright=60")     # a GENERAL instantiation
+    return fam, " ".join(args), okw
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block", range(8))
+def test_trimfailuresto1bp_parity(block):
+    rng = random.Random(4242 + block)
+    ncut = 0
+    for _ in range(6):
+        fam, args, okw = tf1bp_config(rng)
+        refs = [util.rand_seq(rng, rng.randint(12, 90), 0.01) for _ in range(6)]
+        d, o = make_pair(args, okw, refs=refs)
+        reads = util.fuzz_reads(rng, refs, 500, [0, 1, 2, 3, 9, 10, 12, 22, 23, 31, 40, 64, 75, 150, 151, 300], junk=True)
+        try:
+            if fam == "n":
+                check_kmask(d, o, reads, True); check_kmask(d, o, reads[:201], False)
+            elif fam == "rl":
+                check_tips(d, o, reads, True); check_tips(d, o, reads[:201], False)
+            elif fam == "ksplit":
+                gf = check_split(d, o, reads); assert not (gf & B.FLAG_REMOVED).any()
+            else:
+                check_batch(d, o, reads, True); check_batch(d, o, reads[:201], False)
+            c = d.gpu.counters()
+            assert c[8] == 0 and c[9] == 0 and c[6] == c[0], (args, c[:10])           # nothing leaves through outm (:1431)
+            ncut += int(c[1] - c[7])
+        except AssertionError as e:
+            raise AssertionError("config %r: %s" % (args, str(e)[:1500]))
+        d.close()
+    assert ncut > 0
+
+
+@pytest.mark.gpu
+def test_trimfailuresto1bp_refuses_units_beyond_the_main_kernel():
+    rng = random.Random(5)
+    refs = [util.rand_seq(rng, 60)]
+    d = B.BBDuk("k=21 ktrim=r trimfailures=t", refs=refs)
+    reads = [util.rand_seq(rng, 150), util.rand_seq(rng, 150), util.rand_seq(rng, 3000), util.rand_seq(rng, 100)]
+    b, off = pack_reads(reads)
+    with pytest.raises(B.BBDukError, match="trimfailuresto1bp"):
+        d.gpu.process_batch(b, off, True)
+    b, off = pack_reads(reads[:2])
+    d.gpu.process_batch(b, off, True)                              # the handle stays usable
+    with pytest.raises(B.BBDukError):
+        B.BBDuk("k=40 trimfailures=t", refs=refs)                  # k>31 runs on the tiled kernel only
+    d.close()

@@ -125,9 +125,13 @@ FUZZ = [dict(k=23, ktrimRight=1), dict(k=23, ktrimRight=1, mink=11, hdist=1), di
         dict(k=12, qSkip=3), dict(k=14, ktrimRight=1, mink=6, qSkip=2), dict(k=11, speed=5, hdist=1), dict(k=15, ktrimLeft=1, mink=9, speed=9, qhdist=1),
         dict(k=11, minKmerFraction=0.3), dict(k=13, minKmerFraction=0.1, maxBadKmers0=3, requireBothBad=1, forbidN=1), dict(k=12, minCoveredFraction=0.4),
         dict(k=15, minCoveredFraction=0.9, hdist=1, restrictLeft=60), dict(k=9, minCoveredFraction=0.05, minKmerFraction=0.5, maskMiddle=0),
-        dict(k=13, minSkip=3, maxSkip=3, ktrimRight=1, mink=6), dict(k=11, minSkip=2, maxSkip=5, hdist=1), dict(k=9, minSkip=4, maxSkip=4, ktrimLeft=1, mink=5, hdist=1, hdist2=0)]
-BOOLS = ("maskMiddle", "rcomp", "forbidN", "ktrimRight", "ktrimLeft", "requireBothBad", "ktrimExclusive", "skipR1", "skipR2", "trimPairsEvenly", "ktrimN", "kmaskFullyCovered")
-KMASK_FUZZ = [dict(k=11, ktrimN=1, kmaskFullyCovered=1), dict(k=13, ktrimN=1, mink=6, hdist=1, kmaskFullyCovered=1),
+        dict(k=13, minSkip=3, maxSkip=3, ktrimRight=1, mink=6), dict(k=11, minSkip=2, maxSkip=5, hdist=1), dict(k=9, minSkip=4, maxSkip=4, ktrimLeft=1, mink=5, hdist=1, hdist2=0),
+        # trimfailuresto1bp (BBDukParser.java:105-109, 774; BBDukProcessorS.java:1431, 1464-1488)
+        dict(k=13, ktrimRight=1, mink=6, trimFailuresTo1bp=1), dict(k=15, ktrimRight=1, trimPairsEvenly=1, trimFailuresTo1bp=1, minReadLength=40),
+        dict(k=11, ktrimLeft=1, trimFailuresTo1bp=1, minLenFraction=0.6), dict(k=12, trimFailuresTo1bp=1, hdist=1), dict(k=12, trimFailuresTo1bp=1, minCoveredFraction=0.3, minReadLength=1),
+        dict(k=14, trimFailuresTo1bp=1, maxBadKmers0=2, requireBothBad=1)]
+BOOLS = ("maskMiddle", "rcomp", "forbidN", "ktrimRight", "ktrimLeft", "requireBothBad", "ktrimExclusive", "skipR1", "skipR2", "trimPairsEvenly", "ktrimN", "kmaskFullyCovered", "trimFailuresTo1bp")
+KMASK_FUZZ = [dict(k=11, ktrimN=1, trimFailuresTo1bp=1, minReadLength=30), dict(k=11, ktrimN=1, kmaskFullyCovered=1), dict(k=13, ktrimN=1, mink=6, hdist=1, kmaskFullyCovered=1),
               dict(k=15, ktrimN=1, trimPad=2, forbidN=1, restrictRight=50, kmaskFullyCovered=1), dict(k=12, ktrimN=1, mink=5, trimPad=-2, restrictLeft=70, kmaskFullyCovered=1, qhdist=1),
               dict(k=11, ktrimN=1), dict(k=13, ktrimN=1, mink=6, hdist=1), dict(k=15, ktrimN=1, trimPad=2, forbidN=1, restrictRight=50),
               dict(k=12, ktrimN=1, mink=5, trimPad=-2, qhdist=1, maskMiddle=0), dict(k=17, ktrimN=1, requireBothBad=1, minReadLength=40, skipR1=1)]
@@ -146,7 +150,8 @@ def spec_mask_words(reads, masks, nwords):
 TIPS_FUZZ = [dict(k=11, ktrimLeft=1, ktrimRight=1), dict(k=13, ktrimLeft=1, ktrimRight=1, mink=6, hdist=1),
              dict(k=15, ktrimLeft=1, ktrimRight=1, restrictLeft=30, restrictRight=25, trimPad=1, forbidN=1),
              dict(k=12, ktrimLeft=1, ktrimRight=1, mink=5, trimPairsEvenly=1, ktrimExclusive=1, maskMiddle=0),
-             dict(k=17, ktrimLeft=1, ktrimRight=1, requireBothBad=1, minReadLength=40, qhdist=1)]
+             dict(k=17, ktrimLeft=1, ktrimRight=1, requireBothBad=1, minReadLength=40, qhdist=1),
+             dict(k=13, ktrimLeft=1, ktrimRight=1, mink=7, trimFailuresTo1bp=1, trimPairsEvenly=1, minReadLength=30)]
 
 
 @pytest.mark.parametrize("ci", range(len(TIPS_FUZZ)))
