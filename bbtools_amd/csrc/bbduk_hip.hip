@@ -1261,6 +1261,64 @@ __device__ __forceinline__ void main_scan_pair_cand(const KParams& P, const Plan
     }
 }
 
+// The candidate scan for reads whose spans are short: up to FOUR reads share one block.  The right pass of ktrim=rl looks at 76 positions of
+// a 150-base read (38 lanes) where the pair scan gives every read 128, so three reads fit the 128 lane-slots of a block (two slot pairs of 64
+// lanes): read r owns the lane-slots [T[r], T[r+1]) in the order (slot pair, lane), two adjacent positions per lane-slot from first[r] on, and may
+// straddle the two slot pairs.  The windows are cut with lane-varying read coordinates; every read then takes its first candidate out of its
+// part of the ballots.  One block serves all positions (the caller groups the reads so that they fit); the spans' windows are all "full"
+// (every position looked up, SPAN cuts in front of `start`).
+template <bool FORBIDN, bool GENERAL>
+__device__ __forceinline__ void packed_scan_cand(const KParams& P, const Planes& Q, const int ra, const int nr, const int* T, const bool anyN,
+                                                 const int vBase0, const int vStart, const int vStop, const int vFirstLook, const int lane,
+                                                 int& vCSlot, int& vFirst, uint32_t& vCKeyLo, uint32_t& vCKeyHi) {
+    // (the reads' coordinates come from their lanes by shuffle: keeping them wave-uniform for four reads costs more SGPRs than the kernel has)
+    ReadWin W[2]; int pos[2]; bool val[2];
+#pragma unroll
+    for (int sp = 0; sp < 2; sp++) {
+        const int t = 64 * sp + lane;
+        const int r = (t >= T[1] ? 1 : 0) + (t >= T[2] ? 1 : 0) + (t >= T[3] ? 1 : 0);
+        val[sp] = t < T[4];
+        const int src = min(ra + r, 63);
+        W[sp].base0 = __shfl(vBase0, src); W[sp].start = __shfl(vStart, src); W[sp].stop = __shfl(vStop, src);
+        const int f = __shfl(vFirstLook, src);
+        const int tr = r == 0 ? T[0] : (r == 1 ? T[1] : (r == 2 ? T[2] : T[3]));
+        pos[sp] = f + 2 * (t - tr);
+        W[sp].first = f; W[sp].on = true; W[sp].full = true; W[sp].hasN = anyN;
+    }
+    uint64_t kmer[4], rk[4]; bool ok[4]; int ref[4]; Cand4 C;
+    windows2<FORBIDN, GENERAL, true>(P, Q, W[0], pos[0], val[0], kmer, rk, ok);
+    windows2<FORBIDN, GENERAL, true>(P, Q, W[1], pos[1], val[1], kmer + 2, rk + 2, ok + 2);
+    const uint64_t anyFlag = cand_probe4<GENERAL, false, true>(P, Q.filt, kmer, rk, C);
+    if (anyFlag == 0ULL) return;                                  // the common block: nothing to look at
+    cand_resolve4(P, C, ref);
+    const uint64_t m[4] = {__ballot(ref[0] != -1 && ok[0]), __ballot(ref[1] != -1 && ok[1]), __ballot(ref[2] != -1 && ok[2]), __ballot(ref[3] != -1 && ok[3])};
+    if (!(m[0] | m[1] | m[2] | m[3])) return;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {                                 // (compile-time indices: the arrays stay in registers)
+        if (r >= nr) continue;
+        bool found = false;
+#pragma unroll
+        for (int sp = 0; sp < 2; sp++) {
+            const int lo = max(T[r], 64 * sp) - 64 * sp, hi = min(T[r + 1], 64 * sp + 64) - 64 * sp;
+            if (found || lo >= hi) continue;
+            const uint64_t mask = (hi >= 64 ? ~0ULL : ((1ULL << hi) - 1ULL)) & ~((1ULL << lo) - 1ULL);
+            const uint64_t me = m[2 * sp] & mask, mo = m[2 * sp + 1] & mask;
+            if (!(me | mo)) continue;
+            const int le = me ? __ffsll((unsigned long long)me) - 1 : 64, lq = mo ? __ffsll((unsigned long long)mo) - 1 : 64;
+            const int h = (2 * lq + 1 < 2 * le) ? 1 : 0;
+            const int l = h ? lq : le;
+            const int rs = h ? ref[2 * sp + 1] : ref[2 * sp];
+            const uint64_t ks = h ? C.key[2 * sp + 1] : C.key[2 * sp];
+            const int cs = __builtin_amdgcn_readlane(rs, l);
+            const uint32_t klo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ks, l), khi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ks >> 32), l);
+            const int ifirst = __builtin_amdgcn_readlane(vFirstLook, min(ra + r, 63)) + 2 * (64 * sp + l - T[r]) + h;
+            vCSlot = (lane == ra + r) ? cs : vCSlot; vFirst = (lane == ra + r) ? ifirst : vFirst;
+            vCKeyLo = (lane == ra + r) ? klo : vCKeyLo; vCKeyHi = (lane == ra + r) ? khi : vCKeyHi;
+            found = true;
+        }
+    }
+}
+
 // Short k-mer scans of two reads in one pass: lanes 0-31 serve read A, lanes 32-63 read B, one lane per
 // length mink..  (bbduk/BBDukProcessorS.java:2034-2103).  Only reads whose main scan found nothing take part.
 template <int MODE, bool GENERAL>
@@ -2682,6 +2740,30 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
             }
             bool quadDone = false;
             if constexpr (TIPS) {
+                if (pass == 0 && candP && (!GENERAL || P.qskip < 2) && !TSW(P, 3)) {
+                    // the right pass: reads packed by the lanes their spans need, up to four per block (packed_scan_cand)
+                    const int firstLook = max(P.k - 1, vStart > 0 ? vStart + P.minlen2 - 1 : 0);
+                    const int vCnt = (vScan && lane >= s && lane < e && vStop > firstLook) ? ((vStop - firstLook + 1) >> 1) : 0;
+                    if (__ballot(vCnt > 64) == 0ULL) {
+                        quadDone = true;
+                        const int vBase0p = origin + rel;
+                        const bool anyN = (FORBIDN && P.forbidNs) && nMask != 0ULL;
+                        int ra = s;
+                        while (ra < e) {
+                            int T4[5]; int nr = 0, lanes = 0;
+                            T4[0] = 0;
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                const int c = (ra + q < e) ? __builtin_amdgcn_readlane(vCnt, min(ra + q, 63)) : 0;
+                                const bool take = nr == q && (ra + q) < e && lanes + c <= 128;
+                                if (take) { lanes += c; nr++; }
+                                T4[q + 1] = lanes;
+                            }
+                            if (lanes > 0) packed_scan_cand<FORBIDN, GENERAL>(P, Q, ra, nr, T4, anyN, vBase0p, vStart, vStop, firstLook, lane, vCSlot, vFirst, vCKeyLo, vCKeyHi);
+                            ra += nr;
+                        }
+                    }
+                }
                 if (pass == 1 && (!GENERAL || P.qskip < 2)) {       // the left pass: four reads per block (left_scan_quad)
                     quadDone = true;
                     for (int ra = s; ra < e; ra += 4) {
