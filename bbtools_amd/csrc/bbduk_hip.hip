@@ -338,7 +338,7 @@ __device__ __forceinline__ void encode4(uint32_t w, uint32_t& x, uint32_t& c, ui
 
 // 16 consecutive bases starting at byte a -> 32-bit reversed forward codes, 32-bit complement codes, 16 valid bits
 __device__ __forceinline__ void encode_chunk(const uint8_t* __restrict__ bases, const int64_t a, const int64_t totalBases,
-                                             uint32_t& fwdRev, uint32_t& comp, uint32_t& valid) {
+                                             uint32_t& fwdRev, uint32_t& comp, uint32_t& valid, uint32_t* raw = nullptr) {
     uint32_t w[4];
     if (a + 16 <= totalBases) {
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -356,6 +356,7 @@ __device__ __forceinline__ void encode_chunk(const uint8_t* __restrict__ bases, 
             w[q] = x;
         }
     }
+    if (raw) { raw[0] = w[0]; raw[1] = w[1]; raw[2] = w[2]; raw[3] = w[3]; }   // the 16 symbols themselves (Seal: which of them is the letter N)
     // Packing: a multiply moves the four 2-bit fields of a word (bits 8j) next to each other into the top byte
     // (field j lands at 24+2j; all partial products fall on distinct bits, so nothing carries), and byte permutes
     // collect the four top bytes.  The 1-bit validity fields pack the same way with a 7-bit stride.
