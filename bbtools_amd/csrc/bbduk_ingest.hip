@@ -90,16 +90,17 @@ __device__ __forceinline__ void load64(const uint8_t* __restrict__ text, const i
     }
 }
 
-__device__ __forceinline__ int block_exclusive_scan(int v, int* s_tmp, int& total) {      // FQ_THREADS threads
+template <class T>
+__device__ __forceinline__ T block_exclusive_scan(T v, T* s_tmp, T& total) {      // FQ_THREADS threads
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int x = v;
+    T x = v;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if (lane >= o) x += y; }
+    for (int o = 1; o < 64; o <<= 1) { const T y = __shfl_up(x, o); if (lane >= o) x += y; }
     if (lane == 63) s_tmp[wave] = x;
     __syncthreads();
-    int base = 0, tot = 0;
+    T base = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < FQ_THREADS / 64; w++) { const int c = s_tmp[w]; if (w < wave) base += c; tot += c; }
+    for (int w = 0; w < FQ_THREADS / 64; w++) { const T c = s_tmp[w]; if (w < wave) base += c; tot += c; }
     __syncthreads();
     total = tot;
     return base + x - v;
@@ -205,21 +206,21 @@ constexpr int SC_PER_THREAD = 8;
 constexpr int SC_BLOCK = FQ_THREADS * SC_PER_THREAD;
 __global__ __launch_bounds__(FQ_THREADS)
 void block_sum_kernel(const int32_t* __restrict__ in, const int64_t n, int64_t* __restrict__ sums) {
-    __shared__ int s_tmp[FQ_THREADS / 64];
+    __shared__ int64_t s_tmp[FQ_THREADS / 64];
     const int64_t a = (int64_t)blockIdx.x * SC_BLOCK + (int64_t)threadIdx.x * SC_PER_THREAD;
-    int c = 0;
+    int64_t c = 0;                                  // 64-bit: a block of long reads (or of their output records) can pass 2^31
     for (int q = 0; q < SC_PER_THREAD; q++) if (a + q < n) c += in[a + q];
-    int total;
-    block_exclusive_scan(c, s_tmp, total);          // reads are < 2^31 bases per 2048 reads: BBDUK_MAX_READ_LEN * 2048 fits
+    int64_t total;
+    block_exclusive_scan(c, s_tmp, total);
     if (threadIdx.x == 0) sums[blockIdx.x] = total;
 }
 __global__ __launch_bounds__(FQ_THREADS)
 void scan_final_kernel(const int32_t* __restrict__ in, const int64_t n, const int64_t* __restrict__ sums, int64_t* __restrict__ out) {
-    __shared__ int s_tmp[FQ_THREADS / 64];
+    __shared__ int64_t s_tmp[FQ_THREADS / 64];
     const int64_t a = (int64_t)blockIdx.x * SC_BLOCK + (int64_t)threadIdx.x * SC_PER_THREAD;
-    int v[SC_PER_THREAD]; int c = 0;
+    int v[SC_PER_THREAD]; int64_t c = 0;
     for (int q = 0; q < SC_PER_THREAD; q++) { v[q] = (a + q < n) ? in[a + q] : 0; c += v[q]; }
-    int total;
+    int64_t total;
     int64_t run = sums[blockIdx.x] + block_exclusive_scan(c, s_tmp, total);
     for (int q = 0; q < SC_PER_THREAD; q++) {
         if (a + q <= n) out[a + q] = run;            // out[n] = total
