@@ -249,3 +249,48 @@ def test_seal_args_are_parsed_like_the_reference_and_refusals_are_loud():
     for bad in ("qhdist=1", "edist=1", "czf=0.1", "rename=t", "ambig=sometimes", "k=abc", "processcontainedref=t"):
         with pytest.raises(S.BBDukError):
             S.parse_args(bad)
+
+
+# ---------------------------------------------------------------------------------------------- committed fixtures (tests/golden/seal_*)
+GOLD = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden")
+SEAL_MODES = {"all": 1, "first": 0, "toss": 3, "random": 2}
+
+
+def _seal_fixture():
+    refs, names = [], []
+    for line in open(GOLD + "/seal_refs.fa").read().split("\n"):
+        if line.startswith(">"): names.append(line[1:])
+        elif line: refs.append(line.encode())
+    lines = open(GOLD + "/seal_reads.fq").read().split("\n")
+    rnames = [lines[i][1:] for i in range(0, len(lines) - 1, 4)]
+    reads = [lines[i + 1].encode() for i in range(0, len(lines) - 1, 4)]
+    return refs, names, rnames, reads
+
+
+def _seal_tsv(names, rnames, res):
+    sites, assigned, mx, ids, flags = res
+    return "".join("%s\t%d\t%d\t%d\t%s\t%d\n" % (rnames[u], sites[u], assigned[u], mx[u], ",".join(names[i - 1] for i in ids[u][:assigned[u]]), flags[u])
+                   for u in range(0, len(rnames), 2))
+
+
+@pytest.mark.parametrize("mode", list(SEAL_MODES))
+def test_seal_restatement_reproduces_the_committed_fixture(mode):
+    refs, names, rnames, reads = _seal_fixture()
+    o = SealOracle(refs, ambigMode=SEAL_MODES[mode])
+    assert _seal_tsv(names, rnames, o.process_reads(reads, True, 0, max_ids=8)) == open(GOLD + "/seal_%s.tsv" % mode).read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", list(SEAL_MODES))
+def test_seal_hip_reproduces_the_committed_fixture(mode):
+    from bbtools_amd.seal import Seal
+    refs, names, rnames, reads = _seal_fixture()
+    g = Seal("ambig=%s k=31 mm=t" % mode, refs=refs, max_scaffolds=16)
+    assert _seal_tsv(names, rnames, g.process_reads(reads, True, 0, max_ids=8)) == open(GOLD + "/seal_%s.tsv" % mode).read()
+    c, reads_, bases_, frags_, ambig_ = g.counters()
+    # the stats file of the fixture, from the device's counters (Seal.writeStats, statscolumns=5)
+    rows = sorted(((names[i - 1], int(reads_[i]), int(bases_[i]), int(ambig_[i])) for i in range(1, len(names) + 1) if reads_[i] > 0), key=lambda r: (-r[2], -r[1], r[0]))
+    rm, bm = 100.0 / c["readsIn"], 100.0 / c["basesIn"]
+    txt = "#Total\t%d\t%d\n#Matched\t%d\t%.5f%%\t%d\n#Name\tReads\tReadsPct\tBases\tBasesPct\tAmbigReads\n" % (c["readsIn"], c["basesIn"], c["readsMatched"], rm * c["readsMatched"], c["basesMatched"])
+    txt += "".join("%s\t%d\t%.5f%%\t%d\t%.5f%%\t%d\n" % (n, r, r * rm, b, b * bm, a) for n, r, b, a in rows)
+    assert txt == open(GOLD + "/seal_%s_stats.txt" % mode).read()

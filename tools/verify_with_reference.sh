@@ -53,7 +53,19 @@ for pair in "ks_o.fq cli_ksplit_expected_out.fq" "ks_m.fq cli_ksplit_expected_ou
   if diff "$W/$1" "$G/$2" > "$W/ks.diff"; then echo "  $2: identical"; else echo "  $2: DIFFERS"; head -8 "$W/ks.diff"; fail=1; fi
 done
 
-# 5. optional: the reference's own grader on the trimmed reads (names are <initial>_<remaining>)
+# 5. Seal (jgi/Seal.java; include/seal_gpu.h): pairs binned by scaffold, the four ambig= modes, per-scaffold files and the stats file
+SEAL="$BB/seal.sh"
+if [ -x "$SEAL" ]; then
+  for mode in all first toss random; do
+    run "$SEAL" in="$G/seal_reads.fq" int=t ref="$G/seal_refs.fa" pattern="$W/seal_${mode}_%.fq" outu="$W/seal_${mode}_u.fq" stats="$W/seal_${mode}_stats.txt" \
+        ambig=$mode k=31 mm=t statscolumns=5 $COMMON
+    python3 "$ROOT/tools/compare_seal_with_reference.py" --tsv "$G/seal_$mode.tsv" --pattern "$W/seal_${mode}_%.fq" --outu "$W/seal_${mode}_u.fq" \
+        --names scafA scafB scafC scafD scafE scafF || fail=1
+    cmp_stats "$W/seal_${mode}_stats.txt" "$G/seal_${mode}_stats.txt"
+  done
+else echo "no seal.sh under $BB: the Seal fixtures were not checked"; fi
+
+# 6. optional: the reference's own grader on the trimmed reads (names are <initial>_<remaining>)
 if [ -x "$BB/addadapters.sh" ]; then "$BB/addadapters.sh" in="$W/c2_o1.fq" in2="$W/c2_o2.fq" grade 2>&1 | tail -15; fi
 
 if [ $fail -eq 0 ]; then echo "REFERENCE AGREES with every committed expectation: parity pinned."; else echo "DIFFERENCES found (see above; work dir $W)."; fi
