@@ -21,7 +21,7 @@ SYMBOLS = ["seal_default_params", "seal_params_from_args", "seal_create", "seal_
 class SealParams(C.Structure):     # struct seal_params
     _fields_ = [(n, C.c_int32) for n in ("k", "maskMiddle", "midMaskLen", "rcomp", "forbidNs", "hdist", "refSkip", "restrictLeft",
                                          "restrictRight", "qSkip", "speed", "matchMode", "ambigMode", "keepPairsTogether", "minKmerHits")] + \
-               [("minKmerFraction", C.c_float), ("clearzone", C.c_int32), ("minReadLength", C.c_int32), ("maxReadLength", C.c_int32),
+               [("minKmerFraction", C.c_float), ("clearzone", C.c_int32), ("clearzoneFraction", C.c_float), ("minReadLength", C.c_int32), ("maxReadLength", C.c_int32),
                 ("minLenFraction", C.c_float), ("requireBothBad", C.c_int32), ("maxScaffolds", C.c_int32), ("device", C.c_int32)]
 
 

@@ -12,7 +12,7 @@
  *   seal_read_counters         the thread totals run() adds up                        jgi/Seal.java:1624-1660
  *
  * A k-mer maps to the SET of scaffolds that contain it (ascending ids, as the reference's loader leaves them).
- * Not served (seal_create / seal_params_from_args refuse them): qhdist>0, edist, clearzonefraction, processcontainedref,
+ * Not served (seal_create / seal_params_from_args refuse them): qhdist>0, edist, processcontainedref,
  * countvector=t, rename, taxonomy / barcode / gene-set outputs, quality trimming and filtering other than the length rule.
  */
 #ifndef SEAL_GPU_H
@@ -56,6 +56,7 @@ typedef struct seal_params {
     int32_t minKmerHits;            /* mkh= (>= 1) */
     float   minKmerFraction;        /* mkf= */
     int32_t clearzone;              /* cz= */
+    float   clearzoneFraction;      /* czf=: the clear zone is at least ceil(czf * valid k-mers of the pair) (Seal.java:2213-2214) */
     int32_t minReadLength;          /* minlength= (default 10) */
     int32_t maxReadLength;          /* maxlength= */
     float   minLenFraction;         /* mlf= */

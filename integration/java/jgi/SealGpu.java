@@ -11,7 +11,7 @@ import shared.Shared;
  *
  * Usage from Seal (jgi/Seal.java):
  *   long h = SealGpu.create(k, maskMiddle, midMaskLen, rcomp, forbidNs, hammingDistance, refSkip, restrictLeft, restrictRight, qSkip, speed,
- *                           matchMode, ambigMode, keepPairsTogether, minKmerHits, minKmerFraction, clearzone, minReadLength, maxReadLength,
+ *                           matchMode, ambigMode, keepPairsTogether, minKmerHits, minKmerFraction, clearzone, clearzoneFraction, minReadLength, maxReadLength,
  *                           minLenFraction, !removePairsIfEitherBad, scaffoldNames.size(), device);
  *   // table: either let the library load the references (what LoadThread.addToMap does, Seal.java:1760-1945) ...
  *   for each scaffold in file order: SealGpu.addRefSequence(h, bases);                 // ids 1, 2, ... as scaffoldNames assigns them
@@ -44,14 +44,14 @@ public final class SealGpu {
 	/** Scalars as Seal holds them after its constructor (jgi/Seal.java:480-570). */
 	public static long create(int k, boolean maskMiddle, int midMaskLen, boolean rcomp, boolean forbidNs, int hdist, int refSkip,
 			int restrictLeft, int restrictRight, int qSkip, int speed, int matchMode, int ambigMode, boolean keepPairsTogether,
-			int minKmerHits, float minKmerFraction, int clearzone, int minReadLength, int maxReadLength, float minLenFraction,
+			int minKmerHits, float minKmerFraction, int clearzone, float clearzoneFraction, int minReadLength, int maxReadLength, float minLenFraction,
 			boolean requireBothBad, int maxScaffolds, int device){
 		// Seal.AMBIG_* / MATCH_* -> SEAL_AMBIG_* / SEAL_MATCH_* of seal_gpu.h
 		final int am=(ambigMode==Seal.AMBIG_FIRST ? 0 : ambigMode==Seal.AMBIG_ALL ? 1 : ambigMode==Seal.AMBIG_RANDOM ? 2 : 3);
 		final int mm=(matchMode==Seal.MATCH_ALL ? 0 : matchMode==Seal.MATCH_FIRST ? 1 : 2);
 		final int[] ip={k, maskMiddle ? 1 : 0, midMaskLen, rcomp ? 1 : 0, forbidNs ? 1 : 0, hdist, refSkip, restrictLeft, restrictRight, qSkip, speed,
 				mm, am, keepPairsTogether ? 1 : 0, minKmerHits, clearzone, minReadLength, maxReadLength, requireBothBad ? 1 : 0, maxScaffolds, device};
-		final long h=createJNI(ip, new float[] {minKmerFraction, minLenFraction});
+		final long h=createJNI(ip, new float[] {minKmerFraction, minLenFraction, clearzoneFraction});
 		if(h<=0){throw new RuntimeException("seal_create failed: "+h);}
 		return h;
 	}

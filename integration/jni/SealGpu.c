@@ -18,15 +18,15 @@ static void* dbuf(JNIEnv* env, jobject buf, jlong need, int* bad) {
 }
 
 JNIEXPORT jlong JNICALL Java_jgi_SealGpu_createJNI(JNIEnv* env, jclass cls, jintArray ip, jfloatArray fp) {
-    jint v[21]; jfloat f[2];
-    if ((*env)->GetArrayLength(env, ip) < 21 || (*env)->GetArrayLength(env, fp) < 2) return -1;
-    (*env)->GetIntArrayRegion(env, ip, 0, 21, v); (*env)->GetFloatArrayRegion(env, fp, 0, 2, f);
+    jint v[21]; jfloat f[3];
+    if ((*env)->GetArrayLength(env, ip) < 21 || (*env)->GetArrayLength(env, fp) < 3) return -1;
+    (*env)->GetIntArrayRegion(env, ip, 0, 21, v); (*env)->GetFloatArrayRegion(env, fp, 0, 3, f);
     seal_params p; seal_default_params(&p);
     p.k = v[0]; p.maskMiddle = v[1]; p.midMaskLen = v[2]; p.rcomp = v[3]; p.forbidNs = v[4]; p.hdist = v[5]; p.refSkip = v[6];
     p.restrictLeft = v[7]; p.restrictRight = v[8]; p.qSkip = v[9]; p.speed = v[10]; p.matchMode = v[11]; p.ambigMode = v[12];
     p.keepPairsTogether = v[13]; p.minKmerHits = v[14]; p.clearzone = v[15]; p.minReadLength = v[16]; p.maxReadLength = v[17];
     p.requireBothBad = v[18]; p.maxScaffolds = v[19]; p.device = v[20];
-    p.minKmerFraction = f[0]; p.minLenFraction = f[1];
+    p.minKmerFraction = f[0]; p.minLenFraction = f[1]; p.clearzoneFraction = f[2];
     seal_handle* h = NULL;
     const int rc = seal_create(&p, &h);
     return rc == 0 ? (jlong)(intptr_t)h : (jlong)rc;

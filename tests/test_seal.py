@@ -71,7 +71,7 @@ def rand_cfg(rng):
     cfg = dict(k=k, mm=rng.random() < 0.6, hdist=rng.choice([0, 0, 0, 1]) if k <= 15 else rng.choice([0, 0, 0, 0, 1]),
                rcomp=rng.random() < 0.85, fn=rng.random() < 0.3, match=rng.choice(["all", "all", "first", "unique"]),
                ambig=rng.choice(["random", "first", "all", "toss"]), kpt=rng.random() < 0.6, mkh=rng.choice([1, 1, 2, 5]),
-               mkf=rng.choice([0.0, 0.0, 0.05, 0.3]), cz=rng.choice([0, 0, 1, 3, 20]), qskip=rng.choice([1, 1, 1, 2, 3]),
+               mkf=rng.choice([0.0, 0.0, 0.05, 0.3]), cz=rng.choice([0, 0, 1, 3, 20]), czf=rng.choice([0.0, 0.0, 0.0, 0.02, 0.2]), qskip=rng.choice([1, 1, 1, 2, 3]),
                speed=rng.choice([0, 0, 0, 4]), rl=rng.choice([0, 0, 0, 40]), rr=rng.choice([0, 0, 0, 50]),
                minlength=rng.choice([10, 10, 1, 40]), maxlength=rng.choice([0, 0, 200]), mlf=rng.choice([0.0, 0.0, 0.5]),
                rieb=rng.random() < 0.7, rskip=rng.choice([0, 0, 0, 2, 3]))
@@ -83,7 +83,7 @@ def rand_cfg(rng):
 def cfg_args(c):
     a = ["k=%d" % c["k"], "mm=%s" % (str(c["mmlen"]) if c.get("mmlen") else ("t" if c["mm"] else "f")), "hdist=%d" % c["hdist"],
          "rcomp=%s" % ("t" if c["rcomp"] else "f"), "fn=%s" % ("t" if c["fn"] else "f"), "match=%s" % c["match"], "ambig=%s" % c["ambig"],
-         "kpt=%s" % ("t" if c["kpt"] else "f"), "mkh=%d" % c["mkh"], "mkf=%g" % c["mkf"], "cz=%d" % c["cz"], "qskip=%d" % c["qskip"],
+         "kpt=%s" % ("t" if c["kpt"] else "f"), "mkh=%d" % c["mkh"], "mkf=%g" % c["mkf"], "cz=%d" % c["cz"], "czf=%g" % c["czf"], "qskip=%d" % c["qskip"],
          "speed=%d" % c["speed"], "restrictleft=%d" % c["rl"], "restrictright=%d" % c["rr"], "minlength=%d" % c["minlength"],
          "mlf=%g" % c["mlf"], "rieb=%s" % ("t" if c["rieb"] else "f"), "rskip=%d" % c["rskip"]]
     if c["maxlength"]:
@@ -95,7 +95,7 @@ def cfg_oracle(c):
     return dict(k=c["k"], maskMiddle=1 if c["mm"] else 0, midMaskLen=c.get("mmlen", 0), hdist=c["hdist"], rcomp=1 if c["rcomp"] else 0,
                 forbidN=1 if c["fn"] else 0, matchMode={"all": 0, "first": 1, "unique": 2}[c["match"]],
                 ambigMode={"first": 0, "all": 1, "random": 2, "toss": 3}[c["ambig"]], keepPairsTogether=1 if c["kpt"] else 0,
-                minKmerHits=c["mkh"], minKmerFraction=c["mkf"], clearzone=c["cz"], qSkip=c["qskip"], speed=c["speed"], restrictLeft=c["rl"],
+                minKmerHits=c["mkh"], minKmerFraction=c["mkf"], clearzone=c["cz"], clearzoneFraction=c["czf"], qSkip=c["qskip"], speed=c["speed"], restrictLeft=c["rl"],
                 restrictRight=c["rr"], minReadLength=c["minlength"], maxReadLength=c["maxlength"] or 0x7FFFFFFF, minLenFraction=c["mlf"],
                 requireBothBad=0 if c["rieb"] else 1, refSkip=c["rskip"])
 
@@ -237,7 +237,7 @@ def test_seal_args_are_parsed_like_the_reference_and_refusals_are_loud():
     txt = open(os.path.join(util.ROOT, "include", "seal_gpu.h")).read()
     decl = set(re.findall(r"\b(seal_[a-z0-9_]+)\s*\(", txt)) - {"seal_params", "seal_handle"}
     assert decl == set(S.SYMBOLS)
-    assert C.sizeof(S.SealParams) == 23 * 4
+    assert C.sizeof(S.SealParams) == 24 * 4
     p = S.parse_args("")
     assert (p.k, p.maskMiddle, p.rcomp, p.hdist, p.matchMode, p.ambigMode, p.keepPairsTogether, p.minKmerHits, p.minReadLength, p.qSkip) == \
         (31, 1, 1, 0, S.MATCH_ALL, S.AMBIG_RANDOM, 1, 1, 10, 1)
@@ -246,7 +246,7 @@ def test_seal_args_are_parsed_like_the_reference_and_refusals_are_loud():
             p.requireBothBad, p.minReadLength) == (25, 1, 3, 1, S.AMBIG_TOSS, S.MATCH_UNIQUE, 0, 3, 4, 1, 1, 20)
     assert abs(p.minKmerFraction - 0.25) < 1e-7
     assert S.parse_args("fbm=f").matchMode == S.MATCH_FIRST and S.parse_args("fum").matchMode == S.MATCH_UNIQUE
-    for bad in ("qhdist=1", "edist=1", "czf=0.1", "rename=t", "ambig=sometimes", "k=abc", "processcontainedref=t"):
+    for bad in ("qhdist=1", "edist=1", "rename=t", "ambig=sometimes", "k=abc", "processcontainedref=t"):
         with pytest.raises(S.BBDukError):
             S.parse_args(bad)
 
