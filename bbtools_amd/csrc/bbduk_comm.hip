@@ -189,6 +189,17 @@ extern "C" int bbduk_allreduce_counters_device(bbduk_handle* h, int64_t* d_count
     return BBDUK_OK;
 }
 
+// the same all-reduce over another int64 vector of this handle's rank (the counter vector of a seal_handle: seal_allreduce_counters)
+int bbduk_comm_allreduce_i64(bbduk_handle* h, int64_t* d_buf, int64_t n, void* stream) {
+    if (!h || !d_buf || n < 1) return fail(h, BBDUK_ERR_ARG, "allreduce: null argument");
+    bbduk_comm* c = h->comm;
+    if (!c || c->local) return fail(h, BBDUK_ERR_STATE, "allreduce: the handle is not a rank of a multi-process communicator (bbduk_comm_create / seal_comm_create)");
+    HIP_TRY(h, hipSetDevice(h->p.device));
+    const ncclResult_t r = rccl()->AllReduce(d_buf, d_buf, (size_t)n, ncclInt64, ncclSum, c->comm, (hipStream_t)stream);
+    if (r != ncclSuccess) return nccl_fail(h, "ncclAllReduce", r);
+    return BBDUK_OK;
+}
+
 extern "C" int bbduk_allreduce_counters(bbduk_handle* h) {
     if (!h) return BBDUK_ERR_ARG;
     if (h->comm && h->comm->local) return bbduk_allreduce_counters_local(h->comm->members.data(), (int32_t)h->comm->members.size());

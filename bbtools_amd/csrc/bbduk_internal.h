@@ -103,6 +103,8 @@ struct bbduk_handle {
 #define HIP_TRY(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
     (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return BBDUK_ERR_DEVICE; } } while (0)
 
+int bbduk_comm_allreduce_i64(bbduk_handle* h, int64_t* d_buf, int64_t n, void* stream);   // bbduk_comm.hip
+
 static inline int fail(bbduk_handle* h, int code, const char* msg) { if (h) h->err = msg; return code; }
 
 #endif

@@ -15,7 +15,7 @@ COUNTER_NAMES = ["readsIn", "basesIn", "fragsIn", "readsMatched", "basesMatched"
                  "readsQFiltered", "basesQFiltered", "readsQTrimmed"]
 SYMBOLS = ["seal_default_params", "seal_params_from_args", "seal_create", "seal_destroy", "seal_last_error", "seal_add_ref_sequence",
            "seal_upload_pairs", "seal_finalize", "seal_num_scaffolds", "seal_table_keys", "seal_table_pairs", "seal_batch_device",
-           "seal_batch", "seal_counters_len", "seal_read_counters", "seal_reset_counters", "seal_last_kernel_ms"]
+           "seal_batch", "seal_counters_len", "seal_read_counters", "seal_reset_counters", "seal_last_kernel_ms", "seal_comm_create", "seal_allreduce_counters"]
 
 
 class SealParams(C.Structure):     # struct seal_params
@@ -51,6 +51,8 @@ def lib():
         L.seal_read_counters.argtypes = [vp, vp]
         L.seal_reset_counters.argtypes = [vp]
         L.seal_last_kernel_ms.restype = C.c_double; L.seal_last_kernel_ms.argtypes = [vp]
+        L.seal_comm_create.argtypes = [vp, i32, i32, C.c_char_p]
+        L.seal_allreduce_counters.argtypes = [vp]
         _bound = True
     return L
 
@@ -139,3 +141,9 @@ class Seal:
 
     def kernel_ms(self):
         return lib().seal_last_kernel_ms(self.h)
+
+    def comm_create(self, nranks: int, rank: int, unique_id: bytes):
+        self._check(lib().seal_comm_create(self.h, nranks, rank, unique_id), "seal_comm_create")
+
+    def allreduce_counters(self):
+        self._check(lib().seal_allreduce_counters(self.h), "seal_allreduce_counters")

@@ -102,6 +102,12 @@ int  seal_read_counters(seal_handle* h, int64_t* out);     /* the handle's own v
 int  seal_reset_counters(seal_handle* h);
 double seal_last_kernel_ms(seal_handle* h);                /* HIP events around the last seal kernel */
 
+/* ---- multi-GPU: one process per GPU, the reads sharded over the ranks, the whole table on every rank; the only exchange is one RCCL
+ * all-reduce (sum, int64) of the handles' counter vectors, as Seal adds up its ProcessThreads (jgi/Seal.java:1624-1660).  id128 from
+ * bbduk_comm_unique_id (bbduk_gpu.h), broadcast by the caller's own launcher. */
+int  seal_comm_create(seal_handle* h, int32_t nranks, int32_t rank, const uint8_t* id128);
+int  seal_allreduce_counters(seal_handle* h);
+
 #ifdef __cplusplus
 }
 #endif

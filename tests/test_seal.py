@@ -294,3 +294,22 @@ def test_seal_hip_reproduces_the_committed_fixture(mode):
     txt = "#Total\t%d\t%d\n#Matched\t%d\t%.5f%%\t%d\n#Name\tReads\tReadsPct\tBases\tBasesPct\tAmbigReads\n" % (c["readsIn"], c["basesIn"], c["readsMatched"], rm * c["readsMatched"], c["basesMatched"])
     txt += "".join("%s\t%d\t%.5f%%\t%d\t%.5f%%\t%d\n" % (n, r, r * rm, b, b * bm, a) for n, r, b, a in rows)
     assert txt == open(GOLD + "/seal_%s_stats.txt" % mode).read()
+
+
+@pytest.mark.gpu
+def test_seal_counter_allreduce_world1():
+    """seal_comm_create / seal_allreduce_counters with the only world a 1-GPU box can form: one rank's all-reduce leaves the vector as it is."""
+    from bbtools_amd import bbduk as B
+    from bbtools_amd.seal import Seal
+    rng = random.Random(3)
+    refs = [rnd_seq(rng, 300) for _ in range(3)]
+    g = Seal("k=21", refs=refs, max_scaffolds=8)
+    g.process_reads([refs[i % 3][10:110] for i in range(40)], True)
+    before = g.counters()
+    with pytest.raises(B.BBDukError):
+        g.allreduce_counters()                         # no communicator yet
+    g.comm_create(1, 0, B.comm_unique_id())
+    g.allreduce_counters()
+    after = g.counters()
+    assert before[0] == after[0] and before[0]["readsMatched"] == 40 and all(np.array_equal(x, y) for x, y in zip(before[1:], after[1:]))
+    g.close()
