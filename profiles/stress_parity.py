@@ -57,7 +57,24 @@ def main():
     while time.time() - t0 < a.seconds and not (a.only is not None and it):
         seed = a.seed * 1_000_003 + it if a.only is None else a.only; it += 1
         rng = random.Random(seed)
-        fam = rng.choice(["base", "base", "base", "kmask", "tips", "ksplit", "big", "fbm", "seal"])
+        fam = rng.choice(["base", "base", "base", "kmask", "tips", "ksplit", "big", "fbm", "seal", "tf1bp"])
+        if fam == "tf1bp":                                     # trimfailuresto1bp over every operator family (units within the main kernel's planes)
+            try:
+                tfam, targs, tokw = T.tf1bp_config(rng)
+                trefs = [util.rand_seq(rng, rng.randint(12, 90), 0.01) for _ in range(rng.randint(1, 8))]
+                td, to = T.make_pair(targs, tokw, refs=trefs)
+                treads = util.fuzz_reads(rng, trefs, rng.choice([60, 400, 1500]), [0, 1, 2, 3, 9, 10, 12, 22, 23, 31, 40, 64, 75, 150, 151, 300, 1000], junk=True)
+                if len(treads) % 2: treads.append(b"")
+                if tfam == "n": T.check_kmask(td, to, treads, True); T.check_kmask(td, to, treads[:101], False)
+                elif tfam == "rl": T.check_tips(td, to, treads, True); T.check_tips(td, to, treads[:101], False)
+                elif tfam == "ksplit": T.check_split(td, to, treads)
+                else: T.check_batch(td, to, treads, True); T.check_batch(td, to, treads[:101], False)
+                td.close()
+            except Exception as e:
+                print(json.dumps({"FAILED": True, "seed": seed, "family": fam, "args": locals().get("targs"), "error": (str(e) or traceback.format_exc())[-2000:]}))
+                sys.exit(1)
+            n_cfg += 1; n_reads += len(treads); fam_count[fam] = fam_count.get(fam, 0) + 1
+            continue
         if fam == "seal":                                      # Seal's k-mer path (include/seal_gpu.h) against oracle/seal_oracle.c
             from tests import test_seal
             try:
