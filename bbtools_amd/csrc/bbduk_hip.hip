@@ -3123,7 +3123,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
             int leftmost = 0x7FFFFFFF, rightmost = -1;
             if (vSide == 0) { leftmost = max(0, vFirst - (k - 1 - tp)); rightmost = vLast + tp; }
             else if (vSide == 1) { leftmost = max(0, (vStop - (P.mink + vSLl)) - tp); rightmost = L - 1; }
-            else { leftmost = 0; rightmost = (vStart + (P.mink + vSLl) - 1) + tp; }
+            else { leftmost = 0; rightmost = max(-1, (vStart + (P.mink + vSLl) - 1) + tp); }     // (:2434: max with the -1 it starts from; a negative trimpad)
             int npl = L, split = 0;
             if (any) {
                 int n1 = L;

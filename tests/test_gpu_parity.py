@@ -576,7 +576,9 @@ BIG = [("k=40", dict(k=31, kbig=40)), ("k=32 hdist=1", dict(k=31, kbig=32, hdist
        ("k=40 mcf=0.3", dict(k=31, kbig=40, minCoveredFraction=0.3))]
 SPLIT = [("k=23 ksplit=t", dict(k=23, ksplit=1)), ("k=15 ksplit mink=7 hdist=1", dict(k=15, ksplit=1, mink=7, hdist=1)),
          ("k=13 ksplit=t tp=-2 forbidn=t", dict(k=13, ksplit=1, trimPad=-2, forbidN=1)), ("k=17 ksplit mink=9 restrictleft=100 qhdist=1", dict(k=17, ksplit=1, mink=9, restrictLeft=100, qhdist=1)),
-         ("k=11 ksplit mink=5 restrictright=60 rcomp=f", dict(k=11, ksplit=1, mink=5, restrictRight=60, rcomp=0))]
+         ("k=11 ksplit mink=5 restrictright=60 rcomp=f", dict(k=11, ksplit=1, mink=5, restrictRight=60, rcomp=0)),
+         # (soak seed 301004544: a left-end short k-mer of 2 bases with a negative trimpad leaves rightmost at the -1 it starts from, :2434)
+         ("k=13 mink=2 hdist=1 forbidn=t restrictleft=68 tp=-3 ksplit=t", dict(k=13, mink=2, hdist=1, forbidN=1, restrictLeft=68, trimPad=-3, ksplit=1))]
 
 
 @pytest.mark.parametrize("ci", range(len(BIG)))
