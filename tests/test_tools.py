@@ -75,3 +75,31 @@ def test_fixture_names_follow_the_addadapters_convention():
         if remaining < initial - 11:                                       # at least mink adapter bases in the read
             total += 1; agree += -5 <= int(newlen) - remaining <= 0 or (remaining == 0 and int(newlen) <= 1)
     assert total > 20 and agree >= 0.95 * total, (agree, total)
+
+
+def test_seal_comparator_on_synthesised_output(tmp_path):
+    """tools/compare_seal_with_reference.py: what a Seal that agrees with tests/golden/seal_all.tsv would write (pattern=, outu=) passes; a pair in
+    the wrong scaffold's file or missing from outu is reported."""
+    tool = os.path.join(ROOT, "tools", "compare_seal_with_reference.py")
+    recs = _fastq(os.path.join(GOLD, "seal_reads.fq"))
+    pair = {recs[i][0]: (recs[i], recs[i + 1]) for i in range(0, len(recs), 2)}
+    names = ["scafA", "scafB", "scafC", "scafD", "scafE", "scafF"]
+    files = {n: [] for n in names}; unmatched = []
+    for line in open(os.path.join(GOLD, "seal_all.tsv")):
+        name, sites, assigned, mx, who, flags = line.rstrip("\n").split("\t")
+        if who:
+            for n in who.split(","):
+                files[n] += list(pair[name])
+        else:
+            unmatched += list(pair[name])
+    for n in names:
+        _write(str(tmp_path / ("s_%s.fq" % n)), files[n])
+    _write(str(tmp_path / "u.fq"), unmatched)
+    args = ["--tsv", os.path.join(GOLD, "seal_all.tsv"), "--pattern", str(tmp_path / "s_%.fq"), "--outu", str(tmp_path / "u.fq"), "--names"] + names
+    r = subprocess.run([sys.executable, tool] + args, capture_output=True, text=True)
+    assert r.returncode == 0 and "identical" in r.stdout, r.stdout + r.stderr
+    assert any(len(v) for v in files.values()) and unmatched
+    moved = files["scafA"][:2]                                   # one pair into the wrong file
+    _write(str(tmp_path / "s_scafA.fq"), files["scafA"][2:]); _write(str(tmp_path / "s_scafE.fq"), files["scafE"] + moved)
+    r = subprocess.run([sys.executable, tool] + args, capture_output=True, text=True)
+    assert r.returncode == 1 and "DIFFERENCES" in r.stdout and moved[0][0] in r.stdout
