@@ -860,7 +860,8 @@ __device__ __forceinline__ uint64_t gap_h0(const KParams& P, const uint64_t kmer
 // flagged and looked up by the generic exact path in cand_resolve4_big.  Windows at the top of the block (position >= 128 - W
 // within it) lack their successors: the caller advances by BIG_STEP positions and ignores them.
 #define BIG_STEP 120
-struct Cand4Big { uint64_t key[4], t1[4], t2[4], ts[4]; uint32_t ma[4], mb[4], w1[4], w2[4]; uint64_t hm[4]; bool nf[4], sp[4]; };
+// (the tag words themselves are not kept: the rare resolve step loads them again, which keeps 24 VGPRs out of the common path's live ranges)
+struct Cand4Big { uint64_t key[4]; uint32_t ma[4], mb[4], w1[4], w2[4]; uint64_t hm[4]; bool nf[4], sp[4]; };
 template <bool NOMM>
 __device__ __forceinline__ uint64_t cand_probe4_big(const KParams& P, const uint64_t* kmer, const uint64_t* rk, const uint64_t* rkRaw, const bool* nf, Cand4Big& C) {
     const uint32_t mmLo = (uint32_t)P.middleMask, mmHi = (uint32_t)(P.middleMask >> 32);
@@ -886,26 +887,27 @@ __device__ __forceinline__ uint64_t cand_probe4_big(const KParams& P, const uint
 #pragma unroll
         for (int s = 0; s < 4; s++) hw[s] = (uint64_t)(C.ma[s] ^ 0x5BD1E995u);
     }
+    uint64_t t1[4], t2[4], ts[4];
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         big_words(gap_line(hw[s], P.bigLines), C.mb[s], C.w1[s], C.w2[s]);
-        C.t1[s] = P.bigTags[C.w1[s]];                              // eight gathers in flight; a lane's two words and its neighbours' share a sector
-        C.t2[s] = P.bigTags[C.w2[s]];
+        t1[s] = P.bigTags[C.w1[s]];                                // eight gathers in flight; a lane's two words and its neighbours' share a sector
+        t2[s] = P.bigTags[C.w2[s]];
     }
     // the key's spill bit in its primary word: only those lanes (~5 %) look into the secondary map, the others re-read its bucket 0
 #pragma unroll
     for (int s = 0; s < 4; s++) {
-        const uint32_t half = (C.ma[s] & 0x4000u) ? (uint32_t)(C.t1[s] >> 32) : (uint32_t)C.t1[s];    // spill_bit(ma) = 16*((ma>>13)&3)+15
+        const uint32_t half = (C.ma[s] & 0x4000u) ? (uint32_t)(t1[s] >> 32) : (uint32_t)t1[s];    // spill_bit(ma) = 16*((ma>>13)&3)+15
         C.sp[s] = ((half >> ((C.ma[s] & 0x2000u) ? 31 : 15)) & 1u) != 0u;
-        C.ts[s] = P.tags[C.sp[s] ? bucket_of(C.mb[s], P.bucketBits) : 0u];
+        ts[s] = P.tags[C.sp[s] ? bucket_of(C.mb[s], P.bucketBits) : 0u];
     }
     uint64_t any = 0;
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         const uint32_t fp = tag_of(C.ma[s]);
-        const uint32_t alo = (uint32_t)C.t1[s] & 0x7FFF7FFFu, ahi = (uint32_t)(C.t1[s] >> 32) & 0x7FFF7FFFu;      // without the spill bits
-        const uint32_t blo = (uint32_t)C.t2[s] & 0x7FFF7FFFu, bhi = (uint32_t)(C.t2[s] >> 32) & 0x7FFF7FFFu;
-        const uint32_t slo = (uint32_t)C.ts[s], shi = (uint32_t)(C.ts[s] >> 32);
+        const uint32_t alo = (uint32_t)t1[s] & 0x7FFF7FFFu, ahi = (uint32_t)(t1[s] >> 32) & 0x7FFF7FFFu;      // without the spill bits
+        const uint32_t blo = (uint32_t)t2[s] & 0x7FFF7FFFu, bhi = (uint32_t)(t2[s] >> 32) & 0x7FFF7FFFu;
+        const uint32_t slo = (uint32_t)ts[s], shi = (uint32_t)(ts[s] >> 32);
         // twelve 16-bit compares; in the secondary map's bucket lane 3 carries the continuation flag and never compares equal then
         const uint64_t prim = __ballot((alo & 0xFFFFu) == fp) | __ballot((alo >> 16) == fp) | __ballot((ahi & 0xFFFFu) == fp) | __ballot((ahi >> 16) == fp) |
                               __ballot((blo & 0xFFFFu) == fp) | __ballot((blo >> 16) == fp) | __ballot((bhi & 0xFFFFu) == fp) | __ballot((bhi >> 16) == fp);
@@ -929,13 +931,15 @@ __device__ __forceinline__ void cand_resolve4_big(const KParams& P, const Cand4B
             continue;
         }
         const uint64_t pat = (uint64_t)tag_of(C.ma[s]) * 0x0001000100010001ULL;
-        const uint64_t c1 = zero16((C.t1[s] & TAG_FPS15) ^ pat), c2 = zero16((C.t2[s] & TAG_FPS15) ^ pat);
+        const uint64_t t1 = P.bigTags[C.w1[s]], t2 = P.bigTags[C.w2[s]];       // (again: cache hits)
+        const uint64_t c1 = zero16((t1 & TAG_FPS15) ^ pat), c2 = zero16((t2 & TAG_FPS15) ^ pat);
         if (c1) ref[s] = (__ffsll((unsigned long long)c1) - 1) >> 4;
         else if (c2) ref[s] = 4 + ((__ffsll((unsigned long long)c2) - 1) >> 4);
         else if (C.sp[s]) {                                       // a key of this kind was spilled from the primary word: the secondary map answers
-            const uint64_t c3 = zero16((C.ts[s] & TAG_FPS) ^ pat);
-            if (c3 != 0ULL || (C.ts[s] & TAG_CONT)) {
-                const int id = table_find_t(P, C.key[s] | P.kmask, C.ma[s], C.mb[s], C.ts[s]);
+            const uint64_t ts = P.tags[bucket_of(C.mb[s], P.bucketBits)];
+            const uint64_t c3 = zero16((ts & TAG_FPS) ^ pat);
+            if (c3 != 0ULL || (ts & TAG_CONT)) {
+                const int id = table_find_t(P, C.key[s] | P.kmask, C.ma[s], C.mb[s], ts);
                 ref[s] = id > 0 ? -3 - id : -1;
             }
         }
