@@ -454,7 +454,8 @@ template <int MODE, bool SHORT, bool GENERAL>
 __device__ __forceinline__ bool scan_due(const KParams& P, int L, int pairnum, bool present) {
     const int k = P.k;
     bool s = present && P.storedKmers > 0;
-    if (MODE == BBDUK_MODE_KFILTER || MODE == BBDUK_MODE_KSPLIT || MODE == BBDUK_MODE_KMASK || MODE == 6 /* BBDUK_MODE_FBM */) s = s && (L >= k);   // BBDukProcessorS.java:1535; ksplit :2333, 2338; kmask :2151
+    if (MODE == 7 /* BBDUK_MODE_KBIG */) s = s && (L >= P.kbig);                          // :1727-1728
+    else if (MODE == BBDUK_MODE_KFILTER || MODE == BBDUK_MODE_KSPLIT || MODE == BBDUK_MODE_KMASK || MODE == 6 /* BBDUK_MODE_FBM */) s = s && (L >= k);   // BBDukProcessorS.java:1535; ksplit :2333, 2338; kmask :2151
     else s = s && (L >= max(1, (SHORT && P.useShort) ? min(k, P.mink) : k));               // :1995
     if constexpr (GENERAL) {
         if ((P.skipR1 && pairnum == 0) || (P.skipR2 && pairnum == 1)) s = false;           // :1536, :1996
@@ -2087,6 +2088,28 @@ __device__ __forceinline__ void best_fold(KScanState& S, const uint64_t he, cons
         re &= ~se; ro &= ~so;
     }
 }
+// countSetKmersBig's run state machine (:1749-1779) over 128 positions, replayed position by position in scalar code: ke / ko = the lanes whose
+// even / odd position was looked up (the others are transparent), refE / refO their results, i0 = the position of lane 0's even slot
+__device__ __forceinline__ void big_fold(KScanState& S, const uint64_t ke, const uint64_t ko, const int refE, const int refO, const int i0, const int sub, const int thr) {
+    for (int j = 0; j < 64 && !S.done; j++) {
+#pragma unroll
+        for (int par = 0; par < 2; par++) {
+            if (S.done || !(((par ? ko : ke) >> j) & 1ULL)) continue;    // not looked up: transparent
+            const int i = i0 + 2 * j + par;
+            const int id = __builtin_amdgcn_readlane(par ? refO : refE, j);
+            if (id > 0) { S.lastId = id; if (S.bkStart == -1) S.bkStart = i; S.bkStop = i; }
+            else if (S.bkStart > -1) {
+                const int dif = S.bkStop - S.bkStart - sub;
+                S.bkStop = S.bkStart = -1;
+                if (dif > 0) {
+                    const int old = S.found;
+                    S.found += dif;
+                    if (S.found > thr && old <= thr) { S.rid = S.lastId; S.done = true; }     // :1763-1773 early exit
+                }
+            }
+        }
+    }
+}
 // the positions [W.first, W.stop) of one read (or of one chunk of it), 256 per step
 template <int RED>
 __device__ __forceinline__ void kscan_window(const KParams& P, const Planes& Q, const ReadWin& W, KScanState& S, const int thr, const int lane,
@@ -2118,25 +2141,7 @@ __device__ __forceinline__ void kscan_window(const KParams& P, const Planes& Q, 
                 best_fold(S, he, ho, ref[2 * hb], ref[2 * hb + 1], lane, counters);
             } else {
                 if (!(he | ho) && S.bkStart < 0) continue;          // nothing to open, nothing to close
-                const uint64_t ke = __ballot(ok[2 * hb]), ko = __ballot(ok[2 * hb + 1]);
-                for (int j = 0; j < 64 && !S.done; j++) {            // the reference's loop body (:1749-1779), scalar
-#pragma unroll
-                    for (int par = 0; par < 2; par++) {
-                        if (S.done || !(((par ? ko : ke) >> j) & 1ULL)) continue;    // not looked up: transparent
-                        const int i = i0 + 2 * j + par;
-                        const int id = __builtin_amdgcn_readlane(ref[2 * hb + par], j);
-                        if (id > 0) { S.lastId = id; if (S.bkStart == -1) S.bkStart = i; S.bkStop = i; }
-                        else if (S.bkStart > -1) {
-                            const int dif = S.bkStop - S.bkStart - sub;
-                            S.bkStop = S.bkStart = -1;
-                            if (dif > 0) {
-                                const int old = S.found;
-                                S.found += dif;
-                                if (S.found > thr && old <= thr) { S.rid = S.lastId; S.done = true; }     // :1763-1773 early exit
-                            }
-                        }
-                    }
-                }
+                big_fold(S, __ballot(ok[2 * hb]), __ballot(ok[2 * hb + 1]), ref[2 * hb], ref[2 * hb + 1], i0, sub, thr);
             }
         }
     }
@@ -2545,6 +2550,37 @@ __device__ __forceinline__ void main_scan_pair_best(const KParams& P, const Plan
     A.found = SA.found; A.ref = SA.rid; B.found = SB.found; B.ref = SB.rid;
 }
 
+// countSetKmersBig (k > 31: runs of consecutive matching 31-mers) on the wave kernel's pair scan; A.found / A.ref = the count / the scaffold
+// returned, A.maxBad = the read's threshold
+#define BBDUK_MODE_KBIG 7                           // internal: kfilter with kbig > k, as a mode of bbduk_wave_kernel
+template <bool FORBIDN, bool GENERAL>
+__device__ __forceinline__ void main_scan_pair_kbig(const KParams& P, const Planes& Q, ReadScan& A, ReadScan& B, const int lane) {
+    ReadWin WA, WB;
+    win_init<FORBIDN, GENERAL>(P, Q, A, WA, lane);
+    win_init<FORBIDN, GENERAL>(P, Q, B, WB, lane);
+    int ibA = WA.first, ibB = WB.first;
+    bool onA = WA.on, onB = WB.on;
+    const int sub = P.kbig - P.k - 1;
+    KScanState SA, SB; kscan_init(SA); kscan_init(SB);
+    while (onA || onB) {
+        uint64_t kmer[4], rk[4]; bool ok[4]; int id[4];
+        windows2<FORBIDN, GENERAL>(P, Q, WA, ibA + 2 * lane, onA, kmer, rk, ok);
+        windows2<FORBIDN, GENERAL>(P, Q, WB, ibB + 2 * lane, onB, kmer + 2, rk + 2, ok + 2);
+        lookup4_probe<GENERAL>(P, Q.filt, kmer, rk, ok, id);
+        const uint64_t m0 = __ballot(id[0] != -1), m1 = __ballot(id[1] != -1), m2 = __ballot(id[2] != -1), m3 = __ballot(id[3] != -1);
+        if (onA) {
+            if ((m0 | m1) || SA.bkStart >= 0) big_fold(SA, __ballot(ok[0]), __ballot(ok[1]), id[0], id[1], ibA, sub, A.maxBad);
+            ibA += 128; onA = !SA.done && ibA < WA.stop;
+        }
+        if (onB) {
+            if ((m2 | m3) || SB.bkStart >= 0) big_fold(SB, __ballot(ok[2]), __ballot(ok[3]), id[2], id[3], ibB, sub, B.maxBad);
+            ibB += 128; onB = !SB.done && ibB < WB.stop;
+        }
+    }
+    kscan_finish<RED_BIG>(SA, A.maxBad, sub, lane); kscan_finish<RED_BIG>(SB, B.maxBad, sub, lane);
+    A.found = SA.found; A.ref = SA.rid; B.found = SB.found; B.ref = SB.rid;
+}
+
 // --------------------------------------------------------------------------------------------------
 // Wave-autonomous batch kernel (the fast path): every wave owns a mini-tile of MT_READS consecutive reads,
 // stages it into its private slice of LDS and scans it, with no workgroup barrier after the one that lands
@@ -2589,6 +2625,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
     // address 0 + offset), which saves an add per lookup.  Behind it: per-wave planes, counters, short-scan lists.
     extern __shared__ uint32_t s_dyn[];
     uint32_t* const s_filt = s_dyn;
+    constexpr bool KBIG = MODE == BBDUK_MODE_KBIG;                // kfilter with k > 31: runs of matching 31-mers (main_scan_pair_kbig)
     constexpr bool FBM = MODE == BBDUK_MODE_FBM;                  // kfilter with findBestMatch: per-read id lists in the pair scan (main_scan_pair_best)
     constexpr bool KMASK = MODE == BBDUK_MODE_KMASK;              // ktrim=n: every hit of the main scan, both ends' short k-mers, a mask per base
     constexpr int CAPB = KMASK ? WCAP_BASES_KM : WCAP_BASES;      // per-wave plane capacity in bases
@@ -2837,6 +2874,16 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                 if constexpr (TIPS) {
                     if (pass == 0) main_scan_pair<BBDUK_MODE_KTRIM_R, FORBIDN, GENERAL, false, true, false, true>(P, Q, A, Bz, lane);
                     else main_scan_pair<BBDUK_MODE_KTRIM_L, FORBIDN, GENERAL, false, true, false, true>(P, Q, A, Bz, lane);
+                } else if constexpr (KBIG) {
+                    if constexpr (GENERAL) {
+                        if (P.mkf != 0.f) {                         // :1056-1062 with keff = kbig: numValidKmers over windows longer than a plane word
+                            const int va = (A.L >= P.kbig) ? valid_kmers_any_k(Q, A.base0, A.L, P.kbig, lane) : 0;
+                            const int vb = (hasB && Bz.L >= P.kbig) ? valid_kmers_any_k(Q, Bz.base0, Bz.L, P.kbig, lane) : 0;
+                            A.maxBad = max(P.maxBadKmers, (int)((float)(va - 1) * P.mkf)); Bz.maxBad = max(P.maxBadKmers, (int)((float)(vb - 1) * P.mkf));
+                            vThr = (lane == ra) ? A.maxBad : ((lane == ra + 1) ? Bz.maxBad : vThr);
+                        }
+                    }
+                    main_scan_pair_kbig<FORBIDN, GENERAL>(P, Q, A, Bz, lane);
                 } else if constexpr (FBM) main_scan_pair_best<FORBIDN, GENERAL>(P, Q, A, Bz, lane, counters, r0 + ra, r0 + ra + 1, hasB);
                 else if constexpr (KMASK) main_scan_pair<BBDUK_MODE_KTRIM_L, FORBIDN, GENERAL, false, false, true, true>(P, Q, A, Bz, lane, -1, wh);   // hits counted, first id kept, none ends the scan
                 else main_scan_pair<MODE, FORBIDN, GENERAL, BIG, false, false, true>(P, Q, A, Bz, lane);
@@ -3150,14 +3197,15 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                 if (remove) { vRm += 1; vBm += (unsigned)npl; }
                 if (P.tf) vBm += (unsigned)npl;
             }
-        } else if constexpr (FBM) {
-            // findBestMatch (:1064-1089): discard iff a scaffold was returned; the counters are kfilter's
+        } else if constexpr (FBM || KBIG) {
+            // findBestMatch (:1064-1089): discard iff a scaffold was returned; countSetKmersBig: iff the count passes the read's threshold
+            // (the scaffold it returns is credited then); the counters are kfilter's
             hit = mine && vScan && vRef > 0; ref = vRef; a = (mine && vScan) ? vFound : 0; newLen = vL;
             if (hit) id = ref_to_id(P, ref);
             if (P.matchN && mine && !vScan) P.matchN[r0 + lane] = 0;
             int fLen = vL;
             if (P.storedKmers > 0) {
-                d = hit; tf1bp(P, d, fLen);
+                d = KBIG ? (a > vThr) : hit; tf1bp(P, d, fLen);
                 if (paired) { const bool dm = __shfl_xor((int)d, 1) != 0; remove = (P.rieb && (d || dm)) || (d && dm); }
                 else remove = d;
             }
@@ -3301,7 +3349,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
         }
     }
     __syncthreads();
-    if (tid == 0) publish_counters<MODE == BBDUK_MODE_KTRIM_TIPS ? BBDUK_MODE_KTRIM_R : (MODE == BBDUK_MODE_FBM ? BBDUK_MODE_KFILTER : MODE)>(s_acc, counters, P.tf != 0);
+    if (tid == 0) publish_counters<MODE == BBDUK_MODE_KTRIM_TIPS ? BBDUK_MODE_KTRIM_R : ((MODE == BBDUK_MODE_FBM || MODE == BBDUK_MODE_KBIG) ? BBDUK_MODE_KFILTER : MODE)>(s_acc, counters, P.tf != 0);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -4057,7 +4105,6 @@ extern "C" int bbduk_create(const bbduk_params* p, bbduk_handle** out) {
     if (p->minlen != p->k - 1) return BBDUK_ERR_ARG;
     if (p->speed < 0 || p->speed > 16 || p->qSkip < 0) return BBDUK_ERR_ARG;    // BBDukParser.java:568
     if (p->kmaskFullyCovered && p->mode != BBDUK_MODE_KMASK) return BBDUK_ERR_ARG;
-    if (p->trimFailuresTo1bp && p->kbig > p->k && !(p->minCoveredFraction > 0.f)) return BBDUK_ERR_ARG;   // k>31 runs on the tiled kernel only
     if (p->reserved0 != 0) return BBDUK_ERR_ARG;
     const bool big = p->kbig > p->k;
     if (big) {                                                                  // BBDukParser.java:164, 207-243, 299
@@ -4552,18 +4599,22 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
         // wave's planes (bit 0) sends it to the tiled kernel, else bbduk_wave_kernel<KSPLIT> takes it
         const int sgrid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)h->numCU * 8);
         bbduk_span_kernel<<<dim3(std::max(sgrid, 1)), dim3(256), 0, st>>>(d_offsets, n, 0, d_flag, red == RED_SPLIT && !packed ? (int64_t)WUNIT_MAX : (int64_t)(KM_CAP_BASES - 32), (int64_t)(KM_CAP_BASES - 32));
-        if (red == RED_BEST) {                                      // findBestMatch: a unit (pair) beyond a wave's planes (bit 0) -> the tiled kernel
+        if (red != RED_SPLIT) {                                     // findBestMatch, k > 31: a unit (pair) beyond a wave's planes (bit 0) -> the tiled kernel
             const int64_t units = paired ? n / 2 : n;
             const int ugrid = (int)std::min<int64_t>((units + 255) / 256, (int64_t)h->numCU * 8);
             bbduk_span_kernel<<<dim3(std::max(ugrid, 1)), dim3(256), 0, st>>>(d_offsets, n, (int)paired, d_flag, (int64_t)WUNIT_MAX, (int64_t)0x7FFFFFFFFFFFLL);
         }
     }
-    if (red == RED_BEST) {                                          // the main kernel's shape; the pair scan keeps an id list per read (main_scan_pair_best)
-        K.waveFirst = 1;
+    if (red != RED_SPLIT) {                                         // the main kernel's shape; the pair scan keeps an id list (main_scan_pair_best) or the run state
+        K.waveFirst = 1;                                            // (main_scan_pair_kbig) per read
         const bool general = params_general(h->p);
-        const batch_kernel_t wk = general ? bbduk_wave_kernel<BBDUK_MODE_FBM, false, true, true, 2>
+        const batch_kernel_t wkBest = general ? bbduk_wave_kernel<BBDUK_MODE_FBM, false, true, true, 2>
                                 : (packed ? (K.forbidNs ? bbduk_wave_kernel<BBDUK_MODE_FBM, false, true, false, 1> : bbduk_wave_kernel<BBDUK_MODE_FBM, false, false, false, 1>)
                                           : (K.forbidNs ? bbduk_wave_kernel<BBDUK_MODE_FBM, false, true, false, 0> : bbduk_wave_kernel<BBDUK_MODE_FBM, false, false, false, 0>));
+        const batch_kernel_t wkBig = general ? bbduk_wave_kernel<BBDUK_MODE_KBIG, false, true, true, 2>
+                                : (packed ? (K.forbidNs ? bbduk_wave_kernel<BBDUK_MODE_KBIG, false, true, false, 1> : bbduk_wave_kernel<BBDUK_MODE_KBIG, false, false, false, 1>)
+                                          : (K.forbidNs ? bbduk_wave_kernel<BBDUK_MODE_KBIG, false, true, false, 0> : bbduk_wave_kernel<BBDUK_MODE_KBIG, false, false, false, 0>));
+        const batch_kernel_t wk = red == RED_BEST ? wkBest : wkBig;
         const size_t waveLds = dynLds + WAVE_LDS_BYTES;
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(wk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)waveLds));
         const int64_t nmt = (n + MT_READS - 1) / MT_READS;

@@ -109,7 +109,7 @@ typedef struct bbduk_params {
                                        would be discarded is cut to its FIRST base instead, "discarded" then means "one base long", pairs are
                                        removed only when both mates are, and nothing is evicted: BBDUK_FLAG_DISCARDED marks the reads to cut
                                        (after the k-trim the operator reports), BBDUK_FLAG_REMOVED is never set, readsOutm stays 0.  Served
-                                       by the main kernel (every unit <= 2512 bases); longer units and k>31: BBDUK_ERR_UNSUPPORTED / _ARG */
+                                       by the main kernel (every unit <= 2512 bases); longer units: BBDUK_ERR_UNSUPPORTED */
     int32_t reserved0;              /* 0 */
 } bbduk_params;
 

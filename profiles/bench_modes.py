@@ -18,7 +18,8 @@ def run(reads=20_000_000):
     L = B.lib()
     for args, mode in (("ktrim=n k=23 mink=11 hdist=1 ref=adapters", "kmask"), ("ktrim=rl k=23 mink=11 hdist=1 ref=adapters", "tips"),
                        ("ksplit=t k=23 mink=11 hdist=1 ref=adapters", "ksplit"),
-                       ("k=23 hdist=1 fbm ref=adapters", "fbm"), ("k=23 hdist=1 rename=t ref=adapters", "fbm+matches")):
+                       ("k=23 hdist=1 fbm ref=adapters", "fbm"), ("k=23 hdist=1 rename=t ref=adapters", "fbm+matches"),
+                       ("k=40 hdist=1 ref=phix", "k40")):
         duk = B.BBDuk(args)
         d_a = torch.empty(n, dtype=torch.int32, device="cuda"); d_b = torch.empty(n, dtype=torch.int32, device="cuda"); d_c2 = torch.empty(n, dtype=torch.int32, device="cuda")
         d_i = torch.empty(n, dtype=torch.int32, device="cuda"); d_f = torch.empty(n, dtype=torch.uint8, device="cuda")
@@ -33,7 +34,7 @@ def run(reads=20_000_000):
                 rc = L.bbduk_kmask_batch_device(h, d_bases.data_ptr(), d_off.data_ptr(), n, n * 150, 1, d_a.data_ptr(), d_i.data_ptr(), d_f.data_ptr(), d_m.data_ptr(), d_ctr.data_ptr(), None)
             elif mode == "tips":
                 rc = L.bbduk_ktrimtips_batch_device(h, d_bases.data_ptr(), d_off.data_ptr(), n, n * 150, 1, d_a.data_ptr(), d_b.data_ptr(), d_i.data_ptr(), d_f.data_ptr(), d_ctr.data_ptr(), None)
-            elif mode == "fbm":
+            elif mode in ("fbm", "k40"):
                 rc = L.bbduk_kfilter_batch_device(h, d_bases.data_ptr(), d_off.data_ptr(), n, n * 150, 1, d_a.data_ptr(), d_i.data_ptr(), d_f.data_ptr(), d_ctr.data_ptr(), None)
             elif mode == "fbm+matches":                       # the lists rename=t prints, eight entries per read
                 rc = L.bbduk_kfilter_batch_matches_device(h, d_bases.data_ptr(), d_off.data_ptr(), n, n * 150, 1, d_a.data_ptr(), d_i.data_ptr(), d_f.data_ptr(),
