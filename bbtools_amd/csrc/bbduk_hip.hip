@@ -288,10 +288,12 @@ __device__ __noinline__ int get_value_expand(const KParams& P, uint64_t kmer, ui
     return get_value<2>(P, kmer, rkmer, lengthMask, len, qh);
 }
 // index.getValue(kmer, rkmer, lengthMask, qPos, len, qHDist) as a ref: filtered fast path when there is no query expansion
-template <bool GENERAL>
+// QH = false (bbduk_wave_kernel): no query expansion in this instantiation -- batches with qhdist / qhdist2 > 0 go to the tiled kernels, so the
+// wave kernels carry neither the expansion's calls nor the register spills around them
+template <bool GENERAL, bool QH = true>
 __device__ __forceinline__ int lookup(const KParams& P, const uint32_t* s_filt, uint64_t kmer, uint64_t rkmer,
                                       uint64_t lengthMask, int len, int qh, bool ok) {
-    if constexpr (GENERAL) {
+    if constexpr (GENERAL && QH) {
         if (qh > 0) {
             const int id = ok ? get_value_expand(P, kmer, rkmer, lengthMask, len, qh) : -1;
             return id > 0 ? id : -1;
@@ -527,7 +529,7 @@ __device__ __forceinline__ void finish_read(const KParams& P, const int L, const
 
 struct ReadWin { int first, stop, start, base0; bool on, full, hasN; };   // wave-uniform per read
 
-template <bool FORBIDN, bool GENERAL, bool BIG = false>
+template <bool FORBIDN, bool GENERAL, bool BIG = false, bool SPAN = false>
 __device__ __forceinline__ void win_init(const KParams& P, const Planes& Q, const ReadScan& R, ReadWin& W, const int lane) {
     W.start = R.start; W.stop = R.stop; W.base0 = R.base0;
     W.first = max(R.start, P.k - 1);                             // i>=minlen (minlen=k-1)
@@ -546,7 +548,9 @@ __device__ __forceinline__ void win_init(const KParams& P, const Planes& Q, cons
         }
         W.hasN = __ballot(acc != 0) != 0;
     }
-    W.full = (!GENERAL || (W.start == 0 && P.qskip < 2));        // every window holds k bases and every position is looked up
+    // full: the fast window path serves the read -- every window holds k bases and every position is looked up; with SPAN it also cuts the
+    // windows in front of `start` and thins the positions by qskip itself
+    W.full = (!GENERAL || SPAN || (W.start == 0 && P.qskip < 2));
 }
 
 // kmer / rkmer of the windows ending at the ADJACENT positions i and i+1 of read W (lane-varying i); ok=false: no
@@ -572,6 +576,9 @@ __device__ __forceinline__ void windows2(const KParams& P, const Planes& Q, cons
         }
         ok[0] = on & (i < W.stop);
         ok[1] = on & (i + 1 < W.stop);
+        if constexpr (GENERAL && SPAN) {
+            if (P.qskip > 1) { ok[0] = ok[0] && (i % P.qskip) == 0; ok[1] = ok[1] && ((i + 1) % P.qskip) == 0; }     // BBDukIndexMod.java:494
+        }
         if (rkRaw) { rkRaw[0] = rk[0]; rkRaw[1] = rk[1]; }        // before any reset (big layout: the neighbours' minimizer hashes)
         int cut[2] = {0, 0};                                      // SPAN: bases of the window that lie in front of the span
         if constexpr (SPAN) {
@@ -791,10 +798,7 @@ __device__ __forceinline__ void cand_resolve4(const KParams& P, const Cand4& C, 
 // ktrim=rl): the straight-line probe, one scalar test that ends most blocks, and only flagged lanes fetch keys.  Exact like lookup4.
 template <bool GENERAL>
 __device__ __forceinline__ void lookup4_probe(const KParams& P, const uint32_t* s_filt, const uint64_t* kmer, const uint64_t* rk, const bool* ok, int* ref) {
-    if constexpr (GENERAL) {
-        if (P.qhdist > 0) { lookup4<GENERAL>(P, s_filt, kmer, rk, ok, ref); return; }
-    }
-    Cand4 C;
+    Cand4 C;                                                      // (no query expansion here: such batches run on the tiled kernels)
     const uint64_t any = cand_probe4<GENERAL, false, true>(P, s_filt, kmer, rk, C);
 #pragma unroll
     for (int s = 0; s < 4; s++) ref[s] = -1;
@@ -1092,8 +1096,8 @@ template <int MODE, bool FORBIDN, bool GENERAL, bool BIG = false, bool SPAN = fa
 __device__ __forceinline__ void main_scan_pair(const KParams& P, const Planes& Q, ReadScan& A, ReadScan& B, const int lane, const int firstA = -1,
                                                uint32_t* hitPlane = nullptr) {
     ReadWin WA, WB;
-    win_init<FORBIDN, GENERAL>(P, Q, A, WA, lane);
-    win_init<FORBIDN, GENERAL>(P, Q, B, WB, lane);
+    win_init<FORBIDN, GENERAL, false, SPAN>(P, Q, A, WA, lane);
+    win_init<FORBIDN, GENERAL, false, SPAN>(P, Q, B, WB, lane);
     if (firstA >= 0) { WA.first = max(WA.first, firstA); WA.on = A.scan && WA.first < WA.stop; }
     int ibA = WA.first, ibB = WB.first, foundA = (firstA >= 0) ? A.found : 0, foundB = 0;
     bool onA = WA.on, onB = WB.on;
@@ -1176,8 +1180,8 @@ __device__ __forceinline__ void left_scan_quad(const KParams& P, const Planes& Q
 template <bool FORBIDN, bool GENERAL, bool NOMM, bool BIG = false, bool SPAN = false>
 __device__ __forceinline__ void main_scan_pair_cand(const KParams& P, const Planes& Q, ReadScan& A, ReadScan& B, const int lane, const int firstA = -1) {
     ReadWin WA, WB;
-    win_init<FORBIDN, GENERAL, BIG>(P, Q, A, WA, lane);
-    win_init<FORBIDN, GENERAL, BIG>(P, Q, B, WB, lane);
+    win_init<FORBIDN, GENERAL, BIG, SPAN>(P, Q, A, WA, lane);
+    win_init<FORBIDN, GENERAL, BIG, SPAN>(P, Q, B, WB, lane);
     if (firstA >= 0) { WA.first = max(WA.first, firstA); WA.on = A.scan && WA.first < WA.stop; }     // resume behind an impostor
     int ibA = WA.first, ibB = WB.first;
     bool onA = WA.on, onB = WB.on;
@@ -1186,7 +1190,8 @@ __device__ __forceinline__ void main_scan_pair_cand(const KParams& P, const Plan
     // Lanes past a read's end look up whatever lies behind it in the planes.  When every window of the read is plain
     // nothing masks them: positions grow with the lane, so a first candidate at a position >= stop means the read has
     // none.  Reads with cut or reset windows (restrictRight, an undefined base) mask their ballots with `ok` instead.
-    const bool plainA = WA.full && !((FORBIDN || BIG) && WA.hasN) && !(SPAN && WA.start > 0), plainB = WB.full && !((FORBIDN || BIG) && WB.hasN) && !(SPAN && WB.start > 0);
+    const bool thin = GENERAL && SPAN && P.qskip > 1;             // qskip: `ok` thins the positions
+    const bool plainA = WA.full && !thin && !((FORBIDN || BIG) && WA.hasN) && !(SPAN && WA.start > 0), plainB = WB.full && !thin && !((FORBIDN || BIG) && WB.hasN) && !(SPAN && WB.start > 0);
     while (onA || onB) {
         uint64_t kmer[4], rk[4], rkRaw[4]; bool ok[4]; int ref[4]; Cand4 C;
         windows2<FORBIDN, GENERAL, SPAN>(P, Q, WA, ibA + 2 * lane, onA, kmer, rk, ok, BIG ? rkRaw : nullptr);
@@ -2530,15 +2535,15 @@ template <bool FORBIDN, bool GENERAL>
 __device__ __forceinline__ void main_scan_pair_best(const KParams& P, const Planes& Q, ReadScan& A, ReadScan& B, const int lane,
                                                     int64_t* __restrict__ counters, const int64_t readA, const int64_t readB, const bool hasB) {
     ReadWin WA, WB;
-    win_init<FORBIDN, GENERAL>(P, Q, A, WA, lane);
-    win_init<FORBIDN, GENERAL>(P, Q, B, WB, lane);
+    win_init<FORBIDN, GENERAL, false, GENERAL>(P, Q, A, WA, lane);
+    win_init<FORBIDN, GENERAL, false, GENERAL>(P, Q, B, WB, lane);
     int ibA = WA.first, ibB = WB.first;
     bool onA = WA.on, onB = WB.on;
     KScanState SA, SB; kscan_init(SA); kscan_init(SB);
     while (onA || onB) {
         uint64_t kmer[4], rk[4]; bool ok[4]; int id[4];
-        windows2<FORBIDN, GENERAL>(P, Q, WA, ibA + 2 * lane, onA, kmer, rk, ok);
-        windows2<FORBIDN, GENERAL>(P, Q, WB, ibB + 2 * lane, onB, kmer + 2, rk + 2, ok + 2);
+        windows2<FORBIDN, GENERAL, GENERAL>(P, Q, WA, ibA + 2 * lane, onA, kmer, rk, ok);
+        windows2<FORBIDN, GENERAL, GENERAL>(P, Q, WB, ibB + 2 * lane, onB, kmer + 2, rk + 2, ok + 2);
         lookup4_probe<GENERAL>(P, Q.filt, kmer, rk, ok, id);
         const uint64_t m0 = __ballot(id[0] != -1), m1 = __ballot(id[1] != -1), m2 = __ballot(id[2] != -1), m3 = __ballot(id[3] != -1);
         if (onA) { if (m0 | m1) best_fold(SA, m0, m1, id[0], id[1], lane, counters); ibA += 128; onA = ibA < WA.stop; }
@@ -2556,16 +2561,16 @@ __device__ __forceinline__ void main_scan_pair_best(const KParams& P, const Plan
 template <bool FORBIDN, bool GENERAL>
 __device__ __forceinline__ void main_scan_pair_kbig(const KParams& P, const Planes& Q, ReadScan& A, ReadScan& B, const int lane) {
     ReadWin WA, WB;
-    win_init<FORBIDN, GENERAL>(P, Q, A, WA, lane);
-    win_init<FORBIDN, GENERAL>(P, Q, B, WB, lane);
+    win_init<FORBIDN, GENERAL, false, GENERAL>(P, Q, A, WA, lane);
+    win_init<FORBIDN, GENERAL, false, GENERAL>(P, Q, B, WB, lane);
     int ibA = WA.first, ibB = WB.first;
     bool onA = WA.on, onB = WB.on;
     const int sub = P.kbig - P.k - 1;
     KScanState SA, SB; kscan_init(SA); kscan_init(SB);
     while (onA || onB) {
         uint64_t kmer[4], rk[4]; bool ok[4]; int id[4];
-        windows2<FORBIDN, GENERAL>(P, Q, WA, ibA + 2 * lane, onA, kmer, rk, ok);
-        windows2<FORBIDN, GENERAL>(P, Q, WB, ibB + 2 * lane, onB, kmer + 2, rk + 2, ok + 2);
+        windows2<FORBIDN, GENERAL, GENERAL>(P, Q, WA, ibA + 2 * lane, onA, kmer, rk, ok);
+        windows2<FORBIDN, GENERAL, GENERAL>(P, Q, WB, ibB + 2 * lane, onB, kmer + 2, rk + 2, ok + 2);
         lookup4_probe<GENERAL>(P, Q.filt, kmer, rk, ok, id);
         const uint64_t m0 = __ballot(id[0] != -1), m1 = __ballot(id[1] != -1), m2 = __ballot(id[2] != -1), m3 = __ballot(id[3] != -1);
         if (onA) {
@@ -2851,7 +2856,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                 A.found = 0; A.iFirst = BIGLOC; A.iLast = -1; A.ref = -1; A.shortFl = -1; A.shortLl = -1;
                 Bz.found = 0; Bz.iFirst = BIGLOC; Bz.iLast = -1; Bz.ref = -1; Bz.shortFl = -1; Bz.shortLl = -1;
                 if (candP) {
-                    if (!TSW(P, 3)) main_scan_pair_cand<FORBIDN, GENERAL, SHORT && !GENERAL && !TIPS, BIG, TIPS>(P, Q, A, Bz, lane); else { A.candSlot = -1; Bz.candSlot = -1; }
+                    if (!TSW(P, 3)) main_scan_pair_cand<FORBIDN, GENERAL, SHORT && !GENERAL && !TIPS, BIG, TIPS || GENERAL>(P, Q, A, Bz, lane); else { A.candSlot = -1; Bz.candSlot = -1; }
                     if (A.candSlot != -1) {
                         vCSlot = (lane == ra) ? A.candSlot : vCSlot; vFirst = (lane == ra) ? A.iFirst : vFirst;
                         vCKeyLo = (lane == ra) ? A.candKeyLo : vCKeyLo; vCKeyHi = (lane == ra) ? A.candKeyHi : vCKeyHi;
@@ -2885,8 +2890,8 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                     }
                     main_scan_pair_kbig<FORBIDN, GENERAL>(P, Q, A, Bz, lane);
                 } else if constexpr (FBM) main_scan_pair_best<FORBIDN, GENERAL>(P, Q, A, Bz, lane, counters, r0 + ra, r0 + ra + 1, hasB);
-                else if constexpr (KMASK) main_scan_pair<BBDUK_MODE_KTRIM_L, FORBIDN, GENERAL, false, false, true, true>(P, Q, A, Bz, lane, -1, wh);   // hits counted, first id kept, none ends the scan
-                else main_scan_pair<MODE, FORBIDN, GENERAL, BIG, false, false, true>(P, Q, A, Bz, lane);
+                else if constexpr (KMASK) main_scan_pair<BBDUK_MODE_KTRIM_L, FORBIDN, GENERAL, false, GENERAL, true, true>(P, Q, A, Bz, lane, -1, wh);   // hits counted, first id kept, none ends the scan
+                else main_scan_pair<MODE, FORBIDN, GENERAL, BIG, GENERAL, false, true>(P, Q, A, Bz, lane);
                 if (A.found) {                                      // hand the facts to lane ra (most reads have none)
                     vFound = (lane == ra) ? A.found : vFound; vFirst = (lane == ra) ? A.iFirst : vFirst;
                     vLast = (lane == ra) ? A.iLast : vLast;   vRef = (lane == ra) ? A.ref : vRef;
@@ -2966,8 +2971,8 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                     }
                     A.found = 0; A.iFirst = BIGLOC; A.iLast = -1; A.ref = -1; A.shortFl = -1; A.shortLl = -1;
                     Bz.found = 0; Bz.iFirst = BIGLOC; Bz.iLast = -1; Bz.ref = -1; Bz.shortFl = -1; Bz.shortLl = -1;
-                    if constexpr (TIPS) main_scan_pair<BBDUK_MODE_KTRIM_R, FORBIDN, GENERAL, false, true>(P, Q, A, Bz, lane);
-                    else main_scan_pair<MODE, FORBIDN, GENERAL, BIG>(P, Q, A, Bz, lane);
+                    if constexpr (TIPS) main_scan_pair<BBDUK_MODE_KTRIM_R, FORBIDN, GENERAL, false, true, false, true>(P, Q, A, Bz, lane);
+                    else main_scan_pair<MODE, FORBIDN, GENERAL, BIG, GENERAL, false, true>(P, Q, A, Bz, lane);
                     vFound = (lane == ra) ? A.found : vFound; vFirst = (lane == ra) ? A.iFirst : vFirst; vRef = (lane == ra) ? A.ref : vRef;
                     if (hasB) { vFound = (lane == ra + 1) ? Bz.found : vFound; vFirst = (lane == ra + 1) ? Bz.iFirst : vFirst; vRef = (lane == ra + 1) ? Bz.ref : vRef; }
                     fbm &= ~(3ULL << ra);
@@ -3065,7 +3070,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                                     rk   = extract2(Q.cmp, jb + jstop - Lc, Lc) & P.mask;            // base i in bits 0-1
                                 }
                             }
-                            const int sref = lookup<GENERAL>(P, Q.filt, kmer, rk, 1ULL << (2 * Lc), Lc, P.qhdist2, act);
+                            const int sref = lookup<GENERAL, false>(P, Q.filt, kmer, rk, 1ULL << (2 * Lc), Lc, 0, act);
                             take_hits(__ballot(sref != -1), sref, pb);
                         }
                     }
@@ -4257,6 +4262,9 @@ static Sink make_sink(const bbduk_handle* h, const BuildState* st) {
 }
 // The configurations the big-layout kernels run: plain kfilter (what pick_kernel calls "not general"), no k>31 runs, no findBestMatch.
 // Every other configuration keeps the cache-resident layout at any size it can index (2^29 buckets, ~10^9 keys), as before.
+// qhdist / qhdist2 > 0: every query k-mer is looked up with its whole Hamming neighbourhood (1 + 3k lookups per position at distance 1).  Only the
+// tiled kernels carry that code; the wave kernels stand back (their flag starts at 1).
+static bool query_expansion(const bbduk_params& p) { return p.qhdist > 0 || (p.qhdist2 > 0 && p.mink > 0 && p.mink < p.k); }
 static bool params_general(const bbduk_params& p) {               // the same predicate as pick_kernel's, on the boundary struct
     const bool useShort = p.mink > 0 && p.mink < p.k;
     return p.qhdist > 0 || p.qhdist2 > 0 || p.restrictLeft > 0 || p.restrictRight > 0 || p.skipR1 || p.skipR2 || !p.rcomp ||
@@ -4595,6 +4603,7 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     HIP_TRY(h, hipEventRecord(h->ev0[evi], st));
     int* const d_flag = h->d_slowFlag + evi;
     HIP_TRY(h, hipMemsetAsync(d_flag, 0, sizeof(int), st));
+    if (query_expansion(h->p)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
     {   // pre-pass per READ: one beyond the tiled kernel's planes sends the batch to bbduk_kscan_long_kernel; ksplit: one beyond a
         // wave's planes (bit 0) sends it to the tiled kernel, else bbduk_wave_kernel<KSPLIT> takes it
         const int sgrid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)h->numCU * 8);
@@ -4674,8 +4683,9 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
     int* const d_flag = h->d_slowFlag + evi;
     HIP_TRY(h, hipMemsetAsync(d_flag, 0, sizeof(int), st));
+    if (query_expansion(h->p)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
     if (h->hookForceTile) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }
-    else {
+    {
         const int64_t units = paired ? n / 2 : n;
         const int sgrid = (int)std::min<int64_t>((units + 255) / 256, (int64_t)h->numCU * 8);
         bbduk_span_kernel<<<dim3(std::max(sgrid, 1)), dim3(256), 0, st>>>(d_offsets, n, (int)paired, d_flag);
@@ -4687,9 +4697,9 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
     HIP_TRY(h, hipEventRecord(h->ev0[evi], st));
     kp.wave<<<dim3(wgrid), dim3(BLOCK_THREADS), waveLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
-    HIP_TRY(h, hipEventRecord(h->ev1[evi], st));
-    h->evCount++;
     kp.tile<<<dim3(tgrid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
+    HIP_TRY(h, hipEventRecord(h->ev1[evi], st));                    // around both: whichever of the two took the batch (the other returns at once)
+    h->evCount++;
     {   // reads beyond BBDUK_MAX_READ_LEN: chunked scan, one wave per unit (returns at once unless the pre-pass asked for it)
         const batch_kernel_t lk = K.mode == BBDUK_MODE_KFILTER ? (K.big ? bbduk_long_kernel<BBDUK_MODE_KFILTER, true> : bbduk_long_kernel<BBDUK_MODE_KFILTER>) :
                                   (K.mode == BBDUK_MODE_KTRIM_L ? bbduk_long_kernel<BBDUK_MODE_KTRIM_L> : bbduk_long_kernel<BBDUK_MODE_KTRIM_R>);
@@ -4889,6 +4899,7 @@ static int launch_tips(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d
     const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
     int* const d_flag = h->d_slowFlag + evi;
     HIP_TRY(h, hipMemsetAsync(d_flag, 0, sizeof(int), st));
+    if (query_expansion(h->p)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
     {   // pre-pass: a unit (pair) beyond a wave's planes (bit 0) sends the batch to the tiled kernel, a READ beyond the tiled kernel's
         // planes (bit 1) to bbduk_long_tips_kernel; else bbduk_wave_kernel<KTRIM_TIPS> takes it
         const int64_t units = paired ? n / 2 : n;
@@ -4993,6 +5004,7 @@ static int launch_kmask(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
     int* const d_flag = h->d_slowFlag + evi;
     HIP_TRY(h, hipMemsetAsync(d_flag, 0, sizeof(int), st));
+    if (query_expansion(h->p)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
     if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
     {   // pre-pass: a unit (pair) beyond a wave's planes sends the batch to the tiled kernel (which in turn leaves the reads beyond ITS planes
         // to bbduk_kmask_long_kernel); else bbduk_wave_kernel<KMASK> takes it
