@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Secondary measurement: configurations that run in the GENERAL kernel instantiations (and a few plain ones for scale) on the configs[1] reads,
+device-resident, kernel time from the library's HIP events.  One JSON line per configuration."""
 import sys, json, os
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import torch
 from bbtools_amd import bbduk as B
 n = 20_000_000
