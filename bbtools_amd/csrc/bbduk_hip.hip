@@ -38,6 +38,11 @@ static_assert(sizeof(bbduk_synth_params) == 80, "bbduk_synth_params layout is pa
 
 #define BLOCK_THREADS   1024
 #define NWAVES          (BLOCK_THREADS / 64)
+#ifdef BBDUK_AB_NO_TF
+#define PTF 0
+#else
+#define PTF P.tf
+#endif
 #define TILE_READS      256                    // reads per tile (even: whole pairs)
 #define CAP_BASES       40960                  // LDS plane capacity in bases (>= 2*BBDUK_MAX_READ_LEN + 32: a pair fits)
 #define CAP_CHUNKS      (CAP_BASES / 16)
@@ -420,7 +425,7 @@ __device__ __forceinline__ int trim_by_amount(int len, int left, int right, int 
 }
 // setDiscarded / isDiscarded with trimfailuresto1bp (BBDukProcessorS.java:1464-1482): a read that was to be discarded is cut to one base
 // (if it is longer), and "discarded" then means "exactly one base long" -- also for a read that is one base long for any other reason
-__device__ __forceinline__ void tf1bp(const KParams& P, bool& d, int& len) { if (P.tf) { if (d && len > 1) len = 1; d = (len == 1); } }
+__device__ __forceinline__ void tf1bp(const KParams& P, bool& d, int& len) { if (PTF) { if (d && len > 1) len = 1; d = (len == 1); } }
 __device__ __forceinline__ int imid(int lo, int x, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }   // value known wave-uniform -> SGPR
 
@@ -1511,7 +1516,7 @@ void bbduk_batch_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
                         const int64_t n, const int64_t totalBases, const int paired,
                         int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
                         int64_t* __restrict__ counters, const int* __restrict__ slowFlag) {
-    if (P.tf) return;                                             // trimfailuresto1bp: bbduk_wave_kernel reports BBDUK_ERR_UNSUPPORTED for such batches
+    if (PTF) return;                                             // trimfailuresto1bp: bbduk_wave_kernel reports BBDUK_ERR_UNSUPPORTED for such batches
     if (*slowFlag != 1) return;                                   // 0: every unit fits a wave's planes, the wave kernel ran; 2/3: a unit
                                                                   // exceeds this kernel's planes too, bbduk_long_kernel takes the batch
     __shared__ uint32_t s_fwd[PLANE_PAD + CAP_CHUNKS + PLANE_PAD];   // padded both ends: the plain path reads past a read's end unclamped
@@ -1861,7 +1866,7 @@ void bbduk_kmask_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
     __shared__ unsigned long long s_acc[6];                       // rkt, basesKTrimmed, readsOutm, basesOutm, readsIn, basesIn
     extern __shared__ uint32_t s_filt[];
 
-    if (P.tf) return;                                             // trimfailuresto1bp: bbduk_wave_kernel reports BBDUK_ERR_UNSUPPORTED for such batches
+    if (PTF) return;                                             // trimfailuresto1bp: bbduk_wave_kernel reports BBDUK_ERR_UNSUPPORTED for such batches
     if (P.waveFirst && *longFlag == 0) return;                    // every unit fits a wave's planes: bbduk_wave_kernel<KMASK> did the batch
     const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
@@ -2185,7 +2190,7 @@ void bbduk_kscan_kernel(const KParams P, const uint8_t* __restrict__ bases, cons
                         const int64_t n, const int64_t totalBases, const int paired,
                         int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
                         int32_t* __restrict__ outLeft, int32_t* __restrict__ outRight, int64_t* __restrict__ counters, const int* __restrict__ longFlag) {
-    if (P.tf) return;                                             // trimfailuresto1bp: bbduk_wave_kernel reports BBDUK_ERR_UNSUPPORTED for such batches
+    if (PTF) return;                                             // trimfailuresto1bp: bbduk_wave_kernel reports BBDUK_ERR_UNSUPPORTED for such batches
     if (*longFlag & 2) return;                                    // a read beyond these planes: bbduk_kscan_long_kernel takes the batch
     if (P.waveFirst && *longFlag == 0) return;                    // every read fits a wave's planes: bbduk_wave_kernel<KSPLIT> did the batch
     __shared__ uint32_t s_fwd[PLANE_PAD + KM_CAP_CHUNKS + PLANE_PAD];
@@ -2382,7 +2387,7 @@ void bbduk_ktrimtips_kernel(const KParams P, const uint8_t* __restrict__ bases, 
                             const int64_t n, const int64_t totalBases, const int paired,
                             int32_t* __restrict__ outRight, int32_t* __restrict__ outLeft, int32_t* __restrict__ outId,
                             uint8_t* __restrict__ outFlags, int64_t* __restrict__ counters, const int* __restrict__ longFlag) {
-    if (P.tf) return;                                             // trimfailuresto1bp: bbduk_wave_kernel reports BBDUK_ERR_UNSUPPORTED for such batches
+    if (PTF) return;                                             // trimfailuresto1bp: bbduk_wave_kernel reports BBDUK_ERR_UNSUPPORTED for such batches
     if (*longFlag & 2) return;                                    // a read beyond these planes: bbduk_long_tips_kernel takes the batch
     if (P.waveFirst && *longFlag == 0) return;                    // every unit fits a wave's planes: bbduk_wave_kernel<KTRIM_TIPS> did the batch
     __shared__ uint32_t s_fwd[PLANE_PAD + KM_CAP_CHUNKS + PLANE_PAD];
@@ -2650,7 +2655,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
     }
     __syncthreads();
     if (*slowFlag != 0) {                                         // a unit does not fit a wave's planes: tile kernel's job
-        if (P.tf && tid == 0 && blockIdx.x == 0) atomicMax((unsigned long long*)&counters[BBDUK_CTR_STATUS], (unsigned long long)(-BBDUK_ERR_UNSUPPORTED));
+        if (PTF && tid == 0 && blockIdx.x == 0) atomicMax((unsigned long long*)&counters[BBDUK_CTR_STATUS], (unsigned long long)(-BBDUK_ERR_UNSUPPORTED));
         return;                                                   // (trimfailuresto1bp is served by this kernel only: the others stand back)
     }
     // short-scan geometry: `lens` candidate lengths per read, rpp reads per 64-lane pass
@@ -2972,7 +2977,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                     A.found = 0; A.iFirst = BIGLOC; A.iLast = -1; A.ref = -1; A.shortFl = -1; A.shortLl = -1;
                     Bz.found = 0; Bz.iFirst = BIGLOC; Bz.iLast = -1; Bz.ref = -1; Bz.shortFl = -1; Bz.shortLl = -1;
                     if constexpr (TIPS) main_scan_pair<BBDUK_MODE_KTRIM_R, FORBIDN, GENERAL, false, true, false, true>(P, Q, A, Bz, lane);
-                    else main_scan_pair<MODE, FORBIDN, GENERAL, BIG, GENERAL, false, true>(P, Q, A, Bz, lane);
+                    else main_scan_pair<MODE, FORBIDN, GENERAL, BIG, GENERAL, false, GENERAL>(P, Q, A, Bz, lane);   // (the probe form only where lookup4 would bring the query expansion along)
                     vFound = (lane == ra) ? A.found : vFound; vFirst = (lane == ra) ? A.iFirst : vFirst; vRef = (lane == ra) ? A.ref : vRef;
                     if (hasB) { vFound = (lane == ra + 1) ? Bz.found : vFound; vFirst = (lane == ra + 1) ? Bz.iFirst : vFirst; vRef = (lane == ra + 1) ? Bz.ref : vRef; }
                     fbm &= ~(3ULL << ra);
@@ -3013,11 +3018,14 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                     if constexpr (!GENERAL) {
                         // specialised kernels: two passes' probes in flight together.  Unpredicated cuts: inactive lanes cut a 1-base window.
                         const int Ls = P.mink + st;
-                        for (int pb = 0; pb < nneed; pb += 2 * rpp) {
+                        // (ktrim=r keeps one probe per step: its scan is the headline's, where the second probe's registers cost more than the
+                        // overlap returns -- 457 vs 450 Gbases/s)
+                        constexpr int SPW = (MODE == BBDUK_MODE_KTRIM_R) ? 1 : 2;
+                        for (int pb = 0; pb < nneed; pb += SPW * rpp) {
                             uint64_t kmer[2], rk[2], lm[2]; bool act[2]; int sref[2];
-                            const bool two = pb + rpp < nneed;      // (wave-uniform) an odd pass at the end goes alone
+                            const bool two = SPW == 2 && pb + rpp < nneed;      // (wave-uniform) an odd pass at the end goes alone
 #pragma unroll
-                            for (int u = 0; u < 2; u++) {
+                            for (int u = 0; u < SPW; u++) {
                                 if (u == 1 && !two) break;
                                 const int q = pb + u * rpp + sslot;
                                 const bool have = sslot < rpp && q < nneed;
@@ -3038,10 +3046,15 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                                     rk[u]   = cut64_lds(Q.cmpBits + 2u * (uint32_t)(jb + max(jstop - Lc, 0))) & (lm[u] - 1ULL);
                                 }
                             }
-                            if (two) short_probe2(P, kmer, rk, lm, act, sref);
-                            else { sref[0] = short_probe(P, kmer[0], rk[0], lm[0], act[0]); sref[1] = -1; }
-                            take_hits(__ballot(sref[0] != -1), sref[0], pb);
-                            if (two) take_hits(__ballot(sref[1] != -1), sref[1], pb + rpp);
+                            if constexpr (SPW == 2) {
+                                if (two) short_probe2(P, kmer, rk, lm, act, sref);
+                                else { sref[0] = short_probe(P, kmer[0], rk[0], lm[0], act[0]); sref[1] = -1; }
+                                take_hits(__ballot(sref[0] != -1), sref[0], pb);
+                                if (two) take_hits(__ballot(sref[1] != -1), sref[1], pb + rpp);
+                            } else {
+                                sref[0] = short_probe(P, kmer[0], rk[0], lm[0], act[0]);
+                                take_hits(__ballot(sref[0] != -1), sref[0], pb);
+                            }
                         }
                     } else {
                         for (int pb = 0; pb < nneed; pb += rpp) {
@@ -3193,14 +3206,14 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
             }
             a = any ? L - npl : 0; newLen = npl; hit = any; ref = vRef;
             if (hit) id = ref_to_id(P, ref);
-            remove = split != 0 && !P.tf;                           // remove=(r1.mate!=null): the two pieces go to outm together (trimfailuresto1bp: they stay, :1431)
+            remove = split != 0 && !PTF;                           // remove=(r1.mate!=null): the two pieces go to outm together (trimfailuresto1bp: they stay, :1431)
             if (mine) {
                 outA[r0 + lane] = a; outId[r0 + lane] = id;
                 outFlags[r0 + lane] = (uint8_t)(remove ? BBDUK_FLAG_REMOVED : 0);
                 P.outLeft[r0 + lane] = any ? leftmost : -1; P.outRight[r0 + lane] = any ? rightmost : -1;
                 vRkt += a > 0 ? 1u : 0u; vXs += (unsigned)a;
                 if (remove) { vRm += 1; vBm += (unsigned)npl; }
-                if (P.tf) vBm += (unsigned)npl;
+                if (PTF) vBm += (unsigned)npl;
             }
         } else if constexpr (FBM || KBIG) {
             // findBestMatch (:1064-1089): discard iff a scaffold was returned; countSetKmersBig: iff the count passes the read's threshold
@@ -3216,8 +3229,8 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
             }
             if (mine) {
                 outA[r0 + lane] = a; outId[r0 + lane] = (mine && vScan) ? vRef : -1;
-                outFlags[r0 + lane] = (uint8_t)((d ? BBDUK_FLAG_DISCARDED : 0) | ((remove && !P.tf) ? BBDUK_FLAG_REMOVED : 0));
-                if (P.tf) { if (remove) { vRkt += 1; vXs += (unsigned)vL; } vBm += (unsigned)fLen; }
+                outFlags[r0 + lane] = (uint8_t)((d ? BBDUK_FLAG_DISCARDED : 0) | ((remove && !PTF) ? BBDUK_FLAG_REMOVED : 0));
+                if (PTF) { if (remove) { vRkt += 1; vXs += (unsigned)vL; } vBm += (unsigned)fLen; }
                 else if (remove) { vRm += 1; vBm += (unsigned)vL; }
             }
         } else if constexpr (KMASK) {
@@ -3235,9 +3248,9 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
             }
             if (mine) {
                 outA[r0 + lane] = a; outId[r0 + lane] = id;
-                outFlags[r0 + lane] = (uint8_t)((d ? BBDUK_FLAG_DISCARDED : 0) | ((remove && !P.tf) ? BBDUK_FLAG_REMOVED : 0));
+                outFlags[r0 + lane] = (uint8_t)((d ? BBDUK_FLAG_DISCARDED : 0) | ((remove && !PTF) ? BBDUK_FLAG_REMOVED : 0));
                 vRkt += a > 0 ? 1u : 0u; vXs += (unsigned)a;
-                if (P.tf) vBm += (unsigned)fLen;
+                if (PTF) vBm += (unsigned)fLen;
                 else if (remove) { vRm += 1; vBm += (unsigned)vL; }
             }
         } else if constexpr (TIPS) {
@@ -3267,12 +3280,12 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
             a = xr; newLen = n1;
             if (mine) {
                 outA[r0 + lane] = xr; P.outLeft[r0 + lane] = xl; outId[r0 + lane] = id;
-                outFlags[r0 + lane] = (uint8_t)((d ? BBDUK_FLAG_DISCARDED : 0) | ((remove && !P.tf) ? BBDUK_FLAG_REMOVED : 0));
+                outFlags[r0 + lane] = (uint8_t)((d ? BBDUK_FLAG_DISCARDED : 0) | ((remove && !PTF) ? BBDUK_FLAG_REMOVED : 0));
                 if (P.storedKmers > 0) {
                     vRkt += (remove || evened) ? 1u : ((xr + xl) > 0 ? 1u : 0u);
                     vXs += (unsigned)(xr + xl) + (remove ? (unsigned)nPre : 0u);
                 }
-                if (P.tf) vBm += (unsigned)n1;
+                if (PTF) vBm += (unsigned)n1;
                 else if (remove) { vRm += 1; vBm += (unsigned)n1; }
             }
         } else {
@@ -3282,31 +3295,37 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
         if (hit) id = ref_to_id(P, ref);
         const float g = (float)vL * P.minLenFraction;              // BBDukProcessorS.java:812-813
         const int minlenR = (int)(g > (float)P.minReadLength ? g : (float)P.minReadLength);
-        const int nPre = newLen;                                   // rlen: the length the k-trim left (:974, 980)
-        if (P.storedKmers > 0) {
-            d = (MODE != BBDUK_MODE_KFILTER) ? (newLen < minlenR) : ((GENERAL && P.mcf > 0.f) ? (a >= vThr) : (a > vThr));
-            tf1bp(P, d, newLen);
-            if (paired) {
-                const bool dm = __shfl_xor((int)d, 1) != 0;         // my mate's verdict
-                remove = (P.rieb && (d || dm)) || (d && dm);        // shouldRemove (:1489-1492)
-            } else remove = d;
-        }
-        bool evened = false;
-        if (MODE == BBDUK_MODE_KTRIM_R && P.tpe && paired && P.storedKmers > 0) {   // trimpairsevenly (:1021-1031)
-            const int am = __shfl_xor(a, 1), nm = __shfl_xor(newLen, 1);
-            evened = mine && !remove && (a + am) > 0 && newLen != nm;               // the same verdict in both mates' lanes
-            if (evened && newLen > nm) a += trim_by_amount(newLen, 0, newLen - nm, 1, newLen);
-        }
-        if (mine) {
-            outA[r0 + lane] = a; outId[r0 + lane] = id;
-            outFlags[r0 + lane] = (uint8_t)((d ? BBDUK_FLAG_DISCARDED : 0) | ((remove && !P.tf) ? BBDUK_FLAG_REMOVED : 0));
-            if (MODE != BBDUK_MODE_KFILTER) {                       // :1011-1029, per read: the pair's sums are the mates' sums
-                vRkt += (remove || evened) ? 1u : (a > 0 ? 1u : 0u);   // evened pairs count both mates (rktsum -> 2)
-                vXs += (unsigned)a + (remove ? (unsigned)nPre : 0u);
-            } else if (P.tf && remove) { vRkt += 1; vXs += (unsigned)vL; }        // readsKFiltered / basesKFiltered (:1079-1088)
-            if (P.tf) vBm += (unsigned)newLen;
-            else if (remove) { vRm += 1; vBm += (unsigned)newLen; }
-        }
+        // (two copies of the verdict block, chosen by one wave-uniform branch: with trimfailuresto1bp folded into a single copy the headline
+        // kernel lost 1.2 % to the extra live values, measured)
+        auto verdicts = [&](auto tfTag) {
+            constexpr bool TF = decltype(tfTag)::value;
+            const int nPre = newLen;                               // rlen: the length the k-trim left (:974, 980)
+            if (P.storedKmers > 0) {
+                d = (MODE != BBDUK_MODE_KFILTER) ? (newLen < minlenR) : ((GENERAL && P.mcf > 0.f) ? (a >= vThr) : (a > vThr));
+                if constexpr (TF) { if (d && newLen > 1) newLen = 1; d = (newLen == 1); }       // setDiscarded / isDiscarded (:1464-1482)
+                if (paired) {
+                    const bool dm = __shfl_xor((int)d, 1) != 0;     // my mate's verdict
+                    remove = (P.rieb && (d || dm)) || (d && dm);    // shouldRemove (:1489-1492)
+                } else remove = d;
+            }
+            bool evened = false;
+            if (MODE == BBDUK_MODE_KTRIM_R && P.tpe && paired && P.storedKmers > 0) {   // trimpairsevenly (:1021-1031)
+                const int am = __shfl_xor(a, 1), nm = __shfl_xor(newLen, 1);
+                evened = mine && !remove && (a + am) > 0 && newLen != nm;               // the same verdict in both mates' lanes
+                if (evened && newLen > nm) a += trim_by_amount(newLen, 0, newLen - nm, 1, newLen);
+            }
+            if (mine) {
+                outA[r0 + lane] = a; outId[r0 + lane] = id;
+                outFlags[r0 + lane] = (uint8_t)((d ? BBDUK_FLAG_DISCARDED : 0) | ((remove && !TF) ? BBDUK_FLAG_REMOVED : 0));
+                if (MODE != BBDUK_MODE_KFILTER) {                   // :1011-1029, per read: the pair's sums are the mates' sums
+                    vRkt += (remove || evened) ? 1u : (a > 0 ? 1u : 0u);   // evened pairs count both mates (rktsum -> 2)
+                    vXs += (unsigned)a + (remove ? (unsigned)(TF ? nPre : newLen) : 0u);
+                } else if (TF && remove) { vRkt += 1; vXs += (unsigned)vL; }        // readsKFiltered / basesKFiltered (:1079-1088)
+                if (TF) vBm += (unsigned)newLen;
+                else if (remove) { vRm += 1; vBm += (unsigned)newLen; }
+            }
+        };
+        if (PTF) verdicts(std::true_type{}); else verdicts(std::false_type{});
         }
         // scaffold counters (:2111-2119, :1577-1583): group the hit lanes by id, one cache update per distinct id
         auto credit = [&](const bool hit_, const int id_, const int len_) {
@@ -3354,7 +3373,7 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
         }
     }
     __syncthreads();
-    if (tid == 0) publish_counters<MODE == BBDUK_MODE_KTRIM_TIPS ? BBDUK_MODE_KTRIM_R : ((MODE == BBDUK_MODE_FBM || MODE == BBDUK_MODE_KBIG) ? BBDUK_MODE_KFILTER : MODE)>(s_acc, counters, P.tf != 0);
+    if (tid == 0) publish_counters<MODE == BBDUK_MODE_KTRIM_TIPS ? BBDUK_MODE_KTRIM_R : ((MODE == BBDUK_MODE_FBM || MODE == BBDUK_MODE_KBIG) ? BBDUK_MODE_KFILTER : MODE)>(s_acc, counters, PTF != 0);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -3398,7 +3417,7 @@ void bbduk_long_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                        const int64_t n, const int64_t totalBases, const int paired,
                        int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
                        int64_t* __restrict__ counters, const int* __restrict__ slowFlag) {
-    if (P.tf) return;                                             // trimfailuresto1bp: bbduk_wave_kernel reports BBDUK_ERR_UNSUPPORTED for such batches
+    if (PTF) return;                                             // trimfailuresto1bp: bbduk_wave_kernel reports BBDUK_ERR_UNSUPPORTED for such batches
     if ((*slowFlag & 2) == 0) return;
     __shared__ uint32_t s_wf[NWAVES * WPLANE_WORDS];
     __shared__ uint32_t s_wc[NWAVES * WPLANE_WORDS];
@@ -3512,7 +3531,7 @@ void bbduk_kmask_long_kernel(const KParams P, const uint8_t* __restrict__ bases,
                              const int64_t n, const int64_t totalBases, const int paired,
                              int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint32_t* __restrict__ outMask,
                              int64_t* __restrict__ counters, const int* __restrict__ longFlag) {
-    if (P.tf) return;                                             // trimfailuresto1bp: bbduk_wave_kernel reports BBDUK_ERR_UNSUPPORTED for such batches
+    if (PTF) return;                                             // trimfailuresto1bp: bbduk_wave_kernel reports BBDUK_ERR_UNSUPPORTED for such batches
     if (*longFlag == 0) return;
     __shared__ uint32_t s_wf[NWAVES * WPLANE_WORDS];
     __shared__ uint32_t s_wc[NWAVES * WPLANE_WORDS];
@@ -3708,7 +3727,7 @@ void bbduk_kscan_long_kernel(const KParams P, const uint8_t* __restrict__ bases,
                              const int64_t n, const int64_t totalBases, const int paired,
                              int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
                              int32_t* __restrict__ outLeft, int32_t* __restrict__ outRight, int64_t* __restrict__ counters, const int* __restrict__ longFlag) {
-    if (P.tf) return;                                             // trimfailuresto1bp: bbduk_wave_kernel reports BBDUK_ERR_UNSUPPORTED for such batches
+    if (PTF) return;                                             // trimfailuresto1bp: bbduk_wave_kernel reports BBDUK_ERR_UNSUPPORTED for such batches
     if ((*longFlag & 2) == 0) return;
     __shared__ uint32_t s_wf[NWAVES * WPLANE_WORDS];
     __shared__ uint32_t s_wc[NWAVES * WPLANE_WORDS];
@@ -3890,7 +3909,7 @@ void bbduk_long_tips_kernel(const KParams P, const uint8_t* __restrict__ bases, 
                             const int64_t n, const int64_t totalBases, const int paired,
                             int32_t* __restrict__ outRight, int32_t* __restrict__ outLeft, int32_t* __restrict__ outId,
                             uint8_t* __restrict__ outFlags, int64_t* __restrict__ counters, const int* __restrict__ longFlag) {
-    if (P.tf) return;                                             // trimfailuresto1bp: bbduk_wave_kernel reports BBDUK_ERR_UNSUPPORTED for such batches
+    if (PTF) return;                                             // trimfailuresto1bp: bbduk_wave_kernel reports BBDUK_ERR_UNSUPPORTED for such batches
     if ((*longFlag & 2) == 0) return;
     __shared__ uint32_t s_wf[NWAVES * WPLANE_WORDS];
     __shared__ uint32_t s_wc[NWAVES * WPLANE_WORDS];
