@@ -1009,8 +1009,13 @@ __device__ __forceinline__ bool fold_hits(const KParams& P, ReadScan& R, int& fo
 // Short k-mer lookup of the specialised wave kernel (no middle mask, no query expansion; filter at LDS address 0), in the
 // style of cand_probe4: straight-line probe for every lane, one scalar test, and only flagged lanes check keys.
 // Returns the id (>0) or -1.
-__device__ __forceinline__ int short_probe(const KParams& P, const uint64_t kmer, const uint64_t rk, const uint64_t lengthMask, const bool act) {
-    const uint64_t mx = kmer > rk ? kmer : rk;
+template <bool GENERAL = false>
+__device__ __forceinline__ int short_probe(const KParams& P, const uint64_t kmer, const uint64_t rk, const uint64_t lengthMask, bool act) {
+    uint64_t mx = (!GENERAL || P.rcomp) ? (kmer > rk ? kmer : rk) : kmer;
+    if constexpr (GENERAL) {                                      // (the specialised kernels run without middle mask and speed)
+        mx &= P.middleMask;
+        if (P.speed > 0) act = act && passes_speed(P, mx | lengthMask);
+    }
     const uint32_t ma = mix_a(mx), mb = mix_b(mx);
     uint32_t pv = P.ldsBits ? __builtin_amdgcn_ubfe(lds_word_at(filt_byte(ma, P.ldsBits)), ma, 1u) : 1u;
     pv = act ? pv : 0u;
@@ -1028,11 +1033,16 @@ __device__ __forceinline__ int short_probe(const KParams& P, const uint64_t kmer
 
 // Two short k-mer probes with their filter reads and fingerprint gathers in flight together (the short scans are latency-bound: one
 // dependent L2 access per pass otherwise).
-__device__ __forceinline__ void short_probe2(const KParams& P, const uint64_t* kmer, const uint64_t* rk, const uint64_t* lengthMask, const bool* act, int* sref) {
-    uint64_t mx[2], t[2]; uint32_t ma[2], mb[2], pv[2];
+template <bool GENERAL = false>
+__device__ __forceinline__ void short_probe2(const KParams& P, const uint64_t* kmer, const uint64_t* rk, const uint64_t* lengthMask, const bool* act0, int* sref) {
+    uint64_t mx[2], t[2]; uint32_t ma[2], mb[2], pv[2]; bool act[2] = {act0[0], act0[1]};
 #pragma unroll
     for (int q = 0; q < 2; q++) {
-        mx[q] = kmer[q] > rk[q] ? kmer[q] : rk[q];
+        mx[q] = (!GENERAL || P.rcomp) ? (kmer[q] > rk[q] ? kmer[q] : rk[q]) : kmer[q];
+        if constexpr (GENERAL) {
+            mx[q] &= P.middleMask;
+            if (P.speed > 0) act[q] = act[q] && passes_speed(P, mx[q] | lengthMask[q]);
+        }
         ma[q] = mix_a(mx[q]); mb[q] = mix_b(mx[q]);
         pv[q] = P.ldsBits ? __builtin_amdgcn_ubfe(lds_word_at(filt_byte(ma[q], P.ldsBits)), ma[q], 1u) : 1u;
     }
@@ -3015,8 +3025,9 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                             hm &= ~(((1ULL << lens) - 1ULL) << (slot * lens));
                         }
                     };
-                    if constexpr (!GENERAL) {
-                        // specialised kernels: two passes' probes in flight together.  Unpredicated cuts: inactive lanes cut a 1-base window.
+                    {
+                        // Two passes' probes in flight together.  Unpredicated cuts: inactive lanes cut a 1-base window.  (The general kernels add
+                        // the span start, qskip, rcomp=f, speed; query expansion never reaches this kernel.)
                         const int Ls = P.mink + st;
                         // (ktrim=r keeps one probe per step: its scan is the headline's, where the second probe's registers cost more than the
                         // overlap returns -- 457 vs 450 Gbases/s)
@@ -3030,61 +3041,37 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                                 const int q = pb + u * rpp + sslot;
                                 const bool have = sslot < rpp && q < nneed;
                                 const int j = have ? sel[q] : 0;   // the read this worker lane serves
-                                const int pk = __shfl(vBase0 | (vStop << 16), j);       // start is 0 here: one shuffle carries base0 (< 2^16) and stop
+                                const int pk = __shfl(vBase0 | (vStop << 16), j);       // one shuffle carries base0 (< 2^16) and stop
                                 const int jb = pk & 0xFFFF, jstop = (int)((unsigned)pk >> 16);
+                                int jstart = 0;
+                                if constexpr (GENERAL) jstart = __shfl(vStart, j);
                                 if (LEFT) {
-                                    const int Lmax = min(P.k, jstop);
-                                    act[u] = have && Ls <= Lmax; const int Lc = act[u] ? Ls : 1;
+                                    const int Lmax = min(P.k, jstop) - jstart;         // lengths 1..Lmax, i = start+Ls-1
+                                    act[u] = have && Ls <= Lmax;
+                                    if constexpr (GENERAL) { if (P.qskip > 1) act[u] = act[u] && ((jstart + Ls - 1) % P.qskip) == 0; }
+                                    const int Lc = act[u] ? Ls : 1;
                                     lm[u] = 1ULL << (2 * Lc);
-                                    kmer[u] = cut64_lds(Q.fwdBits + 2u * (uint32_t)(Q.T - 1 - (jb + Lc - 1))) & (lm[u] - 1ULL);
-                                    rk[u]   = cut64_lds(Q.cmpBits + 2u * (uint32_t)jb) & (lm[u] - 1ULL);
+                                    kmer[u] = cut64_lds(Q.fwdBits + 2u * (uint32_t)(Q.T - 1 - (jb + jstart + Lc - 1))) & (lm[u] - 1ULL);
+                                    rk[u]   = cut64_lds(Q.cmpBits + 2u * (uint32_t)(jb + jstart)) & (lm[u] - 1ULL);
                                 } else {
-                                    const int Lmax = (jstop >= P.k ? P.k - 1 : jstop);
-                                    act[u] = have && Ls <= Lmax; const int Lc = act[u] ? Ls : 1;
+                                    const int Lmax = (jstop >= P.k ? P.k - 1 : jstop);  // lengths 1..Lmax, i = stop-Ls
+                                    act[u] = have && Ls <= Lmax;
+                                    if constexpr (GENERAL) { if (P.qskip > 1) act[u] = act[u] && ((jstop - Ls) % P.qskip) == 0; }
+                                    const int Lc = act[u] ? Ls : 1;
                                     lm[u] = 1ULL << (2 * Lc);
                                     kmer[u] = cut64_lds(Q.fwdBits + 2u * (uint32_t)(Q.T - 1 - (jb + jstop - 1))) & (lm[u] - 1ULL);
                                     rk[u]   = cut64_lds(Q.cmpBits + 2u * (uint32_t)(jb + max(jstop - Lc, 0))) & (lm[u] - 1ULL);
                                 }
                             }
                             if constexpr (SPW == 2) {
-                                if (two) short_probe2(P, kmer, rk, lm, act, sref);
-                                else { sref[0] = short_probe(P, kmer[0], rk[0], lm[0], act[0]); sref[1] = -1; }
+                                if (two) short_probe2<GENERAL>(P, kmer, rk, lm, act, sref);
+                                else { sref[0] = short_probe<GENERAL>(P, kmer[0], rk[0], lm[0], act[0]); sref[1] = -1; }
                                 take_hits(__ballot(sref[0] != -1), sref[0], pb);
                                 if (two) take_hits(__ballot(sref[1] != -1), sref[1], pb + rpp);
                             } else {
-                                sref[0] = short_probe(P, kmer[0], rk[0], lm[0], act[0]);
+                                sref[0] = short_probe<GENERAL>(P, kmer[0], rk[0], lm[0], act[0]);
                                 take_hits(__ballot(sref[0] != -1), sref[0], pb);
                             }
-                        }
-                    } else {
-                        for (int pb = 0; pb < nneed; pb += rpp) {
-                            const int q = pb + sslot;
-                            const bool have = sslot < rpp && q < nneed;
-                            const int j = have ? sel[q] : 0;   // the read this worker lane serves
-                            const int jb = __shfl(vBase0, j), jstart = __shfl(vStart, j), jstop = __shfl(vStop, j);
-                            const int Ls = P.mink + st;
-                            uint64_t kmer = 0, rk = 0; bool act; int Lc;
-                            if (LEFT) {
-                                const int Lmax = min(P.k, jstop) - jstart;         // lengths 1..Lmax, i = start+Ls-1
-                                act = have && Ls <= Lmax;
-                                if (P.qskip > 1) act = act && ((jstart + Ls - 1) % P.qskip) == 0;
-                                Lc = act ? Ls : 1;
-                                if (act) {
-                                    kmer = extract2(Q.fwd, Q.T - 1 - (jb + jstart + Lc - 1), Lc) & P.mask;
-                                    rk   = extract2(Q.cmp, jb + jstart, Lc);
-                                }
-                            } else {
-                                const int Lmax = (jstop >= P.k ? P.k - 1 : jstop);  // lengths 1..Lmax, i = stop-Ls
-                                act = have && Ls <= Lmax;
-                                if (P.qskip > 1) act = act && ((jstop - Ls) % P.qskip) == 0;
-                                Lc = act ? Ls : 1;
-                                if (act) {
-                                    kmer = extract2(Q.fwd, Q.T - 1 - (jb + jstop - 1), Lc);          // base stop-1 in bits 0-1
-                                    rk   = extract2(Q.cmp, jb + jstop - Lc, Lc) & P.mask;            // base i in bits 0-1
-                                }
-                            }
-                            const int sref = lookup<GENERAL, false>(P, Q.filt, kmer, rk, 1ULL << (2 * Lc), Lc, 0, act);
-                            take_hits(__ballot(sref != -1), sref, pb);
                         }
                     }
                 };
