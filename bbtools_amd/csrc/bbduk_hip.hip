@@ -36,7 +36,9 @@
 static_assert(sizeof(bbduk_params) == 136, "bbduk_params layout is part of the ABI");
 static_assert(sizeof(bbduk_synth_params) == 80, "bbduk_synth_params layout is part of the ABI");
 
+#ifndef BLOCK_THREADS
 #define BLOCK_THREADS   1024
+#endif
 #define NWAVES          (BLOCK_THREADS / 64)
 #ifdef BBDUK_AB_NO_TF
 #define PTF 0
@@ -48,7 +50,9 @@ static_assert(sizeof(bbduk_synth_params) == 80, "bbduk_synth_params layout is pa
 #define CAP_CHUNKS      (CAP_BASES / 16)
 #define PLANE_PAD       12                     // words of slack on both sides of the 2-bit planes
 #define EMPTY_KEY       0xFFFFFFFFFFFFFFFFULL  // keys are < 2^63
+#ifndef MAX_LDS_BITS
 #define MAX_LDS_BITS    20                     // 128 KiB presence filter per workgroup
+#endif
 #define BIGLOC          999999999
 
 // Deletion experiments (profiles/ab.sh): a build with -DBBDUK_TIMING_SWITCHES honours bbduk_test_hook(BBDUK_HOOK_TIMING_MASK, n) and skips one
@@ -2609,7 +2613,9 @@ __device__ __forceinline__ void main_scan_pair_kbig(const KParams& P, const Plan
 // waits, much of it at barriers behind the slowest wave.  Requires every unit (pair) to fit WCAP_BASES;
 // a pre-pass (bbduk_span_kernel) raises *slowFlag otherwise and the tile kernel takes the batch instead.
 #define MT_READS     62                            // reads per wave mini-tile (even: whole pairs)
+#ifndef WCAP_BASES
 #define WCAP_BASES   2560                          // per-wave plane capacity in bases
+#endif
 #define WCAP_CHUNKS  (WCAP_BASES / 16)
 #define WPLANE_WORDS (PLANE_PAD + WCAP_CHUNKS + PLANE_PAD)
 #define WNM_WORDS    (WCAP_CHUNKS / 2 + 4)
@@ -2635,8 +2641,11 @@ __device__ __forceinline__ int wave_sum(int v) {
     return __builtin_amdgcn_readfirstlane(v);
 }
 
+#ifndef WAVE_KERNEL_ATTR
+#define WAVE_KERNEL_ATTR
+#endif
 template <int MODE, bool SHORT, bool FORBIDN, bool GENERAL, int FMT, bool BIG = false>
-__global__ __launch_bounds__(BLOCK_THREADS)
+__global__ __launch_bounds__(BLOCK_THREADS) WAVE_KERNEL_ATTR
 void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
                        const int64_t n, const int64_t totalBases, const int paired,
                        int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
@@ -4696,7 +4705,10 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
         const int sgrid = (int)std::min<int64_t>((units + 255) / 256, (int64_t)h->numCU * 8);
         bbduk_span_kernel<<<dim3(std::max(sgrid, 1)), dim3(256), 0, st>>>(d_offsets, n, (int)paired, d_flag);
     }
-    const int perCU = 1;                                            // 1024-thread workgroups; VGPR budget admits one per CU
+#ifndef WAVE_WGS_PER_CU
+#define WAVE_WGS_PER_CU 1
+#endif
+    const int perCU = WAVE_WGS_PER_CU;                                            // 1024-thread workgroups; VGPR budget admits one per CU
     const int64_t nmt = (n + MT_READS - 1) / MT_READS;
     const int wgrid = (int)std::min<int64_t>((nmt + NWAVES - 1) / NWAVES, (int64_t)h->numCU * perCU);
     const int tgrid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU * perCU);
