@@ -257,3 +257,23 @@ def test_cli_trimfailuresto1bp_cuts_instead_of_removing(tmp_path):
     assert ncut > 0 and "Contaminants:" in r1.stderr
     r = run_cli(base + ["trimfailures=t", "deviceingest=t"])
     assert r.returncode != 0 and "trimfailuresto1bp" in r.stderr
+
+
+# ---- the reference's own sample reads (resources/sample1.fq.gz, sample2.fq.gz of the BBTools tree, kept as data/): gzipped two-file
+# input, real names and qualities; expectations from oracle/spec.py (tests/golden/make_sample_golden.py)
+@pytest.mark.gpu
+@pytest.mark.parametrize("stem,flags", [("cli_sample_ktrimr_k25_phix", ["ktrim=r", "k=25", "ref=phix"]),
+                                        ("cli_sample_kfilter_k31_hdist1_phix", ["k=31", "hdist=1", "ref=phix"]),
+                                        ("cli_sample_kfilter_k31_mkf_phix", ["k=31", "mkf=0.5", "ref=phix"])])
+def test_cli_on_the_reference_sample_reads(tmp_path, stem, flags):
+    tsv, out, outm = (str(tmp_path / n) for n in ("o.tsv", "clean.fq", "removed.fq"))
+    r = run_cli(["in=" + os.path.join(ROOT, "data", "sample1.fq.gz"), "in2=" + os.path.join(ROOT, "data", "sample2.fq.gz"),
+                 "tsv=" + tsv, "out=" + out, "outm=" + outm] + flags)
+    assert r.returncode == 0, r.stderr
+    assert open(tsv).read() == open(os.path.join(GOLD, stem + ".tsv")).read()
+    rows = [l.split("\t") for l in open(tsv).read().splitlines()]
+    kept, removed = _read_fastq(out), _read_fastq(outm)
+    assert len(kept) + len(removed) == len(rows) == 200
+    assert {n for n, _, _ in removed} == {x[0] for x in rows if int(x[5]) & 2}
+    newlen = {x[0]: int(x[4]) for x in rows}
+    assert all(len(b) == len(q) == newlen[n] for n, b, q in kept + removed)

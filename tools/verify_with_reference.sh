@@ -46,6 +46,15 @@ python3 "$ROOT/tools/compare_with_reference.py" --kfilter --tsv "$G/cli_c3.tsv" 
 run "$DUK" in="$G/cli_c3_interleaved.fq" int=t out="$W/c3k40_o.fq" outm="$W/c3k40_m.fq" k=40 hdist=1 ref="$REFP" $COMMON
 python3 "$ROOT/tools/compare_with_reference.py" --kfilter --tsv "$G/cli_c3_k40.tsv" --out "$W/c3k40_o.fq" --outm "$W/c3k40_m.fq" || fail=1
 
+# 3b. the reference's own sample reads (resources/sample1.fq.gz, sample2.fq.gz: kept byte-identical under data/), gzipped, two files
+S1=$ROOT/data/sample1.fq.gz; S2=$ROOT/data/sample2.fq.gz
+run "$DUK" in="$S1" in2="$S2" out="$W/s_tr_o.fq" outm="$W/s_tr_m.fq" ktrim=r k=25 ref="$REFP" $COMMON
+python3 "$ROOT/tools/compare_with_reference.py" --tsv "$G/cli_sample_ktrimr_k25_phix.tsv" --out "$W/s_tr_o.fq" --outm "$W/s_tr_m.fq" || fail=1
+run "$DUK" in="$S1" in2="$S2" out="$W/s_kf_o.fq" outm="$W/s_kf_m.fq" k=31 hdist=1 ref="$REFP" $COMMON
+python3 "$ROOT/tools/compare_with_reference.py" --kfilter --tsv "$G/cli_sample_kfilter_k31_hdist1_phix.tsv" --out "$W/s_kf_o.fq" --outm "$W/s_kf_m.fq" || fail=1
+run "$DUK" in="$S1" in2="$S2" out="$W/s_mkf_o.fq" outm="$W/s_mkf_m.fq" k=31 mkf=0.5 ref="$REFP" $COMMON
+python3 "$ROOT/tools/compare_with_reference.py" --kfilter --tsv "$G/cli_sample_kfilter_k31_mkf_phix.tsv" --out "$W/s_mkf_o.fq" --outm "$W/s_mkf_m.fq" || fail=1
+
 # 4. ksplit: kept reads and the split pairs byte for byte
 run "$DUK" in="$G/cli_ksplit.fq" out="$W/ks_o.fq" outm="$W/ks_m.fq" ksplit=t k=23 mink=11 hdist=1 ref="$REFA" $COMMON
 for pair in "ks_o.fq cli_ksplit_expected_out.fq" "ks_m.fq cli_ksplit_expected_outm.fq"; do
