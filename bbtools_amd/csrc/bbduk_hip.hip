@@ -1297,7 +1297,9 @@ __device__ __forceinline__ void main_scan_pair_cand(const KParams& P, const Plan
 // straddle the two slot pairs.  The windows are cut with lane-varying read coordinates; every read then takes its first candidate out of its
 // part of the ballots.  One block serves all positions (the caller groups the reads so that they fit); the spans' windows are all "full"
 // (every position looked up, SPAN cuts in front of `start`).
-template <bool FORBIDN, bool GENERAL>
+// The same scan serves ktrim=r / kfilter (PACKSCAN in bbduk_wave_kernel) when the pair scan would waste blocks: there a read may start in one
+// block and end in the next (T[0] < 0: slots of the first read that earlier blocks scanned; T[nr] > 128: the last read goes on).
+template <bool FORBIDN, bool GENERAL, bool NOMM = false, bool SPAN = true>
 __device__ __forceinline__ void packed_scan_cand(const KParams& P, const Planes& Q, const int ra, const int nr, const int* T, const bool anyN,
                                                  const int vBase0, const int vStart, const int vStop, const int vFirstLook, const int lane,
                                                  int& vCSlot, int& vFirst, uint32_t& vCKeyLo, uint32_t& vCKeyHi) {
@@ -1316,9 +1318,9 @@ __device__ __forceinline__ void packed_scan_cand(const KParams& P, const Planes&
         W[sp].first = f; W[sp].on = true; W[sp].full = true; W[sp].hasN = anyN;
     }
     uint64_t kmer[4], rk[4]; bool ok[4]; int ref[4]; Cand4 C;
-    windows2<FORBIDN, GENERAL, true>(P, Q, W[0], pos[0], val[0], kmer, rk, ok);
-    windows2<FORBIDN, GENERAL, true>(P, Q, W[1], pos[1], val[1], kmer + 2, rk + 2, ok + 2);
-    const uint64_t anyFlag = cand_probe4<GENERAL, false, true>(P, Q.filt, kmer, rk, C);
+    windows2<FORBIDN, GENERAL, SPAN>(P, Q, W[0], pos[0], val[0], kmer, rk, ok);
+    windows2<FORBIDN, GENERAL, SPAN>(P, Q, W[1], pos[1], val[1], kmer + 2, rk + 2, ok + 2);
+    const uint64_t anyFlag = cand_probe4<GENERAL, NOMM, true>(P, Q.filt, kmer, rk, C);
     if (anyFlag == 0ULL) return;                                  // the common block: nothing to look at
     cand_resolve4(P, C, ref);
     const uint64_t m[4] = {__ballot(ref[0] != -1 && ok[0]), __ballot(ref[1] != -1 && ok[1]), __ballot(ref[2] != -1 && ok[2]), __ballot(ref[3] != -1 && ok[3])};
@@ -1345,6 +1347,75 @@ __device__ __forceinline__ void packed_scan_cand(const KParams& P, const Planes&
             vCSlot = (lane == ra + r) ? cs : vCSlot; vFirst = (lane == ra + r) ? ifirst : vFirst;
             vCKeyLo = (lane == ra + r) ? klo : vCKeyLo; vCKeyHi = (lane == ra + r) ? khi : vCKeyHi;
             found = true;
+        }
+    }
+}
+
+// maximum of v over the lanes of a wave, returned wave-uniform
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+// The tail pass of the candidate scans (ktrim=r, kfilter): reads whose span overshoots the pair scan's last full block by a few positions
+// (vTail of them, 1..32) have those positions looked up here, many reads per block: LPR lanes per read (4, 8 or 16, by the longest tail of
+// the sub-tile), two adjacent positions per lane, two groups of 64 lane-slots per block.  Only reads without a candidate so far take part
+// (their first candidate is all that matters); `sel` is the wave's scratch list in LDS.
+template <bool FORBIDN, bool GENERAL, bool NOMM, bool SPAN>
+__device__ __forceinline__ void tail_scan_cand(const KParams& P, const Planes& Q, uint8_t* sel, const bool anyN, const int vBase0, const int vStart, const int vStop,
+                                               const int vTail, const int lane, int& vCSlot, int& vFirst, uint32_t& vCKeyLo, uint32_t& vCKeyHi) {
+    const bool need = vTail > 0 && vCSlot == -1;
+    const uint64_t needM = __ballot(need);
+    if (!needM) return;
+    const int rank = __popcll(needM & ((1ULL << lane) - 1ULL));
+    if (need) sel[rank] = (uint8_t)lane;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int nneed = __popcll(needM);
+    const int tmax = wave_max_i(need ? vTail : 0);
+    const int sh = tmax <= 8 ? 2 : (tmax <= 16 ? 3 : 4);        // log2(lanes per read)
+    const int rpg = 64 >> sh;                                     // reads per group of 64 lane-slots
+    const int u = lane & ((1 << sh) - 1);
+    for (int pb = 0; pb < nneed; pb += 2 * rpg) {
+        ReadWin W[2]; int pos[2]; bool val[2];
+#pragma unroll
+        for (int sp = 0; sp < 2; sp++) {
+            const int idx = pb + sp * rpg + (lane >> sh);
+            val[sp] = idx < nneed;
+            const int src = sel[min(idx, nneed - 1)];
+            W[sp].base0 = __shfl(vBase0, src); W[sp].start = __shfl(vStart, src); W[sp].stop = __shfl(vStop, src);
+            pos[sp] = W[sp].stop - __shfl(vTail, src) + 2 * u;
+            W[sp].first = P.k - 1; W[sp].on = true; W[sp].full = true; W[sp].hasN = anyN;
+        }
+        uint64_t kmer[4], rk[4]; bool ok[4]; int ref[4]; Cand4 C;
+        windows2<FORBIDN, GENERAL, SPAN>(P, Q, W[0], pos[0], val[0], kmer, rk, ok);
+        windows2<FORBIDN, GENERAL, SPAN>(P, Q, W[1], pos[1], val[1], kmer + 2, rk + 2, ok + 2);
+        const uint64_t anyFlag = cand_probe4<GENERAL, NOMM, true>(P, Q.filt, kmer, rk, C);
+        if (anyFlag == 0ULL) continue;
+        cand_resolve4(P, C, ref);
+#pragma unroll
+        for (int sp = 0; sp < 2; sp++) {
+            const uint64_t me = __ballot(ref[2 * sp] != -1 && ok[2 * sp]), mo = __ballot(ref[2 * sp + 1] != -1 && ok[2 * sp + 1]);
+            uint64_t mm = me | mo;
+            while (mm) {                                          // rare: a read with a candidate in its tail
+                const int g = (__ffsll((unsigned long long)mm) - 1) >> sh;
+                const uint64_t gm = ((sh == 4 ? 0xFFFFULL : (sh == 3 ? 0xFFULL : 0xFULL)) << (g << sh));
+                const uint64_t ge = me & gm, go = mo & gm;
+                const int le = ge ? __ffsll((unsigned long long)ge) - 1 : 64, lo = go ? __ffsll((unsigned long long)go) - 1 : 64;
+                const int h = (2 * lo + 1 < 2 * le) ? 1 : 0;
+                const int l = h ? lo : le;
+                const int rs = h ? ref[2 * sp + 1] : ref[2 * sp];
+                const uint64_t ks = h ? C.key[2 * sp + 1] : C.key[2 * sp];
+                const int cs = __builtin_amdgcn_readlane(rs, l);
+                const uint32_t klo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ks, l), khi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ks >> 32), l);
+                const int ifirst = __builtin_amdgcn_readlane(pos[sp], l) + h;
+                const int jr = sel[pb + sp * rpg + g];
+                vCSlot = (lane == jr) ? cs : vCSlot; vFirst = (lane == jr) ? ifirst : vFirst;
+                vCKeyLo = (lane == jr) ? klo : vCKeyLo; vCKeyHi = (lane == jr) ? khi : vCKeyHi;
+                mm &= ~gm;
+            }
         }
     }
 }
@@ -2622,6 +2693,8 @@ __device__ __forceinline__ void main_scan_pair_kbig(const KParams& P, const Plan
 #define SEL_BYTES    ((MT_READS + 3) & ~3)
 #define WAVE_LDS_BYTES ((2 * NWAVES * WPLANE_WORDS + NWAVES * WNM_WORDS) * 4 + 6 * 8 + NWAVES * SEL_BYTES)   // behind the filter
 #define WUNIT_MAX    (WCAP_BASES - 48)             // longest unit (pair) the wave kernel accepts
+#define TAIL_MAX     32                            // positions a read may leave to the tail pass (bbduk_wave_kernel<.., TAIL>)
+#define TAIL_SHARE   8                             // the TAIL instantiation takes a batch in which at least one read in TAIL_SHARE has a tail
 // ktrim=n keeps a fourth per-wave plane (the k-mer end positions that hit).  To fit behind a 128 KiB filter its planes are a little shorter
 // (sixteen 150-base reads still fit) and its short-scan lists live in the undefined-plane, which is dead once the main scan of the
 // sub-tile is over.
@@ -2644,7 +2717,7 @@ __device__ __forceinline__ int wave_sum(int v) {
 #ifndef WAVE_KERNEL_ATTR
 #define WAVE_KERNEL_ATTR
 #endif
-template <int MODE, bool SHORT, bool FORBIDN, bool GENERAL, int FMT, bool BIG = false>
+template <int MODE, bool SHORT, bool FORBIDN, bool GENERAL, int FMT, bool BIG = false, bool TAIL = false>
 __global__ __launch_bounds__(BLOCK_THREADS) WAVE_KERNEL_ATTR
 void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
                        const int64_t n, const int64_t totalBases, const int paired,
@@ -2657,6 +2730,11 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
     constexpr bool KBIG = MODE == BBDUK_MODE_KBIG;                // kfilter with k > 31: runs of matching 31-mers (main_scan_pair_kbig)
     constexpr bool FBM = MODE == BBDUK_MODE_FBM;                  // kfilter with findBestMatch: per-read id lists in the pair scan (main_scan_pair_best)
     constexpr bool KMASK = MODE == BBDUK_MODE_KMASK;              // ktrim=n: every hit of the main scan, both ends' short k-mers, a mask per base
+    // TAIL: the instantiation that also runs the tail pass (see "tails" below).  It takes the batch when the pre-pass counted enough reads
+    // that overshoot the pair scan's blocks by a few positions (2x151 with k=23); the plain instantiation then stands back.  Two kernels
+    // rather than one branch: the extra code costs the plain kernel's hot loop 4 % through register allocation alone.
+    constexpr bool TAILSCAN = TAIL;
+    static_assert(!TAIL || ((MODE == BBDUK_MODE_KTRIM_R || MODE == BBDUK_MODE_KFILTER) && !BIG), "tail pass: first-hit scans of the cache-resident layout only");
     constexpr int CAPB = KMASK ? WCAP_BASES_KM : WCAP_BASES;      // per-wave plane capacity in bases
     constexpr int PLW = KMASK ? WPLANE_WORDS_KM : WPLANE_WORDS, NMW = KMASK ? WNM_WORDS_KM : WNM_WORDS, HW = KMASK ? WHIT_WORDS : 0;
     uint32_t* const s_wfAll = s_dyn + (P.ldsBits ? (1 << (P.ldsBits - 5)) : 0);
@@ -2667,6 +2745,10 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
     uint8_t* const s_selAll = reinterpret_cast<uint8_t*>(s_acc + 6);   // short-scan: compacted list of participating reads (lane ids)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+    if constexpr (TAIL) {                                         // most batches are not this instantiation's: leave before the filter is copied
+        const int tails = slowFlag[1];                            // (the same test at the top of the plain kernel costs its hot loop 1.8 %: register allocation)
+        if (slowFlag[0] != 0 || !(tails > 0 && (int64_t)tails * TAIL_SHARE >= n)) return;
+    }
     if (tid < 6) s_acc[tid] = 0;
     if (P.ldsBits) {
         const int words = 1 << (P.ldsBits - 5);
@@ -2674,8 +2756,12 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
     }
     __syncthreads();
     if (*slowFlag != 0) {                                         // a unit does not fit a wave's planes: tile kernel's job
-        if (PTF && tid == 0 && blockIdx.x == 0) atomicMax((unsigned long long*)&counters[BBDUK_CTR_STATUS], (unsigned long long)(-BBDUK_ERR_UNSUPPORTED));
+        if (!TAIL && PTF && tid == 0 && blockIdx.x == 0) atomicMax((unsigned long long*)&counters[BBDUK_CTR_STATUS], (unsigned long long)(-BBDUK_ERR_UNSUPPORTED));
         return;                                                   // (trimfailuresto1bp is served by this kernel only: the others stand back)
+    }
+    {   // whose batch is it?  The pre-pass counted the reads with a tail; the instantiation that stands back returns here
+        const int tails = slowFlag[1];
+        if (TAIL != (tails > 0 && (int64_t)tails * TAIL_SHARE >= n)) return;
     }
     // short-scan geometry: `lens` candidate lengths per read, rpp reads per 64-lane pass
     // first-hit-only operators verify candidates in batches (see main_scan_pair_cand)
@@ -2860,6 +2946,18 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                     }
                 }
             }
+            // ---- tails.  The pair scan gives a read 128 positions per block: a 150-base read with k=23 fills its half exactly, a 151-base read
+            // would need a second block for ONE position.  A read that overshoots its last full block by at most TAIL_MAX positions leaves
+            // them to the tail pass below, which serves the tails of up to 32 reads in one block (lane-varying read coordinates).
+            int vTail = 0;
+            if constexpr (TAILSCAN) {
+                if (candP && (!GENERAL || P.qskip < 2)) {
+                    const int npos = (vScan && lane >= s && lane < e) ? max(0, vStop - max(vStart, P.k - 1)) : 0;
+                    const int rem = npos & 127;
+                    vTail = (npos > 128 && rem >= 1 && rem <= TAIL_MAX) ? rem : 0;
+                }
+            }
+            const uint64_t tailMask = TAILSCAN ? __ballot(vTail > 0) : 0ULL;
             for (int ra = s; ra < e && !quadDone; ra += 2) {
                 const bool hasB = (ra + 1) < e;
                 ReadScan A, Bz;
@@ -2876,6 +2974,9 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                 if constexpr (TIPS) {
                     A.start = __builtin_amdgcn_readlane(vStart, ra); A.stop = __builtin_amdgcn_readlane(vStop, ra);
                     Bz.start = hasB ? __builtin_amdgcn_readlane(vStart, ra + 1) : 0; Bz.stop = hasB ? __builtin_amdgcn_readlane(vStop, ra + 1) : 0;
+                }
+                if constexpr (TAILSCAN) {
+                    if ((tailMask >> ra) & 3ULL) { A.stop -= __builtin_amdgcn_readlane(vTail, ra); if (hasB) Bz.stop -= __builtin_amdgcn_readlane(vTail, ra + 1); }
                 }
                 A.found = 0; A.iFirst = BIGLOC; A.iLast = -1; A.ref = -1; A.shortFl = -1; A.shortLl = -1;
                 Bz.found = 0; Bz.iFirst = BIGLOC; Bz.iLast = -1; Bz.ref = -1; Bz.shortFl = -1; Bz.shortLl = -1;
@@ -2926,6 +3027,10 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
                     vLast = (lane == ra + 1) ? Bz.iLast : vLast;   vRef = (lane == ra + 1) ? Bz.ref : vRef;
                     vSFl = (lane == ra + 1) ? Bz.shortFl : vSFl;   vSLl = (lane == ra + 1) ? Bz.shortLl : vSLl;
                 }
+            }
+            if constexpr (TAILSCAN) {
+                if (tailMask) tail_scan_cand<FORBIDN, GENERAL, SHORT && !GENERAL, GENERAL>(P, Q, sel, (FORBIDN && P.forbidNs) && (nMask & tailMask) != 0ULL, origin + rel, vStart, vStop,
+                                                                                               vTail, lane, vCSlot, vFirst, vCKeyLo, vCKeyHi);
             }
             if (candP) {
                 // ---- verify the sub-tile's candidates together: lane j fetches key+id of read j's candidate
@@ -4014,32 +4119,52 @@ void bbduk_long_tips_kernel(const KParams P, const uint8_t* __restrict__ bases, 
 
 // Pre-pass: does every unit (mate pair, or single read) fit a wave's planes?  One thread per unit.
 // wmax / hmax: longest unit the first / the second kernel of the operator accepts (flag bit 0 / bit 1 otherwise).
+// tailK >= 0 (launch_batch, first-hit scans): slowFlag[1] counts the reads whose k-mer end positions (length - tailK of them) overshoot the pair
+// scan's 128-position blocks by 1..TAIL_MAX: enough of them and bbduk_wave_kernel<.., TAIL> takes the batch.
 __global__ void bbduk_span_kernel(const int64_t* __restrict__ offsets, const int64_t n, const int paired, int* __restrict__ slowFlag,
-                                  const int64_t wmax = WUNIT_MAX, const int64_t hmax = CAP_BASES - 64) {
+                                  const int64_t wmax = WUNIT_MAX, const int64_t hmax = CAP_BASES - 64, const int tailK = -1) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int step = paired ? 2 : 1;
     const int64_t units = n / step;
     bool bad = false, huge = false;
+    int tails = 0;
     for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += stride) {
-        const int64_t len = offsets[u * step + step] - offsets[u * step];
+        const int64_t o0 = offsets[u * step], o2 = offsets[u * step + step];
+        const int64_t len = o2 - o0;
         bad |= len > wmax;
         huge |= len > hmax;                                       // not even the tile kernel's planes hold this unit: bbduk_long_kernel
+        if (tailK >= 0) {
+            const int64_t o1 = paired ? offsets[u * step + 1] : o2;
+            const int64_t pa = (o1 - o0) - tailK, pb = (o2 - o1) - tailK;
+            tails += (pa > 128 && (pa & 127) >= 1 && (pa & 127) <= TAIL_MAX) ? 1 : 0;
+            tails += (paired && pb > 128 && (pb & 127) >= 1 && (pb & 127) <= TAIL_MAX) ? 1 : 0;
+        }
     }
     if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(slowFlag, 1);
     if (__ballot(huge) && (threadIdx.x & 63) == 0) atomicOr(slowFlag, 2);
+    if (tailK >= 0) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tails += __shfl_xor(tails, o);
+        if (tails > 0 && (threadIdx.x & 63) == 0) atomicAdd(slowFlag + 1, tails);
+    }
 }
 
 // runtime -> template dispatch
 typedef void (*batch_kernel_t)(const KParams, const uint8_t*, const int64_t*, const int64_t, const int64_t, const int,
                                int32_t*, int32_t*, uint8_t*, int64_t*, const int*);
-struct KernelPair { batch_kernel_t wave, wavePacked, tile; };
+struct KernelPair { batch_kernel_t wave, wavePacked, tile, waveTail = nullptr, wavePackedTail = nullptr; };
 template <int MODE, bool SHORT, bool FORBIDN, bool GENERAL>
 static KernelPair kpair() {
     // the specialised wave kernels exist once per input format; the general one and the tile fallback decide per launch
-    if (GENERAL) return KernelPair{bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL, 2>, bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL, 2>,
-                                   bbduk_batch_kernel<MODE, SHORT, FORBIDN, GENERAL>};
-    return KernelPair{bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL, 0>, bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL, 1>,
-                      bbduk_batch_kernel<MODE, SHORT, FORBIDN, GENERAL>};
+    KernelPair kp = GENERAL ? KernelPair{bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL, 2>, bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL, 2>,
+                                         bbduk_batch_kernel<MODE, SHORT, FORBIDN, GENERAL>}
+                            : KernelPair{bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL, 0>, bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL, 1>,
+                                         bbduk_batch_kernel<MODE, SHORT, FORBIDN, GENERAL>};
+    if constexpr (MODE == BBDUK_MODE_KTRIM_R || MODE == BBDUK_MODE_KFILTER) {       // the first-hit scans have a TAIL instantiation each
+        kp.waveTail = GENERAL ? bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL, 2, false, true> : bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL, 0, false, true>;
+        kp.wavePackedTail = GENERAL ? bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL, 2, false, true> : bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL, 1, false, true>;
+    }
+    return kp;
 }
 template <int MODE>
 static KernelPair pick_kernel_mode(bool general, bool useShort, bool forbidN) {
@@ -4153,7 +4278,7 @@ extern "C" int bbduk_create(const bbduk_params* p, bbduk_handle** out) {
     if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return BBDUK_ERR_DEVICE; }
     const size_t nc = (size_t)(BBDUK_NCOUNTERS + 2 * p->numScaffolds);
     if (hipMalloc(&h->d_counters, nc * sizeof(int64_t)) != hipSuccess ||
-        hipMemset(h->d_counters, 0, nc * sizeof(int64_t)) != hipSuccess || hipMalloc(&h->d_slowFlag, bbduk_handle::EV_RING * sizeof(int)) != hipSuccess) { hipStreamDestroy(h->stream); delete h; return BBDUK_ERR_DEVICE; }
+        hipMemset(h->d_counters, 0, nc * sizeof(int64_t)) != hipSuccess || hipMalloc(&h->d_slowFlag, 2 * bbduk_handle::EV_RING * sizeof(int)) != hipSuccess) { hipStreamDestroy(h->stream); delete h; return BBDUK_ERR_DEVICE; }
     *out = h;
     return BBDUK_OK;
 }
@@ -4616,8 +4741,8 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
     if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
     HIP_TRY(h, hipEventRecord(h->ev0[evi], st));
-    int* const d_flag = h->d_slowFlag + evi;
-    HIP_TRY(h, hipMemsetAsync(d_flag, 0, sizeof(int), st));
+    int* const d_flag = h->d_slowFlag + 2 * evi;      // [0] pre-pass bits, [1] reads with a tail (launch_batch)
+    HIP_TRY(h, hipMemsetAsync(d_flag, 0, 2 * sizeof(int), st));
     if (query_expansion(h->p)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
     {   // pre-pass per READ: one beyond the tiled kernel's planes sends the batch to bbduk_kscan_long_kernel; ksplit: one beyond a
         // wave's planes (bit 0) sends it to the tiled kernel, else bbduk_wave_kernel<KSPLIT> takes it
@@ -4690,20 +4815,24 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     const size_t dynLds = h->ldsBits ? ((size_t)1 << (h->ldsBits - 3)) : 0;    // tile kernel: the filter only
     const size_t waveLds = dynLds + WAVE_LDS_BYTES;                             // wave kernel: filter + its per-wave state
     KernelPair kp = pick_kernel(K);
-    if (packed) kp.wave = kp.wavePacked;
+    if (packed) { kp.wave = kp.wavePacked; kp.waveTail = kp.wavePackedTail; }
+    // the tail pass belongs to the candidate form of the scans (bbduk_wave_kernel's candMode): elsewhere no TAIL kernel is launched
+    const bool tailForm = kp.waveTail && !K.big && K.qhdist == 0 && K.qskip < 2 &&
+                          (K.mode == BBDUK_MODE_KTRIM_R || (K.mode == BBDUK_MODE_KFILTER && K.maxBadKmers == 0 && K.mkf == 0.f && K.mcf == 0.f));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)waveLds));
+    if (tailForm) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.waveTail), hipFuncAttributeMaxDynamicSharedMemorySize, (int)waveLds));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.tile), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
     // pre-pass: if some pair is longer than a wave's planes the tile kernel takes the whole batch, else the wave kernel
     std::lock_guard<std::mutex> lg(h->launchMu);
     const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
-    int* const d_flag = h->d_slowFlag + evi;
-    HIP_TRY(h, hipMemsetAsync(d_flag, 0, sizeof(int), st));
+    int* const d_flag = h->d_slowFlag + 2 * evi;      // [0] pre-pass bits, [1] reads with a tail (launch_batch)
+    HIP_TRY(h, hipMemsetAsync(d_flag, 0, 2 * sizeof(int), st));
     if (query_expansion(h->p)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
     if (h->hookForceTile) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }
     {
         const int64_t units = paired ? n / 2 : n;
         const int sgrid = (int)std::min<int64_t>((units + 255) / 256, (int64_t)h->numCU * 8);
-        bbduk_span_kernel<<<dim3(std::max(sgrid, 1)), dim3(256), 0, st>>>(d_offsets, n, (int)paired, d_flag);
+        bbduk_span_kernel<<<dim3(std::max(sgrid, 1)), dim3(256), 0, st>>>(d_offsets, n, (int)paired, d_flag, (int64_t)WUNIT_MAX, (int64_t)(CAP_BASES - 64), tailForm ? K.k - 1 : -1);
     }
 #ifndef WAVE_WGS_PER_CU
 #define WAVE_WGS_PER_CU 1
@@ -4715,6 +4844,7 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
     HIP_TRY(h, hipEventRecord(h->ev0[evi], st));
     kp.wave<<<dim3(wgrid), dim3(BLOCK_THREADS), waveLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
+    if (tailForm) kp.waveTail<<<dim3(wgrid), dim3(BLOCK_THREADS), waveLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
     kp.tile<<<dim3(tgrid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
     HIP_TRY(h, hipEventRecord(h->ev1[evi], st));                    // around both: whichever of the two took the batch (the other returns at once)
     h->evCount++;
@@ -4915,8 +5045,8 @@ static int launch_tips(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d
     const int grid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU);
     std::lock_guard<std::mutex> lg(h->launchMu);
     const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
-    int* const d_flag = h->d_slowFlag + evi;
-    HIP_TRY(h, hipMemsetAsync(d_flag, 0, sizeof(int), st));
+    int* const d_flag = h->d_slowFlag + 2 * evi;      // [0] pre-pass bits, [1] reads with a tail (launch_batch)
+    HIP_TRY(h, hipMemsetAsync(d_flag, 0, 2 * sizeof(int), st));
     if (query_expansion(h->p)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
     {   // pre-pass: a unit (pair) beyond a wave's planes (bit 0) sends the batch to the tiled kernel, a READ beyond the tiled kernel's
         // planes (bit 1) to bbduk_long_tips_kernel; else bbduk_wave_kernel<KTRIM_TIPS> takes it
@@ -5020,8 +5150,8 @@ static int launch_kmask(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     const int grid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU);
     std::lock_guard<std::mutex> lg(h->launchMu);
     const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
-    int* const d_flag = h->d_slowFlag + evi;
-    HIP_TRY(h, hipMemsetAsync(d_flag, 0, sizeof(int), st));
+    int* const d_flag = h->d_slowFlag + 2 * evi;      // [0] pre-pass bits, [1] reads with a tail (launch_batch)
+    HIP_TRY(h, hipMemsetAsync(d_flag, 0, 2 * sizeof(int), st));
     if (query_expansion(h->p)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
     if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
     {   // pre-pass: a unit (pair) beyond a wave's planes sends the batch to the tiled kernel (which in turn leaves the reads beyond ITS planes

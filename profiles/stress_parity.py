@@ -57,7 +57,9 @@ def main():
     while time.time() - t0 < a.seconds and not (a.only is not None and it):
         seed = a.seed * 1_000_003 + it if a.only is None else a.only; it += 1
         rng = random.Random(seed)
-        fam = rng.choice(["base", "base", "base", "kmask", "tips", "ksplit", "big", "fbm", "seal", "tf1bp"])
+        fam = rng.choice(["base", "base", "base", "tails", "kmask", "tips", "ksplit", "big", "fbm", "seal", "tf1bp"])
+        tails = fam == "tails"                                 # base configurations on reads that overshoot the pair scan's blocks by 1..32 positions:
+        if tails: fam = "base"                                 # the TAIL instantiations of the main kernel (first-hit scans) take such batches
         if fam == "tf1bp":                                     # trimfailuresto1bp over every operator family (units within the main kernel's planes)
             try:
                 tfam, targs, tokw = T.tf1bp_config(rng)
@@ -131,7 +133,16 @@ def main():
         k = okw["k"]
         refs = [util.rand_seq(rng, rng.randint(10, 260 if fam in ("big", "fbm", "ksplit") else 90), 0.01) for _ in range(rng.randint(1, 10))]
         lengths = [0, 1, 5, 10, 22, 23, 31, 40, 64, 75, 150, 151, 300, 1000] + ([2500, 6000] if rng.random() < 0.3 else [])
+        if tails:
+            lengths = [k - 1 + 128 * rng.choice([1, 1, 1, 2]) + rng.randint(1, 32) for _ in range(12)] + [150, 100, k - 1 + 128, k + 160, 0, 30]
         reads = util.fuzz_reads(rng, refs, rng.choice([50, 400, 1500]), lengths, junk=True)
+        if tails:                                               # reference pieces that end in the tail zone or right in front of it
+            for _ in range(60):
+                L = rng.choice(lengths[:12]); r = rng.choice(refs); g = bytearray(util.rand_seq(rng, L, 0.002))
+                end = rng.choice([L, L - 1, L - rng.randint(0, 34), k - 1 + 128 + rng.randint(-2, 3)])
+                piece = r[:rng.randint(min(len(r), 8), len(r))]
+                if len(piece) <= end <= L: g[end - len(piece):end] = piece
+                reads.insert(rng.randrange(len(reads) + 1), bytes(g))
         if fam in ("big", "fbm", "ksplit"):
             reads += util.long_refs_and_reads(rng)[1][:0]
             reads += [util.rand_seq(rng, rng.randint(0, 60)) + rng.choice(refs)[:rng.randint(20, 260)] + util.rand_seq(rng, rng.randint(0, 60)) for _ in range(100)]
@@ -174,7 +185,7 @@ def main():
         except Exception as e:
             print(json.dumps({"FAILED": True, "seed": seed, "family": fam, "args": args, "okw": okw, "build": build, "squeeze": locals().get("squeeze", ""), "error": (str(e) or traceback.format_exc())[-2000:]}))
             sys.exit(1)
-        n_cfg += 1; n_reads += len(reads); fam_count[fam] = fam_count.get(fam, 0) + 1
+        n_cfg += 1; n_reads += len(reads); fam_count["tails" if tails else fam] = fam_count.get("tails" if tails else fam, 0) + 1
     print(json.dumps({"soak_seconds": round(time.time() - t0, 1), "configs": n_cfg, "reads_checked": n_reads * 3, "families": fam_count, "mismatches": 0, "seed": a.seed}))
 
 

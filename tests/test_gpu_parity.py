@@ -1057,3 +1057,46 @@ def test_trimfailuresto1bp_refuses_units_beyond_the_main_kernel():
     b, off = pack_reads(reads[:2])
     d.gpu.process_batch(b, off, True)                              # the handle stays usable
     d.close()
+
+
+# ---- the tail pass (bbduk_wave_kernel<.., TAIL>): reads whose k-mer end positions overshoot the pair scan's 128-position blocks by 1..32
+# take their last positions to a packed pass; the instantiation runs when at least one read in eight has such a tail.  Lengths around every
+# edge of that rule, reference pieces ending at the last pair-scan position, the first tail position and the read's end.
+TAIL_CASES = [("ktrim=r k=23 mink=11 hdist=1", dict(k=23, ktrimRight=1, mink=11, hdist=1), 23),
+              ("ktrim=r k=23", dict(k=23, ktrimRight=1), 23),                                                       # hdist=0: forbidNs, the undefined-base path
+              ("ktrim=r k=23 mink=11 hdist=1 tpe minlen=20", dict(k=23, ktrimRight=1, mink=11, hdist=1, trimPairsEvenly=1, minReadLength=20), 23),
+              ("k=31 hdist=1", dict(k=31, hdist=1), 31), ("k=27", dict(k=27), 27),
+              ("ktrim=r k=21 hdist=1 restrictright=150", dict(k=21, ktrimRight=1, hdist=1, restrictRight=150), 21),        # GENERAL: the span starts inside the read
+              ("k=25 restrictleft=160 forbidn=t", dict(k=25, restrictLeft=160, forbidN=1), 25),
+              ("ktrim=r k=19 mink=9 speed=3", dict(k=19, ktrimRight=1, mink=9, speed=3), 19),
+              ("ktrim=r k=23 mink=11 hdist=1 trimfailuresto1bp=t", dict(k=23, ktrimRight=1, mink=11, hdist=1, trimFailuresTo1bp=1), 23)]
+
+
+@pytest.mark.parametrize("ci", range(len(TAIL_CASES)))
+@pytest.mark.parametrize("paired", [True, False])
+def test_tail_pass_parity(ci, paired):
+    args, okw, k = TAIL_CASES[ci]
+    rng = random.Random(7000 + ci)
+    refs = [util.rand_seq(rng, rng.randint(40, 120), 0.0) for _ in range(6)]
+    d, o = make_pair(args, okw, refs=refs)
+    edge = [k - 1 + 128 + t for t in (0, 1, 2, 8, 9, 16, 17, 31, 32, 33)] + [k - 1 + 256 + t for t in (1, 5, 32, 33)]   # 0 / 33: just outside the rule
+    lengths = edge * 3 + [100, 150, k - 1 + 128 - 1, 40, 0, 5]
+    reads = util.fuzz_reads(rng, refs, 1200, lengths, p_insert=0.5)
+    for L in edge:                                              # a piece of a reference ending exactly at chosen positions of a read of length L
+        for end in (L, L - 1, L - 3, k - 1 + 128, k - 1 + 128 + 1, k - 1 + 128 + 2, k - 1 + 127, max(k, L - 33)):
+            if end > L or end < k + 5:
+                continue
+            r = rng.choice(refs)
+            piece = r[rng.randint(0, len(r) - k - 5):][:k + 5]
+            g = bytearray(util.rand_seq(rng, L, 0.0))
+            g[end - len(piece):end] = piece
+            if rng.random() < 0.3:
+                g[rng.randrange(L)] = ord("N")
+            reads.append(bytes(g))
+    rng.shuffle(reads)
+    if paired and len(reads) & 1:
+        reads.pop()
+    check_batch(d, o, reads, paired)
+    # and a batch where too few reads have a tail for the TAIL instantiation to take it: the same answers from the plain kernel
+    few = util.fuzz_reads(rng, refs, 400, [150, 100, 75, 64], p_insert=0.5) + reads[:20]
+    check_batch(d, o, few, paired)
