@@ -1351,6 +1351,57 @@ __device__ __forceinline__ void packed_scan_cand(const KParams& P, const Planes&
     }
 }
 
+// The candidate scan for short reads (wave_body<.., SHAPE>): THREE reads share a block when none of them has more than TRI_MAX k-mer
+// end positions (a 100-base read with k=23 has 78 and leaves 39 % of the pair scan's lanes idle).  R[0] and R[1] take lanes 0-41 of the two
+// slot pairs (84 positions each), R[2] takes lanes 42-63 of both (44 + 44 positions); the read coordinates stay wave-uniform per lane
+// group (two selects per field, no shuffles: that is what made lane-slot packing too dear).  One block serves all three reads.
+#define TRI_LANES 42
+#define TRI_MAX   (2 * TRI_LANES)
+template <bool FORBIDN, bool GENERAL, bool NOMM, bool SPAN>
+__device__ __forceinline__ void tri_scan_cand(const KParams& P, const Planes& Q, ReadScan* R, const int lane) {
+    const bool hiL = lane >= TRI_LANES;
+    const int lt = hiL ? lane - TRI_LANES : lane;
+    const int f0 = max(R[0].start, P.k - 1), f1 = max(R[1].start, P.k - 1), f2 = max(R[2].start, P.k - 1);
+    ReadWin W[2]; int pos[2]; bool on[2];
+    W[0].base0 = hiL ? R[2].base0 : R[0].base0; W[0].stop = hiL ? R[2].stop : R[0].stop; W[0].start = hiL ? R[2].start : R[0].start;
+    W[1].base0 = hiL ? R[2].base0 : R[1].base0; W[1].stop = hiL ? R[2].stop : R[1].stop; W[1].start = hiL ? R[2].start : R[1].start;
+    pos[0] = (hiL ? f2 : f0) + 2 * lt; pos[1] = (hiL ? f2 + 2 * (64 - TRI_LANES) : f1) + 2 * lt;
+    on[0] = hiL ? R[2].scan : R[0].scan; on[1] = hiL ? R[2].scan : R[1].scan;
+#pragma unroll
+    for (int sp = 0; sp < 2; sp++) {
+        W[sp].first = P.k - 1; W[sp].on = true; W[sp].full = true;
+        W[sp].hasN = (FORBIDN && P.forbidNs) && (R[0].hasN != 0 || R[1].hasN != 0 || R[2].hasN != 0);
+    }
+    R[0].candSlot = -1; R[1].candSlot = -1; R[2].candSlot = -1;
+    uint64_t kmer[4], rk[4]; bool ok[4]; int ref[4]; Cand4 C;
+    windows2<FORBIDN, GENERAL, SPAN>(P, Q, W[0], pos[0], on[0], kmer, rk, ok);
+    windows2<FORBIDN, GENERAL, SPAN>(P, Q, W[1], pos[1], on[1], kmer + 2, rk + 2, ok + 2);
+    const uint64_t anyFlag = cand_probe4<GENERAL, NOMM, true>(P, Q.filt, kmer, rk, C);
+    if (anyFlag == 0ULL) return;                                  // the common block: nothing to look at
+    cand_resolve4(P, C, ref);
+    const uint64_t m0e = __ballot(ref[0] != -1 && ok[0]), m0o = __ballot(ref[1] != -1 && ok[1]);
+    const uint64_t m1e = __ballot(ref[2] != -1 && ok[2]), m1o = __ballot(ref[3] != -1 && ok[3]);
+    if (!(m0e | m0o | m1e | m1o)) return;
+    const uint64_t LOW = (1ULL << TRI_LANES) - 1ULL;
+    // first candidate in position order among the lanes [lb, lb+..) of one slot pair: lane l, parity h
+    auto take = [&](ReadScan& T, const uint64_t me, const uint64_t mo, const int refE, const int refO, const uint64_t keyE, const uint64_t keyO,
+                    const int lb, const int posBase) {
+        const int le = me ? __ffsll((unsigned long long)me) - 1 : 64, lo = mo ? __ffsll((unsigned long long)mo) - 1 : 64;
+        const int h = (2 * lo + 1 < 2 * le) ? 1 : 0;
+        const int l = h ? lo : le;
+        const int rs = h ? refO : refE;
+        const uint64_t ks = h ? keyO : keyE;
+        T.candSlot = __builtin_amdgcn_readlane(rs, l);
+        T.candKeyLo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ks, l);
+        T.candKeyHi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ks >> 32), l);
+        T.iFirst = posBase + 2 * (l - lb) + h;
+    };
+    if ((m0e | m0o) & LOW) take(R[0], m0e & LOW, m0o & LOW, ref[0], ref[1], C.key[0], C.key[1], 0, f0);
+    if ((m1e | m1o) & LOW) take(R[1], m1e & LOW, m1o & LOW, ref[2], ref[3], C.key[2], C.key[3], 0, f1);
+    if ((m0e | m0o) & ~LOW) take(R[2], m0e & ~LOW, m0o & ~LOW, ref[0], ref[1], C.key[0], C.key[1], TRI_LANES, f2);
+    else if ((m1e | m1o) & ~LOW) take(R[2], m1e & ~LOW, m1o & ~LOW, ref[2], ref[3], C.key[2], C.key[3], TRI_LANES, f2 + 2 * (64 - TRI_LANES));
+}
+
 // maximum of v over the lanes of a wave, returned wave-uniform
 __device__ __forceinline__ int wave_max_i(int v) {
 #pragma unroll
@@ -2693,8 +2744,9 @@ __device__ __forceinline__ void main_scan_pair_kbig(const KParams& P, const Plan
 #define SEL_BYTES    ((MT_READS + 3) & ~3)
 #define WAVE_LDS_BYTES ((2 * NWAVES * WPLANE_WORDS + NWAVES * WNM_WORDS) * 4 + 6 * 8 + NWAVES * SEL_BYTES)   // behind the filter
 #define WUNIT_MAX    (WCAP_BASES - 48)             // longest unit (pair) the wave kernel accepts
-#define TAIL_MAX     32                            // positions a read may leave to the tail pass (bbduk_wave_kernel<.., TAIL>)
-#define TAIL_SHARE   8                             // the TAIL instantiation takes a batch in which at least one read in TAIL_SHARE has a tail
+#define TAIL_MAX     32                            // positions a read may leave to the tail pass (wave_body<.., SHAPE>)
+#define TRI_SHARE    3                             // ... or one read in TRI_SHARE is short enough for three to share a block (tri_scan_cand)
+#define TAIL_SHARE   8                             // the tail-pass body takes a batch in which at least one read in TAIL_SHARE has a tail
 // ktrim=n keeps a fourth per-wave plane (the k-mer end positions that hit).  To fit behind a 128 KiB filter its planes are a little shorter
 // (sixteen 150-base reads still fit) and its short-scan lists live in the undefined-plane, which is dead once the main scan of the
 // sub-tile is over.
@@ -2717,12 +2769,24 @@ __device__ __forceinline__ int wave_sum(int v) {
 #ifndef WAVE_KERNEL_ATTR
 #define WAVE_KERNEL_ATTR
 #endif
-template <int MODE, bool SHORT, bool FORBIDN, bool GENERAL, int FMT, bool BIG = false, bool TAIL = false>
-__global__ __launch_bounds__(BLOCK_THREADS) WAVE_KERNEL_ATTR
-void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
-                       const int64_t n, const int64_t totalBases, const int paired,
-                       int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
-                       int64_t* __restrict__ counters, const int* __restrict__ slowFlag) {
+// Which kernel takes a batch of the first-hit scans: what the pre-pass counted (launch_batch), wave-uniform.  0 = bbduk_wave_kernel,
+// 1 / 2 = bbduk_wave_shape_kernel with its tail-pass body / its three-reads-per-block body.
+__device__ __forceinline__ int batch_shape(const int* __restrict__ slowFlag, const int64_t n) {
+    const int tails = slowFlag[1], shorts = slowFlag[2];
+    if (tails > 0 && (int64_t)tails * TAIL_SHARE >= n) return 1;
+    if (shorts > 0 && (int64_t)shorts * TRI_SHARE >= n) return 2;
+    return 0;
+}
+
+// SHAPE picks what the first-hit scans (ktrim=r, kfilter with maxbadkmers=0) do about reads the pair scan fits badly: 0 = nothing (the
+// 2x150 shape: 128 positions per read and block), 1 = the tail pass, 2 = three short reads per block.  bbduk_wave_kernel is body 0,
+// bbduk_wave_shape_kernel holds bodies 1 and 2 (see there).
+template <int MODE, bool SHORT, bool FORBIDN, bool GENERAL, int FMT, bool BIG, int SHAPE>
+__device__ __forceinline__
+void wave_body(const KParams& P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
+               const int64_t n, const int64_t totalBases, const int paired,
+               int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
+               int64_t* __restrict__ counters, const int* __restrict__ slowFlag) {
     // One dynamic LDS block, the presence filter FIRST: its words are then addressed by the hash bits alone (LDS
     // address 0 + offset), which saves an add per lookup.  Behind it: per-wave planes, counters, short-scan lists.
     extern __shared__ uint32_t s_dyn[];
@@ -2730,11 +2794,8 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
     constexpr bool KBIG = MODE == BBDUK_MODE_KBIG;                // kfilter with k > 31: runs of matching 31-mers (main_scan_pair_kbig)
     constexpr bool FBM = MODE == BBDUK_MODE_FBM;                  // kfilter with findBestMatch: per-read id lists in the pair scan (main_scan_pair_best)
     constexpr bool KMASK = MODE == BBDUK_MODE_KMASK;              // ktrim=n: every hit of the main scan, both ends' short k-mers, a mask per base
-    // TAIL: the instantiation that also runs the tail pass (see "tails" below).  It takes the batch when the pre-pass counted enough reads
-    // that overshoot the pair scan's blocks by a few positions (2x151 with k=23); the plain instantiation then stands back.  Two kernels
-    // rather than one branch: the extra code costs the plain kernel's hot loop 4 % through register allocation alone.
-    constexpr bool TAILSCAN = TAIL;
-    static_assert(!TAIL || ((MODE == BBDUK_MODE_KTRIM_R || MODE == BBDUK_MODE_KFILTER) && !BIG), "tail pass: first-hit scans of the cache-resident layout only");
+    constexpr bool TAILSCAN = SHAPE == 1, TRISCAN = SHAPE == 2;   // see "tails" below and tri_scan_cand
+    static_assert(SHAPE == 0 || ((MODE == BBDUK_MODE_KTRIM_R || MODE == BBDUK_MODE_KFILTER) && !BIG), "shapes: first-hit scans of the cache-resident layout only");
     constexpr int CAPB = KMASK ? WCAP_BASES_KM : WCAP_BASES;      // per-wave plane capacity in bases
     constexpr int PLW = KMASK ? WPLANE_WORDS_KM : WPLANE_WORDS, NMW = KMASK ? WNM_WORDS_KM : WNM_WORDS, HW = KMASK ? WHIT_WORDS : 0;
     uint32_t* const s_wfAll = s_dyn + (P.ldsBits ? (1 << (P.ldsBits - 5)) : 0);
@@ -2745,10 +2806,6 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
     uint8_t* const s_selAll = reinterpret_cast<uint8_t*>(s_acc + 6);   // short-scan: compacted list of participating reads (lane ids)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
-    if constexpr (TAIL) {                                         // most batches are not this instantiation's: leave before the filter is copied
-        const int tails = slowFlag[1];                            // (the same test at the top of the plain kernel costs its hot loop 1.8 %: register allocation)
-        if (slowFlag[0] != 0 || !(tails > 0 && (int64_t)tails * TAIL_SHARE >= n)) return;
-    }
     if (tid < 6) s_acc[tid] = 0;
     if (P.ldsBits) {
         const int words = 1 << (P.ldsBits - 5);
@@ -2756,12 +2813,11 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
     }
     __syncthreads();
     if (*slowFlag != 0) {                                         // a unit does not fit a wave's planes: tile kernel's job
-        if (!TAIL && PTF && tid == 0 && blockIdx.x == 0) atomicMax((unsigned long long*)&counters[BBDUK_CTR_STATUS], (unsigned long long)(-BBDUK_ERR_UNSUPPORTED));
+        if (PTF && tid == 0 && blockIdx.x == 0) atomicMax((unsigned long long*)&counters[BBDUK_CTR_STATUS], (unsigned long long)(-BBDUK_ERR_UNSUPPORTED));
         return;                                                   // (trimfailuresto1bp is served by this kernel only: the others stand back)
     }
-    {   // whose batch is it?  The pre-pass counted the reads with a tail; the instantiation that stands back returns here
-        const int tails = slowFlag[1];
-        if (TAIL != (tails > 0 && (int64_t)tails * TAIL_SHARE >= n)) return;
+    if constexpr (SHAPE == 0 && (MODE == BBDUK_MODE_KTRIM_R || MODE == BBDUK_MODE_KFILTER) && !BIG) {
+        if (batch_shape(slowFlag, n) != 0) return;                // bbduk_wave_shape_kernel's batch
     }
     // short-scan geometry: `lens` candidate lengths per read, rpp reads per 64-lane pass
     // first-hit-only operators verify candidates in batches (see main_scan_pair_cand)
@@ -2950,15 +3006,40 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
             // would need a second block for ONE position.  A read that overshoots its last full block by at most TAIL_MAX positions leaves
             // them to the tail pass below, which serves the tails of up to 32 reads in one block (lane-varying read coordinates).
             int vTail = 0;
-            if constexpr (TAILSCAN) {
+            uint64_t triMask = 0;                                   // short reads: three of them share a block (tri_scan_cand)
+            if constexpr (TAILSCAN || TRISCAN) {
                 if (candP && (!GENERAL || P.qskip < 2)) {
                     const int npos = (vScan && lane >= s && lane < e) ? max(0, vStop - max(vStart, P.k - 1)) : 0;
                     const int rem = npos & 127;
-                    vTail = (npos > 128 && rem >= 1 && rem <= TAIL_MAX) ? rem : 0;
+                    if constexpr (TAILSCAN) vTail = (npos > 128 && rem >= 1 && rem <= TAIL_MAX) ? rem : 0;
+                    if constexpr (TRISCAN) triMask = __ballot(lane >= s && lane < e && npos <= TRI_MAX);
                 }
             }
             const uint64_t tailMask = TAILSCAN ? __ballot(vTail > 0) : 0ULL;
-            for (int ra = s; ra < e && !quadDone; ra += 2) {
+            int step = 2;
+            for (int ra = s; ra < e && !quadDone; ra += step) {
+                if constexpr (TRISCAN) {
+                    step = 2;
+                    if (ra + 2 < e && ((triMask >> ra) & 7ULL) == 7ULL) {
+                        ReadScan T3[3];
+#pragma unroll
+                        for (int q = 0; q < 3; q++) {
+                            T3[q].base0 = origin + __builtin_amdgcn_readlane(rel, ra + q); T3[q].L = __builtin_amdgcn_readlane(vL, ra + q);
+                            T3[q].scan = (scanMask >> (ra + q)) & 1; T3[q].hasN = (int)((nMask >> (ra + q)) & 1);
+                            T3[q].start = span_start<GENERAL>(P, T3[q].L); T3[q].stop = span_stop<GENERAL>(P, T3[q].L);
+                        }
+                        tri_scan_cand<FORBIDN, GENERAL, SHORT && !GENERAL, GENERAL>(P, Q, T3, lane);
+#pragma unroll
+                        for (int q = 0; q < 3; q++) {
+                            if (T3[q].candSlot != -1) {
+                                vCSlot = (lane == ra + q) ? T3[q].candSlot : vCSlot; vFirst = (lane == ra + q) ? T3[q].iFirst : vFirst;
+                                vCKeyLo = (lane == ra + q) ? T3[q].candKeyLo : vCKeyLo; vCKeyHi = (lane == ra + q) ? T3[q].candKeyHi : vCKeyHi;
+                            }
+                        }
+                        step = 3;
+                        continue;
+                    }
+                }
                 const bool hasB = (ra + 1) < e;
                 ReadScan A, Bz;
                 A.hasN = (int)((nMask >> ra) & 1); Bz.hasN = (int)((nMask >> (ra + 1)) & 1);
@@ -3475,6 +3556,31 @@ void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const
     }
     __syncthreads();
     if (tid == 0) publish_counters<MODE == BBDUK_MODE_KTRIM_TIPS ? BBDUK_MODE_KTRIM_R : ((MODE == BBDUK_MODE_FBM || MODE == BBDUK_MODE_KBIG) ? BBDUK_MODE_KFILTER : MODE)>(s_acc, counters, PTF != 0);
+}
+
+template <int MODE, bool SHORT, bool FORBIDN, bool GENERAL, int FMT, bool BIG = false>
+__global__ __launch_bounds__(BLOCK_THREADS) WAVE_KERNEL_ATTR
+void bbduk_wave_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
+                       const int64_t n, const int64_t totalBases, const int paired,
+                       int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
+                       int64_t* __restrict__ counters, const int* __restrict__ slowFlag) {
+    wave_body<MODE, SHORT, FORBIDN, GENERAL, FMT, BIG, 0>(P, bases, offsets, n, totalBases, paired, outA, outId, outFlags, counters, slowFlag);
+}
+
+// The bodies for badly fitting read lengths, in a kernel of their own: inside bbduk_wave_kernel -- as extra code in its body or as further
+// bodies behind a wave-uniform branch -- they cost the 2x150 hot loop 4-4.5 % through register allocation alone.  Both kernels are launched;
+// this one returns before it touches anything unless the batch is its own (bbduk_wave_kernel stands back then: SHAPE 0's test in wave_body).
+template <int MODE, bool SHORT, bool FORBIDN, bool GENERAL, int FMT>
+__global__ __launch_bounds__(BLOCK_THREADS) WAVE_KERNEL_ATTR
+void bbduk_wave_shape_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
+                             const int64_t n, const int64_t totalBases, const int paired,
+                             int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
+                             int64_t* __restrict__ counters, const int* __restrict__ slowFlag) {
+    static_assert(MODE == BBDUK_MODE_KTRIM_R || MODE == BBDUK_MODE_KFILTER, "first-hit scans only");
+    if (slowFlag[0] != 0) return;
+    const int shape = batch_shape(slowFlag, n);
+    if (shape == 1) wave_body<MODE, SHORT, FORBIDN, GENERAL, FMT, false, 1>(P, bases, offsets, n, totalBases, paired, outA, outId, outFlags, counters, slowFlag);
+    else if (shape == 2) wave_body<MODE, SHORT, FORBIDN, GENERAL, FMT, false, 2>(P, bases, offsets, n, totalBases, paired, outA, outId, outFlags, counters, slowFlag);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -4120,14 +4226,14 @@ void bbduk_long_tips_kernel(const KParams P, const uint8_t* __restrict__ bases, 
 // Pre-pass: does every unit (mate pair, or single read) fit a wave's planes?  One thread per unit.
 // wmax / hmax: longest unit the first / the second kernel of the operator accepts (flag bit 0 / bit 1 otherwise).
 // tailK >= 0 (launch_batch, first-hit scans): slowFlag[1] counts the reads whose k-mer end positions (length - tailK of them) overshoot the pair
-// scan's 128-position blocks by 1..TAIL_MAX: enough of them and bbduk_wave_kernel<.., TAIL> takes the batch.
+// scan's 128-position blocks by 1..TAIL_MAX: enough of them and bbduk_wave_kernel runs its tail-pass body (wave_body<.., 1>); slowFlag[2] counts the reads with 1..TRI_MAX positions (wave_body<.., 2>).
 __global__ void bbduk_span_kernel(const int64_t* __restrict__ offsets, const int64_t n, const int paired, int* __restrict__ slowFlag,
                                   const int64_t wmax = WUNIT_MAX, const int64_t hmax = CAP_BASES - 64, const int tailK = -1) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int step = paired ? 2 : 1;
     const int64_t units = n / step;
     bool bad = false, huge = false;
-    int tails = 0;
+    int tails = 0, shorts = 0;
     for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += stride) {
         const int64_t o0 = offsets[u * step], o2 = offsets[u * step + step];
         const int64_t len = o2 - o0;
@@ -4138,21 +4244,24 @@ __global__ void bbduk_span_kernel(const int64_t* __restrict__ offsets, const int
             const int64_t pa = (o1 - o0) - tailK, pb = (o2 - o1) - tailK;
             tails += (pa > 128 && (pa & 127) >= 1 && (pa & 127) <= TAIL_MAX) ? 1 : 0;
             tails += (paired && pb > 128 && (pb & 127) >= 1 && (pb & 127) <= TAIL_MAX) ? 1 : 0;
+            shorts += (pa >= 1 && pa <= TRI_MAX) ? 1 : 0;
+            shorts += (paired && pb >= 1 && pb <= TRI_MAX) ? 1 : 0;
         }
     }
     if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(slowFlag, 1);
     if (__ballot(huge) && (threadIdx.x & 63) == 0) atomicOr(slowFlag, 2);
     if (tailK >= 0) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) tails += __shfl_xor(tails, o);
+        for (int o = 32; o > 0; o >>= 1) { tails += __shfl_xor(tails, o); shorts += __shfl_xor(shorts, o); }
         if (tails > 0 && (threadIdx.x & 63) == 0) atomicAdd(slowFlag + 1, tails);
+        if (shorts > 0 && (threadIdx.x & 63) == 0) atomicAdd(slowFlag + 2, shorts);
     }
 }
 
 // runtime -> template dispatch
 typedef void (*batch_kernel_t)(const KParams, const uint8_t*, const int64_t*, const int64_t, const int64_t, const int,
                                int32_t*, int32_t*, uint8_t*, int64_t*, const int*);
-struct KernelPair { batch_kernel_t wave, wavePacked, tile, waveTail = nullptr, wavePackedTail = nullptr; };
+struct KernelPair { batch_kernel_t wave, wavePacked, tile, shape = nullptr, shapePacked = nullptr; };
 template <int MODE, bool SHORT, bool FORBIDN, bool GENERAL>
 static KernelPair kpair() {
     // the specialised wave kernels exist once per input format; the general one and the tile fallback decide per launch
@@ -4160,9 +4269,9 @@ static KernelPair kpair() {
                                          bbduk_batch_kernel<MODE, SHORT, FORBIDN, GENERAL>}
                             : KernelPair{bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL, 0>, bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL, 1>,
                                          bbduk_batch_kernel<MODE, SHORT, FORBIDN, GENERAL>};
-    if constexpr (MODE == BBDUK_MODE_KTRIM_R || MODE == BBDUK_MODE_KFILTER) {       // the first-hit scans have a TAIL instantiation each
-        kp.waveTail = GENERAL ? bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL, 2, false, true> : bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL, 0, false, true>;
-        kp.wavePackedTail = GENERAL ? bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL, 2, false, true> : bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL, 1, false, true>;
+    if constexpr (MODE == BBDUK_MODE_KTRIM_R || MODE == BBDUK_MODE_KFILTER) {       // the first-hit scans have a kernel for badly fitting read lengths each
+        kp.shape = GENERAL ? bbduk_wave_shape_kernel<MODE, SHORT, FORBIDN, GENERAL, 2> : bbduk_wave_shape_kernel<MODE, SHORT, FORBIDN, GENERAL, 0>;
+        kp.shapePacked = GENERAL ? bbduk_wave_shape_kernel<MODE, SHORT, FORBIDN, GENERAL, 2> : bbduk_wave_shape_kernel<MODE, SHORT, FORBIDN, GENERAL, 1>;
     }
     return kp;
 }
@@ -4278,7 +4387,7 @@ extern "C" int bbduk_create(const bbduk_params* p, bbduk_handle** out) {
     if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return BBDUK_ERR_DEVICE; }
     const size_t nc = (size_t)(BBDUK_NCOUNTERS + 2 * p->numScaffolds);
     if (hipMalloc(&h->d_counters, nc * sizeof(int64_t)) != hipSuccess ||
-        hipMemset(h->d_counters, 0, nc * sizeof(int64_t)) != hipSuccess || hipMalloc(&h->d_slowFlag, 2 * bbduk_handle::EV_RING * sizeof(int)) != hipSuccess) { hipStreamDestroy(h->stream); delete h; return BBDUK_ERR_DEVICE; }
+        hipMemset(h->d_counters, 0, nc * sizeof(int64_t)) != hipSuccess || hipMalloc(&h->d_slowFlag, 4 * bbduk_handle::EV_RING * sizeof(int)) != hipSuccess) { hipStreamDestroy(h->stream); delete h; return BBDUK_ERR_DEVICE; }
     *out = h;
     return BBDUK_OK;
 }
@@ -4741,8 +4850,8 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
     if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
     HIP_TRY(h, hipEventRecord(h->ev0[evi], st));
-    int* const d_flag = h->d_slowFlag + 2 * evi;      // [0] pre-pass bits, [1] reads with a tail (launch_batch)
-    HIP_TRY(h, hipMemsetAsync(d_flag, 0, 2 * sizeof(int), st));
+    int* const d_flag = h->d_slowFlag + 4 * evi;      // [0] pre-pass bits, [1] reads with a tail, [2] short reads (launch_batch)
+    HIP_TRY(h, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), st));
     if (query_expansion(h->p)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
     {   // pre-pass per READ: one beyond the tiled kernel's planes sends the batch to bbduk_kscan_long_kernel; ksplit: one beyond a
         // wave's planes (bit 0) sends it to the tiled kernel, else bbduk_wave_kernel<KSPLIT> takes it
@@ -4815,18 +4924,19 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     const size_t dynLds = h->ldsBits ? ((size_t)1 << (h->ldsBits - 3)) : 0;    // tile kernel: the filter only
     const size_t waveLds = dynLds + WAVE_LDS_BYTES;                             // wave kernel: filter + its per-wave state
     KernelPair kp = pick_kernel(K);
-    if (packed) { kp.wave = kp.wavePacked; kp.waveTail = kp.wavePackedTail; }
-    // the tail pass belongs to the candidate form of the scans (bbduk_wave_kernel's candMode): elsewhere no TAIL kernel is launched
-    const bool tailForm = kp.waveTail && !K.big && K.qhdist == 0 && K.qskip < 2 &&
+    if (packed) { kp.wave = kp.wavePacked; kp.shape = kp.shapePacked; }
+    // the tail pass and the three-read blocks belong to the candidate form of the scans (wave_body's candMode): elsewhere the pre-pass counts
+    // nothing and bbduk_wave_shape_kernel is not launched
+    const bool tailForm = kp.shape && !K.big && K.qhdist == 0 && K.qskip < 2 &&
                           (K.mode == BBDUK_MODE_KTRIM_R || (K.mode == BBDUK_MODE_KFILTER && K.maxBadKmers == 0 && K.mkf == 0.f && K.mcf == 0.f));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)waveLds));
-    if (tailForm) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.waveTail), hipFuncAttributeMaxDynamicSharedMemorySize, (int)waveLds));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.tile), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
+    if (tailForm) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.shape), hipFuncAttributeMaxDynamicSharedMemorySize, (int)waveLds));
     // pre-pass: if some pair is longer than a wave's planes the tile kernel takes the whole batch, else the wave kernel
     std::lock_guard<std::mutex> lg(h->launchMu);
     const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
-    int* const d_flag = h->d_slowFlag + 2 * evi;      // [0] pre-pass bits, [1] reads with a tail (launch_batch)
-    HIP_TRY(h, hipMemsetAsync(d_flag, 0, 2 * sizeof(int), st));
+    int* const d_flag = h->d_slowFlag + 4 * evi;      // [0] pre-pass bits, [1] reads with a tail, [2] short reads (launch_batch)
+    HIP_TRY(h, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), st));
     if (query_expansion(h->p)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
     if (h->hookForceTile) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }
     {
@@ -4844,7 +4954,7 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
     HIP_TRY(h, hipEventRecord(h->ev0[evi], st));
     kp.wave<<<dim3(wgrid), dim3(BLOCK_THREADS), waveLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
-    if (tailForm) kp.waveTail<<<dim3(wgrid), dim3(BLOCK_THREADS), waveLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
+    if (tailForm) kp.shape<<<dim3(wgrid), dim3(BLOCK_THREADS), waveLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
     kp.tile<<<dim3(tgrid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
     HIP_TRY(h, hipEventRecord(h->ev1[evi], st));                    // around both: whichever of the two took the batch (the other returns at once)
     h->evCount++;
@@ -5045,8 +5155,8 @@ static int launch_tips(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d
     const int grid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU);
     std::lock_guard<std::mutex> lg(h->launchMu);
     const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
-    int* const d_flag = h->d_slowFlag + 2 * evi;      // [0] pre-pass bits, [1] reads with a tail (launch_batch)
-    HIP_TRY(h, hipMemsetAsync(d_flag, 0, 2 * sizeof(int), st));
+    int* const d_flag = h->d_slowFlag + 4 * evi;      // [0] pre-pass bits, [1] reads with a tail, [2] short reads (launch_batch)
+    HIP_TRY(h, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), st));
     if (query_expansion(h->p)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
     {   // pre-pass: a unit (pair) beyond a wave's planes (bit 0) sends the batch to the tiled kernel, a READ beyond the tiled kernel's
         // planes (bit 1) to bbduk_long_tips_kernel; else bbduk_wave_kernel<KTRIM_TIPS> takes it
@@ -5150,8 +5260,8 @@ static int launch_kmask(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     const int grid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU);
     std::lock_guard<std::mutex> lg(h->launchMu);
     const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
-    int* const d_flag = h->d_slowFlag + 2 * evi;      // [0] pre-pass bits, [1] reads with a tail (launch_batch)
-    HIP_TRY(h, hipMemsetAsync(d_flag, 0, 2 * sizeof(int), st));
+    int* const d_flag = h->d_slowFlag + 4 * evi;      // [0] pre-pass bits, [1] reads with a tail, [2] short reads (launch_batch)
+    HIP_TRY(h, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), st));
     if (query_expansion(h->p)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
     if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
     {   // pre-pass: a unit (pair) beyond a wave's planes sends the batch to the tiled kernel (which in turn leaves the reads beyond ITS planes

@@ -17,6 +17,7 @@ torch.distributed is used for the rendezvous (handing the 128-byte RCCL id to th
 Besides the contract's line for configs[1] (device-resident, ASCII boundary), rank 0 at N=1 adds:
   "end_to_end": Gbases/s THROUGH the C ABI's host-buffer operators (H2D + kernel + D2H inside the call), ASCII and packed
   "operators":  operator Gbases/s of ktrim=n, ktrim=rl, ksplit, findbestmatch (+ match lists) on the configs[1] reads; "seal": Seal's k-mer path
+  "read_lengths": kernel Gbases/s of the configs[1] flags on synthetic pairs of 2x100, 2x151, 2x250 bases (3 Gbases each)
   "configs":    kernel Gbases/s of the other BASELINE configurations (C1, C3, C5 at 20 M reads; C4 = the 10 Gbase reference, map in HBM)
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--no-cpu-baseline] [--no-extras]
@@ -322,6 +323,8 @@ def main():
             import bench_modes, bench_seal
             out["operators"] = {r["mode"]: {k: r[k] for k in ("args", "reads", "operator_ms", "Gbases_per_s")} for r in bench_modes.run(a.extra_reads)}
             out["seal"] = bench_seal.run(pairs=1_000_000, check=0)
+            import bench_readlens                      # the configs[1] flags on pairs of other lengths (2x151: the tail pass of the main kernel)
+            out["read_lengths"] = {"2x%d" % r["read_len"]: {k: r[k] for k in ("reads", "kernel_ms", "Gbases_per_s")} for r in bench_readlens.run(lens=(100, 151, 250))}
         except Exception as e:
             out["operators"] = {"error": repr(e)}
         try:

@@ -7,14 +7,15 @@ sys.path.insert(0, ROOT)
 import ctypes as C
 
 
-def run(reads=20_000_000):
+def run(reads=20_000_000, read_len=150):
     """-> one dict per operator (bench.py's `operators` block calls this too)"""
     import torch
     from bbtools_amd import bbduk as B
     n = reads // 2 * 2
+    RL = read_len
     out = []
-    d_bases = torch.empty(n * 150, dtype=torch.uint8, device="cuda"); d_off = torch.empty(n + 1, dtype=torch.int64, device="cuda")
-    B.synth_generate_device(B.synth_params(2), 0, n // 2, d_bases, d_off, 0)
+    d_bases = torch.empty(n * RL, dtype=torch.uint8, device="cuda"); d_off = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    B.synth_generate_device(B.synth_params(2) if RL == 150 else B.synth_params(2, read_len=RL, ins_min=RL // 3, ins_max=RL * 7 // 3), 0, n // 2, d_bases, d_off, 0)
     L = B.lib()
     for args, mode in (("ktrim=n k=23 mink=11 hdist=1 ref=adapters", "kmask"), ("ktrim=rl k=23 mink=11 hdist=1 ref=adapters", "tips"),
                        ("ksplit=t k=23 mink=11 hdist=1 ref=adapters", "ksplit"),
@@ -23,7 +24,7 @@ def run(reads=20_000_000):
         duk = B.BBDuk(args)
         d_a = torch.empty(n, dtype=torch.int32, device="cuda"); d_b = torch.empty(n, dtype=torch.int32, device="cuda"); d_c2 = torch.empty(n, dtype=torch.int32, device="cuda")
         d_i = torch.empty(n, dtype=torch.int32, device="cuda"); d_f = torch.empty(n, dtype=torch.uint8, device="cuda")
-        d_m = torch.zeros(n * 150 // 32 + 8, dtype=torch.int32, device="cuda")
+        d_m = torch.zeros(n * RL // 32 + 8, dtype=torch.int32, device="cuda")
         d_mi = torch.zeros(n * 8 if mode == "fbm+matches" else 1, dtype=torch.int32, device="cuda"); d_mc = torch.zeros_like(d_mi)
         d_ctr = torch.zeros(duk.gpu.counters_len, dtype=torch.int64, device="cuda")
         h = duk.gpu.h
@@ -31,29 +32,29 @@ def run(reads=20_000_000):
         for _ in range(4):
             d_ctr.zero_(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
             if mode == "kmask":
-                rc = L.bbduk_kmask_batch_device(h, d_bases.data_ptr(), d_off.data_ptr(), n, n * 150, 1, d_a.data_ptr(), d_i.data_ptr(), d_f.data_ptr(), d_m.data_ptr(), d_ctr.data_ptr(), None)
+                rc = L.bbduk_kmask_batch_device(h, d_bases.data_ptr(), d_off.data_ptr(), n, n * RL, 1, d_a.data_ptr(), d_i.data_ptr(), d_f.data_ptr(), d_m.data_ptr(), d_ctr.data_ptr(), None)
             elif mode == "tips":
-                rc = L.bbduk_ktrimtips_batch_device(h, d_bases.data_ptr(), d_off.data_ptr(), n, n * 150, 1, d_a.data_ptr(), d_b.data_ptr(), d_i.data_ptr(), d_f.data_ptr(), d_ctr.data_ptr(), None)
+                rc = L.bbduk_ktrimtips_batch_device(h, d_bases.data_ptr(), d_off.data_ptr(), n, n * RL, 1, d_a.data_ptr(), d_b.data_ptr(), d_i.data_ptr(), d_f.data_ptr(), d_ctr.data_ptr(), None)
             elif mode in ("fbm", "k40"):
-                rc = L.bbduk_kfilter_batch_device(h, d_bases.data_ptr(), d_off.data_ptr(), n, n * 150, 1, d_a.data_ptr(), d_i.data_ptr(), d_f.data_ptr(), d_ctr.data_ptr(), None)
+                rc = L.bbduk_kfilter_batch_device(h, d_bases.data_ptr(), d_off.data_ptr(), n, n * RL, 1, d_a.data_ptr(), d_i.data_ptr(), d_f.data_ptr(), d_ctr.data_ptr(), None)
             elif mode == "fbm+matches":                       # the lists rename=t prints, eight entries per read
-                rc = L.bbduk_kfilter_batch_matches_device(h, d_bases.data_ptr(), d_off.data_ptr(), n, n * 150, 1, d_a.data_ptr(), d_i.data_ptr(), d_f.data_ptr(),
+                rc = L.bbduk_kfilter_batch_matches_device(h, d_bases.data_ptr(), d_off.data_ptr(), n, n * RL, 1, d_a.data_ptr(), d_i.data_ptr(), d_f.data_ptr(),
                                                           8, d_b.data_ptr(), d_mi.data_ptr(), d_mc.data_ptr(), d_ctr.data_ptr(), None)
             else:
-                rc = L.bbduk_ksplit_batch_device(h, d_bases.data_ptr(), d_off.data_ptr(), n, n * 150, d_a.data_ptr(), d_b.data_ptr(), d_c2.data_ptr(), d_i.data_ptr(), d_f.data_ptr(), d_ctr.data_ptr(), None)
+                rc = L.bbduk_ksplit_batch_device(h, d_bases.data_ptr(), d_off.data_ptr(), n, n * RL, d_a.data_ptr(), d_b.data_ptr(), d_c2.data_ptr(), d_i.data_ptr(), d_f.data_ptr(), d_ctr.data_ptr(), None)
             e1.record(); torch.cuda.synchronize()
             assert rc == 0, rc
             ts.append(e0.elapsed_time(e1))
         ms = min(ts[1:]); c = d_ctr.cpu().numpy()
-        out.append({"mode": mode, "args": args, "reads": n, "operator_ms": round(ms, 2), "Gbases_per_s": round(n * 150 / ms / 1e6, 1), "readsKTrimmed": int(c[2]), "readsKFiltered": int(c[4]), "status": int(c[15])})
+        out.append({"mode": mode, "args": args, "reads": n, "read_len": RL, "operator_ms": round(ms, 2), "Gbases_per_s": round(n * RL / ms / 1e6, 1), "readsKTrimmed": int(c[2]), "readsKFiltered": int(c[4]), "status": int(c[15])})
         duk.close()
     return out
 
 
 def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("--reads", type=int, default=20_000_000)
+    ap = argparse.ArgumentParser(); ap.add_argument("--reads", type=int, default=20_000_000); ap.add_argument("--read-len", type=int, default=150)
     a = ap.parse_args()
-    for r in run(a.reads):
+    for r in run(a.reads, a.read_len):
         print(json.dumps(r))
 
 

@@ -1097,6 +1097,22 @@ def test_tail_pass_parity(ci, paired):
     if paired and len(reads) & 1:
         reads.pop()
     check_batch(d, o, reads, paired)
-    # and a batch where too few reads have a tail for the TAIL instantiation to take it: the same answers from the plain kernel
-    few = util.fuzz_reads(rng, refs, 400, [150, 100, 75, 64], p_insert=0.5) + reads[:20]
+    # and a batch where too few reads have a tail for the tail-pass body to take it: the same answers from the plain kernel
+    few = util.fuzz_reads(rng, refs, 400, [150, k - 1 + 100, k - 1 + 128], p_insert=0.5) + reads[:20]
     check_batch(d, o, few, paired)
+    # short reads: three share a block when none has more than 84 k-mer end positions (tri_scan_cand: lanes 0-41 / 0-41 / 42-63 twice)
+    sl = [k - 1 + t for t in (84, 84, 83, 85, 44, 45, 43, 1, 2, 60, 70, 78)] + [k - 2, 5, 0, 150]
+    shorts = util.fuzz_reads(rng, refs, 1500, sl, p_insert=0.6)
+    for L in (k - 1 + 84, k - 1 + 83, k - 1 + 60):               # pieces ending at the lane-group borders of the three-read block
+        for end in (L, L - 1, k - 1 + 44, k - 1 + 45, k - 1 + 43, k + 1, k, k - 1 + 84, k - 1 + 2):
+            if end > L or end < k:
+                continue
+            r = rng.choice(refs)
+            piece = r[rng.randint(0, len(r) - k - 3):][:k + 3]
+            g = bytearray(util.rand_seq(rng, L, 0.0))
+            g[max(0, end - len(piece)):end] = piece[-min(len(piece), end):]
+            for rep in range(3):                                # at each of the three places of a block
+                shorts.insert(rng.randrange(len(shorts) + 1), bytes(g))
+    if paired and len(shorts) & 1:
+        shorts.pop()
+    check_batch(d, o, shorts, paired)
