@@ -1471,6 +1471,62 @@ __device__ __forceinline__ void tail_scan_cand(const KParams& P, const Planes& Q
     }
 }
 
+// The tail pass of the every-hit scans (ktrim=l, ksplit): the same lane layout as tail_scan_cand, exact lookups, and every read with a hit in
+// its tail folds it into its scan facts (fold_hits: count, first / last position, id of the first hit) -- the tails lie behind everything
+// the pair scan saw, so position order is kept.
+template <int MODE, bool FORBIDN, bool GENERAL>
+__device__ __forceinline__ void tail_scan_hits(const KParams& P, const Planes& Q, uint8_t* sel, const bool anyN, const int vBase0, const int vStart, const int vStop,
+                                               const int vTail, const int lane, int& vFound, int& vFirst, int& vLast, int& vRef) {
+    const bool need = vTail > 0;
+    const uint64_t needM = __ballot(need);
+    if (!needM) return;
+    const int rank = __popcll(needM & ((1ULL << lane) - 1ULL));
+    if (need) sel[rank] = (uint8_t)lane;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int nneed = __popcll(needM);
+    const int tmax = wave_max_i(need ? vTail : 0);
+    const int sh = tmax <= 8 ? 2 : (tmax <= 16 ? 3 : 4);        // log2(lanes per read)
+    const int rpg = 64 >> sh;
+    const int u = lane & ((1 << sh) - 1);
+    for (int pb = 0; pb < nneed; pb += 2 * rpg) {
+        ReadWin W[2]; int pos[2]; bool val[2];
+#pragma unroll
+        for (int sp = 0; sp < 2; sp++) {
+            const int idx = pb + sp * rpg + (lane >> sh);
+            val[sp] = idx < nneed;
+            const int src = sel[min(idx, nneed - 1)];
+            W[sp].base0 = __shfl(vBase0, src); W[sp].start = __shfl(vStart, src); W[sp].stop = __shfl(vStop, src);
+            pos[sp] = W[sp].stop - __shfl(vTail, src) + 2 * u;
+            W[sp].first = P.k - 1; W[sp].on = true; W[sp].full = true; W[sp].hasN = anyN;
+        }
+        uint64_t kmer[4], rk[4]; bool ok[4]; int id[4];
+        windows2<FORBIDN, GENERAL, GENERAL>(P, Q, W[0], pos[0], val[0], kmer, rk, ok);
+        windows2<FORBIDN, GENERAL, GENERAL>(P, Q, W[1], pos[1], val[1], kmer + 2, rk + 2, ok + 2);
+        lookup4_probe<GENERAL>(P, Q.filt, kmer, rk, ok, id);
+#pragma unroll
+        for (int sp = 0; sp < 2; sp++) {
+            const uint64_t me = __ballot(id[2 * sp] != -1), mo = __ballot(id[2 * sp + 1] != -1);
+            uint64_t mm = me | mo;
+            while (mm) {                                          // rare: a read with hits in its tail
+                const int g = (__ffsll((unsigned long long)mm) - 1) >> sh;
+                const int l0 = g << sh;
+                const uint32_t lm = sh == 4 ? 0xFFFFu : (sh == 3 ? 0xFFu : 0xFu);
+                const uint64_t m = interleave32((uint32_t)(me >> l0) & lm, (uint32_t)(mo >> l0) & lm);
+                const int jr = __builtin_amdgcn_readfirstlane((int)sel[pb + sp * rpg + g]);
+                ReadScan R;
+                int found = __builtin_amdgcn_readlane(vFound, jr);
+                R.iFirst = __builtin_amdgcn_readlane(vFirst, jr); R.iLast = __builtin_amdgcn_readlane(vLast, jr); R.ref = __builtin_amdgcn_readlane(vRef, jr);
+                fold_hits<MODE>(P, R, found, m, id[2 * sp], id[2 * sp + 1], __builtin_amdgcn_readlane(pos[sp], l0), l0);
+                vFound = (lane == jr) ? found : vFound; vFirst = (lane == jr) ? R.iFirst : vFirst;
+                vLast = (lane == jr) ? R.iLast : vLast; vRef = (lane == jr) ? R.ref : vRef;
+                mm &= ~((uint64_t)lm << l0);
+            }
+        }
+    }
+}
+
 // Short k-mer scans of two reads in one pass: lanes 0-31 serve read A, lanes 32-63 read B, one lane per
 // length mink..  (bbduk/BBDukProcessorS.java:2034-2103).  Only reads whose main scan found nothing take part.
 template <int MODE, bool GENERAL>
@@ -2795,6 +2851,7 @@ void wave_body(const KParams& P, const uint8_t* __restrict__ bases, const int64_
     constexpr bool FBM = MODE == BBDUK_MODE_FBM;                  // kfilter with findBestMatch: per-read id lists in the pair scan (main_scan_pair_best)
     constexpr bool KMASK = MODE == BBDUK_MODE_KMASK;              // ktrim=n: every hit of the main scan, both ends' short k-mers, a mask per base
     constexpr bool TAILSCAN = SHAPE == 1, TRISCAN = SHAPE == 2;   // see "tails" below and tri_scan_cand
+    constexpr bool TAILHITS = SHAPE == 0 && (MODE == BBDUK_MODE_KTRIM_L || MODE == BBDUK_MODE_KSPLIT);   // the every-hit scans' tail pass (tail_scan_hits), always on
     static_assert(SHAPE == 0 || ((MODE == BBDUK_MODE_KTRIM_R || MODE == BBDUK_MODE_KFILTER) && !BIG), "shapes: first-hit scans of the cache-resident layout only");
     constexpr int CAPB = KMASK ? WCAP_BASES_KM : WCAP_BASES;      // per-wave plane capacity in bases
     constexpr int PLW = KMASK ? WPLANE_WORDS_KM : WPLANE_WORDS, NMW = KMASK ? WNM_WORDS_KM : WNM_WORDS, HW = KMASK ? WHIT_WORDS : 0;
@@ -3007,15 +3064,15 @@ void wave_body(const KParams& P, const uint8_t* __restrict__ bases, const int64_
             // them to the tail pass below, which serves the tails of up to 32 reads in one block (lane-varying read coordinates).
             int vTail = 0;
             uint64_t triMask = 0;                                   // short reads: three of them share a block (tri_scan_cand)
-            if constexpr (TAILSCAN || TRISCAN) {
-                if (candP && (!GENERAL || P.qskip < 2)) {
+            if constexpr (TAILSCAN || TRISCAN || TAILHITS) {
+                if ((TAILHITS || candP) && (!GENERAL || P.qskip < 2)) {
                     const int npos = (vScan && lane >= s && lane < e) ? max(0, vStop - max(vStart, P.k - 1)) : 0;
                     const int rem = npos & 127;
-                    if constexpr (TAILSCAN) vTail = (npos > 128 && rem >= 1 && rem <= TAIL_MAX) ? rem : 0;
+                    if constexpr (TAILSCAN || TAILHITS) vTail = (npos > 128 && rem >= 1 && rem <= TAIL_MAX) ? rem : 0;
                     if constexpr (TRISCAN) triMask = __ballot(lane >= s && lane < e && npos <= TRI_MAX);
                 }
             }
-            const uint64_t tailMask = TAILSCAN ? __ballot(vTail > 0) : 0ULL;
+            const uint64_t tailMask = (TAILSCAN || TAILHITS) ? __ballot(vTail > 0) : 0ULL;
             int step = 2;
             for (int ra = s; ra < e && !quadDone; ra += step) {
                 if constexpr (TRISCAN) {
@@ -3056,7 +3113,7 @@ void wave_body(const KParams& P, const uint8_t* __restrict__ bases, const int64_
                     A.start = __builtin_amdgcn_readlane(vStart, ra); A.stop = __builtin_amdgcn_readlane(vStop, ra);
                     Bz.start = hasB ? __builtin_amdgcn_readlane(vStart, ra + 1) : 0; Bz.stop = hasB ? __builtin_amdgcn_readlane(vStop, ra + 1) : 0;
                 }
-                if constexpr (TAILSCAN) {
+                if constexpr (TAILSCAN || TAILHITS) {
                     if ((tailMask >> ra) & 3ULL) { A.stop -= __builtin_amdgcn_readlane(vTail, ra); if (hasB) Bz.stop -= __builtin_amdgcn_readlane(vTail, ra + 1); }
                 }
                 A.found = 0; A.iFirst = BIGLOC; A.iLast = -1; A.ref = -1; A.shortFl = -1; A.shortLl = -1;
@@ -3108,6 +3165,10 @@ void wave_body(const KParams& P, const uint8_t* __restrict__ bases, const int64_
                     vLast = (lane == ra + 1) ? Bz.iLast : vLast;   vRef = (lane == ra + 1) ? Bz.ref : vRef;
                     vSFl = (lane == ra + 1) ? Bz.shortFl : vSFl;   vSLl = (lane == ra + 1) ? Bz.shortLl : vSLl;
                 }
+            }
+            if constexpr (TAILHITS) {
+                if (tailMask) tail_scan_hits<MODE, FORBIDN, GENERAL>(P, Q, sel, (FORBIDN && P.forbidNs) && (nMask & tailMask) != 0ULL, origin + rel, vStart, vStop, vTail, lane,
+                                                                  vFound, vFirst, vLast, vRef);
             }
             if constexpr (TAILSCAN) {
                 if (tailMask) tail_scan_cand<FORBIDN, GENERAL, SHORT && !GENERAL, GENERAL>(P, Q, sel, (FORBIDN && P.forbidNs) && (nMask & tailMask) != 0ULL, origin + rel, vStart, vStop,

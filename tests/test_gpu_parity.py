@@ -1116,3 +1116,41 @@ def test_tail_pass_parity(ci, paired):
     if paired and len(shorts) & 1:
         shorts.pop()
     check_batch(d, o, shorts, paired)
+
+
+# the every-hit scans' tail pass (tail_scan_hits: ktrim=l and ksplit fold the hits of the tail into the read's scan facts)
+TAIL_HITS_CASES = [("ktrim=l k=23 mink=11 hdist=1", dict(k=23, ktrimLeft=1, mink=11, hdist=1), 23, "batch"),
+                   ("ktrim=l k=21", dict(k=21, ktrimLeft=1), 21, "batch"),
+                   ("ktrim=l k=19 hdist=1 restrictleft=170 tp=1", dict(k=19, ktrimLeft=1, hdist=1, restrictLeft=170, trimPad=1), 19, "batch"),
+                   ("ksplit=t k=23 mink=11 hdist=1", dict(k=23, mink=11, hdist=1, ksplit=1), 23, "split"),
+                   ("ksplit=t k=25", dict(k=25, ksplit=1), 25, "split")]
+
+
+@pytest.mark.parametrize("ci", range(len(TAIL_HITS_CASES)))
+def test_tail_pass_every_hit_scans(ci):
+    args, okw, k, kind = TAIL_HITS_CASES[ci]
+    rng = random.Random(7100 + ci)
+    refs = [util.rand_seq(rng, rng.randint(40, 120), 0.0) for _ in range(6)]
+    d, o = make_pair(args, okw, refs=refs)
+    edge = [k - 1 + 128 + t for t in (0, 1, 2, 8, 9, 16, 17, 31, 32, 33)] + [k - 1 + 256 + t for t in (1, 5, 32, 33)]
+    reads = util.fuzz_reads(rng, refs, 1000, edge * 3 + [100, 150, 40, 0, 5], p_insert=0.6)
+    for L in edge:
+        for end in (L, L - 1, L - 3, k - 1 + 128, k - 1 + 128 + 1, k - 1 + 128 + 2, k - 1 + 127, max(k, L - 33)):
+            if end > L or end < k + 5:
+                continue
+            r = rng.choice(refs)
+            piece = r[rng.randint(0, len(r) - k - 5):][:k + 5]
+            g = bytearray(util.rand_seq(rng, L, 0.0))
+            g[end - len(piece):end] = piece
+            if rng.random() < 0.5:                              # and a second piece far to the left: first / last hit in different passes
+                g[30:30 + len(piece)] = piece
+            if rng.random() < 0.3:
+                g[rng.randrange(L)] = ord("N")
+            reads.append(bytes(g))
+    rng.shuffle(reads)
+    if len(reads) & 1:
+        reads.pop()
+    if kind == "split":
+        check_split(d, o, reads)
+    else:
+        check_batch(d, o, reads, True); check_batch(d, o, reads[:301], False)
