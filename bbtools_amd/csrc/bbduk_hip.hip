@@ -1474,18 +1474,25 @@ __device__ __forceinline__ void tail_scan_cand(const KParams& P, const Planes& Q
 // The tail pass of the every-hit scans (ktrim=l, ksplit): the same lane layout as tail_scan_cand, exact lookups, and every read with a hit in
 // its tail folds it into its scan facts (fold_hits: count, first / last position, id of the first hit) -- the tails lie behind everything
 // the pair scan saw, so position order is kept.
-template <int MODE, bool FORBIDN, bool GENERAL>
+// MASK (ktrim=n): the tails' positions also set their bits of the hit plane, as main_scan_pair<.., MASK> does for the positions it sees.
+template <int MODE, bool FORBIDN, bool GENERAL, bool MASK = false>
 __device__ __forceinline__ void tail_scan_hits(const KParams& P, const Planes& Q, uint8_t* sel, const bool anyN, const int vBase0, const int vStart, const int vStop,
-                                               const int vTail, const int lane, int& vFound, int& vFirst, int& vLast, int& vRef) {
+                                               const int vTail, const int lane, int& vFound, int& vFirst, int& vLast, int& vRef, uint32_t* hitPlane = nullptr,
+                                               const int s0 = 0, const int e0 = 0) {
     const bool need = vTail > 0;
     const uint64_t needM = __ballot(need);
     if (!needM) return;
-    const int rank = __popcll(needM & ((1ULL << lane) - 1ULL));
-    if (need) sel[rank] = (uint8_t)lane;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int nneed = __popcll(needM);
+    // the reads that take part: a compact list in `sel` -- except for ktrim=n, whose list would lie on the undefined-plane the windows
+    // still read: there the reads [s0, e0) of the sub-tile are walked as they stand (sixteen 151-base reads: one or two blocks either way)
+    int nneed;
+    if constexpr (!MASK) {
+        const int rank = __popcll(needM & ((1ULL << lane) - 1ULL));
+        if (need) sel[rank] = (uint8_t)lane;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        nneed = __popcll(needM);
+    } else nneed = e0 - s0;
     const int tmax = wave_max_i(need ? vTail : 0);
     const int sh = tmax <= 8 ? 2 : (tmax <= 16 ? 3 : 4);        // log2(lanes per read)
     const int rpg = 64 >> sh;
@@ -1495,16 +1502,27 @@ __device__ __forceinline__ void tail_scan_hits(const KParams& P, const Planes& Q
 #pragma unroll
         for (int sp = 0; sp < 2; sp++) {
             const int idx = pb + sp * rpg + (lane >> sh);
-            val[sp] = idx < nneed;
-            const int src = sel[min(idx, nneed - 1)];
+            int src;
+            if constexpr (!MASK) src = sel[min(idx, nneed - 1)]; else src = min(s0 + idx, 63);
+            const int tl = __shfl(vTail, src);
+            val[sp] = idx < nneed && tl > 0;
             W[sp].base0 = __shfl(vBase0, src); W[sp].start = __shfl(vStart, src); W[sp].stop = __shfl(vStop, src);
-            pos[sp] = W[sp].stop - __shfl(vTail, src) + 2 * u;
+            pos[sp] = W[sp].stop - tl + 2 * u;
             W[sp].first = P.k - 1; W[sp].on = true; W[sp].full = true; W[sp].hasN = anyN;
         }
+        if constexpr (MASK) { if (__ballot(val[0] || val[1]) == 0ULL) continue; }
         uint64_t kmer[4], rk[4]; bool ok[4]; int id[4];
         windows2<FORBIDN, GENERAL, GENERAL>(P, Q, W[0], pos[0], val[0], kmer, rk, ok);
         windows2<FORBIDN, GENERAL, GENERAL>(P, Q, W[1], pos[1], val[1], kmer + 2, rk + 2, ok + 2);
         lookup4_probe<GENERAL>(P, Q.filt, kmer, rk, ok, id);
+        if constexpr (MASK) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int sp = q >> 1, i = pos[sp] + (q & 1);
+                const bool mark = P.mfc ? (val[sp] && i < W[sp].stop && id[q] == -1) : (id[q] != -1);
+                if (mark) atomicOr(&hitPlane[(W[sp].base0 + i) >> 5], 1u << ((W[sp].base0 + i) & 31));
+            }
+        }
 #pragma unroll
         for (int sp = 0; sp < 2; sp++) {
             const uint64_t me = __ballot(id[2 * sp] != -1), mo = __ballot(id[2 * sp + 1] != -1);
@@ -1514,7 +1532,7 @@ __device__ __forceinline__ void tail_scan_hits(const KParams& P, const Planes& Q
                 const int l0 = g << sh;
                 const uint32_t lm = sh == 4 ? 0xFFFFu : (sh == 3 ? 0xFFu : 0xFu);
                 const uint64_t m = interleave32((uint32_t)(me >> l0) & lm, (uint32_t)(mo >> l0) & lm);
-                const int jr = __builtin_amdgcn_readfirstlane((int)sel[pb + sp * rpg + g]);
+                const int jr = MASK ? (s0 + pb + sp * rpg + g) : __builtin_amdgcn_readfirstlane((int)sel[pb + sp * rpg + g]);
                 ReadScan R;
                 int found = __builtin_amdgcn_readlane(vFound, jr);
                 R.iFirst = __builtin_amdgcn_readlane(vFirst, jr); R.iLast = __builtin_amdgcn_readlane(vLast, jr); R.ref = __builtin_amdgcn_readlane(vRef, jr);
@@ -2851,7 +2869,7 @@ void wave_body(const KParams& P, const uint8_t* __restrict__ bases, const int64_
     constexpr bool FBM = MODE == BBDUK_MODE_FBM;                  // kfilter with findBestMatch: per-read id lists in the pair scan (main_scan_pair_best)
     constexpr bool KMASK = MODE == BBDUK_MODE_KMASK;              // ktrim=n: every hit of the main scan, both ends' short k-mers, a mask per base
     constexpr bool TAILSCAN = SHAPE == 1, TRISCAN = SHAPE == 2;   // see "tails" below and tri_scan_cand
-    constexpr bool TAILHITS = SHAPE == 0 && (MODE == BBDUK_MODE_KTRIM_L || MODE == BBDUK_MODE_KSPLIT);   // the every-hit scans' tail pass (tail_scan_hits), always on
+    constexpr bool TAILHITS = SHAPE == 0 && (MODE == BBDUK_MODE_KTRIM_L || MODE == BBDUK_MODE_KSPLIT || KMASK);   // the every-hit scans' tail pass (tail_scan_hits), always on
     static_assert(SHAPE == 0 || ((MODE == BBDUK_MODE_KTRIM_R || MODE == BBDUK_MODE_KFILTER) && !BIG), "shapes: first-hit scans of the cache-resident layout only");
     constexpr int CAPB = KMASK ? WCAP_BASES_KM : WCAP_BASES;      // per-wave plane capacity in bases
     constexpr int PLW = KMASK ? WPLANE_WORDS_KM : WPLANE_WORDS, NMW = KMASK ? WNM_WORDS_KM : WNM_WORDS, HW = KMASK ? WHIT_WORDS : 0;
@@ -3167,8 +3185,8 @@ void wave_body(const KParams& P, const uint8_t* __restrict__ bases, const int64_
                 }
             }
             if constexpr (TAILHITS) {
-                if (tailMask) tail_scan_hits<MODE, FORBIDN, GENERAL>(P, Q, sel, (FORBIDN && P.forbidNs) && (nMask & tailMask) != 0ULL, origin + rel, vStart, vStop, vTail, lane,
-                                                                  vFound, vFirst, vLast, vRef);
+                if (tailMask) tail_scan_hits<KMASK ? BBDUK_MODE_KTRIM_L : MODE, FORBIDN, GENERAL, KMASK>(P, Q, sel, (FORBIDN && P.forbidNs) && (nMask & tailMask) != 0ULL, origin + rel, vStart, vStop,
+                                                                                                      vTail, lane, vFound, vFirst, vLast, vRef, wh, s, e);
             }
             if constexpr (TAILSCAN) {
                 if (tailMask) tail_scan_cand<FORBIDN, GENERAL, SHORT && !GENERAL, GENERAL>(P, Q, sel, (FORBIDN && P.forbidNs) && (nMask & tailMask) != 0ULL, origin + rel, vStart, vStop,

@@ -1154,3 +1154,30 @@ def test_tail_pass_every_hit_scans(ci):
         check_split(d, o, reads)
     else:
         check_batch(d, o, reads, True); check_batch(d, o, reads[:301], False)
+
+
+@pytest.mark.parametrize("ci", range(4))
+def test_tail_pass_kmask(ci):
+    args, okw, k = [("ktrim=n k=23 mink=11 hdist=1", dict(k=23, ktrimN=1, mink=11, hdist=1), 23), ("ktrim=n k=21", dict(k=21, ktrimN=1), 21),
+                    ("ktrim=n k=23 mink=11 hdist=1 mfc=t", dict(k=23, ktrimN=1, mink=11, hdist=1, kmaskFullyCovered=1), 23),
+                    ("ktrim=n k=19 tp=2 restrictright=160 forbidn=t mfc=t", dict(k=19, ktrimN=1, trimPad=2, restrictRight=160, forbidN=1, kmaskFullyCovered=1), 19)][ci]
+    rng = random.Random(7200 + ci)
+    refs = [util.rand_seq(rng, rng.randint(40, 120), 0.0) for _ in range(6)]
+    d, o = make_pair(args, okw, refs=refs)
+    edge = [k - 1 + 128 + t for t in (0, 1, 2, 8, 9, 16, 17, 31, 32, 33)] + [k - 1 + 256 + t for t in (1, 5, 32, 33)]
+    reads = util.fuzz_reads(rng, refs, 800, edge * 3 + [100, 150, 40, 0, 5], p_insert=0.6)
+    for L in edge:
+        for end in (L, L - 1, L - 3, k - 1 + 128, k - 1 + 128 + 1, k - 1 + 128 + 2, k - 1 + 127, max(k, L - 33)):
+            if end > L or end < k + 5:
+                continue
+            r = rng.choice(refs)
+            piece = r[rng.randint(0, len(r) - k - 5):][:k + 5]
+            g = bytearray(util.rand_seq(rng, L, 0.0))
+            g[end - len(piece):end] = piece
+            if rng.random() < 0.3:
+                g[rng.randrange(L)] = ord("N")
+            reads.append(bytes(g))
+    rng.shuffle(reads)
+    if len(reads) & 1:
+        reads.pop()
+    check_kmask(d, o, reads, True); check_kmask(d, o, reads[:301], False)
