@@ -1297,8 +1297,8 @@ __device__ __forceinline__ void main_scan_pair_cand(const KParams& P, const Plan
 // straddle the two slot pairs.  The windows are cut with lane-varying read coordinates; every read then takes its first candidate out of its
 // part of the ballots.  One block serves all positions (the caller groups the reads so that they fit); the spans' windows are all "full"
 // (every position looked up, SPAN cuts in front of `start`).
-// The same scan serves ktrim=r / kfilter (PACKSCAN in bbduk_wave_kernel) when the pair scan would waste blocks: there a read may start in one
-// block and end in the next (T[0] < 0: slots of the first read that earlier blocks scanned; T[nr] > 128: the last read goes on).
+// (T[0] < 0 and T[4] > 128 are allowed -- a read that starts in an earlier block or goes on in the next: the lane-slot packing tried for
+// 2x151 reads, DESIGN 4.1 "Read length"; a packed block costs 1.43x a pair block, so only ktrim=rl's right pass uses this scan.)
 template <bool FORBIDN, bool GENERAL, bool NOMM = false, bool SPAN = true>
 __device__ __forceinline__ void packed_scan_cand(const KParams& P, const Planes& Q, const int ra, const int nr, const int* T, const bool anyN,
                                                  const int vBase0, const int vStart, const int vStop, const int vFirstLook, const int lane,

@@ -1059,8 +1059,8 @@ def test_trimfailuresto1bp_refuses_units_beyond_the_main_kernel():
     d.close()
 
 
-# ---- the tail pass (bbduk_wave_kernel<.., TAIL>): reads whose k-mer end positions overshoot the pair scan's 128-position blocks by 1..32
-# take their last positions to a packed pass; the instantiation runs when at least one read in eight has such a tail.  Lengths around every
+# ---- the tail pass (bbduk_wave_shape_kernel, wave_body<.., 1>): reads whose k-mer end positions overshoot the pair scan's 128-position blocks by 1..32
+# take their last positions to a packed pass; that body runs when at least one read in eight has such a tail.  Lengths around every
 # edge of that rule, reference pieces ending at the last pair-scan position, the first tail position and the read's end.
 TAIL_CASES = [("ktrim=r k=23 mink=11 hdist=1", dict(k=23, ktrimRight=1, mink=11, hdist=1), 23),
               ("ktrim=r k=23", dict(k=23, ktrimRight=1), 23),                                                       # hdist=0: forbidNs, the undefined-base path
