@@ -46,7 +46,26 @@ def cli_tsv(stem, spec_args, ref, ktrim):
             f.write("%s\t%d\t%d\t%d\t%d\t%d\n" % (nm, len(r), t[0], t[1], len(r) - (t[0] if ktrim else 0), t[2]))
 
 
+def len151_fixture():
+    """2x151 pairs from the repo's generator (the commonest Illumina length: one k-mer end position more than the pair scan's block holds with
+    k=23, so the tail pass serves it), AddAdapters-style names, interleaved FASTQ + the per-read table of ktrim=r k=23 mink=11 hdist=1."""
+    from make_golden import synth_reads, truth_names, write_fastq
+    from oracle.spec import Spec, Args
+    kw = dict(read_len=151, ins_min=100, ins_max=175, sub_rate=0.01, n_rate=0.002)
+    reads = synth_reads(21, 150, **kw)
+    names = truth_names(21, 150, reads, **kw)
+    here = os.path.dirname(__file__)
+    write_fastq(os.path.join(here, "cli_len151_interleaved.fq"), names, reads)
+    s = Spec(Args(k=23, mink=11, hdist=1, ktrimRight=True)); s.load_fasta(ADAPTERS)
+    out = s.process_batch([r.encode() for r in reads], True)
+    with open(os.path.join(here, "cli_len151.tsv"), "w") as f:
+        for nm, r, t in zip(names, reads, out):
+            f.write("%s\t%d\t%d\t%d\t%d\t%d\n" % (nm, len(r), t[0], t[1], len(r) - t[0], t[2]))
+    print("cli_len151", len(reads), "reads,", sum(1 for t in out if t[0]), "trimmed,", sum(1 for r, t in zip(reads, out) if t[0] == 23), "with their only 23-mer hit at the last (tail) position")
+
+
 def main():
+    len151_fixture()
     reads = sample_pairs()
     cli_tsv("cli_sample_ktrimr_k25_phix", dict(k=25, ktrimRight=True), PHIX, True)
     cli_tsv("cli_sample_kfilter_k31_hdist1_phix", dict(k=31, hdist=1), PHIX, False)

@@ -277,3 +277,14 @@ def test_cli_on_the_reference_sample_reads(tmp_path, stem, flags):
     assert {n for n, _, _ in removed} == {x[0] for x in rows if int(x[5]) & 2}
     newlen = {x[0]: int(x[4]) for x in rows}
     assert all(len(b) == len(q) == newlen[n] for n, b, q in kept + removed)
+
+
+@pytest.mark.gpu
+def test_cli_2x151_reads_take_the_tail_pass(tmp_path):
+    """2x151 with k=23: 129 k-mer end positions per read, one more than the pair scan's block holds (the tail pass of the main kernel)."""
+    tsv = str(tmp_path / "o.tsv")
+    r = run_cli(["in=" + os.path.join(GOLD, "cli_len151_interleaved.fq"), "int=t", "tsv=" + tsv, "ktrim=r", "k=23", "mink=11", "hdist=1", "ref=adapters"])
+    assert r.returncode == 0, r.stderr
+    assert open(tsv).read() == open(os.path.join(GOLD, "cli_len151.tsv")).read()
+    rows = [l.split("\t") for l in open(tsv).read().splitlines()]
+    assert sum(1 for x in rows if int(x[1]) == 151 and int(x[4]) == 128) >= 3               # first hit = the 129th position: found by the tail pass

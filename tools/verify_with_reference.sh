@@ -55,6 +55,10 @@ python3 "$ROOT/tools/compare_with_reference.py" --kfilter --tsv "$G/cli_sample_k
 run "$DUK" in="$S1" in2="$S2" out="$W/s_mkf_o.fq" outm="$W/s_mkf_m.fq" k=31 mkf=0.5 ref="$REFP" $COMMON
 python3 "$ROOT/tools/compare_with_reference.py" --kfilter --tsv "$G/cli_sample_kfilter_k31_mkf_phix.tsv" --out "$W/s_mkf_o.fq" --outm "$W/s_mkf_m.fq" || fail=1
 
+# 3c. 2x151 pairs (one k-mer end position more than 128 with k=23), interleaved
+run "$DUK" in="$G/cli_len151_interleaved.fq" int=t out="$W/l151_o.fq" outm="$W/l151_m.fq" ktrim=r k=23 mink=11 hdist=1 ref="$REFA" $COMMON
+python3 "$ROOT/tools/compare_with_reference.py" --tsv "$G/cli_len151.tsv" --out "$W/l151_o.fq" --outm "$W/l151_m.fq" || fail=1
+
 # 4. ksplit: kept reads and the split pairs byte for byte
 run "$DUK" in="$G/cli_ksplit.fq" out="$W/ks_o.fq" outm="$W/ks_m.fq" ksplit=t k=23 mink=11 hdist=1 ref="$REFA" $COMMON
 for pair in "ks_o.fq cli_ksplit_expected_out.fq" "ks_m.fq cli_ksplit_expected_outm.fq"; do
