@@ -2819,7 +2819,8 @@ __device__ __forceinline__ void main_scan_pair_kbig(const KParams& P, const Plan
 #define WAVE_LDS_BYTES ((2 * NWAVES * WPLANE_WORDS + NWAVES * WNM_WORDS) * 4 + 6 * 8 + NWAVES * SEL_BYTES)   // behind the filter
 #define WUNIT_MAX    (WCAP_BASES - 48)             // longest unit (pair) the wave kernel accepts
 #define TAIL_MAX     32                            // positions a read may leave to the tail pass (wave_body<.., SHAPE>)
-#define TRI_SHARE    3                             // ... or one read in TRI_SHARE is short enough for three to share a block (tri_scan_cand)
+#define TRI_SHARE    2                             // ... or one read in TRI_SHARE is short enough for three to share a block (tri_scan_cand);
+                                                   // a triple needs three short reads in a row: below a half the slower body 2 is not paid back
 #define TAIL_SHARE   8                             // the tail-pass body takes a batch in which at least one read in TAIL_SHARE has a tail
 // ktrim=n keeps a fourth per-wave plane (the k-mer end positions that hit).  To fit behind a 128 KiB filter its planes are a little shorter
 // (sixteen 150-base reads still fit) and its short-scan lists live in the undefined-plane, which is dead once the main scan of the
