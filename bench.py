@@ -323,10 +323,13 @@ def main():
             import bench_modes, bench_seal
             out["operators"] = {r["mode"]: {k: r[k] for k in ("args", "reads", "operator_ms", "Gbases_per_s")} for r in bench_modes.run(a.extra_reads)}
             out["seal"] = bench_seal.run(pairs=1_000_000, check=0)
-            import bench_readlens                      # the configs[1] flags on pairs of other lengths (2x151: the tail pass of the main kernel)
-            out["read_lengths"] = {"2x%d" % r["read_len"]: {k: r[k] for k in ("reads", "kernel_ms", "Gbases_per_s")} for r in bench_readlens.run(lens=(100, 151, 250))}
         except Exception as e:
             out["operators"] = {"error": repr(e)}
+        try:                                           # the configs[1] flags on pairs of other lengths (2x151: the tail pass of the main kernel)
+            import bench_readlens
+            out["read_lengths"] = {"2x%d" % r["read_len"]: {k: r[k] for k in ("reads", "kernel_ms", "Gbases_per_s")} for r in bench_readlens.run(lens=(100, 151, 250))}
+        except Exception as e:
+            out["read_lengths"] = {"error": repr(e)}
         try:
             out["configs"] = measure_configs(B, a.extra_reads, a.c4_ref_bases)
         except Exception as e:
