@@ -2888,12 +2888,13 @@ void wave_body(const KParams& P, const uint8_t* __restrict__ bases, const int64_
         for (int w = tid; w < words; w += BLOCK_THREADS) s_filt[w] = P.ldsImage[w];
     }
     __syncthreads();
-    if (*slowFlag != 0) {                                         // a unit does not fit a wave's planes: tile kernel's job
-        if (PTF && tid == 0 && blockIdx.x == 0) atomicMax((unsigned long long*)&counters[BBDUK_CTR_STATUS], (unsigned long long)(-BBDUK_ERR_UNSUPPORTED));
+    // slowFlag[0] != 0: a unit does not fit a wave's planes, the tile kernel's job; slowFlag[3] != 0 (bbduk_shape_kernel's verdict on the
+    // pre-pass's counts): bbduk_wave_shape_kernel's batch.  One combined test, as before the shapes existed.
+    const int sf0 = slowFlag[0];
+    const int sf3 = (SHAPE == 0 && (MODE == BBDUK_MODE_KTRIM_R || MODE == BBDUK_MODE_KFILTER) && !BIG) ? slowFlag[3] : 0;
+    if ((sf0 | sf3) != 0) {
+        if (sf0 != 0 && PTF && tid == 0 && blockIdx.x == 0) atomicMax((unsigned long long*)&counters[BBDUK_CTR_STATUS], (unsigned long long)(-BBDUK_ERR_UNSUPPORTED));
         return;                                                   // (trimfailuresto1bp is served by this kernel only: the others stand back)
-    }
-    if constexpr (SHAPE == 0 && (MODE == BBDUK_MODE_KTRIM_R || MODE == BBDUK_MODE_KFILTER) && !BIG) {
-        if (batch_shape(slowFlag, n) != 0) return;                // bbduk_wave_shape_kernel's batch
     }
     // short-scan geometry: `lens` candidate lengths per read, rpp reads per 64-lane pass
     // first-hit-only operators verify candidates in batches (see main_scan_pair_cand)
@@ -3658,7 +3659,7 @@ void bbduk_wave_shape_kernel(const KParams P, const uint8_t* __restrict__ bases,
                              int64_t* __restrict__ counters, const int* __restrict__ slowFlag) {
     static_assert(MODE == BBDUK_MODE_KTRIM_R || MODE == BBDUK_MODE_KFILTER, "first-hit scans only");
     if (slowFlag[0] != 0) return;
-    const int shape = batch_shape(slowFlag, n);
+    const int shape = slowFlag[3];
     if (shape == 1) wave_body<MODE, SHORT, FORBIDN, GENERAL, FMT, false, 1>(P, bases, offsets, n, totalBases, paired, outA, outId, outFlags, counters, slowFlag);
     else if (shape == 2) wave_body<MODE, SHORT, FORBIDN, GENERAL, FMT, false, 2>(P, bases, offsets, n, totalBases, paired, outA, outId, outFlags, counters, slowFlag);
 }
@@ -4337,6 +4338,8 @@ __global__ void bbduk_span_kernel(const int64_t* __restrict__ offsets, const int
         if (shorts > 0 && (threadIdx.x & 63) == 0) atomicAdd(slowFlag + 2, shorts);
     }
 }
+// one thread: the pre-pass's counts -> which kernel takes the batch (slowFlag[3]: 0 bbduk_wave_kernel, 1 / 2 bbduk_wave_shape_kernel's bodies)
+__global__ void bbduk_shape_kernel(int* __restrict__ slowFlag, const int64_t n) { slowFlag[3] = batch_shape(slowFlag, n); }
 
 // runtime -> template dispatch
 typedef void (*batch_kernel_t)(const KParams, const uint8_t*, const int64_t*, const int64_t, const int64_t, const int,
@@ -5023,6 +5026,7 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
         const int64_t units = paired ? n / 2 : n;
         const int sgrid = (int)std::min<int64_t>((units + 255) / 256, (int64_t)h->numCU * 8);
         bbduk_span_kernel<<<dim3(std::max(sgrid, 1)), dim3(256), 0, st>>>(d_offsets, n, (int)paired, d_flag, (int64_t)WUNIT_MAX, (int64_t)(CAP_BASES - 64), tailForm ? K.k - 1 : -1);
+        if (tailForm) bbduk_shape_kernel<<<dim3(1), dim3(1), 0, st>>>(d_flag, n);
     }
 #ifndef WAVE_WGS_PER_CU
 #define WAVE_WGS_PER_CU 1
