@@ -47,6 +47,7 @@ def ingest_roundtrip(B, d, o, okw, reads, rng):
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=300.0); ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--only", type=int, default=None, help="re-run the one configuration a FAILED line names by its seed")
+    ap.add_argument("--families", default=None, help="comma-separated subset of the families to draw from (e.g. tails,base,kmask,ksplit)")
     a = ap.parse_args()
     from bbtools_amd import bbduk as B
     from oracle.oracle_ffi import Oracle
@@ -57,7 +58,7 @@ def main():
     while time.time() - t0 < a.seconds and not (a.only is not None and it):
         seed = a.seed * 1_000_003 + it if a.only is None else a.only; it += 1
         rng = random.Random(seed)
-        fam = rng.choice(["base", "base", "base", "tails", "kmask", "tips", "ksplit", "big", "fbm", "seal", "tf1bp"])
+        fam = rng.choice(a.families.split(",") if a.families else ["base", "base", "base", "tails", "kmask", "tips", "ksplit", "big", "fbm", "seal", "tf1bp"])
         tails = fam == "tails"                                 # base configurations on reads that overshoot the pair scan's blocks by 1..32 positions:
         if tails: fam = "base"                                 # bbduk_wave_shape_kernel / the every-hit scans' tail pass take such batches
         if fam == "tf1bp":                                     # trimfailuresto1bp over every operator family (units within the main kernel's planes)
