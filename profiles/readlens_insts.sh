@@ -14,11 +14,11 @@ import csv,glob,collections,json
 agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/p/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "bbduk_wave_kernel" in r["Kernel_Name"]:
-            agg[r["Kernel_Name"].split("(")[0][:40]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if "bbduk_wave" in r["Kernel_Name"]:
+            agg[r["Kernel_Name"].split("(")[0][:48]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 n=json.loads(open("$OUT/run.json").read().strip().splitlines()[-1])["reads"]
 for k,cs in agg.items():
     m={c:sum(v)/len(v) for c,v in cs.items()}
-    print("$which L=$L %-30s per read: VALU %.1f SALU %.1f LDS %.1f VMEM_RD %.2f  wave-cycles(x4)/read %.0f wait %.0f" % (k, m["SQ_INSTS_VALU"]/n, m["SQ_INSTS_SALU"]/n, m["SQ_INSTS_LDS"]/n, m["SQ_INSTS_VMEM_RD"]/n, m["SQ_WAVE_CYCLES"]*4/n, m["SQ_WAIT_ANY"]*4/n))
+    print("$which L=$L %-48s per read: VALU %.1f SALU %.1f LDS %.1f VMEM_RD %.2f  wave-cycles(x4)/read %.0f wait %.0f" % (k, m["SQ_INSTS_VALU"]/n, m["SQ_INSTS_SALU"]/n, m["SQ_INSTS_LDS"]/n, m["SQ_INSTS_VMEM_RD"]/n, m["SQ_WAVE_CYCLES"]*4/n, m["SQ_WAIT_ANY"]*4/n))
 PY
 done
