@@ -1,0 +1,51 @@
+// bbduk_kernels.h -- run-time -> template dispatch of the batch kernels.  The kernel families are instantiated in translation units of
+// their own (bbduk_k_*.hip) so that they compile in parallel; the host code (bbduk_hip.hip) only sees these pick functions.
+#ifndef BBDUK_KERNELS_H
+#define BBDUK_KERNELS_H
+#include "bbduk_internal.h"
+
+typedef void (*batch_kernel_t)(const KParams, const uint8_t*, const int64_t*, const int64_t, const int64_t, const int,
+                               int32_t*, int32_t*, uint8_t*, int64_t*, const int*);
+// wave / wavePacked: bbduk_wave_kernel for the ASCII / the packed boundary format; tile: bbduk_batch_kernel (units beyond a wave's planes);
+// shape / shapePacked: bbduk_wave_shape_kernel (first-hit scans of the GENERAL family); stream / streamPacked: bbduk_stream_kernel (the
+// length-agnostic first-hit scan of the specialised family) -- null where the family has none
+struct KernelPair { batch_kernel_t wave, wavePacked, tile, shape = nullptr, shapePacked = nullptr, stream = nullptr, streamPacked = nullptr; };
+
+KernelPair bbduk_pick_ktrim_r(bool general, bool useShort, bool forbidN);       // bbduk_k_ktrimr.hip
+KernelPair bbduk_pick_ktrim_l(bool general, bool useShort, bool forbidN);       // bbduk_k_ktriml.hip
+KernelPair bbduk_pick_kfilter(bool general, bool forbidN);                      // bbduk_k_kfilter.hip
+KernelPair bbduk_pick_kfilter_big(bool forbidN);                                // bbduk_k_kfilter.hip (HBM-resident layout)
+// the other modes of bbduk_wave_kernel: BBDUK_MODE_FBM / _KBIG (bbduk_k_modes_a.hip), _KSPLIT / _KTRIM_TIPS / _KMASK (bbduk_k_modes_b.hip)
+batch_kernel_t bbduk_pick_mode_wave(int mode, bool general, bool packed, bool forbidN);
+// the stream kernels (bbduk_stream.hip): mode = BBDUK_MODE_KTRIM_R | BBDUK_MODE_KFILTER
+batch_kernel_t bbduk_pick_stream(int mode, bool useShort, bool forbidN, bool packed);
+
+#ifdef BBDUK_DEVICE_INC            /* translation units that hold kernel templates */
+template <int MODE, bool SHORT, bool FORBIDN, bool GENERAL>
+static KernelPair kpair() {
+    // the specialised wave kernels exist once per input format; the general one and the tile fallback decide per launch
+    KernelPair kp = GENERAL ? KernelPair{bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL, 2>, bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL, 2>,
+                                         bbduk_batch_kernel<MODE, SHORT, FORBIDN, GENERAL>}
+                            : KernelPair{bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL, 0>, bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL, 1>,
+                                         bbduk_batch_kernel<MODE, SHORT, FORBIDN, GENERAL>};
+    if constexpr (MODE == BBDUK_MODE_KTRIM_R || MODE == BBDUK_MODE_KFILTER) {       // the first-hit scans have a kernel for badly fitting read lengths each
+        kp.shape = GENERAL ? bbduk_wave_shape_kernel<MODE, SHORT, FORBIDN, GENERAL, 2> : bbduk_wave_shape_kernel<MODE, SHORT, FORBIDN, GENERAL, 0>;
+        kp.shapePacked = GENERAL ? bbduk_wave_shape_kernel<MODE, SHORT, FORBIDN, GENERAL, 2> : bbduk_wave_shape_kernel<MODE, SHORT, FORBIDN, GENERAL, 1>;
+    }
+    return kp;
+}
+template <int MODE>
+static KernelPair pick_kernel_mode(bool general, bool useShort, bool forbidN) {
+    if (general) return kpair<MODE, true, true, true>();
+    if (MODE == BBDUK_MODE_KFILTER) return forbidN ? kpair<MODE, false, true, false>() : kpair<MODE, false, false, false>();
+    if (useShort) return forbidN ? kpair<MODE, true, true, false>() : kpair<MODE, true, false, false>();
+    return forbidN ? kpair<MODE, false, true, false>() : kpair<MODE, false, false, false>();
+}
+template <int MODE, bool SHORT>
+static batch_kernel_t pick_mode_wave(bool general, bool packed, bool forbidN) {
+    if (general) return bbduk_wave_kernel<MODE, SHORT, true, true, 2>;
+    if (packed) return forbidN ? bbduk_wave_kernel<MODE, SHORT, true, false, 1> : bbduk_wave_kernel<MODE, SHORT, false, false, 1>;
+    return forbidN ? bbduk_wave_kernel<MODE, SHORT, true, false, 0> : bbduk_wave_kernel<MODE, SHORT, false, false, 0>;
+}
+#endif
+#endif
