@@ -78,11 +78,14 @@ __global__ void bbduk_span_kernel(const int64_t* __restrict__ offsets, const int
 __global__ void bbduk_shape_kernel(int* __restrict__ slowFlag, const int64_t n) { slowFlag[3] = batch_shape(slowFlag, n); }
 
 // runtime -> template dispatch: the kernel families live in translation units of their own (bbduk_kernels.h)
-static KernelPair pick_kernel(const KParams& K) {
-    // the specialised kernels assume k >= 16 (BBDuk's usual 23-31) and what BBDukParser guarantees (mink turns
-    // maskMiddle off, :295-301); anything else takes the general kernel
-    const bool general = K.qhdist > 0 || K.qhdist2 > 0 || K.restrictLeft > 0 || K.restrictRight > 0 || K.skipR1 || K.skipR2 || !K.rcomp ||
+// the specialised kernels assume k >= 16 (BBDuk's usual 23-31) and what BBDukParser guarantees (mink turns
+// maskMiddle off, :295-301); anything else takes the general kernel
+static bool kparams_general(const KParams& K) {
+    return K.qhdist > 0 || K.qhdist2 > 0 || K.restrictLeft > 0 || K.restrictRight > 0 || K.skipR1 || K.skipR2 || !K.rcomp ||
                          (K.useShort && K.middleMask != ~0ULL) || K.k < 16 || K.qskip > 1 || K.speed > 0 || K.mkf != 0.f || K.mcf > 0.f;
+}
+static KernelPair pick_kernel(const KParams& K) {
+    const bool general = kparams_general(K);
     if (K.big) return bbduk_pick_kfilter_big(K.forbidNs != 0);        // HBM-resident layout (BASELINE configs[3]): see bbduk_k_kfilter.hip
     if (K.mode == BBDUK_MODE_KFILTER) return bbduk_pick_kfilter(general, K.forbidNs != 0);
     if (K.mode == BBDUK_MODE_KTRIM_L) return bbduk_pick_ktrim_l(general, K.useShort != 0, K.forbidNs != 0);
@@ -189,6 +192,7 @@ extern "C" int bbduk_test_hook(bbduk_handle* h, int32_t which, int64_t value) {
     std::lock_guard<std::mutex> g(h->mu);
     switch (which) {
     case BBDUK_HOOK_FORCE_TILE:  h->hookForceTile = value != 0; return BBDUK_OK;
+    case BBDUK_HOOK_PAIR_SCAN:   h->hookPairScan = value != 0; return BBDUK_OK;
     case BBDUK_HOOK_BUCKET_BITS: if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookBucketBits = (int)value; return BBDUK_OK;
     case BBDUK_HOOK_LDS_BITS:    if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookLdsBits = (int)value; return BBDUK_OK;
     case BBDUK_HOOK_BIG_LAYOUT:  if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookBigLayout = value != 0; return BBDUK_OK;
@@ -709,8 +713,11 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     if (packed) { kp.wave = kp.wavePacked; kp.shape = kp.shapePacked; }
     // the tail pass and the three-read blocks belong to the candidate form of the scans (wave_body's candMode): elsewhere the pre-pass counts
     // nothing and bbduk_wave_shape_kernel is not launched
-    const bool tailForm = kp.shape && !K.big && K.qhdist == 0 && K.qskip < 2 &&
-                          (K.mode == BBDUK_MODE_KTRIM_R || (K.mode == BBDUK_MODE_KFILTER && K.maxBadKmers == 0 && K.mkf == 0.f && K.mcf == 0.f));
+    const bool firstHit = K.mode == BBDUK_MODE_KTRIM_R || (K.mode == BBDUK_MODE_KFILTER && K.maxBadKmers == 0 && K.mkf == 0.f && K.mcf == 0.f);
+    // the specialised first-hit scans run as bbduk_stream_kernel (one body for every read length, bbduk_stream_scan.inc); the pair-scan
+    // kernel and its shape bodies keep the GENERAL family (and serve a handle with BBDUK_HOOK_PAIR_SCAN set)
+    if (firstHit && !K.big && !kparams_general(K) && !h->hookPairScan) { kp.wave = bbduk_pick_stream(K.mode, K.useShort != 0, K.forbidNs != 0, packed); kp.shape = nullptr; }
+    const bool tailForm = kp.shape && !K.big && K.qhdist == 0 && K.qskip < 2 && firstHit;
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)waveLds));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.tile), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
     if (tailForm) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.shape), hipFuncAttributeMaxDynamicSharedMemorySize, (int)waveLds));
@@ -933,7 +940,7 @@ static int launch_tips(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d
     KParams K = make_kparams(h);
     K.undef = packed ? d_undef : nullptr;
     const size_t dynLds = h->ldsBits ? ((size_t)1 << (h->ldsBits - 3)) : 0;
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bbduk_ktrimtips_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bbduk_ktrimtips_kernel<>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
     const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
     const int grid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU);
     std::lock_guard<std::mutex> lg(h->launchMu);
@@ -961,13 +968,13 @@ static int launch_tips(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d
         const int wgrid = (int)std::min<int64_t>((nmt + NWAVES - 1) / NWAVES, (int64_t)h->numCU);
         wk<<<dim3(std::max(wgrid, 1)), dim3(BLOCK_THREADS), waveLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_r, d_id, d_fl, d_counters, d_flag);
     }
-    bbduk_ktrimtips_kernel<<<dim3(grid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_r, d_l, d_id, d_fl, d_counters, d_flag);
+    bbduk_ktrimtips_kernel<><<<dim3(grid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_r, d_l, d_id, d_fl, d_counters, d_flag);
     HIP_TRY(h, hipEventRecord(h->ev1[evi], st));
     h->evCount++;
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bbduk_long_tips_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bbduk_long_tips_kernel<>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
     const int64_t units = paired ? n / 2 : n;
     const int lgrid = (int)std::min<int64_t>((units + NWAVES - 1) / NWAVES, (int64_t)h->numCU);
-    bbduk_long_tips_kernel<<<dim3(std::max(lgrid, 1)), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_r, d_l, d_id, d_fl, d_counters, d_flag);
+    bbduk_long_tips_kernel<><<<dim3(std::max(lgrid, 1)), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_r, d_l, d_id, d_fl, d_counters, d_flag);
     HIP_TRY(h, hipGetLastError());
     return BBDUK_OK;
 }
@@ -1035,7 +1042,7 @@ static int launch_kmask(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     KParams K = make_kparams(h);
     K.undef = packed ? d_undef : nullptr;
     const size_t dynLds = h->ldsBits ? ((size_t)1 << (h->ldsBits - 3)) : 0;
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bbduk_kmask_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bbduk_kmask_kernel<>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
     HIP_TRY(h, hipMemsetAsync(d_mask, 0, ((size_t)(total_bases + 31) / 32 + 2) * sizeof(uint32_t), st));
     const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
     const int grid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU);
@@ -1062,12 +1069,12 @@ static int launch_kmask(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
         const int wgrid = (int)std::min<int64_t>((nmt + NWAVES - 1) / NWAVES, (int64_t)h->numCU);
         wk<<<dim3(std::max(wgrid, 1)), dim3(BLOCK_THREADS), waveLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
     }
-    bbduk_kmask_kernel<<<dim3(grid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_mask, d_counters, d_flag);
+    bbduk_kmask_kernel<><<<dim3(grid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_mask, d_counters, d_flag);
     HIP_TRY(h, hipEventRecord(h->ev1[evi], st));
     h->evCount++;
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bbduk_kmask_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bbduk_kmask_long_kernel<>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
     const int lgrid = (int)std::min<int64_t>((n + NWAVES - 1) / NWAVES, (int64_t)h->numCU);     // sequences beyond the tiled kernel's planes
-    bbduk_kmask_long_kernel<<<dim3(std::max(lgrid, 1)), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_mask, d_counters, d_flag);
+    bbduk_kmask_long_kernel<><<<dim3(std::max(lgrid, 1)), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_mask, d_counters, d_flag);
     HIP_TRY(h, hipGetLastError());
     return BBDUK_OK;
 }

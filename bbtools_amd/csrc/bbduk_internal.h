@@ -97,7 +97,7 @@ struct bbduk_handle {
     int numCU = 256;
     bbduk_comm* comm = nullptr;          // set by bbduk_comm_create / bbduk_comm_create_local
     // include/bbduk_test_hooks.h (tests and experiments only)
-    bool hookForceTile = false, hookBigLayout = false; int hookBucketBits = 0, hookLdsBits = -1, hookDbg = 0;
+    bool hookForceTile = false, hookBigLayout = false, hookPairScan = false; int hookBucketBits = 0, hookLdsBits = -1, hookDbg = 0;
 };
 
 #define HIP_TRY(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \

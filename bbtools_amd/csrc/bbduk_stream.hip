@@ -1,4 +1,24 @@
-// bbduk_stream.hip -- the length-agnostic first-hit scan (bbduk_stream_kernel), DESIGN 4.1.
+// bbduk_stream.hip -- bbduk_stream_kernel: the length-agnostic first-hit scan of the specialised family (ktrim=r; kfilter with
+// maxbadkmers = 0), i.e. wave_body with the stream scan of bbduk_stream_scan.inc in place of the pair scan (SHAPE = 3).  DESIGN 4.1.
 #include "bbduk_device.inc"
 #include "bbduk_kernels.h"
-batch_kernel_t bbduk_pick_stream(int mode, bool useShort, bool forbidN, bool packed) { return nullptr; }
+
+template <int MODE, bool SHORT, bool FORBIDN, int FMT>
+__global__ __launch_bounds__(BLOCK_THREADS)
+void bbduk_stream_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
+                         const int64_t n, const int64_t totalBases, const int paired,
+                         int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
+                         int64_t* __restrict__ counters, const int* __restrict__ slowFlag) {
+    static_assert(MODE == BBDUK_MODE_KTRIM_R || MODE == BBDUK_MODE_KFILTER, "first-hit scans only");
+    wave_body<MODE, SHORT, FORBIDN, false, FMT, false, 3>(P, bases, offsets, n, totalBases, paired, outA, outId, outFlags, counters, slowFlag);
+}
+
+template <int MODE, bool SHORT>
+static batch_kernel_t pick(bool forbidN, bool packed) {
+    if (packed) return forbidN ? bbduk_stream_kernel<MODE, SHORT, true, 1> : bbduk_stream_kernel<MODE, SHORT, false, 1>;
+    return forbidN ? bbduk_stream_kernel<MODE, SHORT, true, 0> : bbduk_stream_kernel<MODE, SHORT, false, 0>;
+}
+batch_kernel_t bbduk_pick_stream(int mode, bool useShort, bool forbidN, bool packed) {
+    if (mode == BBDUK_MODE_KFILTER) return pick<BBDUK_MODE_KFILTER, false>(forbidN, packed);
+    return useShort ? pick<BBDUK_MODE_KTRIM_R, true>(forbidN, packed) : pick<BBDUK_MODE_KTRIM_R, false>(forbidN, packed);
+}

@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--c4-ref-bases", type=float, default=1e10, help="reference size of BASELINE configs[3] in `configs` (0 = skip; 1e10 needs ~245 GB of HBM)")
     ap.add_argument("--dry-run-share-gpu", action="store_true", help="N>1 control-flow rehearsal on one GPU (gloo; not a measurement)")
     ap.add_argument("--insert-range", default=None, help="experiments: 'min,max' insert size of the synthetic pairs")
+    ap.add_argument("--pair-scan", action="store_true", help="experiments: the pair-scan kernel of rounds 1-2 instead of bbduk_stream_kernel (BBDUK_HOOK_PAIR_SCAN)")
     ap.add_argument("--lib", default=None, help="experiments: bind to another build of the library (bbtools_amd/<name>.so)")
     a = ap.parse_args()
 
@@ -182,7 +183,7 @@ def main():
 
     n_pairs = a.reads // 2
     n = 2 * n_pairs
-    duk = B.BBDuk(ARGS_C2, device=dev)
+    duk = B.BBDuk(ARGS_C2, device=dev, hooks={B.HOOK_PAIR_SCAN: 1} if a.pair_scan else None)
     if distributed and not a.dry_run_share_gpu:       # the RCCL communicator behind the C ABI: rank 0's id goes to every rank
         box = [B.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)

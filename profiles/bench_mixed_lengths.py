@@ -9,7 +9,7 @@ from bbtools_amd import bbduk as B
 
 n = 4_000_000
 L = 151
-duk = B.BBDuk("ktrim=r k=23 mink=11 hdist=1 ref=adapters")
+duk = B.BBDuk("ktrim=r k=23 mink=11 hdist=1 ref=adapters", hooks={B.HOOK_PAIR_SCAN: 1} if "--pair-scan" in sys.argv else None)
 st = torch.cuda.current_stream().cuda_stream
 src = torch.empty(n * L, dtype=torch.uint8, device="cuda"); soff = torch.empty(n + 1, dtype=torch.int64, device="cuda")
 B.synth_generate_device(B.synth_params(2, read_len=L, ins_min=L // 3, ins_max=L * 7 // 3), 0, n // 2, src, soff, 0)

@@ -5,11 +5,11 @@ import argparse, json, os, sys
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 
 
-def run(args="ktrim=r k=23 mink=11 hdist=1 ref=adapters", lens=(100, 150, 151, 250, 300), bases=3e9):
+def run(args="ktrim=r k=23 mink=11 hdist=1 ref=adapters", lens=(100, 150, 151, 250, 300), bases=3e9, hooks=None):
     """-> one dict per read length (bench.py's `read_lengths` block calls this too)"""
     import torch
     from bbtools_amd import bbduk as B
-    duk = B.BBDuk(args)
+    duk = B.BBDuk(args, hooks=hooks)
     st = torch.cuda.current_stream().cuda_stream
     out = []
     for L in lens:
@@ -31,14 +31,15 @@ def run(args="ktrim=r k=23 mink=11 hdist=1 ref=adapters", lens=(100, 150, 151, 2
 
 
 def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("--lib", default=None); ap.add_argument("--bases", type=float, default=3e9)
+    ap = argparse.ArgumentParser(); ap.add_argument("--lib", default=None); ap.add_argument("--bases", type=float, default=3e9); ap.add_argument("--pair-scan", action="store_true")
     ap.add_argument("--args", default="ktrim=r k=23 mink=11 hdist=1 ref=adapters")
     ap.add_argument("lens", nargs="*", type=int, default=[100, 150, 151, 250, 300])
     a = ap.parse_args()
     if a.lib:
         from bbtools_amd import bbduk as B
         B.use_library(a.lib)
-    for r in run(a.args, a.lens, a.bases):
+    from bbtools_amd import bbduk as B_
+    for r in run(a.args, a.lens, a.bases, {B_.HOOK_PAIR_SCAN: 1} if a.pair_scan else None):
         print(json.dumps(r))
 
 

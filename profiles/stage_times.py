@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Stage deletion on the configs[1] launch: kernel ms per timing mask (a -DBBDUK_TIMING_SWITCHES build: bbtools_amd/ab_tsw.so, made by
+bbtools_amd._build.build_timing_variant()).  Results of a masked run are wrong by construction; only the time is read.
+Bits: 3 no main scan, 4 no short k-mers, 5 no staging loads, 7 no decide stage; stream kernel: 10 no resolve of flagged blocks, 11 no
+candidate verification, 13 no fingerprint gathers (tag words faked from the hash), 14 no presence-filter reads.
+usage: python profiles/stage_times.py [--reads N] [--read-len L] [--pair-scan] mask [mask ...]"""
+import argparse, json, os, sys
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+import torch
+from bbtools_amd import bbduk as B
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--reads", type=int, default=20_000_000); ap.add_argument("--read-len", type=int, default=150)
+ap.add_argument("--pair-scan", action="store_true"); ap.add_argument("--lib", default="ab_tsw")
+ap.add_argument("--args", default="ktrim=r k=23 mink=11 hdist=1 ref=adapters")
+ap.add_argument("masks", nargs="*", default=["0"])
+a = ap.parse_args()
+B.use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bbtools_amd", a.lib + ".so"))
+n, L = a.reads & ~1, a.read_len
+d_bases = torch.empty(n * L, dtype=torch.uint8, device="cuda"); d_off = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+B.synth_generate_device(B.synth_params(2, read_len=L, ins_min=L // 3, ins_max=L * 7 // 3), 0, n // 2, d_bases, d_off, 0)
+d_a = torch.empty(n, dtype=torch.int32, device="cuda"); d_id = torch.empty_like(d_a); d_fl = torch.empty(n, dtype=torch.uint8, device="cuda")
+st = torch.cuda.current_stream().cuda_stream
+for m in a.masks:
+    bits = sum(1 << int(b) for b in m.split("+")) if m != "0" else 0
+    hooks = {B.HOOK_TIMING_MASK: bits} if bits else {}          # (mask 0 also runs on the product build)
+    if a.pair_scan:
+        hooks[B.HOOK_PAIR_SCAN] = 1
+    duk = B.BBDuk(a.args, hooks=hooks)
+    d_c = torch.zeros(duk.gpu.counters_len, dtype=torch.int64, device="cuda")
+    for _ in range(5):
+        d_c.zero_(); duk.gpu.process_batch_device(d_bases, d_off, True, d_a, d_id, d_fl, d_c, st)
+    torch.cuda.synchronize()
+    ms = duk.gpu.kernel_time_ms(4)
+    print(json.dumps({"bits": m, "mask": bits, "pair_scan": a.pair_scan, "reads": n, "read_len": L, "kernel_ms": round(ms, 3), "Gbases_per_s": round(n * L / ms / 1e6, 1)}), flush=True)
+    duk.close()
