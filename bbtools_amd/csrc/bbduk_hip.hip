@@ -352,12 +352,12 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
         if (nlines >= (1ULL << 29)) return bail(BBDUK_ERR_ARG, "too many keys for the 32-bit tag word index");
         if (hipMalloc(&h->d_bigTags, nlines * 64) != hipSuccess || hipMalloc(&h->d_bigKeys, nlines * 256) != hipSuccess ||
             hipMalloc(&h->d_bigIds, nlines * 32 * (size_t)idBytes) != hipSuccess ||
-            hipMalloc(&h->d_tags, snb * 8) != hipSuccess || hipMalloc(&h->d_bkv, 4 * snb * sizeof(uint4)) != hipSuccess) return bail(BBDUK_ERR_NOMEM, "hipMalloc (map)");
+            hipMalloc(&h->d_tags, (snb + 1) * 8) != hipSuccess || hipMalloc(&h->d_bkv, 4 * snb * sizeof(uint4)) != hipSuccess) return bail(BBDUK_ERR_NOMEM, "hipMalloc (map)");
         h->big = true; h->bigLines = (uint32_t)nlines; h->bigIdBytes = idBytes; h->nbuckets = snb; h->bucketBits = sbits;
         hipMemsetAsync(h->d_bigTags, 0, nlines * 64, h->stream);
         hipMemsetAsync(h->d_bigKeys, 0xFF, nlines * 256, h->stream);
         hipMemsetAsync(h->d_bigIds, 0xFF, nlines * 32 * (size_t)idBytes, h->stream);
-        hipMemsetAsync(h->d_tags, 0, snb * 8, h->stream);
+        hipMemsetAsync(h->d_tags, 0, (snb + 1) * 8, h->stream);      // (+ the dummy word behind the last bucket: see StreamProbe)
         hipMemsetAsync(h->d_bkv, 0xFF, 4 * snb * sizeof(uint4), h->stream);
     } else {
         uint64_t cslots = 1024; while ((double)cslots < 2.0 * maxKeys + 16.0) cslots <<= 1;      // a power of two, load <= 0.5
@@ -422,9 +422,9 @@ static int build_end_impl(bbduk_handle* h) {
         int lb = 0;
         if (distinct > 0 && distinct <= (1ULL << 22)) lb = std::min(MAX_LDS_BITS, std::max(10, ceil_log2(32ULL * distinct)));
         if (h->hookLdsBits >= 0) lb = h->hookLdsBits == 0 ? 0 : std::min(MAX_LDS_BITS, std::max(10, h->hookLdsBits));   // bbduk_test_hook
-        if (hipMalloc(&h->d_tags, nb * sizeof(uint64_t)) != hipSuccess || hipMalloc(&h->d_bkv, 4 * nb * sizeof(uint4)) != hipSuccess ||
+        if (hipMalloc(&h->d_tags, (nb + 1) * sizeof(uint64_t)) != hipSuccess || hipMalloc(&h->d_bkv, 4 * nb * sizeof(uint4)) != hipSuccess ||
             (lb && hipMalloc(&h->d_ldsImage, ((size_t)1 << (lb - 5)) * 4) != hipSuccess)) return bail(BBDUK_ERR_NOMEM, "hipMalloc (map)");
-        hipMemsetAsync(h->d_tags, 0, nb * sizeof(uint64_t), h->stream);
+        hipMemsetAsync(h->d_tags, 0, (nb + 1) * sizeof(uint64_t), h->stream);      // (+ the dummy word behind the last bucket: always zero, see StreamProbe)
         hipMemsetAsync(h->d_bkv, 0xFF, 4 * nb * sizeof(uint4), h->stream);
         if (lb) hipMemsetAsync(h->d_ldsImage, 0, ((size_t)1 << (lb - 5)) * 4, h->stream);
         const int grid = (int)std::min<uint64_t>((st->cslots + 255) / 256, (uint64_t)h->numCU * 32);
