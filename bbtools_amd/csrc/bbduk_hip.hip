@@ -716,7 +716,7 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     const bool firstHit = K.mode == BBDUK_MODE_KTRIM_R || (K.mode == BBDUK_MODE_KFILTER && K.maxBadKmers == 0 && K.mkf == 0.f && K.mcf == 0.f);
     // the specialised first-hit scans run as bbduk_stream_kernel (one body for every read length, bbduk_stream_scan.inc); the pair-scan
     // kernel and its shape bodies keep the GENERAL family (and serve a handle with BBDUK_HOOK_PAIR_SCAN set)
-    if (firstHit && !K.big && !kparams_general(K) && !h->hookPairScan) { kp.wave = bbduk_pick_stream(K.mode, K.useShort != 0, K.forbidNs != 0, packed); kp.shape = nullptr; }
+    if (firstHit && !K.big && K.bucketBits <= 28 && !kparams_general(K) && !h->hookPairScan) { kp.wave = bbduk_pick_stream(K.mode, K.useShort != 0, K.forbidNs != 0, packed); kp.shape = nullptr; }
     const bool tailForm = kp.shape && !K.big && K.qhdist == 0 && K.qskip < 2 && firstHit;
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)waveLds));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.tile), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
