@@ -130,7 +130,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU (pairs = reads/2)")
+    ap.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU (pairs = reads/2): weak scaling, the default")
+    ap.add_argument("--total-reads", type=int, default=0, help="strong scaling instead: this many reads in all, sharded over the GPUs in contiguous "
+                    "blocks of whole pairs (BASELINE configs[4]: --gpus 8 --total-reads 1000000000 = 125 M reads per GPU)")
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -181,7 +183,12 @@ def main():
     if torch.cuda.device_count() <= dev:
         raise SystemExit("bench.py: rank %d needs GPU %d but only %d visible" % (rank, dev, torch.cuda.device_count()))
 
-    n_pairs = a.reads // 2
+    strong = a.total_reads > 0
+    if strong:                                       # configs[4]'s shape: the read set is fixed, every rank takes its contiguous block of pairs
+        lo, hi = D.shard_pairs(a.total_reads // 2, rank, world)
+        n_pairs = hi - lo
+    else:
+        n_pairs = a.reads // 2
     n = 2 * n_pairs
     duk = B.BBDuk(ARGS_C2, device=dev, hooks={B.HOOK_PAIR_SCAN: 1} if a.pair_scan else None)
     if distributed and not a.dry_run_share_gpu:       # the RCCL communicator behind the C ABI: rank 0's id goes to every rank
@@ -193,7 +200,8 @@ def main():
         lo_, hi_ = a.insert_range.split(",")
         sp_kw = dict(ins_min=int(lo_), ins_max=int(hi_))
     sp = B.synth_params(a.seed, **sp_kw)
-    lo, hi = D.weak_shard(n_pairs, rank)
+    if not strong:
+        lo, hi = D.weak_shard(n_pairs, rank)
 
     d_bases = torch.empty(n * READ_LEN, dtype=torch.uint8, device="cuda")
     d_off = torch.empty(n + 1, dtype=torch.int64, device="cuda")
@@ -250,18 +258,27 @@ def main():
 
     ctr = totals.cpu().numpy()
     status = int(d_ctr[B.NCOUNTERS - 1].item())
-    total_bases = float(n) * READ_LEN * world
+    if distributed:                                  # strong scaling: the shards differ by a pair at most, but count what was really done
+        t = torch.tensor([float(n)], dtype=torch.float64, device="cpu" if a.dry_run_share_gpu else "cuda")
+        dist.all_reduce(t)
+        total_reads = float(t.item())
+    else:
+        total_reads = float(n)
+    total_bases = total_reads * READ_LEN
     gbases = total_bases * a.steps / dt / 1e9
     out = {
         "metric": "Gbases/s BBDuk k=23 ktrim on 2x150bp synthetic FASTQ",
         "value": round(gbases, 3), "unit": "Gbases/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "int64", "data": "synthetic",
         "config": {"workload": "BBDuk ktrim=r k=23 mink=11 hdist=1 ref=adapters, %d synthetic 2x150bp reads per GPU "
                                "(configs[1]), device-resident batch%s" % (n, ", packed 2-bit boundary format" if packed else ""),
                    "args": ARGS_C2, "reads_per_gpu": n, "read_len": READ_LEN, "seed": a.seed,
                    "table_keys": int(duk.stored_kmers), "table_bytes": int(duk.gpu.table_bytes),
-                   "parallelism": "reads sharded x%d, table replicated, 1 counter all-reduce/step (RCCL via bbduk_allreduce_counters_device)" % world},
+                   "total_reads": int(total_reads),
+                   "parallelism": ("reads sharded x%d (%s), table replicated, 1 counter all-reduce/step (RCCL via bbduk_allreduce_counters_device)"
+                                   % (world, "contiguous blocks of a fixed read set" if strong else "every rank its own %d reads" % n)) if world > 1
+                                  else "1 GPU: no collective in the step"},
         "counters": {k: int(v) for k, v in zip(B.COUNTER_NAMES, ctr[:10])},
         **({"dry_run": "all ranks share GPU 0, counters summed by gloo: control-flow rehearsal, not a measurement"} if a.dry_run_share_gpu else {}),
         "device_status": status,
@@ -279,12 +296,18 @@ def main():
             traffic, traffic_src = int(pt["traffic_bytes"]), pt["source"]
     except Exception:
         pass
-    out["roofline"] = {"bound": "hbm", "kernel": "bbduk_wave_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+    issue = None                                     # what paces the kernel, from the committed counter pass of this workload (profiles/r03_pmc.sh)
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_issue.json")) as fh:
+            issue = json.load(fh)
+    except Exception:
+        pass
+    out["roofline"] = {"bound": "hbm", "kernel": "bbduk_wave_kernel" if a.pair_scan else "bbduk_stream_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                        "kernel_ms": round(kern_ms, 3), "launch_ms": round(launch_ms, 3), "algorithmic_bytes_per_launch": int(algo_bytes),
-                       # the contract prices this path against HBM; what actually paces the kernel is instruction issue
-                       # (131 VALU + 70 SALU wave-instructions per read at ~4.4 / ~2.6 SIMD cycles each)
-                       "limiter": "instruction issue, not HBM: 133 VALU + 71 SALU per read (profiles/r02_final_summary.txt)"}
+                       # the contract prices this path against HBM; what paces the kernel is instruction issue: the
+                       # measured wave-instructions per read, echoed from the committed counter pass (null if none is committed)
+                       "issue_counters": issue}
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
@@ -307,6 +330,15 @@ def main():
                                    "kind": "port", "sample": "first %d reads of the same synthetic workload, %.1f s, "
                                    "oracle/bbduk_oracle.c with %d pthreads (match only, no I/O)" % (m, cpu_dt, cores)}
             out["parity_sample_ok"] = ok
+            scal = {}                                 # the same port at fewer threads, ~2 s each: what one host core does
+            for th in sorted({1, 16, 64, cores}):
+                if th > cores:
+                    continue
+                pairs_t = int(max(2_000, min(sample_pairs, 100_000 * (2.0 / max(probe, 1e-3)) * th / cores)))
+                o.reset_counters()
+                t = time.perf_counter(); o.process_batch(hb[:2 * pairs_t * READ_LEN], hoff[:2 * pairs_t + 1], True, nthreads=th); dt_t = time.perf_counter() - t
+                scal[str(th)] = round(2 * pairs_t * READ_LEN / dt_t / 1e9, 4)
+            out["cpu_baseline"]["threads_scaling"] = scal
         except Exception as e:                        # the bench line must not depend on the checker building / running
             out["cpu_baseline"] = {"value": None, "unit": "Gbases/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
     if rank == 0 and world == 1 and not a.no_extras:

@@ -68,6 +68,11 @@ int64_t bbo_rcomp(int64_t kmer, int k) {
 #define NOT_PRESENT   (-1)
 #define HASH_COLLISION (-2)
 #define HA_EXTRA 60                         /* kmer/HashArray.java:687 */
+/* Test knob (bbo_test_set_probe_window): the probe window actually walked, <= HA_EXTRA.  The reference's is 60, which real reference
+ * sets never fill, so its victim path (HashForest) would go untested; with a window of 2 the SAME code sends a few per cent of the
+ * keys there.  The arrays keep their prime + 60 cells either way. */
+static int g_probe_window = HA_EXTRA;
+void bbo_test_set_probe_window(int n) { g_probe_window = n < 1 ? 1 : (n > HA_EXTRA ? HA_EXTRA : n); }
 #define HA_MAX_LOAD 0.88f                   /* :695 */
 #define HA_MIN_LOAD 0.58f                   /* :693 */
 #define HA_RESIZE_MULT 2.0f                 /* :691 */
@@ -114,7 +119,7 @@ static inline int ha_kmer_to_cell(const hash_array* h, int64_t kmer) { return (i
 /* kmer/HashArray.java:434-447 findKmer */
 static int ha_find_kmer(const hash_array* h, int64_t kmer) {
     int cell = ha_kmer_to_cell(h, kmer);
-    for (const int max = cell + HA_EXTRA; cell < max; cell++) {
+    for (const int max = cell + g_probe_window; cell < max; cell++) {
         const int64_t n = h->array[cell];
         if (n == kmer) return cell;
         else if (n == NOT_PRESENT) return NOT_PRESENT;
@@ -169,7 +174,7 @@ static void ha_resize(hash_array* h) {
 /* kmer/HashArray.java:221-239 setIfNotPresent: first writer wins */
 static int ha_set_if_not_present(hash_array* h, int64_t kmer, int value) {
     int cell = ha_kmer_to_cell(h, kmer);
-    for (const int max = cell + HA_EXTRA; cell < max; cell++) {
+    for (const int max = cell + g_probe_window; cell < max; cell++) {
         int64_t n = h->array[cell];
         if (n == kmer) return 0;
         else if (n == NOT_PRESENT) {

@@ -93,6 +93,8 @@ int      bbo_num_scaffolds(const bbo_ctx* c);            /* scaffoldNames.size()
 int64_t  bbo_stored_kmers(const bbo_ctx* c);
 
 /* Table access. */
+/* tests only: walk a shorter probe window than the reference's 60 cells (process-wide; set before loading references) */
+void     bbo_test_set_probe_window(int n);
 int      bbo_table_get(const bbo_ctx* c, int64_t key);   /* AbstractKmerTable.getValue: -1 if absent */
 /* Image of one HashArray1D way, the arrays a JVM caller would hand to bbduk_upload_table_way():
  * array() (kmer/HashArray.java:672), values() (kmer/HashArray1D.java:407), victims().toList(). */

@@ -50,6 +50,8 @@ def lib():
         L.bbo_stored_kmers.restype = C.c_int64
         L.bbo_stored_kmers.argtypes = [C.c_void_p]
         L.bbo_table_get.argtypes = [C.c_void_p, C.c_int64]
+        L.bbo_test_set_probe_window.argtypes = [C.c_int]
+        L.bbo_test_set_probe_window.restype = None
         L.bbo_num_ways.argtypes = [C.c_void_p]
         L.bbo_way_image.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64),
                                     C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
@@ -85,6 +87,11 @@ def make_args(**kw) -> BboArgs:
             raise KeyError(k)
         setattr(a, k, v)
     return a
+
+
+def set_probe_window(n: int = 60):
+    """Tests only: the HashArray1D probe window of oracles created from now on (reference: 60, kmer/HashArray.java:687)."""
+    lib().bbo_test_set_probe_window(n)
 
 
 class Oracle:

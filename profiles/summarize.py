@@ -30,7 +30,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcc"):
                 agg[r.get("Kernel_Name", "")][r.get("Counter_Name", "")].append(float(r.get("Counter_Value", 0)))
     print("== %s (per-dispatch mean)" % sub)
     for k, cs in agg.items():
-        if "bbduk_wave" not in k and "bbduk_span" not in k:
+        if "bbduk_wave" not in k and "bbduk_stream" not in k and "bbduk_span" not in k:
             continue
         for c, vals in cs.items():
             print("  %-50s %-24s n=%d mean=%.6g" % (k[:50], c, len(vals), sum(vals) / len(vals)))

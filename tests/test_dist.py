@@ -92,6 +92,8 @@ def test_two_shards_through_the_hip_path_and_the_abi_allreduce():
     gpus = [d.gpu for d in duks]
     B.comm_create_local(gpus)
     assert gpus[0].comm_size == len(set(devices))
+    if torch.cuda.device_count() >= 2:                 # a multi-GPU lease: the device leaders went through RCCL, not just the same-device sum
+        assert gpus[0].comm_size >= 2
     B.allreduce_counters_local(gpus)
     for g in gpus:
         assert np.array_equal(g.counters(), want)
@@ -127,3 +129,45 @@ def test_multi_process_form_of_the_communicator_world1():
     with pytest.raises(B.BBDukError):
         d.gpu.comm_create(1, 0, uid)                   # one communicator per handle
     d.close()
+
+
+def _rccl_worker(rank, world, uid, n_pairs, q):
+    import torch
+    torch.cuda.set_device(rank)
+    args, okw, ref = util.CONFIGS["c2"]
+    d = B.BBDuk(args, device=rank)
+    d.gpu.comm_create(world, rank, uid)
+    lo, hi = D.shard_pairs(n_pairs, rank, world)
+    b, off = B.synth_generate_host(B.synth_params(2), lo, hi - lo)
+    d.gpu.process_batch(b, off, True)
+    d.gpu.allreduce_counters()                         # ncclAllReduce(int64, sum) over xGMI behind the C ABI
+    q.put((rank, d.gpu.comm_size, d.gpu.counters().tolist()))
+    d.close()
+
+
+@pytest.mark.gpu
+def test_two_rank_communicator_over_rccl():
+    """One process per GPU, the form bench.py --gpus N runs (BASELINE configs[4]): two ranks on two DEVICES form the communicator
+    from rank 0's id, each processes its contiguous block of pairs, and the library's all-reduce leaves both with the counters of
+    the whole read set (= the oracle's).  Skipped on a 1-GPU box: the first multi-GPU lease exercises RCCL without a code change."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from oracle.oracle_ffi import Oracle
+    args, okw, ref = util.CONFIGS["c2"]
+    n_pairs = 20001
+    uid = B.comm_unique_id()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, uid, n_pairs, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    o = Oracle(**okw); o.load_fasta(ref)
+    b, off = B.synth_generate_host(B.synth_params(2), 0, n_pairs)
+    o.process_batch(b, off, True, nthreads=8)
+    for rank, size, counters in got:
+        assert size == 2 and counters == o.counters().tolist()

@@ -92,6 +92,40 @@ def test_table_lookup_and_way_images():
         g1.finalize_table()                      # read-only after finalize
 
 
+def test_way_images_with_victims():
+    """SURVEY a9 on the boundary: HashArray1D images whose victim lists are NOT empty (the restatement walks a probe window of 2 cells
+    instead of 60, see tests/test_oracle.py) go through bbduk_upload_table_way; the device map has to hold every key of the arrays and
+    of the victim lists with its id (HashForest.getValue semantics, kmer/HashForest.java:229-233), and a batch through it has to give
+    what the plain oracle gives."""
+    from oracle import oracle_ffi as O
+    args, okw, ref = util.CONFIGS["c2"]
+    plain = Oracle(**okw); plain.load_fasta(ref)
+    h = B.HostIndex(args); h.load_refs(); h.build_index()
+    O.set_probe_window(2)
+    try:
+        o = Oracle(**okw); o.load_fasta(ref)
+        images = o.way_images()
+        assert sum(len(w[3]) for w in images) > 1000
+        g = B.BBDukGpu(h.params(0))
+        for w, (prime, keys, vals, vk, vv) in enumerate(images):
+            g.upload_table_way(w, prime, keys, vals, vk, vv)
+        g.finalize_table()
+        ks, vs = o.dump_pairs()
+        assert g.table_size == len(ks) == plain.stored_kmers
+        vk = np.concatenate([w[3] for w in images]); vv = np.concatenate([w[4] for w in images])
+        assert np.array_equal(g.table_lookup(vk), vv)                    # the victims, each with its id
+        rng = np.random.default_rng(5)
+        probe = np.concatenate([ks, rng.integers(0, 1 << 47, 20000, dtype=np.int64)])
+        assert np.array_equal(g.table_lookup(probe), np.array([o.table_get(int(x)) for x in probe], np.int32))
+    finally:
+        O.set_probe_window(60)
+    b, off = B.synth_generate_host(B.synth_params(4), 0, 10000)
+    ga, gi, gf = g.process_batch(b, off, True)
+    oa, oi, of = plain.process_batch(b, off, True, nthreads=4)
+    assert np.array_equal(ga, oa) and np.array_equal(gi, oi) and np.array_equal(gf, of)
+    assert np.array_equal(g.counters(), plain.counters())
+
+
 # ---- seeded synthetic inputs, the BASELINE configs at oracle-sized n
 @pytest.mark.parametrize("cfg", list(util.CONFIGS))
 def test_synthetic_config_parity(cfg):

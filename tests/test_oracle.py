@@ -326,3 +326,28 @@ def test_way_images_cover_the_map():
     for key in ks[:200].tolist():
         assert o.table_get(key) == seen[key]
     assert o.table_get(12345) == -1
+
+
+def test_victim_path_of_the_hash_array_holds_the_same_map():
+    """SURVEY a9: HashArray1D hands keys whose probe window is full to its victim forest (kmer/HashArray.java:221-239, 434-447;
+    kmer/HashForest.java:229-233).  The reference's window of 60 cells is never full for real reference sets, so the restatement walks
+    a window of 2 here: a few per cent of the keys become victims, and the map -- every key, every id -- has to stay what it was."""
+    from oracle import oracle_ffi as O
+    args, okw, ref = util.CONFIGS["c2"]
+    plain = Oracle(**okw); plain.load_fasta(ref)
+    assert sum(len(w[3]) for w in plain.way_images()) == 0
+    O.set_probe_window(2)
+    try:
+        o = Oracle(**okw); o.load_fasta(ref)
+        images = o.way_images()
+        nv = sum(len(w[3]) for w in images)
+        assert nv > 1000 and o.stored_kmers == plain.stored_kmers
+        k0, v0 = plain.dump_pairs(); k1, v1 = o.dump_pairs()
+        a, b = np.argsort(k0), np.argsort(k1)
+        assert np.array_equal(k0[a], k1[b]) and np.array_equal(v0[a], v1[b])
+        vk = np.concatenate([w[3] for w in images]); vv = np.concatenate([w[4] for w in images])
+        for key, val in list(zip(vk.tolist(), vv.tolist()))[:500]:      # a victim is found through the forest, with its id
+            assert o.table_get(key) == val
+    finally:
+        O.set_probe_window(60)
+
