@@ -135,7 +135,12 @@ __global__ void bbduk_synth_kernel(const bb_synth_dev sp, const int64_t firstPai
 
 
 extern "C" int bbduk_abi_version(void) { return BBDUK_ABI_VERSION; }
-extern "C" const char* bbduk_last_error(const bbduk_handle* h) { return h ? h->err.c_str() : "null handle"; }
+extern "C" const char* bbduk_last_error(const bbduk_handle* h) {
+    if (!h) return "null handle";
+    static thread_local std::string copy;                         // (the caller's own copy: another thread may fail meanwhile)
+    { std::lock_guard<std::mutex> lg(const_cast<bbduk_handle*>(h)->errMu); copy = h->err; }
+    return copy.c_str();
+}
 
 extern "C" int bbduk_create(const bbduk_params* p, bbduk_handle** out) {
     if (!p || !out) return BBDUK_ERR_ARG;
@@ -212,7 +217,7 @@ extern "C" int bbduk_destroy(bbduk_handle* h) {
     hipSetDevice(h->p.device);
     build_release(h);
     hipFree(h->d_bigTags); hipFree(h->d_bigKeys); hipFree(h->d_bigIds);
-    for (auto& q : h->slot) { hipFree(q.d_bases); hipFree(q.d_undef); hipFree(q.d_off); hipFree(q.d_a); hipFree(q.d_id); hipFree(q.d_fl); if (q.stream) hipStreamDestroy(q.stream); }
+    for (auto& q : h->slot) { hipFree(q.d_bases); hipFree(q.d_undef); hipFree(q.d_off); hipFree(q.d_a); hipFree(q.d_id); hipFree(q.d_fl); hipFree(q.d_status); if (q.stream) hipStreamDestroy(q.stream); }
     hipFree(h->d_tags); hipFree(h->d_bkv);
     hipFree(h->d_ldsImage); hipFree(h->d_slowFlag);
     for (int q = 0; q < bbduk_handle::EV_RING; q++) { if (h->ev0[q]) hipEventDestroy(h->ev0[q]); if (h->ev1[q]) hipEventDestroy(h->ev1[q]); }
@@ -624,9 +629,10 @@ struct MatchOut { int32_t* n; int32_t* ids; int32_t* counts; int32_t cap; };    
 // kbig / findBestMatch (through the kfilter operators) and ksplit: bbduk_kscan_kernel
 static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d_offsets, int64_t n, int64_t total_bases, int32_t paired,
                         int32_t* d_a, int32_t* d_id, uint8_t* d_fl, int32_t* d_left, int32_t* d_right, int64_t* d_counters, hipStream_t st,
-                        const uint32_t* d_undef, bool packed, const MatchOut* mo = nullptr) {
+                        const uint32_t* d_undef, bool packed, const MatchOut* mo = nullptr, int64_t* d_status = nullptr) {
     KParams K = make_kparams(h);
     K.undef = packed ? d_undef : nullptr;
+    K.status = reinterpret_cast<unsigned long long*>(d_status);
     if (mo) { K.matchN = mo->n; K.matchIds = mo->ids; K.matchCnt = mo->counts; K.matchCap = mo->cap; }
     const int red = h->p.mode == BBDUK_MODE_KSPLIT ? RED_SPLIT : (K.fbm ? RED_BEST : RED_BIG);
     typedef void (*kscan_t)(const KParams, const uint8_t*, const int64_t*, const int64_t, const int64_t, const int,
@@ -689,7 +695,8 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
 
 static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases, const int64_t* d_offsets, int64_t n,
                         int64_t total_bases, int32_t paired, int32_t* d_a, int32_t* d_id, uint8_t* d_fl,
-                        int64_t* d_counters, hipStream_t st, const uint32_t* d_undef = nullptr, bool packed = false, const MatchOut* mo = nullptr) {
+                        int64_t* d_counters, hipStream_t st, const uint32_t* d_undef = nullptr, bool packed = false, const MatchOut* mo = nullptr,
+                        int64_t* d_status = nullptr) {
     if (!h) return BBDUK_ERR_ARG;
     if (!h->finalized) return fail(h, BBDUK_ERR_STATE, "table not finalized");
     if (mo && !h->p.findBestMatch) return fail(h, BBDUK_ERR_STATE, "match lists need findBestMatch (rename / fbm) in the parameters given to bbduk_create");
@@ -703,9 +710,10 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     if (packed && (!d_undef || ((uintptr_t)d_bases & 3) != 0)) return fail(h, BBDUK_ERR_ARG, "packed input needs both planes, 4-byte aligned");
     if ((h->p.kbig > h->p.k && !(h->p.minCoveredFraction > 0.f)) || h->p.findBestMatch)   // countSetKmersBig / findBestMatch behind the kfilter operators;
                                                                                 // with mcf the reference runs countCoveredBases on the 31-mers instead (:1038)
-        return launch_kscan(h, d_bases, d_offsets, n, total_bases, paired, d_a, d_id, d_fl, nullptr, nullptr, d_counters, st, d_undef, packed, mo);
+        return launch_kscan(h, d_bases, d_offsets, n, total_bases, paired, d_a, d_id, d_fl, nullptr, nullptr, d_counters, st, d_undef, packed, mo, d_status);
     KParams K = make_kparams(h);
     K.undef = packed ? d_undef : nullptr;
+    K.status = reinterpret_cast<unsigned long long*>(d_status);
     const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
     const size_t dynLds = h->ldsBits ? ((size_t)1 << (h->ldsBits - 3)) : 0;    // tile kernel: the filter only
     const size_t waveLds = dynLds + WAVE_LDS_BYTES;                             // wave kernel: filter + its per-wave state
@@ -846,6 +854,7 @@ static int host_batch(bbduk_handle* h, int wantKfilter, const uint8_t* bases, co
     }
     struct Release { bbduk_handle* h; bbduk_handle::Slot* S; ~Release() { { std::lock_guard<std::mutex> lk(h->slotMu); S->busy = false; } h->slotCv.notify_one(); } } rel{h, S};
     if (!S->stream) HIP_TRY(h, hipStreamCreateWithFlags(&S->stream, hipStreamNonBlocking));
+    if (!S->d_status) { HIP_TRY(h, hipMalloc(&S->d_status, sizeof(int64_t))); HIP_TRY(h, hipMemset(S->d_status, 0, sizeof(int64_t))); }
     // a capacity is recorded only once its buffers exist: a failed hipMalloc leaves the handle usable for a smaller batch
     if (undefBytes + 8 > S->cap_undef) {
         hipFree(S->d_undef); S->d_undef = nullptr; S->cap_undef = 0;
@@ -882,7 +891,7 @@ static int host_batch(bbduk_handle* h, int wantKfilter, const uint8_t* bases, co
             hipMemsetAsync(dm.ids, 0, lw, st) != hipSuccess || hipMemsetAsync(dm.counts, 0, lw, st) != hipSuccess) { release(); return fail(h, BBDUK_ERR_NOMEM, "hipMalloc (match lists)"); }
     }
     const int rc = launch_batch(h, wantKfilter, S->d_bases, S->d_off, n, total, paired, S->d_a, S->d_id, S->d_fl, h->d_counters, st,
-                                reinterpret_cast<const uint32_t*>(S->d_undef), packed, hostMatches ? &dm : nullptr);
+                                reinterpret_cast<const uint32_t*>(S->d_undef), packed, hostMatches ? &dm : nullptr, S->d_status);
     if (rc != BBDUK_OK) { release(); return rc; }
     if (hostMatches) {
         const size_t lw = (size_t)n * (size_t)dm.cap * sizeof(int32_t);
@@ -897,11 +906,11 @@ static int host_batch(bbduk_handle* h, int wantKfilter, const uint8_t* bases, co
     HIP_TRY(h, hipMemcpyAsync(out_id, S->d_id, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipMemcpyAsync(out_fl, S->d_fl, (size_t)n, hipMemcpyDeviceToHost, st));
     int64_t status = 0;
-    HIP_TRY(h, hipMemcpyAsync(&status, h->d_counters + BBDUK_CTR_STATUS, sizeof status, hipMemcpyDeviceToHost, st));
-    HIP_TRY(h, hipStreamSynchronize(st));
+    HIP_TRY(h, hipMemcpyAsync(&status, S->d_status, sizeof status, hipMemcpyDeviceToHost, st));      // this slot's own word: the other
+    HIP_TRY(h, hipStreamSynchronize(st));                                                             // submitter's errors are its own
     if (status != 0) {
         int64_t z = 0;
-        hipMemcpyAsync(h->d_counters + BBDUK_CTR_STATUS, &z, sizeof z, hipMemcpyHostToDevice, st);
+        hipMemcpyAsync(S->d_status, &z, sizeof z, hipMemcpyHostToDevice, st);
         hipStreamSynchronize(st);
         return fail(h, -(int)status, "device reported an error (a read longer than BBDUK_MAX_READ_LEN, or trimfailuresto1bp on a unit beyond the main kernel's planes)");
     }

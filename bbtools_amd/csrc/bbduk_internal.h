@@ -52,6 +52,8 @@ struct KParams {
     // presence filter in front of the map: one bit per hash slot, copied into LDS by every workgroup
     const uint32_t* ldsImage;   // HBM copy of the LDS bitmap (2^ldsBits bits); 0 bits = absent
     int32_t  ldsBits;
+    unsigned long long* status; // where a kernel reports a device-side error code; nullptr = counters[BBDUK_CTR_STATUS] (the *_device operators).
+                                // The host-buffer operators give every staging slot a word of its own: two submitting threads share the counters.
     int32_t  dbg;               // timing mask (bbduk_test_hook): timing experiments only (results become wrong); needs -DBBDUK_TIMING_SWITCHES
 };
 
@@ -59,7 +61,7 @@ struct bbduk_comm;                   // bbduk_comm.cpp: the RCCL communicator(s)
 
 struct bbduk_handle {
     bbduk_params p;
-    std::string err;
+    std::string err; std::mutex errMu;                           // (several submitters may fail at once: writes and bbduk_last_error copy under errMu)
     std::mutex mu;
     bool finalized = false;
     std::vector<int64_t> hkeys;          // staged (key,value) pairs before finalize
@@ -87,6 +89,7 @@ struct bbduk_handle {
         uint8_t* d_undef = nullptr; size_t cap_undef = 0;     // packed boundary: one undefined-base bit per base
         int64_t* d_off = nullptr;   size_t cap_reads = 0;
         int32_t* d_a = nullptr; int32_t* d_id = nullptr; uint8_t* d_fl = nullptr;
+        int64_t* d_status = nullptr;                             // this slot's device-side error word (see KParams::status)
         hipStream_t stream = nullptr; bool busy = false;
     };
     static const int NSLOTS = 2;
@@ -101,10 +104,10 @@ struct bbduk_handle {
 };
 
 #define HIP_TRY(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
-    (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return BBDUK_ERR_DEVICE; } } while (0)
+    { std::lock_guard<std::mutex> lg_(( h)->errMu); (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); } return BBDUK_ERR_DEVICE; } } while (0)
 
 int bbduk_comm_allreduce_i64(bbduk_handle* h, int64_t* d_buf, int64_t n, void* stream);   // bbduk_comm.hip
 
-static inline int fail(bbduk_handle* h, int code, const char* msg) { if (h) h->err = msg; return code; }
+static inline int fail(bbduk_handle* h, int code, const char* msg) { if (h) { std::lock_guard<std::mutex> lg(h->errMu); h->err = msg; } return code; }
 
 #endif
