@@ -1080,16 +1080,44 @@ def test_trimfailuresto1bp_parity(block):
 
 
 @pytest.mark.gpu
-def test_trimfailuresto1bp_refuses_units_beyond_the_main_kernel():
+@pytest.mark.parametrize("args,okw", [("k=21 ktrim=r trimfailures=t minlen=100 hdist=1", dict(k=21, ktrimRight=1, trimFailuresTo1bp=1, minReadLength=100, hdist=1)),
+                                      ("k=21 ktrim=l trimfailures=t minlen=60 tpe", dict(k=21, ktrimLeft=1, trimFailuresTo1bp=1, minReadLength=60, trimPairsEvenly=1)),
+                                      ("k=25 trimfailures=t hdist=1", dict(k=25, trimFailuresTo1bp=1, hdist=1)),
+                                      ("k=23 ktrim=r mink=11 trimfailures=t minlen=2000 tpe", dict(k=23, ktrimRight=1, mink=11, trimFailuresTo1bp=1, minReadLength=2000, trimPairsEvenly=1))])
+def test_trimfailuresto1bp_units_beyond_the_main_kernel(args, okw):
+    """trimfailuresto1bp on units the wave kernel cannot hold: a 5 kb pair sends the batch to the tiled kernel, a 45 kb read to the chunked
+    long-read kernel; both decide through record_stage, which cuts a failed read to its first base as BBDukProcessorS.java:1464-1488 does."""
+    rng = random.Random(77)
+    refs = [util.rand_seq(rng, 70) for _ in range(3)]
+    d, o = make_pair(args, okw, refs=refs)
+    def planted(n, where):
+        r = bytearray(util.rand_seq(rng, n)); piece = refs[rng.randrange(3)][5:45]
+        if where >= 0: r[where:where + len(piece)] = piece
+        return bytes(r)
+    for big in (5000, 45000):
+        reads = []
+        for i in range(60):
+            n = big if i in (6, 7, 20, 33) else rng.choice([30, 150, 151, 400])
+            reads.append(planted(n, rng.choice([-1, 0, 20, n // 2, max(0, n - 45)])))
+        check_batch(d, o, reads, True)
+        check_batch(d, o, reads[:31], False)
+        c = d.gpu.counters()
+        assert c[8] == 0 and c[9] == 0 and c[6] == c[0]                # nothing leaves through outm (:1431)
+    d.close()
+
+
+@pytest.mark.gpu
+def test_trimfailuresto1bp_other_modes_refuse_units_beyond_the_main_kernel():
+    """ktrim=n / ktrim=rl / ksplit / findbestmatch / k>31 serve trimfailuresto1bp on the main kernel only: a longer unit is reported, not answered wrongly."""
     rng = random.Random(5)
     refs = [util.rand_seq(rng, 60)]
-    d = B.BBDuk("k=21 ktrim=r trimfailures=t", refs=refs)
+    d = B.BBDuk("k=21 ktrim=n trimfailures=t", refs=refs)
     reads = [util.rand_seq(rng, 150), util.rand_seq(rng, 150), util.rand_seq(rng, 3000), util.rand_seq(rng, 100)]
     b, off = pack_reads(reads)
     with pytest.raises(B.BBDukError, match="trimfailuresto1bp"):
-        d.gpu.process_batch(b, off, True)
+        d.gpu.kmask_batch(b, off, True)
     b, off = pack_reads(reads[:2])
-    d.gpu.process_batch(b, off, True)                              # the handle stays usable
+    d.gpu.kmask_batch(b, off, True)                                # the handle stays usable
     d.close()
 
 
