@@ -35,7 +35,7 @@ def keys_of(windows, k=31, mm=True):
 def run(ref_bases=1e10, scaffold_bases=10_000_000, chunk_scaffolds=50, reads=20_000_000, steps=3, check_reads=50_000, oracle_bases=50_000_000):
     import types
     return _run(types.SimpleNamespace(ref_bases=ref_bases, scaffold_bases=scaffold_bases, chunk_scaffolds=chunk_scaffolds, reads=reads, steps=steps,
-                                      check_reads=check_reads, oracle_bases=oracle_bases))
+                                      check_reads=check_reads, oracle_bases=oracle_bases, pair_scan=False))
 
 
 def main():
@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--reads", type=int, default=20_000_000)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--check-reads", type=int, default=50_000)
+    ap.add_argument("--pair-scan", action="store_true", help="experiments: the pair-scan kernel of round 2 instead of the stream kernel")
     ap.add_argument("--oracle-bases", type=int, default=50_000_000, help="prefix of scaffold 1.. the contaminated reads are drawn from (and the oracle indexes)")
     a = ap.parse_args()
     print(json.dumps(_run(a)))
@@ -60,6 +61,8 @@ def _run(a):
     host = B.HostIndex("k=31 hdist=0")
     p = host.params(0); p.numScaffolds = n_scaf + 1
     gpu = B.BBDukGpu(p)
+    if getattr(a, "pair_scan", False):
+        gpu.test_hook(B.HOOK_PAIR_SCAN, 1)
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")
     t0 = time.perf_counter()
     gpu.build_begin(ref_bases, 0, 0)

@@ -6,7 +6,7 @@ set -u
 TAG=${1:-a}; REF=${2:-1e10}
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/c4pmc_$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python $ROOT/profiles/bench_c4_full.py --ref-bases $REF --check-reads 0 --steps 2"
+CMD="python $ROOT/profiles/bench_c4_full.py --ref-bases $REF --check-reads 0 --steps 2 ${3:-}"
 cd /tmp
 i=0
 for C in "TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_MISS_UNDER_MISS_sum TCP_UTCL1_STALL_UTCL2_REQ_OUT_OF_CREDITS_sum" \
@@ -17,7 +17,7 @@ for C in "TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_TRANSLAT
          "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INST_LEVEL_VMEM SQ_INSTS_BRANCH" \
          "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout 900 rocprofv3 --pmc $C --output-format csv -d $OUT/p$i -- $CMD > $OUT/p$i.json 2> $OUT/p$i.err
+  timeout 600 rocprofv3 --kernel-include-regex "bbduk_(wave|stream)_kernel" --pmc $C --output-format csv -d $OUT/p$i -- $CMD > $OUT/p$i.json 2> $OUT/p$i.err
 done
 cd $ROOT
 python - <<PY > $OUT/summary.txt
@@ -25,7 +25,7 @@ import csv,glob,collections
 agg=collections.defaultdict(list)
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "bbduk_wave_kernel" in r["Kernel_Name"]:
+        if "bbduk_wave_kernel" in r["Kernel_Name"] or "bbduk_stream_kernel" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 print("# bbduk_wave_kernel<KFILTER, .., BIG>, per launch (mean over the launches of a pass); reference $REF bases, 20 M reads per launch")
 for k in sorted(agg): print("%-46s n=%d mean=%.6g" % (k, len(agg[k]), sum(agg[k])/len(agg[k])))
