@@ -9,7 +9,7 @@ _SRC = [os.path.join(_HERE, "csrc", f) for f in ("bbduk_hip.hip", "bbduk_k_ktrim
                                                   "bbduk_k_modes_a.hip", "bbduk_k_modes_b.hip", "bbduk_stream.hip",
                                                   "bbduk_ingest.hip", "bbduk_comm.hip", "bbduk_host.cpp")]
 _DEPS = _SRC + [os.path.join(_HERE, "csrc", "synth.h"), os.path.join(_HERE, "csrc", "bbduk_internal.h"),
-                os.path.join(_HERE, "csrc", "bbduk_device.inc"), os.path.join(_HERE, "csrc", "bbduk_kernels.h"), os.path.join(_HERE, "csrc", "bbduk_stream_scan.inc"),
+                os.path.join(_HERE, "csrc", "bbduk_device.inc"), os.path.join(_HERE, "csrc", "bbduk_kernels.h"), os.path.join(_HERE, "csrc", "bbduk_stream_scan.inc"), os.path.join(_HERE, "csrc", "bbduk_seed.inc"),
                 os.path.join(_HERE, "csrc", "bbduk_seal.inc"), os.path.join(_HERE, "..", "include", "seal_gpu.h"),
                 os.path.join(_HERE, "..", "include", "bbduk_gpu.h"), os.path.join(_HERE, "..", "include", "bbduk_host.h")]
 _SO = os.path.join(_HERE, "libbbduk_hip.so")

@@ -86,7 +86,7 @@ static bool kparams_general(const KParams& K) {
 }
 static KernelPair pick_kernel(const KParams& K) {
     const bool general = kparams_general(K);
-    if (K.big) return bbduk_pick_kfilter_big(K.forbidNs != 0);        // HBM-resident layout (BASELINE configs[3]): see bbduk_k_kfilter.hip
+    if (K.big || K.seed) return bbduk_pick_kfilter_big(K.forbidNs != 0);        // HBM-resident layout (BASELINE configs[3]): see bbduk_k_kfilter.hip
     if (K.mode == BBDUK_MODE_KFILTER) return bbduk_pick_kfilter(general, K.forbidNs != 0);
     if (K.mode == BBDUK_MODE_KTRIM_L) return bbduk_pick_ktrim_l(general, K.useShort != 0, K.forbidNs != 0);
     return bbduk_pick_ktrim_r(general, K.useShort != 0, K.forbidNs != 0);
@@ -108,7 +108,7 @@ __global__ void bbduk_lookup_kernel(const KParams P, const int64_t* keys, int64_
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         const uint64_t key = (uint64_t)keys[i], v = strip_len(key);
-        out[i] = (keys[i] < 0) ? -1 : (P.big ? big_find(P, key, mix_a(v), mix_b(v)) : table_get(P, key));
+        out[i] = (keys[i] < 0) ? -1 : (P.seed ? seed_find_key(P, key) : (P.big ? big_find(P, key, mix_a(v), mix_b(v)) : table_get(P, key)));
     }
 }
 
@@ -200,6 +200,7 @@ extern "C" int bbduk_test_hook(bbduk_handle* h, int32_t which, int64_t value) {
     case BBDUK_HOOK_PAIR_SCAN:   h->hookPairScan = value != 0; return BBDUK_OK;
     case BBDUK_HOOK_BUCKET_BITS: if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookBucketBits = (int)value; return BBDUK_OK;
     case BBDUK_HOOK_LDS_BITS:    if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookLdsBits = (int)value; return BBDUK_OK;
+    case BBDUK_HOOK_SEED_LAYOUT: if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookSeedLayout = value != 0; return BBDUK_OK;
     case BBDUK_HOOK_BIG_LAYOUT:  if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookBigLayout = value != 0; return BBDUK_OK;
     case BBDUK_HOOK_TIMING_MASK:
 #ifdef BBDUK_TIMING_SWITCHES
@@ -265,6 +266,7 @@ extern "C" int bbduk_upload_table_way(bbduk_handle* h, int32_t way, int32_t prim
 // -- and two layouts, chosen by the expected key count: the cache-resident one (scratch set, then placement into buckets sized for
 // the distinct count, LDS filter) and the big one (in place).  BuildState lives from begin to end.
 struct BuildState {
+    bool seed = false;                   // the seed layout (bbduk_seed.inc): parents under their halves, inserted in place
     bool big = false; int hdist = 0, hdist2 = 0;
     uint64_t* d_sk = nullptr; int32_t* d_si = nullptr; uint64_t cslots = 0;     // scratch set of the two-pass build
     unsigned long long* d_cnt = nullptr;                                        // [0] distinct, [1] overflow flag
@@ -320,6 +322,20 @@ static bool params_general(const bbduk_params& p) {               // the same pr
 static bool big_layout_eligible(const bbduk_params& p) {
     return p.mode == BBDUK_MODE_KFILTER && !params_general(p) && !(p.kbig > p.k) && !p.findBestMatch;
 }
+// seed layout (bbduk_seed.inc): the two halves beside the (at most one) masked middle base, each <= 16 bases
+static bool seed_geometry(bbduk_handle* h) {
+    const int k = h->p.k;
+    if (k < 16 || k > 31) return false;
+    const uint64_t full = ~(~0ULL << (2 * k));
+    const uint64_t masked = ~(uint64_t)h->p.middleMask & full;
+    if (!masked) { h->seedHl = k / 2; h->seedHr = k - k / 2; }
+    else {
+        if (__builtin_popcountll(masked) != 2) return false;      // more than one masked base
+        const int base = k - 1 - __builtin_ctzll(masked) / 2;     // index of the masked base, 0 = the k-mer's first
+        h->seedHl = base; h->seedHr = k - 1 - base;
+    }
+    return h->seedHl >= 6 && h->seedHr >= 6 && h->seedHl <= 16 && h->seedHr <= 16;
+}
 #define BIG_LAYOUT_MIN_KEYS (1LL << 25)            // beyond ~3e7 keys the fingerprints alone outgrow L2 + Infinity Cache
 
 // expected number of keys (an upper bound is fine) -> layout, allocations
@@ -332,10 +348,25 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
     h->build = st; st->hdist = hdist; st->hdist2 = hdist2;
     // reference-side Hamming neighbourhoods put ~2/3 of a k-mer's 1+3k variants on one minimizer: such maps take plain lines
     if (hdist > 0) h->bigPlain = true;
-    st->big = (maxKeys > (double)BIG_LAYOUT_MIN_KEYS || h->hookBigLayout) && big_layout_eligible(h->p) && !h->sealTable && big_geometry(h);
+    // large hdist=1 maps of the plain first-hit kfilter: the seed layout stores the parents, not their 1+3k neighbours (bbduk_seed.inc)
+    st->seed = (maxKeys > (double)BIG_LAYOUT_MIN_KEYS || h->hookSeedLayout) && !h->hookBigLayout && hdist == 1 && big_layout_eligible(h->p) &&
+               h->p.maxBadKmers == 0 && !h->p.forbidNs && !h->sealTable && seed_geometry(h);
+    st->big = !st->seed && (maxKeys > (double)BIG_LAYOUT_MIN_KEYS || h->hookBigLayout) && big_layout_eligible(h->p) && !h->sealTable && big_geometry(h);
     auto bail = [&](int code, const char* msg) { build_release(h); table_release(h); return fail(h, code, msg); };
     if (hipMalloc(&st->d_cnt, 32) != hipSuccess || hipMemsetAsync(st->d_cnt, 0, 32, h->stream) != hipSuccess) return bail(BBDUK_ERR_NOMEM, "hipMalloc");
-    if (st->big) {
+    if (st->seed) {
+        // four records per reference window (two orientations x two halves); maxKeys counted 1 + 3k keys per window
+        const double records = 4.0 * maxKeys / (1.0 + 3.0 * h->p.k) + 64.0;
+        int sbits = 10;
+        while (sbits < 28 && (double)(1ULL << sbits) < records / 1.1) sbits++;      // ~1.1 records per 4-way bucket: 0.5 % of the buckets overflow
+        if (h->hookBucketBits >= 4 && h->hookBucketBits <= 28) sbits = h->hookBucketBits;
+        const uint64_t snb = 1ULL << sbits;
+        if ((double)(4 * snb) < records * 1.05) return bail(BBDUK_ERR_ARG, "too many reference windows for the seed layout");
+        if (hipMalloc(&h->d_tags, (snb + 1) * 8) != hipSuccess || hipMalloc(&h->d_bkv, 4 * snb * sizeof(uint4)) != hipSuccess) return bail(BBDUK_ERR_NOMEM, "hipMalloc (map)");
+        h->seed = true; h->nbuckets = snb; h->bucketBits = sbits;
+        hipMemsetAsync(h->d_tags, 0, (snb + 1) * 8, h->stream);
+        hipMemsetAsync(h->d_bkv, 0xFF, 4 * snb * sizeof(uint4), h->stream);
+    } else if (st->big) {
         // 32-slot lines at ~0.6 keys per slot (the lines' loads vary with the minimizers: 10 % of them overflow into the next line
         // there, 3 % of the keys); a tighter fit is tried when HBM is short.  12 or 14 bytes per slot: 10^10 keys = 200-233 GB.
         const int idBytes = h->p.numScaffolds <= 65535 ? 2 : 4;
@@ -393,6 +424,13 @@ static int build_add_pieces(bbduk_handle* h, const uint8_t* d_refs, const int64_
     BuildParams B;
     B.k = h->p.k; B.mink = h->p.mink; B.useShort = (h->p.mink > 0 && h->p.mink < h->p.k) ? 1 : 0; B.hdist = st->hdist; B.hdist2 = st->hdist2;
     B.rcomp = h->p.rcomp; B.middleMask = (uint64_t)h->p.middleMask; B.totalBases = total; B.nrefs = npieces;
+    if (st->seed) {
+        const int grid = (int)std::min<int64_t>((total + 255) / 256, (int64_t)h->numCU * 32);
+        bbduk_build_seed_kernel<<<dim3(std::max(grid, 1)), dim3(256), 0, h->stream>>>(B, d_refs, st->d_roff, st->d_rid, h->seedHl, h->seedHr, make_sink(h, st));
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        return BBDUK_OK;
+    }
     const int V1 = (st->hdist > 0 || (B.useShort && st->hdist2 > 0)) ? 1 + 3 * B.k : 1;
     const int64_t work = total * (int64_t)V1;
     const int grid = (int)std::min<int64_t>((work + 255) / 256, (int64_t)h->numCU * 32);
@@ -409,7 +447,10 @@ static int build_end_impl(bbduk_handle* h) {
     if (hipMemcpyAsync(cnt, st->d_cnt, 24, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
         return bail(BBDUK_ERR_DEVICE, "table build failed on the device");
     const unsigned long long distinct = cnt[0];
-    if (st->big) {
+    if (st->seed) {                                               // nkeys = RECORDS (four per distinct reference window), not the reference's key count
+        if (cnt[1]) return bail(BBDUK_ERR_NOMEM, "the map overflowed: more reference windows than announced to bbduk_build_begin");
+        h->nkeys = (int64_t)distinct; h->ldsBits = 0;
+    } else if (st->big) {
         if (cnt[1]) return bail(BBDUK_ERR_NOMEM, "the map overflowed: more keys than announced to bbduk_build_begin");
         h->nkeys = (int64_t)distinct; h->ldsBits = 0; h->nspilled = (int64_t)cnt[2];
     } else {
@@ -618,6 +659,7 @@ static KParams make_kparams(const bbduk_handle* h) {
     K.storedKmers = h->nkeys; K.undef = nullptr;
     K.big = h->big ? 1 : 0; K.bigTags = h->d_bigTags; K.bigKeys = h->d_bigKeys; K.bigIds = h->d_bigIds; K.bigIdBytes = h->bigIdBytes; K.bigLines = h->bigLines;
     K.gm = h->gm; K.gW = h->gW; K.gH = h->gH; K.gD = h->gD;
+    K.seed = h->seed ? 1 : 0; K.seedHl = h->seedHl; K.seedHr = h->seedHr;
     K.matchN = nullptr; K.matchIds = nullptr; K.matchCnt = nullptr; K.matchCap = 0;
     K.dbg = h->hookDbg;
     K.ldsImage = h->d_ldsImage; K.ldsBits = h->ldsBits;
@@ -725,8 +767,13 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     // the specialised first-hit scans run as bbduk_stream_kernel (one body for every read length, bbduk_stream_scan.inc); the pair-scan
     // kernel and its shape bodies keep the GENERAL family (and serve a handle with BBDUK_HOOK_PAIR_SCAN set)
     if (firstHit && !K.big && K.bucketBits <= 28 && !kparams_general(K) && !h->hookPairScan) { kp.wave = bbduk_pick_stream(K.mode, K.useShort != 0, K.forbidNs != 0, packed); kp.shape = nullptr; }
-    const bool tailForm = kp.shape && !K.big && K.qhdist == 0 && K.qskip < 2 && firstHit;
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)waveLds));
+    size_t waveLdsUse = waveLds;
+    if (K.seed) {                                                 // seed layout: its own stream scan (such a map exists for the first-hit kfilter only)
+        if (!firstHit) return fail(h, BBDUK_ERR_STATE, "seed-layout map with a scan that needs every hit");
+        kp.wave = bbduk_pick_stream_seed(K.forbidNs != 0, packed); kp.shape = nullptr; waveLdsUse = dynLds + WAVE_LDS_BYTES_SEED;
+    }
+    const bool tailForm = kp.shape && !K.big && !K.seed && K.qhdist == 0 && K.qskip < 2 && firstHit;
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)waveLdsUse));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.tile), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
     if (tailForm) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.shape), hipFuncAttributeMaxDynamicSharedMemorySize, (int)waveLds));
     // pre-pass: if some pair is longer than a wave's planes the tile kernel takes the whole batch, else the wave kernel
@@ -751,13 +798,13 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     const int tgrid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU * perCU);
     if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
     HIP_TRY(h, hipEventRecord(h->ev0[evi], st));
-    kp.wave<<<dim3(wgrid), dim3(BLOCK_THREADS), waveLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
+    kp.wave<<<dim3(wgrid), dim3(BLOCK_THREADS), waveLdsUse, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
     if (tailForm) kp.shape<<<dim3(wgrid), dim3(BLOCK_THREADS), waveLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
     kp.tile<<<dim3(tgrid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
     HIP_TRY(h, hipEventRecord(h->ev1[evi], st));                    // around both: whichever of the two took the batch (the other returns at once)
     h->evCount++;
     {   // reads beyond BBDUK_MAX_READ_LEN: chunked scan, one wave per unit (returns at once unless the pre-pass asked for it)
-        const batch_kernel_t lk = K.mode == BBDUK_MODE_KFILTER ? (K.big ? bbduk_long_kernel<BBDUK_MODE_KFILTER, true> : bbduk_long_kernel<BBDUK_MODE_KFILTER>) :
+        const batch_kernel_t lk = K.mode == BBDUK_MODE_KFILTER ? ((K.big || K.seed) ? bbduk_long_kernel<BBDUK_MODE_KFILTER, true> : bbduk_long_kernel<BBDUK_MODE_KFILTER>) :
                                   (K.mode == BBDUK_MODE_KTRIM_L ? bbduk_long_kernel<BBDUK_MODE_KTRIM_L> : bbduk_long_kernel<BBDUK_MODE_KTRIM_R>);
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(lk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
         const int64_t units = paired ? n / 2 : n;

@@ -48,6 +48,7 @@ struct KParams {
     const void*     bigIds;     // uint16 or uint32 per slot
     int32_t  bigIdBytes;
     uint32_t bigLines;
+    int32_t  seed, seedHl, seedHr;   // the seed layout (bbduk_seed.inc): tags / bkv hold PARENTS under their left (seedHl bases) and right (seedHr) halves
     int32_t  gm, gW, gH, gD;    // gapped minimizer: m bases from each half, W candidates, half length H, right half starts at D = k-H
     // presence filter in front of the map: one bit per hash slot, copied into LDS by every workgroup
     const uint32_t* ldsImage;   // HBM copy of the LDS bitmap (2^ldsBits bits); 0 bits = absent
@@ -71,6 +72,7 @@ struct bbduk_handle {
     // big layout (HBM-resident maps): 8 * bigLines tag words, slot-parallel keys / ids; d_tags / d_bkv = the secondary map of the spilled keys
     bool big = false; uint64_t* d_bigTags = nullptr; uint64_t* d_bigKeys = nullptr; void* d_bigIds = nullptr; int bigIdBytes = 0; uint32_t bigLines = 0;
     int gm = 0, gW = 0, gH = 0, gD = 0; int64_t nspilled = 0;
+    bool seed = false; int seedHl = 0, seedHr = 0;   // seed layout: parents only, under their halves (large hdist=1 maps built on the device)
     bool bigPlain = false;               // lines by a plain key hash instead of the gapped minimizer (gW = 0)
     bool sealTable = false;              // the map of a seal_handle: record ids may be SEAL_MULTI | offset; always the cache-resident layout
     // streaming device-side build (bbduk_build_begin / _add_device / _end)
@@ -100,7 +102,7 @@ struct bbduk_handle {
     int numCU = 256;
     bbduk_comm* comm = nullptr;          // set by bbduk_comm_create / bbduk_comm_create_local
     // include/bbduk_test_hooks.h (tests and experiments only)
-    bool hookForceTile = false, hookBigLayout = false, hookPairScan = false; int hookBucketBits = 0, hookLdsBits = -1, hookDbg = 0;
+    bool hookForceTile = false, hookBigLayout = false, hookPairScan = false, hookSeedLayout = false; int hookBucketBits = 0, hookLdsBits = -1, hookDbg = 0;
 };
 
 #define HIP_TRY(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \

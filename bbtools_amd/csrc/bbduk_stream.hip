@@ -3,14 +3,14 @@
 #include "bbduk_device.inc"
 #include "bbduk_kernels.h"
 
-template <int MODE, bool SHORT, bool FORBIDN, int FMT>
+template <int MODE, bool SHORT, bool FORBIDN, int FMT, bool SEED = false>
 __global__ __launch_bounds__(BLOCK_THREADS)
 void bbduk_stream_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
                          const int64_t n, const int64_t totalBases, const int paired,
                          int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
                          int64_t* __restrict__ counters, const int* __restrict__ slowFlag) {
     static_assert(MODE == BBDUK_MODE_KTRIM_R || MODE == BBDUK_MODE_KFILTER, "first-hit scans only");
-    wave_body<MODE, SHORT, FORBIDN, false, FMT, false, 3>(P, bases, offsets, n, totalBases, paired, outA, outId, outFlags, counters, slowFlag);
+    wave_body<MODE, SHORT, FORBIDN, false, FMT, SEED, 3>(P, bases, offsets, n, totalBases, paired, outA, outId, outFlags, counters, slowFlag);
 }
 
 template <int MODE, bool SHORT>
@@ -21,4 +21,9 @@ static batch_kernel_t pick(bool forbidN, bool packed) {
 batch_kernel_t bbduk_pick_stream(int mode, bool useShort, bool forbidN, bool packed) {
     if (mode == BBDUK_MODE_KFILTER) return pick<BBDUK_MODE_KFILTER, false>(forbidN, packed);
     return useShort ? pick<BBDUK_MODE_KTRIM_R, true>(forbidN, packed) : pick<BBDUK_MODE_KTRIM_R, false>(forbidN, packed);
+}
+// the seed layout (bbduk_seed.inc): large hdist=1 kfilter maps
+batch_kernel_t bbduk_pick_stream_seed(bool forbidN, bool packed) {
+    if (packed) return forbidN ? bbduk_stream_kernel<BBDUK_MODE_KFILTER, false, true, 1, true> : bbduk_stream_kernel<BBDUK_MODE_KFILTER, false, false, 1, true>;
+    return forbidN ? bbduk_stream_kernel<BBDUK_MODE_KFILTER, false, true, 0, true> : bbduk_stream_kernel<BBDUK_MODE_KFILTER, false, false, 0, true>;
 }

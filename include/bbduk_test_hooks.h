@@ -15,6 +15,8 @@ extern "C" {
 #define BBDUK_HOOK_TIMING_MASK  4   /* -DBBDUK_TIMING_SWITCHES builds only: bit n deletes stage n of the scan (results become wrong) */
 #define BBDUK_HOOK_PAIR_SCAN    6   /* value != 0: the first-hit scans of the specialised family run the pair-scan kernels (bbduk_wave_kernel and its
                                        shape bodies) instead of bbduk_stream_kernel: A/B runs, and the tests that keep those bodies covered */
+#define BBDUK_HOOK_SEED_LAYOUT  7   /* before a device build: value != 0 asks for the seed layout (parents under their halves) at any size, where it is
+                                       served (kfilter hdist=1, see bbduk_seed.inc) */
 #define BBDUK_HOOK_BIG_LAYOUT   5   /* before finalize / device build: value != 0 forces the HBM-resident map layout at any size */
 int  bbduk_test_hook(bbduk_handle* h, int32_t which, int64_t value);
 /* big layout: keys that found both of their words full and live in the secondary map (0 for the cache-resident layout) */

@@ -1,0 +1,107 @@
+"""The seed layout (bbtools_amd/csrc/bbduk_seed.inc): large reference-side hdist=1 maps stored as PARENTS under their halves instead of
+1 + 3k neighbours per window.  Forced onto small references with bbduk_test_hook so that the oracle -- which enumerates the mutants as
+BBDukIndexMod.mutate does -- can check every key, every id and every per-read decision, on the stream kernel, the tiled kernel and the
+long-read kernel."""
+import random
+
+import numpy as np
+import pytest
+
+from bbtools_amd import bbduk as B
+from oracle.oracle_ffi import Oracle, pack_reads
+from tests import util
+from tests.test_gpu_parity import check_batch
+
+pytestmark = pytest.mark.gpu
+SEED = {B.HOOK_SEED_LAYOUT: 1}
+CFGS = [("k=31 hdist=1", dict(k=31, hdist=1)), ("k=25 hdist=1", dict(k=25, hdist=1)), ("k=31 hdist=1 mm=f", dict(k=31, hdist=1, maskMiddle=0)),
+        ("k=24 hdist=1 mm=f rieb=f", dict(k=24, hdist=1, maskMiddle=0, requireBothBad=1)), ("k=27 hdist=1 minlen=40", dict(k=27, hdist=1, minReadLength=40))]
+
+
+def seed_pair(args, okw, refs):
+    o = Oracle(**okw)
+    for r in refs:
+        o.add_ref(r)
+    d = B.BBDuk(args, refs=refs, hooks=SEED, build="device")
+    assert d.gpu.table_bytes > 0
+    return d, o
+
+
+@pytest.mark.parametrize("ci", range(len(CFGS)))
+def test_seed_layout_keys_and_ids(ci):
+    args, okw = CFGS[ci]
+    rng = random.Random(900 + ci)
+    # scaffolds that share pieces (the smallest id has to win), reverse-complemented pieces, one with undefined bases, one shorter than k
+    base = util.rand_seq(rng, 400)
+    refs = [base, util.rand_seq(rng, 300) + base[100:180], util.revcomp(base[200:320]),
+            util.rand_seq(rng, 150, 0.03), util.rand_seq(rng, 12), util.rand_seq(rng, 500)]
+    d, o = seed_pair(args, okw, refs)
+    ks, vs = o.dump_pairs()
+    rs = np.random.default_rng(ci)
+    near = ks[rs.integers(0, len(ks), 20000)] ^ (np.int64(1) << rs.integers(0, 2 * okw["k"], 20000).astype(np.int64))      # one bit off a key
+    probe = np.concatenate([ks, near, rs.integers(0, 1 << (2 * okw["k"]), 20000, dtype=np.int64) | (np.int64(1) << (2 * okw["k"])), np.array([-1, 0], np.int64)])
+    exp = np.array([o.table_get(int(x)) for x in probe], np.int32)
+    got = d.gpu.table_lookup(probe)
+    bad = np.nonzero(got != exp)[0]
+    assert len(bad) == 0, (args, len(bad), [(hex(int(probe[i])), int(got[i]), int(exp[i])) for i in bad[:5]])
+    d.close()
+
+
+@pytest.mark.parametrize("ci", range(len(CFGS)))
+def test_seed_layout_read_parity(ci):
+    args, okw = CFGS[ci]
+    for seed in range(2):
+        rng = random.Random(7100 + 10 * ci + seed)
+        refs = [util.rand_seq(rng, rng.randint(20, 400), 0.01) for _ in range(8)]
+        d, o = seed_pair(args, okw, refs)
+        reads = util.fuzz_reads(rng, refs, 600, [0, 1, 2, 23, 30, 31, 32, 40, 63, 64, 65, 75, 150, 151, 300], junk=True)
+        # reads that carry reference pieces with ONE substitution (the neighbours the reference stores), and with two (which it does not)
+        for _ in range(150):
+            r = bytearray(util.rand_seq(rng, rng.choice([100, 150, 151, 250])))
+            src = refs[rng.randrange(len(refs))]
+            if len(src) >= 45:
+                a = rng.randrange(len(src) - 44); piece = bytearray(src[a:a + 45])
+                for _m in range(rng.choice([0, 1, 1, 2])):
+                    j = rng.randrange(len(piece)); piece[j] = rng.choice(b"ACGT")
+                if rng.random() < 0.5:
+                    piece = bytearray(bytes(piece)[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA")))
+                w = rng.randrange(len(r) - 45); r[w:w + 45] = piece
+            if rng.random() < 0.2:
+                r[rng.randrange(len(r))] = ord("N")
+            reads.append(bytes(r))
+        if len(reads) % 2:
+            reads.pop()
+        check_batch(d, o, reads, True)
+        check_batch(d, o, reads[:301], False)
+        d.close()
+
+
+def test_seed_layout_is_not_chosen_where_it_is_not_served():
+    """forbidn=t, maxbadkmers > 0, hdist = 2: the hook only asks; such handles keep the mutants (cache-resident or big layout) and stay exact"""
+    rng = random.Random(8)
+    refs = [util.rand_seq(rng, 200, 0.01) for _ in range(4)]
+    for args, okw in (("k=27 hdist=1 forbidn=t", dict(k=27, hdist=1, forbidN=1)), ("k=25 hdist=1 mbk=1", dict(k=25, hdist=1, maxBadKmers0=1)), ("k=21 hdist=2", dict(k=21, hdist=2))):
+        d, o = seed_pair(args, okw, refs)
+        assert d.gpu.table_size == o.stored_kmers                  # the reference's keys, not records
+        reads = util.fuzz_reads(rng, refs, 200, [0, 30, 31, 75, 150, 151], junk=True)
+        check_batch(d, o, reads, True)
+        d.close()
+
+
+def test_seed_layout_long_units():
+    """units beyond a wave's planes: the tiled kernel (5 kb pair) and the long-read kernel (45 kb read) look the seed layout up through lookup4"""
+    args, okw = CFGS[0]
+    rng = random.Random(31)
+    refs = [util.rand_seq(rng, 300) for _ in range(4)]
+    d, o = seed_pair(args, okw, refs)
+    for big in (5000, 45000):
+        reads = []
+        for i in range(40):
+            n = big if i in (4, 5, 22) else rng.choice([150, 151, 400])
+            r = bytearray(util.rand_seq(rng, n))
+            if rng.random() < 0.5:
+                src = refs[rng.randrange(4)]; a = rng.randrange(len(src) - 50); piece = bytearray(src[a:a + 50]); piece[rng.randrange(50)] = rng.choice(b"ACGT")
+                w = rng.randrange(n - 50); r[w:w + 50] = piece
+            reads.append(bytes(r))
+        check_batch(d, o, reads, True)
+    d.close()
