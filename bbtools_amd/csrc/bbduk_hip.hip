@@ -334,7 +334,13 @@ static bool seed_geometry(bbduk_handle* h) {
         const int base = k - 1 - __builtin_ctzll(masked) / 2;     // index of the masked base, 0 = the k-mer's first
         h->seedHl = base; h->seedHr = k - 1 - base;
     }
-    return h->seedHl >= 6 && h->seedHr >= 6 && h->seedHl <= 16 && h->seedHr <= 16;
+    // m-mers of the halves' minimizers: two candidates per half (W = 2).  Measured on the 4.6 Mbase genome (profiles/bench_hdist_big.py,
+    // 2^25 buckets): m = 10 5 Gbases/s, 11 15, 12 34, 13 46, 14 50; plain buckets 26 -- short m-mers have few values and pile their records
+    // on few lines (chains of overflowed buckets, walked with dependent gathers), long ones still put a lane's two positions on one line
+    h->seedM = std::min(h->seedHl, h->seedHr) - 1;
+    if (h->hookLdsBits == 0) h->seedM = 0;                        // (experiments: BBDUK_HOOK_LDS_BITS = 0 -> plain buckets, no minimizer lines; 6.. = m)
+    else if (h->hookLdsBits >= 6 && h->hookLdsBits <= std::min(h->seedHl, h->seedHr) - 1) h->seedM = h->hookLdsBits;
+    return h->seedHl >= 7 && h->seedHr >= 7 && h->seedHl <= 16 && h->seedHr <= 16;
 }
 #define BIG_LAYOUT_MIN_KEYS (1LL << 25)            // beyond ~3e7 keys the fingerprints alone outgrow L2 + Infinity Cache
 
@@ -358,7 +364,7 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
         // four records per reference window (two orientations x two halves); maxKeys counted 1 + 3k keys per window
         const double records = 4.0 * maxKeys / (1.0 + 3.0 * h->p.k) + 64.0;
         int sbits = 10;
-        while (sbits < 28 && (double)(1ULL << sbits) < records / 1.1) sbits++;      // ~1.1 records per 4-way bucket: 0.5 % of the buckets overflow
+        while (sbits < 28 && (double)(1ULL << sbits) < records / 0.6) sbits++;      // <= 0.6 records per 4-way bucket: the minimizer lines load unevenly
         if (h->hookBucketBits >= 4 && h->hookBucketBits <= 28) sbits = h->hookBucketBits;
         const uint64_t snb = 1ULL << sbits;
         if ((double)(4 * snb) < records * 1.05) return bail(BBDUK_ERR_ARG, "too many reference windows for the seed layout");
@@ -426,7 +432,7 @@ static int build_add_pieces(bbduk_handle* h, const uint8_t* d_refs, const int64_
     B.rcomp = h->p.rcomp; B.middleMask = (uint64_t)h->p.middleMask; B.totalBases = total; B.nrefs = npieces;
     if (st->seed) {
         const int grid = (int)std::min<int64_t>((total + 255) / 256, (int64_t)h->numCU * 32);
-        bbduk_build_seed_kernel<<<dim3(std::max(grid, 1)), dim3(256), 0, h->stream>>>(B, d_refs, st->d_roff, st->d_rid, h->seedHl, h->seedHr, make_sink(h, st));
+        bbduk_build_seed_kernel<<<dim3(std::max(grid, 1)), dim3(256), 0, h->stream>>>(B, d_refs, st->d_roff, st->d_rid, h->seedHl, h->seedHr, h->seedM, make_sink(h, st));
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         return BBDUK_OK;
@@ -659,7 +665,7 @@ static KParams make_kparams(const bbduk_handle* h) {
     K.storedKmers = h->nkeys; K.undef = nullptr;
     K.big = h->big ? 1 : 0; K.bigTags = h->d_bigTags; K.bigKeys = h->d_bigKeys; K.bigIds = h->d_bigIds; K.bigIdBytes = h->bigIdBytes; K.bigLines = h->bigLines;
     K.gm = h->gm; K.gW = h->gW; K.gH = h->gH; K.gD = h->gD;
-    K.seed = h->seed ? 1 : 0; K.seedHl = h->seedHl; K.seedHr = h->seedHr;
+    K.seed = h->seed ? 1 : 0; K.seedHl = h->seedHl; K.seedHr = h->seedHr; K.seedM = h->seedM;
     K.matchN = nullptr; K.matchIds = nullptr; K.matchCnt = nullptr; K.matchCap = 0;
     K.dbg = h->hookDbg;
     K.ldsImage = h->d_ldsImage; K.ldsBits = h->ldsBits;

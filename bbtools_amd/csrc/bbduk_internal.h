@@ -48,7 +48,7 @@ struct KParams {
     const void*     bigIds;     // uint16 or uint32 per slot
     int32_t  bigIdBytes;
     uint32_t bigLines;
-    int32_t  seed, seedHl, seedHr;   // the seed layout (bbduk_seed.inc): tags / bkv hold PARENTS under their left (seedHl bases) and right (seedHr) halves
+    int32_t  seed, seedHl, seedHr, seedM;   // the seed layout (bbduk_seed.inc): tags / bkv hold PARENTS under their left (seedHl bases) and right (seedHr) halves
     int32_t  gm, gW, gH, gD;    // gapped minimizer: m bases from each half, W candidates, half length H, right half starts at D = k-H
     // presence filter in front of the map: one bit per hash slot, copied into LDS by every workgroup
     const uint32_t* ldsImage;   // HBM copy of the LDS bitmap (2^ldsBits bits); 0 bits = absent
@@ -72,7 +72,7 @@ struct bbduk_handle {
     // big layout (HBM-resident maps): 8 * bigLines tag words, slot-parallel keys / ids; d_tags / d_bkv = the secondary map of the spilled keys
     bool big = false; uint64_t* d_bigTags = nullptr; uint64_t* d_bigKeys = nullptr; void* d_bigIds = nullptr; int bigIdBytes = 0; uint32_t bigLines = 0;
     int gm = 0, gW = 0, gH = 0, gD = 0; int64_t nspilled = 0;
-    bool seed = false; int seedHl = 0, seedHr = 0;   // seed layout: parents only, under their halves (large hdist=1 maps built on the device)
+    bool seed = false; int seedHl = 0, seedHr = 0, seedM = 0;   // seed layout: parents only, under their halves (large hdist=1 maps built on the device)
     bool bigPlain = false;               // lines by a plain key hash instead of the gapped minimizer (gW = 0)
     bool sealTable = false;              // the map of a seal_handle: record ids may be SEAL_MULTI | offset; always the cache-resident layout
     // streaming device-side build (bbduk_build_begin / _add_device / _end)

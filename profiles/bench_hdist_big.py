@@ -13,14 +13,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--genome-bases", type=int, default=4_600_000); ap.add_argument("--reads", type=int, default=20_000_000)
     ap.add_argument("--steps", type=int, default=3); ap.add_argument("--check-reads", type=int, default=0); ap.add_argument("--oracle-bases", type=int, default=100_000)
-    ap.add_argument("--args", default="k=31 hdist=1")
+    ap.add_argument("--args", default="k=31 hdist=1"); ap.add_argument("--bucket-bits", type=int, default=0); ap.add_argument("--plain", action="store_true"); ap.add_argument("--m", type=int, default=0)
     a = ap.parse_args()
     import torch
     from bbtools_amd import bbduk as B
     rng = np.random.default_rng(77)
     genome = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, a.genome_bases)].tobytes()
     t0 = time.perf_counter()
-    duk = B.BBDuk(a.args, refs=[genome], build="device")
+    hooks = {}
+    if a.bucket_bits: hooks[B.HOOK_BUCKET_BITS] = a.bucket_bits
+    if a.plain: hooks[B.HOOK_LDS_BITS] = 0
+    if a.m: hooks[B.HOOK_LDS_BITS] = a.m
+    duk = B.BBDuk(a.args, refs=[genome], build="device", hooks=hooks)
     build_s = time.perf_counter() - t0
     n = a.reads & ~1
     d_bases = torch.empty(n * 150, dtype=torch.uint8, device="cuda"); d_off = torch.empty(n + 1, dtype=torch.int64, device="cuda")
