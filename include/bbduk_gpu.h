@@ -145,7 +145,9 @@ int  bbduk_build_table_device(bbduk_handle* h, const uint8_t* refs, const int64_
 int  bbduk_build_begin(bbduk_handle* h, int64_t max_keys, int32_t hdist, int32_t hdist2);
 int  bbduk_build_add_device(bbduk_handle* h, const uint8_t* d_refs, const int64_t* ref_offsets, int32_t n_refs, int32_t first_id);
 int  bbduk_build_end(bbduk_handle* h);
-int64_t bbduk_table_size(const bbduk_handle* h);          /* distinct keys resident, or <0 */
+int64_t bbduk_table_size(const bbduk_handle* h);          /* distinct keys resident, or <0.  (A large hdist=1 kfilter map built on the device
+                                                             is stored as its PARENT windows -- bbduk_seed.inc, DESIGN 4.12: same key -> id
+                                                             answers, but this call then counts records, four per distinct window.) */
 int64_t bbduk_table_bytes(const bbduk_handle* h);         /* HBM bytes held by the table image */
 /* point lookups through the device table (test hook): out_ids[i] = id or -1 */
 int  bbduk_table_lookup(bbduk_handle* h, const int64_t* keys, int64_t n, int32_t* out_ids);
