@@ -111,6 +111,13 @@ def measure_configs(B, reads, c4_ref_bases):
         res[name] = {"args": args, "reads": n, "keys": int(duk.stored_kmers), "kernel_ms": round(ms, 3),
                      "Gbases_per_s": round(n * READ_LEN / (ms * 1e-3) / 1e9, 1), "readsKTrimmed": int(c[2]), "readsKFiltered": int(c[4])}
         duk.close()
+    try:                                               # the reference's own sizing example (BBDukGuide.txt:34): k=31 hdist=1 vs a 4.6 Mbase genome -- the seed layout
+        sys.path.insert(0, os.path.join(ROOT, "profiles"))
+        import bench_hdist_big
+        r = bench_hdist_big.run(reads=reads)
+        res["C6_hdist1_genome"] = {k: r[k] for k in ("workload", "keys", "table_bytes", "build_s", "reads", "kernel_ms", "Gbases_per_s", "readsKFiltered")}
+    except Exception as e:
+        res["C6_hdist1_genome"] = {"error": repr(e)}
     if c4_ref_bases > 0:
         # BASELINE configs[3]: kfilter k=31 hdist=0 against a seeded uniform-random reference (default: the full 10 Gbases, ~10^10 keys,
         # a 239 GB map resident in HBM in the big layout), generated and indexed on the device chunk by chunk, 1 % of the pairs

@@ -9,12 +9,24 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 
+def run(**kw):
+    """bench.py's `configs` block calls this (defaults = the command line's)"""
+    import types
+    d = dict(genome_bases=4_600_000, reads=20_000_000, steps=3, check_reads=0, oracle_bases=100_000, args="k=31 hdist=1", bucket_bits=0, plain=False, m=0)
+    d.update(kw)
+    return _run(types.SimpleNamespace(**d))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--genome-bases", type=int, default=4_600_000); ap.add_argument("--reads", type=int, default=20_000_000)
     ap.add_argument("--steps", type=int, default=3); ap.add_argument("--check-reads", type=int, default=0); ap.add_argument("--oracle-bases", type=int, default=100_000)
     ap.add_argument("--args", default="k=31 hdist=1"); ap.add_argument("--bucket-bits", type=int, default=0); ap.add_argument("--plain", action="store_true"); ap.add_argument("--m", type=int, default=0)
     a = ap.parse_args()
+    print(json.dumps(_run(a)))
+
+
+def _run(a):
     import torch
     from bbtools_amd import bbduk as B
     rng = np.random.default_rng(77)
@@ -52,8 +64,8 @@ def main():
         # the device map holds the WHOLE genome: a read the oracle's prefix map misses may still hit elsewhere (reported, ~0 expected)
         out["checked_reads"] = m; out["oracle_hits"] = int((oa > 0).sum()); out["device_hits"] = int((ga > 0).sum())
         out["oracle_hit_device_miss"] = int(((oa > 0) & (ga == 0)).sum()); out["device_hit_oracle_miss"] = int(((ga > 0) & (oa == 0)).sum())
-    print(json.dumps(out))
     duk.close()
+    return out
 
 
 if __name__ == "__main__":
