@@ -772,8 +772,12 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     const bool firstHit = K.mode == BBDUK_MODE_KTRIM_R || (K.mode == BBDUK_MODE_KFILTER && K.maxBadKmers == 0 && K.mkf == 0.f && K.mcf == 0.f);
     // the specialised first-hit scans run as bbduk_stream_kernel (one body for every read length, bbduk_stream_scan.inc); the pair-scan
     // kernel and its shape bodies keep the GENERAL family (and serve a handle with BBDUK_HOOK_PAIR_SCAN set)
-    if (firstHit && !K.big && K.bucketBits <= 28 && !kparams_general(K) && !h->hookPairScan) { kp.wave = bbduk_pick_stream(K.mode, K.useShort != 0, K.forbidNs != 0, packed); kp.shape = nullptr; }
     size_t waveLdsUse = waveLds;
+    int64_t wunitMax = WUNIT_MAX;
+    if (firstHit && !K.big && !K.seed && K.bucketBits <= 28 && !kparams_general(K) && !h->hookPairScan) {
+        kp.wave = bbduk_pick_stream(K.mode, K.useShort != 0, K.forbidNs != 0, packed); kp.shape = nullptr;
+        if (K.forbidNs) { waveLdsUse = dynLds + WAVE_LDS_BYTES_KM; wunitMax = WUNIT_MAX_KM; }      // four planes per wave (wave_body: FOURP)
+    }
     if (K.seed) {                                                 // seed layout: its own stream scan (such a map exists for the first-hit kfilter only)
         if (!firstHit) return fail(h, BBDUK_ERR_STATE, "seed-layout map with a scan that needs every hit");
         kp.wave = bbduk_pick_stream_seed(K.forbidNs != 0, packed); kp.shape = nullptr; waveLdsUse = dynLds + WAVE_LDS_BYTES_SEED;
@@ -792,7 +796,7 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     {
         const int64_t units = paired ? n / 2 : n;
         const int sgrid = (int)std::min<int64_t>((units + 255) / 256, (int64_t)h->numCU * 8);
-        bbduk_span_kernel<<<dim3(std::max(sgrid, 1)), dim3(256), 0, st>>>(d_offsets, n, (int)paired, d_flag, (int64_t)WUNIT_MAX, (int64_t)(CAP_BASES - 64), tailForm ? K.k - 1 : -1);
+        bbduk_span_kernel<<<dim3(std::max(sgrid, 1)), dim3(256), 0, st>>>(d_offsets, n, (int)paired, d_flag, wunitMax, (int64_t)(CAP_BASES - 64), tailForm ? K.k - 1 : -1);
         if (tailForm) bbduk_shape_kernel<<<dim3(1), dim3(1), 0, st>>>(d_flag, n);
     }
 #ifndef WAVE_WGS_PER_CU
