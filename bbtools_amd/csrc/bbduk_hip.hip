@@ -774,9 +774,11 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     // kernel and its shape bodies keep the GENERAL family (and serve a handle with BBDUK_HOOK_PAIR_SCAN set)
     size_t waveLdsUse = waveLds;
     int64_t wunitMax = WUNIT_MAX;
-    if (firstHit && !K.big && !K.seed && K.bucketBits <= 28 && !kparams_general(K) && !h->hookPairScan) {
-        kp.wave = bbduk_pick_stream(K.mode, K.useShort != 0, K.forbidNs != 0, packed); kp.shape = nullptr;
-        if (K.forbidNs) { waveLdsUse = dynLds + WAVE_LDS_BYTES_KM; wunitMax = WUNIT_MAX_KM; }      // four planes per wave (wave_body: FOURP)
+    // (query expansion -- qhdist -- runs on the tiled kernels: the pre-pass flag starts at 1 for such handles)
+    if (firstHit && !K.big && !K.seed && K.bucketBits <= 28 && K.qhdist == 0 && K.qhdist2 == 0 && !h->hookPairScan) {
+        const bool general = kparams_general(K);
+        kp.wave = bbduk_pick_stream(K.mode, K.useShort != 0, K.forbidNs != 0, packed, general); kp.shape = nullptr;
+        if (K.forbidNs || general) { waveLdsUse = dynLds + WAVE_LDS_BYTES_KM; wunitMax = WUNIT_MAX_KM; }      // four planes per wave (wave_body: FOURP)
     }
     if (K.seed) {                                                 // seed layout: its own stream scan (such a map exists for the first-hit kfilter only)
         if (!firstHit) return fail(h, BBDUK_ERR_STATE, "seed-layout map with a scan that needs every hit");

@@ -18,7 +18,7 @@ KernelPair bbduk_pick_kfilter_big(bool forbidN);                                
 // the other modes of bbduk_wave_kernel: BBDUK_MODE_FBM / _KBIG (bbduk_k_modes_a.hip), _KSPLIT / _KTRIM_TIPS / _KMASK (bbduk_k_modes_b.hip)
 batch_kernel_t bbduk_pick_mode_wave(int mode, bool general, bool packed, bool forbidN);
 // the stream kernels (bbduk_stream.hip): mode = BBDUK_MODE_KTRIM_R | BBDUK_MODE_KFILTER
-batch_kernel_t bbduk_pick_stream(int mode, bool useShort, bool forbidN, bool packed);
+batch_kernel_t bbduk_pick_stream(int mode, bool useShort, bool forbidN, bool packed, bool general);
 batch_kernel_t bbduk_pick_stream_seed(bool forbidN, bool packed);              // the stream scan over a seed-layout map (bbduk_seed.inc)
 
 #ifdef BBDUK_DEVICE_INC            /* translation units that hold kernel templates */

@@ -13,12 +13,24 @@ void bbduk_stream_kernel(const KParams P, const uint8_t* __restrict__ bases, con
     wave_body<MODE, SHORT, FORBIDN, false, FMT, SEED, 3>(P, bases, offsets, n, totalBases, paired, outA, outId, outFlags, counters, slowFlag);
 }
 
+// the GENERAL family (restrictleft/right, skipr1/2, qskip, speed, rcomp=f, k < 16, mink with a middle mask): one instantiation per mode,
+// input format decided per launch
+template <int MODE>
+__global__ __launch_bounds__(BLOCK_THREADS)
+void bbduk_stream_general_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
+                                 const int64_t n, const int64_t totalBases, const int paired,
+                                 int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
+                                 int64_t* __restrict__ counters, const int* __restrict__ slowFlag) {
+    wave_body<MODE, true, true, true, 2, false, 3>(P, bases, offsets, n, totalBases, paired, outA, outId, outFlags, counters, slowFlag);
+}
+
 template <int MODE, bool SHORT>
 static batch_kernel_t pick(bool forbidN, bool packed) {
     if (packed) return forbidN ? bbduk_stream_kernel<MODE, SHORT, true, 1> : bbduk_stream_kernel<MODE, SHORT, false, 1>;
     return forbidN ? bbduk_stream_kernel<MODE, SHORT, true, 0> : bbduk_stream_kernel<MODE, SHORT, false, 0>;
 }
-batch_kernel_t bbduk_pick_stream(int mode, bool useShort, bool forbidN, bool packed) {
+batch_kernel_t bbduk_pick_stream(int mode, bool useShort, bool forbidN, bool packed, bool general) {
+    if (general) return mode == BBDUK_MODE_KFILTER ? bbduk_stream_general_kernel<BBDUK_MODE_KFILTER> : bbduk_stream_general_kernel<BBDUK_MODE_KTRIM_R>;
     if (mode == BBDUK_MODE_KFILTER) return pick<BBDUK_MODE_KFILTER, false>(forbidN, packed);
     return useShort ? pick<BBDUK_MODE_KTRIM_R, true>(forbidN, packed) : pick<BBDUK_MODE_KTRIM_R, false>(forbidN, packed);
 }
