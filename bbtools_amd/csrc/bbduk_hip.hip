@@ -42,40 +42,20 @@ static_assert(sizeof(bbduk_synth_params) == 80, "bbduk_synth_params layout is pa
 
 // Pre-pass: does every unit (mate pair, or single read) fit a wave's planes?  One thread per unit.
 // wmax / hmax: longest unit the first / the second kernel of the operator accepts (flag bit 0 / bit 1 otherwise).
-// tailK >= 0 (launch_batch, first-hit scans): slowFlag[1] counts the reads whose k-mer end positions (length - tailK of them) overshoot the pair
-// scan's 128-position blocks by 1..TAIL_MAX: enough of them and bbduk_wave_kernel runs its tail-pass body (wave_body<.., 1>); slowFlag[2] counts the reads with 1..TRI_MAX positions (wave_body<.., 2>).
 __global__ void bbduk_span_kernel(const int64_t* __restrict__ offsets, const int64_t n, const int paired, int* __restrict__ slowFlag,
-                                  const int64_t wmax = WUNIT_MAX, const int64_t hmax = CAP_BASES - 64, const int tailK = -1) {
+                                  const int64_t wmax = WUNIT_MAX, const int64_t hmax = CAP_BASES - 64) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int step = paired ? 2 : 1;
     const int64_t units = n / step;
     bool bad = false, huge = false;
-    int tails = 0, shorts = 0;
     for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += stride) {
-        const int64_t o0 = offsets[u * step], o2 = offsets[u * step + step];
-        const int64_t len = o2 - o0;
+        const int64_t len = offsets[u * step + step] - offsets[u * step];
         bad |= len > wmax;
         huge |= len > hmax;                                       // not even the tile kernel's planes hold this unit: bbduk_long_kernel
-        if (tailK >= 0) {
-            const int64_t o1 = paired ? offsets[u * step + 1] : o2;
-            const int64_t pa = (o1 - o0) - tailK, pb = (o2 - o1) - tailK;
-            tails += (pa > 128 && (pa & 127) >= 1 && (pa & 127) <= TAIL_MAX) ? 1 : 0;
-            tails += (paired && pb > 128 && (pb & 127) >= 1 && (pb & 127) <= TAIL_MAX) ? 1 : 0;
-            shorts += (pa >= 1 && pa <= TRI_MAX) ? 1 : 0;
-            shorts += (paired && pb >= 1 && pb <= TRI_MAX) ? 1 : 0;
-        }
     }
     if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(slowFlag, 1);
     if (__ballot(huge) && (threadIdx.x & 63) == 0) atomicOr(slowFlag, 2);
-    if (tailK >= 0) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { tails += __shfl_xor(tails, o); shorts += __shfl_xor(shorts, o); }
-        if (tails > 0 && (threadIdx.x & 63) == 0) atomicAdd(slowFlag + 1, tails);
-        if (shorts > 0 && (threadIdx.x & 63) == 0) atomicAdd(slowFlag + 2, shorts);
-    }
 }
-// one thread: the pre-pass's counts -> which kernel takes the batch (slowFlag[3]: 0 bbduk_wave_kernel, 1 / 2 bbduk_wave_shape_kernel's bodies)
-__global__ void bbduk_shape_kernel(int* __restrict__ slowFlag, const int64_t n) { slowFlag[3] = batch_shape(slowFlag, n); }
 
 // runtime -> template dispatch: the kernel families live in translation units of their own (bbduk_kernels.h)
 // the specialised kernels assume k >= 16 (BBDuk's usual 23-31) and what BBDukParser guarantees (mink turns
@@ -697,7 +677,7 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
     if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
     HIP_TRY(h, hipEventRecord(h->ev0[evi], st));
-    int* const d_flag = h->d_slowFlag + 4 * evi;      // [0] pre-pass bits, [1] reads with a tail, [2] short reads (launch_batch)
+    int* const d_flag = h->d_slowFlag + 4 * evi;      // [0] pre-pass bits (1: a unit beyond a wave's planes, 2: beyond the tile kernel's)
     HIP_TRY(h, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), st));
     if (query_expansion(h->p)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
     {   // pre-pass per READ: one beyond the tiled kernel's planes sends the batch to bbduk_kscan_long_kernel; ksplit: one beyond a
@@ -766,40 +746,36 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     const size_t dynLds = h->ldsBits ? ((size_t)1 << (h->ldsBits - 3)) : 0;    // tile kernel: the filter only
     const size_t waveLds = dynLds + WAVE_LDS_BYTES;                             // wave kernel: filter + its per-wave state
     KernelPair kp = pick_kernel(K);
-    if (packed) { kp.wave = kp.wavePacked; kp.shape = kp.shapePacked; }
-    // the tail pass and the three-read blocks belong to the candidate form of the scans (wave_body's candMode): elsewhere the pre-pass counts
-    // nothing and bbduk_wave_shape_kernel is not launched
+    if (packed) kp.wave = kp.wavePacked;
     const bool firstHit = K.mode == BBDUK_MODE_KTRIM_R || (K.mode == BBDUK_MODE_KFILTER && K.maxBadKmers == 0 && K.mkf == 0.f && K.mcf == 0.f);
-    // the specialised first-hit scans run as bbduk_stream_kernel (one body for every read length, bbduk_stream_scan.inc); the pair-scan
-    // kernel and its shape bodies keep the GENERAL family (and serve a handle with BBDUK_HOOK_PAIR_SCAN set)
+    // the first-hit scans run as bbduk_stream_kernel (one body for every read length and both parameter families, bbduk_stream_scan.inc);
+    // bbduk_wave_kernel's pair scan keeps the every-hit scans, ktrim=l, the big layout, tables beyond 2^28 buckets and a handle with
+    // BBDUK_HOOK_PAIR_SCAN set
     size_t waveLdsUse = waveLds;
     int64_t wunitMax = WUNIT_MAX;
     // (query expansion -- qhdist -- runs on the tiled kernels: the pre-pass flag starts at 1 for such handles)
     if (firstHit && !K.big && !K.seed && K.bucketBits <= 28 && K.qhdist == 0 && K.qhdist2 == 0 && !h->hookPairScan) {
         const bool general = kparams_general(K);
-        kp.wave = bbduk_pick_stream(K.mode, K.useShort != 0, K.forbidNs != 0, packed, general); kp.shape = nullptr;
+        kp.wave = bbduk_pick_stream(K.mode, K.useShort != 0, K.forbidNs != 0, packed, general);
         if (K.forbidNs || general) { waveLdsUse = dynLds + WAVE_LDS_BYTES_KM; wunitMax = WUNIT_MAX_KM; }      // four planes per wave (wave_body: FOURP)
     }
     if (K.seed) {                                                 // seed layout: its own stream scan (such a map exists for the first-hit kfilter only)
         if (!firstHit) return fail(h, BBDUK_ERR_STATE, "seed-layout map with a scan that needs every hit");
-        kp.wave = bbduk_pick_stream_seed(K.forbidNs != 0, packed); kp.shape = nullptr; waveLdsUse = dynLds + WAVE_LDS_BYTES_SEED;
+        kp.wave = bbduk_pick_stream_seed(K.forbidNs != 0, packed); waveLdsUse = dynLds + WAVE_LDS_BYTES_SEED;
     }
-    const bool tailForm = kp.shape && !K.big && !K.seed && K.qhdist == 0 && K.qskip < 2 && firstHit;
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)waveLdsUse));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.tile), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
-    if (tailForm) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.shape), hipFuncAttributeMaxDynamicSharedMemorySize, (int)waveLds));
     // pre-pass: if some pair is longer than a wave's planes the tile kernel takes the whole batch, else the wave kernel
     std::lock_guard<std::mutex> lg(h->launchMu);
     const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
-    int* const d_flag = h->d_slowFlag + 4 * evi;      // [0] pre-pass bits, [1] reads with a tail, [2] short reads (launch_batch)
+    int* const d_flag = h->d_slowFlag + 4 * evi;      // [0] pre-pass bits (1: a unit beyond a wave's planes, 2: beyond the tile kernel's)
     HIP_TRY(h, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), st));
     if (query_expansion(h->p)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
     if (h->hookForceTile) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }
     {
         const int64_t units = paired ? n / 2 : n;
         const int sgrid = (int)std::min<int64_t>((units + 255) / 256, (int64_t)h->numCU * 8);
-        bbduk_span_kernel<<<dim3(std::max(sgrid, 1)), dim3(256), 0, st>>>(d_offsets, n, (int)paired, d_flag, wunitMax, (int64_t)(CAP_BASES - 64), tailForm ? K.k - 1 : -1);
-        if (tailForm) bbduk_shape_kernel<<<dim3(1), dim3(1), 0, st>>>(d_flag, n);
+        bbduk_span_kernel<<<dim3(std::max(sgrid, 1)), dim3(256), 0, st>>>(d_offsets, n, (int)paired, d_flag, wunitMax, (int64_t)(CAP_BASES - 64));
     }
 #ifndef WAVE_WGS_PER_CU
 #define WAVE_WGS_PER_CU 1
@@ -811,7 +787,6 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
     HIP_TRY(h, hipEventRecord(h->ev0[evi], st));
     kp.wave<<<dim3(wgrid), dim3(BLOCK_THREADS), waveLdsUse, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
-    if (tailForm) kp.shape<<<dim3(wgrid), dim3(BLOCK_THREADS), waveLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
     kp.tile<<<dim3(tgrid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
     HIP_TRY(h, hipEventRecord(h->ev1[evi], st));                    // around both: whichever of the two took the batch (the other returns at once)
     h->evCount++;
@@ -1013,7 +988,7 @@ static int launch_tips(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d
     const int grid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU);
     std::lock_guard<std::mutex> lg(h->launchMu);
     const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
-    int* const d_flag = h->d_slowFlag + 4 * evi;      // [0] pre-pass bits, [1] reads with a tail, [2] short reads (launch_batch)
+    int* const d_flag = h->d_slowFlag + 4 * evi;      // [0] pre-pass bits (1: a unit beyond a wave's planes, 2: beyond the tile kernel's)
     HIP_TRY(h, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), st));
     if (query_expansion(h->p)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
     {   // pre-pass: a unit (pair) beyond a wave's planes (bit 0) sends the batch to the tiled kernel, a READ beyond the tiled kernel's
@@ -1116,7 +1091,7 @@ static int launch_kmask(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     const int grid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU);
     std::lock_guard<std::mutex> lg(h->launchMu);
     const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
-    int* const d_flag = h->d_slowFlag + 4 * evi;      // [0] pre-pass bits, [1] reads with a tail, [2] short reads (launch_batch)
+    int* const d_flag = h->d_slowFlag + 4 * evi;      // [0] pre-pass bits (1: a unit beyond a wave's planes, 2: beyond the tile kernel's)
     HIP_TRY(h, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), st));
     if (query_expansion(h->p)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
     if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }

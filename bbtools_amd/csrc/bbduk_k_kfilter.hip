@@ -1,4 +1,4 @@
-// bbduk_k_kfilter.hip -- the kfilter instantiations of bbduk_wave_kernel / bbduk_wave_shape_kernel / bbduk_batch_kernel, including the
+// bbduk_k_kfilter.hip -- the kfilter instantiations of bbduk_wave_kernel / bbduk_batch_kernel, including the
 // BIG ones of the HBM-resident layout (BASELINE configs[3]).
 #include "bbduk_device.inc"
 #include "bbduk_kernels.h"

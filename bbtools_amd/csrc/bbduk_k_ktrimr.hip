@@ -1,4 +1,4 @@
-// bbduk_k_ktrimr.hip -- the ktrim=r instantiations of bbduk_wave_kernel / bbduk_wave_shape_kernel / bbduk_batch_kernel (one translation
+// bbduk_k_ktrimr.hip -- the ktrim=r instantiations of bbduk_wave_kernel / bbduk_batch_kernel (one translation
 // unit per kernel family: they compile in parallel).
 #include "bbduk_device.inc"
 #include "bbduk_kernels.h"

@@ -6,10 +6,9 @@
 
 typedef void (*batch_kernel_t)(const KParams, const uint8_t*, const int64_t*, const int64_t, const int64_t, const int,
                                int32_t*, int32_t*, uint8_t*, int64_t*, const int*);
-// wave / wavePacked: bbduk_wave_kernel for the ASCII / the packed boundary format; tile: bbduk_batch_kernel (units beyond a wave's planes);
-// shape / shapePacked: bbduk_wave_shape_kernel (first-hit scans of the GENERAL family); stream / streamPacked: bbduk_stream_kernel (the
-// length-agnostic first-hit scan of the specialised family) -- null where the family has none
-struct KernelPair { batch_kernel_t wave, wavePacked, tile, shape = nullptr, shapePacked = nullptr, stream = nullptr, streamPacked = nullptr; };
+// wave / wavePacked: bbduk_wave_kernel for the ASCII / the packed boundary format; tile: bbduk_batch_kernel (units beyond a wave's planes).
+// The first-hit scans of ktrim=r / kfilter run in bbduk_stream_kernel instead (bbduk_pick_stream) wherever it takes the handle.
+struct KernelPair { batch_kernel_t wave, wavePacked, tile; };
 
 KernelPair bbduk_pick_ktrim_r(bool general, bool useShort, bool forbidN);       // bbduk_k_ktrimr.hip
 KernelPair bbduk_pick_ktrim_l(bool general, bool useShort, bool forbidN);       // bbduk_k_ktriml.hip
@@ -29,10 +28,6 @@ static KernelPair kpair() {
                                          bbduk_batch_kernel<MODE, SHORT, FORBIDN, GENERAL>}
                             : KernelPair{bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL, 0>, bbduk_wave_kernel<MODE, SHORT, FORBIDN, GENERAL, 1>,
                                          bbduk_batch_kernel<MODE, SHORT, FORBIDN, GENERAL>};
-    if constexpr (MODE == BBDUK_MODE_KTRIM_R || MODE == BBDUK_MODE_KFILTER) {       // the first-hit scans have a kernel for badly fitting read lengths each
-        kp.shape = GENERAL ? bbduk_wave_shape_kernel<MODE, SHORT, FORBIDN, GENERAL, 2> : bbduk_wave_shape_kernel<MODE, SHORT, FORBIDN, GENERAL, 0>;
-        kp.shapePacked = GENERAL ? bbduk_wave_shape_kernel<MODE, SHORT, FORBIDN, GENERAL, 2> : bbduk_wave_shape_kernel<MODE, SHORT, FORBIDN, GENERAL, 1>;
-    }
     return kp;
 }
 template <int MODE>

@@ -13,8 +13,8 @@ extern "C" {
 #define BBDUK_HOOK_BUCKET_BITS  2   /* before finalize / device build: log2 of the map's bucket count (4..32; 0 = sized by key count) */
 #define BBDUK_HOOK_LDS_BITS     3   /* before finalize: log2 bits of the LDS presence filter (0 = no filter, -1 = sized by key count) */
 #define BBDUK_HOOK_TIMING_MASK  4   /* -DBBDUK_TIMING_SWITCHES builds only: bit n deletes stage n of the scan (results become wrong) */
-#define BBDUK_HOOK_PAIR_SCAN    6   /* value != 0: the first-hit scans of the specialised family run the pair-scan kernels (bbduk_wave_kernel and its
-                                       shape bodies) instead of bbduk_stream_kernel: A/B runs, and the tests that keep those bodies covered */
+#define BBDUK_HOOK_PAIR_SCAN    6   /* value != 0: the first-hit scans run bbduk_wave_kernel's pair scan instead of bbduk_stream_kernel: A/B runs,
+                                       and the tests that keep the pair scan's candidate form covered (tables beyond 2^28 buckets use it) */
 #define BBDUK_HOOK_SEED_LAYOUT  7   /* before a device build: value != 0 asks for the seed layout (parents under their halves) at any size, where it is
                                        served (kfilter hdist=1, see bbduk_seed.inc) */
 #define BBDUK_HOOK_BIG_LAYOUT   5   /* before finalize / device build: value != 0 forces the HBM-resident map layout at any size */

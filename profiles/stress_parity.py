@@ -60,7 +60,7 @@ def main():
         rng = random.Random(seed)
         fam = rng.choice(a.families.split(",") if a.families else ["base", "base", "base", "tails", "kmask", "tips", "ksplit", "big", "fbm", "seal", "tf1bp"])
         tails = fam == "tails"                                 # base configurations on reads that overshoot the pair scan's blocks by 1..32 positions:
-        if tails: fam = "base"                                 # bbduk_wave_shape_kernel / the every-hit scans' tail pass take such batches
+        if tails: fam = "base"                                 # (block borders of the stream scan / the every-hit scans' tail pass)
         if fam == "tf1bp":                                     # trimfailuresto1bp over every operator family (units within the main kernel's planes)
             try:
                 tfam, targs, tokw = T.tf1bp_config(rng)

@@ -13,9 +13,9 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-def make_pair(args, okw, refs=None, ref_fasta=None):
+def make_pair(args, okw, refs=None, ref_fasta=None, hooks=None):
     if refs is not None:
-        d = B.BBDuk(args, refs=refs)
+        d = B.BBDuk(args, refs=refs, hooks=hooks)
         o = Oracle(**okw)
         for r in refs:
             o.add_ref(r)
@@ -1121,9 +1121,9 @@ def test_trimfailuresto1bp_other_modes_refuse_units_beyond_the_main_kernel():
     d.close()
 
 
-# ---- the tail pass (bbduk_wave_shape_kernel, wave_body<.., 1>): reads whose k-mer end positions overshoot the pair scan's 128-position blocks by 1..32
-# take their last positions to a packed pass; that body runs when at least one read in eight has such a tail.  Lengths around every
-# edge of that rule, reference pieces ending at the last pair-scan position, the first tail position and the read's end.
+# ---- read lengths around the block borders of the scans (the stream scan's 256-position blocks run across read borders; the pair scan of a
+# handle the stream kernel does not take gives a read 128 positions per block): lengths around every such edge, reference pieces ending at
+# the last position of a block, the first of the next and the read's end.
 TAIL_CASES = [("ktrim=r k=23 mink=11 hdist=1", dict(k=23, ktrimRight=1, mink=11, hdist=1), 23),
               ("ktrim=r k=23", dict(k=23, ktrimRight=1), 23),                                                       # hdist=0: forbidNs, the undefined-base path
               ("ktrim=r k=23 mink=11 hdist=1 tpe minlen=20", dict(k=23, ktrimRight=1, mink=11, hdist=1, trimPairsEvenly=1, minReadLength=20), 23),
@@ -1159,13 +1159,13 @@ def test_tail_pass_parity(ci, paired):
     if paired and len(reads) & 1:
         reads.pop()
     check_batch(d, o, reads, paired)
-    # and a batch where too few reads have a tail for the tail-pass body to take it: the same answers from the plain kernel
+    # the same edges diluted among plain lengths
     few = util.fuzz_reads(rng, refs, 400, [150, k - 1 + 100, k - 1 + 128], p_insert=0.5) + reads[:20]
     check_batch(d, o, few, paired)
-    # short reads: three share a block when none has more than 84 k-mer end positions (tri_scan_cand: lanes 0-41 / 0-41 / 42-63 twice)
+    # short reads: many per block, pieces ending near their borders
     sl = [k - 1 + t for t in (84, 84, 83, 85, 44, 45, 43, 1, 2, 60, 70, 78)] + [k - 2, 5, 0, 150]
     shorts = util.fuzz_reads(rng, refs, 1500, sl, p_insert=0.6)
-    for L in (k - 1 + 84, k - 1 + 83, k - 1 + 60):               # pieces ending at the lane-group borders of the three-read block
+    for L in (k - 1 + 84, k - 1 + 83, k - 1 + 60):
         for end in (L, L - 1, k - 1 + 44, k - 1 + 45, k - 1 + 43, k + 1, k, k - 1 + 84, k - 1 + 2):
             if end > L or end < k:
                 continue
@@ -1173,11 +1173,26 @@ def test_tail_pass_parity(ci, paired):
             piece = r[rng.randint(0, len(r) - k - 3):][:k + 3]
             g = bytearray(util.rand_seq(rng, L, 0.0))
             g[max(0, end - len(piece)):end] = piece[-min(len(piece), end):]
-            for rep in range(3):                                # at each of the three places of a block
+            for rep in range(3):
                 shorts.insert(rng.randrange(len(shorts) + 1), bytes(g))
     if paired and len(shorts) & 1:
         shorts.pop()
     check_batch(d, o, shorts, paired)
+
+
+@pytest.mark.parametrize("ci", [0, 1, 3, 5, 6, 7])
+def test_pair_scan_candidate_form_behind_the_hook(ci):
+    """BBDUK_HOOK_PAIR_SCAN: the first-hit scans on bbduk_wave_kernel's pair scan (what a table beyond 2^28 buckets runs, and the A/B
+    reference of the stream kernel) give the oracle's answers at the same length edges."""
+    args, okw, k = TAIL_CASES[ci]
+    rng = random.Random(7300 + ci)
+    refs = [util.rand_seq(rng, rng.randint(40, 120), 0.0) for _ in range(6)]
+    d, o = make_pair(args, okw, refs=refs, hooks={B.HOOK_PAIR_SCAN: 1})
+    lengths = [k - 1 + 128 + t for t in (0, 1, 2, 17, 32, 33)] + [k - 1 + 256 + 5, 100, 150, 151, 40, 0, 5, k - 1 + 84, k - 1 + 44]
+    reads = util.fuzz_reads(rng, refs, 1500, lengths, p_insert=0.5)
+    check_batch(d, o, reads, True)
+    check_batch(d, o, reads[:701], False)
+    d.close()
 
 
 # the every-hit scans' tail pass (tail_scan_hits: ktrim=l and ksplit fold the hits of the tail into the read's scan facts)
