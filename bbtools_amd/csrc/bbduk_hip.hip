@@ -654,6 +654,13 @@ static KParams make_kparams(const bbduk_handle* h) {
 
 struct MatchOut { int32_t* n; int32_t* ids; int32_t* counts; int32_t cap; };     // device buffers of bbduk_kfilter_batch_matches*
 
+// Does the stream scan with the exact hit plane (bbduk_stream_every_kernel: ktrim=l, ksplit, ktrim=n, kfilter with a threshold) take this
+// handle's batches?  Cache-resident map whose bucket offsets fit 32 bits, no query expansion (the tiled kernels expand), no qskip (its grid
+// is per read; the pair scan keeps it), not behind BBDUK_HOOK_PAIR_SCAN.
+static bool stream_every_ok(const bbduk_handle* h, const KParams& K) {
+    return !K.big && !K.seed && K.bucketBits <= 28 && K.qhdist == 0 && K.qhdist2 == 0 && K.qskip < 2 && !h->hookPairScan;
+}
+
 // kbig / findBestMatch (through the kfilter operators) and ksplit: bbduk_kscan_kernel
 static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d_offsets, int64_t n, int64_t total_bases, int32_t paired,
                         int32_t* d_a, int32_t* d_id, uint8_t* d_fl, int32_t* d_left, int32_t* d_right, int64_t* d_counters, hipStream_t st,
@@ -683,7 +690,8 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     {   // pre-pass per READ: one beyond the tiled kernel's planes sends the batch to bbduk_kscan_long_kernel; ksplit: one beyond a
         // wave's planes (bit 0) sends it to the tiled kernel, else bbduk_wave_kernel<KSPLIT> takes it
         const int sgrid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)h->numCU * 8);
-        bbduk_span_kernel<<<dim3(std::max(sgrid, 1)), dim3(256), 0, st>>>(d_offsets, n, 0, d_flag, red == RED_SPLIT && !packed ? (int64_t)WUNIT_MAX : (int64_t)(KM_CAP_BASES - 32), (int64_t)(KM_CAP_BASES - 32));
+        const bool splitFour = red == RED_SPLIT && !packed && stream_every_ok(h, K) && (K.forbidNs || kparams_general(K));   // four planes per wave: shorter ones
+        bbduk_span_kernel<<<dim3(std::max(sgrid, 1)), dim3(256), 0, st>>>(d_offsets, n, 0, d_flag, red == RED_SPLIT && !packed ? (int64_t)(splitFour ? WUNIT_MAX_KM : WUNIT_MAX) : (int64_t)(KM_CAP_BASES - 32), (int64_t)(KM_CAP_BASES - 32));
         if (red != RED_SPLIT) {                                     // findBestMatch, k > 31: a unit (pair) beyond a wave's planes (bit 0) -> the tiled kernel
             const int64_t units = paired ? n / 2 : n;
             const int ugrid = (int)std::min<int64_t>((units + 255) / 256, (int64_t)h->numCU * 8);
@@ -703,8 +711,9 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     if (red == RED_SPLIT && !packed) {                              // the main kernel's shape: wave-autonomous mini-tiles, one lane per read in the finish
         K.waveFirst = 1; K.outLeft = d_left; K.outRight = d_right;
         const bool general = params_general(h->p);
-        const batch_kernel_t wk = bbduk_pick_mode_wave(BBDUK_MODE_KSPLIT, general, false, K.forbidNs != 0);
-        const size_t waveLds = dynLds + WAVE_LDS_BYTES;
+        const bool every = stream_every_ok(h, K);
+        const batch_kernel_t wk = every ? bbduk_pick_stream_every(BBDUK_MODE_KSPLIT, true, K.forbidNs != 0, general) : bbduk_pick_mode_wave(BBDUK_MODE_KSPLIT, general, false, K.forbidNs != 0);
+        const size_t waveLds = dynLds + ((every && (K.forbidNs || general)) ? WAVE_LDS_BYTES_KM : WAVE_LDS_BYTES);
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(wk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)waveLds));
         const int64_t nmt = (n + MT_READS - 1) / MT_READS;
         const int wgrid = (int)std::min<int64_t>((nmt + NWAVES - 1) / NWAVES, (int64_t)h->numCU);
@@ -758,6 +767,12 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
         const bool general = kparams_general(K);
         kp.wave = bbduk_pick_stream(K.mode, K.useShort != 0, K.forbidNs != 0, packed, general);
         if (K.forbidNs || general) { waveLdsUse = dynLds + WAVE_LDS_BYTES_KM; wunitMax = WUNIT_MAX_KM; }      // four planes per wave (wave_body: FOURP)
+    }
+    const bool everyStream = !firstHit && (K.mode == BBDUK_MODE_KTRIM_L || K.mode == BBDUK_MODE_KFILTER) && stream_every_ok(h, K);
+    if (everyStream) {                                            // ktrim=l, kfilter with a threshold: the stream scan + the exact hit plane
+        const bool general = kparams_general(K);
+        kp.wave = bbduk_pick_stream_every(K.mode, K.useShort != 0, K.forbidNs != 0, general);
+        if (K.forbidNs || general) { waveLdsUse = dynLds + WAVE_LDS_BYTES_KM; wunitMax = WUNIT_MAX_KM; }
     }
     if (K.seed) {                                                 // seed layout: its own stream scan (such a map exists for the first-hit kfilter only)
         if (!firstHit) return fail(h, BBDUK_ERR_STATE, "seed-layout map with a scan that needs every hit");
@@ -1105,7 +1120,8 @@ static int launch_kmask(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     {   // the main kernel's shape: wave-autonomous mini-tiles, a fourth plane for the hit positions, one lane per read in the finish
         K.waveFirst = 1; K.outMask = d_mask;
         const bool general = params_general(h->p);
-        const batch_kernel_t wk = bbduk_pick_mode_wave(BBDUK_MODE_KMASK, general, packed, K.forbidNs != 0);
+        const batch_kernel_t wk = stream_every_ok(h, K) ? bbduk_pick_stream_every(BBDUK_MODE_KMASK, true, K.forbidNs != 0, general)
+                                                        : bbduk_pick_mode_wave(BBDUK_MODE_KMASK, general, packed, K.forbidNs != 0);
         const size_t waveLds = dynLds + WAVE_LDS_BYTES_KM;
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(wk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)waveLds));
         const int64_t nmt = (n + MT_READS - 1) / MT_READS;
