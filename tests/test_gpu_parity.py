@@ -1195,7 +1195,31 @@ def test_pair_scan_candidate_form_behind_the_hook(ci):
     d.close()
 
 
-# the every-hit scans' tail pass (tail_scan_hits: ktrim=l and ksplit fold the hits of the tail into the read's scan facts)
+@pytest.mark.parametrize("kind,args,okw", [
+    ("batch", "ktrim=l k=23 mink=11 hdist=1", dict(k=23, ktrimLeft=1, mink=11, hdist=1)),
+    ("batch", "k=25 mbk=2", dict(k=25, maxBadKmers0=2)),
+    ("batch", "k=21 hdist=1 mkf=0.1", dict(k=21, hdist=1, minKmerFraction=0.1)),
+    ("mask", "ktrim=n k=23 mink=11 hdist=1", dict(k=23, ktrimN=1, mink=11, hdist=1)),
+    ("split", "ksplit=t k=23 mink=11 hdist=1", dict(k=23, mink=11, hdist=1, ksplit=1))])
+def test_pair_scan_every_hit_behind_the_hook(kind, args, okw):
+    """BBDUK_HOOK_PAIR_SCAN for the every-hit scans: bbduk_wave_kernel's pair scan (their path for maps beyond 2^28 buckets and for qskip)."""
+    rng = random.Random(7400 + len(args))
+    k = okw["k"]
+    refs = [util.rand_seq(rng, rng.randint(40, 120), 0.0) for _ in range(6)]
+    d, o = make_pair(args, okw, refs=refs, hooks={B.HOOK_PAIR_SCAN: 1})
+    lengths = [k - 1 + 128 + t for t in (0, 1, 2, 17, 32, 33)] + [k - 1 + 256 + 5, 100, 150, 151, 40, 0, 5]
+    reads = util.fuzz_reads(rng, refs, 1200, lengths, p_insert=0.5)
+    if kind == "batch":
+        check_batch(d, o, reads, True)
+        check_batch(d, o, reads[:501], False)
+    elif kind == "mask":
+        check_kmask(d, o, reads, True)
+    else:
+        check_split(d, o, reads)
+    d.close()
+
+
+# the every-hit scans at the block borders of the pair scan (round 2 had a tail pass there; they run the stream scan now)
 TAIL_HITS_CASES = [("ktrim=l k=23 mink=11 hdist=1", dict(k=23, ktrimLeft=1, mink=11, hdist=1), 23, "batch"),
                    ("ktrim=l k=21", dict(k=21, ktrimLeft=1), 21, "batch"),
                    ("ktrim=l k=19 hdist=1 restrictleft=170 tp=1", dict(k=19, ktrimLeft=1, hdist=1, restrictLeft=170, trimPad=1), 19, "batch"),
