@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Secondary measurement: batches of mixed read lengths, as a quality-trimmed data set has them.  2x151 pairs from the generator; a random share
-of the pairs is cut to 2x100 (both mates keep their first 100 bases).  Shows which body takes the batch (tails >= 1/8 -> tail pass, else
-short reads >= 1/2 -> three per block, else the plain kernel) and what it yields.  One JSON line per share."""
+of the pairs is cut to 2x100 (both mates keep their first 100 bases).  (--pair-scan: the pair scan of rounds 1-2 behind BBDUK_HOOK_PAIR_SCAN.)
+One JSON line per share."""
 import json, os, sys
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import torch
