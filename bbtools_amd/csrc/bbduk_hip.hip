@@ -695,14 +695,17 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
         if (red != RED_SPLIT) {                                     // findBestMatch, k > 31: a unit (pair) beyond a wave's planes (bit 0) -> the tiled kernel
             const int64_t units = paired ? n / 2 : n;
             const int ugrid = (int)std::min<int64_t>((units + 255) / 256, (int64_t)h->numCU * 8);
-            bbduk_span_kernel<<<dim3(std::max(ugrid, 1)), dim3(256), 0, st>>>(d_offsets, n, (int)paired, d_flag, (int64_t)WUNIT_MAX, (int64_t)0x7FFFFFFFFFFFLL);
+            const bool bestFour = red == RED_BEST && stream_every_ok(h, K) && (K.forbidNs || kparams_general(K));     // four planes per wave: shorter ones
+            bbduk_span_kernel<<<dim3(std::max(ugrid, 1)), dim3(256), 0, st>>>(d_offsets, n, (int)paired, d_flag, (int64_t)(bestFour ? WUNIT_MAX_KM : WUNIT_MAX), (int64_t)0x7FFFFFFFFFFFLL);
         }
     }
     if (red != RED_SPLIT) {                                         // the main kernel's shape; the pair scan keeps an id list (main_scan_pair_best) or the run state
         K.waveFirst = 1;                                            // (main_scan_pair_kbig) per read
         const bool general = params_general(h->p);
-        const batch_kernel_t wk = bbduk_pick_mode_wave(red == RED_BEST ? BBDUK_MODE_FBM : BBDUK_MODE_KBIG, general, packed, K.forbidNs != 0);
-        const size_t waveLds = dynLds + WAVE_LDS_BYTES;
+        const bool every = red == RED_BEST && stream_every_ok(h, K);     // findbestmatch: the stream scan, ids gathered per read (wave_body: FBM)
+        const batch_kernel_t wk = every ? bbduk_pick_stream_every(BBDUK_MODE_FBM, false, K.forbidNs != 0, general)
+                                        : bbduk_pick_mode_wave(red == RED_BEST ? BBDUK_MODE_FBM : BBDUK_MODE_KBIG, general, packed, K.forbidNs != 0);
+        const size_t waveLds = dynLds + ((every && (K.forbidNs || general)) ? WAVE_LDS_BYTES_KM : WAVE_LDS_BYTES);
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(wk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)waveLds));
         const int64_t nmt = (n + MT_READS - 1) / MT_READS;
         const int wgrid = (int)std::min<int64_t>((nmt + NWAVES - 1) / NWAVES, (int64_t)h->numCU);

@@ -15,7 +15,7 @@ void bbduk_stream_every_kernel(const KParams P, const uint8_t* __restrict__ base
 
 batch_kernel_t bbduk_pick_stream_every_b(int mode, bool forbidN, bool general);
 batch_kernel_t bbduk_pick_stream_every(int mode, bool useShort, bool forbidN, bool general) {
-    if (mode == BBDUK_MODE_KSPLIT || mode == BBDUK_MODE_KMASK) return bbduk_pick_stream_every_b(mode, forbidN, general);
+    if (mode == BBDUK_MODE_KSPLIT || mode == BBDUK_MODE_KMASK || mode == BBDUK_MODE_FBM) return bbduk_pick_stream_every_b(mode, forbidN, general);
     if (mode == BBDUK_MODE_KFILTER) {
         if (general) return bbduk_stream_every_kernel<BBDUK_MODE_KFILTER, true, true, true>;
         return forbidN ? bbduk_stream_every_kernel<BBDUK_MODE_KFILTER, false, true, false> : bbduk_stream_every_kernel<BBDUK_MODE_KFILTER, false, false, false>;
