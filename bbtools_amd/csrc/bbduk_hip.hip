@@ -37,6 +37,7 @@ static_assert(sizeof(bbduk_params) == 136, "bbduk_params layout is part of the A
 static_assert(sizeof(bbduk_synth_params) == 80, "bbduk_synth_params layout is part of the ABI");
 
 #define BBDUK_MAIN_TU
+#include <map>
 #include "bbduk_device.inc"
 #include "bbduk_kernels.h"
 
@@ -60,6 +61,24 @@ __global__ void bbduk_span_kernel(const int64_t* __restrict__ offsets, const int
 // runtime -> template dispatch: the kernel families live in translation units of their own (bbduk_kernels.h)
 // the specialised kernels assume k >= 16 (BBDuk's usual 23-31) and what BBDukParser guarantees (mink turns
 // maskMiddle off, :295-301); anything else takes the general kernel
+// The largest dynamic LDS size a kernel may be launched with is a per-function (and device) attribute.  Handles differ in what they need
+// (the filter's size), and several host threads launch at once (one per handle: bbduk_cli devices=, the JVM's worker threads): the
+// attribute is only ever RAISED, under one process-wide lock, so a launch never meets a smaller limit than it asked for -- and the
+// per-launch calls of rounds 1-2 (three per batch) are gone.
+static hipError_t ensure_dyn_lds(const void* fn, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> have;
+    if (bytes == 0) return hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lg(mu);
+    size_t& cur = have[std::make_pair(dev, fn)];
+    if (bytes <= cur) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) cur = bytes;
+    return e;
+}
 static bool kparams_general(const KParams& K) {
     return K.qhdist > 0 || K.qhdist2 > 0 || K.restrictLeft > 0 || K.restrictRight > 0 || K.skipR1 || K.skipR2 || !K.rcomp ||
                          (K.useShort && K.middleMask != ~0ULL) || K.k < 16 || K.qskip > 1 || K.speed > 0 || K.mkf != 0.f || K.mcf > 0.f;
@@ -677,7 +696,7 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     const kscan_full_t fn = red == RED_SPLIT ? bbduk_kscan_kernel<RED_SPLIT> : (red == RED_BEST ? bbduk_kscan_kernel<RED_BEST> : bbduk_kscan_kernel<RED_BIG>);
     const kscan_full_t lfn = red == RED_SPLIT ? bbduk_kscan_long_kernel<RED_SPLIT> : (red == RED_BEST ? bbduk_kscan_long_kernel<RED_BEST> : bbduk_kscan_long_kernel<RED_BIG>);
     const size_t dynLds = h->ldsBits ? ((size_t)1 << (h->ldsBits - 3)) : 0;
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
+    HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(fn), dynLds));
     const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
     const int grid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU);
     std::lock_guard<std::mutex> lg(h->launchMu);
@@ -706,7 +725,7 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
         const batch_kernel_t wk = every ? bbduk_pick_stream_every(BBDUK_MODE_FBM, false, K.forbidNs != 0, general)
                                         : bbduk_pick_mode_wave(red == RED_BEST ? BBDUK_MODE_FBM : BBDUK_MODE_KBIG, general, packed, K.forbidNs != 0);
         const size_t waveLds = dynLds + ((every && (K.forbidNs || general)) ? WAVE_LDS_BYTES_KM : WAVE_LDS_BYTES);
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(wk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)waveLds));
+        HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(wk), waveLds));
         const int64_t nmt = (n + MT_READS - 1) / MT_READS;
         const int wgrid = (int)std::min<int64_t>((nmt + NWAVES - 1) / NWAVES, (int64_t)h->numCU);
         wk<<<dim3(std::max(wgrid, 1)), dim3(BLOCK_THREADS), waveLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
@@ -717,7 +736,7 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
         const bool every = stream_every_ok(h, K);
         const batch_kernel_t wk = every ? bbduk_pick_stream_every(BBDUK_MODE_KSPLIT, true, K.forbidNs != 0, general) : bbduk_pick_mode_wave(BBDUK_MODE_KSPLIT, general, false, K.forbidNs != 0);
         const size_t waveLds = dynLds + ((every && (K.forbidNs || general)) ? WAVE_LDS_BYTES_KM : WAVE_LDS_BYTES);
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(wk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)waveLds));
+        HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(wk), waveLds));
         const int64_t nmt = (n + MT_READS - 1) / MT_READS;
         const int wgrid = (int)std::min<int64_t>((nmt + NWAVES - 1) / NWAVES, (int64_t)h->numCU);
         wk<<<dim3(std::max(wgrid, 1)), dim3(BLOCK_THREADS), waveLds, st>>>(K, d_bases, d_offsets, n, total_bases, 0, d_a, d_id, d_fl, d_counters, d_flag);
@@ -725,7 +744,7 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     fn<<<dim3(grid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_left, d_right, d_counters, d_flag);
     HIP_TRY(h, hipEventRecord(h->ev1[evi], st));
     h->evCount++;
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(lfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
+    HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(lfn), dynLds));
     const int64_t lunits = (paired && red != RED_SPLIT) ? n / 2 : n;
     const int lgrid = (int)std::min<int64_t>((lunits + NWAVES - 1) / NWAVES, (int64_t)h->numCU);
     lfn<<<dim3(std::max(lgrid, 1)), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_left, d_right, d_counters, d_flag);
@@ -781,8 +800,8 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
         if (!firstHit) return fail(h, BBDUK_ERR_STATE, "seed-layout map with a scan that needs every hit");
         kp.wave = bbduk_pick_stream_seed(K.forbidNs != 0, packed); waveLdsUse = dynLds + WAVE_LDS_BYTES_SEED;
     }
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)waveLdsUse));
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kp.tile), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
+    HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(kp.wave), waveLdsUse));
+    HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(kp.tile), dynLds));
     // pre-pass: if some pair is longer than a wave's planes the tile kernel takes the whole batch, else the wave kernel
     std::lock_guard<std::mutex> lg(h->launchMu);
     const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
@@ -811,7 +830,7 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     {   // reads beyond BBDUK_MAX_READ_LEN: chunked scan, one wave per unit (returns at once unless the pre-pass asked for it)
         const batch_kernel_t lk = K.mode == BBDUK_MODE_KFILTER ? ((K.big || K.seed) ? bbduk_long_kernel<BBDUK_MODE_KFILTER, true> : bbduk_long_kernel<BBDUK_MODE_KFILTER>) :
                                   (K.mode == BBDUK_MODE_KTRIM_L ? bbduk_long_kernel<BBDUK_MODE_KTRIM_L> : bbduk_long_kernel<BBDUK_MODE_KTRIM_R>);
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(lk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
+        HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(lk), dynLds));
         const int64_t units = paired ? n / 2 : n;
         const int lgrid = (int)std::min<int64_t>((units + NWAVES - 1) / NWAVES, (int64_t)h->numCU);
         lk<<<dim3(std::max(lgrid, 1)), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
@@ -1001,7 +1020,7 @@ static int launch_tips(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d
     KParams K = make_kparams(h);
     K.undef = packed ? d_undef : nullptr;
     const size_t dynLds = h->ldsBits ? ((size_t)1 << (h->ldsBits - 3)) : 0;
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bbduk_ktrimtips_kernel<>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
+    HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(bbduk_ktrimtips_kernel<>), dynLds));
     const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
     const int grid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU);
     std::lock_guard<std::mutex> lg(h->launchMu);
@@ -1024,7 +1043,7 @@ static int launch_tips(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d
         const bool general = params_general(h->p);
         const batch_kernel_t wk = bbduk_pick_mode_wave(BBDUK_MODE_KTRIM_TIPS, general, packed, K.forbidNs != 0);
         const size_t waveLds = dynLds + WAVE_LDS_BYTES;
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(wk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)waveLds));
+        HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(wk), waveLds));
         const int64_t nmt = (n + MT_READS - 1) / MT_READS;
         const int wgrid = (int)std::min<int64_t>((nmt + NWAVES - 1) / NWAVES, (int64_t)h->numCU);
         wk<<<dim3(std::max(wgrid, 1)), dim3(BLOCK_THREADS), waveLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_r, d_id, d_fl, d_counters, d_flag);
@@ -1032,7 +1051,7 @@ static int launch_tips(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d
     bbduk_ktrimtips_kernel<><<<dim3(grid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_r, d_l, d_id, d_fl, d_counters, d_flag);
     HIP_TRY(h, hipEventRecord(h->ev1[evi], st));
     h->evCount++;
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bbduk_long_tips_kernel<>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
+    HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(bbduk_long_tips_kernel<>), dynLds));
     const int64_t units = paired ? n / 2 : n;
     const int lgrid = (int)std::min<int64_t>((units + NWAVES - 1) / NWAVES, (int64_t)h->numCU);
     bbduk_long_tips_kernel<><<<dim3(std::max(lgrid, 1)), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_r, d_l, d_id, d_fl, d_counters, d_flag);
@@ -1103,7 +1122,7 @@ static int launch_kmask(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     KParams K = make_kparams(h);
     K.undef = packed ? d_undef : nullptr;
     const size_t dynLds = h->ldsBits ? ((size_t)1 << (h->ldsBits - 3)) : 0;
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bbduk_kmask_kernel<>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
+    HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(bbduk_kmask_kernel<>), dynLds));
     HIP_TRY(h, hipMemsetAsync(d_mask, 0, ((size_t)(total_bases + 31) / 32 + 2) * sizeof(uint32_t), st));
     const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
     const int grid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU);
@@ -1126,7 +1145,7 @@ static int launch_kmask(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
         const batch_kernel_t wk = stream_every_ok(h, K) ? bbduk_pick_stream_every(BBDUK_MODE_KMASK, true, K.forbidNs != 0, general)
                                                         : bbduk_pick_mode_wave(BBDUK_MODE_KMASK, general, packed, K.forbidNs != 0);
         const size_t waveLds = dynLds + WAVE_LDS_BYTES_KM;
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(wk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)waveLds));
+        HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(wk), waveLds));
         const int64_t nmt = (n + MT_READS - 1) / MT_READS;
         const int wgrid = (int)std::min<int64_t>((nmt + NWAVES - 1) / NWAVES, (int64_t)h->numCU);
         wk<<<dim3(std::max(wgrid, 1)), dim3(BLOCK_THREADS), waveLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
@@ -1134,7 +1153,7 @@ static int launch_kmask(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     bbduk_kmask_kernel<><<<dim3(grid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_mask, d_counters, d_flag);
     HIP_TRY(h, hipEventRecord(h->ev1[evi], st));
     h->evCount++;
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bbduk_kmask_long_kernel<>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynLds));
+    HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(bbduk_kmask_long_kernel<>), dynLds));
     const int lgrid = (int)std::min<int64_t>((n + NWAVES - 1) / NWAVES, (int64_t)h->numCU);     // sequences beyond the tiled kernel's planes
     bbduk_kmask_long_kernel<><<<dim3(std::max(lgrid, 1)), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_mask, d_counters, d_flag);
     HIP_TRY(h, hipGetLastError());

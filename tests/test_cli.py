@@ -12,7 +12,15 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 
 def run_cli(args, cwd=ROOT):
-    return subprocess.run([_build.cli_path()] + args, cwd=cwd, capture_output=True, text=True, timeout=600)
+    # (one run in ~150 of the devices= test has been seen to hang on a GPU box -- inside the process, after 9-second normal runs on
+    # every other box -- so a run that exceeds two minutes is started once more and reported)
+    for attempt in (0, 1):
+        try:
+            return subprocess.run([_build.cli_path()] + args, cwd=cwd, capture_output=True, text=True, timeout=120 if attempt == 0 else 600)
+        except subprocess.TimeoutExpired:
+            if attempt:
+                raise
+            print("bbduk_cli exceeded 120 s, run again:", " ".join(args))
 
 
 def test_cli_is_built_and_prints_usage():
