@@ -296,7 +296,9 @@ static bool big_geometry(bbduk_handle* h) {
         H = std::min(firstMasked, k - 1 - lastMasked);
     }
     if (H < 4) return false;
-    h->gH = H; h->gD = k - H; h->gm = std::min(10, H - 1); h->gW = h->bigPlain ? 0 : H - h->gm + 1;
+    h->gH = H; h->gD = k - H; h->gm = std::min(10, H - 1);
+    if (h->hookLdsBits >= 4 && h->hookLdsBits <= H - 1) h->gm = h->hookLdsBits;      // (experiments: BBDUK_HOOK_LDS_BITS = m; such maps have no LDS filter)
+    h->gW = h->bigPlain ? 0 : H - h->gm + 1;
     return true;
 }
 static BigGeom host_geom(const bbduk_handle* h) { BigGeom G; G.k = h->p.k; G.m = h->gm; G.W = h->gW; G.H = h->gH; G.D = h->gD; G.nlines = h->bigLines; G.middleMask = (uint64_t)h->p.middleMask; return G; }

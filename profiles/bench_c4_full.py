@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--check-reads", type=int, default=50_000)
     ap.add_argument("--pair-scan", action="store_true", help="experiments: the pair-scan kernel of round 2 instead of the stream kernel")
+    ap.add_argument("--gm", type=int, default=0, help="experiments: minimizer length m of the big layout's lines (W = H - m + 1)")
     ap.add_argument("--oracle-bases", type=int, default=50_000_000, help="prefix of scaffold 1.. the contaminated reads are drawn from (and the oracle indexes)")
     a = ap.parse_args()
     print(json.dumps(_run(a)))
@@ -63,6 +64,8 @@ def _run(a):
     gpu = B.BBDukGpu(p)
     if getattr(a, "pair_scan", False):
         gpu.test_hook(B.HOOK_PAIR_SCAN, 1)
+    if getattr(a, "gm", 0):
+        gpu.test_hook(B.HOOK_LDS_BITS, a.gm)
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")
     t0 = time.perf_counter()
     gpu.build_begin(ref_bases, 0, 0)
