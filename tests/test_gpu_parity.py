@@ -1196,6 +1196,45 @@ def test_pair_scan_candidate_form_behind_the_hook(ci):
 
 
 @pytest.mark.parametrize("kind,args,okw", [
+    ("batch", "ktrim=r k=23 mink=11 hdist=1", dict(k=23, ktrimRight=1, mink=11, hdist=1)),          # three planes per wave: units up to 2512 bases
+    ("batch", "ktrim=r k=23", dict(k=23, ktrimRight=1)),                                              # forbidNs: four planes, units up to 2384
+    ("batch", "ktrim=l k=23 mink=11 hdist=1", dict(k=23, ktrimLeft=1, mink=11, hdist=1)),
+    ("batch", "k=27 hdist=1 mbk=5", dict(k=27, hdist=1, maxBadKmers0=5)),                             # the exact plane
+    ("batch", "k=25 hdist=1 fbm", dict(k=25, hdist=1, findBestMatch=1)),
+    ("mask", "ktrim=n k=23 mink=11 hdist=1", dict(k=23, ktrimN=1, mink=11, hdist=1)),
+    ("split", "ksplit=t k=23 mink=11 hdist=1", dict(k=23, mink=11, hdist=1, ksplit=1))])
+def test_units_at_the_planes_capacity(kind, args, okw):
+    """Units (pairs; ksplit: reads) whose length sits at and around what a wave's planes hold -- the stream kernels' candidate plane is
+    full to its last word there, and one base more sends the batch to the tiled kernel."""
+    rng = random.Random(7500 + len(args))
+    refs = [util.rand_seq(rng, rng.randint(40, 120), 0.0) for _ in range(6)]
+    d, o = make_pair(args, okw, refs=refs)
+    for cap in (2384, 2512):                                        # WUNIT_MAX_KM, WUNIT_MAX
+        for delta in (-3, -1, 0, 1):
+            unit = cap + delta
+            L1 = unit if kind == "split" else unit // 2
+            L2 = unit - L1
+            lens = [L1] if kind == "split" else [L1, L2]
+            reads = []
+            for i in range(40):                                     # long units among short ones, pieces of the references at both ends
+                if i % 4 == 0:
+                    for L in lens:
+                        g = bytearray(util.rand_seq(rng, L, 0.001))
+                        for at in (0, L - 60, rng.randrange(max(1, L - 60))):
+                            r = rng.choice(refs); g[at:at + min(len(r), 50)] = r[:min(len(r), 50)]
+                        reads.append(bytes(g))
+                else:
+                    reads += util.fuzz_reads(rng, refs, 1 if kind == "split" else 2, [150, 100, 31], p_insert=0.5)
+            if kind == "batch":
+                check_batch(d, o, reads, True)
+            elif kind == "mask":
+                check_kmask(d, o, reads, True)
+            else:
+                check_split(d, o, reads)
+    d.close()
+
+
+@pytest.mark.parametrize("kind,args,okw", [
     ("batch", "ktrim=l k=23 mink=11 hdist=1", dict(k=23, ktrimLeft=1, mink=11, hdist=1)),
     ("batch", "k=25 mbk=2", dict(k=25, maxBadKmers0=2)),
     ("batch", "k=21 hdist=1 mkf=0.1", dict(k=21, hdist=1, minKmerFraction=0.1)),
