@@ -1043,7 +1043,8 @@ static int launch_tips(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d
     {   // the main kernel's shape: wave-autonomous mini-tiles, candidate scan for the right pass, one lane per read in the finish
         K.waveFirst = 1; K.outLeft = d_l;
         const bool general = params_general(h->p);
-        const batch_kernel_t wk = bbduk_pick_mode_wave(BBDUK_MODE_KTRIM_TIPS, general, packed, K.forbidNs != 0);
+        const batch_kernel_t wk = (stream_every_ok(h, K) && !K.forbidNs && !general) ? bbduk_pick_stream_tips(packed)
+                                                                                      : bbduk_pick_mode_wave(BBDUK_MODE_KTRIM_TIPS, general, packed, K.forbidNs != 0);
         const size_t waveLds = dynLds + WAVE_LDS_BYTES;
         HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(wk), waveLds));
         const int64_t nmt = (n + MT_READS - 1) / MT_READS;

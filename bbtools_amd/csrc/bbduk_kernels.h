@@ -20,6 +20,7 @@ batch_kernel_t bbduk_pick_mode_wave(int mode, bool general, bool packed, bool fo
 batch_kernel_t bbduk_pick_stream(int mode, bool useShort, bool forbidN, bool packed, bool general);
 // the every-hit scans on the stream (bbduk_stream_every*.hip): mode = BBDUK_MODE_KTRIM_L | _KFILTER (with a threshold) | _KSPLIT | _KMASK
 batch_kernel_t bbduk_pick_stream_every(int mode, bool useShort, bool forbidN, bool general);
+batch_kernel_t bbduk_pick_stream_tips(bool packed);                            // ktrim=rl, no forbidNs, specialised family
 batch_kernel_t bbduk_pick_stream_seed(bool forbidN, bool packed);              // the stream scan over a seed-layout map (bbduk_seed.inc)
 
 #ifdef BBDUK_DEVICE_INC            /* translation units that hold kernel templates */

@@ -24,6 +24,17 @@ void bbduk_stream_general_kernel(const KParams P, const uint8_t* __restrict__ ba
     wave_body<MODE, true, true, true, 2, false, 3>(P, bases, offsets, n, totalBases, paired, outA, outId, outFlags, counters, slowFlag);
 }
 
+// ktrim=rl without forbidNs: both passes off one stream scan (wave_body: TIPS && STREAM)
+template <int FMT>
+__global__ __launch_bounds__(BLOCK_THREADS)
+void bbduk_stream_tips_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
+                              const int64_t n, const int64_t totalBases, const int paired,
+                              int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
+                              int64_t* __restrict__ counters, const int* __restrict__ slowFlag) {
+    wave_body<BBDUK_MODE_KTRIM_TIPS, true, false, false, FMT, false, 3>(P, bases, offsets, n, totalBases, paired, outA, outId, outFlags, counters, slowFlag);
+}
+batch_kernel_t bbduk_pick_stream_tips(bool packed) { return packed ? bbduk_stream_tips_kernel<1> : bbduk_stream_tips_kernel<0>; }
+
 template <int MODE, bool SHORT>
 static batch_kernel_t pick(bool forbidN, bool packed) {
     if (packed) return forbidN ? bbduk_stream_kernel<MODE, SHORT, true, 1> : bbduk_stream_kernel<MODE, SHORT, false, 1>;
