@@ -220,7 +220,7 @@ extern "C" int bbduk_destroy(bbduk_handle* h) {
     for (auto& q : h->slot) { hipFree(q.d_bases); hipFree(q.d_undef); hipFree(q.d_off); hipFree(q.d_a); hipFree(q.d_id); hipFree(q.d_fl); hipFree(q.d_status); if (q.stream) hipStreamDestroy(q.stream); }
     hipFree(h->d_tags); hipFree(h->d_bkv);
     hipFree(h->d_ldsImage); hipFree(h->d_slowFlag);
-    for (int q = 0; q < bbduk_handle::EV_RING; q++) { if (h->ev0[q]) hipEventDestroy(h->ev0[q]); if (h->ev1[q]) hipEventDestroy(h->ev1[q]); }
+    for (int q = 0; q < bbduk_handle::EV_RING; q++) { if (h->ev0[q]) hipEventDestroy(h->ev0[q]); if (h->ev1[q]) hipEventDestroy(h->ev1[q]); if (h->evDone[q]) hipEventDestroy(h->evDone[q]); }
     hipFree(h->d_counters);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -683,6 +683,14 @@ static bool stream_every_ok(const bbduk_handle* h, const KParams& K) {
 }
 
 // kbig / findBestMatch (through the kfilter operators) and ksplit: bbduk_kscan_kernel
+
+// The pre-pass flag block (and the timing events) of ring entry evi come round again after EV_RING launches -- possibly on another stream
+// while the launch that had them before is still queued (the *_device operators take the caller's stream).  The new launch waits for the
+// last kernel of that earlier one (evDone, recorded at the end of every launch function) before it clears the block.  
+static hipError_t ring_acquire(bbduk_handle* h, const int evi, hipStream_t st) {
+    if (!h->evDone[evi]) return hipEventCreateWithFlags(&h->evDone[evi], hipEventDisableTiming);
+    return hipStreamWaitEvent(st, h->evDone[evi], 0);
+}
 static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d_offsets, int64_t n, int64_t total_bases, int32_t paired,
                         int32_t* d_a, int32_t* d_id, uint8_t* d_fl, int32_t* d_left, int32_t* d_right, int64_t* d_counters, hipStream_t st,
                         const uint32_t* d_undef, bool packed, const MatchOut* mo = nullptr, int64_t* d_status = nullptr) {
@@ -706,6 +714,7 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
     HIP_TRY(h, hipEventRecord(h->ev0[evi], st));
     int* const d_flag = h->d_slowFlag + 4 * evi;      // [0] pre-pass bits (1: a unit beyond a wave's planes, 2: beyond the tile kernel's)
+    HIP_TRY(h, ring_acquire(h, evi, st));
     HIP_TRY(h, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), st));
     if (query_expansion(h->p)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
     {   // pre-pass per READ: one beyond the tiled kernel's planes sends the batch to bbduk_kscan_long_kernel; ksplit: one beyond a
@@ -750,6 +759,7 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     const int64_t lunits = (paired && red != RED_SPLIT) ? n / 2 : n;
     const int lgrid = (int)std::min<int64_t>((lunits + NWAVES - 1) / NWAVES, (int64_t)h->numCU);
     lfn<<<dim3(std::max(lgrid, 1)), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_left, d_right, d_counters, d_flag);
+    HIP_TRY(h, hipEventRecord(h->evDone[evi], st));
     HIP_TRY(h, hipGetLastError());
     return BBDUK_OK;
 }
@@ -808,6 +818,7 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     std::lock_guard<std::mutex> lg(h->launchMu);
     const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
     int* const d_flag = h->d_slowFlag + 4 * evi;      // [0] pre-pass bits (1: a unit beyond a wave's planes, 2: beyond the tile kernel's)
+    HIP_TRY(h, ring_acquire(h, evi, st));
     HIP_TRY(h, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), st));
     if (query_expansion(h->p)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
     if (h->hookForceTile) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }
@@ -837,6 +848,7 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
         const int lgrid = (int)std::min<int64_t>((units + NWAVES - 1) / NWAVES, (int64_t)h->numCU);
         lk<<<dim3(std::max(lgrid, 1)), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
     }
+    HIP_TRY(h, hipEventRecord(h->evDone[evi], st));
     HIP_TRY(h, hipGetLastError());
     return BBDUK_OK;
 }
@@ -1028,6 +1040,7 @@ static int launch_tips(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d
     std::lock_guard<std::mutex> lg(h->launchMu);
     const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
     int* const d_flag = h->d_slowFlag + 4 * evi;      // [0] pre-pass bits (1: a unit beyond a wave's planes, 2: beyond the tile kernel's)
+    HIP_TRY(h, ring_acquire(h, evi, st));
     HIP_TRY(h, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), st));
     if (query_expansion(h->p)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
     {   // pre-pass: a unit (pair) beyond a wave's planes (bit 0) sends the batch to the tiled kernel, a READ beyond the tiled kernel's
@@ -1058,6 +1071,7 @@ static int launch_tips(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d
     const int64_t units = paired ? n / 2 : n;
     const int lgrid = (int)std::min<int64_t>((units + NWAVES - 1) / NWAVES, (int64_t)h->numCU);
     bbduk_long_tips_kernel<><<<dim3(std::max(lgrid, 1)), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_r, d_l, d_id, d_fl, d_counters, d_flag);
+    HIP_TRY(h, hipEventRecord(h->evDone[evi], st));
     HIP_TRY(h, hipGetLastError());
     return BBDUK_OK;
 }
@@ -1132,6 +1146,7 @@ static int launch_kmask(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     std::lock_guard<std::mutex> lg(h->launchMu);
     const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
     int* const d_flag = h->d_slowFlag + 4 * evi;      // [0] pre-pass bits (1: a unit beyond a wave's planes, 2: beyond the tile kernel's)
+    HIP_TRY(h, ring_acquire(h, evi, st));
     HIP_TRY(h, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), st));
     if (query_expansion(h->p)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
     if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
@@ -1159,6 +1174,7 @@ static int launch_kmask(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(bbduk_kmask_long_kernel<>), dynLds));
     const int lgrid = (int)std::min<int64_t>((n + NWAVES - 1) / NWAVES, (int64_t)h->numCU);     // sequences beyond the tiled kernel's planes
     bbduk_kmask_long_kernel<><<<dim3(std::max(lgrid, 1)), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_mask, d_counters, d_flag);
+    HIP_TRY(h, hipEventRecord(h->evDone[evi], st));
     HIP_TRY(h, hipGetLastError());
     return BBDUK_OK;
 }

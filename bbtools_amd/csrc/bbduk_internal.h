@@ -81,6 +81,7 @@ struct bbduk_handle {
     int* d_slowFlag = nullptr;
     static const int EV_RING = 64;                                // HIP events around the dominant kernel of the last launches
     hipEvent_t ev0[EV_RING] = {}, ev1[EV_RING] = {}; int64_t evCount = 0;
+    hipEvent_t evDone[EV_RING] = {};                              // behind the LAST kernel of the launch that holds ring entry q (its flag block: ring_acquire)
     std::mutex launchMu;                                          // device-buffer operators may be issued from several host threads /
                                                                   // streams at once: slot choice and enqueue of one launch are atomic,
                                                                   // and every launch in flight has its own pre-pass flag (d_slowFlag[slot])

@@ -32,10 +32,10 @@ def keys_of(windows, k=31, mm=True):
     return (v | (np.uint64(1) << np.uint64(2 * k))).astype(np.int64)
 
 
-def run(ref_bases=1e10, scaffold_bases=10_000_000, chunk_scaffolds=50, reads=20_000_000, steps=3, check_reads=50_000, oracle_bases=50_000_000):
+def run(ref_bases=1e10, scaffold_bases=10_000_000, chunk_scaffolds=50, reads=20_000_000, steps=3, check_reads=50_000, oracle_bases=50_000_000, fallback_reads=0):
     import types
     return _run(types.SimpleNamespace(ref_bases=ref_bases, scaffold_bases=scaffold_bases, chunk_scaffolds=chunk_scaffolds, reads=reads, steps=steps,
-                                      check_reads=check_reads, oracle_bases=oracle_bases, pair_scan=False))
+                                      check_reads=check_reads, oracle_bases=oracle_bases, pair_scan=False, fallback_reads=fallback_reads))
 
 
 def main():
@@ -108,11 +108,22 @@ def _run(a):
     rk &= ~(np.int64(3) << np.int64(30))
     out["random_keys_found"] = int((gpu.table_lookup(rk) > 0).sum())
     # ---- the operator
-    n_pairs = a.reads // 2; n = 2 * n_pairs
     sp = B.synth_params(4, contam=contam, contam_frac=0.01)
-    d_bases = torch.empty(n * 150, dtype=torch.uint8, device="cuda"); d_off = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    fb = int(getattr(a, "fallback_reads", 0) or 0)
+    for reads in ([a.reads, fb] if 0 < fb < a.reads else [a.reads]):      # the batch beside the map: the requested size, else the smaller one
+        n_pairs = reads // 2; n = 2 * n_pairs
+        try:
+            d_bases = torch.empty(n * 150, dtype=torch.uint8, device="cuda"); d_off = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+            d_a = torch.empty(n, dtype=torch.int32, device="cuda"); d_id = torch.empty_like(d_a); d_fl = torch.empty(n, dtype=torch.uint8, device="cuda")
+            break
+        except torch.OutOfMemoryError as e:
+            if reads != a.reads or not fb:
+                gpu.close(); host.close()
+                raise
+            out["reads_requested"] = int(a.reads); out["full_batch_error"] = repr(e)[:200]
+            d_bases = d_off = d_a = d_id = d_fl = None
+            torch.cuda.empty_cache()
     B.synth_generate_device(sp, 0, n_pairs, d_bases, d_off, 0)
-    d_a = torch.empty(n, dtype=torch.int32, device="cuda"); d_id = torch.empty_like(d_a); d_fl = torch.empty(n, dtype=torch.uint8, device="cuda")
     d_c = torch.zeros(gpu.counters_len, dtype=torch.int64, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(1 + a.steps):

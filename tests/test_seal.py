@@ -193,6 +193,26 @@ def test_seal_fuzz_parity(seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k,rcomp", [(9, True), (11, False), (13, True)])
+def test_seal_hdist2_table_is_the_reference_neighbourhood(k, rcomp):
+    """hdist=2: the loader emits every neighbour once (ascending positions) where Seal.java:1890-1921 nests two rounds of single
+    substitutions; the (k-mer, scaffold) SET and every read's answer have to be the restatement's."""
+    from bbtools_amd.seal import Seal
+    rng = random.Random(900 + k)
+    refs = make_refs(rng, 3, 120, 0.3)
+    o = SealOracle(refs, k=k, hdist=2, maskMiddle=0, rcomp=1 if rcomp else 0)
+    g = Seal("k=%d hdist=2 mm=f rcomp=%s" % (k, "t" if rcomp else "f"), refs=refs, max_scaffolds=8)
+    keys, ids = o.pairs()
+    assert g.table_pairs == len(keys) and g.table_keys == len(np.unique(keys))
+    reads = make_reads(rng, refs, 120, True)
+    want = o.process_reads(reads, True, 3, max_ids=8); got = g.process_reads(reads, True, 3, max_ids=8)
+    for w, h in zip(want, got):
+        assert np.array_equal(w, h)
+    assert o.counters()[0] == g.counters()[0]
+    g.close()
+
+
+@pytest.mark.gpu
 def test_seal_uploaded_pairs_and_defaults():
     """A table handed over as (k-mer, scaffold) pairs (what a JVM-built HashArrayHybridFast holds) with Seal's defaults (k=31 mm=t ambig=random)."""
     from bbtools_amd.seal import Seal
