@@ -343,7 +343,14 @@ static bool seed_geometry(bbduk_handle* h) {
     else if (h->hookLdsBits >= 6 && h->hookLdsBits <= std::min(h->seedHl, h->seedHr) - 1) h->seedM = h->hookLdsBits;
     return h->seedHl >= 7 && h->seedHr >= 7 && h->seedHl <= 16 && h->seedHr <= 16;
 }
-#define BIG_LAYOUT_MIN_KEYS (1LL << 25)            // beyond ~3e7 keys the fingerprints alone outgrow L2 + Infinity Cache
+// Which layout a map takes, by its (announced) key count.  Measured at the end of round 3 (profiles/r03_layout_mid*.jsonl, r03_l2_boundary*.jsonl;
+// kfilter k=31, 2x150 bp, 20 M reads): the cache-resident layout lives off its fingerprint array staying in an XCD's 4 MB of L2 -- 4 MB: 480-500
+// Gbases/s, 8 MB: 200-310, 16 MB: 105-135, >= 64 MB: 62 -- while the big layout's minimizer lines hold 170 Gbases/s from 5e5 to 3e7 keys (hdist=0;
+// 139 at 1e9, 88 at 1e10) and its plain lines (reference-side hdist>0) 130 / 107 / 87 / 72 at 1.3 / 2.5 / 4.9 / 9.7 M keys against 129 / 81 / 66 / 63.
+// So eligible maps (big_layout_eligible) beyond 2^20 keys take the big layout (was: 2^25); the seed layout keeps its threshold (below it the plain
+// lines are faster: 58-64 against 60-130).
+#define BIG_LAYOUT_MIN_KEYS (1LL << 20)
+#define SEED_LAYOUT_MIN_KEYS (1LL << 25)
 
 // expected number of keys (an upper bound is fine) -> layout, allocations
 static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdist2) {
@@ -356,7 +363,7 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
     // reference-side Hamming neighbourhoods put ~2/3 of a k-mer's 1+3k variants on one minimizer: such maps take plain lines
     if (hdist > 0) h->bigPlain = true;
     // large hdist=1 maps of the plain first-hit kfilter: the seed layout stores the parents, not their 1+3k neighbours (bbduk_seed.inc)
-    st->seed = (maxKeys > (double)BIG_LAYOUT_MIN_KEYS || h->hookSeedLayout) && !h->hookBigLayout && hdist == 1 && big_layout_eligible(h->p) &&
+    st->seed = (maxKeys > (double)SEED_LAYOUT_MIN_KEYS || h->hookSeedLayout) && !h->hookBigLayout && hdist == 1 && big_layout_eligible(h->p) &&
                h->p.maxBadKmers == 0 && !h->p.forbidNs && !h->sealTable && seed_geometry(h);
     st->big = !st->seed && (maxKeys > (double)BIG_LAYOUT_MIN_KEYS || h->hookBigLayout) && big_layout_eligible(h->p) && !h->sealTable && big_geometry(h);
     auto bail = [&](int code, const char* msg) { build_release(h); table_release(h); return fail(h, code, msg); };
@@ -465,7 +472,11 @@ static int build_end_impl(bbduk_handle* h) {
         // overflow and carry the continuation flag, so almost every lookup ends in its home bucket).
         int bbits = 10;
         while (bbits < 32 && (1ULL << bbits) < distinct) bbits++;
-        if (bbits == 30 && distinct <= (1ULL << 30)) bbits = 29;     // the slot index is 31 bits: the largest maps of this layout run at up to 2 keys per bucket
+        // From 2^20 buckets on the fingerprint array would leave the L2 (8 MB and more): half as many buckets -- 1-2 keys per bucket, ~5 % of
+        // them overflowing at 2 -- is faster at every size measured (5.6e5 keys: 451 against 309 Gbases/s, 1.04e6: 233 / 203, 1.27e6: 180 / 129,
+        // 2.5e6: 97 / 82, 1e7: 65 / 63; profiles/r03_l2_boundary*.jsonl).  Up to 2^19 buckets the array fits and the sparser map wins
+        // (5.2e5 keys at 0.98 / 1.97 keys per bucket: 478 / 331).  (This also keeps the slot index within 31 bits for up to 2^30 keys.)
+        if (bbits >= 20) bbits--;
         if (h->hookBucketBits >= 4 && h->hookBucketBits <= 32) bbits = h->hookBucketBits;      // bbduk_test_hook
         const uint64_t nb = 1ULL << bbits;
         if (4 * nb < distinct + nb / 8 || 4 * nb > (1ULL << 31)) return bail(BBDUK_ERR_ARG, "too many keys for the bucket index");

@@ -53,6 +53,7 @@ def lib():
         L.seal_last_kernel_ms.restype = C.c_double; L.seal_last_kernel_ms.argtypes = [vp]
         L.seal_comm_create.argtypes = [vp, i32, i32, C.c_char_p]
         L.seal_allreduce_counters.argtypes = [vp]
+        L.seal_test_hook.argtypes = [vp, i32, i64]
         _bound = True
     return L
 
@@ -69,7 +70,7 @@ def parse_args(args: str, device: int = 0, max_scaffolds: int = 1 << 16) -> Seal
 class Seal:
     """One table + the batch operator.  refs: list[bytes] (scaffold i gets id i+1), or pairs=(keys, ids) from a table built elsewhere."""
 
-    def __init__(self, args: str, refs=None, pairs=None, device: int = 0, max_scaffolds: int = 1 << 16):
+    def __init__(self, args: str, refs=None, pairs=None, device: int = 0, max_scaffolds: int = 1 << 16, hooks=None):
         self.p = parse_args(args, device, max_scaffolds)
         self.h = C.c_void_p()
         if lib().seal_create(C.byref(self.p), C.byref(self.h)) != OK:
@@ -81,6 +82,8 @@ class Seal:
         if pairs is not None:
             keys = np.ascontiguousarray(pairs[0], np.int64); ids = np.ascontiguousarray(pairs[1], np.int32)
             self._check(lib().seal_upload_pairs(self.h, keys.ctypes.data, ids.ctypes.data, len(keys)), "seal_upload_pairs")
+        for k_, v_ in (hooks or {}).items():         # include/bbduk_test_hooks.h (tests / experiments): e.g. {HOOK_BUCKET_BITS: 21}
+            self._check(lib().seal_test_hook(self.h, int(k_), int(v_)), "seal_test_hook")
         self._check(lib().seal_finalize(self.h), "seal_finalize")
 
     def _check(self, rc, what):

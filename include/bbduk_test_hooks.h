@@ -19,6 +19,9 @@ extern "C" {
                                        served (kfilter hdist=1, see bbduk_seed.inc) */
 #define BBDUK_HOOK_BIG_LAYOUT   5   /* before finalize / device build: value != 0 forces the HBM-resident map layout at any size */
 int  bbduk_test_hook(bbduk_handle* h, int32_t which, int64_t value);
+/* the same controls on the map behind a Seal handle (include/seal_gpu.h), before seal_finalize */
+struct seal_handle;
+int  seal_test_hook(struct seal_handle* h, int32_t which, int64_t value);
 /* big layout: keys that found both of their words full and live in the secondary map (0 for the cache-resident layout) */
 int64_t bbduk_table_spilled(const bbduk_handle* h);
 /* big layout: out33[c] = number of 32-slot lines that hold c keys */

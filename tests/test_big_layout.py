@@ -165,3 +165,42 @@ def test_big_layout_secondary_operators():
         rr = reads + reads[:1] * (len(reads) % 2)
         check_batch(d, o, rr, "ksplit" not in args)
         d.close()
+
+
+def _is_big(d):
+    try:
+        d.gpu.line_histogram()
+        return True
+    except B.BBDukError:
+        return False
+
+
+@pytest.mark.parametrize("args,okw,genome,want_big", [
+    ("k=31", dict(k=31), 1_150_000, True),                          # plain kfilter beyond 2^20 keys: minimizer lines without any hook
+    ("k=31 hdist=1", dict(k=31, hdist=1), 14_000, True),            # 1.27 M keys of Hamming neighbourhoods: plain lines
+    ("k=31", dict(k=31), 900_000, False),                           # below the threshold: the cache-resident map
+    ("k=31 mkf=0.1", dict(k=31, minKmerFraction=0.1), 1_150_000, False),      # not a plain first-hit kfilter: cache-resident at 1-2 keys per bucket
+    ("ktrim=r k=27", dict(k=27, ktrimRight=1), 1_150_000, False),   # ktrim: the same
+])
+def test_layout_chosen_by_key_count(args, okw, genome, want_big):
+    """The layouts as the library picks them by itself (round 3: the big layout from 2^20 keys on for the configurations that have its scan,
+    half as many buckets for the others), each against the oracle: table, reads, counters."""
+    g = np.frombuffer(b"ACGT", np.uint8)[np.random.default_rng(genome).integers(0, 4, genome)].tobytes()
+    o = Oracle(**okw); o.add_ref(g)
+    for build in ("host", "device"):
+        d = B.BBDuk(args, refs=[g], build=build)
+        assert d.gpu.table_size == o.stored_kmers and _is_big(d) == want_big
+        ks, vs = o.dump_pairs()
+        sel = np.random.default_rng(1).integers(0, len(ks), 200_000)
+        probe = np.concatenate([ks[sel], np.random.default_rng(2).integers(0, 1 << 62, 50_000, dtype=np.int64)])
+        got = d.gpu.table_lookup(probe)
+        assert np.array_equal(got[:len(sel)], vs[sel]) and int((got[len(sel):] > 0).sum()) == 0
+        b, off = B.synth_generate_host(B.synth_params(17, n_rate=0.002, contam=g[:200_000], contam_frac=0.05), 0, 20_000)
+        for paired in (True, False):
+            d.gpu.reset_counters(); o.reset_counters()
+            ga, gi, gf = d.gpu.process_batch(b, off, paired)
+            oa, oi, of = o.process_batch(b, off, paired, nthreads=8)
+            assert np.array_equal(ga, oa) and np.array_equal(gi, oi) and np.array_equal(gf, of)
+            assert np.array_equal(d.gpu.counters(), o.counters())
+        assert int((oa > 0).sum()) > 100
+        d.close()
