@@ -118,6 +118,11 @@ def measure_configs(B, reads, c4_ref_bases, c4_reads=0):
         res["C6_hdist1_genome"] = {k: r[k] for k in ("workload", "keys", "table_bytes", "build_s", "reads", "kernel_ms", "Gbases_per_s", "readsKFiltered")}
     except Exception as e:
         res["C6_hdist1_genome"] = {"error": repr(e)}
+    try:                                               # the same guide line's hdist=0 figure (E. coli: 4554207 keys): the big layout's minimizer lines since round 3 (was cache-resident: 67.6 Gbases/s)
+        r = bench_hdist_big.run(reads=reads, args="k=31 hdist=0")
+        res["C7_hdist0_genome"] = {k: r[k] for k in ("workload", "keys", "table_bytes", "build_s", "reads", "kernel_ms", "Gbases_per_s", "readsKFiltered")}
+    except Exception as e:
+        res["C7_hdist0_genome"] = {"error": repr(e)}
     if c4_ref_bases > 0:
         # BASELINE configs[3]: kfilter k=31 hdist=0 against a seeded uniform-random reference (default: the full 10 Gbases, ~10^10 keys,
         # a 239 GB map resident in HBM in the big layout), generated and indexed on the device chunk by chunk, 1 % of the pairs
