@@ -200,7 +200,7 @@ extern "C" int bbduk_test_hook(bbduk_handle* h, int32_t which, int64_t value) {
     case BBDUK_HOOK_BUCKET_BITS: if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookBucketBits = (int)value; return BBDUK_OK;
     case BBDUK_HOOK_LDS_BITS:    if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookLdsBits = (int)value; return BBDUK_OK;
     case BBDUK_HOOK_SEED_LAYOUT: if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookSeedLayout = value != 0; return BBDUK_OK;
-    case BBDUK_HOOK_BIG_LAYOUT:  if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookBigLayout = value != 0; return BBDUK_OK;
+    case BBDUK_HOOK_BIG_LAYOUT:  if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookBigLayout = value > 0; h->hookNoBigLayout = value < 0; return BBDUK_OK;
     case BBDUK_HOOK_TIMING_MASK:
 #ifdef BBDUK_TIMING_SWITCHES
         h->hookDbg = (int)value; return BBDUK_OK;
@@ -219,7 +219,7 @@ extern "C" int bbduk_destroy(bbduk_handle* h) {
     hipFree(h->d_bigTags); hipFree(h->d_bigKeys); hipFree(h->d_bigIds);
     for (auto& q : h->slot) { hipFree(q.d_bases); hipFree(q.d_undef); hipFree(q.d_off); hipFree(q.d_a); hipFree(q.d_id); hipFree(q.d_fl); hipFree(q.d_status); if (q.stream) hipStreamDestroy(q.stream); }
     hipFree(h->d_tags); hipFree(h->d_bkv);
-    hipFree(h->d_ldsImage); hipFree(h->d_slowFlag);
+    hipFree(h->d_ldsImage); hipFree(h->d_slowFlag); hipFree(h->d_tagsAlt); hipFree(h->d_bkvAlt); hipFree(h->d_ldsAlt);
     for (int q = 0; q < bbduk_handle::EV_RING; q++) { if (h->ev0[q]) hipEventDestroy(h->ev0[q]); if (h->ev1[q]) hipEventDestroy(h->ev1[q]); if (h->evDone[q]) hipEventDestroy(h->evDone[q]); }
     hipFree(h->d_counters);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -282,6 +282,8 @@ static void table_release(bbduk_handle* h) {       // a failed build leaves no h
     hipFree(h->d_tags); hipFree(h->d_bkv); hipFree(h->d_ldsImage); hipFree(h->d_bigTags); hipFree(h->d_bigKeys); hipFree(h->d_bigIds);
     h->d_tags = nullptr; h->d_bkv = nullptr; h->d_ldsImage = nullptr; h->d_bigTags = nullptr; h->d_bigKeys = nullptr; h->d_bigIds = nullptr;
     h->big = false; h->nbuckets = 0; h->bigLines = 0; h->ldsBits = 0; h->nkeys = 0;
+    hipFree(h->d_tagsAlt); hipFree(h->d_bkvAlt); hipFree(h->d_ldsAlt);
+    h->d_tagsAlt = nullptr; h->d_bkvAlt = nullptr; h->d_ldsAlt = nullptr; h->hasAlt = false; h->nbucketsAlt = 0;
 }
 // gapped-minimizer geometry of the big layout for this k and middle mask (see "big layout"); false: k too small for it
 static bool big_geometry(bbduk_handle* h) {
@@ -365,7 +367,7 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
     // large hdist=1 maps of the plain first-hit kfilter: the seed layout stores the parents, not their 1+3k neighbours (bbduk_seed.inc)
     st->seed = (maxKeys > (double)SEED_LAYOUT_MIN_KEYS || h->hookSeedLayout) && !h->hookBigLayout && hdist == 1 && big_layout_eligible(h->p) &&
                h->p.maxBadKmers == 0 && !h->p.forbidNs && !h->sealTable && seed_geometry(h);
-    st->big = !st->seed && (maxKeys > (double)BIG_LAYOUT_MIN_KEYS || h->hookBigLayout) && big_layout_eligible(h->p) && !h->sealTable && big_geometry(h);
+    st->big = !st->seed && !h->hookNoBigLayout && (maxKeys > (double)BIG_LAYOUT_MIN_KEYS || h->hookBigLayout) && big_layout_eligible(h->p) && !h->sealTable && big_geometry(h);
     auto bail = [&](int code, const char* msg) { build_release(h); table_release(h); return fail(h, code, msg); };
     if (hipMalloc(&st->d_cnt, 32) != hipSuccess || hipMemsetAsync(st->d_cnt, 0, 32, h->stream) != hipSuccess) return bail(BBDUK_ERR_NOMEM, "hipMalloc");
     if (st->seed) {
@@ -530,11 +532,7 @@ extern "C" int bbduk_build_end(bbduk_handle* h) {
 
 // The pairs a host staged with bbduk_upload_pairs / bbduk_upload_table_way go to the device in chunks and are placed there (one
 // thread per pair; 10^8 keys took 17.8 s in a serial host loop, they take about a second this way).
-extern "C" int bbduk_finalize_table(bbduk_handle* h) {
-    if (!h) return BBDUK_ERR_ARG;
-    std::lock_guard<std::mutex> g(h->mu);
-    if (h->finalized) return fail(h, BBDUK_ERR_STATE, "table already finalized");
-    if (h->build) return fail(h, BBDUK_ERR_STATE, "a device-side build is in progress: end it with bbduk_build_end");
+static int finalize_once(bbduk_handle* h) {
     const int64_t n = (int64_t)h->hkeys.size();
     int rc = BBDUK_OK;
   for (int attempt = 0; attempt < 2; attempt++) {                  // second attempt: plain lines, if the minimizer lines spilled too much
@@ -561,12 +559,54 @@ extern "C" int bbduk_finalize_table(bbduk_handle* h) {
     if (rc == BBDUK_ERR_NOMEM && !h->bigPlain && !h->finalized) { h->bigPlain = true; continue; }
     break;
   }
+    return rc;
+}
+// Would a map of this (announced) size take the big layout -- and is it small enough to keep a cache-resident twin beside it?  (Measured,
+// profiles/r03_layout_mid_long.jsonl: against a 4.6 M-key map, 2x150 and 2x1000 reads run 2.3x / 2.1x faster on the big layout's stream scan, but
+// units beyond a wave's planes -- the tile and long-read kernels, whose big-layout instantiations look every key up on its own -- 2x3000: 33 against
+// 70 Gbases/s, 2x20000: 6.8 against 28.  The twin costs 65 bytes per key up to 2^25 keys, at most 2 GB.)  A forced layout (test hooks) stays single.
+static bool wants_twin(bbduk_handle* h, const double maxKeys, const int hdist) {
+    if (h->hookBigLayout || h->hookNoBigLayout || h->hookSeedLayout || h->sealTable) return false;
+    if (!(maxKeys > (double)BIG_LAYOUT_MIN_KEYS) || maxKeys > (double)SEED_LAYOUT_MIN_KEYS) return false;
+    (void)hdist;
+    return big_layout_eligible(h->p) && big_geometry(h);
+}
+// the map just built becomes the twin: the next build starts from an empty handle
+static void stash_twin(bbduk_handle* h) {
+    h->d_tagsAlt = h->d_tags; h->d_bkvAlt = h->d_bkv; h->d_ldsAlt = h->d_ldsImage; h->nbucketsAlt = h->nbuckets; h->bucketBitsAlt = h->bucketBits; h->ldsBitsAlt = h->ldsBits;
+    h->d_tags = nullptr; h->d_bkv = nullptr; h->d_ldsImage = nullptr; h->nbuckets = 0; h->bucketBits = 0; h->ldsBits = 0; h->nkeys = 0;
+    h->finalized = false; h->hasAlt = true;
+}
+template <class Once>
+static int build_both(bbduk_handle* h, const double maxKeys, const int hdist, Once once) {
+    if (wants_twin(h, maxKeys, hdist)) {
+        h->hookNoBigLayout = true;
+        const int rc = once();
+        h->hookNoBigLayout = false;
+        if (rc != BBDUK_OK) return rc;
+        if (h->big || h->seed) return BBDUK_OK;                      // (cannot happen: the hook keeps both away)
+        stash_twin(h);
+    }
+    const int rc = once();
+    if (rc == BBDUK_OK && h->hasAlt && !h->big) {                    // the second build did not come out big after all: one cache-resident map is enough
+        hipFree(h->d_tagsAlt); hipFree(h->d_bkvAlt); hipFree(h->d_ldsAlt);
+        h->d_tagsAlt = nullptr; h->d_bkvAlt = nullptr; h->d_ldsAlt = nullptr; h->hasAlt = false; h->nbucketsAlt = 0;
+    }
+    return rc;
+}
+extern "C" int bbduk_finalize_table(bbduk_handle* h) {
+    if (!h) return BBDUK_ERR_ARG;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (h->finalized) return fail(h, BBDUK_ERR_STATE, "table already finalized");
+    if (h->build) return fail(h, BBDUK_ERR_STATE, "a device-side build is in progress: end it with bbduk_build_end");
+    const int rc = build_both(h, (double)h->hkeys.size(), 0, [&]() { return finalize_once(h); });
     if (rc == BBDUK_OK) { h->hkeys.clear(); h->hkeys.shrink_to_fit(); h->hvals.clear(); h->hvals.shrink_to_fit(); }
     return rc;
 }
 
 // bbduk_build_table_device: the reference sequences are HOST memory here; they go to the device in chunks of whole scaffolds
 // (a scaffold longer than a chunk as pieces that overlap by k-1 bases) through bbduk_build_begin / build_add_pieces / bbduk_build_end.
+static int build_device_once(bbduk_handle* h, const uint8_t* refs, const int64_t* ref_offsets, const int32_t n_refs, const int32_t hdist, const int32_t hdist2, const double ub);
 extern "C" int bbduk_build_table_device(bbduk_handle* h, const uint8_t* refs, const int64_t* ref_offsets, int32_t n_refs,
                                         int32_t hdist, int32_t hdist2) {
     if (!h) return BBDUK_ERR_ARG;
@@ -583,6 +623,11 @@ extern "C" int bbduk_build_table_device(bbduk_handle* h, const uint8_t* refs, co
     auto variants = [](int len, int d) { const double t = 3.0 * len; double v = 1.0; if (d >= 1) v += t; if (d >= 2) v += t * (t - 3.0) / 2.0; if (d >= 3) v += t * (t - 3.0) * (t - 6.0) / 6.0; return v; };
     double ub = (double)total * variants(k, hdist);
     if (useShort) for (int L = h->p.mink; L < k; L++) ub += 2.0 * (double)n_refs * variants(L, hdist2);
+    return build_both(h, ub, hdist, [&]() { return build_device_once(h, refs, ref_offsets, n_refs, hdist, hdist2, ub); });
+}
+static int build_device_once(bbduk_handle* h, const uint8_t* refs, const int64_t* ref_offsets, const int32_t n_refs, const int32_t hdist, const int32_t hdist2, const double ub) {
+    const int k = h->p.k;
+    const int64_t total = n_refs > 0 ? ref_offsets[n_refs] : 0;
     int rc = BBDUK_OK;
   for (int attempt = 0; attempt < 2; attempt++) {                  // second attempt: plain lines, if the minimizer lines spilled too much
     rc = build_begin_impl(h, ub, hdist, hdist2);
@@ -649,7 +694,8 @@ extern "C" int64_t bbduk_table_spilled(const bbduk_handle* h) { return (h && h->
 extern "C" int64_t bbduk_table_size(const bbduk_handle* h) { return (h && h->finalized) ? h->nkeys : -1; }
 extern "C" int64_t bbduk_table_bytes(const bbduk_handle* h) {
     if (!h || !h->finalized) return -1;
-    if (h->big) return (int64_t)h->bigLines * (64 + 256 + 32 * h->bigIdBytes) + (int64_t)(h->nbuckets * (8 + 4 * 16));
+    if (h->big) return (int64_t)h->bigLines * (64 + 256 + 32 * h->bigIdBytes) + (int64_t)(h->nbuckets * (8 + 4 * 16)) +
+                       (h->hasAlt ? (int64_t)(h->nbucketsAlt * (8 + 4 * 16)) + (h->ldsBitsAlt ? (1LL << (h->ldsBitsAlt - 3)) : 0) : 0);
     return (int64_t)(h->nbuckets * (8 + 4 * 16)) + (h->ldsBits ? (1LL << (h->ldsBits - 3)) : 0);
 }
 
@@ -681,6 +727,14 @@ static KParams make_kparams(const bbduk_handle* h) {
     K.matchN = nullptr; K.matchIds = nullptr; K.matchCnt = nullptr; K.matchCap = 0;
     K.dbg = h->hookDbg;
     K.ldsImage = h->d_ldsImage; K.ldsBits = h->ldsBits;
+    return K;
+}
+
+// the same parameters over the cache-resident twin of a big-layout map (bbduk_handle::hasAlt)
+static KParams alt_kparams(const bbduk_handle* h, KParams K) {
+    K.big = 0; K.bigTags = nullptr; K.bigKeys = nullptr; K.bigIds = nullptr; K.bigLines = 0;
+    K.tags = h->d_tagsAlt; K.bkv = h->d_bkvAlt; K.bucketMask = (uint32_t)(h->nbucketsAlt - 1); K.bucketBits = h->bucketBitsAlt;
+    K.ldsImage = h->d_ldsAlt; K.ldsBits = h->ldsBitsAlt;
     return K;
 }
 
@@ -823,8 +877,14 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
         if (!firstHit) return fail(h, BBDUK_ERR_STATE, "seed-layout map with a scan that needs every hit");
         kp.wave = bbduk_pick_stream_seed(K.forbidNs != 0, packed); waveLdsUse = dynLds + WAVE_LDS_BYTES_SEED;
     }
+    // a big-layout map with a cache-resident twin (build_both): the wave kernel scans the big layout, the fallbacks for units beyond a wave's
+    // planes (tile kernel, long-read kernel) run their cache-resident instantiations over the twin
+    const bool twin = K.big && h->hasAlt;
+    const KParams K2 = twin ? alt_kparams(h, K) : K;
+    const size_t dynLds2 = twin ? (K2.ldsBits ? ((size_t)1 << (K2.ldsBits - 3)) : 0) : dynLds;
+    if (twin) kp.tile = pick_kernel(K2).tile;
     HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(kp.wave), waveLdsUse));
-    HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(kp.tile), dynLds));
+    HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(kp.tile), dynLds2));
     // pre-pass: if some pair is longer than a wave's planes the tile kernel takes the whole batch, else the wave kernel
     std::lock_guard<std::mutex> lg(h->launchMu);
     const int evi = (int)(h->evCount % bbduk_handle::EV_RING);
@@ -848,16 +908,16 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
     HIP_TRY(h, hipEventRecord(h->ev0[evi], st));
     kp.wave<<<dim3(wgrid), dim3(BLOCK_THREADS), waveLdsUse, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
-    kp.tile<<<dim3(tgrid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
+    kp.tile<<<dim3(tgrid), dim3(BLOCK_THREADS), dynLds2, st>>>(K2, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
     HIP_TRY(h, hipEventRecord(h->ev1[evi], st));                    // around both: whichever of the two took the batch (the other returns at once)
     h->evCount++;
     {   // reads beyond BBDUK_MAX_READ_LEN: chunked scan, one wave per unit (returns at once unless the pre-pass asked for it)
-        const batch_kernel_t lk = K.mode == BBDUK_MODE_KFILTER ? ((K.big || K.seed) ? bbduk_long_kernel<BBDUK_MODE_KFILTER, true> : bbduk_long_kernel<BBDUK_MODE_KFILTER>) :
-                                  (K.mode == BBDUK_MODE_KTRIM_L ? bbduk_long_kernel<BBDUK_MODE_KTRIM_L> : bbduk_long_kernel<BBDUK_MODE_KTRIM_R>);
-        HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(lk), dynLds));
+        const batch_kernel_t lk = K2.mode == BBDUK_MODE_KFILTER ? ((K2.big || K2.seed) ? bbduk_long_kernel<BBDUK_MODE_KFILTER, true> : bbduk_long_kernel<BBDUK_MODE_KFILTER>) :
+                                  (K2.mode == BBDUK_MODE_KTRIM_L ? bbduk_long_kernel<BBDUK_MODE_KTRIM_L> : bbduk_long_kernel<BBDUK_MODE_KTRIM_R>);
+        HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(lk), dynLds2));
         const int64_t units = paired ? n / 2 : n;
         const int lgrid = (int)std::min<int64_t>((units + NWAVES - 1) / NWAVES, (int64_t)h->numCU);
-        lk<<<dim3(std::max(lgrid, 1)), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
+        lk<<<dim3(std::max(lgrid, 1)), dim3(BLOCK_THREADS), dynLds2, st>>>(K2, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
     }
     HIP_TRY(h, hipEventRecord(h->evDone[evi], st));
     HIP_TRY(h, hipGetLastError());

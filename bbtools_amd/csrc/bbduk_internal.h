@@ -69,6 +69,9 @@ struct bbduk_handle {
     std::vector<int32_t> hvals;
     int64_t nkeys = 0;
     uint64_t* d_tags = nullptr; uint4* d_bkv = nullptr; uint64_t nbuckets = 0; int bucketBits = 0;
+    // A big-layout map of 2^20..2^25 keys keeps a cache-resident map of the same keys beside it (bbduk_hip.hip: build_both): batches with units
+    // beyond a wave's planes run the tile / long-read kernels, whose big-layout instantiations look every key up on its own
+    uint64_t* d_tagsAlt = nullptr; uint4* d_bkvAlt = nullptr; uint32_t* d_ldsAlt = nullptr; uint64_t nbucketsAlt = 0; int bucketBitsAlt = 0, ldsBitsAlt = 0; bool hasAlt = false;
     // big layout (HBM-resident maps): 8 * bigLines tag words, slot-parallel keys / ids; d_tags / d_bkv = the secondary map of the spilled keys
     bool big = false; uint64_t* d_bigTags = nullptr; uint64_t* d_bigKeys = nullptr; void* d_bigIds = nullptr; int bigIdBytes = 0; uint32_t bigLines = 0;
     int gm = 0, gW = 0, gH = 0, gD = 0; int64_t nspilled = 0;
@@ -103,7 +106,7 @@ struct bbduk_handle {
     int numCU = 256;
     bbduk_comm* comm = nullptr;          // set by bbduk_comm_create / bbduk_comm_create_local
     // include/bbduk_test_hooks.h (tests and experiments only)
-    bool hookForceTile = false, hookBigLayout = false, hookPairScan = false, hookSeedLayout = false; int hookBucketBits = 0, hookLdsBits = -1, hookDbg = 0;
+    bool hookForceTile = false, hookBigLayout = false, hookNoBigLayout = false, hookPairScan = false, hookSeedLayout = false; int hookBucketBits = 0, hookLdsBits = -1, hookDbg = 0;
 };
 
 #define HIP_TRY(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \

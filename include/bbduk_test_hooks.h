@@ -17,7 +17,8 @@ extern "C" {
                                        and the tests that keep the pair scan's candidate form covered (tables beyond 2^28 buckets use it) */
 #define BBDUK_HOOK_SEED_LAYOUT  7   /* before a device build: value != 0 asks for the seed layout (parents under their halves) at any size, where it is
                                        served (kfilter hdist=1, see bbduk_seed.inc) */
-#define BBDUK_HOOK_BIG_LAYOUT   5   /* before finalize / device build: value != 0 forces the HBM-resident map layout at any size */
+#define BBDUK_HOOK_BIG_LAYOUT   5   /* before finalize / device build: value > 0 forces the HBM-resident map layout at any size, value < 0 keeps it
+                                       from being chosen (A/B runs of the cache-resident layout at sizes that would take it) */
 int  bbduk_test_hook(bbduk_handle* h, int32_t which, int64_t value);
 /* the same controls on the map behind a Seal handle (include/seal_gpu.h), before seal_finalize */
 struct seal_handle;

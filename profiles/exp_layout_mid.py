@@ -10,21 +10,21 @@ import numpy as np
 
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--reads", type=int, default=20_000_000)
-    ap.add_argument("--genomes", default="500000,1000000,2000000,4600000,10000000,30000000"); ap.add_argument("--args", default="k=31 hdist=0"); ap.add_argument("--layouts", default="default,big")
+    ap.add_argument("--genomes", default="500000,1000000,2000000,4600000,10000000,30000000"); ap.add_argument("--args", default="k=31 hdist=0"); ap.add_argument("--layouts", default="default,big"); ap.add_argument("--read-len", type=int, default=150); ap.add_argument("--contam-frac", type=float, default=0.01)
     a = ap.parse_args()
     import torch
     from bbtools_amd import bbduk as B
-    n_pairs = a.reads // 2; n = 2 * n_pairs
-    d_bases = torch.empty(n * 150, dtype=torch.uint8, device="cuda"); d_off = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    RL = a.read_len; n_pairs = a.reads * 150 // RL // 2; n = 2 * n_pairs
+    d_bases = torch.empty(n * RL, dtype=torch.uint8, device="cuda"); d_off = torch.empty(n + 1, dtype=torch.int64, device="cuda")
     d_a = torch.empty(n, dtype=torch.int32, device="cuda"); d_id = torch.empty_like(d_a); d_fl = torch.empty(n, dtype=torch.uint8, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
     for G in [int(x) for x in a.genomes.split(",")]:
         genome = np.frombuffer(b"ACGT", np.uint8)[np.random.default_rng(G).integers(0, 4, G)].tobytes()
-        B.synth_generate_device(B.synth_params(3, contam=genome, contam_frac=0.01), 0, n_pairs, d_bases, d_off, 0)
+        B.synth_generate_device(B.synth_params(3, read_len=RL, ins_min=max(50, RL // 3), ins_max=max(350, 2 * RL), contam=genome, contam_frac=a.contam_frac), 0, n_pairs, d_bases, d_off, 0)
         ref = None
         for layout in a.layouts.split(","):
             try:
-                duk = B.BBDuk(a.args, refs=[genome], build="device", hooks={"big": {B.HOOK_BIG_LAYOUT: 1}, "seed": {B.HOOK_SEED_LAYOUT: 1}}.get(layout))
+                duk = B.BBDuk(a.args, refs=[genome], build="device", hooks={"big": {B.HOOK_BIG_LAYOUT: 1}, "seed": {B.HOOK_SEED_LAYOUT: 1}, "cache": {B.HOOK_BIG_LAYOUT: -1}}.get(layout))
                 d_c = torch.zeros(duk.gpu.counters_len, dtype=torch.int64, device="cuda")
                 for _ in range(4):
                     d_c.zero_(); duk.gpu.process_batch_device(d_bases, d_off, True, d_a, d_id, d_fl, d_c, st)
@@ -33,7 +33,7 @@ def main():
                 sig = (int(d_a.sum().item()), int(d_id.sum().item()), int(d_fl.sum().item()), d_c.cpu().numpy()[:10].tolist())
                 ref = ref or sig
                 print(json.dumps({"genome_bases": G, "layout": layout, "keys": int(duk.stored_kmers), "table_bytes": int(duk.gpu.table_bytes),
-                                  "kernel_ms": round(ms, 3), "Gbases_per_s": round(n * 150 / ms / 1e6, 1), "readsKFiltered": int(sig[3][4]), "same_answers": sig == ref}), flush=True)
+                                  "kernel_ms": round(ms, 3), "read_len": RL, "Gbases_per_s": round(n * RL / ms / 1e6, 1), "readsKFiltered": int(sig[3][4]), "same_answers": sig == ref}), flush=True)
                 duk.close()
             except Exception as e:
                 print(json.dumps({"genome_bases": G, "layout": layout, "error": repr(e)}), flush=True)

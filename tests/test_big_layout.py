@@ -203,4 +203,18 @@ def test_layout_chosen_by_key_count(args, okw, genome, want_big):
             assert np.array_equal(ga, oa) and np.array_equal(gi, oi) and np.array_equal(gf, of)
             assert np.array_equal(d.gpu.counters(), o.counters())
         assert int((oa > 0).sum()) > 100
+        # units beyond a wave's planes (tile kernel) and beyond the tiles (long-read kernel): a big-layout map of this size answers them from its
+        # cache-resident twin (build_both), the others from the one map they have
+        rng = random.Random(genome)
+        cut = lambda n: g[(p0 := rng.randrange(0, len(g) - n)):p0 + n]
+        longs = [util.rand_seq(rng, 3000), util.rand_seq(rng, 1400) + cut(200) + util.rand_seq(rng, 1400), util.rand_seq(rng, 30000) + cut(64), util.rand_seq(rng, 150),
+                 cut(5000), util.rand_seq(rng, 2600), util.rand_seq(rng, 64000), cut(40) + util.rand_seq(rng, 45000)]
+        for reads in (longs[:2] + [util.rand_seq(rng, 150) for _ in range(600)], longs):
+            bb, oo = pack_reads(reads)
+            for paired in (True, False):
+                d.gpu.reset_counters(); o.reset_counters()
+                ga, gi, gf = d.gpu.process_batch(bb, oo, paired)
+                oa, oi, of = o.process_batch(bb, oo, paired, nthreads=4)
+                assert np.array_equal(ga, oa) and np.array_equal(gi, oi) and np.array_equal(gf, of), (args, build, paired)
+                assert np.array_equal(d.gpu.counters(), o.counters())
         d.close()
