@@ -353,6 +353,7 @@ static bool seed_geometry(bbduk_handle* h) {
 // lines are faster: 58-64 against 60-130).
 #define BIG_LAYOUT_MIN_KEYS (1LL << 20)
 #define SEED_LAYOUT_MIN_KEYS (1LL << 25)
+#define BIG_PLAIN_MIN_KEYS (1LL << 21)             // plain lines (hdist > 0 on the reference side) take over later than minimizer lines: build_both
 
 // expected number of keys (an upper bound is fine) -> layout, allocations
 static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdist2) {
@@ -456,7 +457,7 @@ static int build_add_pieces(bbduk_handle* h, const uint8_t* d_refs, const int64_
     return BBDUK_OK;
 }
 
-static int build_end_impl(bbduk_handle* h) {
+static int build_end_impl(bbduk_handle* h, const bool canStartOver = false) {      // canStartOver: the caller still holds the keys and repeats the build with plain lines on BBDUK_ERR_NOMEM
     BuildState* st = h->build;
     auto bail = [&](int code, const char* msg) { build_release(h); table_release(h); return fail(h, code, msg); };
     unsigned long long cnt[3] = {0, 0, 0};
@@ -468,6 +469,10 @@ static int build_end_impl(bbduk_handle* h) {
         h->nkeys = (int64_t)distinct; h->ldsBits = 0;
     } else if (st->big) {
         if (cnt[1]) return bail(BBDUK_ERR_NOMEM, "the map overflowed: more keys than announced to bbduk_build_begin");
+        // Minimizer lines that spill far beyond the ~5.5 % of a random reference hold keys that crowd on few minimizers (an uploaded map of
+        // Hamming neighbourhoods: 27 % spilled at 1.8 M keys, and the scan ran at 9.8 Gbases/s through the secondary map): the callers start
+        // over with plain lines, as they do when the secondary map overflows
+        if (canStartOver && !h->bigPlain && cnt[2] > distinct / 8) return bail(BBDUK_ERR_NOMEM, "the minimizer lines are overloaded");
         h->nkeys = (int64_t)distinct; h->ldsBits = 0; h->nspilled = (int64_t)cnt[2];
     } else {
         // 4-way buckets of 15-bit fingerprints, >= 1 bucket per key (load 0.5-1 keys/bucket: ~0.1-0.4 % of buckets
@@ -555,7 +560,7 @@ static int finalize_once(bbduk_handle* h) {
             if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(BBDUK_ERR_DEVICE, "placing the pairs");
         }
     }
-    rc = build_end_impl(h);
+    rc = build_end_impl(h, true);
     if (rc == BBDUK_ERR_NOMEM && !h->bigPlain && !h->finalized) { h->bigPlain = true; continue; }
     break;
   }
@@ -571,28 +576,35 @@ static bool wants_twin(bbduk_handle* h, const double maxKeys, const int hdist) {
     (void)hdist;
     return big_layout_eligible(h->p) && big_geometry(h);
 }
-// the map just built becomes the twin: the next build starts from an empty handle
-static void stash_twin(bbduk_handle* h) {
-    h->d_tagsAlt = h->d_tags; h->d_bkvAlt = h->d_bkv; h->d_ldsAlt = h->d_ldsImage; h->nbucketsAlt = h->nbuckets; h->bucketBitsAlt = h->bucketBits; h->ldsBitsAlt = h->ldsBits;
-    h->d_tags = nullptr; h->d_bkv = nullptr; h->d_ldsImage = nullptr; h->nbuckets = 0; h->bucketBits = 0; h->ldsBits = 0; h->nkeys = 0;
-    h->finalized = false; h->hasAlt = true;
-}
 template <class Once>
 static int build_both(bbduk_handle* h, const double maxKeys, const int hdist, Once once) {
-    if (wants_twin(h, maxKeys, hdist)) {
-        h->hookNoBigLayout = true;
-        const int rc = once();
-        h->hookNoBigLayout = false;
-        if (rc != BBDUK_OK) return rc;
-        if (h->big || h->seed) return BBDUK_OK;                      // (cannot happen: the hook keeps both away)
-        stash_twin(h);
+    if (!wants_twin(h, maxKeys, hdist)) return once();
+    h->hookNoBigLayout = true;
+    int rc = once();
+    h->hookNoBigLayout = false;
+    if (rc != BBDUK_OK) return rc;
+    if (h->big || h->seed) return BBDUK_OK;                          // (cannot happen: the hook keeps both away)
+    // Plain lines (reference-side Hamming neighbourhoods) pay less than minimizer lines: up to 2^21 keys the cache-resident map alone is the faster
+    // one (1.27 M keys: 180 against 130 Gbases/s; 2.45 M: 98 / 108; 4.9 M: 72 / 87 -- profiles/r03_layout_mid_hdist1*.jsonl)
+    if (hdist > 0 && h->nkeys <= BIG_PLAIN_MIN_KEYS) return BBDUK_OK;
+    const int64_t nkeys1 = h->nkeys;
+    // the map just built becomes the twin; it is kept OUT of the handle while the second build runs (a build that fails -- and one that
+    // starts over with plain lines -- releases whatever map the handle holds)
+    uint64_t* tags = h->d_tags; uint4* bkv = h->d_bkv; uint32_t* lds = h->d_ldsImage;
+    const uint64_t nb = h->nbuckets; const int bbits = h->bucketBits, lbits = h->ldsBits;
+    h->d_tags = nullptr; h->d_bkv = nullptr; h->d_ldsImage = nullptr; h->nbuckets = 0; h->bucketBits = 0; h->ldsBits = 0; h->nkeys = 0; h->finalized = false;
+    rc = once();
+    if (rc != BBDUK_OK || !h->big) {                                 // failed, or not big after all: one cache-resident map is enough
+        hipFree(tags); hipFree(bkv); hipFree(lds);
+        return rc;
     }
-    const int rc = once();
-    if (rc == BBDUK_OK && h->hasAlt && !h->big) {                    // the second build did not come out big after all: one cache-resident map is enough
-        hipFree(h->d_tagsAlt); hipFree(h->d_bkvAlt); hipFree(h->d_ldsAlt);
-        h->d_tagsAlt = nullptr; h->d_bkvAlt = nullptr; h->d_ldsAlt = nullptr; h->hasAlt = false; h->nbucketsAlt = 0;
+    if (h->bigPlain && nkeys1 <= BIG_PLAIN_MIN_KEYS) {               // uploaded pairs that turned out to be such a map (the minimizer lines overflowed): back to the first map
+        table_release(h);
+        h->d_tags = tags; h->d_bkv = bkv; h->d_ldsImage = lds; h->nbuckets = nb; h->bucketBits = bbits; h->ldsBits = lbits; h->nkeys = nkeys1; h->finalized = true;
+        return BBDUK_OK;
     }
-    return rc;
+    h->d_tagsAlt = tags; h->d_bkvAlt = bkv; h->d_ldsAlt = lds; h->nbucketsAlt = nb; h->bucketBitsAlt = bbits; h->ldsBitsAlt = lbits; h->hasAlt = true;
+    return BBDUK_OK;
 }
 extern "C" int bbduk_finalize_table(bbduk_handle* h) {
     if (!h) return BBDUK_ERR_ARG;
@@ -661,7 +673,7 @@ static int build_device_once(bbduk_handle* h, const uint8_t* refs, const int64_t
         } while (true);
     }
     if ((rc = flush()) != BBDUK_OK) return bail(rc, "device build (enumeration)");
-    rc = build_end_impl(h);
+    rc = build_end_impl(h, true);
     if (rc == BBDUK_ERR_NOMEM && !h->bigPlain && !h->finalized) { h->bigPlain = true; continue; }
     break;
   }

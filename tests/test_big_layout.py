@@ -177,7 +177,8 @@ def _is_big(d):
 
 @pytest.mark.parametrize("args,okw,genome,want_big", [
     ("k=31", dict(k=31), 1_150_000, True),                          # plain kfilter beyond 2^20 keys: minimizer lines without any hook
-    ("k=31 hdist=1", dict(k=31, hdist=1), 14_000, True),            # 1.27 M keys of Hamming neighbourhoods: plain lines
+    ("k=31 hdist=1", dict(k=31, hdist=1), 14_000, False),           # 1.27 M keys of Hamming neighbourhoods: plain lines pay only beyond 2^21 keys
+    ("k=31 hdist=1", dict(k=31, hdist=1), 27_000, True),            # 2.45 M of them: plain lines (+ the twin)
     ("k=31", dict(k=31), 900_000, False),                           # below the threshold: the cache-resident map
     ("k=31 mkf=0.1", dict(k=31, minKmerFraction=0.1), 1_150_000, False),      # not a plain first-hit kfilter: cache-resident at 1-2 keys per bucket
     ("ktrim=r k=27", dict(k=27, ktrimRight=1), 1_150_000, False),   # ktrim: the same
