@@ -10,7 +10,7 @@ import numpy as np
 
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--reads", type=int, default=20_000_000)
-    ap.add_argument("--genomes", default="500000,1000000,2000000,4600000,10000000,30000000"); ap.add_argument("--args", default="k=31 hdist=0"); ap.add_argument("--layouts", default="default,big"); ap.add_argument("--read-len", type=int, default=150); ap.add_argument("--build", default="device"); ap.add_argument("--contam-frac", type=float, default=0.01)
+    ap.add_argument("--genomes", default="500000,1000000,2000000,4600000,10000000,30000000"); ap.add_argument("--args", default="k=31 hdist=0"); ap.add_argument("--layouts", default="default,big"); ap.add_argument("--read-len", type=int, default=150); ap.add_argument("--build", default="device"); ap.add_argument("--lds-bits", type=int, default=-1, help="BBDUK_HOOK_LDS_BITS on top of the layout hook (0 = no LDS filter)"); ap.add_argument("--contam-frac", type=float, default=0.01)
     a = ap.parse_args()
     import torch
     from bbtools_amd import bbduk as B
@@ -24,7 +24,7 @@ def main():
         ref = None
         for layout in a.layouts.split(","):
             try:
-                duk = B.BBDuk(a.args, refs=[genome], build=a.build, hooks={"big": {B.HOOK_BIG_LAYOUT: 1}, "seed": {B.HOOK_SEED_LAYOUT: 1}, "cache": {B.HOOK_BIG_LAYOUT: -1}}.get(layout))
+                duk = B.BBDuk(a.args, refs=[genome], build=a.build, hooks={**{"big": {B.HOOK_BIG_LAYOUT: 1}, "seed": {B.HOOK_SEED_LAYOUT: 1}, "cache": {B.HOOK_BIG_LAYOUT: -1}}.get(layout, {}), **({B.HOOK_LDS_BITS: a.lds_bits} if a.lds_bits >= 0 else {})} or None)
                 d_c = torch.zeros(duk.gpu.counters_len, dtype=torch.int64, device="cuda")
                 for _ in range(4):
                     d_c.zero_(); duk.gpu.process_batch_device(d_bases, d_off, True, d_a, d_id, d_fl, d_c, st)
