@@ -347,6 +347,15 @@ def main():
                     continue
                 t = time.perf_counter(); o.process_batch(hb, hoff, True, nthreads=th); probes[th] = time.perf_counter() - t
             cores = min(probes, key=probes.get)
+            try:                                      # a CPU quota names the thread count outright (r03's box: "1600000 100000" = 16 CPUs; the short probe is noisy above it)
+                with open("/sys/fs/cgroup/cpu.max") as fh:
+                    q_, p_ = fh.read().split()[:2]
+                if q_ != "max" and 1 <= int(q_) // int(p_) < avail:
+                    cores = max(1, int(q_) // int(p_))
+                    if cores not in probes:
+                        t = time.perf_counter(); o.process_batch(hb, hoff, True, nthreads=cores); probes[cores] = time.perf_counter() - t
+            except (OSError, ValueError):
+                pass
             probe = probes[cores]
             sample_pairs = int(min(n_pairs, max(100_000, 100_000 * a.cpu_seconds / max(probe, 1e-3))))
             hb, hoff = B.synth_generate_host(sp, lo, sample_pairs)
@@ -357,7 +366,7 @@ def main():
                       and np.array_equal(d_fl[:m].cpu().numpy(), of))
             out["cpu_baseline"] = {"value": round(m * READ_LEN / cpu_dt / 1e9, 4), "unit": "Gbases/s", "cores": cores,
                                    "kind": "port", "sample": "first %d reads of the same synthetic workload, %.1f s, "
-                                   "oracle/bbduk_oracle.c with %d pthreads, the fastest of %s on a 100k-pair probe; os.cpu_count() = %d "
+                                   "oracle/bbduk_oracle.c with %d pthreads (the cgroup's CPU quota if there is one, else the fastest of %s on a 100k-pair probe); os.cpu_count() = %d "
                                    "(match only, no I/O)" % (m, cpu_dt, cores, sorted(probes), os.cpu_count() or 1)}
             try:
                 with open("/sys/fs/cgroup/cpu.max") as fh:
