@@ -219,3 +219,22 @@ def test_layout_chosen_by_key_count(args, okw, genome, want_big):
                 assert np.array_equal(ga, oa) and np.array_equal(gi, oi) and np.array_equal(gf, of), (args, build, paired)
                 assert np.array_equal(d.gpu.counters(), o.counters())
         d.close()
+
+
+def test_big_layout_window_whose_first_fingerprint_match_is_an_impostor():
+    """k=17 against 4.6 M keys: a fifth of the random reads hit the map by chance, mostly with ONE window.  The candidate scan reports a window's first
+    fingerprint match; when that is another key (an impostor) the window's own key can still sit in a later way, in the alternate word or in the
+    secondary map -- the verification has to ask for it before it moves on (before the fix: 25-37 of 2 M reads lost their only hit; found at the end of
+    round 3 when the layout became the default from 2^20 keys on)."""
+    G = 4_600_000
+    g = np.frombuffer(b"ACGT", np.uint8)[np.random.default_rng(G).integers(0, 4, G)].tobytes()
+    o = Oracle(k=17); o.add_ref(g)
+    b, off = B.synth_generate_host(B.synth_params(3, contam=g, contam_frac=0.01), 0, 1_000_000)
+    oa, oi, of = o.process_batch(b, off, True, nthreads=16)
+    assert int((oa > 0).sum()) > 300_000
+    for hooks in (BIG, None):
+        d = B.BBDuk("k=17", refs=[g], build="device", hooks=hooks)
+        ga, gi, gf = d.gpu.process_batch(b, off, True)
+        bad = np.nonzero((ga != oa) | (gi != oi) | (gf != of))[0]
+        assert len(bad) == 0, (hooks, len(bad), bad[:6])
+        d.close()
