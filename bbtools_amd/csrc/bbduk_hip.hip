@@ -353,6 +353,10 @@ static bool seed_geometry(bbduk_handle* h) {
 // lines are faster: 58-64 against 60-130).
 #define BIG_LAYOUT_MIN_KEYS (1LL << 20)
 #define SEED_LAYOUT_MIN_KEYS (1LL << 25)
+// The early threshold holds for long k-mers only: the scan's line arithmetic has its 32-bit form at k = 31 (170 against the cache-resident map's 74
+// Gbases/s at 4.6 M keys) and pays less below (k = 27: 97 / 75, k = 25: 84 / 76) until the cache-resident map is the faster one (k = 21: 64 / 76,
+// k = 17: 69 / 77; profiles/r03_layout_mid_other_k.jsonl) -- those keep the old threshold, where the fingerprints alone outgrow the caches.
+static inline long long big_min_keys(const bbduk_params& p) { return p.k >= 25 ? BIG_LAYOUT_MIN_KEYS : SEED_LAYOUT_MIN_KEYS; }
 #define BIG_PLAIN_MIN_KEYS (1LL << 21)             // plain lines (hdist > 0 on the reference side) take over later than minimizer lines: build_both
 
 // expected number of keys (an upper bound is fine) -> layout, allocations
@@ -368,7 +372,7 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
     // large hdist=1 maps of the plain first-hit kfilter: the seed layout stores the parents, not their 1+3k neighbours (bbduk_seed.inc)
     st->seed = (maxKeys > (double)SEED_LAYOUT_MIN_KEYS || h->hookSeedLayout) && !h->hookBigLayout && hdist == 1 && big_layout_eligible(h->p) &&
                h->p.maxBadKmers == 0 && !h->p.forbidNs && !h->sealTable && seed_geometry(h);
-    st->big = !st->seed && !h->hookNoBigLayout && (maxKeys > (double)BIG_LAYOUT_MIN_KEYS || h->hookBigLayout) && big_layout_eligible(h->p) && !h->sealTable && big_geometry(h);
+    st->big = !st->seed && !h->hookNoBigLayout && (maxKeys > (double)big_min_keys(h->p) || h->hookBigLayout) && big_layout_eligible(h->p) && !h->sealTable && big_geometry(h);
     auto bail = [&](int code, const char* msg) { build_release(h); table_release(h); return fail(h, code, msg); };
     if (hipMalloc(&st->d_cnt, 32) != hipSuccess || hipMemsetAsync(st->d_cnt, 0, 32, h->stream) != hipSuccess) return bail(BBDUK_ERR_NOMEM, "hipMalloc");
     if (st->seed) {
@@ -572,7 +576,7 @@ static int finalize_once(bbduk_handle* h) {
 // 70 Gbases/s, 2x20000: 6.8 against 28.  The twin costs 65 bytes per key up to 2^25 keys, at most 2 GB.)  A forced layout (test hooks) stays single.
 static bool wants_twin(bbduk_handle* h, const double maxKeys, const int hdist) {
     if (h->hookBigLayout || h->hookNoBigLayout || h->hookSeedLayout || h->sealTable) return false;
-    if (!(maxKeys > (double)BIG_LAYOUT_MIN_KEYS) || maxKeys > (double)SEED_LAYOUT_MIN_KEYS) return false;
+    if (!(maxKeys > (double)big_min_keys(h->p)) || maxKeys > (double)SEED_LAYOUT_MIN_KEYS) return false;
     (void)hdist;
     return big_layout_eligible(h->p) && big_geometry(h);
 }

@@ -180,6 +180,7 @@ def _is_big(d):
     ("k=31 hdist=1", dict(k=31, hdist=1), 14_000, False),           # 1.27 M keys of Hamming neighbourhoods: plain lines pay only beyond 2^21 keys
     ("k=31 hdist=1", dict(k=31, hdist=1), 27_000, True),            # 2.45 M of them: plain lines (+ the twin)
     ("k=31", dict(k=31), 900_000, False),                           # below the threshold: the cache-resident map
+    ("k=21", dict(k=21), 1_150_000, False),                         # short k-mers: the cache-resident map is the faster one until 2^25 keys
     ("k=31 mkf=0.1", dict(k=31, minKmerFraction=0.1), 1_150_000, False),      # not a plain first-hit kfilter: cache-resident at 1-2 keys per bucket
     ("ktrim=r k=27", dict(k=27, ktrimRight=1), 1_150_000, False),   # ktrim: the same
 ])
