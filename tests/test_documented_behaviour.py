@@ -253,3 +253,79 @@ def test_seal_hip_clearzone_example(cz, want):
     n = int(assigned[0])
     assert np.asarray(ids).reshape(1, -1)[0, :n].tolist() == want and int(mx[0]) == 10
     g.close()
+
+
+# ---------------------------------------------------------------------------------------------- the other operators' descriptions (bbduk.sh)
+def _bits(mask, lo, hi):
+    return [int((mask[i >> 5] >> (i & 31)) & 1) for i in range(lo, hi)]
+
+
+def _kmask_cases():
+    """bbduk.sh:195 'kmask= Replace bases matching ref kmers with another symbol ... and processes short kmers on both ends if mink is set'."""
+    mid = rnd(61, 40) + ADAPTER[:30] + rnd(62, 30)                  # six adapter 25-mers: bases 40..69 match, nothing else
+    right = rnd(63, 88) + ADAPTER[:12]                              # the adapter's first 12 bases at the read's right end
+    left = util.revcomp(ADAPTER[:12]) + rnd(64, 88)                 # and, reverse-complemented, at its left end ("both ends")
+    return [("ktrim=n k=25 mm=f", dict(k=25, maskMiddle=0, ktrimN=1), mid, 30, (40, 70)),
+            ("ktrim=n k=25 mm=f mink=8", dict(k=25, maskMiddle=0, ktrimN=1, mink=8), right, 12, (88, 100)),
+            ("ktrim=n k=25 mm=f mink=8", dict(k=25, maskMiddle=0, ktrimN=1, mink=8), left, 12, (0, 12)),
+            ("ktrim=n k=25 mm=f", dict(k=25, maskMiddle=0, ktrimN=1), right, 0, None)]      # without mink the 12 bases are too short (Guide :39)
+
+
+def _ksplit_cases():
+    """bbduk.sh:200 'ksplit=f For single-ended reads only.  Reads will be split into pairs around the kmer.  If the kmer is at the end of the read, it
+    will be trimmed instead.  Singletons will go to out, and pairs will go to outm.'   (bases removed, leftmost, rightmost, sent to outm)"""
+    # (the split read's count of removed bases is left unchecked: the reference cuts the second piece with Read.subRead(rightmost+1, length-1), whose end is
+    # exclusive -- stream/Read.java:3731 -- so the piece loses its last base, 26 bases go instead of the k-mer's 25; both restatements carry the quirk)
+    return [(rnd(65, 40) + ADAPTER[:25] + rnd(66, 35), (None, 40, 64, True)),      # split around the k-mer: the two sides leave as a pair
+            (rnd(67, 75) + ADAPTER[:25], (25, 75, 99, False)),                     # the k-mer at the end: trimmed, a singleton
+            (rnd(68, 100), (0, -1, -1, False))]
+
+
+def _tips_cases():
+    """bbduk.sh:193 'ktrimtips=0 Set this to a positive number to perform ktrim on both ends, examining only the outermost X bases.'   (right, left)"""
+    both = ADAPTER[-25:] + rnd(69, 50) + ADAPTER[:25]
+    middle = rnd(70, 40) + ADAPTER[:25] + rnd(71, 40)               # an adapter 25-mer 40 bases from either end: outside the outermost 30
+    return [(both, (25, 25)), (middle, (0, 0))]
+
+
+def test_oracle_kmask_ksplit_ktrimtips_as_documented():
+    for args, okw, read, want_n, span in _kmask_cases():
+        o = Oracle(**okw); o.add_ref(ADAPTER)
+        b, off = pack_reads([read])
+        a, ids, fl, mask = o.process_batch_mask(b, off, False)
+        assert int(a[0]) == want_n and sum(_bits(mask, 0, len(read))) == want_n, (args, int(a[0]))
+        if span:
+            assert all(_bits(mask, *span))
+    o = Oracle(k=25, maskMiddle=0, ksplit=1); o.add_ref(ADAPTER)
+    for read, (x, lm, rm, outm) in _ksplit_cases():
+        b, off = pack_reads([read])
+        a, ids, fl, l, r = o.process_batch_split(b, off)
+        assert (int(l[0]), int(r[0]), bool(fl[0] & 2)) == (lm, rm, outm) and (x is None or int(a[0]) == x), (read, a, l, r, fl)
+    o = Oracle(k=25, maskMiddle=0, ktrimLeft=1, ktrimRight=1, restrictLeft=30, restrictRight=30); o.add_ref(ADAPTER)
+    for read, (wr, wl) in _tips_cases():
+        b, off = pack_reads([read])
+        xr, xl, ids, fl = o.process_batch_tips(b, off, False)
+        assert (int(xr[0]), int(xl[0])) == (wr, wl), (read, xr, xl)
+
+
+@pytest.mark.gpu
+def test_hip_kmask_ksplit_ktrimtips_as_documented():
+    from bbtools_amd import bbduk as B
+    for args, okw, read, want_n, span in _kmask_cases():
+        d = B.BBDuk(args, refs=[ADAPTER])
+        b, off = pack_reads([read])
+        a, ids, fl, mask = d.gpu.kmask_batch(b, off, False)
+        assert int(a[0]) == want_n and sum(_bits(mask, 0, len(read))) == want_n and (not span or all(_bits(mask, *span))), (args, int(a[0]))
+        d.close()
+    d = B.BBDuk("ksplit=t k=25 mm=f", refs=[ADAPTER])
+    for read, (x, lm, rm, outm) in _ksplit_cases():
+        b, off = pack_reads([read])
+        a, ids, fl, l, r = d.gpu.ksplit_batch(b, off)
+        assert (int(l[0]), int(r[0]), bool(fl[0] & 2)) == (lm, rm, outm) and (x is None or int(a[0]) == x)
+    d.close()
+    d = B.BBDuk("ktrimtips=30 k=25 mm=f", refs=[ADAPTER])
+    for read, (wr, wl) in _tips_cases():
+        b, off = pack_reads([read])
+        xr, xl, ids, fl = d.gpu.ktrimtips_batch(b, off, False)
+        assert (int(xr[0]), int(xl[0])) == (wr, wl)
+    d.close()
