@@ -139,7 +139,7 @@ int  bbduk_build_table_device(bbduk_handle* h, const uint8_t* refs, const int64_
                               int32_t hdist, int32_t hdist2);
 /* The same build, streamed, for references that are produced or ingested on the device or do not fit one host buffer (the 10 GB
  * reference of BASELINE configs[3]): begin announces an upper bound on the number of keys (for hdist 0: the number of reference
- * bases) -- beyond 2^20 keys (plain kfilter configurations) the map takes the HBM-resident layout, 12-14 bytes per slot at ~0.6 keys per slot, built in place;
+ * bases) -- beyond 2^20 keys (plain kfilter configurations with k >= 25; 2^21 with hdist > 0; 2^25 for shorter k-mers) the map takes the HBM-resident layout, 12-14 bytes per slot at ~0.6 keys per slot, built in place (bbduk_finalize_table and bbduk_build_table_device keep a cache-resident twin beside it up to 2^25 keys, which serves batches with units beyond 2 512 bases; the streamed build has none);
  * every add hands over WHOLE scaffolds already in HBM (d_refs device pointer, ref_offsets HOST array of n_refs+1 values starting at
  * 0; scaffold i of the call gets id first_id + i); end leaves the handle finalized.  An error ends the build and frees the map. */
 int  bbduk_build_begin(bbduk_handle* h, int64_t max_keys, int32_t hdist, int32_t hdist2);
