@@ -372,7 +372,8 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
     // large hdist=1 maps of the plain first-hit kfilter: the seed layout stores the parents, not their 1+3k neighbours (bbduk_seed.inc)
     st->seed = (maxKeys > (double)SEED_LAYOUT_MIN_KEYS || h->hookSeedLayout) && !h->hookBigLayout && hdist == 1 && big_layout_eligible(h->p) &&
                h->p.maxBadKmers == 0 && !h->p.forbidNs && !h->sealTable && seed_geometry(h);
-    st->big = !st->seed && !h->hookNoBigLayout && (maxKeys > (double)big_min_keys(h->p) || h->hookBigLayout) && big_layout_eligible(h->p) && !h->sealTable && big_geometry(h);
+    const long long bigMin = hdist > 0 ? std::max<long long>(big_min_keys(h->p), BIG_PLAIN_MIN_KEYS) : big_min_keys(h->p);      // (plain lines take over later: build_both)
+    st->big = !st->seed && !h->hookNoBigLayout && (maxKeys > (double)bigMin || h->hookBigLayout) && big_layout_eligible(h->p) && !h->sealTable && big_geometry(h);
     auto bail = [&](int code, const char* msg) { build_release(h); table_release(h); return fail(h, code, msg); };
     if (hipMalloc(&st->d_cnt, 32) != hipSuccess || hipMemsetAsync(st->d_cnt, 0, 32, h->stream) != hipSuccess) return bail(BBDUK_ERR_NOMEM, "hipMalloc");
     if (st->seed) {
