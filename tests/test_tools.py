@@ -103,3 +103,33 @@ def test_seal_comparator_on_synthesised_output(tmp_path):
     _write(str(tmp_path / "s_scafA.fq"), files["scafA"][2:]); _write(str(tmp_path / "s_scafE.fq"), files["scafE"] + moved)
     r = subprocess.run([sys.executable, tool] + args, capture_output=True, text=True)
     assert r.returncode == 1 and "DIFFERENCES" in r.stdout and moved[0][0] in r.stdout
+
+
+def test_documented_cases_export_and_check(tmp_path):
+    """tools/doc_cases.py (section 5b of the pinning kit): the exported inputs, and the checker on output synthesised from the C oracle's answers --
+    what bbduk.sh would write if it behaves as its guide says -- and on a perturbed copy."""
+    import importlib.util
+    import numpy as np
+    from oracle.oracle_ffi import Oracle, pack_reads
+    from tests.test_documented_behaviour import CASES
+    spec = importlib.util.spec_from_file_location("doc_cases", os.path.join(ROOT, "tools", "doc_cases.py"))
+    dc = importlib.util.module_from_spec(spec); spec.loader.exec_module(dc)
+    d = str(tmp_path)
+    names = dc.export(d)
+    assert names == [c[0] for c in CASES] and all(os.path.exists(os.path.join(d, n + ".args")) for n in names)
+    for name, args, okw, refs, reads, paired, want_a, want_fl in CASES:
+        o = Oracle(**okw)
+        for r in refs:
+            o.add_ref(r)
+        b, off = pack_reads(reads)
+        a, ids, fl = o.process_batch(b, off, paired)
+        ktrim = bool(okw.get("ktrimRight") or okw.get("ktrimLeft"))
+        out, outm = [], []
+        for i, rd in enumerate(reads):
+            n = max(1, len(rd) - int(a[i])) if (ktrim and a[i]) else len(rd)
+            (outm if fl[i] & 2 else out).append("@r%d\n%s\n+\n%s\n" % (i, rd[:n].decode(), "I" * n))
+        po, pm = os.path.join(d, name + ".o.fq"), os.path.join(d, name + ".m.fq")
+        open(po, "w").write("".join(out)); open(pm, "w").write("".join(outm))
+        assert dc.check(d, name, po, pm), name
+        open(po, "w").write("".join(outm)); open(pm, "w").write("".join(out))          # routed the other way round: must be reported
+        assert not dc.check(d, name, po, pm), name

@@ -78,6 +78,14 @@ if [ -x "$SEAL" ]; then
   done
 else echo "no seal.sh under $BB: the Seal fixtures were not checked"; fi
 
+# 5b. the guides' own worked examples (tests/test_documented_behaviour.py: expectations derived by hand from BBDukGuide.txt / bbduk.sh, which the
+#     restatements and the HIP operators already meet): the real tool on the same inputs
+D=$W/doc
+for name in $(python3 "$ROOT/tools/doc_cases.py" export "$D"); do
+  run "$DUK" in="$D/$name.fq" ref="$D/$name.fa" out="$D/$name.out.fq" outm="$D/$name.outm.fq" $(cat "$D/$name.args") $COMMON
+  python3 "$ROOT/tools/doc_cases.py" check "$D" "$name" "$D/$name.out.fq" "$D/$name.outm.fq" || fail=1
+done
+
 # 6. optional: the reference's own grader on the trimmed reads (names are <initial>_<remaining>)
 if [ -x "$BB/addadapters.sh" ]; then "$BB/addadapters.sh" in="$W/c2_o1.fq" in2="$W/c2_o2.fq" grade 2>&1 | tail -15; fi
 
