@@ -336,6 +336,10 @@ static bool seed_geometry(bbduk_handle* h) {
         if (__builtin_popcountll(masked) != 2) return false;      // more than one masked base
         const int base = k - 1 - __builtin_ctzll(masked) / 2;     // index of the masked base, 0 = the k-mer's first
         h->seedHl = base; h->seedHr = k - 1 - base;
+        // seed_check looks the FORWARD window up and relies on rc(mutant) carrying its masked base where the stored rc window does: true only
+        // when the mask sits on the mirror-symmetric centre (odd k).  Even k with an explicit midmasklen=1 would lose windows whose canonical
+        // strand is the other one and that differ at the masked base plus one more (36/1868 hit windows at k=30) -> plain big layout.
+        if (h->seedHl != h->seedHr) return false;
     }
     // m-mers of the halves' minimizers: two candidates per half (W = 2).  Measured on the 4.6 Mbase genome (profiles/bench_hdist_big.py,
     // 2^25 buckets): m = 10 5 Gbases/s, 11 15, 12 34, 13 46, 14 50; plain buckets 26 -- short m-mers have few values and pile their records
@@ -360,7 +364,7 @@ static inline long long big_min_keys(const bbduk_params& p) { return p.k >= 25 ?
 #define BIG_PLAIN_MIN_KEYS (1LL << 21)             // plain lines (hdist > 0 on the reference side) take over later than minimizer lines: build_both
 
 // expected number of keys (an upper bound is fine) -> layout, allocations
-static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdist2) {
+static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdist2, const bool streamed = false) {
     if (h->finalized) return fail(h, BBDUK_ERR_STATE, "table already finalized");
     if (h->build) return fail(h, BBDUK_ERR_STATE, "a table build is already in progress");
     HIP_TRY(h, hipSetDevice(h->p.device));
@@ -372,7 +376,10 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
     // large hdist=1 maps of the plain first-hit kfilter: the seed layout stores the parents, not their 1+3k neighbours (bbduk_seed.inc)
     st->seed = (maxKeys > (double)SEED_LAYOUT_MIN_KEYS || h->hookSeedLayout) && !h->hookBigLayout && hdist == 1 && big_layout_eligible(h->p) &&
                h->p.maxBadKmers == 0 && !h->p.forbidNs && !h->sealTable && seed_geometry(h);
-    const long long bigMin = hdist > 0 ? std::max<long long>(big_min_keys(h->p), BIG_PLAIN_MIN_KEYS) : big_min_keys(h->p);      // (plain lines take over later: build_both)
+    long long bigMin = hdist > 0 ? std::max<long long>(big_min_keys(h->p), BIG_PLAIN_MIN_KEYS) : big_min_keys(h->p);      // (plain lines take over later: build_both)
+    // a streamed build (bbduk_build_begin / _add_device / _end) sees the reference once and cannot keep the cache-resident twin build_both gives the
+    // other builders for units beyond a wave's planes (2x3000: 33 against 70 Gbases/s on the big layout alone): it keeps the old threshold
+    if (streamed) bigMin = std::max<long long>(bigMin, SEED_LAYOUT_MIN_KEYS);
     st->big = !st->seed && !h->hookNoBigLayout && (maxKeys > (double)bigMin || h->hookBigLayout) && big_layout_eligible(h->p) && !h->sealTable && big_geometry(h);
     auto bail = [&](int code, const char* msg) { build_release(h); table_release(h); return fail(h, code, msg); };
     if (hipMalloc(&st->d_cnt, 32) != hipSuccess || hipMemsetAsync(st->d_cnt, 0, 32, h->stream) != hipSuccess) return bail(BBDUK_ERR_NOMEM, "hipMalloc");
@@ -518,7 +525,7 @@ extern "C" int bbduk_build_begin(bbduk_handle* h, int64_t max_keys, int32_t hdis
     if (max_keys < 0 || hdist < 0 || hdist > 3 || hdist2 < 0 || hdist2 > 3) return fail(h, BBDUK_ERR_ARG, "build_begin: bad argument (the device build serves hdist <= 3)");
     std::lock_guard<std::mutex> g(h->mu);
     if (!h->hkeys.empty()) return fail(h, BBDUK_ERR_STATE, "pairs were uploaded already: finalize them instead");
-    return build_begin_impl(h, (double)max_keys, hdist, hdist2);
+    return build_begin_impl(h, (double)max_keys, hdist, hdist2, true);
 }
 extern "C" int bbduk_build_add_device(bbduk_handle* h, const uint8_t* d_refs, const int64_t* ref_offsets, int32_t n_refs, int32_t first_id) {
     if (!h) return BBDUK_ERR_ARG;

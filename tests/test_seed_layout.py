@@ -80,7 +80,9 @@ def test_seed_layout_is_not_chosen_where_it_is_not_served():
     """forbidn=t, maxbadkmers > 0, hdist = 2: the hook only asks; such handles keep the mutants (cache-resident or big layout) and stay exact"""
     rng = random.Random(8)
     refs = [util.rand_seq(rng, 200, 0.01) for _ in range(4)]
-    for args, okw in (("k=27 hdist=1 forbidn=t", dict(k=27, hdist=1, forbidN=1)), ("k=25 hdist=1 mbk=1", dict(k=25, hdist=1, maxBadKmers0=1)), ("k=21 hdist=2", dict(k=21, hdist=2))):
+    for args, okw in (("k=27 hdist=1 forbidn=t", dict(k=27, hdist=1, forbidN=1)), ("k=25 hdist=1 mbk=1", dict(k=25, hdist=1, maxBadKmers0=1)), ("k=21 hdist=2", dict(k=21, hdist=2)),
+                      # even k with an explicit one-base mask: the mask is off the mirror centre, seed_check is not exact there (ADVICE r3) -> mutants kept
+                      ("k=24 hdist=1 mm=1", dict(k=24, hdist=1, midMaskLen=1)), ("k=30 hdist=1 mm=1", dict(k=30, hdist=1, midMaskLen=1))):
         d, o = seed_pair(args, okw, refs)
         assert d.gpu.table_size == o.stored_kmers                  # the reference's keys, not records
         reads = util.fuzz_reads(rng, refs, 200, [0, 30, 31, 75, 150, 151], junk=True)
