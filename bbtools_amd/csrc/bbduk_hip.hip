@@ -200,7 +200,7 @@ extern "C" int bbduk_test_hook(bbduk_handle* h, int32_t which, int64_t value) {
     case BBDUK_HOOK_BUCKET_BITS: if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookBucketBits = (int)value; return BBDUK_OK;
     case BBDUK_HOOK_LDS_BITS:    if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookLdsBits = (int)value; return BBDUK_OK;
     case BBDUK_HOOK_SEED_LAYOUT: if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookSeedLayout = value != 0; return BBDUK_OK;
-    case BBDUK_HOOK_BIG_LAYOUT:  if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookBigLayout = value > 0; h->hookNoBigLayout = value < 0; return BBDUK_OK;
+    case BBDUK_HOOK_BIG_LAYOUT:  if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookBigLayout = value > 0; h->hookNoBigLayout = value < 0; h->hookBig52 = value == 2; return BBDUK_OK;
     case BBDUK_HOOK_TIMING_MASK:
 #ifdef BBDUK_TIMING_SWITCHES
         h->hookDbg = (int)value; return BBDUK_OK;
@@ -286,7 +286,7 @@ static void table_release(bbduk_handle* h) {       // a failed build leaves no h
     h->d_tagsAlt = nullptr; h->d_bkvAlt = nullptr; h->d_ldsAlt = nullptr; h->hasAlt = false; h->nbucketsAlt = 0;
 }
 // gapped-minimizer geometry of the big layout for this k and middle mask (see "big layout"); false: k too small for it
-static bool big_geometry(bbduk_handle* h) {
+static bool big_geometry(bbduk_handle* h, const double maxKeys = 0.0) {
     const int k = h->p.k;
     const uint64_t full = (2 * k > 63) ? ~0ULL : ~(~0ULL << (2 * k));
     const uint64_t masked = ~(uint64_t)h->p.middleMask & full;           // 2 bits per masked base
@@ -299,11 +299,21 @@ static bool big_geometry(bbduk_handle* h) {
     }
     if (H < 4) return false;
     h->gH = H; h->gD = k - H; h->gm = std::min(10, H - 1);
+    // The 32-bit variant of the line function (gap_v32, bbduk_bigs.inc's scan) serves maps of up to 2^31 keys; the 52-bit one remains for the
+    // 10^10-key map (and behind BBDUK_HOOK_BIG_LAYOUT = 2 for the tests that keep it covered at small sizes).
+    h->gV32 = maxKeys > 0.0 && maxKeys <= 2147483648.0 && !h->hookBig52;
+    if (h->gV32) {
+        // m follows the reference's size: a minimizer has to be rare in the REFERENCE (4m bits well above log2 of its positions), and
+        // every base m gives up widens the window W = H - m + 1 over which consecutive k-mers share a line: 4.6 M keys at k = 31: m = 8, W = 8,
+        // 4.5 keys per run (27 lines per 150-base read) where m = 10 gives 3.5 (34 lines); 10^9 keys keep m = 10
+        const int need = (int)std::ceil((std::log2(std::max(maxKeys, 1024.0)) + 8.0) / 4.0);
+        h->gm = std::max(std::min(6, H - 1), std::min(std::min(10, H - 1), need));
+    }
     if (h->hookLdsBits >= 4 && h->hookLdsBits <= H - 1) h->gm = h->hookLdsBits;      // (experiments: BBDUK_HOOK_LDS_BITS = m; such maps have no LDS filter)
     h->gW = h->bigPlain ? 0 : H - h->gm + 1;
     return true;
 }
-static BigGeom host_geom(const bbduk_handle* h) { BigGeom G; G.k = h->p.k; G.m = h->gm; G.W = h->gW; G.H = h->gH; G.D = h->gD; G.nlines = h->bigLines; G.middleMask = (uint64_t)h->p.middleMask; return G; }
+static BigGeom host_geom(const bbduk_handle* h) { BigGeom G; G.k = h->p.k; G.m = h->gm; G.W = h->gW; G.H = h->gH; G.D = h->gD; G.nlines = h->bigLines; G.middleMask = (uint64_t)h->p.middleMask; G.v32 = h->gV32 ? 1 : 0; return G; }
 static Sink make_sink(const bbduk_handle* h, const BuildState* st) {
     Sink S; memset(&S, 0, sizeof S);
     S.big = st->big ? 1 : 0; S.skeys = st->d_sk; S.sids = st->d_si; S.cmask = st->cslots ? st->cslots - 1 : 0;
@@ -380,7 +390,7 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
     // a streamed build (bbduk_build_begin / _add_device / _end) sees the reference once and cannot keep the cache-resident twin build_both gives the
     // other builders for units beyond a wave's planes (2x3000: 33 against 70 Gbases/s on the big layout alone): it keeps the old threshold
     if (streamed) bigMin = std::max<long long>(bigMin, SEED_LAYOUT_MIN_KEYS);
-    st->big = !st->seed && !h->hookNoBigLayout && (maxKeys > (double)bigMin || h->hookBigLayout) && big_layout_eligible(h->p) && !h->sealTable && big_geometry(h);
+    st->big = !st->seed && !h->hookNoBigLayout && (maxKeys > (double)bigMin || h->hookBigLayout) && big_layout_eligible(h->p) && !h->sealTable && big_geometry(h, maxKeys);
     auto bail = [&](int code, const char* msg) { build_release(h); table_release(h); return fail(h, code, msg); };
     if (hipMalloc(&st->d_cnt, 32) != hipSuccess || hipMemsetAsync(st->d_cnt, 0, 32, h->stream) != hipSuccess) return bail(BBDUK_ERR_NOMEM, "hipMalloc");
     if (st->seed) {
@@ -408,7 +418,13 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
         const uint64_t snb = 1ULL << sbits;
         const double perLine = 64.0 + 256.0 + 32.0 * idBytes, spillBytes = (double)snb * (8.0 + 64.0);
         uint64_t nlines = 0;
-        for (const double load : {0.6, 0.7, 0.8}) {
+        // The 32-bit variant's scan (bbduk_bigs.inc) does not look into the secondary map while it streams: a window whose primary word carries its
+        // spill bit becomes a candidate and is looked up exactly afterwards, so spilled keys should be rare -- 0.35 keys per slot: 1.1-2 % of the keys
+        // spill, 0.4-0.6 % of the absent windows meet their bit (0.6 keys per slot: 5.2 % / 2.8 %; line-load simulation, 4.6 M keys, m = 8..10).  Such
+        // maps are at most 2^31 keys = 80 GB, so the room is there; the 10^10-key map keeps 0.6.
+        const double loads32[3] = {0.35, 0.45, 0.6}, loads52[3] = {0.6, 0.7, 0.8};
+        for (int li = 0; li < 3; li++) {
+            const double load = h->gV32 ? loads32[li] : loads52[li];
             nlines = std::max<uint64_t>(64, (uint64_t)(maxKeys / (32.0 * load)) + 1);
             if ((double)nlines * perLine + spillBytes + 3e9 < (double)freeB) break;
             nlines = 0;
@@ -746,7 +762,7 @@ static KParams make_kparams(const bbduk_handle* h) {
     K.tags = h->d_tags; K.bkv = h->d_bkv; K.bucketMask = (uint32_t)(h->nbuckets - 1); K.bucketBits = h->bucketBits;
     K.storedKmers = h->nkeys; K.undef = nullptr;
     K.big = h->big ? 1 : 0; K.bigTags = h->d_bigTags; K.bigKeys = h->d_bigKeys; K.bigIds = h->d_bigIds; K.bigIdBytes = h->bigIdBytes; K.bigLines = h->bigLines;
-    K.gm = h->gm; K.gW = h->gW; K.gH = h->gH; K.gD = h->gD;
+    K.gm = h->gm; K.gW = h->gW; K.gH = h->gH; K.gD = h->gD; K.gV32 = h->gV32 ? 1 : 0;
     K.seed = h->seed ? 1 : 0; K.seedHl = h->seedHl; K.seedHr = h->seedHr; K.seedM = h->seedM;
     K.matchN = nullptr; K.matchIds = nullptr; K.matchCnt = nullptr; K.matchCap = 0;
     K.dbg = h->hookDbg;
@@ -900,6 +916,9 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     if (K.seed) {                                                 // seed layout: its own stream scan (such a map exists for the first-hit kfilter only)
         if (!firstHit) return fail(h, BBDUK_ERR_STATE, "seed-layout map with a scan that needs every hit");
         kp.wave = bbduk_pick_stream_seed(K.forbidNs != 0, packed); waveLdsUse = dynLds + WAVE_LDS_BYTES_SEED;
+    }
+    if (K.big && K.gV32 && firstHit && !h->hookPairScan) {       // big layout, 32-bit line function: its own stream scan (bbduk_bigs.inc)
+        kp.wave = bbduk_pick_bigs(packed); waveLdsUse = dynLds + WAVE_LDS_BYTES_SEED;
     }
     // a big-layout map with a cache-resident twin (build_both): the wave kernel scans the big layout, the fallbacks for units beyond a wave's
     // planes (tile kernel, long-read kernel) run their cache-resident instantiations over the twin

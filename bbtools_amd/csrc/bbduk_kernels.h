@@ -22,6 +22,7 @@ batch_kernel_t bbduk_pick_stream(int mode, bool useShort, bool forbidN, bool pac
 batch_kernel_t bbduk_pick_stream_every(int mode, bool useShort, bool forbidN, bool general);
 batch_kernel_t bbduk_pick_stream_tips(bool packed);                            // ktrim=rl, no forbidNs, specialised family
 batch_kernel_t bbduk_pick_stream_seed(bool forbidN, bool packed);              // the stream scan over a seed-layout map (bbduk_seed.inc)
+batch_kernel_t bbduk_pick_bigs(bool packed);                                  // bbduk_bigs.hip: the stream scan over a big-layout map with the 32-bit line function
 
 #ifdef BBDUK_DEVICE_INC            /* translation units that hold kernel templates */
 template <int MODE, bool SHORT, bool FORBIDN, bool GENERAL>

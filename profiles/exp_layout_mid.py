@@ -24,7 +24,7 @@ def main():
         ref = None
         for layout in a.layouts.split(","):
             try:
-                duk = B.BBDuk(a.args, refs=[genome], build=a.build, hooks={**{"big": {B.HOOK_BIG_LAYOUT: 1}, "seed": {B.HOOK_SEED_LAYOUT: 1}, "cache": {B.HOOK_BIG_LAYOUT: -1}}.get(layout, {}), **({B.HOOK_LDS_BITS: a.lds_bits} if a.lds_bits >= 0 else {})} or None)
+                duk = B.BBDuk(a.args, refs=[genome], build=a.build, hooks={**{"big": {B.HOOK_BIG_LAYOUT: 1}, "big52": {B.HOOK_BIG_LAYOUT: 2}, "bigpair": {B.HOOK_BIG_LAYOUT: 1, B.HOOK_PAIR_SCAN: 1}, "seed": {B.HOOK_SEED_LAYOUT: 1}, "cache": {B.HOOK_BIG_LAYOUT: -1}}.get(layout, {}), **({B.HOOK_LDS_BITS: a.lds_bits} if a.lds_bits >= 0 else {})} or None)
                 d_c = torch.zeros(duk.gpu.counters_len, dtype=torch.int64, device="cuda")
                 for _ in range(4):
                     d_c.zero_(); duk.gpu.process_batch_device(d_bases, d_off, True, d_a, d_id, d_fl, d_c, st)
