@@ -304,9 +304,10 @@ static bool big_geometry(bbduk_handle* h, const double maxKeys = 0.0) {
     h->gV32 = maxKeys > 0.0 && maxKeys <= 2147483648.0 && !h->hookBig52;
     if (h->gV32) {
         // m follows the reference's size: a minimizer has to be rare in the REFERENCE (4m bits well above log2 of its positions), and
-        // every base m gives up widens the window W = H - m + 1 over which consecutive k-mers share a line: 4.6 M keys at k = 31: m = 8, W = 8,
-        // 4.5 keys per run (27 lines per 150-base read) where m = 10 gives 3.5 (34 lines); 10^9 keys keep m = 10
-        const int need = (int)std::ceil((std::log2(std::max(maxKeys, 1024.0)) + 8.0) / 4.0);
+        // every base m gives up widens the window W = H - m + 1 over which consecutive k-mers share a line: 4.6 M keys at k = 31: m = 7, W = 9,
+        // 5 keys per run (24 lines per 150-base read) where m = 10 gives 3.5 (34 lines); 10^9 keys keep m = 9-10
+        // (measured, 4.6 M keys, k = 31: m = 6 224 Gbases/s -- 5.3 % of the keys spill --, 7 262, 8 255, 9 240, 10 219: ~6 bits of margin over the key count)
+        const int need = (int)std::ceil((std::log2(std::max(maxKeys, 1024.0)) + 5.5) / 4.0);
         h->gm = std::max(std::min(6, H - 1), std::min(std::min(10, H - 1), need));
     }
     if (h->hookLdsBits >= 4 && h->hookLdsBits <= H - 1) h->gm = h->hookLdsBits;      // (experiments: BBDUK_HOOK_LDS_BITS = m; such maps have no LDS filter)
@@ -419,10 +420,10 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
         const double perLine = 64.0 + 256.0 + 32.0 * idBytes, spillBytes = (double)snb * (8.0 + 64.0);
         uint64_t nlines = 0;
         // The 32-bit variant's scan (bbduk_bigs.inc) does not look into the secondary map while it streams: a window whose primary word carries its
-        // spill bit becomes a candidate and is looked up exactly afterwards, so spilled keys should be rare -- 0.35 keys per slot: 1.1-2 % of the keys
-        // spill, 0.4-0.6 % of the absent windows meet their bit (0.6 keys per slot: 5.2 % / 2.8 %; line-load simulation, 4.6 M keys, m = 8..10).  Such
+        // spill bit becomes a candidate and is looked up afterwards, so spilled keys should be rare -- 0.30 keys per slot: ~1.9 % of the keys
+        // spill, ~0.9 % of the absent windows meet their bit (0.6 keys per slot: 6.4 % / 5.5 %; line-load simulation, 4.6 M keys, m = 8..10).  Such
         // maps are at most 2^31 keys = 80 GB, so the room is there; the 10^10-key map keeps 0.6.
-        const double loads32[3] = {0.35, 0.45, 0.6}, loads52[3] = {0.6, 0.7, 0.8};
+        const double loads32[3] = {0.30, 0.45, 0.6}, loads52[3] = {0.6, 0.7, 0.8};
         for (int li = 0; li < 3; li++) {
             const double load = h->gV32 ? loads32[li] : loads52[li];
             nlines = std::max<uint64_t>(64, (uint64_t)(maxKeys / (32.0 * load)) + 1);
@@ -918,7 +919,7 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
         kp.wave = bbduk_pick_stream_seed(K.forbidNs != 0, packed); waveLdsUse = dynLds + WAVE_LDS_BYTES_SEED;
     }
     if (K.big && K.gV32 && firstHit && !h->hookPairScan) {       // big layout, 32-bit line function: its own stream scan (bbduk_bigs.inc)
-        kp.wave = bbduk_pick_bigs(packed); waveLdsUse = dynLds + WAVE_LDS_BYTES_SEED;
+        kp.wave = bbduk_pick_bigs(packed); waveLdsUse = dynLds + WAVE_LDS_BYTES_BIGS;
     }
     // a big-layout map with a cache-resident twin (build_both): the wave kernel scans the big layout, the fallbacks for units beyond a wave's
     // planes (tile kernel, long-read kernel) run their cache-resident instantiations over the twin
