@@ -18,7 +18,7 @@ OK = 0
 MODE_KFILTER, MODE_KTRIM_R, MODE_KTRIM_L, MODE_KMASK, MODE_KTRIM_TIPS, MODE_KSPLIT = 0, 1, 2, 3, 4, 5
 FLAG_DISCARDED, FLAG_REMOVED = 1, 2
 NCOUNTERS = 16
-HOOK_FORCE_TILE, HOOK_BUCKET_BITS, HOOK_LDS_BITS, HOOK_TIMING_MASK, HOOK_BIG_LAYOUT, HOOK_PAIR_SCAN, HOOK_SEED_LAYOUT = 1, 2, 3, 4, 5, 6, 7      # include/bbduk_test_hooks.h
+HOOK_FORCE_TILE, HOOK_BUCKET_BITS, HOOK_LDS_BITS, HOOK_TIMING_MASK, HOOK_BIG_LAYOUT, HOOK_PAIR_SCAN, HOOK_SEED_LAYOUT, HOOK_BIG_LOAD = 1, 2, 3, 4, 5, 6, 7, 8      # include/bbduk_test_hooks.h
 COUNTER_NAMES = ["readsIn", "basesIn", "readsKTrimmed", "basesKTrimmed", "readsKFiltered", "basesKFiltered",
                  "readsOutu", "basesOutu", "readsOutm", "basesOutm"]
 DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "data")

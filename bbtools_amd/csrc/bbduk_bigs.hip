@@ -4,12 +4,17 @@
 #include "bbduk_device.inc"
 #include "bbduk_kernels.h"
 
-template <int FMT>
+template <int MODE, bool SHORT, int FMT>
 __global__ __launch_bounds__(BLOCK_THREADS)
 void bbduk_bigs_kernel(const KParams P, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
                        const int64_t n, const int64_t totalBases, const int paired,
                        int32_t* __restrict__ outA, int32_t* __restrict__ outId, uint8_t* __restrict__ outFlags,
                        int64_t* __restrict__ counters, const int* __restrict__ slowFlag) {
-    wave_body<BBDUK_MODE_KFILTER, false, true, false, FMT, true, 5>(P, bases, offsets, n, totalBases, paired, outA, outId, outFlags, counters, slowFlag);
+    wave_body<MODE, SHORT, true, false, FMT, true, 5>(P, bases, offsets, n, totalBases, paired, outA, outId, outFlags, counters, slowFlag);
 }
-batch_kernel_t bbduk_pick_bigs(bool packed) { return packed ? bbduk_bigs_kernel<1> : bbduk_bigs_kernel<0>; }
+// kfilter (maxbadkmers = 0): one kernel per input format; ktrim=r (the large-map path of the trimming mode, round 4): with and without the short
+// k-mers of mink, input format decided per launch
+batch_kernel_t bbduk_pick_bigs(int mode, bool useShort, bool packed) {
+    if (mode == BBDUK_MODE_KTRIM_R) return useShort ? bbduk_bigs_kernel<BBDUK_MODE_KTRIM_R, true, 2> : bbduk_bigs_kernel<BBDUK_MODE_KTRIM_R, false, 2>;
+    return packed ? bbduk_bigs_kernel<BBDUK_MODE_KFILTER, false, 1> : bbduk_bigs_kernel<BBDUK_MODE_KFILTER, false, 0>;
+}

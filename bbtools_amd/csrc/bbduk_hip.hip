@@ -200,6 +200,7 @@ extern "C" int bbduk_test_hook(bbduk_handle* h, int32_t which, int64_t value) {
     case BBDUK_HOOK_BUCKET_BITS: if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookBucketBits = (int)value; return BBDUK_OK;
     case BBDUK_HOOK_LDS_BITS:    if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookLdsBits = (int)value; return BBDUK_OK;
     case BBDUK_HOOK_SEED_LAYOUT: if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookSeedLayout = value != 0; return BBDUK_OK;
+    case BBDUK_HOOK_BIG_LOAD:    if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookBigLoad = (int)value; return BBDUK_OK;
     case BBDUK_HOOK_BIG_LAYOUT:  if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookBigLayout = value > 0; h->hookNoBigLayout = value < 0; h->hookBig52 = value == 2; return BBDUK_OK;
     case BBDUK_HOOK_TIMING_MASK:
 #ifdef BBDUK_TIMING_SWITCHES
@@ -333,8 +334,10 @@ static bool params_general(const bbduk_params& p) {               // the same pr
     return p.qhdist > 0 || p.qhdist2 > 0 || p.restrictLeft > 0 || p.restrictRight > 0 || p.skipR1 || p.skipR2 || !p.rcomp ||
            (useShort && p.middleMask != -1) || p.k < 16 || p.qSkip > 1 || p.speed > 0 || p.minKmerFraction != 0.f || p.minCoveredFraction > 0.f;
 }
+// Round 4: ktrim=r too (its first-hit scan is bbduk_bigs_kernel's, its short k-mers live in the secondary map) -- such maps take the 32-bit line
+// function, i.e. up to 2^31 keys; a ktrim map beyond that is refused at build time (big_geometry_ok_for).
 static bool big_layout_eligible(const bbduk_params& p) {
-    return p.mode == BBDUK_MODE_KFILTER && !params_general(p) && !(p.kbig > p.k) && !p.findBestMatch;
+    return (p.mode == BBDUK_MODE_KFILTER || p.mode == BBDUK_MODE_KTRIM_R) && !params_general(p) && !(p.kbig > p.k) && !p.findBestMatch;
 }
 // seed layout (bbduk_seed.inc): the two halves beside the (at most one) masked middle base, each <= 16 bases
 static bool seed_geometry(bbduk_handle* h) {
@@ -392,6 +395,9 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
     // other builders for units beyond a wave's planes (2x3000: 33 against 70 Gbases/s on the big layout alone): it keeps the old threshold
     if (streamed) bigMin = std::max<long long>(bigMin, SEED_LAYOUT_MIN_KEYS);
     st->big = !st->seed && !h->hookNoBigLayout && (maxKeys > (double)bigMin || h->hookBigLayout) && big_layout_eligible(h->p) && !h->sealTable && big_geometry(h, maxKeys);
+    // ktrim=r has the stream scan of the 32-bit line function only (no pair-scan form): beyond 2^31 keys, or behind the 52-bit hook, it keeps the
+    // cache-resident layout (which refuses what it cannot index)
+    if (st->big && h->p.mode != BBDUK_MODE_KFILTER && !h->gV32) st->big = false;
     auto bail = [&](int code, const char* msg) { build_release(h); table_release(h); return fail(h, code, msg); };
     if (hipMalloc(&st->d_cnt, 32) != hipSuccess || hipMemsetAsync(st->d_cnt, 0, 32, h->stream) != hipSuccess) return bail(BBDUK_ERR_NOMEM, "hipMalloc");
     if (st->seed) {
@@ -414,8 +420,9 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
         if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return bail(BBDUK_ERR_DEVICE, "hipMemGetInfo");
         // the secondary map holds what the lines spill (both words of a key full): ~6 % of the keys at 0.6 keys per slot; its
         // buckets are sized for twice that at 2.5 keys per bucket (it keeps working, with longer chains, until it is full)
+        // (+ the short k-mers of mink, which live there alone -- big_insert: h->expectShort, where the caller can tell)
         int sbits = 10;
-        while (sbits < 29 && (double)(1ULL << sbits) < 0.12 * maxKeys / 2.5) sbits++;
+        while (sbits < 29 && (double)(1ULL << sbits) < 0.12 * maxKeys / 2.5 + h->expectShort / 2.0) sbits++;
         const uint64_t snb = 1ULL << sbits;
         const double perLine = 64.0 + 256.0 + 32.0 * idBytes, spillBytes = (double)snb * (8.0 + 64.0);
         uint64_t nlines = 0;
@@ -425,7 +432,7 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
         // maps are at most 2^31 keys = 80 GB, so the room is there; the 10^10-key map keeps 0.6.
         const double loads32[3] = {0.30, 0.45, 0.6}, loads52[3] = {0.6, 0.7, 0.8};
         for (int li = 0; li < 3; li++) {
-            const double load = h->gV32 ? loads32[li] : loads52[li];
+            const double load = (h->hookBigLoad > 0 && li == 0) ? 0.01 * h->hookBigLoad : (h->gV32 ? loads32[li] : loads52[li]);
             nlines = std::max<uint64_t>(64, (uint64_t)(maxKeys / (32.0 * load)) + 1);
             if ((double)nlines * perLine + spillBytes + 3e9 < (double)freeB) break;
             nlines = 0;
@@ -640,6 +647,8 @@ extern "C" int bbduk_finalize_table(bbduk_handle* h) {
     std::lock_guard<std::mutex> g(h->mu);
     if (h->finalized) return fail(h, BBDUK_ERR_STATE, "table already finalized");
     if (h->build) return fail(h, BBDUK_ERR_STATE, "a device-side build is in progress: end it with bbduk_build_end");
+    h->expectShort = 0.0;                                            // uploaded pairs: the keys of other lengths are the short k-mers
+    { const int sh = 2 * h->p.k; for (const int64_t key : h->hkeys) if (((uint64_t)key >> sh) != 1ULL) h->expectShort += 1.0; }
     const int rc = build_both(h, (double)h->hkeys.size(), 0, [&]() { return finalize_once(h); });
     if (rc == BBDUK_OK) { h->hkeys.clear(); h->hkeys.shrink_to_fit(); h->hvals.clear(); h->hvals.shrink_to_fit(); }
     return rc;
@@ -663,7 +672,9 @@ extern "C" int bbduk_build_table_device(bbduk_handle* h, const uint8_t* refs, co
     // upper bound on the keys: every position times the variants within hdist substitutions, plus the short k-mers of mink
     auto variants = [](int len, int d) { const double t = 3.0 * len; double v = 1.0; if (d >= 1) v += t; if (d >= 2) v += t * (t - 3.0) / 2.0; if (d >= 3) v += t * (t - 3.0) * (t - 6.0) / 6.0; return v; };
     double ub = (double)total * variants(k, hdist);
-    if (useShort) for (int L = h->p.mink; L < k; L++) ub += 2.0 * (double)n_refs * variants(L, hdist2);
+    h->expectShort = 0.0;
+    if (useShort) for (int L = h->p.mink; L < k; L++) h->expectShort += 2.0 * (double)n_refs * variants(L, hdist2);
+    ub += h->expectShort;
     return build_both(h, ub, hdist, [&]() { return build_device_once(h, refs, ref_offsets, n_refs, hdist, hdist2, ub); });
 }
 static int build_device_once(bbduk_handle* h, const uint8_t* refs, const int64_t* ref_offsets, const int32_t n_refs, const int32_t hdist, const int32_t hdist2, const double ub) {
@@ -918,8 +929,9 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
         if (!firstHit) return fail(h, BBDUK_ERR_STATE, "seed-layout map with a scan that needs every hit");
         kp.wave = bbduk_pick_stream_seed(K.forbidNs != 0, packed); waveLdsUse = dynLds + WAVE_LDS_BYTES_SEED;
     }
-    if (K.big && K.gV32 && firstHit && !h->hookPairScan) {       // big layout, 32-bit line function: its own stream scan (bbduk_bigs.inc)
-        kp.wave = bbduk_pick_bigs(packed); waveLdsUse = dynLds + WAVE_LDS_BYTES_BIGS;
+    if (K.big && K.gV32 && firstHit && (!h->hookPairScan || K.mode != BBDUK_MODE_KFILTER)) {      // big layout, 32-bit line function: its own stream scan (bbduk_bigs.inc)
+        kp.wave = bbduk_pick_bigs(K.mode, K.useShort != 0, packed); waveLdsUse = dynLds + WAVE_LDS_BYTES_BIGS;
+        if (K.mode == BBDUK_MODE_KTRIM_R) kp.tile = bbduk_pick_ktrim_r_big_tile();
     }
     // a big-layout map with a cache-resident twin (build_both): the wave kernel scans the big layout, the fallbacks for units beyond a wave's
     // planes (tile kernel, long-read kernel) run their cache-resident instantiations over the twin
@@ -957,7 +969,7 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     h->evCount++;
     {   // reads beyond BBDUK_MAX_READ_LEN: chunked scan, one wave per unit (returns at once unless the pre-pass asked for it)
         const batch_kernel_t lk = K2.mode == BBDUK_MODE_KFILTER ? ((K2.big || K2.seed) ? bbduk_long_kernel<BBDUK_MODE_KFILTER, true> : bbduk_long_kernel<BBDUK_MODE_KFILTER>) :
-                                  (K2.mode == BBDUK_MODE_KTRIM_L ? bbduk_long_kernel<BBDUK_MODE_KTRIM_L> : bbduk_long_kernel<BBDUK_MODE_KTRIM_R>);
+                                  (K2.mode == BBDUK_MODE_KTRIM_L ? bbduk_long_kernel<BBDUK_MODE_KTRIM_L> : (K2.big ? bbduk_long_kernel<BBDUK_MODE_KTRIM_R, true> : bbduk_long_kernel<BBDUK_MODE_KTRIM_R>));
         HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(lk), dynLds2));
         const int64_t units = paired ? n / 2 : n;
         const int lgrid = (int)std::min<int64_t>((units + NWAVES - 1) / NWAVES, (int64_t)h->numCU);

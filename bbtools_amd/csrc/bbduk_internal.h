@@ -77,6 +77,7 @@ struct bbduk_handle {
     bool big = false; uint64_t* d_bigTags = nullptr; uint64_t* d_bigKeys = nullptr; void* d_bigIds = nullptr; int bigIdBytes = 0; uint32_t bigLines = 0;
     int gm = 0, gW = 0, gH = 0, gD = 0; int64_t nspilled = 0; bool gV32 = false;
     bool seed = false; int seedHl = 0, seedHr = 0, seedM = 0;   // seed layout: parents only, under their halves (large hdist=1 maps built on the device)
+    double expectShort = 0.0;            // short k-mers of mink the next build will see (they live in the secondary map of a big-layout map)
     bool bigPlain = false;               // lines by a plain key hash instead of the gapped minimizer (gW = 0)
     bool sealTable = false;              // the map of a seal_handle: record ids may be SEAL_MULTI | offset; always the cache-resident layout
     // streaming device-side build (bbduk_build_begin / _add_device / _end)
@@ -107,7 +108,7 @@ struct bbduk_handle {
     int numCU = 256;
     bbduk_comm* comm = nullptr;          // set by bbduk_comm_create / bbduk_comm_create_local
     // include/bbduk_test_hooks.h (tests and experiments only)
-    bool hookForceTile = false, hookBigLayout = false, hookNoBigLayout = false, hookPairScan = false, hookSeedLayout = false, hookBig52 = false; int hookBucketBits = 0, hookLdsBits = -1, hookDbg = 0;
+    bool hookForceTile = false, hookBigLayout = false, hookNoBigLayout = false, hookPairScan = false, hookSeedLayout = false, hookBig52 = false; int hookBucketBits = 0, hookLdsBits = -1, hookDbg = 0, hookBigLoad = 0;
 };
 
 #define HIP_TRY(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \

@@ -14,6 +14,7 @@ KernelPair bbduk_pick_ktrim_r(bool general, bool useShort, bool forbidN);       
 KernelPair bbduk_pick_ktrim_l(bool general, bool useShort, bool forbidN);       // bbduk_k_ktriml.hip
 KernelPair bbduk_pick_kfilter(bool general, bool forbidN);                      // bbduk_k_kfilter.hip
 KernelPair bbduk_pick_kfilter_big(bool forbidN);                                // bbduk_k_kfilter.hip (HBM-resident layout)
+batch_kernel_t bbduk_pick_ktrim_r_big_tile();                                   // bbduk_k_ktrimr.hip: units beyond a wave's planes against a big-layout ktrim=r map
 // the other modes of bbduk_wave_kernel: BBDUK_MODE_FBM / _KBIG (bbduk_k_modes_a.hip), _KSPLIT / _KTRIM_TIPS / _KMASK (bbduk_k_modes_b.hip)
 batch_kernel_t bbduk_pick_mode_wave(int mode, bool general, bool packed, bool forbidN);
 // the stream kernels (bbduk_stream.hip): mode = BBDUK_MODE_KTRIM_R | BBDUK_MODE_KFILTER
@@ -22,7 +23,7 @@ batch_kernel_t bbduk_pick_stream(int mode, bool useShort, bool forbidN, bool pac
 batch_kernel_t bbduk_pick_stream_every(int mode, bool useShort, bool forbidN, bool general);
 batch_kernel_t bbduk_pick_stream_tips(bool packed);                            // ktrim=rl, no forbidNs, specialised family
 batch_kernel_t bbduk_pick_stream_seed(bool forbidN, bool packed);              // the stream scan over a seed-layout map (bbduk_seed.inc)
-batch_kernel_t bbduk_pick_bigs(bool packed);                                  // bbduk_bigs.hip: the stream scan over a big-layout map with the 32-bit line function
+batch_kernel_t bbduk_pick_bigs(int mode, bool useShort, bool packed);                                 // bbduk_bigs.hip: the stream scan over a big-layout map with the 32-bit line function
 
 #ifdef BBDUK_DEVICE_INC            /* translation units that hold kernel templates */
 template <int MODE, bool SHORT, bool FORBIDN, bool GENERAL>

@@ -19,6 +19,8 @@ extern "C" {
                                        served (kfilter hdist=1, see bbduk_seed.inc) */
 #define BBDUK_HOOK_BIG_LAYOUT   5   /* before finalize / device build: value > 0 forces the HBM-resident map layout at any size, value < 0 keeps it
                                        from being chosen (A/B runs of the cache-resident layout at sizes that would take it) */
+#define BBDUK_HOOK_BIG_LOAD     8   /* before finalize / device build: keys per 100 slots the big layout's lines are sized for (0 = the default); value 2 of
+                                       BBDUK_HOOK_BIG_LAYOUT forces the 52-bit line function and its pair scan below 2^31 keys too */
 int  bbduk_test_hook(bbduk_handle* h, int32_t which, int64_t value);
 /* the same controls on the map behind a Seal handle (include/seal_gpu.h), before seal_finalize */
 struct seal_handle;

@@ -35,7 +35,7 @@ def keys_of(windows, k=31, mm=True):
 def run(ref_bases=1e10, scaffold_bases=10_000_000, chunk_scaffolds=50, reads=20_000_000, steps=3, check_reads=50_000, oracle_bases=50_000_000, fallback_reads=0):
     import types
     return _run(types.SimpleNamespace(ref_bases=ref_bases, scaffold_bases=scaffold_bases, chunk_scaffolds=chunk_scaffolds, reads=reads, steps=steps,
-                                      check_reads=check_reads, oracle_bases=oracle_bases, pair_scan=False, fallback_reads=fallback_reads))
+                                      check_reads=check_reads, oracle_bases=oracle_bases, pair_scan=False, big52=False, gm=0, ktrim=False, fallback_reads=fallback_reads))
 
 
 def main():
@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--check-reads", type=int, default=50_000)
     ap.add_argument("--pair-scan", action="store_true", help="experiments: the pair-scan kernel of round 2 instead of the stream kernel")
+    ap.add_argument("--ktrim", action="store_true", help="ktrim=r k=31 against the same reference (round 4: the trimming mode's large-map path) instead of kfilter")
+    ap.add_argument("--big52", action="store_true", help="experiments: the 52-bit line function and its pair scan below 2^31 keys too")
     ap.add_argument("--gm", type=int, default=0, help="experiments: minimizer length m of the big layout's lines (W = H - m + 1)")
     ap.add_argument("--oracle-bases", type=int, default=50_000_000, help="prefix of scaffold 1.. the contaminated reads are drawn from (and the oracle indexes)")
     a = ap.parse_args()
@@ -59,13 +61,15 @@ def _run(a):
     ref_bases = int(a.ref_bases)
     n_scaf = max(1, ref_bases // a.scaffold_bases)
     ref_bases = n_scaf * a.scaffold_bases
-    host = B.HostIndex("k=31 hdist=0")
+    host = B.HostIndex("ktrim=r k=31 hdist=0" if getattr(a, "ktrim", False) else "k=31 hdist=0")
     p = host.params(0); p.numScaffolds = n_scaf + 1
     gpu = B.BBDukGpu(p)
     if getattr(a, "pair_scan", False):
         gpu.test_hook(B.HOOK_PAIR_SCAN, 1)
     if getattr(a, "gm", 0):
         gpu.test_hook(B.HOOK_LDS_BITS, a.gm)
+    if getattr(a, "big52", False):                                  # the 52-bit line function + the pair scan (what maps beyond 2^31 keys take) at any size
+        gpu.test_hook(B.HOOK_BIG_LAYOUT, 2)
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")
     t0 = time.perf_counter()
     gpu.build_begin(ref_bases, 0, 0)
@@ -137,13 +141,14 @@ def _run(a):
                 "readsKFiltered": int(c[4]), "device_status": int(c[15])})
     if a.check_reads > 0:
         from oracle.oracle_ffi import Oracle
-        o = Oracle(k=31); o.add_ref(contam)
+        o = Oracle(k=31, ktrimRight=1) if getattr(a, "ktrim", False) else Oracle(k=31); o.add_ref(contam)
         m = min(n, a.check_reads) & ~1
         hb, hoff = B.synth_generate_host(sp, 0, m // 2)
         oa, oi, of = o.process_batch(hb, hoff, True, nthreads=os.cpu_count())
         ga = d_a[:m].cpu().numpy(); gi = d_id[:m].cpu().numpy(); gf = d_fl[:m].cpu().numpy()
         diff = np.nonzero((ga != oa) | (gi != oi) | (gf != of))[0]
         out["checked_reads"] = int(m); out["checked_reads_differ"] = int(len(diff)); out["checked_reads_hit"] = int((oa > 0).sum())
+        out["readsKTrimmed"] = int(c[2])
         # a difference is legitimate only if the device found a k-mer of the reference OUTSIDE the oracle's part of it
         out["differ_device_hit_oracle_miss"] = int(((ga[diff] > 0) & (oa[diff] == 0)).sum()) if len(diff) else 0
     gpu.close(); host.close()

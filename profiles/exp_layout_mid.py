@@ -11,7 +11,7 @@ import numpy as np
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--reads", type=int, default=20_000_000)
     ap.add_argument("--genomes", default="500000,1000000,2000000,4600000,10000000,30000000"); ap.add_argument("--args", default="k=31 hdist=0"); ap.add_argument("--layouts", default="default,big"); ap.add_argument("--read-len", type=int, default=150); ap.add_argument("--build", default="device"); ap.add_argument("--lds-bits", type=int, default=-1, help="BBDUK_HOOK_LDS_BITS on top of the layout hook (0 = no LDS filter)"); ap.add_argument("--contam-frac", type=float, default=0.01)
-    ap.add_argument("--lib", default="", help="experiment build under bbtools_amd/ (ab_tsw: stage deletion)"); ap.add_argument("--masks", default="0", help="timing masks (a+b = bits), comma-separated: big layout stream scan: 3 no scan, 5 no staging, 7 no decide, 11 no walk, 12 no N pass, 13 no gathers, 16 no back half, 19 no minimizer")
+    ap.add_argument("--big-load", type=int, default=0, help="BBDUK_HOOK_BIG_LOAD: keys per 100 slots"); ap.add_argument("--lib", default="", help="experiment build under bbtools_amd/ (ab_tsw: stage deletion)"); ap.add_argument("--masks", default="0", help="timing masks (a+b = bits), comma-separated: big layout stream scan: 3 no scan, 5 no staging, 7 no decide, 11 no walk, 12 no N pass, 13 no gathers, 16 no back half, 19 no minimizer")
     a = ap.parse_args()
     import torch
     from bbtools_amd import bbduk as B
@@ -28,7 +28,7 @@ def main():
           for m in a.masks.split(","):
             bits = sum(1 << int(b) for b in m.split("+")) if m != "0" else 0
             try:
-                duk = B.BBDuk(a.args, refs=[genome], build=a.build, hooks={**{"big": {B.HOOK_BIG_LAYOUT: 1}, "big52": {B.HOOK_BIG_LAYOUT: 2}, "bigpair": {B.HOOK_BIG_LAYOUT: 1, B.HOOK_PAIR_SCAN: 1}, "seed": {B.HOOK_SEED_LAYOUT: 1}, "cache": {B.HOOK_BIG_LAYOUT: -1}}.get(layout, {}), **({B.HOOK_LDS_BITS: a.lds_bits} if a.lds_bits >= 0 else {}), **({B.HOOK_TIMING_MASK: bits} if bits else {})} or None)
+                duk = B.BBDuk(a.args, refs=[genome], build=a.build, hooks={**{"big": {B.HOOK_BIG_LAYOUT: 1}, "big52": {B.HOOK_BIG_LAYOUT: 2}, "bigpair": {B.HOOK_BIG_LAYOUT: 1, B.HOOK_PAIR_SCAN: 1}, "seed": {B.HOOK_SEED_LAYOUT: 1}, "cache": {B.HOOK_BIG_LAYOUT: -1}}.get(layout, {}), **({B.HOOK_LDS_BITS: a.lds_bits} if a.lds_bits >= 0 else {}), **({B.HOOK_TIMING_MASK: bits} if bits else {}), **({B.HOOK_BIG_LOAD: a.big_load} if a.big_load else {})} or None)
                 d_c = torch.zeros(duk.gpu.counters_len, dtype=torch.int64, device="cuda")
                 for _ in range(4):
                     d_c.zero_(); duk.gpu.process_batch_device(d_bases, d_off, True, d_a, d_id, d_fl, d_c, st)

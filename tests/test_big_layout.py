@@ -14,26 +14,32 @@ from tests.test_gpu_parity import check_batch, FUZZ
 
 pytestmark = pytest.mark.gpu
 BIG = {B.HOOK_BIG_LAYOUT: 1}
+BIG52 = {B.HOOK_BIG_LAYOUT: 2}            # the 52-bit line function and its pair scan (what maps beyond 2^31 keys take) at test sizes
 
 
-def big_pair(args, okw, refs=None, ref_fasta=None, build="host"):
+def big_pair(args, okw, refs=None, ref_fasta=None, build="host", hooks=BIG):
     o = Oracle(**okw)
     if refs is not None:
-        d = B.BBDuk(args, refs=refs, hooks=BIG, build=build)
+        d = B.BBDuk(args, refs=refs, hooks=hooks, build=build)
         for r in refs:
             o.add_ref(r)
     else:
-        d = B.BBDuk(args, hooks=BIG, build=build)
+        d = B.BBDuk(args, hooks=hooks, build=build)
         o.load_fasta(ref_fasta)
     assert d.gpu.table_size == o.stored_kmers
     return d, o
 
 
-@pytest.mark.parametrize("build", ["host", "device"])
+@pytest.mark.parametrize("build", ["host", "device", "device52"])
 @pytest.mark.parametrize("cfg", ["c4s", "c3", "c2", "c1", "c5", "c3q", "c3mcf", "c3mkf"])
 def test_big_layout_on_the_baseline_configs(cfg, build):
     args, okw, ref = util.CONFIGS[cfg]
-    d, o = big_pair(args, okw, ref_fasta=ref, build=build)
+    hooks = BIG
+    if build == "device52":
+        if cfg not in ("c4s", "c3"):
+            pytest.skip("the 52-bit variant's own scan serves the plain kfilter")
+        build, hooks = "device", BIG52
+    d, o = big_pair(args, okw, ref_fasta=ref, build=build, hooks=hooks)
     assert d.gpu.table_bytes >= 64 * (64 + 256 + 64)               # whole 32-slot lines
     ks, vs = o.dump_pairs()
     rng = np.random.default_rng(3)
@@ -66,7 +72,7 @@ def test_big_layout_fuzz(ci):
     for seed in range(2):
         rng = random.Random(7000 + 100 * ci + seed)
         refs = [util.rand_seq(rng, rng.randint(5, 90), 0.01) for _ in range(8)]
-        d, o = big_pair(args, okw, refs=refs, build="host")
+        d, o = big_pair(args, okw, refs=refs, build="host", hooks=BIG52 if seed == 1 and ci in (0, 1, 2, 3) else BIG)
         reads = util.fuzz_reads(rng, refs, 600, [0, 1, 2, 5, 10, 11, 22, 23, 30, 31, 32, 40, 63, 64, 65, 75, 150, 151, 300], junk=True)
         check_batch(d, o, reads, True)
         check_batch(d, o, reads[:301], False)
@@ -182,7 +188,8 @@ def _is_big(d):
     ("k=31", dict(k=31), 900_000, False),                           # below the threshold: the cache-resident map
     ("k=21", dict(k=21), 1_150_000, False),                         # short k-mers: the cache-resident map is the faster one until 2^25 keys
     ("k=31 mkf=0.1", dict(k=31, minKmerFraction=0.1), 1_150_000, False),      # not a plain first-hit kfilter: cache-resident at 1-2 keys per bucket
-    ("ktrim=r k=27", dict(k=27, ktrimRight=1), 1_150_000, False),   # ktrim: the same
+    ("ktrim=r k=27", dict(k=27, ktrimRight=1), 1_150_000, True),    # ktrim=r: minimizer lines too since round 4 (bbduk_bigs_kernel<KTRIM_R>)
+        ("ktrim=l k=27", dict(k=27, ktrimLeft=1), 1_150_000, False),    # the every-hit scans have no big-layout form: cache-resident
 ])
 def test_layout_chosen_by_key_count(args, okw, genome, want_big):
     """The layouts as the library picks them by itself (round 3: the big layout from 2^20 keys on for the configurations that have its scan,
@@ -238,4 +245,42 @@ def test_big_layout_window_whose_first_fingerprint_match_is_an_impostor():
         ga, gi, gf = d.gpu.process_batch(b, off, True)
         bad = np.nonzero((ga != oa) | (gi != oi) | (gf != of))[0]
         assert len(bad) == 0, (hooks, len(bad), bad[:6])
+        d.close()
+
+
+@pytest.mark.parametrize("args,okw", [("ktrim=r k=31", dict(k=31, ktrimRight=1)),
+                                      ("ktrim=r k=27 mink=12", dict(k=27, mink=12, ktrimRight=1)),
+                                      ("ktrim=r k=25 mink=11 hdist=1", dict(k=25, mink=11, hdist=1, ktrimRight=1)),
+                                      ("ktrim=r k=23 mm=f tpe", dict(k=23, maskMiddle=0, ktrimRight=1, trimPairsEvenly=1)),
+                                      ("ktrim=r k=29 forbidn=t hdist=1 tp=2 minlen=30", dict(k=29, forbidN=1, hdist=1, ktrimRight=1, trimPad=2, minReadLength=30))])
+def test_big_layout_ktrim_right(args, okw):
+    """ktrim=r against a big-layout map (round 4: bbduk_bigs_kernel<KTRIM_R>): first hit by the stream scan over the minimizer lines, the short
+    k-mers of mink out of the secondary map, units beyond a wave's planes through the tiled and the long-read kernels' exact lookups"""
+    rng = random.Random(len(args))
+    refs = [util.rand_seq(rng, 6000, 0.002), util.rand_seq(rng, 900), util.rand_seq(rng, 40), util.rand_seq(rng, 2500)]
+    for build in ("device", "host"):
+        d, o = big_pair(args, okw, refs=refs, build=build)
+        assert d.gpu.table_bytes >= 64 * (64 + 256 + 64)
+        ks, vs = o.dump_pairs()
+        assert np.array_equal(d.gpu.table_lookup(ks), vs)          # the short k-mers too
+        reads = util.fuzz_reads(rng, refs, 800, [0, 1, 10, 11, 12, 24, 25, 30, 31, 32, 75, 100, 150, 151, 250, 300], junk=True)
+        for i in range(200):                                        # reads that run into a reference piece, cut at every distance from their end
+            r = bytearray(util.rand_seq(rng, rng.choice([100, 150, 151])))
+            src = refs[rng.choice([0, 0, 1, 3])]; a = rng.randrange(len(src) - 60); cut = rng.randint(5, 60)
+            piece = bytearray(src[a:a + cut])
+            if rng.random() < 0.3: piece[rng.randrange(len(piece))] = rng.choice(b"ACGTN")
+            w = len(r) - cut if rng.random() < 0.6 else rng.randrange(len(r) - cut)
+            r[w:w + cut] = piece
+            reads.append(bytes(r))
+        if len(reads) % 2: reads.pop()
+        check_batch(d, o, reads, True)
+        check_batch(d, o, reads[:401], False)
+        long_reads = []
+        for i in range(24):                                         # 4 kb pairs (tile kernel) and one 60 kb read (long-read kernel)
+            n = 60000 if i == 7 else rng.choice([150, 4000])
+            r = bytearray(util.rand_seq(rng, n))
+            if rng.random() < 0.6:
+                src = refs[0]; a = rng.randrange(len(src) - 80); w = rng.randrange(n - 80); r[w:w + 80] = src[a:a + 80]
+            long_reads.append(bytes(r))
+        check_batch(d, o, long_reads, True)
         d.close()
