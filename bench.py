@@ -123,6 +123,14 @@ def measure_configs(B, reads, c4_ref_bases, c4_reads=0):
         res["C7_hdist0_genome"] = {k: r[k] for k in ("workload", "keys", "table_bytes", "build_s", "reads", "kernel_ms", "Gbases_per_s", "readsKFiltered")}
     except Exception as e:
         res["C7_hdist0_genome"] = {"error": repr(e)}
+    # round 4: the same genome at BBDuk's default k = 27, and as a ktrim=r reference (the trimming mode's large-map path);
+    # all three on bbduk_bigs_kernel, the stream scan over the minimizer lines (bbduk_bigs.inc)
+    for name, args in (("C8_k27_genome", "k=27 hdist=0"), ("C9_ktrim_genome", "ktrim=r k=31 hdist=0")):
+        try:
+            r = bench_hdist_big.run(reads=reads, args=args)
+            res[name] = {k: r[k] for k in ("workload", "keys", "table_bytes", "build_s", "reads", "kernel_ms", "Gbases_per_s", "readsKFiltered", "readsKTrimmed")}
+        except Exception as e:
+            res[name] = {"error": repr(e)}
     if c4_ref_bases > 0:
         # BASELINE configs[3]: kfilter k=31 hdist=0 against a seeded uniform-random reference (default: the full 10 Gbases, ~10^10 keys,
         # a 239 GB map resident in HBM in the big layout), generated and indexed on the device chunk by chunk, 1 % of the pairs
@@ -329,6 +337,24 @@ def main():
                        # measured wave-instructions per read, echoed from the committed counter pass (null if none is committed)
                        "issue_counters": issue}
 
+    if rank == 0 and world == 1 and not packed and not a.no_extras:
+        # the same launch on the packed boundary format (2-bit codes + undefined bits, what the device ingest produces anyway;
+        # DESIGN 4.7) as one extra field -- never `value`, which stays on the reference's byte-per-base Read.bases
+        try:
+            d_codes = torch.empty((n * READ_LEN + 15) // 16 + 4, dtype=torch.int32, device="cuda")
+            d_undef = torch.empty((n * READ_LEN + 31) // 32 + 4, dtype=torch.int32, device="cuda")
+            B.pack_bases_device(d_bases, d_codes, d_undef, dev)
+            d_a2 = torch.empty_like(d_a); d_id2 = torch.empty_like(d_id); d_fl2 = torch.empty_like(d_fl); d_c2 = torch.zeros_like(d_ctr)
+            for _ in range(1 + 3):
+                d_c2.zero_(); duk.gpu.process_batch_packed_device(d_codes, d_undef, d_off, n * READ_LEN, True, d_a2, d_id2, d_fl2, d_c2, stream)
+            torch.cuda.synchronize()
+            pk_ms = duk.gpu.kernel_time_ms(3)
+            out["packed_format"] = {"kernel_ms": round(pk_ms, 3), "Gbases_per_s": round(n * READ_LEN / (pk_ms * 1e-3) / 1e9, 1),
+                                    "same_results_as_ascii": bool(torch.equal(d_a2, d_a) and torch.equal(d_id2, d_id) and torch.equal(d_fl2, d_fl)),
+                                    "note": "kernel rate of the same launch on 2-bit codes + undefined bits (bbduk_ktrim_batch_packed_device); secondary"}
+            del d_codes, d_undef, d_a2, d_id2, d_fl2, d_c2
+        except Exception as e:
+            out["packed_format"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
             # CPU baseline: the oracle (a C restatement of the reference's loops, NOT the Java reference: no JVM

@@ -50,10 +50,10 @@ def _run(a):
     torch.cuda.synchronize()
     ms = duk.gpu.kernel_time_ms(a.steps)
     c = d_c.cpu().tolist()
-    out = {"workload": "kfilter %s vs a random %d-base genome (BBDukGuide.txt:34's E. coli example), 2x150 bp, 1 %% of the pairs from the genome" % (a.args, a.genome_bases),
+    out = {"workload": "%s vs a random %d-base genome (BBDukGuide.txt:34's E. coli example), 2x150 bp, 1 %% of the pairs from the genome" % (a.args if "ktrim" in a.args else "kfilter " + a.args, a.genome_bases),
            "keys": int(duk.stored_kmers), "table_bytes": int(duk.gpu.table_bytes), "spilled_keys": int(duk.gpu.table_spilled) if hasattr(duk.gpu, "table_spilled") else None,
            "build_s": round(build_s, 2), "reads": n, "kernel_ms": round(ms, 3), "Gbases_per_s": round(n * 150 / ms / 1e6, 1),
-           "readsKFiltered": int(c[B.COUNTER_NAMES.index("readsKFiltered")])}
+           "readsKFiltered": int(c[B.COUNTER_NAMES.index("readsKFiltered")]), "readsKTrimmed": int(c[B.COUNTER_NAMES.index("readsKTrimmed")])}
     if a.check_reads:
         from oracle.oracle_ffi import Oracle
         o = Oracle(k=31, hdist=1); o.add_ref(genome[:a.oracle_bases])
