@@ -50,7 +50,7 @@ class SynthParams(C.Structure):     # struct bbduk_synth_params
 
 # every symbol include/bbduk_gpu.h and include/bbduk_host.h declare
 GPU_SYMBOLS = ["bbduk_abi_version", "bbduk_create", "bbduk_destroy", "bbduk_last_error", "bbduk_upload_table_way",
-               "bbduk_upload_pairs", "bbduk_finalize_table", "bbduk_build_table_device", "bbduk_table_size", "bbduk_table_bytes",
+               "bbduk_upload_pairs", "bbduk_finalize_table", "bbduk_build_table_device", "bbduk_build_table_device_edits", "bbduk_table_size", "bbduk_table_bytes",
                "bbduk_table_lookup", "bbduk_ktrim_batch", "bbduk_kfilter_batch", "bbduk_ktrim_batch_device",
                "bbduk_kfilter_batch_device", "bbduk_pack_bases_host", "bbduk_pack_bases_device", "bbduk_ktrim_batch_packed",
                "bbduk_kfilter_batch_packed", "bbduk_ktrim_batch_packed_device", "bbduk_kfilter_batch_packed_device", "bbduk_kmask_batch", "bbduk_kmask_batch_device", "bbduk_ktrimtips_batch", "bbduk_ktrimtips_batch_device", "bbduk_ksplit_batch", "bbduk_kfilter_batch_matches", "bbduk_kfilter_batch_matches_device", "bbduk_ksplit_batch_device", "bbduk_kmask_batch_packed_device", "bbduk_ktrimtips_batch_packed_device", "bbduk_fastq_ingest_device", "bbduk_fastq_write_device", "bbduk_fastq_write_masked_device", "bbduk_device_malloc", "bbduk_device_free", "bbduk_pinned_malloc", "bbduk_pinned_free",
@@ -214,6 +214,7 @@ def lib():
     L.bbduk_host_upload_index.argtypes = [vp, vp]
     L.bbduk_host_build_on_device.argtypes = [vp, vp]
     L.bbduk_build_table_device.argtypes = [vp, vp, vp, i32, i32, i32]
+    L.bbduk_build_table_device_edits.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32]
     L.bbduk_test_hook.argtypes = [vp, i32, i64]
     L.bbduk_table_line_histogram.argtypes = [vp, vp]
     L.bbduk_table_spilled.restype = i64

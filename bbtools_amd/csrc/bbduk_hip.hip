@@ -267,7 +267,7 @@ extern "C" int bbduk_upload_table_way(bbduk_handle* h, int32_t way, int32_t prim
 // the distinct count, LDS filter) and the big one (in place).  BuildState lives from begin to end.
 struct BuildState {
     bool seed = false;                   // the seed layout (bbduk_seed.inc): parents under their halves, inserted in place
-    bool big = false; int hdist = 0, hdist2 = 0;
+    bool big = false; int hdist = 0, hdist2 = 0, edist = 0, edist2 = 0;      // edist / edist2 (<= 1): bbduk_build_table_device_edits
     uint64_t* d_sk = nullptr; int32_t* d_si = nullptr; uint64_t cslots = 0;     // scratch set of the two-pass build
     unsigned long long* d_cnt = nullptr;                                        // [0] distinct, [1] overflow flag
     uint8_t* d_stage = nullptr; size_t stageCap = 0;                            // upload staging of bbduk_build_table_device / finalize
@@ -476,7 +476,7 @@ static int build_add_pieces(bbduk_handle* h, const uint8_t* d_refs, const int64_
     HIP_TRY(h, hipMemcpyAsync(st->d_rfl, rfl, (size_t)npieces, hipMemcpyHostToDevice, h->stream));
     BuildParams B;
     B.k = h->p.k; B.mink = h->p.mink; B.useShort = (h->p.mink > 0 && h->p.mink < h->p.k) ? 1 : 0; B.hdist = st->hdist; B.hdist2 = st->hdist2;
-    B.rcomp = h->p.rcomp; B.middleMask = (uint64_t)h->p.middleMask; B.totalBases = total; B.nrefs = npieces;
+    B.rcomp = h->p.rcomp; B.middleMask = (uint64_t)h->p.middleMask; B.totalBases = total; B.nrefs = npieces; B.edist = st->edist; B.edist2 = st->edist2;
     if (st->seed) {
         const int grid = (int)std::min<int64_t>((total + 255) / 256, (int64_t)h->numCU * 32);
         bbduk_build_seed_kernel<<<dim3(std::max(grid, 1)), dim3(256), 0, h->stream>>>(B, d_refs, st->d_roff, st->d_rid, h->seedHl, h->seedHr, h->seedM, make_sink(h, st));
@@ -484,7 +484,8 @@ static int build_add_pieces(bbduk_handle* h, const uint8_t* d_refs, const int64_
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         return BBDUK_OK;
     }
-    const int V1 = (st->hdist > 0 || (B.useShort && st->hdist2 > 0)) ? 1 + 3 * B.k : 1;
+    const bool edits = (st->hdist > 0 && st->edist > 0) || (B.useShort && st->hdist2 > 0 && st->edist2 > 0);
+    const int V1 = edits ? 8 * B.k - 4 : ((st->hdist > 0 || (B.useShort && st->hdist2 > 0)) ? 1 + 3 * B.k : 1);      // first-level choices per position (emit_variants / emit_edits1)
     const int64_t work = total * (int64_t)V1;
     const int grid = (int)std::min<int64_t>((work + 255) / 256, (int64_t)h->numCU * 32);
     bbduk_build_enum_kernel<<<dim3(std::max(grid, 1)), dim3(256), 0, h->stream>>>(B, d_refs, st->d_roff, st->d_rid, st->d_rfl, V1, make_sink(h, st));
@@ -656,10 +657,17 @@ extern "C" int bbduk_finalize_table(bbduk_handle* h) {
 
 // bbduk_build_table_device: the reference sequences are HOST memory here; they go to the device in chunks of whole scaffolds
 // (a scaffold longer than a chunk as pieces that overlap by k-1 bases) through bbduk_build_begin / build_add_pieces / bbduk_build_end.
-static int build_device_once(bbduk_handle* h, const uint8_t* refs, const int64_t* ref_offsets, const int32_t n_refs, const int32_t hdist, const int32_t hdist2, const double ub);
+static int build_device_once(bbduk_handle* h, const uint8_t* refs, const int64_t* ref_offsets, const int32_t n_refs, const int32_t hdist, const int32_t hdist2, const double ub,
+                             const int32_t edist, const int32_t edist2);
 extern "C" int bbduk_build_table_device(bbduk_handle* h, const uint8_t* refs, const int64_t* ref_offsets, int32_t n_refs,
                                         int32_t hdist, int32_t hdist2) {
+    return bbduk_build_table_device_edits(h, refs, ref_offsets, n_refs, hdist, hdist2, 0, 0);
+}
+extern "C" int bbduk_build_table_device_edits(bbduk_handle* h, const uint8_t* refs, const int64_t* ref_offsets, int32_t n_refs,
+                                              int32_t hdist, int32_t hdist2, int32_t edist, int32_t edist2) {
     if (!h) return BBDUK_ERR_ARG;
+    if (edist < 0 || edist > 1 || edist2 < 0 || edist2 > 1) return fail(h, BBDUK_ERR_ARG, "the device build serves edist <= 1 (as bbduk_host_parse does)");
+    if ((edist > 0 && hdist < edist) || (edist2 > 0 && hdist2 < edist2)) return fail(h, BBDUK_ERR_ARG, "hdist must be max(edist, hdist) as BBDukParser.java:146 leaves it");
     std::lock_guard<std::mutex> g(h->mu);
     if (h->finalized) return fail(h, BBDUK_ERR_STATE, "table already finalized");
     if (!h->hkeys.empty()) return fail(h, BBDUK_ERR_STATE, "pairs were uploaded already: finalize them instead");
@@ -670,21 +678,26 @@ extern "C" int bbduk_build_table_device(bbduk_handle* h, const uint8_t* refs, co
     if (n_refs + 1 != h->p.numScaffolds) return fail(h, BBDUK_ERR_ARG, "numScaffolds given to bbduk_create must be n_refs + 1");
     const int k = h->p.k; const bool useShort = h->p.mink > 0 && h->p.mink < k;
     // upper bound on the keys: every position times the variants within hdist substitutions, plus the short k-mers of mink
-    auto variants = [](int len, int d) { const double t = 3.0 * len; double v = 1.0; if (d >= 1) v += t; if (d >= 2) v += t * (t - 3.0) / 2.0; if (d >= 3) v += t * (t - 3.0) * (t - 6.0) / 6.0; return v; };
-    double ub = (double)total * variants(k, hdist);
+    auto variants = [](int len, int d, int ed) {
+        if (d > 0 && ed > 0) return 8.0 * len - 4.0;               // emit_edits1: the k-mer, 3 len substitutions, len-1 deletions, 4 (len-1) insertions
+        const double t = 3.0 * len; double v = 1.0; if (d >= 1) v += t; if (d >= 2) v += t * (t - 3.0) / 2.0; if (d >= 3) v += t * (t - 3.0) * (t - 6.0) / 6.0; return v; };
+    double ub = (double)total * variants(k, hdist, edist);
     h->expectShort = 0.0;
-    if (useShort) for (int L = h->p.mink; L < k; L++) h->expectShort += 2.0 * (double)n_refs * variants(L, hdist2);
+    if (useShort) for (int L = h->p.mink; L < k; L++) h->expectShort += 2.0 * (double)n_refs * variants(L, hdist2, edist2);
     ub += h->expectShort;
-    return build_both(h, ub, hdist, [&]() { return build_device_once(h, refs, ref_offsets, n_refs, hdist, hdist2, ub); });
+    return build_both(h, ub, hdist, [&]() { return build_device_once(h, refs, ref_offsets, n_refs, hdist, hdist2, ub, edist, edist2); });
 }
-static int build_device_once(bbduk_handle* h, const uint8_t* refs, const int64_t* ref_offsets, const int32_t n_refs, const int32_t hdist, const int32_t hdist2, const double ub) {
+static int build_device_once(bbduk_handle* h, const uint8_t* refs, const int64_t* ref_offsets, const int32_t n_refs, const int32_t hdist, const int32_t hdist2, const double ub,
+                             const int32_t edist, const int32_t edist2) {
     const int k = h->p.k;
+    const bool edits = edist > 0 || edist2 > 0;
     const int64_t total = n_refs > 0 ? ref_offsets[n_refs] : 0;
     int rc = BBDUK_OK;
   for (int attempt = 0; attempt < 2; attempt++) {                  // second attempt: plain lines, if the minimizer lines spilled too much
     rc = build_begin_impl(h, ub, hdist, hdist2);
     if (rc != BBDUK_OK) return rc;
     BuildState* st = h->build;
+    st->edist = edist; st->edist2 = edist2;
     auto bail = [&](int code, const char* msg) { build_release(h); table_release(h); return fail(h, code, msg); };
     const int64_t CH = 256LL << 20;                                 // bases per upload
     st->stageCap = (size_t)std::min<int64_t>(std::max<int64_t>(total, 16), CH) + 64;
@@ -709,7 +722,7 @@ static int build_device_once(bbduk_handle* h, const uint8_t* refs, const int64_t
             srcOff.push_back(s0 + pos); roff.push_back(roff.back() + len); rid.push_back(sidx + 1);
             rfl.push_back((uint8_t)((pos == 0 ? 1 : 0) | (pos + len == n ? 2 : 0)));
             if (pos + len == n) break;
-            pos += len - (k - 1);
+            pos += len - (edits ? k : k - 1);                       // (edits: one base more, so that the next piece sees the base behind this piece's last window)
         } while (true);
     }
     if ((rc = flush()) != BBDUK_OK) return bail(rc, "device build (enumeration)");

@@ -473,7 +473,7 @@ extern "C" int bbduk_host_params(const bbduk_host* h, int32_t device, bbduk_para
 extern "C" int bbduk_host_build_on_device(const bbduk_host* h, bbduk_handle* dev) {
     if (!h || !dev) return BBDUK_ERR_ARG;
     const Parsed& p = h->p;
-    if (p.edist > 0 || p.edist2 > 0 || p.hdist > 3 || p.hdist2 > 3) return BBDUK_ERR_ARG;      // the host builder / upload path serves those
+    if (p.edist > 1 || p.edist2 > 1 || p.hdist > 3 || p.hdist2 > 3) return BBDUK_ERR_ARG;      // (edist = 1 goes to bbduk_build_table_device_edits since round 4)
     for (const auto& sc : h->scaffolds) {                                                       // so does it serve reference-side skipping
         const int64_t n = (int64_t)sc.size();
         const int heur = n > 20000000 ? p.k : n > 5000000 ? 11 : n > 500000 ? 2 : 0;
@@ -482,7 +482,7 @@ extern "C" int bbduk_host_build_on_device(const bbduk_host* h, bbduk_handle* dev
     std::vector<uint8_t> cat; std::vector<int64_t> off(1, 0);
     for (const auto& s : h->scaffolds) { cat.insert(cat.end(), s.begin(), s.end()); off.push_back((int64_t)cat.size()); }
     if (cat.empty()) cat.push_back(0);
-    return bbduk_build_table_device(dev, cat.data(), off.data(), (int32_t)h->scaffolds.size(), p.hdist, p.hdist2);
+    return bbduk_build_table_device_edits(dev, cat.data(), off.data(), (int32_t)h->scaffolds.size(), p.hdist, p.hdist2, p.edist, p.edist2);
 }
 
 extern "C" int bbduk_host_upload_index(const bbduk_host* h, bbduk_handle* dev) {

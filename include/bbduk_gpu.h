@@ -137,6 +137,10 @@ int  bbduk_finalize_table(bbduk_handle* h);
  * k, mink, rcomp, middleMask come from bbduk_create.  Leaves the handle finalized. */
 int  bbduk_build_table_device(bbduk_handle* h, const uint8_t* refs, const int64_t* ref_offsets, int32_t n_refs,
                               int32_t hdist, int32_t hdist2);
+/* The same with reference-side EDIT distance (edist / edist2 <= 1: substitutions, deletions, insertions -- BBDukIndexMod.java:383-445 with
+ * editDistance > 0; hdist / hdist2 as BBDukParser.java:146 leaves them, i.e. max(edist, hdist)).  Round 4: until then only the host builder. */
+int  bbduk_build_table_device_edits(bbduk_handle* h, const uint8_t* refs, const int64_t* ref_offsets, int32_t n_refs,
+                                    int32_t hdist, int32_t hdist2, int32_t edist, int32_t edist2);
 /* The same build, streamed, for references that are produced or ingested on the device or do not fit one host buffer (the 10 GB
  * reference of BASELINE configs[3]): begin announces an upper bound on the number of keys (for hdist 0: the number of reference
  * bases) -- beyond 2^20 keys (plain kfilter configurations with k >= 25; 2^21 with hdist > 0; 2^25 for shorter k-mers) the map takes the HBM-resident layout, 12-14 bytes per slot at ~0.6 keys per slot, built in place (bbduk_finalize_table and bbduk_build_table_device keep a cache-resident twin beside it up to 2^25 keys, which serves batches with units beyond 2 512 bases; the streamed build has none);

@@ -58,7 +58,9 @@ def main():
     while time.time() - t0 < a.seconds and not (a.only is not None and it):
         seed = a.seed * 1_000_003 + it if a.only is None else a.only; it += 1
         rng = random.Random(seed)
-        fam = rng.choice(a.families.split(",") if a.families else ["base", "base", "base", "tails", "kmask", "tips", "ksplit", "big", "fbm", "seal", "tf1bp"])
+        fam = rng.choice(a.families.split(",") if a.families else ["base", "base", "base", "tails", "kmask", "tips", "ksplit", "big", "fbm", "seal", "tf1bp", "bigmap", "bigmap"])
+        bigmap = fam == "bigmap"                               # base configurations with the HBM-resident map layout asked for (round 4: bbduk_bigs_kernel for
+        if bigmap: fam = "base"                                # kfilter and ktrim=r, the 52-bit variant's pair scan, the exact scans for the rest)
         tails = fam == "tails"                                 # base configurations on reads that overshoot the pair scan's blocks by 1..32 positions:
         if tails: fam = "base"                                 # (block borders of the stream scan / the every-hit scans' tail pass)
         if fam == "tf1bp":                                     # trimfailuresto1bp over every operator family (units within the main kernel's planes)
@@ -169,6 +171,10 @@ def main():
                 bb = max(4, math.ceil(math.log2(o.stored_kmers / 3.4)))
                 if rng.random() < 0.7: hooks[B.HOOK_BUCKET_BITS] = bb; squeeze += " bucketbits=%d" % bb
                 if rng.random() < 0.6: lb = rng.choice([0, 10, 12]); hooks[B.HOOK_LDS_BITS] = lb; squeeze += " ldsbits=%d" % lb
+            if bigmap:
+                hooks = {B.HOOK_BIG_LAYOUT: rng.choice([1, 1, 1, 2]), B.HOOK_BIG_LOAD: rng.choice([0, 0, 30, 60, 95])}
+                if rng.random() < 0.5: hooks[B.HOOK_LDS_BITS] = rng.choice([4, 6, 7, 8, 9, 10, 12])      # (m of the minimizer lines)
+                squeeze = " bigmap=%r" % (sorted(hooks.items()),)
             d = B.BBDuk(args, refs=refs, build=build, hooks=hooks)
             if squeeze: fam_count["squeezed"] = fam_count.get("squeezed", 0) + 1
             assert d.stored_kmers == o.stored_kmers, ("stored", d.stored_kmers, o.stored_kmers)

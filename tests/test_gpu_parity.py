@@ -553,7 +553,11 @@ def test_random_flag_combinations(block):
 DEVBUILD = [("ktrim=r k=23 mink=11 hdist=1", dict(k=23, ktrimRight=1, mink=11, hdist=1)), ("k=31 hdist=1", dict(k=31, hdist=1)),
             ("k=27", dict(k=27)), ("ktrim=l k=13 mink=6 hdist=1 hdist2=0", dict(k=13, ktrimLeft=1, mink=6, hdist=1, hdist2=0)),
             ("k=11 hdist=2 mm=f", dict(k=11, hdist=2, maskMiddle=0)), ("ktrim=r k=12 mink=5 hdist=2 hdist2=2 rcomp=f", dict(k=12, ktrimRight=1, mink=5, hdist=2, hdist2=2, rcomp=0)),
-            ("k=20 hdist=1 mm=2", dict(k=20, hdist=1, midMaskLen=2)), ("ktrim=n k=16 mink=16 hdist=1", dict(k=16, ktrimN=1, mink=16, hdist=1))]
+            ("k=20 hdist=1 mm=2", dict(k=20, hdist=1, midMaskLen=2)), ("ktrim=n k=16 mink=16 hdist=1", dict(k=16, ktrimN=1, mink=16, hdist=1)),
+            # reference-side edit distance on the device (round 4; BBDukIndexMod.java:414-445): substitutions, deletions, insertions
+            ("k=21 edist=1", dict(k=21, hdist=1, edist=1)), ("ktrim=r k=17 mink=8 edist=1 mm=f", dict(k=17, ktrimRight=1, mink=8, hdist=1, edist=1, maskMiddle=0)),
+            ("ktrim=l k=15 mink=7 edist=1 edist2=0 rcomp=f", dict(k=15, ktrimLeft=1, mink=7, hdist=1, hdist2=0, edist=1, edist2=0, rcomp=0)),
+            ("ktrim=r k=19 mink=9 hdist=1 edist2=1", dict(k=19, ktrimRight=1, mink=9, hdist=1, hdist2=1, edist=0, edist2=1))]
 
 
 @pytest.mark.parametrize("ci", range(len(DEVBUILD)))
