@@ -340,7 +340,7 @@ static bool big_layout_eligible(const bbduk_params& p) {
     return (p.mode == BBDUK_MODE_KFILTER || p.mode == BBDUK_MODE_KTRIM_R) && !params_general(p) && !(p.kbig > p.k) && !p.findBestMatch;
 }
 // seed layout (bbduk_seed.inc): the two halves beside the (at most one) masked middle base, each <= 16 bases
-static bool seed_geometry(bbduk_handle* h) {
+static bool seed_geometry(bbduk_handle* h, const double maxKeys = 0.0) {
     const int k = h->p.k;
     if (k < 16 || k > 31) return false;
     const uint64_t full = ~(~0ULL << (2 * k));
@@ -359,6 +359,14 @@ static bool seed_geometry(bbduk_handle* h) {
     // 2^25 buckets): m = 10 5 Gbases/s, 11 15, 12 34, 13 46, 14 50; plain buckets 26 -- short m-mers have few values and pile their records
     // on few lines (chains of overflowed buckets, walked with dependent gathers), long ones still put a lane's two positions on one line
     h->seedM = std::min(h->seedHl, h->seedHr) - 1;
+    // Round 4 (the scan no longer hides it: profiles/r04_seed_m_sweep.txt, 4.6 Mbase genome, halves of 15): m = 14 74 Gbases/s, 13 98.6, 12 118, 11 43
+    // -- a shorter m-mer widens the window over which neighbouring halves share a line (W = H - m + 1: 2, 3, 4), until the m-mers are too few for
+    // the reference's H-mers (2 x windows of them: 4^11 = 4.2 M against 9.2 M) and pile their records on few lines.  So: 4^m ~ 2 x the H-mers.
+    if (maxKeys > 0.0) {
+        const double windows = std::max(maxKeys / (1.0 + 3.0 * k), 1024.0);
+        const int mm = (int)std::lround((std::log2(2.0 * windows) + 1.0) / 2.0);
+        h->seedM = std::max(8, std::min(std::min(h->seedHl, h->seedHr) - 1, mm));
+    }
     if (h->hookLdsBits == 0) h->seedM = 0;                        // (experiments: BBDUK_HOOK_LDS_BITS = 0 -> plain buckets, no minimizer lines; 6.. = m)
     else if (h->hookLdsBits >= 6 && h->hookLdsBits <= std::min(h->seedHl, h->seedHr) - 1) h->seedM = h->hookLdsBits;
     return h->seedHl >= 7 && h->seedHr >= 7 && h->seedHl <= 16 && h->seedHr <= 16;
@@ -389,7 +397,7 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
     if (hdist > 0) h->bigPlain = true;
     // large hdist=1 maps of the plain first-hit kfilter: the seed layout stores the parents, not their 1+3k neighbours (bbduk_seed.inc)
     st->seed = (maxKeys > (double)SEED_LAYOUT_MIN_KEYS || h->hookSeedLayout) && !h->hookBigLayout && hdist == 1 && big_layout_eligible(h->p) &&
-               h->p.maxBadKmers == 0 && !h->p.forbidNs && !h->sealTable && seed_geometry(h);
+               h->p.maxBadKmers == 0 && !h->p.forbidNs && !h->sealTable && seed_geometry(h, maxKeys);
     long long bigMin = hdist > 0 ? std::max<long long>(big_min_keys(h->p), BIG_PLAIN_MIN_KEYS) : big_min_keys(h->p);      // (plain lines take over later: build_both)
     // a streamed build (bbduk_build_begin / _add_device / _end) sees the reference once and cannot keep the cache-resident twin build_both gives the
     // other builders for units beyond a wave's planes (2x3000: 33 against 70 Gbases/s on the big layout alone): it keeps the old threshold
@@ -940,7 +948,7 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     }
     if (K.seed) {                                                 // seed layout: its own stream scan (such a map exists for the first-hit kfilter only)
         if (!firstHit) return fail(h, BBDUK_ERR_STATE, "seed-layout map with a scan that needs every hit");
-        kp.wave = bbduk_pick_stream_seed(K.forbidNs != 0, packed); waveLdsUse = dynLds + WAVE_LDS_BYTES_SEED;
+        kp.wave = bbduk_pick_stream_seed(K.forbidNs != 0, packed); waveLdsUse = dynLds + WAVE_LDS_BYTES_BIGS;      // (candidate planes + the verification's list)
     }
     if (K.big && K.gV32 && firstHit && (!h->hookPairScan || K.mode != BBDUK_MODE_KFILTER)) {      // big layout, 32-bit line function: its own stream scan (bbduk_bigs.inc)
         kp.wave = bbduk_pick_bigs(K.mode, K.useShort != 0, packed); waveLdsUse = dynLds + WAVE_LDS_BYTES_BIGS;
