@@ -379,6 +379,7 @@ static bool seed_geometry(bbduk_handle* h, const double maxKeys = 0.0) {
 // lines are faster: 58-64 against 60-130).
 #define BIG_LAYOUT_MIN_KEYS (1LL << 20)
 #define SEED_LAYOUT_MIN_KEYS (1LL << 25)
+#define SEED_JOINT_MIN_KEYS (1LL << 22)
 // The early threshold holds for long k-mers only: the scan's line arithmetic has its 32-bit form at k = 31 (170 against the cache-resident map's 74
 // Gbases/s at 4.6 M keys) and pays less below (k = 27: 97 / 75, k = 25: 84 / 76) until the cache-resident map is the faster one (k = 21: 64 / 76,
 // k = 17: 69 / 77; profiles/r03_layout_mid_other_k.jsonl) -- those keep the old threshold, where the fingerprints alone outgrow the caches.
@@ -396,8 +397,12 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
     // reference-side Hamming neighbourhoods put ~2/3 of a k-mer's 1+3k variants on one minimizer: such maps take plain lines
     if (hdist > 0) h->bigPlain = true;
     // large hdist=1 maps of the plain first-hit kfilter: the seed layout stores the parents, not their 1+3k neighbours (bbduk_seed.inc)
-    st->seed = (maxKeys > (double)SEED_LAYOUT_MIN_KEYS || h->hookSeedLayout) && !h->hookBigLayout && hdist == 1 && big_layout_eligible(h->p) &&
-               h->p.maxBadKmers == 0 && !h->p.forbidNs && !h->sealTable && seed_geometry(h, maxKeys);
+    // (round 4: with halves of equal length -- one gather per read position, bbduk_seed.inc -- the seed layout beats the big layout's plain lines from
+    // 2^22 keys on: a 52 kbase reference, 4.7 M keys, 115 against 87 Gbases/s; 19 M keys 159 / 75; 2.45 M keys 87 / 102 -- profiles/r04_seed_vs_plain.jsonl;
+    // up to 2^25 keys build_both keeps the cache-resident twin for the units beyond a wave's planes)
+    st->seed = (maxKeys > (double)SEED_JOINT_MIN_KEYS || h->hookSeedLayout) && !h->hookBigLayout && !h->hookNoBigLayout && hdist == 1 && big_layout_eligible(h->p) &&
+               h->p.mode == BBDUK_MODE_KFILTER && h->p.maxBadKmers == 0 && !h->p.forbidNs && !h->sealTable && seed_geometry(h, maxKeys);
+    if (st->seed && h->seedHl != h->seedHr && !(maxKeys > (double)SEED_LAYOUT_MIN_KEYS || h->hookSeedLayout)) st->seed = false;      // (the two-gather form keeps 2^25)
     long long bigMin = hdist > 0 ? std::max<long long>(big_min_keys(h->p), BIG_PLAIN_MIN_KEYS) : big_min_keys(h->p);      // (plain lines take over later: build_both)
     // a streamed build (bbduk_build_begin / _add_device / _end) sees the reference once and cannot keep the cache-resident twin build_both gives the
     // other builders for units beyond a wave's planes (2x3000: 33 against 70 Gbases/s on the big layout alone): it keeps the old threshold
@@ -639,10 +644,11 @@ static int build_both(bbduk_handle* h, const double maxKeys, const int hdist, On
     const uint64_t nb = h->nbuckets; const int bbits = h->bucketBits, lbits = h->ldsBits;
     h->d_tags = nullptr; h->d_bkv = nullptr; h->d_ldsImage = nullptr; h->nbuckets = 0; h->bucketBits = 0; h->ldsBits = 0; h->nkeys = 0; h->finalized = false;
     rc = once();
-    if (rc != BBDUK_OK || !h->big) {                                 // failed, or not big after all: one cache-resident map is enough
+    if (rc != BBDUK_OK || !(h->big || h->seed)) {                    // failed, or not big after all: one cache-resident map is enough
         hipFree(tags); hipFree(bkv); hipFree(lds);
         return rc;
     }
+    if (h->seed) h->nkeysRef = nkeys1;                               // (the twin holds the reference's keys: bbduk_table_size answers in its semantics)
     if (h->bigPlain && nkeys1 <= BIG_PLAIN_MIN_KEYS) {               // uploaded pairs that turned out to be such a map (the minimizer lines overflowed): back to the first map
         table_release(h);
         h->d_tags = tags; h->d_bkv = bkv; h->d_ldsImage = lds; h->nbuckets = nb; h->bucketBits = bbits; h->ldsBits = lbits; h->nkeys = nkeys1; h->finalized = true;
@@ -764,7 +770,7 @@ extern "C" int bbduk_table_line_histogram(bbduk_handle* h, int64_t* out33) {
     return e == hipSuccess ? BBDUK_OK : BBDUK_ERR_DEVICE;
 }
 extern "C" int64_t bbduk_table_spilled(const bbduk_handle* h) { return (h && h->finalized && h->big) ? h->nspilled : 0; }
-extern "C" int64_t bbduk_table_size(const bbduk_handle* h) { return (h && h->finalized) ? h->nkeys : -1; }
+extern "C" int64_t bbduk_table_size(const bbduk_handle* h) { return (h && h->finalized) ? ((h->seed && h->nkeysRef > 0) ? h->nkeysRef : h->nkeys) : -1; }
 extern "C" int64_t bbduk_table_bytes(const bbduk_handle* h) {
     if (!h || !h->finalized) return -1;
     if (h->big) return (int64_t)h->bigLines * (64 + 256 + 32 * h->bigIdBytes) + (int64_t)(h->nbuckets * (8 + 4 * 16)) +
@@ -805,7 +811,7 @@ static KParams make_kparams(const bbduk_handle* h) {
 
 // the same parameters over the cache-resident twin of a big-layout map (bbduk_handle::hasAlt)
 static KParams alt_kparams(const bbduk_handle* h, KParams K) {
-    K.big = 0; K.bigTags = nullptr; K.bigKeys = nullptr; K.bigIds = nullptr; K.bigLines = 0;
+    K.big = 0; K.bigTags = nullptr; K.bigKeys = nullptr; K.bigIds = nullptr; K.bigLines = 0; K.seed = 0;
     K.tags = h->d_tagsAlt; K.bkv = h->d_bkvAlt; K.bucketMask = (uint32_t)(h->nbucketsAlt - 1); K.bucketBits = h->bucketBitsAlt;
     K.ldsImage = h->d_ldsAlt; K.ldsBits = h->ldsBitsAlt;
     return K;
@@ -956,7 +962,7 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     }
     // a big-layout map with a cache-resident twin (build_both): the wave kernel scans the big layout, the fallbacks for units beyond a wave's
     // planes (tile kernel, long-read kernel) run their cache-resident instantiations over the twin
-    const bool twin = K.big && h->hasAlt;
+    const bool twin = (K.big || K.seed) && h->hasAlt;
     const KParams K2 = twin ? alt_kparams(h, K) : K;
     const size_t dynLds2 = twin ? (K2.ldsBits ? ((size_t)1 << (K2.ldsBits - 3)) : 0) : dynLds;
     if (twin) kp.tile = pick_kernel(K2).tile;

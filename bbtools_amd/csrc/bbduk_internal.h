@@ -69,6 +69,7 @@ struct bbduk_handle {
     std::vector<int64_t> hkeys;          // staged (key,value) pairs before finalize
     std::vector<int32_t> hvals;
     int64_t nkeys = 0;
+    int64_t nkeysRef = 0;                // seed layout with a twin: the reference's distinct key count (nkeys counts records there)
     uint64_t* d_tags = nullptr; uint4* d_bkv = nullptr; uint64_t nbuckets = 0; int bucketBits = 0;
     // A big-layout map of 2^20..2^25 keys keeps a cache-resident map of the same keys beside it (bbduk_hip.hip: build_both): batches with units
     // beyond a wave's planes run the tile / long-read kernels, whose big-layout instantiations look every key up on its own

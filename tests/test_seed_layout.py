@@ -107,3 +107,35 @@ def test_seed_layout_long_units():
             reads.append(bytes(r))
         check_batch(d, o, reads, True)
     d.close()
+
+
+def test_seed_layout_chosen_from_2e22_keys_with_its_twin():
+    """Round 4: a device build of k=31 hdist=1 beyond 2^22 keys (a 52 kbase reference: 4.7 M keys) takes the seed layout by itself -- joint halves,
+    one gather per read position -- and keeps the cache-resident twin for units beyond a wave's planes; bbduk_table_size answers with the reference's
+    key count.  Against the oracle: sampled keys, 2x150 reads with an N rate that puts undefined bases into most sub-tiles, long reads."""
+    G = 52_000
+    g = np.frombuffer(b"ACGT", np.uint8)[np.random.default_rng(G).integers(0, 4, G)].tobytes()
+    o = Oracle(k=31, hdist=1); o.add_ref(g)
+    d = B.BBDuk("k=31 hdist=1", refs=[g], build="device")
+    assert d.gpu.table_size == o.stored_kmers
+    assert d.gpu.table_bytes < 40 * o.stored_kmers                 # parents + twin, not 94 keys per window in a big-layout map (~100 bytes per key)
+    ks, vs = o.dump_pairs()
+    sel = np.random.default_rng(1).integers(0, len(ks), 100_000)
+    probe = np.concatenate([ks[sel], np.random.default_rng(2).integers(0, 1 << 62, 20_000, dtype=np.int64) | (np.int64(1) << 62)])
+    got = d.gpu.table_lookup(probe)
+    assert np.array_equal(got[:len(sel)], vs[sel]) and int((got[len(sel):] > 0).sum()) == 0
+    b, off = B.synth_generate_host(B.synth_params(23, n_rate=0.003, contam=g, contam_frac=0.08), 0, 20_000)
+    for paired in (True, False):
+        d.gpu.reset_counters(); o.reset_counters()
+        ga, gi, gf = d.gpu.process_batch(b, off, paired)
+        oa, oi, of = o.process_batch(b, off, paired, nthreads=8)
+        bad = np.nonzero((ga != oa) | (gi != oi) | (gf != of))[0]
+        assert len(bad) == 0, (paired, bad[:5], ga[bad[:5]], oa[bad[:5]])
+        assert np.array_equal(d.gpu.counters(), o.counters())
+    assert int((oa > 0).sum()) > 500
+    rng = random.Random(5)
+    cut = lambda n: g[(p0 := rng.randrange(0, len(g) - n)):p0 + n]
+    longs = [util.rand_seq(rng, 3000), util.rand_seq(rng, 1400) + cut(200) + util.rand_seq(rng, 1400), util.rand_seq(rng, 30000) + cut(64), util.rand_seq(rng, 150),
+             cut(5000), util.rand_seq(rng, 2600), util.rand_seq(rng, 64000), cut(40) + util.rand_seq(rng, 45000)]
+    check_batch(d, o, longs, True)
+    d.close()
