@@ -367,23 +367,22 @@ def main():
             # the thread count the sample runs with is the one a 100k-pair probe is fastest at: a box can show more cores than its
             # cgroup lets the process use (r03: 256 visible, 16 threads 1.7x faster than 256), and the baseline should be the port's best
             avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else cores
-            probes = {}
-            for th in sorted({avail, 128, 64, 32, 16}, reverse=True):
-                if th > avail:
-                    continue
-                t = time.perf_counter(); o.process_batch(hb, hoff, True, nthreads=th); probes[th] = time.perf_counter() - t
-            cores = min(probes, key=probes.get)
-            try:                                      # a CPU quota names the thread count outright (r03's box: "1600000 100000" = 16 CPUs; the short probe is noisy above it)
+            cand = {avail, 128, 64, 32, 16}
+            try:                                      # a CPU quota joins the probe set (r03's box: "1600000 100000" = 16 CPUs of 256 visible)
                 with open("/sys/fs/cgroup/cpu.max") as fh:
                     q_, p_ = fh.read().split()[:2]
                 if q_ != "max" and 1 <= int(q_) // int(p_) < avail:
-                    qc = max(1, int(q_) // int(p_))   # the quota joins the probe set; the FASTEST probe still names the thread count
-                    if qc not in probes:
-                        t = time.perf_counter(); o.process_batch(hb, hoff, True, nthreads=qc); probes[qc] = time.perf_counter() - t
-                    t = time.perf_counter(); o.process_batch(hb, hoff, True, nthreads=cores); probes[cores] = min(probes[cores], time.perf_counter() - t)
-                    cores = min(probes, key=probes.get)
+                    qc = max(1, int(q_) // int(p_)); cand |= {qc, 2 * qc, 4 * qc}
             except (OSError, ValueError):
                 pass
+            probes = {}
+            for rep in range(2):                      # two rounds, the better time counts: a single 100k-pair probe is noisy; the FASTEST names the thread count
+                for th in sorted(cand, reverse=True):
+                    if th > avail:
+                        continue
+                    t = time.perf_counter(); o.process_batch(hb, hoff, True, nthreads=th); dt_ = time.perf_counter() - t
+                    probes[th] = min(probes.get(th, dt_), dt_)
+            cores = min(probes, key=probes.get)
             probe = probes[cores]
             sample_pairs = int(min(n_pairs, max(100_000, 100_000 * a.cpu_seconds / max(probe, 1e-3))))
             hb, hoff = B.synth_generate_host(sp, lo, sample_pairs)
@@ -394,7 +393,7 @@ def main():
                       and np.array_equal(d_fl[:m].cpu().numpy(), of))
             out["cpu_baseline"] = {"value": round(m * READ_LEN / cpu_dt / 1e9, 4), "unit": "Gbases/s", "cores": cores,
                                    "kind": "port", "sample": "first %d reads of the same synthetic workload, %.1f s, "
-                                   "oracle/bbduk_oracle.c with %d pthreads (the cgroup's CPU quota if there is one, else the fastest of %s on a 100k-pair probe); os.cpu_count() = %d "
+                                   "oracle/bbduk_oracle.c with %d pthreads (the fastest of %s on a 100k-pair probe run twice; the cgroup's CPU quota and its multiples are in the set); os.cpu_count() = %d "
                                    "(match only, no I/O)" % (m, cpu_dt, cores, sorted(probes), os.cpu_count() or 1)}
             try:
                 with open("/sys/fs/cgroup/cpu.max") as fh:
