@@ -407,7 +407,8 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
     // a streamed build (bbduk_build_begin / _add_device / _end) sees the reference once and cannot keep the cache-resident twin build_both gives the
     // other builders for units beyond a wave's planes (2x3000: 33 against 70 Gbases/s on the big layout alone): it keeps the old threshold
     if (streamed) bigMin = std::max<long long>(bigMin, SEED_LAYOUT_MIN_KEYS);
-    st->big = !st->seed && !h->hookNoBigLayout && (maxKeys > (double)bigMin || h->hookBigLayout) && big_layout_eligible(h->p) && !h->sealTable && big_geometry(h, maxKeys);
+    // (a Seal map -- seal_gpu.h: its own kernel looks the map up, bbduk_seal.inc -- takes the big layout by its size alone, round 4)
+    st->big = !st->seed && !h->hookNoBigLayout && (maxKeys > (double)bigMin || h->hookBigLayout) && (big_layout_eligible(h->p) || (h->sealTable && h->p.k >= 16)) && big_geometry(h, maxKeys);
     // ktrim=r has the stream scan of the 32-bit line function only (no pair-scan form): beyond 2^31 keys, or behind the 52-bit hook, it keeps the
     // cache-resident layout (which refuses what it cannot index)
     if (st->big && h->p.mode != BBDUK_MODE_KFILTER && !h->gV32) st->big = false;
@@ -428,7 +429,7 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
     } else if (st->big) {
         // 32-slot lines at ~0.6 keys per slot (the lines' loads vary with the minimizers: 10 % of them overflow into the next line
         // there, 3 % of the keys); a tighter fit is tried when HBM is short.  12 or 14 bytes per slot: 10^10 keys = 200-233 GB.
-        const int idBytes = h->p.numScaffolds <= 65535 ? 2 : 4;
+        const int idBytes = (h->p.numScaffolds <= 65535 && !h->sealTable) ? 2 : 4;      // (a Seal record is a scaffold or SEAL_MULTI | offset into the id lists: 32 bits)
         size_t freeB = 0, totalB = 0;
         if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return bail(BBDUK_ERR_DEVICE, "hipMemGetInfo");
         // the secondary map holds what the lines spill (both words of a key full): ~6 % of the keys at 0.6 keys per slot; its

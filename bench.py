@@ -426,7 +426,7 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "profiles"))
             import bench_modes, bench_seal
             out["operators"] = {r["mode"]: {k: r[k] for k in ("args", "reads", "operator_ms", "Gbases_per_s")} for r in bench_modes.run(a.extra_reads)}
-            out["seal"] = bench_seal.run(pairs=1_000_000, check=0)
+            out["seal"] = bench_seal.run(pairs=1_000_000, check=2000)      # (the first 2 000 pairs replayed by oracle/seal_oracle.c: sample_equals_restatement)
         except Exception as e:
             out["operators"] = {"error": repr(e)}
         try:                                           # the configs[1] flags on pairs of other lengths (2x151: the tail pass of the main kernel)
