@@ -143,7 +143,7 @@ int  bbduk_build_table_device_edits(bbduk_handle* h, const uint8_t* refs, const 
                                     int32_t hdist, int32_t hdist2, int32_t edist, int32_t edist2);
 /* The same build, streamed, for references that are produced or ingested on the device or do not fit one host buffer (the 10 GB
  * reference of BASELINE configs[3]): begin announces an upper bound on the number of keys (for hdist 0: the number of reference
- * bases) -- beyond 2^20 keys (plain kfilter configurations with k >= 25; 2^21 with hdist > 0; 2^25 for shorter k-mers) the map takes the HBM-resident layout, 12-14 bytes per slot at ~0.6 keys per slot, built in place (bbduk_finalize_table and bbduk_build_table_device keep a cache-resident twin beside it up to 2^25 keys, which serves batches with units beyond 2 512 bases; the streamed build has none);
+ * bases) -- beyond 2^25 keys (streamed builds; bbduk_finalize_table and bbduk_build_table_device: beyond 2^20 keys for plain kfilter and ktrim=r configurations with k >= 25, 2^21 with hdist > 0, and they keep a cache-resident twin beside it up to 2^25 keys, which serves batches with units beyond 2 512 bases) the map takes the HBM-resident layout: 12-14 bytes per slot, ~0.3 keys per slot up to 2^31 keys (the 32-bit line function, scanned by bbduk_bigs_kernel), ~0.6 beyond (BASELINE configs[3]); built in place;
  * every add hands over WHOLE scaffolds already in HBM (d_refs device pointer, ref_offsets HOST array of n_refs+1 values starting at
  * 0; scaffold i of the call gets id first_id + i); end leaves the handle finalized.  An error ends the build and frees the map. */
 int  bbduk_build_begin(bbduk_handle* h, int64_t max_keys, int32_t hdist, int32_t hdist2);
@@ -151,7 +151,8 @@ int  bbduk_build_add_device(bbduk_handle* h, const uint8_t* d_refs, const int64_
 int  bbduk_build_end(bbduk_handle* h);
 int64_t bbduk_table_size(const bbduk_handle* h);          /* distinct keys resident, or <0.  (A large hdist=1 kfilter map built on the device
                                                              is stored as its PARENT windows -- bbduk_seed.inc, DESIGN 4.12: same key -> id
-                                                             answers, but this call then counts records, four per distinct window.) */
+                                                             answers; with its cache-resident twin -- up to 2^25 keys -- this call answers
+                                                             in the reference's keys, without one it counts records, four per window.) */
 int64_t bbduk_table_bytes(const bbduk_handle* h);         /* HBM bytes held by the table image */
 /* point lookups through the device table (test hook): out_ids[i] = id or -1 */
 int  bbduk_table_lookup(bbduk_handle* h, const int64_t* keys, int64_t n, int32_t* out_ids);
