@@ -201,7 +201,7 @@ extern "C" int bbduk_test_hook(bbduk_handle* h, int32_t which, int64_t value) {
     case BBDUK_HOOK_LDS_BITS:    if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookLdsBits = (int)value; return BBDUK_OK;
     case BBDUK_HOOK_SEED_LAYOUT: if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookSeedLayout = value != 0; return BBDUK_OK;
     case BBDUK_HOOK_BIG_LOAD:    if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookBigLoad = (int)value; return BBDUK_OK;
-    case BBDUK_HOOK_BIG_LAYOUT:  if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookBigLayout = value > 0; h->hookNoBigLayout = value < 0; h->hookBig52 = value == 2; return BBDUK_OK;
+    case BBDUK_HOOK_BIG_LAYOUT:  if (h->finalized) return fail(h, BBDUK_ERR_STATE, "hook after finalize"); h->hookBigLayout = value > 0; h->hookNoBigLayout = value < 0; h->hookBig52 = value == 2; h->hookBigWide = value == 3; return BBDUK_OK;
     case BBDUK_HOOK_TIMING_MASK:
 #ifdef BBDUK_TIMING_SWITCHES
         h->hookDbg = (int)value; return BBDUK_OK;
@@ -300,9 +300,9 @@ static bool big_geometry(bbduk_handle* h, const double maxKeys = 0.0) {
     }
     if (H < 4) return false;
     h->gH = H; h->gD = k - H; h->gm = std::min(10, H - 1);
-    // The 32-bit variant of the line function (gap_v32, bbduk_bigs.inc's scan) serves maps of up to 2^31 keys; the 52-bit one remains for the
-    // 10^10-key map (and behind BBDUK_HOOK_BIG_LAYOUT = 2 for the tests that keep it covered at small sizes).
-    h->gV32 = maxKeys > 0.0 && maxKeys <= 2147483648.0 && !h->hookBig52;
+    // The 32-bit variant of the line function (gap_v32, bbduk_bigs.inc's scan) serves every size the tag word index allows (2^29 lines: 10^10 keys at 0.6
+    // per slot); the 52-bit one remains behind BBDUK_HOOK_BIG_LAYOUT = 2 (tests and A/B runs).
+    h->gV32 = (maxKeys > 0.0 && !h->hookBig52) ? ((maxKeys > 2147483648.0 || h->hookBigWide) ? 2 : 1) : 0;      // (2: the wide values, gap_v52)
     if (h->gV32) {
         // m follows the reference's size: a minimizer has to be rare in the REFERENCE (4m bits well above log2 of its positions), and
         // every base m gives up widens the window W = H - m + 1 over which consecutive k-mers share a line: 4.6 M keys at k = 31: m = 7, W = 9,
@@ -313,9 +313,10 @@ static bool big_geometry(bbduk_handle* h, const double maxKeys = 0.0) {
     }
     if (h->hookLdsBits >= 4 && h->hookLdsBits <= H - 1) h->gm = h->hookLdsBits;      // (experiments: BBDUK_HOOK_LDS_BITS = m; such maps have no LDS filter)
     h->gW = h->bigPlain ? 0 : H - h->gm + 1;
+    if (h->gV32 == 2 && h->gW > 8) h->gV32 = 1;                   // (the wide scan is instantiated for W <= 8: m = 10 gives W <= 7)
     return true;
 }
-static BigGeom host_geom(const bbduk_handle* h) { BigGeom G; G.k = h->p.k; G.m = h->gm; G.W = h->gW; G.H = h->gH; G.D = h->gD; G.nlines = h->bigLines; G.middleMask = (uint64_t)h->p.middleMask; G.v32 = h->gV32 ? 1 : 0; return G; }
+static BigGeom host_geom(const bbduk_handle* h) { BigGeom G; G.k = h->p.k; G.m = h->gm; G.W = h->gW; G.H = h->gH; G.D = h->gD; G.nlines = h->bigLines; G.middleMask = (uint64_t)h->p.middleMask; G.v32 = h->gV32; return G; }
 static Sink make_sink(const bbduk_handle* h, const BuildState* st) {
     Sink S; memset(&S, 0, sizeof S);
     S.big = st->big ? 1 : 0; S.skeys = st->d_sk; S.sids = st->d_si; S.cmask = st->cslots ? st->cslots - 1 : 0;
@@ -448,11 +449,10 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
         for (int li = 0; li < 3; li++) {
             const double load = (h->hookBigLoad > 0 && li == 0) ? 0.01 * h->hookBigLoad : (h->gV32 ? loads32[li] : loads52[li]);
             nlines = std::max<uint64_t>(64, (uint64_t)(maxKeys / (32.0 * load)) + 1);
-            if ((double)nlines * perLine + spillBytes + 3e9 < (double)freeB) break;
+            if (nlines < (1ULL << 29) && (double)nlines * perLine + spillBytes + 3e9 < (double)freeB) break;      // (2^29 lines: the 32-bit tag word index)
             nlines = 0;
         }
-        if (!nlines) return bail(BBDUK_ERR_NOMEM, "the map does not fit this device's memory");
-        if (nlines >= (1ULL << 29)) return bail(BBDUK_ERR_ARG, "too many keys for the 32-bit tag word index");
+        if (!nlines) return bail(BBDUK_ERR_NOMEM, "the map does not fit this device's memory (or the 32-bit tag word index: 2^29 lines)");
         if (hipMalloc(&h->d_bigTags, nlines * 64) != hipSuccess || hipMalloc(&h->d_bigKeys, nlines * 256) != hipSuccess ||
             hipMalloc(&h->d_bigIds, nlines * 32 * (size_t)idBytes) != hipSuccess ||
             hipMalloc(&h->d_tags, (snb + 1) * 8) != hipSuccess || hipMalloc(&h->d_bkv, 4 * snb * sizeof(uint4)) != hipSuccess) return bail(BBDUK_ERR_NOMEM, "hipMalloc (map)");
@@ -802,7 +802,7 @@ static KParams make_kparams(const bbduk_handle* h) {
     K.tags = h->d_tags; K.bkv = h->d_bkv; K.bucketMask = (uint32_t)(h->nbuckets - 1); K.bucketBits = h->bucketBits;
     K.storedKmers = h->nkeys; K.undef = nullptr;
     K.big = h->big ? 1 : 0; K.bigTags = h->d_bigTags; K.bigKeys = h->d_bigKeys; K.bigIds = h->d_bigIds; K.bigIdBytes = h->bigIdBytes; K.bigLines = h->bigLines;
-    K.gm = h->gm; K.gW = h->gW; K.gH = h->gH; K.gD = h->gD; K.gV32 = h->gV32 ? 1 : 0;
+    K.gm = h->gm; K.gW = h->gW; K.gH = h->gH; K.gD = h->gD; K.gV32 = h->gV32;
     K.seed = h->seed ? 1 : 0; K.seedHl = h->seedHl; K.seedHr = h->seedHr; K.seedM = h->seedM;
     K.matchN = nullptr; K.matchIds = nullptr; K.matchCnt = nullptr; K.matchCap = 0;
     K.dbg = h->hookDbg;

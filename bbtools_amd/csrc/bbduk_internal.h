@@ -50,7 +50,7 @@ struct KParams {
     uint32_t bigLines;
     int32_t  seed, seedHl, seedHr, seedM;   // the seed layout (bbduk_seed.inc): tags / bkv hold PARENTS under their left (seedHl bases) and right (seedHr) halves
     int32_t  gm, gW, gH, gD;    // gapped minimizer: m bases from each half, W candidates, half length H, right half starts at D = k-H
-    int32_t  gV32;              // the line function's 32-bit variant (gap_v32 / gap_line32: maps of up to 2^31 keys; bbduk_bigs.inc scans them)
+    int32_t  gV32;              // the line function's variant: 1 = 32-bit values (gap_v32 / gap_line32: maps of up to 2^31 keys), 2 = wide values (gap_v52: beyond), 0 = round 2's 52-bit minima; bbduk_bigs.inc scans 1 and 2
     // presence filter in front of the map: one bit per hash slot, copied into LDS by every workgroup
     const uint32_t* ldsImage;   // HBM copy of the LDS bitmap (2^ldsBits bits); 0 bits = absent
     int32_t  ldsBits;
@@ -76,7 +76,7 @@ struct bbduk_handle {
     uint64_t* d_tagsAlt = nullptr; uint4* d_bkvAlt = nullptr; uint32_t* d_ldsAlt = nullptr; uint64_t nbucketsAlt = 0; int bucketBitsAlt = 0, ldsBitsAlt = 0; bool hasAlt = false;
     // big layout (HBM-resident maps): 8 * bigLines tag words, slot-parallel keys / ids; d_tags / d_bkv = the secondary map of the spilled keys
     bool big = false; uint64_t* d_bigTags = nullptr; uint64_t* d_bigKeys = nullptr; void* d_bigIds = nullptr; int bigIdBytes = 0; uint32_t bigLines = 0;
-    int gm = 0, gW = 0, gH = 0, gD = 0; int64_t nspilled = 0; bool gV32 = false;
+    int gm = 0, gW = 0, gH = 0, gD = 0; int64_t nspilled = 0; int gV32 = 0;
     bool seed = false; int seedHl = 0, seedHr = 0, seedM = 0;   // seed layout: parents only, under their halves (large hdist=1 maps built on the device)
     double expectShort = 0.0;            // short k-mers of mink the next build will see (they live in the secondary map of a big-layout map)
     bool bigPlain = false;               // lines by a plain key hash instead of the gapped minimizer (gW = 0)
@@ -109,7 +109,7 @@ struct bbduk_handle {
     int numCU = 256;
     bbduk_comm* comm = nullptr;          // set by bbduk_comm_create / bbduk_comm_create_local
     // include/bbduk_test_hooks.h (tests and experiments only)
-    bool hookForceTile = false, hookBigLayout = false, hookNoBigLayout = false, hookPairScan = false, hookSeedLayout = false, hookBig52 = false; int hookBucketBits = 0, hookLdsBits = -1, hookDbg = 0, hookBigLoad = 0;
+    bool hookForceTile = false, hookBigLayout = false, hookNoBigLayout = false, hookPairScan = false, hookSeedLayout = false, hookBig52 = false, hookBigWide = false; int hookBucketBits = 0, hookLdsBits = -1, hookDbg = 0, hookBigLoad = 0;
 };
 
 #define HIP_TRY(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \

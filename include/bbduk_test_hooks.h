@@ -20,7 +20,8 @@ extern "C" {
 #define BBDUK_HOOK_BIG_LAYOUT   5   /* before finalize / device build: value > 0 forces the HBM-resident map layout at any size, value < 0 keeps it
                                        from being chosen (A/B runs of the cache-resident layout at sizes that would take it) */
 #define BBDUK_HOOK_BIG_LOAD     8   /* before finalize / device build: keys per 100 slots the big layout's lines are sized for (0 = the default); value 2 of
-                                       BBDUK_HOOK_BIG_LAYOUT forces the 52-bit line function and its pair scan below 2^31 keys too */
+                                       BBDUK_HOOK_BIG_LAYOUT forces round 2's 52-bit line function and its pair scan, value 3 the wide values that maps beyond 2^31 keys
+                                       take (gap_v52, same scan as the 32-bit values) */
 int  bbduk_test_hook(bbduk_handle* h, int32_t which, int64_t value);
 /* the same controls on the map behind a Seal handle (include/seal_gpu.h), before seal_finalize */
 struct seal_handle;

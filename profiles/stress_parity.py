@@ -172,7 +172,7 @@ def main():
                 if rng.random() < 0.7: hooks[B.HOOK_BUCKET_BITS] = bb; squeeze += " bucketbits=%d" % bb
                 if rng.random() < 0.6: lb = rng.choice([0, 10, 12]); hooks[B.HOOK_LDS_BITS] = lb; squeeze += " ldsbits=%d" % lb
             if bigmap:
-                hooks = {B.HOOK_BIG_LAYOUT: rng.choice([1, 1, 1, 2]), B.HOOK_BIG_LOAD: rng.choice([0, 0, 30, 60, 95])}
+                hooks = {B.HOOK_BIG_LAYOUT: rng.choice([1, 1, 1, 2, 3, 3]), B.HOOK_BIG_LOAD: rng.choice([0, 0, 30, 60, 95])}
                 if rng.random() < 0.5: hooks[B.HOOK_LDS_BITS] = rng.choice([4, 6, 7, 8, 9, 10, 12])      # (m of the minimizer lines)
                 squeeze = " bigmap=%r" % (sorted(hooks.items()),)
             d = B.BBDuk(args, refs=refs, build=build, hooks=hooks)

@@ -14,7 +14,8 @@ from tests.test_gpu_parity import check_batch, FUZZ
 
 pytestmark = pytest.mark.gpu
 BIG = {B.HOOK_BIG_LAYOUT: 1}
-BIG52 = {B.HOOK_BIG_LAYOUT: 2}            # the 52-bit line function and its pair scan (what maps beyond 2^31 keys take) at test sizes
+BIG52 = {B.HOOK_BIG_LAYOUT: 2}            # round 2's 52-bit line function and its pair scan (kept for A/B runs) at test sizes
+BIGWIDE = {B.HOOK_BIG_LAYOUT: 3}          # the wide candidate values (gap_v52) that maps beyond 2^31 keys take, at test sizes
 
 
 def big_pair(args, okw, refs=None, ref_fasta=None, build="host", hooks=BIG):
@@ -30,7 +31,7 @@ def big_pair(args, okw, refs=None, ref_fasta=None, build="host", hooks=BIG):
     return d, o
 
 
-@pytest.mark.parametrize("build", ["host", "device", "device52"])
+@pytest.mark.parametrize("build", ["host", "device", "device52", "devicewide", "hostwide"])
 @pytest.mark.parametrize("cfg", ["c4s", "c3", "c2", "c1", "c5", "c3q", "c3mcf", "c3mkf"])
 def test_big_layout_on_the_baseline_configs(cfg, build):
     args, okw, ref = util.CONFIGS[cfg]
@@ -39,6 +40,10 @@ def test_big_layout_on_the_baseline_configs(cfg, build):
         if cfg not in ("c4s", "c3"):
             pytest.skip("the 52-bit variant's own scan serves the plain kfilter")
         build, hooks = "device", BIG52
+    if build in ("devicewide", "hostwide"):
+        if cfg not in ("c4s", "c3", "c1", "c2"):
+            pytest.skip("the wide values differ from the 32-bit ones in the scan's line function only: kfilter and ktrim=r cover it")
+        build, hooks = build[:-4], BIGWIDE
     d, o = big_pair(args, okw, ref_fasta=ref, build=build, hooks=hooks)
     assert d.gpu.table_bytes >= 64 * (64 + 256 + 64)               # whole 32-slot lines
     ks, vs = o.dump_pairs()
@@ -72,7 +77,7 @@ def test_big_layout_fuzz(ci):
     for seed in range(2):
         rng = random.Random(7000 + 100 * ci + seed)
         refs = [util.rand_seq(rng, rng.randint(5, 90), 0.01) for _ in range(8)]
-        d, o = big_pair(args, okw, refs=refs, build="host", hooks=BIG52 if seed == 1 and ci in (0, 1, 2, 3) else BIG)
+        d, o = big_pair(args, okw, refs=refs, build="host", hooks=BIG52 if seed == 1 and ci in (0, 1, 2, 3) else (BIGWIDE if seed == 1 else BIG))
         reads = util.fuzz_reads(rng, refs, 600, [0, 1, 2, 5, 10, 11, 22, 23, 30, 31, 32, 40, 63, 64, 65, 75, 150, 151, 300], junk=True)
         check_batch(d, o, reads, True)
         check_batch(d, o, reads[:301], False)
