@@ -40,11 +40,11 @@ def make_refs(rng, nrefs, length, share):
     return refs
 
 
-def make_reads(rng, refs, n, paired):
+def make_reads(rng, refs, n, paired, lengths=(0, 5, 9, 10, 30, 75, 150, 151, 260, 300)):
     reads = []
     for _ in range(n * (2 if paired else 1)):
         r = rng.random()
-        L = rng.choice([0, 5, 9, 10, 30, 75, 150, 151, 260, 300])
+        L = rng.choice(lengths)
         if r < 0.15:
             s = bytearray(rnd_seq(rng, L))
         else:
@@ -163,13 +163,13 @@ def test_oracle_only_the_letter_N_resets():
 
 
 # ---------------------------------------------------------------------------------------------- HIP operator vs the restatement
-def run_case(seed, nreads=160):
+def run_case(seed, nreads=160, lengths=None, ref_len=None):
     from bbtools_amd.seal import Seal
     rng = random.Random(seed)
     cfg = rand_cfg(rng)
-    refs = make_refs(rng, rng.choice([2, 3, 6, 12]), rng.choice([150, 300, 600]), rng.choice([0.0, 0.3, 0.7]))
+    refs = make_refs(rng, rng.choice([2, 3, 6, 12]), ref_len or rng.choice([150, 300, 600]), rng.choice([0.0, 0.3, 0.7]))
     paired = rng.random() < 0.6
-    reads = make_reads(rng, refs, nreads, paired)
+    reads = make_reads(rng, refs, nreads, paired, *([lengths] if lengths else []))
     first_id = rng.choice([0, 17, 1 << 33])
     o = SealOracle(refs, **cfg_oracle(cfg))
     g = Seal(cfg_args(cfg), refs=refs, max_scaffolds=len(refs) + 2)
@@ -190,6 +190,14 @@ def run_case(seed, nreads=160):
 @pytest.mark.parametrize("seed", range(40))
 def test_seal_fuzz_parity(seed):
     run_case(1000 + seed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_seal_units_beyond_the_wave_planes(seed):
+    """bbduk_seal_wave_kernel holds units of up to ~690 bases in a wave's own planes and leaves longer ones to the tile kernel launched
+    behind it: batches that mix both, in either order, with pairs whose mates fall on either side of the limit."""
+    run_case(5000 + seed, nreads=120, lengths=(0, 30, 150, 300, 340, 352, 400, 700, 1500), ref_len=2500)
 
 
 @pytest.mark.gpu
