@@ -69,9 +69,13 @@ def main():
     ap.add_argument("--pairs", type=int, default=2_000_000); ap.add_argument("--scaffolds", type=int, default=64)
     ap.add_argument("--scaffold-len", type=int, default=100_000); ap.add_argument("--args", default="")
     ap.add_argument("--check", type=int, default=2000)
+    ap.add_argument("--lib", default="", help="experiments: another build under bbtools_amd/ (ab_tsw: stage deletion through the SEAL_TSW environment variable)")
     ap.add_argument("--layout", type=int, default=0, help="BBDUK_HOOK_BIG_LAYOUT on the map: -1 cache-resident, 1 minimizer lines (default: by key count)")
     ap.add_argument("--bucket-bits", type=int, default=0, help="experiments: log2 of the map's bucket count (default: one bucket per key, rounded up)")
     a = ap.parse_args()
+    if a.lib:
+        from bbtools_amd import bbduk as _B
+        _B.use_library(os.path.join(ROOT, "bbtools_amd", a.lib + ".so"))
     r = run(a.pairs, a.scaffolds, a.scaffold_len, a.args, a.check, a.bucket_bits, a.layout)
     if a.bucket_bits:
         r["bucket_bits"] = a.bucket_bits
