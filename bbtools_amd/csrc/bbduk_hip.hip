@@ -337,8 +337,10 @@ static bool params_general(const bbduk_params& p) {               // the same pr
 }
 // Round 4: ktrim=r too (its first-hit scan is bbduk_bigs_kernel's, its short k-mers live in the secondary map) -- such maps take the 32-bit line
 // function, i.e. up to 2^31 keys; a ktrim map beyond that is refused at build time (big_geometry_ok_for).
+// ... and ktrim=l, like kfilter with maxbadkmers > 0 an every-hit scan: bbduk_bigs_every_kernel (the scan's candidates all verified, the mode's facts read
+// out of the exact hit plane).
 static bool big_layout_eligible(const bbduk_params& p) {
-    return (p.mode == BBDUK_MODE_KFILTER || p.mode == BBDUK_MODE_KTRIM_R) && !params_general(p) && !(p.kbig > p.k) && !p.findBestMatch;
+    return (p.mode == BBDUK_MODE_KFILTER || p.mode == BBDUK_MODE_KTRIM_R || p.mode == BBDUK_MODE_KTRIM_L) && !params_general(p) && !(p.kbig > p.k) && !p.findBestMatch;
 }
 // seed layout (bbduk_seed.inc): the two halves beside the (at most one) masked middle base, each <= 16 bases
 static bool seed_geometry(bbduk_handle* h, const double maxKeys = 0.0) {
@@ -961,6 +963,11 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
         kp.wave = bbduk_pick_bigs(K.mode, K.useShort != 0, packed); waveLdsUse = dynLds + WAVE_LDS_BYTES_BIGS;
         if (K.mode == BBDUK_MODE_KTRIM_R) kp.tile = bbduk_pick_ktrim_r_big_tile();
     }
+    if (K.big && K.gV32 && !firstHit && !h->hookPairScan && (K.mode == BBDUK_MODE_KTRIM_L || (K.mode == BBDUK_MODE_KFILTER && K.mkf == 0.f && K.mcf == 0.f)) &&
+        !kparams_general(K)) {                                    // ... and its every-hit form: ktrim=l, kfilter with maxbadkmers > 0
+        kp.wave = bbduk_pick_bigs_every(K.mode, K.useShort != 0); waveLdsUse = dynLds + WAVE_LDS_BYTES_BIGS;
+        if (K.mode == BBDUK_MODE_KTRIM_L) kp.tile = bbduk_pick_ktrim_l_big_tile();
+    }
     // a big-layout map with a cache-resident twin (build_both): the wave kernel scans the big layout, the fallbacks for units beyond a wave's
     // planes (tile kernel, long-read kernel) run their cache-resident instantiations over the twin
     const bool twin = (K.big || K.seed) && h->hasAlt;
@@ -997,7 +1004,7 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     h->evCount++;
     {   // reads beyond BBDUK_MAX_READ_LEN: chunked scan, one wave per unit (returns at once unless the pre-pass asked for it)
         const batch_kernel_t lk = K2.mode == BBDUK_MODE_KFILTER ? ((K2.big || K2.seed) ? bbduk_long_kernel<BBDUK_MODE_KFILTER, true> : bbduk_long_kernel<BBDUK_MODE_KFILTER>) :
-                                  (K2.mode == BBDUK_MODE_KTRIM_L ? bbduk_long_kernel<BBDUK_MODE_KTRIM_L> : (K2.big ? bbduk_long_kernel<BBDUK_MODE_KTRIM_R, true> : bbduk_long_kernel<BBDUK_MODE_KTRIM_R>));
+                                  (K2.mode == BBDUK_MODE_KTRIM_L ? (K2.big ? bbduk_long_kernel<BBDUK_MODE_KTRIM_L, true> : bbduk_long_kernel<BBDUK_MODE_KTRIM_L>) : (K2.big ? bbduk_long_kernel<BBDUK_MODE_KTRIM_R, true> : bbduk_long_kernel<BBDUK_MODE_KTRIM_R>));
         HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(lk), dynLds2));
         const int64_t units = paired ? n / 2 : n;
         const int lgrid = (int)std::min<int64_t>((units + NWAVES - 1) / NWAVES, (int64_t)h->numCU);

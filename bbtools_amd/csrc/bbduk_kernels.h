@@ -23,6 +23,8 @@ batch_kernel_t bbduk_pick_stream(int mode, bool useShort, bool forbidN, bool pac
 batch_kernel_t bbduk_pick_stream_every(int mode, bool useShort, bool forbidN, bool general);
 batch_kernel_t bbduk_pick_stream_tips(bool packed);                            // ktrim=rl, no forbidNs, specialised family
 batch_kernel_t bbduk_pick_stream_seed(bool forbidN, bool packed);              // the stream scan over a seed-layout map (bbduk_seed.inc)
+batch_kernel_t bbduk_pick_ktrim_l_big_tile();
+batch_kernel_t bbduk_pick_bigs_every(int mode, bool useShort);                                       // bbduk_bigs_every.hip: ... and its every-hit form (ktrim=l, kfilter with maxbadkmers > 0)
 batch_kernel_t bbduk_pick_bigs(int mode, bool useShort, bool packed);                                 // bbduk_bigs.hip: the stream scan over a big-layout map with the 32-bit line function
 
 #ifdef BBDUK_DEVICE_INC            /* translation units that hold kernel templates */

@@ -194,7 +194,8 @@ def _is_big(d):
     ("k=21", dict(k=21), 1_150_000, False),                         # short k-mers: the cache-resident map is the faster one until 2^25 keys
     ("k=31 mkf=0.1", dict(k=31, minKmerFraction=0.1), 1_150_000, False),      # not a plain first-hit kfilter: cache-resident at 1-2 keys per bucket
     ("ktrim=r k=27", dict(k=27, ktrimRight=1), 1_150_000, True),    # ktrim=r: minimizer lines too since round 4 (bbduk_bigs_kernel<KTRIM_R>)
-        ("ktrim=l k=27", dict(k=27, ktrimLeft=1), 1_150_000, False),    # the every-hit scans have no big-layout form: cache-resident
+    ("ktrim=l k=27", dict(k=27, ktrimLeft=1), 1_150_000, True),     # ktrim=l and kfilter with maxbadkmers > 0: bbduk_bigs_every_kernel (round 4)
+    ("k=31 mbk=2", dict(k=31, maxBadKmers0=2), 1_150_000, True),
 ])
 def test_layout_chosen_by_key_count(args, okw, genome, want_big):
     """The layouts as the library picks them by itself (round 3: the big layout from 2^20 keys on for the configurations that have its scan,
@@ -261,6 +262,23 @@ def test_big_layout_window_whose_first_fingerprint_match_is_an_impostor():
 def test_big_layout_ktrim_right(args, okw):
     """ktrim=r against a big-layout map (round 4: bbduk_bigs_kernel<KTRIM_R>): first hit by the stream scan over the minimizer lines, the short
     k-mers of mink out of the secondary map, units beyond a wave's planes through the tiled and the long-read kernels' exact lookups"""
+    _planted_pieces_case(args, okw)
+
+
+@pytest.mark.parametrize("args,okw", [("ktrim=l k=31", dict(k=31, ktrimLeft=1)),
+                                      ("ktrim=l k=27 mink=12", dict(k=27, mink=12, ktrimLeft=1)),
+                                      ("ktrim=l k=25 mink=11 hdist=1 tp=1", dict(k=25, mink=11, hdist=1, ktrimLeft=1, trimPad=1)),
+                                      ("ktrim=l k=29 forbidn=t minlen=30", dict(k=29, forbidN=1, ktrimLeft=1, minReadLength=30)),
+                                      ("k=31 mbk=1", dict(k=31, maxBadKmers0=1)),
+                                      ("k=27 mbk=3 forbidn=t", dict(k=27, maxBadKmers0=3, forbidN=1)),
+                                      ("k=25 mbk=2 hdist=1 mm=f", dict(k=25, maxBadKmers0=2, hdist=1, maskMiddle=0))])
+def test_big_layout_every_hit_scans(args, okw):
+    """ktrim=l and kfilter with maxbadkmers > 0 against a big-layout map (round 4: bbduk_bigs_every_kernel): every candidate of the stream scan
+    is verified (lanes = candidates), the last hit / the hit count come out of the exact hit plane; same reads as the ktrim=r cases."""
+    _planted_pieces_case(args, okw)
+
+
+def _planted_pieces_case(args, okw):
     rng = random.Random(len(args))
     refs = [util.rand_seq(rng, 6000, 0.002), util.rand_seq(rng, 900), util.rand_seq(rng, 40), util.rand_seq(rng, 2500)]
     for build in ("device", "host"):
