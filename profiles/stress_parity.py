@@ -175,6 +175,9 @@ def main():
                 hooks = {B.HOOK_BIG_LAYOUT: rng.choice([1, 1, 1, 2, 3, 3]), B.HOOK_BIG_LOAD: rng.choice([0, 0, 30, 60, 95])}
                 if rng.random() < 0.5: hooks[B.HOOK_LDS_BITS] = rng.choice([4, 6, 7, 8, 9, 10, 12])      # (m of the minimizer lines)
                 squeeze = " bigmap=%r" % (sorted(hooks.items()),)
+            if os.environ.get("SOAK_DUMP"):
+                import pickle; pickle.dump(dict(args=args, okw=okw, refs=refs, reads=reads, build=build), open(os.environ["SOAK_DUMP"], "wb"))
+            if os.environ.get("SOAK_HOOKS"): hooks = {int(k_): int(v_) for k_, v_ in (kv.split(":") for kv in os.environ["SOAK_HOOKS"].split(",") if kv)}      # (debugging a --only run)
             d = B.BBDuk(args, refs=refs, build=build, hooks=hooks)
             if squeeze: fam_count["squeezed"] = fam_count.get("squeezed", 0) + 1
             assert d.stored_kmers == o.stored_kmers, ("stored", d.stored_kmers, o.stored_kmers)

@@ -305,5 +305,17 @@ def _planted_pieces_case(args, okw):
             if rng.random() < 0.6:
                 src = refs[0]; a = rng.randrange(len(src) - 80); w = rng.randrange(n - 80); r[w:w + 80] = src[a:a + 80]
             long_reads.append(bytes(r))
+        # ... and in the same batch (the long-read kernel takes all of it) short reads whose only hit is an end's short k-mer, or the left end's
+        # length-k lookup behind a junk symbol (found by the soak: the fallbacks' short scans asked the secondary map for a full-length key)
+        mk = okw.get("mink", 0)
+        for i in range(40):
+            src = refs[rng.choice([0, 1, 3])]; a = rng.randrange(len(src) - 40)
+            n = rng.choice([okw["k"], okw["k"] + 3, 60, 151])
+            r = bytearray(util.rand_seq(rng, n))
+            m = rng.randint(max(mk, 8), okw["k"])
+            if okw.get("ktrimLeft"): r[:m] = src[a:a + m]
+            else: r[n - m:] = src[a:a + m]
+            if rng.random() < 0.5 and n > okw["k"]: r[rng.randrange(n)] = rng.choice(b".N")
+            long_reads.append(bytes(r))
         check_batch(d, o, long_reads, True)
         d.close()
