@@ -167,7 +167,12 @@ FUZZ = [("ktrim=r k=23", dict(k=23, ktrimRight=1)),
         ("k=25 mcf=0.4", dict(k=25, minCoveredFraction=0.4)), ("k=15 mcf=0.9 hdist=1 restrictleft=60", dict(k=15, minCoveredFraction=0.9, hdist=1, restrictLeft=60)),
         ("k=19 mcf=0.05 mkf=0.5 mm=f", dict(k=19, minCoveredFraction=0.05, minKmerFraction=0.5, maskMiddle=0)),
         ("ktrim=r k=21 mink=9 rskip=3 hdist=1", dict(k=21, ktrimRight=1, mink=9, minSkip=3, maxSkip=3, hdist=1)),
-        ("ktrim=r k=13 mink=7 edist=1", dict(k=13, ktrimRight=1, mink=7, edist=1)), ("k=15 edist=1 mm=f", dict(k=15, edist=1, maskMiddle=0))]
+        ("ktrim=r k=13 mink=7 edist=1", dict(k=13, ktrimRight=1, mink=7, edist=1)), ("k=15 edist=1 mm=f", dict(k=15, edist=1, maskMiddle=0)),
+        # qhdist = 1 on otherwise plain first-hit configurations: bbduk_qh_kernel (round 4; the ones above with k < 16 or other general flags stay tiled)
+        ("ktrim=r k=21 mink=11 hdist=1 qhdist=1", dict(k=21, ktrimRight=1, mink=11, hdist=1, qhdist=1)), ("k=23 qhdist=1", dict(k=23, qhdist=1)),
+        ("ktrim=r k=25 mink=12 qhdist=1 qhdist2=0 forbidn=t", dict(k=25, ktrimRight=1, mink=12, qhdist=1, qhdist2=0, forbidN=1)),
+        ("k=19 qhdist=1 mm=f forbidn=t", dict(k=19, qhdist=1, maskMiddle=0, forbidN=1)),
+        ("ktrim=r k=31 qhdist=1 tpe minlen=20", dict(k=31, ktrimRight=1, qhdist=1, trimPairsEvenly=1, minReadLength=20))]
 
 
 @pytest.mark.parametrize("ci", range(len(FUZZ)))
