@@ -383,10 +383,10 @@ static bool seed_geometry(bbduk_handle* h, const double maxKeys = 0.0) {
 #define BIG_LAYOUT_MIN_KEYS (1LL << 20)
 #define SEED_LAYOUT_MIN_KEYS (1LL << 25)
 #define SEED_JOINT_MIN_KEYS (1LL << 22)
-// The early threshold holds for long k-mers only: the scan's line arithmetic has its 32-bit form at k = 31 (170 against the cache-resident map's 74
-// Gbases/s at 4.6 M keys) and pays less below (k = 27: 97 / 75, k = 25: 84 / 76) until the cache-resident map is the faster one (k = 21: 64 / 76,
-// k = 17: 69 / 77; profiles/r03_layout_mid_other_k.jsonl) -- those keep the old threshold, where the fingerprints alone outgrow the caches.
-static inline long long big_min_keys(const bbduk_params& p) { return p.k >= 25 ? BIG_LAYOUT_MIN_KEYS : SEED_LAYOUT_MIN_KEYS; }
+// Rounds 3-4a kept the early threshold for k >= 25 only (the pair scan's line arithmetic paid less below: k = 21 64 against the cache-resident map's 76
+// Gbases/s at 4.6 M keys).  With bbduk_bigs_kernel it holds for every k the layout serves (profiles/r04_small_k.jsonl, big / cache-resident Gbases/s at
+// 1.15 M, 4.6 M, 30 M keys: k = 17 238/204, 144/78, 116/63; k = 19 299/203, 189/78, 120/63; k = 21 320/202, 231/77, 158/62; k = 23 324/200, 268/76, 194/62).
+static inline long long big_min_keys(const bbduk_params& p) { (void)p; return BIG_LAYOUT_MIN_KEYS; }
 #define BIG_PLAIN_MIN_KEYS (1LL << 21)             // plain lines (hdist > 0 on the reference side) take over later than minimizer lines: build_both
 
 // expected number of keys (an upper bound is fine) -> layout, allocations

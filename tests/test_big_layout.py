@@ -191,7 +191,8 @@ def _is_big(d):
     ("k=31 hdist=1", dict(k=31, hdist=1), 14_000, False),           # 1.27 M keys of Hamming neighbourhoods: plain lines pay only beyond 2^21 keys
     ("k=31 hdist=1", dict(k=31, hdist=1), 27_000, True),            # 2.45 M of them: plain lines (+ the twin)
     ("k=31", dict(k=31), 900_000, False),                           # below the threshold: the cache-resident map
-    ("k=21", dict(k=21), 1_150_000, False),                         # short k-mers: the cache-resident map is the faster one until 2^25 keys
+    ("k=21", dict(k=21), 1_150_000, True),                          # short k-mers too since bbduk_bigs_kernel (round 4: 320 against 202 Gbases/s)
+    ("ktrim=r k=17 mink=9", dict(k=17, ktrimRight=1, mink=9), 1_150_000, True),
     ("k=31 mkf=0.1", dict(k=31, minKmerFraction=0.1), 1_150_000, False),      # not a plain first-hit kfilter: cache-resident at 1-2 keys per bucket
     ("ktrim=r k=27", dict(k=27, ktrimRight=1), 1_150_000, True),    # ktrim=r: minimizer lines too since round 4 (bbduk_bigs_kernel<KTRIM_R>)
     ("ktrim=l k=27", dict(k=27, ktrimLeft=1), 1_150_000, True),     # ktrim=l and kfilter with maxbadkmers > 0: bbduk_bigs_every_kernel (round 4)
