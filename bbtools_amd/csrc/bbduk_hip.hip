@@ -308,8 +308,16 @@ static bool big_geometry(bbduk_handle* h, const double maxKeys = 0.0) {
         // every base m gives up widens the window W = H - m + 1 over which consecutive k-mers share a line: 4.6 M keys at k = 31: m = 7, W = 9,
         // 5 keys per run (24 lines per 150-base read) where m = 10 gives 3.5 (34 lines); 10^9 keys keep m = 9-10
         // (measured, 4.6 M keys, k = 31: m = 6 224 Gbases/s -- 5.3 % of the keys spill --, 7 262, 8 255, 9 240, 10 219: ~6 bits of margin over the key count)
-        const int need = (int)std::ceil((std::log2(std::max(maxKeys, 1024.0)) + 5.5) / 4.0);
-        h->gm = std::max(std::min(6, H - 1), std::min(std::min(10, H - 1), need));
+        // Re-swept behind the position-ordered gathers (profiles/r04_m_sweep_gather_order.txt).  Two things pull m down -- every base it gives up widens
+        // the window, and short halves have little window to give (k = 21, H = 10, 4.6 M keys: m = 6 264, 7 232, 8 191 Gbases/s; k = 17, 3e7 keys: m = 6 140,
+        // 7 116) -- and one pushes it up: a minimizer of 2m bases has to be rare among the reference's positions, or lines overflow (k = 21, 3e7 keys:
+        // m = 6 185 with 8 % of the keys spilled, m = 7 194; 10^8 keys with m = 6: the build gives up on minimizer lines, 78 Gbases/s).  So: 4m >= log2(keys)
+        // + c with c = 1 for short halves and 3 from H = 13 on (k = 27: 3e7 keys m = 7 265, 8 259; k = 31: 4.6 M keys m = 6 288, 7 308, 8 311), at most
+        // H - 2 (W >= 3), and never less than log2(keys) - 1 bits.
+        const double L2 = std::log2(std::max(maxKeys, 1024.0));
+        const int c = std::max(1, std::min(3, H - 10));
+        const int need = (int)std::ceil((L2 + c) / 4.0), least = (int)std::ceil((L2 - 1.0) / 4.0);
+        h->gm = std::max(std::min(6, H - 1), std::min(std::min(10, H - 1), std::max(least, std::min(need, std::max(6, H - 2)))));
     }
     if (h->hookLdsBits >= 4 && h->hookLdsBits <= H - 1) h->gm = h->hookLdsBits;      // (experiments: BBDUK_HOOK_LDS_BITS = m; such maps have no LDS filter)
     h->gW = h->bigPlain ? 0 : H - h->gm + 1;
