@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(ROOT, "profiles"))
 
 
 def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("--reads", type=int, default=4_000_000); ap.add_argument("--dir", default="/tmp")
+    ap = argparse.ArgumentParser(); ap.add_argument("--reads", type=int, default=4_000_000); ap.add_argument("--dir", default="/tmp"); ap.add_argument("--variants", default="", help="comma-separated subset of host_parse,host_parse_out,deviceingest,deviceingest_out")
     a = ap.parse_args()
     from bbtools_amd import bbduk as B, _build
     from bench_ingest import fastq_text
@@ -21,6 +21,7 @@ def main():
     flags = ["ktrim=r", "k=23", "mink=11", "hdist=1", "ref=adapters", "int=t", "devicebuild=t", "resources=" + os.path.join(ROOT, "data")]
     res = {}
     for name, extra in (("host_parse", []), ("host_parse_out", ["out=" + outp]), ("deviceingest", ["deviceingest=t"]), ("deviceingest_out", ["deviceingest=t", "out=" + outp])):
+        if a.variants and name not in a.variants.split(","): continue
         best = None
         for _ in range(2):
             t0 = time.perf_counter()
