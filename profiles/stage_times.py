@@ -36,12 +36,17 @@ for m in a.masks:
     duk = B.BBDuk(a.args, hooks=hooks)
     d_c = torch.zeros(duk.gpu.counters_len, dtype=torch.int64, device="cuda")
     kmask = duk.gpu.params.mode == B.MODE_KMASK
+    tips = "ktrim=rl" in a.args
+    d_l = torch.empty(n, dtype=torch.int32, device="cuda") if tips else None
     if kmask:
         d_m = torch.zeros(n * L // 32 + 8, dtype=torch.int32, device="cuda")
     for _ in range(5):
         d_c.zero_()
         if kmask:
             rc = B.lib().bbduk_kmask_batch_device(duk.gpu.h, d_bases.data_ptr(), d_off.data_ptr(), n, n * L, 1, d_a.data_ptr(), d_id.data_ptr(), d_fl.data_ptr(), d_m.data_ptr(), d_c.data_ptr(), None)
+            assert rc == 0
+        elif tips:
+            rc = B.lib().bbduk_ktrimtips_batch_device(duk.gpu.h, d_bases.data_ptr(), d_off.data_ptr(), n, n * L, 1, d_a.data_ptr(), d_l.data_ptr(), d_id.data_ptr(), d_fl.data_ptr(), d_c.data_ptr(), None)
             assert rc == 0
         else:
             duk.gpu.process_batch_device(d_bases, d_off, True, d_a, d_id, d_fl, d_c, st)
