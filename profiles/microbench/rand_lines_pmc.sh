@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the binary: mkdir -p profiles/microbench/_bin && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 profiles/microbench/rand_lines.hip -o profiles/microbench/_bin/rand_lines)
+[ -x profiles/microbench/_bin/rand_lines ] || { mkdir -p profiles/microbench/_bin && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 profiles/microbench/rand_lines.hip -o profiles/microbench/_bin/rand_lines; }
 # TLB / fabric counters of the random-line gathers: whole 222 GiB span against 1 GiB slices (sums over all launches of a run).
 # usage: bash profiles/microbench/rand_lines_pmc.sh   (on the GPU box; writes gpurun_out/r04/rand_lines_pmc.txt)
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/r04/rlpmc; mkdir -p $OUT

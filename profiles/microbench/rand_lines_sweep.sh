@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the binary: mkdir -p profiles/microbench/_bin && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 profiles/microbench/rand_lines.hip -o profiles/microbench/_bin/rand_lines)
+[ -x profiles/microbench/_bin/rand_lines ] || { mkdir -p profiles/microbench/_bin && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 profiles/microbench/rand_lines.hip -o profiles/microbench/_bin/rand_lines; }
 # Runs on the GPU box: the random-line rate over a 222 GiB span (configs[3]'s map) and over 23 GiB (the 10^9-key map), whole-span against slices.
 # usage: bash profiles/microbench/rand_lines_sweep.sh > gpurun_out/r04/rand_lines.jsonl
 B=profiles/microbench/_bin/rand_lines
