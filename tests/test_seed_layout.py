@@ -15,7 +15,9 @@ from tests.test_gpu_parity import check_batch
 pytestmark = pytest.mark.gpu
 SEED = {B.HOOK_SEED_LAYOUT: 1}
 CFGS = [("k=31 hdist=1", dict(k=31, hdist=1)), ("k=25 hdist=1", dict(k=25, hdist=1)), ("k=31 hdist=1 mm=f", dict(k=31, hdist=1, maskMiddle=0)),
-        ("k=24 hdist=1 mm=f rieb=f", dict(k=24, hdist=1, maskMiddle=0, requireBothBad=1)), ("k=27 hdist=1 minlen=40", dict(k=27, hdist=1, minReadLength=40))]
+        ("k=24 hdist=1 mm=f rieb=f", dict(k=24, hdist=1, maskMiddle=0, requireBothBad=1)), ("k=27 hdist=1 minlen=40", dict(k=27, hdist=1, minReadLength=40)),
+        # round 4: maxbadkmers > 0 on the seed layout (the per-read walk counts the exact hits)
+        ("k=25 hdist=1 mbk=1", dict(k=25, hdist=1, maxBadKmers0=1)), ("k=31 hdist=1 mbk=3 rieb=f", dict(k=31, hdist=1, maxBadKmers0=3, requireBothBad=1))]
 
 
 def seed_pair(args, okw, refs):
@@ -77,10 +79,10 @@ def test_seed_layout_read_parity(ci):
 
 
 def test_seed_layout_is_not_chosen_where_it_is_not_served():
-    """forbidn=t, maxbadkmers > 0, hdist = 2: the hook only asks; such handles keep the mutants (cache-resident or big layout) and stay exact"""
+    """forbidn=t, hdist = 2: the hook only asks; such handles keep the mutants (cache-resident or big layout) and stay exact"""
     rng = random.Random(8)
     refs = [util.rand_seq(rng, 200, 0.01) for _ in range(4)]
-    for args, okw in (("k=27 hdist=1 forbidn=t", dict(k=27, hdist=1, forbidN=1)), ("k=25 hdist=1 mbk=1", dict(k=25, hdist=1, maxBadKmers0=1)), ("k=21 hdist=2", dict(k=21, hdist=2)),
+    for args, okw in (("k=27 hdist=1 forbidn=t", dict(k=27, hdist=1, forbidN=1)), ("k=21 hdist=2", dict(k=21, hdist=2)),
                       # even k with an explicit one-base mask: the mask is off the mirror centre, seed_check is not exact there (ADVICE r3) -> mutants kept
                       ("k=24 hdist=1 mm=1", dict(k=24, hdist=1, midMaskLen=1)), ("k=30 hdist=1 mm=1", dict(k=30, hdist=1, midMaskLen=1))):
         d, o = seed_pair(args, okw, refs)
@@ -92,21 +94,21 @@ def test_seed_layout_is_not_chosen_where_it_is_not_served():
 
 def test_seed_layout_long_units():
     """units beyond a wave's planes: the tiled kernel (5 kb pair) and the long-read kernel (45 kb read) look the seed layout up through lookup4"""
-    args, okw = CFGS[0]
-    rng = random.Random(31)
-    refs = [util.rand_seq(rng, 300) for _ in range(4)]
-    d, o = seed_pair(args, okw, refs)
-    for big in (5000, 45000):
-        reads = []
-        for i in range(40):
-            n = big if i in (4, 5, 22) else rng.choice([150, 151, 400])
-            r = bytearray(util.rand_seq(rng, n))
-            if rng.random() < 0.5:
-                src = refs[rng.randrange(4)]; a = rng.randrange(len(src) - 50); piece = bytearray(src[a:a + 50]); piece[rng.randrange(50)] = rng.choice(b"ACGT")
-                w = rng.randrange(n - 50); r[w:w + 50] = piece
-            reads.append(bytes(r))
-        check_batch(d, o, reads, True)
-    d.close()
+    for args, okw in (CFGS[0], CFGS[5]):
+        rng = random.Random(31)
+        refs = [util.rand_seq(rng, 300) for _ in range(4)]
+        d, o = seed_pair(args, okw, refs)
+        for big in (5000, 45000):
+            reads = []
+            for i in range(40):
+                n = big if i in (4, 5, 22) else rng.choice([150, 151, 400])
+                r = bytearray(util.rand_seq(rng, n))
+                if rng.random() < 0.5:
+                    src = refs[rng.randrange(4)]; a = rng.randrange(len(src) - 50); piece = bytearray(src[a:a + 50]); piece[rng.randrange(50)] = rng.choice(b"ACGT")
+                    w = rng.randrange(n - 50); r[w:w + 50] = piece
+                reads.append(bytes(r))
+            check_batch(d, o, reads, True)
+        d.close()
 
 
 def test_seed_layout_chosen_from_2e22_keys_with_its_twin():
