@@ -412,7 +412,7 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
     // 2^22 keys on: a 52 kbase reference, 4.7 M keys, 115 against 87 Gbases/s; 19 M keys 159 / 75; 2.45 M keys 87 / 102 -- profiles/r04_seed_vs_plain.jsonl;
     // up to 2^25 keys build_both keeps the cache-resident twin for the units beyond a wave's planes)
     st->seed = (maxKeys > (double)SEED_JOINT_MIN_KEYS || h->hookSeedLayout) && !h->hookBigLayout && !h->hookNoBigLayout && hdist == 1 && big_layout_eligible(h->p) &&
-               h->p.mode == BBDUK_MODE_KFILTER && !h->p.forbidNs && !h->sealTable && seed_geometry(h, maxKeys);      // (maxbadkmers > 0 too: the walk counts)
+               h->p.mode == BBDUK_MODE_KFILTER && !h->sealTable && seed_geometry(h, maxKeys);      // (maxbadkmers > 0 and forbidn too, round 4: the walk counts, seed_window resets)
     if (st->seed && h->seedHl != h->seedHr && !(maxKeys > (double)SEED_LAYOUT_MIN_KEYS || h->hookSeedLayout)) st->seed = false;      // (the two-gather form keeps 2^25)
     long long bigMin = hdist > 0 ? std::max<long long>(big_min_keys(h->p), BIG_PLAIN_MIN_KEYS) : big_min_keys(h->p);      // (plain lines take over later: build_both)
     // a streamed build (bbduk_build_begin / _add_device / _end) sees the reference once and cannot keep the cache-resident twin build_both gives the
