@@ -347,8 +347,16 @@ static bool params_general(const bbduk_params& p) {               // the same pr
 // function, i.e. up to 2^31 keys; a ktrim map beyond that is refused at build time (big_geometry_ok_for).
 // ... and ktrim=l, like kfilter with maxbadkmers > 0 an every-hit scan: bbduk_bigs_every_kernel (the scan's candidates all verified, the mode's facts read
 // out of the exact hit plane).
+// Round 5: every operator family -- ksplit, ktrim=n, ktrim=rl, findbestmatch and kfilter with mkf / mcf read their facts out of the same exact hit plane
+// (bbduk_bigs_every_kernel, wave_body BIGS && EVERY).  Still cache-resident at any size: k > 31 (the pair scan's run state machine), query expansion
+// (qhdist: the tiled kernels), and the flags of the GENERAL family that change a window or the key (params_general_flags).
+static bool params_general_flags(const bbduk_params& p) {         // params_general without the thresholds mkf / mcf (they only read the hit plane)
+    const bool useShort = p.mink > 0 && p.mink < p.k;
+    return p.qhdist > 0 || p.qhdist2 > 0 || p.restrictLeft > 0 || p.restrictRight > 0 || p.skipR1 || p.skipR2 || !p.rcomp ||
+           (useShort && p.middleMask != -1) || p.k < 16 || p.qSkip > 1 || p.speed > 0;
+}
 static bool big_layout_eligible(const bbduk_params& p) {
-    return (p.mode == BBDUK_MODE_KFILTER || p.mode == BBDUK_MODE_KTRIM_R || p.mode == BBDUK_MODE_KTRIM_L) && !params_general(p) && !(p.kbig > p.k) && !p.findBestMatch;
+    return p.mode >= BBDUK_MODE_KFILTER && p.mode <= BBDUK_MODE_KSPLIT && !params_general_flags(p) && !(p.kbig > p.k);
 }
 // seed layout (bbduk_seed.inc): the two halves beside the (at most one) masked middle base, each <= 16 bases
 static bool seed_geometry(bbduk_handle* h, const double maxKeys = 0.0) {
@@ -412,7 +420,7 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
     // 2^22 keys on: a 52 kbase reference, 4.7 M keys, 115 against 87 Gbases/s; 19 M keys 159 / 75; 2.45 M keys 87 / 102 -- profiles/r04_seed_vs_plain.jsonl;
     // up to 2^25 keys build_both keeps the cache-resident twin for the units beyond a wave's planes)
     st->seed = (maxKeys > (double)SEED_JOINT_MIN_KEYS || h->hookSeedLayout) && !h->hookBigLayout && !h->hookNoBigLayout && hdist == 1 && big_layout_eligible(h->p) &&
-               h->p.mode == BBDUK_MODE_KFILTER && !h->sealTable && seed_geometry(h, maxKeys);      // (maxbadkmers > 0 and forbidn too, round 4: the walk counts, seed_window resets)
+               h->p.mode == BBDUK_MODE_KFILTER && !h->p.findBestMatch && h->p.minKmerFraction == 0.f && !(h->p.minCoveredFraction > 0.f) && !h->sealTable && seed_geometry(h, maxKeys);      // (maxbadkmers > 0 and forbidn too, round 4: the walk counts, seed_window resets)
     if (st->seed && h->seedHl != h->seedHr && !(maxKeys > (double)SEED_LAYOUT_MIN_KEYS || h->hookSeedLayout)) st->seed = false;      // (the two-gather form keeps 2^25)
     long long bigMin = hdist > 0 ? std::max<long long>(big_min_keys(h->p), BIG_PLAIN_MIN_KEYS) : big_min_keys(h->p);      // (plain lines take over later: build_both)
     // a streamed build (bbduk_build_begin / _add_device / _end) sees the reference once and cannot keep the cache-resident twin build_both gives the
@@ -858,10 +866,17 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
                             int32_t*, int32_t*, uint8_t*, int32_t*, int32_t*, int64_t*);
     typedef void (*kscan_full_t)(const KParams, const uint8_t*, const int64_t*, const int64_t, const int64_t, const int,
                                  int32_t*, int32_t*, uint8_t*, int32_t*, int32_t*, int64_t*, const int*);
-    const kscan_full_t fn = red == RED_SPLIT ? bbduk_kscan_kernel<RED_SPLIT> : (red == RED_BEST ? bbduk_kscan_kernel<RED_BEST> : bbduk_kscan_kernel<RED_BIG>);
-    const kscan_full_t lfn = red == RED_SPLIT ? bbduk_kscan_long_kernel<RED_SPLIT> : (red == RED_BEST ? bbduk_kscan_long_kernel<RED_BEST> : bbduk_kscan_long_kernel<RED_BIG>);
+    // A big-layout map (round 5: ksplit and findbestmatch take it like the other operators): bbduk_bigs_every_kernel scans, the fallbacks for units beyond
+    // a wave's planes run over the cache-resident twin where the map has one (build_both), else their big-layout instantiations (bbduk_big_tiles.hip)
+    const bool bigs = K.big != 0;
+    if (bigs && (!K.gV32 || h->hookPairScan || red == RED_BIG)) return fail(h, BBDUK_ERR_STATE, "big-layout map with a scan its kernels do not serve");
+    if (K.seed) return fail(h, BBDUK_ERR_STATE, "seed-layout map with a scan its kernel does not serve");
+    const bool twin = bigs && h->hasAlt;
+    const kscan_full_t fn = (bigs && !twin) ? bbduk_pick_kscan_big_tile(red) : (red == RED_SPLIT ? bbduk_kscan_kernel<RED_SPLIT> : (red == RED_BEST ? bbduk_kscan_kernel<RED_BEST> : bbduk_kscan_kernel<RED_BIG>));
+    const kscan_full_t lfn = (bigs && !twin) ? bbduk_pick_kscan_big_long(red) : (red == RED_SPLIT ? bbduk_kscan_long_kernel<RED_SPLIT> : (red == RED_BEST ? bbduk_kscan_long_kernel<RED_BEST> : bbduk_kscan_long_kernel<RED_BIG>));
     const size_t dynLds = h->ldsBits ? ((size_t)1 << (h->ldsBits - 3)) : 0;
-    HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(fn), dynLds));
+    const size_t dynLds2 = twin ? (h->ldsBitsAlt ? ((size_t)1 << (h->ldsBitsAlt - 3)) : 0) : dynLds;      // the fallbacks' filter: the twin's
+    HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(fn), dynLds2));
     const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
     const int grid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU);
     std::lock_guard<std::mutex> lg(h->launchMu);
@@ -875,7 +890,7 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     {   // pre-pass per READ: one beyond the tiled kernel's planes sends the batch to bbduk_kscan_long_kernel; ksplit: one beyond a
         // wave's planes (bit 0) sends it to the tiled kernel, else bbduk_wave_kernel<KSPLIT> takes it
         const int sgrid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)h->numCU * 8);
-        const bool splitFour = red == RED_SPLIT && !packed && stream_every_ok(h, K) && (K.forbidNs || kparams_general(K));   // four planes per wave: shorter ones
+        const bool splitFour = red == RED_SPLIT && !packed && stream_every_ok(h, K) && (K.forbidNs || kparams_general(K));   // four planes per wave: shorter ones (not over a big-layout map: stream_every_ok)
         bbduk_span_kernel<<<dim3(std::max(sgrid, 1)), dim3(256), 0, st>>>(d_offsets, n, 0, d_flag, red == RED_SPLIT && !packed ? (int64_t)(splitFour ? WUNIT_MAX_KM : WUNIT_MAX) : (int64_t)(KM_CAP_BASES - 32), (int64_t)(KM_CAP_BASES - 32));
         if (red != RED_SPLIT) {                                     // findBestMatch, k > 31: a unit (pair) beyond a wave's planes (bit 0) -> the tiled kernel
             const int64_t units = paired ? n / 2 : n;
@@ -888,9 +903,9 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
         K.waveFirst = 1;                                            // (main_scan_pair_kbig) per read
         const bool general = params_general(h->p);
         const bool every = red == RED_BEST && stream_every_ok(h, K);     // findbestmatch: the stream scan, ids gathered per read (wave_body: FBM)
-        const batch_kernel_t wk = every ? bbduk_pick_stream_every(BBDUK_MODE_FBM, false, K.forbidNs != 0, general)
+        const batch_kernel_t wk = bigs ? bbduk_pick_bigs_every(BBDUK_MODE_FBM, false) : every ? bbduk_pick_stream_every(BBDUK_MODE_FBM, false, K.forbidNs != 0, general)
                                         : bbduk_pick_mode_wave(red == RED_BEST ? BBDUK_MODE_FBM : BBDUK_MODE_KBIG, general, packed, K.forbidNs != 0);
-        const size_t waveLds = dynLds + ((every && (K.forbidNs || general)) ? WAVE_LDS_BYTES_KM : WAVE_LDS_BYTES);
+        const size_t waveLds = bigs ? dynLds + WAVE_LDS_BYTES_BIGS : dynLds + ((every && (K.forbidNs || general)) ? WAVE_LDS_BYTES_KM : WAVE_LDS_BYTES);
         HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(wk), waveLds));
         const int64_t nmt = (n + MT_READS - 1) / MT_READS;
         const int wgrid = (int)std::min<int64_t>((nmt + NWAVES - 1) / NWAVES, (int64_t)h->numCU);
@@ -900,20 +915,22 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
         K.waveFirst = 1; K.outLeft = d_left; K.outRight = d_right;
         const bool general = params_general(h->p);
         const bool every = stream_every_ok(h, K);
-        const batch_kernel_t wk = every ? bbduk_pick_stream_every(BBDUK_MODE_KSPLIT, true, K.forbidNs != 0, general) : bbduk_pick_mode_wave(BBDUK_MODE_KSPLIT, general, false, K.forbidNs != 0);
-        const size_t waveLds = dynLds + ((every && (K.forbidNs || general)) ? WAVE_LDS_BYTES_KM : WAVE_LDS_BYTES);
+        const batch_kernel_t wk = bigs ? bbduk_pick_bigs_every(BBDUK_MODE_KSPLIT, true) : every ? bbduk_pick_stream_every(BBDUK_MODE_KSPLIT, true, K.forbidNs != 0, general) : bbduk_pick_mode_wave(BBDUK_MODE_KSPLIT, general, false, K.forbidNs != 0);
+        const size_t waveLds = bigs ? dynLds + WAVE_LDS_BYTES_BIGS : dynLds + ((every && (K.forbidNs || general)) ? WAVE_LDS_BYTES_KM : WAVE_LDS_BYTES);
         HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(wk), waveLds));
         const int64_t nmt = (n + MT_READS - 1) / MT_READS;
         const int wgrid = (int)std::min<int64_t>((nmt + NWAVES - 1) / NWAVES, (int64_t)h->numCU);
         wk<<<dim3(std::max(wgrid, 1)), dim3(BLOCK_THREADS), waveLds, st>>>(K, d_bases, d_offsets, n, total_bases, 0, d_a, d_id, d_fl, d_counters, d_flag);
     }
-    fn<<<dim3(grid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_left, d_right, d_counters, d_flag);
+    if (red == RED_SPLIT && packed && bigs) return fail(h, BBDUK_ERR_STATE, "big-layout map with a scan its kernels do not serve");
+    const KParams K2 = twin ? alt_kparams(h, K) : K;                // (after K's outputs are set)
+    fn<<<dim3(grid), dim3(BLOCK_THREADS), dynLds2, st>>>(K2, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_left, d_right, d_counters, d_flag);
     HIP_TRY(h, hipEventRecord(h->ev1[evi], st));
     h->evCount++;
-    HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(lfn), dynLds));
+    HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(lfn), dynLds2));
     const int64_t lunits = (paired && red != RED_SPLIT) ? n / 2 : n;
     const int lgrid = (int)std::min<int64_t>((lunits + NWAVES - 1) / NWAVES, (int64_t)h->numCU);
-    lfn<<<dim3(std::max(lgrid, 1)), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_left, d_right, d_counters, d_flag);
+    lfn<<<dim3(std::max(lgrid, 1)), dim3(BLOCK_THREADS), dynLds2, st>>>(K2, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_left, d_right, d_counters, d_flag);
     HIP_TRY(h, hipEventRecord(h->evDone[evi], st));
     HIP_TRY(h, hipGetLastError());
     return BBDUK_OK;
@@ -971,11 +988,16 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
         kp.wave = bbduk_pick_bigs(K.mode, K.useShort != 0, packed); waveLdsUse = dynLds + WAVE_LDS_BYTES_BIGS;
         if (K.mode == BBDUK_MODE_KTRIM_R) kp.tile = bbduk_pick_ktrim_r_big_tile();
     }
-    if (K.big && K.gV32 && !firstHit && !h->hookPairScan && (K.mode == BBDUK_MODE_KTRIM_L || (K.mode == BBDUK_MODE_KFILTER && K.mkf == 0.f && K.mcf == 0.f)) &&
-        !kparams_general(K)) {                                    // ... and its every-hit form: ktrim=l, kfilter with maxbadkmers > 0
+    bool bigsChosen = K.big && K.gV32 && firstHit && (!h->hookPairScan || K.mode != BBDUK_MODE_KFILTER);
+    if (K.big && K.gV32 && !firstHit && !h->hookPairScan && (K.mode == BBDUK_MODE_KTRIM_L || K.mode == BBDUK_MODE_KFILTER)) {      // ... and its every-hit form: ktrim=l, kfilter with maxbadkmers > 0, mkf, mcf
+        bigsChosen = true;
         kp.wave = bbduk_pick_bigs_every(K.mode, K.useShort != 0); waveLdsUse = dynLds + WAVE_LDS_BYTES_BIGS;
         if (K.mode == BBDUK_MODE_KTRIM_L) kp.tile = bbduk_pick_ktrim_l_big_tile();
     }
+    // (pick_kernel hands every big-layout map the kfilter pair scan -- round 2's kernel, which serves plain kfilter only: any other configuration must have
+    // been given one of the stream scans above, or it would run a MODE = KFILTER kernel over a ktrim handle: ADVICE r4)
+    if (K.big && !bigsChosen && (K.mode != BBDUK_MODE_KFILTER || K.mkf != 0.f || K.mcf > 0.f))
+        return fail(h, BBDUK_ERR_STATE, "big-layout map with a scan its kernels do not serve (BBDUK_HOOK_PAIR_SCAN serves plain kfilter only)");
     // a big-layout map with a cache-resident twin (build_both): the wave kernel scans the big layout, the fallbacks for units beyond a wave's
     // planes (tile kernel, long-read kernel) run their cache-resident instantiations over the twin
     const bool twin = (K.big || K.seed) && h->hasAlt;
@@ -1204,7 +1226,15 @@ static int launch_tips(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d
     KParams K = make_kparams(h);
     K.undef = packed ? d_undef : nullptr;
     const size_t dynLds = h->ldsBits ? ((size_t)1 << (h->ldsBits - 3)) : 0;
-    HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(bbduk_ktrimtips_kernel<>), dynLds));
+    // a big-layout map (round 5): bbduk_bigs_every_kernel<KTRIM_TIPS> scans; units beyond a wave's planes: the twin, or the big-layout tile kernels
+    const bool bigs = K.big != 0;
+    if (bigs && (!K.gV32 || h->hookPairScan)) return fail(h, BBDUK_ERR_STATE, "big-layout map with a scan its kernels do not serve");
+    if (K.seed) return fail(h, BBDUK_ERR_STATE, "seed-layout map with a scan its kernel does not serve");
+    const bool twin = bigs && h->hasAlt;
+    const size_t dynLds2 = twin ? (h->ldsBitsAlt ? ((size_t)1 << (h->ldsBitsAlt - 3)) : 0) : dynLds;
+    const tips_tile_t tfn = (bigs && !twin) ? bbduk_pick_tips_big_tile() : bbduk_ktrimtips_kernel<>;
+    const tips_tile_t tlfn = (bigs && !twin) ? bbduk_pick_tips_big_long() : bbduk_long_tips_kernel<>;
+    HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(tfn), dynLds2));
     const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
     const int grid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU);
     std::lock_guard<std::mutex> lg(h->launchMu);
@@ -1226,21 +1256,22 @@ static int launch_tips(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d
     {   // the main kernel's shape: wave-autonomous mini-tiles, candidate scan for the right pass, one lane per read in the finish
         K.waveFirst = 1; K.outLeft = d_l;
         const bool general = params_general(h->p);
-        const batch_kernel_t wk = (stream_every_ok(h, K) && !K.forbidNs && !general) ? bbduk_pick_stream_tips(packed)
+        const batch_kernel_t wk = bigs ? bbduk_pick_bigs_every(BBDUK_MODE_KTRIM_TIPS, true) : (stream_every_ok(h, K) && !K.forbidNs && !general) ? bbduk_pick_stream_tips(packed)
                                                                                       : bbduk_pick_mode_wave(BBDUK_MODE_KTRIM_TIPS, general, packed, K.forbidNs != 0);
-        const size_t waveLds = dynLds + WAVE_LDS_BYTES;
+        const size_t waveLds = dynLds + (bigs ? WAVE_LDS_BYTES_BIGS : WAVE_LDS_BYTES);
         HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(wk), waveLds));
         const int64_t nmt = (n + MT_READS - 1) / MT_READS;
         const int wgrid = (int)std::min<int64_t>((nmt + NWAVES - 1) / NWAVES, (int64_t)h->numCU);
         wk<<<dim3(std::max(wgrid, 1)), dim3(BLOCK_THREADS), waveLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_r, d_id, d_fl, d_counters, d_flag);
     }
-    bbduk_ktrimtips_kernel<><<<dim3(grid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_r, d_l, d_id, d_fl, d_counters, d_flag);
+    const KParams K2 = twin ? alt_kparams(h, K) : K;
+    tfn<<<dim3(grid), dim3(BLOCK_THREADS), dynLds2, st>>>(K2, d_bases, d_offsets, n, total_bases, (int)paired, d_r, d_l, d_id, d_fl, d_counters, d_flag);
     HIP_TRY(h, hipEventRecord(h->ev1[evi], st));
     h->evCount++;
-    HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(bbduk_long_tips_kernel<>), dynLds));
+    HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(tlfn), dynLds2));
     const int64_t units = paired ? n / 2 : n;
     const int lgrid = (int)std::min<int64_t>((units + NWAVES - 1) / NWAVES, (int64_t)h->numCU);
-    bbduk_long_tips_kernel<><<<dim3(std::max(lgrid, 1)), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_r, d_l, d_id, d_fl, d_counters, d_flag);
+    tlfn<<<dim3(std::max(lgrid, 1)), dim3(BLOCK_THREADS), dynLds2, st>>>(K2, d_bases, d_offsets, n, total_bases, (int)paired, d_r, d_l, d_id, d_fl, d_counters, d_flag);
     HIP_TRY(h, hipEventRecord(h->evDone[evi], st));
     HIP_TRY(h, hipGetLastError());
     return BBDUK_OK;
@@ -1309,7 +1340,16 @@ static int launch_kmask(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     KParams K = make_kparams(h);
     K.undef = packed ? d_undef : nullptr;
     const size_t dynLds = h->ldsBits ? ((size_t)1 << (h->ldsBits - 3)) : 0;
-    HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(bbduk_kmask_kernel<>), dynLds));
+    // a big-layout map (round 5): bbduk_bigs_every_kernel<KMASK> scans, its exact hit plane is the mask stage's; units beyond a wave's planes: the twin, or
+    // the big-layout tile kernels
+    const bool bigs = K.big != 0;
+    if (bigs && (!K.gV32 || h->hookPairScan)) return fail(h, BBDUK_ERR_STATE, "big-layout map with a scan its kernels do not serve");
+    if (K.seed) return fail(h, BBDUK_ERR_STATE, "seed-layout map with a scan its kernel does not serve");
+    const bool twin = bigs && h->hasAlt;
+    const size_t dynLds2 = twin ? (h->ldsBitsAlt ? ((size_t)1 << (h->ldsBitsAlt - 3)) : 0) : dynLds;
+    const kmask_tile_t mfn = (bigs && !twin) ? bbduk_pick_kmask_big_tile() : bbduk_kmask_kernel<>;
+    const kmask_long_t mlfn = (bigs && !twin) ? bbduk_pick_kmask_big_long() : bbduk_kmask_long_kernel<>;
+    HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(mfn), dynLds2));
     HIP_TRY(h, hipMemsetAsync(d_mask, 0, ((size_t)(total_bases + 31) / 32 + 2) * sizeof(uint32_t), st));
     const int64_t ntiles = (n + TILE_READS - 1) / TILE_READS;
     const int grid = (int)std::min<int64_t>(ntiles, (int64_t)h->numCU);
@@ -1324,26 +1364,27 @@ static int launch_kmask(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
         // to bbduk_kmask_long_kernel); else bbduk_wave_kernel<KMASK> takes it
         const int64_t units = paired ? n / 2 : n;
         const int ugrid = (int)std::min<int64_t>((units + 255) / 256, (int64_t)h->numCU * 8);
-        bbduk_span_kernel<<<dim3(std::max(ugrid, 1)), dim3(256), 0, st>>>(d_offsets, n, (int)paired, d_flag, (int64_t)WUNIT_MAX_KM, (int64_t)0x7FFFFFFFFFFFLL);
+        bbduk_span_kernel<<<dim3(std::max(ugrid, 1)), dim3(256), 0, st>>>(d_offsets, n, (int)paired, d_flag, (int64_t)(bigs ? WUNIT_MAX : WUNIT_MAX_KM), (int64_t)0x7FFFFFFFFFFFLL);
     }
     HIP_TRY(h, hipEventRecord(h->ev0[evi], st));
     {   // the main kernel's shape: wave-autonomous mini-tiles, a fourth plane for the hit positions, one lane per read in the finish
         K.waveFirst = 1; K.outMask = d_mask;
         const bool general = params_general(h->p);
-        const batch_kernel_t wk = stream_every_ok(h, K) ? bbduk_pick_stream_every(BBDUK_MODE_KMASK, true, K.forbidNs != 0, general)
+        const batch_kernel_t wk = bigs ? bbduk_pick_bigs_every(BBDUK_MODE_KMASK, true) : stream_every_ok(h, K) ? bbduk_pick_stream_every(BBDUK_MODE_KMASK, true, K.forbidNs != 0, general)
                                                         : bbduk_pick_mode_wave(BBDUK_MODE_KMASK, general, packed, K.forbidNs != 0);
-        const size_t waveLds = dynLds + WAVE_LDS_BYTES_KM;
+        const size_t waveLds = dynLds + (bigs ? WAVE_LDS_BYTES_BIGS : WAVE_LDS_BYTES_KM);
         HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(wk), waveLds));
         const int64_t nmt = (n + MT_READS - 1) / MT_READS;
         const int wgrid = (int)std::min<int64_t>((nmt + NWAVES - 1) / NWAVES, (int64_t)h->numCU);
         wk<<<dim3(std::max(wgrid, 1)), dim3(BLOCK_THREADS), waveLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_counters, d_flag);
     }
-    bbduk_kmask_kernel<><<<dim3(grid), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_mask, d_counters, d_flag);
+    const KParams K2 = twin ? alt_kparams(h, K) : K;
+    mfn<<<dim3(grid), dim3(BLOCK_THREADS), dynLds2, st>>>(K2, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_fl, d_mask, d_counters, d_flag);
     HIP_TRY(h, hipEventRecord(h->ev1[evi], st));
     h->evCount++;
-    HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(bbduk_kmask_long_kernel<>), dynLds));
+    HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(mlfn), dynLds2));
     const int lgrid = (int)std::min<int64_t>((n + NWAVES - 1) / NWAVES, (int64_t)h->numCU);     // sequences beyond the tiled kernel's planes
-    bbduk_kmask_long_kernel<><<<dim3(std::max(lgrid, 1)), dim3(BLOCK_THREADS), dynLds, st>>>(K, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_mask, d_counters, d_flag);
+    mlfn<<<dim3(std::max(lgrid, 1)), dim3(BLOCK_THREADS), dynLds2, st>>>(K2, d_bases, d_offsets, n, total_bases, (int)paired, d_a, d_id, d_mask, d_counters, d_flag);
     HIP_TRY(h, hipEventRecord(h->evDone[evi], st));
     HIP_TRY(h, hipGetLastError());
     return BBDUK_OK;

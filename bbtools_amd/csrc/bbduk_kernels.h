@@ -25,7 +25,18 @@ batch_kernel_t bbduk_pick_stream_tips(bool packed);                            /
 batch_kernel_t bbduk_pick_stream_seed(bool forbidN, bool packed);              // the stream scan over a seed-layout map (bbduk_seed.inc)
 batch_kernel_t bbduk_pick_ktrim_l_big_tile();
 batch_kernel_t bbduk_pick_bigs_every(int mode, bool useShort);                                       // bbduk_bigs_every.hip: ... and its every-hit form (ktrim=l, kfilter with maxbadkmers > 0)
-batch_kernel_t bbduk_pick_bigs(int mode, bool useShort, bool packed);                                 // bbduk_bigs.hip: the stream scan over a big-layout map with the 32-bit line function
+batch_kernel_t bbduk_pick_bigs(int mode, bool useShort, bool packed);
+// bbduk_big_tiles.hip: the tiled / long-read fallbacks of the secondary operators with a big-layout map's exact lookups (maps without a twin)
+typedef void (*kmask_tile_t)(const KParams, const uint8_t*, const int64_t*, const int64_t, const int64_t, const int, int32_t*, int32_t*, uint8_t*, uint32_t*, int64_t*, int*);
+typedef void (*kmask_long_t)(const KParams, const uint8_t*, const int64_t*, const int64_t, const int64_t, const int, int32_t*, int32_t*, uint32_t*, int64_t*, const int*);
+typedef void (*tips_tile_t)(const KParams, const uint8_t*, const int64_t*, const int64_t, const int64_t, const int, int32_t*, int32_t*, int32_t*, uint8_t*, int64_t*, const int*);
+typedef void (*kscan_tile_t)(const KParams, const uint8_t*, const int64_t*, const int64_t, const int64_t, const int, int32_t*, int32_t*, uint8_t*, int32_t*, int32_t*, int64_t*, const int*);
+kmask_tile_t bbduk_pick_kmask_big_tile();
+kmask_long_t bbduk_pick_kmask_big_long();
+tips_tile_t bbduk_pick_tips_big_tile();
+tips_tile_t bbduk_pick_tips_big_long();
+kscan_tile_t bbduk_pick_kscan_big_tile(int red);       // red = RED_SPLIT | RED_BEST (k > 31 keeps the cache-resident layout)
+kscan_tile_t bbduk_pick_kscan_big_long(int red);                                 // bbduk_bigs.hip: the stream scan over a big-layout map with the 32-bit line function
 
 #ifdef BBDUK_DEVICE_INC            /* translation units that hold kernel templates */
 template <int MODE, bool SHORT, bool FORBIDN, bool GENERAL>

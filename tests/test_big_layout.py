@@ -10,7 +10,7 @@ import pytest
 from bbtools_amd import bbduk as B
 from oracle.oracle_ffi import Oracle, pack_reads
 from tests import util
-from tests.test_gpu_parity import check_batch, FUZZ
+from tests.test_gpu_parity import check_batch, check_kmask, check_tips, check_split, FUZZ
 
 pytestmark = pytest.mark.gpu
 BIG = {B.HOOK_BIG_LAYOUT: 1}
@@ -193,7 +193,14 @@ def _is_big(d):
     ("k=31", dict(k=31), 900_000, False),                           # below the threshold: the cache-resident map
     ("k=21", dict(k=21), 1_150_000, True),                          # short k-mers too since bbduk_bigs_kernel (round 4: 320 against 202 Gbases/s)
     ("ktrim=r k=17 mink=9", dict(k=17, ktrimRight=1, mink=9), 1_150_000, True),
-    ("k=31 mkf=0.1", dict(k=31, minKmerFraction=0.1), 1_150_000, False),      # not a plain first-hit kfilter: cache-resident at 1-2 keys per bucket
+    ("k=31 mkf=0.1", dict(k=31, minKmerFraction=0.1), 1_150_000, True),       # round 5: the thresholds read the exact hit plane of bbduk_bigs_every_kernel
+    ("k=31 mcf=0.3", dict(k=31, minCoveredFraction=0.3), 1_150_000, True),
+    ("k=27 fbm=t", dict(k=27, findBestMatch=1), 1_150_000, True),             # ... and so do findbestmatch, ksplit, ktrim=n and ktrim=rl
+    ("ksplit=t k=27 mink=12", dict(k=27, mink=12, ksplit=1), 1_150_000, True),
+    ("ktrim=n k=27 mink=12", dict(k=27, mink=12, ktrimN=1), 1_150_000, True),
+    ("ktrim=rl k=27 mink=12", dict(k=27, mink=12, ktrimRight=1, ktrimLeft=1), 1_150_000, True),
+    ("k=31 restrictleft=100", dict(k=31, restrictLeft=100), 1_150_000, False),   # a flag of the GENERAL family that changes the windows: cache-resident
+    ("k=40", dict(k=31, kbig=40, maskMiddle=0), 1_150_000, False),            # k > 31: the pair scan's run state machine, cache-resident
     ("ktrim=r k=27", dict(k=27, ktrimRight=1), 1_150_000, True),    # ktrim=r: minimizer lines too since round 4 (bbduk_bigs_kernel<KTRIM_R>)
     ("ktrim=l k=27", dict(k=27, ktrimLeft=1), 1_150_000, True),     # ktrim=l and kfilter with maxbadkmers > 0: bbduk_bigs_every_kernel (round 4)
     ("k=31 mbk=2", dict(k=31, maxBadKmers0=2), 1_150_000, True),
@@ -212,7 +219,8 @@ def test_layout_chosen_by_key_count(args, okw, genome, want_big):
         got = d.gpu.table_lookup(probe)
         assert np.array_equal(got[:len(sel)], vs[sel]) and int((got[len(sel):] > 0).sum()) == 0
         b, off = B.synth_generate_host(B.synth_params(17, n_rate=0.002, contam=g[:200_000], contam_frac=0.05), 0, 20_000)
-        for paired in (True, False):
+        pairings = (False,) if okw.get("ksplit") else (True, False)
+        for paired in pairings:
             d.gpu.reset_counters(); o.reset_counters()
             ga, gi, gf = d.gpu.process_batch(b, off, paired)
             oa, oi, of = o.process_batch(b, off, paired, nthreads=8)
@@ -227,7 +235,7 @@ def test_layout_chosen_by_key_count(args, okw, genome, want_big):
                  cut(5000), util.rand_seq(rng, 2600), util.rand_seq(rng, 64000), cut(40) + util.rand_seq(rng, 45000)]
         for reads in (longs[:2] + [util.rand_seq(rng, 150) for _ in range(600)], longs):
             bb, oo = pack_reads(reads)
-            for paired in (True, False):
+            for paired in pairings:
                 d.gpu.reset_counters(); o.reset_counters()
                 ga, gi, gf = d.gpu.process_batch(bb, oo, paired)
                 oa, oi, of = o.process_batch(bb, oo, paired, nthreads=4)
@@ -319,4 +327,75 @@ def _planted_pieces_case(args, okw):
             if rng.random() < 0.5 and n > okw["k"]: r[rng.randrange(n)] = rng.choice(b".N")
             long_reads.append(bytes(r))
         check_batch(d, o, long_reads, True)
+        d.close()
+
+
+FAMILIES = [("ksplit=t k=23 mink=11 hdist=1", dict(k=23, mink=11, hdist=1, ksplit=1)),
+            ("ksplit=t k=31", dict(k=31, ksplit=1)),
+            ("ksplit=t k=27 mink=9 forbidn=t tp=-1", dict(k=27, mink=9, forbidN=1, ksplit=1, trimPad=-1)),
+            ("ktrim=n k=23 mink=11 hdist=1", dict(k=23, mink=11, hdist=1, ktrimN=1)),
+            ("ktrim=n k=31 tp=2", dict(k=31, ktrimN=1, trimPad=2)),
+            ("ktrim=n k=25 mink=12 kmaskfullycovered=t", dict(k=25, mink=12, ktrimN=1, kmaskFullyCovered=1)),
+            ("kmask=lc k=27 forbidn=t hdist=1 rieb=f minlen=40", dict(k=27, ktrimN=1, forbidN=1, hdist=1, requireBothBad=1, minReadLength=40)),
+            ("ktrim=rl k=23 mink=11 hdist=1 tpe", dict(k=23, mink=11, hdist=1, ktrimLeft=1, ktrimRight=1, trimPairsEvenly=1)),
+            ("ktrim=rl k=31", dict(k=31, ktrimLeft=1, ktrimRight=1)),
+            ("ktrim=rl k=25 mink=10 forbidn=t hdist=1 tp=1", dict(k=25, mink=10, forbidN=1, hdist=1, ktrimLeft=1, ktrimRight=1, trimPad=1)),
+            ("ktrim=rl k=24 mm=f ktrimexclusive=t", dict(k=24, maskMiddle=0, ktrimLeft=1, ktrimRight=1, ktrimExclusive=1)),
+            ("k=25 fbm=t", dict(k=25, findBestMatch=1)),
+            ("k=31 hdist=1 rename=t", dict(k=31, hdist=1, findBestMatch=1)),
+            ("k=31 mkf=0.2", dict(k=31, minKmerFraction=0.2)),
+            ("k=27 mkf=0.05 forbidn=t hdist=1", dict(k=27, minKmerFraction=0.05, forbidN=1, hdist=1)),
+            ("k=31 mcf=0.5", dict(k=31, minCoveredFraction=0.5)),
+            ("k=25 mcf=0.2 mm=f rieb=f", dict(k=25, minCoveredFraction=0.2, maskMiddle=0, requireBothBad=1)),
+            ("k=31 mbk=7", dict(k=31, maxBadKmers0=7))]
+
+
+@pytest.mark.parametrize("ci", range(len(FAMILIES)))
+def test_big_layout_operator_families(ci):
+    """Round 5: ksplit, ktrim=n, ktrim=rl, findbestmatch and kfilter with mkf / mcf against a big-layout map (bbduk_bigs_every_kernel: the exact
+    hit plane behind the stream scan over the minimizer lines; the mode's facts are read out of it).  Forced onto small references, so the map has
+    no cache-resident twin and the units beyond a wave's planes run the big-layout instantiations of the tiled and the long-read kernels
+    (bbduk_big_tiles.hip).  Every output the operator has is compared: mask bits, both trim amounts, split spans, match lists."""
+    args, okw = FAMILIES[ci]
+    rng = random.Random(31000 + ci)
+    refs = [util.rand_seq(rng, 6000, 0.002), util.rand_seq(rng, 900), util.rand_seq(rng, 40), util.rand_seq(rng, 2500)]
+    refs.append(refs[0][100:180] + refs[1][-70:])               # a scaffold sharing k-mers with two others: first-writer-wins ids
+    k = okw["k"]
+    for build, hooks in (("device", BIG), ("host", BIG), ("device", BIGWIDE)):
+        d, o = big_pair(args, okw, refs=refs, build=build, hooks=hooks)
+        assert _is_big(d)
+        ks, vs = o.dump_pairs()
+        assert np.array_equal(d.gpu.table_lookup(ks), vs)
+        reads = util.fuzz_reads(rng, refs, 700, [0, 1, 10, 11, 12, 24, 25, 30, 31, 32, 75, 100, 150, 151, 250, 300], junk=True)
+        for i in range(300):                                    # reference pieces of every length at either end, in the middle, twice, with an N or junk nearby
+            n = rng.choice([100, 150, 151, 250])
+            r = bytearray(util.rand_seq(rng, n))
+            for _ in range(rng.choice([1, 1, 2])):
+                src = refs[rng.choice([0, 0, 1, 3, 4])]; cut = rng.randint(5, 90)
+                a = rng.randrange(max(1, len(src) - cut)); piece = bytearray(src[a:a + cut])
+                if rng.random() < 0.5: piece = bytearray(util.revcomp(bytes(piece)))
+                if rng.random() < 0.3: piece[rng.randrange(len(piece))] = rng.choice(b"ACGTN.")
+                cut = len(piece)
+                w = rng.choice([0, n - cut, rng.randrange(n - cut + 1), n // 2 - cut // 2])
+                r[w:w + cut] = piece
+            if rng.random() < 0.2: r[rng.randrange(n)] = ord("N")
+            reads.append(bytes(r))
+        if len(reads) % 2: reads.pop()
+        longs = []
+        for i in range(20):                                     # 4 kb units (tiled kernel) and one 60 kb read (long-read kernel), beside short ones
+            n = 60000 if i == 7 else rng.choice([150, 4000])
+            r = bytearray(util.rand_seq(rng, n))
+            if rng.random() < 0.7:
+                src = refs[0]; a = rng.randrange(len(src) - 80); w = rng.choice([0, n - 80, rng.randrange(n - 80)]); r[w:w + 80] = src[a:a + 80]
+            longs.append(bytes(r))
+        if okw.get("ksplit"):
+            check_split(d, o, reads); check_split(d, o, longs); check_split(d, o, [])
+        elif okw.get("ktrimN"):
+            for rr, paired in ((reads, True), (reads[:401], False), (longs, True)):
+                check_kmask(d, o, rr, paired)
+        elif okw.get("ktrimLeft") and okw.get("ktrimRight"):
+            for rr, paired in ((reads, True), (reads[:401], False), (longs, True)):
+                check_tips(d, o, rr, paired)
+        else:
+            check_batch(d, o, reads, True); check_batch(d, o, reads[:401], False); check_batch(d, o, longs, True)
         d.close()
