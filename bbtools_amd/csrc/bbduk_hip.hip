@@ -349,14 +349,15 @@ static bool params_general(const bbduk_params& p) {               // the same pr
 // out of the exact hit plane).
 // Round 5: every operator family -- ksplit, ktrim=n, ktrim=rl, findbestmatch and kfilter with mkf / mcf read their facts out of the same exact hit plane
 // (bbduk_bigs_every_kernel, wave_body BIGS && EVERY).  Still cache-resident at any size: k > 31 (the pair scan's run state machine), query expansion
-// (qhdist: the tiled kernels), and the flags of the GENERAL family that change a window or the key (params_general_flags).
-static bool params_general_flags(const bbduk_params& p) {         // params_general without the thresholds mkf / mcf (they only read the hit plane)
-    const bool useShort = p.mink > 0 && p.mink < p.k;
-    return p.qhdist > 0 || p.qhdist2 > 0 || p.restrictLeft > 0 || p.restrictRight > 0 || p.skipR1 || p.skipR2 || !p.rcomp ||
-           (useShort && p.middleMask != -1) || p.k < 16 || p.qSkip > 1 || p.speed > 0;
-}
+// (qhdist: the tiled kernels) and k < 16 (at most 4^15 keys: the cache-resident layout indexes them all).  The other flags of the GENERAL family --
+// restrictleft / restrictright, skipr1 / skipr2, qskip, speed, rcomp=f -- only decide which positions are looked up, cut a window or gate a key: the
+// bbduk_bigs_general kernels serve them (kparams_general_flags).
 static bool big_layout_eligible(const bbduk_params& p) {
-    return p.mode >= BBDUK_MODE_KFILTER && p.mode <= BBDUK_MODE_KSPLIT && !params_general_flags(p) && !(p.kbig > p.k);
+    const bool useShort = p.mink > 0 && p.mink < p.k;
+    return p.mode >= BBDUK_MODE_KFILTER && p.mode <= BBDUK_MODE_KSPLIT && !(p.kbig > p.k) && p.qhdist == 0 && p.qhdist2 == 0 && p.k >= 16 && !(useShort && p.middleMask != -1);
+}
+static bool kparams_general_flags(const KParams& K) {            // kparams_general without the thresholds mkf / mcf (they only read the hit plane)
+    return K.restrictLeft > 0 || K.restrictRight > 0 || K.skipR1 || K.skipR2 || !K.rcomp || K.qskip > 1 || K.speed > 0;
 }
 // seed layout (bbduk_seed.inc): the two halves beside the (at most one) masked middle base, each <= 16 bases
 static bool seed_geometry(bbduk_handle* h, const double maxKeys = 0.0) {
@@ -420,7 +421,7 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
     // 2^22 keys on: a 52 kbase reference, 4.7 M keys, 115 against 87 Gbases/s; 19 M keys 159 / 75; 2.45 M keys 87 / 102 -- profiles/r04_seed_vs_plain.jsonl;
     // up to 2^25 keys build_both keeps the cache-resident twin for the units beyond a wave's planes)
     st->seed = (maxKeys > (double)SEED_JOINT_MIN_KEYS || h->hookSeedLayout) && !h->hookBigLayout && !h->hookNoBigLayout && hdist == 1 && big_layout_eligible(h->p) &&
-               h->p.mode == BBDUK_MODE_KFILTER && !h->p.findBestMatch && h->p.minKmerFraction == 0.f && !(h->p.minCoveredFraction > 0.f) && !h->sealTable && seed_geometry(h, maxKeys);      // (maxbadkmers > 0 and forbidn too, round 4: the walk counts, seed_window resets)
+               h->p.mode == BBDUK_MODE_KFILTER && !h->p.findBestMatch && !params_general(h->p) && !h->sealTable && seed_geometry(h, maxKeys);      // (its stream scan is the plain kfilter's)      // (maxbadkmers > 0 and forbidn too, round 4: the walk counts, seed_window resets)
     if (st->seed && h->seedHl != h->seedHr && !(maxKeys > (double)SEED_LAYOUT_MIN_KEYS || h->hookSeedLayout)) st->seed = false;      // (the two-gather form keeps 2^25)
     long long bigMin = hdist > 0 ? std::max<long long>(big_min_keys(h->p), BIG_PLAIN_MIN_KEYS) : big_min_keys(h->p);      // (plain lines take over later: build_both)
     // a streamed build (bbduk_build_begin / _add_device / _end) sees the reference once and cannot keep the cache-resident twin build_both gives the
@@ -903,7 +904,7 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
         K.waveFirst = 1;                                            // (main_scan_pair_kbig) per read
         const bool general = params_general(h->p);
         const bool every = red == RED_BEST && stream_every_ok(h, K);     // findbestmatch: the stream scan, ids gathered per read (wave_body: FBM)
-        const batch_kernel_t wk = bigs ? bbduk_pick_bigs_every(BBDUK_MODE_FBM, false) : every ? bbduk_pick_stream_every(BBDUK_MODE_FBM, false, K.forbidNs != 0, general)
+        const batch_kernel_t wk = bigs ? (kparams_general_flags(K) ? bbduk_pick_bigs_general(BBDUK_MODE_FBM) : bbduk_pick_bigs_every(BBDUK_MODE_FBM, false)) : every ? bbduk_pick_stream_every(BBDUK_MODE_FBM, false, K.forbidNs != 0, general)
                                         : bbduk_pick_mode_wave(red == RED_BEST ? BBDUK_MODE_FBM : BBDUK_MODE_KBIG, general, packed, K.forbidNs != 0);
         const size_t waveLds = bigs ? dynLds + WAVE_LDS_BYTES_BIGS : dynLds + ((every && (K.forbidNs || general)) ? WAVE_LDS_BYTES_KM : WAVE_LDS_BYTES);
         HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(wk), waveLds));
@@ -915,7 +916,7 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
         K.waveFirst = 1; K.outLeft = d_left; K.outRight = d_right;
         const bool general = params_general(h->p);
         const bool every = stream_every_ok(h, K);
-        const batch_kernel_t wk = bigs ? bbduk_pick_bigs_every(BBDUK_MODE_KSPLIT, true) : every ? bbduk_pick_stream_every(BBDUK_MODE_KSPLIT, true, K.forbidNs != 0, general) : bbduk_pick_mode_wave(BBDUK_MODE_KSPLIT, general, false, K.forbidNs != 0);
+        const batch_kernel_t wk = bigs ? (kparams_general_flags(K) ? bbduk_pick_bigs_general(BBDUK_MODE_KSPLIT) : bbduk_pick_bigs_every(BBDUK_MODE_KSPLIT, true)) : every ? bbduk_pick_stream_every(BBDUK_MODE_KSPLIT, true, K.forbidNs != 0, general) : bbduk_pick_mode_wave(BBDUK_MODE_KSPLIT, general, false, K.forbidNs != 0);
         const size_t waveLds = bigs ? dynLds + WAVE_LDS_BYTES_BIGS : dynLds + ((every && (K.forbidNs || general)) ? WAVE_LDS_BYTES_KM : WAVE_LDS_BYTES);
         HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(wk), waveLds));
         const int64_t nmt = (n + MT_READS - 1) / MT_READS;
@@ -984,19 +985,21 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
         if (!(K.mode == BBDUK_MODE_KFILTER && K.mkf == 0.f && K.mcf == 0.f)) return fail(h, BBDUK_ERR_STATE, "seed-layout map with a scan its kernel does not serve");
         kp.wave = bbduk_pick_stream_seed(K.forbidNs != 0, packed); waveLdsUse = dynLds + WAVE_LDS_BYTES_BIGS;      // (candidate planes + the verification's list)
     }
-    if (K.big && K.gV32 && firstHit && (!h->hookPairScan || K.mode != BBDUK_MODE_KFILTER)) {      // big layout, 32-bit line function: its own stream scan (bbduk_bigs.inc)
+    const bool genFlags = kparams_general_flags(K);
+    if (K.big && K.gV32 && firstHit && !genFlags && (!h->hookPairScan || K.mode != BBDUK_MODE_KFILTER)) {      // big layout, 32-bit line function: its own stream scan (bbduk_bigs.inc)
         kp.wave = bbduk_pick_bigs(K.mode, K.useShort != 0, packed); waveLdsUse = dynLds + WAVE_LDS_BYTES_BIGS;
         if (K.mode == BBDUK_MODE_KTRIM_R) kp.tile = bbduk_pick_ktrim_r_big_tile();
     }
-    bool bigsChosen = K.big && K.gV32 && firstHit && (!h->hookPairScan || K.mode != BBDUK_MODE_KFILTER);
-    if (K.big && K.gV32 && !firstHit && !h->hookPairScan && (K.mode == BBDUK_MODE_KTRIM_L || K.mode == BBDUK_MODE_KFILTER)) {      // ... and its every-hit form: ktrim=l, kfilter with maxbadkmers > 0, mkf, mcf
+    bool bigsChosen = K.big && K.gV32 && firstHit && !genFlags && (!h->hookPairScan || K.mode != BBDUK_MODE_KFILTER);
+    if (K.big && K.gV32 && !h->hookPairScan && (!firstHit || genFlags)) {      // ... and its every-hit form: ktrim=l, kfilter with maxbadkmers > 0, mkf, mcf; every scan of the GENERAL family
         bigsChosen = true;
-        kp.wave = bbduk_pick_bigs_every(K.mode, K.useShort != 0); waveLdsUse = dynLds + WAVE_LDS_BYTES_BIGS;
+        kp.wave = genFlags ? bbduk_pick_bigs_general(K.mode) : bbduk_pick_bigs_every(K.mode, K.useShort != 0); waveLdsUse = dynLds + WAVE_LDS_BYTES_BIGS;
         if (K.mode == BBDUK_MODE_KTRIM_L) kp.tile = bbduk_pick_ktrim_l_big_tile();
+        if (K.mode == BBDUK_MODE_KTRIM_R) kp.tile = bbduk_pick_ktrim_r_big_tile();
     }
     // (pick_kernel hands every big-layout map the kfilter pair scan -- round 2's kernel, which serves plain kfilter only: any other configuration must have
     // been given one of the stream scans above, or it would run a MODE = KFILTER kernel over a ktrim handle: ADVICE r4)
-    if (K.big && !bigsChosen && (K.mode != BBDUK_MODE_KFILTER || K.mkf != 0.f || K.mcf > 0.f))
+    if (K.big && !bigsChosen && (K.mode != BBDUK_MODE_KFILTER || K.mkf != 0.f || K.mcf > 0.f || genFlags))
         return fail(h, BBDUK_ERR_STATE, "big-layout map with a scan its kernels do not serve (BBDUK_HOOK_PAIR_SCAN serves plain kfilter only)");
     // a big-layout map with a cache-resident twin (build_both): the wave kernel scans the big layout, the fallbacks for units beyond a wave's
     // planes (tile kernel, long-read kernel) run their cache-resident instantiations over the twin
@@ -1256,7 +1259,7 @@ static int launch_tips(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d
     {   // the main kernel's shape: wave-autonomous mini-tiles, candidate scan for the right pass, one lane per read in the finish
         K.waveFirst = 1; K.outLeft = d_l;
         const bool general = params_general(h->p);
-        const batch_kernel_t wk = bigs ? bbduk_pick_bigs_every(BBDUK_MODE_KTRIM_TIPS, true) : (stream_every_ok(h, K) && !K.forbidNs && !general) ? bbduk_pick_stream_tips(packed)
+        const batch_kernel_t wk = bigs ? (kparams_general_flags(K) ? bbduk_pick_bigs_general(BBDUK_MODE_KTRIM_TIPS) : bbduk_pick_bigs_every(BBDUK_MODE_KTRIM_TIPS, true)) : (stream_every_ok(h, K) && !K.forbidNs && !general) ? bbduk_pick_stream_tips(packed)
                                                                                       : bbduk_pick_mode_wave(BBDUK_MODE_KTRIM_TIPS, general, packed, K.forbidNs != 0);
         const size_t waveLds = dynLds + (bigs ? WAVE_LDS_BYTES_BIGS : WAVE_LDS_BYTES);
         HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(wk), waveLds));
@@ -1370,7 +1373,7 @@ static int launch_kmask(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     {   // the main kernel's shape: wave-autonomous mini-tiles, a fourth plane for the hit positions, one lane per read in the finish
         K.waveFirst = 1; K.outMask = d_mask;
         const bool general = params_general(h->p);
-        const batch_kernel_t wk = bigs ? bbduk_pick_bigs_every(BBDUK_MODE_KMASK, true) : stream_every_ok(h, K) ? bbduk_pick_stream_every(BBDUK_MODE_KMASK, true, K.forbidNs != 0, general)
+        const batch_kernel_t wk = bigs ? (kparams_general_flags(K) ? bbduk_pick_bigs_general(BBDUK_MODE_KMASK) : bbduk_pick_bigs_every(BBDUK_MODE_KMASK, true)) : stream_every_ok(h, K) ? bbduk_pick_stream_every(BBDUK_MODE_KMASK, true, K.forbidNs != 0, general)
                                                         : bbduk_pick_mode_wave(BBDUK_MODE_KMASK, general, packed, K.forbidNs != 0);
         const size_t waveLds = dynLds + (bigs ? WAVE_LDS_BYTES_BIGS : WAVE_LDS_BYTES_KM);
         HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(wk), waveLds));

@@ -199,7 +199,10 @@ def _is_big(d):
     ("ksplit=t k=27 mink=12", dict(k=27, mink=12, ksplit=1), 1_150_000, True),
     ("ktrim=n k=27 mink=12", dict(k=27, mink=12, ktrimN=1), 1_150_000, True),
     ("ktrim=rl k=27 mink=12", dict(k=27, mink=12, ktrimRight=1, ktrimLeft=1), 1_150_000, True),
-    ("k=31 restrictleft=100", dict(k=31, restrictLeft=100), 1_150_000, False),   # a flag of the GENERAL family that changes the windows: cache-resident
+    ("k=31 restrictleft=100", dict(k=31, restrictLeft=100), 1_150_000, True),    # the GENERAL family's flags too (bbduk_bigs_general_kernel)
+    ("ktrim=r k=27 mink=12 restrictright=80 qskip=2", dict(k=27, mink=12, ktrimRight=1, restrictRight=80, qSkip=2), 1_150_000, True),
+    ("k=25 rcomp=f speed=3 skipr2=t", dict(k=25, rcomp=0, speed=3, skipR2=1), 1_150_000, True),
+    ("k=31 qhdist=1", dict(k=31, qhdist=1), 1_150_000, False),                # query expansion: the tiled kernels over the cache-resident map
     ("k=40", dict(k=31, kbig=40, maskMiddle=0), 1_150_000, False),            # k > 31: the pair scan's run state machine, cache-resident
     ("ktrim=r k=27", dict(k=27, ktrimRight=1), 1_150_000, True),    # ktrim=r: minimizer lines too since round 4 (bbduk_bigs_kernel<KTRIM_R>)
     ("ktrim=l k=27", dict(k=27, ktrimLeft=1), 1_150_000, True),     # ktrim=l and kfilter with maxbadkmers > 0: bbduk_bigs_every_kernel (round 4)
@@ -350,18 +353,52 @@ FAMILIES = [("ksplit=t k=23 mink=11 hdist=1", dict(k=23, mink=11, hdist=1, kspli
             ("k=31 mbk=7", dict(k=31, maxBadKmers0=7))]
 
 
+GENERALS = [("k=31 restrictright=70", dict(k=31, restrictRight=70)),
+            ("k=27 restrictleft=60 restrictright=100 forbidn=t hdist=1", dict(k=27, restrictLeft=60, restrictRight=100, forbidN=1, hdist=1)),
+            ("k=31 qskip=3 mbk=1", dict(k=31, qSkip=3, maxBadKmers0=1)),
+            ("k=25 speed=5 mkf=0.1", dict(k=25, speed=5, minKmerFraction=0.1)),
+            ("k=27 rcomp=f", dict(k=27, rcomp=0)),
+            ("k=24 mm=f rcomp=f skipr2=t mcf=0.2", dict(k=24, maskMiddle=0, rcomp=0, skipR2=1, minCoveredFraction=0.2)),
+            ("ktrim=r k=23 mink=11 hdist=1 restrictright=60", dict(k=23, mink=11, hdist=1, ktrimRight=1, restrictRight=60)),
+            ("ktrim=r k=31 restrictright=20 qskip=2", dict(k=31, ktrimRight=1, restrictRight=20, qSkip=2)),          # a span shorter than k-1 bases
+            ("ktrim=r k=25 mink=9 speed=4 rcomp=f tpe", dict(k=25, mink=9, ktrimRight=1, speed=4, rcomp=0, trimPairsEvenly=1)),
+            ("ktrim=l k=27 mink=12 restrictleft=50 skipr1=t", dict(k=27, mink=12, ktrimLeft=1, restrictLeft=50, skipR1=1)),
+            ("ktrim=l k=31 restrictright=90 qskip=2 forbidn=t", dict(k=31, ktrimLeft=1, restrictRight=90, qSkip=2, forbidN=1)),
+            ("ksplit=t k=25 mink=10 restrictright=120 speed=2", dict(k=25, mink=10, ksplit=1, restrictRight=120, speed=2)),
+            ("ksplit=t k=31 rcomp=f qskip=2", dict(k=31, ksplit=1, rcomp=0, qSkip=2)),
+            ("ktrim=n k=27 mink=11 restrictleft=100 restrictright=100", dict(k=27, mink=11, ktrimN=1, restrictLeft=100, restrictRight=100)),
+            ("ktrim=n k=31 kmaskfullycovered=t restrictright=80 qskip=2", dict(k=31, ktrimN=1, kmaskFullyCovered=1, restrictRight=80, qSkip=2)),
+            ("kmask=lc k=25 speed=6 rcomp=f skipr1=t", dict(k=25, ktrimN=1, speed=6, rcomp=0, skipR1=1)),
+            ("ktrimtips=40 k=23 mink=11 hdist=1", dict(k=23, mink=11, hdist=1, ktrimLeft=1, ktrimRight=1, restrictLeft=40, restrictRight=40)),
+            ("ktrim=rl k=27 qskip=2 forbidn=t speed=2", dict(k=27, ktrimLeft=1, ktrimRight=1, qSkip=2, forbidN=1, speed=2)),
+            ("ktrim=rl k=25 mink=12 rcomp=f skipr2=t", dict(k=25, mink=12, ktrimLeft=1, ktrimRight=1, rcomp=0, skipR2=1)),
+            ("k=25 fbm=t restrictright=90 skipr1=t", dict(k=25, findBestMatch=1, restrictRight=90, skipR1=1)),
+            ("k=27 fbm=t qskip=2 speed=3 rcomp=f", dict(k=27, findBestMatch=1, qSkip=2, speed=3, rcomp=0))]
+
+
+@pytest.mark.parametrize("ci", range(len(GENERALS)))
+def test_big_layout_general_family(ci):
+    """Round 5: the flags of the GENERAL family (restrictleft / restrictright, skipr1 / skipr2, qskip, speed, rcomp=f) in every operator over a
+    big-layout map (bbduk_bigs_general_kernel): the plane of looked-up positions follows the span and qskip's grid, the windows that reach in
+    front of a span start are looked up exactly by worker lanes, speed gates and rcomp=f picks the key in the exact lookups."""
+    _families_case(*GENERALS[ci], seed=47000 + ci, builds=(("device", BIG), ("host", BIGWIDE)))
+
+
 @pytest.mark.parametrize("ci", range(len(FAMILIES)))
 def test_big_layout_operator_families(ci):
     """Round 5: ksplit, ktrim=n, ktrim=rl, findbestmatch and kfilter with mkf / mcf against a big-layout map (bbduk_bigs_every_kernel: the exact
     hit plane behind the stream scan over the minimizer lines; the mode's facts are read out of it).  Forced onto small references, so the map has
     no cache-resident twin and the units beyond a wave's planes run the big-layout instantiations of the tiled and the long-read kernels
     (bbduk_big_tiles.hip).  Every output the operator has is compared: mask bits, both trim amounts, split spans, match lists."""
-    args, okw = FAMILIES[ci]
-    rng = random.Random(31000 + ci)
+    _families_case(*FAMILIES[ci], seed=31000 + ci, builds=(("device", BIG), ("host", BIG), ("device", BIGWIDE)))
+
+
+def _families_case(args, okw, seed, builds):
+    rng = random.Random(seed)
     refs = [util.rand_seq(rng, 6000, 0.002), util.rand_seq(rng, 900), util.rand_seq(rng, 40), util.rand_seq(rng, 2500)]
     refs.append(refs[0][100:180] + refs[1][-70:])               # a scaffold sharing k-mers with two others: first-writer-wins ids
     k = okw["k"]
-    for build, hooks in (("device", BIG), ("host", BIG), ("device", BIGWIDE)):
+    for build, hooks in builds:
         d, o = big_pair(args, okw, refs=refs, build=build, hooks=hooks)
         assert _is_big(d)
         ks, vs = o.dump_pairs()
