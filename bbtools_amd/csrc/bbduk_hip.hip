@@ -267,6 +267,7 @@ extern "C" int bbduk_upload_table_way(bbduk_handle* h, int32_t way, int32_t prim
 // the distinct count, LDS filter) and the big one (in place).  BuildState lives from begin to end.
 struct BuildState {
     bool seed = false;                   // the seed layout (bbduk_seed.inc): parents under their halves, inserted in place
+    bool twin = false;                   // a streamed build of a big / seed map of up to 2^25 keys: every piece also goes into the scratch set, which becomes the cache-resident twin (round 5)
     bool big = false; int hdist = 0, hdist2 = 0, edist = 0, edist2 = 0;      // edist / edist2 (<= 1): bbduk_build_table_device_edits
     uint64_t* d_sk = nullptr; int32_t* d_si = nullptr; uint64_t cslots = 0;     // scratch set of the two-pass build
     unsigned long long* d_cnt = nullptr;                                        // [0] distinct, [1] overflow flag
@@ -282,7 +283,7 @@ static void build_release(bbduk_handle* h) {
 static void table_release(bbduk_handle* h) {       // a failed build leaves no half-made map behind
     hipFree(h->d_tags); hipFree(h->d_bkv); hipFree(h->d_ldsImage); hipFree(h->d_bigTags); hipFree(h->d_bigKeys); hipFree(h->d_bigIds);
     h->d_tags = nullptr; h->d_bkv = nullptr; h->d_ldsImage = nullptr; h->d_bigTags = nullptr; h->d_bigKeys = nullptr; h->d_bigIds = nullptr;
-    h->big = false; h->nbuckets = 0; h->bigLines = 0; h->ldsBits = 0; h->nkeys = 0;
+    h->big = false; h->seed = false; h->nbuckets = 0; h->bigLines = 0; h->ldsBits = 0; h->nkeys = 0; h->nkeysRef = 0;
     hipFree(h->d_tagsAlt); hipFree(h->d_bkvAlt); hipFree(h->d_ldsAlt);
     h->d_tagsAlt = nullptr; h->d_bkvAlt = nullptr; h->d_ldsAlt = nullptr; h->hasAlt = false; h->nbucketsAlt = 0;
 }
@@ -424,16 +425,24 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
                h->p.mode == BBDUK_MODE_KFILTER && !h->p.findBestMatch && !params_general(h->p) && !h->sealTable && seed_geometry(h, maxKeys);      // (its stream scan is the plain kfilter's)      // (maxbadkmers > 0 and forbidn too, round 4: the walk counts, seed_window resets)
     if (st->seed && h->seedHl != h->seedHr && !(maxKeys > (double)SEED_LAYOUT_MIN_KEYS || h->hookSeedLayout)) st->seed = false;      // (the two-gather form keeps 2^25)
     long long bigMin = hdist > 0 ? std::max<long long>(big_min_keys(h->p), BIG_PLAIN_MIN_KEYS) : big_min_keys(h->p);      // (plain lines take over later: build_both)
-    // a streamed build (bbduk_build_begin / _add_device / _end) sees the reference once and cannot keep the cache-resident twin build_both gives the
-    // other builders for units beyond a wave's planes (2x3000: 33 against 70 Gbases/s on the big layout alone): it keeps the old threshold
-    if (streamed) bigMin = std::max<long long>(bigMin, SEED_LAYOUT_MIN_KEYS);
+    // (a streamed build -- bbduk_build_begin / _add_device / _end -- sees the reference once: it builds the cache-resident twin build_both gives the other
+    // builders ALONGSIDE, every piece into both sinks while it is in HBM: st->twin below.  Until round 5 it kept the 2^25-key threshold instead.)
     // (a Seal map -- seal_gpu.h: its own kernel looks the map up, bbduk_seal.inc -- takes the big layout by its size alone, round 4)
     st->big = !st->seed && !h->hookNoBigLayout && (maxKeys > (double)bigMin || h->hookBigLayout) && (big_layout_eligible(h->p) || (h->sealTable && h->p.k >= 16)) && big_geometry(h, maxKeys);
     // ktrim=r has the stream scan of the 32-bit line function only (no pair-scan form): beyond 2^31 keys, or behind the 52-bit hook, it keeps the
     // cache-resident layout (which refuses what it cannot index)
     if (st->big && h->p.mode != BBDUK_MODE_KFILTER && !h->gV32) st->big = false;
     auto bail = [&](int code, const char* msg) { build_release(h); table_release(h); return fail(h, code, msg); };
-    if (hipMalloc(&st->d_cnt, 32) != hipSuccess || hipMemsetAsync(st->d_cnt, 0, 32, h->stream) != hipSuccess) return bail(BBDUK_ERR_NOMEM, "hipMalloc");
+    if (hipMalloc(&st->d_cnt, 64) != hipSuccess || hipMemsetAsync(st->d_cnt, 0, 64, h->stream) != hipSuccess) return bail(BBDUK_ERR_NOMEM, "hipMalloc");      // [0..3]: Sink::distinct, [4]: the twin's distinct keys
+    // the twin of a streamed build: the same sizes build_both keeps one for (wants_twin), never beside a forced layout
+    st->twin = streamed && (st->big || st->seed) && maxKeys <= (double)SEED_LAYOUT_MIN_KEYS && !h->hookBigLayout && !h->hookSeedLayout && !h->sealTable;
+    if (st->twin) {
+        uint64_t cslots = 1024; while ((double)cslots < 2.0 * maxKeys + 16.0) cslots <<= 1;
+        if (hipMalloc(&st->d_sk, cslots * 8) != hipSuccess || hipMalloc(&st->d_si, cslots * 4) != hipSuccess) return bail(BBDUK_ERR_NOMEM, "hipMalloc (scratch set of the twin)");
+        st->cslots = cslots;
+        hipMemsetAsync(st->d_sk, 0xFF, cslots * 8, h->stream);
+        hipMemsetAsync(st->d_si, 0x7F, cslots * 4, h->stream);
+    }
     if (st->seed) {
         // four records per reference window (two orientations x two halves); maxKeys counted 1 + 3k keys per window
         const double records = 4.0 * maxKeys / (1.0 + 3.0 * h->p.k) + 64.0;
@@ -514,14 +523,17 @@ static int build_add_pieces(bbduk_handle* h, const uint8_t* d_refs, const int64_
         const int grid = (int)std::min<int64_t>((total + 255) / 256, (int64_t)h->numCU * 32);
         bbduk_build_seed_kernel<<<dim3(std::max(grid, 1)), dim3(256), 0, h->stream>>>(B, d_refs, st->d_roff, st->d_rid, h->seedHl, h->seedHr, h->seedM, make_sink(h, st));
         HIP_TRY(h, hipGetLastError());
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        return BBDUK_OK;
+        if (!st->twin) { HIP_TRY(h, hipStreamSynchronize(h->stream)); return BBDUK_OK; }
     }
     const bool edits = (st->hdist > 0 && st->edist > 0) || (B.useShort && st->hdist2 > 0 && st->edist2 > 0);
     const int V1 = edits ? 8 * B.k - 4 : ((st->hdist > 0 || (B.useShort && st->hdist2 > 0)) ? 1 + 3 * B.k : 1);      // first-level choices per position (emit_variants / emit_edits1)
     const int64_t work = total * (int64_t)V1;
     const int grid = (int)std::min<int64_t>((work + 255) / 256, (int64_t)h->numCU * 32);
-    bbduk_build_enum_kernel<<<dim3(std::max(grid, 1)), dim3(256), 0, h->stream>>>(B, d_refs, st->d_roff, st->d_rid, st->d_rfl, V1, make_sink(h, st));
+    if (!st->seed) bbduk_build_enum_kernel<<<dim3(std::max(grid, 1)), dim3(256), 0, h->stream>>>(B, d_refs, st->d_roff, st->d_rid, st->d_rfl, V1, make_sink(h, st));
+    if (st->twin) {                                              // the same pieces into the scratch set of the cache-resident twin
+        Sink T = make_sink(h, st); T.big = 0; T.distinct = st->d_cnt + 4;
+        bbduk_build_enum_kernel<<<dim3(std::max(grid, 1)), dim3(256), 0, h->stream>>>(B, d_refs, st->d_roff, st->d_rid, st->d_rfl, V1, T);
+    }
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(h->stream));                 // the caller may reuse d_refs and the host arrays
     return BBDUK_OK;
@@ -530,10 +542,41 @@ static int build_add_pieces(bbduk_handle* h, const uint8_t* d_refs, const int64_
 static int build_end_impl(bbduk_handle* h, const bool canStartOver = false) {      // canStartOver: the caller still holds the keys and repeats the build with plain lines on BBDUK_ERR_NOMEM
     BuildState* st = h->build;
     auto bail = [&](int code, const char* msg) { build_release(h); table_release(h); return fail(h, code, msg); };
-    unsigned long long cnt[3] = {0, 0, 0};
-    if (hipMemcpyAsync(cnt, st->d_cnt, 24, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
+    unsigned long long cnt[5] = {0, 0, 0, 0, 0};
+    if (hipMemcpyAsync(cnt, st->d_cnt, 40, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
         return bail(BBDUK_ERR_DEVICE, "table build failed on the device");
     const unsigned long long distinct = cnt[0];
+    // the scratch set -> a cache-resident map: buckets sized for the distinct count, LDS filter
+    auto place_scratch = [&](const unsigned long long nkeysD, const bool hooks, uint64_t*& tags, uint4*& bkv, uint32_t*& lds, uint64_t& nbOut, int& bbitsOut, int& lbOut) -> int {
+        // 4-way buckets of 15-bit fingerprints, >= 1 bucket per key (load 0.5-1 keys/bucket: ~0.1-0.4 % of buckets
+        // overflow and carry the continuation flag, so almost every lookup ends in its home bucket).
+        int bbits = 10;
+        while (bbits < 32 && (1ULL << bbits) < nkeysD) bbits++;
+        // From 2^20 buckets on the fingerprint array would leave the L2 (8 MB and more): half as many buckets -- 1-2 keys per bucket, ~5 % of
+        // them overflowing at 2 -- is faster at every size measured (5.6e5 keys: 451 against 309 Gbases/s, 1.04e6: 233 / 203, 1.27e6: 180 / 129,
+        // 2.5e6: 97 / 82, 1e7: 65 / 63; profiles/r03_l2_boundary*.jsonl).  Up to 2^19 buckets the array fits and the sparser map wins
+        // (5.2e5 keys at 0.98 / 1.97 keys per bucket: 478 / 331).  (This also keeps the slot index within 31 bits for up to 2^30 keys.)
+        if (bbits >= 20) bbits--;
+        if (hooks && h->hookBucketBits >= 4 && h->hookBucketBits <= 32) bbits = h->hookBucketBits;      // bbduk_test_hook
+        const uint64_t nb = 1ULL << bbits;
+        if (4 * nb < nkeysD + nb / 8 || 4 * nb > (1ULL << 31)) return bail(BBDUK_ERR_ARG, "too many keys for the bucket index");
+        // Presence filter in front of the map.  Most query k-mers are absent, so one bit per hash slot held in LDS
+        // (<=128 KiB per workgroup) answers most of them without leaving the CU.  Size follows the key count.
+        auto ceil_log2 = [](uint64_t x) { int b = 0; while ((1ULL << b) < x) b++; return b; };
+        int lb = 0;
+        if (nkeysD > 0 && nkeysD <= (1ULL << 22)) lb = std::min(MAX_LDS_BITS, std::max(10, ceil_log2(32ULL * nkeysD)));
+        if (hooks && h->hookLdsBits >= 0) lb = h->hookLdsBits == 0 ? 0 : std::min(MAX_LDS_BITS, std::max(10, h->hookLdsBits));   // bbduk_test_hook
+        if (hipMalloc(&tags, (nb + 1) * sizeof(uint64_t)) != hipSuccess || hipMalloc(&bkv, 4 * nb * sizeof(uint4)) != hipSuccess ||
+            (lb && hipMalloc(&lds, ((size_t)1 << (lb - 5)) * 4) != hipSuccess)) return bail(BBDUK_ERR_NOMEM, "hipMalloc (map)");
+        hipMemsetAsync(tags, 0, (nb + 1) * sizeof(uint64_t), h->stream);      // (+ the dummy word behind the last bucket: always zero, see StreamProbe)
+        hipMemsetAsync(bkv, 0xFF, 4 * nb * sizeof(uint4), h->stream);
+        if (lb) hipMemsetAsync(lds, 0, ((size_t)1 << (lb - 5)) * 4, h->stream);
+        const int grid = (int)std::min<uint64_t>((st->cslots + 255) / 256, (uint64_t)h->numCU * 32);
+        bbduk_build_place_kernel<<<dim3(grid), dim3(256), 0, h->stream>>>(st->d_sk, st->d_si, st->cslots, tags, bkv, bbits, (uint32_t)(nb - 1), lds, lb);
+        if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(BBDUK_ERR_DEVICE, "device build (placement) failed");
+        nbOut = nb; bbitsOut = bbits; lbOut = lb;
+        return BBDUK_OK;
+    };
     if (st->seed) {                                               // nkeys = RECORDS (four per distinct reference window), not the reference's key count
         if (cnt[1]) return bail(BBDUK_ERR_NOMEM, "the map overflowed: more reference windows than announced to bbduk_build_begin");
         h->nkeys = (int64_t)distinct; h->ldsBits = 0;
@@ -545,33 +588,16 @@ static int build_end_impl(bbduk_handle* h, const bool canStartOver = false) {   
         if (canStartOver && !h->bigPlain && cnt[2] > distinct / 8) return bail(BBDUK_ERR_NOMEM, "the minimizer lines are overloaded");
         h->nkeys = (int64_t)distinct; h->ldsBits = 0; h->nspilled = (int64_t)cnt[2];
     } else {
-        // 4-way buckets of 15-bit fingerprints, >= 1 bucket per key (load 0.5-1 keys/bucket: ~0.1-0.4 % of buckets
-        // overflow and carry the continuation flag, so almost every lookup ends in its home bucket).
-        int bbits = 10;
-        while (bbits < 32 && (1ULL << bbits) < distinct) bbits++;
-        // From 2^20 buckets on the fingerprint array would leave the L2 (8 MB and more): half as many buckets -- 1-2 keys per bucket, ~5 % of
-        // them overflowing at 2 -- is faster at every size measured (5.6e5 keys: 451 against 309 Gbases/s, 1.04e6: 233 / 203, 1.27e6: 180 / 129,
-        // 2.5e6: 97 / 82, 1e7: 65 / 63; profiles/r03_l2_boundary*.jsonl).  Up to 2^19 buckets the array fits and the sparser map wins
-        // (5.2e5 keys at 0.98 / 1.97 keys per bucket: 478 / 331).  (This also keeps the slot index within 31 bits for up to 2^30 keys.)
-        if (bbits >= 20) bbits--;
-        if (h->hookBucketBits >= 4 && h->hookBucketBits <= 32) bbits = h->hookBucketBits;      // bbduk_test_hook
-        const uint64_t nb = 1ULL << bbits;
-        if (4 * nb < distinct + nb / 8 || 4 * nb > (1ULL << 31)) return bail(BBDUK_ERR_ARG, "too many keys for the bucket index");
-        // Presence filter in front of the map.  Most query k-mers are absent, so one bit per hash slot held in LDS
-        // (<=128 KiB per workgroup) answers most of them without leaving the CU.  Size follows the key count.
-        auto ceil_log2 = [](uint64_t x) { int b = 0; while ((1ULL << b) < x) b++; return b; };
-        int lb = 0;
-        if (distinct > 0 && distinct <= (1ULL << 22)) lb = std::min(MAX_LDS_BITS, std::max(10, ceil_log2(32ULL * distinct)));
-        if (h->hookLdsBits >= 0) lb = h->hookLdsBits == 0 ? 0 : std::min(MAX_LDS_BITS, std::max(10, h->hookLdsBits));   // bbduk_test_hook
-        if (hipMalloc(&h->d_tags, (nb + 1) * sizeof(uint64_t)) != hipSuccess || hipMalloc(&h->d_bkv, 4 * nb * sizeof(uint4)) != hipSuccess ||
-            (lb && hipMalloc(&h->d_ldsImage, ((size_t)1 << (lb - 5)) * 4) != hipSuccess)) return bail(BBDUK_ERR_NOMEM, "hipMalloc (map)");
-        hipMemsetAsync(h->d_tags, 0, (nb + 1) * sizeof(uint64_t), h->stream);      // (+ the dummy word behind the last bucket: always zero, see StreamProbe)
-        hipMemsetAsync(h->d_bkv, 0xFF, 4 * nb * sizeof(uint4), h->stream);
-        if (lb) hipMemsetAsync(h->d_ldsImage, 0, ((size_t)1 << (lb - 5)) * 4, h->stream);
-        const int grid = (int)std::min<uint64_t>((st->cslots + 255) / 256, (uint64_t)h->numCU * 32);
-        bbduk_build_place_kernel<<<dim3(grid), dim3(256), 0, h->stream>>>(st->d_sk, st->d_si, st->cslots, h->d_tags, h->d_bkv, bbits, (uint32_t)(nb - 1), h->d_ldsImage, lb);
-        if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(BBDUK_ERR_DEVICE, "device build (placement) failed");
+        uint64_t nb = 0; int bbits = 0, lb = 0;
+        const int rc = place_scratch(distinct, true, h->d_tags, h->d_bkv, h->d_ldsImage, nb, bbits, lb);
+        if (rc != BBDUK_OK) return rc;
         h->nbuckets = nb; h->bucketBits = bbits; h->nkeys = (int64_t)distinct; h->ldsBits = lb;
+    }
+    if (st->twin) {                                               // the scratch set of a streamed big / seed build -> the cache-resident twin (build_both's, for the other builders)
+        const int rc = place_scratch(cnt[4], false, h->d_tagsAlt, h->d_bkvAlt, h->d_ldsAlt, h->nbucketsAlt, h->bucketBitsAlt, h->ldsBitsAlt);
+        if (rc != BBDUK_OK) return rc;
+        h->hasAlt = true;
+        if (h->seed) h->nkeysRef = (int64_t)cnt[4];               // (bbduk_table_size answers in the reference's key count)
     }
     build_release(h);
     h->finalized = true;
@@ -583,6 +609,14 @@ extern "C" int bbduk_build_begin(bbduk_handle* h, int64_t max_keys, int32_t hdis
     if (max_keys < 0 || hdist < 0 || hdist > 3 || hdist2 < 0 || hdist2 > 3) return fail(h, BBDUK_ERR_ARG, "build_begin: bad argument (the device build serves hdist <= 3)");
     std::lock_guard<std::mutex> g(h->mu);
     if (!h->hkeys.empty()) return fail(h, BBDUK_ERR_STATE, "pairs were uploaded already: finalize them instead");
+    // the short k-mers of mink live in the secondary map of a big-layout map alone (big_insert), which is sized from this estimate: a streamed build
+    // does not say how many scaffolds will come, so it is the bound numScaffolds gives -- two ends per scaffold, every length, every variant
+    h->expectShort = 0.0;
+    if (h->p.mink > 0 && h->p.mink < h->p.k) {
+        auto variants = [](int len, int d) { const double t = 3.0 * len; double v = 1.0; if (d >= 1) v += t; if (d >= 2) v += t * (t - 3.0) / 2.0; if (d >= 3) v += t * (t - 3.0) * (t - 6.0) / 6.0; return v; };
+        for (int L = h->p.mink; L < h->p.k; L++) h->expectShort += 2.0 * (double)(h->p.numScaffolds - 1) * variants(L, hdist2);
+        h->expectShort = std::min(h->expectShort, 4.0 * (double)max_keys + 1e6);      // (never more than the announcement could hold)
+    }
     return build_begin_impl(h, (double)max_keys, hdist, hdist2, true);
 }
 extern "C" int bbduk_build_add_device(bbduk_handle* h, const uint8_t* d_refs, const int64_t* ref_offsets, int32_t n_refs, int32_t first_id) {
@@ -664,6 +698,12 @@ static int build_both(bbduk_handle* h, const double maxKeys, const int hdist, On
     const uint64_t nb = h->nbuckets; const int bbits = h->bucketBits, lbits = h->ldsBits;
     h->d_tags = nullptr; h->d_bkv = nullptr; h->d_ldsImage = nullptr; h->nbuckets = 0; h->bucketBits = 0; h->ldsBits = 0; h->nkeys = 0; h->finalized = false;
     rc = once();
+    if (rc == BBDUK_ERR_NOMEM && !h->finalized) {                    // the second layout found no room (HBM is short): the map already built serves the handle
+        table_release(h);
+        h->d_tags = tags; h->d_bkv = bkv; h->d_ldsImage = lds; h->nbuckets = nb; h->bucketBits = bbits; h->ldsBits = lbits; h->nkeys = nkeys1; h->finalized = true;
+        h->bigPlain = false;
+        return BBDUK_OK;
+    }
     if (rc != BBDUK_OK || !(h->big || h->seed)) {                    // failed, or not big after all: one cache-resident map is enough
         hipFree(tags); hipFree(bkv); hipFree(lds);
         return rc;
@@ -795,7 +835,8 @@ extern "C" int64_t bbduk_table_bytes(const bbduk_handle* h) {
     if (!h || !h->finalized) return -1;
     if (h->big) return (int64_t)h->bigLines * (64 + 256 + 32 * h->bigIdBytes) + (int64_t)(h->nbuckets * (8 + 4 * 16)) +
                        (h->hasAlt ? (int64_t)(h->nbucketsAlt * (8 + 4 * 16)) + (h->ldsBitsAlt ? (1LL << (h->ldsBitsAlt - 3)) : 0) : 0);
-    return (int64_t)(h->nbuckets * (8 + 4 * 16)) + (h->ldsBits ? (1LL << (h->ldsBits - 3)) : 0);
+    return (int64_t)(h->nbuckets * (8 + 4 * 16)) + (h->ldsBits ? (1LL << (h->ldsBits - 3)) : 0) +
+           (h->hasAlt ? (int64_t)(h->nbucketsAlt * (8 + 4 * 16)) + (h->ldsBitsAlt ? (1LL << (h->ldsBitsAlt - 3)) : 0) : 0);      // (a seed-layout map's twin)
 }
 
 static KParams make_kparams(const bbduk_handle* h) {

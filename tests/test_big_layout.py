@@ -436,3 +436,46 @@ def _families_case(args, okw, seed, builds):
         else:
             check_batch(d, o, reads, True); check_batch(d, o, reads[:401], False); check_batch(d, o, longs, True)
         d.close()
+
+
+@pytest.mark.parametrize("args,okw,hdist", [("k=31", dict(k=31), 0), ("ktrim=r k=27 mink=12", dict(k=27, mink=12, ktrimRight=1), 0),
+                                            ("ksplit=t k=25 mink=11", dict(k=25, mink=11, ksplit=1), 0), ("k=31 hdist=1", dict(k=31, hdist=1), 1)])
+def test_streamed_build_keeps_a_twin(args, okw, hdist):
+    """Round 5: a streamed device build (bbduk_build_begin / _add_device / _end) of a map between 2^20 and 2^25 keys takes the big
+    (or the seed) layout like the other builders and builds the cache-resident twin alongside -- every piece goes into both sinks while it is in HBM --
+    so that units beyond a wave's planes run the faster fallbacks.  Table, short reads and 3 kb - 64 kb units against the oracle."""
+    import torch
+    G = 1_150_000 if hdist == 0 else 60_000
+    rng0 = np.random.default_rng(G + hdist)
+    refs = [np.frombuffer(b"ACGT", np.uint8)[rng0.integers(0, 4, n)].tobytes() for n in (G // 2, 40, G // 2)]
+    o = Oracle(**okw)
+    for r in refs: o.add_ref(r)
+    d = B.BBDuk.__new__(B.BBDuk)
+    d.host = B.HostIndex(args)
+    for r in refs: d.host.add_ref(r)
+    d.gpu = B.BBDukGpu(d.host.params(0))
+    d.gpu.build_begin(sum(len(r) for r in refs) * (1 + 3 * okw["k"] * hdist) + 100000, hdist, hdist)
+    for first, group in ((1, refs[:2]), (3, refs[2:])):
+        cat = np.frombuffer(b"".join(group), np.uint8)
+        offs = np.concatenate([[0], np.cumsum([len(r) for r in group])]).astype(np.int64)
+        d.gpu.build_add_device(torch.from_numpy(cat.copy()).cuda(), offs, first)
+    d.gpu.build_end()
+    d.stored_kmers = d.gpu.table_size
+    assert d.gpu.table_size == o.stored_kmers
+    if hdist == 0: assert _is_big(d)
+    big_alone = (64 + 256 + 64) * (d.gpu.table_size / (32 * 0.30))
+    assert d.gpu.table_bytes > 8 * d.gpu.table_size                  # (more than one layout's worth: the twin is there)
+    ks, vs = o.dump_pairs()
+    sel = np.random.default_rng(1).integers(0, len(ks), 100_000)
+    assert np.array_equal(d.gpu.table_lookup(ks[sel]), vs[sel])
+    g = refs[0]
+    rng = random.Random(G)
+    cut = lambda n: g[(p0 := rng.randrange(0, len(g) - n)):p0 + n]
+    reads = [util.rand_seq(rng, 150, 0.002) if i % 3 else cut(150) for i in range(4000)]
+    longs = [util.rand_seq(rng, 3000), util.rand_seq(rng, 1400) + cut(200) + util.rand_seq(rng, 1400), util.rand_seq(rng, 30000) + cut(64), util.rand_seq(rng, 150),
+             cut(5000), util.rand_seq(rng, 2600), util.rand_seq(rng, 64000), cut(40) + util.rand_seq(rng, 45000)]
+    paired = not okw.get("ksplit")
+    check_batch(d, o, reads, paired, nthreads=8)
+    check_batch(d, o, longs[:2] + reads[:600], paired, nthreads=8)
+    check_batch(d, o, longs, paired, nthreads=8)
+    d.close()

@@ -124,7 +124,7 @@ def test_seed_layout_chosen_from_2e22_keys_with_its_twin():
     o = Oracle(k=31, hdist=1); o.add_ref(g)
     d = B.BBDuk("k=31 hdist=1", refs=[g], build="device")
     assert d.gpu.table_size == o.stored_kmers
-    assert d.gpu.table_bytes < 40 * o.stored_kmers                 # parents + twin, not 94 keys per window in a big-layout map (~100 bytes per key)
+    assert d.gpu.table_bytes < 80 * o.stored_kmers                 # parents + the twin (counted since round 5: ~65 bytes per key), not 94 keys per window in a big-layout map BESIDE a twin (~105)
     ks, vs = o.dump_pairs()
     sel = np.random.default_rng(1).integers(0, len(ks), 100_000)
     probe = np.concatenate([ks[sel], np.random.default_rng(2).integers(0, 1 << 62, 20_000, dtype=np.int64) | (np.int64(1) << 62)])
