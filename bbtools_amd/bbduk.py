@@ -58,7 +58,7 @@ GPU_SYMBOLS = ["bbduk_abi_version", "bbduk_create", "bbduk_destroy", "bbduk_last
                "bbduk_synth_generate_device", "bbduk_synth_generate_host", "bbduk_synth_pair_inserts",
                "bbduk_comm_unique_id", "bbduk_comm_create", "bbduk_comm_create_local", "bbduk_comm_destroy", "bbduk_comm_size",
                "bbduk_allreduce_counters", "bbduk_allreduce_counters_device", "bbduk_allreduce_counters_local",
-               "bbduk_test_hook", "bbduk_table_spilled", "bbduk_table_line_histogram", "bbduk_build_begin", "bbduk_build_add_device", "bbduk_build_end"]
+               "bbduk_test_hook", "bbduk_table_spilled", "bbduk_table_line_histogram", "bbduk_table_layout", "bbduk_build_begin", "bbduk_build_add_device", "bbduk_build_end"]
 HOST_SYMBOLS = ["bbduk_host_parse", "bbduk_host_destroy", "bbduk_host_add_ref", "bbduk_host_load_fasta",
                 "bbduk_host_load_refs", "bbduk_host_build_index", "bbduk_host_index_pairs",
                 "bbduk_host_num_scaffolds", "bbduk_host_scaffold_info", "bbduk_host_num_refs", "bbduk_host_ref_info", "bbduk_host_params", "bbduk_host_upload_index", "bbduk_host_build_on_device"]
@@ -217,6 +217,7 @@ def lib():
     L.bbduk_build_table_device_edits.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32]
     L.bbduk_test_hook.argtypes = [vp, i32, i64]
     L.bbduk_table_line_histogram.argtypes = [vp, vp]
+    L.bbduk_table_layout.argtypes = [vp]
     L.bbduk_table_spilled.restype = i64
     L.bbduk_table_spilled.argtypes = [vp]
     L.bbduk_build_begin.argtypes = [vp, i64, i32, i32]
@@ -384,6 +385,11 @@ class BBDukGpu:
     @property
     def table_spilled(self) -> int:
         return lib().bbduk_table_spilled(self.h)
+
+    @property
+    def table_layout(self) -> int:
+        """0 cache-resident, 1 big, 2 seed; + 4 with a cache-resident twin (include/bbduk_test_hooks.h)"""
+        return lib().bbduk_table_layout(self.h)
 
     def line_histogram(self) -> np.ndarray:
         out = np.zeros(33, np.int64)

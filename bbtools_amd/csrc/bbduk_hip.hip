@@ -717,6 +717,85 @@ static int build_both(bbduk_handle* h, const double maxKeys, const int hdist, On
     h->d_tagsAlt = tags; h->d_bkvAlt = bkv; h->d_ldsAlt = lds; h->nbucketsAlt = nb; h->bucketBitsAlt = bbits; h->ldsBitsAlt = lbits; h->hasAlt = true;
     return BBDUK_OK;
 }
+// An uploaded map of reference-side Hamming-1 neighbourhoods (a JVM-built hdist=1 table) -> the seed layout: see bbduk_collapse_parents_kernel.  Called with
+// the plain map of the pairs built and the pairs still on the host.  Returns BBDUK_OK whether or not the map was collapsed (a map that is no union of
+// full 1-neighbourhoods, or too small to gain, keeps the layout it has); an error only for device failures.
+static KParams make_kparams(const bbduk_handle* h);
+static int try_collapse_to_seed(bbduk_handle* h) {
+    const int64_t n = (int64_t)h->hkeys.size();
+    if (h->seed || h->sealTable || h->hookBigLayout || h->hookNoBigLayout) return BBDUK_OK;
+    if (!(h->p.mode == BBDUK_MODE_KFILTER && !h->p.findBestMatch && !params_general(h->p) && big_layout_eligible(h->p))) return BBDUK_OK;      // (the seed layout's scan is the plain kfilter's)
+    if (!(n > SEED_JOINT_MIN_KEYS || h->hookSeedLayout) || h->expectShort > 0.0) return BBDUK_OK;
+    if (!seed_geometry(h, (double)n)) return BBDUK_OK;
+    if (h->seedHl != h->seedHr && !(n > SEED_LAYOUT_MIN_KEYS || h->hookSeedLayout)) return BBDUK_OK;
+    if (h->nkeys != n) return BBDUK_OK;                              // (duplicates among the pairs: leave it)
+    HIP_TRY(h, hipSetDevice(h->p.device));
+    const int64_t CH = 32LL << 20;
+    const uint64_t cap = (uint64_t)n / 16 + 4096;                    // a Hamming-1 map has n / (1 + 3k) parents; more than n / 16: it is something else
+    uint8_t* d_stage = nullptr; uint64_t* d_W = nullptr; int32_t* d_pid = nullptr; unsigned long long* d_cnt = nullptr;
+    uint64_t* sTags = nullptr; uint4* sBkv = nullptr;
+    auto release = [&]() { hipFree(d_stage); hipFree(d_W); hipFree(d_pid); hipFree(d_cnt); hipFree(sTags); hipFree(sBkv); };
+    const int64_t chunk = std::min<int64_t>(n, CH);
+    if (hipMalloc(&d_stage, (size_t)chunk * 12) != hipSuccess || hipMalloc(&d_W, cap * 8) != hipSuccess || hipMalloc(&d_pid, cap * 4) != hipSuccess ||
+        hipMalloc(&d_cnt, 64) != hipSuccess) { release(); return BBDUK_OK; }      // (no room for the attempt: the plain map stands)
+    int64_t* dk = reinterpret_cast<int64_t*>(d_stage); int32_t* dv = reinterpret_cast<int32_t*>(d_stage + (size_t)chunk * 8);
+    const KParams Kold = make_kparams(h);
+    auto for_chunks = [&](auto launch) -> bool {
+        for (int64_t q = 0; q < n; q += CH) {
+            const int64_t m = std::min<int64_t>(CH, n - q);
+            if (hipMemcpyAsync(dk, h->hkeys.data() + q, (size_t)m * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+                hipMemcpyAsync(dv, h->hvals.data() + q, (size_t)m * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess) return false;
+            launch(m, (int)std::min<int64_t>((m + 255) / 256, (int64_t)h->numCU * 32));
+            if (hipStreamSynchronize(h->stream) != hipSuccess) return false;
+        }
+        return true;
+    };
+    unsigned long long cnt[4] = {0, 0, 0, 0};
+    for (int allMiddles = 0; allMiddles < 2; allMiddles++) {         // second attempt: every middle base whose neighbourhood is complete (a strand that turns with it)
+        hipMemsetAsync(d_cnt, 0, 64, h->stream);
+        if (!for_chunks([&](int64_t m, int grid) { bbduk_collapse_parents_kernel<<<dim3(std::max(grid, 1)), dim3(256), 0, h->stream>>>(Kold, dk, dv, m, allMiddles, d_W, d_pid, d_cnt, cap); })) { release(); return fail(h, BBDUK_ERR_DEVICE, "collapsing the uploaded map (parents)"); }
+        if (hipMemcpy(cnt, d_cnt, 32, hipMemcpyDeviceToHost) != hipSuccess) { release(); return fail(h, BBDUK_ERR_DEVICE, "collapsing the uploaded map"); }
+        const unsigned long long np = cnt[0];
+        if (cnt[2] != 0 || np == 0 || np > cap) { release(); return BBDUK_OK; }
+        // the seed map: four records per parent, <= 0.6 records per 4-way bucket (build_begin_impl's sizing)
+        const double records = 4.0 * (double)np + 64.0;
+        int sbits = 10;
+        while (sbits < 28 && (double)(1ULL << sbits) < records / 0.6) sbits++;
+        if (h->hookBucketBits >= 4 && h->hookBucketBits <= 28) sbits = h->hookBucketBits;
+        const uint64_t snb = 1ULL << sbits;
+        if ((double)(4 * snb) < records * 1.05) { release(); return BBDUK_OK; }
+        hipFree(sTags); hipFree(sBkv); sTags = nullptr; sBkv = nullptr;
+        if (hipMalloc(&sTags, (snb + 1) * 8) != hipSuccess || hipMalloc(&sBkv, 4 * snb * sizeof(uint4)) != hipSuccess) { release(); return BBDUK_OK; }
+        hipMemsetAsync(sTags, 0, (snb + 1) * 8, h->stream);
+        hipMemsetAsync(sBkv, 0xFF, 4 * snb * sizeof(uint4), h->stream);
+        Sink S; memset(&S, 0, sizeof S);
+        S.tags2 = sTags; S.bkv2 = sBkv; S.bucketBits2 = sbits; S.bucketMask2 = (uint32_t)(snb - 1); S.distinct = d_cnt + 4;      // [4] records, [5] overflow
+        bbduk_collapse_insert_kernel<<<dim3((unsigned)std::min<uint64_t>((np + 255) / 256, (uint64_t)h->numCU * 32)), dim3(256), 0, h->stream>>>(h->p.k, d_W, d_pid, (int64_t)np, h->seedHl, h->seedHr, h->seedM, S);
+        unsigned long long rec[2] = {0, 0};
+        if (hipMemcpyAsync(rec, d_cnt + 4, 16, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) { release(); return fail(h, BBDUK_ERR_DEVICE, "collapsing the uploaded map (insert)"); }
+        if (rec[1]) { release(); return BBDUK_OK; }
+        KParams Kseed = Kold;
+        Kseed.big = 0; Kseed.bigTags = nullptr; Kseed.bigKeys = nullptr; Kseed.bigIds = nullptr; Kseed.bigLines = 0;
+        Kseed.seed = 1; Kseed.seedHl = h->seedHl; Kseed.seedHr = h->seedHr; Kseed.seedM = h->seedM;
+        Kseed.tags = sTags; Kseed.bkv = sBkv; Kseed.bucketMask = (uint32_t)(snb - 1); Kseed.bucketBits = sbits; Kseed.ldsImage = nullptr; Kseed.ldsBits = 0;
+        if (!for_chunks([&](int64_t m, int grid) { bbduk_collapse_check_kernel<<<dim3(std::max(grid, 1)), dim3(256), 0, h->stream>>>(Kseed, dk, dv, m, d_cnt); })) { release(); return fail(h, BBDUK_ERR_DEVICE, "collapsing the uploaded map (check)"); }
+        if (hipMemcpy(cnt, d_cnt, 32, hipMemcpyDeviceToHost) != hipSuccess) { release(); return fail(h, BBDUK_ERR_DEVICE, "collapsing the uploaded map"); }
+        if (cnt[3] != 0) continue;                                   // some key is not answered (with its id) by the parents found
+        // every uploaded key is answered with its id: the seed map replaces the plain one (the cache-resident twin, where there is one, stays)
+        hipFree(h->d_bigTags); hipFree(h->d_bigKeys); hipFree(h->d_bigIds); h->d_bigTags = nullptr; h->d_bigKeys = nullptr; h->d_bigIds = nullptr;
+        if (!h->big && !h->hasAlt && n <= SEED_LAYOUT_MIN_KEYS) {    // a cache-resident map alone: it becomes the twin
+            h->d_tagsAlt = h->d_tags; h->d_bkvAlt = h->d_bkv; h->d_ldsAlt = h->d_ldsImage; h->nbucketsAlt = h->nbuckets; h->bucketBitsAlt = h->bucketBits; h->ldsBitsAlt = h->ldsBits; h->hasAlt = true;
+        } else { hipFree(h->d_tags); hipFree(h->d_bkv); hipFree(h->d_ldsImage); }
+        h->d_tags = sTags; h->d_bkv = sBkv; h->d_ldsImage = nullptr; h->ldsBits = 0; sTags = nullptr; sBkv = nullptr;
+        h->big = false; h->bigLines = 0; h->bigPlain = false; h->seed = true; h->nbuckets = snb; h->bucketBits = sbits;
+        h->nkeys = (int64_t)rec[0]; h->nkeysRef = n; h->nspilled = 0;
+        release();
+        return BBDUK_OK;
+    }
+    release();
+    return BBDUK_OK;
+}
+
 extern "C" int bbduk_finalize_table(bbduk_handle* h) {
     if (!h) return BBDUK_ERR_ARG;
     std::lock_guard<std::mutex> g(h->mu);
@@ -725,8 +804,10 @@ extern "C" int bbduk_finalize_table(bbduk_handle* h) {
     h->expectShort = 0.0;                                            // uploaded pairs: the keys of other lengths are the short k-mers
     { const int sh = 2 * h->p.k; for (const int64_t key : h->hkeys) if (((uint64_t)key >> sh) != 1ULL) h->expectShort += 1.0; }
     const int rc = build_both(h, (double)h->hkeys.size(), 0, [&]() { return finalize_once(h); });
+    int rc2 = BBDUK_OK;
+    if (rc == BBDUK_OK) rc2 = try_collapse_to_seed(h);                // (a JVM-built hdist=1 table -> the seed layout, where the pairs are exactly that)
     if (rc == BBDUK_OK) { h->hkeys.clear(); h->hkeys.shrink_to_fit(); h->hvals.clear(); h->hvals.shrink_to_fit(); }
-    return rc;
+    return rc != BBDUK_OK ? rc : rc2;
 }
 
 // bbduk_build_table_device: the reference sequences are HOST memory here; they go to the device in chunks of whole scaffolds
@@ -829,6 +910,7 @@ extern "C" int bbduk_table_line_histogram(bbduk_handle* h, int64_t* out33) {
     hipFree(d);
     return e == hipSuccess ? BBDUK_OK : BBDUK_ERR_DEVICE;
 }
+extern "C" int bbduk_table_layout(const bbduk_handle* h) { return (h && h->finalized) ? ((h->seed ? 2 : (h->big ? 1 : 0)) + (h->hasAlt ? 4 : 0)) : -1; }
 extern "C" int64_t bbduk_table_spilled(const bbduk_handle* h) { return (h && h->finalized && h->big) ? h->nspilled : 0; }
 extern "C" int64_t bbduk_table_size(const bbduk_handle* h) { return (h && h->finalized) ? ((h->seed && h->nkeysRef > 0) ? h->nkeysRef : h->nkeys) : -1; }
 extern "C" int64_t bbduk_table_bytes(const bbduk_handle* h) {

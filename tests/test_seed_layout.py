@@ -145,3 +145,57 @@ def test_seed_layout_chosen_from_2e22_keys_with_its_twin():
              cut(5000), util.rand_seq(rng, 2600), util.rand_seq(rng, 64000), cut(40) + util.rand_seq(rng, 45000)]
     check_batch(d, o, longs, True)
     d.close()
+
+
+@pytest.mark.parametrize("args,okw", [("k=31 hdist=1", dict(k=31, hdist=1)), ("k=25 hdist=1 mbk=1", dict(k=25, hdist=1, maxBadKmers0=1)),
+                                      ("k=24 hdist=1 mm=f", dict(k=24, hdist=1, maskMiddle=0)), ("k=27 hdist=1 forbidn=t", dict(k=27, hdist=1, forbidN=1))])
+def test_uploaded_hdist1_map_collapses_to_the_seed_layout(args, okw):
+    """Round 5: the JVM builds the table (north_star), so an hdist=1 map arrives as (key, id) PAIRS -- 1 + 3k keys per window.
+    bbduk_finalize_table finds the parents (windows whose whole neighbourhood is in the map, id = the largest id in it), builds the seed layout
+    from them and checks every uploaded key against it.  Scaffolds that share pieces (the smallest id has to win), reverse-complemented pieces, a
+    palindromic stretch, a scaffold with undefined bases; forced onto a small reference with the hook."""
+    rng = random.Random(len(args))
+    base = util.rand_seq(rng, 400)
+    pal = util.rand_seq(rng, 40); pal = pal + util.revcomp(pal)
+    refs = [util.rand_seq(rng, 300) + base[100:180], base, util.revcomp(base[200:320]), util.rand_seq(rng, 150, 0.03), util.rand_seq(rng, 12), pal + util.rand_seq(rng, 200), b"A" * 60 + util.rand_seq(rng, 100)]
+    o = Oracle(**okw)
+    for r in refs: o.add_ref(r)
+    d = B.BBDuk(args, refs=refs, hooks=SEED, build="host")             # host index -> bbduk_upload_pairs -> bbduk_finalize_table
+    assert d.gpu.table_layout == 2 + 4, d.gpu.table_layout              # seed, and the cache-resident map of the pairs as its twin
+    assert d.gpu.table_size == o.stored_kmers
+    ks, vs = o.dump_pairs()
+    rs = np.random.default_rng(1)
+    near = ks[rs.integers(0, len(ks), 20000)] ^ (np.int64(1) << rs.integers(0, 2 * okw["k"], 20000).astype(np.int64))
+    probe = np.concatenate([ks, near, rs.integers(0, 1 << (2 * okw["k"]), 20000, dtype=np.int64) | (np.int64(1) << (2 * okw["k"]))])
+    exp = np.array([o.table_get(int(x)) for x in probe], np.int32)
+    got = d.gpu.table_lookup(probe)
+    bad = np.nonzero(got != exp)[0]
+    assert len(bad) == 0, (args, len(bad), [(hex(int(probe[i])), int(got[i]), int(exp[i])) for i in bad[:5]])
+    reads = util.fuzz_reads(rng, refs, 1500, [0, 1, 30, 31, 32, 75, 100, 150, 151, 250, 300], junk=True)
+    for i in range(300):
+        r = bytearray(util.rand_seq(rng, 150)); src = refs[rng.choice([0, 1, 5, 6])]; a = rng.randrange(len(src) - 50); piece = bytearray(src[a:a + 50])
+        for _ in range(rng.choice([0, 1, 1, 2])): piece[rng.randrange(50)] = rng.choice(b"ACGTN")
+        w = rng.randrange(100); r[w:w + 50] = piece; reads.append(bytes(r))
+    check_batch(d, o, reads, True)
+    check_batch(d, o, reads[:401], False)
+    check_batch(d, o, [util.rand_seq(rng, 5000), util.rand_seq(rng, 2000) + refs[1][50:150] + util.rand_seq(rng, 2000)] + reads[:100], True)      # the tiled kernel, over the twin
+    d.close()
+
+
+def test_uploaded_map_that_is_no_hdist1_neighbourhood_keeps_its_layout():
+    """... and a map that is NOT a union of full 1-neighbourhoods (hdist=0 keys beside hdist=1 ones; an hdist=1 map with a key removed) stays what it was."""
+    rng = random.Random(77)
+    refs = [util.rand_seq(rng, 500), util.rand_seq(rng, 300)]
+    o1 = Oracle(k=31, hdist=1); o1.add_ref(refs[0])
+    o0 = Oracle(k=31); o0.add_ref(refs[1])
+    k1, v1 = o1.dump_pairs(); k0, v0 = o0.dump_pairs()
+    for keys, vals in ((np.concatenate([k1, k0]), np.concatenate([v1, v0 + 1])), (k1[1:], v1[1:])):
+        keys, idx = np.unique(keys, return_index=True); vals = vals[idx]
+        host = B.HostIndex("k=31 hdist=1"); host.add_ref(refs[0]); host.add_ref(refs[1])
+        g = B.BBDukGpu(host.params(0)); g.test_hook(B.HOOK_SEED_LAYOUT, 1)
+        g.upload_pairs(keys, vals.astype(np.int32)); g.finalize_table()
+        assert g.table_layout in (0, 2 + 4)
+        got = g.table_lookup(keys)
+        assert np.array_equal(got, vals), int((got != vals).sum())
+        if len(keys) == len(k1) - 1: assert g.table_layout == 0        # the hole cannot be covered by any parent
+        g.close(); host.close()
