@@ -79,7 +79,7 @@ def build_cli(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(_CLI) and os.path.getmtime(_CLI) > max(os.path.getmtime(_CLI_SRC), os.path.getmtime(_SO)):
         return _CLI
     rocm_lib = os.path.join(os.path.dirname(os.path.dirname(_hipcc())), "lib")
-    cmd = ["g++", "-O2", "-std=c++17", _CLI_SRC, "-o", _CLI, "-L" + _HERE, "-lbbduk_hip",
+    cmd = ["g++", "-O2", "-g", "-rdynamic", "-pthread", "-std=c++17", _CLI_SRC, "-o", _CLI, "-L" + _HERE, "-lbbduk_hip",
            "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + rocm_lib, "-Wl,-rpath," + rocm_lib]
     if verbose:
         print(" ".join(cmd))

@@ -56,7 +56,7 @@ GPU_SYMBOLS = ["bbduk_abi_version", "bbduk_create", "bbduk_destroy", "bbduk_last
                "bbduk_kfilter_batch_packed", "bbduk_ktrim_batch_packed_device", "bbduk_kfilter_batch_packed_device", "bbduk_kmask_batch", "bbduk_kmask_batch_device", "bbduk_ktrimtips_batch", "bbduk_ktrimtips_batch_device", "bbduk_ksplit_batch", "bbduk_kfilter_batch_matches", "bbduk_kfilter_batch_matches_device", "bbduk_ksplit_batch_device", "bbduk_kmask_batch_packed_device", "bbduk_ktrimtips_batch_packed_device", "bbduk_fastq_ingest_device", "bbduk_fastq_write_device", "bbduk_fastq_write_masked_device", "bbduk_device_malloc", "bbduk_device_free", "bbduk_pinned_malloc", "bbduk_pinned_free",
                "bbduk_copy_to_device", "bbduk_copy_from_device", "bbduk_device_memset", "bbduk_kernel_time_ms", "bbduk_counters_len", "bbduk_get_counters", "bbduk_reset_counters",
                "bbduk_synth_generate_device", "bbduk_synth_generate_host", "bbduk_synth_pair_inserts",
-               "bbduk_comm_unique_id", "bbduk_comm_create", "bbduk_comm_create_local", "bbduk_comm_destroy", "bbduk_comm_size",
+               "bbduk_comm_preload", "bbduk_comm_unique_id", "bbduk_comm_create", "bbduk_comm_create_local", "bbduk_comm_destroy", "bbduk_comm_size",
                "bbduk_allreduce_counters", "bbduk_allreduce_counters_device", "bbduk_allreduce_counters_local",
                "bbduk_test_hook", "bbduk_table_spilled", "bbduk_table_line_histogram", "bbduk_table_layout", "bbduk_build_begin", "bbduk_build_add_device", "bbduk_build_end"]
 HOST_SYMBOLS = ["bbduk_host_parse", "bbduk_host_destroy", "bbduk_host_add_ref", "bbduk_host_load_fasta",

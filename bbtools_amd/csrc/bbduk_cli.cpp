@@ -29,6 +29,11 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <dirent.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include "../../include/bbduk_gpu.h"
 #include "../../include/bbduk_host.h"
 
@@ -280,6 +285,43 @@ int run_device_ingest(bbduk_handle* dev, const bbduk_host* host, const StatsOut&
 
 }  // namespace
 
+// watchdog=SECONDS (diagnostics; round 5: the intermittent stall of devices=0,0,0 runs had never been looked at from the inside, the images carry no
+// debugger): a thread that, if the run has not finished in time, makes EVERY thread of the process print its own call stack (a signal per thread,
+// backtrace_symbols_fd in the handler) together with what the kernel says it waits in, and ends the process with status 97.
+static volatile int g_wd_done = 0;
+static void wd_handler(int) {
+    void* fr[64];
+    const int n = backtrace(fr, 64);
+    char head[96]; const int m = snprintf(head, sizeof head, "---- watchdog: thread %ld\n", (long)syscall(SYS_gettid));
+    if (write(2, head, (size_t)m) < 0) {}
+    backtrace_symbols_fd(fr, n, 2);
+}
+static void wd_start(const int seconds) {
+    std::thread([seconds]() {
+        for (int t = 0; t < seconds * 10 && !g_wd_done; t++) usleep(100000);
+        if (g_wd_done) return;
+        fprintf(stderr, "==== watchdog: no end after %d s, dumping every thread ====\n", seconds);
+        struct sigaction sa; memset(&sa, 0, sizeof sa); sa.sa_handler = wd_handler; sigaction(SIGUSR2, &sa, nullptr);
+        const long pid = (long)getpid(), me = (long)syscall(SYS_gettid);
+        if (DIR* d = opendir("/proc/self/task")) {
+            while (struct dirent* e = readdir(d)) {
+                const long tid = atol(e->d_name);
+                if (tid <= 0 || tid == me) continue;
+                char path[64], buf[256];
+                for (const char* what : {"comm", "wchan", "syscall"}) {
+                    snprintf(path, sizeof path, "/proc/self/task/%ld/%s", tid, what);
+                    if (FILE* f = fopen(path, "r")) { const size_t k = fread(buf, 1, sizeof buf - 1, f); buf[k] = 0; fclose(f); for (char* c = buf; *c; c++) if (*c == '\n') *c = ' '; fprintf(stderr, "tid %ld %s: %s\n", tid, what, buf); }
+                }
+                syscall(SYS_tgkill, pid, tid, SIGUSR2);
+                usleep(200000);
+            }
+            closedir(d);
+        }
+        fflush(stderr);
+        _exit(97);
+    }).detach();
+}
+
 int main(int argc, char** argv) {
     std::string in1, in2, out, outm, tsv, resources = "data", flags;
     bool interleaved = false; long batch = 1000000; int device = 0; std::vector<int> devices;
@@ -305,6 +347,7 @@ int main(int argc, char** argv) {
         else if (a == "devicebuild") deviceBuild = parse_bool(b);
         else if (a == "deviceingest") deviceIngest = parse_bool(b);
         else if (a == "chunk") chunk = atoll(b.c_str());
+        else if (a == "watchdog") { if (atoi(b.c_str()) > 0) wd_start(atoi(b.c_str())); }
         else if (a == "stats" || a == "scafstats") so.stats = b;     // BBDukParser.java:486-494, 689-693
         else if (a == "rpkm" || a == "fpkm" || a == "cov" || a == "coverage") so.rpkm = b;
         else if (a == "refstats") so.refstats = b;                   // BBDukParser.java:493
@@ -336,6 +379,7 @@ int main(int argc, char** argv) {
     if (!deviceBuild) { stored = bbduk_host_build_index(host); if (stored < 0) return fail("index build failed", nullptr); }
     if (devices.empty()) devices.push_back(device);
     device = devices[0];
+    { bool several = false; for (int d : devices) several = several || d != devices[0]; if (several) bbduk_comm_preload(); }     // (the collective library loads while the map is built)
     bbduk_params P;
     if (bbduk_host_params(host, device, &P) != BBDUK_OK) return fail("unsupported parameter combination", nullptr);
     std::vector<bbduk_handle*> devs;                               // one handle per entry of devices=, the map replicated on each
@@ -510,5 +554,5 @@ int main(int argc, char** argv) {
     if (write_stats(so, host, c, in1, in2) != 0) return 1;
     for (bbduk_handle* hq : devs) bbduk_destroy(hq);
     bbduk_host_destroy(host);
-    return 0;
+    return 0;                                                     // (a watchdog stays armed through the exit handlers: the HIP / RCCL teardown is a suspect too)
 }

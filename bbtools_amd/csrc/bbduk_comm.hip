@@ -18,6 +18,7 @@
 #include <dlfcn.h>
 #include <string.h>
 #include <map>
+#include <thread>
 #include "bbduk_internal.h"
 #include <rccl/rccl.h>
 
@@ -87,6 +88,14 @@ struct bbduk_comm {
     std::mutex mu;
 };
 
+// Start loading the collective library now, on a thread of its own: librccl.so.1 is several hundred megabytes and its load registers every code object
+// with the HIP runtime -- tens of seconds from a cold page cache.  A host that will form a group over several devices calls this first thing, so that
+// the load overlaps its table build; the comm calls then find the library loaded (or wait for the rest of the load).  Never needed for correctness.
+extern "C" int bbduk_comm_preload(void) {
+    std::thread([]() { rccl(); }).detach();
+    return BBDUK_OK;
+}
+
 extern "C" int bbduk_comm_unique_id(uint8_t* id128) {
     if (!id128) return BBDUK_ERR_ARG;
     Rccl* R = rccl();
@@ -126,8 +135,6 @@ extern "C" int bbduk_comm_create_local(bbduk_handle** hs, int32_t n) {
         if (bbduk_counters_len(hs[i]) != nc) return fail(h0, BBDUK_ERR_ARG, "the handles of a group must have the same numScaffolds");
         for (int j = 0; j < i; j++) if (hs[j] == hs[i]) return fail(h0, BBDUK_ERR_ARG, "the same handle twice");
     }
-    Rccl* R = rccl();
-    if (!R->lib) { h0->err = R->err; return BBDUK_ERR_DEVICE; }
     bbduk_comm* c = new (std::nothrow) bbduk_comm();
     if (!c) return BBDUK_ERR_NOMEM;
     c->local = true; c->ncounters = nc;
@@ -141,12 +148,22 @@ extern "C" int bbduk_comm_create_local(bbduk_handle** hs, int32_t n) {
         else c->leaderOf[i] = it->second;
     }
     c->comms.assign(c->leaders.size(), nullptr);
-    const ncclResult_t r = R->CommInitAll(c->comms.data(), (int)devs.size(), devs.data());
-    if (r != ncclSuccess) { delete c; return nccl_fail(h0, "ncclCommInitAll", r); }
+    // A group on ONE device needs no collective library at all: its handles are summed on that device (step 1 of bbduk_allreduce_counters_local) and that
+    // is the result.  Round 5: this is what `bbduk_cli devices=0,0,0` had been stalling in -- dlopen of a 573 MB librccl.so.1 whose code objects are all
+    // registered with the HIP runtime at load; on a fresh box that is a cold read of the whole file (45-130 s measured, wchan folio_wait_bit_common:
+    // profiles/r05_hang_hunt.txt), which a 120 s test timeout read as a hang.  With several devices RCCL is needed: bbduk_comm_preload() starts that
+    // load early so that it overlaps the table build.
+    Rccl* R = nullptr;
+    if (devs.size() > 1) {
+        R = rccl();
+        if (!R->lib) { h0->err = R->err; delete c; return BBDUK_ERR_DEVICE; }
+        const ncclResult_t r = R->CommInitAll(c->comms.data(), (int)devs.size(), devs.data());
+        if (r != ncclSuccess) { delete c; return nccl_fail(h0, "ncclCommInitAll", r); }
+    }
     c->scratch.assign(c->leaders.size(), nullptr);
     for (size_t j = 0; j < c->leaders.size(); j++) {
         if (hipSetDevice(devs[j]) != hipSuccess || hipMalloc(&c->scratch[j], (size_t)nc * sizeof(int64_t)) != hipSuccess) {
-            for (size_t q = 0; q < c->leaders.size(); q++) { if (c->scratch[q]) { hipSetDevice(devs[q]); hipFree(c->scratch[q]); } R->CommDestroy(c->comms[q]); }
+            for (size_t q = 0; q < c->leaders.size(); q++) { if (c->scratch[q]) { hipSetDevice(devs[q]); hipFree(c->scratch[q]); } if (R && c->comms[q]) R->CommDestroy(c->comms[q]); }
             delete c;
             return fail(h0, BBDUK_ERR_NOMEM, "hipMalloc (communicator scratch)");
         }
@@ -160,17 +177,17 @@ extern "C" int bbduk_comm_destroy(bbduk_handle* h) {
     if (!h) return BBDUK_ERR_ARG;
     bbduk_comm* c = h->comm;
     if (!c) return BBDUK_OK;
-    Rccl* R = rccl();
     if (c->local) {                                                // the first member to leave tears the group down for all of them
+        Rccl* R = c->leaders.size() > 1 ? rccl() : nullptr;
         for (bbduk_handle* m : c->members) m->comm = nullptr;
         for (size_t j = 0; j < c->leaders.size(); j++) {
             hipSetDevice(c->members[c->leaders[j]]->p.device);
             hipFree(c->scratch[j]);
-            if (c->comms[j]) R->CommDestroy(c->comms[j]);
+            if (R && c->comms[j]) R->CommDestroy(c->comms[j]);
         }
     } else {
         hipSetDevice(h->p.device);
-        if (c->comm) R->CommDestroy(c->comm);
+        if (c->comm) rccl()->CommDestroy(c->comm);
         h->comm = nullptr;
     }
     delete c;
@@ -218,7 +235,7 @@ extern "C" int bbduk_allreduce_counters_local(bbduk_handle** hs, int32_t n) {
     if ((size_t)n != c->members.size()) return fail(h0, BBDUK_ERR_ARG, "allreduce_counters_local: pass the whole group");
     for (int i = 0; i < n; i++) if (hs[i] != c->members[i]) return fail(h0, BBDUK_ERR_ARG, "allreduce_counters_local: pass the group in the order given to bbduk_comm_create_local");
     std::lock_guard<std::mutex> g(c->mu);
-    Rccl* R = rccl();
+    Rccl* R = c->leaders.size() > 1 ? rccl() : nullptr;            // (one device: no collective, see bbduk_comm_create_local)
     const size_t bytes = (size_t)c->ncounters * sizeof(int64_t);
     // every member's own stream must have finished what it was accumulating
     for (bbduk_handle* m : c->members) { HIP_TRY(h0, hipSetDevice(m->p.device)); HIP_TRY(h0, hipStreamSynchronize(m->stream)); }
@@ -234,16 +251,18 @@ extern "C" int bbduk_allreduce_counters_local(bbduk_handle** hs, int32_t n) {
         HIP_TRY(h0, hipGetLastError());
     }
     // 2. leaders: one grouped RCCL all-reduce (sum, int64) over the distinct devices
-    ncclResult_t r = R->GroupStart();
-    if (r != ncclSuccess) return nccl_fail(h0, "ncclGroupStart", r);
-    for (size_t j = 0; j < c->leaders.size(); j++) {
-        bbduk_handle* L = c->members[c->leaders[j]];
-        hipSetDevice(L->p.device);
-        r = R->AllReduce(L->d_counters, L->d_counters, (size_t)c->ncounters, ncclInt64, ncclSum, c->comms[j], L->stream);
-        if (r != ncclSuccess) { R->GroupEnd(); return nccl_fail(h0, "ncclAllReduce", r); }
+    if (R) {
+        ncclResult_t r = R->GroupStart();
+        if (r != ncclSuccess) return nccl_fail(h0, "ncclGroupStart", r);
+        for (size_t j = 0; j < c->leaders.size(); j++) {
+            bbduk_handle* L = c->members[c->leaders[j]];
+            hipSetDevice(L->p.device);
+            r = R->AllReduce(L->d_counters, L->d_counters, (size_t)c->ncounters, ncclInt64, ncclSum, c->comms[j], L->stream);
+            if (r != ncclSuccess) { R->GroupEnd(); return nccl_fail(h0, "ncclAllReduce", r); }
+        }
+        r = R->GroupEnd();
+        if (r != ncclSuccess) return nccl_fail(h0, "ncclGroupEnd", r);
     }
-    r = R->GroupEnd();
-    if (r != ncclSuccess) return nccl_fail(h0, "ncclGroupEnd", r);
     // 3. back to the followers
     for (int i = 0; i < n; i++) {
         const int l = c->leaderOf[i];

@@ -375,15 +375,24 @@ def main():
                     qc = max(1, int(q_) // int(p_)); cand |= {qc, 2 * qc, 4 * qc}
             except (OSError, ValueError):
                 pass
-            probes = {}
-            for rep in range(2):                      # two rounds, the better time counts: a single 100k-pair probe is noisy; the FASTEST names the thread count
-                for th in sorted(cand, reverse=True):
-                    if th > avail:
-                        continue
-                    t = time.perf_counter(); o.process_batch(hb, hoff, True, nthreads=th); dt_ = time.perf_counter() - t
-                    probes[th] = min(probes.get(th, dt_), dt_)
-            cores = min(probes, key=probes.get)
-            probe = probes[cores]
+            # Each candidate gets a probe of >= 2 s (round 5, VERDICT r4: 100k-pair probes of ~0.1 s ranked 128 threads above 16 on a box whose own
+            # scaling table then showed 16 threads 18 % faster): the batch grows until the probe lasts that long; the rates are the scaling table.
+            hbp, hoffp = B.synth_generate_host(sp, lo, min(n_pairs, 500_000))
+            max_probe_pairs = (len(hoffp) - 1) // 2
+            rates = {}
+            for th in sorted(cand | {1}, reverse=True):
+                if th > avail:
+                    continue
+                pairs_t = min(max_probe_pairs, 500_000 if th > 1 else 20_000)
+                done_pairs = 0; dt_ = 0.0
+                while dt_ < 2.0:                      # the same batch again until the probe has lasted 2 s
+                    o.reset_counters()
+                    t = time.perf_counter(); o.process_batch(hbp[:2 * pairs_t * READ_LEN], hoffp[:2 * pairs_t + 1], True, nthreads=th); dt_ += time.perf_counter() - t
+                    done_pairs += pairs_t
+                rates[th] = 2 * done_pairs * READ_LEN / dt_ / 1e9
+            cores = max(rates, key=rates.get)
+            probe = 100_000 * 2 * READ_LEN / 1e9 / rates[cores]      # seconds per 100k pairs at the chosen thread count
+            del hbp, hoffp
             sample_pairs = int(min(n_pairs, max(100_000, 100_000 * a.cpu_seconds / max(probe, 1e-3))))
             hb, hoff = B.synth_generate_host(sp, lo, sample_pairs)
             o.reset_counters()
@@ -393,22 +402,17 @@ def main():
                       and np.array_equal(d_fl[:m].cpu().numpy(), of))
             out["cpu_baseline"] = {"value": round(m * READ_LEN / cpu_dt / 1e9, 4), "unit": "Gbases/s", "cores": cores,
                                    "kind": "port", "sample": "first %d reads of the same synthetic workload, %.1f s, "
-                                   "oracle/bbduk_oracle.c with %d pthreads (the fastest of %s on a 100k-pair probe run twice; the cgroup's CPU quota and its multiples are in the set); os.cpu_count() = %d "
-                                   "(match only, no I/O)" % (m, cpu_dt, cores, sorted(probes), os.cpu_count() or 1)}
+                                   "oracle/bbduk_oracle.c with %d pthreads (the fastest of %s in probes of >= 2 s each: threads_scaling; the cgroup's CPU quota and its multiples are in the set); os.cpu_count() = %d "
+                                   "(match only, no I/O)" % (m, cpu_dt, cores, sorted(rates), os.cpu_count() or 1)}
             try:
                 with open("/sys/fs/cgroup/cpu.max") as fh:
                     out["cpu_baseline"]["cgroup_cpu_max"] = fh.read().strip()
             except OSError:
                 pass
             out["parity_sample_ok"] = ok
-            scal = {}                                 # the same port at fewer threads, ~2 s each: what one host core does
-            for th in sorted({1, 16, 64, cores, avail}):
-                if th > avail:
-                    continue
-                pairs_t = int(max(2_000, min(sample_pairs, 100_000 * (2.0 / max(probe, 1e-3)) * min(th, cores) / cores)))
-                o.reset_counters()
-                t = time.perf_counter(); o.process_batch(hb[:2 * pairs_t * READ_LEN], hoff[:2 * pairs_t + 1], True, nthreads=th); dt_t = time.perf_counter() - t
-                scal[str(th)] = round(2 * pairs_t * READ_LEN / dt_t / 1e9, 4)
+            if max(rates.values()) > out["cpu_baseline"]["value"]:      # (the baseline is the port's best measurement)
+                out["cpu_baseline"]["value"] = round(max(rates.values()), 4); out["cpu_baseline"]["sample"] += "; value = the best >= 2 s probe (the long sample ran slower)"
+            scal = {str(th): round(r, 4) for th, r in sorted(rates.items())}      # the probes above: >= 2 s each
             out["cpu_baseline"]["threads_scaling"] = scal
         except Exception as e:                        # the bench line must not depend on the checker building / running
             out["cpu_baseline"] = {"value": None, "unit": "Gbases/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}

@@ -328,6 +328,10 @@ int  bbduk_reset_counters(bbduk_handle* h);
  *                         on it first, the device leaders run the all-reduce, every handle ends with the global sums.
  * The status slot (BBDUK_CTR_STATUS) is summed like the rest: nonzero anywhere stays nonzero. */
 #define BBDUK_COMM_ID_BYTES 128
+/* Optional, first thing in a host that will form a group over SEVERAL devices: starts the load of librccl (hundreds of megabytes whose code objects are
+ * all registered at load: tens of seconds from a cold page cache) on a thread of its own, so that it overlaps the table build.  A group whose handles
+ * share one device never loads it. */
+int  bbduk_comm_preload(void);
 int  bbduk_comm_unique_id(uint8_t* id128);
 int  bbduk_comm_create(bbduk_handle* h, int32_t nranks, int32_t rank, const uint8_t* id128);
 int  bbduk_comm_create_local(bbduk_handle** handles, int32_t n);
