@@ -125,6 +125,13 @@ def measure_configs(B, reads, c4_ref_bases, c4_reads=0):
         res["C7_hdist0_genome"] = {"error": repr(e)}
     # round 4: the same genome at BBDuk's default k = 27, and as a ktrim=r reference (the trimming mode's large-map path);
     # all three on bbduk_bigs_kernel, the stream scan over the minimizer lines (bbduk_bigs.inc)
+    try:                                               # round 5: the same hdist=1 map as C6, but UPLOADED as (key, id) pairs -- what a JVM host hands over;
+        # bbduk_finalize_table collapses it to its parents and the seed layout (64 Gbases/s and 11.1 GB as plain lines until round 5).  A 1 Mbase genome here:
+        # the host-side index of the 4.6 Mbase one (4.2e8 pairs) takes a minute to build, profiles/r05_uploaded_hdist1.jsonl has it (121 Gbases/s)
+        r = bench_hdist_big.run(reads=reads, genome_bases=1_000_000, build="host")
+        res["C6u_hdist1_uploaded"] = {k: r[k] for k in ("workload", "keys", "table_bytes", "build", "layout", "build_s", "reads", "kernel_ms", "Gbases_per_s", "readsKFiltered")}
+    except Exception as e:
+        res["C6u_hdist1_uploaded"] = {"error": repr(e)}
     for name, args in (("C8_k27_genome", "k=27 hdist=0"), ("C9_ktrim_genome", "ktrim=r k=31 hdist=0")):
         try:
             r = bench_hdist_big.run(reads=reads, args=args)
@@ -430,6 +437,9 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "profiles"))
             import bench_modes, bench_seal
             out["operators"] = {r["mode"]: {k: r[k] for k in ("args", "reads", "operator_ms", "Gbases_per_s")} for r in bench_modes.run(a.extra_reads)}
+            # round 5: the same operator families against the guide's genome-size example (a random 4.6 Mbase genome), i.e. over a
+            # big-layout map scanned by bbduk_bigs_every_kernel -- cache-resident at 60-75 Gbases/s until round 5
+            out["operators_genome"] = {r["mode"]: {k: r[k] for k in ("args", "keys", "reads", "operator_ms", "Gbases_per_s")} for r in bench_modes.run_genome(a.extra_reads)}
             out["seal"] = bench_seal.run(pairs=1_000_000, check=2000)      # (the first 2 000 pairs replayed by oracle/seal_oracle.c: sample_equals_restatement)
         except Exception as e:
             out["operators"] = {"error": repr(e)}

@@ -12,7 +12,7 @@ import numpy as np
 def run(**kw):
     """bench.py's `configs` block calls this (defaults = the command line's)"""
     import types
-    d = dict(genome_bases=4_600_000, reads=20_000_000, steps=3, check_reads=0, oracle_bases=100_000, args="k=31 hdist=1", bucket_bits=0, plain=False, m=0)
+    d = dict(genome_bases=4_600_000, reads=20_000_000, steps=3, check_reads=0, oracle_bases=100_000, args="k=31 hdist=1", bucket_bits=0, plain=False, m=0, build="device")
     d.update(kw)
     return _run(types.SimpleNamespace(**d))
 
@@ -21,7 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--genome-bases", type=int, default=4_600_000); ap.add_argument("--reads", type=int, default=20_000_000)
     ap.add_argument("--steps", type=int, default=3); ap.add_argument("--check-reads", type=int, default=0); ap.add_argument("--oracle-bases", type=int, default=100_000)
-    ap.add_argument("--args", default="k=31 hdist=1"); ap.add_argument("--bucket-bits", type=int, default=0); ap.add_argument("--plain", action="store_true"); ap.add_argument("--m", type=int, default=0)
+    ap.add_argument("--args", default="k=31 hdist=1"); ap.add_argument("--bucket-bits", type=int, default=0); ap.add_argument("--plain", action="store_true"); ap.add_argument("--m", type=int, default=0); ap.add_argument("--build", default="device", help="host: the map arrives as (key, id) pairs, as a JVM host uploads it")
     a = ap.parse_args()
     print(json.dumps(_run(a)))
 
@@ -36,7 +36,7 @@ def _run(a):
     if a.bucket_bits: hooks[B.HOOK_BUCKET_BITS] = a.bucket_bits
     if a.plain: hooks[B.HOOK_LDS_BITS] = 0
     if a.m: hooks[B.HOOK_LDS_BITS] = a.m
-    duk = B.BBDuk(a.args, refs=[genome], build="device", hooks=hooks)
+    duk = B.BBDuk(a.args, refs=[genome], build=getattr(a, "build", "device"), hooks=hooks)
     build_s = time.perf_counter() - t0
     n = a.reads & ~1
     d_bases = torch.empty(n * 150, dtype=torch.uint8, device="cuda"); d_off = torch.empty(n + 1, dtype=torch.int64, device="cuda")
@@ -51,7 +51,7 @@ def _run(a):
     ms = duk.gpu.kernel_time_ms(a.steps)
     c = d_c.cpu().tolist()
     out = {"workload": "%s vs a random %d-base genome (BBDukGuide.txt:34's E. coli example), 2x150 bp, 1 %% of the pairs from the genome" % (a.args if "ktrim" in a.args else "kfilter " + a.args, a.genome_bases),
-           "keys": int(duk.stored_kmers), "table_bytes": int(duk.gpu.table_bytes), "spilled_keys": int(duk.gpu.table_spilled) if hasattr(duk.gpu, "table_spilled") else None,
+           "keys": int(duk.stored_kmers), "table_bytes": int(duk.gpu.table_bytes), "build": getattr(a, "build", "device"), "layout": int(duk.gpu.table_layout), "spilled_keys": int(duk.gpu.table_spilled) if hasattr(duk.gpu, "table_spilled") else None,
            "build_s": round(build_s, 2), "reads": n, "kernel_ms": round(ms, 3), "Gbases_per_s": round(n * 150 / ms / 1e6, 1),
            "readsKFiltered": int(c[B.COUNTER_NAMES.index("readsKFiltered")]), "readsKTrimmed": int(c[B.COUNTER_NAMES.index("readsKTrimmed")])}
     if a.check_reads:
