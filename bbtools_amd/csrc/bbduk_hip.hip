@@ -107,7 +107,7 @@ __global__ void bbduk_lookup_kernel(const KParams P, const int64_t* keys, int64_
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         const uint64_t key = (uint64_t)keys[i], v = strip_len(key);
-        out[i] = (keys[i] < 0) ? -1 : (P.seed ? seed_find_key(P, key) : (P.big ? big_find(P, key, mix_a(v), mix_b(v)) : table_get(P, key)));
+        out[i] = (keys[i] < 0) ? -1 : P.qx ? qx_find_key(P, key) : (P.seed ? seed_find_key(P, key) : (P.big ? big_find(P, key, mix_a(v), mix_b(v)) : table_get(P, key)));
     }
 }
 
@@ -189,6 +189,7 @@ extern "C" int bbduk_create(const bbduk_params* p, bbduk_handle** out) {
 }
 
 static void build_release(bbduk_handle* h);
+static int qx_rewrite(bbduk_handle* h);
 
 // Test-only controls (include/bbduk_test_hooks.h): explicit calls on a handle instead of environment variables.
 extern "C" int bbduk_test_hook(bbduk_handle* h, int32_t which, int64_t value) {
@@ -220,7 +221,7 @@ extern "C" int bbduk_destroy(bbduk_handle* h) {
     hipFree(h->d_bigTags); hipFree(h->d_bigKeys); hipFree(h->d_bigIds);
     for (auto& q : h->slot) { hipFree(q.d_bases); hipFree(q.d_undef); hipFree(q.d_off); hipFree(q.d_a); hipFree(q.d_id); hipFree(q.d_fl); hipFree(q.d_status); if (q.stream) hipStreamDestroy(q.stream); }
     hipFree(h->d_tags); hipFree(h->d_bkv);
-    hipFree(h->d_ldsImage); hipFree(h->d_slowFlag); hipFree(h->d_tagsAlt); hipFree(h->d_bkvAlt); hipFree(h->d_ldsAlt);
+    hipFree(h->d_ldsImage); hipFree(h->d_slowFlag); hipFree(h->d_tagsAlt); hipFree(h->d_bkvAlt); hipFree(h->d_ldsAlt); hipFree(h->d_tagsQx); hipFree(h->d_bkvQx);
     for (int q = 0; q < bbduk_handle::EV_RING; q++) { if (h->ev0[q]) hipEventDestroy(h->ev0[q]); if (h->ev1[q]) hipEventDestroy(h->ev1[q]); if (h->evDone[q]) hipEventDestroy(h->evDone[q]); }
     hipFree(h->d_counters);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -286,6 +287,7 @@ static void table_release(bbduk_handle* h) {       // a failed build leaves no h
     h->big = false; h->seed = false; h->nbuckets = 0; h->bigLines = 0; h->ldsBits = 0; h->nkeys = 0; h->nkeysRef = 0;
     hipFree(h->d_tagsAlt); hipFree(h->d_bkvAlt); hipFree(h->d_ldsAlt);
     h->d_tagsAlt = nullptr; h->d_bkvAlt = nullptr; h->d_ldsAlt = nullptr; h->hasAlt = false; h->nbucketsAlt = 0;
+    hipFree(h->d_tagsQx); hipFree(h->d_bkvQx); h->d_tagsQx = nullptr; h->d_bkvQx = nullptr; h->qx = false; h->nbucketsQx = 0; h->nkeysQx = 0;
 }
 // gapped-minimizer geometry of the big layout for this k and middle mask (see "big layout"); false: k too small for it
 static bool big_geometry(bbduk_handle* h, const double maxKeys = 0.0) {
@@ -636,7 +638,8 @@ extern "C" int bbduk_build_end(bbduk_handle* h) {
     std::lock_guard<std::mutex> g(h->mu);
     if (!h->build) return fail(h, BBDUK_ERR_STATE, "build_end without bbduk_build_begin");
     HIP_TRY(h, hipSetDevice(h->p.device));
-    return build_end_impl(h);
+    const int rc = build_end_impl(h);
+    return rc == BBDUK_OK ? qx_rewrite(h) : rc;
 }
 
 // The pairs a host staged with bbduk_upload_pairs / bbduk_upload_table_way go to the device in chunks and are placed there (one
@@ -721,6 +724,58 @@ static int build_both(bbduk_handle* h, const double maxKeys, const int hdist, On
 // the plain map of the pairs built and the pairs still on the host.  Returns BBDUK_OK whether or not the map was collapsed (a map that is no union of
 // full 1-neighbourhoods, or too small to gain, keeps the layout it has); an error only for device failures.
 static KParams make_kparams(const bbduk_handle* h);
+// Query-side Hamming expansion (qhdist = 1; BBDukIndexMod.java:462-481) tabulated at the end of the table build (round 5).  getValue's answer for
+// a window depends on kmer alone but for its first, direct lookup (see qx_lookup), and only the forward k-mers within one substitution of a stored key (in
+// either orientation) can get one: they are enumerated, evaluated by the reference's own loop against the map just built, and placed as a second map keyed
+// by the forward k-mer -- which the kernels then look up with rcomp = 0 and no expansion at all: one lookup per window where the reference spends 1 + 3k
+// (round 4: two data-parallel stages, 64 neighbour evaluations and ~12 gathers per window, 6.8 Gbases/s).  Served: qhdist <= 1 and qhdist2 <= 1, rcomp=t,
+// no middle mask (mink, or mm=f: a masked base would make the answer depend on more than the key), speed = 0, a cache-resident map, an expansion of at
+// most 2^28 keys; anything else keeps the expansion inside the tiled kernels.
+static int qx_rewrite(bbduk_handle* h) {
+    const bbduk_params& p = h->p;
+    const bool useShort = p.mink > 0 && p.mink < p.k;
+    const int qh2 = useShort ? p.qhdist2 : 0;
+    if (!h->finalized || h->qx || h->big || h->seed || h->sealTable || h->nkeys < 1) return BBDUK_OK;
+    if (!(p.qhdist == 1 || qh2 == 1) || p.qhdist > 1 || qh2 > 1 || !p.rcomp || p.middleMask != -1 || p.speed > 0 || p.kbig > p.k || p.k > 31) return BBDUK_OK;
+    const double ub = (double)h->nkeys * 2.0 * (1.0 + 3.0 * p.k);
+    if (ub > (double)(1ULL << 28)) return BBDUK_OK;
+    HIP_TRY(h, hipSetDevice(p.device));
+    uint64_t cslots = 1024; while ((double)cslots < 2.0 * ub + 16.0) cslots <<= 1;
+    uint64_t* d_sk = nullptr; int32_t* d_si = nullptr; int32_t* d_sn = nullptr; unsigned long long* d_cnt = nullptr;
+    uint64_t* nTags = nullptr; uint4* nBkv = nullptr; uint32_t* nLds = nullptr;
+    auto release = [&]() { hipFree(d_sk); hipFree(d_si); hipFree(d_sn); hipFree(d_cnt); hipFree(nTags); hipFree(nBkv); hipFree(nLds); };
+    if (hipMalloc(&d_sk, cslots * 8) != hipSuccess || hipMalloc(&d_si, cslots * 4) != hipSuccess || hipMalloc(&d_sn, cslots * 4) != hipSuccess || hipMalloc(&d_cnt, 64) != hipSuccess) { release(); return BBDUK_OK; }
+    hipMemsetAsync(d_sk, 0xFF, cslots * 8, h->stream); hipMemsetAsync(d_si, 0x7F, cslots * 4, h->stream); hipMemsetAsync(d_sn, 0, cslots * 4, h->stream); hipMemsetAsync(d_cnt, 0, 64, h->stream);
+    KParams K = make_kparams(h);                                    // the reference's map, rcomp = 1, qhdist as given
+    K.qhdist2 = qh2;
+    Sink S; memset(&S, 0, sizeof S); S.skeys = d_sk; S.sids = d_si; S.cmask = cslots - 1; S.distinct = d_cnt;
+    const uint64_t nslots = 4ULL * h->nbuckets;
+    const uint64_t work = nslots * 2ULL * (uint64_t)(1 + 3 * p.k);
+    bbduk_qx_enum_kernel<<<dim3((unsigned)std::min<uint64_t>((work + 255) / 256, (uint64_t)h->numCU * 64)), dim3(256), 0, h->stream>>>(K, nslots, S);
+    bbduk_qx_eval_kernel<<<dim3((unsigned)std::min<uint64_t>((cslots + 255) / 256, (uint64_t)h->numCU * 64)), dim3(256), 0, h->stream>>>(K, d_sk, d_si, d_sn, cslots);
+    unsigned long long distinct = 0;
+    if (hipMemcpyAsync(&distinct, d_cnt, 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) { release(); return fail(h, BBDUK_ERR_DEVICE, "tabulating the query expansion"); }
+    int bbits = 10;
+    while (bbits < 32 && (1ULL << bbits) < distinct) bbits++;
+    if (bbits >= 20) bbits--;
+    const uint64_t nb = 1ULL << bbits;
+    if (4 * nb < distinct + nb / 8 || 4 * nb > (1ULL << 31)) { release(); return BBDUK_OK; }
+    auto ceil_log2 = [](uint64_t x) { int b = 0; while ((1ULL << b) < x) b++; return b; };
+    int lb = 0;
+    if (distinct > 0 && distinct <= (1ULL << 22)) lb = std::min(MAX_LDS_BITS, std::max(10, ceil_log2(32ULL * distinct)));
+    if (hipMalloc(&nTags, (nb + 1) * 8) != hipSuccess || hipMalloc(&nBkv, 4 * nb * sizeof(uint4)) != hipSuccess || (lb && hipMalloc(&nLds, ((size_t)1 << (lb - 5)) * 4) != hipSuccess)) { release(); return BBDUK_OK; }
+    hipMemsetAsync(nTags, 0, (nb + 1) * 8, h->stream); hipMemsetAsync(nBkv, 0xFF, 4 * nb * sizeof(uint4), h->stream);
+    if (lb) hipMemsetAsync(nLds, 0, ((size_t)1 << (lb - 5)) * 4, h->stream);
+    bbduk_build_place_kernel<<<dim3((unsigned)std::min<uint64_t>((cslots + 255) / 256, (uint64_t)h->numCU * 32)), dim3(256), 0, h->stream>>>(d_sk, d_si, cslots, nTags, nBkv, bbits, (uint32_t)(nb - 1), nLds, lb, d_sn);
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { release(); return fail(h, BBDUK_ERR_DEVICE, "tabulating the query expansion (placement)"); }
+    // the expansion becomes the map the kernels look up; the reference's map moves beside it
+    h->d_tagsQx = h->d_tags; h->d_bkvQx = h->d_bkv; h->nbucketsQx = h->nbuckets; h->bucketBitsQx = h->bucketBits; h->nkeysQx = h->nkeys;
+    hipFree(h->d_ldsImage);
+    h->d_tags = nTags; h->d_bkv = nBkv; h->d_ldsImage = nLds; h->nbuckets = nb; h->bucketBits = bbits; h->ldsBits = lb; h->nkeys = (int64_t)distinct; h->qx = true;
+    nTags = nullptr; nBkv = nullptr; nLds = nullptr;
+    release();
+    return BBDUK_OK;
+}
 static int try_collapse_to_seed(bbduk_handle* h) {
     const int64_t n = (int64_t)h->hkeys.size();
     if (h->seed || h->sealTable || h->hookBigLayout || h->hookNoBigLayout) return BBDUK_OK;
@@ -806,6 +861,7 @@ extern "C" int bbduk_finalize_table(bbduk_handle* h) {
     const int rc = build_both(h, (double)h->hkeys.size(), 0, [&]() { return finalize_once(h); });
     int rc2 = BBDUK_OK;
     if (rc == BBDUK_OK) rc2 = try_collapse_to_seed(h);                // (a JVM-built hdist=1 table -> the seed layout, where the pairs are exactly that)
+    if (rc == BBDUK_OK && rc2 == BBDUK_OK) rc2 = qx_rewrite(h);       // (qhdist = 1: the expansion tabulated)
     if (rc == BBDUK_OK) { h->hkeys.clear(); h->hkeys.shrink_to_fit(); h->hvals.clear(); h->hvals.shrink_to_fit(); }
     return rc != BBDUK_OK ? rc : rc2;
 }
@@ -840,7 +896,8 @@ extern "C" int bbduk_build_table_device_edits(bbduk_handle* h, const uint8_t* re
     h->expectShort = 0.0;
     if (useShort) for (int L = h->p.mink; L < k; L++) h->expectShort += 2.0 * (double)n_refs * variants(L, hdist2, edist2);
     ub += h->expectShort;
-    return build_both(h, ub, hdist, [&]() { return build_device_once(h, refs, ref_offsets, n_refs, hdist, hdist2, ub, edist, edist2); });
+    const int rc = build_both(h, ub, hdist, [&]() { return build_device_once(h, refs, ref_offsets, n_refs, hdist, hdist2, ub, edist, edist2); });
+    return rc == BBDUK_OK ? qx_rewrite(h) : rc;
 }
 static int build_device_once(bbduk_handle* h, const uint8_t* refs, const int64_t* ref_offsets, const int32_t n_refs, const int32_t hdist, const int32_t hdist2, const double ub,
                              const int32_t edist, const int32_t edist2) {
@@ -910,15 +967,16 @@ extern "C" int bbduk_table_line_histogram(bbduk_handle* h, int64_t* out33) {
     hipFree(d);
     return e == hipSuccess ? BBDUK_OK : BBDUK_ERR_DEVICE;
 }
-extern "C" int bbduk_table_layout(const bbduk_handle* h) { return (h && h->finalized) ? ((h->seed ? 2 : (h->big ? 1 : 0)) + (h->hasAlt ? 4 : 0)) : -1; }
+extern "C" int bbduk_table_layout(const bbduk_handle* h) { return (h && h->finalized) ? ((h->seed ? 2 : (h->big ? 1 : 0)) + (h->hasAlt ? 4 : 0) + (h->qx ? 8 : 0)) : -1; }
 extern "C" int64_t bbduk_table_spilled(const bbduk_handle* h) { return (h && h->finalized && h->big) ? h->nspilled : 0; }
-extern "C" int64_t bbduk_table_size(const bbduk_handle* h) { return (h && h->finalized) ? ((h->seed && h->nkeysRef > 0) ? h->nkeysRef : h->nkeys) : -1; }
+extern "C" int64_t bbduk_table_size(const bbduk_handle* h) { return (h && h->finalized) ? (h->qx ? h->nkeysQx : ((h->seed && h->nkeysRef > 0) ? h->nkeysRef : h->nkeys)) : -1; }
 extern "C" int64_t bbduk_table_bytes(const bbduk_handle* h) {
     if (!h || !h->finalized) return -1;
     if (h->big) return (int64_t)h->bigLines * (64 + 256 + 32 * h->bigIdBytes) + (int64_t)(h->nbuckets * (8 + 4 * 16)) +
                        (h->hasAlt ? (int64_t)(h->nbucketsAlt * (8 + 4 * 16)) + (h->ldsBitsAlt ? (1LL << (h->ldsBitsAlt - 3)) : 0) : 0);
     return (int64_t)(h->nbuckets * (8 + 4 * 16)) + (h->ldsBits ? (1LL << (h->ldsBits - 3)) : 0) +
-           (h->hasAlt ? (int64_t)(h->nbucketsAlt * (8 + 4 * 16)) + (h->ldsBitsAlt ? (1LL << (h->ldsBitsAlt - 3)) : 0) : 0);      // (a seed-layout map's twin)
+           (h->hasAlt ? (int64_t)(h->nbucketsAlt * (8 + 4 * 16)) + (h->ldsBitsAlt ? (1LL << (h->ldsBitsAlt - 3)) : 0) : 0) +      // (a seed-layout map's twin)
+           (h->qx ? (int64_t)(h->nbucketsQx * (8 + 4 * 16)) : 0);
 }
 
 static KParams make_kparams(const bbduk_handle* h) {
@@ -949,6 +1007,10 @@ static KParams make_kparams(const bbduk_handle* h) {
     K.matchN = nullptr; K.matchIds = nullptr; K.matchCnt = nullptr; K.matchCap = 0;
     K.dbg = h->hookDbg;
     K.ldsImage = h->d_ldsImage; K.ldsBits = h->ldsBits;
+    if (h->qx) {                                                  // the tabulated query expansion: forward keys, no expansion left to do (qx_rewrite)
+        K.qx = 1; K.qxTags = h->d_tagsQx; K.qxBkv = h->d_bkvQx; K.qxBucketMask = (uint32_t)(h->nbucketsQx - 1); K.qxBucketBits = h->bucketBitsQx;
+        K.rcomp = 0; K.qhdist = 0; K.qhdist2 = 0;
+    }
     return K;
 }
 

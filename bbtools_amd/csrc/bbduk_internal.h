@@ -50,6 +50,10 @@ struct KParams {
     uint32_t bigLines;
     int32_t  seed, seedHl, seedHr, seedM;   // the seed layout (bbduk_seed.inc): tags / bkv hold PARENTS under their left (seedHl bases) and right (seedHr) halves
     int32_t  gm, gW, gH, gD;    // gapped minimizer: m bases from each half, W candidates, half length H, right half starts at D = k-H
+    // Query-side Hamming expansion precomputed (round 5; bbduk_hip.hip: qx_rewrite).  qx != 0: tags / bkv above hold the EXPANSION -- every forward k-mer X for
+    // which getValue(X, rc X, qhdist) finds something, keyed as it stands (so the lookups run with rcomp = 0), bkv.z = getValue's answer, bkv.w = the answer
+    // of its neighbour loop alone -- and the map the reference holds sits here, for the windows whose rolling rkmer is not kmer's reverse complement.
+    int32_t  qx; const uint64_t* qxTags; const uint4* qxBkv; uint32_t qxBucketMask; int32_t qxBucketBits;
     int32_t  gV32;              // the line function's variant: 1 = 32-bit values (gap_v32 / gap_line32: maps of up to 2^31 keys), 2 = wide values (gap_v52: beyond), 0 = round 2's 52-bit minima; bbduk_bigs.inc scans 1 and 2
     // presence filter in front of the map: one bit per hash slot, copied into LDS by every workgroup
     const uint32_t* ldsImage;   // HBM copy of the LDS bitmap (2^ldsBits bits); 0 bits = absent
@@ -77,6 +81,8 @@ struct bbduk_handle {
     // big layout (HBM-resident maps): 8 * bigLines tag words, slot-parallel keys / ids; d_tags / d_bkv = the secondary map of the spilled keys
     bool big = false; uint64_t* d_bigTags = nullptr; uint64_t* d_bigKeys = nullptr; void* d_bigIds = nullptr; int bigIdBytes = 0; uint32_t bigLines = 0;
     int gm = 0, gW = 0, gH = 0, gD = 0; int64_t nspilled = 0; int gV32 = 0;
+    // qhdist = 1 handles (round 5): the expansion is the map the kernels look up, the reference's own map is kept beside it (KParams::qx)
+    bool qx = false; uint64_t* d_tagsQx = nullptr; uint4* d_bkvQx = nullptr; uint64_t nbucketsQx = 0; int bucketBitsQx = 0; int64_t nkeysQx = 0;
     bool seed = false; int seedHl = 0, seedHr = 0, seedM = 0;   // seed layout: parents only, under their halves (large hdist=1 maps built on the device)
     double expectShort = 0.0;            // short k-mers of mink the next build will see (they live in the secondary map of a big-layout map)
     bool bigPlain = false;               // lines by a plain key hash instead of the gapped minimizer (gW = 0)

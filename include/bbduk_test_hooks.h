@@ -30,7 +30,7 @@ int  seal_test_hook(struct seal_handle* h, int32_t which, int64_t value);
 int64_t bbduk_table_spilled(const bbduk_handle* h);
 /* big layout: out33[c] = number of 32-slot lines that hold c keys */
 int  bbduk_table_line_histogram(bbduk_handle* h, int64_t* out33);
-/* which layout the finalized map took: 0 cache-resident, 1 big (minimizer or plain lines), 2 seed (parents under their halves); + 4: a cache-resident twin beside it; -1: not finalized */
+/* which layout the finalized map took: 0 cache-resident, 1 big (minimizer or plain lines), 2 seed (parents under their halves); + 4: a cache-resident twin beside it; + 8: the query-side expansion (qhdist = 1) is tabulated (the map the kernels look up is the expansion); -1: not finalized */
 int  bbduk_table_layout(const bbduk_handle* h);
 #ifdef __cplusplus
 }

@@ -1330,3 +1330,62 @@ def test_tail_pass_kmask(ci):
     if len(reads) & 1:
         reads.pop()
     check_kmask(d, o, reads, True); check_kmask(d, o, reads[:301], False)
+
+
+# ---- query-side expansion tabulated at build time (round 5: KParams::qx, qx_rewrite)
+QX = [("ktrim=r k=21 mink=11 hdist=1 qhdist=1", dict(k=21, mink=11, hdist=1, qhdist=1, ktrimRight=1)),
+      ("ktrim=r k=23 mink=9 qhdist=1", dict(k=23, mink=9, qhdist=1, ktrimRight=1)),                         # hdist=0: forbidNs stays on (BBDukParser.java:150), the rolling rkmer restarts at an N
+      ("ktrim=l k=19 mink=8 hdist=1 qhdist=1 tp=1", dict(k=19, mink=8, hdist=1, qhdist=1, ktrimLeft=1, trimPad=1)),
+      ("k=25 mm=f qhdist=1", dict(k=25, maskMiddle=0, qhdist=1)),
+      ("k=24 mm=f hdist=1 qhdist=1 mbk=2 rieb=f", dict(k=24, maskMiddle=0, hdist=1, qhdist=1, maxBadKmers0=2, requireBothBad=1)),
+      ("ktrim=r k=21 mink=11 qhdist2=1", dict(k=21, mink=11, qhdist2=1, ktrimRight=1)),                     # the short k-mers alone are expanded
+      ("ktrim=r k=21 mink=11 qhdist=1 qhdist2=0 restrictright=80", dict(k=21, mink=11, qhdist=1, qhdist2=0, ktrimRight=1, restrictRight=80)),
+      ("ktrim=n k=17 mink=7 qhdist=1 hdist=1", dict(k=17, mink=7, qhdist=1, hdist=1, ktrimN=1)),
+      ("ktrim=rl k=21 mink=10 qhdist=1", dict(k=21, mink=10, qhdist=1, ktrimLeft=1, ktrimRight=1)),
+      ("ksplit=t k=21 mink=10 qhdist=1", dict(k=21, mink=10, qhdist=1, ksplit=1)),
+      ("k=22 mm=f fbm=t qhdist=1", dict(k=22, maskMiddle=0, findBestMatch=1, qhdist=1))]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ci", range(len(QX)))
+def test_query_expansion_tabulated(ci):
+    """qhdist = 1 where the answer depends on kmer alone (no middle mask, rcomp=t, speed=0): bbduk finalizes such a handle by tabulating getValue over every
+    forward k-mer within one substitution of a stored key and the kernels look THAT map up, one lookup per window; a window whose rolling rkmer is
+    not kmer's reverse complement (an undefined base inside: N reads as A in kmer and as 0 in rkmer, and under forbidNs rkmer restarts) takes its direct
+    lookup in the reference's own map.  Reads dense in Ns and junk, pieces with 0-2 substitutions, both builds, every mode; ids (the (j, i) order
+    of the neighbour loop decides which scaffold is credited) and counters included."""
+    args, okw = QX[ci]
+    rng = random.Random(51000 + ci)
+    base = util.rand_seq(rng, 300)
+    refs = [base, util.rand_seq(rng, 200) + base[50:120], util.revcomp(base[150:260]), util.rand_seq(rng, 90, 0.02), util.rand_seq(rng, 14), util.rand_seq(rng, 400)]
+    # two scaffolds one substitution apart: which one a neighbour lookup credits depends on the loop order
+    twin = bytearray(refs[5][100:160]); twin[30] = ord("A") if twin[30] != ord("A") else ord("C"); refs.append(bytes(twin))
+    for build in ("host", "device"):
+        d = B.BBDuk(args, refs=refs, build=build)
+        o = Oracle(**okw)
+        for r in refs: o.add_ref(r)
+        assert d.gpu.table_layout & 8, d.gpu.table_layout
+        assert d.gpu.table_size == o.stored_kmers
+        ks, vs = o.dump_pairs()
+        assert np.array_equal(d.gpu.table_lookup(ks), vs)
+        reads = util.fuzz_reads(rng, refs, 600, [0, 1, 7, 8, 9, 17, 19, 20, 21, 22, 25, 30, 40, 75, 150, 151, 300], junk=True)
+        for i in range(500):
+            n = rng.choice([60, 100, 150, 151])
+            r = bytearray(util.rand_seq(rng, n))
+            src = refs[rng.choice([0, 1, 2, 5, 6])]; cut = rng.randint(8, 50); a = rng.randrange(len(src) - cut); piece = bytearray(src[a:a + cut])
+            if rng.random() < 0.5: piece = bytearray(util.revcomp(bytes(piece)))
+            for _ in range(rng.choice([0, 1, 1, 2, 3])): piece[rng.randrange(len(piece))] = rng.choice(b"ACGTNN.")
+            w = rng.choice([0, n - cut, rng.randrange(n - cut + 1)]); r[w:w + cut] = piece
+            for _ in range(rng.choice([0, 0, 1, 2])): r[rng.randrange(n)] = ord("N")
+            reads.append(bytes(r))
+        if len(reads) % 2: reads.pop()
+        longs = [util.rand_seq(rng, 3000) + refs[0][20:80], util.rand_seq(rng, 150), refs[5][10:70] + util.rand_seq(rng, 45000), util.rand_seq(rng, 100)]
+        if okw.get("ksplit"):
+            check_split(d, o, reads); check_split(d, o, longs)
+        elif okw.get("ktrimN"):
+            check_kmask(d, o, reads, True); check_kmask(d, o, reads[:301], False); check_kmask(d, o, longs, True)
+        elif okw.get("ktrimLeft") and okw.get("ktrimRight"):
+            check_tips(d, o, reads, True); check_tips(d, o, reads[:301], False); check_tips(d, o, longs, True)
+        else:
+            check_batch(d, o, reads, True); check_batch(d, o, reads[:301], False); check_batch(d, o, longs, True)
+        d.close()
