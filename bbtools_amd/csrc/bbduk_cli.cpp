@@ -26,12 +26,19 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 #include <dirent.h>
 #include <execinfo.h>
+#include <fcntl.h>
 #include <signal.h>
+#include <sys/stat.h>
 #include <sys/syscall.h>
 #include <unistd.h>
 #include "../../include/bbduk_gpu.h"
@@ -283,6 +290,260 @@ int run_device_ingest(bbduk_handle* dev, const bbduk_host* host, const StatsOut&
     return write_stats(so, host, c, in1, in2);
 }
 
+// ---- deviceingest=t, pipelined (round 5; one plain input file, no tsv=).  The serial form above reads, copies, runs and writes one chunk after
+// the other, so a run costs the SUM of its stages (profiles/r04_cli_31gb.json: 2.7 s for 31 GB, 8.4 s with out=).  Here each stage has its own
+// thread and the run costs the slowest one:
+//   reader    `rthreads` pread()s per piece of the file into one of NB pinned buffers
+//   uploader  host to device on a stream of its own into one of ND text slots, each with room in front for the tail the piece before left over
+//   main      tail (a device to device copy of a partial record), bbduk_fastq_ingest_device, the packed operator, bbduk_fastq_write_masked_device
+//             into one of NO output slots, device to host queued on that slot's stream
+//   writer    waits for that copy, writes the bytes
+// Pieces are cut at fixed file offsets, so a record (or the second mate of an interleaved pair) can straddle two pieces: what a piece leaves
+// unconsumed is copied in front of the next one on the device, where the text may start at any byte.
+struct Turnstile {                   // a counter that only grows; other threads wait for it to pass a value
+    std::mutex m; std::condition_variable cv; int64_t v = 0; bool dead = false;
+    void set(int64_t x) { { std::lock_guard<std::mutex> g(m); v = x; } cv.notify_all(); }
+    bool wait_above(int64_t x) { std::unique_lock<std::mutex> g(m); cv.wait(g, [&] { return v > x || dead; }); return v > x; }   // false: the run was abandoned
+    void kill() { { std::lock_guard<std::mutex> g(m); dead = true; } cv.notify_all(); }
+};
+struct StageClock {                  // seconds a stage spent working, for timeline=t
+    double busy = 0; std::chrono::steady_clock::time_point t0;
+    void start() { t0 = std::chrono::steady_clock::now(); }
+    void stop() { busy += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+bool pread_all(int fd, uint8_t* dst, int64_t off, int64_t bytes) {
+    while (bytes > 0) { const ssize_t g = pread(fd, dst, (size_t)std::min<int64_t>(bytes, 1LL << 30), (off_t)off); if (g <= 0) return false; dst += g; off += g; bytes -= g; }
+    return true;
+}
+bool pwrite_all(int fd, const uint8_t* src, int64_t off, int64_t bytes) {
+    while (bytes > 0) { const ssize_t g = pwrite(fd, src, (size_t)std::min<int64_t>(bytes, 1LL << 30), (off_t)off); if (g <= 0) return false; src += g; off += g; bytes -= g; }
+    return true;
+}
+// `bytes` at `off`, by `nt` threads over 1 MiB-aligned ranges
+template <class F> bool in_parallel(int64_t bytes, int nt, F&& part) {
+    const int64_t step = std::max<int64_t>(((bytes + nt - 1) / nt + 0xFFFFF) & ~0xFFFFFLL, 1 << 20);
+    std::vector<std::thread> th; std::vector<char> ok((size_t)nt, 1);
+    int used = 0;
+    for (int64_t a = step; a < bytes && used + 1 < nt; a += step) { const int me = ++used; th.emplace_back([&, a, me]() { ok[(size_t)me] = part(a, std::min(step, bytes - a)) ? 1 : 0; }); }
+    ok[0] = part(0, std::min(step, bytes)) ? 1 : 0;
+    for (auto& t : th) t.join();
+    for (char c : ok) if (!c) return false;
+    return true;
+}
+
+// The buffers of a pipelined run.  They depend on chunk= and the device only, so main() allocates them on a thread of their own while the reference is
+// parsed and the k-mer map is built (pinning ~0.6 GB of host memory is ~70 ms of a run that lasts ~1 s).
+struct PipeBufs {
+    static constexpr int NB = 4, ND = 3, NO = 3;
+    int64_t chunk = 0, haveMax = 0, maxReads = 0, capBases = 0, capOut = 0; int device = 0; bool ok = false; double seconds = 0;
+    uint8_t* H[NB] = {}; uint8_t* D[ND] = {}; void* upStream = nullptr;
+    uint8_t* dOut[NO] = {}; uint8_t* hOut[NO] = {}; void* outStream[NO] = {};
+    int64_t* d_lines = nullptr; int64_t* d_off = nullptr; uint32_t* d_codes = nullptr; uint32_t* d_undef = nullptr; int32_t* d_a = nullptr; int32_t* d_id = nullptr; uint8_t* d_fl = nullptr;
+    std::thread worker;
+    void start(int dev, int64_t chunkBytes, bool anyOut) {
+        device = dev; chunk = chunkBytes;
+        haveMax = 2 * chunk;                                      // a tail (< chunk) + a piece
+        maxReads = haveMax / 40 + 16; capBases = haveMax / 2 + 64; capOut = haveMax + 64;
+        worker = std::thread([this, anyOut]() {
+            const double t0 = now_s();
+            void* p = nullptr;
+            auto dmal = [&](int64_t bytes) -> void* { return bbduk_device_malloc(device, bytes, &p) == BBDUK_OK ? p : nullptr; };
+            auto pmal = [&](int64_t bytes) -> void* { return bbduk_pinned_malloc(bytes, &p) == BBDUK_OK ? p : nullptr; };
+            bool good = true;
+            for (int i = 0; i < NB; i++) good = good && (H[i] = (uint8_t*)pmal(chunk + 16));
+            for (int i = 0; i < ND; i++) good = good && (D[i] = (uint8_t*)dmal(haveMax + 64));
+            good = good && bbduk_stream_create(device, &upStream) == BBDUK_OK;
+            if (anyOut) for (int i = 0; i < NO; i++) good = good && (dOut[i] = (uint8_t*)dmal(capOut)) && (hOut[i] = (uint8_t*)pmal(capOut)) && bbduk_stream_create(device, &outStream[i]) == BBDUK_OK;
+            good = good && (d_lines = (int64_t*)dmal((4 * maxReads + 1) * 8)) && (d_off = (int64_t*)dmal((maxReads + 1) * 8)) && (d_codes = (uint32_t*)dmal(capBases / 4 + 64)) &&
+                   (d_undef = (uint32_t*)dmal(capBases / 8 + 64)) && (d_a = (int32_t*)dmal(maxReads * 4)) && (d_id = (int32_t*)dmal(maxReads * 4)) && (d_fl = (uint8_t*)dmal(maxReads));
+            ok = good; seconds = now_s() - t0;
+        });
+    }
+    bool wait() { if (worker.joinable()) worker.join(); return ok; }
+    ~PipeBufs() { wait(); }
+};
+
+int run_device_ingest_piped(bbduk_handle* dev, const bbduk_host* host, const StatsOut& so, const bbduk_params& P, const std::string& in1, bool paired,
+                            const std::string& out, const std::string& outm, PipeBufs& B, bool maskLower, char maskSymbol,
+                            int rthreads, int wthreads, bool timeline, double tProcess) {
+    if (P.mode == BBDUK_MODE_KSPLIT) return fail("deviceingest=t serves ktrim=r|l|rl|n and kfilter, not ksplit", nullptr);
+    const double tBegin = now_s();
+    const int fd = open(in1.c_str(), O_RDONLY);
+    if (fd < 0) return fail("cannot open", in1.c_str());
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) return fail("cannot stat", in1.c_str());
+    const int64_t chunk = B.chunk; const int device = B.device;
+    const int64_t fileBytes = (int64_t)sb.st_size, NP = (fileBytes + chunk - 1) / chunk;
+    const int fdOut[2] = {out.empty() ? -1 : open(out.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644), outm.empty() ? -1 : open(outm.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644)};
+    if ((!out.empty() && fdOut[0] < 0) || (!outm.empty() && fdOut[1] < 0)) return fail("cannot open an output file", nullptr);
+    const double tOpen = now_s();
+    if (!B.wait()) return fail("out of memory (chunk= too large?)", nullptr);
+    constexpr int NB = PipeBufs::NB, ND = PipeBufs::ND, NO = PipeBufs::NO;
+    const int64_t maxReads = B.maxReads, capBases = B.capBases, capOut = B.capOut;
+    uint8_t** H = B.H; uint8_t** D = B.D; void* upStream = B.upStream; uint8_t** dOut = B.dOut; uint8_t** hOut = B.hOut; void** outStream = B.outStream;
+    int64_t* d_lines = B.d_lines; int64_t* d_off = B.d_off; uint32_t* d_codes = B.d_codes; uint32_t* d_undef = B.d_undef; int32_t* d_a = B.d_a; int32_t* d_id = B.d_id; uint8_t* d_fl = B.d_fl;
+    void* p = nullptr;
+    auto dmal = [&](int64_t bytes) -> void* { return bbduk_device_malloc(device, bytes, &p) == BBDUK_OK ? p : nullptr; };
+    int32_t* d_b = P.mode == BBDUK_MODE_KTRIM_TIPS ? (int32_t*)dmal(maxReads * 4) : nullptr;
+    uint32_t* d_mask = P.mode == BBDUK_MODE_KMASK ? (uint32_t*)dmal((capBases / 32 + 4) * 4) : nullptr;
+    const int nctr = bbduk_counters_len(dev);
+    int64_t* d_ctr = (int64_t*)dmal((int64_t)nctr * 8);
+    if (!d_ctr || (P.mode == BBDUK_MODE_KTRIM_TIPS && !d_b) || (P.mode == BBDUK_MODE_KMASK && !d_mask)) return fail("out of memory (chunk= too large?)", nullptr);
+    bbduk_device_memset(device, d_ctr, 0, (int64_t)nctr * 8, nullptr);
+    const double tAlloc = now_s();
+
+    Turnstile filled, hostFreed, uploaded, devFreed, outQueued, outFreed;
+    StageClock cRead, cUp, cTail, cIngest, cOp, cWriteK, cD2H, cWrite, cWaitUp, cWaitOut;
+    std::atomic<const char*> failed{nullptr};                     // set by a stage thread before it kills the turnstiles
+    auto abandon = [&](const char* why) { const char* none = nullptr; failed.compare_exchange_strong(none, why); for (Turnstile* t : {&filled, &hostFreed, &uploaded, &devFreed, &outQueued, &outFreed}) t->kill(); };
+    auto piece_bytes = [&](int64_t q) { return std::min(chunk, fileBytes - q * chunk); };
+
+    std::thread reader([&]() {
+        for (int64_t q = 0; q < NP; q++) {
+            if (q >= NB && !hostFreed.wait_above(q - NB)) return;
+            cRead.start();
+            const int64_t off = q * chunk;
+            const bool ok = in_parallel(piece_bytes(q), rthreads, [&](int64_t a, int64_t n) { return pread_all(fd, H[q % NB] + a, off + a, n); });
+            cRead.stop();
+            if (!ok) { abandon("read error"); return; }
+            filled.set(q + 1);
+        }
+    });
+    std::thread uploader([&]() {
+        for (int64_t q = 0; q < NP; q++) {
+            if (!filled.wait_above(q)) return;
+            if (q >= ND && !devFreed.wait_above(q - ND)) return;
+            cUp.start();
+            const bool ok = bbduk_copy_async(device, D[q % ND] + chunk, H[q % NB], piece_bytes(q), 0, upStream) == BBDUK_OK && bbduk_stream_synchronize(device, upStream) == BBDUK_OK;
+            cUp.stop();
+            if (!ok) { abandon("host to device copy"); return; }
+            hostFreed.set(q + 1); uploaded.set(q + 1);
+        }
+    });
+    struct OutJob { int slot; int64_t bytes; int sel; };
+    std::mutex jobMu; std::deque<OutJob> jobs;
+    int64_t outPos[2] = {0, 0};
+    std::thread writer([&]() {
+        for (int64_t j = 0;; j++) {
+            if (!outQueued.wait_above(j)) return;
+            OutJob job; { std::lock_guard<std::mutex> g(jobMu); job = jobs.front(); jobs.pop_front(); }
+            if (job.slot < 0) return;                             // the end marker
+            cD2H.start();
+            const bool okc = bbduk_stream_synchronize(device, outStream[job.slot]) == BBDUK_OK;
+            cD2H.stop();
+            cWrite.start();
+            const int f = fdOut[job.sel]; const int64_t at = outPos[job.sel];
+            const bool okw = okc && in_parallel(job.bytes, wthreads, [&](int64_t a, int64_t n) { return pwrite_all(f, hOut[job.slot] + a, at + a, n); });
+            cWrite.stop();
+            outPos[job.sel] += job.bytes;
+            if (!okw) { abandon(okc ? "write error" : "device to host copy"); return; }
+            outFreed.set(j + 1);
+        }
+    });
+    auto push_job = [&](const OutJob& j, int64_t seq) { { std::lock_guard<std::mutex> g(jobMu); jobs.push_back(j); } outQueued.set(seq + 1); };
+    int64_t outSeq = 0;
+    auto finish = [&](int rc) {                                   // every exit goes through here: the threads hold references to this frame
+        if (rc != 0) abandon("stopped");
+        else push_job(OutJob{-1, 0, 0}, outSeq);
+        reader.join(); uploader.join(); writer.join();
+        close(fd); for (int f : fdOut) if (f >= 0) close(f);
+        return rc;
+    };
+
+    const bool kfilter = P.mode == BBDUK_MODE_KFILTER;
+    long long nread = 0; int64_t tailLen = 0; const uint8_t* tailPtr = nullptr; int rounds = 0;
+    for (int64_t q = 0; q < NP; q++) {
+        cWaitUp.start();
+        const bool okq = uploaded.wait_above(q);
+        cWaitUp.stop();
+        if (!okq) return finish(fail(failed.load() ? failed.load() : "pipeline stopped", nullptr));
+        uint8_t* text = D[q % ND] + chunk - tailLen;
+        cTail.start();
+        if (tailLen > 0 && (bbduk_copy_async(device, text, tailPtr, tailLen, 2, nullptr) != BBDUK_OK || bbduk_stream_synchronize(device, nullptr) != BBDUK_OK)) return finish(fail("device to device copy", nullptr));
+        cTail.stop();
+        devFreed.set(q);                                          // the slots of the pieces before this one can be overwritten
+        int64_t have = tailLen + piece_bytes(q);
+        const bool fin = q == NP - 1;
+        for (bool again = true; again;) {
+            rounds++;
+            bbduk_fastq_result R;
+            cIngest.start();
+            const int rc = bbduk_fastq_ingest_device(text, have, nullptr, 0, fin ? 1 : 0, maxReads, capBases, d_lines, nullptr, d_off, d_codes, d_undef, device, nullptr, &R);
+            cIngest.stop();
+            if (rc == BBDUK_ERR_FORMAT) { char m[64]; snprintf(m, sizeof m, "read %lld", nread + (long long)R.first_bad_read); return finish(fail("malformed FASTQ record at", m)); }
+            if (rc != BBDUK_OK) return finish(fail("bbduk_fastq_ingest_device", nullptr));
+            int64_t n = R.n_reads;
+            const bool full = n >= maxReads;                      // the record limit, not the end of the text, ended this round
+            if (paired && (n & 1)) {                              // a pair stays together; its second record comes with the next piece
+                if (fin && !full) return finish(fail("unpaired or malformed mate at the end of", in1.c_str()));
+                n--;
+                if (bbduk_copy_from_device(device, &R.consumed1, d_lines + 4 * n, 8, nullptr) != BBDUK_OK) return finish(fail("device to host copy", nullptr));
+            }
+            if (n == 0) {
+                if (fin) { if (have > 0) return finish(fail("truncated FASTQ record at the end of", in1.c_str())); break; }
+                if (have >= chunk) return finish(fail("a FASTQ record exceeds chunk=", nullptr));
+                break;
+            }
+            const int64_t total = [&]() { int64_t v = 0; bbduk_copy_from_device(device, &v, d_off + n, 8, nullptr); return v; }();
+            cOp.start();
+            const int orc = kfilter ? bbduk_kfilter_batch_packed_device(dev, d_codes, d_undef, d_off, n, total, paired ? 1 : 0, d_a, d_id, d_fl, d_ctr, nullptr)
+                          : P.mode == BBDUK_MODE_KTRIM_TIPS ? bbduk_ktrimtips_batch_packed_device(dev, d_codes, d_undef, d_off, n, total, paired ? 1 : 0, d_a, d_b, d_id, d_fl, d_ctr, nullptr)
+                          : P.mode == BBDUK_MODE_KMASK ? bbduk_kmask_batch_packed_device(dev, d_codes, d_undef, d_off, n, total, paired ? 1 : 0, d_a, d_id, d_fl, d_mask, d_ctr, nullptr)
+                          : bbduk_ktrim_batch_packed_device(dev, d_codes, d_undef, d_off, n, total, paired ? 1 : 0, d_a, d_id, d_fl, d_ctr, nullptr);
+            if (orc == BBDUK_OK && timeline) bbduk_stream_synchronize(device, nullptr);        // so that the operator's time is its own in the table
+            cOp.stop();
+            if (orc != BBDUK_OK) return finish(fail("batch operator", bbduk_last_error(dev)));
+            const int32_t* dl = P.mode == BBDUK_MODE_KTRIM_L ? d_a : (P.mode == BBDUK_MODE_KTRIM_TIPS ? d_b : nullptr);
+            const int32_t* dr = (P.mode == BBDUK_MODE_KTRIM_R || P.mode == BBDUK_MODE_KTRIM_TIPS) ? d_a : nullptr;
+            for (int sel = 0; sel < 2; sel++) {
+                if (fdOut[sel] < 0) continue;
+                const int slot = (int)(outSeq % NO);
+                cWaitOut.start();
+                const bool oko = outSeq < NO || outFreed.wait_above(outSeq - NO);
+                cWaitOut.stop();
+                if (!oko) return finish(fail(failed.load() ? failed.load() : "pipeline stopped", nullptr));
+                int64_t nb = 0;
+                cWriteK.start();
+                const int wrc = bbduk_fastq_write_masked_device(text, d_lines, nullptr, nullptr, n, dl, dr, d_fl, sel, d_mask ? d_off : nullptr, d_mask,
+                                                                maskLower ? -1 : (int)(unsigned char)maskSymbol, dOut[slot], capOut, device, nullptr, &nb);
+                cWriteK.stop();
+                if (wrc != BBDUK_OK) return finish(fail("bbduk_fastq_write_device", nullptr));
+                if (bbduk_copy_async(device, hOut[slot], dOut[slot], nb, 1, outStream[slot]) != BBDUK_OK) return finish(fail("device to host copy", nullptr));
+                push_job(OutJob{slot, nb, sel}, outSeq); outSeq++;
+            }
+            nread += n;
+            text += R.consumed1; have -= R.consumed1;
+            again = have > 0 && (full || fin);
+        }
+        if (have > chunk) return finish(fail("a FASTQ record exceeds chunk=", nullptr));
+        tailLen = have; tailPtr = text;
+    }
+    const double tLoop = now_s();
+    if (finish(0) != 0) return 1;
+    if (failed.load()) return fail(failed.load(), nullptr);
+    const double tEnd = now_s();
+    std::vector<int64_t> c((size_t)nctr);
+    bbduk_copy_from_device(device, c.data(), d_ctr, (int64_t)nctr * 8, nullptr);
+    fprintf(stderr, "Input:                  \t%lld reads \t\t%lld bases.\n", (long long)c[BBDUK_READS_IN], (long long)c[BBDUK_BASES_IN]);
+    if (d_mask) fprintf(stderr, "KMasked:                \t%lld reads \t%lld bases\n", (long long)c[BBDUK_READS_KTRIMMED], (long long)c[BBDUK_BASES_KTRIMMED]);
+    else if (!kfilter) fprintf(stderr, "KTrimmed:               \t%lld reads \t%lld bases\n", (long long)c[BBDUK_READS_KTRIMMED], (long long)c[BBDUK_BASES_KTRIMMED]);
+    else fprintf(stderr, "Contaminants:           \t%lld reads \t%lld bases\n", (long long)c[BBDUK_READS_KFILTERED], (long long)c[BBDUK_BASES_KFILTERED]);
+    fprintf(stderr, "Total Removed:          \t%lld reads \t%lld bases\n", (long long)(c[BBDUK_READS_IN] - c[BBDUK_READS_OUTU]), (long long)(c[BBDUK_BASES_IN] - c[BBDUK_BASES_OUTU]));
+    fprintf(stderr, "Result:                 \t%lld reads \t%lld bases\n", (long long)c[BBDUK_READS_OUTU], (long long)c[BBDUK_BASES_OUTU]);
+    if (timeline) {                                               // one JSON line: where the wall clock went (seconds; stages on different threads overlap)
+        fprintf(stderr, "{\"timeline\": {\"file_bytes\": %lld, \"pieces\": %lld, \"rounds\": %d, \"chunk\": %lld, \"rthreads\": %d, \"wthreads\": %d, "
+                        "\"startup_to_pipeline\": %.3f, \"open_files\": %.3f, \"wait_buffers\": %.3f, \"buffers_alloc_thread\": %.3f, \"pipeline_wall\": %.3f, \"drain\": %.3f, "
+                        "\"reader_pread\": %.3f, \"uploader_h2d\": %.3f, \"main_wait_upload\": %.3f, \"main_tail_copy\": %.3f, \"main_ingest\": %.3f, \"main_operator\": %.3f, "
+                        "\"main_write_kernels\": %.3f, \"main_wait_out_slot\": %.3f, \"writer_wait_d2h\": %.3f, \"writer_pwrite\": %.3f, \"out_bytes\": %lld}}\n",
+                (long long)fileBytes, (long long)NP, rounds, (long long)chunk, rthreads, wthreads, tBegin - tProcess, tOpen - tBegin, tAlloc - tOpen, B.seconds, tLoop - tAlloc, tEnd - tLoop,
+                cRead.busy, cUp.busy, cWaitUp.busy, cTail.busy, cIngest.busy, cOp.busy, cWriteK.busy, cWaitOut.busy, cD2H.busy, cWrite.busy, (long long)(outPos[0] + outPos[1]));
+    }
+    if (c[BBDUK_CTR_STATUS]) return fail("device reported an error status", nullptr);
+    return write_stats(so, host, c, in1, "");
+}
+
 }  // namespace
 
 // watchdog=SECONDS (diagnostics; round 5: the intermittent stall of devices=0,0,0 runs had never been looked at from the inside, the images carry no
@@ -328,7 +589,9 @@ int main(int argc, char** argv) {
     bool maskLower = false; char maskSymbol = 'N';
     bool rename = false;                                          // rename=t: matched reads get "\tscaffold=hits" appended (BBDukProcessorS.java:2508-2522)
     StatsOut so;
-    bool deviceIngest = false; long long chunk = 256LL << 20;     // deviceingest=t: FASTQ text to the GPU, chunk= bytes per file and round
+    bool deviceIngest = false; long long chunk = 0;               // deviceingest=t: FASTQ text to the GPU, chunk= bytes per file and round (default 256 MiB; pipelined: 64 MiB)
+    bool pipeline = true, timeline = false; int rthreads = 8, wthreads = 1;      // pipeline=f: the serial form; timeline=t: one JSON line of stage times on stderr
+    const double tProcess = now_s();
     bool deviceBuild = false;        // devicebuild=t: the GPU builds the k-mer map from the reference sequences (bbduk_build_table_device)
     for (int i = 1; i < argc; i++) {
         const std::string tok = argv[i];
@@ -347,6 +610,10 @@ int main(int argc, char** argv) {
         else if (a == "devicebuild") deviceBuild = parse_bool(b);
         else if (a == "deviceingest") deviceIngest = parse_bool(b);
         else if (a == "chunk") chunk = atoll(b.c_str());
+        else if (a == "pipeline") pipeline = parse_bool(b);
+        else if (a == "timeline") timeline = parse_bool(b);
+        else if (a == "readthreads") rthreads = std::max(1, atoi(b.c_str()));
+        else if (a == "writethreads") wthreads = std::max(1, atoi(b.c_str()));
         else if (a == "watchdog") { if (atoi(b.c_str()) > 0) wd_start(atoi(b.c_str())); }
         else if (a == "stats" || a == "scafstats") so.stats = b;     // BBDukParser.java:486-494, 689-693
         else if (a == "rpkm" || a == "fpkm" || a == "cov" || a == "coverage") so.rpkm = b;
@@ -370,6 +637,13 @@ int main(int argc, char** argv) {
     }
     if (batch < 2) batch = 2;
     const bool paired = interleaved || !in2.empty();
+    if (devices.empty()) devices.push_back(device);
+    device = devices[0];
+    const bool piped = deviceIngest && pipeline && in2.empty() && tsv.empty() && !(in1.size() > 3 && in1.compare(in1.size() - 3, 3, ".gz") == 0);
+    if (chunk == 0) chunk = piped ? (64LL << 20) : (256LL << 20);
+    if (chunk < 4096) chunk = 4096;
+    PipeBufs pipeBufs;
+    if (piped) pipeBufs.start(device, (int64_t)chunk, !out.empty() || !outm.empty());      // (allocated while the map is built)
 
     char err[512] = {0};
     bbduk_host* host = nullptr;
@@ -377,8 +651,6 @@ int main(int argc, char** argv) {
     if (bbduk_host_load_refs(host, resources.c_str()) < 0) return fail("cannot load ref=", resources.c_str());
     int64_t stored = 0;
     if (!deviceBuild) { stored = bbduk_host_build_index(host); if (stored < 0) return fail("index build failed", nullptr); }
-    if (devices.empty()) devices.push_back(device);
-    device = devices[0];
     { bool several = false; for (int d : devices) several = several || d != devices[0]; if (several) bbduk_comm_preload(); }     // (the collective library loads while the map is built)
     bbduk_params P;
     if (bbduk_host_params(host, device, &P) != BBDUK_OK) return fail("unsupported parameter combination", nullptr);
@@ -401,8 +673,9 @@ int main(int argc, char** argv) {
         if (rename && P.findBestMatch) return fail("deviceingest=t does not rewrite read names: use rename=t without it", nullptr);
         if (ndev > 1) return fail("deviceingest=t drives one device: use device=", nullptr);
         if (P.trimFailuresTo1bp) return fail("deviceingest=t does not cut discarded reads to one base: use trimfailuresto1bp without it", nullptr);
-        if (chunk < 4096) chunk = 4096;
-        const int rc = run_device_ingest(dev, host, so, P, in1, in2, paired, out, outm, tsv, (int64_t)chunk, device, maskLower, maskSymbol);
+        const int rc = piped ? run_device_ingest_piped(dev, host, so, P, in1, paired, out, outm, pipeBufs, maskLower, maskSymbol, rthreads, wthreads, timeline, tProcess)
+                             : run_device_ingest(dev, host, so, P, in1, in2, paired, out, outm, tsv, (int64_t)chunk, device, maskLower, maskSymbol);
+        if (piped) { pipeBufs.wait(); fflush(stdout); fflush(stderr); g_wd_done = 1; _exit(rc); }   // every file is closed; the buffers go with the process (tearing the runtime down in order costs ~0.1 s of a ~1 s run)
         if (rc == 0) { for (bbduk_handle* hq : devs) bbduk_destroy(hq); bbduk_host_destroy(host); }
         return rc;
     }

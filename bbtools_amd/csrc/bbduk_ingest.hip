@@ -74,13 +74,13 @@ __device__ __forceinline__ void encode16(const U128 v, uint32_t& code, uint32_t&
     }
 }
 
-// 64 bytes of text starting at byte `a` (a multiple of 16; the buffer is 16-byte aligned), zero past nbytes
+// 64 bytes of text starting at byte `a`, zero past nbytes
 __device__ __forceinline__ void load64(const uint8_t* __restrict__ text, const int64_t a, const int64_t nbytes, uint32_t* w) {
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int64_t p = a + 16 * q;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (p + 16 <= nbytes) v = *reinterpret_cast<const uint4*>(text + p);
+        if (p + 16 <= nbytes) __builtin_memcpy(&v, text + p, 16);   // the text may start at any byte (a chunk's carried-over tail)
         else if (p < nbytes) {
             uint32_t t[4] = {0, 0, 0, 0};
             for (int b = 0; b < 16 && p + b < nbytes; b++) t[b >> 2] |= (uint32_t)text[p + b] << (8 * (b & 3));
@@ -449,7 +449,7 @@ extern "C" int bbduk_fastq_ingest_device(const uint8_t* d_text1, int64_t nbytes1
     out->n_reads = 0; out->total_bases = 0; out->consumed1 = 0; out->consumed2 = 0; out->first_bad_read = -1;
     const int ns = d_text2 ? 2 : 1;
     if ((!d_text1 && nbytes1 > 0) || (d_text2 == nullptr && nbytes2 > 0) || nbytes1 < 0 || nbytes2 < 0 || max_reads < 0 || max_bases < 0 || !d_lines1 || (ns == 2 && !d_lines2) || !d_offsets || !d_codes || !d_undef) return BBDUK_ERR_ARG;
-    if (((uintptr_t)d_text1 & 15) || ((uintptr_t)d_text2 & 15) || ((uintptr_t)d_codes & 15) || ((uintptr_t)d_undef & 3)) return BBDUK_ERR_ARG;
+    if (((uintptr_t)d_codes & 15) || ((uintptr_t)d_undef & 3)) return BBDUK_ERR_ARG;
     if (ns == 2 && (max_reads & 1)) max_reads--;
     if (hipSetDevice(device) != hipSuccess) return BBDUK_ERR_DEVICE;
     hipStream_t st = (hipStream_t)stream;
@@ -616,6 +616,33 @@ extern "C" int bbduk_copy_from_device(int32_t device, void* dst, const void* d_s
     if (hipSetDevice(device) != hipSuccess) return BBDUK_ERR_DEVICE;
     if (hipMemcpyAsync(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return BBDUK_ERR_DEVICE;
     return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? BBDUK_OK : BBDUK_ERR_DEVICE;
+}
+// The asynchronous forms (round 5, the pipelined deviceingest=t path of bbduk_cli): a stream of the caller's own that does not synchronise with
+// the default stream, copies that return at once, and the wait.
+extern "C" int bbduk_stream_create(int32_t device, void** out) {
+    if (!out) return BBDUK_ERR_ARG;
+    *out = nullptr;
+    if (hipSetDevice(device) != hipSuccess) return BBDUK_ERR_DEVICE;
+    hipStream_t st;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return BBDUK_ERR_DEVICE;
+    *out = (void*)st;
+    return BBDUK_OK;
+}
+extern "C" int bbduk_stream_destroy(int32_t device, void* stream) {
+    if (!stream) return BBDUK_OK;
+    if (hipSetDevice(device) != hipSuccess) return BBDUK_ERR_DEVICE;
+    return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? BBDUK_OK : BBDUK_ERR_DEVICE;
+}
+extern "C" int bbduk_stream_synchronize(int32_t device, void* stream) {
+    if (hipSetDevice(device) != hipSuccess) return BBDUK_ERR_DEVICE;
+    return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? BBDUK_OK : BBDUK_ERR_DEVICE;
+}
+extern "C" int bbduk_copy_async(int32_t device, void* dst, const void* src, int64_t bytes, int32_t kind, void* stream) {
+    if (bytes < 0 || (bytes > 0 && (!dst || !src)) || kind < 0 || kind > 2) return BBDUK_ERR_ARG;
+    if (bytes == 0) return BBDUK_OK;
+    if (hipSetDevice(device) != hipSuccess) return BBDUK_ERR_DEVICE;
+    const hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    return hipMemcpyAsync(dst, src, (size_t)bytes, k, (hipStream_t)stream) == hipSuccess ? BBDUK_OK : BBDUK_ERR_DEVICE;
 }
 extern "C" int bbduk_device_memset(int32_t device, void* d_dst, int32_t value, int64_t bytes, void* stream) {
     if (bytes < 0 || (bytes > 0 && !d_dst)) return BBDUK_ERR_ARG;

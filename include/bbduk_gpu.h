@@ -236,12 +236,18 @@ int  bbduk_pinned_free(void* p);
 int  bbduk_copy_to_device(int32_t device, void* d_dst, const void* src, int64_t bytes, void* stream);     /* returns after the copy */
 int  bbduk_copy_from_device(int32_t device, void* dst, const void* d_src, int64_t bytes, void* stream);
 int  bbduk_device_memset(int32_t device, void* d_dst, int32_t value, int64_t bytes, void* stream);
+/* asynchronous forms: a stream that does not synchronise with the default stream (hipStreamNonBlocking); bbduk_copy_async returns once the copy is
+ * queued (kind 0 host to device, 1 device to host, 2 device to device; host memory from bbduk_pinned_malloc), bbduk_stream_synchronize waits. */
+int  bbduk_stream_create(int32_t device, void** out);
+int  bbduk_stream_destroy(int32_t device, void* stream);
+int  bbduk_stream_synchronize(int32_t device, void* stream);
+int  bbduk_copy_async(int32_t device, void* dst, const void* src, int64_t bytes, int32_t kind, void* stream);
 
 /* ---- device-side FASTQ ingest: raw FASTQ text in HBM -> line offsets, base offsets and the packed
  * boundary format, without the host looking at a base.  Restates the record splitting of stream/FASTQ.java:778-853
  * (toReadList: every four lines that fileIO/ByteFile.nextLine returns -- a line ends at '\n', one preceding '\r' is
  * dropped -- are one read: '@' header, bases, '+' line, qualities; the '@' and '+' are asserted at :1047-1049).
- *   d_text1 (, d_text2)  16-byte aligned text; with two texts read 2i comes from record i of text 1 and read 2i+1 from
+ *   d_text1 (, d_text2)  the text (any alignment); with two texts read 2i comes from record i of text 1 and read 2i+1 from
  *                        record i of text 2 (the two-file pairing of the reference's input stream); one interleaved text
  *                        gives the same layout by itself
  *   is_final             nonzero: an unterminated last line counts as a line (end of file); zero: the text is a chunk, the

@@ -1,6 +1,6 @@
 """bbduk_cli: the non-JVM caller of SURVEY 8(b), pinned by fixture FASTQs and the spec's per-read TSV
 (tests/golden/cli_*.{fq,tsv}, written by tests/golden/make_golden.py from oracle/spec.py)."""
-import os
+import json, os
 import subprocess
 
 import pytest
@@ -149,6 +149,51 @@ def test_cli_deviceingest_kmask_and_tips(tmp_path, chunk):
     r = run_cli(["in=" + f1, "in2=" + f2, "tsv=" + str(tmp_path / "k.tsv"), "out=" + str(tmp_path / "k.fq"), "ktrim=n", "k=23", "mink=11", "hdist=1", "ref=adapters", "deviceingest=t", "chunk=" + chunk])
     assert r.returncode == 0 and open(str(tmp_path / "k.fq")).read() == open(os.path.join(GOLD, "cli_kmask_expected.fq")).read()
     assert open(str(tmp_path / "k.tsv")).read() == open(os.path.join(GOLD, "cli_kmask.tsv")).read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", ["4096", "5001", "20000", "3000000", ""])
+def test_cli_deviceingest_pipelined(tmp_path, chunk):
+    """One plain input file and no tsv=: the pipelined form (reader threads, uploads, operator and writer overlapped; pieces cut at fixed file
+    offsets, tails carried on the device).  Its out= / outm= bytes and counter lines equal the serial form's (pipeline=f) and the host parser's,
+    for piece sizes that cut records and pairs anywhere, and for a file of several pieces read by several threads each."""
+    big = tmp_path / "big.fq"
+    one = open(os.path.join(GOLD, "cli_c3_interleaved.fq"), "rb").read() + open(os.path.join(GOLD, "cli_c2_r1.fq"), "rb").read() + open(os.path.join(GOLD, "cli_c2_r2.fq"), "rb").read()
+    big.write_bytes(one * (1 + 12_000_000 // len(one) if chunk in ("3000000", "") else 1))
+    ck = ["chunk=" + chunk] if chunk else []
+    for flags in (["ktrim=r", "k=23", "mink=11", "hdist=1", "ref=adapters", "int=t"], ["k=31", "hdist=1", "ref=phix", "int=t"], ["ktrim=n", "k=23", "mink=11", "hdist=1", "ref=adapters"],
+                  ["ktrim=rl", "k=23", "mink=11", "hdist=1", "ref=adapters", "int=t", "tpe"], ["ktrim=l", "k=23", "mink=11", "ref=adapters", "readthreads=3", "writethreads=2"]):
+        got = {}
+        for mode, extra in (("host", []), ("serial", ["deviceingest=t", "pipeline=f"] + ck), ("piped", ["deviceingest=t", "timeline=t"] + ck)):
+            if mode == "host" and len(one) * 2 < os.path.getsize(big) and flags[0] != "ktrim=r":
+                continue                                          # (the host parser on the 12 MB file: once is enough)
+            out, outm = (str(tmp_path / (mode + n)) for n in ("o.fq", "m.fq"))
+            r = run_cli(["in=" + str(big), "out=" + out, "outm=" + outm] + flags + extra)
+            assert r.returncode == 0, (flags, mode, r.stderr)
+            got[mode] = (open(out, "rb").read(), open(outm, "rb").read(), [l for l in r.stderr.splitlines() if "reads" in l and not l.startswith("{")])
+            if mode == "piped":
+                tl = json.loads([l for l in r.stderr.splitlines() if l.startswith('{"timeline"')][0])["timeline"]
+                assert tl["file_bytes"] == os.path.getsize(big) and tl["out_bytes"] == len(got[mode][0]) + len(got[mode][1])
+                assert tl["pieces"] == -(-tl["file_bytes"] // tl["chunk"])
+        assert got["piped"] == got["serial"], (flags, chunk)
+        if "host" in got:
+            assert got["piped"] == got["host"], (flags, chunk)
+        assert len(got["piped"][0]) > 1000
+    # what the serial form refuses, with the same words
+    cut = tmp_path / "cut.fq"
+    cut.write_bytes(one[:len(one) // 2 - 7])
+    for extra in (["pipeline=f"], []):
+        r = run_cli(["in=" + str(cut), "k=23", "ref=adapters", "deviceingest=t"] + ck + extra)
+        assert r.returncode == 1 and ("truncated FASTQ record" in r.stderr or "malformed FASTQ record" in r.stderr), r.stderr
+    odd = tmp_path / "odd.fq"
+    odd.write_bytes(b"".join(b"@r%d\nACGTACGTACGTACGTACGTACGTACGTAC\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIIIII\n" % i for i in range(301)))
+    for extra in (["pipeline=f"], []):
+        r = run_cli(["in=" + str(odd), "int=t", "k=23", "ref=adapters", "deviceingest=t"] + ck + extra)
+        assert r.returncode == 1 and "unpaired" in r.stderr, r.stderr
+    empty = tmp_path / "empty.fq"
+    empty.write_bytes(b"")
+    r = run_cli(["in=" + str(empty), "k=23", "ref=adapters", "deviceingest=t", "out=" + str(tmp_path / "e.fq")] + ck)
+    assert r.returncode == 0 and os.path.getsize(tmp_path / "e.fq") == 0 and "Input:" in r.stderr
 
 
 @pytest.mark.gpu
