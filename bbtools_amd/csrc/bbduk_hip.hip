@@ -1377,7 +1377,7 @@ static int host_batch(bbduk_handle* h, int wantKfilter, const uint8_t* bases, co
         int64_t z = 0;
         hipMemcpyAsync(S->d_status, &z, sizeof z, hipMemcpyHostToDevice, st);
         hipStreamSynchronize(st);
-        return fail(h, -(int)status, "device reported an error (a read longer than BBDUK_MAX_READ_LEN, or trimfailuresto1bp on a unit beyond the main kernel's planes)");
+        return fail(h, -(int)status, "device reported an error (a read longer than BBDUK_MAX_READ_LEN)");
     }
     return BBDUK_OK;
 }
@@ -1507,7 +1507,7 @@ extern "C" int bbduk_ktrimtips_batch(bbduk_handle* h, const uint8_t* bases, cons
     if (status != 0) {
         int64_t z = 0;
         hipMemcpy(h->d_counters + BBDUK_CTR_STATUS, &z, sizeof z, hipMemcpyHostToDevice);
-        return fail(h, -(int)status, "device reported an error (a read longer than BBDUK_MAX_READ_LEN, or trimfailuresto1bp on a unit beyond the main kernel's planes)");
+        return fail(h, -(int)status, "device reported an error (a read longer than BBDUK_MAX_READ_LEN)");
     }
     return BBDUK_OK;
 }
@@ -1679,7 +1679,7 @@ extern "C" int bbduk_kmask_batch(bbduk_handle* h, const uint8_t* bases, const in
     if (status != 0) {
         int64_t z = 0;
         hipMemcpy(h->d_counters + BBDUK_CTR_STATUS, &z, sizeof z, hipMemcpyHostToDevice);
-        return fail(h, -(int)status, "device reported an error (a read longer than BBDUK_MAX_READ_LEN, or trimfailuresto1bp on a unit beyond the main kernel's planes)");
+        return fail(h, -(int)status, "device reported an error (a read longer than BBDUK_MAX_READ_LEN)");
     }
     return BBDUK_OK;
 }

@@ -47,8 +47,8 @@ extern "C" {
 #define BBDUK_ERR_DEVICE        -4   /* a HIP call failed; see bbduk_last_error           */
 #define BBDUK_ERR_READ_TOO_LONG -5   /* a read exceeds BBDUK_MAX_READ_LEN                  */
 #define BBDUK_ERR_ID_OVERFLOW   -6   /* findBestMatch: a read hit more than 64 distinct scaffolds */
-#define BBDUK_ERR_UNSUPPORTED   -8   /* trimfailuresto1bp with ktrim=n / ktrim=rl / ksplit / findbestmatch / k>31 on a batch that holds a unit beyond the
-                                         main kernel's planes (2512 bases per pair); ktrim=r|l and kfilter serve it at any length */
+#define BBDUK_ERR_UNSUPPORTED   -8   /* (rounds 3-4: trimfailuresto1bp on units beyond 2512 bases outside ktrim=r|l / kfilter; every operator serves it at
+                                         any length since round 5 -- the code stays reserved) */
 #define BBDUK_ERR_FORMAT        -7   /* FASTQ ingest: a record without '@' / '+' or with unequal base and quality lines */
 
 #define BBDUK_MAX_READ_LEN   16384   /* reads up to this length go through the LDS-tiled kernels; longer ones (any length that
@@ -109,9 +109,8 @@ typedef struct bbduk_params {
     int32_t trimFailuresTo1bp;      /* trimfailures / trimfailuresto1bp (BBDukParser.java:105-109, 774; BBDukProcessorS.java:1431, 1464-1488): a read that
                                        would be discarded is cut to its FIRST base instead, "discarded" then means "one base long", pairs are
                                        removed only when both mates are, and nothing is evicted: BBDUK_FLAG_DISCARDED marks the reads to cut
-                                       (after the k-trim the operator reports), BBDUK_FLAG_REMOVED is never set, readsOutm stays 0.  ktrim=r|l
-                                       and kfilter serve it at any read length; the other operators on units <= 2512 bases, else
-                                       BBDUK_ERR_UNSUPPORTED */
+                                       (after the k-trim the operator reports), BBDUK_FLAG_REMOVED is never set, readsOutm stays 0.  Every operator
+                                       serves it at any read length */
     int32_t reserved0;              /* 0 */
 } bbduk_params;
 

@@ -1115,18 +1115,47 @@ def test_trimfailuresto1bp_units_beyond_the_main_kernel(args, okw):
     d.close()
 
 
+TF_LONG = [("n", "k=21 ktrim=n trimfailures=t minlen=100 hdist=1", dict(k=21, ktrimN=1, trimFailuresTo1bp=1, minReadLength=100, hdist=1)),
+           ("n", "k=23 ktrim=n mink=11 trimfailures=t minlen=2000 mlf=0.5", dict(k=23, ktrimN=1, mink=11, trimFailuresTo1bp=1, minReadLength=2000, minLenFraction=0.5)),
+           ("rl", "k=21 ktrim=rl mink=9 trimfailures=t minlen=100 tpe hdist=1", dict(k=21, ktrimRight=1, ktrimLeft=1, mink=9, trimFailuresTo1bp=1, minReadLength=100, trimPairsEvenly=1, hdist=1)),
+           ("rl", "k=25 ktrim=rl trimfailures=t minlen=4000", dict(k=25, ktrimRight=1, ktrimLeft=1, trimFailuresTo1bp=1, minReadLength=4000)),
+           ("ksplit", "k=23 ksplit=t mink=11 trimfailures=t minlen=50 hdist=1", dict(k=23, ksplit=1, mink=11, trimFailuresTo1bp=1, minReadLength=50, hdist=1)),
+           ("f", "k=25 fbm=t trimfailures=t hdist=1", dict(k=25, findBestMatch=1, trimFailuresTo1bp=1, hdist=1)),
+           ("f", "k=40 trimfailures=t", dict(k=31, kbig=40, trimFailuresTo1bp=1)),
+           ("f", "k=36 trimfailures=t mbk=2 hdist=1", dict(k=31, kbig=36, trimFailuresTo1bp=1, maxBadKmers0=2, hdist=1))]
+
+
 @pytest.mark.gpu
-def test_trimfailuresto1bp_other_modes_refuse_units_beyond_the_main_kernel():
-    """ktrim=n / ktrim=rl / ksplit / findbestmatch / k>31 serve trimfailuresto1bp on the main kernel only: a longer unit is reported, not answered wrongly."""
-    rng = random.Random(5)
-    refs = [util.rand_seq(rng, 60)]
-    d = B.BBDuk("k=21 ktrim=n trimfailures=t", refs=refs)
-    reads = [util.rand_seq(rng, 150), util.rand_seq(rng, 150), util.rand_seq(rng, 3000), util.rand_seq(rng, 100)]
-    b, off = pack_reads(reads)
-    with pytest.raises(B.BBDukError, match="trimfailuresto1bp"):
-        d.gpu.kmask_batch(b, off, True)
-    b, off = pack_reads(reads[:2])
-    d.gpu.kmask_batch(b, off, True)                                # the handle stays usable
+@pytest.mark.parametrize("ci", range(len(TF_LONG)))
+def test_trimfailuresto1bp_other_modes_units_beyond_the_main_kernel(ci):
+    """ktrim=n / ktrim=rl / ksplit / findbestmatch / k>31 with trimfailuresto1bp on units the wave kernel cannot hold (round 5; rounds 3-4 refused
+    them): a 5 kb pair sends the batch to the tiled kernels, a 45 kb read to the long-unit kernels; their record stages cut a failed read to its first
+    base and evict nothing, as BBDukProcessorS.java:1431, 1464-1488 do."""
+    fam, args, okw = TF_LONG[ci]
+    rng = random.Random(99 + ci)
+    refs = [util.rand_seq(rng, 70) for _ in range(3)]
+    d, o = make_pair(args, okw, refs=refs)
+    def planted(n, where):
+        r = bytearray(util.rand_seq(rng, n)); piece = refs[rng.randrange(3)][5:50]
+        if where >= 0: r[where:where + len(piece)] = piece
+        return bytes(r)
+    ncut = 0
+    for big in (5000, 45000):
+        reads = []
+        for i in range(60):
+            n = big if i in (6, 7, 20, 33) else rng.choice([1, 30, 150, 151, 400])
+            reads.append(planted(n, rng.choice([-1, 0, 20, n // 2, max(0, n - 50)])))
+        for paired, sub in ((True, reads), (False, reads[:31])):
+            if fam == "n": check_kmask(d, o, sub, paired)
+            elif fam == "rl": check_tips(d, o, sub, paired)
+            elif fam == "ksplit":
+                if paired: continue
+                gf = check_split(d, o, sub); assert not (gf & B.FLAG_REMOVED).any()
+            else: check_batch(d, o, sub, paired)
+            c = d.gpu.counters()
+            assert c[8] == 0 and c[9] == 0 and c[6] == c[0], (args, c[:10])         # nothing leaves through outm (:1431)
+            ncut += int(c[1] - c[7])
+    assert ncut > 0 or fam == "ksplit"
     d.close()
 
 
