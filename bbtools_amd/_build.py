@@ -6,7 +6,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # bbduk_hip.hip = host code + the secondary kernels; bbduk_k_*.hip / bbduk_stream.hip = one kernel family each (they compile in parallel)
 _SRC = [os.path.join(_HERE, "csrc", f) for f in ("bbduk_hip.hip", "bbduk_k_ktrimr.hip", "bbduk_k_ktriml.hip", "bbduk_k_kfilter.hip",
-                                                  "bbduk_k_modes_a.hip", "bbduk_k_modes_b.hip", "bbduk_stream.hip", "bbduk_bigs.hip", "bbduk_bigs_every.hip", "bbduk_bigs_every_b.hip", "bbduk_big_tiles.hip", "bbduk_bigs_general.hip", "bbduk_bigs_general_b.hip", "bbduk_stream_every.hip", "bbduk_stream_every_b.hip",
+                                                  "bbduk_k_modes_a.hip", "bbduk_k_modes_b.hip", "bbduk_stream.hip", "bbduk_bigs.hip", "bbduk_bigs_every.hip", "bbduk_bigs_every_b.hip", "bbduk_big_tiles.hip", "bbduk_bigs_general.hip", "bbduk_bigs_general_b.hip", "bbduk_bigs_kbig.hip", "bbduk_stream_every.hip", "bbduk_stream_every_b.hip",
                                                   "bbduk_ingest.hip", "bbduk_comm.hip", "bbduk_host.cpp")]
 _DEPS = _SRC + [os.path.join(_HERE, "csrc", "synth.h"), os.path.join(_HERE, "csrc", "bbduk_internal.h"),
                 os.path.join(_HERE, "csrc", "bbduk_device.inc"), os.path.join(_HERE, "csrc", "bbduk_kernels.h"), os.path.join(_HERE, "csrc", "bbduk_stream_scan.inc"), os.path.join(_HERE, "csrc", "bbduk_seed.inc"), os.path.join(_HERE, "csrc", "bbduk_bigs.inc"),

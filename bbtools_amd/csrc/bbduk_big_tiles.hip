@@ -9,5 +9,5 @@ kmask_tile_t bbduk_pick_kmask_big_tile() { return bbduk_kmask_kernel<1>; }
 kmask_long_t bbduk_pick_kmask_big_long() { return bbduk_kmask_long_kernel<1>; }
 tips_tile_t bbduk_pick_tips_big_tile() { return bbduk_ktrimtips_kernel<1>; }
 tips_tile_t bbduk_pick_tips_big_long() { return bbduk_long_tips_kernel<1>; }
-kscan_tile_t bbduk_pick_kscan_big_tile(int red) { return red == RED_SPLIT ? bbduk_kscan_kernel<RED_SPLIT, 1> : bbduk_kscan_kernel<RED_BEST, 1>; }
-kscan_tile_t bbduk_pick_kscan_big_long(int red) { return red == RED_SPLIT ? bbduk_kscan_long_kernel<RED_SPLIT, 1> : bbduk_kscan_long_kernel<RED_BEST, 1>; }
+kscan_tile_t bbduk_pick_kscan_big_tile(int red) { return red == RED_SPLIT ? bbduk_kscan_kernel<RED_SPLIT, 1> : (red == RED_BEST ? bbduk_kscan_kernel<RED_BEST, 1> : bbduk_kscan_kernel<RED_BIG, 1>); }
+kscan_tile_t bbduk_pick_kscan_big_long(int red) { return red == RED_SPLIT ? bbduk_kscan_long_kernel<RED_SPLIT, 1> : (red == RED_BEST ? bbduk_kscan_long_kernel<RED_BEST, 1> : bbduk_kscan_long_kernel<RED_BIG, 1>); }

@@ -351,13 +351,13 @@ static bool params_general(const bbduk_params& p) {               // the same pr
 // ... and ktrim=l, like kfilter with maxbadkmers > 0 an every-hit scan: bbduk_bigs_every_kernel (the scan's candidates all verified, the mode's facts read
 // out of the exact hit plane).
 // Round 5: every operator family -- ksplit, ktrim=n, ktrim=rl, findbestmatch and kfilter with mkf / mcf read their facts out of the same exact hit plane
-// (bbduk_bigs_every_kernel, wave_body BIGS && EVERY).  Still cache-resident at any size: k > 31 (the pair scan's run state machine), query expansion
-// (qhdist: the tiled kernels) and k < 16 (at most 4^15 keys: the cache-resident layout indexes them all).  The other flags of the GENERAL family --
+// (bbduk_bigs_every_kernel, wave_body BIGS && EVERY), and so does k > 31 (bbduk_bigs_kbig.hip: the run state machine replayed over the reads that have
+// hits).  Still cache-resident at any size: query expansion (qhdist: the tiled kernels) and k < 16 (at most 4^15 keys: the cache-resident layout indexes them all).  The other flags of the GENERAL family --
 // restrictleft / restrictright, skipr1 / skipr2, qskip, speed, rcomp=f -- only decide which positions are looked up, cut a window or gate a key: the
 // bbduk_bigs_general kernels serve them (kparams_general_flags).
 static bool big_layout_eligible(const bbduk_params& p) {
     const bool useShort = p.mink > 0 && p.mink < p.k;
-    return p.mode >= BBDUK_MODE_KFILTER && p.mode <= BBDUK_MODE_KSPLIT && !(p.kbig > p.k) && p.qhdist == 0 && p.qhdist2 == 0 && p.k >= 16 && !(useShort && p.middleMask != -1);
+    return p.mode >= BBDUK_MODE_KFILTER && p.mode <= BBDUK_MODE_KSPLIT && p.qhdist == 0 && p.qhdist2 == 0 && p.k >= 16 && !(useShort && p.middleMask != -1);
 }
 static bool kparams_general_flags(const KParams& K) {            // kparams_general without the thresholds mkf / mcf (they only read the hit plane)
     return K.restrictLeft > 0 || K.restrictRight > 0 || K.skipR1 || K.skipR2 || !K.rcomp || K.qskip > 1 || K.speed > 0;
@@ -424,7 +424,7 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
     // 2^22 keys on: a 52 kbase reference, 4.7 M keys, 115 against 87 Gbases/s; 19 M keys 159 / 75; 2.45 M keys 87 / 102 -- profiles/r04_seed_vs_plain.jsonl;
     // up to 2^25 keys build_both keeps the cache-resident twin for the units beyond a wave's planes)
     st->seed = (maxKeys > (double)SEED_JOINT_MIN_KEYS || h->hookSeedLayout) && !h->hookBigLayout && !h->hookNoBigLayout && hdist == 1 && big_layout_eligible(h->p) &&
-               h->p.mode == BBDUK_MODE_KFILTER && !h->p.findBestMatch && !params_general(h->p) && !h->sealTable && seed_geometry(h, maxKeys);      // (its stream scan is the plain kfilter's)      // (maxbadkmers > 0 and forbidn too, round 4: the walk counts, seed_window resets)
+               h->p.mode == BBDUK_MODE_KFILTER && !h->p.findBestMatch && !(h->p.kbig > h->p.k) && !params_general(h->p) && !h->sealTable && seed_geometry(h, maxKeys);      // (its stream scan is the plain kfilter's)      // (maxbadkmers > 0 and forbidn too, round 4: the walk counts, seed_window resets)
     if (st->seed && h->seedHl != h->seedHr && !(maxKeys > (double)SEED_LAYOUT_MIN_KEYS || h->hookSeedLayout)) st->seed = false;      // (the two-gather form keeps 2^25)
     long long bigMin = hdist > 0 ? std::max<long long>(big_min_keys(h->p), BIG_PLAIN_MIN_KEYS) : big_min_keys(h->p);      // (plain lines take over later: build_both)
     // (a streamed build -- bbduk_build_begin / _add_device / _end -- sees the reference once: it builds the cache-resident twin build_both gives the other
@@ -779,7 +779,7 @@ static int qx_rewrite(bbduk_handle* h) {
 static int try_collapse_to_seed(bbduk_handle* h) {
     const int64_t n = (int64_t)h->hkeys.size();
     if (h->seed || h->sealTable || h->hookBigLayout || h->hookNoBigLayout) return BBDUK_OK;
-    if (!(h->p.mode == BBDUK_MODE_KFILTER && !h->p.findBestMatch && !params_general(h->p) && big_layout_eligible(h->p))) return BBDUK_OK;      // (the seed layout's scan is the plain kfilter's)
+    if (!(h->p.mode == BBDUK_MODE_KFILTER && !h->p.findBestMatch && !(h->p.kbig > h->p.k) && !params_general(h->p) && big_layout_eligible(h->p))) return BBDUK_OK;      // (the seed layout's scan is the plain kfilter's)
     if (!(n > SEED_JOINT_MIN_KEYS || h->hookSeedLayout) || h->expectShort > 0.0) return BBDUK_OK;
     if (!seed_geometry(h, (double)n)) return BBDUK_OK;
     if (h->seedHl != h->seedHr && !(n > SEED_LAYOUT_MIN_KEYS || h->hookSeedLayout)) return BBDUK_OK;
@@ -1055,7 +1055,7 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     // A big-layout map (round 5: ksplit and findbestmatch take it like the other operators): bbduk_bigs_every_kernel scans, the fallbacks for units beyond
     // a wave's planes run over the cache-resident twin where the map has one (build_both), else their big-layout instantiations (bbduk_big_tiles.hip)
     const bool bigs = K.big != 0;
-    if (bigs && (!K.gV32 || h->hookPairScan || red == RED_BIG)) return fail(h, BBDUK_ERR_STATE, "big-layout map with a scan its kernels do not serve");
+    if (bigs && (!K.gV32 || h->hookPairScan)) return fail(h, BBDUK_ERR_STATE, "big-layout map with a scan its kernels do not serve");
     if (K.seed) return fail(h, BBDUK_ERR_STATE, "seed-layout map with a scan its kernel does not serve");
     const bool twin = bigs && h->hasAlt;
     const kscan_full_t fn = (bigs && !twin) ? bbduk_pick_kscan_big_tile(red) : (red == RED_SPLIT ? bbduk_kscan_kernel<RED_SPLIT> : (red == RED_BEST ? bbduk_kscan_kernel<RED_BEST> : bbduk_kscan_kernel<RED_BIG>));
@@ -1089,7 +1089,7 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
         K.waveFirst = 1;                                            // (main_scan_pair_kbig) per read
         const bool general = params_general(h->p);
         const bool every = red == RED_BEST && stream_every_ok(h, K);     // findbestmatch: the stream scan, ids gathered per read (wave_body: FBM)
-        const batch_kernel_t wk = bigs ? (kparams_general_flags(K) ? bbduk_pick_bigs_general(BBDUK_MODE_FBM) : bbduk_pick_bigs_every(BBDUK_MODE_FBM, false)) : every ? bbduk_pick_stream_every(BBDUK_MODE_FBM, false, K.forbidNs != 0, general)
+        const batch_kernel_t wk = bigs ? (red == RED_BIG ? bbduk_pick_bigs_kbig(kparams_general_flags(K)) : kparams_general_flags(K) ? bbduk_pick_bigs_general(BBDUK_MODE_FBM) : bbduk_pick_bigs_every(BBDUK_MODE_FBM, false)) : every ? bbduk_pick_stream_every(BBDUK_MODE_FBM, false, K.forbidNs != 0, general)
                                         : bbduk_pick_mode_wave(red == RED_BEST ? BBDUK_MODE_FBM : BBDUK_MODE_KBIG, general, packed, K.forbidNs != 0);
         const size_t waveLds = bigs ? dynLds + WAVE_LDS_BYTES_BIGS : dynLds + ((every && (K.forbidNs || general)) ? WAVE_LDS_BYTES_KM : WAVE_LDS_BYTES);
         HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(wk), waveLds));

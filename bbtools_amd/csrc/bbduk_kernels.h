@@ -26,6 +26,7 @@ batch_kernel_t bbduk_pick_stream_seed(bool forbidN, bool packed);              /
 batch_kernel_t bbduk_pick_ktrim_l_big_tile();
 batch_kernel_t bbduk_pick_bigs_every(int mode, bool useShort);                                       // bbduk_bigs_every.hip: ... and its every-hit form (ktrim=l, kfilter with maxbadkmers > 0)
 batch_kernel_t bbduk_pick_bigs(int mode, bool useShort, bool packed);
+batch_kernel_t bbduk_pick_bigs_kbig(bool general);                                                // bbduk_bigs_kbig.hip: k > 31 over a big-layout map
 batch_kernel_t bbduk_pick_bigs_general(int mode);                                                  // bbduk_bigs_general*.hip: the GENERAL family (restrict*, skipr*, qskip, speed, rcomp=f) over a big-layout map, every mode (mode = BBDUK_MODE_* | _FBM)
 // bbduk_big_tiles.hip: the tiled / long-read fallbacks of the secondary operators with a big-layout map's exact lookups (maps without a twin)
 typedef void (*kmask_tile_t)(const KParams, const uint8_t*, const int64_t*, const int64_t, const int64_t, const int, int32_t*, int32_t*, uint8_t*, uint32_t*, int64_t*, int*);

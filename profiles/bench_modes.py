@@ -14,7 +14,7 @@ ADAPTER_MODES = (("ktrim=n k=23 mink=11 hdist=1 ref=adapters", "kmask"), ("ktrim
 # round 5: the same operators against the guide's genome-size example (a random 4.6 Mbase genome, BBDukGuide.txt:34), i.e. a
 # big-layout map scanned by bbduk_bigs_every_kernel; 1 % of the pairs drawn from the genome
 GENOME_MODES = (("ktrim=n k=31", "kmask"), ("ktrim=rl k=31", "tips"), ("ksplit=t k=31", "ksplit"), ("k=31 fbm", "fbm"), ("k=31 mkf=0.1", "mkf"), ("k=31 mcf=0.3", "mcf"),
-                ("ktrim=l k=31", "ktriml"), ("k=31 mbk=1", "mbk"))
+                ("ktrim=l k=31", "ktriml"), ("k=31 mbk=1", "mbk"), ("k=40", "k40"))
 
 
 def run_genome(reads=20_000_000, genome_bases=4_600_000, modes=GENOME_MODES):

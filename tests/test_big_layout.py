@@ -203,7 +203,7 @@ def _is_big(d):
     ("ktrim=r k=27 mink=12 restrictright=80 qskip=2", dict(k=27, mink=12, ktrimRight=1, restrictRight=80, qSkip=2), 1_150_000, True),
     ("k=25 rcomp=f speed=3 skipr2=t", dict(k=25, rcomp=0, speed=3, skipR2=1), 1_150_000, True),
     ("k=31 qhdist=1", dict(k=31, qhdist=1), 1_150_000, False),                # query expansion: the tiled kernels over the cache-resident map
-    ("k=40", dict(k=31, kbig=40, maskMiddle=0), 1_150_000, False),            # k > 31: the pair scan's run state machine, cache-resident
+    ("k=40", dict(k=31, kbig=40, maskMiddle=0), 1_150_000, True),             # k > 31 (round 5, bbduk_bigs_kbig.hip): the run state machine over the exact hit plane
     ("ktrim=r k=27", dict(k=27, ktrimRight=1), 1_150_000, True),    # ktrim=r: minimizer lines too since round 4 (bbduk_bigs_kernel<KTRIM_R>)
     ("ktrim=l k=27", dict(k=27, ktrimLeft=1), 1_150_000, True),     # ktrim=l and kfilter with maxbadkmers > 0: bbduk_bigs_every_kernel (round 4)
     ("k=31 mbk=2", dict(k=31, maxBadKmers0=2), 1_150_000, True),
@@ -350,7 +350,11 @@ FAMILIES = [("ksplit=t k=23 mink=11 hdist=1", dict(k=23, mink=11, hdist=1, kspli
             ("k=27 mkf=0.05 forbidn=t hdist=1", dict(k=27, minKmerFraction=0.05, forbidN=1, hdist=1)),
             ("k=31 mcf=0.5", dict(k=31, minCoveredFraction=0.5)),
             ("k=25 mcf=0.2 mm=f rieb=f", dict(k=25, minCoveredFraction=0.2, maskMiddle=0, requireBothBad=1)),
-            ("k=31 mbk=7", dict(k=31, maxBadKmers0=7))]
+            ("k=31 mbk=7", dict(k=31, maxBadKmers0=7)),
+            ("k=40", dict(k=31, kbig=40, maskMiddle=0)),                                    # k > 31 (bbduk_bigs_kbig.hip): runs of matching 31-mers over the exact hit plane
+            ("k=33 mbk=2 hdist=1", dict(k=31, kbig=33, maskMiddle=0, maxBadKmers0=2, hdist=1)),
+            ("k=55 mkf=0.1 forbidn=t", dict(k=31, kbig=55, maskMiddle=0, minKmerFraction=0.1, forbidN=1)),
+            ("k=36 rieb=f minlen=40", dict(k=31, kbig=36, maskMiddle=0, requireBothBad=1, minReadLength=40))]
 
 
 GENERALS = [("k=31 restrictright=70", dict(k=31, restrictRight=70)),
@@ -373,7 +377,9 @@ GENERALS = [("k=31 restrictright=70", dict(k=31, restrictRight=70)),
             ("ktrim=rl k=27 qskip=2 forbidn=t speed=2", dict(k=27, ktrimLeft=1, ktrimRight=1, qSkip=2, forbidN=1, speed=2)),
             ("ktrim=rl k=25 mink=12 rcomp=f skipr2=t", dict(k=25, mink=12, ktrimLeft=1, ktrimRight=1, rcomp=0, skipR2=1)),
             ("k=25 fbm=t restrictright=90 skipr1=t", dict(k=25, findBestMatch=1, restrictRight=90, skipR1=1)),
-            ("k=27 fbm=t qskip=2 speed=3 rcomp=f", dict(k=27, findBestMatch=1, qSkip=2, speed=3, rcomp=0))]
+            ("k=27 fbm=t qskip=2 speed=3 rcomp=f", dict(k=27, findBestMatch=1, qSkip=2, speed=3, rcomp=0)),
+            ("k=40 restrictright=100 skipr2=t", dict(k=31, kbig=40, maskMiddle=0, restrictRight=100, skipR2=1)),      # k > 31 with the flags it accepts (no speed, no qskip: BBDukParser reduces kbig there)
+            ("k=34 rcomp=f restrictleft=120 mbk=1", dict(k=31, kbig=34, maskMiddle=0, rcomp=0, restrictLeft=120, maxBadKmers0=1))]
 
 
 @pytest.mark.parametrize("ci", range(len(GENERALS)))
