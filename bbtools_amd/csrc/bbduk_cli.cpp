@@ -5,14 +5,16 @@
 // TrimRead.trimByAmount to bases+qualities with the returned amounts, route removed pairs, print the counters.
 //
 //   bbduk_cli in=r1.fq [in2=r2.fq | int=t] [out=clean.fq] [outm=removed.fq] [tsv=per_read.tsv] [resources=DIR]
-//             [batch=N] [device=D | devices=0,1,..] [devicebuild=t] [deviceingest=t [chunk=BYTES]] <BBDuk flags: ktrim= k= mink= hdist= ref= literal= ...>
+//             [batch=N] [device=D | devices=0,1,..] [devicebuild=t] [deviceingest=t|f [chunk=BYTES] [pipeline=f] [timeline=t] [readthreads=N]]
+//             <BBDuk flags: ktrim= k= mink= hdist= ref= literal= ...>
 //
 // devices=0,1,..: one handle per listed device (a device may be listed twice), the map replicated on each; every batch
 // is cut into contiguous blocks of whole pairs, one block per handle, submitted from one host thread per handle; output keeps the
 // input order; at the end ONE counter all-reduce (bbduk_comm_create_local + bbduk_allreduce_counters_local: RCCL) merges the
 // per-device counters, as BBDukProcessorS.add merges the per-thread processors (bbduk/BBDukProcessorS.java:300-342).
 //
-// deviceingest=t (ktrim=r|l, kfilter): the FASTQ text itself goes to the GPU in chunks; record splitting, 2-bit packing,
+// deviceingest=t (the default wherever it serves the run: one device, not ksplit, no renaming, no trimfailuresto1bp): the FASTQ text itself goes to
+// the GPU in chunks; record splitting, 2-bit packing,
 // matching and the writing of the trimmed records all happen there (bbduk_fastq_ingest_device, bbduk_*_batch_packed_device,
 // bbduk_fastq_write_device); the host only moves bytes between the files and pinned buffers.
 //
@@ -589,7 +591,8 @@ int main(int argc, char** argv) {
     bool maskLower = false; char maskSymbol = 'N';
     bool rename = false;                                          // rename=t: matched reads get "\tscaffold=hits" appended (BBDukProcessorS.java:2508-2522)
     StatsOut so;
-    bool deviceIngest = false; long long chunk = 0;               // deviceingest=t: FASTQ text to the GPU, chunk= bytes per file and round (default 256 MiB; pipelined: 64 MiB)
+    int deviceIngestArg = -1; long long chunk = 0;                // deviceingest=t|f; not given: on wherever that path serves the run (see below)
+    bool deviceIngest = false;               // deviceingest=t: FASTQ text to the GPU, chunk= bytes per file and round (default 256 MiB; pipelined: 64 MiB)
     bool pipeline = true, timeline = false; int rthreads = 8, wthreads = 1;      // pipeline=f: the serial form; timeline=t: one JSON line of stage times on stderr
     const double tProcess = now_s();
     bool deviceBuild = false;        // devicebuild=t: the GPU builds the k-mer map from the reference sequences (bbduk_build_table_device)
@@ -608,7 +611,7 @@ int main(int argc, char** argv) {
         else if (a == "device") device = atoi(b.c_str());
         else if (a == "devices") { devices.clear(); size_t q = 0; while (q <= b.size()) { const size_t c = b.find(',', q); const std::string t = b.substr(q, c == std::string::npos ? std::string::npos : c - q); if (!t.empty()) devices.push_back(atoi(t.c_str())); if (c == std::string::npos) break; q = c + 1; } }
         else if (a == "devicebuild") deviceBuild = parse_bool(b);
-        else if (a == "deviceingest") deviceIngest = parse_bool(b);
+        else if (a == "deviceingest") deviceIngestArg = parse_bool(b) ? 1 : 0;
         else if (a == "chunk") chunk = atoll(b.c_str());
         else if (a == "pipeline") pipeline = parse_bool(b);
         else if (a == "timeline") timeline = parse_bool(b);
@@ -639,15 +642,21 @@ int main(int argc, char** argv) {
     const bool paired = interleaved || !in2.empty();
     if (devices.empty()) devices.push_back(device);
     device = devices[0];
+    char err[512] = {0};
+    bbduk_host* host = nullptr;
+    if (bbduk_host_parse(flags.c_str(), &host, err, sizeof err) != BBDUK_OK) return fail("bad arguments", err);
+    {   // deviceingest= not given: the device pipeline wherever it serves the run (round 5: the host parser moves 0.5 Gbases/s, the pipeline 15) --
+        // one device, FASTQ text, no read renaming, no cutting of failed reads to one base, not ksplit
+        bbduk_params P0;
+        const bool can = bbduk_host_params(host, device, &P0) == BBDUK_OK && devices.size() == 1 && P0.mode != BBDUK_MODE_KSPLIT && !(rename && P0.findBestMatch) && !P0.trimFailuresTo1bp;
+        deviceIngest = deviceIngestArg < 0 ? can : deviceIngestArg != 0;
+    }
     const bool piped = deviceIngest && pipeline && in2.empty() && tsv.empty() && !(in1.size() > 3 && in1.compare(in1.size() - 3, 3, ".gz") == 0);
     if (chunk == 0) chunk = piped ? (64LL << 20) : (256LL << 20);
     if (chunk < 4096) chunk = 4096;
     PipeBufs pipeBufs;
     if (piped) pipeBufs.start(device, (int64_t)chunk, !out.empty() || !outm.empty());      // (allocated while the map is built)
 
-    char err[512] = {0};
-    bbduk_host* host = nullptr;
-    if (bbduk_host_parse(flags.c_str(), &host, err, sizeof err) != BBDUK_OK) return fail("bad arguments", err);
     if (bbduk_host_load_refs(host, resources.c_str()) < 0) return fail("cannot load ref=", resources.c_str());
     int64_t stored = 0;
     if (!deviceBuild) { stored = bbduk_host_build_index(host); if (stored < 0) return fail("index build failed", nullptr); }

@@ -20,7 +20,7 @@ def main():
     text.tofile(path)
     flags = ["ktrim=r", "k=23", "mink=11", "hdist=1", "ref=adapters", "int=t", "devicebuild=t", "resources=" + os.path.join(ROOT, "data")]
     res = {}
-    for name, extra in (("host_parse", []), ("host_parse_out", ["out=" + outp]), ("deviceingest_serial", ["deviceingest=t", "pipeline=f"]), ("deviceingest_serial_out", ["deviceingest=t", "pipeline=f", "out=" + outp]),
+    for name, extra in (("host_parse", ["deviceingest=f"]), ("host_parse_out", ["deviceingest=f", "out=" + outp]), ("deviceingest_serial", ["deviceingest=t", "pipeline=f"]), ("deviceingest_serial_out", ["deviceingest=t", "pipeline=f", "out=" + outp]),
                         ("deviceingest", ["deviceingest=t", "timeline=t"]), ("deviceingest_out", ["deviceingest=t", "timeline=t", "out=" + outp])):
         if a.variants and name not in a.variants.split(","): continue
         best = None

@@ -15,7 +15,10 @@ def run_cli(args, cwd=ROOT):
     # A plain timeout that fails.  (Rounds 3-4 re-ran a devices=0,0,0 call that exceeded two minutes: "one run in ~150 hangs".  Round 5 looked inside with
     # bbduk_cli's watchdog= stack dump: the process sat in dlopen("librccl.so.1") -- 573 MB, cold page cache on a fresh box -- not in a deadlock; a group
     # on one device no longer loads the collective library at all, and 2 000 consecutive runs are clean: profiles/r05_hang_hunt.txt.)
-    return subprocess.run([_build.cli_path()] + args, cwd=cwd, capture_output=True, text=True, timeout=300)
+    # (the tests name the path they mean: without deviceingest= the CLI would pick the device pipeline wherever it can, see test_cli_picks_the_device_pipeline_by_itself)
+    if not any(a.startswith("deviceingest") or a == "auto" for a in args):
+        args = args + ["deviceingest=f"]
+    return subprocess.run([_build.cli_path()] + [a for a in args if a != "auto"], cwd=cwd, capture_output=True, text=True, timeout=300)
 
 
 def test_cli_is_built_and_prints_usage():
@@ -194,6 +197,24 @@ def test_cli_deviceingest_pipelined(tmp_path, chunk):
     empty.write_bytes(b"")
     r = run_cli(["in=" + str(empty), "k=23", "ref=adapters", "deviceingest=t", "out=" + str(tmp_path / "e.fq")] + ck)
     assert r.returncode == 0 and os.path.getsize(tmp_path / "e.fq") == 0 and "Input:" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_picks_the_device_pipeline_by_itself(tmp_path):
+    """Without deviceingest= the CLI takes the device pipeline where it serves the run (timeline=t only prints there) and the host parser elsewhere
+    (ksplit, trimfailuresto1bp, several devices); the outputs do not depend on the choice."""
+    f1 = os.path.join(GOLD, "cli_c3_interleaved.fq")
+    outs = {}
+    for name, extra in (("auto", ["auto"]), ("host", ["deviceingest=f"])):
+        out = str(tmp_path / (name + ".fq"))
+        r = run_cli(["in=" + f1, "int=t", "out=" + out, "k=31", "hdist=1", "ref=phix", "timeline=t"] + extra)
+        assert r.returncode == 0, r.stderr
+        outs[name] = (open(out, "rb").read(), [l for l in r.stderr.splitlines() if "reads" in l and not l.startswith("{")])
+        assert ('{"timeline"' in r.stderr) == (name == "auto")
+    assert outs["auto"] == outs["host"]
+    for flags in (["ksplit=t", "k=23", "ref=adapters"], ["ktrim=r", "k=23", "ref=adapters", "trimfailures=t"], ["k=31", "ref=phix", "devices=0,0"]):
+        r = run_cli(["in=" + os.path.join(GOLD, "cli_c2_r1.fq"), "timeline=t", "auto"] + flags)
+        assert r.returncode == 0 and '{"timeline"' not in r.stderr, (flags, r.stderr)
 
 
 @pytest.mark.gpu

@@ -157,7 +157,7 @@ def test_writer_matches_oracle_and_the_cli_files(tmp_path):
     # (b) the CLI's files
     f1, f2 = os.path.join(GOLD, "cli_c2_r1.fq"), os.path.join(GOLD, "cli_c2_r2.fq")
     out, outm = str(tmp_path / "clean.fq"), str(tmp_path / "removed.fq")
-    r = subprocess.run([_build.cli_path(), "in=" + f1, "in2=" + f2, "out=" + out, "outm=" + outm, "ktrim=r", "k=23", "mink=11", "hdist=1", "ref=adapters"],
+    r = subprocess.run([_build.cli_path(), "in=" + f1, "in2=" + f2, "out=" + out, "outm=" + outm, "ktrim=r", "k=23", "mink=11", "hdist=1", "ref=adapters", "deviceingest=f"],
                        cwd=util.ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
     t1, t2 = np.fromfile(f1, np.uint8), np.fromfile(f2, np.uint8)
