@@ -434,6 +434,8 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
     // ktrim=r has the stream scan of the 32-bit line function only (no pair-scan form): beyond 2^31 keys, or behind the 52-bit hook, it keeps the
     // cache-resident layout (which refuses what it cannot index)
     if (st->big && h->p.mode != BBDUK_MODE_KFILTER && !h->gV32) st->big = false;
+    // (the 52-bit line function exists behind its hook only; its pair scan serves the plain kfilter: the families round 5 made eligible keep the cache-resident map there)
+    if (st->big && !h->gV32 && !h->sealTable && (params_general(h->p) || h->p.findBestMatch || h->p.kbig > h->p.k)) st->big = false;
     auto bail = [&](int code, const char* msg) { build_release(h); table_release(h); return fail(h, code, msg); };
     if (hipMalloc(&st->d_cnt, 64) != hipSuccess || hipMemsetAsync(st->d_cnt, 0, 64, h->stream) != hipSuccess) return bail(BBDUK_ERR_NOMEM, "hipMalloc");      // [0..3]: Sink::distinct, [4]: the twin's distinct keys
     // the twin of a streamed build: the same sizes build_both keeps one for (wants_twin), never beside a forced layout

@@ -58,9 +58,11 @@ def main():
     while time.time() - t0 < a.seconds and not (a.only is not None and it):
         seed = a.seed * 1_000_003 + it if a.only is None else a.only; it += 1
         rng = random.Random(seed)
-        fam = rng.choice(a.families.split(",") if a.families else ["base", "base", "base", "tails", "kmask", "tips", "ksplit", "big", "fbm", "seal", "tf1bp", "bigmap", "bigmap"])
+        fam = rng.choice(a.families.split(",") if a.families else ["base", "base", "base", "tails", "kmask", "tips", "ksplit", "big", "fbm", "seal", "tf1bp", "bigmap", "bigmap", "seedmap"])
         bigmap = fam == "bigmap"                               # base configurations with the HBM-resident map layout asked for (round 4: bbduk_bigs_kernel for
         if bigmap: fam = "base"                                # kfilter and ktrim=r, the 52-bit variant's pair scan, the exact scans for the rest)
+        # round 5: every other operator family over a big-layout map too (bbduk_bigs_every_kernel's facts, the GENERAL flags, k > 31: bbduk_bigs_kbig.hip)
+        if fam in ("kmask", "tips", "ksplit", "big", "fbm") and rng.random() < 0.35: bigmap = True
         tails = fam == "tails"                                 # base configurations on reads that overshoot the pair scan's blocks by 1..32 positions:
         if tails: fam = "base"                                 # (block borders of the stream scan / the every-hit scans' tail pass)
         if fam == "tf1bp":                                     # trimfailuresto1bp over every operator family (units within the main kernel's planes)
@@ -69,6 +71,11 @@ def main():
                 trefs = [util.rand_seq(rng, rng.randint(12, 90), 0.01) for _ in range(rng.randint(1, 8))]
                 td, to = T.make_pair(targs, tokw, refs=trefs)
                 treads = util.fuzz_reads(rng, trefs, rng.choice([60, 400, 1500]), [0, 1, 2, 3, 9, 10, 12, 22, 23, 31, 40, 64, 75, 150, 151, 300, 1000], junk=True)
+                if rng.random() < 0.4:                             # units beyond a wave's planes / beyond the tiles: the tiled and long-unit kernels' record stages (round 5)
+                    for _ in range(rng.randint(1, 3)):
+                        L = rng.choice([3000, 5000, 45000]); g = bytearray(util.rand_seq(rng, L, 0.0005))
+                        r = rng.choice(trefs); pos = rng.choice([0, L - len(r), rng.randrange(L - len(r))]); g[pos:pos + len(r)] = r
+                        treads.insert(rng.randrange(len(treads) + 1), bytes(g))
                 if len(treads) % 2: treads.append(b"")
                 if tfam == "n": T.check_kmask(td, to, treads, True); T.check_kmask(td, to, treads[:101], False)
                 elif tfam == "rl": T.check_tips(td, to, treads, True); T.check_tips(td, to, treads[:101], False)
@@ -90,6 +97,16 @@ def main():
             n_cfg += 1; n_reads += 300; fam_count[fam] = fam_count.get(fam, 0) + 1
             continue
         args, okw = T.random_config(rng)
+        seedfam = fam == "seedmap"                             # round 5: the seed layout with forbidn / maxbadkmers / mm=f, device-built, forced at any size
+        if seedfam:
+            fam = "base"
+            k = rng.choice([16, 17, 20, 21, 23, 24, 25, 27, 31]); okw, ar = dict(k=k, hdist=1), ["k=%d" % k, "hdist=1"]
+            if rng.random() < 0.3: okw["maskMiddle"] = 0; ar.append("mm=f")
+            if rng.random() < 0.4: okw["forbidN"] = 1; ar.append("forbidn=t")
+            if rng.random() < 0.4: v = rng.randint(1, 4); okw["maxBadKmers0"] = v; ar.append("mbk=%d" % v)
+            if rng.random() < 0.2: okw["requireBothBad"] = 1; ar.append("rieb=f")
+            if rng.random() < 0.3: v = rng.choice([1, 20, 40]); okw["minReadLength"] = v; ar.append("minlen=%d" % v)
+            args = " ".join(ar)
         toks = [t for t in args.split() if not t.startswith("ktrim=") and t != "tpe"]
         for key in ("ktrimRight", "ktrimLeft", "trimPairsEvenly"):
             if fam != "base":
@@ -130,7 +147,7 @@ def main():
                 toks = [t for t in toks if not t.startswith(("mbk=", "mkf="))]
         if "mink" in okw and fam in ("base",) and not (okw.get("ktrimRight") or okw.get("ktrimLeft")):
             okw.pop("mink"); toks = [t for t in toks if not t.startswith("mink=")]
-        if rng.random() < 0.15 and fam not in ("big",):
+        if rng.random() < 0.15 and fam not in ("big",) and not seedfam:
             sk = rng.randint(2, 4); okw["minSkip"] = okw["maxSkip"] = sk; toks.append("rskip=%d" % sk)
         args = " ".join(toks)
         k = okw["k"]
@@ -158,7 +175,7 @@ def main():
                     g[pos:pos + len(r)] = r
                 reads.insert(rng.randrange(len(reads) + 1), bytes(g))
         if len(reads) % 2: reads.append(b"")
-        build = "device" if (rng.random() < 0.4 and okw.get("hdist", 0) <= 2 and "minSkip" not in okw) else "host"
+        build = "device" if ((rng.random() < 0.4 or seedfam) and okw.get("hdist", 0) <= 2 and "minSkip" not in okw) else "host"
         try:
             o = Oracle(**okw)
             for r in refs: o.add_ref(r)
@@ -171,8 +188,11 @@ def main():
                 bb = max(4, math.ceil(math.log2(o.stored_kmers / 3.4)))
                 if rng.random() < 0.7: hooks[B.HOOK_BUCKET_BITS] = bb; squeeze += " bucketbits=%d" % bb
                 if rng.random() < 0.6: lb = rng.choice([0, 10, 12]); hooks[B.HOOK_LDS_BITS] = lb; squeeze += " ldsbits=%d" % lb
+            seedmap = (not bigmap and fam == "base" and build == "device" and okw.get("hdist", 0) == 1 and not (okw.get("ktrimRight") or okw.get("ktrimLeft")) and (rng.random() < 0.5 or seedfam))
+            if seedmap:                                         # the seed layout (parents under their halves) where the library has it: forbidn, mbk > 0 too
+                hooks = {B.HOOK_SEED_LAYOUT: 1}; squeeze = " seedmap"
             if bigmap:
-                hooks = {B.HOOK_BIG_LAYOUT: rng.choice([1, 1, 1, 2, 3, 3]), B.HOOK_BIG_LOAD: rng.choice([0, 0, 30, 60, 95])}
+                hooks = {B.HOOK_BIG_LAYOUT: rng.choice([1, 1, 1, 2, 3, 3]) if fam == "base" else rng.choice([1, 1, 3]), B.HOOK_BIG_LOAD: rng.choice([0, 0, 30, 60, 95])}
                 if rng.random() < 0.5: hooks[B.HOOK_LDS_BITS] = rng.choice([4, 6, 7, 8, 9, 10, 12])      # (m of the minimizer lines)
                 squeeze = " bigmap=%r" % (sorted(hooks.items()),)
             if os.environ.get("SOAK_DUMP"):
@@ -180,7 +200,10 @@ def main():
             if os.environ.get("SOAK_HOOKS"): hooks = {int(k_): int(v_) for k_, v_ in (kv.split(":") for kv in os.environ["SOAK_HOOKS"].split(",") if kv)}      # (debugging a --only run)
             d = B.BBDuk(args, refs=refs, build=build, hooks=hooks)
             if squeeze: fam_count["squeezed"] = fam_count.get("squeezed", 0) + 1
-            assert d.stored_kmers == o.stored_kmers, ("stored", d.stored_kmers, o.stored_kmers)
+            lay = d.gpu.table_layout
+            fam_count["layout_%d" % (lay & 3)] = fam_count.get("layout_%d" % (lay & 3), 0) + 1        # 0 cache-resident, 1 big, 2 seed
+            if lay & 8: fam_count["qx_tabulated"] = fam_count.get("qx_tabulated", 0) + 1
+            assert d.stored_kmers == o.stored_kmers or (d.gpu.table_layout & 3) == 2, ("stored", d.stored_kmers, o.stored_kmers)      # (a seed-layout map counts its parents)
             if fam == "kmask":
                 T.check_kmask(d, o, reads, True); T.check_kmask(d, o, reads[:101], False)
             elif fam == "tips":
@@ -196,6 +219,7 @@ def main():
             print(json.dumps({"FAILED": True, "seed": seed, "family": fam, "args": args, "okw": okw, "build": build, "squeeze": locals().get("squeeze", ""), "error": (str(e) or traceback.format_exc())[-2000:]}))
             sys.exit(1)
         n_cfg += 1; n_reads += len(reads); fam_count["tails" if tails else fam] = fam_count.get("tails" if tails else fam, 0) + 1
+        if bigmap and fam != "base": fam_count["bigmap_" + fam] = fam_count.get("bigmap_" + fam, 0) + 1
     print(json.dumps({"soak_seconds": round(time.time() - t0, 1), "configs": n_cfg, "reads_checked": n_reads * 3, "families": fam_count, "mismatches": 0, "seed": a.seed}))
 
 
