@@ -46,10 +46,11 @@ def test_oracle_splits_like_a_line_reader():
     assert FQ.ingest([np.frombuffer(b"@a\nACGT\n+\nIII\n", np.uint8)], True, 100)["first_bad"] == 0
 
 
-def _check(texts, is_final, max_reads=None):
+def _check(texts, is_final, max_reads=None, shift=0):
     import torch
     want = FQ.ingest(texts, is_final, max_reads if max_reads is not None else 10 ** 9)
-    dts = [torch.from_numpy(np.concatenate([t, np.zeros(16, np.uint8)])).cuda()[:len(t)] for t in texts]
+    # shift: the text starts `shift` bytes into its allocation (round 5: any alignment -- a chunk's carried-over tail starts wherever the record does)
+    dts = [torch.from_numpy(np.concatenate([np.full(shift, 10, np.uint8), t, np.zeros(16, np.uint8)])).cuda()[shift:shift + len(t)] for t in texts]
     fb = B.fastq_ingest_device(dts[0], dts[1] if len(dts) == 2 else None, is_final, max_reads)
     assert fb.n == want["n"] and list(fb.consumed[:len(texts)]) == want["consumed"]
     n = fb.n
@@ -84,6 +85,11 @@ def test_ingest_matches_oracle_on_random_fastq():
     _check([a, b], True, max_reads=101)
     big, _ = make_fastq(rng, 60000, lengths=(100, 150, 151))     # > one scan block of reads, ~20 MB of text
     _check([big], True)
+    for shift in (1, 3, 7, 8, 13, 15):                          # texts that start at any byte
+        t, _ = make_fastq(rng, 700, crlf=shift == 7, final_newline=shift != 13)
+        _check([t], True, shift=shift)
+        _check([a, b], True, shift=shift)
+    _check([big], True, shift=5)
 
 
 @pytest.mark.gpu
