@@ -234,9 +234,9 @@ int run_device_ingest(bbduk_handle* dev, const bbduk_host* host, const StatsOut&
             if (bbduk_copy_from_device(device, &R.consumed1, T[0].d_lines + 4 * n, 8, nullptr) != BBDUK_OK) return fail("device to host copy", nullptr);
         }
         if (n == 0) {
+            if (ns == 2 && (T[0].have == 0) != (T[1].have == 0) && (T[0].have == 0 ? T[0].eof : T[1].eof)) return fail("the two input files hold different numbers of reads", nullptr);
             if (fin) return fail("truncated FASTQ record at the end of", in1.c_str());
             if (T[0].have >= chunk || (ns == 2 && T[1].have >= chunk)) return fail("a FASTQ record exceeds chunk=", nullptr);
-            if (ns == 2 && (T[0].eof != T[1].eof) && (T[0].have == 0 || T[1].have == 0)) return fail("the two input files hold different numbers of reads", nullptr);
             continue;
         }
         const int64_t total = [&]() { int64_t v = 0; bbduk_copy_from_device(device, &v, d_off + n, 8, nullptr); return v; }();
@@ -292,7 +292,7 @@ int run_device_ingest(bbduk_handle* dev, const bbduk_host* host, const StatsOut&
     return write_stats(so, host, c, in1, in2);
 }
 
-// ---- deviceingest=t, pipelined (round 5; one plain input file, no tsv=).  The serial form above reads, copies, runs and writes one chunk after
+// ---- deviceingest=t, pipelined (round 5; plain input files -- one, or in= + in2= -- and no tsv=).  The serial form above reads, copies, runs and writes one chunk after
 // the other, so a run costs the SUM of its stages (profiles/r04_cli_31gb.json: 2.7 s for 31 GB, 8.4 s with out=).  Here each stage has its own
 // thread and the run costs the slowest one:
 //   reader    `rthreads` pread()s per piece of the file into one of NB pinned buffers
@@ -301,7 +301,8 @@ int run_device_ingest(bbduk_handle* dev, const bbduk_host* host, const StatsOut&
 //             into one of NO output slots, device to host queued on that slot's stream
 //   writer    waits for that copy, writes the bytes
 // Pieces are cut at fixed file offsets, so a record (or the second mate of an interleaved pair) can straddle two pieces: what a piece leaves
-// unconsumed is copied in front of the next one on the device, where the text may start at any byte.
+// unconsumed is copied in front of the next one on the device, where the text may start at any byte.  Two files: reader, uploader and tail per file;
+// a batch takes as many records as BOTH hold, so the file that is ahead keeps a longer tail and skips a round of taking a new piece when it passes chunk.
 struct Turnstile {                   // a counter that only grows; other threads wait for it to pass a value
     std::mutex m; std::condition_variable cv; int64_t v = 0; bool dead = false;
     void set(int64_t x) { { std::lock_guard<std::mutex> g(m); v = x; } cv.notify_all(); }
@@ -335,30 +336,32 @@ template <class F> bool in_parallel(int64_t bytes, int nt, F&& part) {
     return true;
 }
 
-// The buffers of a pipelined run.  They depend on chunk= and the device only, so main() allocates them on a thread of their own while the reference is
-// parsed and the k-mer map is built (pinning ~0.6 GB of host memory is ~70 ms of a run that lasts ~1 s).
+// The buffers of a pipelined run.  They depend on chunk=, the device and the number of input files only, so main() allocates them on a thread of their
+// own while the reference is parsed and the k-mer map is built (pinning ~0.6 GB of host memory is ~70 ms of a run that lasts ~1 s).
 struct PipeBufs {
     static constexpr int NB = 4, ND = 3, NO = 3;
-    int64_t chunk = 0, haveMax = 0, maxReads = 0, capBases = 0, capOut = 0; int device = 0; bool ok = false; double seconds = 0;
-    uint8_t* H[NB] = {}; uint8_t* D[ND] = {}; void* upStream = nullptr;
+    int64_t chunk = 0, haveMax = 0, maxRec = 0, maxReads = 0, capBases = 0, capOut = 0; int device = 0, ns = 1; bool ok = false; double seconds = 0;
+    uint8_t* H[2][NB] = {}; uint8_t* D[2][ND] = {}; void* upStream[2] = {}; int64_t* d_lines[2] = {};
     uint8_t* dOut[NO] = {}; uint8_t* hOut[NO] = {}; void* outStream[NO] = {};
-    int64_t* d_lines = nullptr; int64_t* d_off = nullptr; uint32_t* d_codes = nullptr; uint32_t* d_undef = nullptr; int32_t* d_a = nullptr; int32_t* d_id = nullptr; uint8_t* d_fl = nullptr;
+    int64_t* d_off = nullptr; uint32_t* d_codes = nullptr; uint32_t* d_undef = nullptr; int32_t* d_a = nullptr; int32_t* d_id = nullptr; uint8_t* d_fl = nullptr;
     std::thread worker;
-    void start(int dev, int64_t chunkBytes, bool anyOut) {
-        device = dev; chunk = chunkBytes;
-        haveMax = 2 * chunk;                                      // a tail (< chunk) + a piece
-        maxReads = haveMax / 40 + 16; capBases = haveMax / 2 + 64; capOut = haveMax + 64;
+    void start(int dev, int64_t chunkBytes, int nstreams, bool anyOut) {
+        device = dev; chunk = chunkBytes; ns = nstreams;
+        haveMax = 2 * chunk;                                      // per text: a tail (<= chunk) + a piece
+        maxRec = haveMax / 40 + 16; maxReads = maxRec * ns; capBases = (haveMax * ns) / 2 + 64; capOut = haveMax * ns + 64;
         worker = std::thread([this, anyOut]() {
             const double t0 = now_s();
             void* p = nullptr;
             auto dmal = [&](int64_t bytes) -> void* { return bbduk_device_malloc(device, bytes, &p) == BBDUK_OK ? p : nullptr; };
             auto pmal = [&](int64_t bytes) -> void* { return bbduk_pinned_malloc(bytes, &p) == BBDUK_OK ? p : nullptr; };
             bool good = true;
-            for (int i = 0; i < NB; i++) good = good && (H[i] = (uint8_t*)pmal(chunk + 16));
-            for (int i = 0; i < ND; i++) good = good && (D[i] = (uint8_t*)dmal(haveMax + 64));
-            good = good && bbduk_stream_create(device, &upStream) == BBDUK_OK;
+            for (int s = 0; s < ns; s++) {
+                for (int i = 0; i < NB; i++) good = good && (H[s][i] = (uint8_t*)pmal(chunk + 16));
+                for (int i = 0; i < ND; i++) good = good && (D[s][i] = (uint8_t*)dmal(haveMax + 64));
+                good = good && bbduk_stream_create(device, &upStream[s]) == BBDUK_OK && (d_lines[s] = (int64_t*)dmal((4 * maxRec + 1) * 8));
+            }
             if (anyOut) for (int i = 0; i < NO; i++) good = good && (dOut[i] = (uint8_t*)dmal(capOut)) && (hOut[i] = (uint8_t*)pmal(capOut)) && bbduk_stream_create(device, &outStream[i]) == BBDUK_OK;
-            good = good && (d_lines = (int64_t*)dmal((4 * maxReads + 1) * 8)) && (d_off = (int64_t*)dmal((maxReads + 1) * 8)) && (d_codes = (uint32_t*)dmal(capBases / 4 + 64)) &&
+            good = good && (d_off = (int64_t*)dmal((maxReads + 1) * 8)) && (d_codes = (uint32_t*)dmal(capBases / 4 + 64)) &&
                    (d_undef = (uint32_t*)dmal(capBases / 8 + 64)) && (d_a = (int32_t*)dmal(maxReads * 4)) && (d_id = (int32_t*)dmal(maxReads * 4)) && (d_fl = (uint8_t*)dmal(maxReads));
             ok = good; seconds = now_s() - t0;
         });
@@ -367,25 +370,40 @@ struct PipeBufs {
     ~PipeBufs() { wait(); }
 };
 
-int run_device_ingest_piped(bbduk_handle* dev, const bbduk_host* host, const StatsOut& so, const bbduk_params& P, const std::string& in1, bool paired,
+// One input file of a pipelined run: its pieces (fixed file offsets), the reader and the uploader that bring them to the device, and what the main
+// stage holds of it -- `have` bytes at `text` (the unconsumed tail of the pieces taken so far, then nothing else).
+struct InStream {
+    int fd = -1; int64_t bytes = 0, NP = 0, next = 0;             // next: the first piece main has not taken yet
+    Turnstile filled, hostFreed, uploaded, devFreed;
+    std::thread reader, uploader;
+    uint8_t* text = nullptr; int64_t have = 0;
+    StageClock cRead, cUp;
+};
+
+int run_device_ingest_piped(bbduk_handle* dev, const bbduk_host* host, const StatsOut& so, const bbduk_params& P, const std::string& in1, const std::string& in2, bool paired,
                             const std::string& out, const std::string& outm, PipeBufs& B, bool maskLower, char maskSymbol,
                             int rthreads, int wthreads, bool timeline, double tProcess) {
     if (P.mode == BBDUK_MODE_KSPLIT) return fail("deviceingest=t serves ktrim=r|l|rl|n and kfilter, not ksplit", nullptr);
     const double tBegin = now_s();
-    const int fd = open(in1.c_str(), O_RDONLY);
-    if (fd < 0) return fail("cannot open", in1.c_str());
-    struct stat sb;
-    if (fstat(fd, &sb) != 0) return fail("cannot stat", in1.c_str());
+    const int ns = B.ns;
+    InStream S[2];
+    for (int s = 0; s < ns; s++) {
+        const std::string& path = s ? in2 : in1;
+        S[s].fd = open(path.c_str(), O_RDONLY);
+        if (S[s].fd < 0) return fail("cannot open", path.c_str());
+        struct stat sb;
+        if (fstat(S[s].fd, &sb) != 0) return fail("cannot stat", path.c_str());
+        S[s].bytes = (int64_t)sb.st_size; S[s].NP = (S[s].bytes + B.chunk - 1) / B.chunk;
+    }
     const int64_t chunk = B.chunk; const int device = B.device;
-    const int64_t fileBytes = (int64_t)sb.st_size, NP = (fileBytes + chunk - 1) / chunk;
     const int fdOut[2] = {out.empty() ? -1 : open(out.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644), outm.empty() ? -1 : open(outm.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644)};
     if ((!out.empty() && fdOut[0] < 0) || (!outm.empty() && fdOut[1] < 0)) return fail("cannot open an output file", nullptr);
     const double tOpen = now_s();
     if (!B.wait()) return fail("out of memory (chunk= too large?)", nullptr);
     constexpr int NB = PipeBufs::NB, ND = PipeBufs::ND, NO = PipeBufs::NO;
     const int64_t maxReads = B.maxReads, capBases = B.capBases, capOut = B.capOut;
-    uint8_t** H = B.H; uint8_t** D = B.D; void* upStream = B.upStream; uint8_t** dOut = B.dOut; uint8_t** hOut = B.hOut; void** outStream = B.outStream;
-    int64_t* d_lines = B.d_lines; int64_t* d_off = B.d_off; uint32_t* d_codes = B.d_codes; uint32_t* d_undef = B.d_undef; int32_t* d_a = B.d_a; int32_t* d_id = B.d_id; uint8_t* d_fl = B.d_fl;
+    uint8_t** dOut = B.dOut; uint8_t** hOut = B.hOut; void** outStream = B.outStream;
+    int64_t* d_off = B.d_off; uint32_t* d_codes = B.d_codes; uint32_t* d_undef = B.d_undef; int32_t* d_a = B.d_a; int32_t* d_id = B.d_id; uint8_t* d_fl = B.d_fl;
     void* p = nullptr;
     auto dmal = [&](int64_t bytes) -> void* { return bbduk_device_malloc(device, bytes, &p) == BBDUK_OK ? p : nullptr; };
     int32_t* d_b = P.mode == BBDUK_MODE_KTRIM_TIPS ? (int32_t*)dmal(maxReads * 4) : nullptr;
@@ -396,34 +414,43 @@ int run_device_ingest_piped(bbduk_handle* dev, const bbduk_host* host, const Sta
     bbduk_device_memset(device, d_ctr, 0, (int64_t)nctr * 8, nullptr);
     const double tAlloc = now_s();
 
-    Turnstile filled, hostFreed, uploaded, devFreed, outQueued, outFreed;
-    StageClock cRead, cUp, cTail, cIngest, cOp, cWriteK, cD2H, cWrite, cWaitUp, cWaitOut;
+    Turnstile outQueued, outFreed;
+    StageClock cTail, cIngest, cOp, cWriteK, cD2H, cWrite, cWaitUp, cWaitOut;
     std::atomic<const char*> failed{nullptr};                     // set by a stage thread before it kills the turnstiles
-    auto abandon = [&](const char* why) { const char* none = nullptr; failed.compare_exchange_strong(none, why); for (Turnstile* t : {&filled, &hostFreed, &uploaded, &devFreed, &outQueued, &outFreed}) t->kill(); };
-    auto piece_bytes = [&](int64_t q) { return std::min(chunk, fileBytes - q * chunk); };
-
-    std::thread reader([&]() {
-        for (int64_t q = 0; q < NP; q++) {
-            if (q >= NB && !hostFreed.wait_above(q - NB)) return;
-            cRead.start();
-            const int64_t off = q * chunk;
-            const bool ok = in_parallel(piece_bytes(q), rthreads, [&](int64_t a, int64_t n) { return pread_all(fd, H[q % NB] + a, off + a, n); });
-            cRead.stop();
-            if (!ok) { abandon("read error"); return; }
-            filled.set(q + 1);
-        }
-    });
-    std::thread uploader([&]() {
-        for (int64_t q = 0; q < NP; q++) {
-            if (!filled.wait_above(q)) return;
-            if (q >= ND && !devFreed.wait_above(q - ND)) return;
-            cUp.start();
-            const bool ok = bbduk_copy_async(device, D[q % ND] + chunk, H[q % NB], piece_bytes(q), 0, upStream) == BBDUK_OK && bbduk_stream_synchronize(device, upStream) == BBDUK_OK;
-            cUp.stop();
-            if (!ok) { abandon("host to device copy"); return; }
-            hostFreed.set(q + 1); uploaded.set(q + 1);
-        }
-    });
+    auto abandon = [&](const char* why) {
+        const char* none = nullptr; failed.compare_exchange_strong(none, why);
+        for (int s = 0; s < ns; s++) for (Turnstile* t : {&S[s].filled, &S[s].hostFreed, &S[s].uploaded, &S[s].devFreed}) t->kill();
+        outQueued.kill(); outFreed.kill();
+    };
+    const int rt = std::max(1, rthreads / ns);
+    for (int s = 0; s < ns; s++) {
+        InStream& X = S[s];
+        auto piece_bytes = [&X, chunk](int64_t q) { return std::min(chunk, X.bytes - q * chunk); };
+        X.reader = std::thread([&, s, piece_bytes]() {
+            InStream& Y = S[s];
+            for (int64_t q = 0; q < Y.NP; q++) {
+                if (q >= NB && !Y.hostFreed.wait_above(q - NB)) return;
+                Y.cRead.start();
+                const int64_t off = q * chunk;
+                const bool ok = in_parallel(piece_bytes(q), rt, [&](int64_t a, int64_t n) { return pread_all(Y.fd, B.H[s][q % NB] + a, off + a, n); });
+                Y.cRead.stop();
+                if (!ok) { abandon("read error"); return; }
+                Y.filled.set(q + 1);
+            }
+        });
+        X.uploader = std::thread([&, s, piece_bytes]() {
+            InStream& Y = S[s];
+            for (int64_t q = 0; q < Y.NP; q++) {
+                if (!Y.filled.wait_above(q)) return;
+                if (q >= ND && !Y.devFreed.wait_above(q - ND)) return;
+                Y.cUp.start();
+                const bool ok = bbduk_copy_async(device, B.D[s][q % ND] + chunk, B.H[s][q % NB], piece_bytes(q), 0, B.upStream[s]) == BBDUK_OK && bbduk_stream_synchronize(device, B.upStream[s]) == BBDUK_OK;
+                Y.cUp.stop();
+                if (!ok) { abandon("host to device copy"); return; }
+                Y.hostFreed.set(q + 1); Y.uploaded.set(q + 1);
+            }
+        });
+    }
     struct OutJob { int slot; int64_t bytes; int sel; };
     std::mutex jobMu; std::deque<OutJob> jobs;
     int64_t outPos[2] = {0, 0};
@@ -449,78 +476,88 @@ int run_device_ingest_piped(bbduk_handle* dev, const bbduk_host* host, const Sta
     auto finish = [&](int rc) {                                   // every exit goes through here: the threads hold references to this frame
         if (rc != 0) abandon("stopped");
         else push_job(OutJob{-1, 0, 0}, outSeq);
-        reader.join(); uploader.join(); writer.join();
-        close(fd); for (int f : fdOut) if (f >= 0) close(f);
+        for (int s = 0; s < ns; s++) { S[s].reader.join(); S[s].uploader.join(); }
+        writer.join();
+        for (int s = 0; s < ns; s++) close(S[s].fd);
+        for (int f : fdOut) if (f >= 0) close(f);
         return rc;
     };
 
     const bool kfilter = P.mode == BBDUK_MODE_KFILTER;
-    long long nread = 0; int64_t tailLen = 0; const uint8_t* tailPtr = nullptr; int rounds = 0;
-    for (int64_t q = 0; q < NP; q++) {
-        cWaitUp.start();
-        const bool okq = uploaded.wait_above(q);
-        cWaitUp.stop();
-        if (!okq) return finish(fail(failed.load() ? failed.load() : "pipeline stopped", nullptr));
-        uint8_t* text = D[q % ND] + chunk - tailLen;
-        cTail.start();
-        if (tailLen > 0 && (bbduk_copy_async(device, text, tailPtr, tailLen, 2, nullptr) != BBDUK_OK || bbduk_stream_synchronize(device, nullptr) != BBDUK_OK)) return finish(fail("device to device copy", nullptr));
-        cTail.stop();
-        devFreed.set(q);                                          // the slots of the pieces before this one can be overwritten
-        int64_t have = tailLen + piece_bytes(q);
-        const bool fin = q == NP - 1;
-        for (bool again = true; again;) {
-            rounds++;
-            bbduk_fastq_result R;
-            cIngest.start();
-            const int rc = bbduk_fastq_ingest_device(text, have, nullptr, 0, fin ? 1 : 0, maxReads, capBases, d_lines, nullptr, d_off, d_codes, d_undef, device, nullptr, &R);
-            cIngest.stop();
-            if (rc == BBDUK_ERR_FORMAT) { char m[64]; snprintf(m, sizeof m, "read %lld", nread + (long long)R.first_bad_read); return finish(fail("malformed FASTQ record at", m)); }
-            if (rc != BBDUK_OK) return finish(fail("bbduk_fastq_ingest_device", nullptr));
-            int64_t n = R.n_reads;
-            const bool full = n >= maxReads;                      // the record limit, not the end of the text, ended this round
-            if (paired && (n & 1)) {                              // a pair stays together; its second record comes with the next piece
-                if (fin && !full) return finish(fail("unpaired or malformed mate at the end of", in1.c_str()));
-                n--;
-                if (bbduk_copy_from_device(device, &R.consumed1, d_lines + 4 * n, 8, nullptr) != BBDUK_OK) return finish(fail("device to host copy", nullptr));
-            }
-            if (n == 0) {
-                if (fin) { if (have > 0) return finish(fail("truncated FASTQ record at the end of", in1.c_str())); break; }
-                if (have >= chunk) return finish(fail("a FASTQ record exceeds chunk=", nullptr));
-                break;
-            }
-            const int64_t total = [&]() { int64_t v = 0; bbduk_copy_from_device(device, &v, d_off + n, 8, nullptr); return v; }();
-            cOp.start();
-            const int orc = kfilter ? bbduk_kfilter_batch_packed_device(dev, d_codes, d_undef, d_off, n, total, paired ? 1 : 0, d_a, d_id, d_fl, d_ctr, nullptr)
-                          : P.mode == BBDUK_MODE_KTRIM_TIPS ? bbduk_ktrimtips_batch_packed_device(dev, d_codes, d_undef, d_off, n, total, paired ? 1 : 0, d_a, d_b, d_id, d_fl, d_ctr, nullptr)
-                          : P.mode == BBDUK_MODE_KMASK ? bbduk_kmask_batch_packed_device(dev, d_codes, d_undef, d_off, n, total, paired ? 1 : 0, d_a, d_id, d_fl, d_mask, d_ctr, nullptr)
-                          : bbduk_ktrim_batch_packed_device(dev, d_codes, d_undef, d_off, n, total, paired ? 1 : 0, d_a, d_id, d_fl, d_ctr, nullptr);
-            if (orc == BBDUK_OK && timeline) bbduk_stream_synchronize(device, nullptr);        // so that the operator's time is its own in the table
-            cOp.stop();
-            if (orc != BBDUK_OK) return finish(fail("batch operator", bbduk_last_error(dev)));
-            const int32_t* dl = P.mode == BBDUK_MODE_KTRIM_L ? d_a : (P.mode == BBDUK_MODE_KTRIM_TIPS ? d_b : nullptr);
-            const int32_t* dr = (P.mode == BBDUK_MODE_KTRIM_R || P.mode == BBDUK_MODE_KTRIM_TIPS) ? d_a : nullptr;
-            for (int sel = 0; sel < 2; sel++) {
-                if (fdOut[sel] < 0) continue;
-                const int slot = (int)(outSeq % NO);
-                cWaitOut.start();
-                const bool oko = outSeq < NO || outFreed.wait_above(outSeq - NO);
-                cWaitOut.stop();
-                if (!oko) return finish(fail(failed.load() ? failed.load() : "pipeline stopped", nullptr));
-                int64_t nb = 0;
-                cWriteK.start();
-                const int wrc = bbduk_fastq_write_masked_device(text, d_lines, nullptr, nullptr, n, dl, dr, d_fl, sel, d_mask ? d_off : nullptr, d_mask,
-                                                                maskLower ? -1 : (int)(unsigned char)maskSymbol, dOut[slot], capOut, device, nullptr, &nb);
-                cWriteK.stop();
-                if (wrc != BBDUK_OK) return finish(fail("bbduk_fastq_write_device", nullptr));
-                if (bbduk_copy_async(device, hOut[slot], dOut[slot], nb, 1, outStream[slot]) != BBDUK_OK) return finish(fail("device to host copy", nullptr));
-                push_job(OutJob{slot, nb, sel}, outSeq); outSeq++;
-            }
-            nread += n;
-            text += R.consumed1; have -= R.consumed1;
-            again = have > 0 && (full || fin);
+    long long nread = 0; int rounds = 0;
+    for (;;) {
+        // a text takes its next piece when what it still holds fits the room in front of one (<= chunk): with two files the one that is ahead in
+        // records waits a round while the other catches up, as the serial form's fill-to-chunk does
+        bool took = false;
+        for (int s = 0; s < ns; s++) {
+            InStream& X = S[s];
+            if (X.next >= X.NP || X.have > chunk) continue;
+            const int64_t q = X.next;
+            cWaitUp.start();
+            const bool okq = X.uploaded.wait_above(q);
+            cWaitUp.stop();
+            if (!okq) return finish(fail(failed.load() ? failed.load() : "pipeline stopped", nullptr));
+            uint8_t* fresh = B.D[s][q % ND] + chunk - X.have;
+            cTail.start();
+            if (X.have > 0 && (bbduk_copy_async(device, fresh, X.text, X.have, 2, nullptr) != BBDUK_OK || bbduk_stream_synchronize(device, nullptr) != BBDUK_OK)) return finish(fail("device to device copy", nullptr));
+            cTail.stop();
+            X.devFreed.set(q);                                    // the slots of the pieces before this one can be overwritten
+            X.text = fresh; X.have += std::min(chunk, X.bytes - q * chunk); X.next++; took = true;
         }
-        if (have > chunk) return finish(fail("a FASTQ record exceeds chunk=", nullptr));
-        tailLen = have; tailPtr = text;
+        const bool fin = S[0].next >= S[0].NP && (ns == 1 || S[1].next >= S[1].NP);
+        if (S[0].have == 0 && (ns == 1 || S[1].have == 0)) { if (fin) break; continue; }
+        rounds++;
+        bbduk_fastq_result R;
+        cIngest.start();
+        const int rc = bbduk_fastq_ingest_device(S[0].text, S[0].have, ns == 2 ? S[1].text : nullptr, ns == 2 ? S[1].have : 0, fin ? 1 : 0, maxReads, capBases,
+                                                 B.d_lines[0], ns == 2 ? B.d_lines[1] : nullptr, d_off, d_codes, d_undef, device, nullptr, &R);
+        cIngest.stop();
+        if (rc == BBDUK_ERR_FORMAT) { char m[64]; snprintf(m, sizeof m, "read %lld", nread + (long long)R.first_bad_read); return finish(fail("malformed FASTQ record at", m)); }
+        if (rc != BBDUK_OK) return finish(fail("bbduk_fastq_ingest_device", nullptr));
+        int64_t n = R.n_reads;
+        const bool full = n >= maxReads - (ns == 2 ? 1 : 0);      // the record limit, not the end of the text, ended this round
+        if (paired && ns == 1 && (n & 1)) {                       // interleaved text: a pair stays together; its second record comes with the next piece
+            if (fin && !full) return finish(fail("unpaired or malformed mate at the end of", in1.c_str()));
+            n--;
+            if (bbduk_copy_from_device(device, &R.consumed1, B.d_lines[0] + 4 * n, 8, nullptr) != BBDUK_OK) return finish(fail("device to host copy", nullptr));
+        }
+        if (n == 0) {
+            if (ns == 2 && (S[0].have == 0) != (S[1].have == 0) && (S[0].have == 0 ? S[0].next >= S[0].NP : S[1].next >= S[1].NP))
+                return finish(fail("the two input files hold different numbers of reads", nullptr));
+            if (fin) return finish(fail("truncated FASTQ record at the end of", in1.c_str()));
+            if (!took) return finish(fail("a FASTQ record exceeds chunk=", nullptr));
+            continue;                                             // the next pieces bring the rest
+        }
+        const int64_t total = [&]() { int64_t v = 0; bbduk_copy_from_device(device, &v, d_off + n, 8, nullptr); return v; }();
+        cOp.start();
+        const int orc = kfilter ? bbduk_kfilter_batch_packed_device(dev, d_codes, d_undef, d_off, n, total, paired ? 1 : 0, d_a, d_id, d_fl, d_ctr, nullptr)
+                      : P.mode == BBDUK_MODE_KTRIM_TIPS ? bbduk_ktrimtips_batch_packed_device(dev, d_codes, d_undef, d_off, n, total, paired ? 1 : 0, d_a, d_b, d_id, d_fl, d_ctr, nullptr)
+                      : P.mode == BBDUK_MODE_KMASK ? bbduk_kmask_batch_packed_device(dev, d_codes, d_undef, d_off, n, total, paired ? 1 : 0, d_a, d_id, d_fl, d_mask, d_ctr, nullptr)
+                      : bbduk_ktrim_batch_packed_device(dev, d_codes, d_undef, d_off, n, total, paired ? 1 : 0, d_a, d_id, d_fl, d_ctr, nullptr);
+        if (orc == BBDUK_OK && timeline) bbduk_stream_synchronize(device, nullptr);            // so that the operator's time is its own in the table
+        cOp.stop();
+        if (orc != BBDUK_OK) return finish(fail("batch operator", bbduk_last_error(dev)));
+        const int32_t* dl = P.mode == BBDUK_MODE_KTRIM_L ? d_a : (P.mode == BBDUK_MODE_KTRIM_TIPS ? d_b : nullptr);
+        const int32_t* dr = (P.mode == BBDUK_MODE_KTRIM_R || P.mode == BBDUK_MODE_KTRIM_TIPS) ? d_a : nullptr;
+        for (int sel = 0; sel < 2; sel++) {
+            if (fdOut[sel] < 0) continue;
+            const int slot = (int)(outSeq % NO);
+            cWaitOut.start();
+            const bool oko = outSeq < NO || outFreed.wait_above(outSeq - NO);
+            cWaitOut.stop();
+            if (!oko) return finish(fail(failed.load() ? failed.load() : "pipeline stopped", nullptr));
+            int64_t nb = 0;
+            cWriteK.start();
+            const int wrc = bbduk_fastq_write_masked_device(S[0].text, B.d_lines[0], ns == 2 ? S[1].text : nullptr, ns == 2 ? B.d_lines[1] : nullptr, n, dl, dr, d_fl, sel,
+                                                            d_mask ? d_off : nullptr, d_mask, maskLower ? -1 : (int)(unsigned char)maskSymbol, dOut[slot], capOut, device, nullptr, &nb);
+            cWriteK.stop();
+            if (wrc != BBDUK_OK) return finish(fail("bbduk_fastq_write_device", nullptr));
+            if (bbduk_copy_async(device, hOut[slot], dOut[slot], nb, 1, outStream[slot]) != BBDUK_OK) return finish(fail("device to host copy", nullptr));
+            push_job(OutJob{slot, nb, sel}, outSeq); outSeq++;
+        }
+        nread += n;
+        S[0].text += R.consumed1; S[0].have -= R.consumed1;
+        if (ns == 2) { S[1].text += R.consumed2; S[1].have -= R.consumed2; }
     }
     const double tLoop = now_s();
     if (finish(0) != 0) return 1;
@@ -535,15 +572,15 @@ int run_device_ingest_piped(bbduk_handle* dev, const bbduk_host* host, const Sta
     fprintf(stderr, "Total Removed:          \t%lld reads \t%lld bases\n", (long long)(c[BBDUK_READS_IN] - c[BBDUK_READS_OUTU]), (long long)(c[BBDUK_BASES_IN] - c[BBDUK_BASES_OUTU]));
     fprintf(stderr, "Result:                 \t%lld reads \t%lld bases\n", (long long)c[BBDUK_READS_OUTU], (long long)c[BBDUK_BASES_OUTU]);
     if (timeline) {                                               // one JSON line: where the wall clock went (seconds; stages on different threads overlap)
-        fprintf(stderr, "{\"timeline\": {\"file_bytes\": %lld, \"pieces\": %lld, \"rounds\": %d, \"chunk\": %lld, \"rthreads\": %d, \"wthreads\": %d, "
+        fprintf(stderr, "{\"timeline\": {\"file_bytes\": %lld, \"pieces\": %lld, \"rounds\": %d, \"chunk\": %lld, \"rthreads\": %d, \"wthreads\": %d, \"files\": %d, "
                         "\"startup_to_pipeline\": %.3f, \"open_files\": %.3f, \"wait_buffers\": %.3f, \"buffers_alloc_thread\": %.3f, \"pipeline_wall\": %.3f, \"drain\": %.3f, "
                         "\"reader_pread\": %.3f, \"uploader_h2d\": %.3f, \"main_wait_upload\": %.3f, \"main_tail_copy\": %.3f, \"main_ingest\": %.3f, \"main_operator\": %.3f, "
                         "\"main_write_kernels\": %.3f, \"main_wait_out_slot\": %.3f, \"writer_wait_d2h\": %.3f, \"writer_pwrite\": %.3f, \"out_bytes\": %lld}}\n",
-                (long long)fileBytes, (long long)NP, rounds, (long long)chunk, rthreads, wthreads, tBegin - tProcess, tOpen - tBegin, tAlloc - tOpen, B.seconds, tLoop - tAlloc, tEnd - tLoop,
-                cRead.busy, cUp.busy, cWaitUp.busy, cTail.busy, cIngest.busy, cOp.busy, cWriteK.busy, cWaitOut.busy, cD2H.busy, cWrite.busy, (long long)(outPos[0] + outPos[1]));
+                (long long)(S[0].bytes + S[1].bytes), (long long)(S[0].NP + S[1].NP), rounds, (long long)chunk, rthreads, wthreads, ns, tBegin - tProcess, tOpen - tBegin, tAlloc - tOpen, B.seconds, tLoop - tAlloc, tEnd - tLoop,
+                std::max(S[0].cRead.busy, S[1].cRead.busy), std::max(S[0].cUp.busy, S[1].cUp.busy), cWaitUp.busy, cTail.busy, cIngest.busy, cOp.busy, cWriteK.busy, cWaitOut.busy, cD2H.busy, cWrite.busy, (long long)(outPos[0] + outPos[1]));
     }
     if (c[BBDUK_CTR_STATUS]) return fail("device reported an error status", nullptr);
-    return write_stats(so, host, c, in1, "");
+    return write_stats(so, host, c, in1, in2);
 }
 
 }  // namespace
@@ -651,11 +688,12 @@ int main(int argc, char** argv) {
         const bool can = bbduk_host_params(host, device, &P0) == BBDUK_OK && devices.size() == 1 && P0.mode != BBDUK_MODE_KSPLIT && !(rename && P0.findBestMatch) && !P0.trimFailuresTo1bp;
         deviceIngest = deviceIngestArg < 0 ? can : deviceIngestArg != 0;
     }
-    const bool piped = deviceIngest && pipeline && in2.empty() && tsv.empty() && !(in1.size() > 3 && in1.compare(in1.size() - 3, 3, ".gz") == 0);
+    auto gz = [](const std::string& f) { return f.size() > 3 && f.compare(f.size() - 3, 3, ".gz") == 0; };
+    const bool piped = deviceIngest && pipeline && tsv.empty() && !gz(in1) && !gz(in2);     // plain files, one or two
     if (chunk == 0) chunk = piped ? (64LL << 20) : (256LL << 20);
     if (chunk < 4096) chunk = 4096;
     PipeBufs pipeBufs;
-    if (piped) pipeBufs.start(device, (int64_t)chunk, !out.empty() || !outm.empty());      // (allocated while the map is built)
+    if (piped) pipeBufs.start(device, (int64_t)chunk, in2.empty() ? 1 : 2, !out.empty() || !outm.empty());      // (allocated while the map is built)
 
     if (bbduk_host_load_refs(host, resources.c_str()) < 0) return fail("cannot load ref=", resources.c_str());
     int64_t stored = 0;
@@ -682,7 +720,7 @@ int main(int argc, char** argv) {
         if (rename && P.findBestMatch) return fail("deviceingest=t does not rewrite read names: use rename=t without it", nullptr);
         if (ndev > 1) return fail("deviceingest=t drives one device: use device=", nullptr);
         if (P.trimFailuresTo1bp) return fail("deviceingest=t does not cut discarded reads to one base: use trimfailuresto1bp without it", nullptr);
-        const int rc = piped ? run_device_ingest_piped(dev, host, so, P, in1, paired, out, outm, pipeBufs, maskLower, maskSymbol, rthreads, wthreads, timeline, tProcess)
+        const int rc = piped ? run_device_ingest_piped(dev, host, so, P, in1, in2, paired, out, outm, pipeBufs, maskLower, maskSymbol, rthreads, wthreads, timeline, tProcess)
                              : run_device_ingest(dev, host, so, P, in1, in2, paired, out, outm, tsv, (int64_t)chunk, device, maskLower, maskSymbol);
         if (piped) { pipeBufs.wait(); fflush(stdout); fflush(stderr); g_wd_done = 1; _exit(rc); }   // every file is closed; the buffers go with the process (tearing the runtime down in order costs ~0.1 s of a ~1 s run)
         if (rc == 0) { for (bbduk_handle* hq : devs) bbduk_destroy(hq); bbduk_host_destroy(host); }

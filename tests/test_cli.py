@@ -200,6 +200,47 @@ def test_cli_deviceingest_pipelined(tmp_path, chunk):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("chunk", ["4096", "7001", "3000000", ""])
+def test_cli_deviceingest_pipelined_two_files(tmp_path, chunk):
+    """in= + in2= through the pipeline: each file has its own reader, uploader and tail; the file that is ahead in records waits a round.  The second
+    file's records are a third longer than the first's here (longer names), so the two run out of step at every piece border."""
+    def grow(path_in, path_out, reps, pad):
+        recs = open(path_in, "rb").read().split(b"\n")
+        lines = []
+        for r in range(reps):
+            for i in range(0, len(recs) - 1, 4):
+                lines += [recs[i] + (b" %s%d" % (pad, r)), recs[i + 1], b"+" + (recs[i][1:] if pad else b""), recs[i + 3]]
+        open(path_out, "wb").write(b"\n".join(lines) + b"\n")
+    reps = 300 if chunk in ("3000000", "") else 3                # ~10 MB per file for the piece sizes in megabytes
+    f1, f2 = str(tmp_path / "a1.fq"), str(tmp_path / "a2.fq")
+    grow(os.path.join(GOLD, "cli_c2_r1.fq"), f1, reps, b"")
+    grow(os.path.join(GOLD, "cli_c2_r2.fq"), f2, reps, b"a-much-longer-name-on-the-second-file-")
+    ck = ["chunk=" + chunk] if chunk else []
+    for flags in (["ktrim=r", "k=23", "mink=11", "hdist=1", "ref=adapters", "tpe"], ["ktrim=n", "k=23", "mink=11", "ref=adapters"], ["ktrim=rl", "k=23", "mink=11", "hdist=1", "ref=adapters"],
+                  ["k=25", "hdist=1", "ref=adapters", "rieb=f"]):
+        got = {}
+        for mode, extra in (("host", ["deviceingest=f"]), ("serial", ["deviceingest=t", "pipeline=f"] + ck), ("piped", ["deviceingest=t", "timeline=t"] + ck)):
+            if mode == "host" and reps > 100 and flags[0] != "ktrim=r":
+                continue
+            out, outm = (str(tmp_path / (mode + n)) for n in ("o.fq", "m.fq"))
+            r = run_cli(["in=" + f1, "in2=" + f2, "out=" + out, "outm=" + outm] + flags + extra)
+            assert r.returncode == 0, (flags, mode, r.stderr)
+            got[mode] = (open(out, "rb").read(), open(outm, "rb").read(), [l for l in r.stderr.splitlines() if "reads" in l and not l.startswith("{")])
+            if mode == "piped":
+                tl = json.loads([l for l in r.stderr.splitlines() if l.startswith('{"timeline"')][0])["timeline"]
+                assert tl["files"] == 2 and tl["file_bytes"] == os.path.getsize(f1) + os.path.getsize(f2) and tl["out_bytes"] == len(got[mode][0]) + len(got[mode][1])
+        assert got["piped"] == got["serial"], (flags, chunk)
+        if "host" in got:
+            assert got["piped"] == got["host"], (flags, chunk)
+        assert len(got["piped"][0]) > 1000
+    short = str(tmp_path / "short.fq")
+    open(short, "wb").write(b"\n".join(open(f2, "rb").read().split(b"\n")[:4 * 37]) + b"\n")
+    for extra in (["pipeline=f"], []):
+        r = run_cli(["in=" + f1, "in2=" + short, "k=23", "ref=adapters", "deviceingest=t"] + ck + extra)
+        assert r.returncode == 1 and "different numbers of reads" in r.stderr, r.stderr
+
+
+@pytest.mark.gpu
 def test_cli_picks_the_device_pipeline_by_itself(tmp_path):
     """Without deviceingest= the CLI takes the device pipeline where it serves the run (timeline=t only prints there) and the host parser elsewhere
     (ksplit, trimfailuresto1bp, several devices); the outputs do not depend on the choice."""
