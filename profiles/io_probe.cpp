@@ -1,7 +1,7 @@
 // What the file system of a box gives the deviceingest=t pipeline of bbduk_cli: page-cache read and write rates against thread count.
 //   g++ -O2 -pthread profiles/io_probe.cpp -o /tmp/io_probe && /tmp/io_probe /tmp/io_probe.dat 8
 // (GiB to use, default 8).  One JSON line.  Reads use pread into malloc'ed memory touched beforehand; writes use pwrite (one file, disjoint ranges),
-// then mmap + memcpy (one file, disjoint ranges) since buffered writes to one file take the inode lock on most file systems.
+// then O_DIRECT pwrite, then mmap + memcpy (one file, disjoint ranges) since buffered writes to one file take the inode lock on most file systems.
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -25,6 +25,21 @@ int main(int argc, char** argv) {
         const double s = timed(nt, [&](int me) { for (int64_t off = (int64_t)me * piece; off < total; off += (int64_t)nt * piece) if (pwrite(fd, buf + (size_t)me * piece, piece, off) != piece) abort(); });
         close(fd);
         printf(", \"pwrite_%d_GBps\": %.2f", nt, total / s / 1e9);
+    }
+    {                                                              // O_DIRECT pwrite (page-aligned source, as pinned host memory is)
+        void* ab = nullptr;
+        if (posix_memalign(&ab, 4096, (size_t)piece * 8) == 0) {
+            memset(ab, 'A', (size_t)piece * 8);
+            for (int nt : {1, 4, 8}) {
+                const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC | O_DIRECT, 0644);
+                if (fd < 0) { printf(", \"odirect\": \"not supported\""); break; }
+                bool bad = false;
+                const double s = timed(nt, [&](int me) { for (int64_t off = (int64_t)me * piece; off < total; off += (int64_t)nt * piece) if (pwrite(fd, (uint8_t*)ab + (size_t)me * piece, piece, off) != piece) { bad = true; return; } });
+                close(fd);
+                if (bad) { printf(", \"odirect_pwrite_%d_GBps\": null", nt); } else printf(", \"odirect_pwrite_%d_GBps\": %.2f", nt, total / s / 1e9);
+            }
+            free(ab);
+        }
     }
     for (int nt : {4, 8, 16}) {                                    // mmap + memcpy into a file grown by ftruncate
         const int fd = open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
