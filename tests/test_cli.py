@@ -375,10 +375,11 @@ def test_cli_trimfailuresto1bp_cuts_instead_of_removing(tmp_path):
 @pytest.mark.parametrize("stem,flags", [("cli_sample_ktrimr_k25_phix", ["ktrim=r", "k=25", "ref=phix"]),
                                         ("cli_sample_kfilter_k31_hdist1_phix", ["k=31", "hdist=1", "ref=phix"]),
                                         ("cli_sample_kfilter_k31_mkf_phix", ["k=31", "mkf=0.5", "ref=phix"])])
-def test_cli_on_the_reference_sample_reads(tmp_path, stem, flags):
+@pytest.mark.parametrize("ingest", ["deviceingest=f", "deviceingest=t", "auto"])      # the host parser; the device pipeline through `gzip -dc` (its serial form); what the CLI picks by itself
+def test_cli_on_the_reference_sample_reads(tmp_path, stem, flags, ingest):
     tsv, out, outm = (str(tmp_path / n) for n in ("o.tsv", "clean.fq", "removed.fq"))
     r = run_cli(["in=" + os.path.join(ROOT, "data", "sample1.fq.gz"), "in2=" + os.path.join(ROOT, "data", "sample2.fq.gz"),
-                 "tsv=" + tsv, "out=" + out, "outm=" + outm] + flags)
+                 "tsv=" + tsv, "out=" + out, "outm=" + outm, ingest] + flags)
     assert r.returncode == 0, r.stderr
     assert open(tsv).read() == open(os.path.join(GOLD, stem + ".tsv")).read()
     rows = [l.split("\t") for l in open(tsv).read().splitlines()]
