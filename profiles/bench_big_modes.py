@@ -10,7 +10,8 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 MODES = (("ksplit=t k=31", dict(k=31, ksplit=1), "ksplit"), ("ktrim=n k=31", dict(k=31, ktrimN=1), "kmask"), ("ktrim=rl k=31", dict(k=31, ktrimRight=1, ktrimLeft=1), "tips"),
-         ("k=31 fbm", dict(k=31, findBestMatch=1), "fbm"), ("k=31 mkf=0.1", dict(k=31, minKmerFraction=0.1), "mkf"))
+         ("k=31 fbm", dict(k=31, findBestMatch=1), "fbm"), ("k=31 mkf=0.1", dict(k=31, minKmerFraction=0.1), "mkf"),
+         ("k=40", dict(k=31, kbig=40, maskMiddle=0), "k40"))                   # k > 31 joined the big layout later in round 5 (bbduk_bigs_kbig.hip)
 
 
 def main():
