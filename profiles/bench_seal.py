@@ -9,9 +9,9 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 
-def run(pairs=2_000_000, scaffolds=64, scaffold_len=100_000, args="", check=2000, bucket_bits=0, layout=0):
+def run(pairs=2_000_000, scaffolds=64, scaffold_len=100_000, args="", check=2000, bucket_bits=0, layout=0, gm=0, big_load=0):
     import types
-    a = types.SimpleNamespace(pairs=pairs, scaffolds=scaffolds, scaffold_len=scaffold_len, args=args, check=check, bucket_bits=bucket_bits, layout=layout)
+    a = types.SimpleNamespace(pairs=pairs, scaffolds=scaffolds, scaffold_len=scaffold_len, args=args, check=check, bucket_bits=bucket_bits, layout=layout, gm=gm, big_load=big_load)
     import torch
     from bbtools_amd.seal import Seal
     rng = np.random.default_rng(11)
@@ -33,7 +33,7 @@ def run(pairs=2_000_000, scaffolds=64, scaffold_len=100_000, args="", check=2000
         r[m] = (r[m] + rng.integers(1, 4, int(m.sum()), dtype=np.uint8)) & 3
     reads = np.empty((2 * n, L), np.uint8); reads[0::2] = lut[r1]; reads[1::2] = lut[r2]
     t0 = time.time()
-    g = Seal(a.args, refs=ref_bytes, max_scaffolds=S + 2, hooks={**({2: a.bucket_bits} if a.bucket_bits else {}), **({5: a.layout} if getattr(a, "layout", 0) else {})} or None)     # experiments: BBDUK_HOOK_BUCKET_BITS
+    g = Seal(a.args, refs=ref_bytes, max_scaffolds=S + 2, hooks={**({2: a.bucket_bits} if a.bucket_bits else {}), **({5: a.layout} if getattr(a, "layout", 0) else {}), **({3: a.gm} if getattr(a, "gm", 0) else {}), **({8: a.big_load} if getattr(a, "big_load", 0) else {})} or None)     # experiments: BBDUK_HOOK_BUCKET_BITS
     build_s = time.time() - t0
     nr = 2 * n
     d_bases = torch.from_numpy(reads.reshape(-1)).cuda(); d_off = (torch.arange(nr + 1, dtype=torch.int64) * L).cuda()
@@ -71,12 +71,16 @@ def main():
     ap.add_argument("--check", type=int, default=2000)
     ap.add_argument("--lib", default="", help="experiments: another build under bbtools_amd/ (ab_tsw: stage deletion through the SEAL_TSW environment variable)")
     ap.add_argument("--layout", type=int, default=0, help="BBDUK_HOOK_BIG_LAYOUT on the map: -1 cache-resident, 1 minimizer lines (default: by key count)")
+    ap.add_argument("--gm", type=int, default=0, help="experiments: minimizer length m of the big layout's lines (BBDUK_HOOK_LDS_BITS)")
+    ap.add_argument("--big-load", type=int, default=0, help="experiments: keys per 100 slots the big layout's lines are sized for (BBDUK_HOOK_BIG_LOAD)")
     ap.add_argument("--bucket-bits", type=int, default=0, help="experiments: log2 of the map's bucket count (default: one bucket per key, rounded up)")
     a = ap.parse_args()
     if a.lib:
         from bbtools_amd import bbduk as _B
         _B.use_library(os.path.join(ROOT, "bbtools_amd", a.lib + ".so"))
-    r = run(a.pairs, a.scaffolds, a.scaffold_len, a.args, a.check, a.bucket_bits, a.layout)
+    r = run(a.pairs, a.scaffolds, a.scaffold_len, a.args, a.check, a.bucket_bits, a.layout, a.gm, a.big_load)
+    if a.gm: r["gm"] = a.gm
+    if a.big_load: r["big_load"] = a.big_load
     if a.bucket_bits:
         r["bucket_bits"] = a.bucket_bits
     print(json.dumps(r))
