@@ -441,6 +441,9 @@ def main():
             # big-layout map scanned by bbduk_bigs_every_kernel -- cache-resident at 60-75 Gbases/s until round 5
             out["operators_genome"] = {r["mode"]: {k: r[k] for k in ("args", "keys", "reads", "operator_ms", "Gbases_per_s")} for r in bench_modes.run_genome(a.extra_reads)}
             out["seal"] = bench_seal.run(pairs=1_000_000, check=2000)      # (the first 2 000 pairs replayed by oracle/seal_oracle.c: sample_equals_restatement)
+            # the same number of keys in FOUR scaffolds: the tool's typical binning run (a handful of reference genomes).  Round 5: the per-scaffold
+            # counters go through a cache in the wave's lanes -- one atomic per unit and column serialised the grid here (17 Gbases/s)
+            out["seal_4_scaffolds"] = bench_seal.run(pairs=1_000_000, scaffolds=4, scaffold_len=1_600_000, check=2000)
         except Exception as e:
             out["operators"] = {"error": repr(e)}
         try:                                           # the configs[1] flags on pairs of other lengths (2x151: the tail pass of the main kernel)

@@ -193,6 +193,41 @@ def test_seal_fuzz_parity(seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nscaf,ambig,kpt", [(3, "random", True), (70, "all", False), (300, "random", True), (300, "all", False)])
+def test_seal_scaffold_counters_through_the_wave_cache(nscaf, ambig, kpt):
+    """The per-scaffold counters (stats= / rpkm= columns) are summed in a 64-entry cache per wave (round 5: one atomic per assigned unit and column
+    serialised the grid when a run had few scaffolds -- 4 scaffolds 17 -> 64 Gbases/s).  Few scaffolds (every unit hits the cache), and more scaffolds
+    than a wave's cache holds with enough units per wave that it has to start over: every counter equal to the restatement's."""
+    from bbtools_amd.seal import Seal
+    rng = random.Random(900 + nscaf)
+    shared = rnd_seq(rng, 60)
+    refs = [rnd_seq(rng, 120) + (shared if i % 7 == 0 else b"") + rnd_seq(rng, 60) for i in range(nscaf)]
+    n = 400_000 if nscaf > 64 else 60_000                      # ~100 units per wave on 256 CUs x 16 waves
+    big = b"".join(refs)
+    starts = np.cumsum([0] + [len(r) for r in refs])
+    reads = []
+    prng = np.random.default_rng(nscaf)
+    which = prng.integers(0, nscaf, n); offs = prng.integers(0, 60, n); lens = prng.choice([60, 100, 150], n)
+    for i in range(n):
+        a = int(starts[which[i]] + offs[i])
+        reads.append(big[a:a + int(lens[i])] if i % 50 else rnd_seq(rng, 80))      # (a read may run into the next scaffold: several sites)
+    cfg = dict(k=21, mm=True, hdist=0, rcomp=True, fn=False, match="all", ambig=ambig, kpt=kpt, mkh=1, mkf=0.0, cz=0, czf=0.0, qskip=1, speed=0, rl=0, rr=0,
+               minlength=10, maxlength=0, mlf=0.0, rieb=True, rskip=0)
+    o = SealOracle(refs, **cfg_oracle(cfg))
+    g = Seal(cfg_args(cfg), refs=refs, max_scaffolds=nscaf + 2)
+    want = o.process_reads(reads, True, 5, max_ids=8)
+    got = g.process_reads(reads, True, 5, max_ids=8)
+    for name, w, h in zip(("sites", "assigned", "max", "ids", "flags"), want, got):
+        assert np.array_equal(w, h), name
+    wc = o.counters(); gc = g.counters()
+    assert wc[0] == gc[0]
+    for q in range(1, 5):
+        assert np.array_equal(wc[q], gc[q][:o.num_scaffolds]) and not gc[q][o.num_scaffolds:].any(), q
+    assert int((np.asarray(wc[1]) > 0).sum()) >= min(nscaf, 3)
+    g.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(8))
 def test_seal_units_beyond_the_wave_planes(seed):
     """bbduk_seal_wave_kernel holds units of up to ~690 bases in a wave's own planes and leaves longer ones to the tile kernel launched
