@@ -180,3 +180,33 @@ def test_writer_matches_oracle_and_the_cli_files(tmp_path):
     nb = B.fastq_write_device(d1, fb, None, d_a, d_f, True, d_out, d2)
     assert bytes(d_out[:nb].cpu().numpy()) == open(outm, "rb").read()
     d.close()
+
+
+@pytest.mark.gpu
+def test_memory_and_stream_helpers_round_trip():
+    """The plumbing a caller without HIP bindings uses (bbduk_cli's pipeline): pinned and device buffers, a non-blocking stream, asynchronous copies
+    host -> device -> device -> host and the wait; the synchronous forms beside them."""
+    import ctypes as C
+    L = B.lib()
+    vp = C.c_void_p
+    for f, at in ((L.bbduk_pinned_malloc, [C.c_int64, C.POINTER(vp)]), (L.bbduk_device_malloc, [C.c_int32, C.c_int64, C.POINTER(vp)]), (L.bbduk_stream_create, [C.c_int32, C.POINTER(vp)]),
+                  (L.bbduk_copy_async, [C.c_int32, vp, vp, C.c_int64, C.c_int32, vp]), (L.bbduk_stream_synchronize, [C.c_int32, vp]), (L.bbduk_stream_destroy, [C.c_int32, vp]),
+                  (L.bbduk_copy_from_device, [C.c_int32, vp, vp, C.c_int64, vp]), (L.bbduk_device_memset, [C.c_int32, vp, C.c_int32, C.c_int64, vp]),
+                  (L.bbduk_pinned_free, [vp]), (L.bbduk_device_free, [C.c_int32, vp])):
+        f.argtypes = at; f.restype = C.c_int
+    n = 3_000_001
+    h_in, h_out, d_a, d_b, st = vp(), vp(), vp(), vp(), vp()
+    assert L.bbduk_pinned_malloc(n, C.byref(h_in)) == 0 and L.bbduk_pinned_malloc(n, C.byref(h_out)) == 0
+    assert L.bbduk_device_malloc(0, n, C.byref(d_a)) == 0 and L.bbduk_device_malloc(0, n, C.byref(d_b)) == 0 and L.bbduk_stream_create(0, C.byref(st)) == 0 and st.value
+    src = np.random.default_rng(3).integers(0, 256, n, dtype=np.uint8)
+    C.memmove(h_in.value, src.ctypes.data, n)
+    assert L.bbduk_device_memset(0, d_b, 0, n, None) == 0
+    assert L.bbduk_copy_async(0, d_a, h_in, n, 0, st) == 0 and L.bbduk_copy_async(0, vp(d_b.value + 5), vp(d_a.value + 5), n - 5, 2, st) == 0       # (any alignment)
+    assert L.bbduk_copy_async(0, h_out, d_b, n, 1, st) == 0 and L.bbduk_stream_synchronize(0, st) == 0
+    got = np.ctypeslib.as_array(C.cast(h_out.value, C.POINTER(C.c_uint8)), (n,))
+    assert not got[:5].any() and np.array_equal(got[5:], src[5:])
+    back = np.empty(n, np.uint8)
+    assert L.bbduk_copy_from_device(0, back.ctypes.data, d_a, n, None) == 0 and np.array_equal(back, src)
+    assert L.bbduk_copy_async(0, d_a, h_in, -1, 0, st) != 0 and L.bbduk_copy_async(0, d_a, h_in, 8, 7, st) != 0                               # bad size / kind
+    assert L.bbduk_stream_destroy(0, st) == 0 and L.bbduk_device_free(0, d_a) == 0 and L.bbduk_device_free(0, d_b) == 0
+    assert L.bbduk_pinned_free(h_in) == 0 and L.bbduk_pinned_free(h_out) == 0
