@@ -183,7 +183,7 @@ extern "C" int bbduk_create(const bbduk_params* p, bbduk_handle** out) {
     if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return BBDUK_ERR_DEVICE; }
     const size_t nc = (size_t)(BBDUK_NCOUNTERS + 2 * p->numScaffolds);
     if (hipMalloc(&h->d_counters, nc * sizeof(int64_t)) != hipSuccess ||
-        hipMemset(h->d_counters, 0, nc * sizeof(int64_t)) != hipSuccess || hipMalloc(&h->d_slowFlag, 4 * bbduk_handle::EV_RING * sizeof(int)) != hipSuccess) { hipStreamDestroy(h->stream); delete h; return BBDUK_ERR_DEVICE; }
+        hipMemset(h->d_counters, 0, nc * sizeof(int64_t)) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess || hipMalloc(&h->d_slowFlag, 4 * bbduk_handle::EV_RING * sizeof(int)) != hipSuccess) { hipStreamDestroy(h->stream); delete h; return BBDUK_ERR_DEVICE; }
     *out = h;
     return BBDUK_OK;
 }
@@ -1190,6 +1190,8 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
         return fail(h, BBDUK_ERR_STATE, "big-layout map with a scan its kernels do not serve (BBDUK_HOOK_PAIR_SCAN serves plain kfilter only)");
     // a big-layout map with a cache-resident twin (build_both): the wave kernel scans the big layout, the fallbacks for units beyond a wave's
     // planes (tile kernel, long-read kernel) run their cache-resident instantiations over the twin
+    // every unit to the kernel that holds it (not where the pre-pass flag is set by hand: query expansion and BBDUK_HOOK_FORCE_TILE send whole batches to the tiled kernel)
+    K.route = (query_expansion(h->p) || h->hookForceTile) ? 0 : 1; K.wunitMax = (int32_t)wunitMax;
     const bool twin = (K.big || K.seed) && h->hasAlt;
     const KParams K2 = twin ? alt_kparams(h, K) : K;
     const size_t dynLds2 = twin ? (K2.ldsBits ? ((size_t)1 << (K2.ldsBits - 3)) : 0) : dynLds;
@@ -1321,7 +1323,7 @@ static int host_batch(bbduk_handle* h, int wantKfilter, const uint8_t* bases, co
     }
     struct Release { bbduk_handle* h; bbduk_handle::Slot* S; ~Release() { { std::lock_guard<std::mutex> lk(h->slotMu); S->busy = false; } h->slotCv.notify_one(); } } rel{h, S};
     if (!S->stream) HIP_TRY(h, hipStreamCreateWithFlags(&S->stream, hipStreamNonBlocking));
-    if (!S->d_status) { HIP_TRY(h, hipMalloc(&S->d_status, sizeof(int64_t))); HIP_TRY(h, hipMemset(S->d_status, 0, sizeof(int64_t))); }
+    if (!S->d_status) { HIP_TRY(h, hipMalloc(&S->d_status, sizeof(int64_t))); HIP_TRY(h, hipMemset(S->d_status, 0, sizeof(int64_t))); HIP_TRY(h, hipStreamSynchronize(nullptr)); }
     // a capacity is recorded only once its buffers exist: a failed hipMalloc leaves the handle usable for a smaller batch
     if (undefBytes + 8 > S->cap_undef) {
         hipFree(S->d_undef); S->d_undef = nullptr; S->cap_undef = 0;
@@ -1743,6 +1745,10 @@ extern "C" int bbduk_reset_counters(bbduk_handle* h) {
     std::lock_guard<std::mutex> g(h->mu);
     HIP_TRY(h, hipSetDevice(h->p.device));
     HIP_TRY(h, hipMemset(h->d_counters, 0, (size_t)bbduk_counters_len(h) * sizeof(int64_t)));
+    // hipMemset on device memory returns before the fill has run, and the null stream does not order against the operators' non-blocking streams:
+    // a batch submitted right behind this call could add its counters and THEN be zeroed (round 5: seen as lost counts under a loaded GPU once a batch
+    // with long units ran three kernels instead of one).  The counters are zero when this returns.
+    HIP_TRY(h, hipStreamSynchronize(nullptr));
     return BBDUK_OK;
 }
 

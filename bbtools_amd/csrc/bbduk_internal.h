@@ -18,6 +18,9 @@ struct KParams {
     float   mkf, mcf;            // kfilter: minkmerfraction / mincoveredfraction (general kernels only)
     int32_t mfc;                 // kmaskfullycovered (ktrim=n): mask only bases all of whose covering k-mers match
     int32_t tf;                  // trimfailuresto1bp (rieb is then off): see tf1bp()
+    int32_t route, wunitMax;     // route != 0 (ktrim=r|l, kfilter; round 5): every UNIT goes to the kernel that holds it -- the wave kernel takes the units of up to
+                                 // wunitMax bases, the tiled kernel the ones up to CAP_BASES - 64, the chunked long-unit kernel the rest -- instead of the whole batch
+                                 // following its longest unit (one 60 kb read among 8 M short ones: 522 -> 32 Gbases/s)
     int32_t kbig, fbm;           // kfilter variants of bbduk_kscan_kernel: k>31 emulation (kbig>k), findBestMatch
     int32_t* matchN; int32_t* matchIds; int32_t* matchCnt; int32_t matchCap;    // findBestMatch's idList / countList per read (rename, :2508-2522), or null
     int32_t* outLeft; int32_t* outRight;   // ksplit: the span it computes per read (leftmost, rightmost), or -1, -1
