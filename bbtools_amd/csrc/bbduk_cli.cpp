@@ -406,9 +406,10 @@ int run_device_ingest_piped(bbduk_handle* dev, const bbduk_host* host, const Sta
     for (int s = 0; s < ns; s++) {
         const std::string& path = s ? in2 : in1;
         S[s].fd = open(path.c_str(), O_RDONLY);
-        if (S[s].fd < 0) return fail("cannot open", path.c_str());
+        if (S[s].fd < 0) { if (s) close(S[0].fd); return fail("cannot open", path.c_str()); }
         struct stat sb;
-        if (fstat(S[s].fd, &sb) != 0) return fail("cannot stat", path.c_str());
+        if (fstat(S[s].fd, &sb) != 0) { for (int t = 0; t <= s; t++) close(S[t].fd); return fail("cannot stat", path.c_str()); }
+        if (!S_ISREG(sb.st_mode)) { for (int t = 0; t <= s; t++) close(S[t].fd); return fail("the pipelined ingest reads regular files (pipeline=f serves pipes and devices)", path.c_str()); }
         S[s].bytes = (int64_t)sb.st_size; S[s].NP = (S[s].bytes + B.chunk - 1) / B.chunk;
     }
     const int64_t chunk = B.chunk; const int device = B.device;
@@ -707,7 +708,10 @@ int main(int argc, char** argv) {
         deviceIngest = deviceIngestArg < 0 ? can : deviceIngestArg != 0;
     }
     auto gz = [](const std::string& f) { return f.size() > 3 && f.compare(f.size() - 3, 3, ".gz") == 0; };
-    const bool piped = deviceIngest && pipeline && tsv.empty() && !gz(in1) && !gz(in2);     // plain files, one or two
+    // (the pipelined form sizes its pieces from st_size and reads them with pread: regular files only.  /dev/stdin, a named pipe or <(zcat ..) report
+    // st_size = 0 -- the run would print "Input: 0 reads" and exit 0 -- so those take the serial form, which reads its FILE* to the end: ADVICE r5)
+    auto regular = [](const std::string& f) { struct stat sb; return f.empty() || (stat(f.c_str(), &sb) == 0 && S_ISREG(sb.st_mode)); };
+    const bool piped = deviceIngest && pipeline && tsv.empty() && !gz(in1) && !gz(in2) && regular(in1) && regular(in2);     // plain files, one or two
     if (chunk == 0) chunk = piped ? ((64LL << 20) / (in2.empty() ? 1 : 2)) : (256LL << 20);      // (64 MiB of text per round, over one file or two: the pinned buffers are what start-up pays for)
     if (chunk < 4096) chunk = 4096;
     PipeBufs pipeBufs;

@@ -259,6 +259,29 @@ def test_cli_picks_the_device_pipeline_by_itself(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_reads_a_named_pipe_to_its_end(tmp_path):
+    """in= may be a FIFO, /dev/stdin or <(zcat ..): st_size is 0 there, and the pipelined ingest (the default) sizes its pieces from st_size -- such inputs
+    take the serial form instead of reporting 'Input: 0 reads' with exit status 0."""
+    import threading
+    f1 = os.path.join(GOLD, "cli_c3_interleaved.fq")
+    want = str(tmp_path / "file.fq")
+    r0 = run_cli(["in=" + f1, "int=t", "out=" + want, "k=31", "hdist=1", "ref=phix", "auto"])
+    assert r0.returncode == 0, r0.stderr
+    fifo, got = str(tmp_path / "in.fifo"), str(tmp_path / "fifo.fq")
+    os.mkfifo(fifo)
+    def feed():
+        with open(fifo, "wb") as w, open(f1, "rb") as src:
+            w.write(src.read())
+    t = threading.Thread(target=feed); t.start()
+    r = run_cli(["in=" + fifo, "int=t", "out=" + got, "k=31", "hdist=1", "ref=phix", "auto"])
+    t.join()
+    assert r.returncode == 0, r.stderr
+    assert open(got, "rb").read() == open(want, "rb").read()
+    line = lambda s: [l for l in s.splitlines() if l.startswith("Input:")]
+    assert line(r.stderr) == line(r0.stderr) and "\t0 reads" not in line(r.stderr)[0]
+
+
+@pytest.mark.gpu
 def test_cli_deviceingest_rejects_what_it_cannot_serve(tmp_path):
     f1 = os.path.join(GOLD, "cli_c2_r1.fq")
     r = run_cli(["in=" + f1, "ksplit=t", "k=23", "ref=adapters", "deviceingest=t"])

@@ -60,3 +60,48 @@ def test_every_native_method_has_its_shim(src):
         assert cparams[2:] == ptypes, (sym, cparams[2:], ptypes)
     left = set(shims) - {"Java_%s_%s_%s" % (pkg, cls, n) for n in nat}
     assert not left, "shims without a native declaration: %s" % sorted(left)
+
+
+def _split_args(text):
+    """top-level comma split of a Java argument list"""
+    out, depth, cur = [], 0, ""
+    for ch in text:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip()); cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def test_batcher_calls_only_what_bbdukgpu_declares():
+    """integration/java/bbduk/BBDukGpuBatcher.java (the pass A / device call / pass B aggregator of INTEGRATION.md section 2) has never met javac either:
+    every BBDukGpu.<method>(...) it calls must be a public static method of BBDukGpu.java with that many parameters, every BBDukGpu.<CONSTANT> it names
+    must be declared there, and the operators it drives must cover every mode constant."""
+    d = os.path.join(ROOT, "integration", "java", "bbduk")
+    strip = lambda t: re.sub(r"/\*.*?\*/", "", re.sub(r"//[^\n]*", "", t), flags=re.S)
+    gpu, bat = strip(open(os.path.join(d, "BBDukGpu.java")).read()), strip(open(os.path.join(d, "BBDukGpuBatcher.java")).read())
+    decl = {}
+    for m in re.finditer(r"public\s+static\s+[\w\[\]<>]+\s+(\w+)\s*\(([^)]*)\)\s*\{", gpu, re.S):
+        decl[m.group(1)] = [p.split()[0] for p in _split_args(m.group(2))]
+    consts = set(re.findall(r"\b([A-Z][A-Z0-9_]+)\s*=\s*\d+", gpu))
+    calls = 0
+    for m in re.finditer(r"BBDukGpu\.(\w+)\s*\(", bat):
+        name, i, depth = m.group(1), m.end(), 1
+        while depth:
+            depth += {"(": 1, ")": -1}.get(bat[i], 0); i += 1
+        args = _split_args(bat[m.end():i - 1])
+        assert name in decl, "BBDukGpu has no public static %s" % name
+        assert len(args) == len(decl[name]), (name, args, decl[name])
+        calls += 1
+    assert calls >= 8
+    used = set(re.findall(r"BBDukGpu\.([A-Z][A-Z0-9_]+)\b", bat))
+    assert used <= consts, used - consts
+    assert {c for c in consts if c.startswith("MODE_")} - {"MODE_KFILTER"} <= used      # (kfilter is the switch's default branch)
+    for t in ("shared.TrimRead", "stream.Read", "structures.ListNum"):                  # the reference classes it leans on, by their real packages
+        assert "import %s;" % t in bat
