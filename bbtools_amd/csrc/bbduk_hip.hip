@@ -318,7 +318,10 @@ static bool big_geometry(bbduk_handle* h, const double maxKeys = 0.0) {
         // + c with c = 1 for short halves and 3 from H = 13 on (k = 27: 3e7 keys m = 7 265, 8 259; k = 31: 4.6 M keys m = 6 288, 7 308, 8 311), at most
         // H - 2 (W >= 3), and never less than log2(keys) - 1 bits.
         const double L2 = std::log2(std::max(maxKeys, 1024.0));
-        const int c = std::max(1, std::min(3, H - 10));
+        // Round 6 (128-byte lines: a crowded line's full pairs overflow into its other half before anything is spilled): the 10^10-key map takes m = 9, W = 7 --
+        // 31 lines per 150-base read instead of 35, 1.7 % of the keys spilled at 0.5 per slot, 208 against 195 Gbases/s (profiles/r06_c4_sweep.jsonl); m = 8
+        // overflows its secondary map there.  10^10 / 4^18 = 0.15 reference positions per minimizer value is what the lines take: c = 2.75 from H = 13 on.
+        const double c = H >= 13 ? 2.75 : (double)std::max(1, H - 10);
         const int need = (int)std::ceil((L2 + c) / 4.0), least = (int)std::ceil((L2 - 1.0) / 4.0);
         h->gm = std::max(std::min(6, H - 1), std::min(std::min(10, H - 1), std::max(least, std::min(need, std::max(6, H - 2)))));
     }
@@ -341,6 +344,12 @@ static Sink make_sink(const bbduk_handle* h, const BuildState* st) {
 // qhdist / qhdist2 > 0: every query k-mer is looked up with its whole Hamming neighbourhood (1 + 3k lookups per position at distance 1).  Only the
 // tiled kernels carry that code; the wave kernels stand back (their flag starts at 1).
 static bool query_expansion(const bbduk_params& p) { return p.qhdist > 0 || (p.qhdist2 > 0 && p.mink > 0 && p.mink < p.k); }
+// Round 6: a handle whose expansion is tabulated (qx_rewrite: the map the kernels look up is keyed by the forward k-mer, no expansion left to do) runs the
+// wave kernels like any rcomp=f handle -- the stream scans in their every-hit form (exact hit plane by qx_lookup, bbduk_stream_scan.inc), the pair scans
+// with exact lookups.  Not with restrictright: a span that starts inside the read cuts the windows in front of it, and a cut window's rkmer is not its
+// kmer's reverse complement -- the tiled kernels keep those handles.
+static bool qx_fast(const bbduk_handle* h) { return h->qx && h->p.restrictRight <= 0; }
+static bool expands_on_tiles(const bbduk_handle* h) { return query_expansion(h->p) && !qx_fast(h); }
 static bool params_general(const bbduk_params& p) {               // the same predicate as pick_kernel's, on the boundary struct
     const bool useShort = p.mink > 0 && p.mink < p.k;
     return p.qhdist > 0 || p.qhdist2 > 0 || p.restrictLeft > 0 || p.restrictRight > 0 || p.skipR1 || p.skipR2 || !p.rcomp ||
@@ -460,38 +469,41 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
         hipMemsetAsync(h->d_tags, 0, (snb + 1) * 8, h->stream);
         hipMemsetAsync(h->d_bkv, 0xFF, 4 * snb * sizeof(uint4), h->stream);
     } else if (st->big) {
-        // 32-slot lines at ~0.6 keys per slot (the lines' loads vary with the minimizers: 10 % of them overflow into the next line
-        // there, 3 % of the keys); a tighter fit is tried when HBM is short.  12 or 14 bytes per slot: 10^10 keys = 200-233 GB.
+        // Lines at 0.3-0.6 keys per slot (the lines' loads vary with the minimizers).  12 or 14 bytes per slot: 10^10 keys = 200-240 GB.
+        // Round 6: the 32-bit / wide line functions' maps (gV32) have 128-byte lines of 64 slots (big_words32: a full pair overflows into the line's other
+        // half before anything is spilled); round 2's 52-bit form behind its hook keeps 64-byte lines of 32 slots.
         const int idBytes = (h->p.numScaffolds <= 65535 && !h->sealTable) ? 2 : 4;      // (a Seal record is a scaffold or SEAL_MULTI | offset into the id lists: 32 bits)
+        const int lineSlots = h->gV32 ? 64 : 32;
         size_t freeB = 0, totalB = 0;
         if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return bail(BBDUK_ERR_DEVICE, "hipMemGetInfo");
-        // the secondary map holds what the lines spill (both words of a key full): ~6 % of the keys at 0.6 keys per slot; its
-        // buckets are sized for twice that at 2.5 keys per bucket (it keeps working, with longer chains, until it is full)
+        // the secondary map holds what the lines spill: 64-byte lines ~6 % of the keys at 0.6 keys per slot, 128-byte lines 1-3 % (profiles/sim_lines.c; both
+        // pairs of a key full); its buckets are sized for twice that at 2.5 keys per bucket (it keeps working, with longer chains, until it is full)
         // (+ the short k-mers of mink, which live there alone -- big_insert: h->expectShort, where the caller can tell)
         int sbits = 10;
-        while (sbits < 29 && (double)(1ULL << sbits) < 0.12 * maxKeys / 2.5 + h->expectShort / 2.0) sbits++;
+        // (a map that fills HBM -- 10^10 keys -- sizes it for 3 %: 1.7-2.4 % spill at 0.5-0.55 keys per slot, profiles/r06_c4_sweep.jsonl, and the ten gigabytes go to the lines)
+        while (sbits < 29 && (double)(1ULL << sbits) < (h->gV32 ? (maxKeys > 4e9 ? 0.03 : 0.06) : 0.12) * maxKeys / 2.5 + h->expectShort / 2.0) sbits++;
         const uint64_t snb = 1ULL << sbits;
-        const double perLine = 64.0 + 256.0 + 32.0 * idBytes, spillBytes = (double)snb * (8.0 + 64.0);
+        const double perLine = (double)lineSlots * (2.0 + 8.0 + idBytes), spillBytes = (double)snb * (8.0 + 64.0);
         uint64_t nlines = 0;
-        // The 32-bit variant's scan (bbduk_bigs.inc) does not look into the secondary map while it streams: a window whose primary word carries its
-        // spill bit becomes a candidate and is looked up afterwards, so spilled keys should be rare -- 0.30 keys per slot: ~1.9 % of the keys
-        // spill, ~0.9 % of the absent windows meet their bit (0.6 keys per slot: 6.4 % / 5.5 %; line-load simulation, 4.6 M keys, m = 8..10).  Such
-        // maps are at most 2^31 keys = 80 GB, so the room is there; the 10^10-key map keeps 0.6.
-        const double loads32[3] = {0.30, 0.45, 0.6}, loads52[3] = {0.6, 0.7, 0.8};
-        for (int li = 0; li < 3; li++) {
+        // The stream scan (bbduk_bigs.inc) does not look beyond a window's primary pair while it streams: a window whose pair carries its class bit
+        // becomes a candidate and is looked up afterwards, so full pairs should be rare -- 0.30 keys per slot where the room is there (maps of up to
+        // 2^31 keys = 80 GB); the 10^10-key map takes what HBM leaves it (0.5-0.6).
+        const double loads32[5] = {0.30, 0.45, 0.5, 0.55, 0.6}, loads52[5] = {0.6, 0.7, 0.8, 0.8, 0.8};
+        for (int li = 0; li < 5; li++) {
             const double load = (h->hookBigLoad > 0 && li == 0) ? 0.01 * h->hookBigLoad : (h->gV32 ? loads32[li] : loads52[li]);
-            nlines = std::max<uint64_t>(64, (uint64_t)(maxKeys / (32.0 * load)) + 1);
-            if (nlines < (1ULL << 29) && (double)nlines * perLine + spillBytes + 3e9 < (double)freeB) break;      // (2^29 lines: the 32-bit tag word index)
+            nlines = std::max<uint64_t>(64, (uint64_t)(maxKeys / ((double)lineSlots * load)) + 1);
+            // (beyond 0.45 the map is filling the device: leave the batches 20 GB -- 100 M reads of 2x150 with their offsets and results are 17)
+            if (nlines < (1ULL << 29) && (double)nlines * perLine + spillBytes + (li >= 2 && li < 4 ? 20e9 : 3e9) < (double)freeB) break;      // (2^29 lines: the 32-bit pair index of the scan's gathers)
             nlines = 0;
         }
-        if (!nlines) return bail(BBDUK_ERR_NOMEM, "the map does not fit this device's memory (or the 32-bit tag word index: 2^29 lines)");
-        if (hipMalloc(&h->d_bigTags, nlines * 64) != hipSuccess || hipMalloc(&h->d_bigKeys, nlines * 256) != hipSuccess ||
-            hipMalloc(&h->d_bigIds, nlines * 32 * (size_t)idBytes) != hipSuccess ||
+        if (!nlines) return bail(BBDUK_ERR_NOMEM, "the map does not fit this device's memory (or the 32-bit pair index: 2^29 lines)");
+        if (hipMalloc(&h->d_bigTags, nlines * 2 * (size_t)lineSlots) != hipSuccess || hipMalloc(&h->d_bigKeys, nlines * 8 * (size_t)lineSlots) != hipSuccess ||
+            hipMalloc(&h->d_bigIds, nlines * lineSlots * (size_t)idBytes) != hipSuccess ||
             hipMalloc(&h->d_tags, (snb + 1) * 8) != hipSuccess || hipMalloc(&h->d_bkv, 4 * snb * sizeof(uint4)) != hipSuccess) return bail(BBDUK_ERR_NOMEM, "hipMalloc (map)");
         h->big = true; h->bigLines = (uint32_t)nlines; h->bigIdBytes = idBytes; h->nbuckets = snb; h->bucketBits = sbits;
-        hipMemsetAsync(h->d_bigTags, 0, nlines * 64, h->stream);
-        hipMemsetAsync(h->d_bigKeys, 0xFF, nlines * 256, h->stream);
-        hipMemsetAsync(h->d_bigIds, 0xFF, nlines * 32 * (size_t)idBytes, h->stream);
+        hipMemsetAsync(h->d_bigTags, 0, nlines * 2 * (size_t)lineSlots, h->stream);
+        hipMemsetAsync(h->d_bigKeys, 0xFF, nlines * 8 * (size_t)lineSlots, h->stream);
+        hipMemsetAsync(h->d_bigIds, 0xFF, nlines * lineSlots * (size_t)idBytes, h->stream);
         hipMemsetAsync(h->d_tags, 0, (snb + 1) * 8, h->stream);      // (+ the dummy word behind the last bucket: see StreamProbe)
         hipMemsetAsync(h->d_bkv, 0xFF, 4 * snb * sizeof(uint4), h->stream);
     } else {
@@ -948,7 +960,8 @@ static int build_device_once(bbduk_handle* h, const uint8_t* refs, const int64_t
 }
 
 // diagnostics of the big layout (include/bbduk_test_hooks.h): how many lines hold 0..32 keys
-__global__ void bbduk_line_hist_kernel(const uint64_t* __restrict__ keys, const uint32_t nlines, unsigned long long* __restrict__ hist) {
+// (32 slots each: the 64-byte lines of round 2's form, or the HALVES of the 128-byte lines)
+__global__ void bbduk_line_hist_kernel(const uint64_t* __restrict__ keys, const uint64_t nlines, unsigned long long* __restrict__ hist) {
     for (uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; l < nlines; l += (uint64_t)gridDim.x * blockDim.x) {
         int c = 0;
         for (int q = 0; q < 32; q++) c += keys[32ULL * l + q] != EMPTY_KEY;
@@ -963,7 +976,7 @@ extern "C" int bbduk_table_line_histogram(bbduk_handle* h, int64_t* out33) {
     unsigned long long* d = nullptr;
     HIP_TRY(h, hipMalloc(&d, 33 * 8));
     hipMemsetAsync(d, 0, 33 * 8, h->stream);
-    bbduk_line_hist_kernel<<<dim3(h->numCU * 16), dim3(256), 0, h->stream>>>(h->d_bigKeys, h->bigLines, d);
+    bbduk_line_hist_kernel<<<dim3(h->numCU * 16), dim3(256), 0, h->stream>>>(h->d_bigKeys, (uint64_t)h->bigLines * (h->gV32 ? 2 : 1), d);
     hipMemcpyAsync(out33, d, 33 * 8, hipMemcpyDeviceToHost, h->stream);
     const hipError_t e = hipStreamSynchronize(h->stream);
     hipFree(d);
@@ -974,7 +987,7 @@ extern "C" int64_t bbduk_table_spilled(const bbduk_handle* h) { return (h && h->
 extern "C" int64_t bbduk_table_size(const bbduk_handle* h) { return (h && h->finalized) ? (h->qx ? h->nkeysQx : ((h->seed && h->nkeysRef > 0) ? h->nkeysRef : h->nkeys)) : -1; }
 extern "C" int64_t bbduk_table_bytes(const bbduk_handle* h) {
     if (!h || !h->finalized) return -1;
-    if (h->big) return (int64_t)h->bigLines * (64 + 256 + 32 * h->bigIdBytes) + (int64_t)(h->nbuckets * (8 + 4 * 16)) +
+    if (h->big) return (int64_t)h->bigLines * (h->gV32 ? 2 : 1) * (64 + 256 + 32 * h->bigIdBytes) + (int64_t)(h->nbuckets * (8 + 4 * 16)) +
                        (h->hasAlt ? (int64_t)(h->nbucketsAlt * (8 + 4 * 16)) + (h->ldsBitsAlt ? (1LL << (h->ldsBitsAlt - 3)) : 0) : 0);
     return (int64_t)(h->nbuckets * (8 + 4 * 16)) + (h->ldsBits ? (1LL << (h->ldsBits - 3)) : 0) +
            (h->hasAlt ? (int64_t)(h->nbucketsAlt * (8 + 4 * 16)) + (h->ldsBitsAlt ? (1LL << (h->ldsBitsAlt - 3)) : 0) : 0) +      // (a seed-layout map's twin)
@@ -1074,7 +1087,7 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     int* const d_flag = h->d_slowFlag + 4 * evi;      // [0] pre-pass bits (1: a unit beyond a wave's planes, 2: beyond the tile kernel's)
     HIP_TRY(h, ring_acquire(h, evi, st));
     HIP_TRY(h, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), st));
-    if (query_expansion(h->p)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
+    if (expands_on_tiles(h)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
     {   // pre-pass per READ: one beyond the tiled kernel's planes sends the batch to bbduk_kscan_long_kernel; ksplit: one beyond a
         // wave's planes (bit 0) sends it to the tiled kernel, else bbduk_wave_kernel<KSPLIT> takes it
         const int sgrid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)h->numCU * 8);
@@ -1157,12 +1170,13 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     size_t waveLdsUse = waveLds;
     int64_t wunitMax = WUNIT_MAX;
     // (query expansion -- qhdist -- runs on the tiled kernels: the pre-pass flag starts at 1 for such handles)
-    if (firstHit && !K.big && !K.seed && K.bucketBits <= 28 && K.qhdist == 0 && K.qhdist2 == 0 && !h->hookPairScan) {
+    if (firstHit && !K.big && !K.seed && K.bucketBits <= 28 && K.qhdist == 0 && K.qhdist2 == 0 && !h->hookPairScan && !h->qx) {
         const bool general = kparams_general(K);
         kp.wave = bbduk_pick_stream(K.mode, K.useShort != 0, K.forbidNs != 0, packed, general);
         if (K.forbidNs || general) { waveLdsUse = dynLds + WAVE_LDS_BYTES_KM; wunitMax = WUNIT_MAX_KM; }      // four planes per wave (wave_body: FOURP)
     }
-    const bool everyStream = !firstHit && (K.mode == BBDUK_MODE_KTRIM_L || K.mode == BBDUK_MODE_KFILTER) && stream_every_ok(h, K);
+    // (the tabulated query expansion: its first-hit operators take the every-hit form too -- the candidates that see an undefined base need the lanes = candidates verification)
+    const bool everyStream = (!firstHit || qx_fast(h)) && (K.mode == BBDUK_MODE_KTRIM_L || K.mode == BBDUK_MODE_KFILTER || (K.mode == BBDUK_MODE_KTRIM_R && qx_fast(h))) && stream_every_ok(h, K);
     if (everyStream) {                                            // ktrim=l, kfilter with a threshold: the stream scan + the exact hit plane
         const bool general = kparams_general(K);
         kp.wave = bbduk_pick_stream_every(K.mode, K.useShort != 0, K.forbidNs != 0, general);
@@ -1191,7 +1205,7 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     // a big-layout map with a cache-resident twin (build_both): the wave kernel scans the big layout, the fallbacks for units beyond a wave's
     // planes (tile kernel, long-read kernel) run their cache-resident instantiations over the twin
     // every unit to the kernel that holds it (not where the pre-pass flag is set by hand: query expansion and BBDUK_HOOK_FORCE_TILE send whole batches to the tiled kernel)
-    K.route = (query_expansion(h->p) || h->hookForceTile) ? 0 : 1; K.wunitMax = (int32_t)wunitMax;
+    K.route = (expands_on_tiles(h) || h->hookForceTile) ? 0 : 1; K.wunitMax = (int32_t)wunitMax;
     const bool twin = (K.big || K.seed) && h->hasAlt;
     const KParams K2 = twin ? alt_kparams(h, K) : K;
     const size_t dynLds2 = twin ? (K2.ldsBits ? ((size_t)1 << (K2.ldsBits - 3)) : 0) : dynLds;
@@ -1204,7 +1218,7 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     int* const d_flag = h->d_slowFlag + 4 * evi;      // [0] pre-pass bits (1: a unit beyond a wave's planes, 2: beyond the tile kernel's)
     HIP_TRY(h, ring_acquire(h, evi, st));
     HIP_TRY(h, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), st));
-    if (query_expansion(h->p)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
+    if (expands_on_tiles(h)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
     if (h->hookForceTile) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }
     {
         const int64_t units = paired ? n / 2 : n;
@@ -1434,7 +1448,7 @@ static int launch_tips(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d
     int* const d_flag = h->d_slowFlag + 4 * evi;      // [0] pre-pass bits (1: a unit beyond a wave's planes, 2: beyond the tile kernel's)
     HIP_TRY(h, ring_acquire(h, evi, st));
     HIP_TRY(h, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), st));
-    if (query_expansion(h->p)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
+    if (expands_on_tiles(h)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
     {   // pre-pass: a unit (pair) beyond a wave's planes (bit 0) sends the batch to the tiled kernel, a READ beyond the tiled kernel's
         // planes (bit 1) to bbduk_long_tips_kernel; else bbduk_wave_kernel<KTRIM_TIPS> takes it
         const int64_t units = paired ? n / 2 : n;
@@ -1550,7 +1564,7 @@ static int launch_kmask(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     int* const d_flag = h->d_slowFlag + 4 * evi;      // [0] pre-pass bits (1: a unit beyond a wave's planes, 2: beyond the tile kernel's)
     HIP_TRY(h, ring_acquire(h, evi, st));
     HIP_TRY(h, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), st));
-    if (query_expansion(h->p)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
+    if (expands_on_tiles(h)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
     if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
     {   // pre-pass: a unit (pair) beyond a wave's planes sends the batch to the tiled kernel (which in turn leaves the reads beyond ITS planes
         // to bbduk_kmask_long_kernel); else bbduk_wave_kernel<KMASK> takes it

@@ -46,8 +46,8 @@ struct KParams {
     // fingerprint from mix_a; probing walks the line's words cyclically, then the next line.  Keys and ids live in two slot-parallel
     // arrays (8 + 2|4 bytes) touched only on a fingerprint match.  See "big layout" in bbduk_hip.hip.
     int32_t  big;
-    const uint64_t* bigTags;    // [8 * bigLines] tag words; `tags` / `bkv` above then hold the secondary map of the spilled keys
-    const uint64_t* bigKeys;    // [32 * bigLines], EMPTY_KEY = free
+    const uint64_t* bigTags;    // [16 * bigLines] tag words (128-byte lines, round 6; round 2's form behind the 52-bit hook: 8); `tags` / `bkv` above then hold the secondary map of the spilled keys
+    const uint64_t* bigKeys;    // [64 * bigLines], EMPTY_KEY = free
     const void*     bigIds;     // uint16 or uint32 per slot
     int32_t  bigIdBytes;
     uint32_t bigLines;

@@ -20,7 +20,8 @@ batch_kernel_t bbduk_pick_stream_every(int mode, bool useShort, bool forbidN, bo
         if (general) return bbduk_stream_every_kernel<BBDUK_MODE_KFILTER, true, true, true>;
         return forbidN ? bbduk_stream_every_kernel<BBDUK_MODE_KFILTER, false, true, false> : bbduk_stream_every_kernel<BBDUK_MODE_KFILTER, false, false, false>;
     }
-    if (general) return bbduk_stream_every_kernel<BBDUK_MODE_KTRIM_L, true, true, true>;
+    // (ktrim=r as an every-hit scan, round 6: handles whose query-side expansion is tabulated -- launch_batch)
+    if (general) return mode == BBDUK_MODE_KTRIM_R ? bbduk_stream_every_kernel<BBDUK_MODE_KTRIM_R, true, true, true> : bbduk_stream_every_kernel<BBDUK_MODE_KTRIM_L, true, true, true>;
     if (useShort) return forbidN ? bbduk_stream_every_kernel<BBDUK_MODE_KTRIM_L, true, true, false> : bbduk_stream_every_kernel<BBDUK_MODE_KTRIM_L, true, false, false>;
     return forbidN ? bbduk_stream_every_kernel<BBDUK_MODE_KTRIM_L, false, true, false> : bbduk_stream_every_kernel<BBDUK_MODE_KTRIM_L, false, false, false>;
 }

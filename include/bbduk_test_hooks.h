@@ -26,9 +26,9 @@ int  bbduk_test_hook(bbduk_handle* h, int32_t which, int64_t value);
 /* the same controls on the map behind a Seal handle (include/seal_gpu.h), before seal_finalize */
 struct seal_handle;
 int  seal_test_hook(struct seal_handle* h, int32_t which, int64_t value);
-/* big layout: keys that found both of their words full and live in the secondary map (0 for the cache-resident layout) */
+/* big layout: keys that found their pair of words AND the sibling pair of the line's other half full and live in the secondary map (0 for the cache-resident layout) */
 int64_t bbduk_table_spilled(const bbduk_handle* h);
-/* big layout: out33[c] = number of 32-slot lines that hold c keys */
+/* big layout: out33[c] = number of 64-byte HALF lines (32 slots; a line is 128 bytes) that hold c keys */
 int  bbduk_table_line_histogram(bbduk_handle* h, int64_t* out33);
 /* which layout the finalized map took: 0 cache-resident, 1 big (minimizer or plain lines), 2 seed (parents under their halves); + 4: a cache-resident twin beside it; + 8: the query-side expansion (qhdist = 1) is tabulated (the map the kernels look up is the expansion); -1: not finalized */
 int  bbduk_table_layout(const bbduk_handle* h);

@@ -35,7 +35,7 @@ def keys_of(windows, k=31, mm=True):
 def run(ref_bases=1e10, scaffold_bases=10_000_000, chunk_scaffolds=50, reads=20_000_000, steps=3, check_reads=50_000, oracle_bases=50_000_000, fallback_reads=0):
     import types
     return _run(types.SimpleNamespace(ref_bases=ref_bases, scaffold_bases=scaffold_bases, chunk_scaffolds=chunk_scaffolds, reads=reads, steps=steps,
-                                      check_reads=check_reads, oracle_bases=oracle_bases, pair_scan=False, big52=False, gm=0, ktrim=False, fallback_reads=fallback_reads))
+                                      check_reads=check_reads, oracle_bases=oracle_bases, pair_scan=False, big52=False, gm=0, load=0, ktrim=False, fallback_reads=fallback_reads))
 
 
 def main():
@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--ktrim", action="store_true", help="ktrim=r k=31 against the same reference (round 4: the trimming mode's large-map path) instead of kfilter")
     ap.add_argument("--big52", action="store_true", help="experiments: the 52-bit line function and its pair scan below 2^31 keys too")
     ap.add_argument("--gm", type=int, default=0, help="experiments: minimizer length m of the big layout's lines (W = H - m + 1)")
+    ap.add_argument("--load", type=int, default=0, help="experiments: keys per 100 slots the lines are sized for (BBDUK_HOOK_BIG_LOAD; 0 = the library's choice)")
     ap.add_argument("--oracle-bases", type=int, default=50_000_000, help="prefix of scaffold 1.. the contaminated reads are drawn from (and the oracle indexes)")
     a = ap.parse_args()
     print(json.dumps(_run(a)))
@@ -68,6 +69,8 @@ def _run(a):
         gpu.test_hook(B.HOOK_PAIR_SCAN, 1)
     if getattr(a, "gm", 0):
         gpu.test_hook(B.HOOK_LDS_BITS, a.gm)
+    if getattr(a, "load", 0):
+        gpu.test_hook(B.HOOK_BIG_LOAD, a.load)
     if getattr(a, "big52", False):                                  # the 52-bit line function + the pair scan (what maps beyond 2^31 keys take) at any size
         gpu.test_hook(B.HOOK_BIG_LAYOUT, 2)
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")
@@ -101,7 +104,8 @@ def _run(a):
            "build_s": round(t_build, 2), "build_detail_s": {"alloc+clear": round(t_alloc, 2), "generate_reference": round(t_gen, 2), "insert": round(t_add, 2), "end": round(t_end, 2)}}
     hist = gpu.line_histogram()
     out["line_load_histogram"] = hist.tolist(); out["lines"] = int(hist.sum())
-    out["line_load_mean"] = round(float((hist * np.arange(33)).sum() / hist.sum()), 3)
+    out["line_load_mean"] = round(float((hist * np.arange(33)).sum() / hist.sum()), 3)      # (per 32 slots: round 6 counts the 64-byte HALVES of its 128-byte lines)
+    out["gm"] = int(getattr(a, "gm", 0)); out["load_hook"] = int(getattr(a, "load", 0))
     # ---- table checks
     W = np.concatenate([w for w, _ in samples]); ids = np.concatenate([i for _, i in samples])
     got = gpu.table_lookup(keys_of(W))

@@ -16,6 +16,7 @@ ap.add_argument("--args", default="ktrim=r k=23 mink=11 hdist=1 ref=adapters")
 ap.add_argument("--contam-phix", type=float, default=0.0, help="share of the pairs drawn from phiX (BASELINE configs[2]'s workload: 0.01)")
 ap.add_argument("--seed", type=int, default=2); ap.add_argument("--bucket-bits", type=int, default=0); ap.add_argument("--lds-bits", type=int, default=-1)
 ap.add_argument("--genome", type=int, default=0, help="bases of a random genome as the reference, built on the device (big-layout maps); 1 %% of the pairs drawn from it")
+ap.add_argument("--big-layout", type=int, default=0, help="BBDUK_HOOK_BIG_LAYOUT (3: the wide candidate values of maps beyond 2^31 keys at any size)")
 ap.add_argument("masks", nargs="*", default=["0"])
 a = ap.parse_args()
 B.use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bbtools_amd", a.lib + ".so"))
@@ -39,6 +40,8 @@ for m in a.masks:
         hooks[B.HOOK_BUCKET_BITS] = a.bucket_bits
     if a.lds_bits >= 0:
         hooks[B.HOOK_LDS_BITS] = a.lds_bits
+    if a.big_layout:
+        hooks[B.HOOK_BIG_LAYOUT] = a.big_layout
     duk = B.BBDuk(a.args, hooks=hooks, refs=[genome], build="device") if genome is not None else B.BBDuk(a.args, hooks=hooks)
     d_c = torch.zeros(duk.gpu.counters_len, dtype=torch.int64, device="cuda")
     kmask = duk.gpu.params.mode == B.MODE_KMASK

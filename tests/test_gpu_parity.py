@@ -1418,3 +1418,75 @@ def test_query_expansion_tabulated(ci):
         else:
             check_batch(d, o, reads, True); check_batch(d, o, reads[:301], False); check_batch(d, o, longs, True)
         d.close()
+
+
+# ---- unit routing at scale (round 6).  Since round 5 every unit of ktrim=r|l and kfilter goes to the kernel that holds it
+# (KParams::route: the wave kernel up to wunitMax bases, the tiled kernel up to CAP_BASES - 64, the chunked long-unit kernel beyond) instead of the whole
+# batch following its longest unit.  A unit's result never depends on its neighbours (BBDukProcessorS.java:948-1093: one pair per iteration), so
+# a batch of 2 M configs[1]-shaped reads with long units planted at the first pair, the last pair, tile and mini-tile borders and back to back must
+# give, read for read and counter for counter, (i) what the same handle gives with routing off (BBDUK_HOOK_FORCE_TILE) and (ii) what the oracle gives.
+ROUTE = [("ktrim=r k=23 mink=11 hdist=1 ref=adapters", dict(k=23, mink=11, hdist=1, ktrimRight=1), util.ADAPTERS),
+         ("k=31 hdist=1 ref=phix", dict(k=31, hdist=1), util.PHIX),
+         ("ktrim=l k=23 mink=11 ref=adapters", dict(k=23, mink=11, ktrimLeft=1), util.ADAPTERS)]
+
+
+@pytest.mark.parametrize("ci", range(len(ROUTE)))
+@pytest.mark.parametrize("paired", [True, False])
+def test_unit_routing_at_scale(ci, paired):
+    args, okw, ref = ROUTE[ci]
+    d, o = make_pair(args, okw, ref_fasta=ref)
+    phix = B.read_fasta(util.PHIX)[0][1]
+    kw = dict(contam=phix, contam_frac=0.01) if "phix" in args else {}
+    n_pairs = 1_000_000
+    b, off = B.synth_generate_host(B.synth_params(2, **kw), 0, n_pairs)
+    rng = random.Random(77 + ci)
+    piece = (lambda: phix[rng.randrange(len(phix) - 200):][:rng.randint(31, 200)]) if "phix" in args else (lambda: rng.choice([B.TRUSEQ_R1, B.TRUSEQ_R2, util.revcomp(B.TRUSEQ_R1)]))
+
+    def long_read(L):
+        g = bytearray(util.rand_seq(rng, L, 0.0005))
+        for _ in range(rng.randint(0, 3)):
+            r = piece()[:max(12, L // 2)]
+            pos = rng.choice([0, L - len(r), rng.randrange(L - len(r))])
+            g[pos:pos + len(r)] = r
+        if rng.random() < 0.4:
+            g[L - 14:] = B.TRUSEQ_R1[:14]                          # a short k-mer at the very end (mink)
+        return bytes(g)
+    # where the long units go (pair indices): the first and the last pair, the borders of the 256-read tiles and of the 62-read mini-tiles (both sides), back to back
+    spots = [0, 1, n_pairs - 1, n_pairs - 2, 127, 128, 129, 30, 31, 32, 61, 62, 63, 128 * 1000 - 1, 128 * 1000, 31 * 4001, 31 * 4001 + 1, 31 * 4001 + 2, 500_000, 500_001, 500_002, 500_003]
+    spots += [rng.randrange(n_pairs) for _ in range(40 - len(spots))]
+    spots = sorted(set(spots))
+    lens = [2400, 2513, 2600, 3000, 5000, 9000, 20000, 40800, 40928, 41000, 45000, 60000]      # around wunitMax (2512) and CAP_BASES - 64 (40896), and well beyond
+    planted = {}
+    for i, p in enumerate(spots):
+        L = lens[i % len(lens)]
+        mate = long_read(rng.choice([100, 150, L])) if i % 3 else long_read(150)
+        planted[p] = (long_read(L), mate) if i % 2 else (mate, long_read(L))
+    # splice: the reads of the planted pairs are replaced, everything else stays where the generator put it
+    parts, lengths, last = [], [], 0
+    rl = np.diff(off)
+    for p in spots:
+        parts.append(b[off[last * 2]:off[2 * p]]); lengths.append(rl[2 * last:2 * p])
+        for r in planted[p]:
+            parts.append(np.frombuffer(r, np.uint8)); lengths.append(np.array([len(r)], np.int64))
+        last = p + 1
+    parts.append(b[off[2 * last]:]); lengths.append(rl[2 * last:])
+    nb = np.concatenate(parts); noff = np.concatenate([[0], np.cumsum(np.concatenate(lengths))]).astype(np.int64)
+    assert len(noff) == 2 * n_pairs + 1 and noff[-1] == len(nb)
+    d.gpu.reset_counters(); o.reset_counters()
+    ga, gi, gf = d.gpu.process_batch(nb, noff, paired)
+    gc = d.gpu.counters().copy()
+    # (ii) the oracle, every read
+    oa, oi, of = o.process_batch(nb, noff, paired, nthreads=16)
+    bad = np.nonzero((ga != oa) | (gi != oi) | (gf != of))[0]
+    assert len(bad) == 0, [(int(i), int(noff[i + 1] - noff[i]), (int(ga[i]), int(gi[i]), int(gf[i])), (int(oa[i]), int(oi[i]), int(of[i]))) for i in bad[:5]]
+    assert np.array_equal(gc, o.counters())
+    longs = np.nonzero(np.diff(noff) > 2000)[0]
+    assert len(longs) >= 40 and (ga[longs] > 0).sum() > 5          # the planted units are there, and some of them hit
+    # (i) the same handle with routing off: every unit through the tiled / long-unit kernels
+    d.gpu.test_hook(B.HOOK_FORCE_TILE, 1)
+    d.gpu.reset_counters()
+    ta, ti, tf = d.gpu.process_batch(nb, noff, paired)
+    d.gpu.test_hook(B.HOOK_FORCE_TILE, 0)
+    assert np.array_equal(ta, ga) and np.array_equal(ti, gi) and np.array_equal(tf, gf)
+    assert np.array_equal(d.gpu.counters(), gc)
+    d.close()
