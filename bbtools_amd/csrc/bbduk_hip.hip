@@ -750,9 +750,9 @@ static int qx_rewrite(bbduk_handle* h) {
     const bool useShort = p.mink > 0 && p.mink < p.k;
     const int qh2 = useShort ? p.qhdist2 : 0;
     if (!h->finalized || h->qx || h->big || h->seed || h->sealTable || h->nkeys < 1) return BBDUK_OK;
-    if (!(p.qhdist == 1 || qh2 == 1) || p.qhdist > 1 || qh2 > 1 || !p.rcomp || p.middleMask != -1 || p.speed > 0 || p.kbig > p.k || p.k > 31) return BBDUK_OK;
+    if (!(p.qhdist == 1 || qh2 == 1) || p.qhdist > 1 || qh2 > 1 || !p.rcomp || p.speed > 0 || p.kbig > p.k || p.k > 31) return BBDUK_OK;      // (round 6: with a middle mask too -- keyed by the masked forward k-mer, KParams::qx)
     const double ub = (double)h->nkeys * 2.0 * (1.0 + 3.0 * p.k);
-    if (ub > (double)(1ULL << 28)) return BBDUK_OK;
+    if (ub > (double)(1ULL << 27)) return BBDUK_OK;                  // (the scratch set is 2-4x that many slots of 16 bytes for the duration of this call: at most 8 GiB -- ADVICE r5)
     HIP_TRY(h, hipSetDevice(p.device));
     uint64_t cslots = 1024; while ((double)cslots < 2.0 * ub + 16.0) cslots <<= 1;
     uint64_t* d_sk = nullptr; int32_t* d_si = nullptr; int32_t* d_sn = nullptr; unsigned long long* d_cnt = nullptr;
@@ -1025,6 +1025,7 @@ static KParams make_kparams(const bbduk_handle* h) {
     if (h->qx) {                                                  // the tabulated query expansion: forward keys, no expansion left to do (qx_rewrite)
         K.qx = 1; K.qxTags = h->d_tagsQx; K.qxBkv = h->d_bkvQx; K.qxBucketMask = (uint32_t)(h->nbucketsQx - 1); K.qxBucketBits = h->bucketBitsQx;
         K.rcomp = 0; K.qhdist = 0; K.qhdist2 = 0;
+        K.qxQh = p.qhdist; K.qxQh2 = (p.mink > 0 && p.mink < p.k) ? p.qhdist2 : 0;
     }
     return K;
 }
@@ -1087,7 +1088,7 @@ static int launch_kscan(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     int* const d_flag = h->d_slowFlag + 4 * evi;      // [0] pre-pass bits (1: a unit beyond a wave's planes, 2: beyond the tile kernel's)
     HIP_TRY(h, ring_acquire(h, evi, st));
     HIP_TRY(h, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), st));
-    if (expands_on_tiles(h)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
+    if (expands_on_tiles(h) || h->hookForceTile) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand (BBDUK_HOOK_FORCE_TILE: tests)
     {   // pre-pass per READ: one beyond the tiled kernel's planes sends the batch to bbduk_kscan_long_kernel; ksplit: one beyond a
         // wave's planes (bit 0) sends it to the tiled kernel, else bbduk_wave_kernel<KSPLIT> takes it
         const int sgrid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)h->numCU * 8);
@@ -1218,8 +1219,7 @@ static int launch_batch(bbduk_handle* h, int wantKfilter, const uint8_t* d_bases
     int* const d_flag = h->d_slowFlag + 4 * evi;      // [0] pre-pass bits (1: a unit beyond a wave's planes, 2: beyond the tile kernel's)
     HIP_TRY(h, ring_acquire(h, evi, st));
     HIP_TRY(h, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), st));
-    if (expands_on_tiles(h)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
-    if (h->hookForceTile) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }
+    if (expands_on_tiles(h) || h->hookForceTile) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand (BBDUK_HOOK_FORCE_TILE: tests)
     {
         const int64_t units = paired ? n / 2 : n;
         const int sgrid = (int)std::min<int64_t>((units + 255) / 256, (int64_t)h->numCU * 8);
@@ -1448,7 +1448,7 @@ static int launch_tips(bbduk_handle* h, const uint8_t* d_bases, const int64_t* d
     int* const d_flag = h->d_slowFlag + 4 * evi;      // [0] pre-pass bits (1: a unit beyond a wave's planes, 2: beyond the tile kernel's)
     HIP_TRY(h, ring_acquire(h, evi, st));
     HIP_TRY(h, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), st));
-    if (expands_on_tiles(h)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
+    if (expands_on_tiles(h) || h->hookForceTile) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand (BBDUK_HOOK_FORCE_TILE: tests)
     {   // pre-pass: a unit (pair) beyond a wave's planes (bit 0) sends the batch to the tiled kernel, a READ beyond the tiled kernel's
         // planes (bit 1) to bbduk_long_tips_kernel; else bbduk_wave_kernel<KTRIM_TIPS> takes it
         const int64_t units = paired ? n / 2 : n;
@@ -1564,7 +1564,7 @@ static int launch_kmask(bbduk_handle* h, const uint8_t* d_bases, const int64_t* 
     int* const d_flag = h->d_slowFlag + 4 * evi;      // [0] pre-pass bits (1: a unit beyond a wave's planes, 2: beyond the tile kernel's)
     HIP_TRY(h, ring_acquire(h, evi, st));
     HIP_TRY(h, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), st));
-    if (expands_on_tiles(h)) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand
+    if (expands_on_tiles(h) || h->hookForceTile) { const int one = 1; HIP_TRY(h, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st)); }   // the tiled kernels expand (BBDUK_HOOK_FORCE_TILE: tests)
     if (!h->ev0[evi]) { HIP_TRY(h, hipEventCreate(&h->ev0[evi])); HIP_TRY(h, hipEventCreate(&h->ev1[evi])); }
     {   // pre-pass: a unit (pair) beyond a wave's planes sends the batch to the tiled kernel (which in turn leaves the reads beyond ITS planes
         // to bbduk_kmask_long_kernel); else bbduk_wave_kernel<KMASK> takes it

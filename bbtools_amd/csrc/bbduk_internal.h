@@ -56,7 +56,10 @@ struct KParams {
     // Query-side Hamming expansion precomputed (round 5; bbduk_hip.hip: qx_rewrite).  qx != 0: tags / bkv above hold the EXPANSION -- every forward k-mer X for
     // which getValue(X, rc X, qhdist) finds something, keyed as it stands (so the lookups run with rcomp = 0), bkv.z = getValue's answer, bkv.w = the answer
     // of its neighbour loop alone -- and the map the reference holds sits here, for the windows whose rolling rkmer is not kmer's reverse complement.
+    // Round 6: with a middle mask the expansion is keyed by the MASKED forward k-mer (what the kernels look up anyway); an entry whose answer would depend on
+    // the masked base(s) -- the four fillings disagree: needs a k-mer whose halves mirror each other -- holds z = w = -2 and is evaluated exactly (qx_exact).
     int32_t  qx; const uint64_t* qxTags; const uint4* qxBkv; uint32_t qxBucketMask; int32_t qxBucketBits;
+    int32_t  qxQh, qxQh2;       // the handle's own qhdist / qhdist2 (KParams::qhdist is 0 on such a handle: nothing left to expand)
     int32_t  gV32;              // the line function's variant: 1 = 32-bit values (gap_v32 / gap_line32: maps of up to 2^31 keys), 2 = wide values (gap_v52: beyond), 0 = round 2's 52-bit minima; bbduk_bigs.inc scans 1 and 2
     // presence filter in front of the map: one bit per hash slot, copied into LDS by every workgroup
     const uint32_t* ldsImage;   // HBM copy of the LDS bitmap (2^ldsBits bits); 0 bits = absent

@@ -9,7 +9,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
-#define BBDUK_HOOK_FORCE_TILE   1   /* value != 0: every ktrim/kfilter batch of this handle takes the tile-synchronous fallback kernel */
+#define BBDUK_HOOK_FORCE_TILE   1   /* value != 0: every batch of this handle (any operator) takes the tile-synchronous fallback kernels */
 #define BBDUK_HOOK_BUCKET_BITS  2   /* before finalize / device build: log2 of the map's bucket count (4..32; 0 = sized by key count) */
 #define BBDUK_HOOK_LDS_BITS     3   /* before finalize: log2 bits of the LDS presence filter (0 = no filter, -1 = sized by key count) */
 #define BBDUK_HOOK_TIMING_MASK  4   /* -DBBDUK_TIMING_SWITCHES builds only: bit n deletes stage n of the scan (results become wrong) */

@@ -1372,7 +1372,11 @@ QX = [("ktrim=r k=21 mink=11 hdist=1 qhdist=1", dict(k=21, mink=11, hdist=1, qhd
       ("ktrim=n k=17 mink=7 qhdist=1 hdist=1", dict(k=17, mink=7, qhdist=1, hdist=1, ktrimN=1)),
       ("ktrim=rl k=21 mink=10 qhdist=1", dict(k=21, mink=10, qhdist=1, ktrimLeft=1, ktrimRight=1)),
       ("ksplit=t k=21 mink=10 qhdist=1", dict(k=21, mink=10, qhdist=1, ksplit=1)),
-      ("k=22 mm=f fbm=t qhdist=1", dict(k=22, maskMiddle=0, findBestMatch=1, qhdist=1))]
+      ("k=22 mm=f fbm=t qhdist=1", dict(k=22, maskMiddle=0, findBestMatch=1, qhdist=1)),
+      # round 6: with the middle mask (the default kfilter): keyed by the masked forward k-mer, every filling of the masked base(s) evaluated
+      ("k=31 qhdist=1", dict(k=31, qhdist=1)), ("k=24 hdist=1 qhdist=1 mbk=1", dict(k=24, hdist=1, qhdist=1, maxBadKmers0=1)),
+      ("ktrim=l k=23 qhdist=1", dict(k=23, qhdist=1, ktrimLeft=1)), ("ktrim=n k=25 qhdist=1", dict(k=25, qhdist=1, ktrimN=1)),
+      ("k=27 qhdist=1 mkf=0.05", dict(k=27, qhdist=1, minKmerFraction=0.05))]
 
 
 @pytest.mark.gpu
