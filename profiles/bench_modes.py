@@ -10,7 +10,10 @@ import ctypes as C
 ADAPTER_MODES = (("ktrim=n k=23 mink=11 hdist=1 ref=adapters", "kmask"), ("ktrim=rl k=23 mink=11 hdist=1 ref=adapters", "tips"),
                  ("ksplit=t k=23 mink=11 hdist=1 ref=adapters", "ksplit"),
                  ("k=23 hdist=1 fbm ref=adapters", "fbm"), ("k=23 hdist=1 rename=t ref=adapters", "fbm+matches"),
-                 ("k=40 hdist=1 ref=phix", "k40"))
+                 ("k=40 hdist=1 ref=phix", "k40"),
+                 # round 6: query-side expansion, tabulated at the end of the table build and looked up by the stream scans
+                 ("ktrim=r k=21 mink=11 qhdist=1 ref=adapters", "qhdist_ktrim"), ("k=31 qhdist=1 ref=phix", "qhdist_kfilter_mm"),
+                 ("ktrim=r k=21 mink=11 hdist=1 qhdist=1 ref=adapters", "qhdist_x_hdist"))
 # round 5: the same operators against the guide's genome-size example (a random 4.6 Mbase genome, BBDukGuide.txt:34), i.e. a
 # big-layout map scanned by bbduk_bigs_every_kernel; 1 % of the pairs drawn from the genome
 GENOME_MODES = (("ktrim=n k=31", "kmask"), ("ktrim=rl k=31", "tips"), ("ksplit=t k=31", "ksplit"), ("k=31 fbm", "fbm"), ("k=31 mkf=0.1", "mkf"), ("k=31 mcf=0.3", "mcf"),
@@ -50,9 +53,9 @@ def run(reads=20_000_000, read_len=150, modes=ADAPTER_MODES, genome=None):
                 rc = L.bbduk_kmask_batch_device(h, d_bases.data_ptr(), d_off.data_ptr(), n, n * RL, 1, d_a.data_ptr(), d_i.data_ptr(), d_f.data_ptr(), d_m.data_ptr(), d_ctr.data_ptr(), None)
             elif mode == "tips":
                 rc = L.bbduk_ktrimtips_batch_device(h, d_bases.data_ptr(), d_off.data_ptr(), n, n * RL, 1, d_a.data_ptr(), d_b.data_ptr(), d_i.data_ptr(), d_f.data_ptr(), d_ctr.data_ptr(), None)
-            elif mode in ("fbm", "k40", "mkf", "mcf", "mbk"):
+            elif mode in ("fbm", "k40", "mkf", "mcf", "mbk", "qhdist_kfilter_mm"):
                 rc = L.bbduk_kfilter_batch_device(h, d_bases.data_ptr(), d_off.data_ptr(), n, n * RL, 1, d_a.data_ptr(), d_i.data_ptr(), d_f.data_ptr(), d_ctr.data_ptr(), None)
-            elif mode == "ktriml":
+            elif mode in ("ktriml", "qhdist_ktrim", "qhdist_x_hdist"):
                 rc = L.bbduk_ktrim_batch_device(h, d_bases.data_ptr(), d_off.data_ptr(), n, n * RL, 1, d_a.data_ptr(), d_i.data_ptr(), d_f.data_ptr(), d_ctr.data_ptr(), None)
             elif mode == "fbm+matches":                       # the lists rename=t prints, eight entries per read
                 rc = L.bbduk_kfilter_batch_matches_device(h, d_bases.data_ptr(), d_off.data_ptr(), n, n * RL, 1, d_a.data_ptr(), d_i.data_ptr(), d_f.data_ptr(),
