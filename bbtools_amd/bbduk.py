@@ -215,6 +215,8 @@ def lib():
     L.bbduk_host_build_on_device.argtypes = [vp, vp]
     L.bbduk_build_table_device.argtypes = [vp, vp, vp, i32, i32, i32]
     L.bbduk_build_table_device_edits.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32]
+    L.bbduk_pinned_malloc.argtypes = [i64, C.POINTER(vp)]
+    L.bbduk_pinned_free.argtypes = [vp]
     L.bbduk_test_hook.argtypes = [vp, i32, i64]
     L.bbduk_table_line_histogram.argtypes = [vp, vp]
     L.bbduk_table_layout.argtypes = [vp]

@@ -81,10 +81,59 @@ def measure_end_to_end(B, duk, reads, seed):
         res[name] = {"Gbases_per_s_1_thread": round(n * READ_LEN / one / 1e9, 2), "Gbases_per_s_2_threads": round(n * READ_LEN / two / 1e9, 2),
                      "ms_per_call_1_thread": round(one * 1e3, 2), "ms_per_call_2_threads": round(two * 1e3, 2),
                      "bytes_in_per_read": 158 if name == "ascii" else round((len(codes) * 4 + len(undef) * 4) / n + 8, 2), "bytes_out_per_read": 9}
+    # The same operators with every buffer in page-locked memory (bbduk_pinned_malloc: what BBDukGpu.allocPinned hands the Java batcher): the
+    # copies then run at the link's rate instead of through the runtime's own staging of pageable memory (round 5: 34 GB/s of a 45-50 GB/s link)
+    try:
+        import ctypes as C
+        L = B.lib()
+        def pin(arr):
+            p = C.c_void_p()
+            assert L.bbduk_pinned_malloc(max(int(arr.nbytes), 16), C.byref(p)) == 0
+            C.memmove(p, arr.ctypes.data, arr.nbytes)
+            return p
+        def pin_out(nbytes):
+            p = C.c_void_p()
+            assert L.bbduk_pinned_malloc(nbytes, C.byref(p)) == 0
+            return p
+        p_b, p_off, p_codes, p_undef = pin(hb), pin(hoff), pin(codes), pin(undef)
+        outs = [(pin_out(4 * n), pin_out(4 * n), pin_out(n)) for _ in range(2)]                      # one set of outputs per submitting thread
+        h = duk.gpu.h
+        def call(name, t):
+            a, i, f = outs[t]
+            rc = L.bbduk_ktrim_batch(h, p_b, p_off, n, 1, a, i, f) if name == "ascii" else L.bbduk_ktrim_batch_packed(h, p_codes, p_undef, p_off, n, 1, a, i, f)
+            assert rc == 0, rc
+        for name in ("ascii", "packed"):
+            call(name, 0)
+            t = time.perf_counter(); call(name, 0); one = time.perf_counter() - t
+            calls = 4
+            th = [threading.Thread(target=lambda t=t: [call(name, t) for _ in range(calls)]) for t in range(2)]
+            t = time.perf_counter()
+            for x in th: x.start()
+            for x in th: x.join()
+            two = (time.perf_counter() - t) / (2 * calls)
+            res[name + "_pinned"] = {"Gbases_per_s_1_thread": round(n * READ_LEN / one / 1e9, 2), "Gbases_per_s_2_threads": round(n * READ_LEN / two / 1e9, 2),
+                                     "ms_per_call_1_thread": round(one * 1e3, 2), "ms_per_call_2_threads": round(two * 1e3, 2)}
+        ga = np.ctypeslib.as_array(C.cast(outs[0][0], C.POINTER(C.c_int32)), shape=(n,))
+        res["pinned_equals_pageable"] = bool(np.array_equal(ga, duk.gpu.process_batch(hb, hoff, True)[0]))
+        for q in (p_b, p_off, p_codes, p_undef, *[x for o in outs for x in o]): L.bbduk_pinned_free(q)
+    except Exception as e:
+        res["pinned_error"] = repr(e)
     return res
 
 
-def measure_configs(B, reads, c4_ref_bases, c4_reads=0):
+# Counter-derived figures of the HBM-bound configurations, ECHOED from the committed profiles (like roofline.traffic: not measured in this run).
+COUNTER_ROWS = {
+    "C4": {"source": "profiles/r06_c4_rdreq.txt + profiles/r06_c4_counters.txt (rocprofv3 --pmc passes of profiles/bench_c4_full.py, 20 M reads per launch, the library's own geometry: m = 9)",
+           "fabric_requests_per_read": 28.6, "l2_requests_per_read": 33.0, "spilled_keys_frac": 0.0114, "valu_per_read": 318.6, "valu_busy_frac": 0.81,
+           "note": "round 5 (64-byte lines, m = 10): 35.4 fabric requests per read, 6.6 % of the keys spilled; every request moves 128 bytes whatever the load asks for "
+                   "(profiles/r06_rand_gran_pmc.txt); 28.6 requests x 20 M reads in 14.5 ms = 39 G requests/s of the ~49 G/s a bare gather kernel reaches over this span: "
+                   "the scan is bound by VALU issue now (profiles/r06_bigs_stage_table.txt)"},
+    "C6_hdist1_genome": {"source": "profiles/r04_seed_counters.txt, profiles/r06_seed_128B.txt", "fabric_requests_per_read": 66.0,
+                         "note": "the kernel runs at the fabric's request rate for lines beyond an XCD's L2 (54.8 of ~55 G/s); 128-byte lines of 16 buckets change neither the count nor the rate"},
+}
+
+
+def measure_configs(B, reads, c4_ref_bases, c4_reads=0, c3_reads=0):
     """Kernel Gbases/s (HIP events inside the library) of the other BASELINE configurations, device-resident batches."""
     import numpy as np
     import torch
@@ -104,18 +153,38 @@ def measure_configs(B, reads, c4_ref_bases, c4_reads=0):
         return duk_gpu.kernel_time_ms(steps), d_c.cpu().numpy()
 
     for name, args, seed, kw in (("C1", "ktrim=r k=23 hdist=0 ref=adapters", 1, {}),
-                                 ("C3", "k=31 hdist=1 ref=phix", 3, dict(contam=phix, contam_frac=0.01)),
                                  ("C5", "ktrim=r k=23 hdist=1 ref=adapters", 5, {})):
         duk = B.BBDuk(args)
         ms, c = run(duk.gpu, B.synth_params(seed, **kw))
         res[name] = {"args": args, "reads": n, "keys": int(duk.stored_kmers), "kernel_ms": round(ms, 3),
                      "Gbases_per_s": round(n * READ_LEN / (ms * 1e-3) / 1e9, 1), "readsKTrimmed": int(c[2]), "readsKFiltered": int(c[4])}
         duk.close()
+    # BASELINE configs[2] at its own size (100 M reads, 1 % of the pairs from phiX): its own buffers (the row ran 20 M reads until round 6)
+    try:
+        n3 = (c3_reads or reads) // 2 * 2
+        b3 = torch.empty(n3 * READ_LEN, dtype=torch.uint8, device="cuda"); o3 = torch.empty(n3 + 1, dtype=torch.int64, device="cuda")
+        a3 = torch.empty(n3, dtype=torch.int32, device="cuda"); i3 = torch.empty_like(a3); f3 = torch.empty(n3, dtype=torch.uint8, device="cuda")
+        args = "k=31 hdist=1 ref=phix"
+        duk = B.BBDuk(args)
+        B.synth_generate_device(B.synth_params(3, contam=phix, contam_frac=0.01), 0, n3 // 2, b3, o3, 0)
+        d_c = torch.zeros(duk.gpu.counters_len, dtype=torch.int64, device="cuda")
+        for _ in range(4):
+            d_c.zero_(); duk.gpu.process_batch_device(b3, o3, True, a3, i3, f3, d_c, st)
+        torch.cuda.synchronize()
+        ms = duk.gpu.kernel_time_ms(3); c = d_c.cpu().numpy()
+        res["C3"] = {"args": args, "reads": n3, "keys": int(duk.stored_kmers), "kernel_ms": round(ms, 3),
+                     "Gbases_per_s": round(n3 * READ_LEN / (ms * 1e-3) / 1e9, 1), "readsKTrimmed": int(c[2]), "readsKFiltered": int(c[4])}
+        duk.close()
+        del b3, o3, a3, i3, f3
+        torch.cuda.empty_cache()
+    except Exception as e:
+        res["C3"] = {"error": repr(e)}
     try:                                               # the reference's own sizing example (BBDukGuide.txt:34): k=31 hdist=1 vs a 4.6 Mbase genome -- the seed layout
         sys.path.insert(0, os.path.join(ROOT, "profiles"))
         import bench_hdist_big
         r = bench_hdist_big.run(reads=reads)
         res["C6_hdist1_genome"] = {k: r[k] for k in ("workload", "keys", "table_bytes", "build_s", "reads", "kernel_ms", "Gbases_per_s", "readsKFiltered")}
+        res["C6_hdist1_genome"]["counters"] = COUNTER_ROWS["C6_hdist1_genome"]
     except Exception as e:
         res["C6_hdist1_genome"] = {"error": repr(e)}
     try:                                               # the same guide line's hdist=0 figure (E. coli: 4554207 keys): the big layout's minimizer lines since round 3 (was cache-resident: 67.6 Gbases/s)
@@ -153,6 +222,7 @@ def measure_configs(B, reads, c4_ref_bases, c4_reads=0):
         except Exception as e:
             res["C4"] = {"error": repr(e)}
             return res
+        res["C4_counters"] = COUNTER_ROWS["C4"]
         res["C4"] = {k: r[k] for k in ("workload", "keys", "table_bytes", "bytes_per_key", "spilled_keys", "build_s", "reads", "kernel_ms", "Gbases_per_s",
                                        "algorithmic_GBps", "frac_of_8TBps", "readsKFiltered", "sampled_reference_windows", "sampled_found_with_id", "random_keys_found",
                                        "checked_reads", "checked_reads_differ", "checked_reads_hit", "differ_device_hit_oracle_miss", "reads_requested", "full_batch_error") if k in r}
@@ -176,6 +246,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the end_to_end and configs measurements")
     ap.add_argument("--extra-reads", type=int, default=20_000_000, help="reads per call / launch of the extra measurements")
     ap.add_argument("--c4-reads", type=int, default=100_000_000, help="reads of the configs[3] launch in `configs` (BASELINE: 100 M)")
+    ap.add_argument("--c3-reads", type=int, default=100_000_000, help="reads of the configs[2] launch in `configs` (BASELINE: 100 M)")
     ap.add_argument("--c4-ref-bases", type=float, default=1e10, help="reference size of BASELINE configs[3] in `configs` (0 = skip; 1e10 needs ~245 GB of HBM)")
     ap.add_argument("--dry-run-share-gpu", action="store_true", help="N>1 control-flow rehearsal on one GPU (gloo; not a measurement)")
     ap.add_argument("--insert-range", default=None, help="experiments: 'min,max' insert size of the synthetic pairs")
@@ -452,7 +523,7 @@ def main():
         except Exception as e:
             out["read_lengths"] = {"error": repr(e)}
         try:
-            out["configs"] = measure_configs(B, a.extra_reads, a.c4_ref_bases, a.c4_reads)
+            out["configs"] = measure_configs(B, a.extra_reads, a.c4_ref_bases, a.c4_reads, a.c3_reads)
         except Exception as e:
             out["configs"] = {"error": repr(e)}
     if duk is not None:

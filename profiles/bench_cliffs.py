@@ -24,7 +24,9 @@ CASES = [
 ]
 n = 8_000_000
 L = B.lib()
+ONLY = os.environ.get("BENCH_CLIFFS_ONLY", "")                   # substring of the case's description
 for args, kw, what in CASES:
+    if ONLY and ONLY not in what: continue
     RL = kw.get("read_len", 150)
     sp = B.synth_params(2, **kw)
     d_bases = torch.empty(n * RL, dtype=torch.uint8, device="cuda"); d_off = torch.empty(n + 1, dtype=torch.int64, device="cuda")

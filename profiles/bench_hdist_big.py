@@ -12,7 +12,7 @@ import numpy as np
 def run(**kw):
     """bench.py's `configs` block calls this (defaults = the command line's)"""
     import types
-    d = dict(genome_bases=4_600_000, reads=20_000_000, steps=3, check_reads=0, oracle_bases=100_000, args="k=31 hdist=1", bucket_bits=0, plain=False, m=0, build="device")
+    d = dict(genome_bases=4_600_000, reads=20_000_000, steps=3, check_reads=0, oracle_bases=100_000, args="k=31 hdist=1", bucket_bits=0, plain=False, m=0, build="device", lib="")
     d.update(kw)
     return _run(types.SimpleNamespace(**d))
 
@@ -21,7 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--genome-bases", type=int, default=4_600_000); ap.add_argument("--reads", type=int, default=20_000_000)
     ap.add_argument("--steps", type=int, default=3); ap.add_argument("--check-reads", type=int, default=0); ap.add_argument("--oracle-bases", type=int, default=100_000)
-    ap.add_argument("--args", default="k=31 hdist=1"); ap.add_argument("--bucket-bits", type=int, default=0); ap.add_argument("--plain", action="store_true"); ap.add_argument("--m", type=int, default=0); ap.add_argument("--build", default="device", help="host: the map arrives as (key, id) pairs, as a JVM host uploads it")
+    ap.add_argument("--args", default="k=31 hdist=1"); ap.add_argument("--bucket-bits", type=int, default=0); ap.add_argument("--plain", action="store_true"); ap.add_argument("--m", type=int, default=0); ap.add_argument("--build", default="device", help="host: the map arrives as (key, id) pairs, as a JVM host uploads it"); ap.add_argument("--lib", default="", help="experiments: another build of the library under bbtools_amd/ (same-box A/B)")
     a = ap.parse_args()
     print(json.dumps(_run(a)))
 
@@ -29,6 +29,7 @@ def main():
 def _run(a):
     import torch
     from bbtools_amd import bbduk as B
+    if getattr(a, "lib", ""): B.use_library(os.path.join(ROOT, "bbtools_amd", a.lib + ".so"))
     rng = np.random.default_rng(77)
     genome = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, a.genome_bases)].tobytes()
     t0 = time.perf_counter()
