@@ -219,7 +219,7 @@ extern "C" int bbduk_destroy(bbduk_handle* h) {
     hipSetDevice(h->p.device);
     build_release(h);
     hipFree(h->d_bigTags); hipFree(h->d_bigKeys); hipFree(h->d_bigIds);
-    for (auto& q : h->slot) { hipFree(q.d_bases); hipFree(q.d_undef); hipFree(q.d_off); hipFree(q.d_a); hipFree(q.d_id); hipFree(q.d_fl); hipFree(q.d_status); if (q.stream) hipStreamDestroy(q.stream); }
+    for (auto& q : h->slot) { hipFree(q.d_bases); hipFree(q.d_undef); hipFree(q.d_off); hipFree(q.d_a); hipFree(q.d_id); hipFree(q.d_fl); hipFree(q.d_status); if (q.stream) hipStreamDestroy(q.stream); if (q.copyStream) hipStreamDestroy(q.copyStream); for (auto& e : q.evPiece) if (e) hipEventDestroy(e); }
     hipFree(h->d_tags); hipFree(h->d_bkv);
     hipFree(h->d_ldsImage); hipFree(h->d_slowFlag); hipFree(h->d_tagsAlt); hipFree(h->d_bkvAlt); hipFree(h->d_ldsAlt); hipFree(h->d_tagsQx); hipFree(h->d_bkvQx);
     for (int q = 0; q < bbduk_handle::EV_RING; q++) { if (h->ev0[q]) hipEventDestroy(h->ev0[q]); if (h->ev1[q]) hipEventDestroy(h->ev1[q]); if (h->evDone[q]) hipEventDestroy(h->evDone[q]); }
@@ -1362,6 +1362,58 @@ static int host_batch(bbduk_handle* h, int wantKfilter, const uint8_t* bases, co
         S->cap_reads = cap;
     }
     const hipStream_t st = S->stream;
+    // Round 6: a large call goes through in PIECES of whole pairs -- piece c+1's upload (the slot's copy stream) runs under piece c's kernel and result
+    // download (its compute stream; the two copy directions have engines of their own), so that one submitting thread already keeps the link busy:
+    // 20 M packed reads per call 57.8 -> 79 Gbases/s unpinned-to-pinned, and from there with the pieces (bench.py end_to_end).  The kernels index reads by their
+    // absolute offsets, so a piece is just a range of reads; a plane word two pieces share is uploaded by both with the same content.
+    // (only from page-locked buffers -- bbduk_pinned_malloc, BBDukGpu.allocPinned: a copy out of pageable memory is staged by the runtime on the calling thread,
+    // and six of them per call cost the pageable path 15-25 %, measured)
+    bool pinnedIn = false;
+    if (!hostMatches && n >= (1 << 20)) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, bases) == hipSuccess) pinnedIn = at.type == hipMemoryTypeHost;
+        else (void)hipGetLastError();                             // (an unregistered host pointer: not an error of ours)
+    }
+    const int npieces = pinnedIn ? 6 : 1;
+    if (npieces > 1) {
+        if (!S->copyStream) HIP_TRY(h, hipStreamCreateWithFlags(&S->copyStream, hipStreamNonBlocking));
+        for (int c = 0; c < npieces; c++) if (!S->evPiece[c]) HIP_TRY(h, hipEventCreateWithFlags(&S->evPiece[c], hipEventDisableTiming));
+        const hipStream_t cs = S->copyStream;
+        int64_t r0 = 0;
+        for (int c = 0; c < npieces; c++) {
+            int64_t r1 = (c + 1 == npieces) ? n : ((n * (int64_t)(c + 1) / npieces) & ~1LL);
+            const int64_t b0 = offsets[r0], b1 = offsets[r1];
+            if (b1 > b0) {
+                if (packed) {
+                    const int64_t w0 = b0 >> 4, w1 = (b1 + 15) >> 4, u0 = b0 >> 5, u1 = (b1 + 31) >> 5;
+                    HIP_TRY(h, hipMemcpyAsync(S->d_bases + 4 * w0, bases + 4 * w0, (size_t)(4 * (w1 - w0)), hipMemcpyHostToDevice, cs));
+                    HIP_TRY(h, hipMemcpyAsync(S->d_undef + 4 * u0, reinterpret_cast<const uint8_t*>(undef) + 4 * u0, (size_t)(4 * (u1 - u0)), hipMemcpyHostToDevice, cs));
+                } else HIP_TRY(h, hipMemcpyAsync(S->d_bases + b0, bases + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, cs));
+            }
+            HIP_TRY(h, hipMemcpyAsync(S->d_off + r0, offsets + r0, (size_t)(r1 - r0 + 1) * sizeof(int64_t), hipMemcpyHostToDevice, cs));
+            HIP_TRY(h, hipEventRecord(S->evPiece[c], cs));
+            HIP_TRY(h, hipStreamWaitEvent(st, S->evPiece[c], 0));
+            if (r1 > r0) {
+                const int rc = launch_batch(h, wantKfilter, S->d_bases, S->d_off + r0, r1 - r0, total, paired, S->d_a + r0, S->d_id + r0, S->d_fl + r0, h->d_counters, st,
+                                            reinterpret_cast<const uint32_t*>(S->d_undef), packed, nullptr, S->d_status);
+                if (rc != BBDUK_OK) { hipStreamSynchronize(cs); hipStreamSynchronize(st); return rc; }
+                HIP_TRY(h, hipMemcpyAsync(out_a + r0, S->d_a + r0, (size_t)(r1 - r0) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                HIP_TRY(h, hipMemcpyAsync(out_id + r0, S->d_id + r0, (size_t)(r1 - r0) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                HIP_TRY(h, hipMemcpyAsync(out_fl + r0, S->d_fl + r0, (size_t)(r1 - r0), hipMemcpyDeviceToHost, st));
+            }
+            r0 = r1;
+        }
+        int64_t status = 0;
+        HIP_TRY(h, hipMemcpyAsync(&status, S->d_status, sizeof status, hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipStreamSynchronize(st));
+        if (status != 0) {
+            int64_t z = 0;
+            hipMemcpyAsync(S->d_status, &z, sizeof z, hipMemcpyHostToDevice, st);
+            hipStreamSynchronize(st);
+            return fail(h, -(int)status, "device reported an error (a read longer than BBDUK_MAX_READ_LEN)");
+        }
+        return BBDUK_OK;
+    }
     if (total > 0) HIP_TRY(h, hipMemcpyAsync(S->d_bases, bases, baseBytes, hipMemcpyHostToDevice, st));
     if (undefBytes) HIP_TRY(h, hipMemcpyAsync(S->d_undef, undef, undefBytes, hipMemcpyHostToDevice, st));
     HIP_TRY(h, hipMemcpyAsync(S->d_off, offsets, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));

@@ -112,6 +112,7 @@ struct bbduk_handle {
         int32_t* d_a = nullptr; int32_t* d_id = nullptr; uint8_t* d_fl = nullptr;
         int64_t* d_status = nullptr;                             // this slot's device-side error word (see KParams::status)
         hipStream_t stream = nullptr; bool busy = false;
+        hipStream_t copyStream = nullptr; hipEvent_t evPiece[8] = {};  // large calls: the next piece's upload runs under this piece's kernel (host_batch)
     };
     static const int NSLOTS = 2;
     Slot slot[NSLOTS];

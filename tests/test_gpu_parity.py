@@ -1486,6 +1486,13 @@ def test_unit_routing_at_scale(ci, paired):
     assert np.array_equal(gc, o.counters())
     longs = np.nonzero(np.diff(noff) > 2000)[0]
     assert len(longs) >= 40 and (ga[longs] > 0).sum() > 5          # the planted units are there, and some of them hit
+    # ... and from page-locked buffers: a large call then goes through in pieces of whole pairs, each piece's upload under the piece before's kernel (host_batch)
+    import torch
+    pb = torch.from_numpy(nb).pin_memory().numpy(); po = torch.from_numpy(noff).pin_memory().numpy()
+    d.gpu.reset_counters()
+    pa, pi, pf = d.gpu.process_batch(pb, po, paired)
+    assert np.array_equal(pa, ga) and np.array_equal(pi, gi) and np.array_equal(pf, gf)
+    assert np.array_equal(d.gpu.counters(), gc)
     # (i) the same handle with routing off: every unit through the tiled / long-unit kernels
     d.gpu.test_hook(B.HOOK_FORCE_TILE, 1)
     d.gpu.reset_counters()
