@@ -35,7 +35,7 @@ def keys_of(windows, k=31, mm=True):
 def run(ref_bases=1e10, scaffold_bases=10_000_000, chunk_scaffolds=50, reads=20_000_000, steps=3, check_reads=50_000, oracle_bases=50_000_000, fallback_reads=0):
     import types
     return _run(types.SimpleNamespace(ref_bases=ref_bases, scaffold_bases=scaffold_bases, chunk_scaffolds=chunk_scaffolds, reads=reads, steps=steps,
-                                      check_reads=check_reads, oracle_bases=oracle_bases, pair_scan=False, big52=False, gm=0, load=0, ktrim=False, fallback_reads=fallback_reads))
+                                      check_reads=check_reads, oracle_bases=oracle_bases, pair_scan=False, big52=False, gm=0, load=0, lib="", mask="0", ktrim=False, fallback_reads=fallback_reads))
 
 
 def main():
@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--big52", action="store_true", help="experiments: the 52-bit line function and its pair scan below 2^31 keys too")
     ap.add_argument("--gm", type=int, default=0, help="experiments: minimizer length m of the big layout's lines (W = H - m + 1)")
     ap.add_argument("--load", type=int, default=0, help="experiments: keys per 100 slots the lines are sized for (BBDUK_HOOK_BIG_LOAD; 0 = the library's choice)")
+    ap.add_argument("--lib", default="", help="experiments: another build of the library under bbtools_amd/ (ab_tsw: the timing switches)")
+    ap.add_argument("--mask", default="0", help="experiments: timing mask of the ab_tsw build (a+b = bits; 22: the stream form instead of the read-aligned one)")
     ap.add_argument("--oracle-bases", type=int, default=50_000_000, help="prefix of scaffold 1.. the contaminated reads are drawn from (and the oracle indexes)")
     a = ap.parse_args()
     print(json.dumps(_run(a)))
@@ -59,6 +61,7 @@ def main():
 def _run(a):
     import torch
     from bbtools_amd import bbduk as B
+    if getattr(a, "lib", ""): B.use_library(os.path.join(ROOT, "bbtools_amd", a.lib + ".so"))
     ref_bases = int(a.ref_bases)
     n_scaf = max(1, ref_bases // a.scaffold_bases)
     ref_bases = n_scaf * a.scaffold_bases
@@ -71,6 +74,8 @@ def _run(a):
         gpu.test_hook(B.HOOK_LDS_BITS, a.gm)
     if getattr(a, "load", 0):
         gpu.test_hook(B.HOOK_BIG_LOAD, a.load)
+    if getattr(a, "mask", "0") != "0":
+        gpu.test_hook(B.HOOK_TIMING_MASK, sum(1 << int(b) for b in a.mask.split("+")))
     if getattr(a, "big52", False):                                  # the 52-bit line function + the pair scan (what maps beyond 2^31 keys take) at any size
         gpu.test_hook(B.HOOK_BIG_LAYOUT, 2)
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")

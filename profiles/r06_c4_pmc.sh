@@ -6,13 +6,13 @@ export TMPDIR=/tmp
 cd /tmp
 for ML in ${1:-10:55 9:50}; do
   M=${ML%%:*}; L=${ML##*:}
-  CMD="python $ROOT/profiles/bench_c4_full.py --ref-bases 1e10 --check-reads 0 --steps 2 --gm $M --load $L ${2:-}"
+  CMD="python $ROOT/profiles/bench_c4_full.py --ref-bases 1e10 --check-reads 0 --steps 2 $( [ "$M" != 0 ] && echo --gm $M --load $L ) ${2:-}"
   i=0
-  for C in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
+  for C in "TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_LDS" \
            "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum"; do
     i=$((i+1))
-    timeout -s KILL 600 rocprofv3 --pmc $C --output-format csv -d $OUT/m${M}_l${L}_p$i -- $CMD > $OUT/m${M}_l${L}_p$i.json 2> $OUT/m${M}_l${L}_p$i.err
+    timeout -s KILL 240 rocprofv3 --pmc $C --output-format csv -d $OUT/m${M}_l${L}_p$i -- $CMD > $OUT/m${M}_l${L}_p$i.json 2> $OUT/m${M}_l${L}_p$i.err
   done
 done
 cd $ROOT
