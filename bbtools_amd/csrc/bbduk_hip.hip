@@ -328,9 +328,10 @@ static bool big_geometry(bbduk_handle* h, const double maxKeys = 0.0) {
     if (h->hookLdsBits >= 4 && h->hookLdsBits <= H - 1) h->gm = h->hookLdsBits;      // (experiments: BBDUK_HOOK_LDS_BITS = m; such maps have no LDS filter)
     h->gW = h->bigPlain ? 0 : H - h->gm + 1;
     if (h->gV32 == 2 && h->gW > 8) h->gV32 = 1;                   // (the wide scan is instantiated for W <= 8: m = 10 gives W <= 7)
+    if (h->gV32 == 2 && h->sealTable) h->gV32 = 1;                // (a Seal map stays below 2^28 lines: its kernel knows the four class bits of the 32-bit form only)
     return true;
 }
-static BigGeom host_geom(const bbduk_handle* h) { BigGeom G; G.k = h->p.k; G.m = h->gm; G.W = h->gW; G.H = h->gH; G.D = h->gD; G.nlines = h->bigLines; G.middleMask = (uint64_t)h->p.middleMask; G.v32 = h->gV32; return G; }
+static BigGeom host_geom(const bbduk_handle* h) { BigGeom G; G.k = h->p.k; G.m = h->gm; G.W = h->gW; G.H = h->gH; G.D = h->gD; G.nlines = h->bigLines; G.middleMask = (uint64_t)h->p.middleMask; G.v32 = h->gV32; G.lb = h->gLb; G.sib = h->gSib; return G; }
 static Sink make_sink(const bbduk_handle* h, const BuildState* st) {
     Sink S; memset(&S, 0, sizeof S);
     S.big = st->big ? 1 : 0; S.skeys = st->d_sk; S.sids = st->d_si; S.cmask = st->cslots ? st->cslots - 1 : 0;
@@ -473,7 +474,9 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
         // Round 6: the 32-bit / wide line functions' maps (gV32) have 128-byte lines of 64 slots (big_words32: a full pair overflows into the line's other
         // half before anything is spilled); round 2's 52-bit form behind its hook keeps 64-byte lines of 32 slots.
         const int idBytes = (h->p.numScaffolds <= 65535 && !h->sealTable) ? 2 : 4;      // (a Seal record is a scaffold or SEAL_MULTI | offset into the id lists: 32 bits)
-        const int lineSlots = h->gV32 ? 64 : 32;
+        h->gLb = (h->gV32 && !h->sealTable) ? 4 : 3;              // (Seal's reads hit at almost every position: 64-byte lines keep a run's keys and ids within 256 bytes, big_words32)
+        h->gSib = (h->gV32 && !h->sealTable) ? 1 : 0;
+        const int lineSlots = 4 << h->gLb;
         size_t freeB = 0, totalB = 0;
         if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return bail(BBDUK_ERR_DEVICE, "hipMemGetInfo");
         // the secondary map holds what the lines spill: 64-byte lines ~6 % of the keys at 0.6 keys per slot, 128-byte lines 1-3 % (profiles/sim_lines.c; both
@@ -497,6 +500,7 @@ static int build_begin_impl(bbduk_handle* h, double maxKeys, int hdist, int hdis
             nlines = 0;
         }
         if (!nlines) return bail(BBDUK_ERR_NOMEM, "the map does not fit this device's memory (or the 32-bit pair index: 2^29 lines)");
+        if (h->sealTable && nlines >= (1ULL << 28)) return bail(BBDUK_ERR_NOMEM, "a Seal map of more than 2^28 lines (its kernel indexes tag words with 32 bits)");
         if (hipMalloc(&h->d_bigTags, nlines * 2 * (size_t)lineSlots) != hipSuccess || hipMalloc(&h->d_bigKeys, nlines * 8 * (size_t)lineSlots) != hipSuccess ||
             hipMalloc(&h->d_bigIds, nlines * lineSlots * (size_t)idBytes) != hipSuccess ||
             hipMalloc(&h->d_tags, (snb + 1) * 8) != hipSuccess || hipMalloc(&h->d_bkv, 4 * snb * sizeof(uint4)) != hipSuccess) return bail(BBDUK_ERR_NOMEM, "hipMalloc (map)");
@@ -976,7 +980,7 @@ extern "C" int bbduk_table_line_histogram(bbduk_handle* h, int64_t* out33) {
     unsigned long long* d = nullptr;
     HIP_TRY(h, hipMalloc(&d, 33 * 8));
     hipMemsetAsync(d, 0, 33 * 8, h->stream);
-    bbduk_line_hist_kernel<<<dim3(h->numCU * 16), dim3(256), 0, h->stream>>>(h->d_bigKeys, (uint64_t)h->bigLines * (h->gV32 ? 2 : 1), d);
+    bbduk_line_hist_kernel<<<dim3(h->numCU * 16), dim3(256), 0, h->stream>>>(h->d_bigKeys, (uint64_t)h->bigLines << (h->gLb - 3), d);
     hipMemcpyAsync(out33, d, 33 * 8, hipMemcpyDeviceToHost, h->stream);
     const hipError_t e = hipStreamSynchronize(h->stream);
     hipFree(d);
@@ -987,7 +991,7 @@ extern "C" int64_t bbduk_table_spilled(const bbduk_handle* h) { return (h && h->
 extern "C" int64_t bbduk_table_size(const bbduk_handle* h) { return (h && h->finalized) ? (h->qx ? h->nkeysQx : ((h->seed && h->nkeysRef > 0) ? h->nkeysRef : h->nkeys)) : -1; }
 extern "C" int64_t bbduk_table_bytes(const bbduk_handle* h) {
     if (!h || !h->finalized) return -1;
-    if (h->big) return (int64_t)h->bigLines * (h->gV32 ? 2 : 1) * (64 + 256 + 32 * h->bigIdBytes) + (int64_t)(h->nbuckets * (8 + 4 * 16)) +
+    if (h->big) return ((int64_t)h->bigLines << (h->gLb - 3)) * (64 + 256 + 32 * h->bigIdBytes) + (int64_t)(h->nbuckets * (8 + 4 * 16)) +
                        (h->hasAlt ? (int64_t)(h->nbucketsAlt * (8 + 4 * 16)) + (h->ldsBitsAlt ? (1LL << (h->ldsBitsAlt - 3)) : 0) : 0);
     return (int64_t)(h->nbuckets * (8 + 4 * 16)) + (h->ldsBits ? (1LL << (h->ldsBits - 3)) : 0) +
            (h->hasAlt ? (int64_t)(h->nbucketsAlt * (8 + 4 * 16)) + (h->ldsBitsAlt ? (1LL << (h->ldsBitsAlt - 3)) : 0) : 0) +      // (a seed-layout map's twin)
@@ -1017,7 +1021,7 @@ static KParams make_kparams(const bbduk_handle* h) {
     K.tags = h->d_tags; K.bkv = h->d_bkv; K.bucketMask = (uint32_t)(h->nbuckets - 1); K.bucketBits = h->bucketBits;
     K.storedKmers = h->nkeys; K.undef = nullptr;
     K.big = h->big ? 1 : 0; K.bigTags = h->d_bigTags; K.bigKeys = h->d_bigKeys; K.bigIds = h->d_bigIds; K.bigIdBytes = h->bigIdBytes; K.bigLines = h->bigLines;
-    K.gm = h->gm; K.gW = h->gW; K.gH = h->gH; K.gD = h->gD; K.gV32 = h->gV32;
+    K.gm = h->gm; K.gW = h->gW; K.gH = h->gH; K.gD = h->gD; K.gV32 = h->gV32; K.gLb = h->gLb; K.gSib = h->gSib;
     K.seed = h->seed ? 1 : 0; K.seedHl = h->seedHl; K.seedHr = h->seedHr; K.seedM = h->seedM;
     K.matchN = nullptr; K.matchIds = nullptr; K.matchCnt = nullptr; K.matchCap = 0;
     K.dbg = h->hookDbg;

@@ -52,6 +52,8 @@ struct KParams {
     int32_t  bigIdBytes;
     uint32_t bigLines;
     int32_t  seed, seedHl, seedHr, seedM;   // the seed layout (bbduk_seed.inc): tags / bkv hold PARENTS under their left (seedHl bases) and right (seedHr) halves
+    int32_t  gSib;              // a full pair overflows into the sibling pair of the line's other half before anything is spilled (0: Seal's maps, round 2's form)
+    int32_t  gLb;               // log2 of the tag words per line: 4 = 128-byte lines (round 6), 3 = 64-byte lines (Seal's maps; round 2's form)
     int32_t  gm, gW, gH, gD;    // gapped minimizer: m bases from each half, W candidates, half length H, right half starts at D = k-H
     // Query-side Hamming expansion precomputed (round 5; bbduk_hip.hip: qx_rewrite).  qx != 0: tags / bkv above hold the EXPANSION -- every forward k-mer X for
     // which getValue(X, rc X, qhdist) finds something, keyed as it stands (so the lookups run with rcomp = 0), bkv.z = getValue's answer, bkv.w = the answer
@@ -86,7 +88,7 @@ struct bbduk_handle {
     uint64_t* d_tagsAlt = nullptr; uint4* d_bkvAlt = nullptr; uint32_t* d_ldsAlt = nullptr; uint64_t nbucketsAlt = 0; int bucketBitsAlt = 0, ldsBitsAlt = 0; bool hasAlt = false;
     // big layout (HBM-resident maps): 8 * bigLines tag words, slot-parallel keys / ids; d_tags / d_bkv = the secondary map of the spilled keys
     bool big = false; uint64_t* d_bigTags = nullptr; uint64_t* d_bigKeys = nullptr; void* d_bigIds = nullptr; int bigIdBytes = 0; uint32_t bigLines = 0;
-    int gm = 0, gW = 0, gH = 0, gD = 0; int64_t nspilled = 0; int gV32 = 0;
+    int gm = 0, gW = 0, gH = 0, gD = 0; int64_t nspilled = 0; int gV32 = 0; int gLb = 4; int gSib = 1;
     // qhdist = 1 handles (round 5): the expansion is the map the kernels look up, the reference's own map is kept beside it (KParams::qx)
     bool qx = false; uint64_t* d_tagsQx = nullptr; uint4* d_bkvQx = nullptr; uint64_t nbucketsQx = 0; int bucketBitsQx = 0; int64_t nkeysQx = 0;
     bool seed = false; int seedHl = 0, seedHr = 0, seedM = 0;   // seed layout: parents only, under their halves (large hdist=1 maps built on the device)
