@@ -166,7 +166,22 @@ def main():
         if fam in ("big", "fbm", "ksplit"):
             reads += util.long_refs_and_reads(rng)[1][:0]
             reads += [util.rand_seq(rng, rng.randint(0, 60)) + rng.choice(refs)[:rng.randint(20, 260)] + util.rand_seq(rng, rng.randint(0, 60)) for _ in range(100)]
-        if rng.random() < 0.2:                                  # a few reads beyond the LDS tiles: the chunked long-read kernels take over
+        uni = 0
+        if rng.random() < 0.3:
+            # every read the same length (round 6: the read-aligned forms of the stream scans -- one slot pair per read where L > 128 and L - k + 1 <= 128,
+            # two reads per block of the big layout's scan where L > 120 and L - k + W <= 128 -- and the lengths right beside their limits): reads are cut
+            # or padded at either end, so reference pieces, Ns and junk land anywhere, the first and the last window included
+            uni = rng.choice([150, 150, 151, 129, 130, k + 127, k + 126, k + 128, 121, 125, 140, 200, 250, 100])
+            made = []
+            for r in reads:
+                if len(r) >= uni:
+                    o0 = rng.choice([0, len(r) - uni, rng.randrange(len(r) - uni + 1)]); r = r[o0:o0 + uni]
+                else:
+                    padl = rng.choice([0, uni - len(r), rng.randrange(uni - len(r) + 1)])
+                    r = util.rand_seq(rng, padl, 0.004) + r + util.rand_seq(rng, uni - len(r) - padl, 0.004)
+                made.append(bytes(r))
+            reads = made
+        if rng.random() < (0.2 if not uni else 0.08):           # a few reads beyond the LDS tiles: the chunked long-read kernels take over
             for _ in range(rng.randint(1, 4)):
                 L = rng.randint(41000, 110000)
                 g = bytearray(util.rand_seq(rng, L, 0.0005))
@@ -220,6 +235,7 @@ def main():
             sys.exit(1)
         n_cfg += 1; n_reads += len(reads); fam_count["tails" if tails else fam] = fam_count.get("tails" if tails else fam, 0) + 1
         if bigmap and fam != "base": fam_count["bigmap_" + fam] = fam_count.get("bigmap_" + fam, 0) + 1
+        if uni: fam_count["uniform_length"] = fam_count.get("uniform_length", 0) + 1
     print(json.dumps({"soak_seconds": round(time.time() - t0, 1), "configs": n_cfg, "reads_checked": n_reads * 3, "families": fam_count, "mismatches": 0, "seed": a.seed}))
 
 
