@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--gm", type=int, default=0, help="experiments: minimizer length m of the big layout's lines (W = H - m + 1)")
     ap.add_argument("--load", type=int, default=0, help="experiments: keys per 100 slots the lines are sized for (BBDUK_HOOK_BIG_LOAD; 0 = the library's choice)")
     ap.add_argument("--lib", default="", help="experiments: another build of the library under bbtools_amd/ (ab_tsw: the timing switches)")
+    ap.add_argument("--n-rate", type=float, default=0.001, help="experiments: share of undefined bases in the synthetic reads (the benchmark's: 0.001)")
     ap.add_argument("--mask", default="0", help="experiments: timing mask of the ab_tsw build (a+b = bits; 22: the stream form instead of the read-aligned one)")
     ap.add_argument("--oracle-bases", type=int, default=50_000_000, help="prefix of scaffold 1.. the contaminated reads are drawn from (and the oracle indexes)")
     a = ap.parse_args()
@@ -121,7 +122,7 @@ def _run(a):
     rk &= ~(np.int64(3) << np.int64(30))
     out["random_keys_found"] = int((gpu.table_lookup(rk) > 0).sum())
     # ---- the operator
-    sp = B.synth_params(4, contam=contam, contam_frac=0.01)
+    sp = B.synth_params(4, contam=contam, contam_frac=0.01, n_rate=float(getattr(a, "n_rate", 0.001)))
     fb = int(getattr(a, "fallback_reads", 0) or 0)
     for reads in ([a.reads, fb] if 0 < fb < a.reads else [a.reads]):      # the batch beside the map: the requested size, else the smaller one
         n_pairs = reads // 2; n = 2 * n_pairs

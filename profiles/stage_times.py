@@ -17,6 +17,7 @@ ap.add_argument("--contam-phix", type=float, default=0.0, help="share of the pai
 ap.add_argument("--seed", type=int, default=2); ap.add_argument("--bucket-bits", type=int, default=0); ap.add_argument("--lds-bits", type=int, default=-1)
 ap.add_argument("--genome", type=int, default=0, help="bases of a random genome as the reference, built on the device (big-layout maps); 1 %% of the pairs drawn from it")
 ap.add_argument("--big-layout", type=int, default=0, help="BBDUK_HOOK_BIG_LAYOUT (3: the wide candidate values of maps beyond 2^31 keys at any size)")
+ap.add_argument("--n-rate", type=float, default=0.001)
 ap.add_argument("masks", nargs="*", default=["0"])
 a = ap.parse_args()
 B.use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bbtools_amd", a.lib + ".so"))
@@ -28,6 +29,7 @@ if a.genome:
     import numpy as np
     genome = np.frombuffer(b"ACGT", np.uint8)[np.random.default_rng(77).integers(0, 4, a.genome)].tobytes()
     kw = dict(contam=genome[:100_000], contam_frac=0.01); a.seed = 9
+kw["n_rate"] = a.n_rate
 B.synth_generate_device(B.synth_params(a.seed, read_len=L, ins_min=L // 3, ins_max=L * 7 // 3, **kw) if not a.genome else B.synth_params(a.seed, **kw), 0, n // 2, d_bases, d_off, 0)
 d_a = torch.empty(n, dtype=torch.int32, device="cuda"); d_id = torch.empty_like(d_a); d_fl = torch.empty(n, dtype=torch.uint8, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
