@@ -123,11 +123,11 @@ def measure_end_to_end(B, duk, reads, seed):
 
 # Counter-derived figures of the HBM-bound configurations, ECHOED from the committed profiles (like roofline.traffic: not measured in this run).
 COUNTER_ROWS = {
-    "C4": {"source": "profiles/r06_c4_rdreq.txt + profiles/r06_c4_counters.txt (rocprofv3 --pmc passes of profiles/bench_c4_full.py, 20 M reads per launch, the library's own geometry: m = 9)",
-           "fabric_requests_per_read": 28.6, "l2_requests_per_read": 33.0, "spilled_keys_frac": 0.0114, "valu_per_read": 318.6, "valu_busy_frac": 0.81,
+    "C4": {"source": "profiles/r06_c4_rdreq.txt + profiles/r06_c4_counters.txt + profiles/r06_c4_aligned_ab.txt (rocprofv3 --pmc passes of profiles/bench_c4_full.py / stage_times.py, 20 M reads per launch, the library's own geometry: m = 9)",
+           "fabric_requests_per_read": 28.6, "l2_requests_per_read": 31.3, "spilled_keys_frac": 0.0114, "valu_per_read": 242.0,
            "note": "round 5 (64-byte lines, m = 10): 35.4 fabric requests per read, 6.6 % of the keys spilled; every request moves 128 bytes whatever the load asks for "
-                   "(profiles/r06_rand_gran_pmc.txt); 28.6 requests x 20 M reads in 14.5 ms = 39 G requests/s of the ~49 G/s a bare gather kernel reaches over this span: "
-                   "the scan is bound by VALU issue now (profiles/r06_bigs_stage_table.txt)"},
+                   "(profiles/r06_rand_gran_pmc.txt); 28.6 requests x 1e8 reads in 58.6 ms = 48.7 G requests/s: what a bare gather kernel reaches for random lines over this span "
+                   "(48.6 G/s, profiles/r06_rand_gran.jsonl) -- the scan runs at the fabric's request rate (profiles/r06_c4_final.txt)"},
     "C6_hdist1_genome": {"source": "profiles/r04_seed_counters.txt, profiles/r06_seed_128B.txt", "fabric_requests_per_read": 66.0,
                          "note": "the kernel runs at the fabric's request rate for lines beyond an XCD's L2 (54.8 of ~55 G/s); 128-byte lines of 16 buckets change neither the count nor the rate"},
 }
