@@ -562,12 +562,18 @@ static int build_add_pieces(bbduk_handle* h, const uint8_t* d_refs, const int64_
 static int build_end_impl(bbduk_handle* h, const bool canStartOver = false) {      // canStartOver: the caller still holds the keys and repeats the build with plain lines on BBDUK_ERR_NOMEM
     BuildState* st = h->build;
     auto bail = [&](int code, const char* msg) { build_release(h); table_release(h); return fail(h, code, msg); };
-    unsigned long long cnt[5] = {0, 0, 0, 0, 0};
-    if (hipMemcpyAsync(cnt, st->d_cnt, 40, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
+    unsigned long long cnt[6] = {0, 0, 0, 0, 0, 0};                  // [0] distinct keys, [1] overflow, [2] spilled, [4] the twin's distinct keys, [5] its overflow
+    if (hipMemcpyAsync(cnt, st->d_cnt, 48, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
         return bail(BBDUK_ERR_DEVICE, "table build failed on the device");
     const unsigned long long distinct = cnt[0];
     // the scratch set -> a cache-resident map: buckets sized for the distinct count, LDS filter
-    auto place_scratch = [&](const unsigned long long nkeysD, const bool hooks, uint64_t*& tags, uint4*& bkv, uint32_t*& lds, uint64_t& nbOut, int& bbitsOut, int& lbOut) -> int {
+    // (fatal = false: the twin's placement -- a failure frees what it allocated and leaves the map that exists standing)
+    auto place_scratch = [&](const unsigned long long nkeysD, const bool hooks, uint64_t*& tags, uint4*& bkv, uint32_t*& lds, uint64_t& nbOut, int& bbitsOut, int& lbOut, const bool fatal = true) -> int {
+        auto give_up = [&](int code, const char* msg) -> int {
+            if (fatal) return bail(code, msg);
+            hipFree(tags); hipFree(bkv); hipFree(lds); tags = nullptr; bkv = nullptr; lds = nullptr;
+            return code;
+        };
         // 4-way buckets of 15-bit fingerprints, >= 1 bucket per key (load 0.5-1 keys/bucket: ~0.1-0.4 % of buckets
         // overflow and carry the continuation flag, so almost every lookup ends in its home bucket).
         int bbits = 10;
@@ -579,7 +585,7 @@ static int build_end_impl(bbduk_handle* h, const bool canStartOver = false) {   
         if (bbits >= 20) bbits--;
         if (hooks && h->hookBucketBits >= 4 && h->hookBucketBits <= 32) bbits = h->hookBucketBits;      // bbduk_test_hook
         const uint64_t nb = 1ULL << bbits;
-        if (4 * nb < nkeysD + nb / 8 || 4 * nb > (1ULL << 31)) return bail(BBDUK_ERR_ARG, "too many keys for the bucket index");
+        if (4 * nb < nkeysD + nb / 8 || 4 * nb > (1ULL << 31)) return give_up(BBDUK_ERR_ARG, "too many keys for the bucket index");
         // Presence filter in front of the map.  Most query k-mers are absent, so one bit per hash slot held in LDS
         // (<=128 KiB per workgroup) answers most of them without leaving the CU.  Size follows the key count.
         auto ceil_log2 = [](uint64_t x) { int b = 0; while ((1ULL << b) < x) b++; return b; };
@@ -587,13 +593,13 @@ static int build_end_impl(bbduk_handle* h, const bool canStartOver = false) {   
         if (nkeysD > 0 && nkeysD <= (1ULL << 22)) lb = std::min(MAX_LDS_BITS, std::max(10, ceil_log2(32ULL * nkeysD)));
         if (hooks && h->hookLdsBits >= 0) lb = h->hookLdsBits == 0 ? 0 : std::min(MAX_LDS_BITS, std::max(10, h->hookLdsBits));   // bbduk_test_hook
         if (hipMalloc(&tags, (nb + 1) * sizeof(uint64_t)) != hipSuccess || hipMalloc(&bkv, 4 * nb * sizeof(uint4)) != hipSuccess ||
-            (lb && hipMalloc(&lds, ((size_t)1 << (lb - 5)) * 4) != hipSuccess)) return bail(BBDUK_ERR_NOMEM, "hipMalloc (map)");
+            (lb && hipMalloc(&lds, ((size_t)1 << (lb - 5)) * 4) != hipSuccess)) return give_up(BBDUK_ERR_NOMEM, "hipMalloc (map)");
         hipMemsetAsync(tags, 0, (nb + 1) * sizeof(uint64_t), h->stream);      // (+ the dummy word behind the last bucket: always zero, see StreamProbe)
         hipMemsetAsync(bkv, 0xFF, 4 * nb * sizeof(uint4), h->stream);
         if (lb) hipMemsetAsync(lds, 0, ((size_t)1 << (lb - 5)) * 4, h->stream);
         const int grid = (int)std::min<uint64_t>((st->cslots + 255) / 256, (uint64_t)h->numCU * 32);
         bbduk_build_place_kernel<<<dim3(grid), dim3(256), 0, h->stream>>>(st->d_sk, st->d_si, st->cslots, tags, bkv, bbits, (uint32_t)(nb - 1), lds, lb);
-        if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(BBDUK_ERR_DEVICE, "device build (placement) failed");
+        if (hipStreamSynchronize(h->stream) != hipSuccess) return give_up(BBDUK_ERR_DEVICE, "device build (placement) failed");
         nbOut = nb; bbitsOut = bbits; lbOut = lb;
         return BBDUK_OK;
     };
@@ -608,15 +614,17 @@ static int build_end_impl(bbduk_handle* h, const bool canStartOver = false) {   
         if (canStartOver && !h->bigPlain && cnt[2] > distinct / 8) return bail(BBDUK_ERR_NOMEM, "the minimizer lines are overloaded");
         h->nkeys = (int64_t)distinct; h->ldsBits = 0; h->nspilled = (int64_t)cnt[2];
     } else {
+        if (cnt[1]) return bail(BBDUK_ERR_NOMEM, "the scratch set overflowed: more keys than announced to bbduk_build_begin");
         uint64_t nb = 0; int bbits = 0, lb = 0;
         const int rc = place_scratch(distinct, true, h->d_tags, h->d_bkv, h->d_ldsImage, nb, bbits, lb);
         if (rc != BBDUK_OK) return rc;
         h->nbuckets = nb; h->bucketBits = bbits; h->nkeys = (int64_t)distinct; h->ldsBits = lb;
     }
     if (st->twin) {                                               // the scratch set of a streamed big / seed build -> the cache-resident twin (build_both's, for the other builders)
-        const int rc = place_scratch(cnt[4], false, h->d_tagsAlt, h->d_bkvAlt, h->d_ldsAlt, h->nbucketsAlt, h->bucketBitsAlt, h->ldsBitsAlt);
-        if (rc != BBDUK_OK) return rc;
-        h->hasAlt = true;
+        // (a twin whose scratch set overflowed -- the caller announced fewer keys than it sent -- or whose placement fails is dropped; the big / seed map is complete
+        // and serves every batch, units beyond a wave's planes through the big layout's tiled kernels)
+        const int rc = cnt[5] ? BBDUK_ERR_NOMEM : place_scratch(cnt[4], false, h->d_tagsAlt, h->d_bkvAlt, h->d_ldsAlt, h->nbucketsAlt, h->bucketBitsAlt, h->ldsBitsAlt, false);
+        if (rc == BBDUK_OK) h->hasAlt = true;
         if (h->seed) h->nkeysRef = (int64_t)cnt[4];               // (bbduk_table_size answers in the reference's key count)
     }
     build_release(h);

@@ -485,3 +485,52 @@ def test_streamed_build_keeps_a_twin(args, okw, hdist):
     check_batch(d, o, longs[:2] + reads[:600], paired, nthreads=8)
     check_batch(d, o, longs, paired, nthreads=8)
     d.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_under_announced_builds_end(tmp_path):
+    """a caller that announces fewer keys to bbduk_build_begin than it then sends.  The scratch set of a cache-resident build stops at 7/8 full and the
+    build fails with BBDUK_ERR_NOMEM (it used to probe a full set for ever); the twin of a streamed big-layout build that overflows is dropped and the map that is
+    complete keeps serving -- table and reads against the oracle."""
+    import torch
+    rng0 = np.random.default_rng(5)
+    # (1) cache-resident: 1 000 keys announced, 200 000 sent
+    ref = np.frombuffer(b"ACGT", np.uint8)[rng0.integers(0, 4, 200_030)].tobytes()
+    d = B.BBDuk.__new__(B.BBDuk)
+    d.host = B.HostIndex("k=31 hdist=0")
+    d.host.add_ref(ref)
+    d.gpu = B.BBDukGpu(d.host.params(0))
+    d.gpu.build_begin(1000, 0, 0)
+    with pytest.raises(B.BBDukError):
+        d.gpu.build_add_device(torch.from_numpy(np.frombuffer(ref, np.uint8).copy()).cuda(), np.array([0, len(ref)], np.int64), 1)
+        d.gpu.build_end()
+    d.gpu.close()
+    # (2) a streamed big-layout build with a twin: 1.2 M keys announced (lines at 0.30 keys per slot: room for 4 M), 3.2 M sent -- the twin's scratch set
+    #     (2^22 slots) passes 7/8 full and is dropped; the lines are complete
+    G = 3_200_000
+    ref = np.frombuffer(b"ACGT", np.uint8)[rng0.integers(0, 4, G + 30)].tobytes()
+    o = Oracle(k=31, hdist=0)
+    o.add_ref(ref)
+    d = B.BBDuk.__new__(B.BBDuk)
+    d.host = B.HostIndex("k=31 hdist=0")
+    d.host.add_ref(ref)
+    d.gpu = B.BBDukGpu(d.host.params(0))
+    d.gpu.build_begin(1_200_000, 0, 0)
+    try:
+        d.gpu.build_add_device(torch.from_numpy(np.frombuffer(ref, np.uint8).copy()).cuda(), np.array([0, len(ref)], np.int64), 1)
+        d.gpu.build_end()
+    except B.BBDukError:
+        d.gpu.close()
+        return                                                   # (the lines overflowed first: a loud failure is an answer too)
+    d.stored_kmers = d.gpu.table_size
+    assert d.gpu.table_size == o.stored_kmers and _is_big(d)
+    ks, vs = o.dump_pairs()
+    sel = np.random.default_rng(1).integers(0, len(ks), 50_000)
+    assert np.array_equal(d.gpu.table_lookup(ks[sel]), vs[sel])
+    rng = random.Random(7)
+    reads = [ref[(p0 := rng.randrange(0, G - 150)):p0 + 150] if rng.random() < 0.3 else util.rand_seq(rng, 150, 0.002) for _ in range(400)]
+    reads += [util.rand_seq(rng, 3000) + ref[1000:1400] + util.rand_seq(rng, 2000), ref[5000:5000 + 70_000]]      # units beyond a wave's planes: without a twin, the big layout's tiled kernels
+    if len(reads) % 2: reads.append(b"")
+    check_batch(d, o, reads, True)
+    d.close()
