@@ -403,17 +403,30 @@ int run_device_ingest_piped(bbduk_handle* dev, const bbduk_host* host, const Sta
     const double tBegin = now_s();
     const int ns = B.ns;
     InStream S[2];
+    const int64_t chunk = B.chunk; const int device = B.device;
+    int fdOut[2] = {-1, -1};
+    void* owned[3] = {nullptr, nullptr, nullptr};                 // this call's own device buffers (d_b, d_mask, d_ctr)
+    // every way out of this function -- the early returns below too -- closes what it opened and frees what it allocated (an in-process caller
+    // inherited the descriptors and buffers; the threads are joined by finish() before any return that follows their start)
+    struct Owned {
+        InStream* S; int* fdOut; void** owned; int device;
+        ~Owned() {
+            for (int s = 0; s < 2; s++) if (S[s].fd >= 0) { close(S[s].fd); S[s].fd = -1; }
+            for (int f = 0; f < 2; f++) if (fdOut[f] >= 0) { close(fdOut[f]); fdOut[f] = -1; }
+            for (int q = 0; q < 3; q++) if (owned[q]) { bbduk_device_free(device, owned[q]); owned[q] = nullptr; }
+        }
+    } ownedGuard{S, fdOut, owned, device};
     for (int s = 0; s < ns; s++) {
         const std::string& path = s ? in2 : in1;
         S[s].fd = open(path.c_str(), O_RDONLY);
-        if (S[s].fd < 0) { if (s) close(S[0].fd); return fail("cannot open", path.c_str()); }
+        if (S[s].fd < 0) return fail("cannot open", path.c_str());
         struct stat sb;
-        if (fstat(S[s].fd, &sb) != 0) { for (int t = 0; t <= s; t++) close(S[t].fd); return fail("cannot stat", path.c_str()); }
-        if (!S_ISREG(sb.st_mode)) { for (int t = 0; t <= s; t++) close(S[t].fd); return fail("the pipelined ingest reads regular files (pipeline=f serves pipes and devices)", path.c_str()); }
+        if (fstat(S[s].fd, &sb) != 0) return fail("cannot stat", path.c_str());
+        if (!S_ISREG(sb.st_mode)) return fail("the pipelined ingest reads regular files (pipeline=f serves pipes and devices)", path.c_str());
         S[s].bytes = (int64_t)sb.st_size; S[s].NP = (S[s].bytes + B.chunk - 1) / B.chunk;
     }
-    const int64_t chunk = B.chunk; const int device = B.device;
-    const int fdOut[2] = {out.empty() ? -1 : open(out.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644), outm.empty() ? -1 : open(outm.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644)};
+    if (!out.empty()) fdOut[0] = open(out.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (!outm.empty()) fdOut[1] = open(outm.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
     if ((!out.empty() && fdOut[0] < 0) || (!outm.empty() && fdOut[1] < 0)) return fail("cannot open an output file", nullptr);
     const double tOpen = now_s();
     if (!B.ready.wait_above(0)) return fail("out of memory (chunk= too large?)", nullptr);
@@ -424,9 +437,12 @@ int run_device_ingest_piped(bbduk_handle* dev, const bbduk_host* host, const Sta
     void* p = nullptr;
     auto dmal = [&](int64_t bytes) -> void* { return bbduk_device_malloc(device, bytes, &p) == BBDUK_OK ? p : nullptr; };
     int32_t* d_b = P.mode == BBDUK_MODE_KTRIM_TIPS ? (int32_t*)dmal(maxReads * 4) : nullptr;
+    owned[0] = d_b;
     uint32_t* d_mask = P.mode == BBDUK_MODE_KMASK ? (uint32_t*)dmal((capBases / 32 + 4) * 4) : nullptr;
+    owned[1] = d_mask;
     const int nctr = bbduk_counters_len(dev);
     int64_t* d_ctr = (int64_t*)dmal((int64_t)nctr * 8);
+    owned[2] = d_ctr;
     if (!d_ctr || (P.mode == BBDUK_MODE_KTRIM_TIPS && !d_b) || (P.mode == BBDUK_MODE_KMASK && !d_mask)) return fail("out of memory (chunk= too large?)", nullptr);
     bbduk_device_memset(device, d_ctr, 0, (int64_t)nctr * 8, nullptr);
     const double tAlloc = now_s();
@@ -497,9 +513,7 @@ int run_device_ingest_piped(bbduk_handle* dev, const bbduk_host* host, const Sta
         for (int s = 0; s < ns; s++) { S[s].reader.join(); S[s].uploader.join(); }
         writer.join();
         B.wait();                                                 // (a tiny input can be through before the last buffer is pinned)
-        for (int s = 0; s < ns; s++) close(S[s].fd);
-        for (int f : fdOut) if (f >= 0) close(f);
-        return rc;
+        return rc;                                                 // (descriptors and buffers: ownedGuard)
     };
 
     const bool kfilter = P.mode == BBDUK_MODE_KFILTER;
