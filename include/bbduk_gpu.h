@@ -144,7 +144,9 @@ int  bbduk_build_table_device_edits(bbduk_handle* h, const uint8_t* refs, const 
  * reference of BASELINE configs[3]): begin announces an upper bound on the number of keys (for hdist 0: the number of reference
  * bases) -- beyond 2^25 keys (streamed builds; bbduk_finalize_table and bbduk_build_table_device: beyond 2^20 keys for plain kfilter (maxbadkmers too), ktrim=r and ktrim=l configurations with k >= 16, 2^21 with hdist > 0, and they keep a cache-resident twin beside it up to 2^25 keys, which serves batches with units beyond 2 512 bases) the map takes the HBM-resident layout: 12-14 bytes per slot, ~0.3 keys per slot up to 2^31 keys (32-bit candidate values), ~0.6 beyond (wide values; BASELINE configs[3]: 10^10 keys in 239 GB), both scanned by bbduk_bigs_kernel / bbduk_bigs_every_kernel; built in place;
  * every add hands over WHOLE scaffolds already in HBM (d_refs device pointer, ref_offsets HOST array of n_refs+1 values starting at
- * 0; scaffold i of the call gets id first_id + i); end leaves the handle finalized.  An error ends the build and frees the map. */
+ * 0; scaffold i of the call gets id first_id + i); end leaves the handle finalized.  An error ends the build and frees the map.
+ * More keys than announced: bbduk_build_end returns BBDUK_ERR_NOMEM ("more keys than announced") -- every sink stops taking keys once it has
+ * overflowed, so the calls return within milliseconds (round 6; a full scratch set used to be probed for ever). */
 int  bbduk_build_begin(bbduk_handle* h, int64_t max_keys, int32_t hdist, int32_t hdist2);
 int  bbduk_build_add_device(bbduk_handle* h, const uint8_t* d_refs, const int64_t* ref_offsets, int32_t n_refs, int32_t first_id);
 int  bbduk_build_end(bbduk_handle* h);
