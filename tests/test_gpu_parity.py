@@ -1501,3 +1501,47 @@ def test_unit_routing_at_scale(ci, paired):
     assert np.array_equal(ta, ga) and np.array_equal(ti, gi) and np.array_equal(tf, gf)
     assert np.array_equal(d.gpu.counters(), gc)
     d.close()
+
+
+# ---- round 6: the read-aligned form of the stream scans (bbduk_stream_scan.inc: one read per slot pair where L > 128 and L - k + 1 <= 128) is taken only by
+# batches whose sub-tiles hold ONE read length: every read of a batch is cut or padded to L (lengths on both sides of the form's limits, and short ones that keep
+# the stream form), reference pieces land at the first window, the last window and anywhere between, with undefined bases.
+def _uniform_reads(rng, refs, n, L):
+    out = []
+    for _ in range(n):
+        g = bytearray(util.rand_seq(rng, L, 0.004))
+        t = rng.random()
+        if t < 0.6 and L >= 8:
+            r = rng.choice(refs)
+            piece = r[(a := rng.randrange(0, max(1, len(r) - 4))):a + rng.randint(4, max(4, min(len(r) - a, L)))]
+            piece = piece[:L]
+            pos = rng.choice([0, L - len(piece), rng.randrange(0, L - len(piece) + 1)])
+            g[pos:pos + len(piece)] = piece
+            if rng.random() < 0.2: g[rng.randrange(L)] = ord("N")
+        out.append(bytes(g))
+    return out
+
+
+ALIGNED_LENGTHS = [36, 40, 50, 51, 64, 75, 76, 100, 125, 129, 140, 150, 151]
+ALIGNED_CFGS = [("fuzz", c) for c in FUZZ[:6]] + [("kmask", KMASK[4]), ("kmask", KMASK[5]), ("tips", TIPS[0]), ("tips", TIPS[1]), ("split", SPLIT[0]), ("split", SPLIT[1])]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ci", range(len(ALIGNED_CFGS)))
+def test_read_aligned_forms(ci):
+    kind, (args, okw) = ALIGNED_CFGS[ci]
+    rng = random.Random(9000 + ci)
+    refs = [util.rand_seq(rng, rng.randint(30, 200), 0.005) for _ in range(6)]
+    d, o = make_pair(args, okw, refs=refs)
+    for L in ALIGNED_LENGTHS:
+        reads = _uniform_reads(rng, refs, 500, L)
+        if kind == "kmask":
+            check_kmask(d, o, reads, True)
+        elif kind == "tips":
+            check_tips(d, o, reads, True)
+        elif kind == "split":
+            check_split(d, o, reads)
+        else:
+            check_batch(d, o, reads, True)
+            check_batch(d, o, reads[:251], False)
+    d.close()
