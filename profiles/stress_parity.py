@@ -171,7 +171,7 @@ def main():
             # every read the same length (round 6: the read-aligned forms of the stream scans -- one slot pair per read where L > 128 and L - k + 1 <= 128,
             # two reads per block of the big layout's scan where L > 120 and L - k + W <= 128 -- and the lengths right beside their limits): reads are cut
             # or padded at either end, so reference pieces, Ns and junk land anywhere, the first and the last window included
-            uni = rng.choice([150, 150, 151, 129, 130, k + 127, k + 126, k + 128, 121, 125, 140, 200, 250, 100, 36, 50, 75, 40, 64, k, k + 1, k + 6, 76])
+            uni = rng.choice([150, 150, 151, 151, 152, 129, 130, k + 127, k + 126, k + 128, 121, 125, 140, 200, 250, 100, 36, 50, 75, 40, 64, k, k + 1, k + 6, 76])
             made = []
             for r in reads:
                 if len(r) >= uni:

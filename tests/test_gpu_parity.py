@@ -1522,7 +1522,7 @@ def _uniform_reads(rng, refs, n, L):
     return out
 
 
-ALIGNED_LENGTHS = [36, 40, 50, 51, 64, 75, 76, 100, 125, 129, 140, 150, 151]
+ALIGNED_LENGTHS = [36, 40, 50, 51, 64, 75, 76, 100, 125, 129, 140, 150, 151, 152, 153]
 ALIGNED_CFGS = [("fuzz", c) for c in FUZZ[:6]] + [("kmask", KMASK[4]), ("kmask", KMASK[5]), ("tips", TIPS[0]), ("tips", TIPS[1]), ("split", SPLIT[0]), ("split", SPLIT[1])]
 
 
